@@ -1,0 +1,194 @@
+/*
+ * safebo.h -- C ABI of libsafebo.so: the MI355X (gfx950) candidate-sweep engine for
+ * SafeOpt / GoOSE safe Bayesian optimisation.
+ *
+ * The reference project (dleeim/Safe-Bayesian-Optimization) is pure Python/JAX and has no
+ * FFI seam of its own; the seam this library sits behind is the one SURVEY.md section 8(b) names:
+ *
+ *   state crossing the seam  = the `inference_datasets` dict      models/GP_Safe.py:16-23, 236-245
+ *                              + `bound`, `b`                     models/SafeOpt.py:12-13
+ *   calls replaced           = GP.GP_inference (batched)          models/GP_Safe.py:310-352
+ *                              BO.mean / ucb / lcb (batched)      models/SafeOpt.py:29-45, test/test_SafeOpt.py:337
+ *                              BO.Minimizer / BO.Expander         models/SafeOpt.py:53-66, 90-124
+ *                              BO.minimize_obj_lcb / Target /
+ *                              explore_safeset                    models/GoOSE.py:63-67, 80-119
+ *
+ * Conventions
+ *   - every entry point returns an int status (SBO_OK == 0, errors < 0) and never throws;
+ *     sbo_last_error() returns a thread-local message for the last failing call.
+ *   - host pointers are borrowed for the duration of the call only (the library copies);
+ *     arrays are C-contiguous, row-major.  Model arrays are always passed as double; the
+ *     `dtype` tag selects the arithmetic the kernels run in (the arrays are rounded once on upload).
+ *   - one sbo_ctx per process and per GPU (one process per GPU, ranks joined with sbo_comm_init);
+ *     a ctx is single-caller; calls return after the device work they issued has completed unless
+ *     the entry point says "asynchronous".
+ *   - flat candidate index g: for grids, axis 0 is the fastest axis
+ *     (jnp.meshgrid 'xy' + ravel, test/test_SafeOpt.py:325-334); indices reported in results are
+ *     GLOBAL flat indices (shard offset included).
+ *   - there is no CPU fallback: without a HIP device sbo_init fails with SBO_E_HIP.
+ */
+#ifndef SAFEBO_H
+#define SAFEBO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBO_ABI_VERSION 1
+#define SBO_MAX_D 8        /* input dimension limit (reference problems use d = 2)          */
+#define SBO_MAX_Q 8        /* modelled outputs: objective + constraints                      */
+#define SBO_MAX_N 2048     /* observations                                                   */
+
+enum sbo_status {
+  SBO_OK = 0,
+  SBO_E_INVALID = -1,         /* bad argument (maps to ValueError, as models/GP_Safe.py:134-137) */
+  SBO_E_NOMEM = -2,
+  SBO_E_HIP = -3,             /* HIP runtime error / no device                                   */
+  SBO_E_NO_MODEL = -4,        /* sweep before sbo_model_set                                      */
+  SBO_E_NO_CANDIDATES = -5,   /* sweep before sbo_candidates_*                                   */
+  SBO_E_EMPTY_SAFE_SET = -6,  /* S_t is empty on this candidate set (all ranks)                  */
+  SBO_E_COMM = -7,            /* RCCL error                                                      */
+  SBO_E_UNSUPPORTED = -8
+};
+
+enum sbo_dtype { SBO_F64 = 0, SBO_F32 = 1 };
+
+/* which matrix the variance contraction uses */
+enum sbo_factor {
+  SBO_FACTOR_INVK = 0,  /* caller's invK (reference-faithful: models/GP_Safe.py:231-232, 343), folded to
+                           its lower triangle:  k^T invK k = sum_{i>=j} F_ij k_i k_j                       */
+  SBO_FACTOR_CHOL = 1   /* library builds K + (sn2 + float32 eps) I = L L^T itself and contracts with L^-1:
+                           var = sf2 - || L^-1 k ||^2  (used when invK == NULL)                            */
+};
+
+enum sbo_bound_kind { SBO_MEAN = 0, SBO_UCB = 1, SBO_LCB = 2, SBO_VAR = 3 };
+
+enum sbo_mask {
+  SBO_MASK_S = 0,   /* safe set                 models/SafeOpt.py:57-59                                   */
+  SBO_MASK_U = 1,   /* "fully unsafe" witnesses models/SafeOpt.py:73-77, 109                              */
+  SBO_MASK_M = 2,   /* potential minimisers     models/SafeOpt.py:62                                      */
+  SBO_MASK_G = 3,   /* expanders G_c  (index c = 1..q-1)  models/SafeOpt.py:85-88, 111                    */
+  SBO_MASK_O = 4    /* GoOSE optimistic set O_c (c = 1..q-1)  models/GoOSE.py:93-101                      */
+};
+
+typedef struct sbo_ctx sbo_ctx;
+
+typedef struct sbo_sweep_opts {
+  double b;                        /* confidence multiplier beta, models/SafeOpt.py:13                    */
+  int32_t reference_quirk_L_index; /* 1: every constraint uses L_{q-1} (models/SafeOpt.py:110 loop leak);
+                                      0: constraint c uses L_c                                            */
+  int32_t want_masks;              /* 1: keep S/U/M/G (or O) masks in HBM for sbo_masks_get               */
+  int32_t posterior_ready;         /* 1: reuse mean/var of the last sbo_posterior_run on these candidates */
+  int32_t reserved;
+} sbo_sweep_opts;
+
+typedef struct sbo_safeopt_result {
+  /* Minimizer(): argmax_{M_t} var_0, returns (x, sqrt(var_0))           models/SafeOpt.py:53-66          */
+  int64_t minimizer_index;
+  double  minimizer_x[SBO_MAX_D];
+  double  minimizer_std;
+  /* Expander(): per constraint argmax_{G_c} var_0, most uncertain kept   models/SafeOpt.py:90-124         */
+  int64_t expander_index_c[SBO_MAX_Q];   /* [c-1], -1 when G_c is empty                                   */
+  double  expander_std_c[SBO_MAX_Q];
+  int32_t expander_best_c;               /* constraint index of the kept expander, 0 when none            */
+  int64_t expander_index;
+  double  expander_x[SBO_MAX_D];
+  double  expander_std;
+  int32_t choose_minimizer;              /* std_min > std_exp, test/test_SafeOpt.py:153                   */
+  double  u_star;                        /* min_{S_t} ucb_0, models/SafeOpt.py:47-51, 61                  */
+  double  L[SBO_MAX_Q];                  /* max over candidates of ||grad MEAN_i||_inf, SafeOpt.py:79-83  */
+  int64_t count_S, count_U, count_M;
+  int64_t count_G[SBO_MAX_Q];            /* [c-1]                                                         */
+  int64_t n_exact_rechecks;              /* expander decisions that fell in the +1e-8 ambiguity band and
+                                            were re-decided by exhaustive evaluation                      */
+} sbo_safeopt_result;
+
+typedef struct sbo_goose_result {
+  int64_t safe_min_index;                /* argmin_{S_t} lcb_0            models/GoOSE.py:63-67            */
+  double  safe_min_x[SBO_MAX_D];
+  double  safe_min_lcb;
+  int64_t target_index_c[SBO_MAX_Q];     /* per constraint argmin_{O_c} lcb_0, -1 when empty   :82-112    */
+  double  target_lcb_c[SBO_MAX_Q];
+  int32_t target_best_c;
+  int64_t target_index;
+  double  target_x[SBO_MAX_D];
+  double  target_lcb;
+  int64_t explore_index;                 /* argmin_{S_t} ||x - target||_2  models/GoOSE.py:116-119        */
+  double  explore_x[SBO_MAX_D];
+  int32_t choose_safe_min;               /* min_safe_lcb <= target_lcb, test/test_GoOSE.py:158            */
+  double  L[SBO_MAX_Q];
+  int64_t count_S, count_U;
+  int64_t count_O[SBO_MAX_Q];
+} sbo_goose_result;
+
+/* per-kernel device time of the last sweep / posterior call, measured with HIP events on the
+ * library's stream (feeds bench.py's roofline.achieved) */
+typedef struct sbo_profile {
+  double posterior_ms;     /* K1: fused cross-covariance + contraction + mean/var                          */
+  double classify_ms;      /* K3: bounds, S/U/M masks, u*, reductions                                      */
+  double expander_ms;      /* K4: distance transform + G_c / O_c decisions                                 */
+  double argreduce_ms;     /* K5: masked arg-max / arg-min                                                 */
+  double comm_ms;          /* RCCL collectives                                                             */
+  double total_ms;         /* first launch to last completion                                              */
+  double posterior_flops;  /* algorithmic flops of the K1 launch(es): q (n^2 + (2d+10) n) per candidate    */
+  int64_t candidates;      /* candidates swept by this rank                                                */
+  int32_t posterior_launches;
+  int32_t reserved;
+} sbo_profile;
+
+/* ---- library / context ------------------------------------------------------------------- */
+int sbo_version(void);
+const char* sbo_last_error(void);
+int sbo_device_count(int* count);
+int sbo_init(int device_id, sbo_ctx** out);
+int sbo_shutdown(sbo_ctx* ctx);
+int sbo_synchronize(sbo_ctx* ctx);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------------- */
+#define SBO_COMM_ID_BYTES 128
+int sbo_comm_unique_id(void* id_out /* SBO_COMM_ID_BYTES, filled on rank 0 and sent to peers */);
+int sbo_comm_init(sbo_ctx* ctx, int world_size, int rank, const void* id);
+int sbo_comm_barrier(sbo_ctx* ctx);
+
+/* ---- model state = inference_datasets (models/GP_Safe.py:236-245) -------------------------- */
+/* hypopt is [d+2, q]: rows 0..d-1 = log ell_a, row d = log sigma_f, row d+1 = log sigma_n, consumed as
+ * exp(2 h) (models/GP_Safe.py:338).  invK is q stacked [n, n] matrices or NULL (see sbo_factor).
+ * kernel must be "RBF" (models/GP_Safe.py:159-162), anything else is SBO_E_INVALID. */
+int sbo_model_set(sbo_ctx* ctx, int dtype, const char* kernel, int n, int d, int q,
+                  const double* X_mean, const double* X_std, const double* Y_mean, const double* Y_std,
+                  const double* X_norm, const double* Y_norm, const double* hypopt, const double* invK);
+
+/* ---- candidates (resident in HBM until replaced) ------------------------------------------- */
+/* explicit list: points[N, d] of doubles (dtype SBO_F64) or floats (SBO_F32); first_index = global flat
+ * index of points[0] (shard offset). */
+int sbo_candidates_points(sbo_ctx* ctx, const void* points, int points_dtype, int64_t n_local, int d,
+                          int64_t first_index);
+/* implicit tensor grid: x_a(i) = lo_a + i (hi_a - lo_a)/(count_a - 1), last = hi_a; this rank sweeps the
+ * flat range [first_index, first_index + n_local). No HBM bytes are read for candidates. */
+int sbo_candidates_grid(sbo_ctx* ctx, int d, const double* lo, const double* hi, const int64_t* count,
+                        int64_t first_index, int64_t n_local);
+
+/* ---- hot path ------------------------------------------------------------------------------ */
+/* K1: GP_inference for every local candidate; mean/var stay in HBM. */
+int sbo_posterior_run(sbo_ctx* ctx);
+/* copy out as [n_local, q] arrays of the model dtype (either pointer may be NULL) */
+int sbo_posterior_get(sbo_ctx* ctx, void* mean_out, void* var_out);
+/* batched BO.mean/ucb/lcb(points, index): out[n_local] of the model dtype (runs K1 if needed) */
+int sbo_bounds(sbo_ctx* ctx, double b, int index, int kind, void* out);
+/* full SafeOpt / GoOSE iteration on the resident candidates */
+int sbo_sweep_safeopt(sbo_ctx* ctx, const sbo_sweep_opts* opts, sbo_safeopt_result* result);
+int sbo_sweep_goose(sbo_ctx* ctx, const sbo_sweep_opts* opts, sbo_goose_result* result);
+/* uint8 mask [n_local] of the last sweep (opts.want_masks); c is the constraint index for G / O */
+int sbo_masks_get(sbo_ctx* ctx, int which, int c, uint8_t* out);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
+/* selects the fp64 contraction engine of K1: 0 = MFMA (v_mfma_f64_16x16x4_f64), 1 = VALU FMA */
+int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAFEBO_H */

@@ -1,0 +1,435 @@
+// api.hip -- C-ABI entry points of libsafebo.so: context, model upload, candidates, posterior, bounds.
+// (sweeps live in sets.hip, collectives in comm.hip).  See include/safebo.h for the contract.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include "internal.hpp"
+#include "device_common.hpp"
+
+namespace sbo {
+
+static thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string("HIP: ") + hipGetErrorString(e) + " in " + what;
+  return SBO_E_HIP;
+}
+int ensure(DevBuf& b, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (b.bytes >= bytes) return SBO_OK;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) {
+    g_err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? SBO_E_NOMEM : SBO_E_HIP;
+  }
+  b.bytes = bytes;
+  return SBO_OK;
+}
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+int launch_soa_to_aos(sbo_ctx* c, const void* soa, void* aos);
+
+// Host Cholesky L L^T = A (lower, in place) and inverse of L; plain loops, n <= SBO_MAX_N.
+static bool cholesky_inv(std::vector<double>& A, int n, std::vector<double>& Linv) {
+  for (int j = 0; j < n; ++j) {
+    double s = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) s -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(s > 0)) return false;
+    const double ljj = std::sqrt(s);
+    A[(size_t)j * n + j] = ljj;
+    for (int i = j + 1; i < n; ++i) {
+      double t = A[(size_t)i * n + j];
+      const double* ai = &A[(size_t)i * n];
+      const double* aj = &A[(size_t)j * n];
+      for (int k = 0; k < j; ++k) t -= ai[k] * aj[k];
+      A[(size_t)i * n + j] = t / ljj;
+    }
+  }
+  Linv.assign((size_t)n * n, 0.0);
+  for (int c = 0; c < n; ++c) {   // solve L x = e_c
+    Linv[(size_t)c * n + c] = 1.0 / A[(size_t)c * n + c];
+    for (int i = c + 1; i < n; ++i) {
+      double t = 0;
+      for (int k = c; k < i; ++k) t -= A[(size_t)i * n + k] * Linv[(size_t)k * n + c];
+      Linv[(size_t)i * n + c] = t / A[(size_t)i * n + i];
+    }
+  }
+  return true;
+}
+
+template <typename T>
+static int upload_vec(DevBuf& b, const std::vector<double>& h, hipStream_t st) {
+  std::vector<T> t(h.size());
+  for (size_t i = 0; i < h.size(); ++i) t[i] = (T)h[i];
+  int rc = ensure(b, sizeof(T) * t.size());
+  if (rc) return rc;
+  SBO_HIP(hipMemcpyAsync(b.p, t.data(), sizeof(T) * t.size(), hipMemcpyHostToDevice, st));
+  SBO_HIP(hipStreamSynchronize(st));
+  return SBO_OK;
+}
+
+template <typename T>
+static int model_upload(sbo_ctx* c, const std::vector<double>& F_all /* [q][n][n] lower */,
+                        const std::vector<double>& As, const std::vector<double>& sqA,
+                        const std::vector<double>& alpha, const std::vector<double>& Xn) {
+  const ModelConst& mc = c->mc;
+  const int n = mc.n, nb = mc.npad / 16, q = mc.q;
+  const size_t ntri = (size_t)nb * (nb + 1) / 2;
+  c->fpk_stride = ntri * 4 * 64;
+  std::vector<double> pk((size_t)q * c->fpk_stride, 0.0);
+  for (int o = 0; o < q; ++o) {
+    const double* F = &F_all[(size_t)o * n * n];
+    double* dst = &pk[(size_t)o * c->fpk_stride];
+    for (int I = 0; I < nb; ++I)
+      for (int J = 0; J <= I; ++J)
+        for (int kk = 0; kk < 4; ++kk)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int row = 16 * I + (lane & 15);
+            const int col = 16 * J + MM<T>::jslot(kk, lane >> 4);
+            double v = 0.0;
+            if (row < n && col < n && col <= row) v = F[(size_t)row * n + col];
+            dst[(((size_t)I * (I + 1) / 2 + J) * 4 + kk) * 64 + lane] = v;
+          }
+  }
+  int rc;
+  if ((rc = upload_vec<T>(c->Fpk, pk, c->stream))) return rc;
+  if ((rc = upload_vec<T>(c->As, As, c->stream))) return rc;
+  if ((rc = upload_vec<T>(c->sqA, sqA, c->stream))) return rc;
+  if ((rc = upload_vec<T>(c->alpha, alpha, c->stream))) return rc;
+  if ((rc = upload_vec<T>(c->Xn, Xn, c->stream))) return rc;
+  return SBO_OK;
+}
+
+}  // namespace sbo
+
+using namespace sbo;
+
+extern "C" {
+
+int sbo_version(void) { return SBO_ABI_VERSION; }
+const char* sbo_last_error(void) { return g_err.c_str(); }
+
+int sbo_device_count(int* count) {
+  if (!count) return fail(SBO_E_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return hip_fail(e, "hipGetDeviceCount"); }
+  *count = n;
+  return SBO_OK;
+}
+
+int sbo_init(int device_id, sbo_ctx** out) {
+  if (!out) return fail(SBO_E_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(SBO_E_HIP, "no HIP device available: libsafebo has no CPU fallback");
+  if (device_id < 0 || device_id >= n) return fail(SBO_E_INVALID, "device_id out of range");
+  SBO_HIP(hipSetDevice(device_id));
+  sbo_ctx* c = new sbo_ctx();
+  c->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+  for (auto& ev : c->ev) {
+    e = hipEventCreate(&ev);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipEventCreate"); }
+  }
+  int rc = ensure(c->Lmax, sizeof(unsigned long long) * kMaxQ);
+  if (!rc) rc = ensure(c->scal, 4096);
+  if (rc) { delete c; return rc; }
+  *out = c;
+  return SBO_OK;
+}
+
+int sbo_comm_destroy_internal(sbo_ctx* ctx);
+
+int sbo_shutdown(sbo_ctx* c) {
+  if (!c) return SBO_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  sbo_comm_destroy_internal(c);
+  for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->Lmax, &c->maskS,
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->scal, &c->partial, &c->amb})
+    release(*b);
+  for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return SBO_OK;
+}
+
+int sbo_synchronize(sbo_ctx* c) {
+  if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  return SBO_OK;
+}
+
+int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
+  if (!c || !key) return fail(SBO_E_INVALID, "ctx/key is NULL");
+  if (!strcmp(key, "fp64_engine")) {
+    if (value != 0 && value != 1) return fail(SBO_E_INVALID, "fp64_engine must be 0 (MFMA) or 1 (VALU)");
+    c->engine = (int)value;
+    return SBO_OK;
+  }
+  return fail(SBO_E_INVALID, std::string("unknown option ") + key);
+}
+
+int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q, const double* X_mean,
+                  const double* X_std, const double* Y_mean, const double* Y_std, const double* X_norm,
+                  const double* Y_norm, const double* hypopt, const double* invK) {
+  if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
+  if (!kernel || strcmp(kernel, "RBF") != 0)      // models/GP_Safe.py:159-162
+    return fail(SBO_E_INVALID, std::string("ERROR no kernel with name ") + (kernel ? kernel : "(null)"));
+  if (dtype != SBO_F64 && dtype != SBO_F32) return fail(SBO_E_INVALID, "dtype must be SBO_F64 or SBO_F32");
+  if (n < 1 || n > SBO_MAX_N) return fail(SBO_E_INVALID, "n out of range [1, SBO_MAX_N]");
+  if (d < 1 || d > SBO_MAX_D) return fail(SBO_E_INVALID, "d out of range [1, SBO_MAX_D]");
+  if (q < 1 || q > SBO_MAX_Q) return fail(SBO_E_INVALID, "q out of range [1, SBO_MAX_Q]");
+  if (!X_mean || !X_std || !Y_mean || !Y_std || !X_norm || !Y_norm || !hypopt)
+    return fail(SBO_E_INVALID, "NULL model array");
+  SBO_HIP(hipSetDevice(c->device));
+  c->has_model = false;
+  c->posterior_valid = false;
+  c->masks_valid = false;
+  ModelConst& mc = c->mc;
+  memset(&mc, 0, sizeof(mc));
+  mc.n = n; mc.d = d; mc.q = q;
+  mc.npad = (n + 15) / 16 * 16;
+  mc.dpad = d <= 2 ? 2 : (d <= 4 ? 4 : 8);
+  mc.factor = invK ? SBO_FACTOR_INVK : SBO_FACTOR_CHOL;
+  for (int a = 0; a < kMaxD; ++a) { mc.X_mean[a] = a < d ? X_mean[a] : 0.0; mc.X_std[a] = a < d ? X_std[a] : 1.0; }
+  const int npad = mc.npad, D = mc.dpad;
+  std::vector<double> As((size_t)q * npad * D, 0.0), sqA((size_t)q * npad, 0.0), alpha((size_t)q * npad, 0.0),
+      Xn((size_t)npad * D, 0.0), F((size_t)q * n * n, 0.0);
+  for (int j = 0; j < n; ++j)
+    for (int a = 0; a < d; ++a) Xn[(size_t)j * D + a] = X_norm[(size_t)j * d + a];
+  c->h_Xnorm.assign(X_norm, X_norm + (size_t)n * d);
+  const double f32eps = (double)std::numeric_limits<float>::epsilon();
+  for (int o = 0; o < q; ++o) {
+    mc.Y_mean[o] = Y_mean[o];
+    mc.Y_std[o] = Y_std[o];
+    mc.mp[o] = (o == 0) ? 0.0 : (-2.0 * Y_mean[o]) / Y_std[o];          // GP_Safe.py:331-332
+    mc.sf2[o] = std::exp(2.0 * hypopt[(size_t)d * q + o]);               // GP_Safe.py:338
+    const double sn2 = std::exp(2.0 * hypopt[(size_t)(d + 1) * q + o]) + f32eps;   // GP_Safe.py:229
+    for (int a = 0; a < d; ++a) {
+      const double ell = std::exp(2.0 * hypopt[(size_t)a * q + o]);
+      mc.vinv[o][a] = std::pow(ell, -0.5);                               // GP_Safe.py:112
+      mc.inv_ell[o][a] = 1.0 / ell;
+    }
+    for (int j = 0; j < n; ++j) {
+      double s = 0;
+      for (int a = 0; a < d; ++a) {
+        const double v = X_norm[(size_t)j * d + a] * mc.vinv[o][a];      // GP_Safe.py:115
+        As[((size_t)o * npad + j) * D + a] = v;
+        s += v * v;
+      }
+      sqA[(size_t)o * npad + j] = s;
+    }
+    std::vector<double> rhs(n);
+    for (int j = 0; j < n; ++j) rhs[j] = Y_norm[(size_t)j * q + o] - mc.mp[o];
+    double* Fo = &F[(size_t)o * n * n];
+    if (invK) {
+      const double* W = invK + (size_t)o * n * n;
+      for (int i = 0; i < n; ++i) {
+        double s = 0;
+        for (int j = 0; j < n; ++j) s += W[(size_t)i * n + j] * rhs[j];
+        alpha[(size_t)o * npad + i] = s;
+        for (int j = 0; j < i; ++j) Fo[(size_t)i * n + j] = W[(size_t)i * n + j] + W[(size_t)j * n + i];
+        Fo[(size_t)i * n + i] = W[(size_t)i * n + i];
+      }
+    } else {
+      // K = sf2 exp(-1/2 dist) + sn2 I with the expanded distance (GP_Safe.py:119, 141, 231), then L^-1
+      std::vector<double> K((size_t)n * n), Linv;
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          double dot = 0;
+          for (int a = 0; a < d; ++a) dot += As[((size_t)o * npad + i) * D + a] * As[((size_t)o * npad + j) * D + a];
+          const double dist = -2.0 * dot + sqA[(size_t)o * npad + i] + sqA[(size_t)o * npad + j];
+          K[(size_t)i * n + j] = mc.sf2[o] * std::exp(-0.5 * dist) + (i == j ? sn2 : 0.0);
+        }
+      if (!cholesky_inv(K, n, Linv)) return fail(SBO_E_INVALID, "K + sn2 I is not positive definite");
+      std::vector<double> t(n, 0.0);
+      for (int i = 0; i < n; ++i) {
+        double s = 0;
+        for (int j = 0; j <= i; ++j) s += Linv[(size_t)i * n + j] * rhs[j];
+        t[i] = s;
+      }
+      for (int j = 0; j < n; ++j) {
+        double s = 0;
+        for (int i = j; i < n; ++i) s += Linv[(size_t)i * n + j] * t[i];
+        alpha[(size_t)o * npad + j] = s;
+      }
+      memcpy(Fo, Linv.data(), sizeof(double) * (size_t)n * n);
+    }
+  }
+  c->dtype = dtype;
+  int rc = (dtype == SBO_F64) ? model_upload<double>(c, F, As, sqA, alpha, Xn) : model_upload<float>(c, F, As, sqA, alpha, Xn);
+  if (rc) return rc;
+  c->has_model = true;
+  return SBO_OK;
+}
+
+static int alloc_workspace(sbo_ctx* c) {
+  const size_t es = c->dtype == SBO_F64 ? 8 : 4;
+  const size_t n = (size_t)std::max<long long>(c->cs.n_local, 1);
+  int rc;
+  if ((rc = ensure(c->mean, es * n * c->mc.q))) return rc;
+  if ((rc = ensure(c->var, es * n * c->mc.q))) return rc;
+  return SBO_OK;
+}
+
+int sbo_candidates_points(sbo_ctx* c, const void* points, int points_dtype, int64_t n_local, int d, int64_t first) {
+  if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
+  if (n_local < 0 || (n_local > 0 && !points)) return fail(SBO_E_INVALID, "bad points / n_local");
+  if (d < 1 || d > SBO_MAX_D) return fail(SBO_E_INVALID, "d out of range");
+  if (points_dtype != SBO_F64 && points_dtype != SBO_F32) return fail(SBO_E_INVALID, "points_dtype");
+  SBO_HIP(hipSetDevice(c->device));
+  const size_t es = points_dtype == SBO_F64 ? 8 : 4;
+  int rc = ensure(c->pts, es * (size_t)std::max<int64_t>(n_local, 1) * d);
+  if (rc) return rc;
+  if (n_local) {
+    SBO_HIP(hipMemcpyAsync(c->pts.p, points, es * (size_t)n_local * d, hipMemcpyHostToDevice, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+  }
+  memset(&c->cs, 0, sizeof(c->cs));
+  c->cs.kind = 0; c->cs.d = d; c->cs.pts_dtype = points_dtype; c->cs.pts = c->pts.p;
+  c->cs.n_local = n_local; c->cs.first = first;
+  c->has_cand = true;
+  c->posterior_valid = false;
+  c->masks_valid = false;
+  return SBO_OK;
+}
+
+int sbo_candidates_grid(sbo_ctx* c, int d, const double* lo, const double* hi, const int64_t* count, int64_t first,
+                        int64_t n_local) {
+  if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
+  if (d < 1 || d > SBO_MAX_D || !lo || !hi || !count) return fail(SBO_E_INVALID, "bad grid description");
+  long double total = 1;
+  for (int a = 0; a < d; ++a) {
+    if (count[a] < 1) return fail(SBO_E_INVALID, "grid count must be >= 1");
+    total *= (long double)count[a];
+  }
+  if (total > 9.0e18L) return fail(SBO_E_INVALID, "grid too large");
+  if (first < 0 || n_local < 0 || (long double)first + (long double)n_local > total)
+    return fail(SBO_E_INVALID, "shard range outside the grid");
+  memset(&c->cs, 0, sizeof(c->cs));
+  c->cs.kind = 1; c->cs.d = d; c->cs.n_local = n_local; c->cs.first = first;
+  for (int a = 0; a < d; ++a) {
+    c->cs.lo[a] = lo[a]; c->cs.hi[a] = hi[a]; c->cs.count[a] = count[a];
+    c->cs.step[a] = count[a] > 1 ? (hi[a] - lo[a]) / (double)(count[a] - 1) : 0.0;
+  }
+  for (int a = d; a < kMaxD; ++a) c->cs.count[a] = 1;
+  c->has_cand = true;
+  c->posterior_valid = false;
+  c->masks_valid = false;
+  return SBO_OK;
+}
+
+static int check_ready(sbo_ctx* c) {
+  if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
+  if (!c->has_model) return fail(SBO_E_NO_MODEL, "sbo_model_set has not been called");
+  if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
+  if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");  // GP_Safe.py:159
+  return SBO_OK;
+}
+
+// K1 without synchronisation or timing (used inside the sweeps)
+int sbo_posterior_enqueue(sbo_ctx* c) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  SBO_HIP(hipSetDevice(c->device));
+  if ((rc = alloc_workspace(c))) return rc;
+  if (c->cs.n_local > 0 && (rc = launch_posterior(c))) return rc;
+  c->posterior_valid = true;
+  return SBO_OK;
+}
+
+double sbo_algorithmic_flops(const sbo_ctx* c) {
+  const double n = c->mc.n, d = c->mc.d, q = c->mc.q;
+  return q * (n * n + (2 * d + 10) * n) * (double)c->cs.n_local;
+}
+
+int sbo_posterior_run(sbo_ctx* c) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  SBO_HIP(hipSetDevice(c->device));
+  SBO_HIP(hipEventRecord(c->ev[0], c->stream));
+  if ((rc = sbo_posterior_enqueue(c))) return rc;
+  SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  SBO_HIP(hipEventSynchronize(c->ev[1]));
+  float ms = 0;
+  SBO_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  memset(&c->prof, 0, sizeof(c->prof));
+  c->prof.posterior_ms = ms;
+  c->prof.total_ms = ms;
+  c->prof.posterior_flops = sbo_algorithmic_flops(c);
+  c->prof.candidates = c->cs.n_local;
+  c->prof.posterior_launches = c->cs.n_local > 0 ? 1 : 0;
+  return SBO_OK;
+}
+
+int sbo_posterior_get(sbo_ctx* c, void* mean_out, void* var_out) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!c->posterior_valid && (rc = sbo_posterior_run(c))) return rc;
+  const size_t es = c->dtype == SBO_F64 ? 8 : 4;
+  const size_t bytes = es * (size_t)c->cs.n_local * c->mc.q;
+  if (bytes == 0) return SBO_OK;
+  DevBuf tmp;
+  if ((rc = ensure(tmp, bytes))) return rc;
+  for (int which = 0; which < 2; ++which) {
+    void* dst = which ? var_out : mean_out;
+    if (!dst) continue;
+    rc = launch_soa_to_aos(c, which ? c->var.p : c->mean.p, tmp.p);
+    if (rc) { release(tmp); return rc; }
+    hipError_t e = hipMemcpyAsync(dst, tmp.p, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { release(tmp); return hip_fail(e, "copy posterior to host"); }
+  }
+  release(tmp);
+  return SBO_OK;
+}
+
+int sbo_bounds(sbo_ctx* c, double b, int index, int kind, void* out) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (index < 0 || index >= c->mc.q) return fail(SBO_E_INVALID, "output index out of range");
+  if (kind < SBO_MEAN || kind > SBO_VAR) return fail(SBO_E_INVALID, "bad bound kind");
+  if (!out) return fail(SBO_E_INVALID, "out is NULL");
+  if (!c->posterior_valid && (rc = sbo_posterior_run(c))) return rc;
+  const size_t es = c->dtype == SBO_F64 ? 8 : 4;
+  const size_t bytes = es * (size_t)c->cs.n_local;
+  if (bytes == 0) return SBO_OK;
+  DevBuf tmp;
+  if ((rc = ensure(tmp, bytes))) return rc;
+  rc = launch_bound(c, b, index, kind, tmp.p);
+  if (!rc) {
+    hipError_t e = hipMemcpyAsync(out, tmp.p, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "copy bounds to host");
+  }
+  release(tmp);
+  return rc;
+}
+
+int sbo_profile_get(sbo_ctx* c, sbo_profile* out) {
+  if (!c || !out) return fail(SBO_E_INVALID, "NULL argument");
+  *out = c->prof;
+  return SBO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// comm.hip -- RCCL plumbing: one process per GPU, ranks joined over xGMI with a broadcast unique id.
+// The reference has no communication layer at all; these collectives exist only
+// because the candidate set is sharded across the GPUs of a node.
+#include <cstring>
+#include <rccl/rccl.h>
+#include "internal.hpp"
+
+namespace sbo {
+static int nccl_fail(ncclResult_t r, const char* what) {
+  return fail(SBO_E_COMM, std::string("RCCL: ") + ncclGetErrorString(r) + " in " + what);
+}
+#define SBO_NCCL(x)                                        \
+  do {                                                     \
+    ncclResult_t r__ = (x);                                \
+    if (r__ != ncclSuccess) return sbo::nccl_fail(r__, #x); \
+  } while (0)
+
+// in-place all-reduce helpers used by the sweeps (no-ops for a single rank)
+int comm_allreduce_max_u64(sbo_ctx* c, unsigned long long* dev, int count) {
+  if (c->world <= 1) return SBO_OK;
+  SBO_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclMax, (ncclComm_t)c->comm, c->stream));
+  return SBO_OK;
+}
+int comm_allreduce_min_u64(sbo_ctx* c, unsigned long long* dev, int count) {
+  if (c->world <= 1) return SBO_OK;
+  SBO_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclMin, (ncclComm_t)c->comm, c->stream));
+  return SBO_OK;
+}
+int comm_allreduce_sum_f64(sbo_ctx* c, double* dev, int count) {
+  if (c->world <= 1) return SBO_OK;
+  SBO_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
+  return SBO_OK;
+}
+int comm_allreduce_sum_i64(sbo_ctx* c, long long* dev, int count) {
+  if (c->world <= 1) return SBO_OK;
+  SBO_NCCL(ncclAllReduce(dev, dev, count, ncclInt64, ncclSum, (ncclComm_t)c->comm, c->stream));
+  return SBO_OK;
+}
+int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_per_rank) {
+  if (c->world <= 1) return SBO_OK;
+  SBO_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclUint8, (ncclComm_t)c->comm, c->stream));
+  return SBO_OK;
+}
+}  // namespace sbo
+
+using namespace sbo;
+
+extern "C" {
+
+int sbo_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(SBO_E_INVALID, "id_out is NULL");
+  static_assert(sizeof(ncclUniqueId) <= SBO_COMM_ID_BYTES, "unique id does not fit");
+  ncclUniqueId id;
+  SBO_NCCL(ncclGetUniqueId(&id));
+  memset(id_out, 0, SBO_COMM_ID_BYTES);
+  memcpy(id_out, &id, sizeof(id));
+  return SBO_OK;
+}
+
+int sbo_comm_init(sbo_ctx* c, int world_size, int rank, const void* id) {
+  if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
+  if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SBO_E_INVALID, "bad world_size / rank");
+  if (c->comm) return fail(SBO_E_INVALID, "communicator already initialised");
+  c->world = world_size;
+  c->rank = rank;
+  if (world_size == 1) return SBO_OK;
+  if (!id) return fail(SBO_E_INVALID, "id is NULL");
+  SBO_HIP(hipSetDevice(c->device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  ncclComm_t comm;
+  SBO_NCCL(ncclCommInitRank(&comm, world_size, uid, rank));
+  c->comm = comm;
+  return SBO_OK;
+}
+
+int sbo_comm_barrier(sbo_ctx* c) {
+  if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
+  if (c->world > 1) {
+    int rc = comm_allreduce_sum_i64(c, (long long*)c->scal.p + 500, 1);
+    if (rc) return rc;
+  }
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  return SBO_OK;
+}
+
+int sbo_comm_destroy_internal(sbo_ctx* c) {
+  if (c && c->comm) {
+    ncclCommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+  }
+  return SBO_OK;
+}
+
+}  // extern "C"

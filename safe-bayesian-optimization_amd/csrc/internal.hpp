@@ -1,0 +1,102 @@
+// internal.hpp -- shared declarations of libsafebo.so (host side + kernel argument blocks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/safebo.h"
+
+namespace sbo {
+
+constexpr int kMaxD = SBO_MAX_D;
+constexpr int kMaxQ = SBO_MAX_Q;
+
+// Model constants handed to kernels by value (kernarg segment).  Everything is kept in double; the
+// fp32 kernels round on use.  Rows a1/a4 of SURVEY.md section 8 (models/GP_Safe.py:236-245, 326-347).
+struct ModelConst {
+  int n, npad, d, dpad, q, factor;
+  double X_mean[kMaxD], X_std[kMaxD];
+  double Y_mean[kMaxQ], Y_std[kMaxQ];
+  double sf2[kMaxQ];            // exp(2 h[d])                       GP_Safe.py:338
+  double mp[kMaxQ];             // prior mean, -2 Y_mean/Y_std, [0]=0 GP_Safe.py:331-332
+  double vinv[kMaxQ][kMaxD];    // ell^-1/2 = exp(-h[a])             GP_Safe.py:112
+  double inv_ell[kMaxQ][kMaxD]; // 1/ell = exp(-2 h[a])
+};
+
+// Candidate description (explicit list or implicit tensor grid), by value.
+struct CandSpec {
+  int kind;        // 0 explicit points, 1 grid
+  int d;
+  int pts_dtype;   // SBO_F64 / SBO_F32 for explicit points
+  int pad;
+  const void* pts; // device pointer [n_local, d]
+  long long n_local, first;
+  double lo[kMaxD], hi[kMaxD], step[kMaxD];
+  long long count[kMaxD];
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace sbo
+
+struct sbo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cu = 256;
+  // model
+  bool has_model = false;
+  int dtype = SBO_F64;
+  sbo::ModelConst mc{};
+  sbo::DevBuf Fpk;     // [q][ntri*4*64] packed MFMA A-fragments of the contraction matrix
+  sbo::DevBuf As;      // [q][npad][dpad]  X_norm * ell^-1/2
+  sbo::DevBuf sqA;     // [q][npad]        sum_a As^2
+  sbo::DevBuf alpha;   // [q][npad]        invK (Y_norm - mp)
+  sbo::DevBuf Xn;      // [npad][dpad]     X_norm (for the mean gradient)
+  size_t fpk_stride = 0;  // elements per output in Fpk
+  std::vector<double> h_Xnorm;   // host copies used by the exact-recheck / result decoding
+  // candidates
+  bool has_cand = false;
+  sbo::CandSpec cs{};
+  sbo::DevBuf pts;
+  // posterior workspace, SoA [q][n_local] of the model dtype
+  sbo::DevBuf mean, var;
+  bool posterior_valid = false;
+  sbo::DevBuf Lmax;    // [kMaxQ] uint64 keys: max ||grad MEAN_i||_inf over the candidates
+  // set workspace
+  sbo::DevBuf maskS, maskU, maskM, maskG, maskO;   // uint8 [n_local] (G/O: [(q-1)][n_local])
+  sbo::DevBuf dist2;   // double [n_local] distance-transform scratch (x2 for ping-pong)
+  sbo::DevBuf dist2b;
+  sbo::DevBuf scal;    // small device scalar block (keys, counters, arg-reduce results)
+  sbo::DevBuf partial; // arg-reduce per-block partials
+  sbo::DevBuf amb;     // ambiguous-index list for the exact recheck
+  int last_sweep = 0;  // 1 safeopt, 2 goose (what the masks hold)
+  bool masks_valid = false;
+  // profile
+  sbo_profile prof{};
+  hipEvent_t ev[8]{};
+  // options
+  int engine = 0;      // 0 MFMA, 1 VALU (fp64 contraction engine)
+  // comm
+  void* comm = nullptr;  // ncclComm_t
+  int world = 1, rank = 0;
+};
+
+namespace sbo {
+int fail(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+int ensure(DevBuf& b, size_t bytes);
+void release(DevBuf& b);
+
+// launchers implemented in the .hip files -----------------------------------------------------
+int launch_posterior(sbo_ctx* c);
+int launch_bound(sbo_ctx* c, double b, int index, int kind, void* dev_out);
+}  // namespace sbo
+
+#define SBO_HIP(x)                                                   \
+  do {                                                               \
+    hipError_t e__ = (x);                                            \
+    if (e__ != hipSuccess) return sbo::hip_fail(e__, #x);            \
+  } while (0)
