@@ -1,8 +1,696 @@
-// sets.hip -- placeholder until the sweep kernels land
-#include "internal.hpp"
-using namespace sbo;
-extern "C" {
-int sbo_sweep_safeopt(sbo_ctx*, const sbo_sweep_opts*, sbo_safeopt_result*) { return fail(SBO_E_UNSUPPORTED, "not built yet"); }
-int sbo_sweep_goose(sbo_ctx*, const sbo_sweep_opts*, sbo_goose_result*) { return fail(SBO_E_UNSUPPORTED, "not built yet"); }
-int sbo_masks_get(sbo_ctx*, int, int, uint8_t*) { return fail(SBO_E_UNSUPPORTED, "not built yet"); }
+// sets.hip -- K3/K4/K5: safe-set classification, minimiser / expander sets and masked arg-reductions.
+//
+// Discretised form of the reference's constrained optimisation problems:
+//   S  = {g : lcb_i(g) >= 0 for all constraints i}                       models/SafeOpt.py:57-59
+//   u* = min_S ucb_0,  M = {g in S : lcb_0(g) <= u*}                      models/SafeOpt.py:47-51, 61-62
+//   U  = {h : lcb_i(h) <= 0 for all constraints i}                        models/SafeOpt.py:73-77, 109
+//   G_c= {g in S : exists h in U, ucb_c(g) - L ||x_g - x_h + 1e-8|| >= 0}  models/SafeOpt.py:85-88, 111
+//   acquisition: argmax var_0 over M and over each G_c                    models/SafeOpt.py:55, 65-66, 92, 117-124
+// These passes are HBM-bound (a few bytes per candidate); the arithmetic that decides a mask bit is written
+// with unfused multiplies/adds in the oracle's order so the masks are reproducible bit for bit from a given
+// mean/var.  The expander query "is some fully-unsafe point within ucb/L of g" is answered with an exact
+// separable Euclidean distance transform of the U mask on the grid, bounded by the largest radius that can
+// matter; decisions that fall inside the rounding band of the reference's "+1e-8" are re-decided by
+// exhaustive evaluation of the reference expression, so the transform never changes a mask bit.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "device_common.hpp"
+
+namespace sbo {
+
+int comm_allreduce_max_u64(sbo_ctx* c, unsigned long long* dev, int count);
+int comm_allreduce_min_u64(sbo_ctx* c, unsigned long long* dev, int count);
+int comm_allreduce_sum_f64(sbo_ctx* c, double* dev, int count);
+int comm_allreduce_sum_i64(sbo_ctx* c, long long* dev, int count);
+int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_per_rank);
+
+constexpr double kInfD = 1.0e300;
+constexpr int kArgSlots = 16;
+
+// small device-resident scalar block of one sweep
+struct SweepScalars {
+  unsigned long long ustar_key;            // min over S of ord_key(ucb_0)
+  unsigned long long rmax_key[kMaxQ];      // max over S of ord_key(ucb_c)
+  long long count_S, count_U, count_M;
+  long long count_set[kMaxQ];              // |G_c| or |O_c|
+  long long n_amb, n_amb_total;
+  double arg_val[kArgSlots];
+  long long arg_idx[kArgSlots];
+};
+
+struct Best {
+  double v;
+  long long i;   // global flat index, -1 = none
+};
+
+template <bool MAX>
+__device__ __forceinline__ bool better(const Best& a, const Best& b) {
+  if (a.i < 0) return false;
+  if (b.i < 0) return true;
+  if (MAX ? (a.v > b.v) : (a.v < b.v)) return true;
+  return a.v == b.v && a.i < b.i;   // ties -> lowest flat index
 }
+
+template <bool MAX>
+__device__ __forceinline__ Best wave_best(Best x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Best y;
+    y.v = __shfl_xor(x.v, o);
+    y.i = __shfl_xor(x.i, o);
+    if (better<MAX>(y, x)) x = y;
+  }
+  return x;
+}
+
+template <bool MAX>
+__device__ __forceinline__ Best block_best(Best x) {
+  __shared__ Best sh[16];
+  x = wave_best<MAX>(x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = x;
+  __syncthreads();
+  if (wave == 0) {
+    Best y = lane < nw ? sh[lane] : Best{0.0, -1};
+    y = wave_best<MAX>(y);
+    x = y;
+  }
+  return x;   // valid in wave 0
+}
+
+__device__ __forceinline__ long long block_sum_ll(long long v) {
+  __shared__ long long sh[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  long long r = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nw; ++w) r += sh[w];
+  return r;   // valid in thread 0
+}
+
+template <bool MAX>
+__device__ __forceinline__ unsigned long long block_ext_u64(unsigned long long v) {
+  __shared__ unsigned long long sh[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long y = __shfl_xor(v, o);
+    v = MAX ? (y > v ? y : v) : (y < v ? y : v);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int w = 1; w < nw; ++w) v = MAX ? (sh[w] > v ? sh[w] : v) : (sh[w] < v ? sh[w] : v);
+  return v;   // valid in thread 0
+}
+
+template <typename T>
+__device__ __forceinline__ void lcb_ucb(T m, T v, T b, T& lcb, T& ucb) {
+  const T sd = mul_rn(b, sqrt_rn(v));    // models/SafeOpt.py:37, 43: mean -/+ b*sqrt(var)
+  lcb = sub_rn(m, sd);
+  ucb = add_rn(m, sd);
+}
+
+// ---- K3a: S / U masks, u* --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, const T* __restrict__ var, long long n,
+                                                  int q, T b, uint8_t* __restrict__ S, uint8_t* __restrict__ U,
+                                                  SweepScalars* sc) {
+  unsigned long long umin = ~0ull;
+  long long cS = 0, cU = 0;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    bool s = true, u = true;
+    for (int c = 1; c < q; ++c) {
+      T lcb, ucb;
+      lcb_ucb(mean[(size_t)c * n + g], var[(size_t)c * n + g], b, lcb, ucb);
+      s = s && (lcb >= T(0));
+      u = u && (lcb <= T(0));
+    }
+    S[g] = s;
+    U[g] = u;
+    cS += s;
+    cU += u;
+    if (s) {
+      T lcb, ucb;
+      lcb_ucb(mean[g], var[g], b, lcb, ucb);
+      const unsigned long long k = ord_key((double)ucb);
+      umin = k < umin ? k : umin;
+    }
+  }
+  umin = block_ext_u64<false>(umin);
+  cS = block_sum_ll(cS);
+  cU = block_sum_ll(cU);
+  if (threadIdx.x == 0) {
+    if (umin != ~0ull) atomicMin(&sc->ustar_key, umin);
+    if (cS) atomicAdd((unsigned long long*)&sc->count_S, (unsigned long long)cS);
+    if (cU) atomicAdd((unsigned long long*)&sc->count_U, (unsigned long long)cU);
+  }
+}
+
+// max over S of ucb_c (bounds the expander search radius)
+template <typename T>
+__global__ __launch_bounds__(256) void k_rmax(const T* __restrict__ mean_c, const T* __restrict__ var_c, long long n, T b,
+                                              const uint8_t* __restrict__ S, SweepScalars* sc, int c) {
+  unsigned long long rk = 0;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    if (S[g]) {
+      T lcb, ucb;
+      lcb_ucb(mean_c[g], var_c[g], b, lcb, ucb);
+      const unsigned long long k = ord_key((double)ucb);
+      rk = k > rk ? k : rk;
+    }
+  }
+  rk = block_ext_u64<true>(rk);
+  if (threadIdx.x == 0 && rk) atomicMax(&sc->rmax_key[c], rk);
+}
+
+// ---- K3b + K5: M mask and arg-max of var_0 over M -----------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, const T* __restrict__ var0, long long n,
+                                                   long long first, T b, const uint8_t* __restrict__ S,
+                                                   uint8_t* __restrict__ M, SweepScalars* sc, Best* partial) {
+  const T ustar = (T)ord_val(sc->ustar_key);
+  Best best{0.0, -1};
+  long long cM = 0;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    bool m = false;
+    if (S[g]) {
+      T lcb, ucb;
+      lcb_ucb(mean0[g], var0[g], b, lcb, ucb);
+      m = lcb <= ustar;                       // models/SafeOpt.py:62
+    }
+    M[g] = m;
+    if (m) {
+      ++cM;
+      const Best cand{(double)var0[g], first + g};
+      if (better<true>(cand, best)) best = cand;
+    }
+  }
+  best = block_best<true>(best);
+  cM = block_sum_ll(cM);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = best;
+    if (cM) atomicAdd((unsigned long long*)&sc->count_M, (unsigned long long)cM);
+  }
+}
+
+// generic masked arg-max / arg-min of a value array, plus the mask population
+template <typename T, bool MAX>
+__global__ __launch_bounds__(256) void k_arg_masked(const T* __restrict__ val, const uint8_t* __restrict__ mask, long long n,
+                                                    long long first, long long* count, Best* partial) {
+  Best best{0.0, -1};
+  long long cnt = 0;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    if (mask[g]) {
+      ++cnt;
+      const Best cand{(double)val[g], first + g};
+      if (better<MAX>(cand, best)) best = cand;
+    }
+  }
+  best = block_best<MAX>(best);
+  cnt = block_sum_ll(cnt);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = best;
+    if (cnt && count) atomicAdd((unsigned long long*)count, (unsigned long long)cnt);
+  }
+}
+
+template <bool MAX>
+__global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ partial, int nparts, SweepScalars* sc, int slot) {
+  Best best{0.0, -1};
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x)
+    if (better<MAX>(partial[i], best)) best = partial[i];
+  best = block_best<MAX>(best);
+  if (threadIdx.x == 0) {
+    sc->arg_val[slot] = best.v;
+    sc->arg_idx[slot] = best.i;
+  }
+}
+
+// ---- K4: exact Euclidean distance transform of the U mask on the grid ---------------------------------
+// axis 0: one wave per grid line, nearest set bit on either side found with ballots (coalesced, exact)
+__global__ __launch_bounds__(256) void k_edt_axis0(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
+                                                   double* __restrict__ D) {
+  const int lane = threadIdx.x & 63;
+  const long long line = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (line >= nlines) return;
+  const uint8_t* u = U + line * count0;
+  double* d = D + line * count0;
+  const int nch = (count0 + 63) >> 6;
+  long long carry = -1;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int i = ch * 64 + lane;
+    const bool bit = i < count0 && u[i];
+    const unsigned long long m = __ballot(bit);
+    const unsigned long long lower = m & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+    const long long li = lower ? (long long)ch * 64 + (63 - __clzll((long long)lower)) : carry;
+    if (i < count0) d[i] = (double)li;
+    if (m) carry = (long long)ch * 64 + (63 - __clzll((long long)m));
+  }
+  carry = -1;
+  for (int ch = nch - 1; ch >= 0; --ch) {
+    const int i = ch * 64 + lane;
+    const bool bit = i < count0 && u[i];
+    const unsigned long long m = __ballot(bit);
+    const unsigned long long upper = m >> lane;
+    const long long ri = upper ? (long long)ch * 64 + lane + (__ffsll((long long)upper) - 1) : carry;
+    if (i < count0) {
+      const long long li = (long long)d[i];
+      long long t = -1;
+      if (li >= 0) t = i - li;
+      if (ri >= 0 && (t < 0 || ri - i < t)) t = ri - i;
+      double v = kInfD;
+      if (t >= 0) {
+        const double dt = h0 * (double)t;
+        v = dt * dt;
+      }
+      d[i] = v;
+    }
+    if (m) carry = (long long)ch * 64 + (__ffsll((long long)m) - 1);
+  }
+}
+
+// axes >= 1: D_out[g] = min_t D_in[g + t stride] + (h t)^2, searched outwards with the two exits
+//   (h t)^2 >= best  (nothing further can improve)  and  h t > cap  (beyond any radius that matters).
+__device__ __forceinline__ double edt_scan_point(const double* __restrict__ Din, long long g, long long stride, int cnt,
+                                                 int ia, double h, double cap) {
+  double best = Din[g];
+  for (int t = 1; t < cnt; ++t) {
+    const double dt = h * (double)t;
+    const double e = dt * dt;
+    if (e >= best || dt > cap) break;
+    const bool lo_ok = ia - t >= 0, hi_ok = ia + t < cnt;
+    if (!lo_ok && !hi_ok) break;
+    const double c1 = lo_ok ? Din[g - (long long)t * stride] : kInfD;
+    const double c2 = hi_ok ? Din[g + (long long)t * stride] : kInfD;
+    const double c = (c1 < c2 ? c1 : c2) + e;
+    best = c < best ? c : best;
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din, double* __restrict__ Dout, long long n,
+                                                  long long stride, int cnt, double h, const SweepScalars* sc, int c,
+                                                  const unsigned long long* Lkeys, int lidx) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const double rmax = sc->rmax_key[c] ? ord_val(sc->rmax_key[c]) : 0.0;
+  const double cap = (L > 0) ? rmax / L * 1.000001 + 1e-6 : kInfD;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    const int ia = (int)((g / stride) % cnt);
+    Dout[g] = edt_scan_point(Din, g, stride, cnt, ia, h, cap);
+  }
+}
+
+// Reference expression for one (g, h) pair, unfused, in the oracle's order:
+//   ucb - L * sqrt(sum_a (x_g[a] - x_h[a] + 1e-8)^2) >= 0            models/SafeOpt.py:85-88
+template <int D>
+__device__ __forceinline__ bool lipschitz_pair(const double (&xg)[D], const double (&xh)[D], int d, double ucb, double L) {
+  double ss = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    if (a < d) {
+      const double df = __dadd_rn(__dsub_rn(xg[a], xh[a]), 1e-8);
+      ss = (a == 0) ? __dmul_rn(df, df) : __dadd_rn(ss, __dmul_rn(df, df));
+    }
+  }
+  const double dist = __dsqrt_rn(ss);
+  return __dsub_rn(ucb, __dmul_rn(L, dist)) >= 0.0;
+}
+
+// last axis + decision.  For g in S: nearest-U distance dm (unshifted) -> G bit, or the ambiguous list when
+// ucb - L dm lies inside the band the "+1e-8" shift and rounding can move it across zero.
+template <typename T>
+__global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ Din, long long n, long long stride, int cnt,
+                                                    double h, int d, double xscale, const T* __restrict__ mean_c,
+                                                    const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
+                                                    const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
+                                                    uint8_t* __restrict__ G, long long* __restrict__ amb) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const bool anyU = sc->count_U > 0;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    uint8_t out = 0;
+    if (S[g] && anyU) {
+      T lcb, ucbT;
+      lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
+      const double ucb = (double)ucbT;
+      if (!(L > 0)) {
+        out = ucb >= 0.0;                         // radius unbounded: any U point is a witness
+      } else {
+        const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
+        const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
+        const int ia = (int)((g / stride) % cnt);
+        const double best = (cnt > 1) ? edt_scan_point(Din, g, stride, cnt, ia, h, cap) : Din[g];
+        if (best < 0.5 * kInfD) {
+          const double dm = sqrt(best);
+          const double eps = eps_abs + 1e-11 * dm;
+          const double tol = 1e-12 * (fabs(ucb) + L * dm);
+          const double lo = ucb - L * (dm + eps), hi = ucb - L * (dm - eps);
+          if (lo > tol) out = 1;
+          else if (hi >= -tol) {
+            const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
+            amb[slot] = g;
+          }
+        }
+      }
+    }
+    G[g] = out;
+  }
+}
+
+// every S point goes to the exhaustive list (explicit candidate lists have no grid to transform)
+__global__ __launch_bounds__(256) void k_list_safe(const uint8_t* __restrict__ S, long long n, SweepScalars* sc,
+                                                   uint8_t* __restrict__ G, long long* __restrict__ amb) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    G[g] = 0;
+    if (S[g]) {
+      const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
+      amb[slot] = g;
+    }
+  }
+}
+
+// exhaustive evaluation of the reference predicate for the listed g: one workgroup per g, all U points
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const T* __restrict__ mean_c,
+                                                        const T* __restrict__ var_c, T b, const uint8_t* __restrict__ U,
+                                                        const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
+                                                        const long long* __restrict__ amb, uint8_t* __restrict__ G) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const long long namb = sc->n_amb;
+  for (long long qi = blockIdx.x; qi < namb; qi += gridDim.x) {
+    const long long g = amb[qi];
+    T lcb, ucbT;
+    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
+    const double ucb = (double)ucbT;
+    double xg[D];
+    cand_coords<D>(cs, g, xg);
+    int found = 0;
+    for (long long hh = threadIdx.x; hh < cs.n_local && !found; hh += blockDim.x) {
+      if (U[hh]) {
+        double xh[D];
+        cand_coords<D>(cs, hh, xh);
+        if (lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
+      }
+    }
+    found = __syncthreads_or(found);
+    if (threadIdx.x == 0 && found) G[g] = 1;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sc->n_amb_total += namb;
+  }
+}
+
+__global__ void k_reset_amb(SweepScalars* sc) { sc->n_amb = 0; }
+__global__ void k_init_scalars(SweepScalars* sc) {
+  if (threadIdx.x == 0) sc->ustar_key = ~0ull;
+  if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
+}
+
+// ---- host orchestration -------------------------------------------------------------------------------
+static int reduce_blocks(const sbo_ctx* c) {
+  const long long n = c->cs.n_local;
+  return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8));
+}
+
+template <typename T>
+static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o) {
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q;
+  int rc;
+  if ((rc = ensure(c->maskS, (size_t)n))) return rc;
+  if ((rc = ensure(c->maskU, (size_t)n))) return rc;
+  if ((rc = ensure(c->maskM, (size_t)n))) return rc;
+  if ((rc = ensure(c->maskG, (size_t)n * std::max(1, q - 1)))) return rc;
+  if ((rc = ensure(c->scal, sizeof(SweepScalars)))) return rc;
+  const int nb = reduce_blocks(c);
+  if ((rc = ensure(c->partial, sizeof(Best) * (size_t)nb))) return rc;
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
+  SBO_HIP(hipMemsetAsync(sc, 0, sizeof(SweepScalars), c->stream));
+  hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(64), 0, c->stream, sc);
+  if (n > 0)
+    hipLaunchKernelGGL(k_classify<T>, dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
+                       (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, sc);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+template <typename T, int D>
+static int launch_exact(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lidx, uint8_t* G) {
+  const long long n = c->cs.n_local;
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
+  const T* mean_c = (const T*)c->mean.p + (size_t)cidx * n;
+  const T* var_c = (const T*)c->var.p + (size_t)cidx * n;
+  hipLaunchKernelGGL((k_expander_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, mean_c, var_c, (T)o->b,
+                     (const uint8_t*)c->maskU.p, (const unsigned long long*)c->Lmax.p, lidx, sc,
+                     (const long long*)c->amb.p, G);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+template <typename T>
+static int launch_exact_d(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lidx, uint8_t* G) {
+  switch (c->mc.dpad) {
+    case 2: return launch_exact<T, 2>(c, o, cidx, lidx, G);
+    case 4: return launch_exact<T, 4>(c, o, cidx, lidx, G);
+    case 8: return launch_exact<T, 8>(c, o, cidx, lidx, G);
+  }
+  return fail(SBO_E_UNSUPPORTED, "unsupported padded dimension");
+}
+
+// G_c for constraint cidx (1..q-1) into G[n]
+template <typename T>
+static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* G) {
+  const long long n = c->cs.n_local;
+  if (n == 0) return SBO_OK;
+  const int q = c->mc.q;
+  const int lidx = o->reference_quirk_L_index ? q - 1 : cidx;   // models/SafeOpt.py:110 (loop-leaked i)
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
+  const T* mean_c = (const T*)c->mean.p + (size_t)cidx * n;
+  const T* var_c = (const T*)c->var.p + (size_t)cidx * n;
+  const int nb = reduce_blocks(c);
+  int rc;
+  if ((rc = ensure(c->amb, sizeof(long long) * (size_t)n))) return rc;
+  hipLaunchKernelGGL(k_reset_amb, dim3(1), dim3(1), 0, c->stream, sc);
+  if (c->cs.kind == 1) {
+    const int d = c->cs.d;
+    if ((rc = ensure(c->dist2, sizeof(double) * (size_t)n))) return rc;
+    if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)n))) return rc;
+    hipLaunchKernelGGL((k_rmax<T>), dim3(nb), dim3(256), 0, c->stream, mean_c, var_c, n, (T)o->b,
+                       (const uint8_t*)c->maskS.p, sc, cidx);
+    const int count0 = (int)c->cs.count[0];
+    const long long nlines = n / count0;
+    hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, c->stream,
+                       (const uint8_t*)c->maskU.p, nlines, count0, c->cs.step[0], (double*)c->dist2.p);
+    double* din = (double*)c->dist2.p;
+    double* dout = (double*)c->dist2b.p;
+    long long stride = count0;
+    for (int a = 1; a < d - 1; ++a) {
+      hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+                         (const double*)din, dout, n, stride, (int)c->cs.count[a], c->cs.step[a],
+                         (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx);
+      std::swap(din, dout);
+      stride *= c->cs.count[a];
+    }
+    double xscale = 0.0;
+    for (int a = 0; a < d; ++a) xscale = std::max(xscale, std::max(std::fabs(c->cs.lo[a]), std::fabs(c->cs.hi[a])));
+    const int last_cnt = d >= 2 ? (int)c->cs.count[d - 1] : 1;
+    const double last_h = d >= 2 ? c->cs.step[d - 1] : 0.0;
+    hipLaunchKernelGGL((k_edt_decide<T>), dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0,
+                       c->stream, (const double*)din, n, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c, (T)o->b,
+                       (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
+                       (long long*)c->amb.p);
+  } else {
+    if (n > (1ll << 17))
+      return fail(SBO_E_UNSUPPORTED, "expander sets on explicit candidate lists are exhaustive: N <= 131072");
+    hipLaunchKernelGGL(k_list_safe, dim3(nb), dim3(256), 0, c->stream, (const uint8_t*)c->maskS.p, n, sc, G,
+                       (long long*)c->amb.p);
+  }
+  SBO_HIP(hipGetLastError());
+  return launch_exact_d<T>(c, o, cidx, lidx, G);
+}
+
+static void coords_of(const sbo_ctx* c, long long gidx, double* x) {
+  // host restatement of cand_coords for result decoding (grid) or a small D2H read (explicit list)
+  for (int a = 0; a < SBO_MAX_D; ++a) x[a] = 0.0;
+  if (gidx < 0) return;
+  if (c->cs.kind == 1) {
+    long long f = gidx;
+    for (int a = 0; a < c->cs.d; ++a) {
+      const long long cnt = c->cs.count[a];
+      const long long i = f % cnt;
+      f /= cnt;
+      x[a] = (i == cnt - 1 && cnt > 1) ? c->cs.hi[a] : c->cs.lo[a] + (double)i * c->cs.step[a];
+    }
+  } else {
+    const long long loc = gidx - c->cs.first;
+    if (loc < 0 || loc >= c->cs.n_local) return;   // owned by another rank: filled by the caller's exchange
+    if (c->cs.pts_dtype == SBO_F64) {
+      (void)hipMemcpy(x, (const double*)c->pts.p + loc * c->cs.d, sizeof(double) * c->cs.d, hipMemcpyDeviceToHost);
+    } else {
+      float tmp[SBO_MAX_D];
+      (void)hipMemcpy(tmp, (const float*)c->pts.p + loc * c->cs.d, sizeof(float) * c->cs.d, hipMemcpyDeviceToHost);
+      for (int a = 0; a < c->cs.d; ++a) x[a] = tmp[a];
+    }
+  }
+}
+
+int sbo_posterior_enqueue_(sbo_ctx* c);
+
+template <typename T>
+static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_result* res) {
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q;
+  int rc;
+  SBO_HIP(hipEventRecord(c->ev[0], c->stream));
+  const bool reuse = o->posterior_ready && c->posterior_valid;
+  if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
+  SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  if ((rc = sweep_common_front<T>(c, o))) return rc;
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
+  const int nb = reduce_blocks(c);
+  if (n > 0)
+    hipLaunchKernelGGL((k_minimizer<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n,
+                       (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, sc,
+                       (Best*)c->partial.p);
+  hipLaunchKernelGGL((k_arg_final<true>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0);
+  SBO_HIP(hipEventRecord(c->ev[2], c->stream));
+  for (int cc = 1; cc < q; ++cc) {
+    uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
+    if ((rc = expander_set<T>(c, o, cc, G))) return rc;
+  }
+  SBO_HIP(hipEventRecord(c->ev[3], c->stream));
+  for (int cc = 1; cc < q; ++cc) {
+    const uint8_t* G = (const uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
+    if (n > 0)
+      hipLaunchKernelGGL((k_arg_masked<T, true>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->var.p, G, n,
+                         (long long)c->cs.first, &sc->count_set[cc - 1], (Best*)c->partial.p);
+    hipLaunchKernelGGL((k_arg_final<true>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0,
+                       sc, cc);
+  }
+  SBO_HIP(hipGetLastError());
+  SBO_HIP(hipEventRecord(c->ev[4], c->stream));
+  SweepScalars h;
+  unsigned long long Lk[kMaxQ];
+  SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipMemcpyAsync(Lk, c->Lmax.p, sizeof(Lk), hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  c->masks_valid = true;
+  c->last_sweep = 1;
+
+  float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t04 = 0;
+  SBO_HIP(hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
+  SBO_HIP(hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
+  SBO_HIP(hipEventElapsedTime(&t23, c->ev[2], c->ev[3]));
+  SBO_HIP(hipEventElapsedTime(&t34, c->ev[3], c->ev[4]));
+  SBO_HIP(hipEventElapsedTime(&t04, c->ev[0], c->ev[4]));
+  memset(&c->prof, 0, sizeof(c->prof));
+  c->prof.posterior_ms = t01;
+  c->prof.classify_ms = t12;
+  c->prof.expander_ms = t23;
+  c->prof.argreduce_ms = t34;
+  c->prof.total_ms = t04;
+  c->prof.candidates = n;
+  c->prof.posterior_launches = (!reuse && n > 0) ? 1 : 0;
+  const double nn = c->mc.n, dd = c->mc.d;
+  c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
+
+  memset(res, 0, sizeof(*res));
+  res->count_S = h.count_S;
+  res->count_U = h.count_U;
+  res->count_M = h.count_M;
+  res->n_exact_rechecks = h.n_amb_total;
+  for (int i = 0; i < q; ++i) memcpy(&res->L[i], &Lk[i], 8);
+  res->minimizer_index = -1;
+  res->expander_index = -1;
+  for (int cc = 1; cc < q; ++cc) res->expander_index_c[cc - 1] = -1;
+  if (h.count_S == 0) return fail(SBO_E_EMPTY_SAFE_SET, "safe set S_t is empty on this candidate set");
+  res->u_star = ord_val(h.ustar_key);
+  res->minimizer_index = h.arg_idx[0];
+  res->minimizer_std = std::sqrt(h.arg_val[0]);                 // models/SafeOpt.py:66
+  coords_of(c, res->minimizer_index, res->minimizer_x);
+  double best_std = 0.0;
+  int best_c = 0;
+  for (int cc = 1; cc < q; ++cc) {
+    res->count_G[cc - 1] = h.count_set[cc - 1];
+    res->expander_index_c[cc - 1] = h.arg_idx[cc];
+    res->expander_std_c[cc - 1] = h.arg_idx[cc] >= 0 ? std::sqrt(h.arg_val[cc]) : 0.0;
+    // max(std_expanders) / .index(max_std): first maximum wins (models/SafeOpt.py:119-121)
+    if (h.arg_idx[cc] >= 0 && (best_c == 0 || res->expander_std_c[cc - 1] > best_std)) {
+      best_std = res->expander_std_c[cc - 1];
+      best_c = cc;
+    }
+  }
+  res->expander_best_c = best_c;
+  if (best_c) {
+    res->expander_index = res->expander_index_c[best_c - 1];
+    res->expander_std = best_std;
+    coords_of(c, res->expander_index, res->expander_x);
+  }
+  res->choose_minimizer = res->minimizer_std > res->expander_std;   // test/test_SafeOpt.py:153
+  return SBO_OK;
+}
+
+}  // namespace sbo
+
+using namespace sbo;
+
+extern "C" {
+
+int sbo_posterior_enqueue(sbo_ctx* c);
+}
+namespace sbo {
+int sbo_posterior_enqueue_(sbo_ctx* c) { return sbo_posterior_enqueue(c); }
+}
+
+extern "C" {
+
+int sbo_sweep_safeopt(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_safeopt_result* result) {
+  if (!c || !opts || !result) return fail(SBO_E_INVALID, "NULL argument");
+  if (!c->has_model) return fail(SBO_E_NO_MODEL, "sbo_model_set has not been called");
+  if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
+  if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
+  if (c->world > 1) return fail(SBO_E_UNSUPPORTED, "multi-rank sweep not built yet");
+  SBO_HIP(hipSetDevice(c->device));
+  return c->dtype == SBO_F64 ? sweep_safeopt_t<double>(c, opts, result) : sweep_safeopt_t<float>(c, opts, result);
+}
+
+int sbo_sweep_goose(sbo_ctx*, const sbo_sweep_opts*, sbo_goose_result*) {
+  return fail(SBO_E_UNSUPPORTED, "GoOSE sweep not built yet");
+}
+
+int sbo_masks_get(sbo_ctx* c, int which, int cidx, uint8_t* out) {
+  if (!c || !out) return fail(SBO_E_INVALID, "NULL argument");
+  if (!c->masks_valid) return fail(SBO_E_INVALID, "no sweep has produced masks on these candidates");
+  const long long n = c->cs.n_local;
+  const void* src = nullptr;
+  switch (which) {
+    case SBO_MASK_S: src = c->maskS.p; break;
+    case SBO_MASK_U: src = c->maskU.p; break;
+    case SBO_MASK_M:
+      if (c->last_sweep != 1) return fail(SBO_E_INVALID, "M is produced by the SafeOpt sweep");
+      src = c->maskM.p;
+      break;
+    case SBO_MASK_G:
+    case SBO_MASK_O:
+      if ((which == SBO_MASK_G) != (c->last_sweep == 1)) return fail(SBO_E_INVALID, "mask not produced by the last sweep");
+      if (cidx < 1 || cidx >= c->mc.q) return fail(SBO_E_INVALID, "constraint index out of range");
+      src = (const uint8_t*)(which == SBO_MASK_G ? c->maskG.p : c->maskO.p) + (size_t)(cidx - 1) * n;
+      break;
+    default: return fail(SBO_E_INVALID, "unknown mask");
+  }
+  if (n > 0) {
+    SBO_HIP(hipMemcpyAsync(out, src, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+  }
+  return SBO_OK;
+}
+
+}  // extern "C"
