@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate-points/sec of the SafeOpt posterior + safe-set sweep on MI355X.
+
+Contract (see the task statement): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the
+driver launches one rank per GPU with ``torch.distributed.run``.  One *step* is one full SafeOpt sweep
+(K1 posterior, S/U/M masks, u*, Lipschitz bound, expander sets, masked arg-max, result to host) over the
+candidates resident in HBM.
+
+Workload at N = 1: BASELINE.json configs[1] -- Benoit 2-D, 2048 x 2048 implicit grid, n = 128 observations,
+q = 2 outputs, fp64.  For N > 1 the grid grows along its slowest axis (2048 x 2048 N): each rank sweeps
+2048^2 candidates ("weak" scaling); the ranks exchange u*/L (one RCCL max all-reduce), the fully-unsafe
+mask (one all-gather) and the arg-max candidates (one sum all-reduce).
+
+torch is used only as the launcher's rendezvous (gloo group: unique-id broadcast, barriers, max over
+ranks); device memory, streams and the collectives on the data path belong to libsafebo.so.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6      # AMD MI355X datasheet, FP64 matrix == FP64 vector (guide has no f64 row)
+FP64_MFMA_MEASURED_TFLOPS = 47.9    # v_mfma_f64_16x16x4_f64 back-to-back at 2.39 GHz (profiles/r01_mfma_probe.txt)
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, f32-input MFMA
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="B", help="synthetic config (B = BASELINE.json configs[1]; H = 4096^2, n = 512)")
+    ap.add_argument("--n", type=int, default=None, help="override the number of observations")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 19, help="candidates timed by the CPU baseline (0 = skip)")
+    ap.add_argument("--engine", type=int, default=None, help="fp64 contraction engine override (0 MFMA, 1 VALU)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, count, sample):
+    """The NumPy oracle (reference formulation: explicit invK, (Nc x n) @ (n x n), row-dot) on a contiguous
+    prefix of the same grid: posterior, bounds, S/U/M masks, u*, arg-max.  The oracle's brute-force
+    expander is quadratic in the candidate count and is left out (that favours the CPU figure)."""
+    import oracle
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    total = int(np.prod(count))
+    sample = min(sample, total)
+    pts = oracle.grid_points(lo, hi, count, first=0, n=sample)
+    oracle.gp_inference(pts[:4096], cfg["ds"])           # warm the BLAS threads
+    t0 = time.perf_counter()
+    mean, var = oracle.gp_inference(pts, cfg["ds"])
+    lcb, ucb = oracle.bounds(mean, var, cfg["b"])
+    S = np.all(lcb[:, 1:] >= 0, axis=1)
+    U = np.all(lcb[:, 1:] <= 0, axis=1)
+    if S.any():
+        u_star = np.min(ucb[S, 0])
+        M = S & (lcb[:, 0] <= u_star)
+        int(np.argmax(np.where(M, var[:, 0], -np.inf)))
+    dt = time.perf_counter() - t0
+    del U
+    return {"value": sample / dt, "unit": "candidates/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": f"first {sample} candidates of the same grid: posterior + bounds + S/U/M masks + u* + arg-max "
+                      f"in NumPy (OpenBLAS, all cores), {dt:.2f} s; the oracle's quadratic brute-force expander is excluded"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+
+    import safebo_amd
+    from safebo_amd import synthetic
+
+    dist = None
+    if world > 1:
+        from safebo_amd import distributed
+        dist = distributed.init_gloo_from_env()   # rendezvous only (gloo over 127.0.0.1)
+
+    cfg = synthetic.make_config(args.config, n=args.n)
+    if cfg["count"] is None:
+        raise SystemExit("bench.py sweeps grid configs (A, B, C, D, H)")
+    count = list(cfg["count"])
+    count[-1] *= world                                   # weak scaling: slowest axis grows with the ranks
+    lo, hi = cfg["bound"][:, 0].copy(), cfg["bound"][:, 1].copy()
+    n_total = int(np.prod(count))
+
+    eng = safebo_amd.SweepEngine(local_rank)
+    if args.engine is not None:
+        eng.set_option("fp64_engine", args.engine)
+    if world > 1:
+        distributed.join(eng)                    # RCCL communicator: unique id broadcast from rank 0
+    eng.set_model(cfg["ds"], dtype=cfg["dtype"])
+    eng.set_grid_sharded(lo, hi, count)                  # candidates are implicit: resident by construction
+
+    def barrier():
+        eng.synchronize()
+        if dist is not None:
+            dist.barrier()
+        eng.synchronize()
+
+    def step():
+        return eng.sweep_safeopt(cfg["b"])
+
+    for _ in range(args.warmup):
+        step()
+    k1_ms, k1_flops, tot_ms = [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        p = eng.profile()
+        k1_ms.append(p["posterior_ms"])
+        k1_flops.append(p["posterior_flops"])
+        tot_ms.append(p["total_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = n_total * args.steps / elapsed
+        k1 = float(np.mean(k1_ms))
+        achieved = float(np.mean(k1_flops)) / (k1 * 1e-3) / 1e12
+        peak = FP64_MATRIX_PEAK_TFLOPS if cfg["dtype"] == "f64" else FP32_MATRIX_PEAK_TFLOPS
+        out = {
+            "metric": "candidate-points/sec, SafeOpt posterior+safe-set sweep",
+            "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": f"config {args.config}: {cfg['plant']} {cfg['d']}-D SafeOpt sweep, implicit grid "
+                                   f"{'x'.join(str(c) for c in count)} ({n_total} candidates), n={cfg['ds']['X_norm'].shape[0]} "
+                                   f"observations, q={cfg['q']} outputs, b={cfg['b']}",
+                       "per_gpu_candidates": n_total // world, "sweep": "safeopt",
+                       "result": {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
+                                  "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "kernel": "k_posterior", "kernel_ms": k1,
+                         "algorithmic_flops_per_candidate": float(np.mean(k1_flops)) / (n_total // world),
+                         "peak_source": "AMD MI355X datasheet FP64 matrix (no f64 row in MI355X_MICROARCH.md)" if cfg["dtype"] == "f64" else "MI355X_MICROARCH.md f32 MFMA",
+                         "peak_measured_mfma_f64": FP64_MFMA_MEASURED_TFLOPS if cfg["dtype"] == "f64" else None,
+                         "device_ms_per_step": float(np.mean(tot_ms))},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, count, args.cpu_sample)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

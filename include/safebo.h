@@ -151,6 +151,14 @@ int sbo_synchronize(sbo_ctx* ctx);
 int sbo_comm_unique_id(void* id_out /* SBO_COMM_ID_BYTES, filled on rank 0 and sent to peers */);
 int sbo_comm_init(sbo_ctx* ctx, int world_size, int rank, const void* id);
 int sbo_comm_barrier(sbo_ctx* ctx);
+/* Rehearsal transport for test rigs where the ranks cannot form an RCCL communicator (e.g. two ranks sharing
+ * the one GPU of a test box, which RCCL refuses): the same collectives, staged through host memory and carried
+ * by caller-supplied functions (the tests use torch.distributed/gloo).  elem: 0 = uint64, 1 = double;
+ * op: 0 = sum, 1 = max, 2 = min.  Not a production path: RCCL over xGMI is. */
+typedef int (*sbo_relay_allreduce_fn)(void* user, void* buf, int64_t count, int elem, int op);
+typedef int (*sbo_relay_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes_per_rank);
+int sbo_comm_init_relay(sbo_ctx* ctx, int world_size, int rank, sbo_relay_allreduce_fn allreduce,
+                        sbo_relay_allgather_fn allgather, void* user);
 
 /* ---- model state = inference_datasets (models/GP_Safe.py:236-245) -------------------------- */
 /* hypopt is [d+2, q]: rows 0..d-1 = log ell_a, row d = log sigma_f, row d+1 = log sigma_n, consumed as
@@ -169,6 +177,11 @@ int sbo_candidates_points(sbo_ctx* ctx, const void* points, int points_dtype, in
  * flat range [first_index, first_index + n_local). No HBM bytes are read for candidates. */
 int sbo_candidates_grid(sbo_ctx* ctx, int d, const double* lo, const double* hi, const int64_t* count,
                         int64_t first_index, int64_t n_local);
+
+/* same grid, sharded over the ranks of sbo_comm_init by whole hyper-planes of the slowest axis (rank r owns
+ * planes [r P / W, (r+1) P / W)); returns this rank's flat range.  Required for multi-rank sweeps. */
+int sbo_candidates_grid_sharded(sbo_ctx* ctx, int d, const double* lo, const double* hi, const int64_t* count,
+                                int64_t* first_index_out, int64_t* n_local_out);
 
 /* ---- hot path ------------------------------------------------------------------------------ */
 /* K1: GP_inference for every local candidate; mean/var stay in HBM. */

@@ -65,6 +65,9 @@ class Profile(C.Structure):
     ]
 
 
+RELAY_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)
+RELAY_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+
 # every symbol include/safebo.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _DP = C.POINTER(C.c_double)
@@ -78,9 +81,11 @@ SYMBOLS = [
     ("sbo_comm_unique_id", C.c_int, [_P]),
     ("sbo_comm_init", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("sbo_comm_barrier", C.c_int, [_P]),
+    ("sbo_comm_init_relay", C.c_int, [_P, C.c_int, C.c_int, RELAY_ALLREDUCE, RELAY_ALLGATHER, _P]),
     ("sbo_model_set", C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("sbo_candidates_points", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_int64]),
     ("sbo_candidates_grid", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int64, C.c_int64]),
+    ("sbo_candidates_grid_sharded", C.c_int, [_P, C.c_int, _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("sbo_posterior_run", C.c_int, [_P]),
     ("sbo_posterior_get", C.c_int, [_P, _P, _P]),
     ("sbo_bounds", C.c_int, [_P, C.c_double, C.c_int, C.c_int, _P]),

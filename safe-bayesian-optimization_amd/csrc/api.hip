@@ -164,7 +164,7 @@ int sbo_shutdown(sbo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->Lmax, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->scal, &c->partial, &c->amb})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->scal, &c->partial, &c->amb, &c->Ufull, &c->gather, &c->xch, &c->shard_first})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -308,6 +308,8 @@ int sbo_candidates_points(sbo_ctx* c, const void* points, int points_dtype, int6
   memset(&c->cs, 0, sizeof(c->cs));
   c->cs.kind = 0; c->cs.d = d; c->cs.pts_dtype = points_dtype; c->cs.pts = c->pts.p;
   c->cs.n_local = n_local; c->cs.first = first;
+  c->grid_total = n_local;
+  c->sharded = false;
   c->has_cand = true;
   c->posterior_valid = false;
   c->masks_valid = false;
@@ -333,9 +335,36 @@ int sbo_candidates_grid(sbo_ctx* c, int d, const double* lo, const double* hi, c
     c->cs.step[a] = count[a] > 1 ? (hi[a] - lo[a]) / (double)(count[a] - 1) : 0.0;
   }
   for (int a = d; a < kMaxD; ++a) c->cs.count[a] = 1;
+  c->grid_total = (long long)total;
+  c->sharded = false;
   c->has_cand = true;
   c->posterior_valid = false;
   c->masks_valid = false;
+  return SBO_OK;
+}
+
+int sbo_candidates_grid_sharded(sbo_ctx* c, int d, const double* lo, const double* hi, const int64_t* count,
+                                int64_t* first_out, int64_t* n_local_out) {
+  if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
+  if (d < 1 || d > SBO_MAX_D || !lo || !hi || !count) return fail(SBO_E_INVALID, "bad grid description");
+  long long stride = 1;
+  for (int a = 0; a < d - 1; ++a) {
+    if (count[a] < 1) return fail(SBO_E_INVALID, "grid count must be >= 1");
+    stride *= count[a];
+  }
+  if (count[d - 1] < 1) return fail(SBO_E_INVALID, "grid count must be >= 1");
+  const long long planes = count[d - 1];
+  const int W = c->world, r = c->rank;
+  std::vector<long long> first_of(W + 1);
+  for (int i = 0; i <= W; ++i) first_of[i] = (planes * i / W) * stride;
+  int rc = sbo_candidates_grid(c, d, lo, hi, count, first_of[r], first_of[r + 1] - first_of[r]);
+  if (rc) return rc;
+  c->first_of = first_of;
+  c->sharded = true;
+  if ((rc = ensure(c->shard_first, sizeof(long long) * (W + 1)))) return rc;
+  SBO_HIP(hipMemcpy(c->shard_first.p, first_of.data(), sizeof(long long) * (W + 1), hipMemcpyHostToDevice));
+  if (first_out) *first_out = first_of[r];
+  if (n_local_out) *n_local_out = first_of[r + 1] - first_of[r];
   return SBO_OK;
 }
 

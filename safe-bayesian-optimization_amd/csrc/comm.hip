@@ -2,6 +2,7 @@
 // The reference has no communication layer at all; these collectives exist only
 // because the candidate set is sharded across the GPUs of a node.
 #include <cstring>
+#include <vector>
 #include <rccl/rccl.h>
 #include "internal.hpp"
 
@@ -15,29 +16,49 @@ static int nccl_fail(ncclResult_t r, const char* what) {
     if (r__ != ncclSuccess) return sbo::nccl_fail(r__, #x); \
   } while (0)
 
+// host-staged collective for the rehearsal transport
+static int relay_reduce(sbo_ctx* c, void* dev, size_t count, int elem, int op) {
+  std::vector<unsigned char> h(count * 8);
+  SBO_HIP(hipMemcpyAsync(h.data(), dev, h.size(), hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  if (c->relay_allreduce(c->relay_user, h.data(), (int64_t)count, elem, op) != 0)
+    return fail(SBO_E_COMM, "relay all-reduce callback failed");
+  SBO_HIP(hipMemcpyAsync(dev, h.data(), h.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  return SBO_OK;
+}
+
 // in-place all-reduce helpers used by the sweeps (no-ops for a single rank)
 int comm_allreduce_max_u64(sbo_ctx* c, unsigned long long* dev, int count) {
   if (c->world <= 1) return SBO_OK;
+  if (!c->comm) return relay_reduce(c, dev, count, 0, 1);
   SBO_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclMax, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
 int comm_allreduce_min_u64(sbo_ctx* c, unsigned long long* dev, int count) {
   if (c->world <= 1) return SBO_OK;
+  if (!c->comm) return relay_reduce(c, dev, count, 0, 2);
   SBO_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclMin, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
 int comm_allreduce_sum_f64(sbo_ctx* c, double* dev, int count) {
   if (c->world <= 1) return SBO_OK;
+  if (!c->comm) return relay_reduce(c, dev, count, 1, 0);
   SBO_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
-  return SBO_OK;
-}
-int comm_allreduce_sum_i64(sbo_ctx* c, long long* dev, int count) {
-  if (c->world <= 1) return SBO_OK;
-  SBO_NCCL(ncclAllReduce(dev, dev, count, ncclInt64, ncclSum, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
 int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_per_rank) {
   if (c->world <= 1) return SBO_OK;
+  if (!c->comm) {
+    std::vector<unsigned char> hs(bytes_per_rank), hr(bytes_per_rank * c->world);
+    SBO_HIP(hipMemcpyAsync(hs.data(), send, hs.size(), hipMemcpyDeviceToHost, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+    if (c->relay_allgather(c->relay_user, hs.data(), hr.data(), (int64_t)bytes_per_rank) != 0)
+      return fail(SBO_E_COMM, "relay all-gather callback failed");
+    SBO_HIP(hipMemcpyAsync(recv, hr.data(), hr.size(), hipMemcpyHostToDevice, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+    return SBO_OK;
+  }
   SBO_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclUint8, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
@@ -74,10 +95,24 @@ int sbo_comm_init(sbo_ctx* c, int world_size, int rank, const void* id) {
   return SBO_OK;
 }
 
+int sbo_comm_init_relay(sbo_ctx* c, int world_size, int rank, sbo_relay_allreduce_fn allreduce,
+                        sbo_relay_allgather_fn allgather, void* user) {
+  if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
+  if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SBO_E_INVALID, "bad world_size / rank");
+  if (c->comm) return fail(SBO_E_INVALID, "communicator already initialised");
+  if (world_size > 1 && (!allreduce || !allgather)) return fail(SBO_E_INVALID, "relay callbacks are NULL");
+  c->world = world_size;
+  c->rank = rank;
+  c->relay_allreduce = allreduce;
+  c->relay_allgather = allgather;
+  c->relay_user = user;
+  return SBO_OK;
+}
+
 int sbo_comm_barrier(sbo_ctx* c) {
   if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
   if (c->world > 1) {
-    int rc = comm_allreduce_sum_i64(c, (long long*)c->scal.p + 500, 1);
+    int rc = comm_allreduce_sum_f64(c, (double*)c->scal.p + 500, 1);
     if (rc) return rc;
   }
   SBO_HIP(hipStreamSynchronize(c->stream));

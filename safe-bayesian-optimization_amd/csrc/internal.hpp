@@ -72,6 +72,13 @@ struct sbo_ctx {
   sbo::DevBuf scal;    // small device scalar block (keys, counters, arg-reduce results)
   sbo::DevBuf partial; // arg-reduce per-block partials
   sbo::DevBuf amb;     // ambiguous-index list for the exact recheck
+  sbo::DevBuf Ufull;   // multi-rank: U mask of the whole grid (all-gathered), uint8 [grid_total]
+  sbo::DevBuf gather;  // multi-rank: all-gather receive buffer [world][max_local]
+  sbo::DevBuf xch;     // multi-rank: small exchange buffers (C1 keys, C3 rows)
+  sbo::DevBuf shard_first;  // device copy of first_of[]
+  long long grid_total = 0; // candidates in the whole grid (all ranks)
+  bool sharded = false;     // candidates were set with the canonical plane sharding
+  std::vector<long long> first_of;   // [world + 1] flat offsets of the rank shards
   int last_sweep = 0;  // 1 safeopt, 2 goose (what the masks hold)
   bool masks_valid = false;
   // profile
@@ -82,6 +89,10 @@ struct sbo_ctx {
   // comm
   void* comm = nullptr;  // ncclComm_t
   int world = 1, rank = 0;
+  // rehearsal transport (tests on a 1-GPU box): collectives staged through host callbacks instead of RCCL
+  sbo_relay_allreduce_fn relay_allreduce = nullptr;
+  sbo_relay_allgather_fn relay_allgather = nullptr;
+  void* relay_user = nullptr;
 };
 
 namespace sbo {

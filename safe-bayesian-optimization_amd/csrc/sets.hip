@@ -22,7 +22,6 @@ namespace sbo {
 int comm_allreduce_max_u64(sbo_ctx* c, unsigned long long* dev, int count);
 int comm_allreduce_min_u64(sbo_ctx* c, unsigned long long* dev, int count);
 int comm_allreduce_sum_f64(sbo_ctx* c, double* dev, int count);
-int comm_allreduce_sum_i64(sbo_ctx* c, long long* dev, int count);
 int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_per_rank);
 
 constexpr double kInfD = 1.0e300;
@@ -327,7 +326,8 @@ __device__ __forceinline__ bool lipschitz_pair(const double (&xg)[D], const doub
 // last axis + decision.  For g in S: nearest-U distance dm (unshifted) -> G bit, or the ambiguous list when
 // ucb - L dm lies inside the band the "+1e-8" shift and rounding can move it across zero.
 template <typename T>
-__global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ Din, long long n, long long stride, int cnt,
+__global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ Din, long long n, long long goff,
+                                                    long long stride, int cnt,
                                                     double h, int d, double xscale, const T* __restrict__ mean_c,
                                                     const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
@@ -345,8 +345,9 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
       } else {
         const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
         const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
-        const int ia = (int)((g / stride) % cnt);
-        const double best = (cnt > 1) ? edt_scan_point(Din, g, stride, cnt, ia, h, cap) : Din[g];
+        const long long gg = goff + g;   // index in the transform (whole grid when ranks share it)
+        const int ia = (int)((gg / stride) % cnt);
+        const double best = (cnt > 1) ? edt_scan_point(Din, gg, stride, cnt, ia, h, cap) : Din[gg];
         if (best < 0.5 * kInfD) {
           const double dm = sqrt(best);
           const double eps = eps_abs + 1e-11 * dm;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void k_list_safe(const uint8_t* __restrict__ S
 
 // exhaustive evaluation of the reference predicate for the listed g: one workgroup per g, all U points
 template <typename T, int D>
-__global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const T* __restrict__ mean_c,
+__global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const CandSpec csU, const T* __restrict__ mean_c,
                                                         const T* __restrict__ var_c, T b, const uint8_t* __restrict__ U,
                                                         const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
                                                         const long long* __restrict__ amb, uint8_t* __restrict__ G) {
@@ -392,10 +393,10 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
     double xg[D];
     cand_coords<D>(cs, g, xg);
     int found = 0;
-    for (long long hh = threadIdx.x; hh < cs.n_local && !found; hh += blockDim.x) {
+    for (long long hh = threadIdx.x; hh < csU.n_local && !found; hh += blockDim.x) {
       if (U[hh]) {
         double xh[D];
-        cand_coords<D>(cs, hh, xh);
+        cand_coords<D>(csU, hh, xh);
         if (lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
       }
     }
@@ -409,6 +410,45 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
 }
 
 __global__ void k_reset_amb(SweepScalars* sc) { sc->n_amb = 0; }
+
+// ---- multi-rank exchange -----------------------------------------------------------
+// C1: one max all-reduce of [~u*_key, L keys, radius keys]
+__global__ void k_pack_c1(const SweepScalars* sc, const unsigned long long* Lkeys, unsigned long long* buf) {
+  const int t = threadIdx.x;
+  if (t == 0) buf[0] = ~sc->ustar_key;
+  if (t < kMaxQ) { buf[1 + t] = Lkeys[t]; buf[1 + kMaxQ + t] = sc->rmax_key[t]; }
+}
+__global__ void k_unpack_c1(SweepScalars* sc, unsigned long long* Lkeys, const unsigned long long* buf) {
+  const int t = threadIdx.x;
+  if (t == 0) sc->ustar_key = ~buf[0];
+  if (t < kMaxQ) { Lkeys[t] = buf[1 + t]; sc->rmax_key[t] = buf[1 + kMaxQ + t]; }
+}
+// C2: all-gathered padded shards -> contiguous whole-grid mask
+__global__ __launch_bounds__(256) void k_compact_shards(const uint8_t* __restrict__ recv, long long maxlocal, int world,
+                                                        const long long* __restrict__ first_of, long long total,
+                                                        uint8_t* __restrict__ full) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    int r = 0;
+    while (r + 1 < world && g >= first_of[r + 1]) ++r;
+    full[g] = recv[(size_t)r * maxlocal + (g - first_of[r])];
+  }
+}
+// C3: each rank fills its own row of [world][kC3Row] doubles, one sum all-reduce delivers every row everywhere
+constexpr int kC3Row = 2 * kArgSlots + 4 + kMaxQ;
+__global__ void k_pack_c3(const SweepScalars* sc, double* buf, int world, int rank) {
+  for (int i = threadIdx.x; i < world * kC3Row; i += blockDim.x) buf[i] = 0.0;
+  __syncthreads();
+  double* row = buf + (size_t)rank * kC3Row;
+  const int t = threadIdx.x;
+  if (t < kArgSlots) { row[t] = sc->arg_idx[t] >= 0 ? sc->arg_val[t] : 0.0; row[kArgSlots + t] = (double)sc->arg_idx[t]; }
+  if (t == 0) {
+    row[2 * kArgSlots + 0] = (double)sc->count_S;
+    row[2 * kArgSlots + 1] = (double)sc->count_U;
+    row[2 * kArgSlots + 2] = (double)sc->count_M;
+    row[2 * kArgSlots + 3] = (double)sc->n_amb_total;
+  }
+  if (t < kMaxQ) row[2 * kArgSlots + 4 + t] = (double)sc->count_set[t];
+}
 __global__ void k_init_scalars(SweepScalars* sc) {
   if (threadIdx.x == 0) sc->ustar_key = ~0ull;
   if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
@@ -448,8 +488,15 @@ static int launch_exact(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lidx,
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const T* mean_c = (const T*)c->mean.p + (size_t)cidx * n;
   const T* var_c = (const T*)c->var.p + (size_t)cidx * n;
-  hipLaunchKernelGGL((k_expander_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, mean_c, var_c, (T)o->b,
-                     (const uint8_t*)c->maskU.p, (const unsigned long long*)c->Lmax.p, lidx, sc,
+  CandSpec csU = c->cs;          // the witness set: every candidate of every rank
+  const uint8_t* Uall = (const uint8_t*)c->maskU.p;
+  if (c->world > 1) {
+    csU.first = 0;
+    csU.n_local = c->grid_total;
+    Uall = (const uint8_t*)c->Ufull.p;
+  }
+  hipLaunchKernelGGL((k_expander_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, csU, mean_c, var_c, (T)o->b,
+                     Uall, (const unsigned long long*)c->Lmax.p, lidx, sc,
                      (const long long*)c->amb.p, G);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
@@ -481,20 +528,22 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
   hipLaunchKernelGGL(k_reset_amb, dim3(1), dim3(1), 0, c->stream, sc);
   if (c->cs.kind == 1) {
     const int d = c->cs.d;
-    if ((rc = ensure(c->dist2, sizeof(double) * (size_t)n))) return rc;
-    if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)n))) return rc;
-    hipLaunchKernelGGL((k_rmax<T>), dim3(nb), dim3(256), 0, c->stream, mean_c, var_c, n, (T)o->b,
-                       (const uint8_t*)c->maskS.p, sc, cidx);
+    // ranks > 1: every rank transforms the all-gathered U mask of the whole grid (witnesses cross shards)
+    const long long nt = c->world > 1 ? c->grid_total : n;
+    const long long goff = c->world > 1 ? c->cs.first : 0;
+    const uint8_t* Uall = c->world > 1 ? (const uint8_t*)c->Ufull.p : (const uint8_t*)c->maskU.p;
+    if ((rc = ensure(c->dist2, sizeof(double) * (size_t)nt))) return rc;
+    if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)nt))) return rc;
     const int count0 = (int)c->cs.count[0];
-    const long long nlines = n / count0;
-    hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, c->stream,
-                       (const uint8_t*)c->maskU.p, nlines, count0, c->cs.step[0], (double*)c->dist2.p);
+    const long long nlines = nt / count0;
+    hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, c->stream, Uall, nlines, count0,
+                       c->cs.step[0], (double*)c->dist2.p);
     double* din = (double*)c->dist2.p;
     double* dout = (double*)c->dist2b.p;
     long long stride = count0;
     for (int a = 1; a < d - 1; ++a) {
-      hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
-                         (const double*)din, dout, n, stride, (int)c->cs.count[a], c->cs.step[a],
+      hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nt + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+                         (const double*)din, dout, nt, stride, (int)c->cs.count[a], c->cs.step[a],
                          (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx);
       std::swap(din, dout);
       stride *= c->cs.count[a];
@@ -504,12 +553,14 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     const int last_cnt = d >= 2 ? (int)c->cs.count[d - 1] : 1;
     const double last_h = d >= 2 ? c->cs.step[d - 1] : 0.0;
     hipLaunchKernelGGL((k_edt_decide<T>), dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0,
-                       c->stream, (const double*)din, n, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c, (T)o->b,
-                       (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
+                       c->stream, (const double*)din, n, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c,
+                       (T)o->b, (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
                        (long long*)c->amb.p);
   } else {
     if (n > (1ll << 17))
       return fail(SBO_E_UNSUPPORTED, "expander sets on explicit candidate lists are exhaustive: N <= 131072");
+    if (c->world > 1)
+      return fail(SBO_E_UNSUPPORTED, "expander sets on explicit candidate lists are single-rank");
     hipLaunchKernelGGL(k_list_safe, dim3(nb), dim3(256), 0, c->stream, (const uint8_t*)c->maskS.p, n, sc, G,
                        (long long*)c->amb.p);
   }
@@ -544,6 +595,80 @@ static void coords_of(const sbo_ctx* c, long long gidx, double* x) {
 
 int sbo_posterior_enqueue_(sbo_ctx* c);
 
+// rmax per constraint, then (ranks > 1) C1: global u*, L and radius keys; C2: whole-grid U mask
+template <typename T>
+static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U) {
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q;
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
+  const int nb = reduce_blocks(c);
+  for (int cc = 1; cc < q && n > 0; ++cc)
+    hipLaunchKernelGGL((k_rmax<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p + (size_t)cc * n,
+                       (const T*)c->var.p + (size_t)cc * n, n, (T)o->b, (const uint8_t*)c->maskS.p, sc, cc);
+  SBO_HIP(hipGetLastError());
+  if (c->world <= 1) return SBO_OK;
+  int rc;
+  if (!c->sharded && q > 1 && need_U)
+    return fail(SBO_E_INVALID, "multi-rank sweeps with constraints need sbo_candidates_grid_sharded");
+  if ((rc = ensure(c->xch, sizeof(double) * (size_t)(c->world * kC3Row + 64)))) return rc;
+  unsigned long long* kb = (unsigned long long*)c->xch.p;
+  hipLaunchKernelGGL(k_pack_c1, dim3(1), dim3(64), 0, c->stream, (const SweepScalars*)sc, (const unsigned long long*)c->Lmax.p, kb);
+  if ((rc = comm_allreduce_max_u64(c, kb, 1 + 2 * kMaxQ))) return rc;
+  hipLaunchKernelGGL(k_unpack_c1, dim3(1), dim3(64), 0, c->stream, sc, (unsigned long long*)c->Lmax.p, (const unsigned long long*)kb);
+  if (need_U && q > 1) {
+    long long maxlocal = 0;
+    for (int r = 0; r < c->world; ++r) maxlocal = std::max(maxlocal, c->first_of[r + 1] - c->first_of[r]);
+    if ((rc = ensure(c->gather, (size_t)maxlocal * c->world))) return rc;
+    if ((rc = ensure(c->Ufull, (size_t)c->grid_total))) return rc;
+    // send buffer: own U mask padded to maxlocal (maskU is allocated >= n; the tail is never compacted)
+    if ((rc = ensure(c->maskU, (size_t)maxlocal))) return rc;
+    if ((rc = comm_allgather_bytes(c, c->maskU.p, c->gather.p, (size_t)maxlocal))) return rc;
+    hipLaunchKernelGGL(k_compact_shards, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
+                       c->stream, (const uint8_t*)c->gather.p, maxlocal, c->world, (const long long*)c->shard_first.p,
+                       c->grid_total, (uint8_t*)c->Ufull.p);
+  }
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+// C3 + host merge: every rank's slots and counters -> global ones.  slot_is_max[i] selects arg-max / arg-min.
+static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_max) {
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
+  if (c->world <= 1) {
+    SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+    return SBO_OK;
+  }
+  double* buf = (double*)c->xch.p + 64;
+  hipLaunchKernelGGL(k_pack_c3, dim3(1), dim3(256), 0, c->stream, (const SweepScalars*)sc, buf, c->world, c->rank);
+  int rc;
+  if ((rc = comm_allreduce_sum_f64(c, buf, c->world * kC3Row))) return rc;
+  std::vector<double> rows((size_t)c->world * kC3Row);
+  SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipMemcpyAsync(rows.data(), buf, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  h.count_S = h.count_U = h.count_M = h.n_amb_total = 0;
+  for (int t = 0; t < kMaxQ; ++t) h.count_set[t] = 0;
+  for (int t = 0; t < kArgSlots; ++t) { h.arg_idx[t] = -1; h.arg_val[t] = 0.0; }
+  for (int r = 0; r < c->world; ++r) {
+    const double* row = &rows[(size_t)r * kC3Row];
+    for (int t = 0; t < kArgSlots; ++t) {
+      const long long idx = (long long)row[kArgSlots + t];
+      if (idx < 0) continue;
+      const double v = row[t];
+      const bool mx = slot_is_max[t];
+      const bool take = h.arg_idx[t] < 0 || (mx ? v > h.arg_val[t] : v < h.arg_val[t]) || (v == h.arg_val[t] && idx < h.arg_idx[t]);
+      if (take) { h.arg_val[t] = v; h.arg_idx[t] = idx; }
+    }
+    h.count_S += (long long)row[2 * kArgSlots + 0];
+    h.count_U += (long long)row[2 * kArgSlots + 1];
+    h.count_M += (long long)row[2 * kArgSlots + 2];
+    h.n_amb_total += (long long)row[2 * kArgSlots + 3];
+    for (int t = 0; t < kMaxQ; ++t) h.count_set[t] += (long long)row[2 * kArgSlots + 4 + t];
+  }
+  return SBO_OK;
+}
+
 template <typename T>
 static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_result* res) {
   const long long n = c->cs.n_local;
@@ -554,6 +679,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   if ((rc = sweep_common_front<T>(c, o))) return rc;
+  if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
   if (n > 0)
@@ -576,10 +702,12 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
                        sc, cc);
   }
   SBO_HIP(hipGetLastError());
-  SBO_HIP(hipEventRecord(c->ev[4], c->stream));
   SweepScalars h;
+  bool is_max[kArgSlots];
+  for (int t = 0; t < kArgSlots; ++t) is_max[t] = true;
+  if ((rc = sweep_exchange_back(c, h, is_max))) return rc;
+  SBO_HIP(hipEventRecord(c->ev[4], c->stream));
   unsigned long long Lk[kMaxQ];
-  SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipMemcpyAsync(Lk, c->Lmax.p, sizeof(Lk), hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
   c->masks_valid = true;
@@ -657,7 +785,6 @@ int sbo_sweep_safeopt(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_safeopt_result
   if (!c->has_model) return fail(SBO_E_NO_MODEL, "sbo_model_set has not been called");
   if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
-  if (c->world > 1) return fail(SBO_E_UNSUPPORTED, "multi-rank sweep not built yet");
   SBO_HIP(hipSetDevice(c->device));
   return c->dtype == SBO_F64 ? sweep_safeopt_t<double>(c, opts, result) : sweep_safeopt_t<float>(c, opts, result);
 }

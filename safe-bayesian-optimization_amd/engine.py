@@ -130,6 +130,17 @@ class SweepEngine:
                                               int(n_local)))
         self.n_local, self.first = int(n_local), int(first)
 
+    def set_grid_sharded(self, lo, hi, count):
+        """Grid sharded over the communicator's ranks by hyper-planes of the slowest axis."""
+        lo, hi = _f64(lo), _f64(hi)
+        cnt = np.ascontiguousarray(np.asarray(count, dtype=np.int64))
+        if not (lo.shape == hi.shape == cnt.shape) or lo.ndim != 1:
+            raise ValueError("lo, hi, count must be 1-D of equal length")
+        first, nloc = C.c_int64(), C.c_int64()
+        L.check(self._lib.sbo_candidates_grid_sharded(self._ctx, lo.shape[0], _ptr(lo), _ptr(hi), _ptr(cnt),
+                                                      C.byref(first), C.byref(nloc)))
+        self.n_local, self.first = int(nloc.value), int(first.value)
+
     # ---- hot path ----------------------------------------------------------------------------
     def posterior_run(self):
         L.check(self._lib.sbo_posterior_run(self._ctx))

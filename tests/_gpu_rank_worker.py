@@ -1,0 +1,39 @@
+"""Worker for the 2-rank GPU rehearsal in tests/test_gpu_parity.py: both ranks drive the single GPU of the
+test box (RCCL refuses duplicate devices, so the collectives ride the gloo relay transport); the sweep code
+path -- shard offsets, whole-grid U mask, exchange kernels, host merge -- is the multi-GPU one."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out_path, cfg_name, n, count, b = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4],
+                                                          sys.argv[5], int(sys.argv[6]), json.loads(sys.argv[7]), float(sys.argv[8]))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    import safebo_amd
+    from safebo_amd import synthetic, distributed
+
+    dist = distributed.init_gloo_from_env()
+    cfg = synthetic.make_config(cfg_name, n=n)
+    eng = safebo_amd.SweepEngine(0)
+    distributed.join(eng, relay=True)
+    eng.set_model(cfg["ds"], dtype="f64")
+    eng.set_grid_sharded(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    res = eng.sweep_safeopt(b, want_masks=True)
+    masks = {k: eng.mask(k) for k in ("S", "U", "M")}
+    masks.update({f"G{c}": eng.mask("G", c) for c in range(1, cfg["q"])})
+    np.savez(out_path + f".rank{rank}.npz", first=eng.first, n_local=eng.n_local, **masks)
+    if rank == 0:
+        json.dump({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in res.items()}, open(out_path, "w"))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

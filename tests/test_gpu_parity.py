@@ -1,0 +1,277 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path behind the C ABI against the NumPy oracle and
+the committed golden fixtures.  Tolerances: posterior mean/variance within 1e-10 (fp64) / 1e-4 (fp32) in
+normalised units (mean / max(1, Y_std), var / max(1, Y_std)^2 -- the reference's GP works on normalised outputs,
+models/GP_Safe.py:92-94, 346-347); masks and arg-max indices bit-exact."""
+import glob
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+import safebo_amd
+from safebo_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+TOL64, TOL32 = 1e-10, 1e-4
+
+
+def _nerr(got, ref, ystd, power):
+    return float(np.max(np.abs(got - ref) / np.maximum(1.0, ystd) ** power))
+
+
+def _check_posterior(eng, ds, pts, tol, dtype="f64"):
+    mean, var = eng.posterior()
+    om, ov = oracle.gp_inference(pts, ds)
+    assert mean.shape == om.shape and var.shape == ov.shape
+    assert mean.dtype == (np.float64 if dtype == "f64" else np.float32)
+    em, ev = _nerr(mean, om, ds["Y_std"], 1), _nerr(var, ov, ds["Y_std"], 2)
+    assert em < tol and ev < tol, (em, ev)
+    return mean, var
+
+
+# ---------------------------------------------------------------------------------------------- posterior
+@pytest.mark.parametrize("cfg_name,n,count", [
+    ("A", 20, [50, 50]), ("A", 4, [40, 40]), ("A", 2, [9, 7]), ("B", 128, [96, 64]), ("B", 100, [70, 33]),
+    ("B", 17, [33, 5]), ("C", 256, [64, 48]), ("H", 512, [64, 32]), ("H", 300, [31, 17]), ("D", 128, [9, 8, 7, 6]),
+])
+@pytest.mark.parametrize("use_invK", [True, False])
+def test_posterior_fp64_grid(engine, cfg_name, n, count, use_invK):
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    engine.set_model(cfg["ds"], dtype="f64", use_invK=use_invK)
+    engine.set_grid(lo, hi, count)
+    _check_posterior(engine, cfg["ds"], oracle.grid_points(lo, hi, count), TOL64)
+
+
+@pytest.mark.parametrize("d,q,n", [(1, 1, 9), (3, 2, 40), (5, 3, 64), (6, 1, 200), (8, 2, 33)])
+def test_posterior_fp64_scattered_points_any_dimension(engine, d, q, n):
+    rng = np.random.default_rng(100 + d)
+    X = rng.uniform(-1, 1, size=(n, d))
+    Y = np.stack([np.sin(X.sum(1) * (i + 1)) + 0.5 * X[:, 0] for i in range(q)], axis=1)
+    hyp = synthetic.default_hypopt(d, q) + rng.uniform(-0.2, 0.2, size=(d + 2, q)) * np.r_[np.ones(d + 1), 0][:, None]
+    ds = synthetic.make_dataset(X, Y, hyp)
+    pts = rng.uniform(-1.3, 1.3, size=(777, d))
+    engine.set_model(ds, dtype="f64")
+    engine.set_points(pts)
+    _check_posterior(engine, ds, pts, TOL64)
+
+
+def test_posterior_fp32(engine):
+    cfg = synthetic.make_config("B", n=128)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, [96, 64])
+    engine.set_model(cfg["ds"], dtype="f32", use_invK=False)      # fp32: contract with L^-1 (no cancellation)
+    engine.set_grid(lo, hi, [96, 64])
+    _check_posterior(engine, cfg["ds"], pts, TOL32, dtype="f32")
+    engine.set_points(pts.astype(np.float32))
+    _check_posterior(engine, cfg["ds"], pts.astype(np.float32).astype(np.float64), TOL32, dtype="f32")
+
+
+def test_posterior_fp32_large_n_scattered(engine):
+    cfg = synthetic.make_config("E", n=2048)
+    pts = synthetic.scattered_points(cfg, 4096)
+    engine.set_model(cfg["ds"], dtype="f32", use_invK=False)
+    engine.set_points(pts)
+    _check_posterior(engine, cfg["ds"], pts.astype(np.float64), TOL32, dtype="f32")
+
+
+def test_grid_equals_explicit_points_bitwise(engine):
+    cfg = synthetic.make_config("B", n=128)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, [61, 47])
+    m1, v1 = engine.posterior()
+    engine.set_points(oracle.grid_points(lo, hi, [61, 47]))
+    m2, v2 = engine.posterior()
+    assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
+
+
+def test_shard_ranges_reproduce_the_whole_grid_bitwise(engine):
+    cfg = synthetic.make_config("B", n=128)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, [64, 50])
+    m, v = engine.posterior()
+    for first, nloc in [(0, 1), (0, 1000), (1000, 2200), (3199, 1), (37, 64)]:
+        engine.set_grid(lo, hi, [64, 50], first=first, n_local=nloc)
+        ms, vs = engine.posterior()
+        assert np.array_equal(ms, m[first:first + nloc]) and np.array_equal(vs, v[first:first + nloc])
+    engine.set_grid(lo, hi, [64, 50], first=5, n_local=0)       # empty shard
+    ms, vs = engine.posterior()
+    assert ms.shape == (0, 2)
+
+
+def test_bounds_match_oracle(engine):
+    cfg = synthetic.make_config("C", n=64)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, [40, 30])
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, [40, 30])
+    mean, var = engine.posterior()
+    lcb, ucb = oracle.bounds(mean, var, 2.0)          # same unfused arithmetic on the device values: bit-exact
+    for i in range(3):
+        assert np.array_equal(engine.bounds(2.0, i, "lcb"), lcb[:, i])
+        assert np.array_equal(engine.bounds(2.0, i, "ucb"), ucb[:, i])
+        assert np.array_equal(engine.bounds(2.0, i, "mean"), mean[:, i])
+    # the plot mask of test/test_SafeOpt.py:337-338: vmap(lcb)(points, 1) > 0.
+    om, ov = oracle.gp_inference(pts, cfg["ds"])
+    assert np.array_equal(engine.bounds(2.0, 1, "lcb") > 0.0, oracle.bounds(om, ov, 2.0)[0][:, 1] > 0.0)
+
+
+# ---------------------------------------------------------------------------------------------- error behaviour
+def test_errors_follow_reference_style(engine):
+    cfg = synthetic.make_config("A")
+    with pytest.raises(ValueError, match="no kernel with name"):
+        engine.set_model(cfg["ds"], kernel="Matern")            # models/GP_Safe.py:161-162
+    engine.set_model(cfg["ds"])
+    engine.set_points(np.zeros((5, 3)))
+    with pytest.raises(ValueError, match="dimension should be same"):
+        engine.posterior()                                      # models/GP_Safe.py:159-160
+    bad = dict(cfg["ds"])
+    bad["hypopt"] = np.zeros((3, 2))
+    with pytest.raises(ValueError):
+        engine.set_model(bad)
+    with pytest.raises(ValueError):
+        engine.set_grid([0, 0], [1, 1], [0, 4])
+    fresh = safebo_amd.SweepEngine(0)
+    with pytest.raises(safebo_amd.SafeBOError):
+        fresh.posterior_run()                                   # no model yet
+    fresh.close()
+
+
+def test_empty_safe_set_is_reported(engine):
+    cfg = synthetic.make_config("D", n=40)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, [6, 5, 4, 3])
+    assert oracle.safeopt_sweep(pts, cfg["ds"], 3.0)["empty_safe_set"]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, [6, 5, 4, 3])
+    with pytest.raises(safebo_amd.EmptySafeSetError):
+        engine.sweep_safeopt(3.0)
+
+
+# ---------------------------------------------------------------------------------------------- sweeps
+def _check_safeopt(eng, ref, q):
+    for k in ("S", "U", "M"):
+        assert np.array_equal(eng.mask(k), ref[k]), k
+    for c in range(1, q):
+        assert np.array_equal(eng.mask("G", c), ref["G"][c - 1]), f"G{c}"
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_safeopt_sweep_against_golden(engine, path):
+    z = np.load(path)
+    ds = synthetic.make_dataset(z["X"], z["Y"], z["hypopt"])
+    lo, hi, count = z["bound"][:, 0], z["bound"][:, 1], [int(c) for c in z["count"]]
+    q = z["Y"].shape[1]
+    engine.set_model(ds)
+    engine.set_grid(lo, hi, count)
+    mean, var = engine.posterior()
+    assert _nerr(mean, z["mean"], ds["Y_std"], 1) < TOL64 and _nerr(var, z["var"], ds["Y_std"], 2) < TOL64
+    res = engine.sweep_safeopt(float(z["b"]), quirk_L_index=bool(z["quirk"]), want_masks=True, posterior_ready=True)
+    _check_safeopt(engine, {k: z[k] for k in ("S", "U", "M", "G")}, q)
+    assert res["minimizer_index"] == int(z["minimizer_index"])
+    assert abs(res["minimizer_std"] - float(z["minimizer_std"])) < 1e-9 * max(1.0, float(z["minimizer_std"]))
+    assert np.array_equal(res["expander_index_c"], z["expander_index"])
+    assert res["expander_best_c"] == int(z["expander_best"]) and res["choose_minimizer"] == bool(z["choose_minimizer"])
+    assert abs(res["u_star"] - float(z["u_star"])) < 1e-9 * max(1.0, abs(float(z["u_star"])))
+    assert np.allclose(res["L"], z["L"], rtol=1e-9)
+    assert (res["count_S"], res["count_U"], res["count_M"]) == (z["S"].sum(), z["U"].sum(), z["M"].sum())
+    assert np.array_equal(res["count_G"], z["G"].sum(1))
+    pts = oracle.grid_points(lo, hi, count)
+    assert np.array_equal(res["minimizer_x"], pts[res["minimizer_index"]])
+
+
+def test_safeopt_sweep_explicit_points_exhaustive_expander(engine):
+    cfg = synthetic.make_config("A")
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, [50, 50])
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"])
+    engine.set_model(cfg["ds"])
+    engine.set_points(pts)
+    res = engine.sweep_safeopt(cfg["b"], want_masks=True)
+    _check_safeopt(engine, ref, 2)
+    assert res["minimizer_index"] == ref["minimizer_index"]
+    assert res["n_exact_rechecks"] == ref["S"].sum()
+
+
+def test_safeopt_single_output_has_no_constraints(engine):
+    cfg = synthetic.make_config("E", n=64)
+    pts = synthetic.scattered_points(cfg, 5000, dtype=np.float64)
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], 2.0)
+    engine.set_model(cfg["ds"])
+    engine.set_points(pts)
+    res = engine.sweep_safeopt(2.0, want_masks=True)
+    assert ref["S"].all() and np.array_equal(engine.mask("M"), ref["M"])
+    assert res["minimizer_index"] == ref["minimizer_index"] and res["expander_best_c"] == 0
+
+
+def test_full_size_properties_config_B(engine):
+    """BASELINE.json configs[1] at full size (2048^2, n = 128): properties that do not need the whole oracle."""
+    cfg = synthetic.make_config("B")
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], cfg["count"]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    res = engine.sweep_safeopt(cfg["b"], want_masks=True)
+    N = count[0] * count[1]
+    lcb1, lcb0, ucb0, var0 = (engine.bounds(cfg["b"], 1, "lcb"), engine.bounds(cfg["b"], 0, "lcb"),
+                              engine.bounds(cfg["b"], 0, "ucb"), engine.bounds(cfg["b"], 0, "var"))
+    S, U, M, G = engine.mask("S"), engine.mask("U"), engine.mask("M"), engine.mask("G", 1)
+    assert np.array_equal(S, lcb1 >= 0) and np.array_equal(U, lcb1 <= 0)          # masks follow the bounds bit for bit
+    assert res["u_star"] == ucb0[S].min()
+    assert np.array_equal(M, S & (lcb0 <= res["u_star"]))
+    assert res["minimizer_index"] == int(np.argmax(np.where(M, var0, -np.inf)))
+    assert res["expander_index_c"][0] == int(np.argmax(np.where(G, var0, -np.inf)))
+    assert not (G & ~S).any() and (res["count_S"], res["count_M"], res["count_G"][0]) == (S.sum(), M.sum(), G.sum())
+    # posterior against the oracle on a random subset, and the expander predicate on a random subset of S
+    rng = np.random.default_rng(5)
+    sub = np.sort(rng.choice(N, size=4096, replace=False))
+    pts = oracle.grid_points(lo, hi, count)
+    om, ov = oracle.gp_inference(pts[sub], cfg["ds"])
+    mean, var = engine.posterior()
+    assert _nerr(mean[sub], om, cfg["ds"]["Y_std"], 1) < TOL64 and _nerr(var[sub], ov, cfg["ds"]["Y_std"], 2) < TOL64
+    ucb1 = engine.bounds(cfg["b"], 1, "ucb")
+    xh = pts[U]
+    for g in rng.choice(np.nonzero(S)[0], size=64, replace=False):
+        want = bool(np.any(ucb1[g] - res["L"][1] * oracle.shifted_norm(pts[g][None, :], xh) >= 0))
+        assert bool(G[g]) == want
+    # sweeping again is idempotent, and reusing the posterior gives the same answer
+    res2 = engine.sweep_safeopt(cfg["b"], posterior_ready=True)
+    assert res2["minimizer_index"] == res["minimizer_index"] and np.array_equal(res2["count_G"], res["count_G"])
+
+
+# ---------------------------------------------------------------------------------------------- two ranks, one GPU
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+@pytest.mark.parametrize("cfg_name,n,count,b", [("A", 20, [50, 37], 3.0), ("C", 64, [48, 41], 2.0), ("D", 128, [9, 8, 7, 5], 0.5)])
+def test_two_rank_sweep_on_one_gpu_matches_oracle(tmp_path, cfg_name, n, count, b):
+    port, out = _free_port(), str(tmp_path / "res.json")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), "2", port, out, cfg_name,
+                               str(n), json.dumps(count), str(b)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    res = json.load(open(out))
+    cfg = synthetic.make_config(cfg_name, n=n)
+    pts = oracle.grid_points(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], b)
+    parts = [np.load(out + f".rank{r}.npz") for r in range(2)]
+    assert int(parts[0]["first"]) == 0 and int(parts[1]["first"]) == int(parts[0]["n_local"])
+    for k in ("S", "U", "M"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), ref[k]), k
+    for c in range(1, cfg["q"]):
+        assert np.array_equal(np.concatenate([p[f"G{c}"] for p in parts]), ref["G"][c - 1])
+    assert res["minimizer_index"] == ref["minimizer_index"]
+    assert res["expander_index_c"] == [int(x) for x in ref["expander_index"]]
+    assert res["count_S"] == int(ref["S"].sum()) and res["count_G"] == [int(x) for x in ref["G"].sum(1)]
+    assert res["u_star"] == pytest.approx(ref["u_star"], rel=1e-10)
