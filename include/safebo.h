@@ -57,9 +57,9 @@ enum sbo_dtype { SBO_F64 = 0, SBO_F32 = 1 };
 
 /* which matrix the variance contraction uses */
 enum sbo_factor {
-  SBO_FACTOR_INVK = 0,  /* caller's invK (reference-faithful: models/GP_Safe.py:231-232, 343), folded to
-                           its lower triangle:  k^T invK k = sum_{i>=j} F_ij k_i k_j                       */
-  SBO_FACTOR_CHOL = 1   /* library builds K + (sn2 + float32 eps) I = L L^T itself and contracts with L^-1:
+  SBO_FACTOR_INVK = 0,  /* caller's invK (models/GP_Safe.py:231-232): alpha = invK (y - mp) uses it as given, the
+                           variance uses its triangular factor M (M^T M = invK):  k^T invK k = ||M k||^2        */
+  SBO_FACTOR_CHOL = 1   /* library builds K + (sn2 + float32 eps) I = L L^T itself and contracts with M = L^-1:
                            var = sf2 - || L^-1 k ||^2  (used when invK == NULL)                            */
 };
 

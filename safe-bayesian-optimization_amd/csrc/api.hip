@@ -41,7 +41,26 @@ void release(DevBuf& b) {
 
 int launch_soa_to_aos(sbo_ctx* c, const void* soa, void* aos);
 
-// Host Cholesky L L^T = A (lower, in place) and inverse of L; plain loops, n <= SBO_MAX_N.
+// Host Cholesky L L^T = A (lower, in place); plain loops, n <= SBO_MAX_N.
+static bool cholesky_lower(std::vector<double>& A, int n) {
+  for (int j = 0; j < n; ++j) {
+    double s = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) s -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(s > 0)) return false;
+    const double ljj = std::sqrt(s);
+    A[(size_t)j * n + j] = ljj;
+    for (int i = j + 1; i < n; ++i) {
+      double t = A[(size_t)i * n + j];
+      const double* ai = &A[(size_t)i * n];
+      const double* aj = &A[(size_t)j * n];
+      for (int k = 0; k < j; ++k) t -= ai[k] * aj[k];
+      A[(size_t)i * n + j] = t / ljj;
+    }
+  }
+  return true;
+}
+
+// Cholesky as above plus the inverse of L.
 static bool cholesky_inv(std::vector<double>& A, int n, std::vector<double>& Linv) {
   for (int j = 0; j < n; ++j) {
     double s = A[(size_t)j * n + j];
@@ -88,20 +107,21 @@ static int model_upload(sbo_ctx* c, const std::vector<double>& F_all /* [q][n][n
   const int n = mc.n, nb = mc.npad / 16, q = mc.q;
   const size_t ntri = (size_t)nb * (nb + 1) / 2;
   c->fpk_stride = ntri * 4 * 64;
-  std::vector<double> pk((size_t)q * c->fpk_stride, 0.0);
+  std::vector<double> pk((size_t)q * c->fpk_stride + 512, 0.0);   // + padding: the K1g pipeline over-reads
   for (int o = 0; o < q; ++o) {
     const double* F = &F_all[(size_t)o * n * n];
     double* dst = &pk[(size_t)o * c->fpk_stride];
     for (int I = 0; I < nb; ++I)
       for (int J = 0; J <= I; ++J)
         for (int kk = 0; kk < 4; ++kk)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int row = 16 * I + (lane & 15);
-            const int col = 16 * J + MM<T>::jslot(kk, lane >> 4);
-            double v = 0.0;
-            if (row < n && col < n && col <= row) v = F[(size_t)row * n + col];
-            dst[(((size_t)I * (I + 1) / 2 + J) * 4 + kk) * 64 + lane] = v;
-          }
+          for (int r = 0; r < 16; ++r)
+            for (int k = 0; k < 4; ++k) {
+              const int row = 16 * I + r;
+              const int col = 16 * J + MM<T>::jslot(kk, k);
+              double v = 0.0;
+              if (row < n && col < n && col <= row) v = F[(size_t)row * n + col];
+              dst[(((size_t)I * (I + 1) / 2 + J) * 4 + kk) * 64 + MM<T>::pack_pos(r, k)] = v;
+            }
   }
   int rc;
   if ((rc = upload_vec<T>(c->Fpk, pk, c->stream))) return rc;
@@ -164,7 +184,7 @@ int sbo_shutdown(sbo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->Lmax, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->scal, &c->partial, &c->amb, &c->Ufull, &c->gather, &c->xch, &c->shard_first})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->scal, &c->partial, &c->amb, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -184,6 +204,17 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "fp64_engine")) {
     if (value != 0 && value != 1) return fail(SBO_E_INVALID, "fp64_engine must be 0 (MFMA) or 1 (VALU)");
     c->engine = (int)value;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "k1_wgs_per_cu")) {
+    if (value < 0 || value > 64) return fail(SBO_E_INVALID, "k1_wgs_per_cu out of range");
+    c->k1_wgs_per_cu = (int)value;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "posterior_path")) {
+    if (value != 0 && value != 1) return fail(SBO_E_INVALID, "posterior_path must be 0 (auto) or 1 (generic)");
+    c->posterior_path = (int)value;
+    c->posterior_valid = false;
     return SBO_OK;
   }
   return fail(SBO_E_INVALID, std::string("unknown option ") + key);
@@ -211,7 +242,7 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
   mc.npad = (n + 15) / 16 * 16;
   mc.dpad = d <= 2 ? 2 : (d <= 4 ? 4 : 8);
   mc.factor = invK ? SBO_FACTOR_INVK : SBO_FACTOR_CHOL;
-  for (int a = 0; a < kMaxD; ++a) { mc.X_mean[a] = a < d ? X_mean[a] : 0.0; mc.X_std[a] = a < d ? X_std[a] : 1.0; }
+  for (int a = 0; a < kMaxD; ++a) { mc.X_mean[a] = a < d ? X_mean[a] : 0.0; mc.X_std[a] = a < d ? X_std[a] : 1.0; mc.X_rstd[a] = 1.0 / mc.X_std[a]; }
   const int npad = mc.npad, D = mc.dpad;
   std::vector<double> As((size_t)q * npad * D, 0.0), sqA((size_t)q * npad, 0.0), alpha((size_t)q * npad, 0.0),
       Xn((size_t)npad * D, 0.0), F((size_t)q * n * n, 0.0);
@@ -243,14 +274,21 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
     for (int j = 0; j < n; ++j) rhs[j] = Y_norm[(size_t)j * q + o] - mc.mp[o];
     double* Fo = &F[(size_t)o * n * n];
     if (invK) {
+      // alpha straight from the caller's inverse (GP_Safe.py:342); for the variance factor the same inverse as
+      // M^T M with M lower triangular: reverse both index orders, Cholesky, reverse back and transpose.
       const double* W = invK + (size_t)o * n * n;
+      std::vector<double> R((size_t)n * n);
       for (int i = 0; i < n; ++i) {
         double s = 0;
         for (int j = 0; j < n; ++j) s += W[(size_t)i * n + j] * rhs[j];
         alpha[(size_t)o * npad + i] = s;
-        for (int j = 0; j < i; ++j) Fo[(size_t)i * n + j] = W[(size_t)i * n + j] + W[(size_t)j * n + i];
-        Fo[(size_t)i * n + i] = W[(size_t)i * n + i];
+        for (int j = 0; j < n; ++j)
+          R[(size_t)(n - 1 - i) * n + (n - 1 - j)] = 0.5 * (W[(size_t)i * n + j] + W[(size_t)j * n + i]);
       }
+      if (!cholesky_lower(R, n)) return fail(SBO_E_INVALID, "invK is not positive definite");
+      // R = C (lower) with P invK P = C C^T  ->  invK = (P C P)(P C P)^T, and M = (P C P)^T is lower triangular
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) Fo[(size_t)i * n + j] = R[(size_t)(n - 1 - j) * n + (n - 1 - i)];
     } else {
       // K = sf2 exp(-1/2 dist) + sn2 I with the expanded distance (GP_Safe.py:119, 141, 231), then L^-1
       std::vector<double> K((size_t)n * n), Linv;

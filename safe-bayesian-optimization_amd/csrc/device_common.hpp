@@ -7,26 +7,47 @@ namespace sbo {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
-// 16x16x4 MFMA per compute type.  A/B operands: one scalar per lane, lane l holds A[i = l&15][k = l>>4]
-// and B[k = l>>4][j = l&15].  C/D: f32 row = 4*(l>>4) + r, f64 row = (l>>4) + 4*r, col = l&15
-// (cdna_hip_programming.md section 3; verified with exact integer data by tools/mfma_probe.hip).
-// jslot(kk, slot) is the observation offset inside a 16-block that k-step kk / k-slot `slot` carries; it is
-// chosen per type so that accumulator register r of block I sits on the lane that also holds B-fragment
-// (J = I, kk = r), i.e. t_i and k_i meet in one lane with no shuffle.
+// Matrix-core step per compute type: one call multiplies a 16(rows) x 4(k) A-fragment with a 4(k) x 16(candidates)
+// B-fragment and accumulates 16 x 16 results, 4 per lane.  B lane map (both types): lane l holds
+// B[k = l>>4][candidate = l&15]; every accumulator element of lane l belongs to candidate l&15 (which row it is
+// does not matter: the epilogue sums squares over all rows).
+//   float : v_mfma_f32_16x16x4_f32 (measured 155 TFLOP/s = the f32 peak); A lane map A[row = l&15][k = l>>4].
+//   double: v_mfma_f64_16x16x4_f64 issues only every ~105 cycles on gfx950 (47.9 TFLOP/s measured,
+//           profiles/r01_mfma_probe.txt) while v_mfma_f64_4x4x4_4b_f64 sustains 72-75 TFLOP/s, so the f64 step is
+//           four 4x4x4 instructions.  Lane layout of that form (found with one-hot data, tools/mfma_probe4.hip):
+//           A[blk][i][k] at lane 16k+4blk+i, B[blk][k][j] at 16k+4blk+j, D[blk][i][j] at 16i+4blk+j, four
+//           independent 4x4x4 products.  Instruction t gives every block the SAME four rows 4t..4t+3 of the
+//           A-fragment (its four lane-quads read identical addresses, so the load still moves 128 unique bytes)
+//           and block blk the candidates 4blk..4blk+3 of the natural B-fragment: no lane movement at all.
+// jslot(kk, slot) is the observation offset inside a 16-block carried by k-step kk / k-slot `slot`;
+// pack_pos(r, k) is where element (row r, k-slot k) of a 16x4 fragment sits in its 64-element packed image,
+// chosen so that one lane's operands are contiguous (f64: its 4 row-groups = 32 bytes, two dwordx4 loads).
 template <typename T> struct MM;
-template <> struct MM<double> {
-  using acc_t = d4_t;
-  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-  }
-  static __host__ __device__ __forceinline__ int jslot(int kk, int slot) { return 4 * kk + slot; }
-};
 template <> struct MM<float> {
   using acc_t = f4_t;
-  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+  using a_t = float;
+  static __device__ __forceinline__ a_t load_a(const float* frag, int lane) { return frag[lane]; }
+  static __device__ __forceinline__ acc_t mfma(a_t a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
   static __host__ __device__ __forceinline__ int jslot(int kk, int slot) { return 4 * slot + kk; }
+  static __host__ __device__ __forceinline__ int pack_pos(int r, int k) { return k * 16 + r; }
+};
+template <> struct MM<double> {
+  using acc_t = d4_t;
+  using a_t = d4_t;   // rows {i, 4+i, 8+i, 12+i} (i = lane&3) at k-slot lane>>4
+  static __device__ __forceinline__ a_t load_a(const double* frag, int lane) {
+    return *reinterpret_cast<const d4_t*>(frag + (((lane >> 4) << 2) + (lane & 3)) * 4);
+  }
+  static __device__ __forceinline__ acc_t mfma(a_t a, double b, acc_t c) {
+    c[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], b, c[0], 0, 0, 0);
+    c[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], b, c[1], 0, 0, 0);
+    c[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], b, c[2], 0, 0, 0);
+    c[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], b, c[3], 0, 0, 0);
+    return c;
+  }
+  static __host__ __device__ __forceinline__ int jslot(int kk, int slot) { return 4 * kk + slot; }
+  static __host__ __device__ __forceinline__ int pack_pos(int r, int k) { return (k * 4 + (r & 3)) * 4 + (r >> 2); }
 };
 
 // unfused arithmetic where the oracle's rounding sequence is part of the contract

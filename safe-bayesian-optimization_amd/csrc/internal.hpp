@@ -15,7 +15,7 @@ constexpr int kMaxQ = SBO_MAX_Q;
 // fp32 kernels round on use.  Rows a1/a4 of SURVEY.md section 8 (models/GP_Safe.py:236-245, 326-347).
 struct ModelConst {
   int n, npad, d, dpad, q, factor;
-  double X_mean[kMaxD], X_std[kMaxD];
+  double X_mean[kMaxD], X_std[kMaxD], X_rstd[kMaxD];
   double Y_mean[kMaxQ], Y_std[kMaxQ];
   double sf2[kMaxQ];            // exp(2 h[d])                       GP_Safe.py:338
   double mp[kMaxQ];             // prior mean, -2 Y_mean/Y_std, [0]=0 GP_Safe.py:331-332
@@ -55,6 +55,9 @@ struct sbo_ctx {
   sbo::DevBuf sqA;     // [q][npad]        sum_a As^2
   sbo::DevBuf alpha;   // [q][npad]        invK (Y_norm - mp)
   sbo::DevBuf Xn;      // [npad][dpad]     X_norm (for the mean gradient)
+  sbo::DevBuf E0f;     // grid path: axis-0 kernel table in B-fragment order [q][tiles0][npad/4][64]
+  sbo::DevBuf Er;      // grid path: tables of the remaining axes [q][sum_a count_a][npad]
+  sbo::DevBuf AXg;     // grid path: alpha_j (1, Xn_j) rows in fragment-slot order [q][npad][1 + dpad]
   size_t fpk_stride = 0;  // elements per output in Fpk
   std::vector<double> h_Xnorm;   // host copies used by the exact-recheck / result decoding
   // candidates
@@ -86,6 +89,8 @@ struct sbo_ctx {
   hipEvent_t ev[8]{};
   // options
   int engine = 0;      // 0 MFMA, 1 VALU (fp64 contraction engine)
+  int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
+  int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
   // comm
   void* comm = nullptr;  // ncclComm_t
   int world = 1, rank = 0;

@@ -7,10 +7,11 @@
 //   MEAN   = mean Y_std + Y_mean, VAR = var Y_std^2      models/GP_Safe.py:346-347
 //   |dMEAN/dx|_inf (for the Lipschitz bound)            models/SafeOpt.py:68-71
 // The cross-covariance tile K*[n, P] is generated straight into LDS in MFMA B-fragment order and never
-// touches HBM.  The quadratic form is the block-triangular GEMM  T = F K*  on v_mfma_{f64,f32}_16x16x4
-// (F = invK folded to its lower triangle, or L^-1), followed by a per-candidate row reduction
-// sum_i k_i t_i (or sum_i t_i^2) inside the wave, then across the four waves through LDS.
+// touches HBM.  The quadratic form k^T invK k = ||M k||^2 (M lower triangular with M^T M = invK, i.e. L^-1)
+// is the block-triangular GEMM  T = M K*  on the matrix cores (device_common.hpp, MM<T>), followed by a
+// per-candidate reduction  sum_i t_i^2  inside the wave, then across the four waves through LDS.
 #include <algorithm>
+#include <cstring>
 #include "device_common.hpp"
 
 namespace sbo {
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void k_posterior(const ModelConst mc, const Ca
   // ---------------- phase 2: block-triangular contraction on the matrix cores ----------------
   {
     const int nb = mc.npad >> 4;
-    const T* F_o = Fpk + (size_t)out * fpk_stride + lane;
+    const T* F_o = Fpk + (size_t)out * fpk_stride;
     T quad[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) quad[s] = 0;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void k_posterior(const ModelConst mc, const Ca
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int st = J * 4 + kk;
-          const T a = fp[(size_t)st * 64];
+          const typename MM<T>::a_t a = MM<T>::load_a(fp + (size_t)st * 64, lane);
 #pragma unroll
           for (int s = 0; s < S; ++s) {
             const T b = Kf[((size_t)s * nfr + st) * 64 + lane];
@@ -130,15 +131,11 @@ __global__ __launch_bounds__(256) void k_posterior(const ModelConst mc, const Ca
           }
         }
       }
-      // row reduction: register r_ of acc sits on the lane holding k of the same observation (B-fragment I*4+r_)
+      // row reduction: every accumulator element of this lane is a t_i of candidate lane&15
 #pragma unroll
       for (int s = 0; s < S; ++s) {
 #pragma unroll
-        for (int r_ = 0; r_ < 4; ++r_) {
-          const T t = acc[s][r_];
-          const T kv = (mc.factor == SBO_FACTOR_INVK) ? Kf[((size_t)s * nfr + I * 4 + r_) * 64 + lane] : t;
-          quad[s] = fma(kv, t, quad[s]);
-        }
+        for (int r_ = 0; r_ < 4; ++r_) quad[s] = fma(acc[s][r_], acc[s][r_], quad[s]);
       }
     }
 #pragma unroll
@@ -198,6 +195,286 @@ __global__ __launch_bounds__(256) void k_posterior(const ModelConst mc, const Ca
       gd = other > gd ? other : gd;
     }
     if (tid == 0) atomicMax(&Lmax[out], (unsigned long long)__double_as_longlong(gd));
+  }
+}
+
+// =====================================================================================================
+// K1g: the same posterior for candidates on a tensor grid, using the separability of the RBF-ARD kernel:
+//   k(x, X_j) = sf2 prod_a exp(-1/2 ((xn_a - X_ja)/l_a)^2) = E0[g0][j] * Erest[(g1, g2, ..)][j].
+// Per-axis tables (count_a x n entries, built by k_build_tables at every launch) replace the N*n exp()
+// evaluations; a B-fragment is one multiply of two table entries, formed in registers right before the MFMA
+// that consumes it, so the cross-covariance tile never exists in LDS either.  Workgroup tile = 16 consecutive
+// axis-0 positions x S lines of the remaining axes.
+// (Differs from the expanded-distance form of models/GP_Safe.py:119 by a few ulp in k; parity bar is 1e-10.)
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_tables(const ModelConst mc, const CandSpec cs, const T* __restrict__ As,
+                                                      int D, T* __restrict__ E0f, size_t e0_stride, T* __restrict__ Er,
+                                                      size_t er_stride_o, size_t er_off1, size_t er_off2, size_t er_off3,
+                                                      size_t er_off4, size_t er_off5, size_t er_off6, size_t er_off7) {
+  const int o = blockIdx.y;
+  const int nfr = mc.npad >> 2;
+  const long long cnt0 = cs.count[0];
+  const long long ntile0 = (cnt0 + 15) / 16;
+  const long long n0 = ntile0 * nfr * 64;
+  long long total = n0;
+  for (int a = 1; a < cs.d; ++a) total += cs.count[a] * mc.npad;
+  const size_t er_off[8] = {0, er_off1, er_off2, er_off3, er_off4, er_off5, er_off6, er_off7};
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int a, j;
+    long long i;
+    T* dst;
+    if (t < n0) {
+      const int lane = (int)(t & 63);
+      const long long fr = t >> 6;
+      const int jj = (int)(fr % nfr);
+      const long long t0 = fr / nfr;
+      a = 0;
+      i = t0 * 16 + (lane & 15);
+      if (i > cnt0 - 1) i = cnt0 - 1;
+      j = ((jj >> 2) << 4) + MM<T>::jslot(jj & 3, lane >> 4);
+      dst = E0f + (size_t)o * e0_stride + t;
+    } else {
+      long long u = t - n0;
+      a = 1;
+      while (u >= cs.count[a] * mc.npad) { u -= cs.count[a] * mc.npad; ++a; }
+      i = u / mc.npad;
+      j = (int)(u % mc.npad);
+      dst = Er + (size_t)o * er_stride_o + er_off[a] + u;
+    }
+    const long long cnt = cs.count[a];
+    const double x = (i == cnt - 1 && cnt > 1) ? cs.hi[a] : cs.lo[a] + (double)i * cs.step[a];
+    const T xn = ((T)x - (T)mc.X_mean[a]) / (T)mc.X_std[a];
+    const T diff = xn * (T)mc.vinv[o][a] - As[((size_t)o * mc.npad + j) * D + a];
+    *dst = exp_t<T>(T(-0.5) * (diff * diff));
+  }
+}
+
+constexpr __host__ __device__ int NC_AX(int D) { return 1 + D; }
+
+struct GridTables {
+  size_t e0_stride;      // elements per output in E0f
+  size_t er_stride_o;    // elements per output in Er
+  size_t er_off[kMaxD];  // element offset of axis a's table inside one output's Er block
+  long long nlines;      // local lines (n_local / count0)
+  long long line0;       // global index of the first local line
+};
+
+// which row block carries the mean / gradient dot products of column block J
+__device__ __forceinline__ int top_row_of_wave(int w, int nb) {
+  // largest I < nb with row_block_of(r, w) == I
+  int best = -1;   // the schedule is non-decreasing in r, so the last row below nb is the largest
+  for (int r = 0;; ++r) {
+    const int I = row_block_of(r, w);
+    if (I >= nb) break;
+    best = I;
+  }
+  return best;
+}
+
+template <typename T, int S, int D>
+__global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, const CandSpec cs, const GridTables gt,
+                                                        const T* __restrict__ Fpk, size_t fpk_stride,
+                                                        const T* __restrict__ E0f, const T* __restrict__ Er,
+                                                        const T* __restrict__ AXg, unsigned int ntiles,
+                                                        T* __restrict__ mean_out, T* __restrict__ var_out,
+                                                        unsigned long long* __restrict__ Lmax) {
+  using acc_t = typename MM<T>::acc_t;
+  using a_t = typename MM<T>::a_t;
+  constexpr int P = 16 * S;
+  constexpr int NC = 2 + D;                       // per-candidate partial sums: quad, m0, ms[D]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int npad = mc.npad, nfr = npad >> 2, nb = npad >> 4;
+  T* E1f = reinterpret_cast<T*>(smem);            // [S][npad]   sf2 * prod_{a>=1} table, in fragment-slot order
+  T* part = E1f + (size_t)S * npad;               // [NC][kWaves * 4][P] partial sums per (wave, k-slot)
+  __shared__ unsigned int line_row[2][S][kMaxD];  // per strip: row index into each remaining-axis table (x2: the
+                                                  // epilogue of tile i overlaps phase 0 of tile i+1)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pp = lane & 15, slot = lane >> 4;
+  const int out = blockIdx.y;
+  const unsigned int cnt0 = (unsigned int)cs.count[0];
+  const unsigned int ntile0 = (cnt0 + 15u) / 16u;
+
+  // Which row block carries the mean / gradient dot products of column block J: the top row of wave J % W while
+  // J <= tmin (the smallest of the waves' top rows), row J itself above that.  All of it is wave-uniform.
+  const int my_top = top_row_of_wave(wave, nb);
+  int tmin = nb;
+  for (int w = 0; w < kWaves; ++w) {
+    const int t = top_row_of_wave(w, nb);
+    tmin = t < tmin ? t : tmin;
+  }
+  const T* F_o = Fpk + (size_t)out * fpk_stride;
+  const T* AX_o = AXg + (size_t)out * npad * NC_AX(D) + slot * NC_AX(D);
+  double gmax = 0.0;                              // running max of |grad MEAN|_inf (threads of wave 0)
+
+  // persistent over tiles: a workgroup lives for many tiles, so dispatch gaps and per-launch setup are paid once
+  int par = 0;
+  for (unsigned int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    const unsigned int t0 = tile % ntile0;
+    const unsigned int lt = tile / ntile0;        // tile of S lines
+
+    // ---------------- phase 0: per-line factors into LDS ----------------
+    if (tid >= 64 && tid < 64 + S) {
+      const int s = tid - 64;
+      long long line = (long long)lt * S + s;
+      if (line >= gt.nlines) line = gt.nlines - 1;
+      unsigned long long f = (unsigned long long)(gt.line0 + line);   // global line index -> (i1, i2, ...)
+      for (int a = 1; a < cs.d; ++a) {
+        const unsigned long long c = (unsigned long long)cs.count[a];
+        line_row[par][s][a] = (unsigned int)(f % c);
+        f /= c;
+      }
+    }
+    __syncthreads();   // also orders the previous tile's epilogue (reads of `part`) before this tile's writes
+    for (int idx = tid; idx < npad; idx += 256) {
+      const int jj = idx >> 2, sl = idx & 3;
+      const int j = ((jj >> 2) << 4) + MM<T>::jslot(jj & 3, sl);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        T v = (T)mc.sf2[out];
+        for (int a = 1; a < cs.d; ++a)
+          v *= Er[(size_t)out * gt.er_stride_o + gt.er_off[a] + (size_t)line_row[par][s][a] * npad + j];
+        E1f[s * npad + idx] = v;
+      }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: block-triangular contraction, B-fragments formed on the fly ----------------
+    const T* E0_t = E0f + (size_t)out * gt.e0_stride + (size_t)t0 * nfr * 64 + lane;
+    T quad[S], m0[S], ms[S][D];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      quad[s] = 0;
+      m0[s] = 0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) ms[s][a] = 0;
+    }
+    for (int r = 0;; ++r) {
+      const int I = row_block_of(r, wave);
+      if (I >= nb) break;
+      acc_t acc[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) acc[s] = acc_t{0, 0, 0, 0};
+      // software pipeline: the two fragment loads of step st+1 are in flight behind the MFMAs of step st.  The
+      // load after the last step of a row reads the next fragment in memory (both buffers carry padding), so the
+      // loop has no clamp and only pointer bumps.
+      const T* fp = F_o + (size_t)(I * (I + 1) / 2) * 4 * 64;
+      const T* ep = E0_t;
+      a_t a_nx = MM<T>::load_a(fp, lane);
+      T e_nx = *ep;
+      const bool is_top = (I == my_top);
+      for (int J = 0; J <= I; ++J) {
+        const bool dots = (J <= tmin) ? (is_top && (J % kWaves) == wave) : (J == I);
+        const T* e1p = E1f + J * 16 + slot;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const a_t a = a_nx;
+          const T e_cur = e_nx;
+          fp += 64;
+          ep += 64;
+          a_nx = MM<T>::load_a(fp, lane);
+          e_nx = *ep;
+          T b[S];
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            b[s] = e_cur * e1p[s * npad + kk * 4];
+            acc[s] = MM<T>::mfma(a, b[s], acc[s]);
+          }
+          if (dots) {
+            const T* ax = AX_o + (J * 16 + kk * 4) * NC_AX(D);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+              m0[s] = fma(ax[0], b[s], m0[s]);
+#pragma unroll
+              for (int a_ = 0; a_ < D; ++a_) ms[s][a_] = fma(ax[1 + a_], b[s], ms[s][a_]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int r_ = 0; r_ < 4; ++r_) quad[s] = fma(acc[s][r_], acc[s][r_], quad[s]);
+      }
+    }
+    // every lane parks its partial sums; 16 (wave, k-slot) partials per candidate are added in a fixed order
+    {
+      const int row = (wave * 4 + slot) * P + pp;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        part[(size_t)0 * kWaves * 4 * P + row + s * 16] = quad[s];
+        part[(size_t)1 * kWaves * 4 * P + row + s * 16] = m0[s];
+#pragma unroll
+        for (int a = 0; a < D; ++a) part[(size_t)(2 + a) * kWaves * 4 * P + row + s * 16] = ms[s][a];
+      }
+    }
+    __syncthreads();
+
+    // ---------------- epilogue: one thread per candidate (wave 0; the other waves move on to the next tile) ----
+    if (tid < 64) {
+      const int s = tid >> 4, p0 = tid & 15;
+      const unsigned int g0 = t0 * 16 + p0;
+      const long long line = (long long)lt * S + s;
+      const bool valid = (tid < P) && (g0 < cnt0) && (line < gt.nlines);
+      if (valid) {
+        const long long g = line * cnt0 + g0;
+        T sums[NC];
+#pragma unroll
+        for (int c_ = 0; c_ < NC; ++c_) {
+          T acc_ = 0;
+#pragma unroll
+          for (int w = 0; w < kWaves * 4; ++w) acc_ += part[((size_t)c_ * kWaves * 4 + w) * P + tid];
+          sums[c_] = acc_;
+        }
+        const T sf2 = (T)mc.sf2[out], ystd = (T)mc.Y_std[out];
+        const T mean = (T)mc.mp[out] + sums[1];
+        T var = sf2 - sums[0];
+        var = var > T(0) ? var : T(0);
+        mean_out[(size_t)out * cs.n_local + g] = mean * ystd + (T)mc.Y_mean[out];
+        var_out[(size_t)out * cs.n_local + g] = var * (ystd * ystd);
+        // gradient of the un-normalised mean; the grid indices of this candidate are (g0, line_row[s][1..])
+        T gn = 0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          if (a < mc.d) {
+            const unsigned int ia = a == 0 ? g0 : line_row[par][s][a];
+            const long long cnt = cs.count[a];
+            const double x = (ia == cnt - 1 && cnt > 1) ? cs.hi[a] : cs.lo[a] + (double)ia * cs.step[a];
+            const T rstd = (T)mc.X_rstd[a];
+            const T xn = ((T)x - (T)mc.X_mean[a]) * rstd;
+            T ga = ystd * (sums[2 + a] - xn * sums[1]) * (T)mc.inv_ell[out][a] * rstd;
+            ga = ga < 0 ? -ga : ga;
+            gn = ga > gn ? ga : gn;
+          }
+        }
+        gmax = (double)gn > gmax ? (double)gn : gmax;
+      }
+    }
+  }
+  if (tid < 64) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double other = __shfl_xor(gmax, o);
+      gmax = other > gmax ? other : gmax;
+    }
+    if (tid == 0) atomicMax(&Lmax[out], (unsigned long long)__double_as_longlong(gmax));
+  }
+}
+
+// alpha_j * (1, Xn_j0, ..) in fragment-slot order [q][npad][1 + D] (the mean / gradient dot-product rows)
+template <typename T>
+__global__ void k_build_ax(const ModelConst mc, const T* __restrict__ alpha, const T* __restrict__ Xn, int D,
+                           T* __restrict__ AX) {
+  const int o = blockIdx.y;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < mc.npad; idx += gridDim.x * blockDim.x) {
+    const int jj = idx >> 2, sl = idx & 3;
+    const int j = ((jj >> 2) << 4) + MM<T>::jslot(jj & 3, sl);
+    const T al = alpha[(size_t)o * mc.npad + j];
+    T* dst = AX + ((size_t)o * mc.npad + idx) * (1 + D);
+    dst[0] = al;
+    for (int a = 0; a < D; ++a) dst[1 + a] = al * Xn[j * D + a];
   }
 }
 
@@ -270,8 +547,77 @@ static int launch_posterior_s(sbo_ctx* c) {
   return fail(SBO_E_UNSUPPORTED, "n too large for the LDS-resident cross-covariance tile");
 }
 
+template <typename T, int D>
+static int launch_posterior_grid_t(sbo_ctx* c) {
+  constexpr int S = 4;
+  constexpr int P = 16 * S;
+  const ModelConst& mc = c->mc;
+  const CandSpec& cs = c->cs;
+  const int npad = mc.npad, nfr = npad / 4, q = mc.q, d = cs.d;
+  const long long cnt0 = cs.count[0];
+  const long long ntile0 = (cnt0 + 15) / 16;
+  GridTables gt;
+  memset(&gt, 0, sizeof(gt));
+  gt.e0_stride = (size_t)ntile0 * nfr * 64;
+  size_t off = 0;
+  for (int a = 1; a < d; ++a) {
+    gt.er_off[a] = off;
+    off += (size_t)cs.count[a] * npad;
+  }
+  gt.er_stride_o = off;
+  gt.nlines = cs.n_local / cnt0;
+  gt.line0 = cs.first / cnt0;
+  int rc;
+  if ((rc = ensure(c->E0f, sizeof(T) * (gt.e0_stride * q + 512)))) return rc;   // + padding: the pipeline over-reads one fragment
+  if ((rc = ensure(c->Er, sizeof(T) * std::max<size_t>(gt.er_stride_o, 1) * q))) return rc;
+  const long long total = (long long)gt.e0_stride + (long long)gt.er_stride_o;
+  hipLaunchKernelGGL((k_build_tables<T>), dim3((unsigned)std::min<long long>((total + 255) / 256, 4096), q), dim3(256), 0,
+                     c->stream, mc, cs, (const T*)c->As.p, mc.dpad, (T*)c->E0f.p, gt.e0_stride, (T*)c->Er.p, gt.er_stride_o,
+                     gt.er_off[1], gt.er_off[2], gt.er_off[3], gt.er_off[4], gt.er_off[5], gt.er_off[6], gt.er_off[7]);
+  if ((rc = ensure(c->AXg, sizeof(T) * (size_t)q * npad * (1 + D)))) return rc;
+  hipLaunchKernelGGL((k_build_ax<T>), dim3(1, q), dim3(256), 0, c->stream, mc, (const T*)c->alpha.p, (const T*)c->Xn.p, D,
+                     (T*)c->AXg.p);
+  const size_t lds = sizeof(T) * ((size_t)S * npad + (size_t)(2 + D) * kWaves * 4 * P);
+  auto kern = k_posterior_grid<T, S, D>;
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long long tiles = ntile0 * ((gt.nlines + S - 1) / S);
+  if (tiles > 0x7fffffffLL) return fail(SBO_E_UNSUPPORTED, "too many candidate tiles for one launch");
+  // persistent grid: a few workgroups per CU (as many as registers / LDS admit), each looping over tiles
+  int per_cu = 0;
+  SBO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
+  per_cu = std::max(1, std::min(per_cu, 4));
+  if (c->k1_wgs_per_cu > 0) per_cu = c->k1_wgs_per_cu;
+  // the q outputs are separate grid rows: share the CU slots between them
+  const long long wgs = std::min<long long>(tiles, ((long long)c->n_cu * per_cu + q - 1) / q);
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::max<long long>(wgs, 1), (unsigned)q), dim3(256), lds, c->stream, mc, cs, gt,
+                     (const T*)c->Fpk.p, c->fpk_stride, (const T*)c->E0f.p, (const T*)c->Er.p, (const T*)c->AXg.p,
+                     (unsigned int)tiles, (T*)c->mean.p, (T*)c->var.p, (unsigned long long*)c->Lmax.p);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+template <typename T>
+static int launch_posterior_grid(sbo_ctx* c) {
+  switch (c->mc.dpad) {
+    case 2: return launch_posterior_grid_t<T, 2>(c);
+    case 4: return launch_posterior_grid_t<T, 4>(c);
+    case 8: return launch_posterior_grid_t<T, 8>(c);
+  }
+  return fail(SBO_E_UNSUPPORTED, "unsupported padded dimension");
+}
+
+// the separable path needs whole axis-0 lines in the shard
+static bool grid_path_ok(const sbo_ctx* c) {
+  const CandSpec& cs = c->cs;
+  if (c->posterior_path == 1) return false;
+  if (cs.kind != 1 || cs.n_local <= 0) return false;
+  const long long cnt0 = cs.count[0];
+  return cs.first % cnt0 == 0 && cs.n_local % cnt0 == 0;
+}
+
 int launch_posterior(sbo_ctx* c) {
   SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
+  if (grid_path_ok(c)) return c->dtype == SBO_F64 ? launch_posterior_grid<double>(c) : launch_posterior_grid<float>(c);
   return c->dtype == SBO_F64 ? launch_posterior_s<double>(c) : launch_posterior_s<float>(c);
 }
 

@@ -82,15 +82,25 @@ def test_posterior_fp32_large_n_scattered(engine):
     _check_posterior(engine, cfg["ds"], pts.astype(np.float64), TOL32, dtype="f32")
 
 
-def test_grid_equals_explicit_points_bitwise(engine):
+def test_grid_paths_agree(engine):
+    """Implicit grid through the separable-table kernel (K1g), the same grid through the generic exp() kernel (K1),
+    and the grid handed over as explicit points: K1 on a grid and on the same points is bit-identical, K1g differs
+    from both only by the rounding of exp(a)exp(b) vs exp(a+b)."""
     cfg = synthetic.make_config("B", n=128)
     lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
     engine.set_model(cfg["ds"])
     engine.set_grid(lo, hi, [61, 47])
     m1, v1 = engine.posterior()
+    engine.set_option("posterior_path", 1)
+    try:
+        engine.set_grid(lo, hi, [61, 47])
+        m2, v2 = engine.posterior()
+    finally:
+        engine.set_option("posterior_path", 0)
     engine.set_points(oracle.grid_points(lo, hi, [61, 47]))
-    m2, v2 = engine.posterior()
-    assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
+    m3, v3 = engine.posterior()
+    assert np.array_equal(m2, m3) and np.array_equal(v2, v3)
+    assert np.max(np.abs(m1 - m2)) < 1e-12 and np.max(np.abs(v1 - v2)) < 1e-12
 
 
 def test_shard_ranges_reproduce_the_whole_grid_bitwise(engine):
@@ -99,10 +109,16 @@ def test_shard_ranges_reproduce_the_whole_grid_bitwise(engine):
     engine.set_model(cfg["ds"])
     engine.set_grid(lo, hi, [64, 50])
     m, v = engine.posterior()
-    for first, nloc in [(0, 1), (0, 1000), (1000, 2200), (3199, 1), (37, 64)]:
+    # whole-line shards run the same separable kernel: bit-identical; ragged shards fall back to the generic
+    # kernel: equal to rounding
+    for first, nloc in [(0, 64), (0, 640), (640, 2560), (3136, 64), (64 * 7, 64 * 3)]:
         engine.set_grid(lo, hi, [64, 50], first=first, n_local=nloc)
         ms, vs = engine.posterior()
         assert np.array_equal(ms, m[first:first + nloc]) and np.array_equal(vs, v[first:first + nloc])
+    for first, nloc in [(0, 1), (0, 1000), (1000, 2200), (3199, 1), (37, 64)]:
+        engine.set_grid(lo, hi, [64, 50], first=first, n_local=nloc)
+        ms, vs = engine.posterior()
+        assert np.max(np.abs(ms - m[first:first + nloc])) < 1e-12 and np.max(np.abs(vs - v[first:first + nloc])) < 1e-12
     engine.set_grid(lo, hi, [64, 50], first=5, n_local=0)       # empty shard
     ms, vs = engine.posterior()
     assert ms.shape == (0, 2)
