@@ -454,6 +454,191 @@ __global__ void k_init_scalars(SweepScalars* sc) {
   if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
 }
 
+// ---- GoOSE: optimistic set O_c (models/GoOSE.py:93-101) -----------------------------------------------------
+//   O_c = {h in U : exists g in S, ucb_c(g) - L ||x_g - x_h + 1e-8|| >= 0}
+// Here the radius ucb_c(g)/L belongs to the *source* g, so the query is a union-of-balls coverage test, not a
+// nearest-neighbour one; it is answered exactly by evaluating the reference predicate on every pair of
+// 256-candidate runs whose bounding boxes are closer than the largest radius in the S-run.
+constexpr int kRun = 256;
+struct RunMeta {
+  double rmax;                    // max ucb_c/L over the S points of the run (< 0: no S point)
+  double lo[kMaxD], hi[kMaxD];    // bounding box of the run's S points
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_goose_run_meta(const CandSpec cs, const T* __restrict__ mean_c,
+                                                        const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
+                                                        const unsigned long long* Lkeys, int lidx, RunMeta* __restrict__ meta) {
+  __shared__ double red[4][1 + 2 * D];
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const long long g = (long long)blockIdx.x * kRun + threadIdx.x;
+  double r = -1.0, lo[D], hi[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) { lo[a] = 1e300; hi[a] = -1e300; }
+  if (g < cs.n_local && S[g]) {
+    T lcb, ucb;
+    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucb);
+    r = L > 0 ? (double)ucb / L : 1e300;
+    double x[D];
+    cand_coords<D>(cs, g, x);
+#pragma unroll
+    for (int a = 0; a < D; ++a) { lo[a] = x[a]; hi[a] = x[a]; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    r = fmax(r, __shfl_xor(r, o));
+#pragma unroll
+    for (int a = 0; a < D; ++a) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[wave][0] = r;
+#pragma unroll
+    for (int a = 0; a < D; ++a) { red[wave][1 + a] = lo[a]; red[wave][1 + D + a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    RunMeta m;
+    m.rmax = fmax(fmax(red[0][0], red[1][0]), fmax(red[2][0], red[3][0]));
+    for (int a = 0; a < kMaxD; ++a) { m.lo[a] = 0; m.hi[a] = 0; }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      m.lo[a] = fmin(fmin(red[0][1 + a], red[1][1 + a]), fmin(red[2][1 + a], red[3][1 + a]));
+      m.hi[a] = fmax(fmax(red[0][1 + D + a], red[1][1 + D + a]), fmax(red[2][1 + D + a], red[3][1 + D + a]));
+    }
+    meta[blockIdx.x] = m;
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_goose_optimistic(const CandSpec cs, const T* __restrict__ mean_c,
+                                                          const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
+                                                          const uint8_t* __restrict__ U, const unsigned long long* Lkeys,
+                                                          int lidx, const RunMeta* __restrict__ meta, int nruns,
+                                                          uint8_t* __restrict__ O) {
+  __shared__ double gx[kRun][D];
+  __shared__ double gr[kRun], gucb[kRun];
+  __shared__ int list[kRun];
+  __shared__ int nlist, nopen;
+  __shared__ double ubox[2 * D];
+  __shared__ double red[4][2 * D];
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const long long h = (long long)blockIdx.x * kRun + threadIdx.x;
+  const bool isU = h < cs.n_local && U[h];
+  double xh[D];
+  if (h < cs.n_local) cand_coords<D>(cs, h, xh);
+  // bounding box of this run's U points
+  double lo[D], hi[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) { lo[a] = isU ? xh[a] : 1e300; hi[a] = isU ? xh[a] : -1e300; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) { red[wave][a] = lo[a]; red[wave][D + a] = hi[a]; }
+  }
+  if (threadIdx.x == 0) nopen = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      ubox[a] = fmin(fmin(red[0][a], red[1][a]), fmin(red[2][a], red[3][a]));
+      ubox[D + a] = fmax(fmax(red[0][D + a], red[1][D + a]), fmax(red[2][D + a], red[3][D + a]));
+    }
+  }
+  if (isU) atomicAdd(&nopen, 1);
+  __syncthreads();
+  bool covered = false;
+  if (nopen > 0) {
+    for (int base = 0; base < nruns; base += kRun) {
+      // which of the next 256 S-runs can reach this run's U points at all
+      if (threadIdx.x == 0) nlist = 0;
+      __syncthreads();
+      const int t = base + threadIdx.x;
+      if (t < nruns) {
+        const RunMeta m = meta[t];
+        if (m.rmax >= 0.0) {
+          double d2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < D; ++a) {
+            const double gap = fmax(0.0, fmax(m.lo[a] - ubox[D + a], ubox[a] - m.hi[a]));
+            d2 += gap * gap;
+          }
+          const double reach = m.rmax * (1.0 + 1e-9) + 1e-6;
+          if (d2 <= reach * reach) list[atomicAdd(&nlist, 1)] = t;
+        }
+      }
+      __syncthreads();
+      const int nl = nlist;
+      for (int li = 0; li < nl; ++li) {
+        const long long g = (long long)list[li] * kRun + threadIdx.x;
+        double r = -1.0, uc = 0.0;
+        if (g < cs.n_local && S[g]) {
+          T lcb, ucb;
+          lcb_ucb(mean_c[g], var_c[g], b, lcb, ucb);
+          uc = (double)ucb;
+          r = L > 0 ? uc / L : 1e300;
+          double x[D];
+          cand_coords<D>(cs, g, x);
+#pragma unroll
+          for (int a = 0; a < D; ++a) gx[threadIdx.x][a] = x[a];
+        }
+        gr[threadIdx.x] = r;
+        gucb[threadIdx.x] = uc;
+        __syncthreads();
+        if (isU && !covered) {
+          for (int k = 0; k < kRun; ++k) {
+            const double r = gr[k];
+            if (r < 0.0) continue;
+            double ss = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+              const double df = (gx[k][a] - xh[a]) + 1e-8;       // x_g - x_h + 1e-8, models/GoOSE.py:71
+              ss = (a == 0) ? df * df : ss + df * df;
+            }
+            const double rhi = r * (1.0 + 1e-12), rlo = r * (1.0 - 1e-12);
+            if (ss > rhi * rhi) continue;
+            if (ss < rlo * rlo || gucb[k] - L * sqrt(ss) >= 0.0) { covered = true; break; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (h < cs.n_local) O[h] = covered;
+}
+
+// value arrays for the arg-reductions of the GoOSE sweep
+template <typename T>
+__global__ void k_lcb0(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b, T* __restrict__ out) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    T lcb, ucb;
+    lcb_ucb(mean0[g], var0[g], b, lcb, ucb);
+    out[g] = lcb;
+  }
+}
+// Euclidean distance to the target, as scipy.spatial.distance.cdist computes it (models/GoOSE.py:117)
+template <typename T, int D>
+__global__ void k_dist_to(const CandSpec cs, long long n, const double* __restrict__ target, T* __restrict__ out) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    double x[D];
+    cand_coords<D>(cs, g, x);
+    double ss = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      if (a < cs.d) {
+        const double df = x[a] - target[a];
+        ss += df * df;
+      }
+    }
+    out[g] = (T)sqrt(ss);
+  }
+}
+
 // ---- host orchestration -------------------------------------------------------------------------------
 static int reduce_blocks(const sbo_ctx* c) {
   const long long n = c->cs.n_local;
@@ -766,6 +951,155 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   return SBO_OK;
 }
 
+template <typename T, int D>
+static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* O) {
+  const long long n = c->cs.n_local;
+  if (n == 0) return SBO_OK;
+  const int q = c->mc.q;
+  const int lidx = o->reference_quirk_L_index ? q - 1 : cidx;   // models/GoOSE.py:100 (loop-leaked i)
+  const T* mean_c = (const T*)c->mean.p + (size_t)cidx * n;
+  const T* var_c = (const T*)c->var.p + (size_t)cidx * n;
+  const int nruns = (int)((n + kRun - 1) / kRun);
+  int rc;
+  if ((rc = ensure(c->amb, sizeof(RunMeta) * (size_t)nruns))) return rc;
+  hipLaunchKernelGGL((k_goose_run_meta<T, D>), dim3(nruns), dim3(256), 0, c->stream, c->cs, mean_c, var_c, (T)o->b,
+                     (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, (RunMeta*)c->amb.p);
+  hipLaunchKernelGGL((k_goose_optimistic<T, D>), dim3(nruns), dim3(256), 0, c->stream, c->cs, mean_c, var_c, (T)o->b,
+                     (const uint8_t*)c->maskS.p, (const uint8_t*)c->maskU.p, (const unsigned long long*)c->Lmax.p, lidx,
+                     (const RunMeta*)c->amb.p, nruns, O);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+template <typename T>
+static int goose_sets_d(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* O) {
+  switch (c->mc.dpad) {
+    case 2: return goose_sets<T, 2>(c, o, cidx, O);
+    case 4: return goose_sets<T, 4>(c, o, cidx, O);
+    case 8: return goose_sets<T, 8>(c, o, cidx, O);
+  }
+  return fail(SBO_E_UNSUPPORTED, "unsupported padded dimension");
+}
+
+template <typename T>
+static int launch_dist_to(sbo_ctx* c, const double* dev_target, T* out) {
+  const long long n = c->cs.n_local;
+  const int nb = reduce_blocks(c);
+  switch (c->mc.dpad) {
+    case 2: hipLaunchKernelGGL((k_dist_to<T, 2>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, dev_target, out); break;
+    case 4: hipLaunchKernelGGL((k_dist_to<T, 4>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, dev_target, out); break;
+    default: hipLaunchKernelGGL((k_dist_to<T, 8>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, dev_target, out); break;
+  }
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+// GoOSE iteration (models/GoOSE.py:63-119, test/test_GoOSE.py:151-162) on the resident candidates (single rank)
+template <typename T>
+static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* res) {
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q;
+  int rc;
+  SBO_HIP(hipEventRecord(c->ev[0], c->stream));
+  const bool reuse = o->posterior_ready && c->posterior_valid;
+  if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
+  SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  if ((rc = sweep_common_front<T>(c, o))) return rc;
+  if ((rc = sweep_exchange_front<T>(c, o, false))) return rc;
+  if ((rc = ensure(c->maskO, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
+  if ((rc = ensure(c->dist2, sizeof(double) * (size_t)std::max<long long>(n, 1)))) return rc;
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
+  const int nb = reduce_blocks(c);
+  T* lcb0 = (T*)c->dist2.p;      // value array for the arg-min reductions
+  if (n > 0) {
+    hipLaunchKernelGGL((k_lcb0<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b, lcb0);
+    hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
+                       (long long)c->cs.first, (long long*)nullptr, (Best*)c->partial.p);
+  }
+  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0);
+  SBO_HIP(hipEventRecord(c->ev[2], c->stream));
+  for (int cc = 1; cc < q; ++cc) {
+    uint8_t* O = (uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
+    if ((rc = goose_sets_d<T>(c, o, cc, O))) return rc;
+  }
+  SBO_HIP(hipEventRecord(c->ev[3], c->stream));
+  for (int cc = 1; cc < q; ++cc) {
+    const uint8_t* O = (const uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
+    if (n > 0)
+      hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, O, n,
+                         (long long)c->cs.first, &sc->count_set[cc - 1], (Best*)c->partial.p);
+    hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, cc);
+  }
+  SBO_HIP(hipGetLastError());
+  SweepScalars h;
+  SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  unsigned long long Lk[kMaxQ];
+  SBO_HIP(hipMemcpyAsync(Lk, c->Lmax.p, sizeof(Lk), hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  c->masks_valid = true;
+  c->last_sweep = 2;
+
+  memset(res, 0, sizeof(*res));
+  res->count_S = h.count_S;
+  res->count_U = h.count_U;
+  for (int i = 0; i < q; ++i) memcpy(&res->L[i], &Lk[i], 8);
+  res->safe_min_index = res->target_index = res->explore_index = -1;
+  for (int cc = 1; cc < q; ++cc) res->target_index_c[cc - 1] = -1;
+  if (h.count_S == 0) return fail(SBO_E_EMPTY_SAFE_SET, "safe set S_t is empty on this candidate set");
+  res->safe_min_index = h.arg_idx[0];
+  res->safe_min_lcb = h.arg_val[0];
+  coords_of(c, res->safe_min_index, res->safe_min_x);
+  int best_c = 0;
+  double best_lcb = 0.0;
+  for (int cc = 1; cc < q; ++cc) {
+    res->count_O[cc - 1] = h.count_set[cc - 1];
+    res->target_index_c[cc - 1] = h.arg_idx[cc];
+    res->target_lcb_c[cc - 1] = h.arg_idx[cc] >= 0 ? h.arg_val[cc] : INFINITY;
+    // min(lcb_target) / .index(min): first minimum wins (models/GoOSE.py:110-112)
+    if (h.arg_idx[cc] >= 0 && (best_c == 0 || h.arg_val[cc] < best_lcb)) {
+      best_c = cc;
+      best_lcb = h.arg_val[cc];
+    }
+  }
+  res->target_best_c = best_c;
+  res->target_lcb = best_c ? best_lcb : INFINITY;
+  res->choose_safe_min = best_c ? (res->safe_min_lcb <= res->target_lcb) : 1;   // test/test_GoOSE.py:158
+  if (best_c) {
+    res->target_index = res->target_index_c[best_c - 1];
+    coords_of(c, res->target_index, res->target_x);
+    // explore_safeset(target): argmin_{S} ||x - target||_2 (models/GoOSE.py:116-119)
+    double* dev_t = (double*)c->scal.p + 256;
+    SBO_HIP(hipMemcpyAsync(dev_t, res->target_x, sizeof(double) * SBO_MAX_D, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_dist_to<T>(c, dev_t, lcb0))) return rc;
+    hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
+                       (long long)c->cs.first, (long long*)nullptr, (Best*)c->partial.p);
+    hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, nb, sc, kArgSlots - 1);
+    SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+    res->explore_index = h.arg_idx[kArgSlots - 1];
+    coords_of(c, res->explore_index, res->explore_x);
+  }
+  SBO_HIP(hipEventRecord(c->ev[4], c->stream));
+  SBO_HIP(hipEventSynchronize(c->ev[4]));
+  float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t04 = 0;
+  SBO_HIP(hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
+  SBO_HIP(hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
+  SBO_HIP(hipEventElapsedTime(&t23, c->ev[2], c->ev[3]));
+  SBO_HIP(hipEventElapsedTime(&t34, c->ev[3], c->ev[4]));
+  SBO_HIP(hipEventElapsedTime(&t04, c->ev[0], c->ev[4]));
+  memset(&c->prof, 0, sizeof(c->prof));
+  c->prof.posterior_ms = t01;
+  c->prof.classify_ms = t12;
+  c->prof.expander_ms = t23;
+  c->prof.argreduce_ms = t34;
+  c->prof.total_ms = t04;
+  c->prof.candidates = n;
+  c->prof.posterior_launches = (!reuse && n > 0) ? 1 : 0;
+  const double nn = c->mc.n, dd = c->mc.d;
+  c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
+  return SBO_OK;
+}
+
 }  // namespace sbo
 
 using namespace sbo;
@@ -789,8 +1123,14 @@ int sbo_sweep_safeopt(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_safeopt_result
   return c->dtype == SBO_F64 ? sweep_safeopt_t<double>(c, opts, result) : sweep_safeopt_t<float>(c, opts, result);
 }
 
-int sbo_sweep_goose(sbo_ctx*, const sbo_sweep_opts*, sbo_goose_result*) {
-  return fail(SBO_E_UNSUPPORTED, "GoOSE sweep not built yet");
+int sbo_sweep_goose(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_goose_result* result) {
+  if (!c || !opts || !result) return fail(SBO_E_INVALID, "NULL argument");
+  if (!c->has_model) return fail(SBO_E_NO_MODEL, "sbo_model_set has not been called");
+  if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
+  if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
+  if (c->world > 1) return fail(SBO_E_UNSUPPORTED, "the GoOSE sweep is single-rank in this release");
+  SBO_HIP(hipSetDevice(c->device));
+  return c->dtype == SBO_F64 ? sweep_goose_t<double>(c, opts, result) : sweep_goose_t<float>(c, opts, result);
 }
 
 int sbo_masks_get(sbo_ctx* c, int which, int cidx, uint8_t* out) {

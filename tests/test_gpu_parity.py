@@ -205,6 +205,44 @@ def test_safeopt_sweep_against_golden(engine, path):
     assert np.array_equal(res["minimizer_x"], pts[res["minimizer_index"]])
 
 
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_goose_sweep_against_golden(engine, path):
+    """GoOSE iteration (models/GoOSE.py:63-119): pessimistic safe minimum, optimistic sets O_c, target, explore point."""
+    z = np.load(path)
+    ds = synthetic.make_dataset(z["X"], z["Y"], z["hypopt"])
+    lo, hi, count = z["bound"][:, 0], z["bound"][:, 1], [int(c) for c in z["count"]]
+    q = z["Y"].shape[1]
+    engine.set_model(ds)
+    engine.set_grid(lo, hi, count)
+    res = engine.sweep_goose(float(z["b"]), quirk_L_index=bool(z["quirk"]), want_masks=True)
+    assert np.array_equal(engine.mask("S"), z["S"]) and np.array_equal(engine.mask("U"), z["U"])
+    for c in range(1, q):
+        assert np.array_equal(engine.mask("O", c), z["O"][c - 1]), f"O{c}"
+    assert res["safe_min_index"] == int(z["safe_min_index"])
+    assert abs(res["safe_min_lcb"] - float(z["safe_min_lcb"])) < 1e-9 * max(1.0, abs(float(z["safe_min_lcb"])))
+    assert np.array_equal(res["target_index_c"], z["target_index_c"])
+    assert res["target_index"] == int(z["target_index"]) and res["target_best_c"] == int(z["target_best"])
+    assert res["explore_index"] == int(z["explore_index"]) and res["choose_safe_min"] == bool(z["choose_safe_min"])
+    assert np.array_equal(res["count_O"], z["O"].sum(1))
+    if res["target_index"] >= 0:
+        pts = oracle.grid_points(lo, hi, count)
+        assert np.array_equal(res["target_x"], pts[res["target_index"]])
+        assert np.array_equal(res["explore_x"], pts[res["explore_index"]])
+
+
+def test_goose_sweep_explicit_points(engine):
+    cfg = synthetic.make_config("C", n=64)
+    pts = np.random.default_rng(9).uniform(cfg["bound"][:, 0], cfg["bound"][:, 1], size=(3000, 2))
+    ref = oracle.goose_sweep(pts, cfg["ds"], cfg["b"])
+    engine.set_model(cfg["ds"])
+    engine.set_points(pts)
+    res = engine.sweep_goose(cfg["b"], want_masks=True)
+    for c in (1, 2):
+        assert np.array_equal(engine.mask("O", c), ref["O"][c - 1])
+    assert res["safe_min_index"] == ref["safe_min_index"] and res["target_index"] == ref["target_index"]
+    assert res["explore_index"] == ref["explore_index"]
+
+
 def test_safeopt_sweep_explicit_points_exhaustive_expander(engine):
     cfg = synthetic.make_config("A")
     lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]

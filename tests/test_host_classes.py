@@ -1,0 +1,153 @@
+"""Host-side mirrors of the reference classes (GP_Safe.GP, SafeOpt.BO, GoOSE.BO): CPU logic here, device-backed
+behaviour under the gpu marker."""
+import numpy as np
+import pytest
+
+import oracle
+from safebo_amd import GoOSE, SafeOpt, synthetic
+from safebo_amd.GP_Safe import GP
+
+
+def benoit_f(u, noise=0):
+    return u[0] ** 2 + u[1] ** 2 + u[0] * u[1]
+
+
+def benoit_g(u, noise=0):
+    return -(1. - u[0] + u[1] ** 2 + 2. * u[1])
+
+
+BOUND = np.array([[-.6, 1.5], [-1., 1.]])
+
+
+def _init(cls, n=12, grid=(50, 50), b=3.0, fixed=True, **kw):
+    m = cls([benoit_f, benoit_g], BOUND, b, grid=grid, **kw)
+    X, Y = m.Data_sampling(n, np.array([1.4, -.8]), 0.3)
+    if fixed:
+        m.fixed_hyper = synthetic.default_hypopt(2, 2)
+    m.GP_initialization(X, Y, "RBF", multi_hyper=5, var_out=True)
+    return m
+
+
+def test_gp_state_matches_oracle_restatement():
+    m = _init(SafeOpt.BO)
+    ds = oracle.make_inference_dataset(m.X, m.Y, m.hypopt)
+    for k in ("X_mean", "X_std", "Y_mean", "Y_std", "X_norm", "Y_norm", "hypopt"):
+        assert np.array_equal(np.asarray(m.inference_datasets[k]), ds[k]), k
+    for a, b in zip(m.inference_datasets["invKopt"], ds["invKopt"]):
+        assert np.array_equal(a, b)
+    assert m.n_point == 12 and m.nx_dim == 2 and m.ny_dim == 2 and m.n_fun == 2
+    # every sample lies in the ball of radius 0.3 around x_0 (models/GP_Safe.py:30-50)
+    assert np.all(np.linalg.norm(m.X - np.array([1.4, -.8]), axis=1) <= 0.3 + 1e-12)
+
+
+def test_nll_matches_direct_formula():
+    m = _init(SafeOpt.BO)
+    hyper = np.array([-0.3, 0.2, 0.1, -3.0])
+    y = m.Y_norm[:, 1:2]
+    K = m.Cov_mat("RBF", m.X_norm, m.X_norm, np.exp(2 * hyper[:2]), np.exp(2 * hyper[2])) + (np.exp(2 * hyper[3]) + 1e-8) * np.eye(12)
+    want = float((y.T @ np.linalg.solve(K, y))[0, 0] + np.linalg.slogdet(K)[1])      # models/GP_Safe.py:186-190
+    assert m.negative_loglikelihood(hyper, m.X_norm, y) == pytest.approx(want, rel=1e-10)
+
+
+def test_reference_error_messages():
+    m = _init(SafeOpt.BO)
+    with pytest.raises(ValueError, match="W and X_norm dimension"):
+        m.Cov_mat("RBF", m.X_norm, m.X_norm, np.ones(3), 1.0)
+    with pytest.raises(ValueError, match="no kernel with name"):
+        m.Cov_mat("Matern", m.X_norm, m.X_norm, np.ones(2), 1.0)
+    with pytest.raises(ValueError):
+        m.calc_Cov_mat("RBF", m.X_norm, np.zeros(2), np.ones(3), 1.0)
+
+
+def test_hyperparameter_fit_stays_in_reference_bounds():
+    m = _init(SafeOpt.BO, n=6, fixed=False)
+    m.de_options = {"seed": 1, "maxiter": 15, "tol": 1e-3}
+    m.add_sample(np.array([1.3, -0.7]), m.calculate_plant_outputs(np.array([1.3, -0.7])))
+    assert m.n_point == 7 and m.hypopt.shape == (4, 2)
+    assert np.all(m.hypopt[:3] >= -1.5) and np.all(m.hypopt[:3] <= 1.5)          # models/GP_Safe.py:205-206
+    assert np.all(m.hypopt[3] >= -5.0) and np.all(m.hypopt[3] <= -2.0)
+    for i in range(2):
+        K = m.Cov_mat("RBF", m.X_norm, m.X_norm, np.exp(2 * m.hypopt[:2, i]), np.exp(2 * m.hypopt[2, i])) \
+            + (np.exp(2 * m.hypopt[3, i]) + np.finfo(np.float32).eps) * np.eye(7)
+        assert np.allclose(m.invKopt[i] @ K, np.eye(7), atol=1e-6)
+
+
+def test_infnorm_mean_grad_matches_oracle():
+    m = _init(GoOSE.BO)
+    pts = np.array([[1.2, -0.5], [0.1, 0.3], [1.45, -0.9]])
+    want = oracle.mean_grad_infnorm(pts, m.inference_datasets)
+    for p in range(3):
+        for i in range(2):
+            assert m.infnorm_mean_grad(pts[p], i) == pytest.approx(want[p, i], rel=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------------------ device
+@pytest.mark.gpu
+def test_bo_bounds_single_and_batched():
+    m = _init(SafeOpt.BO)
+    pts = np.random.default_rng(0).uniform(BOUND[:, 0], BOUND[:, 1], size=(300, 2))
+    om, ov = oracle.gp_inference(pts, m.inference_datasets)
+    ol, ou = oracle.bounds(om, ov, 3.0)
+    assert np.max(np.abs(m.lcb(pts, 1) - ol[:, 1])) < 1e-10            # vmap(GP_m.lcb, (0, None))(points, 1)
+    assert np.max(np.abs(m.ucb(pts, 0) - ou[:, 0])) < 1e-10
+    assert abs(m.mean(pts[7], 0) - om[7, 0]) < 1e-10 and np.ndim(m.lcb(pts[7], 1)) == 0
+    mean, var = m.GP_inference(pts[3], m.inference_datasets)          # reference call shape (models/SafeOpt.py:30)
+    assert mean.shape == (2,) and np.max(np.abs(mean - om[3])) < 1e-10 and np.max(np.abs(var - ov[3])) < 1e-10
+    assert m.lcb_constraint_min(pts[3]) == pytest.approx(ol[3, 1], abs=1e-10)
+    m.var_out = False
+    assert m.GP_inference(pts[3], m.inference_datasets) == pytest.approx(om[3, 0], abs=1e-10)
+
+
+@pytest.mark.gpu
+def test_safeopt_methods_follow_oracle():
+    m = _init(SafeOpt.BO, n=20, grid=(60, 50))
+    pts = oracle.grid_points(BOUND[:, 0], BOUND[:, 1], [60, 50])
+    ref = oracle.safeopt_sweep(pts, m.inference_datasets, 3.0)
+    x, std = m.Minimizer()
+    assert np.array_equal(x, pts[ref["minimizer_index"]]) and std == pytest.approx(ref["minimizer_std"], rel=1e-9)
+    x, std = m.Expander()
+    assert np.array_equal(x, pts[ref["expander_best_index"]]) and std == pytest.approx(ref["expander_best_std"], rel=1e-9)
+    x, val = m.minimize_obj_ucb()
+    assert val == pytest.approx(ref["u_star"], rel=1e-10)
+    assert m.maximize_infnorm_mean_grad(1) == pytest.approx(ref["L"][1], rel=1e-9)
+    masks = m.masks()
+    assert np.array_equal(masks["S"].ravel(), ref["S"]) and np.array_equal(masks["G1"].ravel(), ref["G"][0])
+    xx = np.concatenate([pts[10], pts[500]])
+    want = oracle.bounds(*oracle.gp_inference(pts[10:11], m.inference_datasets), 3.0)[1][0, 1] \
+        - 2.5 * np.linalg.norm(pts[10] - pts[500] + 1e-8)
+    assert m.Lipschitz_continuity_constraint(xx, 1, 2.5) == pytest.approx(want, abs=1e-9)
+
+
+@pytest.mark.gpu
+def test_goose_methods_follow_oracle():
+    m = _init(GoOSE.BO, n=20, grid=(48, 40), b=2.0)
+    pts = oracle.grid_points(BOUND[:, 0], BOUND[:, 1], [48, 40])
+    ref = oracle.goose_sweep(pts, m.inference_datasets, 2.0)
+    x, lcb = m.minimize_obj_lcb()
+    assert np.array_equal(x, pts[ref["safe_min_index"]]) and lcb == pytest.approx(ref["safe_min_lcb"], abs=1e-9)
+    t, tl = m.Target()
+    assert np.array_equal(t, pts[ref["target_index"]]) and tl == pytest.approx(ref["target_lcb"], abs=1e-9)
+    assert np.array_equal(m.explore_safeset(t), pts[ref["explore_index"]])
+    other = np.array([0.2, 0.1])            # an arbitrary target goes through the host fallback
+    d = np.where(ref["S"], np.linalg.norm(pts - other, axis=1), np.inf)
+    assert np.array_equal(m.explore_safeset(other), pts[int(np.argmin(d))])
+
+
+@pytest.mark.gpu
+def test_safeopt_campaign_plumbing_config_A():
+    """BASELINE.json configs[0]: Benoit 2-D, 50x50 grid, n <= 20 -- the loop of test/test_SafeOpt.py:135-186 with
+    its decision rule (:153-158) and stopping test (:178), three iterations, hyper-parameters fitted by DE."""
+    m = _init(SafeOpt.BO, n=4, grid=(50, 50), fixed=False)
+    m.de_options = {"seed": 0, "maxiter": 10, "tol": 1e-2}
+    for it in range(3):
+        minimizer, std_min = m.Minimizer()
+        expander, std_exp = m.Expander()
+        x_new = minimizer if std_min > std_exp else expander
+        assert np.all(x_new >= BOUND[:, 0]) and np.all(x_new <= BOUND[:, 1])
+        assert m.lcb(x_new, 1) >= 0.0                         # the chosen point is in the safe set
+        y = m.calculate_plant_outputs(x_new)
+        assert y[1] >= -0.05                                  # and (nearly) safe on the true plant
+        m.add_sample(x_new, y)
+        if std_exp < 0.01 and std_min < 0.01:
+            break
+    assert m.n_point == 4 + it + 1
