@@ -29,8 +29,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6      # AMD MI355X datasheet, FP64 matrix == FP64 vector (guide has no f64 row)
-FP64_MFMA_MEASURED_TFLOPS = 47.9    # v_mfma_f64_16x16x4_f64 back-to-back at 2.39 GHz (profiles/r01_mfma_probe.txt)
+FP64_MFMA_MEASURED_TFLOPS = {"v_mfma_f64_4x4x4_4b_f64": 75.6, "v_mfma_f64_16x16x4_f64": 47.9}   # profiles/r01_mfma_probe.txt
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, f32-input MFMA
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per K1 launch from rocprofv3 --pmc
 
 
 def parse_args():
@@ -40,7 +41,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="B", help="synthetic config (B = BASELINE.json configs[1]; H = 4096^2, n = 512)")
     ap.add_argument("--n", type=int, default=None, help="override the number of observations")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 19, help="candidates timed by the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="candidates timed by the CPU baseline (0 = skip)")
     ap.add_argument("--engine", type=int, default=None, help="fp64 contraction engine override (0 MFMA, 1 VALU)")
     return ap.parse_args()
 
@@ -66,9 +67,17 @@ def cpu_baseline(cfg, count, sample):
         int(np.argmax(np.where(M, var[:, 0], -np.inf)))
     dt = time.perf_counter() - t0
     del U
-    return {"value": sample / dt, "unit": "candidates/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+    threads = len(os.sched_getaffinity(0))
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"]
+        threads = max(blas) if blas else threads
+    except Exception:
+        pass
+    return {"value": sample / dt, "unit": "candidates/s", "cores": threads, "kind": "port",
             "sample": f"first {sample} candidates of the same grid: posterior + bounds + S/U/M masks + u* + arg-max "
-                      f"in NumPy (OpenBLAS, all cores), {dt:.2f} s; the oracle's quadratic brute-force expander is excluded"}
+                      f"in NumPy ({threads} BLAS threads, {len(os.sched_getaffinity(0))} cores visible), {dt:.2f} s; "
+                      f"the oracle's quadratic brute-force expander is excluded"}
 
 
 def main():
@@ -139,6 +148,10 @@ def main():
         k1 = float(np.mean(k1_ms))
         achieved = float(np.mean(k1_flops)) / (k1 * 1e-3) / 1e12
         peak = FP64_MATRIX_PEAK_TFLOPS if cfg["dtype"] == "f64" else FP32_MATRIX_PEAK_TFLOPS
+        traffic = None
+        if os.path.exists(PMC_TRAFFIC_FILE):       # collected by tools/gpu_bench_profile.sh in separate --pmc passes
+            rec = json.load(open(PMC_TRAFFIC_FILE)).get(f"{args.config}:n={cfg['ds']['X_norm'].shape[0]}")
+            traffic = rec["hbm_bytes_per_launch"] if rec else None
         out = {
             "metric": "candidate-points/sec, SafeOpt posterior+safe-set sweep",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -151,7 +164,7 @@ def main():
                        "result": {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
                                   "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "kernel": "k_posterior", "kernel_ms": k1,
+                         "traffic": traffic, "kernel": "k_posterior_grid", "kernel_ms": k1,
                          "algorithmic_flops_per_candidate": float(np.mean(k1_flops)) / (n_total // world),
                          "peak_source": "AMD MI355X datasheet FP64 matrix (no f64 row in MI355X_MICROARCH.md)" if cfg["dtype"] == "f64" else "MI355X_MICROARCH.md f32 MFMA",
                          "peak_measured_mfma_f64": FP64_MFMA_MEASURED_TFLOPS if cfg["dtype"] == "f64" else None,
