@@ -211,6 +211,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->k1_wgs_per_cu = (int)value;
     return SBO_OK;
   }
+  if (!strcmp(key, "edt_tiled")) {
+    c->edt_tiled = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "posterior_path")) {
     if (value != 0 && value != 1) return fail(SBO_E_INVALID, "posterior_path must be 0 (auto) or 1 (generic)");
     c->posterior_path = (int)value;

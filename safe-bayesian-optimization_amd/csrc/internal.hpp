@@ -90,6 +90,7 @@ struct sbo_ctx {
   // options
   int engine = 0;      // 0 MFMA, 1 VALU (fp64 contraction engine)
   int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
+  int edt_tiled = 0;       // 1: LDS-tiled lock-step form of the last-axis expander scan (slower on measured configs)
   int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
   // comm
   void* comm = nullptr;  // ncclComm_t

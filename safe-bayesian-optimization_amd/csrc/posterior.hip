@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int npad = mc.npad, nfr = npad >> 2, nb = npad >> 4;
   T* E1f = reinterpret_cast<T*>(smem);            // [S][npad]   sf2 * prod_{a>=1} table, in fragment-slot order
-  T* part = E1f + (size_t)S * npad;               // [NC][kWaves * 4][P] partial sums per (wave, k-slot)
+  T* part = E1f + (size_t)S * npad + 8;           // [NC][kWaves * 4][P] partial sums per (wave, k-slot); +8: prefetch slack
   __shared__ unsigned int line_row[2][S][kMaxD];  // per strip: row index into each remaining-axis table (x2: the
                                                   // epilogue of tile i overlaps phase 0 of tile i+1)
 
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, con
     __syncthreads();
 
     // ---------------- phase 2: block-triangular contraction, B-fragments formed on the fly ----------------
-    const T* E0_t = E0f + (size_t)out * gt.e0_stride + (size_t)t0 * nfr * 64 + lane;
+    const T* E0_t = E0f + (size_t)out * gt.e0_stride + (size_t)t0 * nfr * 64;   // wave-uniform base, lane added per load
     T quad[S], m0[S], ms[S][D];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -363,25 +363,31 @@ __global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, con
       const T* fp = F_o + (size_t)(I * (I + 1) / 2) * 4 * 64;
       const T* ep = E0_t;
       a_t a_nx = MM<T>::load_a(fp, lane);
-      T e_nx = *ep;
+      T e_nx = ep[lane];
+      const T* e1p = E1f + slot;                   // per-line factors of step st at e1p[s * npad + st * 4]
+      T e1_nx[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) e1_nx[s] = e1p[s * npad];
       const bool is_top = (I == my_top);
       for (int J = 0; J <= I; ++J) {
         const bool dots = (J <= tmin) ? (is_top && (J % kWaves) == wave) : (J == I);
-        const T* e1p = E1f + J * 16 + slot;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const a_t a = a_nx;
-          const T e_cur = e_nx;
-          fp += 64;
-          ep += 64;
-          a_nx = MM<T>::load_a(fp, lane);
-          e_nx = *ep;
           T b[S];
 #pragma unroll
-          for (int s = 0; s < S; ++s) {
-            b[s] = e_cur * e1p[s * npad + kk * 4];
-            acc[s] = MM<T>::mfma(a, b[s], acc[s]);
-          }
+          for (int s = 0; s < S; ++s) b[s] = e_nx * e1_nx[s];
+          // operands of the next step (global fragments and LDS factors) fly behind this step's MFMAs; the reads
+          // past the row's last step stay inside the padded buffers / the LDS allocation
+          fp += 64;
+          ep += 64;
+          e1p += 4;
+          a_nx = MM<T>::load_a(fp, lane);
+          e_nx = ep[lane];
+#pragma unroll
+          for (int s = 0; s < S; ++s) e1_nx[s] = e1p[s * npad];
+#pragma unroll
+          for (int s = 0; s < S; ++s) acc[s] = MM<T>::mfma(a, b[s], acc[s]);
           if (dots) {
             const T* ax = AX_o + (J * 16 + kk * 4) * NC_AX(D);
 #pragma unroll
@@ -577,7 +583,7 @@ static int launch_posterior_grid_t(sbo_ctx* c) {
   if ((rc = ensure(c->AXg, sizeof(T) * (size_t)q * npad * (1 + D)))) return rc;
   hipLaunchKernelGGL((k_build_ax<T>), dim3(1, q), dim3(256), 0, c->stream, mc, (const T*)c->alpha.p, (const T*)c->Xn.p, D,
                      (T*)c->AXg.p);
-  const size_t lds = sizeof(T) * ((size_t)S * npad + (size_t)(2 + D) * kWaves * 4 * P);
+  const size_t lds = sizeof(T) * ((size_t)S * npad + 8 + (size_t)(2 + D) * kWaves * 4 * P);
   auto kern = k_posterior_grid<T, S, D>;
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long long tiles = ntile0 * ((gt.nlines + S - 1) / S);
