@@ -292,14 +292,55 @@ __device__ __forceinline__ double edt_scan_point(const double* __restrict__ Din,
 
 __global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din, double* __restrict__ Dout, long long n,
                                                   long long stride, int cnt, double h, const SweepScalars* sc, int c,
-                                                  const unsigned long long* Lkeys, int lidx) {
+                                                  const unsigned long long* Lkeys, int lidx, int uncapped) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const double rmax = sc->rmax_key[c] ? ord_val(sc->rmax_key[c]) : 0.0;
-  const double cap = (L > 0) ? rmax / L * 1.000001 + 1e-6 : kInfD;
+  const double cap = (L > 0 && !uncapped) ? rmax / L * 1.000001 + 1e-6 : kInfD;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
     const int ia = (int)((g / stride) % cnt);
     Dout[g] = edt_scan_point(Din, g, stride, cnt, ia, h, cap);
   }
+}
+
+// Coarse pre-decision for the expander query.  The U mask is OR-reduced over cells of kCoarse^d candidates and the
+// exact transform of that small mask gives, for any candidate g in cell C, the sandwich
+//     dC - delta <= dist(g, U) <= dC + delta,   delta = (kCoarse - 1) * sqrt(sum_a h_a^2)
+// (dC = distance between cell origins to the nearest U-holding cell).  Candidates whose verdict is the same at both
+// ends skip the per-candidate scan of the fine transform; only the shell around the boundary of G_c scans.
+constexpr int kCoarse = 8;
+struct CoarseGrid {
+  int enabled;
+  int d;
+  long long count[kMaxD];    // fine counts
+  long long ccount[kMaxD];   // coarse counts
+  double delta;
+  const double* Dc;          // squared coarse distances [prod ccount]
+};
+
+__global__ __launch_bounds__(256) void k_coarsen_mask(const uint8_t* __restrict__ U, long long n, const CoarseGrid cg,
+                                                      uint8_t* __restrict__ Uc) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    if (!U[g]) continue;
+    long long f = g, cell = 0, cs = 1;
+    for (int a = 0; a < cg.d; ++a) {
+      const long long i = f % cg.count[a];
+      f /= cg.count[a];
+      cell += (i / kCoarse) * cs;
+      cs *= cg.ccount[a];
+    }
+    Uc[cell] = 1;   // idempotent store
+  }
+}
+
+__device__ __forceinline__ double coarse_dist2(const CoarseGrid& cg, long long gg) {
+  long long f = gg, cell = 0, cs = 1;
+  for (int a = 0; a < cg.d; ++a) {
+    const long long i = f % cg.count[a];
+    f /= cg.count[a];
+    cell += (i / kCoarse) * cs;
+    cs *= cg.ccount[a];
+  }
+  return cg.Dc[cell];
 }
 
 // Reference expression for one (g, h) pair, unfused, in the oracle's order:
@@ -326,7 +367,8 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
                                                     double h, int d, double xscale, const T* __restrict__ mean_c,
                                                     const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
-                                                    uint8_t* __restrict__ G, long long* __restrict__ amb) {
+                                                    uint8_t* __restrict__ G, long long* __restrict__ amb,
+                                                    const CoarseGrid cg) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const bool anyU = sc->count_U > 0;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
@@ -341,6 +383,13 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
         const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
         const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
         const long long gg = goff + g;   // index in the transform (whole grid when ranks share it)
+        if (cg.enabled) {
+          const double dC = sqrt(coarse_dist2(cg, gg));
+          const double dhi = dC * (1.0 + 1e-9) + cg.delta, dlo = fmax(0.0, dC * (1.0 - 1e-9) - cg.delta);
+          const double tolc = 1e-12 * (fabs(ucb) + L * dhi);
+          if (ucb - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { G[g] = 1; continue; }     // within the radius for sure
+          if (ucb - L * (dlo - eps_abs - 1e-11 * dlo) < -tolc) { G[g] = 0; continue; }    // beyond it for sure
+        }
         const int ia = (int)((gg / stride) % cnt);
         const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it the verdict is "sure true"
         const double best = (cnt > 1) ? edt_scan_point(Din, gg, stride, cnt, ia, h, cap, thr > 0 ? thr * thr : -1.0) : Din[gg];
@@ -840,9 +889,47 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     for (int a = 1; a < d - 1; ++a) {
       hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nt + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
                          (const double*)din, dout, nt, stride, (int)c->cs.count[a], c->cs.step[a],
-                         (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx);
+                         (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, 0);
       std::swap(din, dout);
       stride *= c->cs.count[a];
+    }
+    // coarse transform (whole grid, uncapped, tiny): lets most candidates decide without the per-candidate scan
+    CoarseGrid cg;
+    memset(&cg, 0, sizeof(cg));
+    cg.d = d;
+    bool coarse_ok = d >= 2 && nt >= (1ll << 16);
+    long long nc = 1;
+    double h2 = 0.0;
+    for (int a = 0; a < d; ++a) {
+      cg.count[a] = c->cs.count[a];
+      cg.ccount[a] = (c->cs.count[a] + kCoarse - 1) / kCoarse;
+      nc *= cg.ccount[a];
+      h2 += c->cs.step[a] * c->cs.step[a];
+      if (c->cs.count[a] < 4 * kCoarse) coarse_ok = false;
+    }
+    if (coarse_ok) {
+      cg.enabled = 1;
+      cg.delta = (kCoarse - 1) * std::sqrt(h2) * (1.0 + 1e-9);
+      if ((rc = ensure(c->coarse, (size_t)nc * (1 + 2 * sizeof(double)) + 64))) return rc;
+      double* dc0 = (double*)c->coarse.p;
+      double* dc1 = dc0 + nc;
+      uint8_t* Uc = (uint8_t*)(dc1 + nc);
+      SBO_HIP(hipMemsetAsync(Uc, 0, (size_t)nc, c->stream));
+      hipLaunchKernelGGL(k_coarsen_mask, dim3((unsigned)std::min<long long>((nt + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
+                         Uall, nt, cg, Uc);
+      const int cc0 = (int)cg.ccount[0];
+      const long long clines = nc / cc0;
+      hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((clines + 3) / 4)), dim3(256), 0, c->stream, (const uint8_t*)Uc, clines, cc0,
+                         c->cs.step[0] * kCoarse, dc0);
+      long long cstride = cc0;
+      for (int a = 1; a < d; ++a) {
+        hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
+                           (const double*)dc0, dc1, nc, cstride, (int)cg.ccount[a], c->cs.step[a] * kCoarse,
+                           (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, 1);
+        std::swap(dc0, dc1);
+        cstride *= cg.ccount[a];
+      }
+      cg.Dc = dc0;
     }
     double xscale = 0.0;
     for (int a = 0; a < d; ++a) xscale = std::max(xscale, std::max(std::fabs(c->cs.lo[a]), std::fabs(c->cs.hi[a])));
@@ -857,7 +944,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       hipLaunchKernelGGL((k_edt_decide<T>), dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0,
                          c->stream, (const double*)din, n, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c,
                          (T)o->b, (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
-                         (long long*)c->amb.p);
+                         (long long*)c->amb.p, cg);
     }
   } else {
     if (n > (1ll << 17))
