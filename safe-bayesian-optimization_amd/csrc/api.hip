@@ -120,7 +120,7 @@ static int model_upload(sbo_ctx* c, const std::vector<double>& F_all /* [q][n][n
               const int col = 16 * J + MM<T>::jslot(kk, k);
               double v = 0.0;
               if (row < n && col < n && col <= row) v = F[(size_t)row * n + col];
-              dst[(((size_t)I * (I + 1) / 2 + J) * 4 + kk) * 64 + MM<T>::pack_pos(r, k)] = v;
+              dst[((size_t)I * (I + 1) / 2 + J) * 256 + MM<T>::pack_pos(r, k, kk)] = v;
             }
   }
   int rc;
@@ -216,7 +216,7 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     return SBO_OK;
   }
   if (!strcmp(key, "posterior_path")) {
-    if (value != 0 && value != 1) return fail(SBO_E_INVALID, "posterior_path must be 0 (auto) or 1 (generic)");
+    if (value < 0 || value > 2) return fail(SBO_E_INVALID, "posterior_path must be 0 (auto), 1 (generic) or 2 (generic, chunked)");
     c->posterior_path = (int)value;
     c->posterior_valid = false;
     return SBO_OK;

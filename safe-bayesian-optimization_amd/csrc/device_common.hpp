@@ -20,24 +20,34 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 //           A-fragment (its four lane-quads read identical addresses, so the load still moves 128 unique bytes)
 //           and block blk the candidates 4blk..4blk+3 of the natural B-fragment: no lane movement at all.
 // jslot(kk, slot) is the observation offset inside a 16-block carried by k-step kk / k-slot `slot`;
-// pack_pos(r, k) is where element (row r, k-slot k) of a 16x4 fragment sits in its 64-element packed image,
-// chosen so that one lane's operands are contiguous (f64: its 4 row-groups = 32 bytes, two dwordx4 loads).
+// pack_pos(r, k, kk) is where element (row r, k-slot k, k-step kk) of a 16x16 block sits in its 256-element packed
+// image, chosen so that one lane's operands are contiguous (f64: the 4 row-groups of a k-step = 32 bytes, two
+// dwordx4 loads; f32: the 4 k-steps of a block = 16 bytes, one dwordx4 load).
 template <typename T> struct MM;
 template <> struct MM<float> {
   using acc_t = f4_t;
   using a_t = float;
-  static __device__ __forceinline__ a_t load_a(const float* frag, int lane) { return frag[lane]; }
+  // block = the 256 packed elements of one (I, J) block; a lane's four k-steps are contiguous (one dwordx4)
+  static __device__ __forceinline__ a_t load_a(const float* block, int lane, int kk) { return block[lane * 4 + kk]; }
+  static __device__ __forceinline__ void load_a4(const float* block, int lane, a_t (&a)[4]) {
+    const f4_t v = *reinterpret_cast<const f4_t*>(block + lane * 4);
+    a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+  }
   static __device__ __forceinline__ acc_t mfma(a_t a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
   static __host__ __device__ __forceinline__ int jslot(int kk, int slot) { return 4 * slot + kk; }
-  static __host__ __device__ __forceinline__ int pack_pos(int r, int k) { return k * 16 + r; }
+  static __host__ __device__ __forceinline__ int pack_pos(int r, int k, int kk) { return (k * 16 + r) * 4 + kk; }
 };
 template <> struct MM<double> {
   using acc_t = d4_t;
   using a_t = d4_t;   // rows {i, 4+i, 8+i, 12+i} (i = lane&3) at k-slot lane>>4
-  static __device__ __forceinline__ a_t load_a(const double* frag, int lane) {
-    return *reinterpret_cast<const d4_t*>(frag + (((lane >> 4) << 2) + (lane & 3)) * 4);
+  static __device__ __forceinline__ a_t load_a(const double* block, int lane, int kk) {
+    return *reinterpret_cast<const d4_t*>(block + kk * 64 + (((lane >> 4) << 2) + (lane & 3)) * 4);
+  }
+  static __device__ __forceinline__ void load_a4(const double* block, int lane, a_t (&a)[4]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) a[kk] = load_a(block, lane, kk);
   }
   static __device__ __forceinline__ acc_t mfma(a_t a, double b, acc_t c) {
     c[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], b, c[0], 0, 0, 0);
@@ -47,7 +57,7 @@ template <> struct MM<double> {
     return c;
   }
   static __host__ __device__ __forceinline__ int jslot(int kk, int slot) { return 4 * kk + slot; }
-  static __host__ __device__ __forceinline__ int pack_pos(int r, int k) { return (k * 4 + (r & 3)) * 4 + (r >> 2); }
+  static __host__ __device__ __forceinline__ int pack_pos(int r, int k, int kk) { return kk * 64 + (k * 4 + (r & 3)) * 4 + (r >> 2); }
 };
 
 // unfused arithmetic where the oracle's rounding sequence is part of the contract

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_posterior(const ModelConst mc, const Ca
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int st = J * 4 + kk;
-          const typename MM<T>::a_t a = MM<T>::load_a(fp + (size_t)st * 64, lane);
+          const typename MM<T>::a_t a = MM<T>::load_a(fp + (size_t)J * 256, lane, kk);
 #pragma unroll
           for (int s = 0; s < S; ++s) {
             const T b = Kf[((size_t)s * nfr + st) * 64 + lane];
@@ -188,6 +188,202 @@ __global__ __launch_bounds__(256) void k_posterior(const ModelConst mc, const Ca
       }
     }
     // wave max -> one atomic per workgroup (values are >= 0, so the raw bit pattern orders correctly)
+    double gd = (double)gn;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double other = __shfl_xor(gd, o);
+      gd = other > gd ? other : gd;
+    }
+    if (tid == 0) atomicMax(&Lmax[out], (unsigned long long)__double_as_longlong(gd));
+  }
+}
+
+// =====================================================================================================
+// K1c: generic candidates (explicit lists, ragged shards), any n.  The K* tile of all n observations does not fit
+// LDS once n is large (n = 2048 x 64 candidates x 4 B = 512 KiB), so the triangle is walked in chunks of CB
+// row/column blocks: for row chunk Ic every wave keeps RW row blocks x 4 strips of accumulators in registers and
+// the column chunks Jc <= Ic are generated into LDS one after the other (K* of a column chunk is therefore
+// re-generated for every row chunk at or above it -- (nc+1)/2 times on average -- which costs VALU exp() work
+// but keeps 64 candidates per workgroup, i.e. four MFMAs per A-fragment load instead of one).
+// =====================================================================================================
+template <typename T> struct ChunkCfg;
+template <> struct ChunkCfg<float> { static constexpr int CB = 16, RW = 4; };    // 64 KiB K* chunk, 64 acc VGPRs
+template <> struct ChunkCfg<double> { static constexpr int CB = 8, RW = 2; };    // 64 KiB K* chunk, 64 acc VGPRs
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_posterior_chunked(const ModelConst mc, const CandSpec cs,
+                                                           const T* __restrict__ Fpk, size_t fpk_stride,
+                                                           const T* __restrict__ As, const T* __restrict__ sqA,
+                                                           const T* __restrict__ alpha, const T* __restrict__ Xn,
+                                                           T* __restrict__ mean_out, T* __restrict__ var_out,
+                                                           unsigned long long* __restrict__ Lmax) {
+  using acc_t = typename MM<T>::acc_t;
+  using a_t = typename MM<T>::a_t;
+  constexpr int S = kWaves, P = 16 * S;
+  constexpr int CB = ChunkCfg<T>::CB, RW = ChunkCfg<T>::RW, RC = RW * kWaves;
+  static_assert(RC == CB, "row and column chunks are aligned");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* Kf = reinterpret_cast<T*>(smem);              // [S][CB * 4][64]  K* fragments of the current column chunk
+  T* qpart = Kf + (size_t)S * CB * 4 * 64;         // [kWaves][P]
+  T* mpart = qpart + kWaves * P;                   // [P][1 + D]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pp = lane & 15, slot = lane >> 4;
+  const int out = blockIdx.y;
+  const long long tile0 = (long long)blockIdx.x * P;
+  const int nb = mc.npad >> 4;
+  const int nc = (nb + CB - 1) / CB;               // chunks per side
+
+  // this lane's candidate for the generation phases: strip = wave, candidate pp, k-slot `slot`
+  long long gcand = tile0 + wave * 16 + pp;
+  if (gcand >= cs.n_local) gcand = cs.n_local - 1;  // clamp: computed, never stored
+  T B[D];
+  T sqB = 0;
+  {
+    double xr[D];
+    cand_coords<D>(cs, gcand, xr);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const T xn = ((T)xr[a] - (T)mc.X_mean[a]) / (T)mc.X_std[a];   // GP_Safe.py:326
+      B[a] = xn * (T)mc.vinv[out][a];                                // GP_Safe.py:116
+      sqB += B[a] * B[a];
+    }
+  }
+  const T sf2 = (T)mc.sf2[out];
+  const T* As_o = As + (size_t)out * mc.npad * D;
+  const T* sqA_o = sqA + (size_t)out * mc.npad;
+  const T* al_o = alpha + (size_t)out * mc.npad;
+  const T* F_o = Fpk + (size_t)out * fpk_stride;
+  T m0 = 0, ms[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) ms[a] = 0;
+  T quad[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) quad[s] = 0;
+
+  for (int Ic = 0; Ic < nc; ++Ic) {
+    acc_t acc[RW][S];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int s = 0; s < S; ++s) acc[r][s] = acc_t{0, 0, 0, 0};
+    const bool with_dots = (Ic == nc - 1);          // the last row chunk sees every column chunk exactly once
+    for (int Jc = 0; Jc <= Ic; ++Jc) {
+      // ---- generate K* fragments of column chunk Jc (strip = wave) ----
+      __syncthreads();                              // previous chunk's readers are done
+      const int Jlo = Jc * CB, Jhi = (Jlo + CB < nb) ? Jlo + CB : nb;
+      T* kf_w = Kf + (size_t)wave * CB * 4 * 64 + lane;
+      for (int jl = 0; jl < (Jhi - Jlo) * 4; ++jl) {
+        const int jj = Jlo * 4 + jl;
+        const int j = ((jj >> 2) << 4) + MM<T>::jslot(jj & 3, slot);
+        T dot = 0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) dot = fma(As_o[j * D + a], B[a], dot);
+        const T dist = (T(-2) * dot + sqA_o[j]) + sqB;               // GP_Safe.py:119 (expanded form)
+        const T k = sf2 * exp_t<T>(T(-0.5) * dist);                  // GP_Safe.py:166
+        kf_w[(size_t)jl * 64] = k;
+        if (with_dots) {
+          const T w = al_o[j] * k;
+          m0 += w;
+#pragma unroll
+          for (int a = 0; a < D; ++a) ms[a] = fma(w, Xn[j * D + a], ms[a]);
+        }
+      }
+      __syncthreads();
+      // ---- contraction: my RW row blocks of chunk Ic against the column blocks of chunk Jc ----
+      // A-fragments of column block J + 1 are fetched while block J is multiplied (reads past a row's last block
+      // stay inside the padded buffer)
+      a_t a_nx[RW][4];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int I = Ic * RC + wave + kWaves * r;
+        const int Ic_ = I < nb ? I : nb - 1;
+        MM<T>::load_a4(F_o + ((size_t)Ic_ * (Ic_ + 1) / 2 + Jlo) * 256, lane, a_nx[r]);
+      }
+      for (int J = Jlo; J < Jhi; ++J) {
+        a_t a_cur[RW][4];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const int I = Ic * RC + wave + kWaves * r;
+          const int Ic_ = I < nb ? I : nb - 1;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) a_cur[r][kk] = a_nx[r][kk];
+          MM<T>::load_a4(F_o + ((size_t)Ic_ * (Ic_ + 1) / 2 + J + 1) * 256, lane, a_nx[r]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          T bfr[S];
+#pragma unroll
+          for (int s = 0; s < S; ++s) bfr[s] = Kf[((size_t)s * CB * 4 + (J - Jlo) * 4 + kk) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < RW; ++r) {
+            const int I = Ic * RC + wave + kWaves * r;   // rows interleaved over the waves (diagonal chunk balance)
+            if (I < nb && J <= I) {
+#pragma unroll
+              for (int s = 0; s < S; ++s) acc[r][s] = MM<T>::mfma(a_cur[r][kk], bfr[s], acc[r][s]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) quad[s] = fma(acc[r][s][e], acc[r][s][e], quad[s]);
+  }
+  // reduce over the four k-slots (lanes l, l^16, l^32, l^48 hold the same candidate)
+  m0 += __shfl_xor(m0, 16);
+  m0 += __shfl_xor(m0, 32);
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    ms[a] += __shfl_xor(ms[a], 16);
+    ms[a] += __shfl_xor(ms[a], 32);
+  }
+  if (slot == 0) {
+    T* mp_ = mpart + (size_t)(wave * 16 + pp) * (1 + D);
+    mp_[0] = m0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) mp_[1 + a] = ms[a];
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    T v = quad[s];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (slot == 0) qpart[wave * P + s * 16 + pp] = v;
+  }
+  __syncthreads();
+
+  if (tid < 64) {
+    T gn = 0;
+    const long long g = tile0 + tid;
+    if (g < cs.n_local) {
+      T quad_ = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) quad_ += qpart[w * P + tid];
+      const T* mp_ = mpart + (size_t)tid * (1 + D);
+      const T m0_ = mp_[0];
+      const T ystd = (T)mc.Y_std[out];
+      const T mean = (T)mc.mp[out] + m0_;                        // GP_Safe.py:342
+      T var = sf2 - quad_;                                       // GP_Safe.py:343
+      var = var > T(0) ? var : T(0);
+      mean_out[(size_t)out * cs.n_local + g] = add_rn(mul_rn(mean, ystd), (T)mc.Y_mean[out]);   // :346
+      var_out[(size_t)out * cs.n_local + g] = mul_rn(var, mul_rn(ystd, ystd));                  // :347
+      double xr[D];
+      cand_coords<D>(cs, g, xr);
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        if (a < mc.d) {
+          const T xn = ((T)xr[a] - (T)mc.X_mean[a]) / (T)mc.X_std[a];
+          T ga = ystd * (mp_[1 + a] - xn * m0_) * (T)mc.inv_ell[out][a] / (T)mc.X_std[a];
+          ga = ga < 0 ? -ga : ga;
+          gn = ga > gn ? ga : gn;
+        }
+      }
+    }
     double gd = (double)gn;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -360,9 +556,9 @@ __global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, con
       // software pipeline: the two fragment loads of step st+1 are in flight behind the MFMAs of step st.  The
       // load after the last step of a row reads the next fragment in memory (both buffers carry padding), so the
       // loop has no clamp and only pointer bumps.
-      const T* fp = F_o + (size_t)(I * (I + 1) / 2) * 4 * 64;
+      const T* fp = F_o + (size_t)(I * (I + 1) / 2) * 256;   // packed (I, J) blocks of this row, 256 elements each
       const T* ep = E0_t;
-      a_t a_nx = MM<T>::load_a(fp, lane);
+      a_t a_nx = MM<T>::load_a(fp, lane, 0);
       T e_nx = ep[lane];
       const T* e1p = E1f + slot;                   // per-line factors of step st at e1p[s * npad + st * 4]
       T e1_nx[S];
@@ -379,10 +575,10 @@ __global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, con
           for (int s = 0; s < S; ++s) b[s] = e_nx * e1_nx[s];
           // operands of the next step (global fragments and LDS factors) fly behind this step's MFMAs; the reads
           // past the row's last step stay inside the padded buffers / the LDS allocation
-          fp += 64;
           ep += 64;
           e1p += 4;
-          a_nx = MM<T>::load_a(fp, lane);
+          a_nx = (kk < 3) ? MM<T>::load_a(fp, lane, kk + 1) : MM<T>::load_a(fp + 256, lane, 0);
+          if (kk == 3) fp += 256;
           e_nx = ep[lane];
 #pragma unroll
           for (int s = 0; s < S; ++s) e1_nx[s] = e1p[s * npad];
@@ -541,6 +737,32 @@ static int launch_posterior_d(sbo_ctx* c) {
   return fail(SBO_E_UNSUPPORTED, "unsupported padded dimension");
 }
 
+template <typename T, int D>
+static int launch_posterior_chunked_t(sbo_ctx* c) {
+  const ModelConst& mc = c->mc;
+  constexpr int P = 16 * kWaves, CB = ChunkCfg<T>::CB;
+  const size_t lds = sizeof(T) * ((size_t)kWaves * CB * 4 * 64 + kWaves * P + (size_t)P * (1 + D));
+  auto kern = k_posterior_chunked<T, D>;
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long long tiles = (c->cs.n_local + P - 1) / P;
+  if (tiles > 0x7fffffffLL) return fail(SBO_E_UNSUPPORTED, "too many candidate tiles for one launch");
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)mc.q), dim3(256), lds, c->stream, mc, c->cs, (const T*)c->Fpk.p,
+                     c->fpk_stride, (const T*)c->As.p, (const T*)c->sqA.p, (const T*)c->alpha.p, (const T*)c->Xn.p,
+                     (T*)c->mean.p, (T*)c->var.p, (unsigned long long*)c->Lmax.p);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+template <typename T>
+static int launch_posterior_chunked(sbo_ctx* c) {
+  switch (c->mc.dpad) {
+    case 2: return launch_posterior_chunked_t<T, 2>(c);
+    case 4: return launch_posterior_chunked_t<T, 4>(c);
+    case 8: return launch_posterior_chunked_t<T, 8>(c);
+  }
+  return fail(SBO_E_UNSUPPORTED, "unsupported padded dimension");
+}
+
 template <typename T>
 static int launch_posterior_s(sbo_ctx* c) {
   // strips per workgroup: the K* tile [npad, 16 S] must fit the 160 KiB LDS with room for two workgroups
@@ -615,7 +837,7 @@ static int launch_posterior_grid(sbo_ctx* c) {
 // the separable path needs whole axis-0 lines in the shard
 static bool grid_path_ok(const sbo_ctx* c) {
   const CandSpec& cs = c->cs;
-  if (c->posterior_path == 1) return false;
+  if (c->posterior_path != 0) return false;
   if (cs.kind != 1 || cs.n_local <= 0) return false;
   const long long cnt0 = cs.count[0];
   return cs.first % cnt0 == 0 && cs.n_local % cnt0 == 0;
@@ -624,6 +846,11 @@ static bool grid_path_ok(const sbo_ctx* c) {
 int launch_posterior(sbo_ctx* c) {
   SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
   if (grid_path_ok(c)) return c->dtype == SBO_F64 ? launch_posterior_grid<double>(c) : launch_posterior_grid<float>(c);
+  // generic candidates: the single-phase kernel while the whole K* tile of 64 candidates fits LDS with two workgroups
+  // per CU, the chunked kernel beyond that (and on request: posterior_path 2)
+  const size_t tile_bytes = (c->dtype == SBO_F64 ? 8u : 4u) * (size_t)c->mc.npad * 64;
+  if (c->posterior_path == 2 || tile_bytes > 64 * 1024)
+    return c->dtype == SBO_F64 ? launch_posterior_chunked<double>(c) : launch_posterior_chunked<float>(c);
   return c->dtype == SBO_F64 ? launch_posterior_s<double>(c) : launch_posterior_s<float>(c);
 }
 

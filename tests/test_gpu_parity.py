@@ -63,6 +63,26 @@ def test_posterior_fp64_scattered_points_any_dimension(engine, d, q, n):
     _check_posterior(engine, ds, pts, TOL64)
 
 
+@pytest.mark.parametrize("cfg_name,n,dtype", [("B", 128, "f64"), ("H", 300, "f64"), ("H", 512, "f64"), ("C", 200, "f64"),
+                                               ("B", 128, "f32"), ("H", 512, "f32")])
+def test_posterior_chunked_generic_kernel(engine, cfg_name, n, dtype):
+    """The chunked generic kernel (row/column chunks, K* regenerated per chunk pair) forced on small models."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    pts = np.random.default_rng(n).uniform(cfg["bound"][:, 0], cfg["bound"][:, 1], size=(1500, 2))
+    engine.set_option("posterior_path", 2)
+    try:
+        engine.set_model(cfg["ds"], dtype=dtype, use_invK=(dtype == "f64"))
+        engine.set_points(pts)
+        _check_posterior(engine, cfg["ds"], pts, TOL64 if dtype == "f64" else TOL32, dtype=dtype)
+        if dtype == "f64":
+            ref = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"])
+            res = engine.sweep_safeopt(cfg["b"], want_masks=True, posterior_ready=True)
+            assert np.array_equal(engine.mask("S"), ref["S"]) and res["minimizer_index"] == ref["minimizer_index"]
+            assert np.allclose(res["L"], ref["L"], rtol=1e-9)
+    finally:
+        engine.set_option("posterior_path", 0)
+
+
 def test_posterior_fp32(engine):
     cfg = synthetic.make_config("B", n=128)
     lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
