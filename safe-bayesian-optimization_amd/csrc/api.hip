@@ -76,14 +76,20 @@ static bool cholesky_inv(std::vector<double>& A, int n, std::vector<double>& Lin
       A[(size_t)i * n + j] = t / ljj;
     }
   }
+  // L^-1 row by row: row i = (e_i - sum_{k<i} L[i][k] row_k) / L[i][i]  (contiguous row updates)
   Linv.assign((size_t)n * n, 0.0);
-  for (int c = 0; c < n; ++c) {   // solve L x = e_c
-    Linv[(size_t)c * n + c] = 1.0 / A[(size_t)c * n + c];
-    for (int i = c + 1; i < n; ++i) {
-      double t = 0;
-      for (int k = c; k < i; ++k) t -= A[(size_t)i * n + k] * Linv[(size_t)k * n + c];
-      Linv[(size_t)i * n + c] = t / A[(size_t)i * n + i];
+  for (int i = 0; i < n; ++i) {
+    double* ri = &Linv[(size_t)i * n];
+    ri[i] = 1.0;
+    const double* li = &A[(size_t)i * n];
+    for (int k = 0; k < i; ++k) {
+      const double f = li[k];
+      if (f == 0.0) continue;
+      const double* rk = &Linv[(size_t)k * n];
+      for (int c = 0; c <= k; ++c) ri[c] -= f * rk[c];
     }
+    const double inv = 1.0 / li[i];
+    for (int c = 0; c <= i; ++c) ri[c] *= inv;
   }
   return true;
 }

@@ -287,6 +287,77 @@ def test_safeopt_single_output_has_no_constraints(engine):
     assert res["minimizer_index"] == ref["minimizer_index"] and res["expander_best_c"] == 0
 
 
+@pytest.mark.parametrize("count", [[5, 7], [1, 9], [17, 3], [33, 1]])
+def test_small_and_degenerate_grids(engine, count):
+    cfg = synthetic.make_config("A", n=20)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    _check_posterior(engine, cfg["ds"], pts, TOL64)
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], 1.0)
+    if ref["empty_safe_set"]:
+        with pytest.raises(safebo_amd.EmptySafeSetError):
+            engine.sweep_safeopt(1.0)
+    else:
+        res = engine.sweep_safeopt(1.0, want_masks=True)
+        _check_safeopt(engine, ref, 2)
+        assert res["minimizer_index"] == ref["minimizer_index"]
+
+
+def test_one_dimensional_model_and_grid(engine):
+    rng = np.random.default_rng(4)
+    X = rng.uniform(-1, 1, size=(15, 1))
+    Y = np.stack([np.sin(3 * X[:, 0]), 0.6 - X[:, 0] ** 2], axis=1)
+    ds = synthetic.make_dataset(X, Y, synthetic.default_hypopt(1, 2))
+    pts = oracle.grid_points([-1.0], [1.0], [301])
+    engine.set_model(ds)
+    engine.set_grid([-1.0], [1.0], [301])
+    _check_posterior(engine, ds, pts, TOL64)
+    ref = oracle.safeopt_sweep(pts, ds, 2.0)
+    res = engine.sweep_safeopt(2.0, want_masks=True)
+    _check_safeopt(engine, ref, 2)
+    assert res["minimizer_index"] == ref["minimizer_index"] and list(res["expander_index_c"]) == list(ref["expander_index"])
+
+
+def test_no_unsafe_witness_means_no_expander(engine):
+    """Every candidate safe and none fully unsafe: G_c is empty, the expander is reported as absent and the loop rule
+    falls back to the minimiser (test/test_SafeOpt.py:153-158 with std_expander = 0)."""
+    rng = np.random.default_rng(8)
+    X = rng.uniform(-1, 1, size=(30, 2))
+    Y = np.stack([X[:, 0] ** 2 + X[:, 1] ** 2, 50.0 + 0.01 * X[:, 0]], axis=1)      # constraint far above zero everywhere
+    ds = synthetic.make_dataset(X, Y, synthetic.default_hypopt(2, 2))
+    pts = X + 1e-3            # candidates next to the observations: the pessimistic prior cannot pull them down
+    ref = oracle.safeopt_sweep(pts, ds, 1.0)
+    assert ref["S"].all() and not ref["U"].any() and not ref["G"].any()
+    engine.set_model(ds)
+    engine.set_points(pts)
+    res = engine.sweep_safeopt(1.0, want_masks=True)
+    _check_safeopt(engine, ref, 2)
+    assert res["expander_best_c"] == 0 and res["expander_index"] == -1 and res["expander_std"] == 0.0
+    assert res["choose_minimizer"] and res["minimizer_index"] == ref["minimizer_index"]
+    g = engine.sweep_goose(1.0, want_masks=True)
+    assert g["target_index"] == -1 and g["choose_safe_min"] and not engine.mask("O", 1).any()
+    assert g["safe_min_index"] == oracle.goose_sweep(pts, ds, 1.0)["safe_min_index"]
+
+
+def test_single_candidate_and_empty_shard(engine):
+    cfg = synthetic.make_config("A", n=20)
+    x = np.array([[1.4, -0.8]])                      # inside the sampled safe region
+    ref = oracle.safeopt_sweep(x, cfg["ds"], 0.5)
+    engine.set_model(cfg["ds"])
+    engine.set_points(x)
+    if ref["empty_safe_set"]:
+        with pytest.raises(safebo_amd.EmptySafeSetError):
+            engine.sweep_safeopt(0.5)
+    else:
+        res = engine.sweep_safeopt(0.5)
+        assert res["minimizer_index"] == 0 and res["count_S"] == 1
+    engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], [10, 10], first=30, n_local=0)
+    with pytest.raises(safebo_amd.EmptySafeSetError):
+        engine.sweep_safeopt(0.5)
+
+
 def test_full_size_properties_config_B(engine):
     """BASELINE.json configs[1] at full size (2048^2, n = 128): properties that do not need the whole oracle."""
     cfg = synthetic.make_config("B")
