@@ -42,7 +42,8 @@ def parse_args():
     ap.add_argument("--config", default="B", help="synthetic config (B = BASELINE.json configs[1]; H = 4096^2, n = 512)")
     ap.add_argument("--n", type=int, default=None, help="override the number of observations")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="candidates timed by the CPU baseline (0 = skip)")
-    ap.add_argument("--engine", type=int, default=None, help="fp64 contraction engine override (0 MFMA, 1 VALU)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: the grid's slowest axis grows with the ranks (default); strong: fixed grid, sharded")
     return ap.parse_args()
 
 
@@ -102,13 +103,12 @@ def main():
     if cfg["count"] is None:
         raise SystemExit("bench.py sweeps grid configs (A, B, C, D, H)")
     count = list(cfg["count"])
-    count[-1] *= world                                   # weak scaling: slowest axis grows with the ranks
+    if args.scaling == "weak":
+        count[-1] *= world                               # weak scaling: slowest axis grows with the ranks
     lo, hi = cfg["bound"][:, 0].copy(), cfg["bound"][:, 1].copy()
     n_total = int(np.prod(count))
 
     eng = safebo_amd.SweepEngine(local_rank)
-    if args.engine is not None:
-        eng.set_option("fp64_engine", args.engine)
     if world > 1:
         distributed.join(eng)                    # RCCL communicator: unique id broadcast from rank 0
     eng.set_model(cfg["ds"], dtype=cfg["dtype"])
@@ -155,7 +155,7 @@ def main():
         out = {
             "metric": "candidate-points/sec, SafeOpt posterior+safe-set sweep",
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": f"config {args.config}: {cfg['plant']} {cfg['d']}-D SafeOpt sweep, implicit grid "
                                    f"{'x'.join(str(c) for c in count)} ({n_total} candidates), n={cfg['ds']['X_norm'].shape[0]} "

@@ -196,6 +196,14 @@ int sbo_sweep_goose(sbo_ctx* ctx, const sbo_sweep_opts* opts, sbo_goose_result* 
 /* uint8 mask [n_local] of the last sweep (opts.want_masks); c is the constraint index for G / O */
 int sbo_masks_get(sbo_ctx* ctx, int which, int c, uint8_t* out);
 
+/* ---- model fit ------------------------------------------------- */
+/* negative_loglikelihood (models/GP_Safe.py:169-192) for P hyper-parameter vectors at once:
+ * hyper[P, d+2] rows = (log ell_0.., log sigma_f, log sigma_n); X_norm[n, d]; y[n] = one column of Y_norm;
+ * out[p] = y^T K_p^-1 y + log|K_p| with K_p = sf2 exp(-1/2 D) + (sn2 + 1e-8) I (+inf if not positive definite).
+ * This is the objective SciPy DE evaluates at models/GP_Safe.py:224, one population per call. */
+int sbo_nll_batch(sbo_ctx* ctx, int n, int d, const double* X_norm, const double* y, int P, const double* hyper,
+                  double* out);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
 /* selects the fp64 contraction engine of K1: 0 = MFMA (v_mfma_f64_16x16x4_f64), 1 = VALU FMA */

@@ -3,8 +3,9 @@
 Same method names, argument meaning and error behaviour as the reference ``GP`` so its drivers keep working
 (``from models.GP_Safe import GP`` -> ``from safebo_amd.GP_Safe import GP``); what changes is where the
 arithmetic runs: the posterior (``GP_inference``) is evaluated by the HIP kernels behind the C ABI, batched
-when the caller passes many points.  Model fitting (normalisation, NLL, hyper-parameter search) stays on the
-host in NumPy/SciPy -- it is SURVEY.md section 8(f) "next", not part of the swept hot path.
+when the caller passes many points.  Model fitting (normalisation, hyper-parameter search) is host NumPy/SciPy by
+default; with ``fit_on_device = True`` the differential-evolution search evaluates its whole population per
+generation with the batched device objective ``sbo_nll_batch``.
 
 Differences that are deliberate and documented:
   * no JAX: ``key`` arguments are ``numpy.random.Generator`` objects (or seeds); the reference's threefry
@@ -37,6 +38,7 @@ class GP:
         self._uploaded_version = -1
         self.fixed_hyper = None
         self.de_options = {}         # forwarded to scipy DE (e.g. {"seed": 0, "maxiter": 50})
+        self.fit_on_device = False   # True: DE evaluates whole populations with the batched device NLL (sbo_nll_batch)
         self.var_out = True
 
     # ---- engine plumbing -----------------------------------------------------------------------------------
@@ -121,6 +123,13 @@ class GP:
         for i in range(self.ny_dim):
             if self.fixed_hyper is not None:
                 hypopt[:, i] = np.asarray(self.fixed_hyper, dtype=np.float64)[:, i]
+            elif self.fit_on_device:
+                # same objective and bounds; SciPy hands over the whole trial population (vectorized, deferred
+                # updating) and the device returns one NLL per member
+                y_i = np.ascontiguousarray(Y_norm[:, i])
+                res = differential_evolution(lambda H: self.engine.nll_batch(X_norm, y_i, H.T), bounds=bounds,
+                                             vectorized=True, updating="deferred", **self.de_options)
+                hypopt[:, i] = res.x
             else:
                 res = differential_evolution(self.negative_loglikelihood, args=(X_norm, Y_norm[:, i:i + 1]), bounds=bounds,
                                              **self.de_options)

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("sbo_sweep_safeopt", C.c_int, [_P, C.POINTER(SweepOpts), C.POINTER(SafeOptResult)]),
     ("sbo_sweep_goose", C.c_int, [_P, C.POINTER(SweepOpts), C.POINTER(GooseResult)]),
     ("sbo_masks_get", C.c_int, [_P, C.c_int, C.c_int, _P]),
+    ("sbo_nll_batch", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     ("sbo_profile_get", C.c_int, [_P, C.POINTER(Profile)]),
     ("sbo_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
 ]

@@ -72,6 +72,7 @@ struct sbo_ctx {
   sbo::DevBuf maskS, maskU, maskM, maskG, maskO;   // uint8 [n_local] (G/O: [(q-1)][n_local])
   sbo::DevBuf dist2;   // double [n_local] distance-transform scratch (x2 for ping-pong)
   sbo::DevBuf dist2b;
+  sbo::DevBuf fitbuf, fitwork;   // hyper-parameter objective: inputs/outputs and the P x n x n factor workspace
   sbo::DevBuf coarse;  // coarse U mask + its distance transform (expander pre-decision)
   sbo::DevBuf scal;    // small device scalar block (keys, counters, arg-reduce results)
   sbo::DevBuf partial; // arg-reduce per-block partials

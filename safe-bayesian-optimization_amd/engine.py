@@ -205,6 +205,17 @@ class SweepEngine:
         L.check(self._lib.sbo_masks_get(self._ctx, w, int(c), _ptr(out)))
         return out.astype(bool)
 
+    def nll_batch(self, X_norm, y, hypers):
+        """``negative_loglikelihood`` (models/GP_Safe.py:169-192) for a population: hypers[P, d+2] -> NLL[P]."""
+        X = _f64(X_norm)
+        yv = _f64(np.asarray(y).reshape(-1))
+        H = _f64(hypers)
+        if X.ndim != 2 or H.ndim != 2 or H.shape[1] != X.shape[1] + 2 or yv.shape[0] != X.shape[0]:
+            raise ValueError("X_norm [n, d], y [n], hypers [P, d + 2]")
+        out = np.empty(H.shape[0], dtype=np.float64)
+        L.check(self._lib.sbo_nll_batch(self._ctx, X.shape[0], X.shape[1], _ptr(X), _ptr(yv), H.shape[0], _ptr(H), _ptr(out)))
+        return out
+
     def profile(self) -> dict:
         p = L.Profile()
         L.check(self._lib.sbo_profile_get(self._ctx, C.byref(p)))

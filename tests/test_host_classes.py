@@ -134,6 +134,45 @@ def test_goose_methods_follow_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,d", [(4, 2), (20, 2), (45, 2), (128, 4), (300, 3)])
+def test_device_nll_matches_host_objective(engine, n, d):
+    """sbo_nll_batch against the NumPy objective (models/GP_Safe.py:169-192) over a population inside the
+    reference's search box (:205-206), plus a member that is not positive definite in floating point."""
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-1, 1, size=(n, d))
+    m = GP([lambda u, noise=0: 0.0])
+    m.kernel, m.nx_dim, m.n_point = "RBF", d, n
+    Xn = (X - X.mean(0)) / X.std(0)
+    y = np.sin(Xn.sum(1))[:, None]
+    y = (y - y.mean()) / y.std()
+    H = np.column_stack([rng.uniform(-1.5, 1.5, size=(40, d + 1)), rng.uniform(-5.0, -2.0, size=40)])
+    got = engine.nll_batch(Xn, y[:, 0], H)
+    want = np.array([m.negative_loglikelihood(h, Xn, y) for h in H])
+    ok = np.isfinite(want)
+    assert ok.sum() >= 35
+    assert np.allclose(got[ok], want[ok], rtol=1e-9, atol=1e-9)
+    with pytest.raises(ValueError):
+        engine.nll_batch(Xn, y[:, 0], H[:, :-1])
+
+
+@pytest.mark.gpu
+def test_fit_on_device_reaches_the_host_optimum():
+    m_host = _init(SafeOpt.BO, n=12, fixed=False)
+    m_dev = _init(SafeOpt.BO, n=12, fixed=False)
+    opts = {"seed": 3, "maxiter": 40, "tol": 1e-6, "popsize": 20}
+    m_host.de_options, m_dev.de_options = dict(opts), dict(opts)
+    m_dev.fit_on_device = True
+    m_host.GP_initialization(m_host.X, m_host.Y, "RBF", multi_hyper=5)
+    m_dev.X, m_dev.Y = m_host.X.copy(), m_host.Y.copy()
+    m_dev.GP_initialization(m_dev.X, m_dev.Y, "RBF", multi_hyper=5)
+    for i in range(2):
+        f_host = m_host.negative_loglikelihood(m_host.hypopt[:, i], m_host.X_norm, m_host.Y_norm[:, i:i + 1])
+        f_dev = m_host.negative_loglikelihood(m_dev.hypopt[:, i], m_host.X_norm, m_host.Y_norm[:, i:i + 1])
+        assert f_dev <= f_host + 1e-3 * max(1.0, abs(f_host))     # same objective, equally good minimum
+    assert np.all(m_dev.hypopt[:3] >= -1.5) and np.all(m_dev.hypopt[:3] <= 1.5) and np.all(m_dev.hypopt[3] <= -2.0)
+
+
+@pytest.mark.gpu
 def test_safeopt_campaign_plumbing_config_A():
     """BASELINE.json configs[0]: Benoit 2-D, 50x50 grid, n <= 20 -- the loop of test/test_SafeOpt.py:135-186 with
     its decision rule (:153-158) and stopping test (:178), three iterations, hyper-parameters fitted by DE."""
