@@ -123,6 +123,13 @@ typedef struct sbo_goose_result {
   int64_t count_O[SBO_MAX_Q];
 } sbo_goose_result;
 
+typedef struct sbo_tr_result {
+  int64_t index;                 /* argmin_{S_t and ||x - x_0|| <= r} lcb_0, -1 when that set is empty (models/GP_TR.py:43-51) */
+  double  x[SBO_MAX_D];
+  double  lcb;
+  int64_t count_S, count_T;      /* |S_t|, |S_t intersected with the ball|                                                  */
+} sbo_tr_result;
+
 /* per-kernel device time of the last sweep / posterior call, measured with HIP events on the
  * library's stream (feeds bench.py's roofline.achieved) */
 typedef struct sbo_profile {
@@ -193,6 +200,8 @@ int sbo_bounds(sbo_ctx* ctx, double b, int index, int kind, void* out);
 /* full SafeOpt / GoOSE iteration on the resident candidates */
 int sbo_sweep_safeopt(sbo_ctx* ctx, const sbo_sweep_opts* opts, sbo_safeopt_result* result);
 int sbo_sweep_goose(sbo_ctx* ctx, const sbo_sweep_opts* opts, sbo_goose_result* result);
+/* trust-region acquisition of models/GP_TR.py:43-51 on the resident candidates: x_0[d] centre, r radius */
+int sbo_sweep_tr(sbo_ctx* ctx, const sbo_sweep_opts* opts, const double* x_0, double r, sbo_tr_result* result);
 /* uint8 mask [n_local] of the last sweep (opts.want_masks); c is the constraint index for G / O */
 int sbo_masks_get(sbo_ctx* ctx, int which, int c, uint8_t* out);
 

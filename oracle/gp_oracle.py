@@ -25,7 +25,7 @@ __all__ = [
     "data_normalization", "squared_seuclidean", "cov_mat", "calc_cov_mat", "build_invK",
     "make_inference_dataset", "cast_dataset", "mean_prior", "gp_inference", "bounds",
     "grid_axes", "grid_points", "mean_grad", "mean_grad_infnorm", "shifted_norm",
-    "safeopt_sweep", "goose_sweep", "FLOAT32_EPS",
+    "safeopt_sweep", "goose_sweep", "tr_sweep", "update_TR", "FLOAT32_EPS",
 ]
 
 FLOAT32_EPS = float(np.finfo(np.float32).eps)  # jitter of the stored inverse, models/GP_Safe.py:229
@@ -355,3 +355,39 @@ def goose_sweep(points, ds, b, quirk_L_index=True, mean_var=None):
         res.update({"target_best": 0, "target_index": -1, "target_lcb": np.inf, "choose_safe_min": True,
                     "explore_index": -1})
     return res
+
+
+# --------------------------------------------------------------------------------------
+# Trust-region acquisition: models/GP_TR.py:43-51, 56-91
+# --------------------------------------------------------------------------------------
+def tr_sweep(points, ds, b, x_0, r, mean_var=None):
+    """argmin of lcb_0 over {g : lcb_i(g) >= 0 for all i >= 1 and ||x_g - x_0||_2 <= r} (models/GP_TR.py:43-51;
+    the ball constraint there is NonlinearConstraint(norm(x - x_0), 0, r), no 1e-8 shift)."""
+    points = np.asarray(points, dtype=np.float64)
+    mean, var = mean_var if mean_var is not None else gp_inference(points, ds)
+    lcb, ucb = bounds(mean, var, b)
+    S = np.all(lcb[:, 1:] >= 0, axis=1)
+    diff = points - np.asarray(x_0, dtype=np.float64)
+    dist = np.sqrt(np.sum(diff * diff, axis=1))
+    T = S & (dist <= r)
+    res = {"S": S, "T": T, "lcb": lcb, "empty": not bool(T.any())}
+    if T.any():
+        i = int(np.argmin(np.where(T, lcb[:, 0], np.inf)))
+        res.update({"index": i, "lcb_min": float(lcb[i, 0])})
+    return res
+
+
+def update_TR(TR_parameters, x_initial, x_new, radius, plant_old, plant_new, gp_obj_old, gp_obj_new):
+    """Ratio test of models/GP_TR.py:56-91: returns (centre, radius)."""
+    r = radius
+    for i in range(1, len(plant_new)):
+        if plant_new[i] < 0.:
+            return x_initial, r * TR_parameters["radius_red"]                       # :73-75
+    rho = (plant_new[0] - plant_old[0]) / (gp_obj_new - gp_obj_old)                  # :79
+    if plant_old[0] < plant_new[0]:
+        return x_initial, r * TR_parameters["radius_red"]                           # :81-82
+    if rho < TR_parameters["rho_lb"]:
+        return x_initial, r * TR_parameters["radius_red"]                           # :86-87
+    if rho < TR_parameters["rho_ub"]:
+        return x_new, r                                                               # :89-90
+    return x_new, min(r * TR_parameters["radius_inc"], TR_parameters["radius_max"])  # :92-93

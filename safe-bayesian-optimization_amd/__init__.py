@@ -7,6 +7,6 @@ kernels behind the C ABI of ``include/safebo.h``); this package is NumPy + ctype
 from . import _lib
 from .engine import SweepEngine
 from ._lib import SafeBOError, EmptySafeSetError
-from . import GP_Safe, SafeOpt, GoOSE   # mirrors of the reference's models/GP_Safe.py, SafeOpt.py, GoOSE.py
+from . import GP_Safe, SafeOpt, GoOSE, GP_TR   # mirrors of the reference's models/GP_Safe.py, SafeOpt.py, GoOSE.py, GP_TR.py
 
-__all__ = ["SweepEngine", "SafeBOError", "EmptySafeSetError", "GP_Safe", "SafeOpt", "GoOSE", "_lib"]
+__all__ = ["SweepEngine", "SafeBOError", "EmptySafeSetError", "GP_Safe", "SafeOpt", "GoOSE", "GP_TR", "_lib"]

@@ -56,6 +56,11 @@ class GooseResult(C.Structure):
     ]
 
 
+class TRResult(C.Structure):
+    _fields_ = [("index", C.c_int64), ("x", C.c_double * SBO_MAX_D), ("lcb", C.c_double), ("count_S", C.c_int64),
+                ("count_T", C.c_int64)]
+
+
 class Profile(C.Structure):
     _fields_ = [
         ("posterior_ms", C.c_double), ("classify_ms", C.c_double), ("expander_ms", C.c_double),
@@ -91,6 +96,7 @@ SYMBOLS = [
     ("sbo_bounds", C.c_int, [_P, C.c_double, C.c_int, C.c_int, _P]),
     ("sbo_sweep_safeopt", C.c_int, [_P, C.POINTER(SweepOpts), C.POINTER(SafeOptResult)]),
     ("sbo_sweep_goose", C.c_int, [_P, C.POINTER(SweepOpts), C.POINTER(GooseResult)]),
+    ("sbo_sweep_tr", C.c_int, [_P, C.POINTER(SweepOpts), _P, C.c_double, C.POINTER(TRResult)]),
     ("sbo_masks_get", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("sbo_nll_batch", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     ("sbo_profile_get", C.c_int, [_P, C.POINTER(Profile)]),

@@ -772,6 +772,29 @@ __global__ __launch_bounds__(256) void k_goose_optimistic(const CandSpec cs, con
   if (h < cs.n_local) O[h] = covered;
 }
 
+// trust-region mask: S and ||x - x_0||_2 <= r, the norm evaluated as sqrt(sum (x - x_0)^2) (models/GP_TR.py:49)
+template <int D>
+__global__ void k_ball_mask(const CandSpec cs, long long n, const uint8_t* __restrict__ S, const double* __restrict__ x0,
+                            double r, uint8_t* __restrict__ out) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    uint8_t m = 0;
+    if (S[g]) {
+      double x[D];
+      cand_coords<D>(cs, g, x);
+      double ss = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        if (a < cs.d) {
+          const double df = x[a] - x0[a];
+          ss = (a == 0) ? df * df : ss + df * df;
+        }
+      }
+      m = sqrt(ss) <= r;
+    }
+    out[g] = m;
+  }
+}
+
 // value arrays for the arg-reductions of the GoOSE sweep
 template <typename T>
 __global__ void k_lcb0(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b, T* __restrict__ out) {
@@ -1299,6 +1322,66 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   return SBO_OK;
 }
 
+// Trust-region acquisition (models/GP_TR.py:43-51): argmin lcb_0 over S and the ball
+template <typename T>
+static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, double r, sbo_tr_result* res) {
+  const long long n = c->cs.n_local;
+  int rc;
+  SBO_HIP(hipEventRecord(c->ev[0], c->stream));
+  const bool reuse = o->posterior_ready && c->posterior_valid;
+  if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
+  SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  if ((rc = sweep_common_front<T>(c, o))) return rc;
+  if ((rc = ensure(c->dist2, sizeof(double) * (size_t)std::max<long long>(n, 1)))) return rc;
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
+  const int nb = reduce_blocks(c);
+  T* lcb0 = (T*)c->dist2.p;
+  double* dev_x0 = (double*)c->scal.p + 256;
+  SBO_HIP(hipMemcpyAsync(dev_x0, x0, sizeof(double) * c->cs.d, hipMemcpyHostToDevice, c->stream));
+  if (n > 0) {
+    hipLaunchKernelGGL((k_lcb0<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b, lcb0);
+    switch (c->mc.dpad) {
+      case 2: hipLaunchKernelGGL((k_ball_mask<2>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, (const uint8_t*)c->maskS.p, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
+      case 4: hipLaunchKernelGGL((k_ball_mask<4>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, (const uint8_t*)c->maskS.p, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
+      default: hipLaunchKernelGGL((k_ball_mask<8>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, (const uint8_t*)c->maskS.p, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
+    }
+    hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskM.p, n,
+                       (long long)c->cs.first, &sc->count_M, (Best*)c->partial.p);
+  }
+  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0);
+  SBO_HIP(hipGetLastError());
+  SweepScalars h;
+  bool is_max[kArgSlots];
+  for (int t = 0; t < kArgSlots; ++t) is_max[t] = false;
+  if (c->world > 1) {
+    if ((rc = ensure(c->xch, sizeof(double) * (size_t)(c->world * kC3Row + 64)))) return rc;
+  }
+  if ((rc = sweep_exchange_back(c, h, is_max))) return rc;
+  SBO_HIP(hipEventRecord(c->ev[2], c->stream));
+  SBO_HIP(hipEventSynchronize(c->ev[2]));
+  c->masks_valid = true;
+  c->last_sweep = 3;
+  float t01 = 0, t12 = 0, t02 = 0;
+  SBO_HIP(hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
+  SBO_HIP(hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
+  SBO_HIP(hipEventElapsedTime(&t02, c->ev[0], c->ev[2]));
+  memset(&c->prof, 0, sizeof(c->prof));
+  c->prof.posterior_ms = t01;
+  c->prof.classify_ms = t12;
+  c->prof.total_ms = t02;
+  c->prof.candidates = n;
+  c->prof.posterior_launches = (!reuse && n > 0) ? 1 : 0;
+  const double nn = c->mc.n, dd = c->mc.d;
+  c->prof.posterior_flops = reuse ? 0.0 : c->mc.q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
+  memset(res, 0, sizeof(*res));
+  res->count_S = h.count_S;
+  res->count_T = h.count_M;
+  res->index = h.arg_idx[0];
+  res->lcb = h.arg_idx[0] >= 0 ? h.arg_val[0] : INFINITY;
+  coords_of(c, res->index, res->x);
+  return SBO_OK;
+}
+
 }  // namespace sbo
 
 using namespace sbo;
@@ -1332,6 +1415,16 @@ int sbo_sweep_goose(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_goose_result* re
   return c->dtype == SBO_F64 ? sweep_goose_t<double>(c, opts, result) : sweep_goose_t<float>(c, opts, result);
 }
 
+int sbo_sweep_tr(sbo_ctx* c, const sbo_sweep_opts* opts, const double* x_0, double r, sbo_tr_result* result) {
+  if (!c || !opts || !x_0 || !result) return fail(SBO_E_INVALID, "NULL argument");
+  if (!c->has_model) return fail(SBO_E_NO_MODEL, "sbo_model_set has not been called");
+  if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
+  if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
+  if (!(r >= 0.0)) return fail(SBO_E_INVALID, "trust-region radius must be >= 0");
+  SBO_HIP(hipSetDevice(c->device));
+  return c->dtype == SBO_F64 ? sweep_tr_t<double>(c, opts, x_0, r, result) : sweep_tr_t<float>(c, opts, x_0, r, result);
+}
+
 int sbo_masks_get(sbo_ctx* c, int which, int cidx, uint8_t* out) {
   if (!c || !out) return fail(SBO_E_INVALID, "NULL argument");
   if (!c->masks_valid) return fail(SBO_E_INVALID, "no sweep has produced masks on these candidates");
@@ -1340,8 +1433,8 @@ int sbo_masks_get(sbo_ctx* c, int which, int cidx, uint8_t* out) {
   switch (which) {
     case SBO_MASK_S: src = c->maskS.p; break;
     case SBO_MASK_U: src = c->maskU.p; break;
-    case SBO_MASK_M:
-      if (c->last_sweep != 1) return fail(SBO_E_INVALID, "M is produced by the SafeOpt sweep");
+    case SBO_MASK_M:   // after a trust-region sweep this slot holds S intersected with the ball
+      if (c->last_sweep != 1 && c->last_sweep != 3) return fail(SBO_E_INVALID, "M is produced by the SafeOpt sweep");
       src = c->maskM.p;
       break;
     case SBO_MASK_G:

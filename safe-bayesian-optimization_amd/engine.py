@@ -199,6 +199,17 @@ class SweepEngine:
             "count_O": np.array(res.count_O[:q - 1], dtype=np.int64),
         }
 
+    def sweep_tr(self, b: float, x_0, r: float, posterior_ready: bool = False) -> dict:
+        """Trust-region acquisition of models/GP_TR.py:43-51: argmin lcb_0 over S_t and the ball ||x - x_0|| <= r."""
+        res = L.TRResult()
+        opts = self._opts(b, True, True, posterior_ready)
+        x0 = _f64(x_0)
+        if x0.shape != (self.d,):
+            raise ValueError("x_0 must have shape [d]")
+        L.check(self._lib.sbo_sweep_tr(self._ctx, C.byref(opts), _ptr(x0), float(r), C.byref(res)))
+        return {"index": int(res.index), "x": np.array(res.x[:self.d]), "lcb": float(res.lcb),
+                "count_S": int(res.count_S), "count_T": int(res.count_T)}
+
     def mask(self, which: str, c: int = 0) -> np.ndarray:
         w = {"S": L.SBO_MASK_S, "U": L.SBO_MASK_U, "M": L.SBO_MASK_M, "G": L.SBO_MASK_G, "O": L.SBO_MASK_O}[which]
         out = np.empty(self.n_local, dtype=np.uint8)

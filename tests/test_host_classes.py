@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from safebo_amd import GoOSE, SafeOpt, synthetic
+from safebo_amd import GoOSE, GP_TR, SafeOpt, synthetic
 from safebo_amd.GP_Safe import GP
 
 
@@ -20,7 +20,10 @@ BOUND = np.array([[-.6, 1.5], [-1., 1.]])
 
 
 def _init(cls, n=12, grid=(50, 50), b=3.0, fixed=True, **kw):
-    m = cls([benoit_f, benoit_g], BOUND, b, grid=grid, **kw)
+    if "TR_parameters" in kw:
+        m = cls([benoit_f, benoit_g], BOUND, b, kw.pop("TR_parameters"), grid=grid, **kw)
+    else:
+        m = cls([benoit_f, benoit_g], BOUND, b, grid=grid, **kw)
     X, Y = m.Data_sampling(n, np.array([1.4, -.8]), 0.3)
     if fixed:
         m.fixed_hyper = synthetic.default_hypopt(2, 2)
@@ -170,6 +173,43 @@ def test_fit_on_device_reaches_the_host_optimum():
         f_dev = m_host.negative_loglikelihood(m_dev.hypopt[:, i], m_host.X_norm, m_host.Y_norm[:, i:i + 1])
         assert f_dev <= f_host + 1e-3 * max(1.0, abs(f_host))     # same objective, equally good minimum
     assert np.all(m_dev.hypopt[:3] >= -1.5) and np.all(m_dev.hypopt[:3] <= 1.5) and np.all(m_dev.hypopt[3] <= -2.0)
+
+
+TR_PARAMS = {"radius": 0.5, "radius_max": 1, "radius_red": 0.8, "radius_inc": 1.1, "rho_lb": 0.2, "rho_ub": 0.8}
+
+
+def test_update_TR_rule_matches_oracle_restatement():
+    # models/GP_TR.py:56-91 on synthetic numbers (no device: GP_inference is replaced by fixed values)
+    m = GP_TR.BO([benoit_f, benoit_g], BOUND, 3.0, dict(TR_PARAMS), grid=(20, 20))
+    m.inference_datasets = None
+    vals = {}
+    m.GP_inference = lambda x, ds: (np.array([vals[tuple(np.round(x, 6))], 0.0]), np.zeros(2))
+    x0, x1 = np.array([1.0, -0.5]), np.array([0.8, -0.4])
+    for p_old, p_new, g_old, g_new in [([1.0, 0.1], [0.5, 0.1], 1.0, 0.4), ([1.0, 0.1], [0.9, 0.1], 1.0, 0.2),
+                                       ([1.0, 0.1], [0.7, 0.1], 1.0, 0.4), ([1.0, 0.1], [1.2, 0.1], 1.0, 0.4),
+                                       ([1.0, 0.1], [0.5, -0.1], 1.0, 0.4)]:
+        vals[tuple(np.round(x0, 6))], vals[tuple(np.round(x1, 6))] = g_old, g_new
+        got = m.update_TR(x0, x1, 0.5, p_old, p_new)
+        want = oracle.update_TR(TR_PARAMS, x0, x1, 0.5, p_old, p_new, g_old, g_new)
+        assert np.array_equal(got[0], want[0]) and got[1] == pytest.approx(want[1])
+
+
+@pytest.mark.gpu
+def test_trust_region_acquisition_follows_oracle():
+    m = _init(GP_TR.BO, n=20, grid=(60, 50), TR_parameters=dict(TR_PARAMS))
+    pts = oracle.grid_points(BOUND[:, 0], BOUND[:, 1], [60, 50])
+    for x_0, r in [(np.array([1.4, -0.8]), 0.3), (np.array([1.2, -0.6]), 0.1), (np.array([-0.5, 0.9]), 0.05)]:
+        ref = oracle.tr_sweep(pts, m.inference_datasets, 3.0, x_0, r)
+        x, val = m.minimize_obj_lcb(r, x_0)
+        if ref["empty"]:
+            assert np.array_equal(x, x_0) and val == np.inf
+        else:
+            assert np.array_equal(x, pts[ref["index"]]) and val == pytest.approx(ref["lcb_min"], abs=1e-9)
+            assert np.array_equal(m.engine.mask("M"), ref["T"])
+    x_new, _ = m.minimize_obj_lcb(0.3, np.array([1.4, -0.8]))
+    c, r = m.update_TR(np.array([1.4, -0.8]), x_new, 0.3, m.calculate_plant_outputs(np.array([1.4, -0.8])),
+                       m.calculate_plant_outputs(x_new))
+    assert r in (0.3 * 0.8, 0.3, min(0.3 * 1.1, 1)) and (np.array_equal(c, x_new) or np.array_equal(c, [1.4, -0.8]))
 
 
 @pytest.mark.gpu
