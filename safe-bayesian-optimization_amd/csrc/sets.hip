@@ -833,8 +833,11 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o) {
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
+  long long npad_shard = n;                  // ranks > 1: the U mask is all-gathered with the largest shard's size
+  for (size_t r = 0; r + 1 < c->first_of.size() && c->world > 1 && c->sharded; ++r)
+    npad_shard = std::max(npad_shard, c->first_of[r + 1] - c->first_of[r]);
   if ((rc = ensure(c->maskS, (size_t)n))) return rc;
-  if ((rc = ensure(c->maskU, (size_t)n))) return rc;
+  if ((rc = ensure(c->maskU, (size_t)npad_shard))) return rc;
   if ((rc = ensure(c->maskM, (size_t)n))) return rc;
   if ((rc = ensure(c->maskG, (size_t)n * std::max(1, q - 1)))) return rc;
   if ((rc = ensure(c->scal, sizeof(SweepScalars)))) return rc;
@@ -894,15 +897,39 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
   int rc;
   if ((rc = ensure(c->amb, sizeof(long long) * (size_t)n))) return rc;
   hipLaunchKernelGGL(k_reset_amb, dim3(1), dim3(1), 0, c->stream, sc);
-  if (c->cs.kind == 1) {
-    const int d = c->cs.d;
-    // ranks > 1: every rank transforms the all-gathered U mask of the whole grid (witnesses cross shards)
-    const long long nt = c->world > 1 ? c->grid_total : n;
-    const long long goff = c->world > 1 ? c->cs.first : 0;
-    const uint8_t* Uall = c->world > 1 ? (const uint8_t*)c->Ufull.p : (const uint8_t*)c->maskU.p;
+  const int d_ = c->cs.d;
+  long long plane = 1;                       // candidates per step of the slowest axis
+  for (int a = 0; a < d_ - 1; ++a) plane *= c->cs.count[a];
+  const bool plane_aligned = c->cs.kind == 1 && c->cs.first % plane == 0 && n % plane == 0;
+  if (c->cs.kind == 1 && plane_aligned) {
+    const int d = d_;
+    // Window of the transform: this rank's hyper-planes of the slowest axis plus, with ranks > 1, a halo of
+    // ceil(cap / h) planes on either side taken from the all-gathered U mask (cap = largest radius that can matter,
+    // from the keys of collective C1).  Witnesses further away cannot change a verdict, so the window is exact.
+    const long long planes_total = c->world > 1 ? c->cs.count[d - 1] : n / plane;
+    long long p0 = c->world > 1 ? c->cs.first / plane : 0, p1 = p0 + n / plane;
+    const long long own0 = p0;
+    if (c->world > 1) {
+      double L, rmax = 0.0;
+      memcpy(&L, &c->h_c1[1 + lidx], 8);
+      if (c->h_c1[1 + kMaxQ + cidx]) rmax = ord_val(c->h_c1[1 + kMaxQ + cidx]);
+      const double hl = d >= 2 ? c->cs.step[d - 1] : c->cs.step[0];
+      long long H = planes_total;
+      if (L > 0 && hl > 0) {
+        const double cap = rmax / L * 1.000001 + 1e-6;
+        const double hp = std::ceil(cap / hl) + 2.0;
+        if (hp < (double)planes_total) H = (long long)hp;
+      }
+      p0 = std::max(0ll, p0 - H);
+      p1 = std::min(planes_total, p1 + H);
+    }
+    const long long wplanes = p1 - p0;
+    const long long nt = wplanes * plane;
+    const long long goff = (own0 - p0) * plane;                 // own candidates start here inside the window
+    const uint8_t* Uall = c->world > 1 ? (const uint8_t*)c->Ufull.p + p0 * plane : (const uint8_t*)c->maskU.p;
     if ((rc = ensure(c->dist2, sizeof(double) * (size_t)nt))) return rc;
     if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)nt))) return rc;
-    const int count0 = (int)c->cs.count[0];
+    const int count0 = d >= 2 ? (int)c->cs.count[0] : (int)nt;  // d == 1: the window is one line
     const long long nlines = nt / count0;
     hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, c->stream, Uall, nlines, count0,
                        c->cs.step[0], (double*)c->dist2.p);
@@ -916,7 +943,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       std::swap(din, dout);
       stride *= c->cs.count[a];
     }
-    // coarse transform (whole grid, uncapped, tiny): lets most candidates decide without the per-candidate scan
+    // coarse transform of the window (uncapped, tiny): lets most candidates decide without the per-candidate scan
     CoarseGrid cg;
     memset(&cg, 0, sizeof(cg));
     cg.d = d;
@@ -924,11 +951,11 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     long long nc = 1;
     double h2 = 0.0;
     for (int a = 0; a < d; ++a) {
-      cg.count[a] = c->cs.count[a];
-      cg.ccount[a] = (c->cs.count[a] + kCoarse - 1) / kCoarse;
+      cg.count[a] = a == d - 1 ? wplanes : c->cs.count[a];
+      cg.ccount[a] = (cg.count[a] + kCoarse - 1) / kCoarse;
       nc *= cg.ccount[a];
       h2 += c->cs.step[a] * c->cs.step[a];
-      if (c->cs.count[a] < 4 * kCoarse) coarse_ok = false;
+      if (cg.count[a] < 4 * kCoarse) coarse_ok = false;
     }
     if (coarse_ok) {
       cg.enabled = 1;
@@ -956,9 +983,9 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     }
     double xscale = 0.0;
     for (int a = 0; a < d; ++a) xscale = std::max(xscale, std::max(std::fabs(c->cs.lo[a]), std::fabs(c->cs.hi[a])));
-    const int last_cnt = d >= 2 ? (int)c->cs.count[d - 1] : 1;
+    const int last_cnt = d >= 2 ? (int)wplanes : 1;
     const double last_h = d >= 2 ? c->cs.step[d - 1] : 0.0;
-    if (c->edt_tiled && d >= 2 && last_cnt >= 32 && goff % stride == 0 && n % stride == 0) {
+    if (c->edt_tiled && d >= 2 && last_cnt >= 32) {
       const long long tiles = ((stride + 63) / 64) * ((n / stride + 15) / 16);
       hipLaunchKernelGGL((k_edt_decide_tiled<T>), dim3((unsigned)tiles), dim3(256), 0, c->stream, (const double*)din, n, goff, stride,
                          last_cnt, last_h, d, xscale, mean_c, var_c, (T)o->b, (const uint8_t*)c->maskS.p,
@@ -970,8 +997,9 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
                          (long long*)c->amb.p, cg);
     }
   } else {
+    // explicit candidate lists, and grid ranges that are not whole hyper-planes: exhaustive evaluation
     if (n > (1ll << 17))
-      return fail(SBO_E_UNSUPPORTED, "expander sets on explicit candidate lists are exhaustive: N <= 131072");
+      return fail(SBO_E_UNSUPPORTED, "expander sets need a grid of whole hyper-planes, or at most 131072 candidates (exhaustive)");
     if (c->world > 1)
       return fail(SBO_E_UNSUPPORTED, "expander sets on explicit candidate lists are single-rank");
     hipLaunchKernelGGL(k_list_safe, dim3(nb), dim3(256), 0, c->stream, (const uint8_t*)c->maskS.p, n, sc, G,
@@ -1022,13 +1050,17 @@ static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U
   hipLaunchKernelGGL(k_pack_c1, dim3(1), dim3(64), 0, c->stream, (const SweepScalars*)sc, (const unsigned long long*)c->Lmax.p, kb);
   if ((rc = comm_allreduce_max_u64(c, kb, 1 + 2 * kMaxQ))) return rc;
   hipLaunchKernelGGL(k_unpack_c1, dim3(1), dim3(64), 0, c->stream, sc, (unsigned long long*)c->Lmax.p, (const unsigned long long*)kb);
+  // the host needs the global L and radius keys to size the halo of the expander transform
+  c->h_c1.assign(1 + 2 * kMaxQ, 0ull);
+  SBO_HIP(hipMemcpyAsync(c->h_c1.data(), kb, sizeof(unsigned long long) * (1 + 2 * kMaxQ), hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
   if (need_U && q > 1) {
     long long maxlocal = 0;
     for (int r = 0; r < c->world; ++r) maxlocal = std::max(maxlocal, c->first_of[r + 1] - c->first_of[r]);
     if ((rc = ensure(c->gather, (size_t)maxlocal * c->world))) return rc;
     if ((rc = ensure(c->Ufull, (size_t)c->grid_total))) return rc;
-    // send buffer: own U mask padded to maxlocal (maskU is allocated >= n; the tail is never compacted)
-    if ((rc = ensure(c->maskU, (size_t)maxlocal))) return rc;
+    // send buffer: own U mask, allocated with the padded size in sweep_common_front (the tail is never compacted)
+    if (c->maskU.bytes < (size_t)maxlocal) return fail(SBO_E_INVALID, "internal: U mask smaller than the padded shard");
     if ((rc = comm_allgather_bytes(c, c->maskU.p, c->gather.p, (size_t)maxlocal))) return rc;
     hipLaunchKernelGGL(k_compact_shards, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
                        c->stream, (const uint8_t*)c->gather.p, maxlocal, c->world, (const long long*)c->shard_first.p,

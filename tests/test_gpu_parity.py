@@ -358,6 +358,34 @@ def test_single_candidate_and_empty_shard(engine):
         engine.sweep_safeopt(0.5)
 
 
+@pytest.mark.parametrize("first_plane,planes", [(0, 20), (13, 24), (30, 20)])
+def test_sweep_of_a_plane_range_treats_it_as_the_candidate_set(engine, first_plane, planes):
+    """A single rank sweeping hyper-planes [first, first + planes) of a grid: the candidate set is that range (witnesses
+    outside it do not exist), indices reported are the grid's global flat indices."""
+    cfg = synthetic.make_config("B", n=128)
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [64, 50]
+    first, nloc = first_plane * 64, planes * 64
+    pts = oracle.grid_points(lo, hi, count, first=first, n=nloc)
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"])
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count, first=first, n_local=nloc)
+    if ref["empty_safe_set"]:
+        with pytest.raises(safebo_amd.EmptySafeSetError):
+            engine.sweep_safeopt(cfg["b"])
+        return
+    res = engine.sweep_safeopt(cfg["b"], want_masks=True)
+    _check_safeopt(engine, ref, 2)
+    assert res["minimizer_index"] == first + ref["minimizer_index"]
+    assert [int(i) for i in res["expander_index_c"]] == [first + int(i) if i >= 0 else -1 for i in ref["expander_index"]]
+    # a range that is not made of whole planes goes through the exhaustive path
+    engine.set_grid(lo, hi, count, first=first + 7, n_local=nloc - 20)
+    pts2 = oracle.grid_points(lo, hi, count, first=first + 7, n=nloc - 20)
+    ref2 = oracle.safeopt_sweep(pts2, cfg["ds"], cfg["b"])
+    if not ref2["empty_safe_set"]:
+        engine.sweep_safeopt(cfg["b"], want_masks=True)
+        _check_safeopt(engine, ref2, 2)
+
+
 def test_full_size_properties_config_B(engine):
     """BASELINE.json configs[1] at full size (2048^2, n = 128): properties that do not need the whole oracle."""
     cfg = synthetic.make_config("B")
@@ -399,19 +427,25 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-@pytest.mark.parametrize("cfg_name,n,count,b", [("A", 20, [50, 37], 3.0), ("C", 64, [48, 41], 2.0), ("D", 128, [9, 8, 7, 5], 0.5)])
-def test_two_rank_sweep_on_one_gpu_matches_oracle(tmp_path, cfg_name, n, count, b):
+@pytest.mark.parametrize("world,cfg_name,n,count,b", [(2, "A", 20, [50, 37], 3.0), (2, "C", 64, [48, 41], 2.0),
+                                                       (2, "D", 128, [9, 8, 7, 5], 0.5), (4, "C", 64, [40, 83], 2.0),
+                                                       (3, "B", 128, [64, 50], 3.0)])
+def test_multi_rank_sweep_on_one_gpu_matches_oracle(tmp_path, world, cfg_name, n, count, b):
+    """2-4 ranks share the test box's single GPU (collectives over the gloo relay): uneven plane shards, halo windows
+    of the expander transform for first / middle / last ranks, host merge of the arg-max slots."""
     port, out = _free_port(), str(tmp_path / "res.json")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), "2", port, out, cfg_name,
-                               str(n), json.dumps(count), str(b)]) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), str(world), port, out, cfg_name,
+                               str(n), json.dumps(count), str(b)]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     res = json.load(open(out))
     cfg = synthetic.make_config(cfg_name, n=n)
     pts = oracle.grid_points(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
     ref = oracle.safeopt_sweep(pts, cfg["ds"], b)
-    parts = [np.load(out + f".rank{r}.npz") for r in range(2)]
-    assert int(parts[0]["first"]) == 0 and int(parts[1]["first"]) == int(parts[0]["n_local"])
+    parts = [np.load(out + f".rank{r}.npz") for r in range(world)]
+    assert int(parts[0]["first"]) == 0
+    for r in range(1, world):
+        assert int(parts[r]["first"]) == int(parts[r - 1]["first"]) + int(parts[r - 1]["n_local"])
     for k in ("S", "U", "M"):
         assert np.array_equal(np.concatenate([p[k] for p in parts]), ref[k]), k
     for c in range(1, cfg["q"]):
