@@ -36,6 +36,9 @@ template <> struct MM<float> {
   static __device__ __forceinline__ acc_t mfma(a_t a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
+  // k-step kk of a diagonal block: the 16x16x4 form cannot skip the zero part of the triangle
+  template <int KK>
+  static __device__ __forceinline__ acc_t mfma_diag(a_t a, float b, acc_t c) { return mfma(a, b, c); }
   static __host__ __device__ __forceinline__ int jslot(int kk, int slot) { return 4 * slot + kk; }
   static __host__ __device__ __forceinline__ int pack_pos(int r, int k, int kk) { return (k * 16 + r) * 4 + kk; }
 };
@@ -53,6 +56,16 @@ template <> struct MM<double> {
     c[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], b, c[0], 0, 0, 0);
     c[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], b, c[1], 0, 0, 0);
     c[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], b, c[2], 0, 0, 0);
+    c[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], b, c[3], 0, 0, 0);
+    return c;
+  }
+  // k-step kk of a DIAGONAL block of the lower-triangular factor: row group t (rows 4t..4t+3) times column group kk
+  // (columns 4kk..4kk+3) is identically zero for kk > t, so those 4x4x4 products are skipped (6 of 16 per block)
+  template <int KK>
+  static __device__ __forceinline__ acc_t mfma_diag(a_t a, double b, acc_t c) {
+    if (KK <= 0) c[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], b, c[0], 0, 0, 0);
+    if (KK <= 1) c[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], b, c[1], 0, 0, 0);
+    if (KK <= 2) c[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], b, c[2], 0, 0, 0);
     c[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], b, c[3], 0, 0, 0);
     return c;
   }

@@ -12,6 +12,7 @@
 // per-candidate reduction  sum_i t_i^2  inside the wave, then across the four waves through LDS.
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include "device_common.hpp"
 
 namespace sbo {
@@ -312,20 +313,34 @@ __global__ __launch_bounds__(256) void k_posterior_chunked(const ModelConst mc, 
           for (int kk = 0; kk < 4; ++kk) a_cur[r][kk] = a_nx[r][kk];
           MM<T>::load_a4(F_o + ((size_t)Ic_ * (Ic_ + 1) / 2 + J + 1) * 256, lane, a_nx[r]);
         }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        auto kstep = [&](auto kk_tag) {
+          constexpr int kk = decltype(kk_tag)::value;
           T bfr[S];
 #pragma unroll
           for (int s = 0; s < S; ++s) bfr[s] = Kf[((size_t)s * CB * 4 + (J - Jlo) * 4 + kk) * 64 + lane];
 #pragma unroll
           for (int r = 0; r < RW; ++r) {
             const int I = Ic * RC + wave + kWaves * r;   // rows interleaved over the waves (diagonal chunk balance)
-            if (I < nb && J <= I) {
+            if constexpr (std::is_same<T, double>::value) {
+              if (I < nb && J < I) {
 #pragma unroll
-              for (int s = 0; s < S; ++s) acc[r][s] = MM<T>::mfma(a_cur[r][kk], bfr[s], acc[r][s]);
+                for (int s = 0; s < S; ++s) acc[r][s] = MM<T>::mfma(a_cur[r][kk], bfr[s], acc[r][s]);
+              } else if (J == I) {                       // diagonal block: zero 4x4 sub-blocks skipped
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[r][s] = MM<T>::template mfma_diag<kk>(a_cur[r][kk], bfr[s], acc[r][s]);
+              }
+            } else {
+              if (I < nb && J <= I) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[r][s] = MM<T>::mfma(a_cur[r][kk], bfr[s], acc[r][s]);
+              }
             }
           }
-        }
+        };
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{});
+        kstep(std::integral_constant<int, 3>{});
       }
     }
 #pragma unroll
@@ -566,35 +581,53 @@ __global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, con
 #pragma unroll
       for (int s = 0; s < S; ++s) e1_nx[s] = e1p[s * npad];
       const bool is_top = (I == my_top);
-      for (int J = 0; J <= I; ++J) {
-        const bool dots = (J <= tmin) ? (is_top && (J % kWaves) == wave) : (J == I);
+      // one k-step: consume the prefetched operands, launch the next step's loads, then the matrix-core step
+      // (KK = -1: an off-diagonal block; KK = 0..3: k-step KK of the diagonal block, whose zero 4x4 sub-blocks are skipped)
+      auto kstep = [&](auto kk_tag, auto diag_tag, const int J, const bool dots) {
+        constexpr int kk = decltype(kk_tag)::value;
+        constexpr bool diag = decltype(diag_tag)::value;
+        const a_t a = a_nx;
+        T b[S];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const a_t a = a_nx;
-          T b[S];
+        for (int s = 0; s < S; ++s) b[s] = e_nx * e1_nx[s];
+        // operands of the next step (global fragments and LDS factors) fly behind this step's MFMAs; the reads
+        // past the row's last step stay inside the padded buffers / the LDS allocation
+        ep += 64;
+        e1p += 4;
+        a_nx = (kk < 3) ? MM<T>::load_a(fp, lane, kk + 1) : MM<T>::load_a(fp + 256, lane, 0);
+        if (kk == 3) fp += 256;
+        e_nx = ep[lane];
 #pragma unroll
-          for (int s = 0; s < S; ++s) b[s] = e_nx * e1_nx[s];
-          // operands of the next step (global fragments and LDS factors) fly behind this step's MFMAs; the reads
-          // past the row's last step stay inside the padded buffers / the LDS allocation
-          ep += 64;
-          e1p += 4;
-          a_nx = (kk < 3) ? MM<T>::load_a(fp, lane, kk + 1) : MM<T>::load_a(fp + 256, lane, 0);
-          if (kk == 3) fp += 256;
-          e_nx = ep[lane];
+        for (int s = 0; s < S; ++s) e1_nx[s] = e1p[s * npad];
 #pragma unroll
-          for (int s = 0; s < S; ++s) e1_nx[s] = e1p[s * npad];
+        for (int s = 0; s < S; ++s) {
+          if constexpr (diag) acc[s] = MM<T>::template mfma_diag<kk>(a, b[s], acc[s]);
+          else acc[s] = MM<T>::mfma(a, b[s], acc[s]);
+        }
+        if (dots) {
+          const T* ax = AX_o + (J * 16 + kk * 4) * NC_AX(D);
 #pragma unroll
-          for (int s = 0; s < S; ++s) acc[s] = MM<T>::mfma(a, b[s], acc[s]);
-          if (dots) {
-            const T* ax = AX_o + (J * 16 + kk * 4) * NC_AX(D);
+          for (int s = 0; s < S; ++s) {
+            m0[s] = fma(ax[0], b[s], m0[s]);
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-              m0[s] = fma(ax[0], b[s], m0[s]);
-#pragma unroll
-              for (int a_ = 0; a_ < D; ++a_) ms[s][a_] = fma(ax[1 + a_], b[s], ms[s][a_]);
-            }
+            for (int a_ = 0; a_ < D; ++a_) ms[s][a_] = fma(ax[1 + a_], b[s], ms[s][a_]);
           }
         }
+      };
+      using std::integral_constant;
+      for (int J = 0; J < I; ++J) {
+        const bool dots = (J <= tmin) ? (is_top && (J % kWaves) == wave) : false;
+        kstep(integral_constant<int, 0>{}, integral_constant<bool, false>{}, J, dots);
+        kstep(integral_constant<int, 1>{}, integral_constant<bool, false>{}, J, dots);
+        kstep(integral_constant<int, 2>{}, integral_constant<bool, false>{}, J, dots);
+        kstep(integral_constant<int, 3>{}, integral_constant<bool, false>{}, J, dots);
+      }
+      {
+        const bool dots = (I <= tmin) ? (is_top && (I % kWaves) == wave) : true;
+        kstep(integral_constant<int, 0>{}, integral_constant<bool, true>{}, I, dots);
+        kstep(integral_constant<int, 1>{}, integral_constant<bool, true>{}, I, dots);
+        kstep(integral_constant<int, 2>{}, integral_constant<bool, true>{}, I, dots);
+        kstep(integral_constant<int, 3>{}, integral_constant<bool, true>{}, I, dots);
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
