@@ -212,6 +212,12 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->engine = (int)value;
     return SBO_OK;
   }
+  if (!strcmp(key, "k1_strips")) {
+    if (value != 4 && value != 8) return fail(SBO_E_INVALID, "k1_strips must be 4 or 8");
+    c->k1_strips = (int)value;
+    c->posterior_valid = false;
+    return SBO_OK;
+  }
   if (!strcmp(key, "k1_wgs_per_cu")) {
     if (value < 0 || value > 64) return fail(SBO_E_INVALID, "k1_wgs_per_cu out of range");
     c->k1_wgs_per_cu = (int)value;

@@ -648,12 +648,12 @@ __global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, con
     }
     __syncthreads();
 
-    // ---------------- epilogue: one thread per candidate (wave 0; the other waves move on to the next tile) ----
-    if (tid < 64) {
+    // ---------------- epilogue: one thread per candidate (the other waves move on to the next tile) ----
+    if (tid < P) {
       const int s = tid >> 4, p0 = tid & 15;
       const unsigned int g0 = t0 * 16 + p0;
       const long long line = (long long)lt * S + s;
-      const bool valid = (tid < P) && (g0 < cnt0) && (line < gt.nlines);
+      const bool valid = (g0 < cnt0) && (line < gt.nlines);
       if (valid) {
         const long long g = line * cnt0 + g0;
         T sums[NC];
@@ -689,13 +689,13 @@ __global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, con
       }
     }
   }
-  if (tid < 64) {
+  if (tid < (P < 64 ? 64 : P)) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const double other = __shfl_xor(gmax, o);
       gmax = other > gmax ? other : gmax;
     }
-    if (tid == 0) atomicMax(&Lmax[out], (unsigned long long)__double_as_longlong(gmax));
+    if (lane == 0) atomicMax(&Lmax[out], (unsigned long long)__double_as_longlong(gmax));
   }
 }
 
@@ -809,9 +809,8 @@ static int launch_posterior_s(sbo_ctx* c) {
   return fail(SBO_E_UNSUPPORTED, "n too large for the LDS-resident cross-covariance tile");
 }
 
-template <typename T, int D>
-static int launch_posterior_grid_t(sbo_ctx* c) {
-  constexpr int S = 4;
+template <typename T, int D, int S>
+static int launch_posterior_grid_ts(sbo_ctx* c) {
   constexpr int P = 16 * S;
   const ModelConst& mc = c->mc;
   const CandSpec& cs = c->cs;
@@ -856,6 +855,12 @@ static int launch_posterior_grid_t(sbo_ctx* c) {
                      (unsigned int)tiles, (T*)c->mean.p, (T*)c->var.p, (unsigned long long*)c->Lmax.p);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
+}
+
+template <typename T, int D>
+static int launch_posterior_grid_t(sbo_ctx* c) {
+  if (c->k1_strips == 8 && D == 2) return launch_posterior_grid_ts<T, 2, 8>(c);   // tuning knob, 2-D only
+  return launch_posterior_grid_ts<T, D, 4>(c);
 }
 
 template <typename T>

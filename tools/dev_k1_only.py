@@ -8,6 +8,7 @@ from safebo_amd import synthetic
 eng = safebo_amd.SweepEngine(0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 if len(sys.argv) > 2: eng.set_option("k1_wgs_per_cu", int(sys.argv[2]))
+if len(sys.argv) > 3: eng.set_option("k1_strips", int(sys.argv[3]))
 for name, n in (("B", 128), ("H", 512)):
     cfg = synthetic.make_config(name, n=n)
     eng.set_model(cfg["ds"], dtype="f64")
