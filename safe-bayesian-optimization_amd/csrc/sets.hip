@@ -1206,7 +1206,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
 }
 
 template <typename T, int D>
-static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* O) {
+static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8_t* src, uint8_t* O) {
   const long long n = c->cs.n_local;
   if (n == 0) return SBO_OK;
   const int q = c->mc.q;
@@ -1215,22 +1215,22 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* O)
   const T* var_c = (const T*)c->var.p + (size_t)cidx * n;
   const int nruns = (int)((n + kRun - 1) / kRun);
   int rc;
-  if ((rc = ensure(c->amb, sizeof(RunMeta) * (size_t)nruns))) return rc;
+  if ((rc = ensure(c->runmeta, sizeof(RunMeta) * (size_t)nruns))) return rc;
   hipLaunchKernelGGL((k_goose_run_meta<T, D>), dim3(nruns), dim3(256), 0, c->stream, c->cs, mean_c, var_c, (T)o->b,
-                     (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, (RunMeta*)c->amb.p);
+                     src, (const unsigned long long*)c->Lmax.p, lidx, (RunMeta*)c->runmeta.p);
   hipLaunchKernelGGL((k_goose_optimistic<T, D>), dim3(nruns), dim3(256), 0, c->stream, c->cs, mean_c, var_c, (T)o->b,
-                     (const uint8_t*)c->maskS.p, (const uint8_t*)c->maskU.p, (const unsigned long long*)c->Lmax.p, lidx,
-                     (const RunMeta*)c->amb.p, nruns, O);
+                     src, (const uint8_t*)c->maskU.p, (const unsigned long long*)c->Lmax.p, lidx,
+                     (const RunMeta*)c->runmeta.p, nruns, O);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
 
 template <typename T>
-static int goose_sets_d(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* O) {
+static int goose_sets_d(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8_t* src, uint8_t* O) {
   switch (c->mc.dpad) {
-    case 2: return goose_sets<T, 2>(c, o, cidx, O);
-    case 4: return goose_sets<T, 4>(c, o, cidx, O);
-    case 8: return goose_sets<T, 8>(c, o, cidx, O);
+    case 2: return goose_sets<T, 2>(c, o, cidx, src, O);
+    case 4: return goose_sets<T, 4>(c, o, cidx, src, O);
+    case 8: return goose_sets<T, 8>(c, o, cidx, src, O);
   }
   return fail(SBO_E_UNSUPPORTED, "unsupported padded dimension");
 }
@@ -1261,22 +1261,36 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   if ((rc = sweep_common_front<T>(c, o))) return rc;
   if ((rc = sweep_exchange_front<T>(c, o, false))) return rc;
   if ((rc = ensure(c->maskO, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
-  if ((rc = ensure(c->dist2, sizeof(double) * (size_t)std::max<long long>(n, 1)))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
-  T* lcb0 = (T*)c->dist2.p;      // value array for the arg-min reductions
+  SBO_HIP(hipEventRecord(c->ev[2], c->stream));
+  // Only expanders can cover an unsafe point: "g covers h" is the predicate that puts g into G_c.  So G_c is built
+  // first (distance transform, cheap) and serves as the source set of the coverage search instead of all of S_t.
+  if ((rc = ensure(c->maskG, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
+  for (int cc = 1; cc < q; ++cc) {
+    uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
+    uint8_t* O = (uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
+    // (a large explicit list has no transform to build G_c with: all of S_t stays the source set there)
+    long long plane = 1;
+    for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
+    const bool can_expand = n <= (1ll << 17) || (c->cs.kind == 1 && c->cs.first % plane == 0 && n % plane == 0);
+    const uint8_t* src = (const uint8_t*)c->maskS.p;
+    if (can_expand) {
+      if ((rc = expander_set<T>(c, o, cc, G))) return rc;
+      src = G;
+    }
+    if ((rc = goose_sets_d<T>(c, o, cc, src, O))) return rc;
+  }
+  SBO_HIP(hipEventRecord(c->ev[3], c->stream));
+  // value array for the arg-min reductions (after the expander transform, which uses the same scratch buffer)
+  if ((rc = ensure(c->dist2, sizeof(double) * (size_t)std::max<long long>(n, 1)))) return rc;
+  T* lcb0 = (T*)c->dist2.p;
   if (n > 0) {
     hipLaunchKernelGGL((k_lcb0<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b, lcb0);
     hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
                        (long long)c->cs.first, (long long*)nullptr, (Best*)c->partial.p);
   }
   hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0);
-  SBO_HIP(hipEventRecord(c->ev[2], c->stream));
-  for (int cc = 1; cc < q; ++cc) {
-    uint8_t* O = (uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
-    if ((rc = goose_sets_d<T>(c, o, cc, O))) return rc;
-  }
-  SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   for (int cc = 1; cc < q; ++cc) {
     const uint8_t* O = (const uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
     if (n > 0)
