@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_list_safe(const uint8_t* __restrict__ S
   }
 }
 
-// exhaustive evaluation of the reference predicate for the listed g: one workgroup per g, all U points
+// exhaustive evaluation of the reference predicate for the listed g: one workgroup per g, every U point that can matter
 template <typename T, int D>
 __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const CandSpec csU, const T* __restrict__ mean_c,
                                                         const T* __restrict__ var_c, T b, const uint8_t* __restrict__ U,
@@ -553,11 +553,54 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
     double xg[D];
     cand_coords<D>(cs, g, xg);
     int found = 0;
-    for (long long hh = threadIdx.x; hh < csU.n_local && !found; hh += blockDim.x) {
-      if (U[hh]) {
+    if (csU.kind == 1) {
+      // grid: only witnesses inside the index box of half-width ceil(r / h_a) + 1 around g can satisfy the predicate
+      long long lo[D], len[D], stridea[D];
+      long long f = cs.first + g, total = 1, sa = 1;
+      const double rg = L > 0 ? ucb / L : 1e300;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        lo[a] = 0; len[a] = 1; stridea[a] = 0;
+        if (a < cs.d) {
+          const long long cnt = cs.count[a];
+          const long long ig = f % cnt;
+          f /= cnt;
+          long long R = cnt;
+          if (L > 0 && cs.step[a] > 0) {
+            const double rr = (rg * (1.0 + 1e-9) + 1e-7) / cs.step[a];
+            R = rr < (double)cnt ? (long long)ceil(rr) + 1 : cnt;
+            if (R < 0) R = 0;
+          }
+          const long long l0 = ig - R > 0 ? ig - R : 0, h0 = ig + R < cnt - 1 ? ig + R : cnt - 1;
+          lo[a] = l0; len[a] = h0 - l0 + 1; stridea[a] = sa;
+          total *= len[a];
+          sa *= cnt;
+        }
+      }
+      for (long long t = threadIdx.x; t < total && !found; t += blockDim.x) {
+        long long u = t, hh = 0;
         double xh[D];
-        cand_coords<D>(csU, hh, xh);
-        if (lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          xh[a] = 0.0;
+          if (a < cs.d) {
+            const long long ia = lo[a] + u % len[a];
+            u /= len[a];
+            hh += ia * stridea[a];
+            const long long cnt = cs.count[a];
+            xh[a] = (ia == cnt - 1 && cnt > 1) ? cs.hi[a] : __dadd_rn(cs.lo[a], __dmul_rn((double)ia, cs.step[a]));
+          }
+        }
+        const long long hl = hh - csU.first;
+        if (hl >= 0 && hl < csU.n_local && U[hl] && lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
+      }
+    } else {
+      for (long long hh = threadIdx.x; hh < csU.n_local && !found; hh += blockDim.x) {
+        if (U[hh]) {
+          double xh[D];
+          cand_coords<D>(csU, hh, xh);
+          if (lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
+        }
       }
     }
     found = __syncthreads_or(found);
