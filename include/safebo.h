@@ -215,7 +215,8 @@ int sbo_nll_batch(sbo_ctx* ctx, int n, int d, const double* X_norm, const double
 
 /* ---- measurement --------------------------------------------------------------------------- */
 int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
-/* selects the fp64 contraction engine of K1: 0 = MFMA (v_mfma_f64_16x16x4_f64), 1 = VALU FMA */
+/* tuning / diagnostics knobs: "posterior_path" (0 auto, 1 generic single-phase, 2 generic chunked), "k1_wgs_per_cu",
+ * "k1_strips" (4 | 8), "edt_tiled" (0 | 1) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

@@ -207,11 +207,6 @@ int sbo_synchronize(sbo_ctx* c) {
 
 int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   if (!c || !key) return fail(SBO_E_INVALID, "ctx/key is NULL");
-  if (!strcmp(key, "fp64_engine")) {
-    if (value != 0 && value != 1) return fail(SBO_E_INVALID, "fp64_engine must be 0 (MFMA) or 1 (VALU)");
-    c->engine = (int)value;
-    return SBO_OK;
-  }
   if (!strcmp(key, "k1_strips")) {
     if (value != 4 && value != 8) return fail(SBO_E_INVALID, "k1_strips must be 4 or 8");
     c->k1_strips = (int)value;

@@ -92,7 +92,6 @@ struct sbo_ctx {
   sbo_profile prof{};
   hipEvent_t ev[8]{};
   // options
-  int engine = 0;      // 0 MFMA, 1 VALU (fp64 contraction engine)
   int k1_strips = 4;       // lines per K1g tile (4, or 8 for 2-D grids: tuning)
   int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
   int edt_tiled = 0;       // 1: LDS-tiled lock-step form of the last-axis expander scan (slower on measured configs)

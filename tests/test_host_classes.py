@@ -230,3 +230,28 @@ def test_safeopt_campaign_plumbing_config_A():
         if std_exp < 0.01 and std_min < 0.01:
             break
     assert m.n_point == 4 + it + 1
+
+
+@pytest.mark.gpu
+def test_goose_campaign_reaches_the_benoit_optimum_safely():
+    """The loop of test/test_GoOSE.py:142-190 end to end -- pessimistic safe minimum vs optimistic target, explore_safeset,
+    add_sample with a refit (DE evaluated on the device) -- on a 400 x 400 candidate grid, with the reference's own stopping
+    rule |f(x_new) - 0.145249| <= 0.005 (test/test_GoOSE.py:182).  No evaluated point may violate the plant constraint."""
+    m = GoOSE.BO([benoit_f, benoit_g], BOUND, 2.0, grid=(400, 400), seed=1)
+    m.fit_on_device = True
+    m.de_options = {"seed": 0, "maxiter": 60, "tol": 1e-4}
+    X, Y = m.Data_sampling(4, np.array([1.4, -.8]), 0.3)
+    m.GP_initialization(X, Y, "RBF", multi_hyper=5)
+    reached, worst = False, np.inf
+    for it in range(25):
+        x_safe, lcb_safe = m.minimize_obj_lcb()
+        x_t, lcb_t = m.Target()
+        x_new = x_safe if lcb_safe <= lcb_t else m.explore_safeset(x_t)          # test/test_GoOSE.py:158-162
+        y = m.calculate_plant_outputs(x_new)
+        worst = min(worst, y[1])
+        m.add_sample(x_new, y)
+        if abs(y[0] - 0.145249) <= 0.005:
+            reached = True
+            break
+    assert reached, f"optimum not reached in 25 iterations (last f = {y[0]})"
+    assert worst >= -1e-3, f"unsafe evaluation: constraint value {worst}"
