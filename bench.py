@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--config", default="B", help="synthetic config (B = BASELINE.json configs[1]; H = 4096^2, n = 512)")
     ap.add_argument("--n", type=int, default=None, help="override the number of observations")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="candidates timed by the CPU baseline (0 = skip)")
+    ap.add_argument("--points", type=int, default=10_000_000, help="candidates per rank for the scattered config E")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: the grid's slowest axis grows with the ranks (default); strong: fixed grid, sharded")
     return ap.parse_args()
@@ -100,19 +101,27 @@ def main():
         dist = distributed.init_gloo_from_env()   # rendezvous only (gloo over 127.0.0.1)
 
     cfg = synthetic.make_config(args.config, n=args.n)
-    if cfg["count"] is None:
-        raise SystemExit("bench.py sweeps grid configs (A, B, C, D, H)")
-    count = list(cfg["count"])
-    if args.scaling == "weak":
-        count[-1] *= world                               # weak scaling: slowest axis grows with the ranks
+    scattered = cfg["count"] is None                      # config E: explicit list of scattered candidates
+    if scattered:
+        per_rank = args.points if args.scaling == "weak" else args.points // world
+        n_total = per_rank * world
+        count = None
+    else:
+        count = list(cfg["count"])
+        if args.scaling == "weak":
+            count[-1] *= world                           # weak scaling: slowest axis grows with the ranks
+        n_total = int(np.prod(count))
     lo, hi = cfg["bound"][:, 0].copy(), cfg["bound"][:, 1].copy()
-    n_total = int(np.prod(count))
 
     eng = safebo_amd.SweepEngine(local_rank)
     if world > 1:
         distributed.join(eng)                    # RCCL communicator: unique id broadcast from rank 0
-    eng.set_model(cfg["ds"], dtype=cfg["dtype"])
-    eng.set_grid_sharded(lo, hi, count)                  # candidates are implicit: resident by construction
+    eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=(cfg["dtype"] == "f64"))
+    if scattered:
+        pts = synthetic.scattered_points(cfg, n_total)[rank * per_rank:(rank + 1) * per_rank]
+        eng.set_points(pts, first=rank * per_rank)       # uploaded to HBM before the timed region
+    else:
+        eng.set_grid_sharded(lo, hi, count)              # candidates are implicit: resident by construction
 
     def barrier():
         eng.synchronize()
@@ -157,20 +166,21 @@ def main():
             "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
-            "config": {"workload": f"config {args.config}: {cfg['plant']} {cfg['d']}-D SafeOpt sweep, implicit grid "
-                                   f"{'x'.join(str(c) for c in count)} ({n_total} candidates), n={cfg['ds']['X_norm'].shape[0]} "
-                                   f"observations, q={cfg['q']} outputs, b={cfg['b']}",
+            "config": {"workload": f"config {args.config}: {cfg['plant']} {cfg['d']}-D SafeOpt sweep, "
+                                   + (f"explicit list of {n_total} scattered candidates" if scattered else
+                                      f"implicit grid {'x'.join(str(c) for c in count)} ({n_total} candidates)")
+                                   + f", n={cfg['ds']['X_norm'].shape[0]} observations, q={cfg['q']} outputs, b={cfg['b']}",
                        "per_gpu_candidates": n_total // world, "sweep": "safeopt",
                        "result": {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
                                   "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel": "k_posterior_grid", "kernel_ms": k1,
+                         "traffic": traffic, "kernel": "k_posterior_chunked" if scattered else "k_posterior_grid", "kernel_ms": k1,
                          "algorithmic_flops_per_candidate": float(np.mean(k1_flops)) / (n_total // world),
                          "peak_source": "AMD MI355X datasheet FP64 matrix (no f64 row in MI355X_MICROARCH.md)" if cfg["dtype"] == "f64" else "MI355X_MICROARCH.md f32 MFMA",
                          "peak_measured_mfma_f64": FP64_MFMA_MEASURED_TFLOPS if cfg["dtype"] == "f64" else None,
                          "device_ms_per_step": float(np.mean(tot_ms))},
         }
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and not scattered:
             out["cpu_baseline"] = cpu_baseline(cfg, count, args.cpu_sample)
         print(json.dumps(out))
     if dist is not None:

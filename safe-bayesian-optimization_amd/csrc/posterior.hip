@@ -205,11 +205,11 @@ __global__ __launch_bounds__(256) void k_posterior(const ModelConst mc, const Ca
 // LDS once n is large (n = 2048 x 64 candidates x 4 B = 512 KiB), so the triangle is walked in chunks of CB
 // row/column blocks: for row chunk Ic every wave keeps RW row blocks x 4 strips of accumulators in registers and
 // the column chunks Jc <= Ic are generated into LDS one after the other (K* of a column chunk is therefore
-// re-generated for every row chunk at or above it -- (nc+1)/2 times on average -- which costs VALU exp() work
+// re-generated for every row chunk at or above it -- about (nc+1)/2 times on average -- which costs VALU exp() work
 // but keeps 64 candidates per workgroup, i.e. four MFMAs per A-fragment load instead of one).
 // =====================================================================================================
 template <typename T> struct ChunkCfg;
-template <> struct ChunkCfg<float> { static constexpr int CB = 16, RW = 4; };    // 64 KiB K* chunk, 64 acc VGPRs
+template <> struct ChunkCfg<float> { static constexpr int CB = 16, RW = 8; };    // 64 KiB K* chunk, 128 acc VGPRs
 template <> struct ChunkCfg<double> { static constexpr int CB = 8, RW = 2; };    // 64 KiB K* chunk, 64 acc VGPRs
 
 template <typename T, int D>
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_posterior_chunked(const ModelConst mc, 
   using a_t = typename MM<T>::a_t;
   constexpr int S = kWaves, P = 16 * S;
   constexpr int CB = ChunkCfg<T>::CB, RW = ChunkCfg<T>::RW, RC = RW * kWaves;
-  static_assert(RC == CB, "row and column chunks are aligned");
+  static_assert(RC % CB == 0, "a row chunk spans whole column chunks");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* Kf = reinterpret_cast<T*>(smem);              // [S][CB * 4][64]  K* fragments of the current column chunk
   T* qpart = Kf + (size_t)S * CB * 4 * 64;         // [kWaves][P]
@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void k_posterior_chunked(const ModelConst mc, 
   const int out = blockIdx.y;
   const long long tile0 = (long long)blockIdx.x * P;
   const int nb = mc.npad >> 4;
-  const int nc = (nb + CB - 1) / CB;               // chunks per side
+  const int ncr = (nb + RC - 1) / RC;              // row chunks
+  const int ncc = (nb + CB - 1) / CB;              // column chunks
 
   // this lane's candidate for the generation phases: strip = wave, candidate pp, k-slot `slot`
   long long gcand = tile0 + wave * 16 + pp;
@@ -264,14 +265,16 @@ __global__ __launch_bounds__(256) void k_posterior_chunked(const ModelConst mc, 
 #pragma unroll
   for (int s = 0; s < S; ++s) quad[s] = 0;
 
-  for (int Ic = 0; Ic < nc; ++Ic) {
+  for (int Ic = 0; Ic < ncr; ++Ic) {
     acc_t acc[RW][S];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
       for (int s = 0; s < S; ++s) acc[r][s] = acc_t{0, 0, 0, 0};
-    const bool with_dots = (Ic == nc - 1);          // the last row chunk sees every column chunk exactly once
-    for (int Jc = 0; Jc <= Ic; ++Jc) {
+    const bool with_dots = (Ic == ncr - 1);         // the last row chunk sees every column chunk exactly once
+    const int last_row = ((Ic + 1) * RC < nb ? (Ic + 1) * RC : nb) - 1;
+    const int Jc_end = last_row / CB < ncc ? last_row / CB : ncc - 1;   // last column chunk a row of this chunk reaches
+    for (int Jc = 0; Jc <= Jc_end; ++Jc) {
       // ---- generate K* fragments of column chunk Jc (strip = wave) ----
       __syncthreads();                              // previous chunk's readers are done
       const int Jlo = Jc * CB, Jhi = (Jlo + CB < nb) ? Jlo + CB : nb;
