@@ -113,9 +113,11 @@ def main():
         n_total = int(np.prod(count))
     lo, hi = cfg["bound"][:, 0].copy(), cfg["bound"][:, 1].copy()
 
-    eng = safebo_amd.SweepEngine(local_rank)
+    # one GPU per process; SBO_BENCH_DEVICE pins every rank to one card (single-GPU rehearsal of the N>1 plumbing only)
+    eng = safebo_amd.SweepEngine(int(os.environ.get("SBO_BENCH_DEVICE", local_rank)))
+    transport = "none"
     if world > 1:
-        distributed.join(eng)                    # RCCL communicator: unique id broadcast from rank 0
+        transport = distributed.join_with_fallback(eng)   # RCCL (unique id broadcast from rank 0); gloo relay if it cannot form
     eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=(cfg["dtype"] == "f64"))
     if scattered:
         pts = synthetic.scattered_points(cfg, n_total)[rank * per_rank:(rank + 1) * per_rank]
@@ -170,7 +172,7 @@ def main():
                                    + (f"explicit list of {n_total} scattered candidates" if scattered else
                                       f"implicit grid {'x'.join(str(c) for c in count)} ({n_total} candidates)")
                                    + f", n={cfg['ds']['X_norm'].shape[0]} observations, q={cfg['q']} outputs, b={cfg['b']}",
-                       "per_gpu_candidates": n_total // world, "sweep": "safeopt",
+                       "per_gpu_candidates": n_total // world, "sweep": "safeopt", "collectives": transport,
                        "result": {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
                                   "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

@@ -99,8 +99,11 @@ int sbo_comm_init_relay(sbo_ctx* c, int world_size, int rank, sbo_relay_allreduc
                         sbo_relay_allgather_fn allgather, void* user) {
   if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
   if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SBO_E_INVALID, "bad world_size / rank");
-  if (c->comm) return fail(SBO_E_INVALID, "communicator already initialised");
   if (world_size > 1 && (!allreduce || !allgather)) return fail(SBO_E_INVALID, "relay callbacks are NULL");
+  if (c->comm) {   // switching transports: drop the RCCL communicator
+    ncclCommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+  }
   c->world = world_size;
   c->rank = rank;
   c->relay_allreduce = allreduce;

@@ -100,6 +100,25 @@ def join(engine, relay: bool = False, group=None):
     engine.comm_init(world, rank, uid[0])
 
 
+def join_with_fallback(engine, group=None) -> str:
+    """RCCL if every rank can form the communicator, otherwise every rank falls back to the gloo relay (so a launcher
+    environment without working RCCL still runs, slower on the three small collectives).  Returns the transport used."""
+    import torch
+    import torch.distributed as dist
+    ok = 1
+    try:
+        join(engine, relay=False, group=group)
+    except Exception as exc:                      # noqa: BLE001 - any failure means "no RCCL here"
+        print(f"[rank {dist.get_rank(group)}] RCCL communicator failed ({exc}); trying the gloo relay")
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag[0]) == 1:
+        return "rccl"
+    join(engine, relay=True, group=group)
+    return "gloo-relay"
+
+
 def init_gloo_from_env():
     """init_process_group(gloo) from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     import torch.distributed as dist
