@@ -78,6 +78,8 @@ struct sbo_ctx {
   sbo::DevBuf partial; // arg-reduce per-block partials
   sbo::DevBuf amb;     // ambiguous-index list for the exact recheck
   sbo::DevBuf runmeta; // GoOSE: per-run bounding boxes / radii of the coverage search
+  sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
+  sbo::DevBuf Wfull;   // multi-rank GoOSE: source weights of the whole grid (all-gathered), T [grid_total]
   sbo::DevBuf Ufull;   // multi-rank: U mask of the whole grid (all-gathered), uint8 [grid_total]
   sbo::DevBuf gather;  // multi-rank: all-gather receive buffer [world][max_local]
   sbo::DevBuf xch;     // multi-rank: small exchange buffers (C1 keys, C3 rows)

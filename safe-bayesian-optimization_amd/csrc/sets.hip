@@ -627,9 +627,10 @@ __global__ void k_unpack_c1(SweepScalars* sc, unsigned long long* Lkeys, const u
   if (t < kMaxQ) { Lkeys[t] = buf[1 + t]; sc->rmax_key[t] = buf[1 + kMaxQ + t]; }
 }
 // C2: all-gathered padded shards -> contiguous whole-grid mask
-__global__ __launch_bounds__(256) void k_compact_shards(const uint8_t* __restrict__ recv, long long maxlocal, int world,
+template <typename E>
+__global__ __launch_bounds__(256) void k_compact_shards(const E* __restrict__ recv, long long maxlocal, int world,
                                                         const long long* __restrict__ first_of, long long total,
-                                                        uint8_t* __restrict__ full) {
+                                                        E* __restrict__ full) {
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     int r = 0;
     while (r + 1 < world && g >= first_of[r + 1]) ++r;
@@ -668,24 +669,37 @@ struct RunMeta {
   double lo[kMaxD], hi[kMaxD];    // bounding box of the run's S points
 };
 
+// source weights: W[g] = ucb_c(g) on the source set, -inf elsewhere (every source is in S_t, so its ucb_c >= lcb_c >= 0)
+template <typename T>
+__global__ __launch_bounds__(256) void k_goose_weights(const T* __restrict__ mean_c, const T* __restrict__ var_c, long long n, T b,
+                                                       const uint8_t* __restrict__ src, T* __restrict__ W) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    T lcb, ucb;
+    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucb);
+    W[g] = src[g] ? ucb : (T)-INFINITY;
+  }
+}
+
+// css / W describe the SOURCE candidates (this rank's, or with ranks > 1 the whole grid); block i handles run run_lo + i
 template <typename T, int D>
-__global__ __launch_bounds__(256) void k_goose_run_meta(const CandSpec cs, const T* __restrict__ mean_c,
-                                                        const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
-                                                        const unsigned long long* Lkeys, int lidx, RunMeta* __restrict__ meta) {
+__global__ __launch_bounds__(256) void k_goose_run_meta(const CandSpec css, const T* __restrict__ W,
+                                                        const unsigned long long* Lkeys, int lidx, long long run_lo,
+                                                        RunMeta* __restrict__ meta) {
   __shared__ double red[4][1 + 2 * D];
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const long long g = (long long)blockIdx.x * kRun + threadIdx.x;
+  const long long g = (run_lo + blockIdx.x) * kRun + threadIdx.x;
   double r = -1.0, lo[D], hi[D];
 #pragma unroll
   for (int a = 0; a < D; ++a) { lo[a] = 1e300; hi[a] = -1e300; }
-  if (g < cs.n_local && S[g]) {
-    T lcb, ucb;
-    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucb);
-    r = L > 0 ? (double)ucb / L : 1e300;
-    double x[D];
-    cand_coords<D>(cs, g, x);
+  if (g < css.n_local) {
+    const double uc = (double)W[g];
+    if (uc >= 0.0) {
+      r = L > 0 ? uc / L : 1e300;
+      double x[D];
+      cand_coords<D>(css, g, x);
 #pragma unroll
-    for (int a = 0; a < D; ++a) { lo[a] = x[a]; hi[a] = x[a]; }
+      for (int a = 0; a < D; ++a) { lo[a] = x[a]; hi[a] = x[a]; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -714,11 +728,10 @@ __global__ __launch_bounds__(256) void k_goose_run_meta(const CandSpec cs, const
 }
 
 template <typename T, int D>
-__global__ __launch_bounds__(256) void k_goose_optimistic(const CandSpec cs, const T* __restrict__ mean_c,
-                                                          const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
+__global__ __launch_bounds__(256) void k_goose_optimistic(const CandSpec cs, const CandSpec css, const T* __restrict__ W,
                                                           const uint8_t* __restrict__ U, const unsigned long long* Lkeys,
-                                                          int lidx, const RunMeta* __restrict__ meta, int nruns,
-                                                          uint8_t* __restrict__ O) {
+                                                          int lidx, const RunMeta* __restrict__ meta, long long run_lo,
+                                                          int nruns, uint8_t* __restrict__ O) {
   __shared__ double gx[kRun][D];
   __shared__ double gr[kRun], gucb[kRun];
   __shared__ int list[kRun];
@@ -778,17 +791,17 @@ __global__ __launch_bounds__(256) void k_goose_optimistic(const CandSpec cs, con
       __syncthreads();
       const int nl = nlist;
       for (int li = 0; li < nl; ++li) {
-        const long long g = (long long)list[li] * kRun + threadIdx.x;
+        const long long g = (run_lo + list[li]) * kRun + threadIdx.x;
         double r = -1.0, uc = 0.0;
-        if (g < cs.n_local && S[g]) {
-          T lcb, ucb;
-          lcb_ucb(mean_c[g], var_c[g], b, lcb, ucb);
-          uc = (double)ucb;
-          r = L > 0 ? uc / L : 1e300;
-          double x[D];
-          cand_coords<D>(cs, g, x);
+        if (g < css.n_local) {
+          uc = (double)W[g];
+          if (uc >= 0.0) {
+            r = L > 0 ? uc / L : 1e300;
+            double x[D];
+            cand_coords<D>(css, g, x);
 #pragma unroll
-          for (int a = 0; a < D; ++a) gx[threadIdx.x][a] = x[a];
+            for (int a = 0; a < D; ++a) gx[threadIdx.x][a] = x[a];
+          }
         }
         gr[threadIdx.x] = r;
         gucb[threadIdx.x] = uc;
@@ -1105,7 +1118,7 @@ static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U
     // send buffer: own U mask, allocated with the padded size in sweep_common_front (the tail is never compacted)
     if (c->maskU.bytes < (size_t)maxlocal) return fail(SBO_E_INVALID, "internal: U mask smaller than the padded shard");
     if ((rc = comm_allgather_bytes(c, c->maskU.p, c->gather.p, (size_t)maxlocal))) return rc;
-    hipLaunchKernelGGL(k_compact_shards, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
+    hipLaunchKernelGGL(k_compact_shards<uint8_t>, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
                        c->stream, (const uint8_t*)c->gather.p, maxlocal, c->world, (const long long*)c->shard_first.p,
                        c->grid_total, (uint8_t*)c->Ufull.p);
   }
@@ -1251,19 +1264,60 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
 template <typename T, int D>
 static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8_t* src, uint8_t* O) {
   const long long n = c->cs.n_local;
-  if (n == 0) return SBO_OK;
   const int q = c->mc.q;
   const int lidx = o->reference_quirk_L_index ? q - 1 : cidx;   // models/GoOSE.py:100 (loop-leaked i)
   const T* mean_c = (const T*)c->mean.p + (size_t)cidx * n;
   const T* var_c = (const T*)c->var.p + (size_t)cidx * n;
-  const int nruns = (int)((n + kRun - 1) / kRun);
   int rc;
-  if ((rc = ensure(c->runmeta, sizeof(RunMeta) * (size_t)nruns))) return rc;
-  hipLaunchKernelGGL((k_goose_run_meta<T, D>), dim3(nruns), dim3(256), 0, c->stream, c->cs, mean_c, var_c, (T)o->b,
-                     src, (const unsigned long long*)c->Lmax.p, lidx, (RunMeta*)c->runmeta.p);
-  hipLaunchKernelGGL((k_goose_optimistic<T, D>), dim3(nruns), dim3(256), 0, c->stream, c->cs, mean_c, var_c, (T)o->b,
-                     src, (const uint8_t*)c->maskU.p, (const unsigned long long*)c->Lmax.p, lidx,
-                     (const RunMeta*)c->runmeta.p, nruns, O);
+  long long maxlocal = n;
+  for (int r = 0; r < c->world && c->world > 1; ++r) maxlocal = std::max(maxlocal, c->first_of[r + 1] - c->first_of[r]);
+  if ((rc = ensure(c->gw, sizeof(T) * (size_t)std::max<long long>(maxlocal, 1)))) return rc;
+  if (n > 0)
+    hipLaunchKernelGGL((k_goose_weights<T>), dim3(reduce_blocks(c)), dim3(256), 0, c->stream, mean_c, var_c, n, (T)o->b, src,
+                       (T*)c->gw.p);
+  CandSpec css = c->cs;                 // the source candidates
+  const T* W = (const T*)c->gw.p;
+  long long run_lo = 0, run_hi = (n + kRun - 1) / kRun;
+  if (c->world > 1) {
+    // sources of every rank: all-gather the weight shards, then search the hyper-planes within reach of this shard
+    // (reach = largest source radius, from the keys of collective C1 -- the window is exact, as for the expanders)
+    if ((rc = ensure(c->gather, sizeof(T) * (size_t)maxlocal * c->world))) return rc;
+    if ((rc = ensure(c->Wfull, sizeof(T) * (size_t)c->grid_total))) return rc;
+    if ((rc = comm_allgather_bytes(c, c->gw.p, c->gather.p, sizeof(T) * (size_t)maxlocal))) return rc;
+    hipLaunchKernelGGL(k_compact_shards<T>, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
+                       c->stream, (const T*)c->gather.p, maxlocal, c->world, (const long long*)c->shard_first.p, c->grid_total,
+                       (T*)c->Wfull.p);
+    css.first = 0;
+    css.n_local = c->grid_total;
+    W = (const T*)c->Wfull.p;
+    const int d = c->cs.d;
+    long long plane = 1;
+    for (int a = 0; a < d - 1; ++a) plane *= c->cs.count[a];
+    const long long planes_total = c->cs.count[d - 1];
+    long long p0 = c->cs.first / plane, p1 = (c->cs.first + n + plane - 1) / plane;
+    double L, rmax = 0.0;
+    memcpy(&L, &c->h_c1[1 + lidx], 8);
+    if (c->h_c1[1 + kMaxQ + cidx]) rmax = ord_val(c->h_c1[1 + kMaxQ + cidx]);
+    const double hl = c->cs.step[d - 1];
+    long long H = planes_total;
+    if (L > 0 && hl > 0) {
+      const double hp = std::ceil((rmax / L * 1.000001 + 1e-6) / hl) + 2.0;
+      if (hp < (double)planes_total) H = (long long)hp;
+    }
+    p0 = std::max(0ll, p0 - H);
+    p1 = std::min(planes_total, p1 + H);
+    run_lo = p0 * plane / kRun;
+    run_hi = (p1 * plane + kRun - 1) / kRun;
+  }
+  if (n == 0) return SBO_OK;           // (an empty shard still took part in the all-gather)
+  const long long nsrc_runs = run_hi - run_lo;
+  if (nsrc_runs > 0x7fffffffll) return fail(SBO_E_UNSUPPORTED, "too many source runs");
+  if ((rc = ensure(c->runmeta, sizeof(RunMeta) * (size_t)std::max<long long>(nsrc_runs, 1)))) return rc;
+  hipLaunchKernelGGL((k_goose_run_meta<T, D>), dim3((unsigned)nsrc_runs), dim3(256), 0, c->stream, css, W,
+                     (const unsigned long long*)c->Lmax.p, lidx, run_lo, (RunMeta*)c->runmeta.p);
+  hipLaunchKernelGGL((k_goose_optimistic<T, D>), dim3((unsigned)((n + kRun - 1) / kRun)), dim3(256), 0, c->stream, c->cs, css, W,
+                     (const uint8_t*)c->maskU.p, (const unsigned long long*)c->Lmax.p, lidx, (const RunMeta*)c->runmeta.p,
+                     run_lo, (int)nsrc_runs, O);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
@@ -1291,7 +1345,9 @@ static int launch_dist_to(sbo_ctx* c, const double* dev_target, T* out) {
   return SBO_OK;
 }
 
-// GoOSE iteration (models/GoOSE.py:63-119, test/test_GoOSE.py:151-162) on the resident candidates (single rank)
+// GoOSE iteration (models/GoOSE.py:63-119, test/test_GoOSE.py:151-162) on the resident candidates.  Ranks > 1: C1 + C2
+// as for SafeOpt, one all-gather of the source weights per constraint, C3 for the arg-min slots and a second C3 for
+// the explore step (every rank derives the same target from the merged slots).
 template <typename T>
 static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* res) {
   const long long n = c->cs.n_local;
@@ -1302,7 +1358,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   if ((rc = sweep_common_front<T>(c, o))) return rc;
-  if ((rc = sweep_exchange_front<T>(c, o, false))) return rc;
+  if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
   if ((rc = ensure(c->maskO, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
@@ -1343,7 +1399,9 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   }
   SBO_HIP(hipGetLastError());
   SweepScalars h;
-  SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  bool is_max[kArgSlots];
+  for (int t = 0; t < kArgSlots; ++t) is_max[t] = false;
+  if ((rc = sweep_exchange_back(c, h, is_max))) return rc;
   unsigned long long Lk[kMaxQ];
   SBO_HIP(hipMemcpyAsync(Lk, c->Lmax.p, sizeof(Lk), hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
@@ -1381,13 +1439,16 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     // explore_safeset(target): argmin_{S} ||x - target||_2 (models/GoOSE.py:116-119)
     double* dev_t = (double*)c->scal.p + 256;
     SBO_HIP(hipMemcpyAsync(dev_t, res->target_x, sizeof(double) * SBO_MAX_D, hipMemcpyHostToDevice, c->stream));
-    if ((rc = launch_dist_to<T>(c, dev_t, lcb0))) return rc;
-    hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
-                       (long long)c->cs.first, (long long*)nullptr, (Best*)c->partial.p);
-    hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, nb, sc, kArgSlots - 1);
-    SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    SBO_HIP(hipStreamSynchronize(c->stream));
-    res->explore_index = h.arg_idx[kArgSlots - 1];
+    if (n > 0) {
+      if ((rc = launch_dist_to<T>(c, dev_t, lcb0))) return rc;
+      hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
+                         (long long)c->cs.first, (long long*)nullptr, (Best*)c->partial.p);
+    }
+    hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
+                       kArgSlots - 1);
+    SweepScalars h2;
+    if ((rc = sweep_exchange_back(c, h2, is_max))) return rc;
+    res->explore_index = h2.arg_idx[kArgSlots - 1];
     coords_of(c, res->explore_index, res->explore_x);
   }
   SBO_HIP(hipEventRecord(c->ev[4], c->stream));
@@ -1499,7 +1560,6 @@ int sbo_sweep_goose(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_goose_result* re
   if (!c->has_model) return fail(SBO_E_NO_MODEL, "sbo_model_set has not been called");
   if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
-  if (c->world > 1) return fail(SBO_E_UNSUPPORTED, "the GoOSE sweep is single-rank in this release");
   SBO_HIP(hipSetDevice(c->device));
   return c->dtype == SBO_F64 ? sweep_goose_t<double>(c, opts, result) : sweep_goose_t<float>(c, opts, result);
 }

@@ -27,9 +27,18 @@ def main():
     res = eng.sweep_safeopt(b, want_masks=True)
     masks = {k: eng.mask(k) for k in ("S", "U", "M")}
     masks.update({f"G{c}": eng.mask("G", c) for c in range(1, cfg["q"])})
+    gres = None
+    if cfg["q"] > 1:
+        try:
+            gres = eng.sweep_goose(b, want_masks=True, posterior_ready=True)
+            masks.update({f"O{c}": eng.mask("O", c) for c in range(1, cfg["q"])})
+        except safebo_amd.EmptySafeSetError:
+            gres = {"empty_safe_set": True}
     np.savez(out_path + f".rank{rank}.npz", first=eng.first, n_local=eng.n_local, **masks)
     if rank == 0:
-        json.dump({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in res.items()}, open(out_path, "w"))
+        def plain(r):
+            return {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
+        json.dump({**plain(res), "goose": plain(gres) if gres is not None else None}, open(out_path, "w"))
     dist.barrier()
     eng.close()
     dist.destroy_process_group()

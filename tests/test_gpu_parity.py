@@ -454,3 +454,14 @@ def test_multi_rank_sweep_on_one_gpu_matches_oracle(tmp_path, world, cfg_name, n
     assert res["expander_index_c"] == [int(x) for x in ref["expander_index"]]
     assert res["count_S"] == int(ref["S"].sum()) and res["count_G"] == [int(x) for x in ref["G"].sum(1)]
     assert res["u_star"] == pytest.approx(ref["u_star"], rel=1e-10)
+    # the GoOSE sweep on the same shards: optimistic sets from the all-gathered source weights, merged arg-min slots
+    gref = oracle.goose_sweep(pts, cfg["ds"], b)
+    g = res["goose"]
+    assert g is not None and not g.get("empty_safe_set", False)
+    for c in range(1, cfg["q"]):
+        assert np.array_equal(np.concatenate([p[f"O{c}"] for p in parts]), gref["O"][c - 1]), f"O{c}"
+    assert g["safe_min_index"] == gref["safe_min_index"]
+    assert g["target_index_c"] == [int(x) for x in gref["target_index_c"]]
+    assert g["target_index"] == gref["target_index"] and g["explore_index"] == gref["explore_index"]
+    assert g["choose_safe_min"] == gref["choose_safe_min"]
+    assert g["count_O"] == [int(x) for x in gref["O"].sum(1)]
