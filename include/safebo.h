@@ -121,6 +121,7 @@ typedef struct sbo_goose_result {
   double  L[SBO_MAX_Q];
   int64_t count_S, count_U;
   int64_t count_O[SBO_MAX_Q];
+  int64_t n_exact_rechecks;              /* candidates decided by the exhaustive reference predicate (expanders + coverage) */
 } sbo_goose_result;
 
 typedef struct sbo_tr_result {
@@ -216,7 +217,7 @@ int sbo_nll_batch(sbo_ctx* ctx, int n, int d, const double* X_norm, const double
 /* ---- measurement --------------------------------------------------------------------------- */
 int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
 /* tuning / diagnostics knobs: "posterior_path" (0 auto, 1 generic single-phase, 2 generic chunked), "k1_wgs_per_cu",
- * "k1_strips" (4 | 8), "edt_tiled" (0 | 1) */
+ * "k1_strips" (4 | 8), "edt_tiled" (0 | 1), "goose_pairs" (1: pair evaluation instead of the transform on grids) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

@@ -52,7 +52,7 @@ class GooseResult(C.Structure):
         ("target_best_c", C.c_int32), ("target_index", C.c_int64), ("target_x", C.c_double * SBO_MAX_D),
         ("target_lcb", C.c_double), ("explore_index", C.c_int64), ("explore_x", C.c_double * SBO_MAX_D),
         ("choose_safe_min", C.c_int32), ("L", C.c_double * SBO_MAX_Q), ("count_S", C.c_int64),
-        ("count_U", C.c_int64), ("count_O", C.c_int64 * SBO_MAX_Q),
+        ("count_U", C.c_int64), ("count_O", C.c_int64 * SBO_MAX_Q), ("n_exact_rechecks", C.c_int64),
     ]
 
 

@@ -222,6 +222,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->edt_tiled = value ? 1 : 0;
     return SBO_OK;
   }
+  if (!strcmp(key, "goose_pairs")) {
+    c->goose_pairs = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "posterior_path")) {
     if (value < 0 || value > 2) return fail(SBO_E_INVALID, "posterior_path must be 0 (auto), 1 (generic) or 2 (generic, chunked)");
     c->posterior_path = (int)value;

@@ -97,6 +97,7 @@ struct sbo_ctx {
   int k1_strips = 4;       // lines per K1g tile (4, or 8 for 2-D grids: tuning)
   int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
   int edt_tiled = 0;       // 1: LDS-tiled lock-step form of the last-axis expander scan (slower on measured configs)
+  int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
   int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
   // comm
   void* comm = nullptr;  // ncclComm_t

@@ -828,6 +828,265 @@ __global__ __launch_bounds__(256) void k_goose_optimistic(const CandSpec cs, con
   if (h < cs.n_local) O[h] = covered;
 }
 
+// ---- GoOSE coverage on grids: power-distance transform --------------------------------------------------------
+// "h is covered" means min over sources g of  ||x_g - x_h||^2 - r_g^2  <= 0  (r_g = ucb_c(g) / L): a min-plus
+// transform of the sampled function F(g) = -r_g^2 (sources) / +inf (others) with parabolas, which separates by axis
+// exactly like the Euclidean transform:  P_a(x) = min_t P_{a-1}(x + t e_a) + (h_a t)^2.
+// The transform is evaluated in index space without the reference's "+1e-8" shift; |P| <= band is the zone where the
+// shift and rounding could move the reference predicate across zero -- those h go to the exact recheck
+// (k_goose_exact), everything else is decided by the sign.  band = 3 rmax eps bounds |dist - r| > eps on both sides:
+// (dist - r)(dist + r) = P and dist + r <= 3 rmax whenever dist <= 2 rmax.
+// Values above `band` can never lead to a covered verdict on a later axis, so the outward scans stop at
+//   (h t)^2 - rmax^2 > band   (no source that far can matter)   and   (h t)^2 - rmax^2 >= best   (cannot improve).
+struct PdtParams {
+  double invL, rmax2, band;    // 1/L, (max source radius)^2, ambiguity band on P
+  int L_positive;
+};
+__device__ __forceinline__ PdtParams pdt_params(const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx, int d,
+                                                double xscale) {
+  PdtParams p;
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  p.L_positive = L > 0;
+  p.invL = p.L_positive ? 1.0 / L : 0.0;
+  const double rm = (sc->rmax_key[c] ? fmax(0.0, ord_val(sc->rmax_key[c])) : 0.0) * p.invL * (1.0 + 1e-12);
+  const double eps = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13 + 1e-10 * rm;
+  p.rmax2 = rm * rm;
+  p.band = 3.03 * rm * eps + eps * eps + 1e-13 * (xscale * xscale + p.rmax2);
+  return p;
+}
+
+// Coarse bounds for the power transform (cells of kCoarse^d candidates, Fmin = smallest F in the cell).  A source of
+// cell J and a candidate of cell I are between lo_t = (t-1) kCoarse + 1 (0 when t = 0) and hi_t = (t+1) kCoarse - 1
+// steps apart along an axis, t = |I - J|, hence
+//     min_J Fmin(J) + sum_a (h_a lo_t)^2  <=  P(x)  <=  min_J Fmin(J) + sum_a (h_a hi_t)^2      for every x in cell I.
+// Both sides are separable min-plus transforms of the small array Fmin.  Lower side > band: nothing in the cell can be
+// covered and its axis-0 values cannot matter either (they are >= P); upper side < -band: every U point is covered.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pdt_cell_min(const T* __restrict__ W, long long nt, const CoarseGrid cg,
+                                                      const unsigned long long* Lkeys, int lidx,
+                                                      unsigned long long* __restrict__ Fkey) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const double invL = L > 0 ? 1.0 / L : 0.0;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nt; g += (long long)gridDim.x * blockDim.x) {
+    const double w = (double)W[g];
+    if (!(w >= 0.0)) continue;
+    long long f = g, cell = 0, cs = 1;
+    for (int a = 0; a < cg.d; ++a) {
+      const long long i = f % cg.count[a];
+      f /= cg.count[a];
+      cell += (i / kCoarse) * cs;
+      cs *= cg.ccount[a];
+    }
+    const double r = w * invL;
+    atomicMin(&Fkey[cell], ord_key(-(r * r)));
+  }
+}
+// keys -> doubles (in place) for both bound arrays; cells without a source become +inf
+__global__ __launch_bounds__(256) void k_pdt_cell_unkey(unsigned long long* __restrict__ Fkey, long long nc, double* __restrict__ lo,
+                                                        double* __restrict__ hi) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long k = Fkey[g];
+    const double v = k == ~0ull ? kInfD : ord_val(k);
+    lo[g] = v;
+    hi[g] = v;
+  }
+}
+// one axis of a coarse bound transform; upper = 0: lower-bound costs, 1: upper-bound costs
+__global__ __launch_bounds__(256) void k_pdt_coarse_scan(const double* __restrict__ Pin, double* __restrict__ Pout, long long nc,
+                                                         long long stride, int cnt, double h, int upper, const SweepScalars* sc,
+                                                         int c, const unsigned long long* Lkeys, int lidx, int d, double xscale) {
+  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += (long long)gridDim.x * blockDim.x) {
+    const int ia = (int)((g / stride) % cnt);
+    double best = kInfD;
+    for (int t = 0; t < cnt; ++t) {
+      const double steps_lo = t == 0 ? 0.0 : (double)((t - 1) * kCoarse + 1);
+      const double steps = upper ? (double)((t + 1) * kCoarse - 1) : steps_lo;
+      const double dl = h * steps_lo, dd = h * steps;
+      const double floor_ = dl * dl - pp.rmax2;          // no source that far can bring any candidate below the band
+      if (floor_ > pp.band || dd * dd - pp.rmax2 >= best) break;
+      const bool lo_ok = ia - t >= 0, hi_ok = ia + t < cnt;
+      if (!lo_ok && !hi_ok) break;
+      const double c1 = lo_ok ? Pin[g - (long long)t * stride] : kInfD;
+      const double c2 = hi_ok ? Pin[g + (long long)t * stride] : kInfD;
+      const double cnd = (c1 < c2 ? c1 : c2) + dd * dd;
+      best = cnd < best ? cnd : best;
+    }
+    Pout[g] = best;
+  }
+}
+__device__ __forceinline__ long long coarse_cell(const CoarseGrid& cg, long long gg) {
+  long long f = gg, cell = 0, cs = 1;
+  for (int a = 0; a < cg.d; ++a) {
+    const long long i = f % cg.count[a];
+    f /= cg.count[a];
+    cell += (i / kCoarse) * cs;
+    cs *= cg.ccount[a];
+  }
+  return cell;
+}
+
+// axis 0, reading the source weights directly
+template <typename T>
+__global__ __launch_bounds__(256) void k_pdt_axis0(const T* __restrict__ W, long long nt, int count0, double h0,
+                                                   const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx,
+                                                   int d, double xscale, const CoarseGrid cg, const double* __restrict__ PcLo,
+                                                   double* __restrict__ P) {
+  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nt; g += (long long)gridDim.x * blockDim.x) {
+    if (cg.enabled && PcLo[coarse_cell(cg, g)] > pp.band) { P[g] = kInfD; continue; }
+    const int i = (int)(g % count0);
+    const double w = (double)W[g];
+    double best = kInfD;
+    if (w >= 0.0) { const double r = w * pp.invL; best = -(r * r); }
+    for (int t = 1; t < count0; ++t) {
+      const double dt = h0 * (double)t;
+      const double e = dt * dt;
+      const double floor_ = e - pp.rmax2;
+      if (floor_ > pp.band || floor_ >= best) break;
+      const bool lo_ok = i - t >= 0, hi_ok = i + t < count0;
+      if (!lo_ok && !hi_ok) break;
+      const double w1 = lo_ok ? (double)W[g - t] : -1.0;
+      const double w2 = hi_ok ? (double)W[g + t] : -1.0;
+      const double wm = fmax(w1, w2);                 // the larger radius wins at equal distance
+      if (wm >= 0.0) {
+        const double r = wm * pp.invL;
+        const double cnd = e - r * r;
+        best = cnd < best ? cnd : best;
+      }
+    }
+    P[g] = best;
+  }
+}
+
+__device__ __forceinline__ double pdt_scan_point(const double* __restrict__ Pin, long long g, long long stride, int cnt, int ia,
+                                                 double h, const PdtParams& pp, bool early_accept) {
+  double best = Pin[g];
+  for (int t = 1; t < cnt; ++t) {
+    const double dt = h * (double)t;
+    const double e = dt * dt;
+    const double floor_ = e - pp.rmax2;
+    if (floor_ > pp.band || floor_ >= best || (early_accept && best < -pp.band)) break;
+    const bool lo_ok = ia - t >= 0, hi_ok = ia + t < cnt;
+    if (!lo_ok && !hi_ok) break;
+    const double c1 = lo_ok ? Pin[g - (long long)t * stride] : kInfD;
+    const double c2 = hi_ok ? Pin[g + (long long)t * stride] : kInfD;
+    const double cnd = (c1 < c2 ? c1 : c2) + e;
+    best = cnd < best ? cnd : best;
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(256) void k_pdt_scan(const double* __restrict__ Pin, double* __restrict__ Pout, long long nt,
+                                                  long long stride, int cnt, double h, const SweepScalars* sc, int c,
+                                                  const unsigned long long* Lkeys, int lidx, int d, double xscale) {
+  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nt; g += (long long)gridDim.x * blockDim.x) {
+    const int ia = (int)((g / stride) % cnt);
+    Pout[g] = pdt_scan_point(Pin, g, stride, cnt, ia, h, pp, false);
+  }
+}
+
+// last axis + verdict for the own U points (window offset goff); ambiguous ones are listed for the exact recheck
+__global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ Pin, long long n, long long goff, long long stride,
+                                                    int cnt, double h, int d, double xscale, const uint8_t* __restrict__ U,
+                                                    const unsigned long long* Lkeys, int lidx, SweepScalars* sc, int c,
+                                                    uint8_t* __restrict__ O, long long* __restrict__ amb, const CoarseGrid cg,
+                                                    const double* __restrict__ PcLo, const double* __restrict__ PcHi) {
+  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
+  const bool anyS = sc->count_S > 0;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    uint8_t out = 0;
+    if (U[g]) {
+      if (!pp.L_positive) {
+        out = anyS;                                  // radius unbounded: any source covers (ucb_c >= 0 on every source)
+      } else {
+        const long long gg = goff + g;
+        if (cg.enabled) {
+          const long long cell = coarse_cell(cg, gg);
+          if (PcHi[cell] < -pp.band) { O[g] = 1; continue; }     // covered wherever it sits in its cell
+          if (PcLo[cell] > pp.band) { O[g] = 0; continue; }      // out of every source's reach
+        }
+        const int ia = (int)((gg / stride) % cnt);
+        const double best = (cnt > 1) ? pdt_scan_point(Pin, gg, stride, cnt, ia, h, pp, true) : Pin[gg];
+        if (best < -pp.band) out = 1;
+        else if (best <= pp.band) {
+          const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
+          amb[slot] = g;
+        }
+      }
+    }
+    O[g] = out;
+  }
+}
+
+// exact recheck of the listed U points: the reference predicate against every source inside the index box that the
+// largest radius can reach.  cs: the own candidates (h); css / W: the source candidates (own range or whole grid)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_goose_exact(const CandSpec cs, const CandSpec css, const T* __restrict__ W,
+                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc, int c,
+                                                     const long long* __restrict__ amb, uint8_t* __restrict__ O) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const long long namb = sc->n_amb;
+  const double rm = (L > 0 && sc->rmax_key[c]) ? fmax(0.0, ord_val(sc->rmax_key[c])) / L : 0.0;
+  // one listed point can own a box as large as the grid: its box is cut into kParts slices, one workgroup each
+  constexpr int kParts = 64;
+  for (long long wi = blockIdx.x; wi < namb * kParts; wi += gridDim.x) {
+    const long long qi = wi / kParts;
+    const int part = (int)(wi % kParts);
+    const long long hl = amb[qi];
+    double xh[D];
+    cand_coords<D>(cs, hl, xh);
+    long long lo[D], len[D], stridea[D];
+    long long f = cs.first + hl, total = 1, sa = 1;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      lo[a] = 0; len[a] = 1; stridea[a] = 0;
+      if (a < cs.d) {
+        const long long cnt = cs.count[a];
+        const long long ih = f % cnt;
+        f /= cnt;
+        long long R = cnt;
+        if (cs.step[a] > 0) {
+          const double rr = (rm * (1.0 + 1e-9) + 1e-7) / cs.step[a];
+          R = rr < (double)cnt ? (long long)ceil(rr) + 1 : cnt;
+        }
+        const long long l0 = ih - R > 0 ? ih - R : 0, h0 = ih + R < cnt - 1 ? ih + R : cnt - 1;
+        lo[a] = l0; len[a] = h0 - l0 + 1; stridea[a] = sa;
+        total *= len[a];
+        sa *= cnt;
+      }
+    }
+    int found = 0;
+    const long long chunk = (total + kParts - 1) / kParts;
+    const long long t1 = (part + 1) * chunk < total ? (part + 1) * chunk : total;
+    for (long long t = part * chunk + threadIdx.x; t < t1 && !found; t += blockDim.x) {
+      long long u = t, gg = 0;
+      double xg[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        xg[a] = 0.0;
+        if (a < cs.d) {
+          const long long ia = lo[a] + u % len[a];
+          u /= len[a];
+          gg += ia * stridea[a];
+          const long long cnt = cs.count[a];
+          xg[a] = (ia == cnt - 1 && cnt > 1) ? cs.hi[a] : __dadd_rn(cs.lo[a], __dmul_rn((double)ia, cs.step[a]));
+        }
+      }
+      const long long gl = gg - css.first;
+      if (gl >= 0 && gl < css.n_local) {
+        const double w = (double)W[gl];
+        if (w >= 0.0 && lipschitz_pair<D>(xg, xh, cs.d, w, L)) found = 1;
+      }
+    }
+    found = __syncthreads_or(found);
+    if (threadIdx.x == 0 && found) O[hl] = 1;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += namb;
+}
+
 // trust-region mask: S and ||x - x_0||_2 <= r, the norm evaluated as sqrt(sum (x - x_0)^2) (models/GP_TR.py:49)
 template <int D>
 __global__ void k_ball_mask(const CandSpec cs, long long n, const uint8_t* __restrict__ S, const double* __restrict__ x0,
@@ -1278,6 +1537,7 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
   CandSpec css = c->cs;                 // the source candidates
   const T* W = (const T*)c->gw.p;
   long long run_lo = 0, run_hi = (n + kRun - 1) / kRun;
+  long long win_p0 = 0, win_p1 = 0;     // ranks > 1: window of hyper-planes holding every source that can matter
   if (c->world > 1) {
     // sources of every rank: all-gather the weight shards, then search the hyper-planes within reach of this shard
     // (reach = largest source radius, from the keys of collective C1 -- the window is exact, as for the expanders)
@@ -1306,10 +1566,96 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     }
     p0 = std::max(0ll, p0 - H);
     p1 = std::min(planes_total, p1 + H);
+    win_p0 = p0;
+    win_p1 = p1;
     run_lo = p0 * plane / kRun;
     run_hi = (p1 * plane + kRun - 1) / kRun;
   }
   if (n == 0) return SBO_OK;           // (an empty shard still took part in the all-gather)
+  long long plane1 = 1;
+  for (int a = 0; a < c->cs.d - 1; ++a) plane1 *= c->cs.count[a];
+  const bool plane_aligned = c->cs.kind == 1 && c->cs.first % plane1 == 0 && n % plane1 == 0;
+  if (plane_aligned && !c->goose_pairs) {
+    // grids: power-distance transform of the source weights over the window, verdict by sign, exact recheck in the band
+    const int d = c->cs.d;
+    SweepScalars* sc = (SweepScalars*)c->scal.p;
+    const long long own0 = c->cs.first / plane1;
+    const long long w0 = c->world > 1 ? win_p0 : own0, w1 = c->world > 1 ? win_p1 : own0 + n / plane1;
+    const long long wplanes = w1 - w0, nt = wplanes * plane1, goff = (own0 - w0) * plane1;
+    const T* Wwin = c->world > 1 ? W + w0 * plane1 : W;
+    if ((rc = ensure(c->dist2, sizeof(double) * (size_t)nt))) return rc;
+    if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)nt))) return rc;
+    if ((rc = ensure(c->amb, sizeof(long long) * (size_t)n))) return rc;
+    double xscale = 0.0;
+    for (int a = 0; a < d; ++a) xscale = std::max(xscale, std::max(std::fabs(c->cs.lo[a]), std::fabs(c->cs.hi[a])));
+    const int count0 = d >= 2 ? (int)c->cs.count[0] : (int)nt;
+    const unsigned gridn = (unsigned)std::min<long long>((nt + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(k_reset_amb, dim3(1), dim3(1), 0, c->stream, sc);
+    // coarse bounds of the window: decide most candidates (and skip their axis-0 scans) without touching the fine arrays
+    CoarseGrid cg;
+    memset(&cg, 0, sizeof(cg));
+    cg.d = d;
+    bool coarse_ok = d >= 2 && nt >= (1ll << 16);
+    long long nc = 1;
+    for (int a = 0; a < d; ++a) {
+      cg.count[a] = a == d - 1 ? wplanes : c->cs.count[a];
+      cg.ccount[a] = (cg.count[a] + kCoarse - 1) / kCoarse;
+      nc *= cg.ccount[a];
+      if (cg.count[a] < 4 * kCoarse) coarse_ok = false;
+    }
+    const double *pc_lo = nullptr, *pc_hi = nullptr;
+    if (coarse_ok) {
+      cg.enabled = 1;
+      if ((rc = ensure(c->coarse, (size_t)nc * 5 * sizeof(double) + 64))) return rc;
+      unsigned long long* fkey = (unsigned long long*)c->coarse.p;
+      double* lo0 = (double*)c->coarse.p + nc;
+      double* lo1 = lo0 + nc;
+      double* hi0 = lo1 + nc;
+      double* hi1 = hi0 + nc;
+      const unsigned gridc = (unsigned)std::min<long long>((nc + 255) / 256, 1 << 16);
+      SBO_HIP(hipMemsetAsync(fkey, 0xff, sizeof(unsigned long long) * (size_t)nc, c->stream));
+      hipLaunchKernelGGL((k_pdt_cell_min<T>), dim3(gridn), dim3(256), 0, c->stream, Wwin, nt, cg,
+                         (const unsigned long long*)c->Lmax.p, lidx, fkey);
+      hipLaunchKernelGGL(k_pdt_cell_unkey, dim3(gridc), dim3(256), 0, c->stream, fkey, nc, lo0, hi0);
+      long long cstride = 1;
+      for (int a = 0; a < d; ++a) {
+        for (int upper = 0; upper < 2; ++upper) {
+          double*& in = upper ? hi0 : lo0;
+          double*& out = upper ? hi1 : lo1;
+          hipLaunchKernelGGL(k_pdt_coarse_scan, dim3(gridc), dim3(256), 0, c->stream, (const double*)in, out, nc, cstride,
+                             (int)cg.ccount[a], c->cs.step[a], upper, (const SweepScalars*)sc, cidx,
+                             (const unsigned long long*)c->Lmax.p, lidx, d, xscale);
+          std::swap(in, out);
+        }
+        cstride *= cg.ccount[a];
+      }
+      pc_lo = lo0;
+      pc_hi = hi0;
+    }
+    hipLaunchKernelGGL((k_pdt_axis0<T>), dim3(gridn), dim3(256), 0, c->stream, Wwin, nt, count0, c->cs.step[0],
+                       (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, d, xscale, cg, pc_lo,
+                       (double*)c->dist2.p);
+    double* pin = (double*)c->dist2.p;
+    double* pout = (double*)c->dist2b.p;
+    long long stride = count0;
+    for (int a = 1; a < d - 1; ++a) {
+      hipLaunchKernelGGL(k_pdt_scan, dim3(gridn), dim3(256), 0, c->stream, (const double*)pin, pout, nt, stride,
+                         (int)c->cs.count[a], c->cs.step[a], (const SweepScalars*)sc, cidx,
+                         (const unsigned long long*)c->Lmax.p, lidx, d, xscale);
+      std::swap(pin, pout);
+      stride *= c->cs.count[a];
+    }
+    const int last_cnt = d >= 2 ? (int)wplanes : 1;
+    const double last_h = d >= 2 ? c->cs.step[d - 1] : 0.0;
+    hipLaunchKernelGGL(k_pdt_decide, dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+                       (const double*)pin, n, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, (const uint8_t*)c->maskU.p,
+                       (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, O, (long long*)c->amb.p, cg, pc_lo, pc_hi);
+    hipLaunchKernelGGL((k_goose_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, css, W,
+                       (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, (const long long*)c->amb.p, O);
+    SBO_HIP(hipGetLastError());
+    return SBO_OK;
+  }
+  // explicit lists and ragged grid ranges: pruned exact pair evaluation over runs of 256 candidates
   const long long nsrc_runs = run_hi - run_lo;
   if (nsrc_runs > 0x7fffffffll) return fail(SBO_E_UNSUPPORTED, "too many source runs");
   if ((rc = ensure(c->runmeta, sizeof(RunMeta) * (size_t)std::max<long long>(nsrc_runs, 1)))) return rc;
@@ -1411,6 +1757,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   memset(res, 0, sizeof(*res));
   res->count_S = h.count_S;
   res->count_U = h.count_U;
+  res->n_exact_rechecks = h.n_amb_total;
   for (int i = 0; i < q; ++i) memcpy(&res->L[i], &Lk[i], 8);
   res->safe_min_index = res->target_index = res->explore_index = -1;
   for (int cc = 1; cc < q; ++cc) res->target_index_c[cc - 1] = -1;

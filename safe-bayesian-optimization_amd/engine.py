@@ -196,7 +196,7 @@ class SweepEngine:
             "target_lcb": float(res.target_lcb), "explore_index": int(res.explore_index),
             "explore_x": np.array(res.explore_x[:d]), "choose_safe_min": bool(res.choose_safe_min),
             "L": np.array(res.L[:q]), "count_S": int(res.count_S), "count_U": int(res.count_U),
-            "count_O": np.array(res.count_O[:q - 1], dtype=np.int64),
+            "count_O": np.array(res.count_O[:q - 1], dtype=np.int64), "n_exact_rechecks": int(res.n_exact_rechecks),
         }
 
     def sweep_tr(self, b: float, x_0, r: float, posterior_ready: bool = False) -> dict:
