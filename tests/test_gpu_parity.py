@@ -420,6 +420,47 @@ def test_full_size_properties_config_B(engine):
     assert res2["minimizer_index"] == res["minimizer_index"] and np.array_equal(res2["count_G"], res["count_G"])
 
 
+@pytest.mark.parametrize("cfg_name,n,count", [("B", 128, [384, 320]), ("C", 64, [352, 416]), ("D", 128, [36, 34, 33, 32])])
+def test_goose_transform_equals_pair_evaluation_with_coarse_bounds(engine, cfg_name, n, count):
+    """Grids large enough for the coarse cell bounds of the power-distance transform: the optimistic sets must be the
+    ones the pruned exact pair evaluation produces (the path the golden vectors pin on explicit lists), and a random
+    subset of U is re-decided by the oracle's predicate."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    out = {}
+    try:
+        for pairs in (1, 0):
+            engine.set_option("goose_pairs", pairs)
+            res = engine.sweep_goose(cfg["b"], want_masks=True)
+            out[pairs] = (res, [engine.mask("O", c) for c in range(1, cfg["q"])])
+    finally:
+        engine.set_option("goose_pairs", 0)
+    for c in range(cfg["q"] - 1):
+        assert np.array_equal(out[0][1][c], out[1][1][c]), f"O{c + 1}"
+    for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min"):
+        assert out[0][0][k] == out[1][0][k], k
+    assert np.array_equal(out[0][0]["count_O"], out[1][0]["count_O"])
+    S, U = engine.mask("S"), engine.mask("U")
+    pts = oracle.grid_points(lo, hi, count)
+    rng = np.random.default_rng(11)
+    Lq = out[0][0]["L"][cfg["q"] - 1]                     # reference quirk: every constraint uses L_{q-1}
+    for c in range(1, cfg["q"]):
+        ucb = engine.bounds(cfg["b"], c, "ucb")
+        O = out[0][1][c - 1]
+        # near the boundary of O_c is where a wrong verdict would sit: sample covered points and their uncovered neighbours
+        cand = np.nonzero(U)[0]
+        pick = rng.choice(cand, size=min(48, cand.size), replace=False)
+        edge = np.nonzero(O[:-1] != O[1:])[0]
+        pick = np.concatenate([pick, rng.choice(edge, size=min(16, edge.size), replace=False)]) if edge.size else pick
+        for hidx in pick:
+            if not U[hidx]:
+                continue
+            want = bool(np.any(ucb[S] - Lq * oracle.shifted_norm(pts[S], pts[hidx][None, :]) >= 0))
+            assert bool(O[hidx]) == want, (c, int(hidx))
+
+
 # ---------------------------------------------------------------------------------------------- two ranks, one GPU
 def _free_port():
     with socket.socket() as s:
@@ -465,3 +506,34 @@ def test_multi_rank_sweep_on_one_gpu_matches_oracle(tmp_path, world, cfg_name, n
     assert g["target_index"] == gref["target_index"] and g["explore_index"] == gref["explore_index"]
     assert g["choose_safe_min"] == gref["choose_safe_min"]
     assert g["count_O"] == [int(x) for x in gref["O"].sum(1)]
+
+
+@pytest.mark.parametrize("world,cfg_name,n,count,b", [(3, "C", 64, [256, 300], 2.0), (2, "D", 128, [34, 33, 32, 70], 0.5)])
+def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_name, n, count, b):
+    """Shards big enough for the coarse cell bounds inside each rank's halo window: every mask and index must equal the
+    single-rank sweep of the whole grid (itself pinned to the oracle by the tests above)."""
+    port, out = _free_port(), str(tmp_path / "res.json")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), str(world), port, out, cfg_name,
+                               str(n), json.dumps(count), str(b)]) for r in range(world)]
+    cfg = synthetic.make_config(cfg_name, n=n)
+    engine.set_model(cfg["ds"])
+    engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    ref = engine.sweep_safeopt(b, want_masks=True)
+    rmask = {k: engine.mask(k) for k in ("S", "U", "M")}
+    rmask.update({f"G{c}": engine.mask("G", c) for c in range(1, cfg["q"])})
+    gref = engine.sweep_goose(b, want_masks=True, posterior_ready=True)
+    rmask.update({f"O{c}": engine.mask("O", c) for c in range(1, cfg["q"])})
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    res = json.load(open(out))
+    parts = [np.load(out + f".rank{r}.npz") for r in range(world)]
+    for k, want in rmask.items():
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), want), k
+    assert rmask["O1"].any() and rmask["G1"].any()
+    for k in ("minimizer_index", "expander_index", "count_S", "count_M"):
+        assert res[k] == ref[k], k
+    assert res["count_G"] == ref["count_G"].tolist() and res["u_star"] == ref["u_star"]
+    g = res["goose"]
+    for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c"):
+        assert g[k] == gref[k], k
+    assert g["count_O"] == gref["count_O"].tolist() and g["target_index_c"] == gref["target_index_c"].tolist()
