@@ -637,6 +637,27 @@ __global__ __launch_bounds__(256) void k_compact_shards(const E* __restrict__ re
     full[g] = recv[(size_t)r * maxlocal + (g - first_of[r])];
   }
 }
+// C2 (bit form): own mask -> one word per 64 candidates (zero beyond n); gathered words -> whole-grid byte mask
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ U, long long n, long long words,
+                                                   unsigned long long* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < words; w += nwaves) {
+    const long long g = w * 64 + lane;
+    const unsigned long long m = __ballot(g < n && U[g]);
+    if (lane == 0) out[w] = m;
+  }
+}
+__global__ __launch_bounds__(256) void k_unpack_shards(const unsigned long long* __restrict__ recv, long long words, int world,
+                                                       const long long* __restrict__ first_of, long long total,
+                                                       uint8_t* __restrict__ full) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    int r = 0;
+    while (r + 1 < world && g >= first_of[r + 1]) ++r;
+    const long long l = g - first_of[r];
+    full[g] = (uint8_t)((recv[(size_t)r * words + (l >> 6)] >> (l & 63)) & 1ull);
+  }
+}
 // C3: each rank fills its own row of [world][kC3Row] doubles, one sum all-reduce delivers every row everywhere
 constexpr int kC3Row = 2 * kArgSlots + 4 + kMaxQ;
 __global__ void k_pack_c3(const SweepScalars* sc, double* buf, int world, int rank) {
@@ -1370,15 +1391,19 @@ static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U
   SBO_HIP(hipMemcpyAsync(c->h_c1.data(), kb, sizeof(unsigned long long) * (1 + 2 * kMaxQ), hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
   if (need_U && q > 1) {
+    // the mask travels as bits (one ballot word per 64 candidates): 8x fewer bytes on the links than the byte mask
     long long maxlocal = 0;
     for (int r = 0; r < c->world; ++r) maxlocal = std::max(maxlocal, c->first_of[r + 1] - c->first_of[r]);
-    if ((rc = ensure(c->gather, (size_t)maxlocal * c->world))) return rc;
+    const long long words = (maxlocal + 63) / 64;
+    if ((rc = ensure(c->gather, sizeof(unsigned long long) * (size_t)words * (c->world + 1)))) return rc;
     if ((rc = ensure(c->Ufull, (size_t)c->grid_total))) return rc;
-    // send buffer: own U mask, allocated with the padded size in sweep_common_front (the tail is never compacted)
-    if (c->maskU.bytes < (size_t)maxlocal) return fail(SBO_E_INVALID, "internal: U mask smaller than the padded shard");
-    if ((rc = comm_allgather_bytes(c, c->maskU.p, c->gather.p, (size_t)maxlocal))) return rc;
-    hipLaunchKernelGGL(k_compact_shards<uint8_t>, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
-                       c->stream, (const uint8_t*)c->gather.p, maxlocal, c->world, (const long long*)c->shard_first.p,
+    unsigned long long* sendw = (unsigned long long*)c->gather.p;
+    unsigned long long* recvw = sendw + words;
+    hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)std::min<long long>((words + 3) / 4, 1 << 16)), dim3(256), 0, c->stream,
+                       (const uint8_t*)c->maskU.p, c->cs.n_local, words, sendw);
+    if ((rc = comm_allgather_bytes(c, sendw, recvw, sizeof(unsigned long long) * (size_t)words))) return rc;
+    hipLaunchKernelGGL(k_unpack_shards, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
+                       c->stream, (const unsigned long long*)recvw, words, c->world, (const long long*)c->shard_first.p,
                        c->grid_total, (uint8_t*)c->Ufull.p);
   }
   SBO_HIP(hipGetLastError());
