@@ -78,6 +78,7 @@ struct sbo_ctx {
   sbo::DevBuf partial; // arg-reduce per-block partials
   sbo::DevBuf amb;     // ambiguous-index list for the exact recheck
   sbo::DevBuf runmeta; // GoOSE: per-run bounding boxes / radii of the coverage search
+  sbo::DevBuf blockmin; // per-block minima along the last axis (blocked last-axis scans)
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
   sbo::DevBuf Wfull;   // multi-rank GoOSE: source weights of the whole grid (all-gathered), T [grid_total]
   sbo::DevBuf Ufull;   // multi-rank: U mask of the whole grid (all-gathered), uint8 [grid_total]
@@ -97,6 +98,7 @@ struct sbo_ctx {
   int k1_strips = 4;       // lines per K1g tile (4, or 8 for 2-D grids: tuning)
   int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
   int edt_tiled = 0;       // 1: LDS-tiled lock-step form of the last-axis expander scan (slower on measured configs)
+  int scan_blocks = 1;     // 0: step-by-step last-axis scans (A/B against the blocked form)
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
   int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
   // comm

@@ -290,6 +290,86 @@ __device__ __forceinline__ double edt_scan_point(const double* __restrict__ Din,
   return best;
 }
 
+// Last-axis scans with a one-level min-pyramid.  Bmin[b * stride + p] = min of the input over the kBlk (or `blk`) steps
+// of block b at in-plane position p.  A block whose bound  Bmin + (h gap)^2  cannot beat the running minimum is skipped
+// with one load instead of `blk`; the candidates examined inside a block and their arithmetic are those of the
+// step-by-step scan, so the minimum (up to the same early exits) is identical.  This keeps the scan cost near
+// O(sqrt(radius in steps)) when the grid is much finer along the last axis than the radius (weak-scaling grids).
+__global__ __launch_bounds__(256) void k_block_min(const double* __restrict__ Din, long long stride, int cnt, int blk,
+                                                   double* __restrict__ Bmin) {
+  const int nblk = (cnt + blk - 1) / blk;
+  const long long total = (long long)nblk * stride;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i % stride;
+    const int b = (int)(i / stride);
+    const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
+    double m = kInfD;
+    for (int j = b * blk; j < j1; ++j) {
+      const double v = Din[(long long)j * stride + p];
+      m = v < m ? v : m;
+    }
+    Bmin[i] = m;
+  }
+}
+
+// Euclidean form (values >= 0, exits as edt_scan_point: (h t)^2 >= best, h t > cap, best <= accept2).
+// Order of visits: the block with the smallest bound first (it almost always holds the minimiser, so `best` is near
+// its final value after one block), then every block whose bound still beats `best`.
+__device__ __forceinline__ double edt_scan_blocked(const double* __restrict__ Din, const double* __restrict__ Bmin, long long p,
+                                                   long long stride, int cnt, int ia, double h, double cap, double accept2,
+                                                   int blk) {
+  double best = Din[(long long)ia * stride + p];
+  const int nblk = (cnt + blk - 1) / blk, b0 = ia / blk;
+  auto scan_block = [&](int b) {
+    const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
+    for (int j = b * blk; j < j1; ++j) {
+      const double dt = h * (double)(j > ia ? j - ia : ia - j);
+      if (dt > cap) continue;
+      const double cnd = Din[(long long)j * stride + p] + dt * dt;
+      best = cnd < best ? cnd : best;
+    }
+  };
+  // gap (in steps) between ia and the nearest step of block b
+  auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? ia - (b * blk + blk - 1) : b * blk - ia); };
+  // pass A: block with the smallest bound
+  double lb_min = Bmin[(long long)b0 * stride + p];
+  int b_min = b0;
+  for (int k = 1; k < nblk; ++k) {
+    bool any = false;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int b = side ? b0 + k : b0 - k;
+      if (b < 0 || b >= nblk) continue;
+      const double dg = h * (double)gap_of(b);
+      const double e = dg * dg;
+      if (e >= best || e >= lb_min || dg > cap) continue;
+      any = true;
+      const double lb = Bmin[(long long)b * stride + p] + e;
+      if (lb < lb_min) { lb_min = lb; b_min = b; }
+    }
+    if (!any) break;
+  }
+  if (lb_min < best) scan_block(b_min);
+  if (best <= accept2) return best;
+  // pass B: whatever can still improve
+  if (b_min != b0 && Bmin[(long long)b0 * stride + p] < best) scan_block(b0);
+  for (int k = 1; k < nblk && !(best <= accept2); ++k) {
+    bool any = false;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int b = side ? b0 + k : b0 - k;
+      if (b < 0 || b >= nblk) continue;
+      const double dg = h * (double)gap_of(b);
+      const double e = dg * dg;
+      if (e >= best || dg > cap) continue;
+      any = true;
+      if (b != b_min && Bmin[(long long)b * stride + p] + e < best) scan_block(b);
+    }
+    if (!any) break;
+  }
+  return best;
+}
+
 __global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din, double* __restrict__ Dout, long long n,
                                                   long long stride, int cnt, double h, const SweepScalars* sc, int c,
                                                   const unsigned long long* Lkeys, int lidx, int uncapped) {
@@ -368,7 +448,7 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
                                                     const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
                                                     uint8_t* __restrict__ G, long long* __restrict__ amb,
-                                                    const CoarseGrid cg) {
+                                                    const CoarseGrid cg, const double* __restrict__ Bmin, int blk) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const bool anyU = sc->count_U > 0;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
@@ -392,7 +472,10 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
         }
         const int ia = (int)((gg / stride) % cnt);
         const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it the verdict is "sure true"
-        const double best = (cnt > 1) ? edt_scan_point(Din, gg, stride, cnt, ia, h, cap, thr > 0 ? thr * thr : -1.0) : Din[gg];
+        const double acc2 = thr > 0 ? thr * thr : -1.0;
+        const double best = cnt <= 1 ? Din[gg]
+                            : Bmin  ? edt_scan_blocked(Din, Bmin, gg % stride, stride, cnt, ia, h, cap, acc2, blk)
+                                    : edt_scan_point(Din, gg, stride, cnt, ia, h, cap, acc2);
         if (best < 0.5 * kInfD) {
           const double dm = sqrt(best);
           const double eps = eps_abs + 1e-11 * dm;
@@ -545,7 +628,10 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
                                                         const long long* __restrict__ amb, uint8_t* __restrict__ G) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const long long namb = sc->n_amb;
-  for (long long qi = blockIdx.x; qi < namb; qi += gridDim.x) {
+  constexpr int kParts = 64;   // a listed candidate's box can be as large as the grid: cut into slices, one workgroup each
+  for (long long wi = blockIdx.x; wi < namb * kParts; wi += gridDim.x) {
+    const long long qi = wi / kParts;
+    const int part = (int)(wi % kParts);
     const long long g = amb[qi];
     T lcb, ucbT;
     lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
@@ -577,7 +663,9 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
           sa *= cnt;
         }
       }
-      for (long long t = threadIdx.x; t < total && !found; t += blockDim.x) {
+      const long long chunk = (total + kParts - 1) / kParts;
+      const long long t1 = (part + 1) * chunk < total ? (part + 1) * chunk : total;
+      for (long long t = part * chunk + threadIdx.x; t < t1 && !found; t += blockDim.x) {
         long long u = t, hh = 0;
         double xh[D];
 #pragma unroll
@@ -595,7 +683,7 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
         if (hl >= 0 && hl < csU.n_local && U[hl] && lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
       }
     } else {
-      for (long long hh = threadIdx.x; hh < csU.n_local && !found; hh += blockDim.x) {
+      for (long long hh = (long long)part * blockDim.x + threadIdx.x; hh < csU.n_local && !found; hh += (long long)kParts * blockDim.x) {
         if (U[hh]) {
           double xh[D];
           cand_coords<D>(csU, hh, xh);
@@ -998,6 +1086,57 @@ __device__ __forceinline__ double pdt_scan_point(const double* __restrict__ Pin,
   return best;
 }
 
+// power-transform form of the blocked last-axis scan (values >= -rmax2; exits as pdt_scan_point), same visiting order
+__device__ __forceinline__ double pdt_scan_blocked(const double* __restrict__ Pin, const double* __restrict__ Bmin, long long p,
+                                                   long long stride, int cnt, int ia, double h, const PdtParams& pp, int blk) {
+  double best = Pin[(long long)ia * stride + p];
+  const int nblk = (cnt + blk - 1) / blk, b0 = ia / blk;
+  auto scan_block = [&](int b) {
+    const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
+    for (int j = b * blk; j < j1; ++j) {
+      const double dt = h * (double)(j > ia ? j - ia : ia - j);
+      const double cnd = Pin[(long long)j * stride + p] + dt * dt;
+      best = cnd < best ? cnd : best;
+    }
+  };
+  auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? ia - (b * blk + blk - 1) : b * blk - ia); };
+  double lb_min = Bmin[(long long)b0 * stride + p];
+  int b_min = b0;
+  for (int k = 1; k < nblk; ++k) {
+    bool any = false;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int b = side ? b0 + k : b0 - k;
+      if (b < 0 || b >= nblk) continue;
+      const double dg = h * (double)gap_of(b);
+      const double e = dg * dg, floor_ = e - pp.rmax2;
+      if (floor_ > pp.band || floor_ >= best || floor_ >= lb_min) continue;
+      any = true;
+      const double lb = Bmin[(long long)b * stride + p] + e;
+      if (lb < lb_min) { lb_min = lb; b_min = b; }
+    }
+    if (!any) break;
+  }
+  if (lb_min < best) scan_block(b_min);
+  if (best < -pp.band) return best;
+  if (b_min != b0 && Bmin[(long long)b0 * stride + p] < best) scan_block(b0);
+  for (int k = 1; k < nblk && !(best < -pp.band); ++k) {
+    bool any = false;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int b = side ? b0 + k : b0 - k;
+      if (b < 0 || b >= nblk) continue;
+      const double dg = h * (double)gap_of(b);
+      const double e = dg * dg, floor_ = e - pp.rmax2;
+      if (floor_ > pp.band || floor_ >= best) continue;
+      any = true;
+      if (b != b_min && Bmin[(long long)b * stride + p] + e < best) scan_block(b);
+    }
+    if (!any) break;
+  }
+  return best;
+}
+
 __global__ __launch_bounds__(256) void k_pdt_scan(const double* __restrict__ Pin, double* __restrict__ Pout, long long nt,
                                                   long long stride, int cnt, double h, const SweepScalars* sc, int c,
                                                   const unsigned long long* Lkeys, int lidx, int d, double xscale) {
@@ -1013,7 +1152,8 @@ __global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ P
                                                     int cnt, double h, int d, double xscale, const uint8_t* __restrict__ U,
                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc, int c,
                                                     uint8_t* __restrict__ O, long long* __restrict__ amb, const CoarseGrid cg,
-                                                    const double* __restrict__ PcLo, const double* __restrict__ PcHi) {
+                                                    const double* __restrict__ PcLo, const double* __restrict__ PcHi,
+                                                    const double* __restrict__ Bmin, int blk) {
   const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
   const bool anyS = sc->count_S > 0;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
@@ -1029,7 +1169,9 @@ __global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ P
           if (PcLo[cell] > pp.band) { O[g] = 0; continue; }      // out of every source's reach
         }
         const int ia = (int)((gg / stride) % cnt);
-        const double best = (cnt > 1) ? pdt_scan_point(Pin, gg, stride, cnt, ia, h, pp, true) : Pin[gg];
+        const double best = cnt <= 1 ? Pin[gg]
+                            : Bmin  ? pdt_scan_blocked(Pin, Bmin, gg % stride, stride, cnt, ia, h, pp, blk)
+                                    : pdt_scan_point(Pin, gg, stride, cnt, ia, h, pp, true);
         if (best < -pp.band) out = 1;
         else if (best <= pp.band) {
           const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
@@ -1327,10 +1469,19 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
                          last_cnt, last_h, d, xscale, mean_c, var_c, (T)o->b, (const uint8_t*)c->maskS.p,
                          (const unsigned long long*)c->Lmax.p, lidx, sc, G, (long long*)c->amb.p);
     } else {
+      const double* bmin = nullptr;
+      const int blk = last_cnt >= 8192 ? 64 : 32;
+      if (d >= 2 && last_cnt >= 4 * blk && c->scan_blocks) {
+        const long long nb_ = (long long)((last_cnt + blk - 1) / blk) * stride;
+        if ((rc = ensure(c->blockmin, sizeof(double) * (size_t)nb_))) return rc;
+        hipLaunchKernelGGL(k_block_min, dim3((unsigned)std::min<long long>((nb_ + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+                           (const double*)din, stride, last_cnt, blk, (double*)c->blockmin.p);
+        bmin = (const double*)c->blockmin.p;
+      }
       hipLaunchKernelGGL((k_edt_decide<T>), dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0,
                          c->stream, (const double*)din, n, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c,
                          (T)o->b, (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
-                         (long long*)c->amb.p, cg);
+                         (long long*)c->amb.p, cg, bmin, blk);
     }
   } else {
     // explicit candidate lists, and grid ranges that are not whole hyper-planes: exhaustive evaluation
@@ -1672,9 +1823,18 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     }
     const int last_cnt = d >= 2 ? (int)wplanes : 1;
     const double last_h = d >= 2 ? c->cs.step[d - 1] : 0.0;
+    const double* bmin = nullptr;
+    const int blk = last_cnt >= 8192 ? 64 : 32;
+    if (d >= 2 && last_cnt >= 4 * blk && c->scan_blocks) {
+      const long long nb_ = (long long)((last_cnt + blk - 1) / blk) * stride;
+      if ((rc = ensure(c->blockmin, sizeof(double) * (size_t)nb_))) return rc;
+      hipLaunchKernelGGL(k_block_min, dim3((unsigned)std::min<long long>((nb_ + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+                         (const double*)pin, stride, last_cnt, blk, (double*)c->blockmin.p);
+      bmin = (const double*)c->blockmin.p;
+    }
     hipLaunchKernelGGL(k_pdt_decide, dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
                        (const double*)pin, n, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, (const uint8_t*)c->maskU.p,
-                       (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, O, (long long*)c->amb.p, cg, pc_lo, pc_hi);
+                       (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, O, (long long*)c->amb.p, cg, pc_lo, pc_hi, bmin, blk);
     hipLaunchKernelGGL((k_goose_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, css, W,
                        (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, (const long long*)c->amb.p, O);
     SBO_HIP(hipGetLastError());
