@@ -320,6 +320,62 @@ def test_one_dimensional_model_and_grid(engine):
     assert res["minimizer_index"] == ref["minimizer_index"] and list(res["expander_index_c"]) == list(ref["expander_index"])
 
 
+@pytest.mark.parametrize("d,count,n,off,ll,b", [(3, [13, 11, 10], 40, 0.9, -0.5, 1.0), (5, [6, 5, 4, 5, 4], 90, 1.1, 0.9, 2.0),
+                                                (6, [4, 4, 3, 4, 3, 4], 120, 1.3, 0.9, 2.0)])
+def test_sweeps_on_grids_of_any_dimension(engine, d, count, n, off, ll, b):
+    """d = 3 (padded to 4), 5 and 6 (padded to 8): separable grid posterior, every middle axis of the distance and power
+    transforms, and the coordinate decoding of the results, against the oracle."""
+    rng = np.random.default_rng(200 + d)
+    X = rng.uniform(-1, 1, size=(n, d))
+    Y = np.stack([np.sin(X.sum(1)) + 0.5 * X[:, 0], off - 1.8 * (X ** 2).mean(1) + 0.3 * X[:, 1]], axis=1)
+    hyp = synthetic.default_hypopt(d, 2)
+    hyp[:d, :] = ll
+    ds = synthetic.make_dataset(X, Y, hyp)
+    lo, hi = -np.ones(d), np.ones(d)
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_model(ds)
+    engine.set_grid(lo, hi, count)
+    _check_posterior(engine, ds, pts, TOL64)
+    ref = oracle.safeopt_sweep(pts, ds, b)
+    assert ref["G"].any() and ref["M"].any()
+    res = engine.sweep_safeopt(b, want_masks=True, posterior_ready=True)
+    _check_safeopt(engine, ref, 2)
+    assert res["minimizer_index"] == ref["minimizer_index"] and list(res["expander_index_c"]) == list(ref["expander_index"])
+    assert np.array_equal(res["minimizer_x"], pts[ref["minimizer_index"]])
+    assert np.allclose(res["L"], ref["L"], rtol=1e-9)
+    gref = oracle.goose_sweep(pts, ds, b)
+    assert gref["O"].any()
+    g = engine.sweep_goose(b, want_masks=True, posterior_ready=True)
+    assert np.array_equal(engine.mask("O", 1), gref["O"][0])
+    assert (g["safe_min_index"], g["target_index"], g["explore_index"]) == (gref["safe_min_index"], gref["target_index"],
+                                                                             gref["explore_index"])
+    assert np.array_equal(g["target_x"], pts[gref["target_index"]])
+    x0 = pts[ref["minimizer_index"]]
+    tref = oracle.tr_sweep(pts, ds, b, x0, 0.8)
+    t = engine.sweep_tr(b, x0, 0.8, posterior_ready=True)
+    assert t["index"] == tref["index"] and t["count_T"] == int(tref["T"].sum())
+
+
+def test_fp32_sweep_masks_follow_the_fp32_posterior(engine):
+    """dtype f32: the classification runs in fp32 on the fp32 posterior; given those mean/var values the masks and the
+    acquisition are bit-exact functions of them (the oracle evaluates the same expressions in numpy float32)."""
+    cfg = synthetic.make_config("B", n=128)
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [96, 80]
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_model(cfg["ds"], dtype="f32", use_invK=False)
+    engine.set_grid(lo, hi, count)
+    mean, var = _check_posterior(engine, cfg["ds"], pts, TOL32, dtype="f32")
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"], mean_var=(mean, var))
+    res = engine.sweep_safeopt(cfg["b"], want_masks=True, posterior_ready=True)
+    for k in ("S", "U", "M"):
+        assert np.array_equal(engine.mask(k), ref[k]), k
+    assert res["minimizer_index"] == ref["minimizer_index"]
+    assert res["u_star"] == float(ref["u_star"])
+    # the expander set also depends on L (fp32 gradient on the device, fp64 in the oracle): compare away from ties
+    G, Gref = engine.mask("G", 1), ref["G"][0]
+    assert not (G & ~ref["S"]).any() and (G != Gref).sum() <= 2e-3 * max(1, Gref.sum())
+
+
 def test_no_unsafe_witness_means_no_expander(engine):
     """Every candidate safe and none fully unsafe: G_c is empty, the expander is reported as absent and the loop rule
     falls back to the minimiser (test/test_SafeOpt.py:153-158 with std_expander = 0)."""
