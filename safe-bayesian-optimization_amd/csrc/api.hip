@@ -190,7 +190,7 @@ int sbo_shutdown(sbo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->Lmax, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->blockmin, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_S0, &c->bl_Vb, &c->blockmin, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -220,6 +220,11 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   }
   if (!strcmp(key, "edt_tiled")) {
     c->edt_tiled = value ? 1 : 0;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "bilinear")) {
+    c->bilinear = value ? 1 : 0;
+    c->posterior_valid = false;
     return SBO_OK;
   }
   if (!strcmp(key, "scan_blocks")) {
@@ -334,6 +339,9 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
     }
   }
   c->dtype = dtype;
+  c->h_F = F;
+  c->h_alpha = alpha;
+  c->bl.valid = false;
   int rc = (dtype == SBO_F64) ? model_upload<double>(c, F, As, sqA, alpha, Xn) : model_upload<float>(c, F, As, sqA, alpha, Xn);
   if (rc) return rc;
   c->has_model = true;
@@ -368,6 +376,7 @@ int sbo_candidates_points(sbo_ctx* c, const void* points, int points_dtype, int6
   c->grid_total = n_local;
   c->sharded = false;
   c->has_cand = true;
+  c->bl.valid = false;
   c->posterior_valid = false;
   c->masks_valid = false;
   return SBO_OK;
@@ -395,6 +404,7 @@ int sbo_candidates_grid(sbo_ctx* c, int d, const double* lo, const double* hi, c
   c->grid_total = (long long)total;
   c->sharded = false;
   c->has_cand = true;
+  c->bl.valid = false;
   c->posterior_valid = false;
   c->masks_valid = false;
   return SBO_OK;

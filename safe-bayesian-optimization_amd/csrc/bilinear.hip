@@ -1,0 +1,317 @@
+// bilinear.hip -- K1b: GP posterior on 2-D tensor grids as two dense fp64 GEMMs (gfx950).
+//
+// Reference arithmetic replaced: GP.GP_inference, models/GP_Safe.py:326-347, evaluated at every point of a
+// linspace x linspace grid (test/test_SafeOpt.py:324-345).  The math and the host-side construction of the bases are
+// in bilinear_host.hpp; this file holds the plan (device tables) and the kernels:
+//
+//   stage 1  Bt[x1, k0]  = sum_k1 P1[k1, x1] T4qq[k0, k1]                 (rows of the grid  x  pair index of axis 0)
+//   stage 2  quad[x1,x0] = sum_k0 Bt[x1, k0] P0[k0, x0]   ->  var = max(0, sf2 - quad) Y_std^2
+//   mean     m[x1, x0]   = sum_p  V0[p, x1] S0[p, x0]     (and the d gradient sums, same shape)
+//
+// Both GEMMs run on the matrix cores with the fragment conventions of device_common.hpp (four v_mfma_f64_4x4x4 per
+// 16x16x4 step): A operands are stored as packed 16x16 block images, B operands in fragment order, so every operand
+// load is one contiguous 512-byte (B) or 2-KiB (A) wave access.  Inner dimensions: K0 = r0 (r0 + 1) / 2 ~ 280 for the
+// reference's length-scales, whatever n is.
+#include <string.h>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+#include "bilinear_host.hpp"
+#include "device_common.hpp"
+
+namespace sbo {
+
+// OUT[rows x cols] = A[rows x K] B[K x cols];  A: [nrb][KB][256] packed block images, Bf: [ncs][KB * 4][64] fragments.
+// A wave owns 16 rows x (16 S) columns; the four waves of a workgroup take four consecutive row blocks.
+//   MODE 0: OUT is written as packed block images [nrb][ncs][256] (it is the A operand of the next GEMM)
+//   MODE 1: posterior-variance epilogue, OUT element (row, col) is candidate row * cnt0 + col
+template <int S, int MODE>
+__global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, size_t a_stride_o, const double* __restrict__ Bf,
+                                               size_t b_stride_o, int KB, int nrb, int ncs, double* __restrict__ out,
+                                               size_t out_stride_o, const ModelConst mc, long long cnt0, long long nlines) {
+  const int o = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rb = blockIdx.y * 4 + wave;
+  if (rb >= nrb) return;                       // (no barriers in this kernel)
+  const int cs0 = blockIdx.x * S;
+  const double* Ablk = A + (size_t)o * a_stride_o + (size_t)rb * KB * 256;
+  const double* Bo = Bf + (size_t)o * b_stride_o;
+  size_t boff[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int cs = cs0 + s < ncs ? cs0 + s : ncs - 1;
+    boff[s] = (size_t)cs * KB * 4 * 64 + lane;
+  }
+  d4_t acc[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) acc[s] = d4_t{0.0, 0.0, 0.0, 0.0};
+  for (int kb = 0; kb < KB; ++kb) {
+    d4_t a[4];
+    MM<double>::load_a4(Ablk + (size_t)kb * 256, lane, a);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const double b = Bo[boff[s] + (size_t)(kb * 4 + kk) * 64];
+        acc[s] = MM<double>::mfma(a[kk], b, acc[s]);
+      }
+    }
+  }
+  // accumulator element t of lane l: row 4 t + (l >> 4), column l & 15 of the 16 x 16 tile
+  const int col_in = lane & 15, row_in = lane >> 4;
+  if (MODE == 0) {
+    double* Oo = out + (size_t)o * out_stride_o + (size_t)rb * ncs * 256;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      if (cs0 + s >= ncs) continue;
+      double* blk = Oo + (size_t)(cs0 + s) * 256;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) blk[MM<double>::pack_pos(4 * t + row_in, col_in & 3, col_in >> 2)] = acc[s][t];
+    }
+  } else {
+    const double sf2 = mc.sf2[o], ystd = mc.Y_std[o];
+    const double y2 = ystd * ystd;
+    double* Vo = out + (size_t)o * out_stride_o;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const long long x0 = (long long)(cs0 + s) * 16 + col_in;
+      if (cs0 + s >= ncs || x0 >= cnt0) continue;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const long long line = (long long)rb * 16 + 4 * t + row_in;
+        if (line >= nlines) continue;
+        double var = sf2 - acc[s][t];                                   // models/GP_Safe.py:343 (clipped at 0)
+        var = var > 0.0 ? var : 0.0;
+        Vo[line * cnt0 + x0] = var * y2;                                // :347
+      }
+    }
+  }
+}
+
+// mean and the gradient sums: 16 grid lines x 256 axis-0 positions per workgroup, one axis-0 position per thread
+template <int NB>   // NB = 1 + d row-vector families (alpha, alpha Xn_0, alpha Xn_1)
+__global__ __launch_bounds__(256) void k_bmean(const ModelConst mc, const CandSpec cs, const double* __restrict__ S0,
+                                               const double* __restrict__ Vb, int r0u, long long nlines, long long nlines_pad,
+                                               long long line0, double* __restrict__ mean_out, unsigned long long* __restrict__ Lmax) {
+  const int o = blockIdx.z;
+  const long long cnt0 = cs.count[0];
+  const long long x0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long rowbase = (long long)blockIdx.y * 16;
+  const bool xok = x0 < cnt0;
+  double acc[NB][16];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0;
+  const double* S0o = S0 + (size_t)o * r0u * cnt0;
+  const double* Vo = Vb + (size_t)o * NB * r0u * nlines_pad;
+  for (int p = 0; p < r0u; ++p) {
+    const double s = xok ? S0o[(size_t)p * cnt0 + x0] : 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const double* v = Vo + ((size_t)b * r0u + p) * nlines_pad + rowbase;     // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = fma(v[r], s, acc[b][r]);
+    }
+  }
+  double gmax = 0.0;
+  if (xok) {
+    const double ystd = mc.Y_std[o];
+    const double xg0 = (x0 == cnt0 - 1 && cnt0 > 1) ? cs.hi[0] : cs.lo[0] + (double)x0 * cs.step[0];
+    const double xn0 = (xg0 - mc.X_mean[0]) * mc.X_rstd[0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long line = rowbase + r;
+      if (line >= nlines) continue;
+      const double s1 = acc[0][r];
+      const double mean = mc.mp[o] + s1;                                                          // GP_Safe.py:342
+      mean_out[(size_t)o * cs.n_local + line * cnt0 + x0] = mean * ystd + mc.Y_mean[o];           // :346
+      // gradient of the un-normalised mean w.r.t. raw x (analytic jax.grad(self.mean), models/SafeOpt.py:68-71)
+      double gn = ystd * (acc[1][r] - xn0 * s1) * mc.inv_ell[o][0] * mc.X_rstd[0];
+      gn = gn < 0 ? -gn : gn;
+      if (NB > 2) {
+        const long long i1 = line0 + line, cnt1 = cs.count[1];
+        const double xg1 = (i1 == cnt1 - 1 && cnt1 > 1) ? cs.hi[1] : cs.lo[1] + (double)i1 * cs.step[1];
+        const double xn1 = (xg1 - mc.X_mean[1]) * mc.X_rstd[1];
+        double g1 = ystd * (acc[NB > 2 ? 2 : 0][r] - xn1 * s1) * mc.inv_ell[o][1] * mc.X_rstd[1];
+        g1 = g1 < 0 ? -g1 : g1;
+        gn = g1 > gn ? g1 : gn;
+      }
+      gmax = gn > gmax ? gn : gmax;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double other = __shfl_xor(gmax, off);
+    gmax = other > gmax ? other : gmax;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(&Lmax[o], (unsigned long long)__double_as_longlong(gmax));
+}
+
+// ---- plan ------------------------------------------------------------------------------------------------
+static void grid_axis_positions(const sbo_ctx* c, int a, long long i0, long long cnt, std::vector<double>& xn) {
+  const CandSpec& cs = c->cs;
+  xn.resize((size_t)cnt);
+  for (long long k = 0; k < cnt; ++k) {
+    const long long i = i0 + k, tot = cs.count[a];
+    const double x = (i == tot - 1 && tot > 1) ? cs.hi[a] : cs.lo[a] + (double)i * cs.step[a];
+    xn[(size_t)k] = (x - c->mc.X_mean[a]) / c->mc.X_std[a];                                       // GP_Safe.py:326
+  }
+}
+
+bool bilinear_applicable(const sbo_ctx* c) {
+  const CandSpec& cs = c->cs;
+  if (!c->bilinear || c->dtype != SBO_F64 || cs.kind != 1 || cs.d != 2 || c->mc.d != 2) return false;
+  const long long cnt0 = cs.count[0];
+  if (cs.n_local <= 0 || cs.first % cnt0 != 0 || cs.n_local % cnt0 != 0) return false;
+  // the bases pay off (and the interpolation interval is meaningful) only on real grids
+  return cnt0 >= 64 && cs.count[1] >= 64 && cs.n_local / cnt0 >= 16 && (int)c->h_F.size() == c->mc.q * c->mc.n * c->mc.n;
+}
+
+// Builds the device tables for the current (model, candidates).  Returns SBO_OK with plan.usable = false when the bases do
+// not qualify (rank / interpolation limits): the caller then keeps the separable-table kernel.
+int bilinear_setup(sbo_ctx* c) {
+  BilinearPlan& pl = c->bl;
+  pl.valid = true;
+  pl.usable = false;
+  const ModelConst& mc = c->mc;
+  const CandSpec& cs = c->cs;
+  const int n = mc.n, q = mc.q, d = 2, NB = 1 + d;
+  const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0, line0 = cs.first / cnt0;
+  std::vector<double> xn0, xn1_all, xn1;
+  grid_axis_positions(c, 0, 0, cnt0, xn0);
+  // the axis-1 basis is built on the interval of the WHOLE axis, so that every rank of a sharded grid uses the same
+  // functions; only the local lines are tabulated
+  grid_axis_positions(c, 1, 0, cs.count[1], xn1_all);
+  std::vector<bl::AxisBasis> b0(q), b1(q);
+  std::vector<double> col(n);
+  for (int o = 0; o < q; ++o) {
+    for (int a = 0; a < 2; ++a) {
+      for (int j = 0; j < n; ++j) col[j] = c->h_Xnorm[(size_t)j * mc.d + a] * mc.vinv[o][a];     // GP_Safe.py:115
+      bl::AxisBasis& b = a == 0 ? b0[o] : b1[o];
+      const std::vector<double>& xs = a == 0 ? xn0 : xn1_all;
+      if (!bl::axis_basis(n, col.data(), mc.vinv[o][a], xs.data(), (int)xs.size(), b)) return SBO_OK;
+    }
+  }
+  int r0u = 0, K0 = 0, K1 = 0;
+  for (int o = 0; o < q; ++o) {
+    r0u = std::max(r0u, b0[o].r);
+    K0 = std::max(K0, bl::pair_count(b0[o].r));
+    K1 = std::max(K1, bl::pair_count(b1[o].r));
+  }
+  const int KB0 = (K0 + 15) / 16, KB1 = (K1 + 15) / 16;
+  const int ncs0 = (int)((cnt0 + 15) / 16), nrb = (int)((nlines + 15) / 16);
+  const long long nlines_pad = (long long)nrb * 16;
+  pl.KB0 = KB0; pl.KB1 = KB1; pl.r0u = r0u; pl.ncs0 = ncs0; pl.nrb = nrb; pl.nlines_pad = nlines_pad;
+  pl.sP0f = (size_t)ncs0 * KB0 * 4 * 64;
+  pl.sP1A = (size_t)nrb * KB1 * 256;
+  pl.sT4f = (size_t)KB0 * KB1 * 4 * 64;
+  pl.sBtA = (size_t)nrb * KB0 * 256;
+  std::vector<double> hP0f(pl.sP0f * q, 0.0), hP1A(pl.sP1A * q, 0.0), hT4f(pl.sT4f * q, 0.0),
+      hS0((size_t)q * r0u * cnt0, 0.0), hVb((size_t)q * NB * r0u * nlines_pad, 0.0);
+  std::vector<double> P0, P1, T4qq, Mb, beta((size_t)NB * n);
+  for (int o = 0; o < q; ++o) {
+    const int r0 = b0[o].r, r1 = b1[o].r, k0n = bl::pair_count(r0), k1n = bl::pair_count(r1);
+    const double sf2 = mc.sf2[o];
+    for (int j = 0; j < n; ++j) {
+      const double al = c->h_alpha[(size_t)o * mc.npad + j];
+      beta[j] = al;
+      beta[(size_t)n + j] = al * c->h_Xnorm[(size_t)j * mc.d + 0];
+      beta[(size_t)2 * n + j] = al * c->h_Xnorm[(size_t)j * mc.d + 1];
+    }
+    const double* bp[3] = {&beta[0], &beta[(size_t)n], &beta[(size_t)2 * n]};
+    bl::build_forms(n, &c->h_F[(size_t)o * n * n], b0[o], b1[o], sf2 * sf2, NB, bp, sf2, T4qq, Mb);
+    bl::pair_table(b0[o], (int)cnt0, P0);                       // [k0n x cnt0]
+    // axis-1 tables for the local lines only
+    bl::AxisBasis b1loc;
+    b1loc.r = r1;
+    b1loc.S.resize((size_t)r1 * nlines);
+    for (int s = 0; s < r1; ++s)
+      for (long long l = 0; l < nlines; ++l) b1loc.S[(size_t)s * nlines + l] = b1[o].S[(size_t)s * cs.count[1] + line0 + l];
+    bl::pair_table(b1loc, (int)nlines, P1);                     // [k1n x nlines]
+    // P0 -> B fragments [ncs0][KB0 * 4][64]
+    double* f = &hP0f[pl.sP0f * o];
+    for (int csx = 0; csx < ncs0; ++csx)
+      for (int ks = 0; ks < KB0 * 4; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int k = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+          const long long x = (long long)csx * 16 + (l & 15);
+          if (k < k0n && x < cnt0) f[((size_t)csx * KB0 * 4 + ks) * 64 + l] = P0[(size_t)k * cnt0 + x];
+        }
+    // P1^T -> packed A images [nrb][KB1][256]
+    double* pa = &hP1A[pl.sP1A * o];
+    for (int rb = 0; rb < nrb; ++rb)
+      for (int kb = 0; kb < KB1; ++kb)
+        for (int r = 0; r < 16; ++r)
+          for (int slot = 0; slot < 4; ++slot)
+            for (int kk = 0; kk < 4; ++kk) {
+              const long long line = (long long)rb * 16 + r;
+              const int k = kb * 16 + MM<double>::jslot(kk, slot);
+              if (line < nlines && k < k1n)
+                pa[((size_t)rb * KB1 + kb) * 256 + MM<double>::pack_pos(r, slot, kk)] = P1[(size_t)k * nlines + line];
+            }
+    // T4qq^T -> B fragments over the columns k0: [KB0][KB1 * 4][64], element (k1, k0)
+    double* tf = &hT4f[pl.sT4f * o];
+    for (int csx = 0; csx < KB0; ++csx)
+      for (int ks = 0; ks < KB1 * 4; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int k1 = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+          const int k0 = csx * 16 + (l & 15);
+          if (k0 < k0n && k1 < k1n) tf[((size_t)csx * KB1 * 4 + ks) * 64 + l] = T4qq[(size_t)k0 * k1n + k1];
+        }
+    for (int p = 0; p < r0; ++p)
+      memcpy(&hS0[((size_t)o * r0u + p) * cnt0], &b0[o].S[(size_t)p * cnt0], sizeof(double) * (size_t)cnt0);
+    // V_b[p][line] = sum_s Mb[b][p, s] S1[s][line]
+    for (int b = 0; b < NB; ++b)
+      for (int p = 0; p < r0; ++p) {
+        double* dst = &hVb[(((size_t)o * NB + b) * r0u + p) * nlines_pad];
+        for (int s = 0; s < r1; ++s) {
+          const double m = Mb[(size_t)b * r0 * r1 + (size_t)p * r1 + s];
+          const double* s1 = &b1loc.S[(size_t)s * nlines];
+          for (long long l = 0; l < nlines; ++l) dst[l] += m * s1[l];
+        }
+      }
+    pl.r0[o] = r0;
+    pl.r1[o] = r1;
+  }
+  int rc;
+  if ((rc = ensure(c->bl_P0f, sizeof(double) * hP0f.size()))) return rc;
+  if ((rc = ensure(c->bl_P1A, sizeof(double) * hP1A.size()))) return rc;
+  if ((rc = ensure(c->bl_T4f, sizeof(double) * hT4f.size()))) return rc;
+  if ((rc = ensure(c->bl_S0, sizeof(double) * hS0.size()))) return rc;
+  if ((rc = ensure(c->bl_Vb, sizeof(double) * hVb.size()))) return rc;
+  if ((rc = ensure(c->bl_BtA, sizeof(double) * pl.sBtA * q))) return rc;
+  SBO_HIP(hipMemcpyAsync(c->bl_P0f.p, hP0f.data(), sizeof(double) * hP0f.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->bl_P1A.p, hP1A.data(), sizeof(double) * hP1A.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->bl_T4f.p, hT4f.data(), sizeof(double) * hT4f.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->bl_S0.p, hS0.data(), sizeof(double) * hS0.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->bl_Vb.p, hVb.data(), sizeof(double) * hVb.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));      // the host vectors go out of scope
+  pl.usable = true;
+  return SBO_OK;
+}
+
+int launch_posterior_bilinear(sbo_ctx* c) {
+  const BilinearPlan& pl = c->bl;
+  const ModelConst& mc = c->mc;
+  const CandSpec& cs = c->cs;
+  const int q = mc.q;
+  const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0, line0 = cs.first / cnt0;
+  constexpr int S1 = 6, S2 = 8;
+  // stage 1: Bt = P1^T T4qq^T, written as the packed A operand of stage 2
+  hipLaunchKernelGGL((k_bgemm<S1, 0>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256),
+                     0, c->stream, (const double*)c->bl_P1A.p, pl.sP1A, (const double*)c->bl_T4f.p, pl.sT4f, pl.KB1, pl.nrb, pl.KB0,
+                     (double*)c->bl_BtA.p, pl.sBtA, mc, cnt0, nlines);
+  // stage 2: quadratic form -> variance
+  hipLaunchKernelGGL((k_bgemm<S2, 1>), dim3((unsigned)((pl.ncs0 + S2 - 1) / S2), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256),
+                     0, c->stream, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, pl.KB0, pl.nrb, pl.ncs0,
+                     (double*)c->var.p, (size_t)cs.n_local, mc, cnt0, nlines);
+  // mean + Lipschitz keys
+  hipLaunchKernelGGL((k_bmean<3>), dim3((unsigned)((cnt0 + 255) / 256), (unsigned)pl.nrb, (unsigned)q), dim3(256), 0, c->stream, mc, cs,
+                     (const double*)c->bl_S0.p, (const double*)c->bl_Vb.p, pl.r0u, nlines, pl.nlines_pad, line0, (double*)c->mean.p,
+                     (unsigned long long*)c->Lmax.p);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+}  // namespace sbo

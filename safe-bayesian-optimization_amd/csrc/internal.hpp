@@ -40,6 +40,18 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// K1b (bilinear.hip): device tables of the reduced-basis posterior on a 2-D grid, valid for one (model, candidates) pair
+struct BilinearPlan {
+  bool valid = false;    // built (or found unusable) for the current model and candidates
+  bool usable = false;   // the bases qualified: the posterior runs as two GEMMs
+  int KB0 = 0, KB1 = 0;  // 16-blocks of the pair indices of axis 0 / axis 1
+  int r0u = 0, ncs0 = 0, nrb = 0;
+  long long nlines_pad = 0;
+  size_t sP0f = 0, sP1A = 0, sT4f = 0, sBtA = 0;   // per-output strides (elements)
+  int r0[kMaxQ] = {0}, r1[kMaxQ] = {0};
+  double setup_ms = 0.0;
+};
+
 }  // namespace sbo
 
 struct sbo_ctx {
@@ -60,6 +72,10 @@ struct sbo_ctx {
   sbo::DevBuf AXg;     // grid path: alpha_j (1, Xn_j) rows in fragment-slot order [q][npad][1 + dpad]
   size_t fpk_stride = 0;  // elements per output in Fpk
   std::vector<double> h_Xnorm;   // host copies used by the exact-recheck / result decoding
+  std::vector<double> h_F;       // [q][n][n] lower-triangular contraction factors (host copy for the K1b plan)
+  std::vector<double> h_alpha;   // [q][npad]
+  sbo::BilinearPlan bl;
+  sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_S0, bl_Vb;
   // candidates
   bool has_cand = false;
   sbo::CandSpec cs{};
@@ -100,6 +116,7 @@ struct sbo_ctx {
   int edt_tiled = 0;       // 1: LDS-tiled lock-step form of the last-axis expander scan (slower on measured configs)
   int scan_blocks = 1;     // 0: step-by-step last-axis scans (A/B against the blocked form)
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
+  int bilinear = 1;        // 1: fp64 2-D grids run the posterior as two GEMMs in a reduced basis when the bases qualify (K1b)
   int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
   // comm
   void* comm = nullptr;  // ncclComm_t
@@ -119,6 +136,9 @@ void release(DevBuf& b);
 // launchers implemented in the .hip files -----------------------------------------------------
 int launch_posterior(sbo_ctx* c);
 int launch_bound(sbo_ctx* c, double b, int index, int kind, void* dev_out);
+bool bilinear_applicable(const sbo_ctx* c);
+int bilinear_setup(sbo_ctx* c);
+int launch_posterior_bilinear(sbo_ctx* c);
 }  // namespace sbo
 
 #define SBO_HIP(x)                                                   \
