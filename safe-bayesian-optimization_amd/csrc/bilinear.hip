@@ -148,6 +148,148 @@ __global__ __launch_bounds__(256) void k_bmean(const ModelConst mc, const CandSp
   if ((threadIdx.x & 63) == 0) atomicMax(&Lmax[o], (unsigned long long)__double_as_longlong(gmax));
 }
 
+// Fused stage 2: variance, mean and gradient keys of a 128 x 128 tile of the grid (8 row blocks x 8 column strips) per
+// workgroup.  Four GEMM phases share the accumulators; operands are staged through LDS one 16-deep k-block at a time
+// (double-buffered), so every fragment is fetched from L2 once per workgroup instead of once per wave:
+//   phase 0  quad = Bt    . P0          (KS0 k-steps)  ->  var  = max(0, sf2 - quad) Y_std^2
+//   phase 1  s1   = V[0]  . S0          (KSm)          ->  mean = (mp + s1) Y_std + Y_mean
+//   phase 2  g0   = [V[1]; V[0]] . [S0; -xn0 S0]  (2 KSm)   gradient sum of axis 0 (the candidate's own xn0 sits in B)
+//   phase 3  g1   = V1x   . S0          (KSm)              gradient sum of axis 1 (xn1 of the line is folded into V1x)
+struct PostPhases {
+  const double* A[4];    // packed block images [nrb][KBp][256] of this output
+  const double* B[4];    // fragments [ncs][KBp * 4][64] of this output
+  int KS[4];             // k-steps actually run
+  int KB[4];             // k-blocks the images / fragments are laid out with
+};
+
+__global__ __launch_bounds__(256) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
+                                               const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
+                                               size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
+                                               int KSm, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
+                                               double* __restrict__ var_out, unsigned long long* __restrict__ Lmax) {
+  extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
+  const int o = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rb0 = blockIdx.y * 8, cs0 = blockIdx.x * 8;
+  const long long cnt0 = cs.count[0];
+  PostPhases ph;
+  // per-output operand bases; VA holds [V0 | V1;V0 | V1x] as three image sets, SBf holds [S0 | S0;-xn0 S0] as two fragment sets
+  const double* VAo = VA + (size_t)o * sVA;
+  const double* SBo = SBf + (size_t)o * sSBf;
+  ph.A[0] = BtA + (size_t)o * sBtA;                 ph.B[0] = P0f + (size_t)o * sP0f;          ph.KS[0] = KS0;     ph.KB[0] = KB0;
+  ph.A[1] = VAo;                                    ph.B[1] = SBo;                             ph.KS[1] = KSm;     ph.KB[1] = KBm;
+  ph.A[2] = VAo + (size_t)nrb * KBm * 256;          ph.B[2] = SBo + (size_t)ncs * KBm * 256;   ph.KS[2] = 2 * KBm * 4; ph.KB[2] = 2 * KBm;
+  ph.A[3] = VAo + (size_t)nrb * KBm * 256 * 3;      ph.B[3] = SBo;                             ph.KS[3] = KSm;     ph.KB[3] = KBm;
+  // staging role of this thread: 64 bytes of one A image and 64 bytes of one B strip per k-block
+  const int st_i = tid >> 5, st_off = (tid & 31) * 8;      // image / strip index 0..7, offset in doubles
+  const int st_rb = rb0 + st_i < nrb ? rb0 + st_i : nrb - 1;
+  const int st_cs = cs0 + st_i < ncs ? cs0 + st_i : ncs - 1;
+  const double sf2 = mc.sf2[o], ystd = mc.Y_std[o];
+  double gmax = 0.0;
+  const int col_in = lane & 15, row_in = lane >> 4;
+#pragma unroll 1
+  for (int phs = 0; phs < 4; ++phs) {
+    const double* Ap = ph.A[phs] + (size_t)st_rb * ph.KB[phs] * 256 + st_off;
+    const double* Bp = ph.B[phs] + (size_t)st_cs * ph.KB[phs] * 256 + st_off;
+    const int KS = ph.KS[phs];
+    const int nkb = (KS + 3) >> 2;
+    d4_t acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) acc[i][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
+    d4_t ra[2], rbv[2];
+    ra[0] = *reinterpret_cast<const d4_t*>(Ap);
+    ra[1] = *reinterpret_cast<const d4_t*>(Ap + 4);
+    rbv[0] = *reinterpret_cast<const d4_t*>(Bp);
+    rbv[1] = *reinterpret_cast<const d4_t*>(Bp + 4);
+    __syncthreads();                             // the previous phase has finished reading the buffers
+    {
+      double* dA = lds + st_i * 256 + st_off;
+      double* dB = lds + 2048 + st_i * 256 + st_off;
+      *reinterpret_cast<d4_t*>(dA) = ra[0];
+      *reinterpret_cast<d4_t*>(dA + 4) = ra[1];
+      *reinterpret_cast<d4_t*>(dB) = rbv[0];
+      *reinterpret_cast<d4_t*>(dB + 4) = rbv[1];
+    }
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+      const int cur = kb & 1;
+      if (kb + 1 < nkb) {
+        ra[0] = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256);
+        ra[1] = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256 + 4);
+        rbv[0] = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256);
+        rbv[1] = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256 + 4);
+      }
+      const double* LA = lds + cur * 4096 + (2 * wave) * 256;
+      const double* LB = lds + cur * 4096 + 2048;
+      const int kkn = KS - kb * 4 < 4 ? KS - kb * 4 : 4;
+#pragma unroll 1
+      for (int kk = 0; kk < kkn; ++kk) {
+        {
+          const d4_t a0 = MM<double>::load_a(LA, lane, kk);
+          const d4_t a1 = MM<double>::load_a(LA + 256, lane, kk);
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            const double b = LB[(s2 * 4 + kk) * 64 + lane];
+            acc[0][s2] = MM<double>::mfma(a0, b, acc[0][s2]);
+            acc[1][s2] = MM<double>::mfma(a1, b, acc[1][s2]);
+          }
+        }
+      }
+      if (kb + 1 < nkb) {
+        double* dA = lds + (cur ^ 1) * 4096 + st_i * 256 + st_off;
+        double* dB = lds + (cur ^ 1) * 4096 + 2048 + st_i * 256 + st_off;
+        *reinterpret_cast<d4_t*>(dA) = ra[0];
+        *reinterpret_cast<d4_t*>(dA + 4) = ra[1];
+        *reinterpret_cast<d4_t*>(dB) = rbv[0];
+        *reinterpret_cast<d4_t*>(dB + 4) = rbv[1];
+      }
+      __syncthreads();
+    }
+    // epilogue of the phase: accumulator element t of lane l is row 4 t + (l >> 4), column l & 15 of its 16 x 16 tile
+    double* const outp = (phs == 0 ? var_out : mean_out) + (size_t)o * cs.n_local;
+    const double y2 = ystd * ystd, mpo = mc.mp[o], ymo = mc.Y_mean[o];
+    const double gscale = phs >= 2 ? ystd * mc.inv_ell[o][phs - 2] * mc.X_rstd[phs - 2] : 0.0;
+    const unsigned int ucnt0 = (unsigned int)cnt0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rb = rb0 + 2 * wave + i;
+      if (rb >= nrb) continue;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const unsigned int line = (unsigned int)rb * 16u + 4u * t + row_in;
+        if ((long long)line >= nlines) continue;
+        const unsigned int rowoff = line * ucnt0;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const unsigned int x0 = (unsigned int)(cs0 + s2) * 16u + col_in;
+          if (cs0 + s2 >= ncs || x0 >= ucnt0) continue;
+          const double v = acc[i][s2][t];
+          if (phs == 0) {
+            double var = sf2 - v;                                             // models/GP_Safe.py:343, clipped at 0
+            var = var > 0.0 ? var : 0.0;
+            outp[rowoff + x0] = var * y2;                                     // :347
+          } else if (phs == 1) {
+            outp[rowoff + x0] = (mpo + v) * ystd + ymo;                       // :342, :346
+          } else {
+            // component of the gradient of the un-normalised mean (analytic jax.grad(self.mean), SafeOpt.py:68-71)
+            double ga = gscale * v;
+            ga = ga < 0 ? -ga : ga;
+            gmax = ga > gmax ? ga : gmax;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double other = __shfl_xor(gmax, off);
+    gmax = other > gmax ? other : gmax;
+  }
+  if (lane == 0) atomicMax(&Lmax[o], (unsigned long long)__double_as_longlong(gmax));
+}
+
 // ---- plan ------------------------------------------------------------------------------------------------
 static void grid_axis_positions(const sbo_ctx* c, int a, long long i0, long long cnt, std::vector<double>& xn) {
   const CandSpec& cs = c->cs;
@@ -207,8 +349,14 @@ int bilinear_setup(sbo_ctx* c) {
   pl.sP1A = (size_t)nrb * KB1 * 256;
   pl.sT4f = (size_t)KB0 * KB1 * 4 * 64;
   pl.sBtA = (size_t)nrb * KB0 * 256;
-  std::vector<double> hP0f(pl.sP0f * q, 0.0), hP1A(pl.sP1A * q, 0.0), hT4f(pl.sT4f * q, 0.0),
-      hS0((size_t)q * r0u * cnt0, 0.0), hVb((size_t)q * NB * r0u * nlines_pad, 0.0);
+  const int KBm = (r0u + 15) / 16;
+  pl.KBm = KBm;
+  pl.KSm = (r0u + 3) / 4;
+  pl.KS0 = (K0 + 3) / 4;
+  pl.sVA = (size_t)nrb * KBm * 256 * 4;          // image sets  V0 | [V1; V0] | V1x
+  pl.sSBf = (size_t)ncs0 * KBm * 256 * 3;       // fragment sets  S0 | [S0; -xn0 S0]
+  std::vector<double> hP0f(pl.sP0f * q, 0.0), hP1A(pl.sP1A * q, 0.0), hT4f(pl.sT4f * q, 0.0), hVA(pl.sVA * q, 0.0),
+      hSBf(pl.sSBf * q, 0.0), Vb((size_t)NB * r0u * nlines);
   std::vector<double> P0, P1, T4qq, Mb, beta((size_t)NB * n);
   for (int o = 0; o < q; ++o) {
     const int r0 = b0[o].r, r1 = b1[o].r, k0n = bl::pair_count(r0), k1n = bl::pair_count(r1);
@@ -259,18 +407,53 @@ int bilinear_setup(sbo_ctx* c) {
           const int k0 = csx * 16 + (l & 15);
           if (k0 < k0n && k1 < k1n) tf[((size_t)csx * KB1 * 4 + ks) * 64 + l] = T4qq[(size_t)k0 * k1n + k1];
         }
-    for (int p = 0; p < r0; ++p)
-      memcpy(&hS0[((size_t)o * r0u + p) * cnt0], &b0[o].S[(size_t)p * cnt0], sizeof(double) * (size_t)cnt0);
-    // V_b[p][line] = sum_s Mb[b][p, s] S1[s][line]
+    // V_b[p][line] = sum_s Mb[b][p, s] S1[s][line]   (b: alpha, alpha Xn_0, alpha Xn_1)
+    std::fill(Vb.begin(), Vb.end(), 0.0);
     for (int b = 0; b < NB; ++b)
       for (int p = 0; p < r0; ++p) {
-        double* dst = &hVb[(((size_t)o * NB + b) * r0u + p) * nlines_pad];
+        double* dst = &Vb[((size_t)b * r0u + p) * nlines];
         for (int s = 0; s < r1; ++s) {
           const double m = Mb[(size_t)b * r0 * r1 + (size_t)p * r1 + s];
           const double* s1 = &b1loc.S[(size_t)s * nlines];
           for (long long l = 0; l < nlines; ++l) dst[l] += m * s1[l];
         }
       }
+    // packed A images of the mean phases: rows = lines, k = basis index p
+    auto put_rows = [&](double* img, int KBx, int kb_off, auto value /* (p, line) */) {
+      for (int rb = 0; rb < nrb; ++rb)
+        for (int kb = 0; kb < KBm; ++kb)
+          for (int r = 0; r < 16; ++r)
+            for (int slot = 0; slot < 4; ++slot)
+              for (int kk = 0; kk < 4; ++kk) {
+                const long long line = (long long)rb * 16 + r;
+                const int pidx = kb * 16 + MM<double>::jslot(kk, slot);
+                if (line < nlines && pidx < r0)
+                  img[((size_t)rb * KBx + kb_off + kb) * 256 + MM<double>::pack_pos(r, slot, kk)] = value(pidx, line);
+              }
+    };
+    double* va = &hVA[pl.sVA * o];
+    const size_t set = (size_t)nrb * KBm * 256;
+    put_rows(va, KBm, 0, [&](int pi, long long l) { return Vb[((size_t)0 * r0u + pi) * nlines + l]; });
+    put_rows(va + set, 2 * KBm, 0, [&](int pi, long long l) { return Vb[((size_t)1 * r0u + pi) * nlines + l]; });
+    put_rows(va + set, 2 * KBm, KBm, [&](int pi, long long l) { return Vb[((size_t)0 * r0u + pi) * nlines + l]; });
+    put_rows(va + 3 * set, KBm, 0, [&](int pi, long long l) {
+      return Vb[((size_t)2 * r0u + pi) * nlines + l] - xn1_all[(size_t)(line0 + l)] * Vb[((size_t)0 * r0u + pi) * nlines + l];
+    });
+    // B fragments of the mean phases: k = basis index p, columns = axis-0 positions
+    auto put_cols = [&](double* frag, int KBx, int kb_off, auto value /* (p, x) */) {
+      for (int csx = 0; csx < ncs0; ++csx)
+        for (int ks = 0; ks < KBm * 4; ++ks)
+          for (int l = 0; l < 64; ++l) {
+            const int pidx = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+            const long long x = (long long)csx * 16 + (l & 15);
+            if (pidx < r0 && x < cnt0) frag[((size_t)csx * KBx * 4 + kb_off * 4 + ks) * 64 + l] = value(pidx, x);
+          }
+    };
+    double* sb = &hSBf[pl.sSBf * o];
+    const size_t fset = (size_t)ncs0 * KBm * 256;
+    put_cols(sb, KBm, 0, [&](int pi, long long x) { return b0[o].S[(size_t)pi * cnt0 + x]; });
+    put_cols(sb + fset, 2 * KBm, 0, [&](int pi, long long x) { return b0[o].S[(size_t)pi * cnt0 + x]; });
+    put_cols(sb + fset, 2 * KBm, KBm, [&](int pi, long long x) { return -xn0[(size_t)x] * b0[o].S[(size_t)pi * cnt0 + x]; });
     pl.r0[o] = r0;
     pl.r1[o] = r1;
   }
@@ -278,14 +461,14 @@ int bilinear_setup(sbo_ctx* c) {
   if ((rc = ensure(c->bl_P0f, sizeof(double) * hP0f.size()))) return rc;
   if ((rc = ensure(c->bl_P1A, sizeof(double) * hP1A.size()))) return rc;
   if ((rc = ensure(c->bl_T4f, sizeof(double) * hT4f.size()))) return rc;
-  if ((rc = ensure(c->bl_S0, sizeof(double) * hS0.size()))) return rc;
-  if ((rc = ensure(c->bl_Vb, sizeof(double) * hVb.size()))) return rc;
+  if ((rc = ensure(c->bl_S0, sizeof(double) * hSBf.size()))) return rc;     // mean-phase B fragments
+  if ((rc = ensure(c->bl_Vb, sizeof(double) * hVA.size()))) return rc;      // mean-phase A images
   if ((rc = ensure(c->bl_BtA, sizeof(double) * pl.sBtA * q))) return rc;
   SBO_HIP(hipMemcpyAsync(c->bl_P0f.p, hP0f.data(), sizeof(double) * hP0f.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(c->bl_P1A.p, hP1A.data(), sizeof(double) * hP1A.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(c->bl_T4f.p, hT4f.data(), sizeof(double) * hT4f.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(c->bl_S0.p, hS0.data(), sizeof(double) * hS0.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(c->bl_Vb.p, hVb.data(), sizeof(double) * hVb.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->bl_S0.p, hSBf.data(), sizeof(double) * hSBf.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->bl_Vb.p, hVA.data(), sizeof(double) * hVA.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));      // the host vectors go out of scope
   pl.usable = true;
   return SBO_OK;
@@ -297,19 +480,23 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   const CandSpec& cs = c->cs;
   const int q = mc.q;
   const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0, line0 = cs.first / cnt0;
-  constexpr int S1 = 6, S2 = 8;
+  constexpr int S1 = 2;
   // stage 1: Bt = P1^T T4qq^T, written as the packed A operand of stage 2
   hipLaunchKernelGGL((k_bgemm<S1, 0>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256),
                      0, c->stream, (const double*)c->bl_P1A.p, pl.sP1A, (const double*)c->bl_T4f.p, pl.sT4f, pl.KB1, pl.nrb, pl.KB0,
                      (double*)c->bl_BtA.p, pl.sBtA, mc, cnt0, nlines);
-  // stage 2: quadratic form -> variance
-  hipLaunchKernelGGL((k_bgemm<S2, 1>), dim3((unsigned)((pl.ncs0 + S2 - 1) / S2), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256),
-                     0, c->stream, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, pl.KB0, pl.nrb, pl.ncs0,
-                     (double*)c->var.p, (size_t)cs.n_local, mc, cnt0, nlines);
-  // mean + Lipschitz keys
-  hipLaunchKernelGGL((k_bmean<3>), dim3((unsigned)((cnt0 + 255) / 256), (unsigned)pl.nrb, (unsigned)q), dim3(256), 0, c->stream, mc, cs,
-                     (const double*)c->bl_S0.p, (const double*)c->bl_Vb.p, pl.r0u, nlines, pl.nlines_pad, line0, (double*)c->mean.p,
-                     (unsigned long long*)c->Lmax.p);
+  // stage 2 (fused): variance, mean, Lipschitz keys
+  const size_t lds = sizeof(double) * 2 * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_bpost, dim3((unsigned)((pl.ncs0 + 7) / 8), (unsigned)((pl.nrb + 7) / 8), (unsigned)q), dim3(256), lds, c->stream,
+                     mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_Vb.p,
+                     pl.sVA, (const double*)c->bl_S0.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.nrb, pl.ncs0, nlines,
+                     (double*)c->mean.p, (double*)c->var.p, (unsigned long long*)c->Lmax.p);
+  (void)line0;
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
