@@ -143,7 +143,9 @@ typedef struct sbo_profile {
   double posterior_flops;  /* algorithmic flops of the K1 launch(es): q (n^2 + (2d+10) n) per candidate    */
   int64_t candidates;      /* candidates swept by this rank                                                */
   int32_t posterior_launches;
-  int32_t reserved;
+  int32_t posterior_kernel;      /* which K1 ran last: 1 generic, 2 generic chunked, 3 separable tables (K1g), 4 bilinear GEMMs (K1b) */
+  double posterior_executed_flops; /* matrix-core flops the last K1 launch(es) actually issued (K1b: far below the algorithmic count) */
+  double posterior_setup_ms;     /* host time of the last per-(model, grid) table build of K1b, 0 when none was needed        */
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */

@@ -66,7 +66,7 @@ class Profile(C.Structure):
         ("posterior_ms", C.c_double), ("classify_ms", C.c_double), ("expander_ms", C.c_double),
         ("argreduce_ms", C.c_double), ("comm_ms", C.c_double), ("total_ms", C.c_double),
         ("posterior_flops", C.c_double), ("candidates", C.c_int64), ("posterior_launches", C.c_int32),
-        ("reserved", C.c_int32),
+        ("posterior_kernel", C.c_int32), ("posterior_executed_flops", C.c_double), ("posterior_setup_ms", C.c_double),
     ]
 
 

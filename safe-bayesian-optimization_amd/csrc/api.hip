@@ -525,6 +525,9 @@ int sbo_bounds(sbo_ctx* c, double b, int index, int kind, void* out) {
 int sbo_profile_get(sbo_ctx* c, sbo_profile* out) {
   if (!c || !out) return fail(SBO_E_INVALID, "NULL argument");
   *out = c->prof;
+  out->posterior_kernel = c->last_k1;
+  out->posterior_executed_flops = c->prof.posterior_launches ? c->last_k1_flops : 0.0;
+  out->posterior_setup_ms = c->bl.setup_ms;
   return SBO_OK;
 }
 

@@ -14,6 +14,7 @@
 // reference's length-scales, whatever n is.
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <vector>
 #include "bilinear_host.hpp"
@@ -316,6 +317,8 @@ int bilinear_setup(sbo_ctx* c) {
   BilinearPlan& pl = c->bl;
   pl.valid = true;
   pl.usable = false;
+  pl.setup_ms = 0.0;
+  const auto t_begin = std::chrono::steady_clock::now();
   const ModelConst& mc = c->mc;
   const CandSpec& cs = c->cs;
   const int n = mc.n, q = mc.q, d = 2, NB = 1 + d;
@@ -471,6 +474,7 @@ int bilinear_setup(sbo_ctx* c) {
   SBO_HIP(hipMemcpyAsync(c->bl_Vb.p, hVA.data(), sizeof(double) * hVA.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));      // the host vectors go out of scope
   pl.usable = true;
+  pl.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return SBO_OK;
 }
 
@@ -497,6 +501,9 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                      pl.sVA, (const double*)c->bl_S0.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.nrb, pl.ncs0, nlines,
                      (double*)c->mean.p, (double*)c->var.p, (unsigned long long*)c->Lmax.p);
   (void)line0;
+  // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (16 x 16 x 4 steps, 2 flops per multiply-add)
+  const double tiles2 = (double)pl.nrb * pl.ncs0, tiles1 = (double)pl.nrb * pl.KB0;
+  c->last_k1_flops = (double)q * 2.0 * 1024.0 * (tiles1 * pl.KB1 * 4 + tiles2 * (pl.KS0 + 2 * pl.KSm + 2 * pl.KBm * 4));
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }

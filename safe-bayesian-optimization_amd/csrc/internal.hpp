@@ -85,6 +85,8 @@ struct sbo_ctx {
   // posterior workspace, SoA [q][n_local] of the model dtype
   sbo::DevBuf mean, var;
   bool posterior_valid = false;
+  int last_k1 = 0;               // kernel family of the last posterior launch (sbo_profile.posterior_kernel)
+  double last_k1_flops = 0.0;    // matrix-core flops it issued
   sbo::DevBuf Lmax;    // [kMaxQ] uint64 keys: max ||grad MEAN_i||_inf over the candidates
   // set workspace
   sbo::DevBuf maskS, maskU, maskM, maskG, maskO;   // uint8 [n_local] (G/O: [(q-1)][n_local])

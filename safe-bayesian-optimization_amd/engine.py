@@ -230,4 +230,4 @@ class SweepEngine:
     def profile(self) -> dict:
         p = L.Profile()
         L.check(self._lib.sbo_profile_get(self._ctx, C.byref(p)))
-        return {name: getattr(p, name) for name, _ in L.Profile._fields_ if name != "reserved"}
+        return {name: getattr(p, name) for name, _ in L.Profile._fields_}

@@ -83,6 +83,74 @@ def test_posterior_chunked_generic_kernel(engine, cfg_name, n, dtype):
         engine.set_option("posterior_path", 0)
 
 
+# K1b: on fp64 2-D grids the posterior runs as two GEMMs in a reduced basis (bilinear.hip) when the axis bases qualify
+@pytest.mark.parametrize("cfg_name,n,count", [("B", 128, [160, 96]), ("C", 64, [96, 130]), ("H", 300, [64, 72]), ("A", 20, [70, 65])])
+def test_bilinear_posterior_matches_oracle_and_table_kernel(engine, cfg_name, n, count):
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    try:
+        engine.set_option("bilinear", 0)
+        engine.posterior_run()
+        assert engine.profile()["posterior_kernel"] == 3
+        m_tab, v_tab = engine.posterior()
+        engine.set_option("bilinear", 1)
+        engine.posterior_run()
+        prof = engine.profile()
+        assert prof["posterior_kernel"] == 4 and 0 < prof["posterior_executed_flops"] < prof["posterior_flops"] * 4
+        mean, var = _check_posterior(engine, cfg["ds"], pts, TOL64)
+    finally:
+        engine.set_option("bilinear", 1)
+    ystd = np.maximum(1.0, cfg["ds"]["Y_std"])
+    assert np.max(np.abs(mean - m_tab) / ystd) < 1e-11 and np.max(np.abs(var - v_tab) / ystd ** 2) < 1e-11
+    # the Lipschitz keys (max |grad mean|) come out of different kernels: same values to rounding
+    r1 = engine.sweep_safeopt(cfg["b"], posterior_ready=True) if cfg_name != "H" else None
+    if r1 is not None:
+        engine.set_option("bilinear", 0)
+        try:
+            r0 = engine.sweep_safeopt(cfg["b"])
+        finally:
+            engine.set_option("bilinear", 1)
+        assert np.allclose(r1["L"], r0["L"], rtol=1e-10)
+        assert r1["minimizer_index"] == r0["minimizer_index"] and r1["count_S"] == r0["count_S"]
+
+
+def test_bilinear_declines_short_length_scales_and_fp32(engine):
+    """Bases that need more than 32 directions per axis, and fp32 models, stay on the separable-table kernel."""
+    cfg = synthetic.make_config("B", n=128)
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [96, 80]
+    hyp = synthetic.default_hypopt(2, 2)
+    hyp[:2] -= 1.0
+    ds = synthetic.make_dataset(cfg["X"], cfg["Y"], hyp)
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_model(ds)
+    engine.set_grid(lo, hi, count)
+    _check_posterior(engine, ds, pts, TOL64)
+    assert engine.profile()["posterior_kernel"] == 3
+    engine.set_model(cfg["ds"], dtype="f32", use_invK=False)
+    engine.set_grid(lo, hi, count)
+    engine.posterior_run()
+    assert engine.profile()["posterior_kernel"] == 3
+
+
+def test_bilinear_shards_reproduce_the_whole_grid_bitwise(engine):
+    """Line ranges of a grid (what a rank of a sharded sweep holds) use the bases of the whole axis: identical values."""
+    cfg = synthetic.make_config("B", n=128)
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [80, 100]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    m, v = engine.posterior()
+    assert engine.profile()["posterior_kernel"] == 4
+    for first_line, lines in [(0, 16), (16, 48), (37, 63), (84, 16)]:
+        engine.set_grid(lo, hi, count, first=first_line * 80, n_local=lines * 80)
+        ms, vs = engine.posterior()
+        assert engine.profile()["posterior_kernel"] == 4
+        sl = slice(first_line * 80, (first_line + lines) * 80)
+        assert np.array_equal(ms, m[sl]) and np.array_equal(vs, v[sl])
+
+
 def test_posterior_fp32(engine):
     cfg = synthetic.make_config("B", n=128)
     lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
