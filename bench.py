@@ -11,6 +11,12 @@ q = 2 outputs, fp64.  For N > 1 the grid grows along its slowest axis (2048 x 20
 2048^2 candidates ("weak" scaling); the ranks exchange u*/L (one RCCL max all-reduce), the fully-unsafe
 mask (one all-gather) and the arg-max candidates (one sum all-reduce).
 
+The posterior (K1) of that workload runs as two dense fp64 GEMMs in a reduced basis of the separable RBF kernel (K1b,
+bilinear.hip) -- inner dimension ~280 whatever n is -- instead of the O(n^2)-per-candidate triangular contraction the
+algorithmic flop count of SURVEY.md 8(d) assumes; ``roofline.achieved`` keeps the contract's definition (algorithmic
+flops / K1 time, so it exceeds the peak), ``roofline.executed`` is what the matrix cores issued, and ``table_kernel``
+times the same sweep with the O(n^2) kernel (K1g) in the same run.
+
 torch is used only as the launcher's rendezvous (gloo group: unique-id broadcast, barriers, max over
 ranks); device memory, streams and the collectives on the data path belong to libsafebo.so.
 """
@@ -45,6 +51,9 @@ def parse_args():
     ap.add_argument("--points", type=int, default=10_000_000, help="candidates per rank for the scattered config E")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: the grid's slowest axis grows with the ranks (default); strong: fixed grid, sharded")
+    ap.add_argument("--posterior", choices=["auto", "table"], default="auto",
+                    help="auto: fp64 2-D grids use the bilinear GEMM posterior (K1b) when its bases qualify; "
+                         "table: force the separable-table kernel (K1g), the O(n^2)-per-candidate contraction")
     return ap.parse_args()
 
 
@@ -134,9 +143,12 @@ def main():
     def step():
         return eng.sweep_safeopt(cfg["b"])
 
+    if args.posterior == "table":
+        eng.set_option("bilinear", 0)
     for _ in range(args.warmup):
         step()
-    k1_ms, k1_flops, tot_ms = [], [], []
+    setup_ms = eng.profile()["posterior_setup_ms"]      # K1b: host build of the per-(model, grid) tables, paid in the warm-up
+    k1_ms, k1_flops, k1_exec, tot_ms = [], [], [], []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -144,7 +156,9 @@ def main():
         p = eng.profile()
         k1_ms.append(p["posterior_ms"])
         k1_flops.append(p["posterior_flops"])
+        k1_exec.append(p["posterior_executed_flops"])
         tot_ms.append(p["total_ms"])
+    k1_kind = p["posterior_kernel"]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -159,9 +173,12 @@ def main():
         k1 = float(np.mean(k1_ms))
         achieved = float(np.mean(k1_flops)) / (k1 * 1e-3) / 1e12
         peak = FP64_MATRIX_PEAK_TFLOPS if cfg["dtype"] == "f64" else FP32_MATRIX_PEAK_TFLOPS
+        kname = {1: "k_posterior", 2: "k_posterior_chunked", 3: "k_posterior_grid", 4: "k_bpost (+ k_bgemm stage 1)"}.get(k1_kind, "?")
+        executed = float(np.mean(k1_exec)) / (k1 * 1e-3) / 1e12
         traffic = None
         if os.path.exists(PMC_TRAFFIC_FILE):       # collected by tools/gpu_bench_profile.sh in separate --pmc passes
-            rec = json.load(open(PMC_TRAFFIC_FILE)).get(f"{args.config}:n={cfg['ds']['X_norm'].shape[0]}")
+            key = f"{args.config}:n={cfg['ds']['X_norm'].shape[0]}" + (":K1b" if k1_kind == 4 else "")
+            rec = json.load(open(PMC_TRAFFIC_FILE)).get(key)
             traffic = rec["hbm_bytes_per_launch"] if rec else None
         out = {
             "metric": "candidate-points/sec, SafeOpt posterior+safe-set sweep",
@@ -175,13 +192,35 @@ def main():
                        "per_gpu_candidates": n_total // world, "sweep": "safeopt", "collectives": transport,
                        "result": {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
                                   "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}},
+            # achieved = ALGORITHMIC flops (q (n^2 + (2d+10) n) per candidate) / K1 time, as the contract
+            # defines it.  With K1b that exceeds the peak: the kernels issue far fewer flops than the O(n^2) count
+            # (two GEMMs of inner dimension ~r(r+1)/2, independent of n); "executed" is what the matrix cores really did.
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel": "k_posterior_chunked" if scattered else "k_posterior_grid", "kernel_ms": k1,
+                         "traffic": traffic, "kernel": kname, "kernel_ms": k1,
+                         "executed": {"achieved": executed, "frac": executed / peak,
+                                      "flops_per_candidate": float(np.mean(k1_exec)) / (n_total // world)},
                          "algorithmic_flops_per_candidate": float(np.mean(k1_flops)) / (n_total // world),
                          "peak_source": "AMD MI355X datasheet FP64 matrix (no f64 row in MI355X_MICROARCH.md)" if cfg["dtype"] == "f64" else "MI355X_MICROARCH.md f32 MFMA",
                          "peak_measured_mfma_f64": FP64_MFMA_MEASURED_TFLOPS if cfg["dtype"] == "f64" else None,
                          "device_ms_per_step": float(np.mean(tot_ms))},
         }
+        if k1_kind == 4:
+            out["roofline"]["table_build_ms"] = setup_ms
+        if world == 1 and k1_kind == 4:
+            # the same sweep with the separable-table kernel (the O(n^2)-per-candidate contraction on MFMA), same run
+            eng.set_option("bilinear", 0)
+            step()
+            t_ms, t_k1 = [], []
+            for _ in range(3):
+                step()
+                pt = eng.profile()
+                t_ms.append(pt["total_ms"])
+                t_k1.append(pt["posterior_ms"])
+            eng.set_option("bilinear", 1)
+            tk1 = float(np.mean(t_k1))
+            out["table_kernel"] = {"kernel": "k_posterior_grid", "device_ms_per_step": float(np.mean(t_ms)), "kernel_ms": tk1,
+                                   "value": n_total / (float(np.mean(t_ms)) * 1e-3), "unit": "candidates/s (device time)",
+                                   "achieved": float(np.mean(k1_flops)) / (tk1 * 1e-3) / 1e12, "frac": float(np.mean(k1_flops)) / (tk1 * 1e-3) / 1e12 / peak}
         if world == 1 and args.cpu_sample > 0 and not scattered:
             out["cpu_baseline"] = cpu_baseline(cfg, count, args.cpu_sample)
         print(json.dumps(out))

@@ -156,139 +156,142 @@ __global__ __launch_bounds__(256) void k_bmean(const ModelConst mc, const CandSp
 //   phase 1  s1   = V[0]  . S0          (KSm)          ->  mean = (mp + s1) Y_std + Y_mean
 //   phase 2  g0   = [V[1]; V[0]] . [S0; -xn0 S0]  (2 KSm)   gradient sum of axis 0 (the candidate's own xn0 sits in B)
 //   phase 3  g1   = V1x   . S0          (KSm)              gradient sum of axis 1 (xn1 of the line is folded into V1x)
-struct PostPhases {
-  const double* A[4];    // packed block images [nrb][KBp][256] of this output
-  const double* B[4];    // fragments [ncs][KBp * 4][64] of this output
-  int KS[4];             // k-steps actually run
-  int KB[4];             // k-blocks the images / fragments are laid out with
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+struct PostCtx {
+  double* lds;
+  int tid, lane, wave, rb0, cs0, nrb, ncs;
+  int st_rb, st_cs, st_off, a_lo, b_st, a_rd;
+  unsigned int ucnt0;
+  long long nlines;
 };
 
-__global__ __launch_bounds__(256) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
-                                               const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
-                                               size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
-                                               int KSm, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
-                                               double* __restrict__ var_out, unsigned long long* __restrict__ Lmax) {
-  extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
-  const int o = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rb0 = blockIdx.y * 8, cs0 = blockIdx.x * 8;
-  const long long cnt0 = cs.count[0];
-  PostPhases ph;
-  // per-output operand bases; VA holds [V0 | V1;V0 | V1x] as three image sets, SBf holds [S0 | S0;-xn0 S0] as two fragment sets
-  const double* VAo = VA + (size_t)o * sVA;
-  const double* SBo = SBf + (size_t)o * sSBf;
-  ph.A[0] = BtA + (size_t)o * sBtA;                 ph.B[0] = P0f + (size_t)o * sP0f;          ph.KS[0] = KS0;     ph.KB[0] = KB0;
-  ph.A[1] = VAo;                                    ph.B[1] = SBo;                             ph.KS[1] = KSm;     ph.KB[1] = KBm;
-  ph.A[2] = VAo + (size_t)nrb * KBm * 256;          ph.B[2] = SBo + (size_t)ncs * KBm * 256;   ph.KS[2] = 2 * KBm * 4; ph.KB[2] = 2 * KBm;
-  ph.A[3] = VAo + (size_t)nrb * KBm * 256 * 3;      ph.B[3] = SBo;                             ph.KS[3] = KSm;     ph.KB[3] = KBm;
-  // staging role of this thread: 64 bytes of one A image and 64 bytes of one B strip per k-block
-  const int st_i = tid >> 5, st_off = (tid & 31) * 8;      // image / strip index 0..7, offset in doubles
-  const int st_rb = rb0 + st_i < nrb ? rb0 + st_i : nrb - 1;
-  const int st_cs = cs0 + st_i < ncs ? cs0 + st_i : ncs - 1;
-  const double sf2 = mc.sf2[o], ystd = mc.Y_std[o];
-  double gmax = 0.0;
-  const int col_in = lane & 15, row_in = lane >> 4;
+// One GEMM phase of k_bpost on the workgroup's 128 x 128 tile: A images / B fragments of `KB` k-blocks per row block /
+// strip, `KS` k-steps run.  PH selects the epilogue: 0 variance, 1 mean, 2 / 3 gradient component of axis 0 / 1.
+template <int PH>
+__device__ __forceinline__ void post_phase(const PostCtx& cx, const double* __restrict__ A, const double* __restrict__ B, int KB,
+                                           int KS, double* __restrict__ outp, double c0, double c1, double c2, double& gmax) {
+  const double* Ap = A + (size_t)cx.st_rb * KB * 256 + cx.st_off;
+  const double* Bp = B + (size_t)cx.st_cs * KB * 256 + cx.st_off;
+  const int nkb = (KS + 3) >> 2;
+  double* const lds = cx.lds;
+  auto stage = [&](double* buf, const d4_t& r0, const d4_t& r1, const d4_t& q0, const d4_t& q1) {
+    *reinterpret_cast<d4_t*>(buf + cx.a_lo) = d4_t{r0[0], r0[1], r1[0], r1[1]};
+    *reinterpret_cast<d4_t*>(buf + cx.a_lo + 32) = d4_t{r0[2], r0[3], r1[2], r1[3]};
+    *reinterpret_cast<d4_t*>(buf + cx.b_st) = q0;
+    *reinterpret_cast<d4_t*>(buf + cx.b_st + 4) = q1;
+  };
+  d4_t acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) acc[i][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
+  d4_t ra0 = *reinterpret_cast<const d4_t*>(Ap), ra1 = *reinterpret_cast<const d4_t*>(Ap + 4);
+  d4_t rb0v = *reinterpret_cast<const d4_t*>(Bp), rb1v = *reinterpret_cast<const d4_t*>(Bp + 4);
+  __syncthreads();                             // the previous phase has finished reading the buffers
+  stage(lds, ra0, ra1, rb0v, rb1v);
+  __syncthreads();
 #pragma unroll 1
-  for (int phs = 0; phs < 4; ++phs) {
-    const double* Ap = ph.A[phs] + (size_t)st_rb * ph.KB[phs] * 256 + st_off;
-    const double* Bp = ph.B[phs] + (size_t)st_cs * ph.KB[phs] * 256 + st_off;
-    const int KS = ph.KS[phs];
-    const int nkb = (KS + 3) >> 2;
-    d4_t acc[2][8];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2) acc[i][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
-    d4_t ra[2], rbv[2];
-    ra[0] = *reinterpret_cast<const d4_t*>(Ap);
-    ra[1] = *reinterpret_cast<const d4_t*>(Ap + 4);
-    rbv[0] = *reinterpret_cast<const d4_t*>(Bp);
-    rbv[1] = *reinterpret_cast<const d4_t*>(Bp + 4);
-    __syncthreads();                             // the previous phase has finished reading the buffers
-    {
-      double* dA = lds + st_i * 256 + st_off;
-      double* dB = lds + 2048 + st_i * 256 + st_off;
-      *reinterpret_cast<d4_t*>(dA) = ra[0];
-      *reinterpret_cast<d4_t*>(dA + 4) = ra[1];
-      *reinterpret_cast<d4_t*>(dB) = rbv[0];
-      *reinterpret_cast<d4_t*>(dB + 4) = rbv[1];
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int cur = kb & 1;
+    if (kb + 1 < nkb) {
+      ra0 = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256);
+      ra1 = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256 + 4);
+      rb0v = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256);
+      rb1v = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256 + 4);
     }
+    const double* LA = lds + cur * 4096 + (2 * cx.wave) * 256 + cx.a_rd;
+    const double* LB = lds + cur * 4096 + 2048 + cx.lane;
+    const int kkn = KS - kb * 4 < 4 ? KS - kb * 4 : 4;
+#pragma unroll 1
+    for (int kk = 0; kk < kkn; ++kk) {
+      const d2_t l0 = *reinterpret_cast<const d2_t*>(LA + kk * 64), h0 = *reinterpret_cast<const d2_t*>(LA + kk * 64 + 32);
+      const d2_t l1 = *reinterpret_cast<const d2_t*>(LA + 256 + kk * 64), h1 = *reinterpret_cast<const d2_t*>(LA + 256 + kk * 64 + 32);
+      const d4_t a0 = d4_t{l0[0], l0[1], h0[0], h0[1]}, a1 = d4_t{l1[0], l1[1], h1[0], h1[1]};
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        const double b = LB[(s2 * 4 + kk) * 64];
+        acc[0][s2] = MM<double>::mfma(a0, b, acc[0][s2]);
+        acc[1][s2] = MM<double>::mfma(a1, b, acc[1][s2]);
+      }
+    }
+    if (kb + 1 < nkb) stage(lds + (cur ^ 1) * 4096, ra0, ra1, rb0v, rb1v);
     __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
-      const int cur = kb & 1;
-      if (kb + 1 < nkb) {
-        ra[0] = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256);
-        ra[1] = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256 + 4);
-        rbv[0] = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256);
-        rbv[1] = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256 + 4);
-      }
-      const double* LA = lds + cur * 4096 + (2 * wave) * 256;
-      const double* LB = lds + cur * 4096 + 2048;
-      const int kkn = KS - kb * 4 < 4 ? KS - kb * 4 : 4;
-#pragma unroll 1
-      for (int kk = 0; kk < kkn; ++kk) {
-        {
-          const d4_t a0 = MM<double>::load_a(LA, lane, kk);
-          const d4_t a1 = MM<double>::load_a(LA + 256, lane, kk);
+  }
+  // epilogue: accumulator element t of lane l is row 4 t + (l >> 4), column l & 15 of its 16 x 16 tile
+  const unsigned int col_in = cx.lane & 15, row_in = cx.lane >> 4;
 #pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) {
-            const double b = LB[(s2 * 4 + kk) * 64 + lane];
-            acc[0][s2] = MM<double>::mfma(a0, b, acc[0][s2]);
-            acc[1][s2] = MM<double>::mfma(a1, b, acc[1][s2]);
-          }
-        }
-      }
-      if (kb + 1 < nkb) {
-        double* dA = lds + (cur ^ 1) * 4096 + st_i * 256 + st_off;
-        double* dB = lds + (cur ^ 1) * 4096 + 2048 + st_i * 256 + st_off;
-        *reinterpret_cast<d4_t*>(dA) = ra[0];
-        *reinterpret_cast<d4_t*>(dA + 4) = ra[1];
-        *reinterpret_cast<d4_t*>(dB) = rbv[0];
-        *reinterpret_cast<d4_t*>(dB + 4) = rbv[1];
-      }
-      __syncthreads();
-    }
-    // epilogue of the phase: accumulator element t of lane l is row 4 t + (l >> 4), column l & 15 of its 16 x 16 tile
-    double* const outp = (phs == 0 ? var_out : mean_out) + (size_t)o * cs.n_local;
-    const double y2 = ystd * ystd, mpo = mc.mp[o], ymo = mc.Y_mean[o];
-    const double gscale = phs >= 2 ? ystd * mc.inv_ell[o][phs - 2] * mc.X_rstd[phs - 2] : 0.0;
-    const unsigned int ucnt0 = (unsigned int)cnt0;
+  for (int i = 0; i < 2; ++i) {
+    const int rb = cx.rb0 + 2 * cx.wave + i;
+    if (rb >= cx.nrb) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rb = rb0 + 2 * wave + i;
-      if (rb >= nrb) continue;
+    for (int t = 0; t < 4; ++t) {
+      const unsigned int line = (unsigned int)rb * 16u + 4u * t + row_in;
+      if ((long long)line >= cx.nlines) continue;
+      double* const rowp = outp + (size_t)line * cx.ucnt0;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const unsigned int line = (unsigned int)rb * 16u + 4u * t + row_in;
-        if ((long long)line >= nlines) continue;
-        const unsigned int rowoff = line * ucnt0;
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-          const unsigned int x0 = (unsigned int)(cs0 + s2) * 16u + col_in;
-          if (cs0 + s2 >= ncs || x0 >= ucnt0) continue;
-          const double v = acc[i][s2][t];
-          if (phs == 0) {
-            double var = sf2 - v;                                             // models/GP_Safe.py:343, clipped at 0
-            var = var > 0.0 ? var : 0.0;
-            outp[rowoff + x0] = var * y2;                                     // :347
-          } else if (phs == 1) {
-            outp[rowoff + x0] = (mpo + v) * ystd + ymo;                       // :342, :346
-          } else {
-            // component of the gradient of the un-normalised mean (analytic jax.grad(self.mean), SafeOpt.py:68-71)
-            double ga = gscale * v;
-            ga = ga < 0 ? -ga : ga;
-            gmax = ga > gmax ? ga : gmax;
-          }
+      for (int s2 = 0; s2 < 8; ++s2) {
+        const unsigned int x0 = (unsigned int)(cx.cs0 + s2) * 16u + col_in;
+        if (cx.cs0 + s2 >= cx.ncs || x0 >= cx.ucnt0) continue;
+        const double v = acc[i][s2][t];
+        if (PH == 0) {
+          double var = c0 - v;                                              // models/GP_Safe.py:343, clipped at 0
+          var = var > 0.0 ? var : 0.0;
+          rowp[x0] = var * c1;                                              // :347
+        } else if (PH == 1) {
+          rowp[x0] = (c0 + v) * c1 + c2;                                    // :342, :346
+        } else {
+          // component of the gradient of the un-normalised mean (analytic jax.grad(self.mean), SafeOpt.py:68-71)
+          double ga = c0 * v;
+          ga = ga < 0 ? -ga : ga;
+          gmax = ga > gmax ? ga : gmax;
         }
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
+                                                  const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
+                                                  size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
+                                                  int KSm, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
+                                                  double* __restrict__ var_out, unsigned long long* __restrict__ Lmax) {
+  extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
+  const int o = blockIdx.z;
+  PostCtx cx;
+  cx.lds = lds;
+  cx.tid = threadIdx.x; cx.lane = cx.tid & 63; cx.wave = cx.tid >> 6;
+  cx.rb0 = blockIdx.y * 8; cx.cs0 = blockIdx.x * 8; cx.nrb = nrb; cx.ncs = ncs;
+  cx.ucnt0 = (unsigned int)cs.count[0];
+  cx.nlines = nlines;
+  // staging role of this thread: 64 bytes of one A image and 64 bytes of one B strip per k-block.
+  // LDS image of an A block: per k-step the 16 lane-chunks are split into their first and second 16 bytes
+  // ([16 x 16 B][16 x 16 B]) so that both ds_read_b128 of a fragment load touch 256 contiguous bytes (no bank conflicts)
+  const int st_i = cx.tid >> 5, st_j = cx.tid & 31;
+  cx.st_off = st_j * 8;
+  cx.st_rb = cx.rb0 + st_i < nrb ? cx.rb0 + st_i : nrb - 1;
+  cx.st_cs = cx.cs0 + st_i < ncs ? cx.cs0 + st_i : ncs - 1;
+  cx.a_lo = st_i * 256 + (st_j >> 3) * 64 + (st_j & 7) * 4;
+  cx.b_st = 2048 + st_i * 256 + cx.st_off;
+  cx.a_rd = (((cx.lane >> 4) << 2) + (cx.lane & 3)) * 2;
+  // per-output operands; VA holds [V0 | V1;V0 | V1x] as three image sets, SBf holds [S0 | S0;-xn0 S0] as two fragment sets
+  const double* VAo = VA + (size_t)o * sVA;
+  const double* SBo = SBf + (size_t)o * sSBf;
+  const double sf2 = mc.sf2[o], ystd = mc.Y_std[o];
+  double* const vo = var_out + (size_t)o * cs.n_local;
+  double* const mo = mean_out + (size_t)o * cs.n_local;
+  double gmax = 0.0;
+  post_phase<0>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, KS0, vo, sf2, ystd * ystd, 0.0, gmax);
+  post_phase<1>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax);
+  post_phase<2>(cx, VAo + (size_t)nrb * KBm * 256, SBo + (size_t)ncs * KBm * 256, 2 * KBm, 2 * KBm * 4, nullptr,
+                ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax);
+  post_phase<3>(cx, VAo + (size_t)nrb * KBm * 256 * 3, SBo, KBm, KSm, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0, gmax);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const double other = __shfl_xor(gmax, off);
     gmax = other > gmax ? other : gmax;
   }
-  if (lane == 0) atomicMax(&Lmax[o], (unsigned long long)__double_as_longlong(gmax));
+  if (cx.lane == 0) atomicMax(&Lmax[o], (unsigned long long)__double_as_longlong(gmax));
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------
