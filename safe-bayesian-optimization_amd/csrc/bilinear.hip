@@ -12,6 +12,8 @@
 // 16x16x4 step): A operands are stored as packed 16x16 block images, B operands in fragment order, so every operand
 // load is one contiguous 512-byte (B) or 2-KiB (A) wave access.  Inner dimensions: K0 = r0 (r0 + 1) / 2 ~ 280 for the
 // reference's length-scales, whatever n is.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <chrono>
@@ -322,6 +324,11 @@ int bilinear_setup(sbo_ctx* c) {
   pl.usable = false;
   pl.setup_ms = 0.0;
   const auto t_begin = std::chrono::steady_clock::now();
+  const bool timing = getenv("SBO_BL_TIMING") != nullptr;
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[K1b setup] %-12s %8.2f ms\n", what,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   const ModelConst& mc = c->mc;
   const CandSpec& cs = c->cs;
   const int n = mc.n, q = mc.q, d = 2, NB = 1 + d;
@@ -341,6 +348,7 @@ int bilinear_setup(sbo_ctx* c) {
       if (!bl::axis_basis(n, col.data(), mc.vinv[o][a], xs.data(), (int)xs.size(), b)) return SBO_OK;
     }
   }
+  lap("bases");
   int r0u = 0, K0 = 0, K1 = 0;
   for (int o = 0; o < q; ++o) {
     r0u = std::max(r0u, b0[o].r);
@@ -375,6 +383,7 @@ int bilinear_setup(sbo_ctx* c) {
     }
     const double* bp[3] = {&beta[0], &beta[(size_t)n], &beta[(size_t)2 * n]};
     bl::build_forms(n, &c->h_F[(size_t)o * n * n], b0[o], b1[o], sf2 * sf2, NB, bp, sf2, T4qq, Mb);
+    lap("forms");
     bl::pair_table(b0[o], (int)cnt0, P0);                       // [k0n x cnt0]
     // axis-1 tables for the local lines only
     bl::AxisBasis b1loc;
@@ -462,6 +471,7 @@ int bilinear_setup(sbo_ctx* c) {
     put_cols(sb + fset, 2 * KBm, KBm, [&](int pi, long long x) { return -xn0[(size_t)x] * b0[o].S[(size_t)pi * cnt0 + x]; });
     pl.r0[o] = r0;
     pl.r1[o] = r1;
+    lap("tables");
   }
   int rc;
   if ((rc = ensure(c->bl_P0f, sizeof(double) * hP0f.size()))) return rc;
@@ -476,6 +486,7 @@ int bilinear_setup(sbo_ctx* c) {
   SBO_HIP(hipMemcpyAsync(c->bl_S0.p, hSBf.data(), sizeof(double) * hSBf.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(c->bl_Vb.p, hVA.data(), sizeof(double) * hVA.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));      // the host vectors go out of scope
+  lap("upload");
   pl.usable = true;
   pl.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return SBO_OK;

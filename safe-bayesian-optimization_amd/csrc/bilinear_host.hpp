@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <thread>
 #include <vector>
 
 namespace sbo {
@@ -197,6 +198,21 @@ inline bool axis_basis(int n, const double* As_col, double vinv, const double* x
   return true;
 }
 
+// run body(first, last) over [0, total) on a few host threads (the T4 build is ~1.4e8 multiply-adds at n = 512)
+template <typename F>
+inline void parallel_ranges(int total, F body) {
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nt = (int)std::max(1u, std::min(hw ? hw : 1u, 8u));
+  if (nt == 1 || total < 2) { body(0, total); return; }
+  std::vector<std::thread> th;
+  const int chunk = (total + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const int a = t * chunk, b = std::min(total, a + chunk);
+    if (a < b) th.emplace_back([=]() { body(a, b); });
+  }
+  for (auto& x : th) x.join();
+}
+
 // symmetric pair index: pairs (p <= p') enumerated row by row; K = r (r + 1) / 2
 inline int pair_count(int r) { return r * (r + 1) / 2; }
 
@@ -213,27 +229,33 @@ inline void build_forms(int n, const double* M, const AxisBasis& b0, const AxisB
       double* z = &Z[(size_t)(p * r1 + s) * n];
       for (int j = 0; j < n; ++j) z[j] = b0.U[(size_t)p * n + j] * b1.U[(size_t)s * n + j];
     }
-  for (int c = 0; c < R; ++c) {
-    const double* z = &Z[(size_t)c * n];
-    double* cc = &C[(size_t)c * n];
-    for (int i = 0; i < n; ++i) {
-      const double* mi = M + (size_t)i * n;
-      double s = 0;
-      for (int j = 0; j <= i; ++j) s += mi[j] * z[j];
-      cc[i] = s;
+  parallel_ranges(R, [&](int c_lo, int c_hi) {
+    for (int c = c_lo; c < c_hi; ++c) {
+      const double* z = &Z[(size_t)c * n];
+      double* cc = &C[(size_t)c * n];
+      for (int i = 0; i < n; ++i) {
+        const double* mi = M + (size_t)i * n;
+        double s = 0;
+        for (int j = 0; j <= i; ++j) s += mi[j] * z[j];
+        cc[i] = s;
+      }
     }
-  }
+  });
   // G = C^T C (upper half), G[(p,s),(p',s')]
   std::vector<double> G((size_t)R * R, 0.0);
-  for (int c = 0; c < R; ++c)
-    for (int c2 = c; c2 < R; ++c2) {
-      const double* x = &C[(size_t)c * n];
-      const double* y = &C[(size_t)c2 * n];
-      double s = 0;
-      for (int i = 0; i < n; ++i) s += x[i] * y[i];
-      G[(size_t)c * R + c2] = s;
-      G[(size_t)c2 * R + c] = s;
-    }
+  // (rows interleaved over the threads: row c has R - c entries)
+  parallel_ranges(8, [&](int t_lo, int t_hi) {
+    for (int t = t_lo; t < t_hi; ++t)
+      for (int c = t; c < R; c += 8)
+        for (int c2 = c; c2 < R; ++c2) {
+          const double* x = &C[(size_t)c * n];
+          const double* y = &C[(size_t)c2 * n];
+          double s = 0;
+          for (int i = 0; i < n; ++i) s += x[i] * y[i];
+          G[(size_t)c * R + c2] = s;
+          G[(size_t)c2 * R + c] = s;
+        }
+  });
   const int K0 = pair_count(r0), K1 = pair_count(r1);
   T4qq.assign((size_t)K0 * K1, 0.0);
   int k0 = 0;

@@ -17,7 +17,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "safe-bayesian-optimization_amd", "cs
 @pytest.fixture(scope="module")
 def shim(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("bl") / "libblt.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", os.path.join(CSRC, "bilinear_host_test.cpp"), "-o", so])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", os.path.join(CSRC, "bilinear_host_test.cpp"), "-o", so])
     return C.CDLL(so)
 
 
