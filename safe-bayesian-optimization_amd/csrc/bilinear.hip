@@ -4,9 +4,9 @@
 // linspace x linspace grid (test/test_SafeOpt.py:324-345).  The math and the host-side construction of the bases are
 // in bilinear_host.hpp; this file holds the plan (device tables) and the kernels:
 //
-//   stage 1  Bt[x1, k0]  = sum_k1 P1[k1, x1] T4qq[k0, k1]                 (rows of the grid  x  pair index of axis 0)
-//   stage 2  quad[x1,x0] = sum_k0 Bt[x1, k0] P0[k0, x0]   ->  var = max(0, sf2 - quad) Y_std^2
-//   mean     m[x1, x0]   = sum_p  V0[p, x1] S0[p, x0]     (and the d gradient sums, same shape)
+//   stage 1 (k_bgemm)  Bt[x1, k0]  = sum_k1 P1[k1, x1] T4qq[k0, k1]        (lines of the grid  x  pair index of axis 0)
+//   stage 2 (k_bpost)  quad[x1,x0] = sum_k0 Bt[x1, k0] P0[k0, x0]   ->  var = max(0, sf2 - quad) Y_std^2
+//                      m[x1, x0]   = sum_p  V0[p, x1] S0[p, x0]     (and the two gradient sums, same shape)
 //
 // Both GEMMs run on the matrix cores with the fragment conventions of device_common.hpp (four v_mfma_f64_4x4x4 per
 // 16x16x4 step): A operands are stored as packed 16x16 block images, B operands in fragment order, so every operand
@@ -24,14 +24,13 @@
 
 namespace sbo {
 
-// OUT[rows x cols] = A[rows x K] B[K x cols];  A: [nrb][KB][256] packed block images, Bf: [ncs][KB * 4][64] fragments.
-// A wave owns 16 rows x (16 S) columns; the four waves of a workgroup take four consecutive row blocks.
-//   MODE 0: OUT is written as packed block images [nrb][ncs][256] (it is the A operand of the next GEMM)
-//   MODE 1: posterior-variance epilogue, OUT element (row, col) is candidate row * cnt0 + col
-template <int S, int MODE>
+// Stage 1.  OUT[rows x cols] = A[rows x K] B[K x cols];  A: [nrb][KB][256] packed block images, Bf: [ncs][KB * 4][64]
+// fragments.  A wave owns 16 rows x (16 S) columns; the four waves of a workgroup take four consecutive row blocks.
+// OUT is written as packed block images [nrb][ncs][256]: it is the A operand of stage 2.
+template <int S>
 __global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, size_t a_stride_o, const double* __restrict__ Bf,
                                                size_t b_stride_o, int KB, int nrb, int ncs, double* __restrict__ out,
-                                               size_t out_stride_o, const ModelConst mc, long long cnt0, long long nlines) {
+                                               size_t out_stride_o) {
   const int o = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rb = blockIdx.y * 4 + wave;
@@ -62,93 +61,14 @@ __global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, siz
   }
   // accumulator element t of lane l: row 4 t + (l >> 4), column l & 15 of the 16 x 16 tile
   const int col_in = lane & 15, row_in = lane >> 4;
-  if (MODE == 0) {
-    double* Oo = out + (size_t)o * out_stride_o + (size_t)rb * ncs * 256;
+  double* Oo = out + (size_t)o * out_stride_o + (size_t)rb * ncs * 256;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      if (cs0 + s >= ncs) continue;
-      double* blk = Oo + (size_t)(cs0 + s) * 256;
+  for (int s = 0; s < S; ++s) {
+    if (cs0 + s >= ncs) continue;
+    double* blk = Oo + (size_t)(cs0 + s) * 256;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) blk[MM<double>::pack_pos(4 * t + row_in, col_in & 3, col_in >> 2)] = acc[s][t];
-    }
-  } else {
-    const double sf2 = mc.sf2[o], ystd = mc.Y_std[o];
-    const double y2 = ystd * ystd;
-    double* Vo = out + (size_t)o * out_stride_o;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const long long x0 = (long long)(cs0 + s) * 16 + col_in;
-      if (cs0 + s >= ncs || x0 >= cnt0) continue;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const long long line = (long long)rb * 16 + 4 * t + row_in;
-        if (line >= nlines) continue;
-        double var = sf2 - acc[s][t];                                   // models/GP_Safe.py:343 (clipped at 0)
-        var = var > 0.0 ? var : 0.0;
-        Vo[line * cnt0 + x0] = var * y2;                                // :347
-      }
-    }
+    for (int t = 0; t < 4; ++t) blk[MM<double>::pack_pos(4 * t + row_in, col_in & 3, col_in >> 2)] = acc[s][t];
   }
-}
-
-// mean and the gradient sums: 16 grid lines x 256 axis-0 positions per workgroup, one axis-0 position per thread
-template <int NB>   // NB = 1 + d row-vector families (alpha, alpha Xn_0, alpha Xn_1)
-__global__ __launch_bounds__(256) void k_bmean(const ModelConst mc, const CandSpec cs, const double* __restrict__ S0,
-                                               const double* __restrict__ Vb, int r0u, long long nlines, long long nlines_pad,
-                                               long long line0, double* __restrict__ mean_out, unsigned long long* __restrict__ Lmax) {
-  const int o = blockIdx.z;
-  const long long cnt0 = cs.count[0];
-  const long long x0 = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long rowbase = (long long)blockIdx.y * 16;
-  const bool xok = x0 < cnt0;
-  double acc[NB][16];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0;
-  const double* S0o = S0 + (size_t)o * r0u * cnt0;
-  const double* Vo = Vb + (size_t)o * NB * r0u * nlines_pad;
-  for (int p = 0; p < r0u; ++p) {
-    const double s = xok ? S0o[(size_t)p * cnt0 + x0] : 0.0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const double* v = Vo + ((size_t)b * r0u + p) * nlines_pad + rowbase;     // wave-uniform
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[b][r] = fma(v[r], s, acc[b][r]);
-    }
-  }
-  double gmax = 0.0;
-  if (xok) {
-    const double ystd = mc.Y_std[o];
-    const double xg0 = (x0 == cnt0 - 1 && cnt0 > 1) ? cs.hi[0] : cs.lo[0] + (double)x0 * cs.step[0];
-    const double xn0 = (xg0 - mc.X_mean[0]) * mc.X_rstd[0];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long long line = rowbase + r;
-      if (line >= nlines) continue;
-      const double s1 = acc[0][r];
-      const double mean = mc.mp[o] + s1;                                                          // GP_Safe.py:342
-      mean_out[(size_t)o * cs.n_local + line * cnt0 + x0] = mean * ystd + mc.Y_mean[o];           // :346
-      // gradient of the un-normalised mean w.r.t. raw x (analytic jax.grad(self.mean), models/SafeOpt.py:68-71)
-      double gn = ystd * (acc[1][r] - xn0 * s1) * mc.inv_ell[o][0] * mc.X_rstd[0];
-      gn = gn < 0 ? -gn : gn;
-      if (NB > 2) {
-        const long long i1 = line0 + line, cnt1 = cs.count[1];
-        const double xg1 = (i1 == cnt1 - 1 && cnt1 > 1) ? cs.hi[1] : cs.lo[1] + (double)i1 * cs.step[1];
-        const double xn1 = (xg1 - mc.X_mean[1]) * mc.X_rstd[1];
-        double g1 = ystd * (acc[NB > 2 ? 2 : 0][r] - xn1 * s1) * mc.inv_ell[o][1] * mc.X_rstd[1];
-        g1 = g1 < 0 ? -g1 : g1;
-        gn = g1 > gn ? g1 : gn;
-      }
-      gmax = gn > gmax ? gn : gmax;
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double other = __shfl_xor(gmax, off);
-    gmax = other > gmax ? other : gmax;
-  }
-  if ((threadIdx.x & 63) == 0) atomicMax(&Lmax[o], (unsigned long long)__double_as_longlong(gmax));
 }
 
 // Fused stage 2: variance, mean and gradient keys of a 128 x 128 tile of the grid (8 row blocks x 8 column strips) per
@@ -477,14 +397,14 @@ int bilinear_setup(sbo_ctx* c) {
   if ((rc = ensure(c->bl_P0f, sizeof(double) * hP0f.size()))) return rc;
   if ((rc = ensure(c->bl_P1A, sizeof(double) * hP1A.size()))) return rc;
   if ((rc = ensure(c->bl_T4f, sizeof(double) * hT4f.size()))) return rc;
-  if ((rc = ensure(c->bl_S0, sizeof(double) * hSBf.size()))) return rc;     // mean-phase B fragments
-  if ((rc = ensure(c->bl_Vb, sizeof(double) * hVA.size()))) return rc;      // mean-phase A images
+  if ((rc = ensure(c->bl_SBf, sizeof(double) * hSBf.size()))) return rc;     // mean-phase B fragments
+  if ((rc = ensure(c->bl_VA, sizeof(double) * hVA.size()))) return rc;      // mean-phase A images
   if ((rc = ensure(c->bl_BtA, sizeof(double) * pl.sBtA * q))) return rc;
   SBO_HIP(hipMemcpyAsync(c->bl_P0f.p, hP0f.data(), sizeof(double) * hP0f.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(c->bl_P1A.p, hP1A.data(), sizeof(double) * hP1A.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(c->bl_T4f.p, hT4f.data(), sizeof(double) * hT4f.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(c->bl_S0.p, hSBf.data(), sizeof(double) * hSBf.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(c->bl_Vb.p, hVA.data(), sizeof(double) * hVA.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->bl_SBf.p, hSBf.data(), sizeof(double) * hSBf.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->bl_VA.p, hVA.data(), sizeof(double) * hVA.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));      // the host vectors go out of scope
   lap("upload");
   pl.usable = true;
@@ -500,9 +420,9 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0, line0 = cs.first / cnt0;
   constexpr int S1 = 2;
   // stage 1: Bt = P1^T T4qq^T, written as the packed A operand of stage 2
-  hipLaunchKernelGGL((k_bgemm<S1, 0>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256),
+  hipLaunchKernelGGL((k_bgemm<S1>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256),
                      0, c->stream, (const double*)c->bl_P1A.p, pl.sP1A, (const double*)c->bl_T4f.p, pl.sT4f, pl.KB1, pl.nrb, pl.KB0,
-                     (double*)c->bl_BtA.p, pl.sBtA, mc, cnt0, nlines);
+                     (double*)c->bl_BtA.p, pl.sBtA);
   // stage 2 (fused): variance, mean, Lipschitz keys
   const size_t lds = sizeof(double) * 2 * 4096;
   static bool attr_set = false;
@@ -511,8 +431,8 @@ int launch_posterior_bilinear(sbo_ctx* c) {
     attr_set = true;
   }
   hipLaunchKernelGGL(k_bpost, dim3((unsigned)((pl.ncs0 + 7) / 8), (unsigned)((pl.nrb + 7) / 8), (unsigned)q), dim3(256), lds, c->stream,
-                     mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_Vb.p,
-                     pl.sVA, (const double*)c->bl_S0.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.nrb, pl.ncs0, nlines,
+                     mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
+                     pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.nrb, pl.ncs0, nlines,
                      (double*)c->mean.p, (double*)c->var.p, (unsigned long long*)c->Lmax.p);
   (void)line0;
   // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (16 x 16 x 4 steps, 2 flops per multiply-add)
