@@ -129,11 +129,15 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
   long long cS = 0, cU = 0;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
     bool s = true, u = true;
-    for (int c = 1; c < q; ++c) {
-      T lcb, ucb;
-      lcb_ucb(mean[(size_t)c * n + g], var[(size_t)c * n + g], b, lcb, ucb);
-      s = s && (lcb >= T(0));
-      u = u && (lcb <= T(0));
+    T ucbc[kMaxQ];                                  // kept for the radius keys: one sqrt per (candidate, constraint)
+#pragma unroll
+    for (int c = 1; c < kMaxQ; ++c) {
+      if (c < q) {
+        T lcb;
+        lcb_ucb(mean[(size_t)c * n + g], var[(size_t)c * n + g], b, lcb, ucbc[c]);
+        s = s && (lcb >= T(0));
+        u = u && (lcb <= T(0));
+      }
     }
     S[g] = s;
     U[g] = u;
@@ -144,10 +148,12 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
       lcb_ucb(mean[g], var[g], b, lcb, ucb);
       const unsigned long long k = ord_key((double)ucb);
       umin = k < umin ? k : umin;
-      for (int c = 1; c < q; ++c) {
-        lcb_ucb(mean[(size_t)c * n + g], var[(size_t)c * n + g], b, lcb, ucb);
-        const unsigned long long kc = ord_key((double)ucb);
-        if (kc > rmax_sh[c]) atomicMax(&rmax_sh[c], kc);
+#pragma unroll
+      for (int c = 1; c < kMaxQ; ++c) {
+        if (c < q) {
+          const unsigned long long kc = ord_key((double)ucbc[c]);
+          if (kc > rmax_sh[c]) atomicMax(&rmax_sh[c], kc);
+        }
       }
     }
   }
