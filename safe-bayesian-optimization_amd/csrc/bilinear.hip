@@ -24,20 +24,26 @@
 
 namespace sbo {
 
-// Stage 1.  OUT[rows x cols] = A[rows x K] B[K x cols];  A: [nrb][KB][256] packed block images, Bf: [ncs][KB * 4][64]
-// fragments.  A wave owns 16 rows x (16 S) columns; the four waves of a workgroup take four consecutive row blocks.
-// OUT is written as packed block images [nrb][ncs][256]: it is the A operand of stage 2.
-template <int S>
+// Plain GEMM on the matrix cores.  OUT[rows x cols] = A[rows x K] B[K x cols];  A: packed 16 x 16 block images, Bf:
+// [ncs][KB * 4][64] fragments.  A wave owns 16 rows x (16 S) columns; the four waves of a workgroup take four
+// consecutive row blocks.  Used for stage 1 of every posterior launch and for the per-model build of T4.
+//   TRI   0: A images [nrb][KB][256];  1: lower-triangular images [tri(rb, kb)][256] (the model's factor M as K1g keeps
+//            it), only k-blocks <= rb exist and are run
+//   OMODE 0: OUT as packed block images [nrb][ncs][256] (the A operand of a following GEMM with K = cols)
+//         1: OUT both as B fragments [ncs][nrb * 4][64] (K = rows) and, transposed, as A images [ncs][nrb][256]
+//         2: OUT row-major with leading dimension ld
+template <int S, int TRI, int OMODE>
 __global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, size_t a_stride_o, const double* __restrict__ Bf,
                                                size_t b_stride_o, int KB, int nrb, int ncs, double* __restrict__ out,
-                                               size_t out_stride_o) {
+                                               size_t out_stride_o, double* __restrict__ out2, long long ld) {
   const int o = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rb = blockIdx.y * 4 + wave;
   if (rb >= nrb) return;                       // (no barriers in this kernel)
   const int cs0 = blockIdx.x * S;
-  const double* Ablk = A + (size_t)o * a_stride_o + (size_t)rb * KB * 256;
+  const double* Ablk = A + (size_t)o * a_stride_o + (TRI ? (size_t)rb * (rb + 1) / 2 : (size_t)rb * KB) * 256;
   const double* Bo = Bf + (size_t)o * b_stride_o;
+  const int kend = TRI ? rb + 1 : KB;
   size_t boff[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -47,7 +53,7 @@ __global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, siz
   d4_t acc[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) acc[s] = d4_t{0.0, 0.0, 0.0, 0.0};
-  for (int kb = 0; kb < KB; ++kb) {
+  for (int kb = 0; kb < kend; ++kb) {
     d4_t a[4];
     MM<double>::load_a4(Ablk + (size_t)kb * 256, lane, a);
 #pragma unroll
@@ -61,13 +67,95 @@ __global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, siz
   }
   // accumulator element t of lane l: row 4 t + (l >> 4), column l & 15 of the 16 x 16 tile
   const int col_in = lane & 15, row_in = lane >> 4;
-  double* Oo = out + (size_t)o * out_stride_o + (size_t)rb * ncs * 256;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     if (cs0 + s >= ncs) continue;
-    double* blk = Oo + (size_t)(cs0 + s) * 256;
+    if (OMODE == 0) {
+      double* blk = out + (size_t)o * out_stride_o + ((size_t)rb * ncs + (cs0 + s)) * 256;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) blk[MM<double>::pack_pos(4 * t + row_in, col_in & 3, col_in >> 2)] = acc[s][t];
+      for (int t = 0; t < 4; ++t) blk[MM<double>::pack_pos(4 * t + row_in, col_in & 3, col_in >> 2)] = acc[s][t];
+    } else if (OMODE == 1) {
+      // as B fragments: k = row = rb * 16 + 4 t + row_in  ->  k-step rb * 4 + t, slot row_in: the lane's own position
+      double* fr = out + ((size_t)(cs0 + s) * nrb * 4 + (size_t)rb * 4) * 64 + lane;
+      // transposed as A images: row = column index, k = rb * 16 + 4 t + row_in
+      double* img = out2 + ((size_t)(cs0 + s) * nrb + rb) * 256;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fr[(size_t)t * 64] = acc[s][t];
+        img[MM<double>::pack_pos(col_in, row_in, t)] = acc[s][t];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        out[(size_t)(rb * 16 + 4 * t + row_in) * ld + (size_t)(cs0 + s) * 16 + col_in] = acc[s][t];
+    }
+  }
+}
+
+// ---- per-model table builders (device side of bilinear_setup) -------------------------------------------------
+// Z_j,(p,s) = U0_jp U1_js as B fragments [ncsR][KBn * 4][64] (k = observation j, column c = p r1 + s)
+__global__ __launch_bounds__(256) void k_bl_zf(const double* __restrict__ U0, const double* __restrict__ U1, int n, int KBn, int r0,
+                                               int r1, int ncsR, double* __restrict__ Zf) {
+  const long long total = (long long)ncsR * KBn * 4 * 64;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const long long fr = i >> 6;
+    const int ks = (int)(fr % (KBn * 4)), cs = (int)(fr / (KBn * 4));
+    const int j = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+    const int cidx = cs * 16 + (l & 15);
+    double v = 0.0;
+    if (j < n && cidx < r0 * r1) v = U0[(size_t)(cidx / r1) * n + j] * U1[(size_t)(cidx % r1) * n + j];
+    Zf[i] = v;
+  }
+}
+// T4qq^T as B fragments over the columns k0: [KB0][KB1 * 4][64], element (k1, k0) = scale/2 (G[(p,s),(p',s')] + G[(p',s),(p,s')])
+__global__ __launch_bounds__(256) void k_bl_t4f(const double* __restrict__ G, long long ldg, int r1, const int* __restrict__ map0,
+                                                int K0, const int* __restrict__ map1, int K1, double scale, int KB0, int KB1,
+                                                double* __restrict__ T4f) {
+  const long long total = (long long)KB0 * KB1 * 4 * 64;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const long long fr = i >> 6;
+    const int ks = (int)(fr % (KB1 * 4)), cs = (int)(fr / (KB1 * 4));
+    const int k1 = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+    const int k0 = cs * 16 + (l & 15);
+    double v = 0.0;
+    if (k0 < K0 && k1 < K1) {
+      const int p = map0[2 * k0], pp = map0[2 * k0 + 1], s1 = map1[2 * k1], ss = map1[2 * k1 + 1];
+      v = scale * 0.5 * (G[(size_t)(p * r1 + s1) * ldg + (pp * r1 + ss)] + G[(size_t)(pp * r1 + s1) * ldg + (p * r1 + ss)]);
+    }
+    T4f[i] = v;
+  }
+}
+// pair products of an axis table S [r][count]: P[(p <= p')][x] = w S_p S_p' (w = 1 diagonal, 2 off it)
+//   FRAG 1: as B fragments [ncs][KB * 4][64] (columns = positions);  FRAG 0: transposed as A images [nrb][KB][256] (rows = positions)
+template <int FRAG>
+__global__ __launch_bounds__(256) void k_bl_pairs(const double* __restrict__ Stab, long long count, const int* __restrict__ map,
+                                                  int K, int KB, int nblk, double* __restrict__ out) {
+  const long long total = (long long)nblk * KB * 256;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int k;
+    long long x;
+    if (FRAG) {
+      const int l = (int)(i & 63);
+      const long long fr = i >> 6;
+      const int ks = (int)(fr % (KB * 4));
+      k = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+      x = (fr / (KB * 4)) * 16 + (l & 15);
+    } else {
+      // invert pack_pos(r, slot, kk) = kk * 64 + (slot * 4 + (r & 3)) * 4 + (r >> 2)
+      const int e = (int)(i & 255);
+      const long long blk = i >> 8;
+      const int kk = e >> 6, rem = e & 63, slot = rem >> 4, r = ((rem >> 2) & 3) + 4 * (rem & 3);
+      k = (int)(blk % KB) * 16 + MM<double>::jslot(kk, slot);
+      x = (blk / KB) * 16 + r;
+    }
+    double v = 0.0;
+    if (k < K && x < count) {
+      const int p = map[2 * k], pp = map[2 * k + 1];
+      v = (p == pp ? 1.0 : 2.0) * Stab[(size_t)p * count + x] * Stab[(size_t)pp * count + x];
+    }
+    out[i] = v;
   }
 }
 
@@ -318,9 +406,14 @@ int bilinear_setup(sbo_ctx* c) {
   pl.KS0 = (K0 + 3) / 4;
   pl.sVA = (size_t)nrb * KBm * 256 * 4;          // image sets  V0 | [V1; V0] | V1x
   pl.sSBf = (size_t)ncs0 * KBm * 256 * 3;       // fragment sets  S0 | [S0; -xn0 S0]
-  std::vector<double> hP0f(pl.sP0f * q, 0.0), hP1A(pl.sP1A * q, 0.0), hT4f(pl.sT4f * q, 0.0), hVA(pl.sVA * q, 0.0),
-      hSBf(pl.sSBf * q, 0.0), Vb((size_t)NB * r0u * nlines);
-  std::vector<double> P0, P1, T4qq, Mb, beta((size_t)NB * n);
+  std::vector<double> hVA(pl.sVA * q, 0.0), hSBf(pl.sSBf * q, 0.0), Vb((size_t)NB * r0u * nlines);
+  std::vector<double> Mb, beta((size_t)NB * n), S1loc;
+  std::vector<int> map0, map1;
+  int rc;
+  if ((rc = ensure(c->bl_P0f, sizeof(double) * pl.sP0f * q))) return rc;
+  if ((rc = ensure(c->bl_P1A, sizeof(double) * pl.sP1A * q))) return rc;
+  if ((rc = ensure(c->bl_T4f, sizeof(double) * pl.sT4f * q))) return rc;
+  const int KBn = mc.npad / 16;
   for (int o = 0; o < q; ++o) {
     const int r0 = b0[o].r, r1 = b1[o].r, k0n = bl::pair_count(r0), k1n = bl::pair_count(r1);
     const double sf2 = mc.sf2[o];
@@ -331,46 +424,60 @@ int bilinear_setup(sbo_ctx* c) {
       beta[(size_t)2 * n + j] = al * c->h_Xnorm[(size_t)j * mc.d + 1];
     }
     const double* bp[3] = {&beta[0], &beta[(size_t)n], &beta[(size_t)2 * n]};
-    bl::build_forms(n, &c->h_F[(size_t)o * n * n], b0[o], b1[o], sf2 * sf2, NB, bp, sf2, T4qq, Mb);
-    lap("forms");
-    bl::pair_table(b0[o], (int)cnt0, P0);                       // [k0n x cnt0]
-    // axis-1 tables for the local lines only
+    bl::mean_forms(n, b0[o], b1[o], NB, bp, sf2, Mb);
+    // axis-1 coordinates of the local lines only
     bl::AxisBasis b1loc;
     b1loc.r = r1;
     b1loc.S.resize((size_t)r1 * nlines);
     for (int s = 0; s < r1; ++s)
       for (long long l = 0; l < nlines; ++l) b1loc.S[(size_t)s * nlines + l] = b1[o].S[(size_t)s * cs.count[1] + line0 + l];
-    bl::pair_table(b1loc, (int)nlines, P1);                     // [k1n x nlines]
-    // P0 -> B fragments [ncs0][KB0 * 4][64]
-    double* f = &hP0f[pl.sP0f * o];
-    for (int csx = 0; csx < ncs0; ++csx)
-      for (int ks = 0; ks < KB0 * 4; ++ks)
-        for (int l = 0; l < 64; ++l) {
-          const int k = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
-          const long long x = (long long)csx * 16 + (l & 15);
-          if (k < k0n && x < cnt0) f[((size_t)csx * KB0 * 4 + ks) * 64 + l] = P0[(size_t)k * cnt0 + x];
-        }
-    // P1^T -> packed A images [nrb][KB1][256]
-    double* pa = &hP1A[pl.sP1A * o];
-    for (int rb = 0; rb < nrb; ++rb)
-      for (int kb = 0; kb < KB1; ++kb)
-        for (int r = 0; r < 16; ++r)
-          for (int slot = 0; slot < 4; ++slot)
-            for (int kk = 0; kk < 4; ++kk) {
-              const long long line = (long long)rb * 16 + r;
-              const int k = kb * 16 + MM<double>::jslot(kk, slot);
-              if (line < nlines && k < k1n)
-                pa[((size_t)rb * KB1 + kb) * 256 + MM<double>::pack_pos(r, slot, kk)] = P1[(size_t)k * nlines + line];
-            }
-    // T4qq^T -> B fragments over the columns k0: [KB0][KB1 * 4][64], element (k1, k0)
-    double* tf = &hT4f[pl.sT4f * o];
-    for (int csx = 0; csx < KB0; ++csx)
-      for (int ks = 0; ks < KB1 * 4; ++ks)
-        for (int l = 0; l < 64; ++l) {
-          const int k1 = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
-          const int k0 = csx * 16 + (l & 15);
-          if (k0 < k0n && k1 < k1n) tf[((size_t)csx * KB1 * 4 + ks) * 64 + l] = T4qq[(size_t)k0 * k1n + k1];
-        }
+    // ---- device: Z -> C = M Z -> G = C^T C -> T4 fragments; pair tables of both axes -------------------------------
+    {
+      const int R = r0 * r1, ncsR = (R + 15) / 16;
+      const size_t nU0 = (size_t)n * r0, nU1 = (size_t)n * r1, nS0 = (size_t)r0 * cnt0, nS1 = (size_t)r1 * nlines;
+      bl::pair_map(r0, map0);
+      bl::pair_map(r1, map1);
+      const size_t small_d = nU0 + nU1 + nS0 + nS1;
+      const size_t nZf = (size_t)ncsR * KBn * 256;              // fragments of Z, of C, images of C^T: same size
+      const size_t ldg = (size_t)ncsR * 16;
+      if ((rc = ensure(c->bl_small, sizeof(double) * small_d + sizeof(int) * (map0.size() + map1.size())))) return rc;
+      if ((rc = ensure(c->bl_work, sizeof(double) * (3 * nZf + ldg * ldg)))) return rc;
+      double* dU0 = (double*)c->bl_small.p;
+      double* dU1 = dU0 + nU0;
+      double* dS0 = dU1 + nU1;
+      double* dS1 = dS0 + nS0;
+      int* dmap0 = (int*)(dS1 + nS1);
+      int* dmap1 = dmap0 + map0.size();
+      SBO_HIP(hipMemcpyAsync(dU0, b0[o].U.data(), sizeof(double) * nU0, hipMemcpyHostToDevice, c->stream));
+      SBO_HIP(hipMemcpyAsync(dU1, b1[o].U.data(), sizeof(double) * nU1, hipMemcpyHostToDevice, c->stream));
+      SBO_HIP(hipMemcpyAsync(dS0, b0[o].S.data(), sizeof(double) * nS0, hipMemcpyHostToDevice, c->stream));
+      SBO_HIP(hipMemcpyAsync(dS1, b1loc.S.data(), sizeof(double) * nS1, hipMemcpyHostToDevice, c->stream));
+      SBO_HIP(hipMemcpyAsync(dmap0, map0.data(), sizeof(int) * map0.size(), hipMemcpyHostToDevice, c->stream));
+      SBO_HIP(hipMemcpyAsync(dmap1, map1.data(), sizeof(int) * map1.size(), hipMemcpyHostToDevice, c->stream));
+      double* Zf = (double*)c->bl_work.p;
+      double* Cf = Zf + nZf;
+      double* CtA = Cf + nZf;
+      double* G = CtA + nZf;
+      auto blocks = [](size_t total) { return dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16)); };
+      hipLaunchKernelGGL(k_bl_zf, blocks(nZf), dim3(256), 0, c->stream, (const double*)dU0, (const double*)dU1, n, KBn, r0, r1, ncsR, Zf);
+      // C = M Z with the model's packed triangular factor; written as fragments (k = observation) and as images of C^T
+      hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), 1), dim3(256), 0, c->stream,
+                         (const double*)c->Fpk.p + (size_t)o * c->fpk_stride, (size_t)0, (const double*)Zf, (size_t)0, KBn, KBn, ncsR,
+                         Cf, (size_t)0, CtA, 0ll);
+      // G = C^T C  (R x R, row-major)
+      hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), 1), dim3(256), 0, c->stream,
+                         (const double*)CtA, (size_t)0, (const double*)Cf, (size_t)0, KBn, ncsR, ncsR, G, (size_t)0, (double*)nullptr,
+                         (long long)ldg);
+      hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f), dim3(256), 0, c->stream, (const double*)G, (long long)ldg, r1, (const int*)dmap0, k0n,
+                         (const int*)dmap1, k1n, sf2 * sf2, KB0, KB1, (double*)c->bl_T4f.p + pl.sT4f * o);
+      hipLaunchKernelGGL((k_bl_pairs<1>), blocks(pl.sP0f), dim3(256), 0, c->stream, (const double*)dS0, cnt0, (const int*)dmap0, k0n, KB0,
+                         ncs0, (double*)c->bl_P0f.p + pl.sP0f * o);
+      hipLaunchKernelGGL((k_bl_pairs<0>), blocks(pl.sP1A), dim3(256), 0, c->stream, (const double*)dS1, nlines, (const int*)dmap1, k1n, KB1,
+                         nrb, (double*)c->bl_P1A.p + pl.sP1A * o);
+      SBO_HIP(hipGetLastError());
+      SBO_HIP(hipStreamSynchronize(c->stream));      // the small upload buffer is reused by the next output
+    }
+    lap("forms");
     // V_b[p][line] = sum_s Mb[b][p, s] S1[s][line]   (b: alpha, alpha Xn_0, alpha Xn_1)
     std::fill(Vb.begin(), Vb.end(), 0.0);
     for (int b = 0; b < NB; ++b)
@@ -422,16 +529,9 @@ int bilinear_setup(sbo_ctx* c) {
     pl.r1[o] = r1;
     lap("tables");
   }
-  int rc;
-  if ((rc = ensure(c->bl_P0f, sizeof(double) * hP0f.size()))) return rc;
-  if ((rc = ensure(c->bl_P1A, sizeof(double) * hP1A.size()))) return rc;
-  if ((rc = ensure(c->bl_T4f, sizeof(double) * hT4f.size()))) return rc;
   if ((rc = ensure(c->bl_SBf, sizeof(double) * hSBf.size()))) return rc;     // mean-phase B fragments
   if ((rc = ensure(c->bl_VA, sizeof(double) * hVA.size()))) return rc;      // mean-phase A images
   if ((rc = ensure(c->bl_BtA, sizeof(double) * pl.sBtA * q))) return rc;
-  SBO_HIP(hipMemcpyAsync(c->bl_P0f.p, hP0f.data(), sizeof(double) * hP0f.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(c->bl_P1A.p, hP1A.data(), sizeof(double) * hP1A.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(c->bl_T4f.p, hT4f.data(), sizeof(double) * hT4f.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(c->bl_SBf.p, hSBf.data(), sizeof(double) * hSBf.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(c->bl_VA.p, hVA.data(), sizeof(double) * hVA.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));      // the host vectors go out of scope
@@ -449,9 +549,9 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0, line0 = cs.first / cnt0;
   constexpr int S1 = 2;
   // stage 1: Bt = P1^T T4qq^T, written as the packed A operand of stage 2
-  hipLaunchKernelGGL((k_bgemm<S1>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256),
+  hipLaunchKernelGGL((k_bgemm<S1, 0, 0>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256),
                      0, c->stream, (const double*)c->bl_P1A.p, pl.sP1A, (const double*)c->bl_T4f.p, pl.sT4f, pl.KB1, pl.nrb, pl.KB0,
-                     (double*)c->bl_BtA.p, pl.sBtA);
+                     (double*)c->bl_BtA.p, pl.sBtA, (double*)nullptr, 0ll);
   // stage 2 (fused): variance, mean, Lipschitz keys
   const size_t lds = sizeof(double) * 2 * 4096;
   static bool attr_set = false;

@@ -22,7 +22,7 @@ namespace bl {
 
 constexpr double kPi = 3.14159265358979323846;
 constexpr int kMaxCheb = 128;    // Chebyshev degree limit of the interpolant (beyond: the separable-table kernel is used)
-constexpr int kMaxRank = 32;     // basis size limit per axis (r0 r1 columns of Z are formed on the host)
+constexpr int kMaxRank = 64;     // basis size limit per axis (inner dimension of the GEMMs: r (r + 1) / 2 <= 2080)
 
 // One-sided Jacobi SVD (Hestenes) of G [rows x cols], column-major (column c at G + c*rows).  On return the columns of G
 // are U_c sigma_c (mutually orthogonal), V [cols x cols] column-major holds the right singular vectors, sig the norms.
@@ -277,6 +277,29 @@ inline void build_forms(int n, const double* M, const AxisBasis& b0, const AxisB
       for (int j = 0; j < n; ++j) s += beta[bi][j] * z[j];
       Mb[(size_t)bi * R + c] = beta_scale * s;
     }
+}
+
+// Mb[b][p r1 + s] = beta_scale sum_j beta_b[j] U0_jp U1_js   (the bilinear forms of the mean and its gradient sums)
+inline void mean_forms(int n, const AxisBasis& b0, const AxisBasis& b1, int nbeta, const double* const* beta, double beta_scale,
+                       std::vector<double>& Mb) {
+  const int r0 = b0.r, r1 = b1.r, R = r0 * r1;
+  Mb.assign((size_t)nbeta * R, 0.0);
+  for (int bi = 0; bi < nbeta; ++bi)
+    for (int p = 0; p < r0; ++p)
+      for (int s = 0; s < r1; ++s) {
+        const double* u0 = &b0.U[(size_t)p * n];
+        const double* u1 = &b1.U[(size_t)s * n];
+        double acc = 0;
+        for (int j = 0; j < n; ++j) acc += beta[bi][j] * u0[j] * u1[j];
+        Mb[(size_t)bi * R + (size_t)p * r1 + s] = beta_scale * acc;
+      }
+}
+
+// (p, p') of every pair index k, pairs enumerated row by row
+inline void pair_map(int r, std::vector<int>& map) {
+  map.clear();
+  for (int p = 0; p < r; ++p)
+    for (int pp = p; pp < r; ++pp) { map.push_back(p); map.push_back(pp); }
 }
 
 // P[(p <= p')][i] = w S_p(i) S_p'(i), w = 1 on the diagonal and 2 off it; row-major [K x count]

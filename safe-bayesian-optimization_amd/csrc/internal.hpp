@@ -77,7 +77,7 @@ struct sbo_ctx {
   std::vector<double> h_F;       // [q][n][n] lower-triangular contraction factors (host copy for the K1b plan)
   std::vector<double> h_alpha;   // [q][npad]
   sbo::BilinearPlan bl;
-  sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA;
+  sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work;
   // candidates
   bool has_cand = false;
   sbo::CandSpec cs{};

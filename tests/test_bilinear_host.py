@@ -28,7 +28,7 @@ def _p(a):
 def _axis(shim, As_col, vinv, xn):
     n, count = As_col.shape[0], xn.shape[0]
     r, rc = C.c_int(), C.c_int()
-    U, S = np.zeros(n * 32), np.zeros(32 * count)
+    U, S = np.zeros(n * 64), np.zeros(64 * count)
     rcode = shim.blt_axis(n, _p(As_col), C.c_double(vinv), _p(xn), count, C.byref(r), C.byref(rc), _p(U), _p(S))
     if rcode != 0:
         return None
@@ -36,7 +36,7 @@ def _axis(shim, As_col, vinv, xn):
 
 
 @pytest.mark.parametrize("name,n,count,shift", [("B", 128, [96, 80], 0.0), ("H", 300, [64, 72], 0.0), ("C", 64, [80, 64], 0.0),
-                                                ("B", 20, [64, 64], 0.3)])
+                                                ("B", 20, [64, 64], 0.3), ("B", 128, [96, 80], -0.5)])
 def test_bilinear_forms_reproduce_the_oracle_posterior(shim, name, n, count, shift):
     cfg = synthetic.make_config(name, n=n)
     hyp = synthetic.default_hypopt(2, cfg["Y"].shape[1])
@@ -84,10 +84,10 @@ def test_bilinear_forms_reproduce_the_oracle_posterior(shim, name, n, count, shi
 
 
 def test_short_length_scales_are_declined(shim):
-    """Length-scales much shorter than the axis: the factor family needs more than 32 directions, the builder says so and
+    """Length-scales much shorter than the axis: the factor family needs more than 64 directions, the builder says so and
     the library keeps the separable-table kernel for such models."""
     cfg = synthetic.make_config("B", n=128)
     xn = np.linspace(-1.9, 1.6, 96)
-    vinv = float(np.exp(1.0))
+    vinv = float(np.exp(2.2))
     As_col = np.ascontiguousarray(cfg["ds"]["X_norm"][:, 0] * vinv)
     assert _axis(shim, As_col, vinv, xn) is None

@@ -117,18 +117,20 @@ def test_bilinear_posterior_matches_oracle_and_table_kernel(engine, cfg_name, n,
         assert r1["minimizer_index"] == r0["minimizer_index"] and r1["count_S"] == r0["count_S"]
 
 
-def test_bilinear_declines_short_length_scales_and_fp32(engine):
-    """Bases that need more than 32 directions per axis, and fp32 models, stay on the separable-table kernel."""
+def test_bilinear_rank_range_and_declines(engine):
+    """Short length-scales need larger bases (r up to 64, inner dimension up to 2080): still the GEMM path and still within
+    tolerance.  Bases beyond that, and fp32 models, stay on the separable-table kernel."""
     cfg = synthetic.make_config("B", n=128)
     lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [96, 80]
-    hyp = synthetic.default_hypopt(2, 2)
-    hyp[:2] -= 1.0
-    ds = synthetic.make_dataset(cfg["X"], cfg["Y"], hyp)
     pts = oracle.grid_points(lo, hi, count)
-    engine.set_model(ds)
-    engine.set_grid(lo, hi, count)
-    _check_posterior(engine, ds, pts, TOL64)
-    assert engine.profile()["posterior_kernel"] == 3
+    for shift, kernel in ((-1.0, 4), (-2.2, 3)):
+        hyp = synthetic.default_hypopt(2, 2)
+        hyp[:2] += shift
+        ds = synthetic.make_dataset(cfg["X"], cfg["Y"], hyp)
+        engine.set_model(ds)
+        engine.set_grid(lo, hi, count)
+        _check_posterior(engine, ds, pts, TOL64)
+        assert engine.profile()["posterior_kernel"] == kernel, shift
     engine.set_model(cfg["ds"], dtype="f32", use_invK=False)
     engine.set_grid(lo, hi, count)
     engine.posterior_run()
