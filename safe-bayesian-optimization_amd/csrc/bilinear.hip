@@ -394,6 +394,12 @@ int bilinear_setup(sbo_ctx* c) {
   }
   const int KB0 = (K0 + 15) / 16, KB1 = (K1 + 15) / 16;
   const int ncs0 = (int)((cnt0 + 15) / 16), nrb = (int)((nlines + 15) / 16);
+  {
+    // worth it only while the two GEMMs issue clearly fewer flops than the triangular contraction of K1g
+    const double gemm = (double)nlines * KB0 * 16.0 * KB1 * 16.0 + (double)cs.n_local * (KB0 * 16.0 + 4.0 * r0u);
+    const double tri = 0.5 * (double)mc.npad * (mc.npad + 16.0) * (double)cs.n_local;
+    if (gemm > 0.7 * tri) return SBO_OK;
+  }
   const long long nlines_pad = (long long)nrb * 16;
   pl.KB0 = KB0; pl.KB1 = KB1; pl.r0u = r0u; pl.ncs0 = ncs0; pl.nrb = nrb; pl.nlines_pad = nlines_pad;
   pl.sP0f = (size_t)ncs0 * KB0 * 4 * 64;

@@ -84,7 +84,7 @@ def test_posterior_chunked_generic_kernel(engine, cfg_name, n, dtype):
 
 
 # K1b: on fp64 2-D grids the posterior runs as two GEMMs in a reduced basis (bilinear.hip) when the axis bases qualify
-@pytest.mark.parametrize("cfg_name,n,count", [("B", 128, [160, 96]), ("C", 64, [96, 130]), ("H", 300, [64, 72]), ("A", 20, [70, 65])])
+@pytest.mark.parametrize("cfg_name,n,count", [("B", 128, [160, 96]), ("C", 64, [96, 130]), ("H", 300, [64, 72]), ("A", 64, [70, 65])])
 def test_bilinear_posterior_matches_oracle_and_table_kernel(engine, cfg_name, n, count):
     cfg = synthetic.make_config(cfg_name, n=n)
     lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
@@ -118,21 +118,24 @@ def test_bilinear_posterior_matches_oracle_and_table_kernel(engine, cfg_name, n,
 
 
 def test_bilinear_rank_range_and_declines(engine):
-    """Short length-scales need larger bases (r up to 64, inner dimension up to 2080): still the GEMM path and still within
-    tolerance.  Bases beyond that, and fp32 models, stay on the separable-table kernel."""
-    cfg = synthetic.make_config("B", n=128)
-    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [96, 80]
-    pts = oracle.grid_points(lo, hi, count)
-    for shift, kernel in ((-1.0, 4), (-2.2, 3)):
+    """Short length-scales need larger bases (r up to 64, inner dimension up to 2080): still the GEMM path when that is
+    cheaper than the O(n^2) contraction (n = 512 here), and still within tolerance.  Bases beyond 64 directions, grids on
+    which the GEMMs would not pay, and fp32 models stay on the separable-table kernel."""
+    lo_count = [96, 80]
+    for cfg_name, n, shift, kernel in (("H", 512, -1.0, 4), ("B", 128, -1.0, 3), ("B", 128, -2.2, 3)):
+        cfg = synthetic.make_config(cfg_name, n=n)
+        lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+        pts = oracle.grid_points(lo, hi, lo_count)
         hyp = synthetic.default_hypopt(2, 2)
         hyp[:2] += shift
         ds = synthetic.make_dataset(cfg["X"], cfg["Y"], hyp)
         engine.set_model(ds)
-        engine.set_grid(lo, hi, count)
+        engine.set_grid(lo, hi, lo_count)
         _check_posterior(engine, ds, pts, TOL64)
-        assert engine.profile()["posterior_kernel"] == kernel, shift
+        assert engine.profile()["posterior_kernel"] == kernel, (cfg_name, shift)
+    cfg = synthetic.make_config("B", n=128)
     engine.set_model(cfg["ds"], dtype="f32", use_invK=False)
-    engine.set_grid(lo, hi, count)
+    engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], lo_count)
     engine.posterior_run()
     assert engine.profile()["posterior_kernel"] == 3
 
