@@ -98,6 +98,7 @@ struct sbo_ctx {
   sbo::DevBuf partial; // arg-reduce per-block partials
   sbo::DevBuf amb;     // ambiguous-index list for the exact recheck
   sbo::DevBuf runmeta; // GoOSE: per-run bounding boxes / radii of the coverage search
+  sbo::DevBuf blockmax; // per-block largest source weight along axis 0 (blocked axis-0 pass of the power transform)
   sbo::DevBuf blockmin; // per-block minima along the last axis (blocked last-axis scans)
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
   sbo::DevBuf Wfull;   // multi-rank GoOSE: source weights of the whole grid (all-gathered), T [grid_total]

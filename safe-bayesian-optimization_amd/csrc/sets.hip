@@ -1041,34 +1041,114 @@ __device__ __forceinline__ long long coarse_cell(const CoarseGrid& cg, long long
   return cell;
 }
 
-// axis 0, reading the source weights directly
+// largest source weight of every block of `blk` consecutive axis-0 positions (-inf when the block holds no source)
+template <typename T>
+__global__ __launch_bounds__(256) void k_block_max_w(const T* __restrict__ W, long long nt, int count0, int blk,
+                                                     T* __restrict__ Bmax) {
+  const int nblk = (count0 + blk - 1) / blk;
+  const long long total = (nt / count0) * nblk;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long line = i / nblk;
+    const int b = (int)(i % nblk);
+    const int j1 = (b + 1) * blk < count0 ? (b + 1) * blk : count0;
+    T m = (T)-INFINITY;
+    for (int j = b * blk; j < j1; ++j) {
+      const T v = W[line * count0 + j];
+      m = v > m ? v : m;
+    }
+    Bmax[i] = m;
+  }
+}
+
+// axis 0, reading the source weights directly.  With Bmax (per-block largest weight = smallest F) the scan is blocked
+// like the last-axis ones: a block whose bound (h gap)^2 - r_block^2 cannot beat the running minimum costs one load,
+// the block with the smallest bound is visited first.  Same candidates and arithmetic as the step-by-step scan.
 template <typename T>
 __global__ __launch_bounds__(256) void k_pdt_axis0(const T* __restrict__ W, long long nt, int count0, double h0,
                                                    const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx,
                                                    int d, double xscale, const CoarseGrid cg, const double* __restrict__ PcLo,
-                                                   double* __restrict__ P) {
+                                                   const T* __restrict__ Bmax, int blk, double* __restrict__ P) {
   const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
+  const int nblk = (count0 + blk - 1) / blk;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nt; g += (long long)gridDim.x * blockDim.x) {
     if (cg.enabled && PcLo[coarse_cell(cg, g)] > pp.band) { P[g] = kInfD; continue; }
     const int i = (int)(g % count0);
     const double w = (double)W[g];
     double best = kInfD;
     if (w >= 0.0) { const double r = w * pp.invL; best = -(r * r); }
-    for (int t = 1; t < count0; ++t) {
-      const double dt = h0 * (double)t;
-      const double e = dt * dt;
-      const double floor_ = e - pp.rmax2;
-      if (floor_ > pp.band || floor_ >= best) break;
-      const bool lo_ok = i - t >= 0, hi_ok = i + t < count0;
-      if (!lo_ok && !hi_ok) break;
-      const double w1 = lo_ok ? (double)W[g - t] : -1.0;
-      const double w2 = hi_ok ? (double)W[g + t] : -1.0;
-      const double wm = fmax(w1, w2);                 // the larger radius wins at equal distance
-      if (wm >= 0.0) {
-        const double r = wm * pp.invL;
-        const double cnd = e - r * r;
-        best = cnd < best ? cnd : best;
+    if (Bmax == nullptr) {
+      for (int t = 1; t < count0; ++t) {
+        const double dt = h0 * (double)t;
+        const double e = dt * dt;
+        const double floor_ = e - pp.rmax2;
+        if (floor_ > pp.band || floor_ >= best) break;
+        const bool lo_ok = i - t >= 0, hi_ok = i + t < count0;
+        if (!lo_ok && !hi_ok) break;
+        const double w1 = lo_ok ? (double)W[g - t] : -1.0;
+        const double w2 = hi_ok ? (double)W[g + t] : -1.0;
+        const double wm = fmax(w1, w2);                 // the larger radius wins at equal distance
+        if (wm >= 0.0) {
+          const double r = wm * pp.invL;
+          const double cnd = e - r * r;
+          best = cnd < best ? cnd : best;
+        }
       }
+      P[g] = best;
+      continue;
+    }
+    const T* Wl = W + (g - i);                           // this line
+    const T* Bl = Bmax + (g / count0) * nblk;
+    const int b0 = i / blk;
+    auto scan_block = [&](int b) {
+      const int j1 = (b + 1) * blk < count0 ? (b + 1) * blk : count0;
+      for (int j = b * blk; j < j1; ++j) {
+        const double wj = (double)Wl[j];
+        if (wj >= 0.0) {
+          const double dt = h0 * (double)(j > i ? j - i : i - j), r = wj * pp.invL;
+          const double cnd = dt * dt - r * r;
+          best = cnd < best ? cnd : best;
+        }
+      }
+    };
+    auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? i - (b * blk + blk - 1) : b * blk - i); };
+    auto bound_of = [&](int b, double e) {
+      const double wb = (double)Bl[b];
+      if (!(wb >= 0.0)) return kInfD;
+      const double r = wb * pp.invL;
+      return e - r * r;
+    };
+    double lb_min = bound_of(b0, 0.0);
+    int b_min = b0;
+    for (int k = 1; k < nblk; ++k) {
+      bool any = false;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int b = side ? b0 + k : b0 - k;
+        if (b < 0 || b >= nblk) continue;
+        const double dg = h0 * (double)gap_of(b);
+        const double e = dg * dg, floor_ = e - pp.rmax2;
+        if (floor_ > pp.band || floor_ >= best || floor_ >= lb_min) continue;
+        any = true;
+        const double lb = bound_of(b, e);
+        if (lb < lb_min) { lb_min = lb; b_min = b; }
+      }
+      if (!any) break;
+    }
+    if (lb_min < best) scan_block(b_min);
+    if (b_min != b0 && bound_of(b0, 0.0) < best) scan_block(b0);
+    for (int k = 1; k < nblk; ++k) {
+      bool any = false;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int b = side ? b0 + k : b0 - k;
+        if (b < 0 || b >= nblk) continue;
+        const double dg = h0 * (double)gap_of(b);
+        const double e = dg * dg, floor_ = e - pp.rmax2;
+        if (floor_ > pp.band || floor_ >= best) continue;
+        any = true;
+        if (b != b_min && bound_of(b, e) < best) scan_block(b);
+      }
+      if (!any) break;
     }
     P[g] = best;
   }
@@ -1814,9 +1894,18 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
       pc_lo = lo0;
       pc_hi = hi0;
     }
+    const T* wbmax = nullptr;
+    const int blk0 = 32;
+    if (c->scan_blocks && count0 >= 16 * blk0) {
+      const long long nbw = (nt / count0) * ((count0 + blk0 - 1) / blk0);
+      if ((rc = ensure(c->blockmax, sizeof(T) * (size_t)nbw))) return rc;
+      hipLaunchKernelGGL((k_block_max_w<T>), dim3((unsigned)std::min<long long>((nbw + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+                         Wwin, nt, count0, blk0, (T*)c->blockmax.p);
+      wbmax = (const T*)c->blockmax.p;
+    }
     hipLaunchKernelGGL((k_pdt_axis0<T>), dim3(gridn), dim3(256), 0, c->stream, Wwin, nt, count0, c->cs.step[0],
-                       (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, d, xscale, cg, pc_lo,
-                       (double*)c->dist2.p);
+                       (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, d, xscale, cg, pc_lo, wbmax,
+                       blk0, (double*)c->dist2.p);
     double* pin = (double*)c->dist2.p;
     double* pout = (double*)c->dist2b.p;
     long long stride = count0;
