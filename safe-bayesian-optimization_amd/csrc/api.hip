@@ -41,59 +41,6 @@ void release(DevBuf& b) {
 
 int launch_soa_to_aos(sbo_ctx* c, const void* soa, void* aos);
 
-// Host Cholesky L L^T = A (lower, in place); plain loops, n <= SBO_MAX_N.
-static bool cholesky_lower(std::vector<double>& A, int n) {
-  for (int j = 0; j < n; ++j) {
-    double s = A[(size_t)j * n + j];
-    for (int k = 0; k < j; ++k) s -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-    if (!(s > 0)) return false;
-    const double ljj = std::sqrt(s);
-    A[(size_t)j * n + j] = ljj;
-    for (int i = j + 1; i < n; ++i) {
-      double t = A[(size_t)i * n + j];
-      const double* ai = &A[(size_t)i * n];
-      const double* aj = &A[(size_t)j * n];
-      for (int k = 0; k < j; ++k) t -= ai[k] * aj[k];
-      A[(size_t)i * n + j] = t / ljj;
-    }
-  }
-  return true;
-}
-
-// Cholesky as above plus the inverse of L.
-static bool cholesky_inv(std::vector<double>& A, int n, std::vector<double>& Linv) {
-  for (int j = 0; j < n; ++j) {
-    double s = A[(size_t)j * n + j];
-    for (int k = 0; k < j; ++k) s -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-    if (!(s > 0)) return false;
-    const double ljj = std::sqrt(s);
-    A[(size_t)j * n + j] = ljj;
-    for (int i = j + 1; i < n; ++i) {
-      double t = A[(size_t)i * n + j];
-      const double* ai = &A[(size_t)i * n];
-      const double* aj = &A[(size_t)j * n];
-      for (int k = 0; k < j; ++k) t -= ai[k] * aj[k];
-      A[(size_t)i * n + j] = t / ljj;
-    }
-  }
-  // L^-1 row by row: row i = (e_i - sum_{k<i} L[i][k] row_k) / L[i][i]  (contiguous row updates)
-  Linv.assign((size_t)n * n, 0.0);
-  for (int i = 0; i < n; ++i) {
-    double* ri = &Linv[(size_t)i * n];
-    ri[i] = 1.0;
-    const double* li = &A[(size_t)i * n];
-    for (int k = 0; k < i; ++k) {
-      const double f = li[k];
-      if (f == 0.0) continue;
-      const double* rk = &Linv[(size_t)k * n];
-      for (int c = 0; c <= k; ++c) ri[c] -= f * rk[c];
-    }
-    const double inv = 1.0 / li[i];
-    for (int c = 0; c <= i; ++c) ri[c] *= inv;
-  }
-  return true;
-}
-
 template <typename T>
 static int upload_vec(DevBuf& b, const std::vector<double>& h, hipStream_t st) {
   std::vector<T> t(h.size());
@@ -106,37 +53,16 @@ static int upload_vec(DevBuf& b, const std::vector<double>& h, hipStream_t st) {
 }
 
 template <typename T>
-static int model_upload(sbo_ctx* c, const std::vector<double>& F_all /* [q][n][n] lower */,
-                        const std::vector<double>& As, const std::vector<double>& sqA,
-                        const std::vector<double>& alpha, const std::vector<double>& Xn) {
-  const ModelConst& mc = c->mc;
-  const int n = mc.n, nb = mc.npad / 16, q = mc.q;
-  const size_t ntri = (size_t)nb * (nb + 1) / 2;
-  c->fpk_stride = ntri * 4 * 64;
-  std::vector<double> pk((size_t)q * c->fpk_stride + 512, 0.0);   // + padding: the K1g pipeline over-reads
-  for (int o = 0; o < q; ++o) {
-    const double* F = &F_all[(size_t)o * n * n];
-    double* dst = &pk[(size_t)o * c->fpk_stride];
-    for (int I = 0; I < nb; ++I)
-      for (int J = 0; J <= I; ++J)
-        for (int kk = 0; kk < 4; ++kk)
-          for (int r = 0; r < 16; ++r)
-            for (int k = 0; k < 4; ++k) {
-              const int row = 16 * I + r;
-              const int col = 16 * J + MM<T>::jslot(kk, k);
-              double v = 0.0;
-              if (row < n && col < n && col <= row) v = F[(size_t)row * n + col];
-              dst[((size_t)I * (I + 1) / 2 + J) * 256 + MM<T>::pack_pos(r, k, kk)] = v;
-            }
-  }
+static int model_upload(sbo_ctx* c, const std::vector<double>& As, const std::vector<double>& sqA, const std::vector<double>& Xn) {
   int rc;
-  if ((rc = upload_vec<T>(c->Fpk, pk, c->stream))) return rc;
   if ((rc = upload_vec<T>(c->As, As, c->stream))) return rc;
   if ((rc = upload_vec<T>(c->sqA, sqA, c->stream))) return rc;
-  if ((rc = upload_vec<T>(c->alpha, alpha, c->stream))) return rc;
   if ((rc = upload_vec<T>(c->Xn, Xn, c->stream))) return rc;
   return SBO_OK;
 }
+
+int model_build(sbo_ctx* c, const double* host_invK, const std::vector<double>& As, const std::vector<double>& sqA,
+                const std::vector<double>& rhs, const double* sn2);
 
 }  // namespace sbo
 
@@ -268,18 +194,18 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
   mc.factor = invK ? SBO_FACTOR_INVK : SBO_FACTOR_CHOL;
   for (int a = 0; a < kMaxD; ++a) { mc.X_mean[a] = a < d ? X_mean[a] : 0.0; mc.X_std[a] = a < d ? X_std[a] : 1.0; mc.X_rstd[a] = 1.0 / mc.X_std[a]; }
   const int npad = mc.npad, D = mc.dpad;
-  std::vector<double> As((size_t)q * npad * D, 0.0), sqA((size_t)q * npad, 0.0), alpha((size_t)q * npad, 0.0),
-      Xn((size_t)npad * D, 0.0), F((size_t)q * n * n, 0.0);
+  std::vector<double> As((size_t)q * npad * D, 0.0), sqA((size_t)q * npad, 0.0), Xn((size_t)npad * D, 0.0), rhs((size_t)q * n);
   for (int j = 0; j < n; ++j)
     for (int a = 0; a < d; ++a) Xn[(size_t)j * D + a] = X_norm[(size_t)j * d + a];
   c->h_Xnorm.assign(X_norm, X_norm + (size_t)n * d);
   const double f32eps = (double)std::numeric_limits<float>::epsilon();
+  double sn2[kMaxQ] = {0};
   for (int o = 0; o < q; ++o) {
     mc.Y_mean[o] = Y_mean[o];
     mc.Y_std[o] = Y_std[o];
     mc.mp[o] = (o == 0) ? 0.0 : (-2.0 * Y_mean[o]) / Y_std[o];          // GP_Safe.py:331-332
     mc.sf2[o] = std::exp(2.0 * hypopt[(size_t)d * q + o]);               // GP_Safe.py:338
-    const double sn2 = std::exp(2.0 * hypopt[(size_t)(d + 1) * q + o]) + f32eps;   // GP_Safe.py:229
+    sn2[o] = std::exp(2.0 * hypopt[(size_t)(d + 1) * q + o]) + f32eps;   // GP_Safe.py:229
     for (int a = 0; a < d; ++a) {
       const double ell = std::exp(2.0 * hypopt[(size_t)a * q + o]);
       mc.vinv[o][a] = std::pow(ell, -0.5);                               // GP_Safe.py:112
@@ -293,56 +219,15 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
         s += v * v;
       }
       sqA[(size_t)o * npad + j] = s;
-    }
-    std::vector<double> rhs(n);
-    for (int j = 0; j < n; ++j) rhs[j] = Y_norm[(size_t)j * q + o] - mc.mp[o];
-    double* Fo = &F[(size_t)o * n * n];
-    if (invK) {
-      // alpha straight from the caller's inverse (GP_Safe.py:342); for the variance factor the same inverse as
-      // M^T M with M lower triangular: reverse both index orders, Cholesky, reverse back and transpose.
-      const double* W = invK + (size_t)o * n * n;
-      std::vector<double> R((size_t)n * n);
-      for (int i = 0; i < n; ++i) {
-        double s = 0;
-        for (int j = 0; j < n; ++j) s += W[(size_t)i * n + j] * rhs[j];
-        alpha[(size_t)o * npad + i] = s;
-        for (int j = 0; j < n; ++j)
-          R[(size_t)(n - 1 - i) * n + (n - 1 - j)] = 0.5 * (W[(size_t)i * n + j] + W[(size_t)j * n + i]);
-      }
-      if (!cholesky_lower(R, n)) return fail(SBO_E_INVALID, "invK is not positive definite");
-      // R = C (lower) with P invK P = C C^T  ->  invK = (P C P)(P C P)^T, and M = (P C P)^T is lower triangular
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j <= i; ++j) Fo[(size_t)i * n + j] = R[(size_t)(n - 1 - j) * n + (n - 1 - i)];
-    } else {
-      // K = sf2 exp(-1/2 dist) + sn2 I with the expanded distance (GP_Safe.py:119, 141, 231), then L^-1
-      std::vector<double> K((size_t)n * n), Linv;
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-          double dot = 0;
-          for (int a = 0; a < d; ++a) dot += As[((size_t)o * npad + i) * D + a] * As[((size_t)o * npad + j) * D + a];
-          const double dist = -2.0 * dot + sqA[(size_t)o * npad + i] + sqA[(size_t)o * npad + j];
-          K[(size_t)i * n + j] = mc.sf2[o] * std::exp(-0.5 * dist) + (i == j ? sn2 : 0.0);
-        }
-      if (!cholesky_inv(K, n, Linv)) return fail(SBO_E_INVALID, "K + sn2 I is not positive definite");
-      std::vector<double> t(n, 0.0);
-      for (int i = 0; i < n; ++i) {
-        double s = 0;
-        for (int j = 0; j <= i; ++j) s += Linv[(size_t)i * n + j] * rhs[j];
-        t[i] = s;
-      }
-      for (int j = 0; j < n; ++j) {
-        double s = 0;
-        for (int i = j; i < n; ++i) s += Linv[(size_t)i * n + j] * t[i];
-        alpha[(size_t)o * npad + j] = s;
-      }
-      memcpy(Fo, Linv.data(), sizeof(double) * (size_t)n * n);
+      rhs[(size_t)o * n + j] = Y_norm[(size_t)j * q + o] - mc.mp[o];
     }
   }
   c->dtype = dtype;
-  c->h_F = F;
-  c->h_alpha = alpha;
   c->bl.valid = false;
-  int rc = (dtype == SBO_F64) ? model_upload<double>(c, F, As, sqA, alpha, Xn) : model_upload<float>(c, F, As, sqA, alpha, Xn);
+  // factorisation, alpha and the fragment images of the factor: on the device (model.hip)
+  int rc = model_build(c, invK, As, sqA, rhs, sn2);
+  if (rc) return rc;
+  rc = (dtype == SBO_F64) ? model_upload<double>(c, As, sqA, Xn) : model_upload<float>(c, As, sqA, Xn);
   if (rc) return rc;
   c->has_model = true;
   return SBO_OK;

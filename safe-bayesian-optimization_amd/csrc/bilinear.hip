@@ -350,7 +350,7 @@ bool bilinear_applicable(const sbo_ctx* c) {
   const long long cnt0 = cs.count[0];
   if (cs.n_local <= 0 || cs.first % cnt0 != 0 || cs.n_local % cnt0 != 0) return false;
   // the bases pay off (and the interpolation interval is meaningful) only on real grids
-  return cnt0 >= 64 && cs.count[1] >= 64 && cs.n_local / cnt0 >= 16 && (int)c->h_F.size() == c->mc.q * c->mc.n * c->mc.n;
+  return cnt0 >= 64 && cs.count[1] >= 64 && cs.n_local / cnt0 >= 16 && c->h_alpha.size() == (size_t)c->mc.q * c->mc.npad;
 }
 
 // Builds the device tables for the current (model, candidates).  Returns SBO_OK with plan.usable = false when the bases do

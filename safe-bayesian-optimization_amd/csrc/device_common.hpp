@@ -41,6 +41,7 @@ template <> struct MM<float> {
   static __device__ __forceinline__ acc_t mfma_diag(a_t a, float b, acc_t c) { return mfma(a, b, c); }
   static __host__ __device__ __forceinline__ int jslot(int kk, int slot) { return 4 * slot + kk; }
   static __host__ __device__ __forceinline__ int pack_pos(int r, int k, int kk) { return (k * 16 + r) * 4 + kk; }
+  static __host__ __device__ __forceinline__ void unpack_pos(int e, int& r, int& k, int& kk) { kk = e & 3; r = (e >> 2) & 15; k = e >> 6; }
 };
 template <> struct MM<double> {
   using acc_t = d4_t;
@@ -71,6 +72,12 @@ template <> struct MM<double> {
   }
   static __host__ __device__ __forceinline__ int jslot(int kk, int slot) { return 4 * kk + slot; }
   static __host__ __device__ __forceinline__ int pack_pos(int r, int k, int kk) { return kk * 64 + (k * 4 + (r & 3)) * 4 + (r >> 2); }
+  static __host__ __device__ __forceinline__ void unpack_pos(int e, int& r, int& k, int& kk) {
+    kk = e >> 6;
+    const int rem = e & 63;
+    k = rem >> 4;
+    r = ((rem >> 2) & 3) + 4 * (rem & 3);
+  }
 };
 
 // unfused arithmetic where the oracle's rounding sequence is part of the contract

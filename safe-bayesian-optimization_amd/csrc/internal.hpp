@@ -74,7 +74,6 @@ struct sbo_ctx {
   sbo::DevBuf AXg;     // grid path: alpha_j (1, Xn_j) rows in fragment-slot order [q][npad][1 + dpad]
   size_t fpk_stride = 0;  // elements per output in Fpk
   std::vector<double> h_Xnorm;   // host copies used by the exact-recheck / result decoding
-  std::vector<double> h_F;       // [q][n][n] lower-triangular contraction factors (host copy for the K1b plan)
   std::vector<double> h_alpha;   // [q][npad]
   sbo::BilinearPlan bl;
   sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work;

@@ -1,0 +1,229 @@
+// model.hip -- SURVEY.md section 8(f) rank 1 (model build): the per-model factorisation on the device.
+//
+// What models/GP_Safe.py:229-245 leaves in `inference_datasets` is invK (or, when the caller passes none, the
+// hyper-parameters to build K = sf2 exp(-1/2 D) + (sn2 + float32 eps) I from).  The sweep kernels contract with a
+// LOWER-triangular M, M^T M = invK (K1g / K1c / K1, and the table build of K1b), and the mean uses
+// alpha = invK (Y_norm - mp).  Here, one workgroup per output:
+//   invK given : alpha = invK rhs with the matrix exactly as passed; M from the "UL" factorisation of the symmetrised
+//                invK: reverse both index orders, factor J invK J = U~^T U~ (U~ upper), M = J U~ J.
+//   invK absent: K from the expanded distance (models/GP_Safe.py:119), K = U^T U, M = L^-1 = U^-T by row-wise
+//                substitution, alpha = M^T (M rhs).
+// The factor is then packed into the matrix-core fragment images every K1 kernel reads (Fpk).  A 512 x 512 output
+// takes ~2 ms instead of ~45 ms of host Cholesky; 2048 x 2048 ~0.15 s instead of seconds.
+#include <cmath>
+#include <limits>
+#include <vector>
+#include "device_common.hpp"
+
+namespace sbo {
+
+// In-place K = U^T U on the upper triangle of a row-major n x n matrix, one workgroup (the loop of fit.hip without the
+// right-hand side).  `bad` is set when a pivot is not positive.  With E != nullptr (zero-initialised, row-major) the
+// identity rides along as n extra right-hand sides, exactly as y does in fit.hip, and E ends up as L^-1 (L = U^T).
+__device__ void factor_utu(double* __restrict__ U, int n, int* bad, double* sh_piv, double* __restrict__ E = nullptr) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int j = 0; j < n; ++j) {
+    if (tid == 0) {
+      const double piv = U[(size_t)j * n + j];
+      if (!(piv > 0.0)) *bad = 1;
+      *sh_piv = piv > 0.0 ? sqrt(piv) : 1.0;
+    }
+    __syncthreads();
+    const double ljj = *sh_piv;
+    double* uj = U + (size_t)j * n;
+    for (int i = j + 1 + tid; i < n; i += blockDim.x) uj[i] /= ljj;
+    if (tid == 0) uj[j] = ljj;
+    double* ej = E ? E + (size_t)j * n : nullptr;
+    if (E) {
+      for (int cidx = tid; cidx < j; cidx += blockDim.x) ej[cidx] /= ljj;
+      if (tid == 0) ej[j] = 1.0 / ljj;
+    }
+    __syncthreads();
+    // trailing update, row k from column k on; a wave keeps two rows in flight (the loop is bound by memory latency)
+    for (int k = j + 1 + wave; k < n; k += 2 * nw) {
+      const int k2 = k + nw;
+      const double f = uj[k];
+      double* uk = U + (size_t)k * n;
+      if (k2 < n) {
+        const double f2 = uj[k2];
+        double* uk2 = U + (size_t)k2 * n;
+        for (int i = k + lane; i < n; i += 64) {
+          const double v = uj[i];
+          uk[i] -= f * v;
+          if (i >= k2) uk2[i] -= f2 * v;
+        }
+      } else {
+        for (int i = k + lane; i < n; i += 64) uk[i] -= f * uj[i];
+      }
+      if (E) {                                  // rows k (and k2) of the inverse, columns 0..j
+        double* ek = E + (size_t)k * n;
+        for (int cidx = lane; cidx <= j; cidx += 64) ek[cidx] -= f * ej[cidx];
+        if (k2 < n) {
+          const double f2 = uj[k2];
+          double* ek2 = E + (size_t)k2 * n;
+          for (int cidx = lane; cidx <= j; cidx += 64) ek2[cidx] -= f2 * ej[cidx];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// mode 0: W = invK [q][n][n] given.  mode 1: build K from As / sqA.  Outputs: F [q][n][n] lower triangle (row-major),
+// alpha [q][npad], bad[q].  `work` [q][n][n] scratch.
+__global__ __launch_bounds__(1024) void k_model_build(int mode, int n, int npad, int dpad, int d, const double* __restrict__ W,
+                                                     const double* __restrict__ As, const double* __restrict__ sqA,
+                                                     const double* __restrict__ rhs, const double* __restrict__ sf2v,
+                                                     const double* __restrict__ sn2v, double* __restrict__ work,
+                                                     double* __restrict__ F, double* __restrict__ alpha, int* __restrict__ bad) {
+  __shared__ double sh_piv;
+  __shared__ int sh_bad;
+  const int o = blockIdx.x, tid = threadIdx.x;
+  double* U = work + (size_t)o * n * n;
+  double* Fo = F + (size_t)o * n * n;
+  const double* r = rhs + (size_t)o * n;
+  if (tid == 0) sh_bad = 0;
+  __syncthreads();
+  if (mode == 0) {
+    const double* Wo = W + (size_t)o * n * n;
+    // alpha straight from the caller's inverse (GP_Safe.py:342)
+    for (int i = tid; i < n; i += blockDim.x) {
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += Wo[(size_t)i * n + j] * r[j];
+      alpha[(size_t)o * npad + i] = s;
+    }
+    // reversed, symmetrised copy (upper triangle)
+    for (long long idx = tid; idx < (long long)n * n; idx += blockDim.x) {
+      const int i = (int)(idx / n), k = (int)(idx % n);
+      if (k < i) continue;
+      const int ri = n - 1 - i, rk = n - 1 - k;
+      U[idx] = 0.5 * (Wo[(size_t)ri * n + rk] + Wo[(size_t)rk * n + ri]);
+    }
+    __syncthreads();
+    factor_utu(U, n, &sh_bad, &sh_piv);
+    // M = J U~ J  (lower triangular):  M[i][j] = U~[n-1-i][n-1-j], j <= i
+    for (long long idx = tid; idx < (long long)n * n; idx += blockDim.x) {
+      const int i = (int)(idx / n), j = (int)(idx % n);
+      Fo[idx] = j <= i ? U[(size_t)(n - 1 - i) * n + (n - 1 - j)] : 0.0;
+    }
+  } else {
+    const double sf2 = sf2v[o], sn2 = sn2v[o];
+    const double* Ao = As + (size_t)o * npad * dpad;
+    const double* so = sqA + (size_t)o * npad;
+    // K[i][k] = sf2 exp(-1/2 dist(i, k)) + sn2 [i == k], dist as GP_Safe.py:119 evaluates it; the lower element (i >= k)
+    // is the one a lower Cholesky reads, stored here at the transposed (upper) position
+    for (long long idx = tid; idx < (long long)n * n; idx += blockDim.x) {
+      const int k = (int)(idx / n), i = (int)(idx % n);      // upper position (k, i), k <= i
+      if (i < k) continue;
+      double dot = 0.0;
+      for (int a = 0; a < d; ++a) dot += Ao[(size_t)i * dpad + a] * Ao[(size_t)k * dpad + a];
+      const double dist = (-2.0 * dot + so[i]) + so[k];
+      U[idx] = sf2 * exp(-0.5 * dist) + (i == k ? sn2 : 0.0);
+    }
+    for (long long idx = tid; idx < (long long)n * n; idx += blockDim.x) Fo[idx] = 0.0;
+    __syncthreads();
+    factor_utu(U, n, &sh_bad, &sh_piv, Fo);       // Fo = L^-1 = M
+    // alpha = M^T (M rhs)
+    double* t = U;                                            // scratch: the factor is no longer needed
+    for (int i = tid; i < n; i += blockDim.x) {
+      double s = 0.0;
+      for (int j = 0; j <= i; ++j) s += Fo[(size_t)i * n + j] * r[j];
+      t[i] = s;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += blockDim.x) {
+      double s = 0.0;
+      for (int i = j; i < n; ++i) s += Fo[(size_t)i * n + j] * t[i];
+      alpha[(size_t)o * npad + j] = s;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) bad[o] = sh_bad;
+}
+
+// lower-triangular factor [q][n][n] -> matrix-core A-fragment images [q][tri(I, J)][256] in the model dtype
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_factor(const double* __restrict__ F, int n, int nb, size_t fpk_stride,
+                                                     T* __restrict__ Fpk) {
+  const int o = blockIdx.y;
+  const size_t ntri = (size_t)nb * (nb + 1) / 2;
+  const double* Fo = F + (size_t)o * n * n;
+  T* dst = Fpk + (size_t)o * fpk_stride;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ntri * 256; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = idx >> 8;
+    const int e = (int)(idx & 255);
+    // block (I, J) of the triangle from its linear index
+    int I = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
+    while ((size_t)(I + 1) * (I + 2) / 2 <= blk) ++I;
+    while ((size_t)I * (I + 1) / 2 > blk) --I;
+    const int J = (int)(blk - (size_t)I * (I + 1) / 2);
+    int r, k, kk;
+    MM<T>::unpack_pos(e, r, k, kk);
+    const int row = 16 * I + r, col = 16 * J + MM<T>::jslot(kk, k);
+    dst[idx] = (row < n && col < n && col <= row) ? (T)Fo[(size_t)row * n + col] : T(0);
+  }
+}
+
+template <typename T>
+__global__ void k_cast(const double* __restrict__ src, size_t nelem, T* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nelem; i += (size_t)gridDim.x * blockDim.x) dst[i] = (T)src[i];
+}
+
+// Device side of sbo_model_set.  host_invK may be NULL (the library factors K itself).  On success Fpk (dtype T) and
+// alpha (dtype T, device) are in place and h_alpha holds the fp64 alpha for the K1b table build.
+template <typename T>
+static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<double>& As, const std::vector<double>& sqA,
+                         const std::vector<double>& rhs, const double* sn2) {
+  const ModelConst& mc = c->mc;
+  const int n = mc.n, npad = mc.npad, q = mc.q, nb = npad / 16;
+  const size_t nn = (size_t)n * n;
+  int rc;
+  // workspace: [W | work | F] (q n^2 each) + As + sqA + rhs + sf2 + sn2 + alpha + bad
+  const size_t small = (size_t)q * npad * mc.dpad + (size_t)q * npad + (size_t)q * n + 2 * (size_t)q + (size_t)q * npad;
+  if ((rc = ensure(c->fitwork, sizeof(double) * (3 * q * nn + small) + sizeof(int) * q))) return rc;
+  double* dW = (double*)c->fitwork.p;
+  double* dwork = dW + q * nn;
+  double* dF = dwork + q * nn;
+  double* dAs = dF + q * nn;
+  double* dsq = dAs + (size_t)q * npad * mc.dpad;
+  double* drhs = dsq + (size_t)q * npad;
+  double* dsf2 = drhs + (size_t)q * n;
+  double* dsn2 = dsf2 + q;
+  double* dalpha = dsn2 + q;
+  int* dbad = (int*)(dalpha + (size_t)q * npad);
+  if (host_invK) SBO_HIP(hipMemcpyAsync(dW, host_invK, sizeof(double) * q * nn, hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(dAs, As.data(), sizeof(double) * As.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(dsq, sqA.data(), sizeof(double) * sqA.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(drhs, rhs.data(), sizeof(double) * rhs.size(), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(dsf2, mc.sf2, sizeof(double) * q, hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(dsn2, sn2, sizeof(double) * q, hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemsetAsync(dalpha, 0, sizeof(double) * (size_t)q * npad, c->stream));
+  hipLaunchKernelGGL(k_model_build, dim3(q), dim3(1024), 0, c->stream, host_invK ? 0 : 1, n, npad, mc.dpad, mc.d, (const double*)dW,
+                     (const double*)dAs, (const double*)dsq, (const double*)drhs, (const double*)dsf2, (const double*)dsn2, dwork, dF,
+                     dalpha, dbad);
+  const size_t ntri = (size_t)nb * (nb + 1) / 2;
+  c->fpk_stride = ntri * 4 * 64;
+  if ((rc = ensure(c->Fpk, sizeof(T) * ((size_t)q * c->fpk_stride + 512)))) return rc;   // + padding: the K1g pipeline over-reads
+  SBO_HIP(hipMemsetAsync(c->Fpk.p, 0, sizeof(T) * ((size_t)q * c->fpk_stride + 512), c->stream));
+  hipLaunchKernelGGL((k_pack_factor<T>), dim3((unsigned)std::min<size_t>((ntri * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
+                     (const double*)dF, n, nb, c->fpk_stride, (T*)c->Fpk.p);
+  if ((rc = ensure(c->alpha, sizeof(T) * (size_t)q * npad))) return rc;
+  hipLaunchKernelGGL((k_cast<T>), dim3(16), dim3(256), 0, c->stream, (const double*)dalpha, (size_t)q * npad, (T*)c->alpha.p);
+  SBO_HIP(hipGetLastError());
+  std::vector<int> hbad(q, 0);
+  c->h_alpha.assign((size_t)q * npad, 0.0);
+  SBO_HIP(hipMemcpyAsync(hbad.data(), dbad, sizeof(int) * q, hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->h_alpha.data(), dalpha, sizeof(double) * (size_t)q * npad, hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  for (int o = 0; o < q; ++o)
+    if (hbad[o]) return fail(SBO_E_INVALID, host_invK ? "invK is not positive definite" : "K + sn2 I is not positive definite");
+  return SBO_OK;
+}
+
+int model_build(sbo_ctx* c, const double* host_invK, const std::vector<double>& As, const std::vector<double>& sqA,
+                const std::vector<double>& rhs, const double* sn2) {
+  return c->dtype == SBO_F64 ? model_build_t<double>(c, host_invK, As, sqA, rhs, sn2)
+                             : model_build_t<float>(c, host_invK, As, sqA, rhs, sn2);
+}
+
+}  // namespace sbo

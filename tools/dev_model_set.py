@@ -1,0 +1,14 @@
+"""Developer driver: sbo_model_set time (device factorisation) for a few n, both factor modes."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import safebo_amd
+from safebo_amd import synthetic
+eng = safebo_amd.SweepEngine(0)
+for name, n in (("B", 128), ("C", 256), ("H", 512), ("H", 1024), ("E", 2048)):
+    cfg = synthetic.make_config(name, n=n)
+    for use_invK in (True, False):
+        ts = []
+        for it in range(3):
+            t = time.perf_counter(); eng.set_model(cfg["ds"], dtype="f64", use_invK=use_invK); ts.append(time.perf_counter() - t)
+        print(f"{name} n={n} q={cfg['q']} use_invK={use_invK}: set_model {min(ts)*1e3:.1f} ms", flush=True)
