@@ -101,6 +101,10 @@ int sbo_init(int device_id, sbo_ctx** out) {
     e = hipEventCreate(&ev);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipEventCreate"); }
   }
+  if (hipHostMalloc((void**)&c->h_c1, sizeof(unsigned long long) * (1 + 2 * kMaxQ), hipHostMallocDefault) != hipSuccess) {
+    delete c;
+    return fail(SBO_E_HIP, "hipHostMalloc");
+  }
   int rc = ensure(c->Lmax, sizeof(unsigned long long) * kMaxQ);
   if (!rc) rc = ensure(c->scal, 4096);
   if (rc) { delete c; return rc; }
@@ -120,6 +124,7 @@ int sbo_shutdown(sbo_ctx* c) {
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
+  if (c->h_c1) (void)hipHostFree(c->h_c1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SBO_OK;

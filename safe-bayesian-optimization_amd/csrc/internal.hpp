@@ -108,7 +108,8 @@ struct sbo_ctx {
   long long grid_total = 0; // candidates in the whole grid (all ranks)
   bool sharded = false;     // candidates were set with the canonical plane sharding
   std::vector<long long> first_of;   // [world + 1] flat offsets of the rank shards
-  std::vector<unsigned long long> h_c1;   // host copy of the C1 keys (global u*, L, radius) of the running sweep
+  unsigned long long* h_c1 = nullptr;     // pinned host copy of the C1 keys (global u*, L, radius) of the running sweep
+  bool c1_pending = false;                // the read-back of h_c1 has been enqueued (event ev[5]) but not yet waited for
   int last_sweep = 0;  // 1 safeopt, 2 goose (what the masks hold)
   bool masks_valid = false;
   // profile

@@ -1447,6 +1447,8 @@ static int launch_exact_d(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lid
   return fail(SBO_E_UNSUPPORTED, "unsupported padded dimension");
 }
 
+static int sweep_exchange_wait(sbo_ctx* c);
+
 // G_c for constraint cidx (1..q-1) into G[n]
 template <typename T>
 static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* G) {
@@ -1474,6 +1476,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     long long p0 = c->world > 1 ? c->cs.first / plane : 0, p1 = p0 + n / plane;
     const long long own0 = p0;
     if (c->world > 1) {
+      if ((rc = sweep_exchange_wait(c))) return rc;
       double L, rmax = 0.0;
       memcpy(&L, &c->h_c1[1 + lidx], 8);
       if (c->h_c1[1 + kMaxQ + cidx]) rmax = ord_val(c->h_c1[1 + kMaxQ + cidx]);
@@ -1623,10 +1626,12 @@ static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U
   hipLaunchKernelGGL(k_pack_c1, dim3(1), dim3(64), 0, c->stream, (const SweepScalars*)sc, (const unsigned long long*)c->Lmax.p, kb);
   if ((rc = comm_allreduce_max_u64(c, kb, 1 + 2 * kMaxQ))) return rc;
   hipLaunchKernelGGL(k_unpack_c1, dim3(1), dim3(64), 0, c->stream, sc, (unsigned long long*)c->Lmax.p, (const unsigned long long*)kb);
-  // the host needs the global L and radius keys to size the halo of the expander transform
-  c->h_c1.assign(1 + 2 * kMaxQ, 0ull);
-  SBO_HIP(hipMemcpyAsync(c->h_c1.data(), kb, sizeof(unsigned long long) * (1 + 2 * kMaxQ), hipMemcpyDeviceToHost, c->stream));
-  SBO_HIP(hipStreamSynchronize(c->stream));
+  // the host needs the global L and radius keys to size the halo of the expander transform: the read-back goes to
+  // pinned memory and is waited for only where the window is computed (sweep_exchange_wait), so the mask all-gather
+  // and the minimiser kernels are already queued behind it and the GPU does not idle through the round trip
+  SBO_HIP(hipMemcpyAsync(c->h_c1, kb, sizeof(unsigned long long) * (1 + 2 * kMaxQ), hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipEventRecord(c->ev[5], c->stream));
+  c->c1_pending = true;
   if (need_U && q > 1) {
     // the mask travels as bits (one ballot word per 64 candidates): 8x fewer bytes on the links than the byte mask
     long long maxlocal = 0;
@@ -1647,6 +1652,14 @@ static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U
   return SBO_OK;
 }
 
+static int sweep_exchange_wait(sbo_ctx* c) {
+  if (c->c1_pending) {
+    SBO_HIP(hipEventSynchronize(c->ev[5]));
+    c->c1_pending = false;
+  }
+  return SBO_OK;
+}
+
 // C3 + host merge: every rank's slots and counters -> global ones.  slot_is_max[i] selects arg-max / arg-min.
 static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_max) {
   SweepScalars* sc = (SweepScalars*)c->scal.p;
@@ -1663,6 +1676,7 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipMemcpyAsync(rows.data(), buf, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
+  c->c1_pending = false;                       // (the whole stream has drained)
   h.count_S = h.count_U = h.count_M = h.n_amb_total = 0;
   for (int t = 0; t < kMaxQ; ++t) h.count_set[t] = 0;
   for (int t = 0; t < kArgSlots; ++t) { h.arg_idx[t] = -1; h.arg_val[t] = 0.0; }
@@ -1817,6 +1831,7 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     for (int a = 0; a < d - 1; ++a) plane *= c->cs.count[a];
     const long long planes_total = c->cs.count[d - 1];
     long long p0 = c->cs.first / plane, p1 = (c->cs.first + n + plane - 1) / plane;
+    if ((rc = sweep_exchange_wait(c))) return rc;
     double L, rmax = 0.0;
     memcpy(&L, &c->h_c1[1 + lidx], 8);
     if (c->h_c1[1 + kMaxQ + cidx]) rmax = ord_val(c->h_c1[1 + kMaxQ + cidx]);
