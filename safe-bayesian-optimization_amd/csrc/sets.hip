@@ -324,34 +324,51 @@ __global__ __launch_bounds__(256) void k_block_min(const double* __restrict__ Di
 __device__ __forceinline__ double edt_scan_blocked(const double* __restrict__ Din, const double* __restrict__ Bmin, long long p,
                                                    long long stride, int cnt, int ia, double h, double cap, double accept2,
                                                    int blk) {
+  // The few candidates that reach this scan decide the kernel's duration through their chain of dependent loads, so
+  // loads are issued in independent batches (eight block values / eight bounds at a time) and only then examined.
   double best = Din[(long long)ia * stride + p];
   const int nblk = (cnt + blk - 1) / blk, b0 = ia / blk;
   auto scan_block = [&](int b) {
     const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
-    for (int j = b * blk; j < j1; ++j) {
-      const double dt = h * (double)(j > ia ? j - ia : ia - j);
-      if (dt > cap) continue;
-      const double cnd = Din[(long long)j * stride + p] + dt * dt;
-      best = cnd < best ? cnd : best;
+    for (int j = b * blk; j < j1; j += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = j + u < j1 ? Din[(long long)(j + u) * stride + p] : kInfD;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int jj = j + u;
+        const double dt = h * (double)(jj > ia ? jj - ia : ia - jj);
+        const double cnd = v[u] + dt * dt;
+        if (dt <= cap && cnd < best) best = cnd;
+      }
     }
   };
   // gap (in steps) between ia and the nearest step of block b
   auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? ia - (b * blk + blk - 1) : b * blk - ia); };
+  auto bound_at = [&](int b) { return (b >= 0 && b < nblk) ? Bmin[(long long)b * stride + p] : kInfD; };
   // pass A: block with the smallest bound
   double lb_min = Bmin[(long long)b0 * stride + p];
   int b_min = b0;
-  for (int k = 1; k < nblk; ++k) {
+  for (int k0 = 1; k0 < nblk; k0 += 4) {
+    double lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { lo[u] = bound_at(b0 - k0 - u); hi[u] = bound_at(b0 + k0 + u); }
     bool any = false;
 #pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const int b = side ? b0 + k : b0 - k;
-      if (b < 0 || b >= nblk) continue;
-      const double dg = h * (double)gap_of(b);
-      const double e = dg * dg;
-      if (e >= best || e >= lb_min || dg > cap) continue;
-      any = true;
-      const double lb = Bmin[(long long)b * stride + p] + e;
-      if (lb < lb_min) { lb_min = lb; b_min = b; }
+    for (int u = 0; u < 4; ++u) {
+      any = false;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int b = side ? b0 + k0 + u : b0 - k0 - u;
+        if (b < 0 || b >= nblk) continue;
+        const double dg = h * (double)gap_of(b);
+        const double e = dg * dg;
+        if (e >= best || e >= lb_min || dg > cap) continue;
+        any = true;
+        const double lb = (side ? hi[u] : lo[u]) + e;
+        if (lb < lb_min) { lb_min = lb; b_min = b; }
+      }
+      if (!any) break;
     }
     if (!any) break;
   }
@@ -359,17 +376,25 @@ __device__ __forceinline__ double edt_scan_blocked(const double* __restrict__ Di
   if (best <= accept2) return best;
   // pass B: whatever can still improve
   if (b_min != b0 && Bmin[(long long)b0 * stride + p] < best) scan_block(b0);
-  for (int k = 1; k < nblk && !(best <= accept2); ++k) {
+  for (int k0 = 1; k0 < nblk && !(best <= accept2); k0 += 4) {
+    double lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { lo[u] = bound_at(b0 - k0 - u); hi[u] = bound_at(b0 + k0 + u); }
     bool any = false;
 #pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const int b = side ? b0 + k : b0 - k;
-      if (b < 0 || b >= nblk) continue;
-      const double dg = h * (double)gap_of(b);
-      const double e = dg * dg;
-      if (e >= best || dg > cap) continue;
-      any = true;
-      if (b != b_min && Bmin[(long long)b * stride + p] + e < best) scan_block(b);
+    for (int u = 0; u < 4; ++u) {
+      any = false;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int b = side ? b0 + k0 + u : b0 - k0 - u;
+        if (b < 0 || b >= nblk) continue;
+        const double dg = h * (double)gap_of(b);
+        const double e = dg * dg;
+        if (e >= best || dg > cap) continue;
+        any = true;
+        if (b != b_min && (side ? hi[u] : lo[u]) + e < best) scan_block(b);
+      }
+      if (!any) break;
     }
     if (!any) break;
   }
