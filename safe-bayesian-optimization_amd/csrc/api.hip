@@ -120,7 +120,7 @@ int sbo_shutdown(sbo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->Lmax, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->blockmin, &c->blockmax, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->blockmin, &c->blockmax, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -156,6 +156,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "bilinear")) {
     c->bilinear = value ? 1 : 0;
     c->posterior_valid = false;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "scan_waves")) {
+    c->scan_waves = value ? 1 : 0;
     return SBO_OK;
   }
   if (!strcmp(key, "scan_blocks")) {

@@ -97,6 +97,7 @@ struct sbo_ctx {
   sbo::DevBuf partial; // arg-reduce per-block partials
   sbo::DevBuf amb;     // ambiguous-index list for the exact recheck
   sbo::DevBuf runmeta; // GoOSE: per-run bounding boxes / radii of the coverage search
+  sbo::DevBuf scanlist; // candidates left open by the coarse expander decision (wave-per-candidate scan)
   sbo::DevBuf blockmax; // per-block largest source weight along axis 0 (blocked axis-0 pass of the power transform)
   sbo::DevBuf blockmin; // per-block minima along the last axis (blocked last-axis scans)
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
@@ -119,6 +120,7 @@ struct sbo_ctx {
   int k1_strips = 4;       // lines per K1g tile (4, or 8 for 2-D grids: tuning)
   int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
   int edt_tiled = 0;       // 1: LDS-tiled lock-step form of the last-axis expander scan (slower on measured configs)
+  int scan_waves = 1;      // 1: candidates the coarse bounds leave open are scanned one wave each (0: by their own thread)
   int scan_blocks = 1;     // 0: step-by-step last-axis scans (A/B against the blocked form)
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
   int bilinear = 1;        // 1: fp64 2-D grids run the posterior as two GEMMs in a reduced basis when the bases qualify (K1b)

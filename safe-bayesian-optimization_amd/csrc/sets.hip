@@ -34,6 +34,7 @@ struct SweepScalars {
   long long count_S, count_U, count_M;
   long long count_set[kMaxQ];              // |G_c| or |O_c|
   long long n_amb, n_amb_total;
+  long long n_scan;                        // candidates handed from the coarse decision to the wave-per-candidate scan
   double arg_val[kArgSlots];
   long long arg_idx[kArgSlots];
 };
@@ -479,7 +480,8 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
                                                     const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
                                                     uint8_t* __restrict__ G, long long* __restrict__ amb,
-                                                    const CoarseGrid cg, const double* __restrict__ Bmin, int blk) {
+                                                    const CoarseGrid cg, const double* __restrict__ Bmin, int blk,
+                                                    long long* __restrict__ scanlist) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const bool anyU = sc->count_U > 0;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
@@ -501,6 +503,13 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
           if (ucb - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { G[g] = 1; continue; }     // within the radius for sure
           if (ucb - L * (dlo - eps_abs - 1e-11 * dlo) < -tolc) { G[g] = 0; continue; }    // beyond it for sure
         }
+        if (scanlist && Bmin && cnt > 1) {
+          // the few candidates the coarse bounds leave open go to k_edt_scan_list (one wave each): a lane scanning
+          // here would hold its whole wave for a chain of ~100 dependent loads
+          scanlist[atomicAdd((unsigned long long*)&sc->n_scan, 1ull)] = g;
+          G[g] = 0;
+          continue;
+        }
         const int ia = (int)((gg / stride) % cnt);
         const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it the verdict is "sure true"
         const double acc2 = thr > 0 ? thr * thr : -1.0;
@@ -521,6 +530,103 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
       }
     }
     G[g] = out;
+  }
+}
+
+// Last-axis scan + verdict for the listed candidates, one group of GL lanes (half a wave or a wave, GL >= blk) per
+// candidate: the lanes take GL blocks (bounds) or the steps of one block at a time and combine with group minima -- the
+// same candidates and arithmetic as edt_scan_blocked, with the dependent-load chain cut from ~100 to ~5 per candidate.
+// (The two halves of a wave follow their own trip counts; every cross-lane operation stays inside one half.)
+template <typename T, int GL>
+__global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict__ Din, long long goff, long long stride, int cnt,
+                                                       double h, int d, double xscale, const T* __restrict__ mean_c,
+                                                       const T* __restrict__ var_c, T b, const unsigned long long* Lkeys, int lidx,
+                                                       SweepScalars* sc, uint8_t* __restrict__ G, long long* __restrict__ amb,
+                                                       const double* __restrict__ Bmin, int blk,
+                                                       const long long* __restrict__ scanlist) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const long long nscan = sc->n_scan;
+  const int lane = threadIdx.x & (GL - 1);
+  const int sub = (threadIdx.x & 63) / GL;
+  const long long ngroups = (long long)gridDim.x * (blockDim.x / GL);
+  const int nblk = (cnt + blk - 1) / blk;
+  auto group_min = [&](double v) {
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+  };
+  auto group_ballot = [&](bool pred) {
+    const unsigned long long m = __ballot(pred);
+    return GL == 64 ? m : ((m >> (32 * sub)) & 0xffffffffull);
+  };
+  for (long long qi = (long long)blockIdx.x * (blockDim.x / GL) + threadIdx.x / GL; qi < nscan; qi += ngroups) {
+    const long long g = scanlist[qi];
+    T lcb, ucbT;
+    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
+    const double ucb = (double)ucbT;
+    const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
+    const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
+    const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;
+    const double acc2 = thr > 0 ? thr * thr : -1.0;
+    const long long gg = goff + g, p = gg % stride;
+    const int ia = (int)((gg / stride) % cnt), b0 = ia / blk;
+    double best = Din[(long long)ia * stride + p];
+    // blocks within reach of the radius
+    const int kmax = (int)fmin((double)nblk, floor(cap / (h * (double)blk)) + 2.0);
+    const int blo = b0 - kmax > 0 ? b0 - kmax : 0, bhi = b0 + kmax < nblk - 1 ? b0 + kmax : nblk - 1;
+    auto bound_of = [&](int bb) {       // bound of block bb for this lane (inf outside the reach / the axis)
+      if (bb < blo || bb > bhi) return kInfD;
+      const int gap = bb == b0 ? 0 : (bb < b0 ? ia - (bb * blk + blk - 1) : bb * blk - ia);
+      const double dg = h * (double)gap;
+      if (dg > cap) return kInfD;
+      return Bmin[(long long)bb * stride + p] + dg * dg;
+    };
+    auto scan_block = [&](int bb) {     // the group: the (<= GL) steps of block bb
+      const int jn = bb * blk + lane;
+      double cnd = kInfD;
+      if (lane < blk && jn < cnt) {
+        const double dt = h * (double)(jn > ia ? jn - ia : ia - jn);
+        if (dt <= cap) cnd = Din[(long long)jn * stride + p] + dt * dt;
+      }
+      cnd = group_min(cnd);
+      best = cnd < best ? cnd : best;
+    };
+    // pass A: the block with the smallest bound
+    double lb_min = kInfD;
+    int b_min = -1;
+    for (int base = blo; base <= bhi; base += GL) {
+      const double lb = bound_of(base + lane);
+      const double m = group_min(lb);
+      if (m < lb_min) {
+        lb_min = m;
+        const unsigned long long who = group_ballot(lb == m);
+        b_min = base + (int)(__ffsll((long long)who) - 1);
+      }
+    }
+    if (b_min >= 0 && lb_min < best) scan_block(b_min);
+    // pass B: every other block whose bound still beats the running minimum
+    for (int base = blo; base <= bhi && !(best <= acc2); base += GL) {
+      const double lb = bound_of(base + lane);
+      unsigned long long todo = group_ballot(lb < best && base + lane != b_min);
+      while (todo && !(best <= acc2)) {
+        const int l = (int)(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const double lbl = __shfl(lb, l + GL * sub);
+        if (lbl < best) scan_block(base + l);
+      }
+    }
+    if (lane == 0) {
+      uint8_t out = 0;
+      if (best < 0.5 * kInfD) {
+        const double dm = sqrt(best);
+        const double eps = eps_abs + 1e-11 * dm;
+        const double tol = 1e-12 * (fabs(ucb) + L * dm);
+        const double lo = ucb - L * (dm + eps), hi = ucb - L * (dm - eps);
+        if (lo > tol) out = 1;
+        else if (hi >= -tol) amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
+      }
+      G[g] = out;
+    }
   }
 }
 
@@ -731,7 +837,7 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
   }
 }
 
-__global__ void k_reset_amb(SweepScalars* sc) { sc->n_amb = 0; }
+__global__ void k_reset_amb(SweepScalars* sc) { sc->n_amb = 0; sc->n_scan = 0; }
 
 // ---- multi-rank exchange -----------------------------------------------------------
 // C1: one max all-reduce of [~u*_key, L keys, radius keys]
@@ -1592,10 +1698,25 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
                            (const double*)din, stride, last_cnt, blk, (double*)c->blockmin.p);
         bmin = (const double*)c->blockmin.p;
       }
+      long long* slist = nullptr;
+      if (bmin && blk <= 64 && c->scan_waves) {
+        if ((rc = ensure(c->scanlist, sizeof(long long) * (size_t)n))) return rc;
+        slist = (long long*)c->scanlist.p;
+      }
       hipLaunchKernelGGL((k_edt_decide<T>), dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0,
                          c->stream, (const double*)din, n, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c,
                          (T)o->b, (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
-                         (long long*)c->amb.p, cg, bmin, blk);
+                         (long long*)c->amb.p, cg, bmin, blk, slist);
+      if (slist) {
+        if (blk <= 32)
+          hipLaunchKernelGGL((k_edt_scan_list<T, 32>), dim3(2048), dim3(256), 0, c->stream, (const double*)din, goff, stride, last_cnt,
+                             last_h, d, xscale, mean_c, var_c, (T)o->b, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
+                             (long long*)c->amb.p, bmin, blk, (const long long*)slist);
+        else
+          hipLaunchKernelGGL((k_edt_scan_list<T, 64>), dim3(2048), dim3(256), 0, c->stream, (const double*)din, goff, stride, last_cnt,
+                             last_h, d, xscale, mean_c, var_c, (T)o->b, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
+                             (long long*)c->amb.p, bmin, blk, (const long long*)slist);
+      }
     }
   } else {
     // explicit candidate lists, and grid ranges that are not whole hyper-planes: exhaustive evaluation
