@@ -549,6 +549,45 @@ def test_full_size_properties_config_B(engine):
     assert res2["minimizer_index"] == res["minimizer_index"] and np.array_equal(res2["count_G"], res["count_G"])
 
 
+def test_full_size_properties_config_H(engine):
+    """The headline configuration (4096^2 grid, n = 512, fp64) at full size on one GPU: the masks are exact functions of
+    the device posterior, the posterior matches the oracle on a random subset and the two posterior kernels agree on the
+    whole grid (linearity-free cross-check of 16.8 M values each)."""
+    cfg = synthetic.make_config("H")
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], cfg["count"]
+    N = count[0] * count[1]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    res = engine.sweep_safeopt(cfg["b"], want_masks=True)
+    assert engine.profile()["posterior_kernel"] == 4
+    lcb1, lcb0, ucb0, var0 = (engine.bounds(cfg["b"], 1, "lcb"), engine.bounds(cfg["b"], 0, "lcb"),
+                              engine.bounds(cfg["b"], 0, "ucb"), engine.bounds(cfg["b"], 0, "var"))
+    S, U, M, G = engine.mask("S"), engine.mask("U"), engine.mask("M"), engine.mask("G", 1)
+    assert np.array_equal(S, lcb1 >= 0) and np.array_equal(U, lcb1 <= 0)
+    assert res["u_star"] == ucb0[S].min() and np.array_equal(M, S & (lcb0 <= res["u_star"]))
+    assert res["minimizer_index"] == int(np.argmax(np.where(M, var0, -np.inf)))
+    assert res["expander_index_c"][0] == int(np.argmax(np.where(G, var0, -np.inf)))
+    assert not (G & ~S).any() and (res["count_S"], res["count_M"], res["count_G"][0]) == (S.sum(), M.sum(), G.sum())
+    mean, var = engine.posterior()
+    rng = np.random.default_rng(6)
+    sub = np.sort(rng.choice(N, size=2048, replace=False))
+    ax = oracle.grid_axes(lo, hi, count)
+    pts_sub = np.stack([ax[0][sub % count[0]], ax[1][sub // count[0]]], axis=1)
+    om, ov = oracle.gp_inference(pts_sub, cfg["ds"])
+    assert _nerr(mean[sub], om, cfg["ds"]["Y_std"], 1) < TOL64 and _nerr(var[sub], ov, cfg["ds"]["Y_std"], 2) < TOL64
+    engine.set_option("bilinear", 0)
+    try:
+        res_t = engine.sweep_safeopt(cfg["b"])
+        assert engine.profile()["posterior_kernel"] == 3
+        m_t, v_t = engine.posterior()
+    finally:
+        engine.set_option("bilinear", 1)
+    ystd = np.maximum(1.0, cfg["ds"]["Y_std"])
+    assert np.max(np.abs(mean - m_t) / ystd) < 1e-11 and np.max(np.abs(var - v_t) / ystd ** 2) < 1e-11
+    assert res_t["minimizer_index"] == res["minimizer_index"] and res_t["count_S"] == res["count_S"]
+    assert np.array_equal(res_t["count_G"], res["count_G"])
+
+
 @pytest.mark.parametrize("cfg_name,n,count", [("B", 128, [384, 320]), ("C", 64, [352, 416]), ("D", 128, [36, 34, 33, 32])])
 def test_goose_transform_equals_pair_evaluation_with_coarse_bounds(engine, cfg_name, n, count):
     """Grids large enough for the coarse cell bounds of the power-distance transform: the optimistic sets must be the
