@@ -117,6 +117,39 @@ def test_bilinear_posterior_matches_oracle_and_table_kernel(engine, cfg_name, n,
         assert r1["minimizer_index"] == r0["minimizer_index"] and r1["count_S"] == r0["count_S"]
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_posterior_over_the_hyper_parameter_range(engine, seed):
+    """Random hyper-parameters inside the reference's search box (models/GP_Safe.py:205-206: log length-scales and log
+    signal std in [-1.5, 1.5]; the noise kept at log std >= -3 so that cond(K) stays below ~1e6 and the 1e-10 bar is about
+    the kernels, not about the conditioning of the reference formula), random n and grid: whichever posterior kernel the
+    library picks must match the oracle, and the two grid kernels must agree with each other."""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(30, 300))
+    cfg = synthetic.make_config("B", n=n, seed=1000 + seed)
+    hyp = np.empty((4, 2))
+    hyp[:2] = rng.uniform(-1.0, 1.5, size=(2, 2))
+    hyp[2] = rng.uniform(-1.0, 1.0, size=2)
+    hyp[3] = rng.uniform(-3.0, -2.0, size=2)
+    ds = synthetic.make_dataset(cfg["X"], cfg["Y"], hyp)
+    count = [int(rng.integers(70, 150)), int(rng.integers(70, 150))]
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_model(ds)
+    engine.set_grid(lo, hi, count)
+    mean, var = _check_posterior(engine, ds, pts, TOL64)
+    kernel = engine.profile()["posterior_kernel"]
+    assert kernel in (3, 4)
+    if kernel == 4:
+        engine.set_option("bilinear", 0)
+        try:
+            engine.posterior_run()
+            m_t, v_t = engine.posterior()
+        finally:
+            engine.set_option("bilinear", 1)
+        ystd = np.maximum(1.0, ds["Y_std"])
+        assert np.max(np.abs(mean - m_t) / ystd) < TOL64 and np.max(np.abs(var - v_t) / ystd ** 2) < TOL64
+
+
 def test_bilinear_rank_range_and_declines(engine):
     """Short length-scales need larger bases (r up to 64, inner dimension up to 2080): still the GEMM path when that is
     cheaper than the O(n^2) contraction (n = 512 here), and still within tolerance.  Bases beyond 64 directions, grids on
