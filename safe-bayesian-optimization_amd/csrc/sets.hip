@@ -1191,6 +1191,101 @@ __global__ __launch_bounds__(256) void k_block_max_w(const T* __restrict__ W, lo
   }
 }
 
+// blocked axis-0 scan of one position i of a line: Wl = the line's source weights, Bl = largest weight per block of
+// `blk` positions (global or LDS pointers).  `best` comes in as the position's own value.
+template <typename TW>
+__device__ __forceinline__ double pdt_axis0_point(const TW* Wl, const TW* Bl, int count0, int nblk, int i, double h0,
+                                                  const PdtParams& pp, int blk, double best) {
+  const int b0 = i / blk;
+  auto scan_block = [&](int b) {
+    const int j1 = (b + 1) * blk < count0 ? (b + 1) * blk : count0;
+    for (int j = b * blk; j < j1; ++j) {
+      const double wj = (double)Wl[j];
+      if (wj >= 0.0) {
+        const double dt = h0 * (double)(j > i ? j - i : i - j), r = wj * pp.invL;
+        const double cnd = dt * dt - r * r;
+        best = cnd < best ? cnd : best;
+      }
+    }
+  };
+  auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? i - (b * blk + blk - 1) : b * blk - i); };
+  auto bound_of = [&](int b, double e) {
+    const double wb = (double)Bl[b];
+    if (!(wb >= 0.0)) return kInfD;
+    const double r = wb * pp.invL;
+    return e - r * r;
+  };
+  double lb_min = bound_of(b0, 0.0);
+  int b_min = b0;
+  for (int k = 1; k < nblk; ++k) {
+    bool any = false;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int b = side ? b0 + k : b0 - k;
+      if (b < 0 || b >= nblk) continue;
+      const double dg = h0 * (double)gap_of(b);
+      const double e = dg * dg, floor_ = e - pp.rmax2;
+      if (floor_ > pp.band || floor_ >= best || floor_ >= lb_min) continue;
+      any = true;
+      const double lb = bound_of(b, e);
+      if (lb < lb_min) { lb_min = lb; b_min = b; }
+    }
+    if (!any) break;
+  }
+  if (lb_min < best) scan_block(b_min);
+  if (b_min != b0 && bound_of(b0, 0.0) < best) scan_block(b0);
+  for (int k = 1; k < nblk; ++k) {
+    bool any = false;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int b = side ? b0 + k : b0 - k;
+      if (b < 0 || b >= nblk) continue;
+      const double dg = h0 * (double)gap_of(b);
+      const double e = dg * dg, floor_ = e - pp.rmax2;
+      if (floor_ > pp.band || floor_ >= best) continue;
+      any = true;
+      if (b != b_min && bound_of(b, e) < best) scan_block(b);
+    }
+    if (!any) break;
+  }
+  return best;
+}
+
+// The same pass with one workgroup per grid line: the line's weights (count0 <= 8192 doubles) and its block maxima sit in
+// LDS, so the dependent loads of a position's scan cost an LDS round trip instead of an L2 / HBM one.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pdt_axis0_lds(const T* __restrict__ W, long long nlines, int count0, double h0,
+                                                       const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx,
+                                                       int d, double xscale, const CoarseGrid cg, const double* __restrict__ PcLo,
+                                                       int blk, double* __restrict__ P) {
+  extern __shared__ double lds_w[];            // [count0] weights as double | [nblk] block maxima
+  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
+  const int nblk = (count0 + blk - 1) / blk;
+  double* Wl = lds_w;
+  double* Bl = lds_w + count0;
+  for (long long line = blockIdx.x; line < nlines; line += gridDim.x) {
+    const long long g0 = line * count0;
+    __syncthreads();                           // the previous line's scans are done with the buffers
+    for (int i = threadIdx.x; i < count0; i += blockDim.x) Wl[i] = (double)W[g0 + i];
+    __syncthreads();
+    for (int bb = threadIdx.x; bb < nblk; bb += blockDim.x) {
+      const int j1 = (bb + 1) * blk < count0 ? (bb + 1) * blk : count0;
+      double m = -INFINITY;
+      for (int j = bb * blk; j < j1; ++j) m = Wl[j] > m ? Wl[j] : m;
+      Bl[bb] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < count0; i += blockDim.x) {
+      const long long g = g0 + i;
+      if (cg.enabled && PcLo[coarse_cell(cg, g)] > pp.band) { P[g] = kInfD; continue; }
+      const double w = Wl[i];
+      double best = kInfD;
+      if (w >= 0.0) { const double r = w * pp.invL; best = -(r * r); }
+      P[g] = pdt_axis0_point((const double*)Wl, (const double*)Bl, count0, nblk, i, h0, pp, blk, best);
+    }
+  }
+}
+
 // axis 0, reading the source weights directly.  With Bmax (per-block largest weight = smallest F) the scan is blocked
 // like the last-axis ones: a block whose bound (h gap)^2 - r_block^2 cannot beat the running minimum costs one load,
 // the block with the smallest bound is visited first.  Same candidates and arithmetic as the step-by-step scan.
@@ -1227,60 +1322,7 @@ __global__ __launch_bounds__(256) void k_pdt_axis0(const T* __restrict__ W, long
       P[g] = best;
       continue;
     }
-    const T* Wl = W + (g - i);                           // this line
-    const T* Bl = Bmax + (g / count0) * nblk;
-    const int b0 = i / blk;
-    auto scan_block = [&](int b) {
-      const int j1 = (b + 1) * blk < count0 ? (b + 1) * blk : count0;
-      for (int j = b * blk; j < j1; ++j) {
-        const double wj = (double)Wl[j];
-        if (wj >= 0.0) {
-          const double dt = h0 * (double)(j > i ? j - i : i - j), r = wj * pp.invL;
-          const double cnd = dt * dt - r * r;
-          best = cnd < best ? cnd : best;
-        }
-      }
-    };
-    auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? i - (b * blk + blk - 1) : b * blk - i); };
-    auto bound_of = [&](int b, double e) {
-      const double wb = (double)Bl[b];
-      if (!(wb >= 0.0)) return kInfD;
-      const double r = wb * pp.invL;
-      return e - r * r;
-    };
-    double lb_min = bound_of(b0, 0.0);
-    int b_min = b0;
-    for (int k = 1; k < nblk; ++k) {
-      bool any = false;
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const int b = side ? b0 + k : b0 - k;
-        if (b < 0 || b >= nblk) continue;
-        const double dg = h0 * (double)gap_of(b);
-        const double e = dg * dg, floor_ = e - pp.rmax2;
-        if (floor_ > pp.band || floor_ >= best || floor_ >= lb_min) continue;
-        any = true;
-        const double lb = bound_of(b, e);
-        if (lb < lb_min) { lb_min = lb; b_min = b; }
-      }
-      if (!any) break;
-    }
-    if (lb_min < best) scan_block(b_min);
-    if (b_min != b0 && bound_of(b0, 0.0) < best) scan_block(b0);
-    for (int k = 1; k < nblk; ++k) {
-      bool any = false;
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const int b = side ? b0 + k : b0 - k;
-        if (b < 0 || b >= nblk) continue;
-        const double dg = h0 * (double)gap_of(b);
-        const double e = dg * dg, floor_ = e - pp.rmax2;
-        if (floor_ > pp.band || floor_ >= best) continue;
-        any = true;
-        if (b != b_min && bound_of(b, e) < best) scan_block(b);
-      }
-      if (!any) break;
-    }
+    best = pdt_axis0_point(W + (g - i), Bmax + (g / count0) * nblk, count0, nblk, i, h0, pp, blk, best);
     P[g] = best;
   }
 }
@@ -2057,16 +2099,26 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     }
     const T* wbmax = nullptr;
     const int blk0 = 32;
-    if (c->scan_blocks && count0 >= 16 * blk0) {
-      const long long nbw = (nt / count0) * ((count0 + blk0 - 1) / blk0);
-      if ((rc = ensure(c->blockmax, sizeof(T) * (size_t)nbw))) return rc;
-      hipLaunchKernelGGL((k_block_max_w<T>), dim3((unsigned)std::min<long long>((nbw + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
-                         Wwin, nt, count0, blk0, (T*)c->blockmax.p);
-      wbmax = (const T*)c->blockmax.p;
+    if (c->scan_blocks && count0 >= 16 * blk0 && count0 <= 8192 && nt / count0 >= 2048) {
+      // one workgroup per line, the line in LDS (pays once there are enough lines to fill the chip: measured on 1024^2 it
+      // loses to the thread-per-position kernel, on 2048^2 it wins)
+      const size_t lds = sizeof(double) * ((size_t)count0 + (count0 + blk0 - 1) / blk0);
+      SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pdt_axis0_lds<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_pdt_axis0_lds<T>), dim3((unsigned)std::min<long long>(nt / count0, 1 << 16)), dim3(256), lds, c->stream, Wwin,
+                         nt / count0, count0, c->cs.step[0], (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, d,
+                         xscale, cg, pc_lo, blk0, (double*)c->dist2.p);
+    } else {
+      if (c->scan_blocks && count0 >= 16 * blk0) {
+        const long long nbw = (nt / count0) * ((count0 + blk0 - 1) / blk0);
+        if ((rc = ensure(c->blockmax, sizeof(T) * (size_t)nbw))) return rc;
+        hipLaunchKernelGGL((k_block_max_w<T>), dim3((unsigned)std::min<long long>((nbw + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+                           Wwin, nt, count0, blk0, (T*)c->blockmax.p);
+        wbmax = (const T*)c->blockmax.p;
+      }
+      hipLaunchKernelGGL((k_pdt_axis0<T>), dim3(gridn), dim3(256), 0, c->stream, Wwin, nt, count0, c->cs.step[0],
+                         (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, d, xscale, cg, pc_lo, wbmax,
+                         blk0, (double*)c->dist2.p);
     }
-    hipLaunchKernelGGL((k_pdt_axis0<T>), dim3(gridn), dim3(256), 0, c->stream, Wwin, nt, count0, c->cs.step[0],
-                       (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, d, xscale, cg, pc_lo, wbmax,
-                       blk0, (double*)c->dist2.p);
     double* pin = (double*)c->dist2.p;
     double* pout = (double*)c->dist2b.p;
     long long stride = count0;
