@@ -128,25 +128,23 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
   __syncthreads();
   unsigned long long umin = ~0ull;
   long long cS = 0, cU = 0;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+  auto one = [&](long long g, const T* mv /* [2 * q]: mean_c, var_c of this candidate */) {
     bool s = true, u = true;
     T ucbc[kMaxQ];                                  // kept for the radius keys: one sqrt per (candidate, constraint)
 #pragma unroll
     for (int c = 1; c < kMaxQ; ++c) {
       if (c < q) {
         T lcb;
-        lcb_ucb(mean[(size_t)c * n + g], var[(size_t)c * n + g], b, lcb, ucbc[c]);
+        lcb_ucb(mv[2 * c], mv[2 * c + 1], b, lcb, ucbc[c]);
         s = s && (lcb >= T(0));
         u = u && (lcb <= T(0));
       }
     }
-    S[g] = s;
-    U[g] = u;
     cS += s;
     cU += u;
     if (s) {
       T lcb, ucb;
-      lcb_ucb(mean[g], var[g], b, lcb, ucb);
+      lcb_ucb(mv[0], mv[1], b, lcb, ucb);
       const unsigned long long k = ord_key((double)ucb);
       umin = k < umin ? k : umin;
 #pragma unroll
@@ -156,6 +154,38 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
           if (kc > rmax_sh[c]) atomicMax(&rmax_sh[c], kc);
         }
       }
+    }
+    return (unsigned)(s ? 1u : 0u) | (unsigned)(u ? 2u : 0u);
+  };
+  // two consecutive candidates per thread: the q mean / var streams are read with 16-byte (fp64) / 8-byte (fp32) loads
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  const long long npair = n >> 1;
+  const bool aligned = (n & 1) == 0;               // output c starts at c * n elements: pairs stay aligned only for even n
+  if (aligned) {
+    for (long long pi = (long long)blockIdx.x * blockDim.x + threadIdx.x; pi < npair; pi += (long long)gridDim.x * blockDim.x) {
+      T mv0[2 * kMaxQ], mv1[2 * kMaxQ];
+#pragma unroll
+      for (int c = 0; c < kMaxQ; ++c) {
+        if (c < q) {
+          const T2 m2 = *reinterpret_cast<const T2*>(mean + (size_t)c * n + 2 * pi);
+          const T2 v2 = *reinterpret_cast<const T2*>(var + (size_t)c * n + 2 * pi);
+          mv0[2 * c] = m2[0]; mv0[2 * c + 1] = v2[0];
+          mv1[2 * c] = m2[1]; mv1[2 * c + 1] = v2[1];
+        }
+      }
+      const unsigned r0 = one(2 * pi, mv0), r1 = one(2 * pi + 1, mv1);
+      *reinterpret_cast<unsigned short*>(S + 2 * pi) = (unsigned short)((r0 & 1u) | ((r1 & 1u) << 8));
+      *reinterpret_cast<unsigned short*>(U + 2 * pi) = (unsigned short)(((r0 >> 1) & 1u) | (((r1 >> 1) & 1u) << 8));
+    }
+  } else {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+      T mv[2 * kMaxQ];
+#pragma unroll
+      for (int c = 0; c < kMaxQ; ++c)
+        if (c < q) { mv[2 * c] = mean[(size_t)c * n + g]; mv[2 * c + 1] = var[(size_t)c * n + g]; }
+      const unsigned r = one(g, mv);
+      S[g] = (uint8_t)(r & 1u);
+      U[g] = (uint8_t)((r >> 1) & 1u);
     }
   }
   umin = block_ext_u64<false>(umin);
@@ -900,6 +930,9 @@ __global__ void k_pack_c3(const SweepScalars* sc, double* buf, int world, int ra
   if (t < kMaxQ) row[2 * kArgSlots + 4 + t] = (double)sc->count_set[t];
 }
 __global__ void k_init_scalars(SweepScalars* sc) {
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(sc);       // (the struct is a multiple of 8 bytes)
+  for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) w[i] = 0ull;
+  __syncthreads();
   if (threadIdx.x == 0) sc->ustar_key = ~0ull;
   if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
 }
@@ -1562,7 +1595,7 @@ __global__ void k_dist_to(const CandSpec cs, long long n, const double* __restri
 // ---- host orchestration -------------------------------------------------------------------------------
 static int reduce_blocks(const sbo_ctx* c) {
   const long long n = c->cs.n_local;
-  return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8));
+  return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));   // (per-block reduction tails cost more than extra grid-stride turns: x4 measured best)
 }
 
 template <typename T>
@@ -1581,10 +1614,10 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o) {
   const int nb = reduce_blocks(c);
   if ((rc = ensure(c->partial, sizeof(Best) * (size_t)nb))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
-  SBO_HIP(hipMemsetAsync(sc, 0, sizeof(SweepScalars), c->stream));
   hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(64), 0, c->stream, sc);
   if (n > 0)
-    hipLaunchKernelGGL(k_classify<T>, dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
+    hipLaunchKernelGGL(k_classify<T>, dim3((unsigned)std::max(1, std::min(nb, c->n_cu * 2))), dim3(256), 0, c->stream,
+                       (const T*)c->mean.p, (const T*)c->var.p, n, q,
                        (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, sc);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
