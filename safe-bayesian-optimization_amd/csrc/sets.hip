@@ -1882,10 +1882,14 @@ static int sweep_exchange_wait(sbo_ctx* c) {
 }
 
 // C3 + host merge: every rank's slots and counters -> global ones.  slot_is_max[i] selects arg-max / arg-min.
-static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_max) {
+static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_max, unsigned long long* Lk = nullptr,
+                               hipEvent_t done_ev = nullptr) {
   SweepScalars* sc = (SweepScalars*)c->scal.p;
+  // (the Lipschitz keys ride in the same read-back: one synchronisation per sweep)
+  if (Lk) SBO_HIP(hipMemcpyAsync(Lk, c->Lmax.p, sizeof(unsigned long long) * kMaxQ, hipMemcpyDeviceToHost, c->stream));
   if (c->world <= 1) {
     SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
     SBO_HIP(hipStreamSynchronize(c->stream));
     return SBO_OK;
   }
@@ -1896,6 +1900,7 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   std::vector<double> rows((size_t)c->world * kC3Row);
   SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipMemcpyAsync(rows.data(), buf, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, c->stream));
+  if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
   c->c1_pending = false;                       // (the whole stream has drained)
   h.count_S = h.count_U = h.count_M = h.n_amb_total = 0;
@@ -1956,11 +1961,8 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   SweepScalars h;
   bool is_max[kArgSlots];
   for (int t = 0; t < kArgSlots; ++t) is_max[t] = true;
-  if ((rc = sweep_exchange_back(c, h, is_max))) return rc;
-  SBO_HIP(hipEventRecord(c->ev[4], c->stream));
   unsigned long long Lk[kMaxQ];
-  SBO_HIP(hipMemcpyAsync(Lk, c->Lmax.p, sizeof(Lk), hipMemcpyDeviceToHost, c->stream));
-  SBO_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = sweep_exchange_back(c, h, is_max, Lk, c->ev[4]))) return rc;
   c->masks_valid = true;
   c->last_sweep = 1;
 
