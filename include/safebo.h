@@ -220,7 +220,7 @@ int sbo_nll_batch(sbo_ctx* ctx, int n, int d, const double* X_norm, const double
 int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
 /* tuning / diagnostics knobs: "posterior_path" (0 auto, 1 generic single-phase, 2 generic chunked), "bilinear" (1 default:
  * fp64 2-D grids run the posterior as two GEMMs in a reduced basis when that is cheaper; 0: always the separable-table
- * kernel), "k1_wgs_per_cu", "k1_strips" (4 | 8), "edt_tiled" (0 | 1), "scan_blocks" (1 default: blocked last-axis scans),
+ * kernel), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
  * "goose_pairs" (1: pair evaluation instead of the transform on grids) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
 

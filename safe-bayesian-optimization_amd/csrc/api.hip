@@ -149,10 +149,6 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->k1_wgs_per_cu = (int)value;
     return SBO_OK;
   }
-  if (!strcmp(key, "edt_tiled")) {
-    c->edt_tiled = value ? 1 : 0;
-    return SBO_OK;
-  }
   if (!strcmp(key, "bilinear")) {
     c->bilinear = value ? 1 : 0;
     c->posterior_valid = false;

@@ -119,7 +119,6 @@ struct sbo_ctx {
   // options
   int k1_strips = 4;       // lines per K1g tile (4, or 8 for 2-D grids: tuning)
   int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
-  int edt_tiled = 0;       // 1: LDS-tiled lock-step form of the last-axis expander scan (slower on measured configs)
   int scan_waves = 1;      // 1: candidates the coarse bounds leave open are scanned one wave each (0: by their own thread)
   int scan_blocks = 1;     // 0: step-by-step last-axis scans (A/B against the blocked form)
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)

@@ -660,121 +660,6 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict_
   }
 }
 
-// Tiled form of the last-axis scan + decision: a workgroup owns 64 consecutive in-plane positions x 16 steps of the
-// last axis and walks the scan distance t outwards in lock step.  The two rows that enter the search window at each
-// step are fetched once per workgroup into LDS rings and shared by the 16 query rows, instead of every query
-// loading its own two values: 16x fewer global load instructions on a pass that is bound by their issue.
-// Same arithmetic and the same exits as edt_scan_point, so the result is identical.
-template <typename T>
-__global__ __launch_bounds__(256) void k_edt_decide_tiled(const double* __restrict__ Din, long long n, long long goff,
-                                                          long long stride, int cnt, double h, int d, double xscale,
-                                                          const T* __restrict__ mean_c, const T* __restrict__ var_c, T b,
-                                                          const uint8_t* __restrict__ S, const unsigned long long* Lkeys,
-                                                          int lidx, SweepScalars* sc, uint8_t* __restrict__ G,
-                                                          long long* __restrict__ amb) {
-  constexpr int RQ = 16, RING = 32;
-  __shared__ double lowb[RING][64], upb[RING][64];
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const bool anyU = sc->count_U > 0;
-  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const long long npb = (stride + 63) / 64;
-  const long long pb = blockIdx.x % npb, jb = blockIdx.x / npb;
-  const long long p = pb * 64 + col;
-  const bool pok = p < stride;
-  const long long jfirst = goff / stride, jend = (goff + n) / stride;   // own rows of the last axis (whole planes)
-  const long long j0 = jfirst + jb * RQ;
-  const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
-
-  double best[4], cap[4], ucbv[4], acc2[4];
-  bool act[4], query[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const long long j = j0 + rg * 4 + k;
-    act[k] = query[k] = false;
-    best[k] = kInfD;
-    cap[k] = 0.0;
-    ucbv[k] = 0.0;
-    acc2[k] = -1.0;
-    if (pok && j < jend) {
-      const long long g = j * stride + p - goff;
-      if (S[g] && anyU) {
-        T lcb, ucbT;
-        lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
-        ucbv[k] = (double)ucbT;
-        query[k] = true;
-        if (L > 0) {
-          cap[k] = ucbv[k] / L + 4.0 * eps_abs + 1e-9 * fabs(ucbv[k] / L);
-          const double thr = ucbv[k] / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it: "sure true"
-          acc2[k] = thr > 0 ? thr * thr : -1.0;
-          act[k] = true;
-        }
-      }
-    }
-  }
-  auto load_row = [&](long long j) -> double { return (pok && j >= 0 && j < cnt) ? Din[j * stride + p] : kInfD; };
-  // window at t = 0: rows j0 .. j0 + 15 (each wave brings four)
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const long long j = j0 + rg * 4 + k;
-    const double v = load_row(j);
-    lowb[(unsigned)j & (RING - 1)][col] = v;
-    upb[(unsigned)j & (RING - 1)][col] = v;
-    if (act[k]) best[k] = v;
-  }
-  // rows entering at step t: j0 - t (lower ring, wave 0) and j0 + 15 + t (upper ring, wave 1); two steps in flight
-  double r_cur = kInfD, r_nxt = kInfD;
-  if (rg == 0) { r_cur = load_row(j0 - 1); r_nxt = load_row(j0 - 2); }
-  if (rg == 1) { r_cur = load_row(j0 + RQ); r_nxt = load_row(j0 + RQ + 1); }
-  if (rg == 0) lowb[(unsigned)(j0 - 1 + (1 << 20)) & (RING - 1)][col] = r_cur;
-  if (rg == 1) upb[(unsigned)(j0 + RQ) & (RING - 1)][col] = r_cur;
-  for (int t = 1; t < cnt; ++t) {
-    const int mine = act[0] | act[1] | act[2] | act[3];
-    if (!__syncthreads_or(mine)) break;          // also publishes the rows of step t
-    // stage the rows of step t + 1 (their ring slots are outside step t's windows) and fetch those of t + 2
-    if (rg == 0) { lowb[(unsigned)(j0 - (t + 1) + (1 << 20)) & (RING - 1)][col] = r_nxt; r_nxt = load_row(j0 - (t + 2)); }
-    if (rg == 1) { upb[(unsigned)(j0 + RQ - 1 + t + 1) & (RING - 1)][col] = r_nxt; r_nxt = load_row(j0 + RQ - 1 + t + 2); }
-    const double dt = h * (double)t;
-    const double e = dt * dt;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (act[k]) {
-        const long long jq = j0 + rg * 4 + k;
-        const bool lo_ok = jq - t >= 0, hi_ok = jq + t < cnt;
-        if (e >= best[k] || dt > cap[k] || best[k] <= acc2[k] || (!lo_ok && !hi_ok)) act[k] = false;
-        else {
-          const double c1 = lowb[(unsigned)(jq - t + (1 << 20)) & (RING - 1)][col];
-          const double c2 = upb[(unsigned)(jq + t) & (RING - 1)][col];
-          const double c = (c1 < c2 ? c1 : c2) + e;
-          best[k] = c < best[k] ? c : best[k];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const long long j = j0 + rg * 4 + k;
-    if (!(pok && j < jend)) continue;
-    const long long g = j * stride + p - goff;
-    uint8_t out = 0;
-    if (query[k]) {
-      const double ucb = ucbv[k];
-      if (!(L > 0)) out = ucb >= 0.0;
-      else if (best[k] < 0.5 * kInfD) {
-        const double dm = sqrt(best[k]);
-        const double eps = eps_abs + 1e-11 * dm;
-        const double tol = 1e-12 * (fabs(ucb) + L * dm);
-        const double lo = ucb - L * (dm + eps), hi = ucb - L * (dm - eps);
-        if (lo > tol) out = 1;
-        else if (hi >= -tol) {
-          const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
-          amb[slot] = g;
-        }
-      }
-    }
-    G[g] = out;
-  }
-}
-
 // every S point goes to the exhaustive list (explicit candidate lists have no grid to transform)
 __global__ __launch_bounds__(256) void k_list_safe(const uint8_t* __restrict__ S, long long n, SweepScalars* sc,
                                                    uint8_t* __restrict__ G, long long* __restrict__ amb) {
@@ -1758,12 +1643,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     for (int a = 0; a < d; ++a) xscale = std::max(xscale, std::max(std::fabs(c->cs.lo[a]), std::fabs(c->cs.hi[a])));
     const int last_cnt = d >= 2 ? (int)wplanes : 1;
     const double last_h = d >= 2 ? c->cs.step[d - 1] : 0.0;
-    if (c->edt_tiled && d >= 2 && last_cnt >= 32) {
-      const long long tiles = ((stride + 63) / 64) * ((n / stride + 15) / 16);
-      hipLaunchKernelGGL((k_edt_decide_tiled<T>), dim3((unsigned)tiles), dim3(256), 0, c->stream, (const double*)din, n, goff, stride,
-                         last_cnt, last_h, d, xscale, mean_c, var_c, (T)o->b, (const uint8_t*)c->maskS.p,
-                         (const unsigned long long*)c->Lmax.p, lidx, sc, G, (long long*)c->amb.p);
-    } else {
+    {
       const double* bmin = nullptr;
       const int blk = last_cnt >= 8192 ? 64 : 32;
       if (d >= 2 && last_cnt >= 4 * blk && c->scan_blocks) {
