@@ -560,11 +560,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                      (double*)c->bl_BtA.p, pl.sBtA, (double*)nullptr, 0ll);
   // stage 2 (fused): variance, mean, Lipschitz keys
   const size_t lds = sizeof(double) * 2 * 4096;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_bpost, dim3((unsigned)((pl.ncs0 + 7) / 8), (unsigned)((pl.nrb + 7) / 8), (unsigned)q), dim3(256), lds, c->stream,
                      mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
                      pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.nrb, pl.ncs0, nlines,
