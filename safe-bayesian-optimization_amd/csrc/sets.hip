@@ -1025,42 +1025,53 @@ __device__ __forceinline__ PdtParams pdt_params(const SweepScalars* sc, int c, c
 //     min_J Fmin(J) + sum_a (h_a lo_t)^2  <=  P(x)  <=  min_J Fmin(J) + sum_a (h_a hi_t)^2      for every x in cell I.
 // Both sides are separable min-plus transforms of the small array Fmin.  Lower side > band: nothing in the cell can be
 // covered and its axis-0 values cannot matter either (they are >= P); upper side < -band: every U point is covered.
+// Fmin of every coarse cell: one thread per cell walks its kCoarse^d candidates (axis 0 innermost); cells without a
+// source get +inf.  Written to both bound arrays (they start from the same values).
 template <typename T>
-__global__ __launch_bounds__(256) void k_pdt_cell_min(const T* __restrict__ W, long long nt, const CoarseGrid cg,
-                                                      const unsigned long long* Lkeys, int lidx,
-                                                      unsigned long long* __restrict__ Fkey) {
+__global__ __launch_bounds__(256) void k_pdt_cell_min(const T* __restrict__ W, const CoarseGrid cg, long long nc,
+                                                      const unsigned long long* Lkeys, int lidx, double* __restrict__ lo,
+                                                      double* __restrict__ hi) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const double invL = L > 0 ? 1.0 / L : 0.0;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nt; g += (long long)gridDim.x * blockDim.x) {
-    const double w = (double)W[g];
-    if (!(w >= 0.0)) continue;
-    long long f = g, cell = 0, cs = 1;
+  for (long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x; cell < nc; cell += (long long)gridDim.x * blockDim.x) {
+    // fine index of the cell origin and the cell's extent per axis
+    long long f = cell, stride = 1, origin = 0, len[kMaxD], fstride[kMaxD], total = 1;
     for (int a = 0; a < cg.d; ++a) {
-      const long long i = f % cg.count[a];
-      f /= cg.count[a];
-      cell += (i / kCoarse) * cs;
-      cs *= cg.ccount[a];
+      const long long ci = f % cg.ccount[a];
+      f /= cg.ccount[a];
+      const long long i0 = ci * kCoarse;
+      len[a] = cg.count[a] - i0 < kCoarse ? cg.count[a] - i0 : kCoarse;
+      fstride[a] = stride;
+      origin += i0 * stride;
+      stride *= cg.count[a];
+      total *= len[a];
     }
-    const double r = w * invL;
-    atomicMin(&Fkey[cell], ord_key(-(r * r)));
+    double wmax = -1.0;
+    for (long long t = 0; t < total; ++t) {
+      long long u = t, g = origin;
+      for (int a = 0; a < cg.d; ++a) {
+        g += (u % len[a]) * fstride[a];
+        u /= len[a];
+      }
+      const double w = (double)W[g];
+      wmax = w > wmax ? w : wmax;
+    }
+    double v = kInfD;
+    if (wmax >= 0.0) { const double r = wmax * invL; v = -(r * r); }
+    lo[cell] = v;
+    hi[cell] = v;
   }
 }
-// keys -> doubles (in place) for both bound arrays; cells without a source become +inf
-__global__ __launch_bounds__(256) void k_pdt_cell_unkey(unsigned long long* __restrict__ Fkey, long long nc, double* __restrict__ lo,
-                                                        double* __restrict__ hi) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += (long long)gridDim.x * blockDim.x) {
-    const unsigned long long k = Fkey[g];
-    const double v = k == ~0ull ? kInfD : ord_val(k);
-    lo[g] = v;
-    hi[g] = v;
-  }
-}
-// one axis of a coarse bound transform; upper = 0: lower-bound costs, 1: upper-bound costs
-__global__ __launch_bounds__(256) void k_pdt_coarse_scan(const double* __restrict__ Pin, double* __restrict__ Pout, long long nc,
-                                                         long long stride, int cnt, double h, int upper, const SweepScalars* sc,
-                                                         int c, const unsigned long long* Lkeys, int lidx, int d, double xscale) {
+// one axis of both coarse bound transforms (lower-bound costs on the first array, upper-bound costs on the second)
+__global__ __launch_bounds__(256) void k_pdt_coarse_scan(const double* __restrict__ LoIn, double* __restrict__ LoOut,
+                                                         const double* __restrict__ HiIn, double* __restrict__ HiOut, long long nc,
+                                                         long long stride, int cnt, double h, const SweepScalars* sc, int c,
+                                                         const unsigned long long* Lkeys, int lidx, int d, double xscale) {
   const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += (long long)gridDim.x * blockDim.x) {
+  for (long long g2 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g2 < 2 * nc; g2 += (long long)gridDim.x * blockDim.x) {
+    const int upper = g2 >= nc;                          // first half of the index space: lower bounds, second half: upper
+    const long long g = upper ? g2 - nc : g2;
+    const double* Pin = upper ? HiIn : LoIn;
     const int ia = (int)((g / stride) % cnt);
     double best = kInfD;
     for (int t = 0; t < cnt; ++t) {
@@ -1076,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_pdt_coarse_scan(const double* __restric
       const double cnd = (c1 < c2 ? c1 : c2) + dd * dd;
       best = cnd < best ? cnd : best;
     }
-    Pout[g] = best;
+    (upper ? HiOut : LoOut)[g] = best;
   }
 }
 __device__ __forceinline__ long long coarse_cell(const CoarseGrid& cg, long long gg) {
@@ -1987,26 +1998,20 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     if (coarse_ok) {
       cg.enabled = 1;
       if ((rc = ensure(c->coarse, (size_t)nc * 5 * sizeof(double) + 64))) return rc;
-      unsigned long long* fkey = (unsigned long long*)c->coarse.p;
-      double* lo0 = (double*)c->coarse.p + nc;
+      double* lo0 = (double*)c->coarse.p;
       double* lo1 = lo0 + nc;
       double* hi0 = lo1 + nc;
       double* hi1 = hi0 + nc;
       const unsigned gridc = (unsigned)std::min<long long>((nc + 255) / 256, 1 << 16);
-      SBO_HIP(hipMemsetAsync(fkey, 0xff, sizeof(unsigned long long) * (size_t)nc, c->stream));
-      hipLaunchKernelGGL((k_pdt_cell_min<T>), dim3(gridn), dim3(256), 0, c->stream, Wwin, nt, cg,
-                         (const unsigned long long*)c->Lmax.p, lidx, fkey);
-      hipLaunchKernelGGL(k_pdt_cell_unkey, dim3(gridc), dim3(256), 0, c->stream, fkey, nc, lo0, hi0);
+      hipLaunchKernelGGL((k_pdt_cell_min<T>), dim3(gridc), dim3(256), 0, c->stream, Wwin, cg, nc,
+                         (const unsigned long long*)c->Lmax.p, lidx, lo0, hi0);
       long long cstride = 1;
       for (int a = 0; a < d; ++a) {
-        for (int upper = 0; upper < 2; ++upper) {
-          double*& in = upper ? hi0 : lo0;
-          double*& out = upper ? hi1 : lo1;
-          hipLaunchKernelGGL(k_pdt_coarse_scan, dim3(gridc), dim3(256), 0, c->stream, (const double*)in, out, nc, cstride,
-                             (int)cg.ccount[a], c->cs.step[a], upper, (const SweepScalars*)sc, cidx,
-                             (const unsigned long long*)c->Lmax.p, lidx, d, xscale);
-          std::swap(in, out);
-        }
+        hipLaunchKernelGGL(k_pdt_coarse_scan, dim3(2 * gridc), dim3(256), 0, c->stream, (const double*)lo0, lo1, (const double*)hi0,
+                           hi1, nc, cstride, (int)cg.ccount[a], c->cs.step[a], (const SweepScalars*)sc, cidx,
+                           (const unsigned long long*)c->Lmax.p, lidx, d, xscale);
+        std::swap(lo0, lo1);
+        std::swap(hi0, hi1);
         cstride *= cg.ccount[a];
       }
       pc_lo = lo0;
