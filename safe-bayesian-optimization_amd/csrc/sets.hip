@@ -13,6 +13,8 @@
 // matter; decisions that fall inside the rounding band of the reference's "+1e-8" are re-decided by
 // exhaustive evaluation of the reference expression, so the transform never changes a mask bit.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include "device_common.hpp"
@@ -1928,23 +1930,16 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
   const T* W = (const T*)c->gw.p;
   long long run_lo = 0, run_hi = (n + kRun - 1) / kRun;
   long long win_p0 = 0, win_p1 = 0;     // ranks > 1: window of hyper-planes holding every source that can matter
+  bool w_is_window = false;             // ranks > 1, slab exchange: W holds exactly the window [win_p0, win_p1)
   if (c->world > 1) {
-    // sources of every rank: all-gather the weight shards, then search the hyper-planes within reach of this shard
-    // (reach = largest source radius, from the keys of collective C1 -- the window is exact, as for the expanders)
-    if ((rc = ensure(c->gather, sizeof(T) * (size_t)maxlocal * c->world))) return rc;
-    if ((rc = ensure(c->Wfull, sizeof(T) * (size_t)c->grid_total))) return rc;
-    if ((rc = comm_allgather_bytes(c, c->gw.p, c->gather.p, sizeof(T) * (size_t)maxlocal))) return rc;
-    hipLaunchKernelGGL(k_compact_shards<T>, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
-                       c->stream, (const T*)c->gather.p, maxlocal, c->world, (const long long*)c->shard_first.p, c->grid_total,
-                       (T*)c->Wfull.p);
-    css.first = 0;
-    css.n_local = c->grid_total;
-    W = (const T*)c->Wfull.p;
+    // Sources of the other ranks that can reach this shard lie within H hyper-planes of it (H from the largest source
+    // radius, keys of collective C1 -- exact, as for the expanders).
     const int d = c->cs.d;
     long long plane = 1;
     for (int a = 0; a < d - 1; ++a) plane *= c->cs.count[a];
     const long long planes_total = c->cs.count[d - 1];
     long long p0 = c->cs.first / plane, p1 = (c->cs.first + n + plane - 1) / plane;
+    const long long own0 = p0, own1 = p1;
     if ((rc = sweep_exchange_wait(c))) return rc;
     double L, rmax = 0.0;
     memcpy(&L, &c->h_c1[1 + lidx], 8);
@@ -1959,8 +1954,53 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     p1 = std::min(planes_total, p1 + H);
     win_p0 = p0;
     win_p1 = p1;
-    run_lo = p0 * plane / kRun;
-    run_hi = (p1 * plane + kRun - 1) / kRun;
+    long long min_planes = planes_total;
+    for (int r = 0; r < c->world; ++r) min_planes = std::min(min_planes, (c->first_of[r + 1] - c->first_of[r]) / plane);
+    if (getenv("SBO_DEBUG_COMM"))
+      fprintf(stderr, "[rank %d] GoOSE sources c=%d: halo %lld planes, smallest shard %lld planes -> %s\n", c->rank, cidx, H, min_planes,
+              (c->sharded && H <= min_planes) ? "slab exchange" : "full all-gather");
+    if (c->sharded && H <= min_planes) {
+      // the halo fits inside the neighbours: every rank contributes only its first and last H planes (2 H plane values
+      // instead of its whole shard), and the window is assembled from the previous rank's top slab, the own shard and
+      // the next rank's bottom slab
+      const size_t slab = (size_t)H * plane;
+      if ((rc = ensure(c->gather, sizeof(T) * slab * 2 * (c->world + 1)))) return rc;
+      if ((rc = ensure(c->Wfull, sizeof(T) * (size_t)(p1 - p0) * plane))) return rc;
+      T* send = (T*)c->gather.p;
+      T* recv = send + 2 * slab;
+      SBO_HIP(hipMemcpyAsync(send, c->gw.p, sizeof(T) * slab, hipMemcpyDeviceToDevice, c->stream));
+      SBO_HIP(hipMemcpyAsync(send + slab, (const T*)c->gw.p + (size_t)n - slab, sizeof(T) * slab, hipMemcpyDeviceToDevice, c->stream));
+      if ((rc = comm_allgather_bytes(c, send, recv, sizeof(T) * slab * 2))) return rc;
+      T* win = (T*)c->Wfull.p;
+      size_t at = 0;
+      if (own0 > p0) {       // previous rank's top slab (p0 = own0 - H exactly, since H <= its planes)
+        SBO_HIP(hipMemcpyAsync(win, recv + (size_t)(c->rank - 1) * 2 * slab + slab, sizeof(T) * slab, hipMemcpyDeviceToDevice, c->stream));
+        at = slab;
+      }
+      SBO_HIP(hipMemcpyAsync(win + at, c->gw.p, sizeof(T) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+      at += (size_t)n;
+      if (p1 > own1)
+        SBO_HIP(hipMemcpyAsync(win + at, recv + (size_t)(c->rank + 1) * 2 * slab, sizeof(T) * slab, hipMemcpyDeviceToDevice, c->stream));
+      css.first = p0 * plane;
+      css.n_local = (p1 - p0) * plane;
+      W = (const T*)win;
+      w_is_window = true;
+      run_lo = 0;
+      run_hi = (css.n_local + kRun - 1) / kRun;
+    } else {
+      // wide halo: all-gather the whole weight shards
+      if ((rc = ensure(c->gather, sizeof(T) * (size_t)maxlocal * c->world))) return rc;
+      if ((rc = ensure(c->Wfull, sizeof(T) * (size_t)c->grid_total))) return rc;
+      if ((rc = comm_allgather_bytes(c, c->gw.p, c->gather.p, sizeof(T) * (size_t)maxlocal))) return rc;
+      hipLaunchKernelGGL(k_compact_shards<T>, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
+                         c->stream, (const T*)c->gather.p, maxlocal, c->world, (const long long*)c->shard_first.p, c->grid_total,
+                         (T*)c->Wfull.p);
+      css.first = 0;
+      css.n_local = c->grid_total;
+      W = (const T*)c->Wfull.p;
+      run_lo = p0 * plane / kRun;
+      run_hi = (p1 * plane + kRun - 1) / kRun;
+    }
   }
   if (n == 0) return SBO_OK;           // (an empty shard still took part in the all-gather)
   long long plane1 = 1;
@@ -1973,7 +2013,7 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     const long long own0 = c->cs.first / plane1;
     const long long w0 = c->world > 1 ? win_p0 : own0, w1 = c->world > 1 ? win_p1 : own0 + n / plane1;
     const long long wplanes = w1 - w0, nt = wplanes * plane1, goff = (own0 - w0) * plane1;
-    const T* Wwin = c->world > 1 ? W + w0 * plane1 : W;
+    const T* Wwin = (c->world > 1 && !w_is_window) ? W + w0 * plane1 : W;
     if ((rc = ensure(c->dist2, sizeof(double) * (size_t)nt))) return rc;
     if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)nt))) return rc;
     if ((rc = ensure(c->amb, sizeof(long long) * (size_t)n))) return rc;
