@@ -158,10 +158,24 @@ class GP:
         self.hypopt, self.invKopt = self.determine_hyperparameters(self.X_norm, self.Y_norm)
         self.update_inference_dataset()
 
-    def add_sample(self, x_new, y_new):
+    def add_sample(self, x_new, y_new, incremental: bool = False):
+        """Reference behaviour (models/GP_Safe.py:283-304): re-normalise, refit, rebuild.  ``incremental=True`` is the
+        opt-in fast path of SURVEY.md 8(f) rank 2: normalisation constants and hyper-parameters stay frozen and the device
+        model gains one row in O(n^2) (``sbo_model_append``); the Python-side ``inference_datasets`` keeps X_norm / Y_norm
+        in step but its ``invKopt`` is then stale until the next full ``add_sample``."""
         self.X = np.vstack([self.X, np.asarray(x_new, dtype=np.float64)])
         self.Y = np.vstack([self.Y, np.asarray(y_new, dtype=np.float64)])
         self.n_point = self.X.shape[0]
+        if incremental:
+            self._sync_model()
+            xn = (np.asarray(x_new, dtype=np.float64).reshape(-1) - self.X_mean) / self.X_std
+            yn = (np.asarray(y_new, dtype=np.float64).reshape(-1) - self.Y_mean) / self.Y_std
+            self.engine.append_sample(xn, yn)
+            self.X_norm = np.vstack([self.X_norm, xn])
+            self.Y_norm = np.vstack([self.Y_norm, yn])
+            self.inference_datasets["X_norm"], self.inference_datasets["Y_norm"] = self.X_norm, self.Y_norm
+            self._cand_token = None
+            return
         self.X_norm, self.Y_norm = self.data_normalization()
         self.hypopt, self.invKopt = self.determine_hyperparameters(self.X_norm, self.Y_norm)
         self.update_inference_dataset()

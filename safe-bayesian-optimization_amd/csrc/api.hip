@@ -61,9 +61,6 @@ static int model_upload(sbo_ctx* c, const std::vector<double>& As, const std::ve
   return SBO_OK;
 }
 
-int model_build(sbo_ctx* c, const double* host_invK, const std::vector<double>& As, const std::vector<double>& sqA,
-                const std::vector<double>& rhs, const double* sn2);
-
 }  // namespace sbo
 
 using namespace sbo;
@@ -120,7 +117,7 @@ int sbo_shutdown(sbo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->Lmax, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->blockmin, &c->blockmax, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -211,6 +208,7 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
     mc.mp[o] = (o == 0) ? 0.0 : (-2.0 * Y_mean[o]) / Y_std[o];          // GP_Safe.py:331-332
     mc.sf2[o] = std::exp(2.0 * hypopt[(size_t)d * q + o]);               // GP_Safe.py:338
     sn2[o] = std::exp(2.0 * hypopt[(size_t)(d + 1) * q + o]) + f32eps;   // GP_Safe.py:229
+    mc.sn2[o] = sn2[o];
     for (int a = 0; a < d; ++a) {
       const double ell = std::exp(2.0 * hypopt[(size_t)a * q + o]);
       mc.vinv[o][a] = std::pow(ell, -0.5);                               // GP_Safe.py:112
@@ -235,6 +233,63 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
   rc = (dtype == SBO_F64) ? model_upload<double>(c, As, sqA, Xn) : model_upload<float>(c, As, sqA, Xn);
   if (rc) return rc;
   c->has_model = true;
+  return SBO_OK;
+}
+
+// one more observation under frozen hyper-parameters and normalisation, O(n^2) on the
+// device instead of a refit (the reference always refits and renormalises, models/GP_Safe.py:283-304 -- this is an
+// opt-in fast path, not its behaviour).
+int sbo_model_append(sbo_ctx* c, const double* x_norm_new, const double* y_norm_new) {
+  if (!c || !x_norm_new || !y_norm_new) return fail(SBO_E_INVALID, "NULL argument");
+  if (!c->has_model || !c->Fplain.p) return fail(SBO_E_NO_MODEL, "sbo_model_set has not been called");
+  ModelConst& mc = c->mc;
+  const int n = mc.n, d = mc.d, q = mc.q, D = mc.dpad;
+  if (n + 1 > SBO_MAX_N || n + 1 > c->f_cap) return fail(SBO_E_UNSUPPORTED, "model is at its capacity: rebuild it with sbo_model_set");
+  SBO_HIP(hipSetDevice(c->device));
+  // cross-covariances of the new point with the expanded distance of the reference (GP_Safe.py:115-119, 166)
+  std::vector<double> kvec((size_t)q * n);
+  double kappa[kMaxQ], rho[kMaxQ];
+  for (int o = 0; o < q; ++o) {
+    double bsq = 0.0, bvec[kMaxD];
+    for (int a = 0; a < d; ++a) { bvec[a] = x_norm_new[a] * mc.vinv[o][a]; bsq += bvec[a] * bvec[a]; }
+    for (int j = 0; j < n; ++j) {
+      double dot = 0.0, asq = 0.0;
+      for (int a = 0; a < d; ++a) {
+        const double v = c->h_Xnorm[(size_t)j * d + a] * mc.vinv[o][a];
+        dot += v * bvec[a];
+        asq += v * v;
+      }
+      kvec[(size_t)o * n + j] = mc.sf2[o] * std::exp(-0.5 * ((-2.0 * dot + asq) + bsq));
+    }
+    kappa[o] = mc.sf2[o] + mc.sn2[o];
+    rho[o] = y_norm_new[o] - mc.mp[o];
+  }
+  int rc = model_append(c, kvec, kappa, rho);
+  if (rc) return rc;
+  // host-side model arrays with the new row, re-upload of the small ones, re-pack of the factor images
+  c->h_Xnorm.insert(c->h_Xnorm.end(), x_norm_new, x_norm_new + d);
+  mc.n = n + 1;
+  mc.npad = (mc.n + 15) / 16 * 16;
+  const int npad = mc.npad;
+  std::vector<double> As((size_t)q * npad * D, 0.0), sqA((size_t)q * npad, 0.0), Xn((size_t)npad * D, 0.0);
+  for (int j = 0; j < mc.n; ++j)
+    for (int a = 0; a < d; ++a) Xn[(size_t)j * D + a] = c->h_Xnorm[(size_t)j * d + a];
+  for (int o = 0; o < q; ++o)
+    for (int j = 0; j < mc.n; ++j) {
+      double s = 0;
+      for (int a = 0; a < d; ++a) {
+        const double v = c->h_Xnorm[(size_t)j * d + a] * mc.vinv[o][a];
+        As[((size_t)o * npad + j) * D + a] = v;
+        s += v * v;
+      }
+      sqA[(size_t)o * npad + j] = s;
+    }
+  rc = (c->dtype == SBO_F64) ? model_upload<double>(c, As, sqA, Xn) : model_upload<float>(c, As, sqA, Xn);
+  if (rc) return rc;
+  if ((rc = model_repack(c))) return rc;
+  c->posterior_valid = false;
+  c->masks_valid = false;
+  c->bl.valid = false;
   return SBO_OK;
 }
 

@@ -18,6 +18,7 @@ struct ModelConst {
   double X_mean[kMaxD], X_std[kMaxD], X_rstd[kMaxD];
   double Y_mean[kMaxQ], Y_std[kMaxQ];
   double sf2[kMaxQ];            // exp(2 h[d])                       GP_Safe.py:338
+  double sn2[kMaxQ];            // exp(2 h[d+1]) + float32 eps       GP_Safe.py:229 (used by the model build / append only)
   double mp[kMaxQ];             // prior mean, -2 Y_mean/Y_std, [0]=0 GP_Safe.py:331-332
   double vinv[kMaxQ][kMaxD];    // ell^-1/2 = exp(-h[a])             GP_Safe.py:112
   double inv_ell[kMaxQ][kMaxD]; // 1/ell = exp(-2 h[a])
@@ -75,6 +76,9 @@ struct sbo_ctx {
   size_t fpk_stride = 0;  // elements per output in Fpk
   std::vector<double> h_Xnorm;   // host copies used by the exact-recheck / result decoding
   std::vector<double> h_alpha;   // [q][npad]
+  sbo::DevBuf Fplain;            // [q][f_cap][f_cap] fp64 lower factor M, row-major (kept for sbo_model_append)
+  sbo::DevBuf alpha64;           // [q][f_cap] fp64 alpha
+  int f_cap = 0;                 // leading dimension / capacity of Fplain and alpha64
   sbo::BilinearPlan bl;
   sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work;
   // candidates
@@ -142,6 +146,10 @@ void release(DevBuf& b);
 // launchers implemented in the .hip files -----------------------------------------------------
 int launch_posterior(sbo_ctx* c);
 int launch_bound(sbo_ctx* c, double b, int index, int kind, void* dev_out);
+int model_build(sbo_ctx* c, const double* host_invK, const std::vector<double>& As, const std::vector<double>& sqA,
+                const std::vector<double>& rhs, const double* sn2);
+int model_append(sbo_ctx* c, const std::vector<double>& kvec /*[q][n]*/, const double* kappa, const double* rho);
+int model_repack(sbo_ctx* c);
 bool bilinear_applicable(const sbo_ctx* c);
 int bilinear_setup(sbo_ctx* c);
 int launch_posterior_bilinear(sbo_ctx* c);

@@ -143,11 +143,11 @@ __global__ __launch_bounds__(1024) void k_model_build(int mode, int n, int npad,
 
 // lower-triangular factor [q][n][n] -> matrix-core A-fragment images [q][tri(I, J)][256] in the model dtype
 template <typename T>
-__global__ __launch_bounds__(256) void k_pack_factor(const double* __restrict__ F, int n, int nb, size_t fpk_stride,
-                                                     T* __restrict__ Fpk) {
+__global__ __launch_bounds__(256) void k_pack_factor(const double* __restrict__ F, int n, int ld, size_t ostride, int nb,
+                                                     size_t fpk_stride, T* __restrict__ Fpk) {
   const int o = blockIdx.y;
   const size_t ntri = (size_t)nb * (nb + 1) / 2;
-  const double* Fo = F + (size_t)o * n * n;
+  const double* Fo = F + (size_t)o * ostride;
   T* dst = Fpk + (size_t)o * fpk_stride;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ntri * 256; idx += (size_t)gridDim.x * blockDim.x) {
     const size_t blk = idx >> 8;
@@ -160,13 +160,78 @@ __global__ __launch_bounds__(256) void k_pack_factor(const double* __restrict__ 
     int r, k, kk;
     MM<T>::unpack_pos(e, r, k, kk);
     const int row = 16 * I + r, col = 16 * J + MM<T>::jslot(kk, k);
-    dst[idx] = (row < n && col < n && col <= row) ? (T)Fo[(size_t)row * n + col] : T(0);
+    dst[idx] = (row < n && col < n && col <= row) ? (T)Fo[(size_t)row * ld + col] : T(0);
   }
 }
 
+// alpha [q][sstride] fp64 -> [q][dstride] in the model dtype (first n entries of each output, zero padding)
 template <typename T>
-__global__ void k_cast(const double* __restrict__ src, size_t nelem, T* __restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nelem; i += (size_t)gridDim.x * blockDim.x) dst[i] = (T)src[i];
+__global__ void k_cast_alpha(const double* __restrict__ src, int sstride, int n, int q, int dstride, T* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < q * dstride; i += gridDim.x * blockDim.x) {
+    const int o = i / dstride, j = i % dstride;
+    dst[i] = j < n ? (T)src[(size_t)o * sstride + j] : T(0);
+  }
+}
+
+// One more observation with frozen hyper-parameters and normalisation.  With k = K(X, x_new),
+// kappa = sf2 + sn2 and u = invK k = M^T (M k), s = kappa - k.u, the inverse of the bordered matrix is
+// [[invK + u u^T / s, -u / s], [-u^T / s, 1 / s]]: the lower factor simply gains the row (-u^T / sqrt(s), 1 / sqrt(s)),
+// and alpha_new = (alpha + u (k.alpha - rho) / s, (rho - k.alpha) / s).  O(n^2), one workgroup per output.
+__global__ __launch_bounds__(1024) void k_model_append(int n, int ld, double* __restrict__ F, double* __restrict__ alpha,
+                                                       const double* __restrict__ kvec, const double* __restrict__ kappa,
+                                                       const double* __restrict__ rho, double* __restrict__ scratch,
+                                                       int* __restrict__ bad) {
+  __shared__ double red[32];
+  __shared__ double sh_s, sh_ka;
+  const int o = blockIdx.x, tid = threadIdx.x;
+  double* M = F + (size_t)o * ld * ld;
+  double* al = alpha + (size_t)o * ld;
+  const double* k = kvec + (size_t)o * n;
+  double* t = scratch + (size_t)o * 2 * ld;
+  double* u = t + ld;
+  for (int i = tid; i < n; i += blockDim.x) {            // t = M k
+    double s = 0.0;
+    for (int j = 0; j <= i; ++j) s += M[(size_t)i * ld + j] * k[j];
+    t[i] = s;
+  }
+  __syncthreads();
+  double ku = 0.0, ka = 0.0;
+  for (int j = tid; j < n; j += blockDim.x) {            // u = M^T t ;  partial sums of k.u and k.alpha
+    double s = 0.0;
+    for (int i = j; i < n; ++i) s += M[(size_t)i * ld + j] * t[i];
+    u[j] = s;
+    ku += k[j] * s;
+    ka += k[j] * al[j];
+  }
+  auto block_sum = [&](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+  };
+  ku = block_sum(ku);
+  ka = block_sum(ka);
+  if (tid == 0) {
+    const double s = kappa[o] - ku;
+    if (!(s > 0.0)) bad[o] = 1;
+    sh_s = s > 0.0 ? s : 1.0;
+    sh_ka = ka;
+  }
+  __syncthreads();
+  const double s = sh_s, rs = 1.0 / sqrt(s), coef = (sh_ka - rho[o]) / s;
+  for (int j = tid; j < n; j += blockDim.x) {
+    M[(size_t)n * ld + j] = -u[j] * rs;
+    al[j] += u[j] * coef;
+  }
+  if (tid == 0) {
+    M[(size_t)n * ld + n] = rs;
+    al[n] = (rho[o] - sh_ka) / s;
+  }
+  for (int j = n + 1 + tid; j < ld; j += blockDim.x) M[(size_t)n * ld + j] = 0.0;
 }
 
 // Device side of sbo_model_set.  host_invK may be NULL (the library factors K itself).  On success Fpk (dtype T) and
@@ -206,9 +271,22 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<
   if ((rc = ensure(c->Fpk, sizeof(T) * ((size_t)q * c->fpk_stride + 512)))) return rc;   // + padding: the K1g pipeline over-reads
   SBO_HIP(hipMemsetAsync(c->Fpk.p, 0, sizeof(T) * ((size_t)q * c->fpk_stride + 512), c->stream));
   hipLaunchKernelGGL((k_pack_factor<T>), dim3((unsigned)std::min<size_t>((ntri * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
-                     (const double*)dF, n, nb, c->fpk_stride, (T*)c->Fpk.p);
+                     (const double*)dF, n, n, nn, nb, c->fpk_stride, (T*)c->Fpk.p);
   if ((rc = ensure(c->alpha, sizeof(T) * (size_t)q * npad))) return rc;
-  hipLaunchKernelGGL((k_cast<T>), dim3(16), dim3(256), 0, c->stream, (const double*)dalpha, (size_t)q * npad, (T*)c->alpha.p);
+  hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)dalpha, npad, n, q, npad, (T*)c->alpha.p);
+  // fp64 factor and alpha stay resident (leading dimension f_cap) so that observations can be appended in O(n^2)
+  const int cap = std::min(SBO_MAX_N, (npad + 256 + 127) / 128 * 128);
+  if (cap != c->f_cap || !c->Fplain.p) {
+    if ((rc = ensure(c->Fplain, sizeof(double) * (size_t)q * cap * cap))) return rc;
+    if ((rc = ensure(c->alpha64, sizeof(double) * (size_t)q * cap))) return rc;
+    c->f_cap = cap;
+  }
+  for (int o = 0; o < q; ++o) {
+    SBO_HIP(hipMemcpy2DAsync((double*)c->Fplain.p + (size_t)o * cap * cap, sizeof(double) * cap, dF + (size_t)o * nn, sizeof(double) * n,
+                             sizeof(double) * n, n, hipMemcpyDeviceToDevice, c->stream));
+    SBO_HIP(hipMemcpyAsync((double*)c->alpha64.p + (size_t)o * cap, dalpha + (size_t)o * npad, sizeof(double) * n,
+                           hipMemcpyDeviceToDevice, c->stream));
+  }
   SBO_HIP(hipGetLastError());
   std::vector<int> hbad(q, 0);
   c->h_alpha.assign((size_t)q * npad, 0.0);
@@ -217,6 +295,55 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<
   SBO_HIP(hipStreamSynchronize(c->stream));
   for (int o = 0; o < q; ++o)
     if (hbad[o]) return fail(SBO_E_INVALID, host_invK ? "invK is not positive definite" : "K + sn2 I is not positive definite");
+  return SBO_OK;
+}
+
+// Re-pack Fpk / alpha of the model dtype from the resident fp64 factor (after an append; mc.n, mc.npad already updated).
+template <typename T>
+static int model_repack_t(sbo_ctx* c) {
+  const ModelConst& mc = c->mc;
+  const int n = mc.n, npad = mc.npad, q = mc.q, nb = npad / 16, cap = c->f_cap;
+  const size_t ntri = (size_t)nb * (nb + 1) / 2;
+  int rc;
+  c->fpk_stride = ntri * 4 * 64;
+  if ((rc = ensure(c->Fpk, sizeof(T) * ((size_t)q * c->fpk_stride + 512)))) return rc;
+  SBO_HIP(hipMemsetAsync(c->Fpk.p, 0, sizeof(T) * ((size_t)q * c->fpk_stride + 512), c->stream));
+  hipLaunchKernelGGL((k_pack_factor<T>), dim3((unsigned)std::min<size_t>((ntri * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
+                     (const double*)c->Fplain.p, n, cap, (size_t)cap * cap, nb, c->fpk_stride, (T*)c->Fpk.p);
+  if ((rc = ensure(c->alpha, sizeof(T) * (size_t)q * npad))) return rc;
+  hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)c->alpha64.p, cap, n, q, npad, (T*)c->alpha.p);
+  SBO_HIP(hipGetLastError());
+  c->h_alpha.assign((size_t)q * npad, 0.0);
+  for (int o = 0; o < q; ++o)
+    SBO_HIP(hipMemcpyAsync(&c->h_alpha[(size_t)o * npad], (const double*)c->alpha64.p + (size_t)o * cap, sizeof(double) * n,
+                           hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  return SBO_OK;
+}
+int model_repack(sbo_ctx* c) { return c->dtype == SBO_F64 ? model_repack_t<double>(c) : model_repack_t<float>(c); }
+
+// kvec [q][n] cross-covariances of the new point, kappa[q] = sf2 + sn2, rho[q] = y_norm_new - mp; appends row n.
+int model_append(sbo_ctx* c, const std::vector<double>& kvec, const double* kappa, const double* rho) {
+  const int n = c->mc.n, q = c->mc.q, cap = c->f_cap;
+  int rc;
+  if ((rc = ensure(c->fitwork, sizeof(double) * ((size_t)q * n + 2 * (size_t)q + 2 * (size_t)q * cap) + sizeof(int) * q))) return rc;
+  double* dk = (double*)c->fitwork.p;
+  double* dkappa = dk + (size_t)q * n;
+  double* drho = dkappa + q;
+  double* dscratch = drho + q;
+  int* dbad = (int*)(dscratch + 2 * (size_t)q * cap);
+  SBO_HIP(hipMemcpyAsync(dk, kvec.data(), sizeof(double) * (size_t)q * n, hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(dkappa, kappa, sizeof(double) * q, hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(drho, rho, sizeof(double) * q, hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemsetAsync(dbad, 0, sizeof(int) * q, c->stream));
+  hipLaunchKernelGGL(k_model_append, dim3(q), dim3(1024), 0, c->stream, n, cap, (double*)c->Fplain.p, (double*)c->alpha64.p,
+                     (const double*)dk, (const double*)dkappa, (const double*)drho, dscratch, dbad);
+  SBO_HIP(hipGetLastError());
+  std::vector<int> hbad(q, 0);
+  SBO_HIP(hipMemcpyAsync(hbad.data(), dbad, sizeof(int) * q, hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  for (int o = 0; o < q; ++o)
+    if (hbad[o]) return fail(SBO_E_INVALID, "appended observation makes K singular (duplicate point without noise?)");
   return SBO_OK;
 }
 

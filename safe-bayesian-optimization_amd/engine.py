@@ -104,6 +104,17 @@ class SweepEngine:
                                         _ptr(invK)))
         self.n, self.d, self.q = n, d, q
 
+    def append_sample(self, x_norm_new, y_norm_new):
+        """One more observation under frozen hyper-parameters and normalisation: O(n^2) on the
+        device instead of a rebuild.  ``x_norm_new`` [d] and ``y_norm_new`` [q] are normalised with the constants of the
+        last ``set_model``."""
+        x = _f64(x_norm_new).reshape(-1)
+        y = _f64(y_norm_new).reshape(-1)
+        if x.shape != (self.d,) or y.shape != (self.q,):
+            raise ValueError("x_norm_new must be [d] and y_norm_new [q]")
+        L.check(self._lib.sbo_model_append(self._ctx, _ptr(x), _ptr(y)))
+        self.n += 1
+
     # ---- candidates --------------------------------------------------------------------------
     def set_points(self, points, first: int = 0):
         pts = np.asarray(points)

@@ -738,3 +738,39 @@ def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_
     for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c"):
         assert g[k] == gref[k], k
     assert g["count_O"] == gref["count_O"].tolist() and g["target_index_c"] == gref["target_index_c"].tolist()
+
+
+@pytest.mark.parametrize("use_invK,dtype", [(True, "f64"), (False, "f64"), (False, "f32")])
+def test_model_append_equals_a_rebuild(engine, use_invK, dtype):
+    """sbo_model_append: five observations appended one by one under frozen normalisation and
+    hyper-parameters give the posterior of a model rebuilt from all observations with the same constants."""
+    cfg = synthetic.make_config("B", n=100)
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [72, 66]
+    ds = cfg["ds"]
+    rng = np.random.default_rng(21)
+    Xnew = rng.uniform(lo, hi, size=(5, 2))
+    Ynew = synthetic.benoit(Xnew)
+    xn = (Xnew - ds["X_mean"]) / ds["X_std"]
+    yn = (Ynew - ds["Y_mean"]) / ds["Y_std"]
+    engine.set_model(ds, dtype=dtype, use_invK=use_invK)
+    for i in range(5):
+        engine.append_sample(xn[i], yn[i])
+    assert engine.n == 105
+    engine.set_grid(lo, hi, count)
+    mean, var = engine.posterior()
+    # the same model built in one go: normalised data extended with the frozen constants, inverse recomputed
+    X_norm = np.vstack([ds["X_norm"], xn])
+    Y_norm = np.vstack([ds["Y_norm"], yn])
+    ds2 = dict(ds)
+    ds2["X_norm"], ds2["Y_norm"] = X_norm, Y_norm
+    ds2["invKopt"] = oracle.build_invK(X_norm, ds["hypopt"])
+    pts = oracle.grid_points(lo, hi, count)
+    om, ov = oracle.gp_inference(pts, ds2)
+    tol = TOL64 if dtype == "f64" else TOL32
+    assert _nerr(mean, om, ds["Y_std"], 1) < tol and _nerr(var, ov, ds["Y_std"], 2) < tol
+    engine.set_model(ds2, dtype=dtype, use_invK=use_invK)
+    engine.set_grid(lo, hi, count)
+    m2, v2 = engine.posterior()
+    assert _nerr(mean, m2, ds["Y_std"], 1) < tol and _nerr(var, v2, ds["Y_std"], 2) < tol
+    res_a = engine.sweep_safeopt(cfg["b"])
+    assert res_a["count_S"] > 0
