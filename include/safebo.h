@@ -222,6 +222,12 @@ int sbo_masks_get(sbo_ctx* ctx, int which, int c, uint8_t* out);
 int sbo_nll_batch(sbo_ctx* ctx, int n, int d, const double* X_norm, const double* y, int P, const double* hyper,
                   double* out);
 
+/* ---- plant evaluation ------------------------------------------ */
+/* The reference's William-Otto reactor (problems/WilliamOttoReactor_Problem.py:19-93), noise-free, for n input rows
+ * u[n, 2] = (Fb, Tr): out[n, 3] = (get_objective, get_constraint1, get_constraint2), each the steady state of the six
+ * mass balances reached from x0 = 0.1 (the reference calls scipy fsolve once per point and output). */
+int sbo_plant_wo(sbo_ctx* ctx, int64_t n, const double* u, double* out);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
 /* tuning / diagnostics knobs: "posterior_path" (0 auto, 1 generic single-phase, 2 generic chunked), "bilinear" (1 default:

@@ -100,6 +100,7 @@ SYMBOLS = [
     ("sbo_sweep_tr", C.c_int, [_P, C.POINTER(SweepOpts), _P, C.c_double, C.POINTER(TRResult)]),
     ("sbo_masks_get", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("sbo_nll_batch", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
+    ("sbo_plant_wo", C.c_int, [_P, C.c_int64, _P, _P]),
     ("sbo_profile_get", C.c_int, [_P, C.POINTER(Profile)]),
     ("sbo_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
 ]

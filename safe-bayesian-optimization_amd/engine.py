@@ -238,6 +238,15 @@ class SweepEngine:
         L.check(self._lib.sbo_nll_batch(self._ctx, X.shape[0], X.shape[1], _ptr(X), _ptr(yv), H.shape[0], _ptr(H), _ptr(out)))
         return out
 
+    def plant_wo(self, U) -> np.ndarray:
+        """William-Otto reactor outputs (objective, constraint 1, constraint 2) for input rows U[N, 2] = (Fb, Tr)."""
+        u = _f64(np.atleast_2d(U))
+        if u.ndim != 2 or u.shape[1] != 2:
+            raise ValueError("U must be [N, 2]")
+        out = np.empty((u.shape[0], 3), dtype=np.float64)
+        L.check(self._lib.sbo_plant_wo(self._ctx, u.shape[0], _ptr(u), _ptr(out)))
+        return out
+
     def profile(self) -> dict:
         p = L.Profile()
         L.check(self._lib.sbo_profile_get(self._ctx, C.byref(p)))

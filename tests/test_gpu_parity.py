@@ -18,7 +18,7 @@ from safebo_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "*.npz")) if "contour_reference" not in p)
 TOL64, TOL32 = 1e-10, 1e-4
 
 
@@ -774,3 +774,28 @@ def test_model_append_equals_a_rebuild(engine, use_invK, dtype):
     assert _nerr(mean, m2, ds["Y_std"], 1) < tol and _nerr(var, v2, ds["Y_std"], 2) < tol
     res_a = engine.sweep_safeopt(cfg["b"])
     assert res_a["count_S"] > 0
+
+
+def test_wo_plant_on_the_device_matches_the_oracle_and_the_reference_table(engine):
+    """sbo_plant_wo: the batched steady-state solve against the NumPy restatement (same Newton
+    iteration: 1e-12) and against the reference project's own 100 x 100 table (made with fsolve: 1e-5 / 1e-8)."""
+    from oracle import plants as oplants
+    from safebo_amd.plants import WilliamOttoReactor
+    z = np.load(os.path.join(HERE, "golden", "wo_contour_reference.npz"), allow_pickle=False)
+    U = np.stack([z["X_0"].ravel(), z["X_1"].ravel()], axis=1)
+    Y = engine.plant_wo(U)
+    ref = oplants.wo_outputs(U)
+    assert np.max(np.abs(Y - ref) / np.maximum(1.0, np.abs(ref))) < 1e-12
+    assert np.max(np.abs(Y[:, 0] - z["Y_objective"].ravel())) < 1e-5
+    assert np.max(np.abs(Y[:, 1] - z["Y_constraint1"].ravel())) < 1e-8
+    assert np.max(np.abs(Y[:, 2] - z["Y_constraint2"].ravel())) < 1e-8
+    plant = WilliamOttoReactor(engine=engine)
+    u = np.array([4.8, 83.0])
+    assert plant.get_objective(u) == pytest.approx(float(oplants.wo_outputs(u[None])[0, 0]), rel=1e-12)
+    assert plant.get_constraint1(u) == pytest.approx(float(oplants.wo_outputs(u[None])[0, 1]), abs=1e-14)
+    rng = np.random.default_rng(3)
+    big = np.stack([rng.uniform(4, 7, 200000), rng.uniform(70, 100, 200000)], axis=1)
+    Yb = engine.plant_wo(big)
+    assert np.isfinite(Yb).all()
+    sub = rng.choice(200000, 500, replace=False)
+    assert np.max(np.abs(Yb[sub] - oplants.wo_outputs(big[sub])) / np.maximum(1.0, np.abs(Yb[sub]))) < 1e-12

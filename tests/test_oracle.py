@@ -9,7 +9,7 @@ import pytest
 import oracle
 from safebo_amd import synthetic
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if "contour_reference" not in p)
 
 
 def _small(n=12, d=2, q=2, seed=3):
@@ -158,3 +158,20 @@ def test_fp32_mode_close_to_fp64():
     m32, v32 = oracle.gp_inference(pts, cfg["ds"], dtype=np.float32)
     assert m32.dtype == np.float32
     assert np.max(np.abs(m32 - m64)) < 5e-4 and np.max(np.abs(v32 - v64)) < 5e-4
+
+
+def test_wo_plant_restatement_matches_the_reference_table():
+    """oracle/plants.py against the reference project's own 100 x 100 table of the William-Otto reactor outputs
+    (tests/golden/wo_contour_reference.npz, a verbatim copy of its data/data_contour_WilliamOttoReactor.npz): the table was
+    made with SciPy fsolve at its default tolerance (~1.5e-8 relative in the states), hence the bars."""
+    from oracle import plants
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "wo_contour_reference.npz"), allow_pickle=False)
+    U = np.stack([z["X_0"].ravel(), z["X_1"].ravel()], axis=1)
+    assert U.shape == (10000, 2) and U[:, 0].min() == 4.0 and U[:, 1].max() == 100.0
+    Y = plants.wo_outputs(U)
+    assert np.max(np.abs(Y[:, 0] - z["Y_objective"].ravel())) < 1e-5          # values up to 268
+    assert np.max(np.abs(Y[:, 1] - z["Y_constraint1"].ravel())) < 1e-8
+    assert np.max(np.abs(Y[:, 2] - z["Y_constraint2"].ravel())) < 1e-8
+    # the known optimum of the reference (test/test_WilliamOttoReactor.py:250): objective -76.036 at the constrained optimum
+    f, J = plants.wo_residual_jacobian(plants.wo_steady_state(U[:7]), U[:7, 0], U[:7, 1])
+    assert np.max(np.abs(f)) < 1e-15
