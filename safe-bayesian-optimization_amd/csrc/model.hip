@@ -8,8 +8,9 @@
 //                invK: reverse both index orders, factor J invK J = U~^T U~ (U~ upper), M = J U~ J.
 //   invK absent: K from the expanded distance (models/GP_Safe.py:119), K = U^T U, M = L^-1 = U^-T by row-wise
 //                substitution, alpha = M^T (M rhs).
-// The factor is then packed into the matrix-core fragment images every K1 kernel reads (Fpk).  A 512 x 512 output
-// takes ~2 ms instead of ~45 ms of host Cholesky; 2048 x 2048 ~0.15 s instead of seconds.
+// The factor is then packed into the matrix-core fragment images every K1 kernel reads (Fpk).  Small models (n < 256)
+// run in one workgroup per output; larger ones use the blocked multi-workgroup form below (n = 512: 1.4 ms, n = 2048:
+// 9 ms per model, against ~95 ms / seconds of host Cholesky).
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -141,6 +142,183 @@ __global__ __launch_bounds__(1024) void k_model_build(int mode, int n, int npad,
   if (tid == 0) bad[o] = sh_bad;
 }
 
+// ---- blocked, multi-workgroup form of the same factorisation (n >= 256) ---------------------------------------------
+// Right-looking U^T U with panels of kPB rows; per panel two kinds of launches, every output (blockIdx.y) at once:
+//   k_chol_panel : every workgroup factors the kPB x kPB diagonal block in LDS (redundantly: it is tiny), then applies
+//                  Ukk^-T to its share of the columns to the right (the panel rows of U) and, with E, to the columns of
+//                  the inverse companion left of and inside the panel (E = L^-1 rides along exactly as in factor_utu);
+//   k_chol_update: rank-kPB update of the trailing matrix (upper triangle) and of the trailing rows of E, tiled 32 x 32.
+constexpr int kPB = 32;
+
+__global__ __launch_bounds__(256) void k_chol_prep(int mode, int n, int npad, int dpad, int d, const double* __restrict__ W,
+                                                   const double* __restrict__ As, const double* __restrict__ sqA,
+                                                   const double* __restrict__ rhs, const double* __restrict__ sf2v,
+                                                   const double* __restrict__ sn2v, double* __restrict__ work,
+                                                   double* __restrict__ F, double* __restrict__ alpha) {
+  const int o = blockIdx.y;
+  double* U = work + (size_t)o * n * n;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gstride = (long long)gridDim.x * blockDim.x;
+  if (mode == 0) {
+    const double* Wo = W + (size_t)o * n * n;
+    const double* r = rhs + (size_t)o * n;
+    for (long long i = gid; i < n; i += gstride) {                       // alpha from the caller's inverse as given
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += Wo[(size_t)i * n + j] * r[j];
+      alpha[(size_t)o * npad + i] = s;
+    }
+    for (long long idx = gid; idx < (long long)n * n; idx += gstride) { // reversed, symmetrised copy (upper triangle)
+      const int i = (int)(idx / n), k = (int)(idx % n);
+      const int ri = n - 1 - i, rk = n - 1 - k;
+      U[idx] = k >= i ? 0.5 * (Wo[(size_t)ri * n + rk] + Wo[(size_t)rk * n + ri]) : 0.0;
+    }
+  } else {
+    const double sf2 = sf2v[o], sn2 = sn2v[o];
+    const double* Ao = As + (size_t)o * npad * dpad;
+    const double* so = sqA + (size_t)o * npad;
+    double* Fo = F + (size_t)o * n * n;
+    for (long long idx = gid; idx < (long long)n * n; idx += gstride) {
+      const int k = (int)(idx / n), i = (int)(idx % n);                  // upper position (k, i)
+      double v = 0.0;
+      if (i >= k) {
+        double dot = 0.0;
+        for (int a = 0; a < d; ++a) dot += Ao[(size_t)i * dpad + a] * Ao[(size_t)k * dpad + a];
+        v = sf2 * exp(-0.5 * ((-2.0 * dot + so[i]) + so[k])) + (i == k ? sn2 : 0.0);
+      }
+      U[idx] = v;
+      Fo[idx] = 0.0;                                                     // E starts empty (its unit diagonal is implicit)
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ work, double* __restrict__ F, int with_E, int n, int kb,
+                                                    int* __restrict__ bad) {
+  __shared__ double D[kPB][kPB + 1];
+  const int o = blockIdx.y, tid = threadIdx.x;
+  double* U = work + (size_t)o * n * n;
+  double* E = F + (size_t)o * n * n;
+  const int kw = n - kb < kPB ? n - kb : kPB;
+  for (int idx = tid; idx < kPB * kPB; idx += blockDim.x) {
+    const int r = idx / kPB, cc = idx % kPB;
+    D[r][cc] = (r < kw && cc < kw && cc >= r) ? U[(size_t)(kb + r) * n + kb + cc] : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < kw; ++j) {                       // U^T U of the diagonal block, all threads in step
+    const double piv = D[j][j];
+    __syncthreads();
+    const double ljj = piv > 0.0 ? sqrt(piv) : 1.0;
+    if (tid == 0) {
+      if (!(piv > 0.0)) bad[o] = 1;
+      D[j][j] = ljj;
+    }
+    if (tid > j && tid < kw) D[j][tid] /= ljj;
+    __syncthreads();
+    for (int idx = tid; idx < kw * kw; idx += blockDim.x) {
+      const int k = idx / kw, i = idx % kw;
+      if (k > j && i >= k) D[k][i] -= D[j][k] * D[j][i];
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0)
+    for (int idx = tid; idx < kw * kw; idx += blockDim.x) {
+      const int r = idx / kw, cc = idx % kw;
+      if (cc >= r) U[(size_t)(kb + r) * n + kb + cc] = D[r][cc];
+    }
+  // columns: [kb + kw, n) of U, then (with E) [0, kb + kw) of E
+  const int nright = n - kb - kw;
+  const int ncols = nright + (with_E ? kb + kw : 0);
+  for (int x = blockIdx.x * blockDim.x + tid; x < ncols; x += gridDim.x * blockDim.x) {
+    double v[kPB];
+    const bool isU = x < nright;
+    const int col = isU ? kb + kw + x : x - nright;
+    double* base = isU ? U : E;
+#pragma unroll
+    for (int r = 0; r < kPB; ++r) {
+      double a = 0.0;
+      if (r < kw) a = (!isU && col >= kb) ? (col - kb == r ? 1.0 : 0.0) : base[(size_t)(kb + r) * n + col];
+      v[r] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < kPB; ++r) {
+      if (r < kw) {
+        double acc = v[r];
+#pragma unroll
+        for (int t = 0; t < kPB; ++t)
+          if (t < r) acc -= D[t][r] * v[t];
+        v[r] = acc / D[r][r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kPB; ++r)
+      if (r < kw && (isU || col <= kb + r)) base[(size_t)(kb + r) * n + col] = v[r];
+  }
+}
+
+// part 0: U[i][j] -= sum_r U[kb+r][i] U[kb+r][j]  (kb+kw <= i <= j < n);  part 1: E[i][c] -= sum_r U[kb+r][i] E[kb+r][c]
+// (i >= kb+kw, c < kb+kw).  32 x 32 output tiles, 4 outputs per thread.
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ work, double* __restrict__ F, int part, int n, int kb) {
+  __shared__ double Pi[kPB][33], Qx[kPB][33];
+  const int o = blockIdx.z, tid = threadIdx.x;
+  double* U = work + (size_t)o * n * n;
+  double* E = F + (size_t)o * n * n;
+  const int kw = n - kb < kPB ? n - kb : kPB;
+  const int i0 = kb + kw + blockIdx.y * 32;
+  const int x0 = part == 0 ? kb + kw + blockIdx.x * 32 : blockIdx.x * 32;
+  if (i0 >= n) return;
+  if (part == 0 && x0 + 31 < i0) return;                 // tile entirely below the diagonal
+  const double* Q = part == 0 ? U : E;
+  for (int idx = tid; idx < kPB * 32; idx += blockDim.x) {
+    const int r = idx / 32, t = idx % 32;
+    Pi[r][t] = (r < kw && i0 + t < n) ? U[(size_t)(kb + r) * n + i0 + t] : 0.0;
+    const int xc = x0 + t;
+    const bool xin = part == 0 ? xc < n : xc < kb + kw;
+    // rows of E inside the panel are lower triangular: entries right of their diagonal are zero
+    Qx[r][t] = (r < kw && xin && (part == 0 || xc <= kb + r)) ? Q[(size_t)(kb + r) * n + xc] : 0.0;
+  }
+  __syncthreads();
+  const int tx = tid % 32, ty = tid / 32;                // ty: 0..7 -> rows ty, ty+8, ty+16, ty+24
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int il = ty + 8 * rr, i = i0 + il, xc = x0 + tx;
+    if (i >= n) continue;
+    if (part == 0 ? (xc >= n || xc < i) : (xc >= kb + kw)) continue;
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < kPB; ++r) acc += Pi[r][il] * Qx[r][tx];
+    double* dst = (part == 0 ? U : E) + (size_t)i * n + xc;
+    *dst -= acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chol_finish(int mode, int n, int npad, const double* __restrict__ rhs,
+                                                     double* __restrict__ work, double* __restrict__ F, double* __restrict__ alpha) {
+  const int o = blockIdx.y;
+  double* U = work + (size_t)o * n * n;
+  double* Fo = F + (size_t)o * n * n;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x, gstride = (long long)gridDim.x * blockDim.x;
+  if (mode == 0) {
+    for (long long idx = gid; idx < (long long)n * n; idx += gstride) {   // M = J U~ J
+      const int i = (int)(idx / n), j = (int)(idx % n);
+      Fo[idx] = j <= i ? U[(size_t)(n - 1 - i) * n + (n - 1 - j)] : 0.0;
+    }
+  } else {
+    // alpha = M^T (M rhs), M = Fo (lower).  t = M rhs goes through the (now free) first row of `work`
+    const double* r = rhs + (size_t)o * n;
+    if (blockIdx.x == 0) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double s = 0.0;
+        for (int j = 0; j <= i; ++j) s += Fo[(size_t)i * n + j] * r[j];
+        U[i] = s;
+      }
+      __syncthreads();
+      for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double s = 0.0;
+        for (int i = j; i < n; ++i) s += Fo[(size_t)i * n + j] * U[i];
+        alpha[(size_t)o * npad + j] = s;
+      }
+    }
+  }
+}
+
 // lower-triangular factor [q][n][n] -> matrix-core A-fragment images [q][tri(I, J)][256] in the model dtype
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_factor(const double* __restrict__ F, int n, int ld, size_t ostride, int nb,
@@ -263,9 +441,32 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<
   SBO_HIP(hipMemcpyAsync(dsf2, mc.sf2, sizeof(double) * q, hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(dsn2, sn2, sizeof(double) * q, hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemsetAsync(dalpha, 0, sizeof(double) * (size_t)q * npad, c->stream));
-  hipLaunchKernelGGL(k_model_build, dim3(q), dim3(1024), 0, c->stream, host_invK ? 0 : 1, n, npad, mc.dpad, mc.d, (const double*)dW,
-                     (const double*)dAs, (const double*)dsq, (const double*)drhs, (const double*)dsf2, (const double*)dsn2, dwork, dF,
-                     dalpha, dbad);
+  const int mode = host_invK ? 0 : 1;
+  if (n >= 256) {
+    // blocked multi-workgroup factorisation: the single-workgroup loop is bound by the latency of its own updates
+    SBO_HIP(hipMemsetAsync(dbad, 0, sizeof(int) * q, c->stream));
+    hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)dW,
+                       (const double*)dAs, (const double*)dsq, (const double*)drhs, (const double*)dsf2, (const double*)dsn2, dwork,
+                       dF, dalpha);
+    for (int kb = 0; kb < n; kb += kPB) {
+      const int kw = std::min(kPB, n - kb);
+      const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
+      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, (ncols + 255) / 256), q), dim3(256), 0, c->stream, dwork, dF, mode, n,
+                         kb, dbad);
+      const int rest = n - kb - kw;
+      if (rest > 0) {
+        const unsigned ti = (unsigned)((rest + 31) / 32);
+        hipLaunchKernelGGL(k_chol_update, dim3(ti, ti, q), dim3(256), 0, c->stream, dwork, dF, 0, n, kb);
+        if (mode)
+          hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((kb + kw + 31) / 32), ti, q), dim3(256), 0, c->stream, dwork, dF, 1, n, kb);
+      }
+    }
+    hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, (const double*)drhs, dwork, dF, dalpha);
+  } else {
+    hipLaunchKernelGGL(k_model_build, dim3(q), dim3(1024), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)dW,
+                       (const double*)dAs, (const double*)dsq, (const double*)drhs, (const double*)dsf2, (const double*)dsn2, dwork, dF,
+                       dalpha, dbad);
+  }
   const size_t ntri = (size_t)nb * (nb + 1) / 2;
   c->fpk_stride = ntri * 4 * 64;
   if ((rc = ensure(c->Fpk, sizeof(T) * ((size_t)q * c->fpk_stride + 512)))) return rc;   // + padding: the K1g pipeline over-reads
