@@ -376,14 +376,21 @@ int bilinear_setup(sbo_ctx* c) {
   // functions; only the local lines are tabulated
   grid_axis_positions(c, 1, 0, cs.count[1], xn1_all);
   std::vector<bl::AxisBasis> b0(q), b1(q);
-  std::vector<double> col(n);
-  for (int o = 0; o < q; ++o) {
-    for (int a = 0; a < 2; ++a) {
-      for (int j = 0; j < n; ++j) col[j] = c->h_Xnorm[(size_t)j * mc.d + a] * mc.vinv[o][a];     // GP_Safe.py:115
-      bl::AxisBasis& b = a == 0 ? b0[o] : b1[o];
-      const std::vector<double>& xs = a == 0 ? xn0 : xn1_all;
-      if (!bl::axis_basis(n, col.data(), mc.vinv[o][a], xs.data(), (int)xs.size(), b)) return SBO_OK;
-    }
+  {
+    // the 2 q bases are independent: one host thread each
+    std::vector<char> ok(2 * q, 0);
+    bl::parallel_ranges(2 * q, [&](int lo_, int hi_) {
+      std::vector<double> col(n);
+      for (int t = lo_; t < hi_; ++t) {
+        const int o = t / 2, a = t % 2;
+        for (int j = 0; j < n; ++j) col[j] = c->h_Xnorm[(size_t)j * mc.d + a] * mc.vinv[o][a];   // GP_Safe.py:115
+        bl::AxisBasis& b = a == 0 ? b0[o] : b1[o];
+        const std::vector<double>& xs = a == 0 ? xn0 : xn1_all;
+        ok[t] = bl::axis_basis(n, col.data(), mc.vinv[o][a], xs.data(), (int)xs.size(), b) ? 1 : 0;
+      }
+    });
+    for (int t = 0; t < 2 * q; ++t)
+      if (!ok[t]) return SBO_OK;
   }
   lap("bases");
   int r0u = 0, K0 = 0, K1 = 0;
