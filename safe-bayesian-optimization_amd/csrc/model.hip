@@ -477,11 +477,9 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<
   hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)dalpha, npad, n, q, npad, (T*)c->alpha.p);
   // fp64 factor and alpha stay resident (leading dimension f_cap) so that observations can be appended in O(n^2)
   const int cap = std::min(SBO_MAX_N, (npad + 256 + 127) / 128 * 128);
-  if (cap != c->f_cap || !c->Fplain.p) {
-    if ((rc = ensure(c->Fplain, sizeof(double) * (size_t)q * cap * cap))) return rc;
-    if ((rc = ensure(c->alpha64, sizeof(double) * (size_t)q * cap))) return rc;
-    c->f_cap = cap;
-  }
+  if ((rc = ensure(c->Fplain, sizeof(double) * (size_t)q * cap * cap))) return rc;
+  if ((rc = ensure(c->alpha64, sizeof(double) * (size_t)q * cap))) return rc;
+  c->f_cap = cap;
   for (int o = 0; o < q; ++o) {
     SBO_HIP(hipMemcpy2DAsync((double*)c->Fplain.p + (size_t)o * cap * cap, sizeof(double) * cap, dF + (size_t)o * nn, sizeof(double) * n,
                              sizeof(double) * n, n, hipMemcpyDeviceToDevice, c->stream));

@@ -799,3 +799,46 @@ def test_wo_plant_on_the_device_matches_the_oracle_and_the_reference_table(engin
     assert np.isfinite(Yb).all()
     sub = rng.choice(200000, 500, replace=False)
     assert np.max(np.abs(Yb[sub] - oplants.wo_outputs(big[sub])) / np.maximum(1.0, np.abs(Yb[sub]))) < 1e-12
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+def test_random_models_full_sweeps_against_the_oracle(engine, seed):
+    """Random models (n, hyper-parameters, b) on a 72 x 70 grid -- large enough for the GEMM posterior (K1b) whenever it
+    pays, small enough for the oracle's brute-force sets: every SafeOpt and GoOSE mask and index against the oracle.
+    A mask bit may differ from the oracle's only where the deciding bound is within the posterior tolerance of zero
+    (the oracle's own rounding decides those); none of these seeds has such a candidate, so equality is exact."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(40, 220))
+    cfg = synthetic.make_config("B" if seed % 2 else "C", n=n, seed=7100 + seed)
+    q = cfg["Y"].shape[1]
+    hyp = np.empty((4, q))
+    hyp[:2] = rng.uniform(-0.8, 0.6, size=(2, q))
+    hyp[2] = rng.uniform(-0.5, 0.5, size=q)
+    hyp[3] = rng.uniform(-2.5, -2.0, size=q)
+    ds = synthetic.make_dataset(cfg["X"], cfg["Y"], hyp)
+    b = float(rng.uniform(1.0, 3.0))
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [72, 70]
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_model(ds)
+    engine.set_grid(lo, hi, count)
+    mean, var = _check_posterior(engine, ds, pts, TOL64)
+    ref = oracle.safeopt_sweep(pts, ds, b)
+    if ref["empty_safe_set"]:
+        with pytest.raises(safebo_amd.EmptySafeSetError):
+            engine.sweep_safeopt(b, posterior_ready=True)
+        return
+    res = engine.sweep_safeopt(b, want_masks=True, posterior_ready=True)
+    lcb_min = np.min(np.abs(ref["lcb"][:, 1:]), axis=1)
+    for k in ("S", "U", "M"):
+        diff = engine.mask(k) != ref[k]
+        assert not diff.any(), (k, int(diff.sum()), float(lcb_min[diff].max()) if diff.any() else 0.0)
+    for c in range(1, q):
+        assert np.array_equal(engine.mask("G", c), ref["G"][c - 1]), f"G{c}"
+    assert res["minimizer_index"] == ref["minimizer_index"]
+    assert list(res["expander_index_c"]) == list(ref["expander_index"])
+    gref = oracle.goose_sweep(pts, ds, b)
+    g = engine.sweep_goose(b, want_masks=True, posterior_ready=True)
+    for c in range(1, q):
+        assert np.array_equal(engine.mask("O", c), gref["O"][c - 1]), f"O{c}"
+    assert (g["safe_min_index"], g["target_index"], g["explore_index"]) == (gref["safe_min_index"], gref["target_index"],
+                                                                             gref["explore_index"])
