@@ -13,7 +13,7 @@
 
 namespace sbo {
 
-__global__ __launch_bounds__(256) void k_nll_batch(int n, int d, const double* __restrict__ X, const double* __restrict__ y,
+__global__ __launch_bounds__(1024) void k_nll_batch(int n, int d, const double* __restrict__ X, const double* __restrict__ y,
                                                    const double* __restrict__ hyper, double* __restrict__ work,
                                                    double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -74,10 +74,22 @@ __global__ __launch_bounds__(256) void k_nll_batch(int n, int d, const double* _
     __syncthreads();
     const double zj = z[j];
     for (int i = j + 1 + tid; i < n; i += blockDim.x) z[i] -= uj[i] * zj;   // forward substitution rides along
-    for (int k = j + 1 + wave; k < n; k += nw) {                          // trailing update, row k from column k on
+    // trailing update, row k from column k on; a wave keeps two rows in flight (the loop is bound by memory latency)
+    for (int k = j + 1 + wave; k < n; k += 2 * nw) {
+      const int k2 = k + nw;
       const double f = uj[k];
       double* uk = U + (size_t)k * n;
-      for (int i = k + lane; i < n; i += 64) uk[i] -= f * uj[i];
+      if (k2 < n) {
+        const double f2 = uj[k2];
+        double* uk2 = U + (size_t)k2 * n;
+        for (int i = k + lane; i < n; i += 64) {
+          const double v = uj[i];
+          uk[i] -= f * v;
+          if (i >= k2) uk2[i] -= f2 * v;
+        }
+      } else {
+        for (int i = k + lane; i < n; i += 64) uk[i] -= f * uj[i];
+      }
     }
     __syncthreads();
   }
@@ -108,7 +120,8 @@ extern "C" int sbo_nll_batch(sbo_ctx* c, int n, int d, const double* X_norm, con
   SBO_HIP(hipMemcpyAsync(dy, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(dh, hyper, sizeof(double) * (size_t)P * (d + 2), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nll_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_nll_batch, dim3(P), dim3(256), lds, c->stream, n, d, (const double*)dX, (const double*)dy,
+  // 1024 threads per member for the larger matrices (more rows of the trailing update in flight); small ones keep 256
+  hipLaunchKernelGGL(k_nll_batch, dim3(P), dim3(n >= 96 ? 1024 : 256), lds, c->stream, n, d, (const double*)dX, (const double*)dy,
                      (const double*)dh, (double*)c->fitwork.p, dout);
   SBO_HIP(hipGetLastError());
   SBO_HIP(hipMemcpyAsync(out, dout, sizeof(double) * P, hipMemcpyDeviceToHost, c->stream));
