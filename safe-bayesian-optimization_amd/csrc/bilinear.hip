@@ -292,7 +292,7 @@ __device__ __forceinline__ void post_phase(const PostCtx& cx, const double* __re
 __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
                                                   const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
                                                   size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
-                                                  int KSm, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
+                                                  int KSm, int KBm2, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
                                                   double* __restrict__ var_out, unsigned long long* __restrict__ Lmax) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
   const int o = blockIdx.z;
@@ -322,9 +322,10 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
   double gmax = 0.0;
   post_phase<0>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, KS0, vo, sf2, ystd * ystd, 0.0, gmax);
   post_phase<1>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax);
-  post_phase<2>(cx, VAo + (size_t)nrb * KBm * 256, SBo + (size_t)ncs * KBm * 256, 2 * KBm, 2 * KBm * 4, nullptr,
+  post_phase<2>(cx, VAo + (size_t)nrb * KBm * 256, SBo + (size_t)ncs * KBm * 256, KBm2, 2 * KSm, nullptr,
                 ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax);
-  post_phase<3>(cx, VAo + (size_t)nrb * KBm * 256 * 3, SBo, KBm, KSm, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0, gmax);
+  post_phase<3>(cx, VAo + (size_t)nrb * (KBm + KBm2) * 256, SBo, KBm, KSm, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0,
+                gmax);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const double other = __shfl_xor(gmax, off);
@@ -413,12 +414,15 @@ int bilinear_setup(sbo_ctx* c) {
   pl.sP1A = (size_t)nrb * KB1 * 256;
   pl.sT4f = (size_t)KB0 * KB1 * 4 * 64;
   pl.sBtA = (size_t)nrb * KB0 * 256;
-  const int KBm = (r0u + 15) / 16;
+  // mean phases: K = r0p (basis size rounded to whole k-steps); the axis-0 gradient phase concatenates two such operands
+  const int r0p = (r0u + 3) / 4 * 4;
+  const int KBm = (r0p + 15) / 16, KBm2 = (2 * r0p + 15) / 16;
   pl.KBm = KBm;
-  pl.KSm = (r0u + 3) / 4;
+  pl.KBm2 = KBm2;
+  pl.KSm = r0p / 4;
   pl.KS0 = (K0 + 3) / 4;
-  pl.sVA = (size_t)nrb * KBm * 256 * 4;          // image sets  V0 | [V1; V0] | V1x
-  pl.sSBf = (size_t)ncs0 * KBm * 256 * 3;       // fragment sets  S0 | [S0; -xn0 S0]
+  pl.sVA = (size_t)nrb * (2 * KBm + KBm2) * 256;     // image sets  V0 | [V1; V0] | V1x
+  pl.sSBf = (size_t)ncs0 * (KBm + KBm2) * 256;      // fragment sets  S0 | [S0; -xn0 S0]
   std::vector<double> hVA(pl.sVA * q, 0.0), hSBf(pl.sSBf * q, 0.0), Vb((size_t)NB * r0u * nlines);
   std::vector<double> Mb, beta((size_t)NB * n), S1loc;
   std::vector<int> map0, map1;
@@ -502,42 +506,35 @@ int bilinear_setup(sbo_ctx* c) {
           for (long long l = 0; l < nlines; ++l) dst[l] += m * s1[l];
         }
       }
-    // packed A images of the mean phases: rows = lines, k = basis index p
-    auto put_rows = [&](double* img, int KBx, int kb_off, auto value /* (p, line) */) {
-      for (int rb = 0; rb < nrb; ++rb)
-        for (int kb = 0; kb < KBm; ++kb)
-          for (int r = 0; r < 16; ++r)
-            for (int slot = 0; slot < 4; ++slot)
-              for (int kk = 0; kk < 4; ++kk) {
-                const long long line = (long long)rb * 16 + r;
-                const int pidx = kb * 16 + MM<double>::jslot(kk, slot);
-                if (line < nlines && pidx < r0)
-                  img[((size_t)rb * KBx + kb_off + kb) * 256 + MM<double>::pack_pos(r, slot, kk)] = value(pidx, line);
-              }
+    // packed A images of the mean phases: rows = lines, k = koff + basis index p (element (row, k) of a K = 16 KBx operand)
+    auto put_rows = [&](double* img, int KBx, int koff, auto value /* (p, line) */) {
+      for (long long line = 0; line < nlines; ++line)
+        for (int pidx = 0; pidx < r0; ++pidx) {
+          const int k = koff + pidx, kb = k >> 4, jin = k & 15;
+          img[((size_t)(line >> 4) * KBx + kb) * 256 + MM<double>::pack_pos((int)(line & 15), jin & 3, jin >> 2)] = value(pidx, line);
+        }
     };
     double* va = &hVA[pl.sVA * o];
-    const size_t set = (size_t)nrb * KBm * 256;
+    const size_t set = (size_t)nrb * KBm * 256, set2 = (size_t)nrb * KBm2 * 256;
     put_rows(va, KBm, 0, [&](int pi, long long l) { return Vb[((size_t)0 * r0u + pi) * nlines + l]; });
-    put_rows(va + set, 2 * KBm, 0, [&](int pi, long long l) { return Vb[((size_t)1 * r0u + pi) * nlines + l]; });
-    put_rows(va + set, 2 * KBm, KBm, [&](int pi, long long l) { return Vb[((size_t)0 * r0u + pi) * nlines + l]; });
-    put_rows(va + 3 * set, KBm, 0, [&](int pi, long long l) {
+    put_rows(va + set, KBm2, 0, [&](int pi, long long l) { return Vb[((size_t)1 * r0u + pi) * nlines + l]; });
+    put_rows(va + set, KBm2, r0p, [&](int pi, long long l) { return Vb[((size_t)0 * r0u + pi) * nlines + l]; });
+    put_rows(va + set + set2, KBm, 0, [&](int pi, long long l) {
       return Vb[((size_t)2 * r0u + pi) * nlines + l] - xn1_all[(size_t)(line0 + l)] * Vb[((size_t)0 * r0u + pi) * nlines + l];
     });
-    // B fragments of the mean phases: k = basis index p, columns = axis-0 positions
-    auto put_cols = [&](double* frag, int KBx, int kb_off, auto value /* (p, x) */) {
-      for (int csx = 0; csx < ncs0; ++csx)
-        for (int ks = 0; ks < KBm * 4; ++ks)
-          for (int l = 0; l < 64; ++l) {
-            const int pidx = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
-            const long long x = (long long)csx * 16 + (l & 15);
-            if (pidx < r0 && x < cnt0) frag[((size_t)csx * KBx * 4 + kb_off * 4 + ks) * 64 + l] = value(pidx, x);
-          }
+    // B fragments of the mean phases: k = koff + basis index p, columns = axis-0 positions
+    auto put_cols = [&](double* frag, int KBx, int koff, auto value /* (p, x) */) {
+      for (long long x = 0; x < cnt0; ++x)
+        for (int pidx = 0; pidx < r0; ++pidx) {
+          const int k = koff + pidx, ks = (k >> 4) * 4 + ((k & 15) >> 2), slot = k & 3;
+          frag[((size_t)(x >> 4) * KBx * 4 + ks) * 64 + (slot << 4) + (int)(x & 15)] = value(pidx, x);
+        }
     };
     double* sb = &hSBf[pl.sSBf * o];
     const size_t fset = (size_t)ncs0 * KBm * 256;
     put_cols(sb, KBm, 0, [&](int pi, long long x) { return b0[o].S[(size_t)pi * cnt0 + x]; });
-    put_cols(sb + fset, 2 * KBm, 0, [&](int pi, long long x) { return b0[o].S[(size_t)pi * cnt0 + x]; });
-    put_cols(sb + fset, 2 * KBm, KBm, [&](int pi, long long x) { return -xn0[(size_t)x] * b0[o].S[(size_t)pi * cnt0 + x]; });
+    put_cols(sb + fset, KBm2, 0, [&](int pi, long long x) { return b0[o].S[(size_t)pi * cnt0 + x]; });
+    put_cols(sb + fset, KBm2, r0p, [&](int pi, long long x) { return -xn0[(size_t)x] * b0[o].S[(size_t)pi * cnt0 + x]; });
     pl.r0[o] = r0;
     pl.r1[o] = r1;
     lap("tables");
@@ -570,12 +567,12 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_bpost, dim3((unsigned)((pl.ncs0 + 7) / 8), (unsigned)((pl.nrb + 7) / 8), (unsigned)q), dim3(256), lds, c->stream,
                      mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
-                     pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.nrb, pl.ncs0, nlines,
+                     pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
                      (double*)c->mean.p, (double*)c->var.p, (unsigned long long*)c->Lmax.p);
   (void)line0;
   // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (16 x 16 x 4 steps, 2 flops per multiply-add)
   const double tiles2 = (double)pl.nrb * pl.ncs0, tiles1 = (double)pl.nrb * pl.KB0;
-  c->last_k1_flops = (double)q * 2.0 * 1024.0 * (tiles1 * pl.KB1 * 4 + tiles2 * (pl.KS0 + 2 * pl.KSm + 2 * pl.KBm * 4));
+  c->last_k1_flops = (double)q * 2.0 * 1024.0 * (4.0 * tiles1 * pl.KB1 + tiles2 * (pl.KS0 + 4 * pl.KSm));
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }

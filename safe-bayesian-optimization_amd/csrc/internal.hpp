@@ -47,7 +47,7 @@ struct BilinearPlan {
   bool usable = false;   // the bases qualified: the posterior runs as two GEMMs
   int KB0 = 0, KB1 = 0;  // 16-blocks of the pair indices of axis 0 / axis 1
   int r0u = 0, ncs0 = 0, nrb = 0;
-  int KS0 = 0, KBm = 0, KSm = 0;   // k-steps of the variance phase; k-blocks / k-steps of the mean phases
+  int KS0 = 0, KBm = 0, KSm = 0, KBm2 = 0;   // k-steps of the variance phase; k-blocks / k-steps of the mean phases
   size_t sVA = 0, sSBf = 0;
   long long nlines_pad = 0;
   size_t sP0f = 0, sP1A = 0, sT4f = 0, sBtA = 0;   // per-output strides (elements)
