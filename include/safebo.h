@@ -222,6 +222,15 @@ int sbo_masks_get(sbo_ctx* ctx, int which, int c, uint8_t* out);
 int sbo_nll_batch(sbo_ctx* ctx, int n, int d, const double* X_norm, const double* y, int P, const double* hyper,
                   double* out);
 
+/* The whole differential-evolution search of that objective on the device (models/GP_Safe.py:205-224: SciPy DE, default
+ * best1bin strategy, mutation dithered in [0.5, 1), recombination 0.7; deferred updating here).  init_pop[P, d+2] is the
+ * initial population (SciPy uses a Latin hypercube over the bounds lo / hi [d+2]); stops after maxiter generations or when
+ * std(energies) <= atol + tol |mean(energies)|.  best_x[d+2], *best_energy, *generations are written on return; the
+ * caller may polish best_x (SciPy does, with L-BFGS-B). */
+int sbo_fit_de(sbo_ctx* ctx, int n, int d, const double* X_norm, const double* y, int P, const double* lo, const double* hi,
+               const double* init_pop, uint64_t seed, int maxiter, double tol, double atol, double* best_x, double* best_energy,
+               int* generations);
+
 /* ---- plant evaluation ------------------------------------------ */
 /* The reference's William-Otto reactor (problems/WilliamOttoReactor_Problem.py:19-93), noise-free, for n input rows
  * u[n, 2] = (Fb, Tr): out[n, 3] = (get_objective, get_constraint1, get_constraint2), each the steady state of the six

@@ -38,7 +38,8 @@ class GP:
         self._uploaded_version = -1
         self.fixed_hyper = None
         self.de_options = {}         # forwarded to scipy DE (e.g. {"seed": 0, "maxiter": 50})
-        self.fit_on_device = False   # True: DE evaluates whole populations with the batched device NLL (sbo_nll_batch)
+        self.fit_on_device = False   # True: DE evaluates whole populations with the batched device NLL (sbo_nll_batch);
+                                     # "de": the whole DE search runs on the device (sbo_fit_de), polish on the host
         self.var_out = True
 
     # ---- engine plumbing -----------------------------------------------------------------------------------
@@ -123,6 +124,25 @@ class GP:
         for i in range(self.ny_dim):
             if self.fixed_hyper is not None:
                 hypopt[:, i] = np.asarray(self.fixed_hyper, dtype=np.float64)[:, i]
+            elif self.fit_on_device == "de":
+                # the whole DE search on the device (sbo_fit_de): SciPy's defaults as the reference uses them (popsize 15 per
+                # dimension, Latin-hypercube start, best1bin, mutation (0.5, 1), recombination 0.7, tol 0.01), deferred
+                # updating, then SciPy's own polish step (L-BFGS-B from the best member) on the host objective
+                from scipy.optimize import minimize
+                from scipy.stats import qmc
+                opts = dict(self.de_options)
+                seed = int(opts.get("seed", 0) or 0)
+                P = int(opts.get("popsize", 15)) * (d + 2)
+                pop = qmc.scale(qmc.LatinHypercube(d + 2, seed=seed).random(P), bounds[:, 0], bounds[:, 1])
+                y_i = np.ascontiguousarray(Y_norm[:, i])
+                best, energy, _ = self.engine.fit_de(X_norm, y_i, bounds, pop, seed=seed + i, maxiter=int(opts.get("maxiter", 1000)),
+                                                     tol=float(opts.get("tol", 0.01)), atol=float(opts.get("atol", 0.0)))
+                if opts.get("polish", True):
+                    res = minimize(self.negative_loglikelihood, best, args=(X_norm, Y_norm[:, i:i + 1]), method="L-BFGS-B",
+                                   bounds=bounds)
+                    if res.fun < energy:
+                        best = res.x
+                hypopt[:, i] = best
             elif self.fit_on_device:
                 # same objective and bounds; SciPy hands over the whole trial population (vectorized, deferred
                 # updating) and the device returns one NLL per member

@@ -100,6 +100,8 @@ SYMBOLS = [
     ("sbo_sweep_tr", C.c_int, [_P, C.POINTER(SweepOpts), _P, C.c_double, C.POINTER(TRResult)]),
     ("sbo_masks_get", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("sbo_nll_batch", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
+    ("sbo_fit_de", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_uint64, C.c_int, C.c_double, C.c_double, _P, _P,
+                             C.POINTER(C.c_int)]),
     ("sbo_plant_wo", C.c_int, [_P, C.c_int64, _P, _P]),
     ("sbo_profile_get", C.c_int, [_P, C.POINTER(Profile)]),
     ("sbo_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),

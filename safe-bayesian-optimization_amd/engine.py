@@ -238,6 +238,22 @@ class SweepEngine:
         L.check(self._lib.sbo_nll_batch(self._ctx, X.shape[0], X.shape[1], _ptr(X), _ptr(yv), H.shape[0], _ptr(H), _ptr(out)))
         return out
 
+    def fit_de(self, X_norm, y, bounds, init_pop, seed: int = 0, maxiter: int = 1000, tol: float = 0.01, atol: float = 0.0):
+        """Differential evolution of ``negative_loglikelihood`` on the device (``sbo_fit_de``).  bounds[d+2, 2],
+        init_pop[P, d+2].  Returns (best hyper-parameters [d+2], NLL, generations run)."""
+        X = _f64(X_norm)
+        yv = _f64(np.asarray(y).reshape(-1))
+        B = _f64(bounds)
+        pop = _f64(init_pop)
+        D = X.shape[1] + 2
+        if X.ndim != 2 or B.shape != (D, 2) or pop.ndim != 2 or pop.shape[1] != D or yv.shape[0] != X.shape[0]:
+            raise ValueError("X_norm [n, d], y [n], bounds [d+2, 2], init_pop [P, d+2]")
+        lo, hi = _f64(B[:, 0]), _f64(B[:, 1])
+        best, energy, gens = np.empty(D), C.c_double(), C.c_int()
+        L.check(self._lib.sbo_fit_de(self._ctx, X.shape[0], X.shape[1], _ptr(X), _ptr(yv), pop.shape[0], _ptr(lo), _ptr(hi), _ptr(pop),
+                                     int(seed), int(maxiter), float(tol), float(atol), _ptr(best), C.byref(energy), C.byref(gens)))
+        return best, float(energy.value), int(gens.value)
+
     def plant_wo(self, U) -> np.ndarray:
         """William-Otto reactor outputs (objective, constraint 1, constraint 2) for input rows U[N, 2] = (Fb, Tr)."""
         u = _f64(np.atleast_2d(U))

@@ -175,6 +175,32 @@ def test_fit_on_device_reaches_the_host_optimum():
     assert np.all(m_dev.hypopt[:3] >= -1.5) and np.all(m_dev.hypopt[:3] <= 1.5) and np.all(m_dev.hypopt[3] <= -2.0)
 
 
+@pytest.mark.gpu
+def test_device_differential_evolution_reaches_the_host_optimum():
+    """fit_on_device = "de": the whole DE search on the device (sbo_fit_de) + SciPy's polish step must find a minimum of
+    the same objective that is as good as SciPy's own DE (the searches are stochastic: the values, not the paths, agree)."""
+    import time
+    m_host = _init(SafeOpt.BO, n=14, fixed=False)
+    m_dev = _init(SafeOpt.BO, n=14, fixed=False)
+    m_host.de_options = {"seed": 5, "tol": 1e-4}
+    m_dev.de_options = {"seed": 5, "tol": 1e-4}
+    m_dev.fit_on_device = "de"
+    t0 = time.perf_counter()
+    m_host.GP_initialization(m_host.X, m_host.Y, "RBF", multi_hyper=5)
+    t_host = time.perf_counter() - t0
+    m_dev.X, m_dev.Y = m_host.X.copy(), m_host.Y.copy()
+    m_dev.GP_initialization(m_dev.X, m_dev.Y, "RBF", multi_hyper=5)        # (includes first-use allocations)
+    t0 = time.perf_counter()
+    m_dev.GP_initialization(m_dev.X, m_dev.Y, "RBF", multi_hyper=5)
+    t_dev = time.perf_counter() - t0
+    for i in range(2):
+        f_host = m_host.negative_loglikelihood(m_host.hypopt[:, i], m_host.X_norm, m_host.Y_norm[:, i:i + 1])
+        f_dev = m_host.negative_loglikelihood(m_dev.hypopt[:, i], m_host.X_norm, m_host.Y_norm[:, i:i + 1])
+        assert f_dev <= f_host + 1e-3 * max(1.0, abs(f_host)), (i, f_dev, f_host)
+    assert np.all(m_dev.hypopt[:3] >= -1.5) and np.all(m_dev.hypopt[:3] <= 1.5) and np.all(m_dev.hypopt[3] <= -2.0)
+    print(f"DE fit of 2 outputs, n = 14: SciPy {t_host * 1e3:.0f} ms, device {t_dev * 1e3:.0f} ms")
+
+
 TR_PARAMS = {"radius": 0.5, "radius_max": 1, "radius_red": 0.8, "radius_inc": 1.1, "rho_lb": 0.2, "rho_ub": 0.8}
 
 
