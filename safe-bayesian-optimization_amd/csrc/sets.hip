@@ -265,1230 +265,9 @@ __global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ part
   }
 }
 
-// ---- K4: exact Euclidean distance transform of the U mask on the grid ---------------------------------
-// axis 0: one wave per grid line, nearest set bit on either side found with ballots (coalesced, exact)
-__global__ __launch_bounds__(256) void k_edt_axis0(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
-                                                   double* __restrict__ D) {
-  const int lane = threadIdx.x & 63;
-  const long long line = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (line >= nlines) return;
-  const uint8_t* u = U + line * count0;
-  double* d = D + line * count0;
-  const int nch = (count0 + 63) >> 6;
-  long long carry = -1;
-  for (int ch = 0; ch < nch; ++ch) {
-    const int i = ch * 64 + lane;
-    const bool bit = i < count0 && u[i];
-    const unsigned long long m = __ballot(bit);
-    const unsigned long long lower = m & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-    const long long li = lower ? (long long)ch * 64 + (63 - __clzll((long long)lower)) : carry;
-    if (i < count0) d[i] = (double)li;
-    if (m) carry = (long long)ch * 64 + (63 - __clzll((long long)m));
-  }
-  carry = -1;
-  for (int ch = nch - 1; ch >= 0; --ch) {
-    const int i = ch * 64 + lane;
-    const bool bit = i < count0 && u[i];
-    const unsigned long long m = __ballot(bit);
-    const unsigned long long upper = m >> lane;
-    const long long ri = upper ? (long long)ch * 64 + lane + (__ffsll((long long)upper) - 1) : carry;
-    if (i < count0) {
-      const long long li = (long long)d[i];
-      long long t = -1;
-      if (li >= 0) t = i - li;
-      if (ri >= 0 && (t < 0 || ri - i < t)) t = ri - i;
-      double v = kInfD;
-      if (t >= 0) {
-        const double dt = h0 * (double)t;
-        v = dt * dt;
-      }
-      d[i] = v;
-    }
-    if (m) carry = (long long)ch * 64 + (__ffsll((long long)m) - 1);
-  }
-}
-
-// axes >= 1: D_out[g] = min_t D_in[g + t stride] + (h t)^2, searched outwards with the two exits
-//   (h t)^2 >= best  (nothing further can improve)  and  h t > cap  (beyond any radius that matters).
-// `accept2`: once best <= accept2 the caller's decision is already "within the radius" and a smaller minimum cannot
-// change it, so the search stops (pass -1 to get the exact minimum).
-__device__ __forceinline__ double edt_scan_point(const double* __restrict__ Din, long long g, long long stride, int cnt,
-                                                 int ia, double h, double cap, double accept2 = -1.0) {
-  double best = Din[g];
-  for (int t = 1; t < cnt; ++t) {
-    const double dt = h * (double)t;
-    const double e = dt * dt;
-    if (e >= best || dt > cap || best <= accept2) break;
-    const bool lo_ok = ia - t >= 0, hi_ok = ia + t < cnt;
-    if (!lo_ok && !hi_ok) break;
-    const double c1 = lo_ok ? Din[g - (long long)t * stride] : kInfD;
-    const double c2 = hi_ok ? Din[g + (long long)t * stride] : kInfD;
-    const double c = (c1 < c2 ? c1 : c2) + e;
-    best = c < best ? c : best;
-  }
-  return best;
-}
-
-// Last-axis scans with a one-level min-pyramid.  Bmin[b * stride + p] = min of the input over the kBlk (or `blk`) steps
-// of block b at in-plane position p.  A block whose bound  Bmin + (h gap)^2  cannot beat the running minimum is skipped
-// with one load instead of `blk`; the candidates examined inside a block and their arithmetic are those of the
-// step-by-step scan, so the minimum (up to the same early exits) is identical.  This keeps the scan cost near
-// O(sqrt(radius in steps)) when the grid is much finer along the last axis than the radius (weak-scaling grids).
-__global__ __launch_bounds__(256) void k_block_min(const double* __restrict__ Din, long long stride, int cnt, int blk,
-                                                   double* __restrict__ Bmin) {
-  const int nblk = (cnt + blk - 1) / blk;
-  const long long total = (long long)nblk * stride;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long p = i % stride;
-    const int b = (int)(i / stride);
-    const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
-    double m = kInfD;
-    for (int j = b * blk; j < j1; ++j) {
-      const double v = Din[(long long)j * stride + p];
-      m = v < m ? v : m;
-    }
-    Bmin[i] = m;
-  }
-}
-
-// Euclidean form (values >= 0, exits as edt_scan_point: (h t)^2 >= best, h t > cap, best <= accept2).
-// Order of visits: the block with the smallest bound first (it almost always holds the minimiser, so `best` is near
-// its final value after one block), then every block whose bound still beats `best`.
-__device__ __forceinline__ double edt_scan_blocked(const double* __restrict__ Din, const double* __restrict__ Bmin, long long p,
-                                                   long long stride, int cnt, int ia, double h, double cap, double accept2,
-                                                   int blk) {
-  // The few candidates that reach this scan decide the kernel's duration through their chain of dependent loads, so
-  // loads are issued in independent batches (eight block values / eight bounds at a time) and only then examined.
-  double best = Din[(long long)ia * stride + p];
-  const int nblk = (cnt + blk - 1) / blk, b0 = ia / blk;
-  auto scan_block = [&](int b) {
-    const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
-    for (int j = b * blk; j < j1; j += 8) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = j + u < j1 ? Din[(long long)(j + u) * stride + p] : kInfD;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int jj = j + u;
-        const double dt = h * (double)(jj > ia ? jj - ia : ia - jj);
-        const double cnd = v[u] + dt * dt;
-        if (dt <= cap && cnd < best) best = cnd;
-      }
-    }
-  };
-  // gap (in steps) between ia and the nearest step of block b
-  auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? ia - (b * blk + blk - 1) : b * blk - ia); };
-  auto bound_at = [&](int b) { return (b >= 0 && b < nblk) ? Bmin[(long long)b * stride + p] : kInfD; };
-  // pass A: block with the smallest bound
-  double lb_min = Bmin[(long long)b0 * stride + p];
-  int b_min = b0;
-  for (int k0 = 1; k0 < nblk; k0 += 4) {
-    double lo[4], hi[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { lo[u] = bound_at(b0 - k0 - u); hi[u] = bound_at(b0 + k0 + u); }
-    bool any = false;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      any = false;
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const int b = side ? b0 + k0 + u : b0 - k0 - u;
-        if (b < 0 || b >= nblk) continue;
-        const double dg = h * (double)gap_of(b);
-        const double e = dg * dg;
-        if (e >= best || e >= lb_min || dg > cap) continue;
-        any = true;
-        const double lb = (side ? hi[u] : lo[u]) + e;
-        if (lb < lb_min) { lb_min = lb; b_min = b; }
-      }
-      if (!any) break;
-    }
-    if (!any) break;
-  }
-  if (lb_min < best) scan_block(b_min);
-  if (best <= accept2) return best;
-  // pass B: whatever can still improve
-  if (b_min != b0 && Bmin[(long long)b0 * stride + p] < best) scan_block(b0);
-  for (int k0 = 1; k0 < nblk && !(best <= accept2); k0 += 4) {
-    double lo[4], hi[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { lo[u] = bound_at(b0 - k0 - u); hi[u] = bound_at(b0 + k0 + u); }
-    bool any = false;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      any = false;
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const int b = side ? b0 + k0 + u : b0 - k0 - u;
-        if (b < 0 || b >= nblk) continue;
-        const double dg = h * (double)gap_of(b);
-        const double e = dg * dg;
-        if (e >= best || dg > cap) continue;
-        any = true;
-        if (b != b_min && (side ? hi[u] : lo[u]) + e < best) scan_block(b);
-      }
-      if (!any) break;
-    }
-    if (!any) break;
-  }
-  return best;
-}
-
-__global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din, double* __restrict__ Dout, long long n,
-                                                  long long stride, int cnt, double h, const SweepScalars* sc, int c,
-                                                  const unsigned long long* Lkeys, int lidx, int uncapped) {
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const double rmax = sc->rmax_key[c] ? ord_val(sc->rmax_key[c]) : 0.0;
-  const double cap = (L > 0 && !uncapped) ? rmax / L * 1.000001 + 1e-6 : kInfD;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    const int ia = (int)((g / stride) % cnt);
-    Dout[g] = edt_scan_point(Din, g, stride, cnt, ia, h, cap);
-  }
-}
-
-// Coarse pre-decision for the expander query.  The U mask is OR-reduced over cells of kCoarse^d candidates and the
-// exact transform of that small mask gives, for any candidate g in cell C, the sandwich
-//     dC - delta <= dist(g, U) <= dC + delta,   delta = (kCoarse - 1) * sqrt(sum_a h_a^2)
-// (dC = distance between cell origins to the nearest U-holding cell).  Candidates whose verdict is the same at both
-// ends skip the per-candidate scan of the fine transform; only the shell around the boundary of G_c scans.
-constexpr int kCoarse = 8;
-struct CoarseGrid {
-  int enabled;
-  int d;
-  long long count[kMaxD];    // fine counts
-  long long ccount[kMaxD];   // coarse counts
-  double delta;
-  const double* Dc;          // squared coarse distances [prod ccount]
-};
-
-__global__ __launch_bounds__(256) void k_coarsen_mask(const uint8_t* __restrict__ U, long long n, const CoarseGrid cg,
-                                                      uint8_t* __restrict__ Uc) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    if (!U[g]) continue;
-    long long f = g, cell = 0, cs = 1;
-    for (int a = 0; a < cg.d; ++a) {
-      const long long i = f % cg.count[a];
-      f /= cg.count[a];
-      cell += (i / kCoarse) * cs;
-      cs *= cg.ccount[a];
-    }
-    Uc[cell] = 1;   // idempotent store
-  }
-}
-
-__device__ __forceinline__ double coarse_dist2(const CoarseGrid& cg, long long gg) {
-  long long f = gg, cell = 0, cs = 1;
-  for (int a = 0; a < cg.d; ++a) {
-    const long long i = f % cg.count[a];
-    f /= cg.count[a];
-    cell += (i / kCoarse) * cs;
-    cs *= cg.ccount[a];
-  }
-  return cg.Dc[cell];
-}
-
-// Reference expression for one (g, h) pair, unfused, in the oracle's order:
-//   ucb - L * sqrt(sum_a (x_g[a] - x_h[a] + 1e-8)^2) >= 0            models/SafeOpt.py:85-88
-template <int D>
-__device__ __forceinline__ bool lipschitz_pair(const double (&xg)[D], const double (&xh)[D], int d, double ucb, double L) {
-  double ss = 0.0;
-#pragma unroll
-  for (int a = 0; a < D; ++a) {
-    if (a < d) {
-      const double df = __dadd_rn(__dsub_rn(xg[a], xh[a]), 1e-8);
-      ss = (a == 0) ? __dmul_rn(df, df) : __dadd_rn(ss, __dmul_rn(df, df));
-    }
-  }
-  const double dist = __dsqrt_rn(ss);
-  return __dsub_rn(ucb, __dmul_rn(L, dist)) >= 0.0;
-}
-
-// last axis + decision.  For g in S: nearest-U distance dm (unshifted) -> G bit, or the ambiguous list when
-// ucb - L dm lies inside the band the "+1e-8" shift and rounding can move it across zero.
-template <typename T>
-__global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ Din, long long n, long long goff,
-                                                    long long stride, int cnt,
-                                                    double h, int d, double xscale, const T* __restrict__ mean_c,
-                                                    const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
-                                                    const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
-                                                    uint8_t* __restrict__ G, long long* __restrict__ amb,
-                                                    const CoarseGrid cg, const double* __restrict__ Bmin, int blk,
-                                                    long long* __restrict__ scanlist) {
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const bool anyU = sc->count_U > 0;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    uint8_t out = 0;
-    if (S[g] && anyU) {
-      T lcb, ucbT;
-      lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
-      const double ucb = (double)ucbT;
-      if (!(L > 0)) {
-        out = ucb >= 0.0;                         // radius unbounded: any U point is a witness
-      } else {
-        const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
-        const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
-        const long long gg = goff + g;   // index in the transform (whole grid when ranks share it)
-        if (cg.enabled) {
-          const double dC = sqrt(coarse_dist2(cg, gg));
-          const double dhi = dC * (1.0 + 1e-9) + cg.delta, dlo = fmax(0.0, dC * (1.0 - 1e-9) - cg.delta);
-          const double tolc = 1e-12 * (fabs(ucb) + L * dhi);
-          if (ucb - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { G[g] = 1; continue; }     // within the radius for sure
-          if (ucb - L * (dlo - eps_abs - 1e-11 * dlo) < -tolc) { G[g] = 0; continue; }    // beyond it for sure
-        }
-        if (scanlist && Bmin && cnt > 1) {
-          // the few candidates the coarse bounds leave open go to k_edt_scan_list (one wave each): a lane scanning
-          // here would hold its whole wave for a chain of ~100 dependent loads
-          scanlist[atomicAdd((unsigned long long*)&sc->n_scan, 1ull)] = g;
-          G[g] = 0;
-          continue;
-        }
-        const int ia = (int)((gg / stride) % cnt);
-        const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it the verdict is "sure true"
-        const double acc2 = thr > 0 ? thr * thr : -1.0;
-        const double best = cnt <= 1 ? Din[gg]
-                            : Bmin  ? edt_scan_blocked(Din, Bmin, gg % stride, stride, cnt, ia, h, cap, acc2, blk)
-                                    : edt_scan_point(Din, gg, stride, cnt, ia, h, cap, acc2);
-        if (best < 0.5 * kInfD) {
-          const double dm = sqrt(best);
-          const double eps = eps_abs + 1e-11 * dm;
-          const double tol = 1e-12 * (fabs(ucb) + L * dm);
-          const double lo = ucb - L * (dm + eps), hi = ucb - L * (dm - eps);
-          if (lo > tol) out = 1;
-          else if (hi >= -tol) {
-            const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
-            amb[slot] = g;
-          }
-        }
-      }
-    }
-    G[g] = out;
-  }
-}
-
-// Last-axis scan + verdict for the listed candidates, one group of GL lanes (half a wave or a wave, GL >= blk) per
-// candidate: the lanes take GL blocks (bounds) or the steps of one block at a time and combine with group minima -- the
-// same candidates and arithmetic as edt_scan_blocked, with the dependent-load chain cut from ~100 to ~5 per candidate.
-// (The two halves of a wave follow their own trip counts; every cross-lane operation stays inside one half.)
-template <typename T, int GL>
-__global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict__ Din, long long goff, long long stride, int cnt,
-                                                       double h, int d, double xscale, const T* __restrict__ mean_c,
-                                                       const T* __restrict__ var_c, T b, const unsigned long long* Lkeys, int lidx,
-                                                       SweepScalars* sc, uint8_t* __restrict__ G, long long* __restrict__ amb,
-                                                       const double* __restrict__ Bmin, int blk,
-                                                       const long long* __restrict__ scanlist) {
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const long long nscan = sc->n_scan;
-  const int lane = threadIdx.x & (GL - 1);
-  const int sub = (threadIdx.x & 63) / GL;
-  const long long ngroups = (long long)gridDim.x * (blockDim.x / GL);
-  const int nblk = (cnt + blk - 1) / blk;
-  auto group_min = [&](double v) {
-#pragma unroll
-    for (int o = GL / 2; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; }
-    return v;
-  };
-  auto group_ballot = [&](bool pred) {
-    const unsigned long long m = __ballot(pred);
-    return GL == 64 ? m : ((m >> (32 * sub)) & 0xffffffffull);
-  };
-  for (long long qi = (long long)blockIdx.x * (blockDim.x / GL) + threadIdx.x / GL; qi < nscan; qi += ngroups) {
-    const long long g = scanlist[qi];
-    T lcb, ucbT;
-    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
-    const double ucb = (double)ucbT;
-    const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
-    const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
-    const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;
-    const double acc2 = thr > 0 ? thr * thr : -1.0;
-    const long long gg = goff + g, p = gg % stride;
-    const int ia = (int)((gg / stride) % cnt), b0 = ia / blk;
-    double best = Din[(long long)ia * stride + p];
-    // blocks within reach of the radius
-    const int kmax = (int)fmin((double)nblk, floor(cap / (h * (double)blk)) + 2.0);
-    const int blo = b0 - kmax > 0 ? b0 - kmax : 0, bhi = b0 + kmax < nblk - 1 ? b0 + kmax : nblk - 1;
-    auto bound_of = [&](int bb) {       // bound of block bb for this lane (inf outside the reach / the axis)
-      if (bb < blo || bb > bhi) return kInfD;
-      const int gap = bb == b0 ? 0 : (bb < b0 ? ia - (bb * blk + blk - 1) : bb * blk - ia);
-      const double dg = h * (double)gap;
-      if (dg > cap) return kInfD;
-      return Bmin[(long long)bb * stride + p] + dg * dg;
-    };
-    auto scan_block = [&](int bb) {     // the group: the (<= GL) steps of block bb
-      const int jn = bb * blk + lane;
-      double cnd = kInfD;
-      if (lane < blk && jn < cnt) {
-        const double dt = h * (double)(jn > ia ? jn - ia : ia - jn);
-        if (dt <= cap) cnd = Din[(long long)jn * stride + p] + dt * dt;
-      }
-      cnd = group_min(cnd);
-      best = cnd < best ? cnd : best;
-    };
-    // pass A: the block with the smallest bound
-    double lb_min = kInfD;
-    int b_min = -1;
-    for (int base = blo; base <= bhi; base += GL) {
-      const double lb = bound_of(base + lane);
-      const double m = group_min(lb);
-      if (m < lb_min) {
-        lb_min = m;
-        const unsigned long long who = group_ballot(lb == m);
-        b_min = base + (int)(__ffsll((long long)who) - 1);
-      }
-    }
-    if (b_min >= 0 && lb_min < best) scan_block(b_min);
-    // pass B: every other block whose bound still beats the running minimum
-    for (int base = blo; base <= bhi && !(best <= acc2); base += GL) {
-      const double lb = bound_of(base + lane);
-      unsigned long long todo = group_ballot(lb < best && base + lane != b_min);
-      while (todo && !(best <= acc2)) {
-        const int l = (int)(__ffsll((long long)todo) - 1);
-        todo &= todo - 1;
-        const double lbl = __shfl(lb, l + GL * sub);
-        if (lbl < best) scan_block(base + l);
-      }
-    }
-    if (lane == 0) {
-      uint8_t out = 0;
-      if (best < 0.5 * kInfD) {
-        const double dm = sqrt(best);
-        const double eps = eps_abs + 1e-11 * dm;
-        const double tol = 1e-12 * (fabs(ucb) + L * dm);
-        const double lo = ucb - L * (dm + eps), hi = ucb - L * (dm - eps);
-        if (lo > tol) out = 1;
-        else if (hi >= -tol) amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
-      }
-      G[g] = out;
-    }
-  }
-}
-
-// every S point goes to the exhaustive list (explicit candidate lists have no grid to transform)
-__global__ __launch_bounds__(256) void k_list_safe(const uint8_t* __restrict__ S, long long n, SweepScalars* sc,
-                                                   uint8_t* __restrict__ G, long long* __restrict__ amb) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    G[g] = 0;
-    if (S[g]) {
-      const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
-      amb[slot] = g;
-    }
-  }
-}
-
-// exhaustive evaluation of the reference predicate for the listed g: one workgroup per g, every U point that can matter
-template <typename T, int D>
-__global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const CandSpec csU, const T* __restrict__ mean_c,
-                                                        const T* __restrict__ var_c, T b, const uint8_t* __restrict__ U,
-                                                        const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
-                                                        const long long* __restrict__ amb, uint8_t* __restrict__ G) {
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const long long namb = sc->n_amb;
-  constexpr int kParts = 64;   // a listed candidate's box can be as large as the grid: cut into slices, one workgroup each
-  for (long long wi = blockIdx.x; wi < namb * kParts; wi += gridDim.x) {
-    const long long qi = wi / kParts;
-    const int part = (int)(wi % kParts);
-    const long long g = amb[qi];
-    T lcb, ucbT;
-    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
-    const double ucb = (double)ucbT;
-    double xg[D];
-    cand_coords<D>(cs, g, xg);
-    int found = 0;
-    if (csU.kind == 1) {
-      // grid: only witnesses inside the index box of half-width ceil(r / h_a) + 1 around g can satisfy the predicate
-      long long lo[D], len[D], stridea[D];
-      long long f = cs.first + g, total = 1, sa = 1;
-      const double rg = L > 0 ? ucb / L : 1e300;
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        lo[a] = 0; len[a] = 1; stridea[a] = 0;
-        if (a < cs.d) {
-          const long long cnt = cs.count[a];
-          const long long ig = f % cnt;
-          f /= cnt;
-          long long R = cnt;
-          if (L > 0 && cs.step[a] > 0) {
-            const double rr = (rg * (1.0 + 1e-9) + 1e-7) / cs.step[a];
-            R = rr < (double)cnt ? (long long)ceil(rr) + 1 : cnt;
-            if (R < 0) R = 0;
-          }
-          const long long l0 = ig - R > 0 ? ig - R : 0, h0 = ig + R < cnt - 1 ? ig + R : cnt - 1;
-          lo[a] = l0; len[a] = h0 - l0 + 1; stridea[a] = sa;
-          total *= len[a];
-          sa *= cnt;
-        }
-      }
-      const long long chunk = (total + kParts - 1) / kParts;
-      const long long t1 = (part + 1) * chunk < total ? (part + 1) * chunk : total;
-      for (long long t = part * chunk + threadIdx.x; t < t1 && !found; t += blockDim.x) {
-        long long u = t, hh = 0;
-        double xh[D];
-#pragma unroll
-        for (int a = 0; a < D; ++a) {
-          xh[a] = 0.0;
-          if (a < cs.d) {
-            const long long ia = lo[a] + u % len[a];
-            u /= len[a];
-            hh += ia * stridea[a];
-            const long long cnt = cs.count[a];
-            xh[a] = (ia == cnt - 1 && cnt > 1) ? cs.hi[a] : __dadd_rn(cs.lo[a], __dmul_rn((double)ia, cs.step[a]));
-          }
-        }
-        const long long hl = hh - csU.first;
-        if (hl >= 0 && hl < csU.n_local && U[hl] && lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
-      }
-    } else {
-      for (long long hh = (long long)part * blockDim.x + threadIdx.x; hh < csU.n_local && !found; hh += (long long)kParts * blockDim.x) {
-        if (U[hh]) {
-          double xh[D];
-          cand_coords<D>(csU, hh, xh);
-          if (lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
-        }
-      }
-    }
-    found = __syncthreads_or(found);
-    if (threadIdx.x == 0 && found) G[g] = 1;
-    __syncthreads();
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    sc->n_amb_total += namb;
-  }
-}
-
-__global__ void k_reset_amb(SweepScalars* sc) { sc->n_amb = 0; sc->n_scan = 0; }
-
-// ---- multi-rank exchange -----------------------------------------------------------
-// C1: one max all-reduce of [~u*_key, L keys, radius keys]
-__global__ void k_pack_c1(const SweepScalars* sc, const unsigned long long* Lkeys, unsigned long long* buf) {
-  const int t = threadIdx.x;
-  if (t == 0) buf[0] = ~sc->ustar_key;
-  if (t < kMaxQ) { buf[1 + t] = Lkeys[t]; buf[1 + kMaxQ + t] = sc->rmax_key[t]; }
-}
-__global__ void k_unpack_c1(SweepScalars* sc, unsigned long long* Lkeys, const unsigned long long* buf) {
-  const int t = threadIdx.x;
-  if (t == 0) sc->ustar_key = ~buf[0];
-  if (t < kMaxQ) { Lkeys[t] = buf[1 + t]; sc->rmax_key[t] = buf[1 + kMaxQ + t]; }
-}
-// C2: all-gathered padded shards -> contiguous whole-grid mask
-template <typename E>
-__global__ __launch_bounds__(256) void k_compact_shards(const E* __restrict__ recv, long long maxlocal, int world,
-                                                        const long long* __restrict__ first_of, long long total,
-                                                        E* __restrict__ full) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    int r = 0;
-    while (r + 1 < world && g >= first_of[r + 1]) ++r;
-    full[g] = recv[(size_t)r * maxlocal + (g - first_of[r])];
-  }
-}
-// C2 (bit form): own mask -> one word per 64 candidates (zero beyond n); gathered words -> whole-grid byte mask
-__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ U, long long n, long long words,
-                                                   unsigned long long* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-  for (long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < words; w += nwaves) {
-    const long long g = w * 64 + lane;
-    const unsigned long long m = __ballot(g < n && U[g]);
-    if (lane == 0) out[w] = m;
-  }
-}
-__global__ __launch_bounds__(256) void k_unpack_shards(const unsigned long long* __restrict__ recv, long long words, int world,
-                                                       const long long* __restrict__ first_of, long long total,
-                                                       uint8_t* __restrict__ full) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    int r = 0;
-    while (r + 1 < world && g >= first_of[r + 1]) ++r;
-    const long long l = g - first_of[r];
-    full[g] = (uint8_t)((recv[(size_t)r * words + (l >> 6)] >> (l & 63)) & 1ull);
-  }
-}
-// C3: each rank fills its own row of [world][kC3Row] doubles, one sum all-reduce delivers every row everywhere
-constexpr int kC3Row = 2 * kArgSlots + 4 + kMaxQ;
-__global__ void k_pack_c3(const SweepScalars* sc, double* buf, int world, int rank) {
-  for (int i = threadIdx.x; i < world * kC3Row; i += blockDim.x) buf[i] = 0.0;
-  __syncthreads();
-  double* row = buf + (size_t)rank * kC3Row;
-  const int t = threadIdx.x;
-  if (t < kArgSlots) { row[t] = sc->arg_idx[t] >= 0 ? sc->arg_val[t] : 0.0; row[kArgSlots + t] = (double)sc->arg_idx[t]; }
-  if (t == 0) {
-    row[2 * kArgSlots + 0] = (double)sc->count_S;
-    row[2 * kArgSlots + 1] = (double)sc->count_U;
-    row[2 * kArgSlots + 2] = (double)sc->count_M;
-    row[2 * kArgSlots + 3] = (double)sc->n_amb_total;
-  }
-  if (t < kMaxQ) row[2 * kArgSlots + 4 + t] = (double)sc->count_set[t];
-}
-__global__ void k_init_scalars(SweepScalars* sc) {
-  unsigned long long* w = reinterpret_cast<unsigned long long*>(sc);       // (the struct is a multiple of 8 bytes)
-  for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) w[i] = 0ull;
-  __syncthreads();
-  if (threadIdx.x == 0) sc->ustar_key = ~0ull;
-  if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
-}
-
-// ---- GoOSE: optimistic set O_c (models/GoOSE.py:93-101) -----------------------------------------------------
-//   O_c = {h in U : exists g in S, ucb_c(g) - L ||x_g - x_h + 1e-8|| >= 0}
-// Here the radius ucb_c(g)/L belongs to the *source* g, so the query is a union-of-balls coverage test, not a
-// nearest-neighbour one; it is answered exactly by evaluating the reference predicate on every pair of
-// 256-candidate runs whose bounding boxes are closer than the largest radius in the S-run.
-constexpr int kRun = 256;
-struct RunMeta {
-  double rmax;                    // max ucb_c/L over the S points of the run (< 0: no S point)
-  double lo[kMaxD], hi[kMaxD];    // bounding box of the run's S points
-};
-
-// source weights: W[g] = ucb_c(g) on the source set, -inf elsewhere (every source is in S_t, so its ucb_c >= lcb_c >= 0)
-template <typename T>
-__global__ __launch_bounds__(256) void k_goose_weights(const T* __restrict__ mean_c, const T* __restrict__ var_c, long long n, T b,
-                                                       const uint8_t* __restrict__ src, T* __restrict__ W) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    T lcb, ucb;
-    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucb);
-    W[g] = src[g] ? ucb : (T)-INFINITY;
-  }
-}
-
-// css / W describe the SOURCE candidates (this rank's, or with ranks > 1 the whole grid); block i handles run run_lo + i
-template <typename T, int D>
-__global__ __launch_bounds__(256) void k_goose_run_meta(const CandSpec css, const T* __restrict__ W,
-                                                        const unsigned long long* Lkeys, int lidx, long long run_lo,
-                                                        RunMeta* __restrict__ meta) {
-  __shared__ double red[4][1 + 2 * D];
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const long long g = (run_lo + blockIdx.x) * kRun + threadIdx.x;
-  double r = -1.0, lo[D], hi[D];
-#pragma unroll
-  for (int a = 0; a < D; ++a) { lo[a] = 1e300; hi[a] = -1e300; }
-  if (g < css.n_local) {
-    const double uc = (double)W[g];
-    if (uc >= 0.0) {
-      r = L > 0 ? uc / L : 1e300;
-      double x[D];
-      cand_coords<D>(css, g, x);
-#pragma unroll
-      for (int a = 0; a < D; ++a) { lo[a] = x[a]; hi[a] = x[a]; }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    r = fmax(r, __shfl_xor(r, o));
-#pragma unroll
-    for (int a = 0; a < D; ++a) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    red[wave][0] = r;
-#pragma unroll
-    for (int a = 0; a < D; ++a) { red[wave][1 + a] = lo[a]; red[wave][1 + D + a] = hi[a]; }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    RunMeta m;
-    m.rmax = fmax(fmax(red[0][0], red[1][0]), fmax(red[2][0], red[3][0]));
-    for (int a = 0; a < kMaxD; ++a) { m.lo[a] = 0; m.hi[a] = 0; }
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-      m.lo[a] = fmin(fmin(red[0][1 + a], red[1][1 + a]), fmin(red[2][1 + a], red[3][1 + a]));
-      m.hi[a] = fmax(fmax(red[0][1 + D + a], red[1][1 + D + a]), fmax(red[2][1 + D + a], red[3][1 + D + a]));
-    }
-    meta[blockIdx.x] = m;
-  }
-}
-
-template <typename T, int D>
-__global__ __launch_bounds__(256) void k_goose_optimistic(const CandSpec cs, const CandSpec css, const T* __restrict__ W,
-                                                          const uint8_t* __restrict__ U, const unsigned long long* Lkeys,
-                                                          int lidx, const RunMeta* __restrict__ meta, long long run_lo,
-                                                          int nruns, uint8_t* __restrict__ O) {
-  __shared__ double gx[kRun][D];
-  __shared__ double gr[kRun], gucb[kRun];
-  __shared__ int list[kRun];
-  __shared__ int nlist, nopen;
-  __shared__ double ubox[2 * D];
-  __shared__ double red[4][2 * D];
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const long long h = (long long)blockIdx.x * kRun + threadIdx.x;
-  const bool isU = h < cs.n_local && U[h];
-  double xh[D];
-  if (h < cs.n_local) cand_coords<D>(cs, h, xh);
-  // bounding box of this run's U points
-  double lo[D], hi[D];
-#pragma unroll
-  for (int a = 0; a < D; ++a) { lo[a] = isU ? xh[a] : 1e300; hi[a] = isU ? xh[a] : -1e300; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-    for (int a = 0; a < D; ++a) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-#pragma unroll
-    for (int a = 0; a < D; ++a) { red[wave][a] = lo[a]; red[wave][D + a] = hi[a]; }
-  }
-  if (threadIdx.x == 0) nopen = 0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-      ubox[a] = fmin(fmin(red[0][a], red[1][a]), fmin(red[2][a], red[3][a]));
-      ubox[D + a] = fmax(fmax(red[0][D + a], red[1][D + a]), fmax(red[2][D + a], red[3][D + a]));
-    }
-  }
-  if (isU) atomicAdd(&nopen, 1);
-  __syncthreads();
-  bool covered = false;
-  if (nopen > 0) {
-    for (int base = 0; base < nruns; base += kRun) {
-      // which of the next 256 S-runs can reach this run's U points at all
-      if (threadIdx.x == 0) nlist = 0;
-      __syncthreads();
-      const int t = base + threadIdx.x;
-      if (t < nruns) {
-        const RunMeta m = meta[t];
-        if (m.rmax >= 0.0) {
-          double d2 = 0.0;
-#pragma unroll
-          for (int a = 0; a < D; ++a) {
-            const double gap = fmax(0.0, fmax(m.lo[a] - ubox[D + a], ubox[a] - m.hi[a]));
-            d2 += gap * gap;
-          }
-          const double reach = m.rmax * (1.0 + 1e-9) + 1e-6;
-          if (d2 <= reach * reach) list[atomicAdd(&nlist, 1)] = t;
-        }
-      }
-      __syncthreads();
-      const int nl = nlist;
-      for (int li = 0; li < nl; ++li) {
-        const long long g = (run_lo + list[li]) * kRun + threadIdx.x;
-        double r = -1.0, uc = 0.0;
-        if (g < css.n_local) {
-          uc = (double)W[g];
-          if (uc >= 0.0) {
-            r = L > 0 ? uc / L : 1e300;
-            double x[D];
-            cand_coords<D>(css, g, x);
-#pragma unroll
-            for (int a = 0; a < D; ++a) gx[threadIdx.x][a] = x[a];
-          }
-        }
-        gr[threadIdx.x] = r;
-        gucb[threadIdx.x] = uc;
-        __syncthreads();
-        if (isU && !covered) {
-          for (int k = 0; k < kRun; ++k) {
-            const double r = gr[k];
-            if (r < 0.0) continue;
-            double ss = 0.0;
-#pragma unroll
-            for (int a = 0; a < D; ++a) {
-              const double df = (gx[k][a] - xh[a]) + 1e-8;       // x_g - x_h + 1e-8, models/GoOSE.py:71
-              ss = (a == 0) ? df * df : ss + df * df;
-            }
-            const double rhi = r * (1.0 + 1e-12), rlo = r * (1.0 - 1e-12);
-            if (ss > rhi * rhi) continue;
-            if (ss < rlo * rlo || gucb[k] - L * sqrt(ss) >= 0.0) { covered = true; break; }
-          }
-        }
-        __syncthreads();
-      }
-    }
-  }
-  if (h < cs.n_local) O[h] = covered;
-}
-
-// ---- GoOSE coverage on grids: power-distance transform --------------------------------------------------------
-// "h is covered" means min over sources g of  ||x_g - x_h||^2 - r_g^2  <= 0  (r_g = ucb_c(g) / L): a min-plus
-// transform of the sampled function F(g) = -r_g^2 (sources) / +inf (others) with parabolas, which separates by axis
-// exactly like the Euclidean transform:  P_a(x) = min_t P_{a-1}(x + t e_a) + (h_a t)^2.
-// The transform is evaluated in index space without the reference's "+1e-8" shift; |P| <= band is the zone where the
-// shift and rounding could move the reference predicate across zero -- those h go to the exact recheck
-// (k_goose_exact), everything else is decided by the sign.  band = 3 rmax eps bounds |dist - r| > eps on both sides:
-// (dist - r)(dist + r) = P and dist + r <= 3 rmax whenever dist <= 2 rmax.
-// Values above `band` can never lead to a covered verdict on a later axis, so the outward scans stop at
-//   (h t)^2 - rmax^2 > band   (no source that far can matter)   and   (h t)^2 - rmax^2 >= best   (cannot improve).
-struct PdtParams {
-  double invL, rmax2, band;    // 1/L, (max source radius)^2, ambiguity band on P
-  int L_positive;
-};
-__device__ __forceinline__ PdtParams pdt_params(const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx, int d,
-                                                double xscale) {
-  PdtParams p;
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  p.L_positive = L > 0;
-  p.invL = p.L_positive ? 1.0 / L : 0.0;
-  const double rm = (sc->rmax_key[c] ? fmax(0.0, ord_val(sc->rmax_key[c])) : 0.0) * p.invL * (1.0 + 1e-12);
-  const double eps = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13 + 1e-10 * rm;
-  p.rmax2 = rm * rm;
-  p.band = 3.03 * rm * eps + eps * eps + 1e-13 * (xscale * xscale + p.rmax2);
-  return p;
-}
-
-// Coarse bounds for the power transform (cells of kCoarse^d candidates, Fmin = smallest F in the cell).  A source of
-// cell J and a candidate of cell I are between lo_t = (t-1) kCoarse + 1 (0 when t = 0) and hi_t = (t+1) kCoarse - 1
-// steps apart along an axis, t = |I - J|, hence
-//     min_J Fmin(J) + sum_a (h_a lo_t)^2  <=  P(x)  <=  min_J Fmin(J) + sum_a (h_a hi_t)^2      for every x in cell I.
-// Both sides are separable min-plus transforms of the small array Fmin.  Lower side > band: nothing in the cell can be
-// covered and its axis-0 values cannot matter either (they are >= P); upper side < -band: every U point is covered.
-// Fmin of every coarse cell: one thread per cell walks its kCoarse^d candidates (axis 0 innermost); cells without a
-// source get +inf.  Written to both bound arrays (they start from the same values).
-template <typename T>
-__global__ __launch_bounds__(256) void k_pdt_cell_min(const T* __restrict__ W, const CoarseGrid cg, long long nc,
-                                                      const unsigned long long* Lkeys, int lidx, double* __restrict__ lo,
-                                                      double* __restrict__ hi) {
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const double invL = L > 0 ? 1.0 / L : 0.0;
-  for (long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x; cell < nc; cell += (long long)gridDim.x * blockDim.x) {
-    // fine index of the cell origin and the cell's extent per axis
-    long long f = cell, stride = 1, origin = 0, len[kMaxD], fstride[kMaxD], total = 1;
-    for (int a = 0; a < cg.d; ++a) {
-      const long long ci = f % cg.ccount[a];
-      f /= cg.ccount[a];
-      const long long i0 = ci * kCoarse;
-      len[a] = cg.count[a] - i0 < kCoarse ? cg.count[a] - i0 : kCoarse;
-      fstride[a] = stride;
-      origin += i0 * stride;
-      stride *= cg.count[a];
-      total *= len[a];
-    }
-    double wmax = -1.0;
-    for (long long t = 0; t < total; ++t) {
-      long long u = t, g = origin;
-      for (int a = 0; a < cg.d; ++a) {
-        g += (u % len[a]) * fstride[a];
-        u /= len[a];
-      }
-      const double w = (double)W[g];
-      wmax = w > wmax ? w : wmax;
-    }
-    double v = kInfD;
-    if (wmax >= 0.0) { const double r = wmax * invL; v = -(r * r); }
-    lo[cell] = v;
-    hi[cell] = v;
-  }
-}
-// one axis of both coarse bound transforms (lower-bound costs on the first array, upper-bound costs on the second)
-__global__ __launch_bounds__(256) void k_pdt_coarse_scan(const double* __restrict__ LoIn, double* __restrict__ LoOut,
-                                                         const double* __restrict__ HiIn, double* __restrict__ HiOut, long long nc,
-                                                         long long stride, int cnt, double h, const SweepScalars* sc, int c,
-                                                         const unsigned long long* Lkeys, int lidx, int d, double xscale) {
-  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
-  for (long long g2 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g2 < 2 * nc; g2 += (long long)gridDim.x * blockDim.x) {
-    const int upper = g2 >= nc;                          // first half of the index space: lower bounds, second half: upper
-    const long long g = upper ? g2 - nc : g2;
-    const double* Pin = upper ? HiIn : LoIn;
-    const int ia = (int)((g / stride) % cnt);
-    double best = kInfD;
-    for (int t = 0; t < cnt; ++t) {
-      const double steps_lo = t == 0 ? 0.0 : (double)((t - 1) * kCoarse + 1);
-      const double steps = upper ? (double)((t + 1) * kCoarse - 1) : steps_lo;
-      const double dl = h * steps_lo, dd = h * steps;
-      const double floor_ = dl * dl - pp.rmax2;          // no source that far can bring any candidate below the band
-      if (floor_ > pp.band || dd * dd - pp.rmax2 >= best) break;
-      const bool lo_ok = ia - t >= 0, hi_ok = ia + t < cnt;
-      if (!lo_ok && !hi_ok) break;
-      const double c1 = lo_ok ? Pin[g - (long long)t * stride] : kInfD;
-      const double c2 = hi_ok ? Pin[g + (long long)t * stride] : kInfD;
-      const double cnd = (c1 < c2 ? c1 : c2) + dd * dd;
-      best = cnd < best ? cnd : best;
-    }
-    (upper ? HiOut : LoOut)[g] = best;
-  }
-}
-__device__ __forceinline__ long long coarse_cell(const CoarseGrid& cg, long long gg) {
-  long long f = gg, cell = 0, cs = 1;
-  for (int a = 0; a < cg.d; ++a) {
-    const long long i = f % cg.count[a];
-    f /= cg.count[a];
-    cell += (i / kCoarse) * cs;
-    cs *= cg.ccount[a];
-  }
-  return cell;
-}
-
-// largest source weight of every block of `blk` consecutive axis-0 positions (-inf when the block holds no source)
-template <typename T>
-__global__ __launch_bounds__(256) void k_block_max_w(const T* __restrict__ W, long long nt, int count0, int blk,
-                                                     T* __restrict__ Bmax) {
-  const int nblk = (count0 + blk - 1) / blk;
-  const long long total = (nt / count0) * nblk;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long line = i / nblk;
-    const int b = (int)(i % nblk);
-    const int j1 = (b + 1) * blk < count0 ? (b + 1) * blk : count0;
-    T m = (T)-INFINITY;
-    for (int j = b * blk; j < j1; ++j) {
-      const T v = W[line * count0 + j];
-      m = v > m ? v : m;
-    }
-    Bmax[i] = m;
-  }
-}
-
-// blocked axis-0 scan of one position i of a line: Wl = the line's source weights, Bl = largest weight per block of
-// `blk` positions (global or LDS pointers).  `best` comes in as the position's own value.
-template <typename TW>
-__device__ __forceinline__ double pdt_axis0_point(const TW* Wl, const TW* Bl, int count0, int nblk, int i, double h0,
-                                                  const PdtParams& pp, int blk, double best) {
-  const int b0 = i / blk;
-  auto scan_block = [&](int b) {
-    const int j1 = (b + 1) * blk < count0 ? (b + 1) * blk : count0;
-    for (int j = b * blk; j < j1; ++j) {
-      const double wj = (double)Wl[j];
-      if (wj >= 0.0) {
-        const double dt = h0 * (double)(j > i ? j - i : i - j), r = wj * pp.invL;
-        const double cnd = dt * dt - r * r;
-        best = cnd < best ? cnd : best;
-      }
-    }
-  };
-  auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? i - (b * blk + blk - 1) : b * blk - i); };
-  auto bound_of = [&](int b, double e) {
-    const double wb = (double)Bl[b];
-    if (!(wb >= 0.0)) return kInfD;
-    const double r = wb * pp.invL;
-    return e - r * r;
-  };
-  double lb_min = bound_of(b0, 0.0);
-  int b_min = b0;
-  for (int k = 1; k < nblk; ++k) {
-    bool any = false;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const int b = side ? b0 + k : b0 - k;
-      if (b < 0 || b >= nblk) continue;
-      const double dg = h0 * (double)gap_of(b);
-      const double e = dg * dg, floor_ = e - pp.rmax2;
-      if (floor_ > pp.band || floor_ >= best || floor_ >= lb_min) continue;
-      any = true;
-      const double lb = bound_of(b, e);
-      if (lb < lb_min) { lb_min = lb; b_min = b; }
-    }
-    if (!any) break;
-  }
-  if (lb_min < best) scan_block(b_min);
-  if (b_min != b0 && bound_of(b0, 0.0) < best) scan_block(b0);
-  for (int k = 1; k < nblk; ++k) {
-    bool any = false;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const int b = side ? b0 + k : b0 - k;
-      if (b < 0 || b >= nblk) continue;
-      const double dg = h0 * (double)gap_of(b);
-      const double e = dg * dg, floor_ = e - pp.rmax2;
-      if (floor_ > pp.band || floor_ >= best) continue;
-      any = true;
-      if (b != b_min && bound_of(b, e) < best) scan_block(b);
-    }
-    if (!any) break;
-  }
-  return best;
-}
-
-// The same pass with one workgroup per grid line: the line's weights (count0 <= 8192 doubles) and its block maxima sit in
-// LDS, so the dependent loads of a position's scan cost an LDS round trip instead of an L2 / HBM one.
-template <typename T>
-__global__ __launch_bounds__(256) void k_pdt_axis0_lds(const T* __restrict__ W, long long nlines, int count0, double h0,
-                                                       const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx,
-                                                       int d, double xscale, const CoarseGrid cg, const double* __restrict__ PcLo,
-                                                       int blk, double* __restrict__ P) {
-  extern __shared__ double lds_w[];            // [count0] weights as double | [nblk] block maxima
-  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
-  const int nblk = (count0 + blk - 1) / blk;
-  double* Wl = lds_w;
-  double* Bl = lds_w + count0;
-  for (long long line = blockIdx.x; line < nlines; line += gridDim.x) {
-    const long long g0 = line * count0;
-    __syncthreads();                           // the previous line's scans are done with the buffers
-    for (int i = threadIdx.x; i < count0; i += blockDim.x) Wl[i] = (double)W[g0 + i];
-    __syncthreads();
-    for (int bb = threadIdx.x; bb < nblk; bb += blockDim.x) {
-      const int j1 = (bb + 1) * blk < count0 ? (bb + 1) * blk : count0;
-      double m = -INFINITY;
-      for (int j = bb * blk; j < j1; ++j) m = Wl[j] > m ? Wl[j] : m;
-      Bl[bb] = m;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < count0; i += blockDim.x) {
-      const long long g = g0 + i;
-      if (cg.enabled && PcLo[coarse_cell(cg, g)] > pp.band) { P[g] = kInfD; continue; }
-      const double w = Wl[i];
-      double best = kInfD;
-      if (w >= 0.0) { const double r = w * pp.invL; best = -(r * r); }
-      P[g] = pdt_axis0_point((const double*)Wl, (const double*)Bl, count0, nblk, i, h0, pp, blk, best);
-    }
-  }
-}
-
-// axis 0, reading the source weights directly.  With Bmax (per-block largest weight = smallest F) the scan is blocked
-// like the last-axis ones: a block whose bound (h gap)^2 - r_block^2 cannot beat the running minimum costs one load,
-// the block with the smallest bound is visited first.  Same candidates and arithmetic as the step-by-step scan.
-template <typename T>
-__global__ __launch_bounds__(256) void k_pdt_axis0(const T* __restrict__ W, long long nt, int count0, double h0,
-                                                   const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx,
-                                                   int d, double xscale, const CoarseGrid cg, const double* __restrict__ PcLo,
-                                                   const T* __restrict__ Bmax, int blk, double* __restrict__ P) {
-  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
-  const int nblk = (count0 + blk - 1) / blk;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nt; g += (long long)gridDim.x * blockDim.x) {
-    if (cg.enabled && PcLo[coarse_cell(cg, g)] > pp.band) { P[g] = kInfD; continue; }
-    const int i = (int)(g % count0);
-    const double w = (double)W[g];
-    double best = kInfD;
-    if (w >= 0.0) { const double r = w * pp.invL; best = -(r * r); }
-    if (Bmax == nullptr) {
-      for (int t = 1; t < count0; ++t) {
-        const double dt = h0 * (double)t;
-        const double e = dt * dt;
-        const double floor_ = e - pp.rmax2;
-        if (floor_ > pp.band || floor_ >= best) break;
-        const bool lo_ok = i - t >= 0, hi_ok = i + t < count0;
-        if (!lo_ok && !hi_ok) break;
-        const double w1 = lo_ok ? (double)W[g - t] : -1.0;
-        const double w2 = hi_ok ? (double)W[g + t] : -1.0;
-        const double wm = fmax(w1, w2);                 // the larger radius wins at equal distance
-        if (wm >= 0.0) {
-          const double r = wm * pp.invL;
-          const double cnd = e - r * r;
-          best = cnd < best ? cnd : best;
-        }
-      }
-      P[g] = best;
-      continue;
-    }
-    best = pdt_axis0_point(W + (g - i), Bmax + (g / count0) * nblk, count0, nblk, i, h0, pp, blk, best);
-    P[g] = best;
-  }
-}
-
-__device__ __forceinline__ double pdt_scan_point(const double* __restrict__ Pin, long long g, long long stride, int cnt, int ia,
-                                                 double h, const PdtParams& pp, bool early_accept) {
-  double best = Pin[g];
-  for (int t = 1; t < cnt; ++t) {
-    const double dt = h * (double)t;
-    const double e = dt * dt;
-    const double floor_ = e - pp.rmax2;
-    if (floor_ > pp.band || floor_ >= best || (early_accept && best < -pp.band)) break;
-    const bool lo_ok = ia - t >= 0, hi_ok = ia + t < cnt;
-    if (!lo_ok && !hi_ok) break;
-    const double c1 = lo_ok ? Pin[g - (long long)t * stride] : kInfD;
-    const double c2 = hi_ok ? Pin[g + (long long)t * stride] : kInfD;
-    const double cnd = (c1 < c2 ? c1 : c2) + e;
-    best = cnd < best ? cnd : best;
-  }
-  return best;
-}
-
-// power-transform form of the blocked last-axis scan (values >= -rmax2; exits as pdt_scan_point), same visiting order
-__device__ __forceinline__ double pdt_scan_blocked(const double* __restrict__ Pin, const double* __restrict__ Bmin, long long p,
-                                                   long long stride, int cnt, int ia, double h, const PdtParams& pp, int blk) {
-  double best = Pin[(long long)ia * stride + p];
-  const int nblk = (cnt + blk - 1) / blk, b0 = ia / blk;
-  auto scan_block = [&](int b) {
-    const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
-    for (int j = b * blk; j < j1; ++j) {
-      const double dt = h * (double)(j > ia ? j - ia : ia - j);
-      const double cnd = Pin[(long long)j * stride + p] + dt * dt;
-      best = cnd < best ? cnd : best;
-    }
-  };
-  auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? ia - (b * blk + blk - 1) : b * blk - ia); };
-  double lb_min = Bmin[(long long)b0 * stride + p];
-  int b_min = b0;
-  for (int k = 1; k < nblk; ++k) {
-    bool any = false;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const int b = side ? b0 + k : b0 - k;
-      if (b < 0 || b >= nblk) continue;
-      const double dg = h * (double)gap_of(b);
-      const double e = dg * dg, floor_ = e - pp.rmax2;
-      if (floor_ > pp.band || floor_ >= best || floor_ >= lb_min) continue;
-      any = true;
-      const double lb = Bmin[(long long)b * stride + p] + e;
-      if (lb < lb_min) { lb_min = lb; b_min = b; }
-    }
-    if (!any) break;
-  }
-  if (lb_min < best) scan_block(b_min);
-  if (best < -pp.band) return best;
-  if (b_min != b0 && Bmin[(long long)b0 * stride + p] < best) scan_block(b0);
-  for (int k = 1; k < nblk && !(best < -pp.band); ++k) {
-    bool any = false;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const int b = side ? b0 + k : b0 - k;
-      if (b < 0 || b >= nblk) continue;
-      const double dg = h * (double)gap_of(b);
-      const double e = dg * dg, floor_ = e - pp.rmax2;
-      if (floor_ > pp.band || floor_ >= best) continue;
-      any = true;
-      if (b != b_min && Bmin[(long long)b * stride + p] + e < best) scan_block(b);
-    }
-    if (!any) break;
-  }
-  return best;
-}
-
-__global__ __launch_bounds__(256) void k_pdt_scan(const double* __restrict__ Pin, double* __restrict__ Pout, long long nt,
-                                                  long long stride, int cnt, double h, const SweepScalars* sc, int c,
-                                                  const unsigned long long* Lkeys, int lidx, int d, double xscale) {
-  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nt; g += (long long)gridDim.x * blockDim.x) {
-    const int ia = (int)((g / stride) % cnt);
-    Pout[g] = pdt_scan_point(Pin, g, stride, cnt, ia, h, pp, false);
-  }
-}
-
-// last axis + verdict for the own U points (window offset goff); ambiguous ones are listed for the exact recheck
-__global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ Pin, long long n, long long goff, long long stride,
-                                                    int cnt, double h, int d, double xscale, const uint8_t* __restrict__ U,
-                                                    const unsigned long long* Lkeys, int lidx, SweepScalars* sc, int c,
-                                                    uint8_t* __restrict__ O, long long* __restrict__ amb, const CoarseGrid cg,
-                                                    const double* __restrict__ PcLo, const double* __restrict__ PcHi,
-                                                    const double* __restrict__ Bmin, int blk) {
-  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
-  const bool anyS = sc->count_S > 0;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    uint8_t out = 0;
-    if (U[g]) {
-      if (!pp.L_positive) {
-        out = anyS;                                  // radius unbounded: any source covers (ucb_c >= 0 on every source)
-      } else {
-        const long long gg = goff + g;
-        if (cg.enabled) {
-          const long long cell = coarse_cell(cg, gg);
-          if (PcHi[cell] < -pp.band) { O[g] = 1; continue; }     // covered wherever it sits in its cell
-          if (PcLo[cell] > pp.band) { O[g] = 0; continue; }      // out of every source's reach
-        }
-        const int ia = (int)((gg / stride) % cnt);
-        const double best = cnt <= 1 ? Pin[gg]
-                            : Bmin  ? pdt_scan_blocked(Pin, Bmin, gg % stride, stride, cnt, ia, h, pp, blk)
-                                    : pdt_scan_point(Pin, gg, stride, cnt, ia, h, pp, true);
-        if (best < -pp.band) out = 1;
-        else if (best <= pp.band) {
-          const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
-          amb[slot] = g;
-        }
-      }
-    }
-    O[g] = out;
-  }
-}
-
-// exact recheck of the listed U points: the reference predicate against every source inside the index box that the
-// largest radius can reach.  cs: the own candidates (h); css / W: the source candidates (own range or whole grid)
-template <typename T, int D>
-__global__ __launch_bounds__(256) void k_goose_exact(const CandSpec cs, const CandSpec css, const T* __restrict__ W,
-                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc, int c,
-                                                     const long long* __restrict__ amb, uint8_t* __restrict__ O) {
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const long long namb = sc->n_amb;
-  const double rm = (L > 0 && sc->rmax_key[c]) ? fmax(0.0, ord_val(sc->rmax_key[c])) / L : 0.0;
-  // one listed point can own a box as large as the grid: its box is cut into kParts slices, one workgroup each
-  constexpr int kParts = 64;
-  for (long long wi = blockIdx.x; wi < namb * kParts; wi += gridDim.x) {
-    const long long qi = wi / kParts;
-    const int part = (int)(wi % kParts);
-    const long long hl = amb[qi];
-    double xh[D];
-    cand_coords<D>(cs, hl, xh);
-    long long lo[D], len[D], stridea[D];
-    long long f = cs.first + hl, total = 1, sa = 1;
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-      lo[a] = 0; len[a] = 1; stridea[a] = 0;
-      if (a < cs.d) {
-        const long long cnt = cs.count[a];
-        const long long ih = f % cnt;
-        f /= cnt;
-        long long R = cnt;
-        if (cs.step[a] > 0) {
-          const double rr = (rm * (1.0 + 1e-9) + 1e-7) / cs.step[a];
-          R = rr < (double)cnt ? (long long)ceil(rr) + 1 : cnt;
-        }
-        const long long l0 = ih - R > 0 ? ih - R : 0, h0 = ih + R < cnt - 1 ? ih + R : cnt - 1;
-        lo[a] = l0; len[a] = h0 - l0 + 1; stridea[a] = sa;
-        total *= len[a];
-        sa *= cnt;
-      }
-    }
-    int found = 0;
-    const long long chunk = (total + kParts - 1) / kParts;
-    const long long t1 = (part + 1) * chunk < total ? (part + 1) * chunk : total;
-    for (long long t = part * chunk + threadIdx.x; t < t1 && !found; t += blockDim.x) {
-      long long u = t, gg = 0;
-      double xg[D];
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        xg[a] = 0.0;
-        if (a < cs.d) {
-          const long long ia = lo[a] + u % len[a];
-          u /= len[a];
-          gg += ia * stridea[a];
-          const long long cnt = cs.count[a];
-          xg[a] = (ia == cnt - 1 && cnt > 1) ? cs.hi[a] : __dadd_rn(cs.lo[a], __dmul_rn((double)ia, cs.step[a]));
-        }
-      }
-      const long long gl = gg - css.first;
-      if (gl >= 0 && gl < css.n_local) {
-        const double w = (double)W[gl];
-        if (w >= 0.0 && lipschitz_pair<D>(xg, xh, cs.d, w, L)) found = 1;
-      }
-    }
-    found = __syncthreads_or(found);
-    if (threadIdx.x == 0 && found) O[hl] = 1;
-    __syncthreads();
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += namb;
-}
-
-// trust-region mask: S and ||x - x_0||_2 <= r, the norm evaluated as sqrt(sum (x - x_0)^2) (models/GP_TR.py:49)
-template <int D>
-__global__ void k_ball_mask(const CandSpec cs, long long n, const uint8_t* __restrict__ S, const double* __restrict__ x0,
-                            double r, uint8_t* __restrict__ out) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    uint8_t m = 0;
-    if (S[g]) {
-      double x[D];
-      cand_coords<D>(cs, g, x);
-      double ss = 0.0;
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        if (a < cs.d) {
-          const double df = x[a] - x0[a];
-          ss = (a == 0) ? df * df : ss + df * df;
-        }
-      }
-      m = sqrt(ss) <= r;
-    }
-    out[g] = m;
-  }
-}
-
-// value arrays for the arg-reductions of the GoOSE sweep
-template <typename T>
-__global__ void k_lcb0(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b, T* __restrict__ out) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    T lcb, ucb;
-    lcb_ucb(mean0[g], var0[g], b, lcb, ucb);
-    out[g] = lcb;
-  }
-}
-// Euclidean distance to the target, as scipy.spatial.distance.cdist computes it (models/GoOSE.py:117)
-template <typename T, int D>
-__global__ void k_dist_to(const CandSpec cs, long long n, const double* __restrict__ target, T* __restrict__ out) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    double x[D];
-    cand_coords<D>(cs, g, x);
-    double ss = 0.0;
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-      if (a < cs.d) {
-        const double df = x[a] - target[a];
-        ss += df * df;
-      }
-    }
-    out[g] = (T)sqrt(ss);
-  }
-}
+#include "sets_expander.inc.hpp"
+#include "sets_exchange.inc.hpp"
+#include "sets_goose.inc.hpp"
 
 // ---- host orchestration -------------------------------------------------------------------------------
 static int reduce_blocks(const sbo_ctx* c) {

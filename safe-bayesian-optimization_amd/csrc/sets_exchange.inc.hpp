@@ -1,0 +1,71 @@
+// sets_exchange.inc.hpp: pack / unpack kernels of the multi-rank collectives C1-C3 -- part of the sets.hip translation unit (included inside namespace sbo; not a standalone header).
+#pragma once
+
+// ---- multi-rank exchange -----------------------------------------------------------
+// C1: one max all-reduce of [~u*_key, L keys, radius keys]
+__global__ void k_pack_c1(const SweepScalars* sc, const unsigned long long* Lkeys, unsigned long long* buf) {
+  const int t = threadIdx.x;
+  if (t == 0) buf[0] = ~sc->ustar_key;
+  if (t < kMaxQ) { buf[1 + t] = Lkeys[t]; buf[1 + kMaxQ + t] = sc->rmax_key[t]; }
+}
+__global__ void k_unpack_c1(SweepScalars* sc, unsigned long long* Lkeys, const unsigned long long* buf) {
+  const int t = threadIdx.x;
+  if (t == 0) sc->ustar_key = ~buf[0];
+  if (t < kMaxQ) { Lkeys[t] = buf[1 + t]; sc->rmax_key[t] = buf[1 + kMaxQ + t]; }
+}
+// C2: all-gathered padded shards -> contiguous whole-grid mask
+template <typename E>
+__global__ __launch_bounds__(256) void k_compact_shards(const E* __restrict__ recv, long long maxlocal, int world,
+                                                        const long long* __restrict__ first_of, long long total,
+                                                        E* __restrict__ full) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    int r = 0;
+    while (r + 1 < world && g >= first_of[r + 1]) ++r;
+    full[g] = recv[(size_t)r * maxlocal + (g - first_of[r])];
+  }
+}
+// C2 (bit form): own mask -> one word per 64 candidates (zero beyond n); gathered words -> whole-grid byte mask
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ U, long long n, long long words,
+                                                   unsigned long long* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < words; w += nwaves) {
+    const long long g = w * 64 + lane;
+    const unsigned long long m = __ballot(g < n && U[g]);
+    if (lane == 0) out[w] = m;
+  }
+}
+__global__ __launch_bounds__(256) void k_unpack_shards(const unsigned long long* __restrict__ recv, long long words, int world,
+                                                       const long long* __restrict__ first_of, long long total,
+                                                       uint8_t* __restrict__ full) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    int r = 0;
+    while (r + 1 < world && g >= first_of[r + 1]) ++r;
+    const long long l = g - first_of[r];
+    full[g] = (uint8_t)((recv[(size_t)r * words + (l >> 6)] >> (l & 63)) & 1ull);
+  }
+}
+// C3: each rank fills its own row of [world][kC3Row] doubles, one sum all-reduce delivers every row everywhere
+constexpr int kC3Row = 2 * kArgSlots + 4 + kMaxQ;
+__global__ void k_pack_c3(const SweepScalars* sc, double* buf, int world, int rank) {
+  for (int i = threadIdx.x; i < world * kC3Row; i += blockDim.x) buf[i] = 0.0;
+  __syncthreads();
+  double* row = buf + (size_t)rank * kC3Row;
+  const int t = threadIdx.x;
+  if (t < kArgSlots) { row[t] = sc->arg_idx[t] >= 0 ? sc->arg_val[t] : 0.0; row[kArgSlots + t] = (double)sc->arg_idx[t]; }
+  if (t == 0) {
+    row[2 * kArgSlots + 0] = (double)sc->count_S;
+    row[2 * kArgSlots + 1] = (double)sc->count_U;
+    row[2 * kArgSlots + 2] = (double)sc->count_M;
+    row[2 * kArgSlots + 3] = (double)sc->n_amb_total;
+  }
+  if (t < kMaxQ) row[2 * kArgSlots + 4 + t] = (double)sc->count_set[t];
+}
+__global__ void k_init_scalars(SweepScalars* sc) {
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(sc);       // (the struct is a multiple of 8 bytes)
+  for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) w[i] = 0ull;
+  __syncthreads();
+  if (threadIdx.x == 0) sc->ustar_key = ~0ull;
+  if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
+}
+

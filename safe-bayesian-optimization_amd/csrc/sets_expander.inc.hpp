@@ -1,0 +1,494 @@
+// sets_expander.inc.hpp: K4 kernels, expander sets by exact distance transform + band recheck -- part of the sets.hip translation unit (included inside namespace sbo; not a standalone header).
+#pragma once
+
+// ---- K4: exact Euclidean distance transform of the U mask on the grid ---------------------------------
+// axis 0: one wave per grid line, nearest set bit on either side found with ballots (coalesced, exact)
+__global__ __launch_bounds__(256) void k_edt_axis0(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
+                                                   double* __restrict__ D) {
+  const int lane = threadIdx.x & 63;
+  const long long line = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (line >= nlines) return;
+  const uint8_t* u = U + line * count0;
+  double* d = D + line * count0;
+  const int nch = (count0 + 63) >> 6;
+  long long carry = -1;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int i = ch * 64 + lane;
+    const bool bit = i < count0 && u[i];
+    const unsigned long long m = __ballot(bit);
+    const unsigned long long lower = m & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+    const long long li = lower ? (long long)ch * 64 + (63 - __clzll((long long)lower)) : carry;
+    if (i < count0) d[i] = (double)li;
+    if (m) carry = (long long)ch * 64 + (63 - __clzll((long long)m));
+  }
+  carry = -1;
+  for (int ch = nch - 1; ch >= 0; --ch) {
+    const int i = ch * 64 + lane;
+    const bool bit = i < count0 && u[i];
+    const unsigned long long m = __ballot(bit);
+    const unsigned long long upper = m >> lane;
+    const long long ri = upper ? (long long)ch * 64 + lane + (__ffsll((long long)upper) - 1) : carry;
+    if (i < count0) {
+      const long long li = (long long)d[i];
+      long long t = -1;
+      if (li >= 0) t = i - li;
+      if (ri >= 0 && (t < 0 || ri - i < t)) t = ri - i;
+      double v = kInfD;
+      if (t >= 0) {
+        const double dt = h0 * (double)t;
+        v = dt * dt;
+      }
+      d[i] = v;
+    }
+    if (m) carry = (long long)ch * 64 + (__ffsll((long long)m) - 1);
+  }
+}
+
+// axes >= 1: D_out[g] = min_t D_in[g + t stride] + (h t)^2, searched outwards with the two exits
+//   (h t)^2 >= best  (nothing further can improve)  and  h t > cap  (beyond any radius that matters).
+// `accept2`: once best <= accept2 the caller's decision is already "within the radius" and a smaller minimum cannot
+// change it, so the search stops (pass -1 to get the exact minimum).
+__device__ __forceinline__ double edt_scan_point(const double* __restrict__ Din, long long g, long long stride, int cnt,
+                                                 int ia, double h, double cap, double accept2 = -1.0) {
+  double best = Din[g];
+  for (int t = 1; t < cnt; ++t) {
+    const double dt = h * (double)t;
+    const double e = dt * dt;
+    if (e >= best || dt > cap || best <= accept2) break;
+    const bool lo_ok = ia - t >= 0, hi_ok = ia + t < cnt;
+    if (!lo_ok && !hi_ok) break;
+    const double c1 = lo_ok ? Din[g - (long long)t * stride] : kInfD;
+    const double c2 = hi_ok ? Din[g + (long long)t * stride] : kInfD;
+    const double c = (c1 < c2 ? c1 : c2) + e;
+    best = c < best ? c : best;
+  }
+  return best;
+}
+
+// Last-axis scans with a one-level min-pyramid.  Bmin[b * stride + p] = min of the input over the kBlk (or `blk`) steps
+// of block b at in-plane position p.  A block whose bound  Bmin + (h gap)^2  cannot beat the running minimum is skipped
+// with one load instead of `blk`; the candidates examined inside a block and their arithmetic are those of the
+// step-by-step scan, so the minimum (up to the same early exits) is identical.  This keeps the scan cost near
+// O(sqrt(radius in steps)) when the grid is much finer along the last axis than the radius (weak-scaling grids).
+__global__ __launch_bounds__(256) void k_block_min(const double* __restrict__ Din, long long stride, int cnt, int blk,
+                                                   double* __restrict__ Bmin) {
+  const int nblk = (cnt + blk - 1) / blk;
+  const long long total = (long long)nblk * stride;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i % stride;
+    const int b = (int)(i / stride);
+    const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
+    double m = kInfD;
+    for (int j = b * blk; j < j1; ++j) {
+      const double v = Din[(long long)j * stride + p];
+      m = v < m ? v : m;
+    }
+    Bmin[i] = m;
+  }
+}
+
+// Euclidean form (values >= 0, exits as edt_scan_point: (h t)^2 >= best, h t > cap, best <= accept2).
+// Order of visits: the block with the smallest bound first (it almost always holds the minimiser, so `best` is near
+// its final value after one block), then every block whose bound still beats `best`.
+__device__ __forceinline__ double edt_scan_blocked(const double* __restrict__ Din, const double* __restrict__ Bmin, long long p,
+                                                   long long stride, int cnt, int ia, double h, double cap, double accept2,
+                                                   int blk) {
+  // The few candidates that reach this scan decide the kernel's duration through their chain of dependent loads, so
+  // loads are issued in independent batches (eight block values / eight bounds at a time) and only then examined.
+  double best = Din[(long long)ia * stride + p];
+  const int nblk = (cnt + blk - 1) / blk, b0 = ia / blk;
+  auto scan_block = [&](int b) {
+    const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
+    for (int j = b * blk; j < j1; j += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = j + u < j1 ? Din[(long long)(j + u) * stride + p] : kInfD;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int jj = j + u;
+        const double dt = h * (double)(jj > ia ? jj - ia : ia - jj);
+        const double cnd = v[u] + dt * dt;
+        if (dt <= cap && cnd < best) best = cnd;
+      }
+    }
+  };
+  // gap (in steps) between ia and the nearest step of block b
+  auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? ia - (b * blk + blk - 1) : b * blk - ia); };
+  auto bound_at = [&](int b) { return (b >= 0 && b < nblk) ? Bmin[(long long)b * stride + p] : kInfD; };
+  // pass A: block with the smallest bound
+  double lb_min = Bmin[(long long)b0 * stride + p];
+  int b_min = b0;
+  for (int k0 = 1; k0 < nblk; k0 += 4) {
+    double lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { lo[u] = bound_at(b0 - k0 - u); hi[u] = bound_at(b0 + k0 + u); }
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      any = false;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int b = side ? b0 + k0 + u : b0 - k0 - u;
+        if (b < 0 || b >= nblk) continue;
+        const double dg = h * (double)gap_of(b);
+        const double e = dg * dg;
+        if (e >= best || e >= lb_min || dg > cap) continue;
+        any = true;
+        const double lb = (side ? hi[u] : lo[u]) + e;
+        if (lb < lb_min) { lb_min = lb; b_min = b; }
+      }
+      if (!any) break;
+    }
+    if (!any) break;
+  }
+  if (lb_min < best) scan_block(b_min);
+  if (best <= accept2) return best;
+  // pass B: whatever can still improve
+  if (b_min != b0 && Bmin[(long long)b0 * stride + p] < best) scan_block(b0);
+  for (int k0 = 1; k0 < nblk && !(best <= accept2); k0 += 4) {
+    double lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { lo[u] = bound_at(b0 - k0 - u); hi[u] = bound_at(b0 + k0 + u); }
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      any = false;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int b = side ? b0 + k0 + u : b0 - k0 - u;
+        if (b < 0 || b >= nblk) continue;
+        const double dg = h * (double)gap_of(b);
+        const double e = dg * dg;
+        if (e >= best || dg > cap) continue;
+        any = true;
+        if (b != b_min && (side ? hi[u] : lo[u]) + e < best) scan_block(b);
+      }
+      if (!any) break;
+    }
+    if (!any) break;
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din, double* __restrict__ Dout, long long n,
+                                                  long long stride, int cnt, double h, const SweepScalars* sc, int c,
+                                                  const unsigned long long* Lkeys, int lidx, int uncapped) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const double rmax = sc->rmax_key[c] ? ord_val(sc->rmax_key[c]) : 0.0;
+  const double cap = (L > 0 && !uncapped) ? rmax / L * 1.000001 + 1e-6 : kInfD;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    const int ia = (int)((g / stride) % cnt);
+    Dout[g] = edt_scan_point(Din, g, stride, cnt, ia, h, cap);
+  }
+}
+
+// Coarse pre-decision for the expander query.  The U mask is OR-reduced over cells of kCoarse^d candidates and the
+// exact transform of that small mask gives, for any candidate g in cell C, the sandwich
+//     dC - delta <= dist(g, U) <= dC + delta,   delta = (kCoarse - 1) * sqrt(sum_a h_a^2)
+// (dC = distance between cell origins to the nearest U-holding cell).  Candidates whose verdict is the same at both
+// ends skip the per-candidate scan of the fine transform; only the shell around the boundary of G_c scans.
+constexpr int kCoarse = 8;
+struct CoarseGrid {
+  int enabled;
+  int d;
+  long long count[kMaxD];    // fine counts
+  long long ccount[kMaxD];   // coarse counts
+  double delta;
+  const double* Dc;          // squared coarse distances [prod ccount]
+};
+
+__global__ __launch_bounds__(256) void k_coarsen_mask(const uint8_t* __restrict__ U, long long n, const CoarseGrid cg,
+                                                      uint8_t* __restrict__ Uc) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    if (!U[g]) continue;
+    long long f = g, cell = 0, cs = 1;
+    for (int a = 0; a < cg.d; ++a) {
+      const long long i = f % cg.count[a];
+      f /= cg.count[a];
+      cell += (i / kCoarse) * cs;
+      cs *= cg.ccount[a];
+    }
+    Uc[cell] = 1;   // idempotent store
+  }
+}
+
+__device__ __forceinline__ double coarse_dist2(const CoarseGrid& cg, long long gg) {
+  long long f = gg, cell = 0, cs = 1;
+  for (int a = 0; a < cg.d; ++a) {
+    const long long i = f % cg.count[a];
+    f /= cg.count[a];
+    cell += (i / kCoarse) * cs;
+    cs *= cg.ccount[a];
+  }
+  return cg.Dc[cell];
+}
+
+// Reference expression for one (g, h) pair, unfused, in the oracle's order:
+//   ucb - L * sqrt(sum_a (x_g[a] - x_h[a] + 1e-8)^2) >= 0            models/SafeOpt.py:85-88
+template <int D>
+__device__ __forceinline__ bool lipschitz_pair(const double (&xg)[D], const double (&xh)[D], int d, double ucb, double L) {
+  double ss = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    if (a < d) {
+      const double df = __dadd_rn(__dsub_rn(xg[a], xh[a]), 1e-8);
+      ss = (a == 0) ? __dmul_rn(df, df) : __dadd_rn(ss, __dmul_rn(df, df));
+    }
+  }
+  const double dist = __dsqrt_rn(ss);
+  return __dsub_rn(ucb, __dmul_rn(L, dist)) >= 0.0;
+}
+
+// last axis + decision.  For g in S: nearest-U distance dm (unshifted) -> G bit, or the ambiguous list when
+// ucb - L dm lies inside the band the "+1e-8" shift and rounding can move it across zero.
+template <typename T>
+__global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ Din, long long n, long long goff,
+                                                    long long stride, int cnt,
+                                                    double h, int d, double xscale, const T* __restrict__ mean_c,
+                                                    const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
+                                                    const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
+                                                    uint8_t* __restrict__ G, long long* __restrict__ amb,
+                                                    const CoarseGrid cg, const double* __restrict__ Bmin, int blk,
+                                                    long long* __restrict__ scanlist) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const bool anyU = sc->count_U > 0;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    uint8_t out = 0;
+    if (S[g] && anyU) {
+      T lcb, ucbT;
+      lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
+      const double ucb = (double)ucbT;
+      if (!(L > 0)) {
+        out = ucb >= 0.0;                         // radius unbounded: any U point is a witness
+      } else {
+        const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
+        const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
+        const long long gg = goff + g;   // index in the transform (whole grid when ranks share it)
+        if (cg.enabled) {
+          const double dC = sqrt(coarse_dist2(cg, gg));
+          const double dhi = dC * (1.0 + 1e-9) + cg.delta, dlo = fmax(0.0, dC * (1.0 - 1e-9) - cg.delta);
+          const double tolc = 1e-12 * (fabs(ucb) + L * dhi);
+          if (ucb - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { G[g] = 1; continue; }     // within the radius for sure
+          if (ucb - L * (dlo - eps_abs - 1e-11 * dlo) < -tolc) { G[g] = 0; continue; }    // beyond it for sure
+        }
+        if (scanlist && Bmin && cnt > 1) {
+          // the few candidates the coarse bounds leave open go to k_edt_scan_list (one wave each): a lane scanning
+          // here would hold its whole wave for a chain of ~100 dependent loads
+          scanlist[atomicAdd((unsigned long long*)&sc->n_scan, 1ull)] = g;
+          G[g] = 0;
+          continue;
+        }
+        const int ia = (int)((gg / stride) % cnt);
+        const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it the verdict is "sure true"
+        const double acc2 = thr > 0 ? thr * thr : -1.0;
+        const double best = cnt <= 1 ? Din[gg]
+                            : Bmin  ? edt_scan_blocked(Din, Bmin, gg % stride, stride, cnt, ia, h, cap, acc2, blk)
+                                    : edt_scan_point(Din, gg, stride, cnt, ia, h, cap, acc2);
+        if (best < 0.5 * kInfD) {
+          const double dm = sqrt(best);
+          const double eps = eps_abs + 1e-11 * dm;
+          const double tol = 1e-12 * (fabs(ucb) + L * dm);
+          const double lo = ucb - L * (dm + eps), hi = ucb - L * (dm - eps);
+          if (lo > tol) out = 1;
+          else if (hi >= -tol) {
+            const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
+            amb[slot] = g;
+          }
+        }
+      }
+    }
+    G[g] = out;
+  }
+}
+
+// Last-axis scan + verdict for the listed candidates, one group of GL lanes (half a wave or a wave, GL >= blk) per
+// candidate: the lanes take GL blocks (bounds) or the steps of one block at a time and combine with group minima -- the
+// same candidates and arithmetic as edt_scan_blocked, with the dependent-load chain cut from ~100 to ~5 per candidate.
+// (The two halves of a wave follow their own trip counts; every cross-lane operation stays inside one half.)
+template <typename T, int GL>
+__global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict__ Din, long long goff, long long stride, int cnt,
+                                                       double h, int d, double xscale, const T* __restrict__ mean_c,
+                                                       const T* __restrict__ var_c, T b, const unsigned long long* Lkeys, int lidx,
+                                                       SweepScalars* sc, uint8_t* __restrict__ G, long long* __restrict__ amb,
+                                                       const double* __restrict__ Bmin, int blk,
+                                                       const long long* __restrict__ scanlist) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const long long nscan = sc->n_scan;
+  const int lane = threadIdx.x & (GL - 1);
+  const int sub = (threadIdx.x & 63) / GL;
+  const long long ngroups = (long long)gridDim.x * (blockDim.x / GL);
+  const int nblk = (cnt + blk - 1) / blk;
+  auto group_min = [&](double v) {
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+  };
+  auto group_ballot = [&](bool pred) {
+    const unsigned long long m = __ballot(pred);
+    return GL == 64 ? m : ((m >> (32 * sub)) & 0xffffffffull);
+  };
+  for (long long qi = (long long)blockIdx.x * (blockDim.x / GL) + threadIdx.x / GL; qi < nscan; qi += ngroups) {
+    const long long g = scanlist[qi];
+    T lcb, ucbT;
+    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
+    const double ucb = (double)ucbT;
+    const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
+    const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
+    const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;
+    const double acc2 = thr > 0 ? thr * thr : -1.0;
+    const long long gg = goff + g, p = gg % stride;
+    const int ia = (int)((gg / stride) % cnt), b0 = ia / blk;
+    double best = Din[(long long)ia * stride + p];
+    // blocks within reach of the radius
+    const int kmax = (int)fmin((double)nblk, floor(cap / (h * (double)blk)) + 2.0);
+    const int blo = b0 - kmax > 0 ? b0 - kmax : 0, bhi = b0 + kmax < nblk - 1 ? b0 + kmax : nblk - 1;
+    auto bound_of = [&](int bb) {       // bound of block bb for this lane (inf outside the reach / the axis)
+      if (bb < blo || bb > bhi) return kInfD;
+      const int gap = bb == b0 ? 0 : (bb < b0 ? ia - (bb * blk + blk - 1) : bb * blk - ia);
+      const double dg = h * (double)gap;
+      if (dg > cap) return kInfD;
+      return Bmin[(long long)bb * stride + p] + dg * dg;
+    };
+    auto scan_block = [&](int bb) {     // the group: the (<= GL) steps of block bb
+      const int jn = bb * blk + lane;
+      double cnd = kInfD;
+      if (lane < blk && jn < cnt) {
+        const double dt = h * (double)(jn > ia ? jn - ia : ia - jn);
+        if (dt <= cap) cnd = Din[(long long)jn * stride + p] + dt * dt;
+      }
+      cnd = group_min(cnd);
+      best = cnd < best ? cnd : best;
+    };
+    // pass A: the block with the smallest bound
+    double lb_min = kInfD;
+    int b_min = -1;
+    for (int base = blo; base <= bhi; base += GL) {
+      const double lb = bound_of(base + lane);
+      const double m = group_min(lb);
+      if (m < lb_min) {
+        lb_min = m;
+        const unsigned long long who = group_ballot(lb == m);
+        b_min = base + (int)(__ffsll((long long)who) - 1);
+      }
+    }
+    if (b_min >= 0 && lb_min < best) scan_block(b_min);
+    // pass B: every other block whose bound still beats the running minimum
+    for (int base = blo; base <= bhi && !(best <= acc2); base += GL) {
+      const double lb = bound_of(base + lane);
+      unsigned long long todo = group_ballot(lb < best && base + lane != b_min);
+      while (todo && !(best <= acc2)) {
+        const int l = (int)(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const double lbl = __shfl(lb, l + GL * sub);
+        if (lbl < best) scan_block(base + l);
+      }
+    }
+    if (lane == 0) {
+      uint8_t out = 0;
+      if (best < 0.5 * kInfD) {
+        const double dm = sqrt(best);
+        const double eps = eps_abs + 1e-11 * dm;
+        const double tol = 1e-12 * (fabs(ucb) + L * dm);
+        const double lo = ucb - L * (dm + eps), hi = ucb - L * (dm - eps);
+        if (lo > tol) out = 1;
+        else if (hi >= -tol) amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
+      }
+      G[g] = out;
+    }
+  }
+}
+
+// every S point goes to the exhaustive list (explicit candidate lists have no grid to transform)
+__global__ __launch_bounds__(256) void k_list_safe(const uint8_t* __restrict__ S, long long n, SweepScalars* sc,
+                                                   uint8_t* __restrict__ G, long long* __restrict__ amb) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    G[g] = 0;
+    if (S[g]) {
+      const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
+      amb[slot] = g;
+    }
+  }
+}
+
+// exhaustive evaluation of the reference predicate for the listed g: one workgroup per g, every U point that can matter
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const CandSpec csU, const T* __restrict__ mean_c,
+                                                        const T* __restrict__ var_c, T b, const uint8_t* __restrict__ U,
+                                                        const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
+                                                        const long long* __restrict__ amb, uint8_t* __restrict__ G) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const long long namb = sc->n_amb;
+  constexpr int kParts = 64;   // a listed candidate's box can be as large as the grid: cut into slices, one workgroup each
+  for (long long wi = blockIdx.x; wi < namb * kParts; wi += gridDim.x) {
+    const long long qi = wi / kParts;
+    const int part = (int)(wi % kParts);
+    const long long g = amb[qi];
+    T lcb, ucbT;
+    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
+    const double ucb = (double)ucbT;
+    double xg[D];
+    cand_coords<D>(cs, g, xg);
+    int found = 0;
+    if (csU.kind == 1) {
+      // grid: only witnesses inside the index box of half-width ceil(r / h_a) + 1 around g can satisfy the predicate
+      long long lo[D], len[D], stridea[D];
+      long long f = cs.first + g, total = 1, sa = 1;
+      const double rg = L > 0 ? ucb / L : 1e300;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        lo[a] = 0; len[a] = 1; stridea[a] = 0;
+        if (a < cs.d) {
+          const long long cnt = cs.count[a];
+          const long long ig = f % cnt;
+          f /= cnt;
+          long long R = cnt;
+          if (L > 0 && cs.step[a] > 0) {
+            const double rr = (rg * (1.0 + 1e-9) + 1e-7) / cs.step[a];
+            R = rr < (double)cnt ? (long long)ceil(rr) + 1 : cnt;
+            if (R < 0) R = 0;
+          }
+          const long long l0 = ig - R > 0 ? ig - R : 0, h0 = ig + R < cnt - 1 ? ig + R : cnt - 1;
+          lo[a] = l0; len[a] = h0 - l0 + 1; stridea[a] = sa;
+          total *= len[a];
+          sa *= cnt;
+        }
+      }
+      const long long chunk = (total + kParts - 1) / kParts;
+      const long long t1 = (part + 1) * chunk < total ? (part + 1) * chunk : total;
+      for (long long t = part * chunk + threadIdx.x; t < t1 && !found; t += blockDim.x) {
+        long long u = t, hh = 0;
+        double xh[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          xh[a] = 0.0;
+          if (a < cs.d) {
+            const long long ia = lo[a] + u % len[a];
+            u /= len[a];
+            hh += ia * stridea[a];
+            const long long cnt = cs.count[a];
+            xh[a] = (ia == cnt - 1 && cnt > 1) ? cs.hi[a] : __dadd_rn(cs.lo[a], __dmul_rn((double)ia, cs.step[a]));
+          }
+        }
+        const long long hl = hh - csU.first;
+        if (hl >= 0 && hl < csU.n_local && U[hl] && lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
+      }
+    } else {
+      for (long long hh = (long long)part * blockDim.x + threadIdx.x; hh < csU.n_local && !found; hh += (long long)kParts * blockDim.x) {
+        if (U[hh]) {
+          double xh[D];
+          cand_coords<D>(csU, hh, xh);
+          if (lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
+        }
+      }
+    }
+    found = __syncthreads_or(found);
+    if (threadIdx.x == 0 && found) G[g] = 1;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sc->n_amb_total += namb;
+  }
+}
+
+__global__ void k_reset_amb(SweepScalars* sc) { sc->n_amb = 0; sc->n_scan = 0; }
+
