@@ -126,6 +126,9 @@ def main():
 
     # one GPU per process; SBO_BENCH_DEVICE pins every rank to one card (single-GPU rehearsal of the N>1 plumbing only)
     eng = safebo_amd.SweepEngine(int(os.environ.get("SBO_BENCH_DEVICE", local_rank)))
+    for kv in filter(None, os.environ.get("SBO_BENCH_OPTIONS", "").split(",")):   # tuning knobs, e.g. "scan_waves=16"
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     transport = "none"
     if world > 1:
         transport = distributed.join_with_fallback(eng)   # RCCL (unique id broadcast from rank 0); gloo relay if it cannot form

@@ -135,9 +135,9 @@ typedef struct sbo_tr_result {
  * library's stream (feeds bench.py's roofline.achieved) */
 typedef struct sbo_profile {
   double posterior_ms;     /* K1: fused cross-covariance + contraction + mean/var                          */
-  double classify_ms;      /* K3: bounds, S/U/M masks, u*, reductions                                      */
-  double expander_ms;      /* K4: distance transform + G_c / O_c decisions                                 */
-  double argreduce_ms;     /* K5: masked arg-max / arg-min                                                 */
+  double classify_ms;      /* K3: bounds, S/U/M masks, u*, reductions     (these three: 0 unless option     */
+  double expander_ms;      /* K4: distance transform + G_c / O_c decisions  "phase_events" is 1 -- an event  */
+  double argreduce_ms;     /* K5: masked arg-max / arg-min                   costs a ~6 us bubble per record) */
   double comm_ms;          /* RCCL collectives                                                             */
   double total_ms;         /* first launch to last completion                                              */
   double posterior_flops;  /* algorithmic flops of the K1 launch(es): q (n^2 + (2d+10) n) per candidate    */
@@ -242,7 +242,8 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
 /* tuning / diagnostics knobs: "posterior_path" (0 auto, 1 generic single-phase, 2 generic chunked), "bilinear" (1 default:
  * fp64 2-D grids run the posterior as two GEMMs in a reduced basis when that is cheaper; 0: always the separable-table
  * kernel), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
- * "goose_pairs" (1: pair evaluation instead of the transform on grids) */
+ * "scan_waves" (1 default: open candidates of the expander query are scanned by half-waves), "goose_pairs" (1: pair
+ * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

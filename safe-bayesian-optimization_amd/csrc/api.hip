@@ -102,9 +102,15 @@ int sbo_init(int device_id, sbo_ctx** out) {
     delete c;
     return fail(SBO_E_HIP, "hipHostMalloc");
   }
-  int rc = ensure(c->Lmax, sizeof(unsigned long long) * kMaxQ);
-  if (!rc) rc = ensure(c->scal, 4096);
+  if (hipHostMalloc((void**)&c->h_back, 8192, hipHostMallocDefault) != hipSuccess) {
+    delete c;
+    return fail(SBO_E_HIP, "hipHostMalloc");
+  }
+  // the sweep's scalar block and, 2 KB further, the Lipschitz keys: one allocation, so one read-back covers both
+  int rc = ensure(c->scal, 4096);
   if (rc) { delete c; return rc; }
+  c->Lmax.p = (char*)c->scal.p + 2048;   // (a view: not in the release list)
+  c->Lmax.bytes = 2048;
   *out = c;
   return SBO_OK;
 }
@@ -116,12 +122,13 @@ int sbo_shutdown(sbo_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   sbo_comm_destroy_internal(c);
-  for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->Lmax, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
+  for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->maskS,
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->h_c1) (void)hipHostFree(c->h_c1);
+  if (c->h_back) (void)hipHostFree(c->h_back);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SBO_OK;
@@ -151,8 +158,12 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->posterior_valid = false;
     return SBO_OK;
   }
+  if (!strcmp(key, "phase_events")) {
+    c->phase_events = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "scan_waves")) {
-    c->scan_waves = value ? 1 : 0;
+    c->scan_waves = (int)value;   // 0: off; 8 / 16 / 32 / 64: lanes per listed candidate (anything else: the default, 16)
     return SBO_OK;
   }
   if (!strcmp(key, "scan_blocks")) {

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
                                                   const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
                                                   size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
                                                   int KSm, int KBm2, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
-                                                  double* __restrict__ var_out, unsigned long long* __restrict__ Lmax) {
+                                                  double* __restrict__ var_out, double* __restrict__ Lpart) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
   const int o = blockIdx.z;
   PostCtx cx;
@@ -331,7 +331,32 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
     const double other = __shfl_xor(gmax, off);
     gmax = other > gmax ? other : gmax;
   }
-  if (cx.lane == 0) atomicMax(&Lmax[o], (unsigned long long)__double_as_longlong(gmax));
+  // one plain store per wave, merged by k_lmax_reduce: every workgroup of this launch is resident at once and ends at
+  // the same time, so atomics on the q keys would queue up in L2 as the kernel's tail
+  if (cx.lane == 0)
+    Lpart[(((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + cx.wave] = gmax;
+}
+
+// Lipschitz keys of a K1b launch: Lmax[o] = max of the per-wave partials (values >= 0, so the bit pattern orders them)
+__global__ __launch_bounds__(256) void k_lmax_reduce(const double* __restrict__ Lpart, int per_out, unsigned long long* __restrict__ Lmax) {
+  __shared__ double sh[4];
+  const int o = blockIdx.x;
+  double g = 0.0;
+  for (int i = threadIdx.x; i < per_out; i += blockDim.x) {
+    const double v = Lpart[(size_t)o * per_out + i];
+    g = v > g ? v : g;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double other = __shfl_xor(g, off);
+    g = other > g ? other : g;
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = g;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) g = sh[w] > g ? sh[w] : g;
+    Lmax[o] = (unsigned long long)__double_as_longlong(g);
+  }
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------
@@ -564,11 +589,16 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                      (double*)c->bl_BtA.p, pl.sBtA, (double*)nullptr, 0ll);
   // stage 2 (fused): variance, mean, Lipschitz keys
   const size_t lds = sizeof(double) * 2 * 4096;
+  const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8), gy = (unsigned)((pl.nrb + 7) / 8);
+  int rc;
+  if ((rc = ensure(c->bl_lpart, sizeof(double) * 4 * (size_t)gx * gy * q))) return rc;
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_bpost, dim3((unsigned)((pl.ncs0 + 7) / 8), (unsigned)((pl.nrb + 7) / 8), (unsigned)q), dim3(256), lds, c->stream,
+  hipLaunchKernelGGL(k_bpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream,
                      mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
                      pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
-                     (double*)c->mean.p, (double*)c->var.p, (unsigned long long*)c->Lmax.p);
+                     (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p);
+  hipLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, (const double*)c->bl_lpart.p, (int)(4 * gx * gy),
+                     (unsigned long long*)c->Lmax.p);
   (void)line0;
   // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (16 x 16 x 4 steps, 2 flops per multiply-add)
   const double tiles2 = (double)pl.nrb * pl.ncs0, tiles1 = (double)pl.nrb * pl.KB0;

@@ -105,6 +105,8 @@ struct sbo_ctx {
   sbo::DevBuf blockmax; // per-block largest source weight along axis 0 (blocked axis-0 pass of the power transform)
   sbo::DevBuf blockmin; // per-block minima along the last axis (blocked last-axis scans)
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
+  sbo::DevBuf bl_lpart; // K1b: per-wave Lipschitz partials of k_bpost
+  sbo::DevBuf cpart;   // per-workgroup partials of k_classify
   sbo::DevBuf Wfull;   // multi-rank GoOSE: source weights of the whole grid (all-gathered), T [grid_total]
   sbo::DevBuf Ufull;   // multi-rank: U mask of the whole grid (all-gathered), uint8 [grid_total]
   sbo::DevBuf gather;  // multi-rank: all-gather receive buffer [world][max_local]
@@ -115,8 +117,10 @@ struct sbo_ctx {
   std::vector<long long> first_of;   // [world + 1] flat offsets of the rank shards
   unsigned long long* h_c1 = nullptr;     // pinned host copy of the C1 keys (global u*, L, radius) of the running sweep
   bool c1_pending = false;                // the read-back of h_c1 has been enqueued (event ev[5]) but not yet waited for
+  unsigned char* h_back = nullptr;        // pinned host landing area of the end-of-sweep read-back (scalars + Lipschitz keys)
   int last_sweep = 0;  // 1 safeopt, 2 goose (what the masks hold)
   bool masks_valid = false;
+  bool amb_clean = false;   // the recheck / scan counters of the scalar block are still zero (no k_reset_amb needed)
   // profile
   sbo_profile prof{};
   hipEvent_t ev[8]{};
@@ -126,6 +130,7 @@ struct sbo_ctx {
   int scan_waves = 1;      // 1: candidates the coarse bounds leave open are scanned one wave each (0: by their own thread)
   int scan_blocks = 1;     // 0: step-by-step last-axis scans (A/B against the blocked form)
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
+  int phase_events = 0;    // 1: events between the set phases too (classify / expander / arg-reduce times in sbo_profile)
   int bilinear = 1;        // 1: fp64 2-D grids run the posterior as two GEMMs in a reduced basis when the bases qualify (K1b)
   int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
   // comm

@@ -886,7 +886,6 @@ static bool grid_path_ok(const sbo_ctx* c) {
 }
 
 int launch_posterior(sbo_ctx* c) {
-  SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
   // block-triangular contraction as issued: npad (npad + 16) / 2 multiply-adds per candidate and output
   const double tri_flops = (double)c->mc.q * c->mc.npad * (c->mc.npad + 16.0) * (double)c->cs.n_local;
   if (grid_path_ok(c)) {
@@ -896,15 +895,17 @@ int launch_posterior(sbo_ctx* c) {
       if (!c->bl.valid && (rc = bilinear_setup(c))) return rc;
       if (c->bl.usable) {
         c->last_k1 = 4;
-        return launch_posterior_bilinear(c);
+        return launch_posterior_bilinear(c);       // (writes the Lipschitz keys itself)
       }
     }
+    SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
     c->last_k1 = 3;
     c->last_k1_flops = tri_flops;
     return c->dtype == SBO_F64 ? launch_posterior_grid<double>(c) : launch_posterior_grid<float>(c);
   }
   // generic candidates: the single-phase kernel while the whole K* tile of 64 candidates fits LDS with two workgroups
   // per CU, the chunked kernel beyond that (and on request: posterior_path 2)
+  SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
   const size_t tile_bytes = (c->dtype == SBO_F64 ? 8u : 4u) * (size_t)c->mc.npad * 64;
   c->last_k1_flops = tri_flops;
   c->last_k1 = (c->posterior_path == 2 || tile_bytes > 64 * 1024) ? 2 : 1;

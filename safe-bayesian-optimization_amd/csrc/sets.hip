@@ -120,11 +120,13 @@ __device__ __forceinline__ void lcb_ucb(T m, T v, T b, T& lcb, T& ucb) {
   ucb = add_rn(m, sd);
 }
 
+constexpr int kClassifyRow = 3 + kMaxQ;   // u* key, |S|, |U|, radius keys
+
 // ---- K3a: S / U masks, u* --------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, const T* __restrict__ var, long long n,
                                                   int q, T b, uint8_t* __restrict__ S, uint8_t* __restrict__ U,
-                                                  SweepScalars* sc) {
+                                                  unsigned long long* __restrict__ part /* [gridDim.x][kClassifyRow] */) {
   __shared__ unsigned long long rmax_sh[kMaxQ];   // max over S of ucb_c: bounds the expander search radius
   if (threadIdx.x < kMaxQ) rmax_sh[threadIdx.x] = 0;
   __syncthreads();
@@ -194,12 +196,59 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
   cS = block_sum_ll(cS);
   cU = block_sum_ll(cU);
   __syncthreads();
+  // per-workgroup partials, merged by k_classify_final (atomics of every workgroup on one cache line serialise in L2:
+  // ~10 ns each, which was most of this kernel's time)
+  unsigned long long* row = part + (size_t)blockIdx.x * kClassifyRow;
   if (threadIdx.x == 0) {
-    if (umin != ~0ull) atomicMin(&sc->ustar_key, umin);
-    if (cS) atomicAdd((unsigned long long*)&sc->count_S, (unsigned long long)cS);
-    if (cU) atomicAdd((unsigned long long*)&sc->count_U, (unsigned long long)cU);
+    row[0] = umin;
+    row[1] = (unsigned long long)cS;
+    row[2] = (unsigned long long)cU;
   }
-  if (threadIdx.x >= 1 && threadIdx.x < q && rmax_sh[threadIdx.x]) atomicMax(&sc->rmax_key[threadIdx.x], rmax_sh[threadIdx.x]);
+  if (threadIdx.x < kMaxQ) row[3 + threadIdx.x] = rmax_sh[threadIdx.x];
+}
+
+// start of a sweep's scalar block: cleared, then u*, |S|, |U| and the radius keys merged from k_classify's partials
+__global__ __launch_bounds__(256) void k_classify_final(const unsigned long long* __restrict__ part, int nparts, int q,
+                                                        SweepScalars* sc) {
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(sc);       // (the struct is a multiple of 8 bytes)
+  for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) w[i] = 0ull;
+  __syncthreads();
+  unsigned long long umin = ~0ull, rmax[kMaxQ];
+  long long cS = 0, cU = 0;
+#pragma unroll
+  for (int c = 0; c < kMaxQ; ++c) rmax[c] = 0ull;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    const unsigned long long* row = part + (size_t)i * kClassifyRow;
+    umin = row[0] < umin ? row[0] : umin;
+    cS += (long long)row[1];
+    cU += (long long)row[2];
+#pragma unroll
+    for (int c = 0; c < kMaxQ; ++c) rmax[c] = row[3 + c] > rmax[c] ? row[3 + c] : rmax[c];
+  }
+  umin = block_ext_u64<false>(umin);
+  cS = block_sum_ll(cS);
+  cU = block_sum_ll(cU);
+#pragma unroll
+  for (int c = 1; c < kMaxQ; ++c)
+    if (c < q) rmax[c] = block_ext_u64<true>(rmax[c]);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sc->ustar_key = umin;
+    sc->count_S = cS;
+    sc->count_U = cU;
+#pragma unroll
+    for (int c = 1; c < kMaxQ; ++c) sc->rmax_key[c] = c < q ? rmax[c] : 0ull;
+  }
+  if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
+}
+
+// Mask-driven loops of K3b / K5.  A wave takes tiles of 512 consecutive candidates: every lane reads eight mask bytes
+// as one word, tiles without a set byte cost nothing more, and for the others the value loads (eight per lane, coalesced
+// across the wave, predicated on the candidate's own byte fetched by a shuffle) are all issued before the first
+// comparison.  The remainder (n mod 512, or everything when the mask is not 8-byte aligned) runs one candidate per lane.
+__device__ __forceinline__ bool tile_byte(unsigned long long w, int k, int lane) {
+  const unsigned long long wk = __shfl(w, k * 8 + (lane >> 3));
+  return ((wk >> (8 * (lane & 7))) & 0xffull) != 0ull;
 }
 
 // ---- K3b + K5: M mask and arg-max of var_0 over M -----------------------------------------------------
@@ -210,7 +259,44 @@ __global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, 
   const T ustar = (T)ord_val(sc->ustar_key);
   Best best{0.0, -1};
   long long cM = 0;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long ntiles = (((uintptr_t)S) & 7) == 0 ? n / 512 : 0;
+  for (long long t = wave; t < ntiles; t += nwaves) {
+    const long long base = t * 512;
+    const unsigned long long w = ((const unsigned long long*)(S + base))[lane];
+    if (__ballot(w != 0ull) == 0ull) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) M[base + k * 64 + lane] = 0;
+      continue;
+    }
+    T mu[8], va[8];
+    bool set[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      set[k] = tile_byte(w, k, lane);
+      const long long g = base + k * 64 + lane;
+      mu[k] = set[k] ? mean0[g] : (T)0;
+      va[k] = set[k] ? var0[g] : (T)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long long g = base + k * 64 + lane;
+      bool m = false;
+      if (set[k]) {
+        T lcb, ucb;
+        lcb_ucb(mu[k], va[k], b, lcb, ucb);
+        m = lcb <= ustar;                     // models/SafeOpt.py:62
+      }
+      M[g] = m;
+      if (m) {
+        ++cM;
+        const Best cand{(double)va[k], first + g};
+        if (better<true>(cand, best)) best = cand;
+      }
+    }
+  }
+  for (long long g = ntiles * 512 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
     bool m = false;
     if (S[g]) {
       T lcb, ucb;
@@ -228,17 +314,40 @@ __global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, 
   cM = block_sum_ll(cM);
   if (threadIdx.x == 0) {
     partial[blockIdx.x] = best;
-    if (cM) atomicAdd((unsigned long long*)&sc->count_M, (unsigned long long)cM);
+    ((long long*)(partial + gridDim.x))[blockIdx.x] = cM;   // summed by k_arg_final (an atomic per workgroup on one counter serialises)
   }
 }
 
 // generic masked arg-max / arg-min of a value array, plus the mask population
 template <typename T, bool MAX>
 __global__ __launch_bounds__(256) void k_arg_masked(const T* __restrict__ val, const uint8_t* __restrict__ mask, long long n,
-                                                    long long first, long long* count, Best* partial) {
+                                                    long long first, Best* partial) {
   Best best{0.0, -1};
   long long cnt = 0;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long ntiles = (((uintptr_t)mask) & 7) == 0 ? n / 512 : 0;
+  for (long long t = wave; t < ntiles; t += nwaves) {
+    const long long base = t * 512;
+    const unsigned long long w = ((const unsigned long long*)(mask + base))[lane];
+    if (__ballot(w != 0ull) == 0ull) continue;
+    T v[8];
+    bool set[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      set[k] = tile_byte(w, k, lane);
+      v[k] = set[k] ? val[base + k * 64 + lane] : (T)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (set[k]) {
+        ++cnt;
+        const Best cand{(double)v[k], first + base + k * 64 + lane};
+        if (better<MAX>(cand, best)) best = cand;
+      }
+    }
+  }
+  for (long long g = ntiles * 512 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
     if (mask[g]) {
       ++cnt;
       const Best cand{(double)val[g], first + g};
@@ -249,19 +358,27 @@ __global__ __launch_bounds__(256) void k_arg_masked(const T* __restrict__ val, c
   cnt = block_sum_ll(cnt);
   if (threadIdx.x == 0) {
     partial[blockIdx.x] = best;
-    if (cnt && count) atomicAdd((unsigned long long*)count, (unsigned long long)cnt);
+    ((long long*)(partial + gridDim.x))[blockIdx.x] = cnt;
   }
 }
 
+// partial: Best[nparts] followed by the workgroups' mask populations long long[nparts]; their sum is added to *count
 template <bool MAX>
-__global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ partial, int nparts, SweepScalars* sc, int slot) {
+__global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ partial, int nparts, SweepScalars* sc, int slot,
+                                                   long long* count) {
   Best best{0.0, -1};
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x)
+  long long cnt = 0;
+  const long long* pc = (const long long*)(partial + nparts);
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
     if (better<MAX>(partial[i], best)) best = partial[i];
+    cnt += pc[i];
+  }
   best = block_best<MAX>(best);
+  cnt = block_sum_ll(cnt);
   if (threadIdx.x == 0) {
     sc->arg_val[slot] = best.v;
     sc->arg_idx[slot] = best.i;
+    if (count) *count += cnt;
   }
 }
 
@@ -289,13 +406,15 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o) {
   if ((rc = ensure(c->maskG, (size_t)n * std::max(1, q - 1)))) return rc;
   if ((rc = ensure(c->scal, sizeof(SweepScalars)))) return rc;
   const int nb = reduce_blocks(c);
-  if ((rc = ensure(c->partial, sizeof(Best) * (size_t)nb))) return rc;
+  if ((rc = ensure(c->partial, (sizeof(Best) + sizeof(long long)) * (size_t)nb))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
-  hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(64), 0, c->stream, sc);
+  const int ncb = std::max(1, std::min(nb, c->n_cu * 2));
+  if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kClassifyRow * (size_t)ncb))) return rc;
   if (n > 0)
-    hipLaunchKernelGGL(k_classify<T>, dim3((unsigned)std::max(1, std::min(nb, c->n_cu * 2))), dim3(256), 0, c->stream,
-                       (const T*)c->mean.p, (const T*)c->var.p, n, q,
-                       (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, sc);
+    hipLaunchKernelGGL(k_classify<T>, dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
+                       (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
+  hipLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)c->cpart.p, n > 0 ? ncb : 0, q, sc);
+  c->amb_clean = true;
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
@@ -333,6 +452,14 @@ static int launch_exact_d(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lid
 static int sweep_exchange_wait(sbo_ctx* c);
 
 // G_c for constraint cidx (1..q-1) into G[n]
+static void launch_edt_axis0(sbo_ctx* c, const uint8_t* U, long long nlines, int count0, double h0, double* D) {
+  if (count0 <= kAxis0Max && count0 >= 128)
+    hipLaunchKernelGGL(k_edt_axis0_wg, dim3((unsigned)std::min<long long>(nlines, 1 << 20)), dim3(256), 0, c->stream, U, nlines, count0,
+                       h0, D);
+  else
+    hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, c->stream, U, nlines, count0, h0, D);
+}
+
 template <typename T>
 static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* G) {
   const long long n = c->cs.n_local;
@@ -345,7 +472,8 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
   const int nb = reduce_blocks(c);
   int rc;
   if ((rc = ensure(c->amb, sizeof(long long) * (size_t)n))) return rc;
-  hipLaunchKernelGGL(k_reset_amb, dim3(1), dim3(1), 0, c->stream, sc);
+  if (!c->amb_clean) hipLaunchKernelGGL(k_reset_amb, dim3(1), dim3(1), 0, c->stream, sc);   // (k_classify_final left the counters at zero)
+  c->amb_clean = false;
   const int d_ = c->cs.d;
   long long plane = 1;                       // candidates per step of the slowest axis
   for (int a = 0; a < d_ - 1; ++a) plane *= c->cs.count[a];
@@ -381,8 +509,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)nt))) return rc;
     const int count0 = d >= 2 ? (int)c->cs.count[0] : (int)nt;  // d == 1: the window is one line
     const long long nlines = nt / count0;
-    hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, c->stream, Uall, nlines, count0,
-                       c->cs.step[0], (double*)c->dist2.p);
+    launch_edt_axis0(c, Uall, nlines, count0, c->cs.step[0], (double*)c->dist2.p);
     double* din = (double*)c->dist2.p;
     double* dout = (double*)c->dist2b.p;
     long long stride = count0;
@@ -414,13 +541,11 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       double* dc0 = (double*)c->coarse.p;
       double* dc1 = dc0 + nc;
       uint8_t* Uc = (uint8_t*)(dc1 + nc);
-      SBO_HIP(hipMemsetAsync(Uc, 0, (size_t)nc, c->stream));
-      hipLaunchKernelGGL(k_coarsen_mask, dim3((unsigned)std::min<long long>((nt + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
-                         Uall, nt, cg, Uc);
+      hipLaunchKernelGGL(k_coarsen_mask, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
+                         Uall, cg, nc, Uc);
       const int cc0 = (int)cg.ccount[0];
       const long long clines = nc / cc0;
-      hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((clines + 3) / 4)), dim3(256), 0, c->stream, (const uint8_t*)Uc, clines, cc0,
-                         c->cs.step[0] * kCoarse, dc0);
+      launch_edt_axis0(c, (const uint8_t*)Uc, clines, cc0, c->cs.step[0] * kCoarse, dc0);
       long long cstride = cc0;
       for (int a = 1; a < d; ++a) {
         hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
@@ -441,7 +566,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       if (d >= 2 && last_cnt >= 4 * blk && c->scan_blocks) {
         const long long nb_ = (long long)((last_cnt + blk - 1) / blk) * stride;
         if ((rc = ensure(c->blockmin, sizeof(double) * (size_t)nb_))) return rc;
-        hipLaunchKernelGGL(k_block_min, dim3((unsigned)std::min<long long>((nb_ + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_block_min, dim3((unsigned)std::min<long long>((stride + 63) / 64 * ((last_cnt + blk - 1) / blk), 1 << 20)), dim3(256), 0, c->stream,
                            (const double*)din, stride, last_cnt, blk, (double*)c->blockmin.p);
         bmin = (const double*)c->blockmin.p;
       }
@@ -450,19 +575,27 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
         if ((rc = ensure(c->scanlist, sizeof(long long) * (size_t)n))) return rc;
         slist = (long long*)c->scanlist.p;
       }
-      hipLaunchKernelGGL((k_edt_decide<T>), dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0,
-                         c->stream, (const double*)din, n, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c,
+      const long long len0 = d >= 2 ? count0 : n;               // positions per line / local lines
+      const long long nl = n / len0;
+      hipLaunchKernelGGL((k_edt_decide<T>), dim3((unsigned)((len0 + 255) / 256), (unsigned)std::min<long long>((nl + kDecideLines - 1) / kDecideLines, 65535)), dim3(256), 0,
+                         c->stream, (const double*)din, nl, (int)len0, goff / len0, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c,
                          (T)o->b, (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
                          (long long*)c->amb.p, cg, bmin, blk, slist);
       if (slist) {
-        if (blk <= 32)
-          hipLaunchKernelGGL((k_edt_scan_list<T, 32>), dim3(2048), dim3(256), 0, c->stream, (const double*)din, goff, stride, last_cnt,
-                             last_h, d, xscale, mean_c, var_c, (T)o->b, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
-                             (long long*)c->amb.p, bmin, blk, (const long long*)slist);
-        else
-          hipLaunchKernelGGL((k_edt_scan_list<T, 64>), dim3(2048), dim3(256), 0, c->stream, (const double*)din, goff, stride, last_cnt,
-                             last_h, d, xscale, mean_c, var_c, (T)o->b, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
-                             (long long*)c->amb.p, bmin, blk, (const long long*)slist);
+        // lanes per listed candidate: 16 by default (more candidates in flight beat shorter rounds: 53 k open candidates
+        // of config B take 19 us with 16 lanes, 32 us with 32), never more than a wave, 64 for 64-step blocks on request
+        const int gl = c->scan_waves == 8 || c->scan_waves == 32 || c->scan_waves == 64 ? c->scan_waves : 16;
+#define SBO_SCAN_LIST(GL)                                                                                                       \
+  hipLaunchKernelGGL((k_edt_scan_list<T, GL>), dim3(2048), dim3(256), 0, c->stream, (const double*)din, goff, stride, last_cnt, \
+                     last_h, d, xscale, mean_c, var_c, (T)o->b, (const unsigned long long*)c->Lmax.p, lidx, sc, G,              \
+                     (long long*)c->amb.p, bmin, blk, (const long long*)slist)
+        switch (gl) {
+          case 8: SBO_SCAN_LIST(8); break;
+          case 32: SBO_SCAN_LIST(32); break;
+          case 64: SBO_SCAN_LIST(64); break;
+          default: SBO_SCAN_LIST(16); break;
+        }
+#undef SBO_SCAN_LIST
       }
     }
   } else {
@@ -558,11 +691,17 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
                                hipEvent_t done_ev = nullptr) {
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   // (the Lipschitz keys ride in the same read-back: one synchronisation per sweep)
-  if (Lk) SBO_HIP(hipMemcpyAsync(Lk, c->Lmax.p, sizeof(unsigned long long) * kMaxQ, hipMemcpyDeviceToHost, c->stream));
+  // (pinned landing area: pageable destinations are staged by the runtime, ~20 us per copy)
+  // (the Lipschitz keys live 2 KB into the same allocation: sbo_create)
+  static_assert(sizeof(SweepScalars) <= 2048 && sizeof(unsigned long long) * kMaxQ <= 2048, "read-back area");
+  constexpr size_t kBack = 2048 + sizeof(unsigned long long) * kMaxQ;
+  const unsigned long long* Lk_pinned = (const unsigned long long*)(c->h_back + 2048);
   if (c->world <= 1) {
-    SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    SBO_HIP(hipMemcpyAsync(c->h_back, sc, kBack, hipMemcpyDeviceToHost, c->stream));
     if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
     SBO_HIP(hipStreamSynchronize(c->stream));
+    memcpy(&h, c->h_back, sizeof(h));
+    if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
     return SBO_OK;
   }
   double* buf = (double*)c->xch.p + 64;
@@ -570,10 +709,12 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   int rc;
   if ((rc = comm_allreduce_sum_f64(c, buf, c->world * kC3Row))) return rc;
   std::vector<double> rows((size_t)c->world * kC3Row);
-  SBO_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipMemcpyAsync(c->h_back, sc, kBack, hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipMemcpyAsync(rows.data(), buf, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, c->stream));
   if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
+  memcpy(&h, c->h_back, sizeof(h));
+  if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
   c->c1_pending = false;                       // (the whole stream has drained)
   h.count_S = h.count_U = h.count_M = h.n_amb_total = 0;
   for (int t = 0; t < kMaxQ; ++t) h.count_set[t] = 0;
@@ -614,20 +755,21 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
     hipLaunchKernelGGL((k_minimizer<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n,
                        (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, sc,
                        (Best*)c->partial.p);
-  hipLaunchKernelGGL((k_arg_final<true>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0);
-  SBO_HIP(hipEventRecord(c->ev[2], c->stream));
+  hipLaunchKernelGGL((k_arg_final<true>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0,
+                     &sc->count_M);
+  if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
   for (int cc = 1; cc < q; ++cc) {
     uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
     if ((rc = expander_set<T>(c, o, cc, G))) return rc;
   }
-  SBO_HIP(hipEventRecord(c->ev[3], c->stream));
+  if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   for (int cc = 1; cc < q; ++cc) {
     const uint8_t* G = (const uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
     if (n > 0)
       hipLaunchKernelGGL((k_arg_masked<T, true>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->var.p, G, n,
-                         (long long)c->cs.first, &sc->count_set[cc - 1], (Best*)c->partial.p);
+                         (long long)c->cs.first, (Best*)c->partial.p);
     hipLaunchKernelGGL((k_arg_final<true>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0,
-                       sc, cc);
+                       sc, cc, &sc->count_set[cc - 1]);
   }
   SBO_HIP(hipGetLastError());
   SweepScalars h;
@@ -637,12 +779,15 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   if ((rc = sweep_exchange_back(c, h, is_max, Lk, c->ev[4]))) return rc;
   c->masks_valid = true;
   c->last_sweep = 1;
+  if (getenv("SBO_DEBUG_SCAN")) fprintf(stderr, "[safebo] open candidates scanned (last constraint) %lld, exact rechecks %lld\n", h.n_scan, h.n_amb_total);
 
   float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t04 = 0;
   SBO_HIP(hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
-  SBO_HIP(hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
-  SBO_HIP(hipEventElapsedTime(&t23, c->ev[2], c->ev[3]));
-  SBO_HIP(hipEventElapsedTime(&t34, c->ev[3], c->ev[4]));
+  if (c->phase_events) {
+    SBO_HIP(hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
+    SBO_HIP(hipEventElapsedTime(&t23, c->ev[2], c->ev[3]));
+    SBO_HIP(hipEventElapsedTime(&t34, c->ev[3], c->ev[4]));
+  }
   SBO_HIP(hipEventElapsedTime(&t04, c->ev[0], c->ev[4]));
   memset(&c->prof, 0, sizeof(c->prof));
   c->prof.posterior_ms = t01;
@@ -800,7 +945,8 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     for (int a = 0; a < d; ++a) xscale = std::max(xscale, std::max(std::fabs(c->cs.lo[a]), std::fabs(c->cs.hi[a])));
     const int count0 = d >= 2 ? (int)c->cs.count[0] : (int)nt;
     const unsigned gridn = (unsigned)std::min<long long>((nt + 255) / 256, 1 << 20);
-    hipLaunchKernelGGL(k_reset_amb, dim3(1), dim3(1), 0, c->stream, sc);
+    if (!c->amb_clean) hipLaunchKernelGGL(k_reset_amb, dim3(1), dim3(1), 0, c->stream, sc);
+    c->amb_clean = false;
     // coarse bounds of the window: decide most candidates (and skip their axis-0 scans) without touching the fine arrays
     CoarseGrid cg;
     memset(&cg, 0, sizeof(cg));
@@ -875,7 +1021,7 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     if (d >= 2 && last_cnt >= 4 * blk && c->scan_blocks) {
       const long long nb_ = (long long)((last_cnt + blk - 1) / blk) * stride;
       if ((rc = ensure(c->blockmin, sizeof(double) * (size_t)nb_))) return rc;
-      hipLaunchKernelGGL(k_block_min, dim3((unsigned)std::min<long long>((nb_ + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+      hipLaunchKernelGGL(k_block_min, dim3((unsigned)std::min<long long>((stride + 63) / 64 * ((last_cnt + blk - 1) / blk), 1 << 20)), dim3(256), 0, c->stream,
                          (const double*)pin, stride, last_cnt, blk, (double*)c->blockmin.p);
       bmin = (const double*)c->blockmin.p;
     }
@@ -940,7 +1086,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   if ((rc = ensure(c->maskO, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
-  SBO_HIP(hipEventRecord(c->ev[2], c->stream));
+  if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
   // Only expanders can cover an unsafe point: "g covers h" is the predicate that puts g into G_c.  So G_c is built
   // first (distance transform, cheap) and serves as the source set of the coverage search instead of all of S_t.
   if ((rc = ensure(c->maskG, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
@@ -958,22 +1104,23 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     }
     if ((rc = goose_sets_d<T>(c, o, cc, src, O))) return rc;
   }
-  SBO_HIP(hipEventRecord(c->ev[3], c->stream));
+  if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   // value array for the arg-min reductions (after the expander transform, which uses the same scratch buffer)
   if ((rc = ensure(c->dist2, sizeof(double) * (size_t)std::max<long long>(n, 1)))) return rc;
   T* lcb0 = (T*)c->dist2.p;
   if (n > 0) {
     hipLaunchKernelGGL((k_lcb0<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b, lcb0);
     hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
-                       (long long)c->cs.first, (long long*)nullptr, (Best*)c->partial.p);
+                       (long long)c->cs.first, (Best*)c->partial.p);
   }
-  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0);
+  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0, (long long*)nullptr);
   for (int cc = 1; cc < q; ++cc) {
     const uint8_t* O = (const uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
     if (n > 0)
       hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, O, n,
-                         (long long)c->cs.first, &sc->count_set[cc - 1], (Best*)c->partial.p);
-    hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, cc);
+                         (long long)c->cs.first, (Best*)c->partial.p);
+    hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, cc,
+                       &sc->count_set[cc - 1]);
   }
   SBO_HIP(hipGetLastError());
   SweepScalars h;
@@ -1021,10 +1168,10 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     if (n > 0) {
       if ((rc = launch_dist_to<T>(c, dev_t, lcb0))) return rc;
       hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
-                         (long long)c->cs.first, (long long*)nullptr, (Best*)c->partial.p);
+                         (long long)c->cs.first, (Best*)c->partial.p);
     }
     hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
-                       kArgSlots - 1);
+                       kArgSlots - 1, (long long*)nullptr);
     SweepScalars h2;
     if ((rc = sweep_exchange_back(c, h2, is_max))) return rc;
     res->explore_index = h2.arg_idx[kArgSlots - 1];
@@ -1034,9 +1181,11 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   SBO_HIP(hipEventSynchronize(c->ev[4]));
   float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t04 = 0;
   SBO_HIP(hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
-  SBO_HIP(hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
-  SBO_HIP(hipEventElapsedTime(&t23, c->ev[2], c->ev[3]));
-  SBO_HIP(hipEventElapsedTime(&t34, c->ev[3], c->ev[4]));
+  if (c->phase_events) {
+    SBO_HIP(hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
+    SBO_HIP(hipEventElapsedTime(&t23, c->ev[2], c->ev[3]));
+    SBO_HIP(hipEventElapsedTime(&t34, c->ev[3], c->ev[4]));
+  }
   SBO_HIP(hipEventElapsedTime(&t04, c->ev[0], c->ev[4]));
   memset(&c->prof, 0, sizeof(c->prof));
   c->prof.posterior_ms = t01;
@@ -1075,9 +1224,9 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
       default: hipLaunchKernelGGL((k_ball_mask<8>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, (const uint8_t*)c->maskS.p, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
     }
     hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskM.p, n,
-                       (long long)c->cs.first, &sc->count_M, (Best*)c->partial.p);
+                       (long long)c->cs.first, (Best*)c->partial.p);
   }
-  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0);
+  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0, &sc->count_M);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];

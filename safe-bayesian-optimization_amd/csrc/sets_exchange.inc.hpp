@@ -61,11 +61,4 @@ __global__ void k_pack_c3(const SweepScalars* sc, double* buf, int world, int ra
   }
   if (t < kMaxQ) row[2 * kArgSlots + 4 + t] = (double)sc->count_set[t];
 }
-__global__ void k_init_scalars(SweepScalars* sc) {
-  unsigned long long* w = reinterpret_cast<unsigned long long*>(sc);       // (the struct is a multiple of 8 bytes)
-  for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) w[i] = 0ull;
-  __syncthreads();
-  if (threadIdx.x == 0) sc->ustar_key = ~0ull;
-  if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
-}
 

@@ -44,23 +44,104 @@ __global__ __launch_bounds__(256) void k_edt_axis0(const uint8_t* __restrict__ U
   }
 }
 
+// axis 0, one workgroup per grid line (count0 <= kAxis0Max): the line's bits go to LDS as 64-bit words (one ballot per
+// wave and chunk), waves 0 and 1 scan the words for the nearest set bit before / after every word, and every element
+// then finds its neighbours from its own word and the two carries -- no serial chain along the line, the mask is read
+// once and the squared distance written once (same arithmetic as k_edt_axis0: (h0 t)^2 with t the step count).
+constexpr int kAxis0Max = 65536;
+__global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
+                                                      double* __restrict__ D) {
+  __shared__ unsigned long long words[kAxis0Max / 64];
+  __shared__ int lastw[kAxis0Max / 64];    // index of the last set bit in words 0..w (-1: none)
+  __shared__ int firstw[kAxis0Max / 64];   // index of the first set bit in words w.. (INT_MAX: none)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwords = (count0 + 63) >> 6;
+  constexpr int kNone = 0x7fffffff;
+  for (long long line = blockIdx.x; line < nlines; line += gridDim.x) {
+    const uint8_t* u = U + line * count0;
+    double* d = D + line * count0;
+    for (int w = wave; w < nwords; w += 4) {
+      const int i = w * 64 + lane;
+      const unsigned long long m = __ballot(i < count0 && u[i]);
+      if (lane == 0) words[w] = m;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      int carry = -1;
+      for (int base = 0; base < nwords; base += 64) {
+        const int w = base + lane;
+        const unsigned long long m = w < nwords ? words[w] : 0ull;
+        int v = m ? w * 64 + (63 - __clzll((long long)m)) : -1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o && t > v) v = t; }
+        v = v > carry ? v : carry;
+        if (w < nwords) lastw[w] = v;
+        carry = __shfl(v, 63);
+      }
+    } else if (wave == 1) {
+      int carry = kNone;
+      for (int base = 0; base < nwords; base += 64) {
+        const int w = nwords - 1 - (base + lane);
+        const unsigned long long m = w >= 0 ? words[w] : 0ull;
+        int v = m ? w * 64 + (__ffsll((long long)m) - 1) : kNone;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o && t < v) v = t; }
+        v = v < carry ? v : carry;
+        if (w >= 0) firstw[w] = v;
+        carry = __shfl(v, 63);
+      }
+    }
+    __syncthreads();
+    for (int w = wave; w < nwords; w += 4) {
+      const int i = w * 64 + lane;
+      const unsigned long long m = words[w];
+      const unsigned long long lower = m & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+      const unsigned long long upper = m >> lane;
+      const int li = lower ? w * 64 + (63 - __clzll((long long)lower)) : (w > 0 ? lastw[w - 1] : -1);
+      const int ri = upper ? i + (__ffsll((long long)upper) - 1) : (w + 1 < nwords ? firstw[w + 1] : kNone);
+      if (i < count0) {
+        int t = -1;
+        if (li >= 0) t = i - li;
+        if (ri != kNone && (t < 0 || ri - i < t)) t = ri - i;
+        double v = kInfD;
+        if (t >= 0) {
+          const double dt = h0 * (double)t;
+          v = dt * dt;
+        }
+        d[i] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // axes >= 1: D_out[g] = min_t D_in[g + t stride] + (h t)^2, searched outwards with the two exits
 //   (h t)^2 >= best  (nothing further can improve)  and  h t > cap  (beyond any radius that matters).
 // `accept2`: once best <= accept2 the caller's decision is already "within the radius" and a smaller minimum cannot
 // change it, so the search stops (pass -1 to get the exact minimum).
 __device__ __forceinline__ double edt_scan_point(const double* __restrict__ Din, long long g, long long stride, int cnt,
                                                  int ia, double h, double cap, double accept2 = -1.0) {
+  // Four steps (eight loads) are issued per round of exit tests: the serial chain of the search is what a thread
+  // waits for, and a step examined beyond an exit cannot lower the minimum (its candidate is >= (h t)^2 >= best; steps
+  // beyond the cap are masked as before).
   double best = Din[g];
-  for (int t = 1; t < cnt; ++t) {
+  for (int t = 1; t < cnt; t += 4) {
     const double dt = h * (double)t;
-    const double e = dt * dt;
-    if (e >= best || dt > cap || best <= accept2) break;
-    const bool lo_ok = ia - t >= 0, hi_ok = ia + t < cnt;
-    if (!lo_ok && !hi_ok) break;
-    const double c1 = lo_ok ? Din[g - (long long)t * stride] : kInfD;
-    const double c2 = hi_ok ? Din[g + (long long)t * stride] : kInfD;
-    const double c = (c1 < c2 ? c1 : c2) + e;
-    best = c < best ? c : best;
+    if (dt * dt >= best || dt > cap || best <= accept2) break;
+    if (ia - t < 0 && ia + t >= cnt) break;
+    double c1[4], c2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tt = t + u;
+      c1[u] = ia - tt >= 0 ? Din[g - (long long)tt * stride] : kInfD;
+      c2[u] = ia + tt < cnt ? Din[g + (long long)tt * stride] : kInfD;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double du = h * (double)(t + u);
+      const double c = (c1[u] < c2[u] ? c1[u] : c2[u]) + du * du;
+      if (du <= cap && c < best) best = c;
+    }
   }
   return best;
 }
@@ -72,18 +153,34 @@ __device__ __forceinline__ double edt_scan_point(const double* __restrict__ Din,
 // O(sqrt(radius in steps)) when the grid is much finer along the last axis than the radius (weak-scaling grids).
 __global__ __launch_bounds__(256) void k_block_min(const double* __restrict__ Din, long long stride, int cnt, int blk,
                                                    double* __restrict__ Bmin) {
+  // 64 in-plane positions x 4 quarters of a block per workgroup: a thread takes blk / 4 steps (all loads in flight),
+  // the quarters meet in LDS
+  __shared__ double part[4][64];
   const int nblk = (cnt + blk - 1) / blk;
-  const long long total = (long long)nblk * stride;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long p = i % stride;
-    const int b = (int)(i / stride);
-    const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
+  const int px = threadIdx.x & 63, sub = threadIdx.x >> 6, per = (blk + 3) / 4;
+  const long long ptiles = (stride + 63) / 64, total = ptiles * nblk;
+  for (long long w = blockIdx.x; w < total; w += gridDim.x) {
+    const long long p = (w % ptiles) * 64 + px;
+    const int b = (int)(w / ptiles);
+    const int j0 = b * blk + sub * per;
+    const int jend = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
+    const int j1 = j0 + per < jend ? j0 + per : jend;
     double m = kInfD;
-    for (int j = b * blk; j < j1; ++j) {
-      const double v = Din[(long long)j * stride + p];
-      m = v < m ? v : m;
+    if (p < stride) {
+#pragma unroll 8
+      for (int j = j0; j < j1; ++j) {
+        const double v = Din[(long long)j * stride + p];
+        m = v < m ? v : m;
+      }
     }
-    Bmin[i] = m;
+    part[sub][px] = m;
+    __syncthreads();
+    if (sub == 0 && p < stride) {
+      const double a = part[0][px] < part[1][px] ? part[0][px] : part[1][px];
+      const double c = part[2][px] < part[3][px] ? part[2][px] : part[3][px];
+      Bmin[(long long)b * stride + p] = a < c ? a : c;
+    }
+    __syncthreads();
   }
 }
 
@@ -188,6 +285,7 @@ __global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din
 // (dC = distance between cell origins to the nearest U-holding cell).  Candidates whose verdict is the same at both
 // ends skip the per-candidate scan of the fine transform; only the shell around the boundary of G_c scans.
 constexpr int kCoarse = 8;
+constexpr int kDecideLines = 8;   // lines per workgroup of k_edt_decide
 struct CoarseGrid {
   int enabled;
   int d;
@@ -197,30 +295,36 @@ struct CoarseGrid {
   const double* Dc;          // squared coarse distances [prod ccount]
 };
 
-__global__ __launch_bounds__(256) void k_coarsen_mask(const uint8_t* __restrict__ U, long long n, const CoarseGrid cg,
+// one thread per coarse cell: OR of the U bytes of its kCoarse^d candidates (lines of <= kCoarse bytes along axis 0)
+__global__ __launch_bounds__(256) void k_coarsen_mask(const uint8_t* __restrict__ U, const CoarseGrid cg, long long ncells,
                                                       uint8_t* __restrict__ Uc) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    if (!U[g]) continue;
-    long long f = g, cell = 0, cs = 1;
+  for (long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x; cell < ncells; cell += (long long)gridDim.x * blockDim.x) {
+    long long f = cell, i0[kMaxD], len[kMaxD], fstride[kMaxD], nsub = 1, fs = 1;
     for (int a = 0; a < cg.d; ++a) {
-      const long long i = f % cg.count[a];
-      f /= cg.count[a];
-      cell += (i / kCoarse) * cs;
-      cs *= cg.ccount[a];
+      const long long ca = f % cg.ccount[a];
+      f /= cg.ccount[a];
+      i0[a] = ca * kCoarse;
+      len[a] = cg.count[a] - i0[a] < kCoarse ? cg.count[a] - i0[a] : kCoarse;
+      fstride[a] = fs;
+      fs *= cg.count[a];
+      if (a > 0) nsub *= len[a];
     }
-    Uc[cell] = 1;   // idempotent store
+    bool any = false;
+    for (long long sline = 0; sline < nsub && !any; ++sline) {
+      long long r = sline, base = i0[0];
+      for (int a = 1; a < cg.d; ++a) {
+        base += (i0[a] + r % len[a]) * fstride[a];
+        r /= len[a];
+      }
+      const uint8_t* u = U + base;
+      if (len[0] == 8 && ((uintptr_t)u & 7) == 0) {
+        any = *(const unsigned long long*)u != 0ull;
+      } else {
+        for (int k = 0; k < (int)len[0]; ++k) any = any || u[k];
+      }
+    }
+    Uc[cell] = any ? 1 : 0;
   }
-}
-
-__device__ __forceinline__ double coarse_dist2(const CoarseGrid& cg, long long gg) {
-  long long f = gg, cell = 0, cs = 1;
-  for (int a = 0; a < cg.d; ++a) {
-    const long long i = f % cg.count[a];
-    f /= cg.count[a];
-    cell += (i / kCoarse) * cs;
-    cs *= cg.ccount[a];
-  }
-  return cg.Dc[cell];
 }
 
 // Reference expression for one (g, h) pair, unfused, in the oracle's order:
@@ -242,8 +346,8 @@ __device__ __forceinline__ bool lipschitz_pair(const double (&xg)[D], const doub
 // last axis + decision.  For g in S: nearest-U distance dm (unshifted) -> G bit, or the ambiguous list when
 // ucb - L dm lies inside the band the "+1e-8" shift and rounding can move it across zero.
 template <typename T>
-__global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ Din, long long n, long long goff,
-                                                    long long stride, int cnt,
+__global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ Din, long long nl, int len0, long long line0,
+                                                    long long goff, long long stride, int cnt,
                                                     double h, int d, double xscale, const T* __restrict__ mean_c,
                                                     const T* __restrict__ var_c, T b, const uint8_t* __restrict__ S,
                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
@@ -252,7 +356,21 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
                                                     long long* __restrict__ scanlist) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const bool anyU = sc->count_U > 0;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+  // launch: x over the positions of a grid line (len0 = count0; the whole range when d == 1), y over blocks of
+  // kDecideLines local lines -- the line index is uniform per workgroup and a 2-D grid needs no division to split a
+  // candidate index.  Open candidates are collected in LDS and appended to the scan list with one atomic per
+  // workgroup (one per wave on a single counter serialises in L2).
+  __shared__ long long sl[256 * kDecideLines];
+  __shared__ int scnt;
+  __shared__ long long sbase;
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i0 < len0;
+  const long long nlb = (nl + kDecideLines - 1) / kDecideLines;
+  for (long long lb = blockIdx.y; lb < nlb; lb += gridDim.y) {
+  if (threadIdx.x == 0) scnt = 0;
+  __syncthreads();
+  for (long long ln = lb * kDecideLines; active && ln < nl && ln < (lb + 1) * kDecideLines; ++ln) {
+    const long long g = ln * len0 + i0;
     uint8_t out = 0;
     if (S[g] && anyU) {
       T lcb, ucbT;
@@ -264,8 +382,17 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
         const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
         const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
         const long long gg = goff + g;   // index in the transform (whole grid when ranks share it)
+        long long f = line0 + ln, cell = i0 / kCoarse, ccs = cg.ccount[0];
+        int ia = 0;                      // index along the last axis (inside the window)
+        for (int a = 1; a < d; ++a) {
+          const long long ix = a == d - 1 ? f : f % cg.count[a];
+          f = a == d - 1 ? 0 : f / cg.count[a];
+          cell += (ix / kCoarse) * ccs;
+          ccs *= cg.ccount[a];
+          ia = (int)ix;
+        }
         if (cg.enabled) {
-          const double dC = sqrt(coarse_dist2(cg, gg));
+          const double dC = sqrt(cg.Dc[cell]);
           const double dhi = dC * (1.0 + 1e-9) + cg.delta, dlo = fmax(0.0, dC * (1.0 - 1e-9) - cg.delta);
           const double tolc = 1e-12 * (fabs(ucb) + L * dhi);
           if (ucb - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { G[g] = 1; continue; }     // within the radius for sure
@@ -274,15 +401,14 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
         if (scanlist && Bmin && cnt > 1) {
           // the few candidates the coarse bounds leave open go to k_edt_scan_list (one wave each): a lane scanning
           // here would hold its whole wave for a chain of ~100 dependent loads
-          scanlist[atomicAdd((unsigned long long*)&sc->n_scan, 1ull)] = g;
+          sl[atomicAdd(&scnt, 1)] = g;
           G[g] = 0;
           continue;
         }
-        const int ia = (int)((gg / stride) % cnt);
         const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it the verdict is "sure true"
         const double acc2 = thr > 0 ? thr * thr : -1.0;
         const double best = cnt <= 1 ? Din[gg]
-                            : Bmin  ? edt_scan_blocked(Din, Bmin, gg % stride, stride, cnt, ia, h, cap, acc2, blk)
+                            : Bmin  ? edt_scan_blocked(Din, Bmin, gg - (long long)ia * stride, stride, cnt, ia, h, cap, acc2, blk)
                                     : edt_scan_point(Din, gg, stride, cnt, ia, h, cap, acc2);
         if (best < 0.5 * kInfD) {
           const double dm = sqrt(best);
@@ -298,6 +424,15 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
       }
     }
     G[g] = out;
+  }
+  __syncthreads();
+  const int cntl = scnt;
+  if (cntl > 0) {
+    if (threadIdx.x == 0) sbase = (long long)atomicAdd((unsigned long long*)&sc->n_scan, (unsigned long long)cntl);
+    __syncthreads();
+    for (int k = threadIdx.x; k < cntl; k += blockDim.x) scanlist[sbase + k] = sl[k];
+  }
+  __syncthreads();
   }
 }
 
@@ -325,7 +460,7 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict_
   };
   auto group_ballot = [&](bool pred) {
     const unsigned long long m = __ballot(pred);
-    return GL == 64 ? m : ((m >> (32 * sub)) & 0xffffffffull);
+    return GL == 64 ? m : ((m >> (GL * sub)) & ((1ull << GL) - 1ull));
   };
   for (long long qi = (long long)blockIdx.x * (blockDim.x / GL) + threadIdx.x / GL; qi < nscan; qi += ngroups) {
     const long long g = scanlist[qi];
@@ -349,12 +484,18 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict_
       if (dg > cap) return kInfD;
       return Bmin[(long long)bb * stride + p] + dg * dg;
     };
-    auto scan_block = [&](int bb) {     // the group: the (<= GL) steps of block bb
-      const int jn = bb * blk + lane;
+    auto scan_block = [&](int bb) {     // the group: the steps of block bb, GL at a time (loads of all rounds in flight)
       double cnd = kInfD;
-      if (lane < blk && jn < cnt) {
-        const double dt = h * (double)(jn > ia ? jn - ia : ia - jn);
-        if (dt <= cap) cnd = Din[(long long)jn * stride + p] + dt * dt;
+#pragma unroll 4
+      for (int s0 = 0; s0 < blk; s0 += GL) {
+        const int jn = bb * blk + s0 + lane;
+        if (s0 + lane < blk && jn < cnt) {
+          const double dt = h * (double)(jn > ia ? jn - ia : ia - jn);
+          if (dt <= cap) {
+            const double v = Din[(long long)jn * stride + p] + dt * dt;
+            cnd = v < cnd ? v : cnd;
+          }
+        }
       }
       cnd = group_min(cnd);
       best = cnd < best ? cnd : best;
