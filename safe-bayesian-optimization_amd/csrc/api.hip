@@ -106,11 +106,13 @@ int sbo_init(int device_id, sbo_ctx** out) {
     delete c;
     return fail(SBO_E_HIP, "hipHostMalloc");
   }
-  // the sweep's scalar block and, 2 KB further, the Lipschitz keys: one allocation, so one read-back covers both
+  // the sweep's scalar block and, 3 KB further, the Lipschitz keys: one allocation, so one read-back covers both
+  // (layout of the 4 KB: SweepScalars at 0, the explore target / trust-region centre at 2048, the keys at 3072, a
+  // collective's scratch word at 4000)
   int rc = ensure(c->scal, 4096);
   if (rc) { delete c; return rc; }
-  c->Lmax.p = (char*)c->scal.p + 2048;   // (a view: not in the release list)
-  c->Lmax.bytes = 2048;
+  c->Lmax.p = (char*)c->scal.p + 3072;   // (a view: not in the release list)
+  c->Lmax.bytes = 512;
   *out = c;
   return SBO_OK;
 }

@@ -692,10 +692,10 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   // (the Lipschitz keys ride in the same read-back: one synchronisation per sweep)
   // (pinned landing area: pageable destinations are staged by the runtime, ~20 us per copy)
-  // (the Lipschitz keys live 2 KB into the same allocation: sbo_create)
-  static_assert(sizeof(SweepScalars) <= 2048 && sizeof(unsigned long long) * kMaxQ <= 2048, "read-back area");
-  constexpr size_t kBack = 2048 + sizeof(unsigned long long) * kMaxQ;
-  const unsigned long long* Lk_pinned = (const unsigned long long*)(c->h_back + 2048);
+  // (the Lipschitz keys live 3 KB into the same allocation: sbo_create)
+  static_assert(sizeof(SweepScalars) <= 2048 && sizeof(unsigned long long) * kMaxQ <= 512, "read-back area");
+  constexpr size_t kBack = 3072 + sizeof(unsigned long long) * kMaxQ;
+  const unsigned long long* Lk_pinned = (const unsigned long long*)(c->h_back + 3072);
   if (c->world <= 1) {
     SBO_HIP(hipMemcpyAsync(c->h_back, sc, kBack, hipMemcpyDeviceToHost, c->stream));
     if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));

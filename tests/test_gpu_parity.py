@@ -662,6 +662,31 @@ def test_goose_transform_equals_pair_evaluation_with_coarse_bounds(engine, cfg_n
             assert bool(O[hidx]) == want, (c, int(hidx))
 
 
+def test_repeated_sweeps_on_a_resident_posterior_are_idempotent(engine):
+    """The host classes call several sweeps per iteration on one posterior (`posterior_ready=True`): SafeOpt, GoOSE
+    (whose explore step parks its target next to the sweep scalars) and the trust-region step, in any order, must
+    leave the resident state (posterior, Lipschitz keys) untouched -- every repetition returns the same answer."""
+    cfg = synthetic.make_config("B", n=64)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, [320, 288])
+    engine.posterior_run()
+    first = {}
+    for rep in range(3):
+        s = engine.sweep_safeopt(cfg["b"], posterior_ready=True)
+        g = engine.sweep_goose(cfg["b"], posterior_ready=True, want_masks=True)
+        O = engine.mask("O", 1)
+        t = engine.sweep_tr(cfg["b"], np.array([1.2, -0.6]), 0.4, posterior_ready=True)
+        got = dict(s_min=s["minimizer_index"], s_exp=list(s["expander_index_c"]), s_cnt=[s["count_S"], s["count_M"]] + list(s["count_G"]),
+                   s_L=list(s["L"]), g_idx=(g["safe_min_index"], g["target_index"], g["explore_index"]), g_cnt=list(g["count_O"]),
+                   g_L=list(g["L"]), O=O, t_idx=t["index"], t_cnt=(t["count_S"], t["count_T"]))
+        if rep == 0:
+            first = got
+            continue
+        for k, v in got.items():
+            assert np.array_equal(np.asarray(v), np.asarray(first[k])), (rep, k)
+
+
 # ---------------------------------------------------------------------------------------------- two ranks, one GPU
 def _free_port():
     with socket.socket() as s:
