@@ -1025,8 +1025,9 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
                          (const double*)pin, stride, last_cnt, blk, (double*)c->blockmin.p);
       bmin = (const double*)c->blockmin.p;
     }
-    hipLaunchKernelGGL(k_pdt_decide, dim3((unsigned)std::min<long long>((n + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
-                       (const double*)pin, n, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, (const uint8_t*)c->maskU.p,
+    const long long len0 = d >= 2 ? count0 : n, nl = n / len0;    // positions per line / local lines
+    hipLaunchKernelGGL(k_pdt_decide, dim3((unsigned)((len0 + 255) / 256), (unsigned)std::min<long long>(nl, 65535)), dim3(256), 0, c->stream,
+                       (const double*)pin, nl, (int)len0, goff / len0, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, (const uint8_t*)c->maskU.p,
                        (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, O, (long long*)c->amb.p, cg, pc_lo, pc_hi, bmin, blk);
     hipLaunchKernelGGL((k_goose_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, css, W,
                        (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, (const long long*)c->amb.p, O);
@@ -1126,10 +1127,26 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   SweepScalars h;
   bool is_max[kArgSlots];
   for (int t = 0; t < kArgSlots; ++t) is_max[t] = false;
-  if ((rc = sweep_exchange_back(c, h, is_max))) return rc;
+  // Single rank: the explore step (target choice, distances, arg-min over S) is enqueued before the read-back, one host
+  // round trip per sweep; ranks > 1 need the merged target slots first and take a second one below.
+  const bool fused_explore = c->world <= 1 && q > 1;
+  double* dev_t = (double*)c->scal.p + 256;
+  if (fused_explore) {
+    switch (c->mc.dpad) {
+      case 2: hipLaunchKernelGGL((k_pick_target<2>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
+      case 4: hipLaunchKernelGGL((k_pick_target<4>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
+      default: hipLaunchKernelGGL((k_pick_target<8>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
+    }
+    if (n > 0) {
+      if ((rc = launch_dist_to<T>(c, dev_t, lcb0))) return rc;
+      hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
+                         (long long)c->cs.first, (Best*)c->partial.p);
+    }
+    hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
+                       kArgSlots - 1, (long long*)nullptr);
+  }
   unsigned long long Lk[kMaxQ];
-  SBO_HIP(hipMemcpyAsync(Lk, c->Lmax.p, sizeof(Lk), hipMemcpyDeviceToHost, c->stream));
-  SBO_HIP(hipStreamSynchronize(c->stream));
+  if ((rc = sweep_exchange_back(c, h, is_max, Lk))) return rc;
   c->masks_valid = true;
   c->last_sweep = 2;
 
@@ -1163,7 +1180,10 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     res->target_index = res->target_index_c[best_c - 1];
     coords_of(c, res->target_index, res->target_x);
     // explore_safeset(target): argmin_{S} ||x - target||_2 (models/GoOSE.py:116-119)
-    double* dev_t = (double*)c->scal.p + 256;
+    if (fused_explore) {
+      res->explore_index = h.arg_idx[kArgSlots - 1];
+      coords_of(c, res->explore_index, res->explore_x);
+    } else {
     SBO_HIP(hipMemcpyAsync(dev_t, res->target_x, sizeof(double) * SBO_MAX_D, hipMemcpyHostToDevice, c->stream));
     if (n > 0) {
       if ((rc = launch_dist_to<T>(c, dev_t, lcb0))) return rc;
@@ -1176,6 +1196,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     if ((rc = sweep_exchange_back(c, h2, is_max))) return rc;
     res->explore_index = h2.arg_idx[kArgSlots - 1];
     coords_of(c, res->explore_index, res->explore_x);
+    }
   }
   SBO_HIP(hipEventRecord(c->ev[4], c->stream));
   SBO_HIP(hipEventSynchronize(c->ev[4]));

@@ -226,14 +226,18 @@ __global__ __launch_bounds__(256) void k_pdt_cell_min(const T* __restrict__ W, c
       total *= len[a];
     }
     double wmax = -1.0;
-    for (long long t = 0; t < total; ++t) {
-      long long u = t, g = origin;
-      for (int a = 0; a < cg.d; ++a) {
+    const long long nsub = total / len[0];             // lines of <= kCoarse consecutive candidates along axis 0
+    for (long long sline = 0; sline < nsub; ++sline) {
+      long long u = sline, g = origin;
+      for (int a = 1; a < cg.d; ++a) {
         g += (u % len[a]) * fstride[a];
         u /= len[a];
       }
-      const double w = (double)W[g];
-      wmax = w > wmax ? w : wmax;
+      double w[kCoarse];
+#pragma unroll
+      for (int k = 0; k < kCoarse; ++k) w[k] = k < (int)len[0] ? (double)W[g + k] : -1.0;
+#pragma unroll
+      for (int k = 0; k < kCoarse; ++k) wmax = w[k] > wmax ? w[k] : wmax;
     }
     double v = kInfD;
     if (wmax >= 0.0) { const double r = wmax * invL; v = -(r * r); }
@@ -383,9 +387,19 @@ __global__ __launch_bounds__(256) void k_pdt_axis0_lds(const T* __restrict__ W, 
       Bl[bb] = m;
     }
     __syncthreads();
+    long long cell0 = 0;                         // coarse cell of the line's first position (uniform per workgroup)
+    if (cg.enabled) {
+      long long f = line, ccs = cg.ccount[0];
+      for (int a = 1; a < cg.d; ++a) {
+        const long long ix = a == cg.d - 1 ? f : f % cg.count[a];
+        f = a == cg.d - 1 ? 0 : f / cg.count[a];
+        cell0 += (ix / kCoarse) * ccs;
+        ccs *= cg.ccount[a];
+      }
+    }
     for (int i = threadIdx.x; i < count0; i += blockDim.x) {
       const long long g = g0 + i;
-      if (cg.enabled && PcLo[coarse_cell(cg, g)] > pp.band) { P[g] = kInfD; continue; }
+      if (cg.enabled && PcLo[cell0 + i / kCoarse] > pp.band) { P[g] = kInfD; continue; }
       const double w = Wl[i];
       double best = kInfD;
       if (w >= 0.0) { const double r = w * pp.invL; best = -(r * r); }
@@ -458,12 +472,19 @@ __device__ __forceinline__ double pdt_scan_blocked(const double* __restrict__ Pi
                                                    long long stride, int cnt, int ia, double h, const PdtParams& pp, int blk) {
   double best = Pin[(long long)ia * stride + p];
   const int nblk = (cnt + blk - 1) / blk, b0 = ia / blk;
-  auto scan_block = [&](int b) {
+  auto scan_block = [&](int b) {       // (eight loads in flight at a time: the chain of loads is what a thread waits for)
     const int j1 = (b + 1) * blk < cnt ? (b + 1) * blk : cnt;
-    for (int j = b * blk; j < j1; ++j) {
-      const double dt = h * (double)(j > ia ? j - ia : ia - j);
-      const double cnd = Pin[(long long)j * stride + p] + dt * dt;
-      best = cnd < best ? cnd : best;
+    for (int j = b * blk; j < j1; j += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = j + u < j1 ? Pin[(long long)(j + u) * stride + p] : kInfD;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int jj = j + u;
+        const double dt = h * (double)(jj > ia ? jj - ia : ia - jj);
+        const double cnd = v[u] + dt * dt;
+        best = cnd < best ? cnd : best;
+      }
     }
   };
   auto gap_of = [&](int b) { return b == b0 ? 0 : (b < b0 ? ia - (b * blk + blk - 1) : b * blk - ia); };
@@ -515,7 +536,8 @@ __global__ __launch_bounds__(256) void k_pdt_scan(const double* __restrict__ Pin
 }
 
 // last axis + verdict for the own U points (window offset goff); ambiguous ones are listed for the exact recheck
-__global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ Pin, long long n, long long goff, long long stride,
+__global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ Pin, long long nl, int len0, long long line0,
+                                                    long long goff, long long stride,
                                                     int cnt, double h, int d, double xscale, const uint8_t* __restrict__ U,
                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc, int c,
                                                     uint8_t* __restrict__ O, long long* __restrict__ amb, const CoarseGrid cg,
@@ -523,21 +545,32 @@ __global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ P
                                                     const double* __restrict__ Bmin, int blk) {
   const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
   const bool anyS = sc->count_S > 0;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+  // launch as k_edt_decide: x over the positions of a grid line, y over the local lines (no division per candidate)
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 >= len0) return;
+  for (long long ln = blockIdx.y; ln < nl; ln += gridDim.y) {
+    const long long g = ln * len0 + i0;
     uint8_t out = 0;
     if (U[g]) {
       if (!pp.L_positive) {
         out = anyS;                                  // radius unbounded: any source covers (ucb_c >= 0 on every source)
       } else {
         const long long gg = goff + g;
+        long long f = line0 + ln, cell = i0 / kCoarse, ccs = cg.ccount[0];
+        int ia = 0;                                  // index along the last axis (inside the window)
+        for (int a = 1; a < d; ++a) {
+          const long long ix = a == d - 1 ? f : f % cg.count[a];
+          f = a == d - 1 ? 0 : f / cg.count[a];
+          cell += (ix / kCoarse) * ccs;
+          ccs *= cg.ccount[a];
+          ia = (int)ix;
+        }
         if (cg.enabled) {
-          const long long cell = coarse_cell(cg, gg);
           if (PcHi[cell] < -pp.band) { O[g] = 1; continue; }     // covered wherever it sits in its cell
           if (PcLo[cell] > pp.band) { O[g] = 0; continue; }      // out of every source's reach
         }
-        const int ia = (int)((gg / stride) % cnt);
         const double best = cnt <= 1 ? Pin[gg]
-                            : Bmin  ? pdt_scan_blocked(Pin, Bmin, gg % stride, stride, cnt, ia, h, pp, blk)
+                            : Bmin  ? pdt_scan_blocked(Pin, Bmin, gg - (long long)ia * stride, stride, cnt, ia, h, pp, blk)
                                     : pdt_scan_point(Pin, gg, stride, cnt, ia, h, pp, true);
         if (best < -pp.band) out = 1;
         else if (best <= pp.band) {
@@ -560,7 +593,7 @@ __global__ __launch_bounds__(256) void k_goose_exact(const CandSpec cs, const Ca
   const long long namb = sc->n_amb;
   const double rm = (L > 0 && sc->rmax_key[c]) ? fmax(0.0, ord_val(sc->rmax_key[c])) / L : 0.0;
   // one listed point can own a box as large as the grid: its box is cut into kParts slices, one workgroup each
-  constexpr int kParts = 64;
+  constexpr int kParts = 256;
   for (long long wi = blockIdx.x; wi < namb * kParts; wi += gridDim.x) {
     const long long qi = wi / kParts;
     const int part = (int)(wi % kParts);
@@ -591,23 +624,37 @@ __global__ __launch_bounds__(256) void k_goose_exact(const CandSpec cs, const Ca
     const long long chunk = (total + kParts - 1) / kParts;
     const long long t1 = (part + 1) * chunk < total ? (part + 1) * chunk : total;
     for (long long t = part * chunk + threadIdx.x; t < t1 && !found; t += blockDim.x) {
-      long long u = t, gg = 0;
-      double xg[D];
+      // position in the box (32-bit divisions when the box allows), source weight first: most positions hold no source
+      long long gg = 0, ia[D];
+      if (total < (1ll << 31)) {
+        unsigned int u = (unsigned int)t;
 #pragma unroll
-      for (int a = 0; a < D; ++a) {
-        xg[a] = 0.0;
-        if (a < cs.d) {
-          const long long ia = lo[a] + u % len[a];
-          u /= len[a];
-          gg += ia * stridea[a];
-          const long long cnt = cs.count[a];
-          xg[a] = (ia == cnt - 1 && cnt > 1) ? cs.hi[a] : __dadd_rn(cs.lo[a], __dmul_rn((double)ia, cs.step[a]));
-        }
+        for (int a = 0; a < D; ++a)
+          if (a < cs.d) { const unsigned int la = (unsigned int)len[a]; ia[a] = lo[a] + u % la; u /= la; }
+      } else {
+        long long u = t;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+          if (a < cs.d) { ia[a] = lo[a] + u % len[a]; u /= len[a]; }
       }
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+        if (a < cs.d) gg += ia[a] * stridea[a];
       const long long gl = gg - css.first;
       if (gl >= 0 && gl < css.n_local) {
         const double w = (double)W[gl];
-        if (w >= 0.0 && lipschitz_pair<D>(xg, xh, cs.d, w, L)) found = 1;
+        if (w >= 0.0) {
+          double xg[D];
+#pragma unroll
+          for (int a = 0; a < D; ++a) {
+            xg[a] = 0.0;
+            if (a < cs.d) {
+              const long long cnt = cs.count[a];
+              xg[a] = (ia[a] == cnt - 1 && cnt > 1) ? cs.hi[a] : __dadd_rn(cs.lo[a], __dmul_rn((double)ia[a], cs.step[a]));
+            }
+          }
+          if (lipschitz_pair<D>(xg, xh, cs.d, w, L)) found = 1;
+        }
       }
     }
     found = __syncthreads_or(found);
@@ -648,6 +695,22 @@ __global__ void k_lcb0(const T* __restrict__ mean0, const T* __restrict__ var0, 
     lcb_ucb(mean0[g], var0[g], b, lcb, ucb);
     out[g] = lcb;
   }
+}
+// Single rank: the target of the explore step chosen on the device (min over the constraints' targets, the first minimum
+// wins -- models/GoOSE.py:110-112) and its coordinates parked for k_dist_to, so the sweep needs one host round trip.
+template <int D>
+__global__ void k_pick_target(const CandSpec cs, const SweepScalars* sc, int q, double* __restrict__ target) {
+  if (blockIdx.x || threadIdx.x) return;
+  int best_c = 0;
+  double best = 0.0;
+  for (int cc = 1; cc < q; ++cc)
+    if (sc->arg_idx[cc] >= 0 && (best_c == 0 || sc->arg_val[cc] < best)) { best_c = cc; best = sc->arg_val[cc]; }
+  double x[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) x[a] = 0.0;
+  if (best_c) cand_coords<D>(cs, sc->arg_idx[best_c] - cs.first, x);
+#pragma unroll
+  for (int a = 0; a < D; ++a) target[a] = x[a];
 }
 // Euclidean distance to the target, as scipy.spatial.distance.cdist computes it (models/GoOSE.py:117)
 template <typename T, int D>
