@@ -364,7 +364,11 @@ __device__ __forceinline__ double pdt_axis0_point(const TW* Wl, const TW* Bl, in
 }
 
 // The same pass with one workgroup per grid line: the line's weights (count0 <= 8192 doubles) and its block maxima sit in
-// LDS, so the dependent loads of a position's scan cost an LDS round trip instead of an L2 / HBM one.
+// LDS.  A wave takes 64 consecutive positions and walks the blocks outwards from them in one order for all its lanes:
+// a block is scanned when any lane's bound (h gap)^2 - r_block^2 still beats that lane's running minimum, every lane
+// then reads the block's weights as LDS broadcasts.  No address depends on loaded data, so nothing waits on a chain of
+// loads; the candidates and their arithmetic are those of pdt_axis0_point (a lane may also see candidates its own
+// bounds would have skipped -- they cannot lower its minimum, or only between values above the band).
 template <typename T>
 __global__ __launch_bounds__(256) void k_pdt_axis0_lds(const T* __restrict__ W, long long nlines, int count0, double h0,
                                                        const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx,
@@ -375,6 +379,7 @@ __global__ __launch_bounds__(256) void k_pdt_axis0_lds(const T* __restrict__ W, 
   const int nblk = (count0 + blk - 1) / blk;
   double* Wl = lds_w;
   double* Bl = lds_w + count0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   for (long long line = blockIdx.x; line < nlines; line += gridDim.x) {
     const long long g0 = line * count0;
     __syncthreads();                           // the previous line's scans are done with the buffers
@@ -397,13 +402,48 @@ __global__ __launch_bounds__(256) void k_pdt_axis0_lds(const T* __restrict__ W, 
         ccs *= cg.ccount[a];
       }
     }
-    for (int i = threadIdx.x; i < count0; i += blockDim.x) {
-      const long long g = g0 + i;
-      if (cg.enabled && PcLo[cell0 + i / kCoarse] > pp.band) { P[g] = kInfD; continue; }
-      const double w = Wl[i];
+    for (int base = wave * 64; base < count0; base += nwave * 64) {
+      const int i = base + lane;
+      const bool valid = i < count0;
+      const bool active = valid && !(cg.enabled && PcLo[cell0 + i / kCoarse] > pp.band);
+      if (valid && !active) P[g0 + i] = kInfD;
+      if (__ballot(active) == 0ull) continue;
       double best = kInfD;
-      if (w >= 0.0) { const double r = w * pp.invL; best = -(r * r); }
-      P[g] = pdt_axis0_point((const double*)Wl, (const double*)Bl, count0, nblk, i, h0, pp, blk, best);
+      if (active) {
+        const double w = Wl[i];
+        if (w >= 0.0) { const double r = w * pp.invL; best = -(r * r); }
+      }
+      const int bfirst = base / blk;                                            // blocks holding the wave's positions
+      const int blast = (base + 63 < count0 ? base + 63 : count0 - 1) / blk;
+      auto visit = [&](int b) -> bool {          // returns whether any lane could still gain from blocks at this distance
+        const int gap = i < b * blk ? b * blk - i : (i > b * blk + blk - 1 ? i - (b * blk + blk - 1) : 0);
+        const double dg = h0 * (double)gap;
+        const double e = dg * dg, floor_ = e - pp.rmax2;
+        const bool reach = active && !(floor_ > pp.band || floor_ >= best);
+        const double wb = Bl[b];                 // (uniform)
+        if (wb >= 0.0) {
+          const double rb = wb * pp.invL;
+          if (__ballot(reach && e - rb * rb < best) != 0ull) {
+            const int j1 = (b + 1) * blk < count0 ? (b + 1) * blk : count0;
+            for (int j = b * blk; j < j1; ++j) {
+              const double wj = Wl[j];           // (uniform: an LDS broadcast)
+              if (wj >= 0.0) {
+                const double dt = h0 * (double)(j > i ? j - i : i - j), r = wj * pp.invL;
+                const double cnd = dt * dt - r * r;
+                best = cnd < best ? cnd : best;
+              }
+            }
+          }
+        }
+        return __ballot(reach) != 0ull;
+      };
+      for (int b = bfirst; b <= blast; ++b) visit(b);
+      bool left = true, right = true;
+      for (int k = 1; left || right; ++k) {
+        if (left) left = bfirst - k >= 0 && visit(bfirst - k);
+        if (right) right = blast + k < nblk && visit(blast + k);
+      }
+      if (active) P[g0 + i] = best;
     }
   }
 }
