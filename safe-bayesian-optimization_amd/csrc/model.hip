@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_chol_prep(int mode, int n, int npad, in
 }
 
 __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ work, double* __restrict__ F, int with_E, int n, int kb,
-                                                    int* __restrict__ bad) {
+                                                    int* __restrict__ bad, double* __restrict__ Dg) {
   __shared__ double D[kPB][kPB + 1];
   const int o = blockIdx.y, tid = threadIdx.x;
   double* U = work + (size_t)o * n * n;
@@ -218,11 +218,12 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ work, d
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0)
-    for (int idx = tid; idx < kw * kw; idx += blockDim.x) {
-      const int r = idx / kw, cc = idx % kw;
-      if (cc >= r) U[(size_t)(kb + r) * n + kb + cc] = D[r][cc];
-    }
+  // The factored block goes to a side array, not back into U: the other workgroups of this launch may not have read
+  // the unfactored block yet (a late one would factor it twice).  k_chol_finish picks it up from there.
+  if (blockIdx.x == 0) {
+    double* dg = Dg + ((size_t)o * ((n + kPB - 1) / kPB) + kb / kPB) * (kPB * kPB);
+    for (int idx = tid; idx < kPB * kPB; idx += blockDim.x) dg[idx] = D[idx / kPB][idx % kPB];
+  }
   // columns: [kb + kw, n) of U, then (with E) [0, kb + kw) of E
   const int nright = n - kb - kw;
   const int ncols = nright + (with_E ? kb + kw : 0);
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ work, 
 }
 
 __global__ __launch_bounds__(256) void k_chol_finish(int mode, int n, int npad, const double* __restrict__ rhs,
-                                                     double* __restrict__ work, double* __restrict__ F, double* __restrict__ alpha) {
+                                                     double* __restrict__ work, double* __restrict__ F, double* __restrict__ alpha,
+                                                     const double* __restrict__ Dg) {
   const int o = blockIdx.y;
   double* U = work + (size_t)o * n * n;
   double* Fo = F + (size_t)o * n * n;
@@ -298,7 +300,12 @@ __global__ __launch_bounds__(256) void k_chol_finish(int mode, int n, int npad, 
   if (mode == 0) {
     for (long long idx = gid; idx < (long long)n * n; idx += gstride) {   // M = J U~ J
       const int i = (int)(idx / n), j = (int)(idx % n);
-      Fo[idx] = j <= i ? U[(size_t)(n - 1 - i) * n + (n - 1 - j)] : 0.0;
+      const int ur = n - 1 - i, uc = n - 1 - j;                           // position in U~ (diagonal blocks: the side array)
+      double v = 0.0;
+      if (j <= i)
+        v = ur / kPB == uc / kPB ? Dg[((size_t)o * ((n + kPB - 1) / kPB) + ur / kPB) * (kPB * kPB) + (ur % kPB) * kPB + uc % kPB]
+                                 : U[(size_t)ur * n + uc];
+      Fo[idx] = v;
     }
   } else {
     // alpha = M^T (M rhs), M = Fo (lower).  t = M rhs goes through the (now free) first row of `work`
@@ -423,7 +430,8 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<
   int rc;
   // workspace: [W | work | F] (q n^2 each) + As + sqA + rhs + sf2 + sn2 + alpha + bad
   const size_t small = (size_t)q * npad * mc.dpad + (size_t)q * npad + (size_t)q * n + 2 * (size_t)q + (size_t)q * npad;
-  if ((rc = ensure(c->fitwork, sizeof(double) * (3 * q * nn + small) + sizeof(int) * q))) return rc;
+  const size_t ndiag = (size_t)q * ((n + kPB - 1) / kPB) * (kPB * kPB);   // factored diagonal blocks of the blocked form
+  if ((rc = ensure(c->fitwork, sizeof(double) * (3 * q * nn + small + ndiag) + sizeof(int) * q + 64))) return rc;
   double* dW = (double*)c->fitwork.p;
   double* dwork = dW + q * nn;
   double* dF = dwork + q * nn;
@@ -433,7 +441,8 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<
   double* dsf2 = drhs + (size_t)q * n;
   double* dsn2 = dsf2 + q;
   double* dalpha = dsn2 + q;
-  int* dbad = (int*)(dalpha + (size_t)q * npad);
+  double* dDg = dalpha + (size_t)q * npad;
+  int* dbad = (int*)(dDg + ndiag);
   if (host_invK) SBO_HIP(hipMemcpyAsync(dW, host_invK, sizeof(double) * q * nn, hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(dAs, As.data(), sizeof(double) * As.size(), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemcpyAsync(dsq, sqA.data(), sizeof(double) * sqA.size(), hipMemcpyHostToDevice, c->stream));
@@ -452,7 +461,7 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<
       const int kw = std::min(kPB, n - kb);
       const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
       hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, (ncols + 255) / 256), q), dim3(256), 0, c->stream, dwork, dF, mode, n,
-                         kb, dbad);
+                         kb, dbad, dDg);
       const int rest = n - kb - kw;
       if (rest > 0) {
         const unsigned ti = (unsigned)((rest + 31) / 32);
@@ -461,7 +470,8 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<
           hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((kb + kw + 31) / 32), ti, q), dim3(256), 0, c->stream, dwork, dF, 1, n, kb);
       }
     }
-    hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, (const double*)drhs, dwork, dF, dalpha);
+    hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, (const double*)drhs, dwork, dF, dalpha,
+                       (const double*)dDg);
   } else {
     hipLaunchKernelGGL(k_model_build, dim3(q), dim3(1024), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)dW,
                        (const double*)dAs, (const double*)dsq, (const double*)drhs, (const double*)dsf2, (const double*)dsn2, dwork, dF,

@@ -765,6 +765,25 @@ def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_
     assert g["count_O"] == gref["count_O"].tolist() and g["target_index_c"] == gref["target_index_c"].tolist()
 
 
+@pytest.mark.parametrize("use_invK", [True, False])
+def test_blocked_model_build_repeats_bitwise(engine, use_invK):
+    """n >= 256 builds the model with the multi-workgroup blocked factorisation (many launches, workgroups sharing the
+    panel's diagonal block): repeated builds of one data set must give the same posterior bit for bit (a workgroup that
+    read a block another one had already factored once made every few builds fail)."""
+    cfg = synthetic.make_config("H", n=512)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    first = None
+    for rep in range(12):
+        engine.set_model(cfg["ds"], use_invK=use_invK)
+        engine.set_grid(lo, hi, [48, 40])
+        mean, var = engine.posterior()
+        if first is None:
+            first = (mean, var)
+            _check_posterior(engine, cfg["ds"], oracle.grid_points(lo, hi, [48, 40]), TOL64)
+        else:
+            assert np.array_equal(mean, first[0]) and np.array_equal(var, first[1]), rep
+
+
 @pytest.mark.parametrize("use_invK,dtype", [(True, "f64"), (False, "f64"), (False, "f32")])
 def test_model_append_equals_a_rebuild(engine, use_invK, dtype):
     """sbo_model_append: five observations appended one by one under frozen normalisation and
