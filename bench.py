@@ -178,7 +178,7 @@ def main():
         k1 = float(np.mean(k1_ms))
         alg_tflops = float(np.mean(k1_flops)) / (k1 * 1e-3) / 1e12
         peak = FP64_MATRIX_PEAK_TFLOPS if cfg["dtype"] == "f64" else FP32_MATRIX_PEAK_TFLOPS
-        kname = {1: "k_posterior", 2: "k_posterior_chunked", 3: "k_posterior_grid", 4: "k_bpost (+ k_bgemm stage 1)"}.get(k1_kind, "?")
+        kname = {1: "k_posterior", 2: "k_posterior_chunked", 3: "k_posterior_grid", 4: "k_bpost (+ k_bstage1, stage 1)"}.get(k1_kind, "?")
         executed = float(np.mean(k1_exec)) / (k1 * 1e-3) / 1e12
         achieved = min(alg_tflops, executed) if executed > 0 else alg_tflops
         traffic = None

@@ -4,7 +4,7 @@
 // linspace x linspace grid (test/test_SafeOpt.py:324-345).  The math and the host-side construction of the bases are
 // in bilinear_host.hpp; this file holds the plan (device tables) and the kernels:
 //
-//   stage 1 (k_bgemm)  Bt[x1, k0]  = sum_k1 P1[k1, x1] T4qq[k0, k1]        (lines of the grid  x  pair index of axis 0)
+//   stage 1 (k_bstage1) Bt[x1, k0]  = sum_k1 P1[k1, x1] T4qq[k0, k1]        (lines of the grid  x  pair index of axis 0)
 //   stage 2 (k_bpost)  quad[x1,x0] = sum_k0 Bt[x1, k0] P0[k0, x0]   ->  var = max(0, sf2 - quad) Y_std^2
 //                      m[x1, x0]   = sum_p  V0[p, x1] S0[p, x0]     (and the two gradient sums, same shape)
 //
@@ -26,7 +26,7 @@ namespace sbo {
 
 // Plain GEMM on the matrix cores.  OUT[rows x cols] = A[rows x K] B[K x cols];  A: packed 16 x 16 block images, Bf:
 // [ncs][KB * 4][64] fragments.  A wave owns 16 rows x (16 S) columns; the four waves of a workgroup take four
-// consecutive row blocks.  Used for stage 1 of every posterior launch and for the per-model build of T4.
+// consecutive row blocks.  Used for the per-model build of T4 (stage 1 of a posterior launch has its own kernel below).
 //   TRI   0: A images [nrb][KB][256];  1: lower-triangular images [tri(rb, kb)][256] (the model's factor M as K1g keeps
 //            it), only k-blocks <= rb exist and are run
 //   OMODE 0: OUT as packed block images [nrb][ncs][256] (the A operand of a following GEMM with K = cols)
@@ -53,16 +53,30 @@ __global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, siz
   d4_t acc[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) acc[s] = d4_t{0.0, 0.0, 0.0, 0.0};
-  for (int kb = 0; kb < kend; ++kb) {
-    d4_t a[4];
-    MM<double>::load_a4(Ablk + (size_t)kb * 256, lane, a);
+  // operands of k-block kb + 1 are loaded while kb is multiplied: with two to three waves per SIMD nothing else hides
+  // the L2 latency of the fragment loads
+  d4_t a[2][4];
+  double b[2][4][S];
+  auto load_kb = [&](int kb, d4_t (&aa)[4], double (&bb)[4][S]) {
+    MM<double>::load_a4(Ablk + (size_t)kb * 256, lane, aa);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const double b = Bo[boff[s] + (size_t)(kb * 4 + kk) * 64];
-        acc[s] = MM<double>::mfma(a[kk], b, acc[s]);
-      }
+      for (int s = 0; s < S; ++s) bb[kk][s] = Bo[boff[s] + (size_t)(kb * 4 + kk) * 64];
+  };
+  auto mul_kb = [&](const d4_t (&aa)[4], const double (&bb)[4][S]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int s = 0; s < S; ++s) acc[s] = MM<double>::mfma(aa[kk], bb[kk][s], acc[s]);
+  };
+  load_kb(0, a[0], b[0]);
+  for (int kb = 0; kb < kend; kb += 2) {
+    if (kb + 1 < kend) load_kb(kb + 1, a[1], b[1]);
+    mul_kb(a[0], b[0]);
+    if (kb + 1 < kend) {
+      if (kb + 2 < kend) load_kb(kb + 2, a[0], b[0]);
+      mul_kb(a[1], b[1]);
     }
   }
   // accumulator element t of lane l: row 4 t + (l >> 4), column l & 15 of the 16 x 16 tile
@@ -89,6 +103,73 @@ __global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, siz
       for (int t = 0; t < 4; ++t)
         out[(size_t)(rb * 16 + 4 * t + row_in) * ld + (size_t)(cs0 + s) * 16 + col_in] = acc[s][t];
     }
+  }
+}
+
+// Stage 1 of every posterior launch (OUT as packed block images, the OMODE 0 of k_bgemm): the four waves of a workgroup
+// own four row blocks and share S column strips, so the strips' B fragments are staged once per workgroup through LDS
+// (double-buffered, one barrier per k-block) instead of once per wave from L2 -- with K ~ 290 and only 16 x 16 S outputs
+// per wave the plain kernel is bound by L2 bandwidth (~110 KB of operands per wave), not by the matrix cores.
+template <int S>
+__global__ __launch_bounds__(256) void k_bstage1(const double* __restrict__ A, size_t a_stride_o, const double* __restrict__ Bf,
+                                                 size_t b_stride_o, int KB, int nrb, int ncs, double* __restrict__ out,
+                                                 size_t out_stride_o) {
+  __shared__ double Bs[2][4 * S * 64];          // [buffer][(kk S + s) 64 + lane]
+  const int o = blockIdx.z, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int rb = blockIdx.y * 4 + wave, rbl = rb < nrb ? rb : nrb - 1;
+  const int cs0 = blockIdx.x * S;
+  const double* Ablk = A + (size_t)o * a_stride_o + (size_t)rbl * KB * 256;
+  const double* Bo = Bf + (size_t)o * b_stride_o;
+  // staging role: element e = tid + 256 j (j < S) of the k-block's [4][S][64] fragment set
+  size_t goff[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const int e = tid + 256 * j, l = e & 63, ks = e >> 6, s_ = ks % S, kk = ks / S;
+    const int cs = cs0 + s_ < ncs ? cs0 + s_ : ncs - 1;
+    goff[j] = ((size_t)cs * KB * 4 + kk) * 64 + l;
+  }
+  d4_t acc[S];
+#pragma unroll
+  for (int s_ = 0; s_ < S; ++s_) acc[s_] = d4_t{0.0, 0.0, 0.0, 0.0};
+  double breg[S];
+  d4_t a[2][4];
+#pragma unroll
+  for (int j = 0; j < S; ++j) Bs[0][tid + 256 * j] = Bo[goff[j]];
+  MM<double>::load_a4(Ablk, lane, a[0]);
+  __syncthreads();
+  // one k-block: prefetch block kb + 1 (registers), multiply block kb out of LDS buffer CUR, park the prefetch in the
+  // other buffer (its last readers passed the previous barrier).  Written twice so that buffers and register sets are
+  // compile-time names.
+  auto step = [&](int kb, const double* bs_cur, double* bs_nxt, const d4_t (&acur)[4], d4_t (&anxt)[4]) {
+    const bool more = kb + 1 < KB;
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < S; ++j) breg[j] = Bo[goff[j] + (size_t)(kb + 1) * 256];
+      MM<double>::load_a4(Ablk + (size_t)(kb + 1) * 256, lane, anxt);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int s_ = 0; s_ < S; ++s_) acc[s_] = MM<double>::mfma(acur[kk], bs_cur[(kk * S + s_) * 64 + lane], acc[s_]);
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < S; ++j) bs_nxt[tid + 256 * j] = breg[j];
+    }
+    __syncthreads();
+  };
+  for (int kb = 0; kb < KB; kb += 2) {
+    step(kb, Bs[0], Bs[1], a[0], a[1]);
+    if (kb + 1 < KB) step(kb + 1, Bs[1], Bs[0], a[1], a[0]);
+  }
+  if (rb >= nrb) return;
+  const int col_in = lane & 15, row_in = lane >> 4;
+#pragma unroll
+  for (int s_ = 0; s_ < S; ++s_) {
+    if (cs0 + s_ >= ncs) continue;
+    double* blk = out + (size_t)o * out_stride_o + ((size_t)rb * ncs + (cs0 + s_)) * 256;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) blk[MM<double>::pack_pos(4 * t + row_in, col_in & 3, col_in >> 2)] = acc[s_][t];
   }
 }
 
@@ -582,11 +663,12 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   const CandSpec& cs = c->cs;
   const int q = mc.q;
   const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0, line0 = cs.first / cnt0;
-  constexpr int S1 = 2;
-  // stage 1: Bt = P1^T T4qq^T, written as the packed A operand of stage 2
-  hipLaunchKernelGGL((k_bgemm<S1, 0, 0>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256),
-                     0, c->stream, (const double*)c->bl_P1A.p, pl.sP1A, (const double*)c->bl_T4f.p, pl.sT4f, pl.KB1, pl.nrb, pl.KB0,
-                     (double*)c->bl_BtA.p, pl.sBtA, (double*)nullptr, 0ll);
+  // stage 1: Bt = P1^T T4qq^T, written as the packed A operand of stage 2 (three strips per workgroup measured best on
+  // config B: 27.7 us against 28.8 with two and 31.3 with four; the per-wave k_bgemm<2, 0, 0> took 32.6)
+  constexpr int S1 = 3;
+  hipLaunchKernelGGL((k_bstage1<S1>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256), 0,
+                     c->stream, (const double*)c->bl_P1A.p, pl.sP1A, (const double*)c->bl_T4f.p, pl.sT4f, pl.KB1, pl.nrb, pl.KB0,
+                     (double*)c->bl_BtA.p, pl.sBtA);
   // stage 2 (fused): variance, mean, Lipschitz keys
   const size_t lds = sizeof(double) * 2 * 4096;
   const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8), gy = (unsigned)((pl.nrb + 7) / 8);

@@ -1,7 +1,7 @@
 """Print the kernel timeline of one bench step from a rocprofv3 kernel trace (gpurun_out/<tag>/trace/**/_kernel_trace.csv)."""
 import csv, glob, sys
 tag = sys.argv[1]
-marker = sys.argv[2] if len(sys.argv) > 2 else "k_bgemm<2, 0, 0>"
+marker = sys.argv[2] if len(sys.argv) > 2 else "k_bstage1<"
 f = glob.glob(f"gpurun_out/{tag}/trace/**/*_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
