@@ -987,7 +987,7 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     if (c->scan_blocks && count0 >= 16 * blk0 && count0 <= 8192 && nt / count0 >= 2048) {
       // one workgroup per line, the line in LDS (pays once there are enough lines to fill the chip: measured on 1024^2 it
       // loses to the thread-per-position kernel, on 2048^2 it wins)
-      const size_t lds = sizeof(double) * ((size_t)count0 + (count0 + blk0 - 1) / blk0);
+      const size_t lds = sizeof(double) * ((size_t)count0 + (count0 + kAnchor - 1) / kAnchor) + sizeof(int) * 2 * ((size_t)(count0 + kAnchor - 1) / kAnchor + 2);
       SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pdt_axis0_lds<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_pdt_axis0_lds<T>), dim3((unsigned)std::min<long long>(nt / count0, 1 << 16)), dim3(256), lds, c->stream, Wwin,
                          nt / count0, count0, c->cs.step[0], (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, d,

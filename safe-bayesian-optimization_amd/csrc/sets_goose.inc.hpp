@@ -363,35 +363,35 @@ __device__ __forceinline__ double pdt_axis0_point(const TW* Wl, const TW* Bl, in
   return best;
 }
 
-// The same pass with one workgroup per grid line: the line's weights (count0 <= 8192 doubles) and its block maxima sit in
-// LDS.  A wave takes 64 consecutive positions and walks the blocks outwards from them in one order for all its lanes:
-// a block is scanned when any lane's bound (h gap)^2 - r_block^2 still beats that lane's running minimum, every lane
-// then reads the block's weights as LDS broadcasts.  No address depends on loaded data, so nothing waits on a chain of
-// loads; the candidates and their arithmetic are those of pdt_axis0_point (a lane may also see candidates its own
-// bounds would have skipped -- they cannot lower its minimum, or only between values above the band).
+// The same pass with one workgroup per grid line, the line's weights (count0 <= 8192 doubles) in LDS, and the search
+// cut down by the structure of the problem: every parabola (h0 (i - j))^2 - r_j^2 has the same curvature, so the
+// (leftmost) minimising source j*(i) never moves left as i moves right -- also inside the sliding window of the global
+// reach, see DESIGN.md.  Phase A finds j* exactly for an anchor every 32 positions (one wave per anchor, the window
+// spread over its lanes); phase B gives every position between two anchors the range [j*(left), j*(right)], on average
+// a few dozen sources instead of the ~1000 inside the reach.  Values agree with the exhaustive search up to rounding
+// between near-ties (1e-16, far inside the band that sends a verdict to the exact recheck).
+constexpr int kAnchor = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void k_pdt_axis0_lds(const T* __restrict__ W, long long nlines, int count0, double h0,
                                                        const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx,
                                                        int d, double xscale, const CoarseGrid cg, const double* __restrict__ PcLo,
                                                        int blk, double* __restrict__ P) {
-  extern __shared__ double lds_w[];            // [count0] weights as double | [nblk] block maxima
+  extern __shared__ double lds_w[];            // [count0] weights as double | [ngap] block maxima | [nanch] int argmins | [nanch] int gap flags
   const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
-  const int nblk = (count0 + blk - 1) / blk;
+  const int ngap = (count0 + kAnchor - 1) / kAnchor, nanch = ngap + 1;      // anchor m sits at min(32 m, count0 - 1)
   double* Wl = lds_w;
-  double* Bl = lds_w + count0;
+  double* Bl = lds_w + count0;                 // largest weight of every block of 32 positions (< 0: no source in it)
+  int* jstar = reinterpret_cast<int*>(Bl + ngap);
+  int* gap_on = jstar + nanch;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  // global reach in steps: sources further away have (h0 t)^2 - rmax2 > band and cannot bring a value below the band
+  const double rsteps = sqrt(pp.rmax2 + pp.band) / h0 + 2.0;
+  const int Rg = rsteps < (double)count0 ? (int)rsteps : count0;
+  auto anchor_pos = [&](int m) { return m * kAnchor < count0 - 1 ? m * kAnchor : count0 - 1; };
   for (long long line = blockIdx.x; line < nlines; line += gridDim.x) {
     const long long g0 = line * count0;
     __syncthreads();                           // the previous line's scans are done with the buffers
     for (int i = threadIdx.x; i < count0; i += blockDim.x) Wl[i] = (double)W[g0 + i];
-    __syncthreads();
-    for (int bb = threadIdx.x; bb < nblk; bb += blockDim.x) {
-      const int j1 = (bb + 1) * blk < count0 ? (bb + 1) * blk : count0;
-      double m = -INFINITY;
-      for (int j = bb * blk; j < j1; ++j) m = Wl[j] > m ? Wl[j] : m;
-      Bl[bb] = m;
-    }
-    __syncthreads();
     long long cell0 = 0;                         // coarse cell of the line's first position (uniform per workgroup)
     if (cg.enabled) {
       long long f = line, ccs = cg.ccount[0];
@@ -402,48 +402,102 @@ __global__ __launch_bounds__(256) void k_pdt_axis0_lds(const T* __restrict__ W, 
         ccs *= cg.ccount[a];
       }
     }
-    for (int base = wave * 64; base < count0; base += nwave * 64) {
-      const int i = base + lane;
-      const bool valid = i < count0;
-      const bool active = valid && !(cg.enabled && PcLo[cell0 + i / kCoarse] > pp.band);
-      if (valid && !active) P[g0 + i] = kInfD;
-      if (__ballot(active) == 0ull) continue;
+    __syncthreads();
+    for (int bb = threadIdx.x; bb < ngap; bb += blockDim.x) {
+      const int j1 = (bb + 1) * kAnchor < count0 ? (bb + 1) * kAnchor : count0;
+      double mx = -1.0;
+      for (int j = bb * kAnchor; j < j1; ++j) mx = Wl[j] > mx ? Wl[j] : mx;
+      Bl[bb] = mx;
+    }
+    for (int m = threadIdx.x; m < ngap; m += blockDim.x) {       // does gap m = [32 m, 32 m + 32) hold an active position?
+      int on = !cg.enabled;
+      for (int cc = 0; cc < kAnchor / kCoarse && !on; ++cc) {
+        const int i = m * kAnchor + cc * kCoarse;
+        if (i < count0 && !(PcLo[cell0 + i / kCoarse] > pp.band)) on = 1;
+      }
+      gap_on[m] = on;
+    }
+    __syncthreads();
+    // phase A: exact leftmost minimiser of every anchor next to an active gap, in two levels -- every eighth anchor (and
+    // the last one) searches its whole window, the anchors between two of those only between their minimisers
+    auto scan_anchor = [&](int m, int lo, int hi) {       // one wave: the range spread over its lanes
+      const int a = anchor_pos(m);
       double best = kInfD;
-      if (active) {
-        const double w = Wl[i];
-        if (w >= 0.0) { const double r = w * pp.invL; best = -(r * r); }
-      }
-      const int bfirst = base / blk;                                            // blocks holding the wave's positions
-      const int blast = (base + 63 < count0 ? base + 63 : count0 - 1) / blk;
-      auto visit = [&](int b) -> bool {          // returns whether any lane could still gain from blocks at this distance
-        const int gap = i < b * blk ? b * blk - i : (i > b * blk + blk - 1 ? i - (b * blk + blk - 1) : 0);
-        const double dg = h0 * (double)gap;
-        const double e = dg * dg, floor_ = e - pp.rmax2;
-        const bool reach = active && !(floor_ > pp.band || floor_ >= best);
-        const double wb = Bl[b];                 // (uniform)
-        if (wb >= 0.0) {
-          const double rb = wb * pp.invL;
-          if (__ballot(reach && e - rb * rb < best) != 0ull) {
-            const int j1 = (b + 1) * blk < count0 ? (b + 1) * blk : count0;
-            for (int j = b * blk; j < j1; ++j) {
-              const double wj = Wl[j];           // (uniform: an LDS broadcast)
-              if (wj >= 0.0) {
-                const double dt = h0 * (double)(j > i ? j - i : i - j), r = wj * pp.invL;
-                const double cnd = dt * dt - r * r;
-                best = cnd < best ? cnd : best;
-              }
-            }
-          }
+      int bj = -1;
+      for (int j0 = (lo / 64) * 64; j0 <= hi; j0 += 64) {          // two blocks per round, empty pairs skipped (uniform)
+        const int b0 = j0 / kAnchor;
+        if (!(Bl[b0] >= 0.0) && !(b0 + 1 < ngap && Bl[b0 + 1] >= 0.0)) continue;
+        const int j = j0 + lane;
+        if (j < lo || j > hi) continue;
+        const double wj = Wl[j];
+        if (wj >= 0.0) {
+          const double dt = h0 * (double)(j > a ? j - a : a - j), r = wj * pp.invL;
+          const double cnd = dt * dt - r * r;
+          if (cnd < best) { best = cnd; bj = j; }
         }
-        return __ballot(reach) != 0ull;
-      };
-      for (int b = bfirst; b <= blast; ++b) visit(b);
-      bool left = true, right = true;
-      for (int k = 1; left || right; ++k) {
-        if (left) left = bfirst - k >= 0 && visit(bfirst - k);
-        if (right) right = blast + k < nblk && visit(blast + k);
       }
-      if (active) P[g0 + i] = best;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int oj = __shfl_xor(bj, off);
+        if (oj >= 0 && (bj < 0 || ob < best || (ob == best && oj < bj))) { best = ob; bj = oj; }
+      }
+      if (lane == 0) jstar[m] = bj;
+    };
+    int any_on = 0;
+    for (int m = threadIdx.x; m < ngap; m += blockDim.x) any_on |= gap_on[m];
+    if (!__syncthreads_or(any_on)) {           // nothing on this line can be covered
+      for (int i = threadIdx.x; i < count0; i += blockDim.x) P[g0 + i] = kInfD;
+      continue;
+    }
+    constexpr int kTop = 8;
+    const int ntop = (nanch - 1 + kTop - 1) / kTop + 1;
+    for (int k = wave; k < ntop; k += nwave) {
+      const int m = k * kTop < nanch - 1 ? k * kTop : nanch - 1;
+      const int a = anchor_pos(m);
+      scan_anchor(m, a - Rg > 0 ? a - Rg : 0, a + Rg < count0 - 1 ? a + Rg : count0 - 1);
+    }
+    __syncthreads();
+    for (int m = wave; m < nanch - 1; m += nwave) {
+      if (m % kTop == 0) continue;
+      if (!(gap_on[m] || gap_on[m - 1])) continue;                 // (uniform per wave)
+      const int m0 = (m / kTop) * kTop, m1 = m0 + kTop < nanch - 1 ? m0 + kTop : nanch - 1;
+      const int a = anchor_pos(m);
+      const int jl = jstar[m0] >= 0 ? jstar[m0] : anchor_pos(m0) - Rg, jr = jstar[m1] >= 0 ? jstar[m1] : anchor_pos(m1) + Rg;
+      int lo = a - Rg > jl ? a - Rg : jl, hi = a + Rg < jr ? a + Rg : jr;
+      lo = lo > 0 ? lo : 0;
+      hi = hi < count0 - 1 ? hi : count0 - 1;
+      scan_anchor(m, lo, hi);
+    }
+    __syncthreads();
+    // phase B: every active position searches between the minimisers of its two anchors
+    for (int i = threadIdx.x; i < count0; i += blockDim.x) {
+      const long long g = g0 + i;
+      if (cg.enabled && PcLo[cell0 + i / kCoarse] > pp.band) { P[g] = kInfD; continue; }
+      const int m = i / kAnchor;
+      const int a0 = anchor_pos(m), a1 = anchor_pos(m + 1);
+      const int jl = jstar[m] >= 0 ? jstar[m] : a0 - Rg, jr = jstar[m + 1] >= 0 ? jstar[m + 1] : a1 + Rg;
+      int lo = i - Rg > jl ? i - Rg : jl, hi = i + Rg < jr ? i + Rg : jr;
+      lo = lo > 0 ? lo : 0;
+      hi = hi < count0 - 1 ? hi : count0 - 1;
+      double best = kInfD;
+      for (int b = lo / kAnchor; b <= hi / kAnchor; ++b) {
+        if (!(Bl[b] >= 0.0)) continue;             // no source in this block
+        const int j0 = b * kAnchor > lo ? b * kAnchor : lo, j1 = b * kAnchor + kAnchor - 1 < hi ? b * kAnchor + kAnchor - 1 : hi;
+        for (int j = j0; j <= j1; j += 4) {        // four reads in flight, branch-free
+          double cnd[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int jj = j + u <= j1 ? j + u : j1;
+            const double wj = Wl[jj];
+            const double dt = h0 * (double)(jj > i ? jj - i : i - jj), r = wj * pp.invL;
+            cnd[u] = wj >= 0.0 ? dt * dt - r * r : kInfD;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) best = cnd[u] < best ? cnd[u] : best;
+        }
+      }
+      P[g] = best;
     }
   }
 }
