@@ -577,10 +577,14 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       }
       const long long len0 = d >= 2 ? count0 : n;               // positions per line / local lines
       const long long nl = n / len0;
-      hipLaunchKernelGGL((k_edt_decide<T>), dim3((unsigned)((len0 + 255) / 256), (unsigned)std::min<long long>((nl + kDecideLines - 1) / kDecideLines, 65535)), dim3(256), 0,
-                         c->stream, (const double*)din, nl, (int)len0, goff / len0, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c,
-                         (T)o->b, (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, sc, G,
-                         (long long*)c->amb.p, cg, bmin, blk, slist);
+      const dim3 dgrid((unsigned)((len0 + 255) / 256), (unsigned)std::min<long long>((nl + kDecideLines - 1) / kDecideLines, 65535));
+#define SBO_DECIDE(LIST)                                                                                                            \
+  hipLaunchKernelGGL((k_edt_decide<T, LIST>), dgrid, dim3(256), 0, c->stream, (const double*)din, nl, (int)len0, goff / len0, goff, \
+                     d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c, (T)o->b, (const uint8_t*)c->maskS.p,          \
+                     (const unsigned long long*)c->Lmax.p, lidx, sc, G, (long long*)c->amb.p, cg, bmin, blk, slist)
+      if (slist) SBO_DECIDE(true);
+      else SBO_DECIDE(false);
+#undef SBO_DECIDE
       if (slist) {
         // lanes per listed candidate: 16 by default (more candidates in flight beat shorter rounds: 53 k open candidates
         // of config B take 19 us with 16 lanes, 32 us with 32), never more than a wave, 64 for 64-step blocks on request

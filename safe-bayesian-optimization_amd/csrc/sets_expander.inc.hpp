@@ -345,7 +345,8 @@ __device__ __forceinline__ bool lipschitz_pair(const double (&xg)[D], const doub
 
 // last axis + decision.  For g in S: nearest-U distance dm (unshifted) -> G bit, or the ambiguous list when
 // ucb - L dm lies inside the band the "+1e-8" shift and rounding can move it across zero.
-template <typename T>
+// LIST: open candidates go to the scan list (the usual grid path); otherwise they are scanned here by their own thread.
+template <typename T, bool LIST>
 __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ Din, long long nl, int len0, long long line0,
                                                     long long goff, long long stride, int cnt,
                                                     double h, int d, double xscale, const T* __restrict__ mean_c,
@@ -369,12 +370,45 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
   for (long long lb = blockIdx.y; lb < nlb; lb += gridDim.y) {
   if (threadIdx.x == 0) scnt = 0;
   __syncthreads();
-  for (long long ln = lb * kDecideLines; active && ln < nl && ln < (lb + 1) * kDecideLines; ++ln) {
+  // the thread's kDecideLines candidates: mask bytes, then mean / var of the safe ones, then their coarse distances are
+  // loaded for all lines before the first verdict (a line at a time would wait out three dependent loads per line)
+  uint8_t sfl[kDecideLines];
+  T mu[kDecideLines], va[kDecideLines];
+  double dcv[kDecideLines];
+  long long cellv[kDecideLines];
+  int iav[kDecideLines];
+#pragma unroll
+  for (int u = 0; u < kDecideLines; ++u) {
+    const long long ln = lb * kDecideLines + u;
+    sfl[u] = (active && ln < nl) ? S[ln * len0 + i0] : 0;
+    long long f = line0 + ln, cell = i0 / kCoarse, ccs = cg.ccount[0];
+    int ia = 0;                          // index along the last axis (inside the window)
+    for (int a = 1; a < d; ++a) {
+      const long long ix = a == d - 1 ? f : f % cg.count[a];
+      f = a == d - 1 ? 0 : f / cg.count[a];
+      cell += (ix / kCoarse) * ccs;
+      ccs *= cg.ccount[a];
+      ia = (int)ix;
+    }
+    cellv[u] = cell;
+    iav[u] = ia;
+  }
+#pragma unroll
+  for (int u = 0; u < kDecideLines; ++u) {
+    const bool on = sfl[u] && anyU;
+    const long long g = (lb * kDecideLines + u) * len0 + i0;
+    mu[u] = on ? mean_c[g] : (T)0;
+    va[u] = on ? var_c[g] : (T)0;
+    dcv[u] = (on && cg.enabled) ? cg.Dc[cellv[u]] : 0.0;
+  }
+  auto decide = [&](int u) {
+    const long long ln = lb * kDecideLines + u;
+    if (!(active && ln < nl)) return;
     const long long g = ln * len0 + i0;
     uint8_t out = 0;
-    if (S[g] && anyU) {
+    if (sfl[u] && anyU) {
       T lcb, ucbT;
-      lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
+      lcb_ucb(mu[u], va[u], b, lcb, ucbT);
       const double ucb = (double)ucbT;
       if (!(L > 0)) {
         out = ucb >= 0.0;                         // radius unbounded: any U point is a witness
@@ -382,28 +416,20 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
         const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
         const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
         const long long gg = goff + g;   // index in the transform (whole grid when ranks share it)
-        long long f = line0 + ln, cell = i0 / kCoarse, ccs = cg.ccount[0];
-        int ia = 0;                      // index along the last axis (inside the window)
-        for (int a = 1; a < d; ++a) {
-          const long long ix = a == d - 1 ? f : f % cg.count[a];
-          f = a == d - 1 ? 0 : f / cg.count[a];
-          cell += (ix / kCoarse) * ccs;
-          ccs *= cg.ccount[a];
-          ia = (int)ix;
-        }
+        const int ia = iav[u];
         if (cg.enabled) {
-          const double dC = sqrt(cg.Dc[cell]);
+          const double dC = sqrt(dcv[u]);
           const double dhi = dC * (1.0 + 1e-9) + cg.delta, dlo = fmax(0.0, dC * (1.0 - 1e-9) - cg.delta);
           const double tolc = 1e-12 * (fabs(ucb) + L * dhi);
-          if (ucb - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { G[g] = 1; continue; }     // within the radius for sure
-          if (ucb - L * (dlo - eps_abs - 1e-11 * dlo) < -tolc) { G[g] = 0; continue; }    // beyond it for sure
+          if (ucb - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { G[g] = 1; return; }     // within the radius for sure
+          if (ucb - L * (dlo - eps_abs - 1e-11 * dlo) < -tolc) { G[g] = 0; return; }    // beyond it for sure
         }
-        if (scanlist && Bmin && cnt > 1) {
-          // the few candidates the coarse bounds leave open go to k_edt_scan_list (one wave each): a lane scanning
-          // here would hold its whole wave for a chain of ~100 dependent loads
+        if (LIST) {
+          // the few candidates the coarse bounds leave open go to k_edt_scan_list (a group of lanes each): a lane
+          // scanning here would hold its whole wave for a chain of ~100 dependent loads
           sl[atomicAdd(&scnt, 1)] = g;
           G[g] = 0;
-          continue;
+          return;
         }
         const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it the verdict is "sure true"
         const double acc2 = thr > 0 ? thr * thr : -1.0;
@@ -424,7 +450,9 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
       }
     }
     G[g] = out;
-  }
+  };
+#pragma unroll
+  for (int u = 0; u < kDecideLines; ++u) decide(u);
   __syncthreads();
   const int cntl = scnt;
   if (cntl > 0) {
