@@ -240,6 +240,82 @@ __global__ __launch_bounds__(256) void k_bl_pairs(const double* __restrict__ Sta
   }
 }
 
+// ---- mean-phase operands on the device (the host only supplies the bases and beta) ---------------------------------
+// Mb[b][p r1 + s] = scale sum_j beta_b[j] U0_jp U1_js  (bilinear forms of the mean and of its two gradient sums)
+__global__ __launch_bounds__(256) void k_bl_mb(const double* __restrict__ U0, const double* __restrict__ U1,
+                                               const double* __restrict__ beta, int n, int r0, int r1, int nbeta, double scale,
+                                               double* __restrict__ Mb) {
+  const int total = nbeta * r0 * r1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int s_ = i % r1, p = (i / r1) % r0, b = i / (r0 * r1);
+    const double *u0 = U0 + (size_t)p * n, *u1 = U1 + (size_t)s_ * n, *be = beta + (size_t)b * n;
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) acc += be[j] * u0[j] * u1[j];
+    Mb[i] = scale * acc;
+  }
+}
+// Vb[b][p][line] = sum_s Mb[b][p, s] S1[s][line]
+__global__ __launch_bounds__(256) void k_bl_vb(const double* __restrict__ Mb, const double* __restrict__ S1, int r0, int r1, int r0u,
+                                               long long nlines, int nbeta, double* __restrict__ Vb) {
+  const long long total = (long long)nbeta * r0 * nlines;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long l = i % nlines;
+    const int p = (int)((i / nlines) % r0), b = (int)(i / (nlines * r0));
+    double acc = 0.0;
+    for (int s_ = 0; s_ < r1; ++s_) acc += Mb[((size_t)b * r0 + p) * r1 + s_] * S1[(size_t)s_ * nlines + l];
+    Vb[((size_t)b * r0u + p) * nlines + l] = acc;
+  }
+}
+// A images of the mean phases, three sets:  V0 (K = 16 KBm) | [V1; V0] (K = 16 KBm2, V0 from k = r0p) | V1x = V2 - xn1 V0
+__global__ __launch_bounds__(256) void k_bl_va(const double* __restrict__ Vb, const double* __restrict__ xn1, int nrb, int KBm,
+                                               int KBm2, int r0, int r0p, int r0u, long long nlines, double* __restrict__ out) {
+  const long long set = (long long)nrb * KBm * 256, set2 = (long long)nrb * KBm2 * 256, total = 2 * set + set2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int which = i < set ? 0 : (i < set + set2 ? 1 : 2);
+    const long long li = which == 0 ? i : (which == 1 ? i - set : i - set - set2);
+    const int KBx = which == 1 ? KBm2 : KBm;
+    // invert pack_pos(r, slot, kk) = kk * 64 + (slot * 4 + (r & 3)) * 4 + (r >> 2)
+    const int e = (int)(li & 255);
+    const long long blk = li >> 8;
+    const int kk = e >> 6, rem = e & 63, slot = rem >> 4, r = ((rem >> 2) & 3) + 4 * (rem & 3);
+    const int k = (int)(blk % KBx) * 16 + MM<double>::jslot(kk, slot);
+    const long long line = (blk / KBx) * 16 + r;
+    double v = 0.0;
+    if (line < nlines) {
+      if (which == 0) {
+        if (k < r0) v = Vb[((size_t)0 * r0u + k) * nlines + line];
+      } else if (which == 1) {
+        if (k < r0) v = Vb[((size_t)1 * r0u + k) * nlines + line];
+        else if (k >= r0p && k < r0p + r0) v = Vb[((size_t)0 * r0u + (k - r0p)) * nlines + line];
+      } else if (k < r0) {
+        v = Vb[((size_t)2 * r0u + k) * nlines + line] - xn1[line] * Vb[((size_t)0 * r0u + k) * nlines + line];
+      }
+    }
+    out[i] = v;
+  }
+}
+// B fragments of the mean phases, two sets:  S0 (K = 16 KBm) | [S0; -xn0 S0] (K = 16 KBm2, second copy from k = r0p)
+__global__ __launch_bounds__(256) void k_bl_sbf(const double* __restrict__ S0, const double* __restrict__ xn0, int ncs0, int KBm,
+                                                int KBm2, int r0, int r0p, long long cnt0, double* __restrict__ out) {
+  const long long fset = (long long)ncs0 * KBm * 256, total = fset + (long long)ncs0 * KBm2 * 256;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int which = i < fset ? 0 : 1;
+    const long long li = which ? i - fset : i;
+    const int KBx = which ? KBm2 : KBm;
+    const int l = (int)(li & 63);
+    const long long fr = li >> 6;
+    const int ks = (int)(fr % (KBx * 4));
+    const int k = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+    const long long x = (fr / (KBx * 4)) * 16 + (l & 15);
+    double v = 0.0;
+    if (x < cnt0) {
+      if (k < r0) v = S0[(size_t)k * cnt0 + x];
+      else if (which == 1 && k >= r0p && k < r0p + r0) v = -xn0[x] * S0[(size_t)(k - r0p) * cnt0 + x];
+    }
+    out[i] = v;
+  }
+}
+
 // Fused stage 2: variance, mean and gradient keys of a 128 x 128 tile of the grid (8 row blocks x 8 column strips) per
 // workgroup.  Four GEMM phases share the accumulators; operands are staged through LDS one 16-deep k-block at a time
 // (double-buffered), so every fragment is fetched from L2 once per workgroup instead of once per wave:
@@ -529,128 +605,116 @@ int bilinear_setup(sbo_ctx* c) {
   pl.KS0 = (K0 + 3) / 4;
   pl.sVA = (size_t)nrb * (2 * KBm + KBm2) * 256;     // image sets  V0 | [V1; V0] | V1x
   pl.sSBf = (size_t)ncs0 * (KBm + KBm2) * 256;      // fragment sets  S0 | [S0; -xn0 S0]
-  std::vector<double> hVA(pl.sVA * q, 0.0), hSBf(pl.sSBf * q, 0.0), Vb((size_t)NB * r0u * nlines);
-  std::vector<double> Mb, beta((size_t)NB * n), S1loc;
-  std::vector<int> map0, map1;
+  // Everything below the bases runs on the device, all outputs back to back on the stream and one synchronisation at
+  // the end: per output the bases / tables / beta go up (a few hundred KB), then Z -> C = M Z -> G = C^T C -> T4, the
+  // pair tables of both axes, and the mean-phase operands Mb -> Vb -> A images / B fragments.
   int rc;
   if ((rc = ensure(c->bl_P0f, sizeof(double) * pl.sP0f * q))) return rc;
   if ((rc = ensure(c->bl_P1A, sizeof(double) * pl.sP1A * q))) return rc;
   if ((rc = ensure(c->bl_T4f, sizeof(double) * pl.sT4f * q))) return rc;
+  if ((rc = ensure(c->bl_SBf, sizeof(double) * pl.sSBf * q))) return rc;     // mean-phase B fragments
+  if ((rc = ensure(c->bl_VA, sizeof(double) * pl.sVA * q))) return rc;      // mean-phase A images
+  if ((rc = ensure(c->bl_BtA, sizeof(double) * pl.sBtA * q))) return rc;
   const int KBn = mc.npad / 16;
+  // host staging that must outlive the asynchronous uploads: one set per output
+  std::vector<std::vector<double>> betas(q), S1locs(q);
+  std::vector<std::vector<int>> maps0(q), maps1(q);
+  struct Region { size_t U0, U1, S0, S1, beta, Mb, Vb, end; };
+  std::vector<Region> reg(q);
+  size_t ndbl = (size_t)cnt0 + (size_t)nlines, nint = 0, work_max = 0;     // xn0 | xn1 (local lines) first
+  for (int o = 0; o < q; ++o) {
+    const int r0 = b0[o].r, r1 = b1[o].r;
+    Region& g = reg[o];
+    g.U0 = ndbl;
+    g.U1 = g.U0 + (size_t)n * r0;
+    g.S0 = g.U1 + (size_t)n * r1;
+    g.S1 = g.S0 + (size_t)r0 * cnt0;
+    g.beta = g.S1 + (size_t)r1 * nlines;
+    g.Mb = g.beta + (size_t)NB * n;
+    g.Vb = g.Mb + (size_t)NB * r0 * r1;
+    g.end = g.Vb + (size_t)NB * r0u * nlines;
+    ndbl = g.end;
+    bl::pair_map(r0, maps0[o]);
+    bl::pair_map(r1, maps1[o]);
+    nint += maps0[o].size() + maps1[o].size();
+    const size_t ncsR = ((size_t)r0 * r1 + 15) / 16;
+    work_max = std::max(work_max, 3 * ncsR * KBn * 256 + (ncsR * 16) * (ncsR * 16));
+  }
+  if ((rc = ensure(c->bl_small, sizeof(double) * ndbl + sizeof(int) * nint))) return rc;
+  if ((rc = ensure(c->bl_work, sizeof(double) * work_max))) return rc;
+  double* dsm = (double*)c->bl_small.p;
+  int* dints = (int*)(dsm + ndbl);
+  std::vector<double> xn1loc(xn1_all.begin() + line0, xn1_all.begin() + line0 + nlines);
+  SBO_HIP(hipMemcpyAsync(dsm, xn0.data(), sizeof(double) * cnt0, hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemcpyAsync(dsm + cnt0, xn1loc.data(), sizeof(double) * nlines, hipMemcpyHostToDevice, c->stream));
+  auto blocks = [](size_t total) { return dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16)); };
   for (int o = 0; o < q; ++o) {
     const int r0 = b0[o].r, r1 = b1[o].r, k0n = bl::pair_count(r0), k1n = bl::pair_count(r1);
     const double sf2 = mc.sf2[o];
+    const Region& g = reg[o];
+    std::vector<double>& beta = betas[o];
+    beta.resize((size_t)NB * n);
     for (int j = 0; j < n; ++j) {
       const double al = c->h_alpha[(size_t)o * mc.npad + j];
       beta[j] = al;
       beta[(size_t)n + j] = al * c->h_Xnorm[(size_t)j * mc.d + 0];
       beta[(size_t)2 * n + j] = al * c->h_Xnorm[(size_t)j * mc.d + 1];
     }
-    const double* bp[3] = {&beta[0], &beta[(size_t)n], &beta[(size_t)2 * n]};
-    bl::mean_forms(n, b0[o], b1[o], NB, bp, sf2, Mb);
-    // axis-1 coordinates of the local lines only
-    bl::AxisBasis b1loc;
-    b1loc.r = r1;
-    b1loc.S.resize((size_t)r1 * nlines);
-    for (int s = 0; s < r1; ++s)
-      for (long long l = 0; l < nlines; ++l) b1loc.S[(size_t)s * nlines + l] = b1[o].S[(size_t)s * cs.count[1] + line0 + l];
-    // ---- device: Z -> C = M Z -> G = C^T C -> T4 fragments; pair tables of both axes -------------------------------
-    {
-      const int R = r0 * r1, ncsR = (R + 15) / 16;
-      const size_t nU0 = (size_t)n * r0, nU1 = (size_t)n * r1, nS0 = (size_t)r0 * cnt0, nS1 = (size_t)r1 * nlines;
-      bl::pair_map(r0, map0);
-      bl::pair_map(r1, map1);
-      const size_t small_d = nU0 + nU1 + nS0 + nS1;
-      const size_t nZf = (size_t)ncsR * KBn * 256;              // fragments of Z, of C, images of C^T: same size
-      const size_t ldg = (size_t)ncsR * 16;
-      if ((rc = ensure(c->bl_small, sizeof(double) * small_d + sizeof(int) * (map0.size() + map1.size())))) return rc;
-      if ((rc = ensure(c->bl_work, sizeof(double) * (3 * nZf + ldg * ldg)))) return rc;
-      double* dU0 = (double*)c->bl_small.p;
-      double* dU1 = dU0 + nU0;
-      double* dS0 = dU1 + nU1;
-      double* dS1 = dS0 + nS0;
-      int* dmap0 = (int*)(dS1 + nS1);
-      int* dmap1 = dmap0 + map0.size();
-      SBO_HIP(hipMemcpyAsync(dU0, b0[o].U.data(), sizeof(double) * nU0, hipMemcpyHostToDevice, c->stream));
-      SBO_HIP(hipMemcpyAsync(dU1, b1[o].U.data(), sizeof(double) * nU1, hipMemcpyHostToDevice, c->stream));
-      SBO_HIP(hipMemcpyAsync(dS0, b0[o].S.data(), sizeof(double) * nS0, hipMemcpyHostToDevice, c->stream));
-      SBO_HIP(hipMemcpyAsync(dS1, b1loc.S.data(), sizeof(double) * nS1, hipMemcpyHostToDevice, c->stream));
-      SBO_HIP(hipMemcpyAsync(dmap0, map0.data(), sizeof(int) * map0.size(), hipMemcpyHostToDevice, c->stream));
-      SBO_HIP(hipMemcpyAsync(dmap1, map1.data(), sizeof(int) * map1.size(), hipMemcpyHostToDevice, c->stream));
-      double* Zf = (double*)c->bl_work.p;
-      double* Cf = Zf + nZf;
-      double* CtA = Cf + nZf;
-      double* G = CtA + nZf;
-      auto blocks = [](size_t total) { return dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16)); };
-      hipLaunchKernelGGL(k_bl_zf, blocks(nZf), dim3(256), 0, c->stream, (const double*)dU0, (const double*)dU1, n, KBn, r0, r1, ncsR, Zf);
-      // C = M Z with the model's packed triangular factor; written as fragments (k = observation) and as images of C^T
-      hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), 1), dim3(256), 0, c->stream,
-                         (const double*)c->Fpk.p + (size_t)o * c->fpk_stride, (size_t)0, (const double*)Zf, (size_t)0, KBn, KBn, ncsR,
-                         Cf, (size_t)0, CtA, 0ll);
-      // G = C^T C  (R x R, row-major)
-      hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), 1), dim3(256), 0, c->stream,
-                         (const double*)CtA, (size_t)0, (const double*)Cf, (size_t)0, KBn, ncsR, ncsR, G, (size_t)0, (double*)nullptr,
-                         (long long)ldg);
-      hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f), dim3(256), 0, c->stream, (const double*)G, (long long)ldg, r1, (const int*)dmap0, k0n,
-                         (const int*)dmap1, k1n, sf2 * sf2, KB0, KB1, (double*)c->bl_T4f.p + pl.sT4f * o);
-      hipLaunchKernelGGL((k_bl_pairs<1>), blocks(pl.sP0f), dim3(256), 0, c->stream, (const double*)dS0, cnt0, (const int*)dmap0, k0n, KB0,
-                         ncs0, (double*)c->bl_P0f.p + pl.sP0f * o);
-      hipLaunchKernelGGL((k_bl_pairs<0>), blocks(pl.sP1A), dim3(256), 0, c->stream, (const double*)dS1, nlines, (const int*)dmap1, k1n, KB1,
-                         nrb, (double*)c->bl_P1A.p + pl.sP1A * o);
-      SBO_HIP(hipGetLastError());
-      SBO_HIP(hipStreamSynchronize(c->stream));      // the small upload buffer is reused by the next output
-    }
-    lap("forms");
-    // V_b[p][line] = sum_s Mb[b][p, s] S1[s][line]   (b: alpha, alpha Xn_0, alpha Xn_1)
-    std::fill(Vb.begin(), Vb.end(), 0.0);
-    for (int b = 0; b < NB; ++b)
-      for (int p = 0; p < r0; ++p) {
-        double* dst = &Vb[((size_t)b * r0u + p) * nlines];
-        for (int s = 0; s < r1; ++s) {
-          const double m = Mb[(size_t)b * r0 * r1 + (size_t)p * r1 + s];
-          const double* s1 = &b1loc.S[(size_t)s * nlines];
-          for (long long l = 0; l < nlines; ++l) dst[l] += m * s1[l];
-        }
-      }
-    // packed A images of the mean phases: rows = lines, k = koff + basis index p (element (row, k) of a K = 16 KBx operand)
-    auto put_rows = [&](double* img, int KBx, int koff, auto value /* (p, line) */) {
-      for (long long line = 0; line < nlines; ++line)
-        for (int pidx = 0; pidx < r0; ++pidx) {
-          const int k = koff + pidx, kb = k >> 4, jin = k & 15;
-          img[((size_t)(line >> 4) * KBx + kb) * 256 + MM<double>::pack_pos((int)(line & 15), jin & 3, jin >> 2)] = value(pidx, line);
-        }
-    };
-    double* va = &hVA[pl.sVA * o];
-    const size_t set = (size_t)nrb * KBm * 256, set2 = (size_t)nrb * KBm2 * 256;
-    put_rows(va, KBm, 0, [&](int pi, long long l) { return Vb[((size_t)0 * r0u + pi) * nlines + l]; });
-    put_rows(va + set, KBm2, 0, [&](int pi, long long l) { return Vb[((size_t)1 * r0u + pi) * nlines + l]; });
-    put_rows(va + set, KBm2, r0p, [&](int pi, long long l) { return Vb[((size_t)0 * r0u + pi) * nlines + l]; });
-    put_rows(va + set + set2, KBm, 0, [&](int pi, long long l) {
-      return Vb[((size_t)2 * r0u + pi) * nlines + l] - xn1_all[(size_t)(line0 + l)] * Vb[((size_t)0 * r0u + pi) * nlines + l];
-    });
-    // B fragments of the mean phases: k = koff + basis index p, columns = axis-0 positions
-    auto put_cols = [&](double* frag, int KBx, int koff, auto value /* (p, x) */) {
-      for (long long x = 0; x < cnt0; ++x)
-        for (int pidx = 0; pidx < r0; ++pidx) {
-          const int k = koff + pidx, ks = (k >> 4) * 4 + ((k & 15) >> 2), slot = k & 3;
-          frag[((size_t)(x >> 4) * KBx * 4 + ks) * 64 + (slot << 4) + (int)(x & 15)] = value(pidx, x);
-        }
-    };
-    double* sb = &hSBf[pl.sSBf * o];
-    const size_t fset = (size_t)ncs0 * KBm * 256;
-    put_cols(sb, KBm, 0, [&](int pi, long long x) { return b0[o].S[(size_t)pi * cnt0 + x]; });
-    put_cols(sb + fset, KBm2, 0, [&](int pi, long long x) { return b0[o].S[(size_t)pi * cnt0 + x]; });
-    put_cols(sb + fset, KBm2, r0p, [&](int pi, long long x) { return -xn0[(size_t)x] * b0[o].S[(size_t)pi * cnt0 + x]; });
+    // axis-1 table of the local lines only
+    std::vector<double>& S1loc = S1locs[o];
+    S1loc.resize((size_t)r1 * nlines);
+    for (int s_ = 0; s_ < r1; ++s_)
+      memcpy(&S1loc[(size_t)s_ * nlines], &b1[o].S[(size_t)s_ * cs.count[1] + line0], sizeof(double) * nlines);
+    const int R = r0 * r1, ncsR = (R + 15) / 16;
+    const size_t nZf = (size_t)ncsR * KBn * 256;              // fragments of Z, of C, images of C^T: same size
+    const size_t ldg = (size_t)ncsR * 16;
+    double *dU0 = dsm + g.U0, *dU1 = dsm + g.U1, *dS0 = dsm + g.S0, *dS1 = dsm + g.S1, *dbeta = dsm + g.beta, *dMb = dsm + g.Mb,
+           *dVb = dsm + g.Vb;
+    int* dmap0 = dints;
+    int* dmap1 = dmap0 + maps0[o].size();
+    dints = dmap1 + maps1[o].size();
+    SBO_HIP(hipMemcpyAsync(dU0, b0[o].U.data(), sizeof(double) * (size_t)n * r0, hipMemcpyHostToDevice, c->stream));
+    SBO_HIP(hipMemcpyAsync(dU1, b1[o].U.data(), sizeof(double) * (size_t)n * r1, hipMemcpyHostToDevice, c->stream));
+    SBO_HIP(hipMemcpyAsync(dS0, b0[o].S.data(), sizeof(double) * (size_t)r0 * cnt0, hipMemcpyHostToDevice, c->stream));
+    SBO_HIP(hipMemcpyAsync(dS1, S1loc.data(), sizeof(double) * (size_t)r1 * nlines, hipMemcpyHostToDevice, c->stream));
+    SBO_HIP(hipMemcpyAsync(dbeta, beta.data(), sizeof(double) * beta.size(), hipMemcpyHostToDevice, c->stream));
+    SBO_HIP(hipMemcpyAsync(dmap0, maps0[o].data(), sizeof(int) * maps0[o].size(), hipMemcpyHostToDevice, c->stream));
+    SBO_HIP(hipMemcpyAsync(dmap1, maps1[o].data(), sizeof(int) * maps1[o].size(), hipMemcpyHostToDevice, c->stream));
+    double* Zf = (double*)c->bl_work.p;
+    double* Cf = Zf + nZf;
+    double* CtA = Cf + nZf;
+    double* G = CtA + nZf;
+    hipLaunchKernelGGL(k_bl_zf, blocks(nZf), dim3(256), 0, c->stream, (const double*)dU0, (const double*)dU1, n, KBn, r0, r1, ncsR, Zf);
+    // C = M Z with the model's packed triangular factor; written as fragments (k = observation) and as images of C^T
+    hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), 1), dim3(256), 0, c->stream,
+                       (const double*)c->Fpk.p + (size_t)o * c->fpk_stride, (size_t)0, (const double*)Zf, (size_t)0, KBn, KBn, ncsR,
+                       Cf, (size_t)0, CtA, 0ll);
+    // G = C^T C  (R x R, row-major)
+    hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), 1), dim3(256), 0, c->stream,
+                       (const double*)CtA, (size_t)0, (const double*)Cf, (size_t)0, KBn, ncsR, ncsR, G, (size_t)0, (double*)nullptr,
+                       (long long)ldg);
+    hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f), dim3(256), 0, c->stream, (const double*)G, (long long)ldg, r1, (const int*)dmap0, k0n,
+                       (const int*)dmap1, k1n, sf2 * sf2, KB0, KB1, (double*)c->bl_T4f.p + pl.sT4f * o);
+    hipLaunchKernelGGL((k_bl_pairs<1>), blocks(pl.sP0f), dim3(256), 0, c->stream, (const double*)dS0, cnt0, (const int*)dmap0, k0n, KB0,
+                       ncs0, (double*)c->bl_P0f.p + pl.sP0f * o);
+    hipLaunchKernelGGL((k_bl_pairs<0>), blocks(pl.sP1A), dim3(256), 0, c->stream, (const double*)dS1, nlines, (const int*)dmap1, k1n, KB1,
+                       nrb, (double*)c->bl_P1A.p + pl.sP1A * o);
+    // mean phases: Mb (forms of alpha, alpha Xn_0, alpha Xn_1) -> Vb = Mb S1 -> A images [V0 | V1;V0 | V1x], B fragments
+    // [S0 | S0;-xn0 S0]
+    hipLaunchKernelGGL(k_bl_mb, blocks((size_t)NB * R), dim3(256), 0, c->stream, (const double*)dU0, (const double*)dU1,
+                       (const double*)dbeta, n, r0, r1, NB, sf2, dMb);
+    hipLaunchKernelGGL(k_bl_vb, blocks((size_t)NB * r0 * nlines), dim3(256), 0, c->stream, (const double*)dMb, (const double*)dS1, r0,
+                       r1, r0u, nlines, NB, dVb);
+    hipLaunchKernelGGL(k_bl_va, blocks(pl.sVA), dim3(256), 0, c->stream, (const double*)dVb, (const double*)(dsm + cnt0), nrb, KBm, KBm2,
+                       r0, r0p, r0u, nlines, (double*)c->bl_VA.p + pl.sVA * o);
+    hipLaunchKernelGGL(k_bl_sbf, blocks(pl.sSBf), dim3(256), 0, c->stream, (const double*)dS0, (const double*)dsm, ncs0, KBm, KBm2, r0,
+                       r0p, cnt0, (double*)c->bl_SBf.p + pl.sSBf * o);
+    SBO_HIP(hipGetLastError());
     pl.r0[o] = r0;
     pl.r1[o] = r1;
-    lap("tables");
   }
-  if ((rc = ensure(c->bl_SBf, sizeof(double) * hSBf.size()))) return rc;     // mean-phase B fragments
-  if ((rc = ensure(c->bl_VA, sizeof(double) * hVA.size()))) return rc;      // mean-phase A images
-  if ((rc = ensure(c->bl_BtA, sizeof(double) * pl.sBtA * q))) return rc;
-  SBO_HIP(hipMemcpyAsync(c->bl_SBf.p, hSBf.data(), sizeof(double) * hSBf.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(c->bl_VA.p, hVA.data(), sizeof(double) * hVA.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipStreamSynchronize(c->stream));      // the host vectors go out of scope
+  lap("enqueue");
+  SBO_HIP(hipStreamSynchronize(c->stream));      // the host staging vectors go out of scope
   lap("upload");
   pl.usable = true;
   pl.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
