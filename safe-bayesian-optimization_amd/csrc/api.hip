@@ -131,6 +131,7 @@ int sbo_shutdown(sbo_ctx* c) {
     if (ev) (void)hipEventDestroy(ev);
   if (c->h_c1) (void)hipHostFree(c->h_c1);
   if (c->h_back) (void)hipHostFree(c->h_back);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SBO_OK;

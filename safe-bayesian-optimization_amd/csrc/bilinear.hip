@@ -240,6 +240,32 @@ __global__ __launch_bounds__(256) void k_bl_pairs(const double* __restrict__ Sta
   }
 }
 
+// Axis table S[p][i] = sig_p sum_c Vs[p][c] T_c(xi_i) from the Chebyshev series of the basis (the arithmetic of
+// bl::axis_basis' own tabulation: three-term recurrence, sum in ascending c, one thread per entry)
+__global__ __launch_bounds__(256) void k_bl_stab(const double* __restrict__ Vs, const double* __restrict__ sig,
+                                                 const double* __restrict__ xn, double a, double b, int rc, int r, long long count,
+                                                 double* __restrict__ S) {
+  const long long total = (long long)r * count;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx / count);
+    const long long i = idx % count;
+    double xi = (2.0 * xn[i] - (a + b)) / (b - a);
+    xi = xi < 1.0 ? xi : 1.0;
+    xi = xi > -1.0 ? xi : -1.0;
+    const double* v = Vs + (size_t)p * rc;
+    double t0 = 1.0, t1 = xi, s_ = 0.0;
+    s_ += v[0] * t0;
+    if (rc > 1) s_ += v[1] * t1;
+    for (int c2 = 2; c2 < rc; ++c2) {
+      const double t = 2.0 * xi * t1 - t0;
+      s_ += v[c2] * t;
+      t0 = t1;
+      t1 = t;
+    }
+    S[idx] = sig[p] * s_;
+  }
+}
+
 // ---- mean-phase operands on the device (the host only supplies the bases and beta) ---------------------------------
 // Mb[b][p r1 + s] = scale sum_j beta_b[j] U0_jp U1_js  (bilinear forms of the mean and of its two gradient sums)
 __global__ __launch_bounds__(256) void k_bl_mb(const double* __restrict__ U0, const double* __restrict__ U1,
@@ -569,7 +595,7 @@ int bilinear_setup(sbo_ctx* c) {
         for (int j = 0; j < n; ++j) col[j] = c->h_Xnorm[(size_t)j * mc.d + a] * mc.vinv[o][a];   // GP_Safe.py:115
         bl::AxisBasis& b = a == 0 ? b0[o] : b1[o];
         const std::vector<double>& xs = a == 0 ? xn0 : xn1_all;
-        ok[t] = bl::axis_basis(n, col.data(), mc.vinv[o][a], xs.data(), (int)xs.size(), b) ? 1 : 0;
+        ok[t] = bl::axis_basis(n, col.data(), mc.vinv[o][a], xs.data(), (int)xs.size(), b, /*tabulate=*/false) ? 1 : 0;
       }
     });
     for (int t = 0; t < 2 * q; ++t)
@@ -617,73 +643,100 @@ int bilinear_setup(sbo_ctx* c) {
   if ((rc = ensure(c->bl_BtA, sizeof(double) * pl.sBtA * q))) return rc;
   const int KBn = mc.npad / 16;
   // host staging that must outlive the asynchronous uploads: one set per output
-  std::vector<std::vector<double>> betas(q), S1locs(q);
+  // Layout of bl_small: [uploaded: xn0 | xn1 (local lines) | per output U0 U1 beta Vs0 sg0 Vs1 sg1 | pair maps (ints)]
+  // [device-made: per output S0 S1 Mb Vb].  The uploaded part is assembled in one pinned staging buffer and goes up
+  // as a single copy (a dozen small copies from pageable memory cost ~30 us each).
   std::vector<std::vector<int>> maps0(q), maps1(q);
-  struct Region { size_t U0, U1, S0, S1, beta, Mb, Vb, end; };
+  struct Region { size_t U0, U1, beta, Vs0, sg0, Vs1, sg1, map0, map1, S0, S1, Mb, Vb; };
   std::vector<Region> reg(q);
-  size_t ndbl = (size_t)cnt0 + (size_t)nlines, nint = 0, work_max = 0;     // xn0 | xn1 (local lines) first
+  size_t ndbl = (size_t)cnt0 + (size_t)nlines, nint = 0, work_max = 0;
   for (int o = 0; o < q; ++o) {
     const int r0 = b0[o].r, r1 = b1[o].r;
     Region& g = reg[o];
     g.U0 = ndbl;
     g.U1 = g.U0 + (size_t)n * r0;
-    g.S0 = g.U1 + (size_t)n * r1;
-    g.S1 = g.S0 + (size_t)r0 * cnt0;
-    g.beta = g.S1 + (size_t)r1 * nlines;
-    g.Mb = g.beta + (size_t)NB * n;
-    g.Vb = g.Mb + (size_t)NB * r0 * r1;
-    g.end = g.Vb + (size_t)NB * r0u * nlines;
-    ndbl = g.end;
+    g.beta = g.U1 + (size_t)n * r1;
+    g.Vs0 = g.beta + (size_t)NB * n;
+    g.sg0 = g.Vs0 + b0[o].Vs.size();
+    g.Vs1 = g.sg0 + (size_t)r0;
+    g.sg1 = g.Vs1 + b1[o].Vs.size();
+    ndbl = g.sg1 + (size_t)r1;
     bl::pair_map(r0, maps0[o]);
     bl::pair_map(r1, maps1[o]);
-    nint += maps0[o].size() + maps1[o].size();
+    g.map0 = nint;
+    g.map1 = nint + maps0[o].size();
+    nint = g.map1 + maps1[o].size();
     const size_t ncsR = ((size_t)r0 * r1 + 15) / 16;
     work_max = std::max(work_max, 3 * ncsR * KBn * 256 + (ncsR * 16) * (ncsR * 16));
   }
-  if ((rc = ensure(c->bl_small, sizeof(double) * ndbl + sizeof(int) * nint))) return rc;
-  if ((rc = ensure(c->bl_work, sizeof(double) * work_max))) return rc;
-  double* dsm = (double*)c->bl_small.p;
-  int* dints = (int*)(dsm + ndbl);
-  std::vector<double> xn1loc(xn1_all.begin() + line0, xn1_all.begin() + line0 + nlines);
-  SBO_HIP(hipMemcpyAsync(dsm, xn0.data(), sizeof(double) * cnt0, hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(dsm + cnt0, xn1loc.data(), sizeof(double) * nlines, hipMemcpyHostToDevice, c->stream));
-  auto blocks = [](size_t total) { return dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16)); };
+  const size_t nint_pad = (nint + 1) / 2 * 2;               // keep the doubles behind the ints 8-byte aligned
+  const size_t up_bytes = sizeof(double) * ndbl + sizeof(int) * nint_pad;
+  size_t ndev = 0;                                          // device-made part, in doubles behind the uploaded bytes
   for (int o = 0; o < q; ++o) {
-    const int r0 = b0[o].r, r1 = b1[o].r, k0n = bl::pair_count(r0), k1n = bl::pair_count(r1);
-    const double sf2 = mc.sf2[o];
+    const int r0 = b0[o].r, r1 = b1[o].r;
+    Region& g = reg[o];
+    g.S0 = ndev;
+    g.S1 = g.S0 + (size_t)r0 * cnt0;
+    g.Mb = g.S1 + (size_t)r1 * nlines;
+    g.Vb = g.Mb + (size_t)NB * r0 * r1;
+    ndev = g.Vb + (size_t)NB * r0u * nlines;
+  }
+  if ((rc = ensure(c->bl_small, up_bytes + sizeof(double) * ndev))) return rc;
+  if ((rc = ensure(c->bl_work, sizeof(double) * work_max))) return rc;
+  if (c->h_stage_bytes < up_bytes) {
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    const size_t want = up_bytes + up_bytes / 2 + 4096;
+    if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) != hipSuccess) return fail(SBO_E_HIP, "hipHostMalloc (K1b staging)");
+    c->h_stage_bytes = want;
+  }
+  double* hsm = (double*)c->h_stage;
+  int* hints = (int*)(hsm + ndbl);
+  double* dsm = (double*)c->bl_small.p;
+  const int* dints = (const int*)(dsm + ndbl);
+  double* ddev = (double*)((char*)c->bl_small.p + up_bytes);
+  memcpy(hsm, xn0.data(), sizeof(double) * cnt0);
+  memcpy(hsm + cnt0, &xn1_all[(size_t)line0], sizeof(double) * nlines);
+  for (int o = 0; o < q; ++o) {
     const Region& g = reg[o];
-    std::vector<double>& beta = betas[o];
-    beta.resize((size_t)NB * n);
+    memcpy(hsm + g.U0, b0[o].U.data(), sizeof(double) * b0[o].U.size());
+    memcpy(hsm + g.U1, b1[o].U.data(), sizeof(double) * b1[o].U.size());
+    double* beta = hsm + g.beta;
     for (int j = 0; j < n; ++j) {
       const double al = c->h_alpha[(size_t)o * mc.npad + j];
       beta[j] = al;
       beta[(size_t)n + j] = al * c->h_Xnorm[(size_t)j * mc.d + 0];
       beta[(size_t)2 * n + j] = al * c->h_Xnorm[(size_t)j * mc.d + 1];
     }
-    // axis-1 table of the local lines only
-    std::vector<double>& S1loc = S1locs[o];
-    S1loc.resize((size_t)r1 * nlines);
-    for (int s_ = 0; s_ < r1; ++s_)
-      memcpy(&S1loc[(size_t)s_ * nlines], &b1[o].S[(size_t)s_ * cs.count[1] + line0], sizeof(double) * nlines);
+    memcpy(hsm + g.Vs0, b0[o].Vs.data(), sizeof(double) * b0[o].Vs.size());
+    memcpy(hsm + g.sg0, b0[o].sig.data(), sizeof(double) * b0[o].sig.size());
+    memcpy(hsm + g.Vs1, b1[o].Vs.data(), sizeof(double) * b1[o].Vs.size());
+    memcpy(hsm + g.sg1, b1[o].sig.data(), sizeof(double) * b1[o].sig.size());
+    memcpy(hints + g.map0, maps0[o].data(), sizeof(int) * maps0[o].size());
+    memcpy(hints + g.map1, maps1[o].data(), sizeof(int) * maps1[o].size());
+  }
+  SBO_HIP(hipMemcpyAsync(dsm, hsm, up_bytes, hipMemcpyHostToDevice, c->stream));
+  auto blocks = [](size_t total) { return dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16)); };
+  for (int o = 0; o < q; ++o) {
+    const int r0 = b0[o].r, r1 = b1[o].r, k0n = bl::pair_count(r0), k1n = bl::pair_count(r1);
+    const double sf2 = mc.sf2[o];
+    const Region& g = reg[o];
     const int R = r0 * r1, ncsR = (R + 15) / 16;
     const size_t nZf = (size_t)ncsR * KBn * 256;              // fragments of Z, of C, images of C^T: same size
     const size_t ldg = (size_t)ncsR * 16;
-    double *dU0 = dsm + g.U0, *dU1 = dsm + g.U1, *dS0 = dsm + g.S0, *dS1 = dsm + g.S1, *dbeta = dsm + g.beta, *dMb = dsm + g.Mb,
-           *dVb = dsm + g.Vb;
-    int* dmap0 = dints;
-    int* dmap1 = dmap0 + maps0[o].size();
-    dints = dmap1 + maps1[o].size();
-    SBO_HIP(hipMemcpyAsync(dU0, b0[o].U.data(), sizeof(double) * (size_t)n * r0, hipMemcpyHostToDevice, c->stream));
-    SBO_HIP(hipMemcpyAsync(dU1, b1[o].U.data(), sizeof(double) * (size_t)n * r1, hipMemcpyHostToDevice, c->stream));
-    SBO_HIP(hipMemcpyAsync(dS0, b0[o].S.data(), sizeof(double) * (size_t)r0 * cnt0, hipMemcpyHostToDevice, c->stream));
-    SBO_HIP(hipMemcpyAsync(dS1, S1loc.data(), sizeof(double) * (size_t)r1 * nlines, hipMemcpyHostToDevice, c->stream));
-    SBO_HIP(hipMemcpyAsync(dbeta, beta.data(), sizeof(double) * beta.size(), hipMemcpyHostToDevice, c->stream));
-    SBO_HIP(hipMemcpyAsync(dmap0, maps0[o].data(), sizeof(int) * maps0[o].size(), hipMemcpyHostToDevice, c->stream));
-    SBO_HIP(hipMemcpyAsync(dmap1, maps1[o].data(), sizeof(int) * maps1[o].size(), hipMemcpyHostToDevice, c->stream));
+    double *dU0 = dsm + g.U0, *dU1 = dsm + g.U1, *dbeta = dsm + g.beta;
+    double *dS0 = ddev + g.S0, *dS1 = ddev + g.S1, *dMb = ddev + g.Mb, *dVb = ddev + g.Vb;
+    const int *dmap0 = dints + g.map0, *dmap1 = dints + g.map1;
     double* Zf = (double*)c->bl_work.p;
     double* Cf = Zf + nZf;
     double* CtA = Cf + nZf;
     double* G = CtA + nZf;
+    // axis tables from the bases' Chebyshev series: all positions of axis 0, the local lines of axis 1
+    hipLaunchKernelGGL(k_bl_stab, blocks((size_t)r0 * cnt0), dim3(256), 0, c->stream, (const double*)(dsm + g.Vs0),
+                       (const double*)(dsm + g.sg0), (const double*)dsm, b0[o].a, b0[o].b, b0[o].rc, r0, cnt0, dS0);
+    hipLaunchKernelGGL(k_bl_stab, blocks((size_t)r1 * nlines), dim3(256), 0, c->stream, (const double*)(dsm + g.Vs1),
+                       (const double*)(dsm + g.sg1), (const double*)(dsm + cnt0), b1[o].a, b1[o].b, b1[o].rc, r1, nlines, dS1);
     hipLaunchKernelGGL(k_bl_zf, blocks(nZf), dim3(256), 0, c->stream, (const double*)dU0, (const double*)dU1, n, KBn, r0, r1, ncsR, Zf);
     // C = M Z with the model's packed triangular factor; written as fragments (k = observation) and as images of C^T
     hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), 1), dim3(256), 0, c->stream,

@@ -68,13 +68,18 @@ inline void jacobi_svd(double* G, int rows, int cols, std::vector<double>& V, st
 
 struct AxisBasis {
   int r = 0, rc = 0;
+  double a = 0.0, b = 0.0; // interval of the axis (normalised coordinates) the Chebyshev series lives on
   std::vector<double> U;   // [n x r] column-major, orthonormal columns
-  std::vector<double> S;   // [r x count] row-major: coordinates of every grid position of the axis
+  std::vector<double> S;   // [r x count] row-major: coordinates of every grid position of the axis (when tabulated)
+  std::vector<double> Vs;  // [r x rc]: Chebyshev coefficients of coordinate p;  S[p][i] = sig[p] sum_c Vs[p][c] T_c(xi_i)
+  std::vector<double> sig; // [r]
 };
 
 // Basis of the family f_j(xn) = exp(-1/2 (xn vinv - As_j)^2), j < n, on the positions xn[0..count).
 // Returns false when the interpolant does not converge within kMaxCheb terms or the rank exceeds kMaxRank.
-inline bool axis_basis(int n, const double* As_col, double vinv, const double* xn, int count, AxisBasis& out) {
+// tabulate = false leaves S empty: the caller evaluates the series itself (the device build does, from Vs / sig / a / b).
+inline bool axis_basis(int n, const double* As_col, double vinv, const double* xn, int count, AxisBasis& out,
+                       bool tabulate = true) {
   double a = xn[0], b = xn[0];
   for (int i = 1; i < count; ++i) { a = std::min(a, xn[i]); b = std::max(b, xn[i]); }
   if (!(b > a)) return false;
@@ -95,14 +100,19 @@ inline bool axis_basis(int n, const double* As_col, double vinv, const double* x
     }
     coef.assign((size_t)rc * n, 0.0);   // column-major [n x rc]: column p = coefficient p of every f_j
     double tail = 0.0;
-    for (int p = 0; p < rc; ++p)
-      for (int j = 0; j < n; ++j) {
-        double s = 0;
-        for (int k = 0; k < rc; ++k) s += fn[(size_t)j * rc + k] * cth[(size_t)p * rc + k];
-        s *= (p == 0 ? 1.0 : 2.0) / rc;
-        coef[(size_t)p * n + j] = s;
-        if (p >= rc - 4) tail = std::max(tail, std::fabs(s));
-      }
+    // the last four coefficients first: a trial that has not converged is dropped without the other rc - 4 sums
+    for (int pass = 0; pass < 2; ++pass) {
+      const int p0 = pass == 0 ? rc - 4 : 0, p1 = pass == 0 ? rc : rc - 4;
+      for (int p = p0; p < p1; ++p)
+        for (int j = 0; j < n; ++j) {
+          double s = 0;
+          for (int k = 0; k < rc; ++k) s += fn[(size_t)j * rc + k] * cth[(size_t)p * rc + k];
+          s *= (p == 0 ? 1.0 : 2.0) / rc;
+          coef[(size_t)p * n + j] = s;
+          if (p >= rc - 4) tail = std::max(tail, std::fabs(s));
+        }
+      if (pass == 0 && tail > 1e-14) break;
+    }
     if (tail <= 1e-14) break;   // (the computed coefficients bottom out at ~1e-15; they fall by > 10x per term there)
     if (trial == kMaxCheb) return false;
   }
@@ -179,6 +189,16 @@ inline bool axis_basis(int n, const double* As_col, double vinv, const double* x
     const double inv = 1.0 / sig[c2];
     for (int j = 0; j < n; ++j) out.U[(size_t)p * n + j] = Ucols[(size_t)c2 * n + j] * inv;
   }
+  out.a = a;
+  out.b = b;
+  out.Vs.assign((size_t)r * rc, 0.0);
+  out.sig.assign(r, 0.0);
+  for (int p = 0; p < r; ++p) {
+    out.sig[p] = sig[order[p]];
+    for (int c2 = 0; c2 < rc; ++c2) out.Vs[(size_t)p * rc + c2] = V[(size_t)order[p] * rc + c2];
+  }
+  out.S.clear();
+  if (!tabulate) return true;
   // S[p][i] = sigma_p sum_c V[c][p] T_c(xi_i), Chebyshev values by the three-term recurrence
   out.S.assign((size_t)r * count, 0.0);
   std::vector<double> Tc(rc);

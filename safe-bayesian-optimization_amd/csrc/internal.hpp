@@ -117,6 +117,8 @@ struct sbo_ctx {
   std::vector<long long> first_of;   // [world + 1] flat offsets of the rank shards
   unsigned long long* h_c1 = nullptr;     // pinned host copy of the C1 keys (global u*, L, radius) of the running sweep
   bool c1_pending = false;                // the read-back of h_c1 has been enqueued (event ev[5]) but not yet waited for
+  void* h_stage = nullptr;                // pinned staging of the K1b table build's single upload
+  size_t h_stage_bytes = 0;
   unsigned char* h_back = nullptr;        // pinned host landing area of the end-of-sweep read-back (scalars + Lipschitz keys)
   int last_sweep = 0;  // 1 safeopt, 2 goose (what the masks hold)
   bool masks_valid = false;
