@@ -582,6 +582,47 @@ def test_full_size_properties_config_B(engine):
     assert res2["minimizer_index"] == res["minimizer_index"] and np.array_equal(res2["count_G"], res["count_G"])
 
 
+def test_full_size_goose_properties_config_B(engine):
+    """GoOSE iteration of BASELINE.json configs[1] at full size (2048^2, n = 128): the optimistic set of the transform path
+    equals the pruned exact pair evaluation on all 4.2 M candidates, the oracle's predicate re-decides a sample of U on both
+    sides of the boundary of O_1, and the arg-min outputs are exact functions of the device bounds and masks."""
+    cfg = synthetic.make_config("B")
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], cfg["count"]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    out = {}
+    try:
+        for pairs in (0, 1):
+            engine.set_option("goose_pairs", pairs)
+            res = engine.sweep_goose(cfg["b"], want_masks=True)
+            out[pairs] = (res, engine.mask("O", 1))
+    finally:
+        engine.set_option("goose_pairs", 0)
+    res, O = out[0]
+    assert np.array_equal(O, out[1][1])
+    for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min"):
+        assert res[k] == out[1][0][k], k
+    S, U = engine.mask("S"), engine.mask("U")
+    lcb0, lcb1, ucb1 = engine.bounds(cfg["b"], 0, "lcb"), engine.bounds(cfg["b"], 1, "lcb"), engine.bounds(cfg["b"], 1, "ucb")
+    assert np.array_equal(S, lcb1 >= 0) and np.array_equal(U, lcb1 <= 0) and not (O & ~U).any()
+    assert res["count_O"][0] == O.sum() and res["count_S"] == S.sum()
+    assert res["safe_min_index"] == int(np.argmin(np.where(S, lcb0, np.inf)))      # models/GoOSE.py:69-76 on the grid
+    assert res["target_index"] == int(np.argmin(np.where(O, lcb0, np.inf)))        # models/GoOSE.py:100-112
+    pts = oracle.grid_points(lo, hi, count)
+    tgt = pts[res["target_index"]]
+    dist = np.sqrt(((pts - tgt[None, :]) ** 2).sum(axis=1))
+    assert res["explore_index"] == int(np.argmin(np.where(S, dist, np.inf)))       # models/GoOSE.py:116-119
+    rng = np.random.default_rng(9)
+    Lq = res["L"][cfg["q"] - 1]
+    edge = np.nonzero(O[:-1] != O[1:])[0]
+    pick = np.concatenate([rng.choice(np.nonzero(U)[0], size=24, replace=False), rng.choice(edge, size=24, replace=False)])
+    src, usrc = pts[S], ucb1[S]
+    for hidx in pick:
+        if U[hidx]:
+            want = bool(np.any(usrc - Lq * oracle.shifted_norm(src, pts[hidx][None, :]) >= 0))
+            assert bool(O[hidx]) == want, int(hidx)
+
+
 def test_full_size_properties_config_H(engine):
     """The headline configuration (4096^2 grid, n = 512, fp64) at full size on one GPU: the masks are exact functions of
     the device posterior, the posterior matches the oracle on a random subset and the two posterior kernels agree on the
