@@ -318,9 +318,46 @@ __global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, 
   }
 }
 
-// generic masked arg-max / arg-min of a value array, plus the mask population
-template <typename T, bool MAX>
-__global__ __launch_bounds__(256) void k_arg_masked(const T* __restrict__ val, const uint8_t* __restrict__ mask, long long n,
+// value sources of the masked arg-reductions: an array, or the value computed for the candidates whose mask byte is set
+// only (no pass over all candidates to fill an array first)
+template <typename T>
+struct ValArray {
+  const T* p;
+  __device__ __forceinline__ T operator()(long long g) const { return p[g]; }
+};
+template <typename T>
+struct ValLcb {            // lcb_0 = mean_0 - b sqrt(var_0), models/GoOSE.py:72, models/GP_TR.py:45
+  const T* m;
+  const T* v;
+  T b;
+  __device__ __forceinline__ T operator()(long long g) const {
+    T lcb, ucb;
+    lcb_ucb(m[g], v[g], b, lcb, ucb);
+    return lcb;
+  }
+};
+template <typename T, int D>
+struct ValDist {           // Euclidean distance to the target, as scipy.spatial.distance.cdist computes it (models/GoOSE.py:117)
+  CandSpec cs;
+  const double* target;
+  __device__ __forceinline__ T operator()(long long g) const {
+    double x[D];
+    cand_coords<D>(cs, g, x);
+    double ss = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      if (a < cs.d) {
+        const double df = x[a] - target[a];
+        ss += df * df;
+      }
+    }
+    return (T)sqrt(ss);
+  }
+};
+
+// generic masked arg-max / arg-min of a value source, plus the mask population
+template <typename T, bool MAX, typename V>
+__global__ __launch_bounds__(256) void k_arg_masked(const V val, const uint8_t* __restrict__ mask, long long n,
                                                     long long first, Best* partial) {
   Best best{0.0, -1};
   long long cnt = 0;
@@ -336,7 +373,7 @@ __global__ __launch_bounds__(256) void k_arg_masked(const T* __restrict__ val, c
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       set[k] = tile_byte(w, k, lane);
-      v[k] = set[k] ? val[base + k * 64 + lane] : (T)0;
+      v[k] = set[k] ? val(base + k * 64 + lane) : (T)0;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -350,7 +387,7 @@ __global__ __launch_bounds__(256) void k_arg_masked(const T* __restrict__ val, c
   for (long long g = ntiles * 512 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
     if (mask[g]) {
       ++cnt;
-      const Best cand{(double)val[g], first + g};
+      const Best cand{(double)val(g), first + g};
       if (better<MAX>(cand, best)) best = cand;
     }
   }
@@ -770,7 +807,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   for (int cc = 1; cc < q; ++cc) {
     const uint8_t* G = (const uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
     if (n > 0)
-      hipLaunchKernelGGL((k_arg_masked<T, true>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->var.p, G, n,
+      hipLaunchKernelGGL((k_arg_masked<T, true, ValArray<T>>), dim3(nb), dim3(256), 0, c->stream, ValArray<T>{(const T*)c->var.p}, G, n,
                          (long long)c->cs.first, (Best*)c->partial.p);
     hipLaunchKernelGGL((k_arg_final<true>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0,
                        sc, cc, &sc->count_set[cc - 1]);
@@ -1061,17 +1098,25 @@ static int goose_sets_d(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uin
   return fail(SBO_E_UNSUPPORTED, "unsupported padded dimension");
 }
 
+// arg-min over S_t of the distance to the target (explore_safeset, models/GoOSE.py:116-119) -> partials for k_arg_final
 template <typename T>
-static int launch_dist_to(sbo_ctx* c, const double* dev_target, T* out) {
+static void launch_argmin_dist(sbo_ctx* c, const double* dev_target, int nb) {
   const long long n = c->cs.n_local;
-  const int nb = reduce_blocks(c);
+  const uint8_t* S = (const uint8_t*)c->maskS.p;
   switch (c->mc.dpad) {
-    case 2: hipLaunchKernelGGL((k_dist_to<T, 2>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, dev_target, out); break;
-    case 4: hipLaunchKernelGGL((k_dist_to<T, 4>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, dev_target, out); break;
-    default: hipLaunchKernelGGL((k_dist_to<T, 8>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, dev_target, out); break;
+    case 2:
+      hipLaunchKernelGGL((k_arg_masked<T, false, ValDist<T, 2>>), dim3(nb), dim3(256), 0, c->stream, ValDist<T, 2>{c->cs, dev_target}, S, n,
+                         (long long)c->cs.first, (Best*)c->partial.p);
+      break;
+    case 4:
+      hipLaunchKernelGGL((k_arg_masked<T, false, ValDist<T, 4>>), dim3(nb), dim3(256), 0, c->stream, ValDist<T, 4>{c->cs, dev_target}, S, n,
+                         (long long)c->cs.first, (Best*)c->partial.p);
+      break;
+    default:
+      hipLaunchKernelGGL((k_arg_masked<T, false, ValDist<T, 8>>), dim3(nb), dim3(256), 0, c->stream, ValDist<T, 8>{c->cs, dev_target}, S, n,
+                         (long long)c->cs.first, (Best*)c->partial.p);
+      break;
   }
-  SBO_HIP(hipGetLastError());
-  return SBO_OK;
 }
 
 // GoOSE iteration (models/GoOSE.py:63-119, test/test_GoOSE.py:151-162) on the resident candidates.  Ranks > 1: C1 + C2
@@ -1110,19 +1155,16 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     if ((rc = goose_sets_d<T>(c, o, cc, src, O))) return rc;
   }
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
-  // value array for the arg-min reductions (after the expander transform, which uses the same scratch buffer)
-  if ((rc = ensure(c->dist2, sizeof(double) * (size_t)std::max<long long>(n, 1)))) return rc;
-  T* lcb0 = (T*)c->dist2.p;
-  if (n > 0) {
-    hipLaunchKernelGGL((k_lcb0<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b, lcb0);
-    hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
+  // arg-min of lcb_0 over S_t and over every O_c: the bound is computed for the masked candidates only
+  const ValLcb<T> lcb0{(const T*)c->mean.p, (const T*)c->var.p, (T)o->b};
+  if (n > 0)
+    hipLaunchKernelGGL((k_arg_masked<T, false, ValLcb<T>>), dim3(nb), dim3(256), 0, c->stream, lcb0, (const uint8_t*)c->maskS.p, n,
                        (long long)c->cs.first, (Best*)c->partial.p);
-  }
   hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0, (long long*)nullptr);
   for (int cc = 1; cc < q; ++cc) {
     const uint8_t* O = (const uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
     if (n > 0)
-      hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, O, n,
+      hipLaunchKernelGGL((k_arg_masked<T, false, ValLcb<T>>), dim3(nb), dim3(256), 0, c->stream, lcb0, O, n,
                          (long long)c->cs.first, (Best*)c->partial.p);
     hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, cc,
                        &sc->count_set[cc - 1]);
@@ -1142,9 +1184,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
       default: hipLaunchKernelGGL((k_pick_target<8>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
     }
     if (n > 0) {
-      if ((rc = launch_dist_to<T>(c, dev_t, lcb0))) return rc;
-      hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
-                         (long long)c->cs.first, (Best*)c->partial.p);
+      launch_argmin_dist<T>(c, dev_t, nb);
     }
     hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
                        kArgSlots - 1, (long long*)nullptr);
@@ -1190,9 +1230,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     } else {
     SBO_HIP(hipMemcpyAsync(dev_t, res->target_x, sizeof(double) * SBO_MAX_D, hipMemcpyHostToDevice, c->stream));
     if (n > 0) {
-      if ((rc = launch_dist_to<T>(c, dev_t, lcb0))) return rc;
-      hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskS.p, n,
-                         (long long)c->cs.first, (Best*)c->partial.p);
+      launch_argmin_dist<T>(c, dev_t, nb);
     }
     hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
                        kArgSlots - 1, (long long*)nullptr);
@@ -1235,20 +1273,18 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   if ((rc = sweep_common_front<T>(c, o))) return rc;
-  if ((rc = ensure(c->dist2, sizeof(double) * (size_t)std::max<long long>(n, 1)))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
-  T* lcb0 = (T*)c->dist2.p;
   double* dev_x0 = (double*)c->scal.p + 256;
   SBO_HIP(hipMemcpyAsync(dev_x0, x0, sizeof(double) * c->cs.d, hipMemcpyHostToDevice, c->stream));
   if (n > 0) {
-    hipLaunchKernelGGL((k_lcb0<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b, lcb0);
     switch (c->mc.dpad) {
       case 2: hipLaunchKernelGGL((k_ball_mask<2>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, (const uint8_t*)c->maskS.p, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
       case 4: hipLaunchKernelGGL((k_ball_mask<4>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, (const uint8_t*)c->maskS.p, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
       default: hipLaunchKernelGGL((k_ball_mask<8>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, (const uint8_t*)c->maskS.p, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
     }
-    hipLaunchKernelGGL((k_arg_masked<T, false>), dim3(nb), dim3(256), 0, c->stream, (const T*)lcb0, (const uint8_t*)c->maskM.p, n,
+    hipLaunchKernelGGL((k_arg_masked<T, false, ValLcb<T>>), dim3(nb), dim3(256), 0, c->stream,
+                       ValLcb<T>{(const T*)c->mean.p, (const T*)c->var.p, (T)o->b}, (const uint8_t*)c->maskM.p, n,
                        (long long)c->cs.first, (Best*)c->partial.p);
   }
   hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0, &sc->count_M);

@@ -781,15 +781,6 @@ __global__ void k_ball_mask(const CandSpec cs, long long n, const uint8_t* __res
   }
 }
 
-// value arrays for the arg-reductions of the GoOSE sweep
-template <typename T>
-__global__ void k_lcb0(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b, T* __restrict__ out) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    T lcb, ucb;
-    lcb_ucb(mean0[g], var0[g], b, lcb, ucb);
-    out[g] = lcb;
-  }
-}
 // Single rank: the target of the explore step chosen on the device (min over the constraints' targets, the first minimum
 // wins -- models/GoOSE.py:110-112) and its coordinates parked for k_dist_to, so the sweep needs one host round trip.
 template <int D>
@@ -805,22 +796,5 @@ __global__ void k_pick_target(const CandSpec cs, const SweepScalars* sc, int q, 
   if (best_c) cand_coords<D>(cs, sc->arg_idx[best_c] - cs.first, x);
 #pragma unroll
   for (int a = 0; a < D; ++a) target[a] = x[a];
-}
-// Euclidean distance to the target, as scipy.spatial.distance.cdist computes it (models/GoOSE.py:117)
-template <typename T, int D>
-__global__ void k_dist_to(const CandSpec cs, long long n, const double* __restrict__ target, T* __restrict__ out) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
-    double x[D];
-    cand_coords<D>(cs, g, x);
-    double ss = 0.0;
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-      if (a < cs.d) {
-        const double df = x[a] - target[a];
-        ss += df * df;
-      }
-    }
-    out[g] = (T)sqrt(ss);
-  }
 }
 
