@@ -1075,9 +1075,25 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
       bmin = (const double*)c->blockmin.p;
     }
     const long long len0 = d >= 2 ? count0 : n, nl = n / len0;    // positions per line / local lines
-    hipLaunchKernelGGL(k_pdt_decide, dim3((unsigned)((len0 + 255) / 256), (unsigned)std::min<long long>(nl, 65535)), dim3(256), 0, c->stream,
-                       (const double*)pin, nl, (int)len0, goff / len0, goff, d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, (const uint8_t*)c->maskU.p,
-                       (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, O, (long long*)c->amb.p, cg, pc_lo, pc_hi, bmin, blk);
+    long long* slist = nullptr;                    // open points of the verdict: listed and scanned by groups of lanes
+    if (bmin && blk <= 64 && c->scan_waves) {
+      if ((rc = ensure(c->scanlist, sizeof(long long) * (size_t)n))) return rc;
+      slist = (long long*)c->scanlist.p;
+    }
+    hipLaunchKernelGGL(k_pdt_decide, dim3((unsigned)((len0 + 255) / 256), (unsigned)std::min<long long>((nl + kDecideLines - 1) / kDecideLines, 65535)),
+                       dim3(256), 0, c->stream, (const double*)pin, nl, (int)len0, goff / len0, goff, d >= 2 ? stride : 1, last_cnt, last_h, d,
+                       xscale, (const uint8_t*)c->maskU.p, (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, O, (long long*)c->amb.p, cg,
+                       pc_lo, pc_hi, bmin, blk, slist);
+    if (slist) {
+      if (c->scan_waves == 32 || c->scan_waves == 64)
+        hipLaunchKernelGGL((k_pdt_scan_list<32>), dim3(2048), dim3(256), 0, c->stream, (const double*)pin, goff, stride, last_cnt, last_h, d,
+                           xscale, (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, O, (long long*)c->amb.p, bmin, blk,
+                           (const long long*)slist);
+      else
+        hipLaunchKernelGGL((k_pdt_scan_list<16>), dim3(2048), dim3(256), 0, c->stream, (const double*)pin, goff, stride, last_cnt, last_h, d,
+                           xscale, (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, O, (long long*)c->amb.p, bmin, blk,
+                           (const long long*)slist);
+    }
     hipLaunchKernelGGL((k_goose_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, css, W,
                        (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, (const long long*)c->amb.p, O);
     SBO_HIP(hipGetLastError());

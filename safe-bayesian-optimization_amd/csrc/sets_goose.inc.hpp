@@ -629,51 +629,164 @@ __global__ __launch_bounds__(256) void k_pdt_scan(const double* __restrict__ Pin
   }
 }
 
-// last axis + verdict for the own U points (window offset goff); ambiguous ones are listed for the exact recheck
+// last axis + verdict for the own U points (window offset goff); ambiguous ones are listed for the exact recheck.
+// With a scan list (grids with block minima) the points the coarse bounds leave open are collected in LDS, appended
+// with one atomic per workgroup and scanned by k_pdt_scan_list; otherwise by their own thread.
 __global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ Pin, long long nl, int len0, long long line0,
                                                     long long goff, long long stride,
                                                     int cnt, double h, int d, double xscale, const uint8_t* __restrict__ U,
                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc, int c,
                                                     uint8_t* __restrict__ O, long long* __restrict__ amb, const CoarseGrid cg,
                                                     const double* __restrict__ PcLo, const double* __restrict__ PcHi,
-                                                    const double* __restrict__ Bmin, int blk) {
+                                                    const double* __restrict__ Bmin, int blk, long long* __restrict__ scanlist) {
+  __shared__ long long sl[256 * kDecideLines];
+  __shared__ int scnt;
+  __shared__ long long sbase;
   const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
   const bool anyS = sc->count_S > 0;
-  // launch as k_edt_decide: x over the positions of a grid line, y over the local lines (no division per candidate)
+  const bool listing = scanlist != nullptr && Bmin != nullptr && cnt > 1;
+  // launch as k_edt_decide: x over the positions of a grid line, y over blocks of kDecideLines local lines
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i0 >= len0) return;
-  for (long long ln = blockIdx.y; ln < nl; ln += gridDim.y) {
-    const long long g = ln * len0 + i0;
-    uint8_t out = 0;
-    if (U[g]) {
-      if (!pp.L_positive) {
-        out = anyS;                                  // radius unbounded: any source covers (ucb_c >= 0 on every source)
-      } else {
-        const long long gg = goff + g;
-        long long f = line0 + ln, cell = i0 / kCoarse, ccs = cg.ccount[0];
-        int ia = 0;                                  // index along the last axis (inside the window)
-        for (int a = 1; a < d; ++a) {
-          const long long ix = a == d - 1 ? f : f % cg.count[a];
-          f = a == d - 1 ? 0 : f / cg.count[a];
-          cell += (ix / kCoarse) * ccs;
-          ccs *= cg.ccount[a];
-          ia = (int)ix;
-        }
-        if (cg.enabled) {
-          if (PcHi[cell] < -pp.band) { O[g] = 1; continue; }     // covered wherever it sits in its cell
-          if (PcLo[cell] > pp.band) { O[g] = 0; continue; }      // out of every source's reach
-        }
-        const double best = cnt <= 1 ? Pin[gg]
-                            : Bmin  ? pdt_scan_blocked(Pin, Bmin, gg - (long long)ia * stride, stride, cnt, ia, h, pp, blk)
-                                    : pdt_scan_point(Pin, gg, stride, cnt, ia, h, pp, true);
-        if (best < -pp.band) out = 1;
-        else if (best <= pp.band) {
-          const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
-          amb[slot] = g;
+  const bool active = i0 < len0;
+  const long long nlb = (nl + kDecideLines - 1) / kDecideLines;
+  for (long long lb = blockIdx.y; lb < nlb; lb += gridDim.y) {
+    if (threadIdx.x == 0) scnt = 0;
+    __syncthreads();
+    for (long long ln = lb * kDecideLines; active && ln < nl && ln < (lb + 1) * kDecideLines; ++ln) {
+      const long long g = ln * len0 + i0;
+      uint8_t out = 0;
+      if (U[g]) {
+        if (!pp.L_positive) {
+          out = anyS;                                  // radius unbounded: any source covers (ucb_c >= 0 on every source)
+        } else {
+          const long long gg = goff + g;
+          long long f = line0 + ln, cell = i0 / kCoarse, ccs = cg.ccount[0];
+          int ia = 0;                                  // index along the last axis (inside the window)
+          for (int a = 1; a < d; ++a) {
+            const long long ix = a == d - 1 ? f : f % cg.count[a];
+            f = a == d - 1 ? 0 : f / cg.count[a];
+            cell += (ix / kCoarse) * ccs;
+            ccs *= cg.ccount[a];
+            ia = (int)ix;
+          }
+          if (cg.enabled) {
+            if (PcHi[cell] < -pp.band) { O[g] = 1; continue; }     // covered wherever it sits in its cell
+            if (PcLo[cell] > pp.band) { O[g] = 0; continue; }      // out of every source's reach
+          }
+          if (listing) {
+            sl[atomicAdd(&scnt, 1)] = g;
+            O[g] = 0;
+            continue;
+          }
+          const double best = cnt <= 1 ? Pin[gg]
+                              : Bmin  ? pdt_scan_blocked(Pin, Bmin, gg - (long long)ia * stride, stride, cnt, ia, h, pp, blk)
+                                      : pdt_scan_point(Pin, gg, stride, cnt, ia, h, pp, true);
+          if (best < -pp.band) out = 1;
+          else if (best <= pp.band) {
+            const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
+            amb[slot] = g;
+          }
         }
       }
+      O[g] = out;
     }
-    O[g] = out;
+    __syncthreads();
+    const int cntl = scnt;
+    if (cntl > 0) {
+      if (threadIdx.x == 0) sbase = (long long)atomicAdd((unsigned long long*)&sc->n_scan, (unsigned long long)cntl);
+      __syncthreads();
+      for (int k = threadIdx.x; k < cntl; k += blockDim.x) scanlist[sbase + k] = sl[k];
+    }
+    __syncthreads();
+  }
+}
+
+// Last-axis scan + verdict of the listed U points, one group of GL lanes per point (the power-transform counterpart of
+// k_edt_scan_list): the lanes take GL block bounds, or GL steps of a block, at a time and combine with group minima --
+// the candidates and arithmetic of pdt_scan_blocked, its chain of dependent loads cut to a handful.
+template <int GL>
+__global__ __launch_bounds__(256) void k_pdt_scan_list(const double* __restrict__ Pin, long long goff, long long stride, int cnt,
+                                                       double h, int d, double xscale, const unsigned long long* Lkeys, int lidx,
+                                                       SweepScalars* sc, int c, uint8_t* __restrict__ O, long long* __restrict__ amb,
+                                                       const double* __restrict__ Bmin, int blk,
+                                                       const long long* __restrict__ scanlist) {
+  const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
+  const long long nscan = sc->n_scan;
+  const int lane = threadIdx.x & (GL - 1);
+  const int sub = (threadIdx.x & 63) / GL;
+  const long long ngroups = (long long)gridDim.x * (blockDim.x / GL);
+  const int nblk = (cnt + blk - 1) / blk;
+  auto group_min = [&](double v) {
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+  };
+  auto group_ballot = [&](bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (GL == 64) return m;
+    return (m >> ((GL & 63) * sub)) & ((1ull << (GL & 63)) - 1ull);
+  };
+  // blocks further than this cannot hold a source that brings a value below the band
+  const double reach_steps = sqrt(pp.rmax2 + pp.band) / h;
+  const int kmax = (int)fmin((double)nblk, floor(reach_steps / (double)blk) + 2.0);
+  for (long long qi = (long long)blockIdx.x * (blockDim.x / GL) + threadIdx.x / GL; qi < nscan; qi += ngroups) {
+    const long long g = scanlist[qi];
+    const long long gg = goff + g, p = gg % stride;
+    const int ia = (int)((gg / stride) % cnt), b0 = ia / blk;
+    double best = Pin[(long long)ia * stride + p];
+    const int blo = b0 - kmax > 0 ? b0 - kmax : 0, bhi = b0 + kmax < nblk - 1 ? b0 + kmax : nblk - 1;
+    auto bound_of = [&](int bb) {       // bound of block bb for this lane (inf outside the reach / the axis)
+      if (bb < blo || bb > bhi) return kInfD;
+      const int gap = bb == b0 ? 0 : (bb < b0 ? ia - (bb * blk + blk - 1) : bb * blk - ia);
+      const double dg = h * (double)gap;
+      const double e = dg * dg;
+      if (e - pp.rmax2 > pp.band) return kInfD;
+      return Bmin[(long long)bb * stride + p] + e;
+    };
+    auto scan_block = [&](int bb) {     // the group: the steps of block bb, GL at a time
+      double cnd = kInfD;
+#pragma unroll 4
+      for (int s0 = 0; s0 < blk; s0 += GL) {
+        const int jn = bb * blk + s0 + lane;
+        if (s0 + lane < blk && jn < cnt) {
+          const double dt = h * (double)(jn > ia ? jn - ia : ia - jn);
+          const double v = Pin[(long long)jn * stride + p] + dt * dt;
+          cnd = v < cnd ? v : cnd;
+        }
+      }
+      cnd = group_min(cnd);
+      best = cnd < best ? cnd : best;
+    };
+    // pass A: the block with the smallest bound
+    double lb_min = kInfD;
+    int b_min = -1;
+    for (int base = blo; base <= bhi; base += GL) {
+      const double lb = bound_of(base + lane);
+      const double m = group_min(lb);
+      if (m < lb_min) {
+        lb_min = m;
+        const unsigned long long who = group_ballot(lb == m);
+        b_min = base + (int)(__ffsll((long long)who) - 1);
+      }
+    }
+    if (b_min >= 0 && lb_min < best) scan_block(b_min);
+    // pass B: every other block whose bound still beats the running minimum, until the verdict is sure
+    for (int base = blo; base <= bhi && !(best < -pp.band); base += GL) {
+      const double lb = bound_of(base + lane);
+      unsigned long long todo = group_ballot(lb < best && base + lane != b_min);
+      while (todo && !(best < -pp.band)) {
+        const int l = (int)(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const double lbl = __shfl(lb, l + GL * sub);
+        if (lbl < best) scan_block(base + l);
+      }
+    }
+    if (lane == 0) {
+      uint8_t out = 0;
+      if (best < -pp.band) out = 1;
+      else if (best <= pp.band) amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
+      O[g] = out;
+    }
   }
 }
 
