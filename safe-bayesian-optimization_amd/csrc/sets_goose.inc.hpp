@@ -256,19 +256,34 @@ __global__ __launch_bounds__(256) void k_pdt_coarse_scan(const double* __restric
     const long long g = upper ? g2 - nc : g2;
     const double* Pin = upper ? HiIn : LoIn;
     const int ia = (int)((g / stride) % cnt);
+    // four steps (eight loads) per round of exit tests, as edt_scan_point: a step examined beyond an exit cannot lower
+    // the minimum (its candidate is >= dd^2 - rmax2 >= best) or only between values above the band
     double best = kInfD;
-    for (int t = 0; t < cnt; ++t) {
-      const double steps_lo = t == 0 ? 0.0 : (double)((t - 1) * kCoarse + 1);
-      const double steps = upper ? (double)((t + 1) * kCoarse - 1) : steps_lo;
-      const double dl = h * steps_lo, dd = h * steps;
-      const double floor_ = dl * dl - pp.rmax2;          // no source that far can bring any candidate below the band
-      if (floor_ > pp.band || dd * dd - pp.rmax2 >= best) break;
-      const bool lo_ok = ia - t >= 0, hi_ok = ia + t < cnt;
-      if (!lo_ok && !hi_ok) break;
-      const double c1 = lo_ok ? Pin[g - (long long)t * stride] : kInfD;
-      const double c2 = hi_ok ? Pin[g + (long long)t * stride] : kInfD;
-      const double cnd = (c1 < c2 ? c1 : c2) + dd * dd;
-      best = cnd < best ? cnd : best;
+    for (int t0 = 0; t0 < cnt; t0 += 4) {
+      {
+        const double steps_lo = t0 == 0 ? 0.0 : (double)((t0 - 1) * kCoarse + 1);
+        const double steps = upper ? (double)((t0 + 1) * kCoarse - 1) : steps_lo;
+        const double dl = h * steps_lo, dd = h * steps;
+        const double floor_ = dl * dl - pp.rmax2;        // no source that far can bring any candidate below the band
+        if (floor_ > pp.band || dd * dd - pp.rmax2 >= best) break;
+        if (ia - t0 < 0 && ia + t0 >= cnt) break;
+      }
+      double c1[4], c2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u;
+        c1[u] = ia - t >= 0 ? Pin[g - (long long)t * stride] : kInfD;
+        c2[u] = ia + t < cnt ? Pin[g + (long long)t * stride] : kInfD;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u;
+        const double steps_lo = t == 0 ? 0.0 : (double)((t - 1) * kCoarse + 1);
+        const double steps = upper ? (double)((t + 1) * kCoarse - 1) : steps_lo;
+        const double dl = h * steps_lo, dd = h * steps;
+        const double cnd = (c1[u] < c2[u] ? c1[u] : c2[u]) + dd * dd;
+        if (!(dl * dl - pp.rmax2 > pp.band) && cnd < best) best = cnd;
+      }
     }
     (upper ? HiOut : LoOut)[g] = best;
   }
