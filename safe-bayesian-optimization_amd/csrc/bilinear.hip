@@ -362,9 +362,12 @@ struct PostCtx {
 
 // One GEMM phase of k_bpost on the workgroup's 128 x 128 tile: A images / B fragments of `KB` k-blocks per row block /
 // strip, `KS` k-steps run.  PH selects the epilogue: 0 variance, 1 mean, 2 / 3 gradient component of axis 0 / 1.
+// The accumulators belong to the caller: phase 2 does not start from zero but from phase 1's sums scaled by -xn0 of the
+// candidate's column, g0 = V1 . S0 - xn0 (V0 . S0) -- six k-steps instead of twelve for the stacked [V1; V0] operand.
 template <int PH>
 __device__ __forceinline__ void post_phase(const PostCtx& cx, const double* __restrict__ A, const double* __restrict__ B, int KB,
-                                           int KS, double* __restrict__ outp, double c0, double c1, double c2, double& gmax) {
+                                           int KS, double* __restrict__ outp, double c0, double c1, double c2, double& gmax,
+                                           d4_t (&acc)[2][8], const double* __restrict__ xn0) {
   const double* Ap = A + (size_t)cx.st_rb * KB * 256 + cx.st_off;
   const double* Bp = B + (size_t)cx.st_cs * KB * 256 + cx.st_off;
   const int nkb = (KS + 3) >> 2;
@@ -375,11 +378,20 @@ __device__ __forceinline__ void post_phase(const PostCtx& cx, const double* __re
     *reinterpret_cast<d4_t*>(buf + cx.b_st) = q0;
     *reinterpret_cast<d4_t*>(buf + cx.b_st + 4) = q1;
   };
-  d4_t acc[2][8];
+  if (PH == 2) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const unsigned int x = (unsigned int)(cx.cs0 + s2) * 16u + (cx.lane & 15);
+      const double f = x < cx.ucnt0 ? -xn0[x] : 0.0;
 #pragma unroll
-    for (int s2 = 0; s2 < 8; ++s2) acc[i][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
+      for (int i = 0; i < 2; ++i) acc[i][s2] = d4_t{acc[i][s2][0] * f, acc[i][s2][1] * f, acc[i][s2][2] * f, acc[i][s2][3] * f};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) acc[i][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
+  }
   d4_t ra0 = *reinterpret_cast<const d4_t*>(Ap), ra1 = *reinterpret_cast<const d4_t*>(Ap + 4);
   d4_t rb0v = *reinterpret_cast<const d4_t*>(Bp), rb1v = *reinterpret_cast<const d4_t*>(Bp + 4);
   __syncthreads();                             // the previous phase has finished reading the buffers
@@ -476,7 +488,8 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
                                                   const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
                                                   size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
                                                   int KSm, int KBm2, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
-                                                  double* __restrict__ var_out, double* __restrict__ Lpart) {
+                                                  double* __restrict__ var_out, double* __restrict__ Lpart,
+                                                  const double* __restrict__ xn0) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
   const int o = blockIdx.z;
   PostCtx cx;
@@ -503,12 +516,14 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
   double* const vo = var_out + (size_t)o * cs.n_local;
   double* const mo = mean_out + (size_t)o * cs.n_local;
   double gmax = 0.0;
-  post_phase<0>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, KS0, vo, sf2, ystd * ystd, 0.0, gmax);
-  post_phase<1>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax);
-  post_phase<2>(cx, VAo + (size_t)nrb * KBm * 256, SBo + (size_t)ncs * KBm * 256, KBm2, 2 * KSm, nullptr,
-                ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax);
+  d4_t acc[2][8];
+  post_phase<0>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0);
+  post_phase<1>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0);
+  // phase 2 continues on phase 1's sums: only the V1 half (the first KSm k-steps) of the stacked operands is run
+  post_phase<2>(cx, VAo + (size_t)nrb * KBm * 256, SBo + (size_t)ncs * KBm * 256, KBm2, KSm, nullptr,
+                ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax, acc, xn0);
   post_phase<3>(cx, VAo + (size_t)nrb * (KBm + KBm2) * 256, SBo, KBm, KSm, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0,
-                gmax);
+                gmax, acc, xn0);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const double other = __shfl_xor(gmax, off);
@@ -612,7 +627,7 @@ int bilinear_setup(sbo_ctx* c) {
   const int ncs0 = (int)((cnt0 + 15) / 16), nrb = (int)((nlines + 15) / 16);
   {
     // worth it only while the two GEMMs issue clearly fewer flops than the triangular contraction of K1g
-    const double gemm = (double)nlines * KB0 * 16.0 * KB1 * 16.0 + (double)cs.n_local * (KB0 * 16.0 + 4.0 * r0u);
+    const double gemm = (double)nlines * KB0 * 16.0 * KB1 * 16.0 + (double)cs.n_local * (KB0 * 16.0 + 3.0 * r0u);
     const double tri = 0.5 * (double)mc.npad * (mc.npad + 16.0) * (double)cs.n_local;
     if (gemm > 0.7 * tri) return SBO_OK;
   }
@@ -795,13 +810,14 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   hipLaunchKernelGGL(k_bpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream,
                      mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
                      pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
-                     (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p);
+                     (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */);
   hipLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, (const double*)c->bl_lpart.p, (int)(4 * gx * gy),
                      (unsigned long long*)c->Lmax.p);
   (void)line0;
-  // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (16 x 16 x 4 steps, 2 flops per multiply-add)
+  // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (KS0 + 3 KSm k-steps: the axis-0 gradient phase
+  // runs on the mean phase's sums; 16 x 16 x 4 steps, 2 flops per multiply-add)
   const double tiles2 = (double)pl.nrb * pl.ncs0, tiles1 = (double)pl.nrb * pl.KB0;
-  c->last_k1_flops = (double)q * 2.0 * 1024.0 * (4.0 * tiles1 * pl.KB1 + tiles2 * (pl.KS0 + 4 * pl.KSm));
+  c->last_k1_flops = (double)q * 2.0 * 1024.0 * (4.0 * tiles1 * pl.KB1 + tiles2 * (pl.KS0 + 3 * pl.KSm));
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
