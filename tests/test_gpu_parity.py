@@ -927,3 +927,65 @@ def test_random_models_full_sweeps_against_the_oracle(engine, seed):
         assert np.array_equal(engine.mask("O", c), gref["O"][c - 1]), f"O{c}"
     assert (g["safe_min_index"], g["target_index"], g["explore_index"]) == (gref["safe_min_index"], gref["target_index"],
                                                                              gref["explore_index"])
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_random_models_large_grid_paths_agree(engine, seed):
+    """Random models on a 512 x 2048 grid (1 M candidates: every blocked / listed / LDS-line kernel of the set phase is
+    on): the expander masks of the blocked + listed scans equal those of the plain step-by-step scans, the optimistic
+    masks of the power transform equal the pruned exact pair evaluation, and the oracle's predicates re-decide a sample
+    on both sides of the boundaries of G_1 and O_1."""
+    rng = np.random.default_rng(8000 + seed)
+    n = int(rng.integers(48, 200))
+    cfg = synthetic.make_config("B" if seed % 2 else "C", n=n, seed=8100 + seed)
+    q = cfg["Y"].shape[1]
+    hyp = np.empty((4, q))
+    hyp[:2] = rng.uniform(-0.8, 0.6, size=(2, q))
+    hyp[2] = rng.uniform(-0.5, 0.5, size=q)
+    hyp[3] = rng.uniform(-2.5, -2.0, size=q)
+    ds = synthetic.make_dataset(cfg["X"], cfg["Y"], hyp)
+    b = float(rng.uniform(1.0, 3.0))
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [512, 2048]
+    engine.set_model(ds)
+    engine.set_grid(lo, hi, count)
+    engine.posterior_run()
+    out = {}
+    try:
+        for plain in (0, 1):
+            engine.set_option("scan_blocks", 0 if plain else 1)
+            engine.set_option("scan_waves", 0 if plain else 1)
+            engine.set_option("goose_pairs", plain)
+            try:
+                s_ = engine.sweep_safeopt(b, want_masks=True, posterior_ready=True)
+            except safebo_amd.EmptySafeSetError:
+                return
+            G = [engine.mask("G", c) for c in range(1, q)]
+            g_ = engine.sweep_goose(b, want_masks=True, posterior_ready=True)
+            out[plain] = (s_, G, g_, [engine.mask("O", c) for c in range(1, q)])
+    finally:
+        engine.set_option("scan_blocks", 1)
+        engine.set_option("scan_waves", 1)
+        engine.set_option("goose_pairs", 0)
+    for c in range(q - 1):
+        assert np.array_equal(out[0][1][c], out[1][1][c]), f"G{c + 1}"
+        assert np.array_equal(out[0][3][c], out[1][3][c]), f"O{c + 1}"
+    assert list(out[0][0]["expander_index_c"]) == list(out[1][0]["expander_index_c"])
+    for k in ("safe_min_index", "target_index", "explore_index"):
+        assert out[0][2][k] == out[1][2][k], k
+    # oracle predicates on samples around the boundaries (reference quirk: every constraint uses L of the last output)
+    S, U = engine.mask("S"), engine.mask("U")
+    pts = oracle.grid_points(lo, hi, count)
+    Lq = out[0][0]["L"][q - 1]
+    ucb1 = engine.bounds(b, 1, "ucb")
+    G1, O1 = out[0][1][0], out[0][3][0]
+    xu, xs, us = pts[U], pts[S], ucb1[S]
+    for mask, dom in ((G1, S), (O1, U)):
+        edge = np.nonzero((mask[:-1] != mask[1:]) & dom[:-1] & dom[1:])[0]
+        pick = rng.choice(edge, size=min(12, edge.size), replace=False) if edge.size else np.array([], dtype=int)
+        for i in np.concatenate([pick, pick + 1]):
+            if mask is G1:
+                want = bool(np.any(ucb1[i] - Lq * oracle.shifted_norm(pts[i][None, :], xu) >= 0))
+            else:
+                want = bool(np.any(us - Lq * oracle.shifted_norm(xs, pts[i][None, :]) >= 0))
+            assert bool(mask[i]) == want, ("G" if mask is G1 else "O", int(i))
+
