@@ -424,7 +424,8 @@ int sbo_posterior_run(sbo_ctx* c) {
   SBO_HIP(hipSetDevice(c->device));
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   if ((rc = sbo_posterior_enqueue(c))) return rc;
-  SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  c->k1_stop_attached = false;
   SBO_HIP(hipEventSynchronize(c->ev[1]));
   float ms = 0;
   SBO_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));

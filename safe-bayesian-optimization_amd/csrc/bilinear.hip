@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cmath>
 #include <vector>
+#include <hip/hip_ext.h>
 #include "bilinear_host.hpp"
 #include "device_common.hpp"
 
@@ -811,8 +812,11 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                      mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
                      pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
                      (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */);
-  hipLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, (const double*)c->bl_lpart.p, (int)(4 * gx * gy),
-                     (unsigned long long*)c->Lmax.p);
+  // the K1 stop event rides on this launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
+  // the next kernel waits ~6 us for
+  hipExtLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, c->ev[1], 0, (const double*)c->bl_lpart.p,
+                        (int)(4 * gx * gy), (unsigned long long*)c->Lmax.p);
+  c->k1_stop_attached = true;
   (void)line0;
   // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (KS0 + 3 KSm k-steps: the axis-0 gradient phase
   // runs on the mean phase's sums; 16 x 16 x 4 steps, 2 flops per multiply-add)

@@ -122,6 +122,7 @@ struct sbo_ctx {
   unsigned char* h_back = nullptr;        // pinned host landing area of the end-of-sweep read-back (scalars + Lipschitz keys)
   int last_sweep = 0;  // 1 safeopt, 2 goose (what the masks hold)
   bool masks_valid = false;
+  bool k1_stop_attached = false;   // the last K1 kernel carries ev[1] as its stop event (no separate record, which costs a ~6 us bubble)
   bool amb_clean = false;   // the recheck / scan counters of the scalar block are still zero (no k_reset_amb needed)
   // profile
   sbo_profile prof{};

@@ -795,7 +795,8 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
-  SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  c->k1_stop_attached = false;
   if ((rc = sweep_common_front<T>(c, o))) return rc;
   if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
@@ -1154,7 +1155,8 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
-  SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  c->k1_stop_attached = false;
   if ((rc = sweep_common_front<T>(c, o))) return rc;
   if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
   if ((rc = ensure(c->maskO, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
@@ -1295,7 +1297,8 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
-  SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
+  c->k1_stop_attached = false;
   if ((rc = sweep_common_front<T>(c, o))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
