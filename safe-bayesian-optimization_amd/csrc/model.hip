@@ -142,13 +142,14 @@ __global__ __launch_bounds__(1024) void k_model_build(int mode, int n, int npad,
   if (tid == 0) bad[o] = sh_bad;
 }
 
-// ---- blocked, multi-workgroup form of the same factorisation (n >= 256) ---------------------------------------------
+// ---- blocked, multi-workgroup form of the same factorisation (n >= kBlockedFrom) ---------------------------------------------
 // Right-looking U^T U with panels of kPB rows; per panel two kinds of launches, every output (blockIdx.y) at once:
 //   k_chol_panel : every workgroup factors the kPB x kPB diagonal block in LDS (redundantly: it is tiny), then applies
 //                  Ukk^-T to its share of the columns to the right (the panel rows of U) and, with E, to the columns of
 //                  the inverse companion left of and inside the panel (E = L^-1 rides along exactly as in factor_utu);
 //   k_chol_update: rank-kPB update of the trailing matrix (upper triangle) and of the trailing rows of E, tiled 32 x 32.
 constexpr int kPB = 32;
+constexpr int kBlockedFrom = 96;   // smallest n factorised by the blocked form (below: one workgroup does everything)
 
 __global__ __launch_bounds__(256) void k_chol_prep(int mode, int n, int npad, int dpad, int d, const double* __restrict__ W,
                                                    const double* __restrict__ As, const double* __restrict__ sqA,
@@ -451,7 +452,7 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<
   SBO_HIP(hipMemcpyAsync(dsn2, sn2, sizeof(double) * q, hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemsetAsync(dalpha, 0, sizeof(double) * (size_t)q * npad, c->stream));
   const int mode = host_invK ? 0 : 1;
-  if (n >= 256) {
+  if (n >= kBlockedFrom) {
     // blocked multi-workgroup factorisation: the single-workgroup loop is bound by the latency of its own updates
     SBO_HIP(hipMemsetAsync(dbad, 0, sizeof(int) * q, c->stream));
     hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)dW,

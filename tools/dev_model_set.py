@@ -5,7 +5,7 @@ import numpy as np
 import safebo_amd
 from safebo_amd import synthetic
 eng = safebo_amd.SweepEngine(0)
-for name, n in (("B", 128), ("C", 256), ("H", 512), ("H", 1024), ("E", 2048)):
+for name, n in (("B", 64), ("B", 100), ("B", 128), ("B", 200), ("C", 256), ("H", 512), ("H", 1024), ("E", 2048)):
     cfg = synthetic.make_config(name, n=n)
     for use_invK in (True, False):
         ts = []
