@@ -16,7 +16,32 @@ struct RunMeta {
 template <typename T>
 __global__ __launch_bounds__(256) void k_goose_weights(const T* __restrict__ mean_c, const T* __restrict__ var_c, long long n, T b,
                                                        const uint8_t* __restrict__ src, T* __restrict__ W) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+  // mean / var are read for the sources only (a tenth of config B's grid): wave tiles of 512 candidates as in
+  // k_arg_masked, every lane reads eight mask bytes as one word
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long ntiles = (((uintptr_t)src) & 7) == 0 ? n / 512 : 0;
+  for (long long t = wave; t < ntiles; t += nwaves) {
+    const long long base = t * 512;
+    const unsigned long long w = ((const unsigned long long*)(src + base))[lane];
+    const bool any = __ballot(w != 0ull) != 0ull;
+    T mu[8], va[8];
+    bool set[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      set[k] = any && tile_byte(w, k, lane);
+      const long long g = base + k * 64 + lane;
+      mu[k] = set[k] ? mean_c[g] : (T)0;
+      va[k] = set[k] ? var_c[g] : (T)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      T lcb, ucb;
+      lcb_ucb(mu[k], va[k], b, lcb, ucb);
+      W[base + k * 64 + lane] = set[k] ? ucb : (T)-INFINITY;
+    }
+  }
+  for (long long g = ntiles * 512 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
     T lcb, ucb;
     lcb_ucb(mean_c[g], var_c[g], b, lcb, ucb);
     W[g] = src[g] ? ucb : (T)-INFINITY;
