@@ -899,7 +899,7 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
   if ((rc = ensure(c->gw, sizeof(T) * (size_t)std::max<long long>(maxlocal, 1)))) return rc;
   if (n > 0)
     hipLaunchKernelGGL((k_goose_weights<T>), dim3(reduce_blocks(c)), dim3(256), 0, c->stream, mean_c, var_c, n, (T)o->b, src,
-                       (T*)c->gw.p);
+                       (T*)c->gw.p, (SweepScalars*)c->scal.p);
   CandSpec css = c->cs;                 // the source candidates
   const T* W = (const T*)c->gw.p;
   long long run_lo = 0, run_hi = (n + kRun - 1) / kRun;
@@ -995,8 +995,7 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     for (int a = 0; a < d; ++a) xscale = std::max(xscale, std::max(std::fabs(c->cs.lo[a]), std::fabs(c->cs.hi[a])));
     const int count0 = d >= 2 ? (int)c->cs.count[0] : (int)nt;
     const unsigned gridn = (unsigned)std::min<long long>((nt + 255) / 256, 1 << 20);
-    if (!c->amb_clean) hipLaunchKernelGGL(k_reset_amb, dim3(1), dim3(1), 0, c->stream, sc);
-    c->amb_clean = false;
+    c->amb_clean = false;                          // (k_goose_weights cleared the counters)
     // coarse bounds of the window: decide most candidates (and skip their axis-0 scans) without touching the fine arrays
     CoarseGrid cg;
     memset(&cg, 0, sizeof(cg));

@@ -15,7 +15,9 @@ struct RunMeta {
 // source weights: W[g] = ucb_c(g) on the source set, -inf elsewhere (every source is in S_t, so its ucb_c >= lcb_c >= 0)
 template <typename T>
 __global__ __launch_bounds__(256) void k_goose_weights(const T* __restrict__ mean_c, const T* __restrict__ var_c, long long n, T b,
-                                                       const uint8_t* __restrict__ src, T* __restrict__ W) {
+                                                       const uint8_t* __restrict__ src, T* __restrict__ W, SweepScalars* sc) {
+  // (also clears the recheck / scan counters for the coverage kernels that follow: the expander's are done with them)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->n_amb = 0; sc->n_scan = 0; }
   // mean / var are read for the sources only (a tenth of config B's grid): wave tiles of 512 candidates as in
   // k_arg_masked, every lane reads eight mask bytes as one word
   const int lane = threadIdx.x & 63;
