@@ -989,3 +989,29 @@ def test_random_models_large_grid_paths_agree(engine, seed):
                 want = bool(np.any(us - Lq * oracle.shifted_norm(xs, pts[i][None, :]) >= 0))
             assert bool(mask[i]) == want, ("G" if mask is G1 else "O", int(i))
 
+
+def test_long_last_axis_blocks_of_64_steps(engine):
+    """Weak-scaling grids get finer along the slowest axis only: from 8192 planes on the last-axis scans use blocks of 64
+    steps (four rounds of a 16-lane group per block).  Blocked + listed scans against the plain step-by-step scans on a
+    256 x 8192 grid, SafeOpt expanders and GoOSE optimistic sets."""
+    cfg = synthetic.make_config("B")
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [256, 8192]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    engine.posterior_run()
+    keep = {}
+    try:
+        for plain in (0, 1):
+            engine.set_option("scan_blocks", 0 if plain else 1)
+            engine.set_option("scan_waves", 0 if plain else 1)
+            s_ = engine.sweep_safeopt(cfg["b"], want_masks=True, posterior_ready=True)
+            G = engine.mask("G", 1)
+            g_ = engine.sweep_goose(cfg["b"], want_masks=True, posterior_ready=True)
+            keep[plain] = (G, engine.mask("O", 1), s_["expander_index_c"][0], g_["target_index"], g_["explore_index"])
+    finally:
+        engine.set_option("scan_blocks", 1)
+        engine.set_option("scan_waves", 1)
+    assert keep[0][0].any() and keep[0][1].any()
+    assert np.array_equal(keep[0][0], keep[1][0]) and np.array_equal(keep[0][1], keep[1][1])
+    assert keep[0][2:] == keep[1][2:]
+
