@@ -617,7 +617,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       }
       long long* slist = nullptr;
       if (bmin && blk <= 64 && c->scan_waves) {
-        if ((rc = ensure(c->scanlist, sizeof(long long) * (size_t)n))) return rc;
+        if ((rc = ensure(c->scanlist, 2 * sizeof(long long) * (size_t)n))) return rc;   // (candidate, ucb) pairs
         slist = (long long*)c->scanlist.p;
       }
       const long long len0 = d >= 2 ? count0 : n;               // positions per line / local lines

@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
   // candidate index.  Open candidates are collected in LDS and appended to the scan list with one atomic per
   // workgroup (one per wave on a single counter serialises in L2).
   __shared__ long long sl[256 * kDecideLines];
+  __shared__ double su[256 * kDecideLines];
   __shared__ int scnt;
   __shared__ long long sbase;
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -427,7 +428,9 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
         if (LIST) {
           // the few candidates the coarse bounds leave open go to k_edt_scan_list (a group of lanes each): a lane
           // scanning here would hold its whole wave for a chain of ~100 dependent loads
-          sl[atomicAdd(&scnt, 1)] = g;
+          const int slot = atomicAdd(&scnt, 1);
+          sl[slot] = g;
+          su[slot] = ucb;                          // (rides along: the list kernel need not read mean / var again)
           G[g] = 0;
           return;
         }
@@ -458,7 +461,10 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
   if (cntl > 0) {
     if (threadIdx.x == 0) sbase = (long long)atomicAdd((unsigned long long*)&sc->n_scan, (unsigned long long)cntl);
     __syncthreads();
-    for (int k = threadIdx.x; k < cntl; k += blockDim.x) scanlist[sbase + k] = sl[k];
+    for (int k = threadIdx.x; k < cntl; k += blockDim.x) {      // entries: (candidate, ucb) pairs of 16 bytes
+      scanlist[2 * (sbase + k)] = sl[k];
+      reinterpret_cast<double*>(scanlist)[2 * (sbase + k) + 1] = su[k];
+    }
   }
   __syncthreads();
   }
@@ -491,10 +497,8 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict_
     return GL == 64 ? m : ((m >> (GL * sub)) & ((1ull << GL) - 1ull));
   };
   for (long long qi = (long long)blockIdx.x * (blockDim.x / GL) + threadIdx.x / GL; qi < nscan; qi += ngroups) {
-    const long long g = scanlist[qi];
-    T lcb, ucbT;
-    lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
-    const double ucb = (double)ucbT;
+    const long long g = scanlist[2 * qi];
+    const double ucb = reinterpret_cast<const double*>(scanlist)[2 * qi + 1];
     const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
     const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
     const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;
