@@ -427,6 +427,29 @@ __global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ part
   }
 }
 
+// The final reductions of a SafeOpt sweep in one launch: workgroup s merges region s of the partials (region stride
+// `stride` bytes; s = 0: minimiser -> slot 0 and |M|, s = c >= 1: expanders of constraint c -> slot c and |G_c|).
+__global__ __launch_bounds__(256) void k_safeopt_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts,
+                                                        SweepScalars* sc) {
+  const int slot = blockIdx.x;
+  const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
+  Best best{0.0, -1};
+  long long cnt = 0;
+  const long long* pc = (const long long*)(partial + nparts);
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    if (better<true>(partial[i], best)) best = partial[i];
+    cnt += pc[i];
+  }
+  best = block_best<true>(best);
+  cnt = block_sum_ll(cnt);
+  if (threadIdx.x == 0) {
+    sc->arg_val[slot] = best.v;
+    sc->arg_idx[slot] = best.i;
+    if (slot == 0) sc->count_M += cnt;
+    else sc->count_set[slot - 1] += cnt;
+  }
+}
+
 #include "sets_expander.inc.hpp"
 #include "sets_exchange.inc.hpp"
 #include "sets_goose.inc.hpp"
@@ -801,12 +824,13 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
+  // partials of the q arg-max reductions side by side: merged by one launch at the end (k_safeopt_finals)
+  const size_t pstride = (sizeof(Best) + sizeof(long long)) * (size_t)nb;
+  if ((rc = ensure(c->partial, pstride * (size_t)q))) return rc;
+  unsigned char* pbase = (unsigned char*)c->partial.p;
   if (n > 0)
     hipLaunchKernelGGL((k_minimizer<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n,
-                       (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, sc,
-                       (Best*)c->partial.p);
-  hipLaunchKernelGGL((k_arg_final<true>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0,
-                     &sc->count_M);
+                       (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, sc, (Best*)pbase);
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
   for (int cc = 1; cc < q; ++cc) {
     uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
@@ -817,10 +841,10 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
     const uint8_t* G = (const uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
     if (n > 0)
       hipLaunchKernelGGL((k_arg_masked<T, true, ValArray<T>>), dim3(nb), dim3(256), 0, c->stream, ValArray<T>{(const T*)c->var.p}, G, n,
-                         (long long)c->cs.first, (Best*)c->partial.p);
-    hipLaunchKernelGGL((k_arg_final<true>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0,
-                       sc, cc, &sc->count_set[cc - 1]);
+                         (long long)c->cs.first, (Best*)(pbase + pstride * (size_t)cc));
   }
+  hipLaunchKernelGGL(k_safeopt_finals, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0,
+                     sc);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
