@@ -427,25 +427,27 @@ __global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ part
   }
 }
 
-// The final reductions of a SafeOpt sweep in one launch: workgroup s merges region s of the partials (region stride
-// `stride` bytes; s = 0: minimiser -> slot 0 and |M|, s = c >= 1: expanders of constraint c -> slot c and |G_c|).
-__global__ __launch_bounds__(256) void k_safeopt_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts,
-                                                        SweepScalars* sc) {
+// The final reductions of a sweep in one launch: workgroup s merges region s of the partials (region stride `stride`
+// bytes).  SafeOpt (MAX): s = 0 minimiser -> slot 0 and |M|, s = c >= 1 expanders of constraint c -> slot c and |G_c|.
+// GoOSE (!MAX): s = 0 arg-min of lcb_0 over S_t -> slot 0 (no count), s = c >= 1 over O_c -> slot c and |O_c|.
+template <bool MAX>
+__global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts,
+                                                      SweepScalars* sc) {
   const int slot = blockIdx.x;
   const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
   Best best{0.0, -1};
   long long cnt = 0;
   const long long* pc = (const long long*)(partial + nparts);
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    if (better<true>(partial[i], best)) best = partial[i];
+    if (better<MAX>(partial[i], best)) best = partial[i];
     cnt += pc[i];
   }
-  best = block_best<true>(best);
+  best = block_best<MAX>(best);
   cnt = block_sum_ll(cnt);
   if (threadIdx.x == 0) {
     sc->arg_val[slot] = best.v;
     sc->arg_idx[slot] = best.i;
-    if (slot == 0) sc->count_M += cnt;
+    if (slot == 0) { if (MAX) sc->count_M += cnt; }
     else sc->count_set[slot - 1] += cnt;
   }
 }
@@ -843,7 +845,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
       hipLaunchKernelGGL((k_arg_masked<T, true, ValArray<T>>), dim3(nb), dim3(256), 0, c->stream, ValArray<T>{(const T*)c->var.p}, G, n,
                          (long long)c->cs.first, (Best*)(pbase + pstride * (size_t)cc));
   }
-  hipLaunchKernelGGL(k_safeopt_finals, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0,
+  hipLaunchKernelGGL(k_sweep_finals<true>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0,
                      sc);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
@@ -1206,18 +1208,20 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   // arg-min of lcb_0 over S_t and over every O_c: the bound is computed for the masked candidates only
   const ValLcb<T> lcb0{(const T*)c->mean.p, (const T*)c->var.p, (T)o->b};
+  const size_t pstride = (sizeof(Best) + sizeof(long long)) * (size_t)nb;     // q regions of partials, one merge launch
+  if ((rc = ensure(c->partial, pstride * (size_t)q))) return rc;
+  unsigned char* pbase = (unsigned char*)c->partial.p;
   if (n > 0)
     hipLaunchKernelGGL((k_arg_masked<T, false, ValLcb<T>>), dim3(nb), dim3(256), 0, c->stream, lcb0, (const uint8_t*)c->maskS.p, n,
-                       (long long)c->cs.first, (Best*)c->partial.p);
-  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0, (long long*)nullptr);
+                       (long long)c->cs.first, (Best*)pbase);
   for (int cc = 1; cc < q; ++cc) {
     const uint8_t* O = (const uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
     if (n > 0)
       hipLaunchKernelGGL((k_arg_masked<T, false, ValLcb<T>>), dim3(nb), dim3(256), 0, c->stream, lcb0, O, n,
-                         (long long)c->cs.first, (Best*)c->partial.p);
-    hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, cc,
-                       &sc->count_set[cc - 1]);
+                         (long long)c->cs.first, (Best*)(pbase + pstride * (size_t)cc));
   }
+  hipLaunchKernelGGL(k_sweep_finals<false>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride,
+                     n > 0 ? nb : 0, sc);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
