@@ -524,8 +524,8 @@ static int sweep_exchange_wait(sbo_ctx* c);
 // G_c for constraint cidx (1..q-1) into G[n]
 static void launch_edt_axis0(sbo_ctx* c, const uint8_t* U, long long nlines, int count0, double h0, double* D) {
   if (count0 <= kAxis0Max && count0 >= 128)
-    hipLaunchKernelGGL(k_edt_axis0_wg, dim3((unsigned)std::min<long long>(nlines, 1 << 20)), dim3(256), 0, c->stream, U, nlines, count0,
-                       h0, D);
+    hipLaunchKernelGGL(k_edt_axis0_wg<false>, dim3((unsigned)std::min<long long>(nlines, 1 << 20)), dim3(256), 0, c->stream, U, nlines,
+                       count0, h0, D, CoarseGrid{});
   else
     hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, c->stream, U, nlines, count0, h0, D);
 }
@@ -611,11 +611,17 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       double* dc0 = (double*)c->coarse.p;
       double* dc1 = dc0 + nc;
       uint8_t* Uc = (uint8_t*)(dc1 + nc);
-      hipLaunchKernelGGL(k_coarsen_mask, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
-                         Uall, cg, nc, Uc);
       const int cc0 = (int)cg.ccount[0];
       const long long clines = nc / cc0;
-      launch_edt_axis0(c, (const uint8_t*)Uc, clines, cc0, c->cs.step[0] * kCoarse, dc0);
+      if (cc0 <= kAxis0Max && cc0 >= 128) {
+        // the coarse axis-0 pass forms the cells' bits from the fine mask itself
+        hipLaunchKernelGGL(k_edt_axis0_wg<true>, dim3((unsigned)std::min<long long>(clines, 1 << 20)), dim3(256), 0, c->stream, Uall,
+                           clines, cc0, c->cs.step[0] * kCoarse, dc0, cg);
+      } else {
+        hipLaunchKernelGGL(k_coarsen_mask, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
+                           Uall, cg, nc, Uc);
+        launch_edt_axis0(c, (const uint8_t*)Uc, clines, cc0, c->cs.step[0] * kCoarse, dc0);
+      }
       long long cstride = cc0;
       for (int a = 1; a < d; ++a) {
         hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,

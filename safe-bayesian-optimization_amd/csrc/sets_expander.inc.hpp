@@ -44,13 +44,56 @@ __global__ __launch_bounds__(256) void k_edt_axis0(const uint8_t* __restrict__ U
   }
 }
 
+constexpr int kCoarse = 8;
+constexpr int kDecideLines = 4;   // lines per workgroup of k_edt_decide / k_pdt_decide (2: 21.8 us, 4: 19.5, 8: 20.8, 16: 27.1 on config B)
+struct CoarseGrid {
+  int enabled;
+  int d;
+  long long count[kMaxD];    // fine counts
+  long long ccount[kMaxD];   // coarse counts
+  double delta;
+  const double* Dc;          // squared coarse distances [prod ccount]
+};
+
+// OR of the U bytes of the kCoarse^d candidates of one coarse cell (lines of <= kCoarse bytes along axis 0)
+__device__ __forceinline__ bool coarse_cell_any(const uint8_t* __restrict__ U, const CoarseGrid& cg, long long cell) {
+  long long f = cell, i0[kMaxD], len[kMaxD], fstride[kMaxD], nsub = 1, fs = 1;
+  for (int a = 0; a < cg.d; ++a) {
+    const long long ca = f % cg.ccount[a];
+    f /= cg.ccount[a];
+    i0[a] = ca * kCoarse;
+    len[a] = cg.count[a] - i0[a] < kCoarse ? cg.count[a] - i0[a] : kCoarse;
+    fstride[a] = fs;
+    fs *= cg.count[a];
+    if (a > 0) nsub *= len[a];
+  }
+  bool any = false;
+  for (long long sline = 0; sline < nsub && !any; ++sline) {
+    long long r = sline, base = i0[0];
+    for (int a = 1; a < cg.d; ++a) {
+      base += (i0[a] + r % len[a]) * fstride[a];
+      r /= len[a];
+    }
+    const uint8_t* u = U + base;
+    if (len[0] == 8 && ((uintptr_t)u & 7) == 0) {
+      any = *(const unsigned long long*)u != 0ull;
+    } else {
+      for (int k = 0; k < (int)len[0]; ++k) any = any || u[k];
+    }
+  }
+  return any;
+}
+
 // axis 0, one workgroup per grid line (count0 <= kAxis0Max): the line's bits go to LDS as 64-bit words (one ballot per
 // wave and chunk), waves 0 and 1 scan the words for the nearest set bit before / after every word, and every element
 // then finds its neighbours from its own word and the two carries -- no serial chain along the line, the mask is read
 // once and the squared distance written once (same arithmetic as k_edt_axis0: (h0 t)^2 with t the step count).
+// COARSE: the lines are lines of coarse cells and the bit of a cell is formed here from the fine mask (no coarse mask in
+// memory, one launch less).
 constexpr int kAxis0Max = 65536;
+template <bool COARSE>
 __global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
-                                                      double* __restrict__ D) {
+                                                      double* __restrict__ D, const CoarseGrid cg) {
   __shared__ unsigned long long words[kAxis0Max / 64];
   __shared__ int lastw[kAxis0Max / 64];    // index of the last set bit in words 0..w (-1: none)
   __shared__ int firstw[kAxis0Max / 64];   // index of the first set bit in words w.. (INT_MAX: none)
@@ -62,7 +105,7 @@ __global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict_
     double* d = D + line * count0;
     for (int w = wave; w < nwords; w += 4) {
       const int i = w * 64 + lane;
-      const unsigned long long m = __ballot(i < count0 && u[i]);
+      const unsigned long long m = __ballot(i < count0 && (COARSE ? coarse_cell_any(U, cg, line * count0 + i) : u[i] != 0));
       if (lane == 0) words[w] = m;
     }
     __syncthreads();
@@ -284,47 +327,11 @@ __global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din
 //     dC - delta <= dist(g, U) <= dC + delta,   delta = (kCoarse - 1) * sqrt(sum_a h_a^2)
 // (dC = distance between cell origins to the nearest U-holding cell).  Candidates whose verdict is the same at both
 // ends skip the per-candidate scan of the fine transform; only the shell around the boundary of G_c scans.
-constexpr int kCoarse = 8;
-constexpr int kDecideLines = 4;   // lines per workgroup of k_edt_decide / k_pdt_decide (2: 21.8 us, 4: 19.5, 8: 20.8, 16: 27.1 on config B)
-struct CoarseGrid {
-  int enabled;
-  int d;
-  long long count[kMaxD];    // fine counts
-  long long ccount[kMaxD];   // coarse counts
-  double delta;
-  const double* Dc;          // squared coarse distances [prod ccount]
-};
-
-// one thread per coarse cell: OR of the U bytes of its kCoarse^d candidates (lines of <= kCoarse bytes along axis 0)
+// one thread per coarse cell (fallback when the coarse axis-0 pass cannot take the fine mask itself)
 __global__ __launch_bounds__(256) void k_coarsen_mask(const uint8_t* __restrict__ U, const CoarseGrid cg, long long ncells,
                                                       uint8_t* __restrict__ Uc) {
-  for (long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x; cell < ncells; cell += (long long)gridDim.x * blockDim.x) {
-    long long f = cell, i0[kMaxD], len[kMaxD], fstride[kMaxD], nsub = 1, fs = 1;
-    for (int a = 0; a < cg.d; ++a) {
-      const long long ca = f % cg.ccount[a];
-      f /= cg.ccount[a];
-      i0[a] = ca * kCoarse;
-      len[a] = cg.count[a] - i0[a] < kCoarse ? cg.count[a] - i0[a] : kCoarse;
-      fstride[a] = fs;
-      fs *= cg.count[a];
-      if (a > 0) nsub *= len[a];
-    }
-    bool any = false;
-    for (long long sline = 0; sline < nsub && !any; ++sline) {
-      long long r = sline, base = i0[0];
-      for (int a = 1; a < cg.d; ++a) {
-        base += (i0[a] + r % len[a]) * fstride[a];
-        r /= len[a];
-      }
-      const uint8_t* u = U + base;
-      if (len[0] == 8 && ((uintptr_t)u & 7) == 0) {
-        any = *(const unsigned long long*)u != 0ull;
-      } else {
-        for (int k = 0; k < (int)len[0]; ++k) any = any || u[k];
-      }
-    }
-    Uc[cell] = any ? 1 : 0;
-  }
+  for (long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x; cell < ncells; cell += (long long)gridDim.x * blockDim.x)
+    Uc[cell] = coarse_cell_any(U, cg, cell) ? 1 : 0;
 }
 
 // Reference expression for one (g, h) pair, unfused, in the oracle's order:
