@@ -586,7 +586,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     for (int a = 1; a < d - 1; ++a) {
       hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nt + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
                          (const double*)din, dout, nt, stride, (int)c->cs.count[a], c->cs.step[a],
-                         (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, 0);
+                         (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, 0, 0.0);
       std::swap(din, dout);
       stride *= c->cs.count[a];
     }
@@ -623,10 +623,13 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
         launch_edt_axis0(c, (const uint8_t*)Uc, clines, cc0, c->cs.step[0] * kCoarse, dc0);
       }
       long long cstride = cc0;
+      double hmax = 0.0;
+      for (int a = 0; a < d; ++a) hmax = std::max(hmax, c->cs.step[a]);
+      const double cap_extra = 2.0 * cg.delta + 2.0 * kCoarse * hmax;
       for (int a = 1; a < d; ++a) {
         hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
                            (const double*)dc0, dc1, nc, cstride, (int)cg.ccount[a], c->cs.step[a] * kCoarse,
-                           (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, 1);
+                           (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, 0, cap_extra);
         std::swap(dc0, dc1);
         cstride *= cg.ccount[a];
       }

@@ -312,10 +312,13 @@ __device__ __forceinline__ double edt_scan_blocked(const double* __restrict__ Di
 
 __global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din, double* __restrict__ Dout, long long n,
                                                   long long stride, int cnt, double h, const SweepScalars* sc, int c,
-                                                  const unsigned long long* Lkeys, int lidx, int uncapped) {
+                                                  const unsigned long long* Lkeys, int lidx, int uncapped, double cap_extra) {
+  // cap: offsets beyond the largest radius that can matter are not examined.  The coarse transform passes
+  // cap_extra = 2 delta + two coarse steps: a cell whose true distance lies beyond that cap is "beyond every radius" by
+  // the sandwich dC -+ delta whether its stored value is the true minimum or a larger one.
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const double rmax = sc->rmax_key[c] ? ord_val(sc->rmax_key[c]) : 0.0;
-  const double cap = (L > 0 && !uncapped) ? rmax / L * 1.000001 + 1e-6 : kInfD;
+  const double cap = (L > 0 && !uncapped) ? rmax / L * 1.000001 + 1e-6 + cap_extra : kInfD;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
     const int ia = (int)((g / stride) % cnt);
     Dout[g] = edt_scan_point(Din, g, stride, cnt, ia, h, cap);
