@@ -20,12 +20,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if ks:
-    shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    shutil.copy(ks[-1], os.path.join(dst, f"{tag}_kernel_stats.csv"))      # (the newest run of this tag)
 pmc = collections.defaultdict(dict)
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
