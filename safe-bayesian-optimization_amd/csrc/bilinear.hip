@@ -107,6 +107,8 @@ __global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, siz
   }
 }
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
 // Stage 1 of every posterior launch (OUT as packed block images, the OMODE 0 of k_bgemm): the four waves of a workgroup
 // own four row blocks and share S column strips, so the strips' B fragments are staged once per workgroup through LDS
 // (double-buffered, one barrier per k-block) instead of once per wave from L2 -- with K ~ 290 and only 16 x 16 S outputs
@@ -116,11 +118,16 @@ __global__ __launch_bounds__(256) void k_bstage1(const double* __restrict__ A, s
                                                  size_t b_stride_o, int KB, int nrb, int ncs, double* __restrict__ out,
                                                  size_t out_stride_o) {
   __shared__ double Bs[2][4 * S * 64];          // [buffer][(kk S + s) 64 + lane]
+  // A: a wave's 16 x 16 block image goes through LDS too.  Read straight from memory, a fragment load has the four
+  // lanes of a quad fetch the same 32 bytes (8 KB of lane traffic for a 2 KB image per k-block, which is what the
+  // texture path then limits); here a lane fetches 32 bytes once and the replicated reads are LDS broadcasts.  Layout per
+  // k-step as in k_bpost: the first 16-byte halves of the 16 chunks, then the second halves (conflict-free b128 reads).
+  __shared__ __attribute__((aligned(16))) double As[2][4][256];   // [buffer][wave][image]
   const int o = blockIdx.z, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int rb = blockIdx.y * 4 + wave, rbl = rb < nrb ? rb : nrb - 1;
   const int cs0 = blockIdx.x * S;
-  const double* Ablk = A + (size_t)o * a_stride_o + (size_t)rbl * KB * 256;
+  const double* Ablk = A + (size_t)o * a_stride_o + (size_t)rbl * KB * 256 + lane * 4;   // this lane's 32 bytes of an image
   const double* Bo = Bf + (size_t)o * b_stride_o;
   // staging role: element e = tid + 256 j (j < S) of the k-block's [4][S][64] fragment set
   size_t goff[S];
@@ -130,38 +137,45 @@ __global__ __launch_bounds__(256) void k_bstage1(const double* __restrict__ A, s
     const int cs = cs0 + s_ < ncs ? cs0 + s_ : ncs - 1;
     goff[j] = ((size_t)cs * KB * 4 + kk) * 64 + l;
   }
+  const int a_st = (lane >> 4) * 64 + (lane & 15) * 2;                        // where this lane's 32 bytes go (two halves)
+  const int a_rd = (((lane >> 4) << 2) + (lane & 3)) * 2;                     // the chunk its fragment reads
   d4_t acc[S];
 #pragma unroll
   for (int s_ = 0; s_ < S; ++s_) acc[s_] = d4_t{0.0, 0.0, 0.0, 0.0};
   double breg[S];
-  d4_t a[2][4];
+  d4_t areg = *reinterpret_cast<const d4_t*>(Ablk);
 #pragma unroll
   for (int j = 0; j < S; ++j) Bs[0][tid + 256 * j] = Bo[goff[j]];
-  MM<double>::load_a4(Ablk, lane, a[0]);
+  *reinterpret_cast<d2_t*>(&As[0][wave][a_st]) = d2_t{areg[0], areg[1]};
+  *reinterpret_cast<d2_t*>(&As[0][wave][a_st + 32]) = d2_t{areg[2], areg[3]};
   __syncthreads();
   // one k-block: prefetch block kb + 1 (registers), multiply block kb out of LDS buffer CUR, park the prefetch in the
-  // other buffer (its last readers passed the previous barrier).  Written twice so that buffers and register sets are
-  // compile-time names.
-  auto step = [&](int kb, const double* bs_cur, double* bs_nxt, const d4_t (&acur)[4], d4_t (&anxt)[4]) {
+  // other buffer (its last readers passed the previous barrier).  Written twice so that the buffers are compile-time names.
+  auto step = [&](int kb, const double* bs_cur, double* bs_nxt, const double* as_cur, double* as_nxt) {
     const bool more = kb + 1 < KB;
     if (more) {
 #pragma unroll
       for (int j = 0; j < S; ++j) breg[j] = Bo[goff[j] + (size_t)(kb + 1) * 256];
-      MM<double>::load_a4(Ablk + (size_t)(kb + 1) * 256, lane, anxt);
+      areg = *reinterpret_cast<const d4_t*>(Ablk + (size_t)(kb + 1) * 256);
     }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int kk = 0; kk < 4; ++kk) {
+      const d2_t lo = *reinterpret_cast<const d2_t*>(as_cur + kk * 64 + a_rd), hi = *reinterpret_cast<const d2_t*>(as_cur + kk * 64 + 32 + a_rd);
+      const d4_t af = d4_t{lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
-      for (int s_ = 0; s_ < S; ++s_) acc[s_] = MM<double>::mfma(acur[kk], bs_cur[(kk * S + s_) * 64 + lane], acc[s_]);
+      for (int s_ = 0; s_ < S; ++s_) acc[s_] = MM<double>::mfma(af, bs_cur[(kk * S + s_) * 64 + lane], acc[s_]);
+    }
     if (more) {
 #pragma unroll
       for (int j = 0; j < S; ++j) bs_nxt[tid + 256 * j] = breg[j];
+      *reinterpret_cast<d2_t*>(as_nxt + a_st) = d2_t{areg[0], areg[1]};
+      *reinterpret_cast<d2_t*>(as_nxt + a_st + 32) = d2_t{areg[2], areg[3]};
     }
     __syncthreads();
   };
   for (int kb = 0; kb < KB; kb += 2) {
-    step(kb, Bs[0], Bs[1], a[0], a[1]);
-    if (kb + 1 < KB) step(kb + 1, Bs[1], Bs[0], a[1], a[0]);
+    step(kb, Bs[0], Bs[1], As[0][wave], As[1][wave]);
+    if (kb + 1 < KB) step(kb + 1, Bs[1], Bs[0], As[1][wave], As[0][wave]);
   }
   if (rb >= nrb) return;
   const int col_in = lane & 15, row_in = lane >> 4;
@@ -350,7 +364,6 @@ __global__ __launch_bounds__(256) void k_bl_sbf(const double* __restrict__ S0, c
 //   phase 1  s1   = V[0]  . S0          (KSm)          ->  mean = (mp + s1) Y_std + Y_mean
 //   phase 2  g0   = [V[1]; V[0]] . [S0; -xn0 S0]  (2 KSm)   gradient sum of axis 0 (the candidate's own xn0 sits in B)
 //   phase 3  g1   = V1x   . S0          (KSm)              gradient sum of axis 1 (xn1 of the line is folded into V1x)
-typedef double d2_t __attribute__((ext_vector_type(2)));
 
 struct PostCtx {
   double* lds;
