@@ -167,7 +167,11 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
   const long long npair = n >> 1;
   const bool aligned = (n & 1) == 0;               // output c starts at c * n elements: pairs stay aligned only for even n
   if (aligned) {
-    for (long long pi = (long long)blockIdx.x * blockDim.x + threadIdx.x; pi < npair; pi += (long long)gridDim.x * blockDim.x) {
+    // a contiguous chunk of pairs per workgroup (the four streams of a workgroup then walk four DRAM pages, not 4 x the
+    // number of workgroups interleaved)
+    const long long chunk = ((npair + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
+    const long long pend = (blockIdx.x + 1) * chunk < npair ? (blockIdx.x + 1) * chunk : npair;
+    for (long long pi = blockIdx.x * chunk + threadIdx.x; pi < pend; pi += blockDim.x) {
       T mv0[2 * kMaxQ], mv1[2 * kMaxQ], uc0[kMaxQ], uc1[kMaxQ];
 #pragma unroll
       for (int c = 1; c < kMaxQ; ++c) {
