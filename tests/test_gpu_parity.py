@@ -1015,3 +1015,37 @@ def test_long_last_axis_blocks_of_64_steps(engine):
     assert np.array_equal(keep[0][0], keep[1][0]) and np.array_equal(keep[0][1], keep[1][1])
     assert keep[0][2:] == keep[1][2:]
 
+
+@pytest.mark.parametrize("seed,count", [(31, [160, 140]), (32, [264, 256])])
+def test_random_models_mid_grids_against_the_oracle(engine, seed, count):
+    """The oracle's brute-force sets on grids large enough for the blocked last-axis scans and the listed open candidates
+    (160 x 140: every safe / unsafe candidate goes through the list kernels; 264 x 256: the coarse bounds decide most and
+    list the rest): every SafeOpt and GoOSE mask and index of a random model, bit for bit."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(40, 160))
+    cfg = synthetic.make_config("B", n=n, seed=9100 + seed)
+    q = cfg["Y"].shape[1]
+    hyp = np.empty((4, q))
+    hyp[:2] = rng.uniform(-0.8, 0.6, size=(2, q))
+    hyp[2] = rng.uniform(-0.5, 0.5, size=q)
+    hyp[3] = rng.uniform(-2.5, -2.0, size=q)
+    ds = synthetic.make_dataset(cfg["X"], cfg["Y"], hyp)
+    b = float(rng.uniform(1.5, 3.0))
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_model(ds)
+    engine.set_grid(lo, hi, count)
+    _check_posterior(engine, ds, pts, TOL64)
+    ref = oracle.safeopt_sweep(pts, ds, b)
+    assert not ref["empty_safe_set"]
+    res = engine.sweep_safeopt(b, want_masks=True, posterior_ready=True)
+    for k in ("S", "U", "M"):
+        assert np.array_equal(engine.mask(k), ref[k]), k
+    assert np.array_equal(engine.mask("G", 1), ref["G"][0]) and ref["G"][0].any()
+    assert res["minimizer_index"] == ref["minimizer_index"] and list(res["expander_index_c"]) == list(ref["expander_index"])
+    gref = oracle.goose_sweep(pts, ds, b)
+    g = engine.sweep_goose(b, want_masks=True, posterior_ready=True)
+    assert np.array_equal(engine.mask("O", 1), gref["O"][0]) and gref["O"][0].any()
+    assert (g["safe_min_index"], g["target_index"], g["explore_index"]) == (gref["safe_min_index"], gref["target_index"],
+                                                                             gref["explore_index"])
+
