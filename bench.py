@@ -131,7 +131,10 @@ def main():
         eng.set_option(k, int(v))
     transport = "none"
     if world > 1:
-        transport = distributed.join_with_fallback(eng)   # RCCL (unique id broadcast from rank 0); gloo relay if it cannot form
+        # RCCL (unique id broadcast from rank 0).  Only a one-GPU rehearsal of the N > 1 plumbing (SBO_BENCH_DEVICE pins
+        # every rank to one card, which RCCL refuses) may fall back to the gloo relay; ranks on distinct devices that
+        # cannot form the communicator fail the run.
+        transport = distributed.join_with_fallback(eng, allow_relay="SBO_BENCH_DEVICE" in os.environ)
     eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=(cfg["dtype"] == "f64"))
     if scattered:
         pts = synthetic.scattered_points(cfg, n_total)[rank * per_rank:(rank + 1) * per_rank]

@@ -159,6 +159,9 @@ int sbo_synchronize(sbo_ctx* ctx);
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------------- */
 #define SBO_COMM_ID_BYTES 128
 int sbo_comm_unique_id(void* id_out /* SBO_COMM_ID_BYTES, filled on rank 0 and sent to peers */);
+/* world_size == 1 with id == NULL: no communicator (the collectives are identities and are skipped); with an id a
+ * one-rank RCCL communicator is built all the same (see option "comm_selftest").  On failure the context stays
+ * single-rank and usable. */
 int sbo_comm_init(sbo_ctx* ctx, int world_size, int rank, const void* id);
 int sbo_comm_barrier(sbo_ctx* ctx);
 /* Rehearsal transport for test rigs where the ranks cannot form an RCCL communicator (e.g. two ranks sharing
@@ -243,7 +246,9 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  * fp64 2-D grids run the posterior as two GEMMs in a reduced basis when that is cheaper; 0: always the separable-table
  * kernel), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
  * "scan_waves" (1 default: open candidates of the expander query are scanned by half-waves), "goose_pairs" (1: pair
- * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile) */
+ * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile), "comm_selftest" (1: a one-rank world created
+ * with sbo_comm_init(ctx, 1, 0, id) sends the collectives C1 / C2 / C3 through its RCCL communicator instead of skipping
+ * them -- the sweep results must not change) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

@@ -181,8 +181,8 @@ class GP:
     def add_sample(self, x_new, y_new, incremental: bool = False):
         """Reference behaviour (models/GP_Safe.py:283-304): re-normalise, refit, rebuild.  ``incremental=True`` is the
         opt-in fast path of SURVEY.md 8(f) rank 2: normalisation constants and hyper-parameters stay frozen and the device
-        model gains one row in O(n^2) (``sbo_model_append``); the Python-side ``inference_datasets`` keeps X_norm / Y_norm
-        in step but its ``invKopt`` is then stale until the next full ``add_sample``."""
+        model gains one row in O(n^2) (``sbo_model_append``); the Python-side ``inference_datasets`` follows with the
+        bordered inverse, also O(n^2)."""
         self.X = np.vstack([self.X, np.asarray(x_new, dtype=np.float64)])
         self.Y = np.vstack([self.Y, np.asarray(y_new, dtype=np.float64)])
         self.n_point = self.X.shape[0]
@@ -191,9 +191,21 @@ class GP:
             xn = (np.asarray(x_new, dtype=np.float64).reshape(-1) - self.X_mean) / self.X_std
             yn = (np.asarray(y_new, dtype=np.float64).reshape(-1) - self.Y_mean) / self.Y_std
             self.engine.append_sample(xn, yn)
+            # the host copy of the model follows: bordered inverse of K + sn2 I under the frozen hyper-parameters, so that
+            # ``inference_datasets`` stays a complete, uploadable state (X_norm [n+1, d] next to invKopt [n+1, n+1])
+            d = self.nx_dim
+            for i in range(self.ny_dim):
+                ell, sf2 = np.exp(2.0 * self.hypopt[:d, i]), np.exp(2.0 * self.hypopt[d, i])
+                sn2 = np.exp(2.0 * self.hypopt[d + 1, i]) + FLOAT32_EPS
+                k = self.Cov_mat(self.kernel, self.X_norm, xn[None, :], ell, sf2)[:, 0]
+                u = self.invKopt[i] @ k
+                s = (sf2 + sn2) - float(k @ u)
+                self.invKopt[i] = np.block([[self.invKopt[i] + np.outer(u, u) / s, -u[:, None] / s],
+                                            [-u[None, :] / s, np.array([[1.0 / s]])]])
             self.X_norm = np.vstack([self.X_norm, xn])
             self.Y_norm = np.vstack([self.Y_norm, yn])
-            self.inference_datasets["X_norm"], self.inference_datasets["Y_norm"] = self.X_norm, self.Y_norm
+            self.update_inference_dataset()              # bumps _model_version: the cached sweeps of SafeOpt / GoOSE.BO are stale
+            self._uploaded_version = self._model_version  # ... but the device model is already current: no re-upload
             self._cand_token = None
             return
         self.X_norm, self.Y_norm = self.data_normalization()

@@ -177,6 +177,12 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->goose_pairs = value ? 1 : 0;
     return SBO_OK;
   }
+  if (!strcmp(key, "comm_selftest")) {
+    if (value && !c->comm && !c->relay_allreduce)
+      return fail(SBO_E_INVALID, "comm_selftest needs a communicator: call sbo_comm_init(ctx, 1, 0, id) with a unique id first");
+    c->comm_selftest = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "posterior_path")) {
     if (value < 0 || value > 2) return fail(SBO_E_INVALID, "posterior_path must be 0 (auto), 1 (generic) or 2 (generic, chunked)");
     c->posterior_path = (int)value;

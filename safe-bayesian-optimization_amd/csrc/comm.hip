@@ -18,6 +18,7 @@ static int nccl_fail(ncclResult_t r, const char* what) {
 
 // host-staged collective for the rehearsal transport
 static int relay_reduce(sbo_ctx* c, void* dev, size_t count, int elem, int op) {
+  if (!c->relay_allreduce) return fail(SBO_E_COMM, "no transport: neither an RCCL communicator nor relay callbacks are installed");
   std::vector<unsigned char> h(count * 8);
   SBO_HIP(hipMemcpyAsync(h.data(), dev, h.size(), hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
@@ -30,26 +31,27 @@ static int relay_reduce(sbo_ctx* c, void* dev, size_t count, int elem, int op) {
 
 // in-place all-reduce helpers used by the sweeps (no-ops for a single rank)
 int comm_allreduce_max_u64(sbo_ctx* c, unsigned long long* dev, int count) {
-  if (c->world <= 1) return SBO_OK;
+  if (!multi_rank(c)) return SBO_OK;
   if (!c->comm) return relay_reduce(c, dev, count, 0, 1);
   SBO_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclMax, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
 int comm_allreduce_min_u64(sbo_ctx* c, unsigned long long* dev, int count) {
-  if (c->world <= 1) return SBO_OK;
+  if (!multi_rank(c)) return SBO_OK;
   if (!c->comm) return relay_reduce(c, dev, count, 0, 2);
   SBO_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclMin, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
 int comm_allreduce_sum_f64(sbo_ctx* c, double* dev, int count) {
-  if (c->world <= 1) return SBO_OK;
+  if (!multi_rank(c)) return SBO_OK;
   if (!c->comm) return relay_reduce(c, dev, count, 1, 0);
   SBO_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
 int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_per_rank) {
-  if (c->world <= 1) return SBO_OK;
+  if (!multi_rank(c)) return SBO_OK;
   if (!c->comm) {
+    if (!c->relay_allgather) return fail(SBO_E_COMM, "no transport: neither an RCCL communicator nor relay callbacks are installed");
     std::vector<unsigned char> hs(bytes_per_rank), hr(bytes_per_rank * c->world);
     SBO_HIP(hipMemcpyAsync(hs.data(), send, hs.size(), hipMemcpyDeviceToHost, c->stream));
     SBO_HIP(hipStreamSynchronize(c->stream));
@@ -82,16 +84,29 @@ int sbo_comm_init(sbo_ctx* c, int world_size, int rank, const void* id) {
   if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
   if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SBO_E_INVALID, "bad world_size / rank");
   if (c->comm) return fail(SBO_E_INVALID, "communicator already initialised");
-  c->world = world_size;
-  c->rank = rank;
-  if (world_size == 1) return SBO_OK;
+  // A one-rank world needs no communicator: the collectives are identities and are skipped.  With an id it still gets a
+  // real one (option "comm_selftest" then sends C1 / C2 / C3 through RCCL anyway: the one-GPU test of the RCCL calls).
+  if (world_size == 1 && !id) {
+    c->world = 1;
+    c->rank = 0;
+    return SBO_OK;
+  }
   if (!id) return fail(SBO_E_INVALID, "id is NULL");
   SBO_HIP(hipSetDevice(c->device));
+  // the library is compiled against /opt/rocm's <rccl/rccl.h>; the process may have mapped another librccl first (a
+  // launcher that imported torch): refuse a major-version mismatch instead of calling through a different ABI
+  int ver = 0;
+  SBO_NCCL(ncclGetVersion(&ver));
+  if (ver / 10000 != NCCL_MAJOR)
+    return fail(SBO_E_COMM, "RCCL version mismatch: loaded " + std::to_string(ver) + ", compiled against " + std::to_string(NCCL_VERSION_CODE));
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
   ncclComm_t comm;
   SBO_NCCL(ncclCommInitRank(&comm, world_size, uid, rank));
+  // world / rank change only once the communicator exists: a failed init leaves the context single-rank and usable
   c->comm = comm;
+  c->world = world_size;
+  c->rank = rank;
   return SBO_OK;
 }
 
@@ -114,7 +129,7 @@ int sbo_comm_init_relay(sbo_ctx* c, int world_size, int rank, sbo_relay_allreduc
 
 int sbo_comm_barrier(sbo_ctx* c) {
   if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
-  if (c->world > 1) {
+  if (multi_rank(c)) {
     int rc = comm_allreduce_sum_f64(c, (double*)c->scal.p + 500, 1);
     if (rc) return rc;
   }

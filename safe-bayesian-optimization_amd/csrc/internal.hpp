@@ -139,6 +139,7 @@ struct sbo_ctx {
   // comm
   void* comm = nullptr;  // ncclComm_t
   int world = 1, rank = 0;
+  int comm_selftest = 0; // 1: a one-rank world still sends C1 / C2 / C3 through its communicator (test of the RCCL calls on one GPU)
   // rehearsal transport (tests on a 1-GPU box): collectives staged through host callbacks instead of RCCL
   sbo_relay_allreduce_fn relay_allreduce = nullptr;
   sbo_relay_allgather_fn relay_allgather = nullptr;
@@ -146,6 +147,8 @@ struct sbo_ctx {
 };
 
 namespace sbo {
+// the sweeps take their multi-rank path (pack, collective, unpack, host merge): more than one rank, or the self-test
+inline bool multi_rank(const sbo_ctx* c) { return c->world > 1 || c->comm_selftest; }
 int fail(int code, const std::string& msg);
 int hip_fail(hipError_t e, const char* what);
 int ensure(DevBuf& b, size_t bytes);

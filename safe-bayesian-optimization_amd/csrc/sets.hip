@@ -472,7 +472,7 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o) {
   const int q = c->mc.q;
   int rc;
   long long npad_shard = n;                  // ranks > 1: the U mask is all-gathered with the largest shard's size
-  for (size_t r = 0; r + 1 < c->first_of.size() && c->world > 1 && c->sharded; ++r)
+  for (size_t r = 0; r + 1 < c->first_of.size() && multi_rank(c) && c->sharded; ++r)
     npad_shard = std::max(npad_shard, c->first_of[r + 1] - c->first_of[r]);
   if ((rc = ensure(c->maskS, (size_t)n))) return rc;
   if ((rc = ensure(c->maskU, (size_t)npad_shard))) return rc;
@@ -501,7 +501,7 @@ static int launch_exact(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lidx,
   const T* var_c = (const T*)c->var.p + (size_t)cidx * n;
   CandSpec csU = c->cs;          // the witness set: every candidate of every rank
   const uint8_t* Uall = (const uint8_t*)c->maskU.p;
-  if (c->world > 1) {
+  if (multi_rank(c)) {
     csU.first = 0;
     csU.n_local = c->grid_total;
     Uall = (const uint8_t*)c->Ufull.p;
@@ -557,10 +557,10 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     // Window of the transform: this rank's hyper-planes of the slowest axis plus, with ranks > 1, a halo of
     // ceil(cap / h) planes on either side taken from the all-gathered U mask (cap = largest radius that can matter,
     // from the keys of collective C1).  Witnesses further away cannot change a verdict, so the window is exact.
-    const long long planes_total = c->world > 1 ? c->cs.count[d - 1] : n / plane;
-    long long p0 = c->world > 1 ? c->cs.first / plane : 0, p1 = p0 + n / plane;
+    const long long planes_total = multi_rank(c) ? c->cs.count[d - 1] : n / plane;
+    long long p0 = multi_rank(c) ? c->cs.first / plane : 0, p1 = p0 + n / plane;
     const long long own0 = p0;
-    if (c->world > 1) {
+    if (multi_rank(c)) {
       if ((rc = sweep_exchange_wait(c))) return rc;
       double L, rmax = 0.0;
       memcpy(&L, &c->h_c1[1 + lidx], 8);
@@ -578,7 +578,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     const long long wplanes = p1 - p0;
     const long long nt = wplanes * plane;
     const long long goff = (own0 - p0) * plane;                 // own candidates start here inside the window
-    const uint8_t* Uall = c->world > 1 ? (const uint8_t*)c->Ufull.p + p0 * plane : (const uint8_t*)c->maskU.p;
+    const uint8_t* Uall = multi_rank(c) ? (const uint8_t*)c->Ufull.p + p0 * plane : (const uint8_t*)c->maskU.p;
     if ((rc = ensure(c->dist2, sizeof(double) * (size_t)nt))) return rc;
     if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)nt))) return rc;
     const int count0 = d >= 2 ? (int)c->cs.count[0] : (int)nt;  // d == 1: the window is one line
@@ -689,7 +689,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     // explicit candidate lists, and grid ranges that are not whole hyper-planes: exhaustive evaluation
     if (n > (1ll << 17))
       return fail(SBO_E_UNSUPPORTED, "expander sets need a grid of whole hyper-planes, or at most 131072 candidates (exhaustive)");
-    if (c->world > 1)
+    if (multi_rank(c))
       return fail(SBO_E_UNSUPPORTED, "expander sets on explicit candidate lists are single-rank");
     hipLaunchKernelGGL(k_list_safe, dim3(nb), dim3(256), 0, c->stream, (const uint8_t*)c->maskS.p, n, sc, G,
                        (long long*)c->amb.p);
@@ -730,7 +730,7 @@ template <typename T>
 static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U) {
   const int q = c->mc.q;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
-  if (c->world <= 1) return SBO_OK;   // (the radius keys, max over S of ucb_c, come out of k_classify)
+  if (!multi_rank(c)) return SBO_OK;   // (the radius keys, max over S of ucb_c, come out of k_classify)
   int rc;
   if (!c->sharded && q > 1 && need_U)
     return fail(SBO_E_INVALID, "multi-rank sweeps with constraints need sbo_candidates_grid_sharded");
@@ -783,7 +783,7 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   static_assert(sizeof(SweepScalars) <= 2048 && sizeof(unsigned long long) * kMaxQ <= 512, "read-back area");
   constexpr size_t kBack = 3072 + sizeof(unsigned long long) * kMaxQ;
   const unsigned long long* Lk_pinned = (const unsigned long long*)(c->h_back + 3072);
-  if (c->world <= 1) {
+  if (!multi_rank(c)) {
     SBO_HIP(hipMemcpyAsync(c->h_back, sc, kBack, hipMemcpyDeviceToHost, c->stream));
     if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
     SBO_HIP(hipStreamSynchronize(c->stream));
@@ -934,7 +934,7 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
   const T* var_c = (const T*)c->var.p + (size_t)cidx * n;
   int rc;
   long long maxlocal = n;
-  for (int r = 0; r < c->world && c->world > 1; ++r) maxlocal = std::max(maxlocal, c->first_of[r + 1] - c->first_of[r]);
+  for (int r = 0; r < c->world && multi_rank(c); ++r) maxlocal = std::max(maxlocal, c->first_of[r + 1] - c->first_of[r]);
   if ((rc = ensure(c->gw, sizeof(T) * (size_t)std::max<long long>(maxlocal, 1)))) return rc;
   if (n > 0)
     hipLaunchKernelGGL((k_goose_weights<T>), dim3(reduce_blocks(c)), dim3(256), 0, c->stream, mean_c, var_c, n, (T)o->b, src,
@@ -944,7 +944,7 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
   long long run_lo = 0, run_hi = (n + kRun - 1) / kRun;
   long long win_p0 = 0, win_p1 = 0;     // ranks > 1: window of hyper-planes holding every source that can matter
   bool w_is_window = false;             // ranks > 1, slab exchange: W holds exactly the window [win_p0, win_p1)
-  if (c->world > 1) {
+  if (multi_rank(c)) {
     // Sources of the other ranks that can reach this shard lie within H hyper-planes of it (H from the largest source
     // radius, keys of collective C1 -- exact, as for the expanders).
     const int d = c->cs.d;
@@ -1024,9 +1024,9 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     const int d = c->cs.d;
     SweepScalars* sc = (SweepScalars*)c->scal.p;
     const long long own0 = c->cs.first / plane1;
-    const long long w0 = c->world > 1 ? win_p0 : own0, w1 = c->world > 1 ? win_p1 : own0 + n / plane1;
+    const long long w0 = multi_rank(c) ? win_p0 : own0, w1 = multi_rank(c) ? win_p1 : own0 + n / plane1;
     const long long wplanes = w1 - w0, nt = wplanes * plane1, goff = (own0 - w0) * plane1;
-    const T* Wwin = (c->world > 1 && !w_is_window) ? W + w0 * plane1 : W;
+    const T* Wwin = (multi_rank(c) && !w_is_window) ? W + w0 * plane1 : W;
     if ((rc = ensure(c->dist2, sizeof(double) * (size_t)nt))) return rc;
     if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)nt))) return rc;
     if ((rc = ensure(c->amb, sizeof(long long) * (size_t)n))) return rc;
@@ -1241,7 +1241,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   for (int t = 0; t < kArgSlots; ++t) is_max[t] = false;
   // Single rank: the explore step (target choice, distances, arg-min over S) is enqueued before the read-back, one host
   // round trip per sweep; ranks > 1 need the merged target slots first and take a second one below.
-  const bool fused_explore = c->world <= 1 && q > 1;
+  const bool fused_explore = !multi_rank(c) && q > 1;
   double* dev_t = (double*)c->scal.p + 256;
   if (fused_explore) {
     switch (c->mc.dpad) {
@@ -1359,7 +1359,7 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
   SweepScalars h;
   bool is_max[kArgSlots];
   for (int t = 0; t < kArgSlots; ++t) is_max[t] = false;
-  if (c->world > 1) {
+  if (multi_rank(c)) {
     if ((rc = ensure(c->xch, sizeof(double) * (size_t)(c->world * kC3Row + 64)))) return rc;
   }
   if ((rc = sweep_exchange_back(c, h, is_max))) return rc;

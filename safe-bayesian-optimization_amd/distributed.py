@@ -95,26 +95,41 @@ def join(engine, relay: bool = False, group=None):
         L.check(engine._lib.sbo_comm_init_relay(engine._ctx, world, rank, cb.allreduce, cb.allgather, None))
         engine.world, engine.rank = world, rank
         return
-    uid = [engine.comm_unique_id() if rank == 0 else None]
+    # the broadcast always happens, also when rank 0 could not create the id: every rank then raises the same error
+    # instead of some of them waiting in the broadcast for a rank that has already left
+    uid = [None]
+    if rank == 0:
+        try:
+            uid[0] = engine.comm_unique_id()
+        except Exception as exc:                  # noqa: BLE001
+            uid[0] = ("error", str(exc))
     dist.broadcast_object_list(uid, src=0, group=group)
+    if isinstance(uid[0], tuple):
+        raise L.SafeBOError(L.SBO_E_COMM, f"rank 0 could not create the RCCL unique id: {uid[0][1]}")
     engine.comm_init(world, rank, uid[0])
 
 
-def join_with_fallback(engine, group=None) -> str:
-    """RCCL if every rank can form the communicator, otherwise every rank falls back to the gloo relay (so a launcher
-    environment without working RCCL still runs, slower on the three small collectives).  Returns the transport used."""
+def join_with_fallback(engine, group=None, allow_relay: bool = True) -> str:
+    """RCCL if every rank can form the communicator.  Otherwise, with ``allow_relay`` (one-GPU rehearsals of the N > 1
+    plumbing, where RCCL refuses two ranks on one device), every rank falls back to the gloo relay; without it every rank
+    raises -- a real multi-GPU run must never publish a relay-speed number.  Returns the transport used."""
     import torch
     import torch.distributed as dist
-    ok = 1
+    ok, err = 1, None
     try:
         join(engine, relay=False, group=group)
     except Exception as exc:                      # noqa: BLE001 - any failure means "no RCCL here"
-        print(f"[rank {dist.get_rank(group)}] RCCL communicator failed ({exc}); trying the gloo relay")
+        err = exc
         ok = 0
     flag = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     if int(flag[0]) == 1:
         return "rccl"
+    if not allow_relay:
+        raise L.SafeBOError(L.SBO_E_COMM, f"[rank {dist.get_rank(group)}] the RCCL communicator could not be formed on every rank"
+                            + (f" (this rank: {err})" if err is not None else " (this rank was fine)"))
+    if err is not None:
+        print(f"[rank {dist.get_rank(group)}] RCCL communicator failed ({err}); using the gloo relay")
     join(engine, relay=True, group=group)
     return "gloo-relay"
 

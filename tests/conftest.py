@@ -10,11 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # the shared library is a build artefact (git-ignored): build it when a fresh checkout runs the tests first
-    lib = os.path.join(ROOT, "safe-bayesian-optimization_amd", "libsafebo.so")
-    if not os.path.exists(lib):
-        import subprocess
-        subprocess.run(["make", "-C", os.path.join(ROOT, "safe-bayesian-optimization_amd", "csrc"), "-j4"], check=True)
+    # the shared library is a build artefact (git-ignored): always run make -- a no-op when it is up to date, and a
+    # library older than its sources must never be what the suite tests
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "safe-bayesian-optimization_amd", "csrc"), "-j4"], check=True,
+                   stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")

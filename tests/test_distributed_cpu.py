@@ -41,8 +41,14 @@ def test_two_rank_gloo_sweep_matches_single_rank_oracle(tmp_path):
     env = dict(os.environ, OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), "2", port, out], env=env)
              for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=300) == 0
+    try:
+        codes = [p.wait(timeout=300) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    assert codes == [0, 0]
     got = json.load(open(out))
     cfg = synthetic.make_config("A", n=20)
     pts = oracle.grid_points(cfg["bound"][:, 0], cfg["bound"][:, 1], [30, 23])

@@ -735,6 +735,18 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
+def _wait_ranks(procs, timeout=600):
+    """Exit codes of the rank workers; whatever happens (a failed rank, a timeout, an exception in the test body between
+    launch and wait), no worker is left behind holding the GPU."""
+    try:
+        return [p.wait(timeout=timeout) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+
+
 @pytest.mark.parametrize("world,cfg_name,n,count,b", [(2, "A", 20, [50, 37], 3.0), (2, "C", 64, [48, 41], 2.0),
                                                        (2, "D", 128, [9, 8, 7, 5], 0.5), (4, "C", 64, [40, 83], 2.0),
                                                        (3, "B", 128, [64, 50], 3.0)])
@@ -744,8 +756,7 @@ def test_multi_rank_sweep_on_one_gpu_matches_oracle(tmp_path, world, cfg_name, n
     port, out = _free_port(), str(tmp_path / "res.json")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), str(world), port, out, cfg_name,
                                str(n), json.dumps(count), str(b)]) for r in range(world)]
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    assert _wait_ranks(procs) == [0] * world
     res = json.load(open(out))
     cfg = synthetic.make_config(cfg_name, n=n)
     pts = oracle.grid_points(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
@@ -782,16 +793,21 @@ def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_
     port, out = _free_port(), str(tmp_path / "res.json")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), str(world), port, out, cfg_name,
                                str(n), json.dumps(count), str(b)]) for r in range(world)]
-    cfg = synthetic.make_config(cfg_name, n=n)
-    engine.set_model(cfg["ds"])
-    engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
-    ref = engine.sweep_safeopt(b, want_masks=True)
-    rmask = {k: engine.mask(k) for k in ("S", "U", "M")}
-    rmask.update({f"G{c}": engine.mask("G", c) for c in range(1, cfg["q"])})
-    gref = engine.sweep_goose(b, want_masks=True, posterior_ready=True)
-    rmask.update({f"O{c}": engine.mask("O", c) for c in range(1, cfg["q"])})
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    try:
+        cfg = synthetic.make_config(cfg_name, n=n)
+        engine.set_model(cfg["ds"])
+        engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+        ref = engine.sweep_safeopt(b, want_masks=True)
+        rmask = {k: engine.mask(k) for k in ("S", "U", "M")}
+        rmask.update({f"G{c}": engine.mask("G", c) for c in range(1, cfg["q"])})
+        gref = engine.sweep_goose(b, want_masks=True, posterior_ready=True)
+        rmask.update({f"O{c}": engine.mask("O", c) for c in range(1, cfg["q"])})
+    except BaseException:
+        for p in procs:
+            p.kill()
+            p.wait()
+        raise
+    assert _wait_ranks(procs) == [0] * world
     res = json.load(open(out))
     parts = [np.load(out + f".rank{r}.npz") for r in range(world)]
     for k, want in rmask.items():

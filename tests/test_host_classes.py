@@ -75,6 +75,28 @@ def test_hyperparameter_fit_stays_in_reference_bounds():
         assert np.allclose(m.invKopt[i] @ K, np.eye(7), atol=1e-6)
 
 
+def test_incremental_host_state_is_the_bordered_inverse():
+    """CPU part of add_sample(incremental=True): invKopt after the append equals inv(K_{n+1}) under the frozen hyper-parameters
+    (the device append itself is checked under the gpu marker)."""
+    m = _init(SafeOpt.BO, n=10)
+
+    class _NoDevice:                      # the append's device call is not under test here
+        def append_sample(self, xn, yn):
+            self.got = (xn.copy(), yn.copy())
+    m._engine = _NoDevice()
+    m._uploaded_version = m._model_version
+    v0 = m._model_version
+    x_new = np.array([1.35, -0.75])
+    m.add_sample(x_new, m.calculate_plant_outputs(x_new), incremental=True)
+    assert m._model_version == v0 + 1 and m._uploaded_version == m._model_version
+    d = 2
+    for i in range(2):
+        K = m.Cov_mat("RBF", m.X_norm, m.X_norm, np.exp(2 * m.hypopt[:d, i]), np.exp(2 * m.hypopt[d, i])) \
+            + (np.exp(2 * m.hypopt[d + 1, i]) + np.finfo(np.float32).eps) * np.eye(11)
+        assert np.allclose(m.inference_datasets["invKopt"][i] @ K, np.eye(11), atol=1e-9)
+    assert np.allclose(m._engine.got[0], (x_new - m.X_mean) / m.X_std)
+
+
 def test_infnorm_mean_grad_matches_oracle():
     m = _init(GoOSE.BO)
     pts = np.array([[1.2, -0.5], [0.1, 0.3], [1.45, -0.9]])
@@ -85,6 +107,41 @@ def test_infnorm_mean_grad_matches_oracle():
 
 
 # ------------------------------------------------------------------------------------------------------------ device
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", [SafeOpt.BO, GoOSE.BO])
+def test_incremental_add_sample_invalidates_the_cached_sweep(cls):
+    """sweep -> add_sample(incremental=True) -> sweep must be the sweep of the (n + 1)-point model: the host classes key their
+    caches on the model version, which the incremental path bumps without re-uploading; the host copy of the model
+    (bordered inverse) stays a complete state that can be uploaded again and that the oracle evaluates."""
+    m = _init(cls, n=14, grid=(60, 50))
+    first = m.sweep()
+    x_new = np.asarray(first["minimizer_x"])
+    y_new = m.calculate_plant_outputs(x_new)
+    m.add_sample(x_new, y_new, incremental=True)
+    assert m.n_point == 15 and m.inference_datasets["X_norm"].shape == (15, 2) and m.inference_datasets["invKopt"][0].shape == (15, 15)
+    second = m.sweep()
+    assert second is not first
+    pts = oracle.grid_points(BOUND[:, 0], BOUND[:, 1], [60, 50])
+    ref = oracle.safeopt_sweep(pts, m.inference_datasets, 3.0)       # frozen normalisation + hyper-parameters, 15 rows
+    assert second["minimizer_index"] == ref["minimizer_index"] and second["count_S"] == int(ref["S"].sum())
+    assert second["minimizer_std"] == pytest.approx(ref["minimizer_std"], rel=1e-7)
+    assert second["minimizer_std"] < first["minimizer_std"]           # the sampled point is no longer the most uncertain
+    if cls is GoOSE.BO:
+        g = m.goose_sweep()
+        gref = oracle.goose_sweep(pts, m.inference_datasets, 3.0)
+        assert g["safe_min_index"] == gref["safe_min_index"] and g["target_index"] == gref["target_index"]
+    # a posterior query with another dataset forces a re-upload of the own one afterwards: it must still be consistent
+    other = _init(cls, n=9)
+    m.GP_inference(np.array([1.2, -0.6]), other.inference_datasets)
+    m._grid_resident()
+    again = m.engine.sweep_safeopt(3.0)
+    assert again["minimizer_index"] == ref["minimizer_index"]
+    # and a rebuild under the same frozen state agrees with the appended device model
+    mean_inc, var_inc = m.GP_inference(pts[::37], None)
+    om, ov = oracle.gp_inference(pts[::37], m.inference_datasets)
+    assert np.max(np.abs(mean_inc - om)) < 1e-8 and np.max(np.abs(var_inc - ov)) < 1e-8
+
+
 @pytest.mark.gpu
 def test_bo_bounds_single_and_batched():
     m = _init(SafeOpt.BO)
