@@ -5,8 +5,10 @@ restatements of the reference's plant callables, used only to label the syntheti
 Benoit ``f = u0^2 + u1^2 + u0 u1`` (problems/Benoit_Problem.py:14-19) with the tight constraint
 ``g = -(1 - u0 + u1^2 + 2 u1)`` (problems/Benoit_Problem.py:38-44); a build-defined 4-D chained
 Rosenbrock (the reference's problems/Rosenbrock_Problem.py:15-18 is 2-D only) with the same constraint on
-(x0, x1); a smooth 3-output stand-in on the Williams-Otto box [[4,7],[70,100]] (test/test_GoOSE.py:279;
-the real plant is an ``fsolve`` steady state and is out of scope here); and a 6-D sum of sines.
+(x0, x1); the Williams-Otto reactor on its box [[4,7],[70,100]] (problems/WilliamOttoReactor_Problem.py:19-93,
+test/test_GoOSE.py:276-280: objective + two constraints, each the steady state of six mass balances -- solved here by a
+vectorised Newton iteration in NumPy so that the config can be built without a GPU; ``sbo_plant_wo`` is the device
+evaluator of the same plant); and a 6-D sum of sines.
 Hyper-parameters are fixed, not fitted: log ell = -0.5, log sigma_f = 0, log sigma_n = -2 for every
 output (inside the reference bounds models/GP_Safe.py:205-206).
 """
@@ -32,15 +34,47 @@ def rosenbrock4(X):
     return np.stack([f, g], axis=1)
 
 
-def wo_standin(X):
-    """Smooth 3-output surrogate on the Williams-Otto box: objective + two constraints that are positive
-    (safe) in the lower-left part of the box, like 0.12 - x_A and 0.08 - x_G of the real plant."""
-    u = (X[:, 0] - 4.0) / 3.0
-    v = (X[:, 1] - 70.0) / 30.0
-    f = -(60.0 + 40.0 * np.sin(2.0 * u + 0.5) * np.cos(1.5 * v - 0.3) + 15.0 * u * v)
-    g1 = 0.06 - 0.10 * (u - 0.35) ** 2 - 0.05 * v ** 2 + 0.02 * np.cos(3.0 * u)
-    g2 = 0.05 - 0.08 * u * v - 0.03 * (v - 0.5) ** 2 + 0.01 * np.sin(4.0 * v)
-    return np.stack([f, g1, g2], axis=1)
+def williams_otto(X, iters=80):
+    """Noise-free outputs of the reference's William-Otto reactor for input rows X[N, 2] = (Fb, Tr): [N, 3] =
+    (get_objective, get_constraint1, get_constraint2) of problems/WilliamOttoReactor_Problem.py:45-93.  The reference finds
+    the steady state of the six balances (:19-43) with ``fsolve`` from x0 = 0.1, once per point and output; here all rows
+    take Newton steps together (analytic Jacobian; a step is halved until the mass fractions stay non-negative).  Checked
+    against the reference's own 100 x 100 table in tests/test_oracle.py."""
+    X = np.asarray(X, dtype=np.float64)
+    Fb, Tr = X[:, 0], X[:, 1]
+    Fa, Vr = 1.8275, 2105.2
+    Fr = Fa + Fb
+    k1, k2, k3 = (k0 * np.exp(-eta / (Tr + 273)) for k0, eta in ((1.6599e6, 6666.7), (7.2177e8, 8333.3), (2.6745e12, 11111.0)))
+    w = np.full((X.shape[0], 6), 0.1)
+    a = -Fr / Vr
+    for _ in range(iters):
+        xa, xb, xc, xp, xe, xg = w.T
+        f = np.stack([(Fa - Fr * xa - Vr * xa * xb * k1) / Vr,
+                      (Fb - Fr * xb - Vr * xa * xb * k1 - Vr * xb * xc * k2) / Vr,
+                      a * xc + 2 * xa * xb * k1 - 2 * xb * xc * k2 - xc * xp * k3,
+                      a * xp + xb * xc * k2 - 0.5 * xp * xc * k3,
+                      a * xe + 2 * xb * xc * k2,
+                      a * xg + 1.5 * xp * xc * k3], axis=1)
+        J = np.zeros((X.shape[0], 6, 6))
+        J[:, 0, 0], J[:, 0, 1] = a - xb * k1, -xa * k1
+        J[:, 1, 0], J[:, 1, 1], J[:, 1, 2] = -xb * k1, a - xa * k1 - xc * k2, -xb * k2
+        J[:, 2, 0], J[:, 2, 1], J[:, 2, 2], J[:, 2, 3] = 2 * xb * k1, 2 * xa * k1 - 2 * xc * k2, a - 2 * xb * k2 - xp * k3, -xc * k3
+        J[:, 3, 1], J[:, 3, 2], J[:, 3, 3] = xc * k2, xb * k2 - 0.5 * xp * k3, a - 0.5 * xc * k3
+        J[:, 4, 1], J[:, 4, 2], J[:, 4, 4] = 2 * xc * k2, 2 * xb * k2, a
+        J[:, 5, 2], J[:, 5, 3], J[:, 5, 5] = 1.5 * xp * k3, 1.5 * xc * k3, a
+        step = np.linalg.solve(J, -f[:, :, None])[:, :, 0]
+        lam = np.ones(X.shape[0])
+        for _ in range(30):
+            neg = np.any(w + lam[:, None] * step < 0, axis=1)
+            if not neg.any():
+                break
+            lam[neg] *= 0.5
+        step *= lam[:, None]
+        w = w + step
+        if np.max(np.abs(step)) < 1e-15:
+            break
+    fx = 1043.38 * w[:, 3] * Fr + 20.92 * w[:, 4] * Fr - 79.23 * Fa - 118.34 * Fb
+    return np.stack([-fx, 0.12 - w[:, 0], 0.08 - w[:, 5]], axis=1)
 
 
 def sines6(X, rng):
@@ -110,7 +144,7 @@ def make_config(name, n=None, seed=None):
     elif cfg["plant"] == "rosenbrock4":
         Y = rosenbrock4(X)
     elif cfg["plant"] == "wo":
-        Y = wo_standin(X)
+        Y = williams_otto(X)
     else:
         Y = sines6(X, rng)
     ds = make_dataset(X, Y, default_hypopt(d, Y.shape[1]))

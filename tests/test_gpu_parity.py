@@ -623,6 +623,79 @@ def test_full_size_goose_properties_config_B(engine):
             assert bool(O[hidx]) == want, int(hidx)
 
 
+def test_full_size_goose_properties_config_C(engine):
+    """BASELINE.json configs[2] as specified: the William-Otto reactor (problems/WilliamOttoReactor_Problem.py, the plant of
+    test/test_GoOSE.py:276-280) on a 1024 x 1024 grid, n = 256 observations, q = 3 outputs, b = 2, GoOSE.  Properties that
+    hold at full size without the brute-force oracle: masks are exact functions of the device bounds, the transform's
+    optimistic sets equal the pruned exact pair evaluation on all candidates, the oracle's predicates re-decide samples on
+    both sides of the boundaries of G_c and O_c, every arg-min is the NumPy arg-min of the device values, and the
+    posterior matches the oracle on a random subset; the SafeOpt sweep of the same posterior is checked the same way."""
+    cfg = synthetic.make_config("C")
+    assert cfg["plant"] == "wo" and cfg["ds"]["X_norm"].shape == (256, 2) and cfg["q"] == 3 and cfg["count"] == [1024, 1024]
+    lo, hi, count, b, q = cfg["bound"][:, 0], cfg["bound"][:, 1], cfg["count"], cfg["b"], 3
+    N = count[0] * count[1]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    out = {}
+    try:
+        for pairs in (0, 1):
+            engine.set_option("goose_pairs", pairs)
+            res = engine.sweep_goose(b, want_masks=True)
+            out[pairs] = (res, [engine.mask("O", c) for c in (1, 2)])
+    finally:
+        engine.set_option("goose_pairs", 0)
+    res, O = out[0]
+    assert engine.profile()["posterior_kernel"] == 4
+    for c in range(2):
+        assert np.array_equal(O[c], out[1][1][c]), f"O{c + 1}"
+    for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c"):
+        assert res[k] == out[1][0][k], k
+    S, U = engine.mask("S"), engine.mask("U")
+    lcb = [engine.bounds(b, i, "lcb") for i in range(3)]
+    ucb = [engine.bounds(b, i, "ucb") for i in range(3)]
+    assert np.array_equal(S, (lcb[1] >= 0) & (lcb[2] >= 0)) and np.array_equal(U, (lcb[1] <= 0) & (lcb[2] <= 0))
+    assert S.any() and U.any() and O[0].any() and O[1].any()
+    assert res["count_S"] == S.sum() and res["count_U"] == U.sum() and list(res["count_O"]) == [O[0].sum(), O[1].sum()]
+    assert res["safe_min_index"] == int(np.argmin(np.where(S, lcb[0], np.inf)))        # models/GoOSE.py:63-67
+    tgt_c = [int(np.argmin(np.where(O[c], lcb[0], np.inf))) for c in range(2)]
+    assert list(res["target_index_c"]) == tgt_c                                          # models/GoOSE.py:100-112
+    best = int(np.argmin([lcb[0][t] for t in tgt_c]))
+    assert res["target_best_c"] == best + 1 and res["target_index"] == tgt_c[best]
+    pts = oracle.grid_points(lo, hi, count)
+    dist = np.sqrt(((pts - pts[res["target_index"]][None, :]) ** 2).sum(axis=1))
+    assert res["explore_index"] == int(np.argmin(np.where(S, dist, np.inf)))             # models/GoOSE.py:116-119
+    assert res["choose_safe_min"] == bool(res["safe_min_lcb"] <= res["target_lcb"])      # test/test_GoOSE.py:158
+    # SafeOpt sweep on the same posterior: expander masks, then the oracle's pair predicates around the set boundaries
+    s = engine.sweep_safeopt(b, want_masks=True, posterior_ready=True)
+    G = [engine.mask("G", c) for c in (1, 2)]
+    M = engine.mask("M")
+    var0 = engine.bounds(b, 0, "var")
+    assert s["u_star"] == ucb[0][S].min() and np.array_equal(M, S & (lcb[0] <= s["u_star"]))
+    assert s["minimizer_index"] == int(np.argmax(np.where(M, var0, -np.inf)))
+    assert list(s["expander_index_c"]) == [int(np.argmax(np.where(G[c], var0, -np.inf))) if G[c].any() else -1 for c in range(2)]
+    assert np.array_equal(s["L"], res["L"])
+    rng = np.random.default_rng(13)
+    Lq = res["L"][q - 1]                                   # reference quirk: every constraint uses L_{q-1}
+    xu, xs = pts[U], pts[S]
+    for c in range(2):
+        assert not (G[c] & ~S).any() and not (O[c] & ~U).any()
+        us = ucb[c + 1][S]
+        for mask, dom in ((G[c], S), (O[c], U)):
+            edge = np.nonzero((mask[:-1] != mask[1:]) & dom[:-1] & dom[1:])[0]
+            pick = rng.choice(edge, size=min(10, edge.size), replace=False) if edge.size else np.array([], dtype=int)
+            extra = rng.choice(np.nonzero(dom)[0], size=10, replace=False)
+            for i in np.concatenate([pick, pick + 1, extra]):
+                if mask is G[c]:
+                    want = bool(np.any(ucb[c + 1][i] - Lq * oracle.shifted_norm(pts[i][None, :], xu) >= 0))
+                else:
+                    want = bool(np.any(us - Lq * oracle.shifted_norm(xs, pts[i][None, :]) >= 0))
+                assert bool(mask[i]) == want, (c + 1, "G" if mask is G[c] else "O", int(i))
+    mean, var = engine.posterior()
+    sub = np.sort(rng.choice(N, size=4096, replace=False))
+    om, ov = oracle.gp_inference(pts[sub], cfg["ds"])
+    assert _nerr(mean[sub], om, cfg["ds"]["Y_std"], 1) < TOL64 and _nerr(var[sub], ov, cfg["ds"]["Y_std"], 2) < TOL64
+
+
 def test_full_size_properties_config_H(engine):
     """The headline configuration (4096^2 grid, n = 512, fp64) at full size on one GPU: the masks are exact functions of
     the device posterior, the posterior matches the oracle on a random subset and the two posterior kernels agree on the
@@ -820,6 +893,66 @@ def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_
     for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c"):
         assert g[k] == gref[k], k
     assert g["count_O"] == gref["count_O"].tolist() and g["target_index_c"] == gref["target_index_c"].tolist()
+
+
+@pytest.mark.parametrize("cfg_name,n,count", [("B", 128, [320, 300]), ("C", 64, [256, 300]), ("D", 128, [20, 18, 17, 24])])
+def test_rccl_collectives_on_a_one_rank_communicator(engine, cfg_name, n, count):
+    """The RCCL calls themselves on the one GPU of the test box: a genuine one-rank communicator (ncclCommInitRank) and
+    option "comm_selftest", which makes the sweeps take their multi-rank path -- C1 ncclAllReduce(ncclUint64, ncclMax, in
+    place), C2 ncclAllGather of the packed U mask (and of the GoOSE source slabs), C3 ncclAllReduce(ncclDouble, ncclSum)
+    with the host merge.  Results must equal the plain single-rank sweep of the same grid bit for bit."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    q = cfg["q"]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    ref = engine.sweep_safeopt(cfg["b"], want_masks=True)
+    rmask = {k: engine.mask(k) for k in ("S", "U", "M")}
+    rmask.update({f"G{c}": engine.mask("G", c) for c in range(1, q)})
+    gref = engine.sweep_goose(cfg["b"], want_masks=True, posterior_ready=True)
+    rmask.update({f"O{c}": engine.mask("O", c) for c in range(1, q)})
+    tref = engine.sweep_tr(cfg["b"], ref["minimizer_x"], 0.7, posterior_ready=True)
+    with safebo_amd.SweepEngine(0) as eng:
+        with pytest.raises(ValueError, match="needs a communicator"):
+            eng.set_option("comm_selftest", 1)
+        eng.comm_init(1, 0, eng.comm_unique_id())
+        eng.set_option("comm_selftest", 1)
+        eng.comm_barrier()
+        eng.set_model(cfg["ds"])
+        eng.set_grid_sharded(lo, hi, count)
+        assert (eng.first, eng.n_local) == (0, int(np.prod(count)))
+        res = eng.sweep_safeopt(cfg["b"], want_masks=True)
+        for k in ("S", "U", "M"):
+            assert np.array_equal(eng.mask(k), rmask[k]), k
+        for c in range(1, q):
+            assert np.array_equal(eng.mask("G", c), rmask[f"G{c}"]), f"G{c}"
+        for k in ("minimizer_index", "expander_index", "count_S", "count_U", "count_M", "u_star", "minimizer_std", "expander_best_c",
+                  "n_exact_rechecks"):
+            assert res[k] == ref[k], k
+        assert np.array_equal(res["L"], ref["L"]) and np.array_equal(res["count_G"], ref["count_G"])
+        g = eng.sweep_goose(cfg["b"], want_masks=True, posterior_ready=True)
+        for c in range(1, q):
+            assert np.array_equal(eng.mask("O", c), rmask[f"O{c}"]), f"O{c}"
+        for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c", "safe_min_lcb"):
+            assert g[k] == gref[k], k
+        assert np.array_equal(g["count_O"], gref["count_O"])
+        t = eng.sweep_tr(cfg["b"], ref["minimizer_x"], 0.7, posterior_ready=True)
+        assert (t["index"], t["count_T"], t["lcb"]) == (tref["index"], tref["count_T"], tref["lcb"])
+
+
+def test_comm_init_failure_leaves_the_context_single_rank(engine):
+    """A communicator that cannot be formed (here: rank out of range / no id) must not leave world > 1 behind with no
+    transport (the next sweep then called a NULL relay callback)."""
+    with safebo_amd.SweepEngine(0) as eng:
+        with pytest.raises(ValueError):
+            eng.comm_init(2, 5, eng.comm_unique_id())
+        with pytest.raises(ValueError):
+            eng.comm_init(2, 0, None)
+        cfg = synthetic.make_config("A")
+        eng.set_model(cfg["ds"])
+        eng.set_grid_sharded(cfg["bound"][:, 0], cfg["bound"][:, 1], [50, 50])
+        assert (eng.world, eng.n_local) == (1, 2500)
+        assert eng.sweep_safeopt(cfg["b"])["count_S"] > 0
 
 
 @pytest.mark.parametrize("use_invK", [True, False])

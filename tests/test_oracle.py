@@ -175,3 +175,41 @@ def test_wo_plant_restatement_matches_the_reference_table():
     # the known optimum of the reference (test/test_WilliamOttoReactor.py:250): objective -76.036 at the constrained optimum
     f, J = plants.wo_residual_jacobian(plants.wo_steady_state(U[:7]), U[:7, 0], U[:7, 1])
     assert np.max(np.abs(f)) < 1e-15
+
+
+def test_config_C_plant_labels_match_the_reference_table():
+    """The host generator of BASELINE.json configs[2]'s observations (safebo_amd.synthetic.williams_otto) against the
+    reference's own 100 x 100 table of the William-Otto plant and against the oracle's restatement."""
+    from oracle import plants
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "wo_contour_reference.npz"), allow_pickle=False)
+    U = np.stack([z["X_0"].ravel(), z["X_1"].ravel()], axis=1)
+    Y = synthetic.williams_otto(U)
+    assert np.max(np.abs(Y[:, 0] - z["Y_objective"].ravel())) < 1e-5
+    assert np.max(np.abs(Y[:, 1] - z["Y_constraint1"].ravel())) < 1e-8
+    assert np.max(np.abs(Y[:, 2] - z["Y_constraint2"].ravel())) < 1e-8
+    assert np.max(np.abs(Y - plants.wo_outputs(U)) / np.maximum(1.0, np.abs(Y))) < 1e-12
+    cfg = synthetic.make_config("C")
+    assert cfg["Y"].shape == (256, 3) and np.array_equal(cfg["Y"], synthetic.williams_otto(cfg["X"]))
+    assert cfg["b"] == 2.0 and cfg["bound"].tolist() == [[4.0, 7.0], [70.0, 100.0]]        # test/test_GoOSE.py:279-280
+
+
+def test_extended_precision_evaluation_brackets_the_fp64_oracle():
+    """oracle/extended.py: in a well-conditioned model the three evaluations agree to fp64 rounding; at the bottom of the
+    reference's noise range the fp64 formula visibly rounds (the quantity the GPU envelope tests are scaled by) while the
+    two extended-precision evaluations still agree with each other to the accuracy of the stored inverse."""
+    from oracle import extended
+    cfg = synthetic.make_config("B", n=60)
+    pts = np.random.default_rng(1).uniform(cfg["bound"][:, 0], cfg["bound"][:, 1], size=(64, 2))
+    ds = cfg["ds"]
+    om, ov = oracle.gp_inference(pts, ds)
+    gm, gv = extended.posterior_given_invK(pts, ds)
+    tm, tv = extended.posterior_true(pts, ds)
+    assert gm.dtype == np.longdouble
+    assert np.max(np.abs(om - gm)) < 1e-12 and np.max(np.abs(ov - gv)) < 1e-12
+    assert np.max(np.abs(gm - tm)) < 1e-12 and np.max(np.abs(gv - tv)) < 1e-12
+    hard = synthetic.make_dataset(cfg["X"], cfg["Y"], synthetic.default_hypopt(2, 2, log_ell=0.5, log_sf=1.5, log_sn=-5.0))
+    assert np.linalg.cond(np.linalg.inv(hard["invKopt"][0])) > 1e6
+    om, ov = oracle.gp_inference(pts, hard)
+    gm, gv = extended.posterior_given_invK(pts, hard)
+    e_formula = float(np.max(np.abs(ov - gv)))
+    assert 1e-11 < e_formula < 1e-5
