@@ -11,13 +11,23 @@ q = 2 outputs, fp64.  For N > 1 the grid grows along its slowest axis (2048 x 20
 2048^2 candidates ("weak" scaling); the ranks exchange u*/L (one RCCL max all-reduce), the fully-unsafe
 mask (one all-gather) and the arg-max candidates (one sum all-reduce).
 
-The posterior (K1) of that workload runs as two dense fp64 GEMMs in a reduced basis of the separable RBF kernel (K1b,
-bilinear.hip) -- inner dimension ~280 whatever n is -- instead of the O(n^2)-per-candidate triangular contraction the
-algorithmic flop count of SURVEY.md 8(d) assumes.  ``roofline.achieved`` counts, per launch, min(algorithmic flops,
-flops the matrix cores actually issued) / K1 time: wasted flops earn nothing (the contract's point) and neither do
-flops a better algorithm no longer executes, so ``frac`` stays a hardware utilisation <= 1; ``roofline.algorithmic``
-gives the literal SURVEY figure (which exceeds the peak with K1b), and ``table_kernel`` times the same sweep with the
-O(n^2) kernel (K1g) in the same run.
+What the JSON line reports (N = 1 adds the last five):
+  value / ms_per_step   sweeps of ONE RESIDENT MODEL (the metric of BASELINE.json: device time of the whole sweep with the
+                        inputs resident in HBM), K timed steps between barriers.
+  roofline              matrix-core side: the posterior kernels (K1).  ``achieved`` = min(ALGORITHMIC flops of SURVEY.md
+                        8(d), flops ISSUED on the matrix cores) / K1 time -- a utilisation <= 1; ``algorithmic`` is the
+                        literal SURVEY figure (above the peak with K1b, whose GEMMs have an inner dimension ~r(r+1)/2 that
+                        does not grow with n); ``executed`` the issued flops.
+  roofline.hbm          HBM side: the set phase K3-K5 (classification, minimiser, expander transform, arg-max) --
+                        SURVEY.md 8(d) bytes (2 q s + 4 per candidate) / set-phase device time, against 8.0 TB/s
+                        (datasheet) and 6.29 TB/s (measured copy rate of the guide).
+  iteration             what ONE SafeOpt ITERATION costs: the reference refits and sweeps once per model
+                        (test/test_SafeOpt.py:144-179), so here two data sets alternate and every timed step is
+                        set_model (upload + factorisation) + the per-(model, grid) table build of K1b + the sweep.
+  table_kernel          the same resident-model sweep with the O(n^2)-per-candidate kernel K1g.
+  extra                 the other single-GPU configs: H (4096^2, n = 512, SafeOpt) and C (Williams-Otto, 1024^2, n = 256,
+                        q = 3, GoOSE), resident-model sweeps + their iteration cost.
+  cpu_baseline          the NumPy oracle on the box's host cores, bounded prefix of the same grid.
 
 torch is used only as the launcher's rendezvous (gloo group: unique-id broadcast, barriers, max over
 ranks); device memory, streams and the collectives on the data path belong to libsafebo.so.
@@ -39,7 +49,9 @@ if ROOT not in sys.path:
 FP64_MATRIX_PEAK_TFLOPS = 78.6      # AMD MI355X datasheet, FP64 matrix == FP64 vector (guide has no f64 row)
 FP64_MFMA_MEASURED_TFLOPS = {"v_mfma_f64_4x4x4_4b_f64": 75.6, "v_mfma_f64_16x16x4_f64": 47.9}   # profiles/r01_mfma_probe.txt
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, f32-input MFMA
+HBM_PEAK_TBS, HBM_MEASURED_TBS = 8.0, 6.29    # MI355X_MICROARCH.md: datasheet / measured float4 copy
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per K1 launch from rocprofv3 --pmc
+K1_NAMES = {1: "k_posterior", 2: "k_posterior_chunked", 3: "k_posterior_grid", 4: "k_bpost (+ k_bstage1, stage 1)"}
 
 
 def parse_args():
@@ -56,6 +68,8 @@ def parse_args():
     ap.add_argument("--posterior", choices=["auto", "table"], default="auto",
                     help="auto: fp64 2-D grids use the bilinear GEMM posterior (K1b) when its bases qualify; "
                          "table: force the separable-table kernel (K1g), the O(n^2)-per-candidate contraction")
+    ap.add_argument("--sweep", choices=["safeopt", "goose"], default="safeopt")
+    ap.add_argument("--no-extra", action="store_true", help="skip the iteration / table-kernel / H / C records")
     return ap.parse_args()
 
 
@@ -91,6 +105,118 @@ def cpu_baseline(cfg, count, sample):
             "sample": f"first {sample} candidates of the same grid: posterior + bounds + S/U/M masks + u* + arg-max "
                       f"in NumPy ({threads} BLAS threads, {len(os.sched_getaffinity(0))} cores visible), {dt:.2f} s; "
                       f"the oracle's quadratic brute-force expander is excluded"}
+
+
+def sweep_fn(eng, kind, b):
+    return (lambda: eng.sweep_safeopt(b)) if kind == "safeopt" else (lambda: eng.sweep_goose(b))
+
+
+def hbm_roofline(q, es, n_local, set_ms):
+    """the classification / expander / arg-max passes are HBM-bound, ~ 2 q s + 4 bytes per candidate
+    (mean and var of every output read once, three mask bytes and the transform's verdict written), no reuse."""
+    per_cand = 2 * q * es + 4
+    byts = float(per_cand) * n_local
+    tbs = byts / (set_ms * 1e-3) / 1e12 if set_ms > 0 else 0.0
+    return {"bound": "hbm", "kernels": "set phase K3-K5: everything between the K1 stop event and the end of the sweep",
+            "bytes_per_candidate": per_cand, "bytes": byts, "set_phase_ms": set_ms, "achieved": tbs, "unit": "TB/s",
+            "peak": HBM_PEAK_TBS, "frac": tbs / HBM_PEAK_TBS, "frac_vs_measured_copy": tbs / HBM_MEASURED_TBS,
+            "definition": "SURVEY.md 8(d): (2 q s + 4) bytes per candidate / set-phase device time"}
+
+
+def mfma_roofline(cfg, prof_rows, n_local):
+    k1 = float(np.mean([p["posterior_ms"] for p in prof_rows]))
+    flops = float(np.mean([p["posterior_flops"] for p in prof_rows]))
+    issued = float(np.mean([p["posterior_executed_flops"] for p in prof_rows]))
+    peak = FP64_MATRIX_PEAK_TFLOPS if cfg["dtype"] == "f64" else FP32_MATRIX_PEAK_TFLOPS
+    alg = flops / (k1 * 1e-3) / 1e12
+    exe = issued / (k1 * 1e-3) / 1e12
+    achieved = min(alg, exe) if exe > 0 else alg
+    kind = prof_rows[-1]["posterior_kernel"]
+    return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "frac_definition": "min(algorithmic flops, flops issued on the matrix cores) / K1 device time / peak: "
+                               + ("the ISSUED term binds (K1b)" if 0 < exe < alg else "the ALGORITHMIC term binds"),
+            "kernel": K1_NAMES.get(kind, "?"), "kernel_ms": k1,
+            "executed": {"achieved": exe, "frac": exe / peak, "flops_per_candidate": issued / n_local},
+            "algorithmic": {"achieved": alg, "frac": alg / peak, "flops_per_candidate": flops / n_local,
+                            "definition": "SURVEY.md 8(d): q (n^2 + (2 d + 10) n) per candidate"},
+            "peak_source": "AMD MI355X datasheet FP64 matrix (no f64 row in MI355X_MICROARCH.md)" if cfg["dtype"] == "f64" else "MI355X_MICROARCH.md f32 MFMA",
+            "peak_measured_mfma_f64": FP64_MFMA_MEASURED_TFLOPS if cfg["dtype"] == "f64" else None,
+            "device_ms_per_step": float(np.mean([p["total_ms"] for p in prof_rows]))}, kind
+
+
+def timed_resident(eng, step, steps, warmup, barrier):
+    for _ in range(warmup):
+        step()
+    rows = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+        rows.append(eng.profile())
+    barrier()
+    return time.perf_counter() - t0, rows, res
+
+
+def timed_iterations(eng, models, dtype, step, steps, warmup, barrier):
+    """Every step installs the OTHER model (upload, factorisation, alpha), which invalidates the K1b tables, and sweeps:
+    the cost of one iteration of the reference loop on a resident candidate grid."""
+    use_invK = dtype == "f64"
+    for i in range(warmup):
+        eng.set_model(models[i % 2], dtype=dtype, use_invK=use_invK)
+        step()
+    t_set, t_sweep, builds, dev = [], [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ta = time.perf_counter()
+        eng.set_model(models[i % 2], dtype=dtype, use_invK=use_invK)
+        tb = time.perf_counter()
+        step()
+        tc = time.perf_counter()
+        p = eng.profile()
+        t_set.append(tb - ta)
+        t_sweep.append(tc - tb)
+        builds.append(p["posterior_setup_ms"])
+        dev.append(p["total_ms"])
+    barrier()
+    el = time.perf_counter() - t0
+    return {"ms_per_step": el * 1e3 / steps, "steps": steps,
+            "set_model_ms": float(np.mean(t_set)) * 1e3, "sweep_call_ms": float(np.mean(t_sweep)) * 1e3,
+            "table_build_ms": float(np.mean(builds)), "sweep_device_ms": float(np.mean(dev)),
+            "definition": "two data sets alternate; every timed step = set_model (upload + factorisation on the device) + the "
+                          "per-(model, grid) K1b table build + one full sweep; wall clock between barriers"}
+
+
+def extra_record(eng, name, kind, steps, barrier):
+    """Resident-model sweep rate + iteration cost of another single-GPU config, same process."""
+    from safebo_amd import synthetic
+    cfg = synthetic.make_config(name)
+    alt = synthetic.make_config(name, seed=synthetic.SEED0 + 100 + cfg["index"])
+    count = list(cfg["count"])
+    n_total = int(np.prod(count))
+    eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=(cfg["dtype"] == "f64"))
+    eng.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    step = sweep_fn(eng, kind, cfg["b"])
+    el, rows, res = timed_resident(eng, step, steps, max(3, steps // 5), barrier)
+    mf, _ = mfma_roofline(cfg, rows, n_total)
+    set_ms = float(np.mean([p["total_ms"] - p["posterior_ms"] for p in rows]))
+    it = timed_iterations(eng, [alt["ds"], cfg["ds"]], cfg["dtype"], step, max(4, steps // 3), 2, barrier)
+    it["value"] = n_total / (it["ms_per_step"] * 1e-3)
+    it["unit"] = "candidates/s"
+    out = {"config": f"config {name}: {cfg['plant']} {cfg['d']}-D {kind} sweep, implicit grid {'x'.join(map(str, count))} ({n_total} candidates), "
+                     f"n={cfg['n']}, q={cfg['q']}, b={cfg['b']}, {cfg['dtype']}",
+           "sweep": kind, "value": n_total * steps / el, "unit": "candidates/s", "steps": steps, "ms_per_step": el * 1e3 / steps,
+           "roofline": {k: mf[k] for k in ("achieved", "peak", "frac", "kernel", "kernel_ms", "device_ms_per_step", "frac_definition")},
+           "roofline_hbm": hbm_roofline(cfg["q"], 8 if cfg["dtype"] == "f64" else 4, n_total, set_ms), "iteration": it}
+    out["roofline"]["executed_frac"] = mf["executed"]["frac"]
+    out["roofline"]["algorithmic_frac"] = mf["algorithmic"]["frac"]
+    if kind == "safeopt":
+        out["result"] = {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
+                         "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}
+    else:
+        out["result"] = {"count_S": res["count_S"], "count_O": [int(x) for x in res["count_O"]], "safe_min_index": res["safe_min_index"],
+                         "target_index": res["target_index"], "explore_index": res["explore_index"], "exact_rechecks": res["n_exact_rechecks"]}
+    return out
 
 
 def main():
@@ -148,27 +274,10 @@ def main():
             dist.barrier()
         eng.synchronize()
 
-    def step():
-        return eng.sweep_safeopt(cfg["b"])
-
+    step = sweep_fn(eng, args.sweep, cfg["b"])
     if args.posterior == "table":
         eng.set_option("bilinear", 0)
-    for _ in range(args.warmup):
-        step()
-    setup_ms = eng.profile()["posterior_setup_ms"]      # K1b: host build of the per-(model, grid) tables, paid in the warm-up
-    k1_ms, k1_flops, k1_exec, tot_ms = [], [], [], []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        p = eng.profile()
-        k1_ms.append(p["posterior_ms"])
-        k1_flops.append(p["posterior_flops"])
-        k1_exec.append(p["posterior_executed_flops"])
-        tot_ms.append(p["total_ms"])
-    k1_kind = p["posterior_kernel"]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, rows, res = timed_resident(eng, step, args.steps, args.warmup, barrier)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -176,63 +285,59 @@ def main():
         elapsed = float(t[0])
 
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = n_total * args.steps / elapsed
-        k1 = float(np.mean(k1_ms))
-        alg_tflops = float(np.mean(k1_flops)) / (k1 * 1e-3) / 1e12
-        peak = FP64_MATRIX_PEAK_TFLOPS if cfg["dtype"] == "f64" else FP32_MATRIX_PEAK_TFLOPS
-        kname = {1: "k_posterior", 2: "k_posterior_chunked", 3: "k_posterior_grid", 4: "k_bpost (+ k_bstage1, stage 1)"}.get(k1_kind, "?")
-        executed = float(np.mean(k1_exec)) / (k1 * 1e-3) / 1e12
-        achieved = min(alg_tflops, executed) if executed > 0 else alg_tflops
-        traffic = None
-        if os.path.exists(PMC_TRAFFIC_FILE):       # collected by tools/gpu_bench_profile.sh in separate --pmc passes
+        n_local = n_total // world
+        es = 8 if cfg["dtype"] == "f64" else 4
+        roof, k1_kind = mfma_roofline(cfg, rows, n_local)
+        set_ms = float(np.mean([p["total_ms"] - p["posterior_ms"] for p in rows]))
+        roof["hbm"] = hbm_roofline(cfg["q"], es, n_local, set_ms)
+        # HBM bytes of the K1 launch(es) are NOT measured by this run: they come from separate rocprofv3 --pmc passes of the
+        # same command (tools/gpu_bench_profile.sh), committed with the kernel they belong to; null when no record matches
+        roof["traffic"], roof["traffic_source"] = None, None
+        if os.path.exists(PMC_TRAFFIC_FILE):
             key = f"{args.config}:n={cfg['ds']['X_norm'].shape[0]}" + (":K1b" if k1_kind == 4 else "")
             rec = json.load(open(PMC_TRAFFIC_FILE)).get(key)
-            traffic = rec["hbm_bytes_per_launch"] if rec else None
+            if rec:
+                roof["traffic"] = rec["hbm_bytes_per_launch"]
+                roof["traffic_source"] = (f"OFFLINE: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                          f"profiles/pmc_traffic.json[{key}] ({rec.get('kernel')}; collected {rec.get('collected', 'round 1')})")
+        if args.sweep == "safeopt":
+            result = {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
+                      "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}
+        else:
+            result = {"count_S": res["count_S"], "count_O": [int(x) for x in res["count_O"]], "target_index": res["target_index"],
+                      "explore_index": res["explore_index"], "exact_rechecks": res["n_exact_rechecks"]}
         out = {
             "metric": "candidate-points/sec, SafeOpt posterior+safe-set sweep",
-            "value": value, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "value": n_total * args.steps / elapsed, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
-            "config": {"workload": f"config {args.config}: {cfg['plant']} {cfg['d']}-D SafeOpt sweep, "
+            "config": {"workload": f"config {args.config}: {cfg['plant']} {cfg['d']}-D {args.sweep} sweep of one RESIDENT model, "
                                    + (f"explicit list of {n_total} scattered candidates" if scattered else
                                       f"implicit grid {'x'.join(str(c) for c in count)} ({n_total} candidates)")
                                    + f", n={cfg['ds']['X_norm'].shape[0]} observations, q={cfg['q']} outputs, b={cfg['b']}",
-                       "per_gpu_candidates": n_total // world, "sweep": "safeopt", "collectives": transport,
-                       "result": {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
-                                  "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}},
-            # achieved = min(ALGORITHMIC flops of SURVEY.md 8d, flops issued on the matrix cores) / K1 time.  With K1g the
-            # first term binds (padding and the dense blocks of the triangle are not counted); with K1b the second one
-            # does: its two GEMMs (inner dimension ~r(r+1)/2, independent of n) issue far fewer flops than the O(n^2)
-            # count, and "algorithmic" below is that count over the same time -- above the peak by construction.
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel": kname, "kernel_ms": k1,
-                         "executed": {"achieved": executed, "frac": executed / peak,
-                                      "flops_per_candidate": float(np.mean(k1_exec)) / (n_total // world)},
-                         "algorithmic": {"achieved": alg_tflops, "frac": alg_tflops / peak,
-                                         "flops_per_candidate": float(np.mean(k1_flops)) / (n_total // world),
-                                         "definition": "SURVEY.md 8(d): q (n^2 + (2 d + 10) n) per candidate"},
-                         "peak_source": "AMD MI355X datasheet FP64 matrix (no f64 row in MI355X_MICROARCH.md)" if cfg["dtype"] == "f64" else "MI355X_MICROARCH.md f32 MFMA",
-                         "peak_measured_mfma_f64": FP64_MFMA_MEASURED_TFLOPS if cfg["dtype"] == "f64" else None,
-                         "device_ms_per_step": float(np.mean(tot_ms))},
+                       "per_gpu_candidates": n_local, "sweep": args.sweep, "collectives": transport, "result": result},
+            "roofline": roof,
         }
-        if k1_kind == 4:
-            out["roofline"]["table_build_ms"] = setup_ms
-        if world == 1 and k1_kind == 4:
+        extras = world == 1 and not args.no_extra and not scattered
+        if extras:
+            alt = synthetic.make_config(args.config, n=args.n, seed=synthetic.SEED0 + 100 + cfg["index"])
+            it = timed_iterations(eng, [alt["ds"], cfg["ds"]], cfg["dtype"], step, max(10, args.steps // 4), 4, barrier)
+            it["value"] = n_total / (it["ms_per_step"] * 1e-3)
+            it["unit"] = "candidates/s"
+            out["iteration"] = it
+            if k1_kind == 4:
+                roof["table_build_ms"] = it["table_build_ms"]
+        if extras and k1_kind == 4:
             # the same sweep with the separable-table kernel (the O(n^2)-per-candidate contraction on MFMA), same run
             eng.set_option("bilinear", 0)
-            step()
-            t_ms, t_k1 = [], []
-            for _ in range(3):
-                step()
-                pt = eng.profile()
-                t_ms.append(pt["total_ms"])
-                t_k1.append(pt["posterior_ms"])
+            el_t, rows_t, _ = timed_resident(eng, step, 5, 2, barrier)
             eng.set_option("bilinear", 1)
-            tk1 = float(np.mean(t_k1))
-            out["table_kernel"] = {"kernel": "k_posterior_grid", "device_ms_per_step": float(np.mean(t_ms)), "kernel_ms": tk1,
-                                   "value": n_total / (float(np.mean(t_ms)) * 1e-3), "unit": "candidates/s (device time)",
-                                   "achieved": float(np.mean(k1_flops)) / (tk1 * 1e-3) / 1e12, "frac": float(np.mean(k1_flops)) / (tk1 * 1e-3) / 1e12 / peak}
+            rt, _ = mfma_roofline(cfg, rows_t, n_local)
+            out["table_kernel"] = {"kernel": "k_posterior_grid", "device_ms_per_step": rt["device_ms_per_step"], "kernel_ms": rt["kernel_ms"],
+                                   "value": n_total * 5 / el_t, "unit": "candidates/s", "achieved": rt["algorithmic"]["achieved"],
+                                   "frac": rt["algorithmic"]["frac"], "frac_definition": "SURVEY.md 8(d) algorithmic flops / kernel time / peak"}
+        if extras and args.config == "B":
+            out["extra"] = [extra_record(eng, "H", "safeopt", 40, barrier), extra_record(eng, "C", "goose", 40, barrier)]
         if world == 1 and args.cpu_sample > 0 and not scattered:
             out["cpu_baseline"] = cpu_baseline(cfg, count, args.cpu_sample)
         print(json.dumps(out))
