@@ -185,7 +185,7 @@ int sbo_model_set(sbo_ctx* ctx, int dtype, const char* kernel, int n, int d, int
 /* One more observation (normalised coordinates / outputs, the caller's frozen X_mean, X_std, Y_mean, Y_std) under the
  * hyper-parameters of the last sbo_model_set: the lower factor gains one row and alpha is updated in O(n^2) on the
  * device.  SURVEY.md 8(f) rank 2 -- an opt-in fast path; the reference itself refits and renormalises on every sample
- * (models/GP_Safe.py:283-304).  Fails with SBO_E_UNSUPPORTED at n = SBO_MAX_N or 256 appends after the last build. */
+ * (models/GP_Safe.py:283-304).  Fails with SBO_E_UNSUPPORTED at n = SBO_MAX_N. */
 int sbo_model_append(sbo_ctx* ctx, const double* x_norm_new, const double* y_norm_new);
 
 /* explicit list: points[N, d] of doubles (dtype SBO_F64) or floats (SBO_F32); first_index = global flat

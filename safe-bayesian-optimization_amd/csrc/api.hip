@@ -41,26 +41,6 @@ void release(DevBuf& b) {
 
 int launch_soa_to_aos(sbo_ctx* c, const void* soa, void* aos);
 
-template <typename T>
-static int upload_vec(DevBuf& b, const std::vector<double>& h, hipStream_t st) {
-  std::vector<T> t(h.size());
-  for (size_t i = 0; i < h.size(); ++i) t[i] = (T)h[i];
-  int rc = ensure(b, sizeof(T) * t.size());
-  if (rc) return rc;
-  SBO_HIP(hipMemcpyAsync(b.p, t.data(), sizeof(T) * t.size(), hipMemcpyHostToDevice, st));
-  SBO_HIP(hipStreamSynchronize(st));
-  return SBO_OK;
-}
-
-template <typename T>
-static int model_upload(sbo_ctx* c, const std::vector<double>& As, const std::vector<double>& sqA, const std::vector<double>& Xn) {
-  int rc;
-  if ((rc = upload_vec<T>(c->As, As, c->stream))) return rc;
-  if ((rc = upload_vec<T>(c->sqA, sqA, c->stream))) return rc;
-  if ((rc = upload_vec<T>(c->Xn, Xn, c->stream))) return rc;
-  return SBO_OK;
-}
-
 }  // namespace sbo
 
 using namespace sbo;
@@ -93,6 +73,7 @@ int sbo_init(int device_id, sbo_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
   for (auto& ev : c->ev) {
     e = hipEventCreate(&ev);
@@ -125,13 +106,14 @@ int sbo_shutdown(sbo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_basis, &c->mwork, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->h_c1) (void)hipHostFree(c->h_c1);
   if (c->h_back) (void)hipHostFree(c->h_back);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SBO_OK;
@@ -177,6 +159,13 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->goose_pairs = value ? 1 : 0;
     return SBO_OK;
   }
+  if (!strcmp(key, "bl_host_bases")) {
+    c->bl_host_bases = value ? 1 : 0;
+    c->bl.valid = false;
+    c->bl_basis_ok = false;
+    c->posterior_valid = false;
+    return SBO_OK;
+  }
   if (!strcmp(key, "comm_selftest")) {
     if (value && !c->comm && !c->relay_allreduce)
       return fail(SBO_E_INVALID, "comm_selftest needs a communicator: call sbo_comm_init(ctx, 1, 0, id) with a unique id first");
@@ -215,42 +204,25 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
   mc.dpad = d <= 2 ? 2 : (d <= 4 ? 4 : 8);
   mc.factor = invK ? SBO_FACTOR_INVK : SBO_FACTOR_CHOL;
   for (int a = 0; a < kMaxD; ++a) { mc.X_mean[a] = a < d ? X_mean[a] : 0.0; mc.X_std[a] = a < d ? X_std[a] : 1.0; mc.X_rstd[a] = 1.0 / mc.X_std[a]; }
-  const int npad = mc.npad, D = mc.dpad;
-  std::vector<double> As((size_t)q * npad * D, 0.0), sqA((size_t)q * npad, 0.0), Xn((size_t)npad * D, 0.0), rhs((size_t)q * n);
-  for (int j = 0; j < n; ++j)
-    for (int a = 0; a < d; ++a) Xn[(size_t)j * D + a] = X_norm[(size_t)j * d + a];
   c->h_Xnorm.assign(X_norm, X_norm + (size_t)n * d);
   const double f32eps = (double)std::numeric_limits<float>::epsilon();
-  double sn2[kMaxQ] = {0};
   for (int o = 0; o < q; ++o) {
     mc.Y_mean[o] = Y_mean[o];
     mc.Y_std[o] = Y_std[o];
     mc.mp[o] = (o == 0) ? 0.0 : (-2.0 * Y_mean[o]) / Y_std[o];          // GP_Safe.py:331-332
     mc.sf2[o] = std::exp(2.0 * hypopt[(size_t)d * q + o]);               // GP_Safe.py:338
-    sn2[o] = std::exp(2.0 * hypopt[(size_t)(d + 1) * q + o]) + f32eps;   // GP_Safe.py:229
-    mc.sn2[o] = sn2[o];
+    mc.sn2[o] = std::exp(2.0 * hypopt[(size_t)(d + 1) * q + o]) + f32eps;   // GP_Safe.py:229
     for (int a = 0; a < d; ++a) {
       const double ell = std::exp(2.0 * hypopt[(size_t)a * q + o]);
       mc.vinv[o][a] = std::pow(ell, -0.5);                               // GP_Safe.py:112
       mc.inv_ell[o][a] = 1.0 / ell;
     }
-    for (int j = 0; j < n; ++j) {
-      double s = 0;
-      for (int a = 0; a < d; ++a) {
-        const double v = X_norm[(size_t)j * d + a] * mc.vinv[o][a];      // GP_Safe.py:115
-        As[((size_t)o * npad + j) * D + a] = v;
-        s += v * v;
-      }
-      sqA[(size_t)o * npad + j] = s;
-      rhs[(size_t)o * n + j] = Y_norm[(size_t)j * q + o] - mc.mp[o];
-    }
   }
   c->dtype = dtype;
   c->bl.valid = false;
-  // factorisation, alpha and the fragment images of the factor: on the device (model.hip)
-  int rc = model_build(c, invK, As, sqA, rhs, sn2);
-  if (rc) return rc;
-  rc = (dtype == SBO_F64) ? model_upload<double>(c, As, sqA, Xn) : model_upload<float>(c, As, sqA, Xn);
+  ++c->model_serial;
+  // derived arrays (As, sqA, Xn, rhs), factorisation, alpha and the fragment images of the factor: on the device (model.hip)
+  int rc = model_build(c, invK, X_norm, Y_norm);
   if (rc) return rc;
   c->has_model = true;
   return SBO_OK;
@@ -263,8 +235,8 @@ int sbo_model_append(sbo_ctx* c, const double* x_norm_new, const double* y_norm_
   if (!c || !x_norm_new || !y_norm_new) return fail(SBO_E_INVALID, "NULL argument");
   if (!c->has_model || !c->Fplain.p) return fail(SBO_E_NO_MODEL, "sbo_model_set has not been called");
   ModelConst& mc = c->mc;
-  const int n = mc.n, d = mc.d, q = mc.q, D = mc.dpad;
-  if (n + 1 > SBO_MAX_N || n + 1 > c->f_cap) return fail(SBO_E_UNSUPPORTED, "model is at its capacity: rebuild it with sbo_model_set");
+  const int n = mc.n, d = mc.d, q = mc.q;
+  if (n + 1 > SBO_MAX_N) return fail(SBO_E_UNSUPPORTED, "model is at its capacity: rebuild it with sbo_model_set");
   SBO_HIP(hipSetDevice(c->device));
   // cross-covariances of the new point with the expanded distance of the reference (GP_Safe.py:115-119, 166)
   std::vector<double> kvec((size_t)q * n);
@@ -286,27 +258,13 @@ int sbo_model_append(sbo_ctx* c, const double* x_norm_new, const double* y_norm_
   }
   int rc = model_append(c, kvec, kappa, rho);
   if (rc) return rc;
-  // host-side model arrays with the new row, re-upload of the small ones, re-pack of the factor images
+  // the derived arrays with the new row (device), then the re-pack of the factor images
   c->h_Xnorm.insert(c->h_Xnorm.end(), x_norm_new, x_norm_new + d);
   mc.n = n + 1;
   mc.npad = (mc.n + 15) / 16 * 16;
-  const int npad = mc.npad;
-  std::vector<double> As((size_t)q * npad * D, 0.0), sqA((size_t)q * npad, 0.0), Xn((size_t)npad * D, 0.0);
-  for (int j = 0; j < mc.n; ++j)
-    for (int a = 0; a < d; ++a) Xn[(size_t)j * D + a] = c->h_Xnorm[(size_t)j * d + a];
-  for (int o = 0; o < q; ++o)
-    for (int j = 0; j < mc.n; ++j) {
-      double s = 0;
-      for (int a = 0; a < d; ++a) {
-        const double v = c->h_Xnorm[(size_t)j * d + a] * mc.vinv[o][a];
-        As[((size_t)o * npad + j) * D + a] = v;
-        s += v * v;
-      }
-      sqA[(size_t)o * npad + j] = s;
-    }
-  rc = (c->dtype == SBO_F64) ? model_upload<double>(c, As, sqA, Xn) : model_upload<float>(c, As, sqA, Xn);
-  if (rc) return rc;
+  if ((rc = model_prep(c, c->h_Xnorm.data()))) return rc;
   if ((rc = model_repack(c))) return rc;
+  ++c->model_serial;
   c->posterior_valid = false;
   c->masks_valid = false;
   c->bl.valid = false;

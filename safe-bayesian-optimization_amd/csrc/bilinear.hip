@@ -82,11 +82,13 @@ __global__ __launch_bounds__(256) void k_bgemm(const double* __restrict__ A, siz
   }
   // accumulator element t of lane l: row 4 t + (l >> 4), column l & 15 of the 16 x 16 tile
   const int col_in = lane & 15, row_in = lane >> 4;
+  out += (size_t)o * out_stride_o;
+  if (OMODE == 1) out2 += (size_t)o * out_stride_o;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     if (cs0 + s >= ncs) continue;
     if (OMODE == 0) {
-      double* blk = out + (size_t)o * out_stride_o + ((size_t)rb * ncs + (cs0 + s)) * 256;
+      double* blk = out + ((size_t)rb * ncs + (cs0 + s)) * 256;
 #pragma unroll
       for (int t = 0; t < 4; ++t) blk[MM<double>::pack_pos(4 * t + row_in, col_in & 3, col_in >> 2)] = acc[s][t];
     } else if (OMODE == 1) {
@@ -188,78 +190,297 @@ __global__ __launch_bounds__(256) void k_bstage1(const double* __restrict__ A, s
   }
 }
 
-// ---- per-model table builders (device side of bilinear_setup) -------------------------------------------------
-// Z_j,(p,s) = U0_jp U1_js as B fragments [ncsR][KBn * 4][64] (k = observation j, column c = p r1 + s)
-__global__ __launch_bounds__(256) void k_bl_zf(const double* __restrict__ U0, const double* __restrict__ U1, int n, int KBn, int r0,
-                                               int r1, int ncsR, double* __restrict__ Zf) {
-  const long long total = (long long)ncsR * KBn * 4 * 64;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int l = (int)(i & 63);
-    const long long fr = i >> 6;
-    const int ks = (int)(fr % (KBn * 4)), cs = (int)(fr / (KBn * 4));
-    const int j = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
-    const int cidx = cs * 16 + (l & 15);
-    double v = 0.0;
-    if (j < n && cidx < r0 * r1) v = U0[(size_t)(cidx / r1) * n + j] * U1[(size_t)(cidx % r1) * n + j];
-    Zf[i] = v;
-  }
+// ---- per-model plan build, all on the device ------------------------------------------------------------------------------
+// A model change costs: the 2 q axis bases (k_bl_basis, one workgroup each), then a dozen launches batched over the outputs
+// (blockIdx.y / .z = output) that turn the bases into the operand tables of the two GEMMs.  The host only reads the bases'
+// ranks back (to size the GEMMs) -- no host numerics, no staging upload.
+constexpr int kBlMaxR = bl::kMaxRank;    // 64
+constexpr int kBlMaxRc = bl::kMaxCheb;   // 128
+
+struct BlDims {                          // plan dimensions, by value
+  int q, n, KBn;
+  int r0[kMaxQ], r1[kMaxQ], rc0[kMaxQ], rc1[kMaxQ];
+  int r0u, r1u, r0p, KB0, KB1, KBm, KBm2, ncs0, nrb, ncsR;
+  long long cnt0, nlines;
+  double a[2], b[2];                     // interval of each axis in normalised coordinates
+  double sf2[kMaxQ];
+};
+
+// pair index k -> (p <= p'), pairs enumerated row by row (bl::pair_map): row p starts at p (2 r - p + 1) / 2
+__device__ __forceinline__ void pair_of(int k, int r, int& p, int& pp) {
+  const double t = 2.0 * r + 1.0;
+  int g = (int)((t - sqrt(t * t - 8.0 * k)) * 0.5);
+  g = g < 0 ? 0 : (g > r - 1 ? r - 1 : g);
+  while (g > 0 && g * (2 * r - g + 1) / 2 > k) --g;
+  while (g + 1 < r && (g + 1) * (2 * r - g) / 2 <= k) ++g;
+  p = g;
+  pp = g + (k - g * (2 * r - g + 1) / 2);
 }
-// T4qq^T as B fragments over the columns k0: [KB0][KB1 * 4][64], element (k1, k0) = scale/2 (G[(p,s),(p',s')] + G[(p',s),(p,s')])
-__global__ __launch_bounds__(256) void k_bl_t4f(const double* __restrict__ G, long long ldg, int r1, const int* __restrict__ map0,
-                                                int K0, const int* __restrict__ map1, int K1, double scale, int KB0, int KB1,
-                                                double* __restrict__ T4f) {
-  const long long total = (long long)KB0 * KB1 * 4 * 64;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int l = (int)(i & 63);
-    const long long fr = i >> 6;
-    const int ks = (int)(fr % (KB1 * 4)), cs = (int)(fr / (KB1 * 4));
-    const int k1 = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
-    const int k0 = cs * 16 + (l & 15);
-    double v = 0.0;
-    if (k0 < K0 && k1 < K1) {
-      const int p = map0[2 * k0], pp = map0[2 * k0 + 1], s1 = map1[2 * k1], ss = map1[2 * k1 + 1];
-      v = scale * 0.5 * (G[(size_t)(p * r1 + s1) * ldg + (pp * r1 + ss)] + G[(size_t)(pp * r1 + s1) * ldg + (p * r1 + ss)]);
-    }
-    T4f[i] = v;
-  }
-}
-// pair products of an axis table S [r][count]: P[(p <= p')][x] = w S_p S_p' (w = 1 diagonal, 2 off it)
-//   FRAG 1: as B fragments [ncs][KB * 4][64] (columns = positions);  FRAG 0: transposed as A images [nrb][KB][256] (rows = positions)
-template <int FRAG>
-__global__ __launch_bounds__(256) void k_bl_pairs(const double* __restrict__ Stab, long long count, const int* __restrict__ map,
-                                                  int K, int KB, int nblk, double* __restrict__ out) {
-  const long long total = (long long)nblk * KB * 256;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    int k;
-    long long x;
-    if (FRAG) {
-      const int l = (int)(i & 63);
-      const long long fr = i >> 6;
-      const int ks = (int)(fr % (KB * 4));
-      k = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
-      x = (fr / (KB * 4)) * 16 + (l & 15);
-    } else {
-      // invert pack_pos(r, slot, kk) = kk * 64 + (slot * 4 + (r & 3)) * 4 + (r >> 2)
-      const int e = (int)(i & 255);
-      const long long blk = i >> 8;
-      const int kk = e >> 6, rem = e & 63, slot = rem >> 4, r = ((rem >> 2) & 3) + 4 * (rem & 3);
-      k = (int)(blk % KB) * 16 + MM<double>::jslot(kk, slot);
-      x = (blk / KB) * 16 + r;
-    }
-    double v = 0.0;
-    if (k < K && x < count) {
-      const int p = map[2 * k], pp = map[2 * k + 1];
-      v = (p == pp ? 1.0 : 2.0) * Stab[(size_t)p * count + x] * Stab[(size_t)pp * count + x];
-    }
-    out[i] = v;
+
+// normalised positions of the grid axes: xn0[cnt0] (all of axis 0), xn1[nlines] (the local lines of axis 1) -- the
+// arithmetic of cand_coords and models/GP_Safe.py:326
+__global__ __launch_bounds__(256) void k_bl_axes(const ModelConst mc, const CandSpec cs, long long cnt0, long long line0, long long nlines,
+                                                 double* __restrict__ xn0, double* __restrict__ xn1) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < cnt0 + nlines; t += (long long)gridDim.x * blockDim.x) {
+    const int a = t < cnt0 ? 0 : 1;
+    const long long i = a == 0 ? t : line0 + (t - cnt0), tot = cs.count[a];
+    const double x = (i == tot - 1 && tot > 1) ? cs.hi[a] : __dadd_rn(cs.lo[a], __dmul_rn((double)i, cs.step[a]));
+    const double v = (x - mc.X_mean[a]) / mc.X_std[a];
+    if (a == 0) xn0[t] = v; else xn1[t - cnt0] = v;
   }
 }
 
-// Axis table S[p][i] = sig_p sum_c Vs[p][c] T_c(xi_i) from the Chebyshev series of the basis (the arithmetic of
-// bl::axis_basis' own tabulation: three-term recurrence, sum in ascending c, one thread per entry)
-__global__ __launch_bounds__(256) void k_bl_stab(const double* __restrict__ Vs, const double* __restrict__ sig,
-                                                 const double* __restrict__ xn, double a, double b, int rc, int r, long long count,
-                                                 double* __restrict__ S) {
+// Basis of one axis family f_j(x) = exp(-1/2 (x vinv - A_j)^2), j < n, on the interval [a, b] (normalised coordinates),
+// one workgroup of 1024 threads per (output, axis):
+//   1. Chebyshev interpolant of every f_j (degree raised 32 -> 128 until the last four coefficients are < 1e-14),
+//      coefficient rows c_j in R^rc by the discrete cosine sum;
+//   2. column-pivoted Gram-Schmidt on the rows (largest residual first, every direction re-orthogonalised twice against
+//      the ones before): directions q_0 .. q_{r-1}, stopped when the largest residual row is below 2e-16 ||coef||_F --
+//      the rank a singular value decomposition finds (or one less), at a fraction of its sequential depth (r steps instead
+//      of several hundred rotations rounds);
+//   3. U = coef Q [n x r] (from the unmodified coefficients), so that f_j(x) = sum_p U_jp S_p(x), S_p = sum_c Q_pc T_c(xi(x)).
+// Outputs: U [r][n], Vs = Q [r][rc], sig = 1, info = (ok, r, rc).  ok = 0: the interpolant did not converge or the rank
+// exceeds kBlMaxR -- the caller keeps the separable-table kernel.
+struct BlJobs {
+  int n, dpad;
+  double vinv[2 * kMaxQ], a[2], b[2];
+};
+constexpr int kBasisThreads = 1024;
+
+__device__ __forceinline__ double bl_block_sum(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < kBasisThreads / 64; ++w) s += red[w];
+  return s;                                             // (same order in every thread: deterministic)
+}
+
+__global__ __launch_bounds__(kBasisThreads) void k_bl_basis(const BlJobs jb, const double* __restrict__ Xn, double* __restrict__ work,
+                                                            size_t work_stride, double* __restrict__ Uout, double* __restrict__ Vsout,
+                                                            double* __restrict__ sigout, int* __restrict__ info) {
+  __shared__ double ct[4 * kBlMaxRc];        // cos(pi m / (2 rc)), m < 4 rc
+  __shared__ double qv[kBlMaxRc];            // the direction being built
+  __shared__ double cf[kBlMaxR];             // its coefficients along the previous directions
+  __shared__ double part[kBasisThreads];     // per-(chunk, row) partial sums of the residual update
+  __shared__ double nrm2[SBO_MAX_N];         // squared residual norm of every row
+  __shared__ double red[kBasisThreads / 64];
+  __shared__ int redi[kBasisThreads / 64];
+  __shared__ double sh_val;
+  __shared__ int sh_idx;
+  const int job = blockIdx.x, axis = job & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = jb.n;
+  const double vinv = jb.vinv[job], a = jb.a[axis], b = jb.b[axis];
+  double* fnT = work + (size_t)job * work_stride;      // [k][j] samples
+  double* coefT = fnT + (size_t)n * kBlMaxRc;          // [p][j] coefficients
+  double* resT = coefT + (size_t)n * kBlMaxRc;         // [p][j] residual rows
+  double* Q = resT + (size_t)n * kBlMaxRc;             // [i][c] directions (row stride kBlMaxRc)
+  int* inf = info + 4 * job;
+  int rc = 0;
+  bool ok = false;
+  for (int trial = 0; trial < 5 && !ok; ++trial) {
+    rc = trial == 0 ? 32 : (trial == 1 ? 48 : (trial == 2 ? 64 : (trial == 3 ? 96 : kBlMaxRc)));
+    __syncthreads();
+    for (int m = tid; m < 4 * rc; m += kBasisThreads) ct[m] = cospi((double)m / (2.0 * rc));
+    __syncthreads();
+    // samples at the Chebyshev points of the first kind, theta_k = pi (k + 1/2) / rc
+    for (int w = tid; w < rc * n; w += kBasisThreads) {
+      const int k = w / n, j = w - k * n;
+      const double x = 0.5 * (ct[2 * k + 1] * (b - a) + (a + b));
+      const double df = x * vinv - Xn[(size_t)j * jb.dpad + axis] * vinv;
+      fnT[w] = exp(-0.5 * (df * df));
+    }
+    __syncthreads();
+    // the last four coefficients decide whether this degree is enough
+    double tail = 0.0;
+    for (int w = tid; w < 4 * n; w += kBasisThreads) {
+      const int p = rc - 4 + w / n, j = w % n;
+      double s_ = 0.0;
+      int m = p;
+      for (int k = 0; k < rc; ++k) {
+        s_ += fnT[(size_t)k * n + j] * ct[m];
+        m += 2 * p;
+        if (m >= 4 * rc) m -= 4 * rc;
+      }
+      s_ = fabs(s_ * (2.0 / rc));
+      tail = s_ > tail ? s_ : tail;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(tail, o); tail = y > tail ? y : tail; }
+    __syncthreads();
+    if (lane == 0) red[wave] = tail;
+    __syncthreads();
+    tail = 0.0;
+    for (int w = 0; w < kBasisThreads / 64; ++w) tail = red[w] > tail ? red[w] : tail;
+    ok = tail <= 1e-14;
+  }
+  if (!ok) {
+    if (tid == 0) { inf[0] = 0; inf[1] = 0; inf[2] = rc; inf[3] = 0; }
+    return;
+  }
+  // all coefficients: coef[j][p] = w_p / rc sum_k f_j(x_k) cos(p theta_k)
+  for (int w = tid; w < rc * n; w += kBasisThreads) {
+    const int p = w / n, j = w - p * n;
+    double s_ = 0.0;
+    int m = p;
+    for (int k = 0; k < rc; ++k) {
+      s_ += fnT[(size_t)k * n + j] * ct[m];
+      m += 2 * p;
+      if (m >= 4 * rc) m -= 4 * rc;
+    }
+    s_ *= (p == 0 ? 1.0 : 2.0) / rc;
+    coefT[w] = s_;
+    resT[w] = s_;
+  }
+  __syncthreads();
+  double fro2 = 0.0;
+  for (int j = tid; j < n; j += kBasisThreads) {
+    double s_ = 0.0;
+    for (int p = 0; p < rc; ++p) { const double v = resT[(size_t)p * n + j]; s_ += v * v; }
+    nrm2[j] = s_;
+    fro2 += s_;
+  }
+  fro2 = bl_block_sum(fro2, red);
+  const double tol2 = (2e-16 * 2e-16) * fro2;
+  // residual update geometry: thread t = g npow + j handles row j, columns of chunk g (G chunks)
+  int npow = 64;
+  while (npow < n) npow <<= 1;
+  const int G = npow >= kBasisThreads ? 1 : kBasisThreads / npow;
+  const int cchunk = (rc + G - 1) / G;
+  int r = 0;
+  const int rmax = rc < n ? rc : n;
+  bool too_large = false;
+  for (;;) {
+    // pivot: the row with the largest residual (ties -> lowest row)
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < n; j += kBasisThreads)
+      if (nrm2[j] > bv) { bv = nrm2[j]; bi = j; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double yv = __shfl_xor(bv, o);
+      const int yi = __shfl_xor(bi, o);
+      if (yv > bv || (yv == bv && yi < bi)) { bv = yv; bi = yi; }
+    }
+    __syncthreads();
+    if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double v = red[0];
+      int i = redi[0];
+      for (int w = 1; w < kBasisThreads / 64; ++w)
+        if (red[w] > v || (red[w] == v && redi[w] < i)) { v = red[w]; i = redi[w]; }
+      sh_val = v;
+      sh_idx = i;
+    }
+    __syncthreads();
+    if (!(sh_val > tol2) || r >= rmax) break;
+    if (r >= kBlMaxR) { too_large = true; break; }
+    const int jp = sh_idx;
+    const double inv0 = 1.0 / sqrt(sh_val);
+    if (tid < rc) qv[tid] = resT[(size_t)tid * n + jp] * inv0;
+    __syncthreads();
+    // twice: remove what is left along the previous directions (the residual rows are only orthogonal to them to the
+    // rounding of the ORIGINAL rows, which is not small against a residual of 1e-12)
+    bool noise = false;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i = wave; i < r; i += kBasisThreads / 64) {
+        double s_ = 0.0;
+        for (int cidx = lane; cidx < rc; cidx += 64) s_ += Q[(size_t)i * kBlMaxRc + cidx] * qv[cidx];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
+        if (lane == 0) cf[i] = s_;
+      }
+      __syncthreads();
+      double mine = 0.0;
+      if (tid < rc) {
+        mine = qv[tid];
+        for (int i = 0; i < r; ++i) mine -= cf[i] * Q[(size_t)i * kBlMaxRc + tid];
+      }
+      const double nq = bl_block_sum(tid < rc ? mine * mine : 0.0, red);
+      if (pass == 0 && nq < 0.25) noise = true;          // mostly rounding of the rows already covered: nothing left to add
+      if (tid < rc) qv[tid] = mine / sqrt(nq);
+      __syncthreads();
+    }
+    if (noise) break;
+    if (tid < rc) Q[(size_t)r * kBlMaxRc + tid] = qv[tid];
+    // residual rows: res_j -= (res_j . q) q, norms recomputed from the updated rows
+    {
+      const int g = tid / npow, j = tid - g * npow;
+      const int c0 = g * cchunk, c1 = c0 + cchunk < rc ? c0 + cchunk : rc;
+      for (int j2 = j; j2 < n; j2 += (G == 1 ? kBasisThreads : npow)) {     // (G == 1: a thread may own two rows)
+        double s_ = 0.0;
+        if (g < G)
+          for (int cidx = c0; cidx < c1; ++cidx) s_ += resT[(size_t)cidx * n + j2] * qv[cidx];
+        if (G == 1) {
+          double nn = 0.0;
+          for (int cidx = 0; cidx < rc; ++cidx) {
+            const double v = resT[(size_t)cidx * n + j2] - s_ * qv[cidx];
+            resT[(size_t)cidx * n + j2] = v;
+            nn += v * v;
+          }
+          nrm2[j2] = nn;
+        } else {
+          part[tid] = s_;
+        }
+      }
+      if (G > 1) {
+        __syncthreads();
+        double d_ = 0.0, nn = 0.0;
+        if (j < n && g < G) {
+          for (int gg = 0; gg < G; ++gg) d_ += part[gg * npow + j];
+          for (int cidx = c0; cidx < c1; ++cidx) {
+            const double v = resT[(size_t)cidx * n + j] - d_ * qv[cidx];
+            resT[(size_t)cidx * n + j] = v;
+            nn += v * v;
+          }
+        }
+        __syncthreads();
+        part[tid] = nn;
+        __syncthreads();
+        if (g == 0 && j < n) {
+          double t_ = 0.0;
+          for (int gg = 0; gg < G; ++gg) t_ += part[gg * npow + j];
+          nrm2[j] = t_;
+        }
+      }
+    }
+    ++r;
+    __syncthreads();
+  }
+  if (too_large || r < 1) {
+    if (tid == 0) { inf[0] = 0; inf[1] = r; inf[2] = rc; inf[3] = 0; }
+    return;
+  }
+  __syncthreads();
+  double* U = Uout + (size_t)job * kBlMaxR * n;
+  for (int w = tid; w < r * n; w += kBasisThreads) {
+    const int p = w / n, j = w - p * n;
+    double s_ = 0.0;
+    for (int cidx = 0; cidx < rc; ++cidx) s_ += coefT[(size_t)cidx * n + j] * Q[(size_t)p * kBlMaxRc + cidx];
+    U[w] = s_;
+  }
+  double* Vs = Vsout + (size_t)job * kBlMaxR * kBlMaxRc;
+  for (int w = tid; w < r * rc; w += kBasisThreads) Vs[w] = Q[(size_t)(w / rc) * kBlMaxRc + (w % rc)];
+  if (tid < r) sigout[(size_t)job * kBlMaxR + tid] = 1.0;
+  if (tid == 0) { inf[0] = 1; inf[1] = r; inf[2] = rc; inf[3] = 0; }
+}
+
+// Axis tables S[p][i] = sig_p sum_c Vs[p][c] T_c(xi_i) from the Chebyshev series of the bases (three-term recurrence, sum
+// in ascending c, one thread per entry); blockIdx.y = 2 o + axis
+__global__ __launch_bounds__(256) void k_bl_stab(const BlDims dm, const double* __restrict__ Vsall, const double* __restrict__ sigall,
+                                                 const double* __restrict__ xn0, const double* __restrict__ xn1, double* __restrict__ S0all,
+                                                 double* __restrict__ S1all) {
+  const int job = blockIdx.y, o = job >> 1, axis = job & 1;
+  const int r = axis ? dm.r1[o] : dm.r0[o], rc = axis ? dm.rc1[o] : dm.rc0[o];
+  const long long count = axis ? dm.nlines : dm.cnt0;
+  const double a = dm.a[axis], b = dm.b[axis];
+  const double* Vs = Vsall + (size_t)job * kBlMaxR * kBlMaxRc;
+  const double* sig = sigall + (size_t)job * kBlMaxR;
+  const double* xn = axis ? xn1 : xn0;
+  double* S = axis ? S1all + (size_t)o * dm.r1u * dm.nlines : S0all + (size_t)o * dm.r0u * dm.cnt0;
   const long long total = (long long)r * count;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int p = (int)(idx / count);
@@ -281,24 +502,120 @@ __global__ __launch_bounds__(256) void k_bl_stab(const double* __restrict__ Vs, 
   }
 }
 
-// ---- mean-phase operands on the device (the host only supplies the bases and beta) ---------------------------------
-// Mb[b][p r1 + s] = scale sum_j beta_b[j] U0_jp U1_js  (bilinear forms of the mean and of its two gradient sums)
-__global__ __launch_bounds__(256) void k_bl_mb(const double* __restrict__ U0, const double* __restrict__ U1,
-                                               const double* __restrict__ beta, int n, int r0, int r1, int nbeta, double scale,
-                                               double* __restrict__ Mb) {
-  const int total = nbeta * r0 * r1;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int s_ = i % r1, p = (i / r1) % r0, b = i / (r0 * r1);
-    const double *u0 = U0 + (size_t)p * n, *u1 = U1 + (size_t)s_ * n, *be = beta + (size_t)b * n;
-    double acc = 0.0;
-    for (int j = 0; j < n; ++j) acc += be[j] * u0[j] * u1[j];
-    Mb[i] = scale * acc;
+// Z_j,(p,s) = U0_jp U1_js as B fragments [ncsR][KBn * 4][64] (k = observation j, column c = p r1 + s); blockIdx.y = o
+__global__ __launch_bounds__(256) void k_bl_zf(const BlDims dm, const double* __restrict__ Uall, size_t nZf, double* __restrict__ Zfall) {
+  const int o = blockIdx.y, n = dm.n, r0 = dm.r0[o], r1 = dm.r1[o], KBn = dm.KBn;
+  const double* U0 = Uall + (size_t)(2 * o) * kBlMaxR * n;
+  const double* U1 = Uall + (size_t)(2 * o + 1) * kBlMaxR * n;
+  double* Zf = Zfall + (size_t)o * nZf;
+  const long long total = (long long)dm.ncsR * KBn * 4 * 64;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const long long fr = i >> 6;
+    const int ks = (int)(fr % (KBn * 4)), cs = (int)(fr / (KBn * 4));
+    const int j = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+    const int cidx = cs * 16 + (l & 15);
+    double v = 0.0;
+    if (j < n && cidx < r0 * r1) v = U0[(size_t)(cidx / r1) * n + j] * U1[(size_t)(cidx % r1) * n + j];
+    Zf[i] = v;
   }
 }
-// Vb[b][p][line] = sum_s Mb[b][p, s] S1[s][line]
-__global__ __launch_bounds__(256) void k_bl_vb(const double* __restrict__ Mb, const double* __restrict__ S1, int r0, int r1, int r0u,
-                                               long long nlines, int nbeta, double* __restrict__ Vb) {
-  const long long total = (long long)nbeta * r0 * nlines;
+// T4qq^T as B fragments over the columns k0: [KB0][KB1 * 4][64], element (k1, k0) = sf2^2 / 2 (G[(p,s),(p',s')] + G[(p',s),(p,s')])
+__global__ __launch_bounds__(256) void k_bl_t4f(const BlDims dm, const double* __restrict__ Gall, long long ldg, size_t sT4f,
+                                                double* __restrict__ T4fall) {
+  const int o = blockIdx.y, r0 = dm.r0[o], r1 = dm.r1[o], KB0 = dm.KB0, KB1 = dm.KB1;
+  const int K0 = r0 * (r0 + 1) / 2, K1 = r1 * (r1 + 1) / 2;
+  const double* G = Gall + (size_t)o * ldg * ldg;
+  double* T4f = T4fall + (size_t)o * sT4f;
+  const double scale = dm.sf2[o] * dm.sf2[o];
+  const long long total = (long long)KB0 * KB1 * 4 * 64;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const long long fr = i >> 6;
+    const int ks = (int)(fr % (KB1 * 4)), cs = (int)(fr / (KB1 * 4));
+    const int k1 = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+    const int k0 = cs * 16 + (l & 15);
+    double v = 0.0;
+    if (k0 < K0 && k1 < K1) {
+      int p, pp, s1, ss;
+      pair_of(k0, r0, p, pp);
+      pair_of(k1, r1, s1, ss);
+      v = scale * 0.5 * (G[(size_t)(p * r1 + s1) * ldg + (pp * r1 + ss)] + G[(size_t)(pp * r1 + s1) * ldg + (p * r1 + ss)]);
+    }
+    T4f[i] = v;
+  }
+}
+// pair products of an axis table S [r][count]: P[(p <= p')][x] = w S_p S_p' (w = 1 diagonal, 2 off it); blockIdx.y = o
+//   FRAG 1: axis 0, as B fragments [ncs0][KB0 * 4][64] (columns = positions);  FRAG 0: axis 1, transposed as A images
+//   [nrb][KB1][256] (rows = lines)
+template <int FRAG>
+__global__ __launch_bounds__(256) void k_bl_pairs(const BlDims dm, const double* __restrict__ Sall, size_t sout, double* __restrict__ outall) {
+  const int o = blockIdx.y;
+  const int r = FRAG ? dm.r0[o] : dm.r1[o], KB = FRAG ? dm.KB0 : dm.KB1, nblk = FRAG ? dm.ncs0 : dm.nrb;
+  const long long count = FRAG ? dm.cnt0 : dm.nlines;
+  const int K = r * (r + 1) / 2;
+  const double* Stab = Sall + (size_t)o * (FRAG ? dm.r0u : dm.r1u) * count;
+  double* out = outall + (size_t)o * sout;
+  const long long total = (long long)nblk * KB * 256;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int k;
+    long long x;
+    if (FRAG) {
+      const int l = (int)(i & 63);
+      const long long fr = i >> 6;
+      const int ks = (int)(fr % (KB * 4));
+      k = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+      x = (fr / (KB * 4)) * 16 + (l & 15);
+    } else {
+      // invert pack_pos(r, slot, kk) = kk * 64 + (slot * 4 + (r & 3)) * 4 + (r >> 2)
+      const int e = (int)(i & 255);
+      const long long blk = i >> 8;
+      const int kk = e >> 6, rem = e & 63, slot = rem >> 4, rr = ((rem >> 2) & 3) + 4 * (rem & 3);
+      k = (int)(blk % KB) * 16 + MM<double>::jslot(kk, slot);
+      x = (blk / KB) * 16 + rr;
+    }
+    double v = 0.0;
+    if (k < K && x < count) {
+      int p, pp;
+      pair_of(k, r, p, pp);
+      v = (p == pp ? 1.0 : 2.0) * Stab[(size_t)p * count + x] * Stab[(size_t)pp * count + x];
+    }
+    out[i] = v;
+  }
+}
+
+// ---- mean-phase operands -------------------------------------------------------------------------------------------------
+// Mb[o][b][p r1 + s] = sf2 sum_j beta_b[j] U0_jp U1_js, beta = (alpha, alpha Xn_0, alpha Xn_1): the bilinear forms of the
+// mean and of its two gradient sums.  One wave per (b, p, s), lanes over the observations; blockIdx.y = o
+__global__ __launch_bounds__(256) void k_bl_mb(const BlDims dm, const double* __restrict__ Uall, const double* __restrict__ alpha, int ald,
+                                               const double* __restrict__ Xn, int dpad, double* __restrict__ Mball) {
+  const int o = blockIdx.y, n = dm.n, r0 = dm.r0[o], r1 = dm.r1[o];
+  const double* U0 = Uall + (size_t)(2 * o) * kBlMaxR * n;
+  const double* U1 = Uall + (size_t)(2 * o + 1) * kBlMaxR * n;
+  const double* al = alpha + (size_t)o * ald;
+  double* Mb = Mball + (size_t)o * 3 * dm.r0u * dm.r1u;
+  const int lane = threadIdx.x & 63, total = 3 * r0 * r1;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < total; i += (gridDim.x * blockDim.x) >> 6) {
+    const int s_ = i % r1, p = (i / r1) % r0, b = i / (r0 * r1);
+    const double *u0 = U0 + (size_t)p * n, *u1 = U1 + (size_t)s_ * n;
+    double acc = 0.0;
+    for (int j = lane; j < n; j += 64) {
+      const double be = b == 0 ? al[j] : al[j] * Xn[(size_t)j * dpad + (b - 1)];
+      acc += be * u0[j] * u1[j];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) Mb[i] = dm.sf2[o] * acc;
+  }
+}
+// Vb[o][b][p][line] = sum_s Mb[b][p, s] S1[s][line]
+__global__ __launch_bounds__(256) void k_bl_vb(const BlDims dm, const double* __restrict__ Mball, const double* __restrict__ S1all,
+                                               double* __restrict__ Vball) {
+  const int o = blockIdx.y, r0 = dm.r0[o], r1 = dm.r1[o], r0u = dm.r0u;
+  const long long nlines = dm.nlines;
+  const double* Mb = Mball + (size_t)o * 3 * dm.r0u * dm.r1u;
+  const double* S1 = S1all + (size_t)o * dm.r1u * nlines;
+  double* Vb = Vball + (size_t)o * 3 * r0u * nlines;
+  const long long total = 3ll * r0 * nlines;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long l = i % nlines;
     const int p = (int)((i / nlines) % r0), b = (int)(i / (nlines * r0));
@@ -308,8 +625,12 @@ __global__ __launch_bounds__(256) void k_bl_vb(const double* __restrict__ Mb, co
   }
 }
 // A images of the mean phases, three sets:  V0 (K = 16 KBm) | [V1; V0] (K = 16 KBm2, V0 from k = r0p) | V1x = V2 - xn1 V0
-__global__ __launch_bounds__(256) void k_bl_va(const double* __restrict__ Vb, const double* __restrict__ xn1, int nrb, int KBm,
-                                               int KBm2, int r0, int r0p, int r0u, long long nlines, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_bl_va(const BlDims dm, const double* __restrict__ Vball, const double* __restrict__ xn1, size_t sVA,
+                                               double* __restrict__ outall) {
+  const int o = blockIdx.y, nrb = dm.nrb, KBm = dm.KBm, KBm2 = dm.KBm2, r0 = dm.r0[o], r0p = dm.r0p, r0u = dm.r0u;
+  const long long nlines = dm.nlines;
+  const double* Vb = Vball + (size_t)o * 3 * r0u * nlines;
+  double* out = outall + (size_t)o * sVA;
   const long long set = (long long)nrb * KBm * 256, set2 = (long long)nrb * KBm2 * 256, total = 2 * set + set2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int which = i < set ? 0 : (i < set + set2 ? 1 : 2);
@@ -336,8 +657,12 @@ __global__ __launch_bounds__(256) void k_bl_va(const double* __restrict__ Vb, co
   }
 }
 // B fragments of the mean phases, two sets:  S0 (K = 16 KBm) | [S0; -xn0 S0] (K = 16 KBm2, second copy from k = r0p)
-__global__ __launch_bounds__(256) void k_bl_sbf(const double* __restrict__ S0, const double* __restrict__ xn0, int ncs0, int KBm,
-                                                int KBm2, int r0, int r0p, long long cnt0, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_bl_sbf(const BlDims dm, const double* __restrict__ S0all, const double* __restrict__ xn0, size_t sSBf,
+                                                double* __restrict__ outall) {
+  const int o = blockIdx.y, ncs0 = dm.ncs0, KBm = dm.KBm, KBm2 = dm.KBm2, r0 = dm.r0[o], r0p = dm.r0p;
+  const long long cnt0 = dm.cnt0;
+  const double* S0 = S0all + (size_t)o * dm.r0u * cnt0;
+  double* out = outall + (size_t)o * sSBf;
   const long long fset = (long long)ncs0 * KBm * 256, total = fset + (long long)ncs0 * KBm2 * 256;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int which = i < fset ? 0 : 1;
@@ -572,23 +897,119 @@ __global__ __launch_bounds__(256) void k_lmax_reduce(const double* __restrict__ 
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------
-static void grid_axis_positions(const sbo_ctx* c, int a, long long i0, long long cnt, std::vector<double>& xn) {
+static double axis_position(const sbo_ctx* c, int a, long long i) {
   const CandSpec& cs = c->cs;
-  xn.resize((size_t)cnt);
-  for (long long k = 0; k < cnt; ++k) {
-    const long long i = i0 + k, tot = cs.count[a];
-    const double x = (i == tot - 1 && tot > 1) ? cs.hi[a] : cs.lo[a] + (double)i * cs.step[a];
-    xn[(size_t)k] = (x - c->mc.X_mean[a]) / c->mc.X_std[a];                                       // GP_Safe.py:326
-  }
+  const long long tot = cs.count[a];
+  const double x = (i == tot - 1 && tot > 1) ? cs.hi[a] : cs.lo[a] + (double)i * cs.step[a];
+  return (x - c->mc.X_mean[a]) / c->mc.X_std[a];                                                  // GP_Safe.py:326
 }
 
 bool bilinear_applicable(const sbo_ctx* c) {
   const CandSpec& cs = c->cs;
-  if (!c->bilinear || c->dtype != SBO_F64 || cs.kind != 1 || cs.d != 2 || c->mc.d != 2) return false;
+  if (!c->bilinear || c->dtype != SBO_F64 || !c->has_cand || cs.kind != 1 || cs.d != 2 || c->mc.d != 2) return false;
   const long long cnt0 = cs.count[0];
   if (cs.n_local <= 0 || cs.first % cnt0 != 0 || cs.n_local % cnt0 != 0) return false;
   // the bases pay off (and the interpolation interval is meaningful) only on real grids
-  return cnt0 >= 64 && cs.count[1] >= 64 && cs.n_local / cnt0 >= 16 && c->h_alpha.size() == (size_t)c->mc.q * c->mc.npad;
+  return cnt0 >= 64 && cs.count[1] >= 64 && cs.n_local / cnt0 >= 16 && c->alpha64.p != nullptr && c->f_cap >= c->mc.n;
+}
+
+// layout of bl_basis (doubles): U [2q][kBlMaxR][n] | Vs [2q][kBlMaxR][kBlMaxRc] | sig [2q][kBlMaxR] | info (ints, 2q x 4, in
+// 4 q doubles) | work [2q][3 n kBlMaxRc + kBlMaxR kBlMaxRc]
+struct BasisLayout {
+  size_t U, Vs, sig, info, work, work_stride, total;
+};
+static BasisLayout basis_layout(int n, int q) {
+  BasisLayout L;
+  L.U = 0;
+  L.Vs = L.U + (size_t)2 * q * kBlMaxR * n;
+  L.sig = L.Vs + (size_t)2 * q * kBlMaxR * kBlMaxRc;
+  L.info = L.sig + (size_t)2 * q * kBlMaxR;
+  L.work = L.info + (size_t)4 * q;
+  L.work_stride = (size_t)3 * n * kBlMaxRc + (size_t)kBlMaxR * kBlMaxRc;
+  L.total = L.work + (size_t)2 * q * L.work_stride;
+  return L;
+}
+
+// The interval of each grid axis in normalised coordinates.  Axis 1 always spans the WHOLE axis, so that every rank of a
+// sharded grid builds the same functions (shard results are bit-identical to the whole grid's).
+static bool basis_intervals(const sbo_ctx* c, double (&ab)[4]) {
+  for (int a = 0; a < 2; ++a) {
+    const double x0 = axis_position(c, a, 0), x1 = axis_position(c, a, c->cs.count[a] - 1);
+    ab[2 * a] = std::min(x0, x1);
+    ab[2 * a + 1] = std::max(x0, x1);
+    if (!(ab[2 * a + 1] > ab[2 * a])) return false;
+  }
+  return true;
+}
+
+// Enqueues the 2 q basis workgroups and the read-back of their (ok, r, rc) records on `st`; the caller synchronises.
+// Used by bilinear_setup, and ahead of time by sbo_model_set (next to the factorisation, on a second stream) when a grid
+// is already resident.
+int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st) {
+  const ModelConst& mc = c->mc;
+  const int n = mc.n, q = mc.q;
+  double ab[4];
+  c->bl_basis_ok = false;
+  if (!basis_intervals(c, ab)) return SBO_OK;
+  const BasisLayout L = basis_layout(n, q);
+  int rc;
+  if ((rc = ensure(c->bl_basis, sizeof(double) * L.total))) return rc;
+  double* base = (double*)c->bl_basis.p;
+  if (c->bl_host_bases) {
+    // A/B path: the bases of bilinear_host.hpp (Chebyshev + Householder QR + one-sided Jacobi SVD on host threads),
+    // uploaded in the layout the device kernel writes
+    std::vector<double> xs0((size_t)c->cs.count[0]), xs1((size_t)c->cs.count[1]);
+    for (long long i = 0; i < c->cs.count[0]; ++i) xs0[(size_t)i] = axis_position(c, 0, i);
+    for (long long i = 0; i < c->cs.count[1]; ++i) xs1[(size_t)i] = axis_position(c, 1, i);
+    std::vector<bl::AxisBasis> bs(2 * q);
+    std::vector<char> ok(2 * q, 0);
+    bl::parallel_ranges(2 * q, [&](int lo_, int hi_) {
+      std::vector<double> col(n);
+      for (int t = lo_; t < hi_; ++t) {
+        const int o = t / 2, a = t % 2;
+        for (int j = 0; j < n; ++j) col[j] = c->h_Xnorm[(size_t)j * mc.d + a] * mc.vinv[o][a];     // GP_Safe.py:115
+        const std::vector<double>& xs = a == 0 ? xs0 : xs1;
+        ok[t] = bl::axis_basis(n, col.data(), mc.vinv[o][a], xs.data(), (int)xs.size(), bs[t], /*tabulate=*/false) ? 1 : 0;
+      }
+    });
+    std::vector<double> up(L.work, 0.0);
+    int* inf = (int*)(up.data() + L.info);
+    for (int t = 0; t < 2 * q; ++t) {
+      inf[4 * t] = ok[t];
+      if (!ok[t]) continue;
+      inf[4 * t + 1] = bs[t].r;
+      inf[4 * t + 2] = bs[t].rc;
+      memcpy(up.data() + L.U + (size_t)t * kBlMaxR * n, bs[t].U.data(), sizeof(double) * bs[t].U.size());
+      memcpy(up.data() + L.Vs + (size_t)t * kBlMaxR * kBlMaxRc, bs[t].Vs.data(), sizeof(double) * bs[t].Vs.size());
+      memcpy(up.data() + L.sig + (size_t)t * kBlMaxR, bs[t].sig.data(), sizeof(double) * bs[t].sig.size());
+    }
+    SBO_HIP(hipMemcpyAsync(base, up.data(), sizeof(double) * L.work, hipMemcpyHostToDevice, st));
+    SBO_HIP(hipStreamSynchronize(st));                 // (`up` goes out of scope)
+  } else {
+    BlJobs jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.n = n;
+    jb.dpad = mc.dpad;
+    for (int o = 0; o < q; ++o)
+      for (int a = 0; a < 2; ++a) jb.vinv[2 * o + a] = mc.vinv[o][a];
+    for (int a = 0; a < 2; ++a) { jb.a[a] = ab[2 * a]; jb.b[a] = ab[2 * a + 1]; }
+    hipLaunchKernelGGL(k_bl_basis, dim3((unsigned)(2 * q)), dim3(kBasisThreads), 0, st, jb, (const double*)c->Xn.p, base + L.work,
+                       L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info));
+    SBO_HIP(hipGetLastError());
+  }
+  SBO_HIP(hipMemcpyAsync(c->h_back + 4096, base + L.info, sizeof(int) * 8 * q, hipMemcpyDeviceToHost, st));
+  for (int t = 0; t < 4; ++t) c->bl_basis_ab[t] = ab[t];
+  c->bl_basis_serial = c->model_serial;
+  c->bl_basis_ok = true;       // (enqueued: valid once `st` has drained)
+  return SBO_OK;
+}
+
+static bool basis_current(const sbo_ctx* c) {
+  double ab[4];
+  if (!c->bl_basis_ok || c->bl_basis_serial != c->model_serial || !basis_intervals(c, ab)) return false;
+  for (int t = 0; t < 4; ++t)
+    if (ab[t] != c->bl_basis_ab[t]) return false;
+  return true;
 }
 
 // Builds the device tables for the current (model, candidates).  Returns SBO_OK with plan.usable = false when the bases do
@@ -606,36 +1027,34 @@ int bilinear_setup(sbo_ctx* c) {
   };
   const ModelConst& mc = c->mc;
   const CandSpec& cs = c->cs;
-  const int n = mc.n, q = mc.q, d = 2, NB = 1 + d;
+  const int n = mc.n, q = mc.q;
   const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0, line0 = cs.first / cnt0;
-  std::vector<double> xn0, xn1_all, xn1;
-  grid_axis_positions(c, 0, 0, cnt0, xn0);
-  // the axis-1 basis is built on the interval of the WHOLE axis, so that every rank of a sharded grid uses the same
-  // functions; only the local lines are tabulated
-  grid_axis_positions(c, 1, 0, cs.count[1], xn1_all);
-  std::vector<bl::AxisBasis> b0(q), b1(q);
-  {
-    // the 2 q bases are independent: one host thread each
-    std::vector<char> ok(2 * q, 0);
-    bl::parallel_ranges(2 * q, [&](int lo_, int hi_) {
-      std::vector<double> col(n);
-      for (int t = lo_; t < hi_; ++t) {
-        const int o = t / 2, a = t % 2;
-        for (int j = 0; j < n; ++j) col[j] = c->h_Xnorm[(size_t)j * mc.d + a] * mc.vinv[o][a];   // GP_Safe.py:115
-        bl::AxisBasis& b = a == 0 ? b0[o] : b1[o];
-        const std::vector<double>& xs = a == 0 ? xn0 : xn1_all;
-        ok[t] = bl::axis_basis(n, col.data(), mc.vinv[o][a], xs.data(), (int)xs.size(), b, /*tabulate=*/false) ? 1 : 0;
-      }
-    });
-    for (int t = 0; t < 2 * q; ++t)
-      if (!ok[t]) return SBO_OK;
+  int rc;
+  if (!basis_current(c)) {
+    if ((rc = bilinear_basis_enqueue(c, c->stream))) return rc;
+    if (!c->bl_basis_ok) return SBO_OK;
+    SBO_HIP(hipStreamSynchronize(c->stream));
   }
   lap("bases");
-  int r0u = 0, K0 = 0, K1 = 0;
+  const int* inf = (const int*)(c->h_back + 4096);
+  BlDims dm;
+  memset(&dm, 0, sizeof(dm));
+  int r0u = 0, r1u = 0, K0 = 0, K1 = 0, Rmax = 0;
   for (int o = 0; o < q; ++o) {
-    r0u = std::max(r0u, b0[o].r);
-    K0 = std::max(K0, bl::pair_count(b0[o].r));
-    K1 = std::max(K1, bl::pair_count(b1[o].r));
+    if (!inf[8 * o] || !inf[8 * o + 4]) return SBO_OK;            // a basis did not qualify
+    dm.r0[o] = inf[8 * o + 1]; dm.rc0[o] = inf[8 * o + 2];
+    dm.r1[o] = inf[8 * o + 5]; dm.rc1[o] = inf[8 * o + 6];
+    if (dm.r0[o] < 1 || dm.r0[o] > kBlMaxR || dm.r1[o] < 1 || dm.r1[o] > kBlMaxR) return SBO_OK;
+    r0u = std::max(r0u, dm.r0[o]);
+    r1u = std::max(r1u, dm.r1[o]);
+    K0 = std::max(K0, bl::pair_count(dm.r0[o]));
+    K1 = std::max(K1, bl::pair_count(dm.r1[o]));
+    Rmax = std::max(Rmax, dm.r0[o] * dm.r1[o]);
+    dm.sf2[o] = mc.sf2[o];
+    pl.r0[o] = dm.r0[o];
+    pl.r1[o] = dm.r1[o];
+    if (timing) fprintf(stderr, "[K1b setup] output %d: r0 %d (degree %d), r1 %d (degree %d)%s\n", o, dm.r0[o], dm.rc0[o], dm.r1[o], dm.rc1[o],
+                        c->bl_host_bases ? "  [host bases]" : "");
   }
   const int KB0 = (K0 + 15) / 16, KB1 = (K1 + 15) / 16;
   const int ncs0 = (int)((cnt0 + 15) / 16), nrb = (int)((nlines + 15) / 16);
@@ -660,145 +1079,62 @@ int bilinear_setup(sbo_ctx* c) {
   pl.KS0 = (K0 + 3) / 4;
   pl.sVA = (size_t)nrb * (2 * KBm + KBm2) * 256;     // image sets  V0 | [V1; V0] | V1x
   pl.sSBf = (size_t)ncs0 * (KBm + KBm2) * 256;      // fragment sets  S0 | [S0; -xn0 S0]
-  // Everything below the bases runs on the device, all outputs back to back on the stream and one synchronisation at
-  // the end: per output the bases / tables / beta go up (a few hundred KB), then Z -> C = M Z -> G = C^T C -> T4, the
-  // pair tables of both axes, and the mean-phase operands Mb -> Vb -> A images / B fragments.
-  int rc;
   if ((rc = ensure(c->bl_P0f, sizeof(double) * pl.sP0f * q))) return rc;
   if ((rc = ensure(c->bl_P1A, sizeof(double) * pl.sP1A * q))) return rc;
   if ((rc = ensure(c->bl_T4f, sizeof(double) * pl.sT4f * q))) return rc;
   if ((rc = ensure(c->bl_SBf, sizeof(double) * pl.sSBf * q))) return rc;     // mean-phase B fragments
   if ((rc = ensure(c->bl_VA, sizeof(double) * pl.sVA * q))) return rc;      // mean-phase A images
   if ((rc = ensure(c->bl_BtA, sizeof(double) * pl.sBtA * q))) return rc;
-  const int KBn = mc.npad / 16;
-  // host staging that must outlive the asynchronous uploads: one set per output
-  // Layout of bl_small: [uploaded: xn0 | xn1 (local lines) | per output U0 U1 beta Vs0 sg0 Vs1 sg1 | pair maps (ints)]
-  // [device-made: per output S0 S1 Mb Vb].  The uploaded part is assembled in one pinned staging buffer and goes up
-  // as a single copy (a dozen small copies from pageable memory cost ~30 us each).
-  std::vector<std::vector<int>> maps0(q), maps1(q);
-  struct Region { size_t U0, U1, beta, Vs0, sg0, Vs1, sg1, map0, map1, S0, S1, Mb, Vb; };
-  std::vector<Region> reg(q);
-  size_t ndbl = (size_t)cnt0 + (size_t)nlines, nint = 0, work_max = 0;
-  for (int o = 0; o < q; ++o) {
-    const int r0 = b0[o].r, r1 = b1[o].r;
-    Region& g = reg[o];
-    g.U0 = ndbl;
-    g.U1 = g.U0 + (size_t)n * r0;
-    g.beta = g.U1 + (size_t)n * r1;
-    g.Vs0 = g.beta + (size_t)NB * n;
-    g.sg0 = g.Vs0 + b0[o].Vs.size();
-    g.Vs1 = g.sg0 + (size_t)r0;
-    g.sg1 = g.Vs1 + b1[o].Vs.size();
-    ndbl = g.sg1 + (size_t)r1;
-    bl::pair_map(r0, maps0[o]);
-    bl::pair_map(r1, maps1[o]);
-    g.map0 = nint;
-    g.map1 = nint + maps0[o].size();
-    nint = g.map1 + maps1[o].size();
-    const size_t ncsR = ((size_t)r0 * r1 + 15) / 16;
-    work_max = std::max(work_max, 3 * ncsR * KBn * 256 + (ncsR * 16) * (ncsR * 16));
-  }
-  const size_t nint_pad = (nint + 1) / 2 * 2;               // keep the doubles behind the ints 8-byte aligned
-  const size_t up_bytes = sizeof(double) * ndbl + sizeof(int) * nint_pad;
-  size_t ndev = 0;                                          // device-made part, in doubles behind the uploaded bytes
-  for (int o = 0; o < q; ++o) {
-    const int r0 = b0[o].r, r1 = b1[o].r;
-    Region& g = reg[o];
-    g.S0 = ndev;
-    g.S1 = g.S0 + (size_t)r0 * cnt0;
-    g.Mb = g.S1 + (size_t)r1 * nlines;
-    g.Vb = g.Mb + (size_t)NB * r0 * r1;
-    ndev = g.Vb + (size_t)NB * r0u * nlines;
-  }
-  if ((rc = ensure(c->bl_small, up_bytes + sizeof(double) * ndev))) return rc;
-  if ((rc = ensure(c->bl_work, sizeof(double) * work_max))) return rc;
-  if (c->h_stage_bytes < up_bytes) {
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
-    c->h_stage = nullptr;
-    c->h_stage_bytes = 0;
-    const size_t want = up_bytes + up_bytes / 2 + 4096;
-    if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) != hipSuccess) return fail(SBO_E_HIP, "hipHostMalloc (K1b staging)");
-    c->h_stage_bytes = want;
-  }
-  double* hsm = (double*)c->h_stage;
-  int* hints = (int*)(hsm + ndbl);
+  const int KBn = mc.npad / 16, ncsR = (Rmax + 15) / 16;
+  const size_t nZf = (size_t)ncsR * KBn * 256;                // fragments of Z, of C, images of C^T: same size
+  const size_t ldg = (size_t)ncsR * 16;
+  if ((rc = ensure(c->bl_work, sizeof(double) * (size_t)q * (3 * nZf + ldg * ldg)))) return rc;
+  // bl_small: xn0 | xn1 (local lines) | S0 | S1 | Mb | Vb  -- everything made on the device
+  const size_t oS0 = (size_t)cnt0 + (size_t)nlines, oS1 = oS0 + (size_t)q * r0u * cnt0, oMb = oS1 + (size_t)q * r1u * nlines,
+               oVb = oMb + (size_t)q * 3 * r0u * r1u, oEnd = oVb + (size_t)q * 3 * r0u * nlines;
+  if ((rc = ensure(c->bl_small, sizeof(double) * oEnd))) return rc;
+  dm.q = q; dm.n = n; dm.KBn = KBn;
+  dm.r0u = r0u; dm.r1u = r1u; dm.r0p = r0p; dm.KB0 = KB0; dm.KB1 = KB1; dm.KBm = KBm; dm.KBm2 = KBm2;
+  dm.ncs0 = ncs0; dm.nrb = nrb; dm.ncsR = ncsR; dm.cnt0 = cnt0; dm.nlines = nlines;
+  for (int a = 0; a < 2; ++a) { dm.a[a] = c->bl_basis_ab[2 * a]; dm.b[a] = c->bl_basis_ab[2 * a + 1]; }
+  const BasisLayout L = basis_layout(n, q);
+  const double* bb = (const double*)c->bl_basis.p;
+  const double *dU = bb + L.U, *dVs = bb + L.Vs, *dsig = bb + L.sig;
   double* dsm = (double*)c->bl_small.p;
-  const int* dints = (const int*)(dsm + ndbl);
-  double* ddev = (double*)((char*)c->bl_small.p + up_bytes);
-  memcpy(hsm, xn0.data(), sizeof(double) * cnt0);
-  memcpy(hsm + cnt0, &xn1_all[(size_t)line0], sizeof(double) * nlines);
-  for (int o = 0; o < q; ++o) {
-    const Region& g = reg[o];
-    memcpy(hsm + g.U0, b0[o].U.data(), sizeof(double) * b0[o].U.size());
-    memcpy(hsm + g.U1, b1[o].U.data(), sizeof(double) * b1[o].U.size());
-    double* beta = hsm + g.beta;
-    for (int j = 0; j < n; ++j) {
-      const double al = c->h_alpha[(size_t)o * mc.npad + j];
-      beta[j] = al;
-      beta[(size_t)n + j] = al * c->h_Xnorm[(size_t)j * mc.d + 0];
-      beta[(size_t)2 * n + j] = al * c->h_Xnorm[(size_t)j * mc.d + 1];
-    }
-    memcpy(hsm + g.Vs0, b0[o].Vs.data(), sizeof(double) * b0[o].Vs.size());
-    memcpy(hsm + g.sg0, b0[o].sig.data(), sizeof(double) * b0[o].sig.size());
-    memcpy(hsm + g.Vs1, b1[o].Vs.data(), sizeof(double) * b1[o].Vs.size());
-    memcpy(hsm + g.sg1, b1[o].sig.data(), sizeof(double) * b1[o].sig.size());
-    memcpy(hints + g.map0, maps0[o].data(), sizeof(int) * maps0[o].size());
-    memcpy(hints + g.map1, maps1[o].data(), sizeof(int) * maps1[o].size());
-  }
-  SBO_HIP(hipMemcpyAsync(dsm, hsm, up_bytes, hipMemcpyHostToDevice, c->stream));
-  auto blocks = [](size_t total) { return dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16)); };
-  for (int o = 0; o < q; ++o) {
-    const int r0 = b0[o].r, r1 = b1[o].r, k0n = bl::pair_count(r0), k1n = bl::pair_count(r1);
-    const double sf2 = mc.sf2[o];
-    const Region& g = reg[o];
-    const int R = r0 * r1, ncsR = (R + 15) / 16;
-    const size_t nZf = (size_t)ncsR * KBn * 256;              // fragments of Z, of C, images of C^T: same size
-    const size_t ldg = (size_t)ncsR * 16;
-    double *dU0 = dsm + g.U0, *dU1 = dsm + g.U1, *dbeta = dsm + g.beta;
-    double *dS0 = ddev + g.S0, *dS1 = ddev + g.S1, *dMb = ddev + g.Mb, *dVb = ddev + g.Vb;
-    const int *dmap0 = dints + g.map0, *dmap1 = dints + g.map1;
-    double* Zf = (double*)c->bl_work.p;
-    double* Cf = Zf + nZf;
-    double* CtA = Cf + nZf;
-    double* G = CtA + nZf;
-    // axis tables from the bases' Chebyshev series: all positions of axis 0, the local lines of axis 1
-    hipLaunchKernelGGL(k_bl_stab, blocks((size_t)r0 * cnt0), dim3(256), 0, c->stream, (const double*)(dsm + g.Vs0),
-                       (const double*)(dsm + g.sg0), (const double*)dsm, b0[o].a, b0[o].b, b0[o].rc, r0, cnt0, dS0);
-    hipLaunchKernelGGL(k_bl_stab, blocks((size_t)r1 * nlines), dim3(256), 0, c->stream, (const double*)(dsm + g.Vs1),
-                       (const double*)(dsm + g.sg1), (const double*)(dsm + cnt0), b1[o].a, b1[o].b, b1[o].rc, r1, nlines, dS1);
-    hipLaunchKernelGGL(k_bl_zf, blocks(nZf), dim3(256), 0, c->stream, (const double*)dU0, (const double*)dU1, n, KBn, r0, r1, ncsR, Zf);
-    // C = M Z with the model's packed triangular factor; written as fragments (k = observation) and as images of C^T
-    hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), 1), dim3(256), 0, c->stream,
-                       (const double*)c->Fpk.p + (size_t)o * c->fpk_stride, (size_t)0, (const double*)Zf, (size_t)0, KBn, KBn, ncsR,
-                       Cf, (size_t)0, CtA, 0ll);
-    // G = C^T C  (R x R, row-major)
-    hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), 1), dim3(256), 0, c->stream,
-                       (const double*)CtA, (size_t)0, (const double*)Cf, (size_t)0, KBn, ncsR, ncsR, G, (size_t)0, (double*)nullptr,
-                       (long long)ldg);
-    hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f), dim3(256), 0, c->stream, (const double*)G, (long long)ldg, r1, (const int*)dmap0, k0n,
-                       (const int*)dmap1, k1n, sf2 * sf2, KB0, KB1, (double*)c->bl_T4f.p + pl.sT4f * o);
-    hipLaunchKernelGGL((k_bl_pairs<1>), blocks(pl.sP0f), dim3(256), 0, c->stream, (const double*)dS0, cnt0, (const int*)dmap0, k0n, KB0,
-                       ncs0, (double*)c->bl_P0f.p + pl.sP0f * o);
-    hipLaunchKernelGGL((k_bl_pairs<0>), blocks(pl.sP1A), dim3(256), 0, c->stream, (const double*)dS1, nlines, (const int*)dmap1, k1n, KB1,
-                       nrb, (double*)c->bl_P1A.p + pl.sP1A * o);
-    // mean phases: Mb (forms of alpha, alpha Xn_0, alpha Xn_1) -> Vb = Mb S1 -> A images [V0 | V1;V0 | V1x], B fragments
-    // [S0 | S0;-xn0 S0]
-    hipLaunchKernelGGL(k_bl_mb, blocks((size_t)NB * R), dim3(256), 0, c->stream, (const double*)dU0, (const double*)dU1,
-                       (const double*)dbeta, n, r0, r1, NB, sf2, dMb);
-    hipLaunchKernelGGL(k_bl_vb, blocks((size_t)NB * r0 * nlines), dim3(256), 0, c->stream, (const double*)dMb, (const double*)dS1, r0,
-                       r1, r0u, nlines, NB, dVb);
-    hipLaunchKernelGGL(k_bl_va, blocks(pl.sVA), dim3(256), 0, c->stream, (const double*)dVb, (const double*)(dsm + cnt0), nrb, KBm, KBm2,
-                       r0, r0p, r0u, nlines, (double*)c->bl_VA.p + pl.sVA * o);
-    hipLaunchKernelGGL(k_bl_sbf, blocks(pl.sSBf), dim3(256), 0, c->stream, (const double*)dS0, (const double*)dsm, ncs0, KBm, KBm2, r0,
-                       r0p, cnt0, (double*)c->bl_SBf.p + pl.sSBf * o);
-    SBO_HIP(hipGetLastError());
-    pl.r0[o] = r0;
-    pl.r1[o] = r1;
-  }
+  double *dxn0 = dsm, *dxn1 = dsm + cnt0, *dS0 = dsm + oS0, *dS1 = dsm + oS1, *dMb = dsm + oMb, *dVb = dsm + oVb;
+  double* Zf = (double*)c->bl_work.p;
+  double* Cf = Zf + (size_t)q * nZf;
+  double* CtA = Cf + (size_t)q * nZf;
+  double* G = CtA + (size_t)q * nZf;
+  auto blocks = [&](size_t total, unsigned y) { return dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16), y); };
+  const unsigned uq = (unsigned)q;
+  hipLaunchKernelGGL(k_bl_axes, dim3((unsigned)std::min<long long>((cnt0 + nlines + 255) / 256, 4096)), dim3(256), 0, c->stream, mc, cs,
+                     cnt0, line0, nlines, dxn0, dxn1);
+  hipLaunchKernelGGL(k_bl_stab, blocks((size_t)std::max(r0u * cnt0, r1u * nlines), 2 * uq), dim3(256), 0, c->stream, dm, dVs, dsig,
+                     (const double*)dxn0, (const double*)dxn1, dS0, dS1);
+  hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, c->stream, dm, dU, nZf, Zf);
+  // C = M Z with the model's packed triangular factor; written as fragments (k = observation) and as images of C^T
+  hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, c->stream,
+                     (const double*)c->Fpk.p, c->fpk_stride, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
+  // G = C^T C  (R x R, row-major)
+  hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
+                     (const double*)CtA, nZf, (const double*)Cf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
+  hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f, uq), dim3(256), 0, c->stream, dm, (const double*)G, (long long)ldg, pl.sT4f,
+                     (double*)c->bl_T4f.p);
+  hipLaunchKernelGGL((k_bl_pairs<1>), blocks(pl.sP0f, uq), dim3(256), 0, c->stream, dm, (const double*)dS0, pl.sP0f, (double*)c->bl_P0f.p);
+  hipLaunchKernelGGL((k_bl_pairs<0>), blocks(pl.sP1A, uq), dim3(256), 0, c->stream, dm, (const double*)dS1, pl.sP1A, (double*)c->bl_P1A.p);
+  // mean phases: Mb (forms of alpha, alpha Xn_0, alpha Xn_1) -> Vb = Mb S1 -> A images [V0 | V1;V0 | V1x], B fragments
+  // [S0 | S0;-xn0 S0]
+  hipLaunchKernelGGL(k_bl_mb, blocks((size_t)3 * r0u * r1u * 64, uq), dim3(256), 0, c->stream, dm, dU, (const double*)c->alpha64.p,
+                     c->a_ld, (const double*)c->Xn.p, mc.dpad, dMb);
+  hipLaunchKernelGGL(k_bl_vb, blocks((size_t)3 * r0u * nlines, uq), dim3(256), 0, c->stream, dm, (const double*)dMb, (const double*)dS1, dVb);
+  hipLaunchKernelGGL(k_bl_va, blocks(pl.sVA, uq), dim3(256), 0, c->stream, dm, (const double*)dVb, (const double*)dxn1, pl.sVA,
+                     (double*)c->bl_VA.p);
+  hipLaunchKernelGGL(k_bl_sbf, blocks(pl.sSBf, uq), dim3(256), 0, c->stream, dm, (const double*)dS0, (const double*)dxn0, pl.sSBf,
+                     (double*)c->bl_SBf.p);
+  SBO_HIP(hipGetLastError());
   lap("enqueue");
-  SBO_HIP(hipStreamSynchronize(c->stream));      // the host staging vectors go out of scope
-  lap("upload");
-  pl.usable = true;
+  pl.usable = true;       // (nothing to wait for: the tables are made in stream order ahead of the posterior kernels)
   pl.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return SBO_OK;
 }

@@ -60,6 +60,7 @@ struct BilinearPlan {
 struct sbo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // side stream: the K1b axis bases of a new model run next to its factorisation
   int n_cu = 256;
   // model
   bool has_model = false;
@@ -75,12 +76,19 @@ struct sbo_ctx {
   sbo::DevBuf AXg;     // grid path: alpha_j (1, Xn_j) rows in fragment-slot order [q][npad][1 + dpad]
   size_t fpk_stride = 0;  // elements per output in Fpk
   std::vector<double> h_Xnorm;   // host copies used by the exact-recheck / result decoding
-  std::vector<double> h_alpha;   // [q][npad]
-  sbo::DevBuf Fplain;            // [q][f_cap][f_cap] fp64 lower factor M, row-major (kept for sbo_model_append)
-  sbo::DevBuf alpha64;           // [q][f_cap] fp64 alpha
-  int f_cap = 0;                 // leading dimension / capacity of Fplain and alpha64
+  sbo::DevBuf Fplain;            // [q][f_cap][f_cap] fp64 lower factor M, row-major (K1b table build, sbo_model_append)
+  sbo::DevBuf alpha64;           // [q][a_ld] fp64 alpha
+  int f_cap = 0;                 // leading dimension / capacity of Fplain: n after a build, n + 256.. once an append has grown it
+  int a_ld = 0;                  // stride of alpha64: npad after a build, f_cap after an append
+  sbo::DevBuf mwork;             // model build workspace (uploads, fp64 copies of the derived arrays, the factorisation's scratch)
   sbo::BilinearPlan bl;
   sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work;
+  sbo::DevBuf bl_basis;            // K1b: the 2 q axis bases (U, Chebyshev series, ranks) and the workspace of their kernel
+  bool bl_basis_ok = false;        // bases enqueued for (bl_basis_serial, bl_basis_ab); their (ok, r, rc) records land at h_back + 4096
+  unsigned long long bl_basis_serial = 0;
+  double bl_basis_ab[4] = {0, 0, 0, 0};
+  unsigned long long model_serial = 0;   // bumped by every sbo_model_set / sbo_model_append
+  int bl_host_bases = 0;           // option: 1 = bases by the host SVD of bilinear_host.hpp (A/B against the device kernel)
   // candidates
   bool has_cand = false;
   sbo::CandSpec cs{};
@@ -157,11 +165,12 @@ void release(DevBuf& b);
 // launchers implemented in the .hip files -----------------------------------------------------
 int launch_posterior(sbo_ctx* c);
 int launch_bound(sbo_ctx* c, double b, int index, int kind, void* dev_out);
-int model_build(sbo_ctx* c, const double* host_invK, const std::vector<double>& As, const std::vector<double>& sqA,
-                const std::vector<double>& rhs, const double* sn2);
+int model_build(sbo_ctx* c, const double* host_invK, const double* X_norm, const double* Y_norm);
+int model_prep(sbo_ctx* c, const double* X_norm);
 int model_append(sbo_ctx* c, const std::vector<double>& kvec /*[q][n]*/, const double* kappa, const double* rho);
 int model_repack(sbo_ctx* c);
 bool bilinear_applicable(const sbo_ctx* c);
+int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st);
 int bilinear_setup(sbo_ctx* c);
 int launch_posterior_bilinear(sbo_ctx* c);
 }  // namespace sbo

@@ -12,6 +12,7 @@
 // run in one workgroup per output; larger ones use the blocked multi-workgroup form below (n = 512: 1.4 ms, n = 2048:
 // 9 ms per model, against ~95 ms / seconds of host Cholesky).
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <vector>
 #include "device_common.hpp"
@@ -74,8 +75,7 @@ __device__ void factor_utu(double* __restrict__ U, int n, int* bad, double* sh_p
 // alpha [q][npad], bad[q].  `work` [q][n][n] scratch.
 __global__ __launch_bounds__(1024) void k_model_build(int mode, int n, int npad, int dpad, int d, const double* __restrict__ W,
                                                      const double* __restrict__ As, const double* __restrict__ sqA,
-                                                     const double* __restrict__ rhs, const double* __restrict__ sf2v,
-                                                     const double* __restrict__ sn2v, double* __restrict__ work,
+                                                     const double* __restrict__ rhs, const ModelConst mc, double* __restrict__ work,
                                                      double* __restrict__ F, double* __restrict__ alpha, int* __restrict__ bad) {
   __shared__ double sh_piv;
   __shared__ int sh_bad;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(1024) void k_model_build(int mode, int n, int npad,
       Fo[idx] = j <= i ? U[(size_t)(n - 1 - i) * n + (n - 1 - j)] : 0.0;
     }
   } else {
-    const double sf2 = sf2v[o], sn2 = sn2v[o];
+    const double sf2 = mc.sf2[o], sn2 = mc.sn2[o];
     const double* Ao = As + (size_t)o * npad * dpad;
     const double* so = sqA + (size_t)o * npad;
     // K[i][k] = sf2 exp(-1/2 dist(i, k)) + sn2 [i == k], dist as GP_Safe.py:119 evaluates it; the lower element (i >= k)
@@ -153,8 +153,7 @@ constexpr int kBlockedFrom = 96;   // smallest n factorised by the blocked form 
 
 __global__ __launch_bounds__(256) void k_chol_prep(int mode, int n, int npad, int dpad, int d, const double* __restrict__ W,
                                                    const double* __restrict__ As, const double* __restrict__ sqA,
-                                                   const double* __restrict__ rhs, const double* __restrict__ sf2v,
-                                                   const double* __restrict__ sn2v, double* __restrict__ work,
+                                                   const double* __restrict__ rhs, const ModelConst mc, double* __restrict__ work,
                                                    double* __restrict__ F, double* __restrict__ alpha) {
   const int o = blockIdx.y;
   double* U = work + (size_t)o * n * n;
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(256) void k_chol_prep(int mode, int n, int npad, in
       U[idx] = k >= i ? 0.5 * (Wo[(size_t)ri * n + rk] + Wo[(size_t)rk * n + ri]) : 0.0;
     }
   } else {
-    const double sf2 = sf2v[o], sn2 = sn2v[o];
+    const double sf2 = mc.sf2[o], sn2 = mc.sn2[o];
     const double* Ao = As + (size_t)o * npad * dpad;
     const double* so = sqA + (size_t)o * npad;
     double* Fo = F + (size_t)o * n * n;
@@ -420,89 +419,169 @@ __global__ __launch_bounds__(1024) void k_model_append(int n, int ld, double* __
   for (int j = n + 1 + tid; j < ld; j += blockDim.x) M[(size_t)n * ld + j] = 0.0;
 }
 
-// Device side of sbo_model_set.  host_invK may be NULL (the library factors K itself).  On success Fpk (dtype T) and
-// alpha (dtype T, device) are in place and h_alpha holds the fp64 alpha for the K1b table build.
+// Derived model arrays from the uploaded X_norm [n][d] / Y_norm [n][q] (models/GP_Safe.py:112-116, 331-342):
+//   As[o][j][a] = X_norm[j][a] ell_a^-1/2, sqA[o][j] = sum_a As^2 (model dtype for the K1 kernels, fp64 for the build),
+//   Xn[j][a] (model dtype, for the mean gradient), rhs[o][j] = Y_norm[j][o] - mp_o (fp64, only with Y_norm).
+// Rows j >= n of the padded arrays are zero.
 template <typename T>
-static int model_build_t(sbo_ctx* c, const double* host_invK, const std::vector<double>& As, const std::vector<double>& sqA,
-                         const std::vector<double>& rhs, const double* sn2) {
+__global__ __launch_bounds__(256) void k_model_prep(const ModelConst mc, const double* __restrict__ Xh, const double* __restrict__ Yh,
+                                                    T* __restrict__ As, T* __restrict__ sqA, T* __restrict__ Xn, double* __restrict__ As64,
+                                                    double* __restrict__ sq64, double* __restrict__ rhs) {
+  const int n = mc.n, npad = mc.npad, d = mc.d, D = mc.dpad, q = mc.q;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < q * npad; i += gridDim.x * blockDim.x) {
+    const int o = i / npad, j = i - o * npad;
+    double s_ = 0.0;
+    for (int a = 0; a < D; ++a) {
+      double v = 0.0, x = 0.0;
+      if (j < n && a < d) {
+        x = Xh[(size_t)j * d + a];
+        v = x * mc.vinv[o][a];                                          // GP_Safe.py:115
+        s_ += v * v;
+      }
+      As[(size_t)i * D + a] = (T)v;
+      As64[(size_t)i * D + a] = v;
+      if (o == 0) Xn[(size_t)j * D + a] = (T)x;
+    }
+    sqA[i] = (T)s_;
+    sq64[i] = s_;
+    if (Yh && j < n) rhs[(size_t)o * n + j] = Yh[(size_t)j * q + o] - mc.mp[o];
+  }
+}
+
+// Upload X_norm (and Y_norm) through the pinned staging area and derive the model arrays on the device.  Layout of
+// c->mwork (doubles): XY [n d + n q] | As64 | sq64 | rhs | sf2 sn2 | W | work | Dg | bad (ints)
+struct ModelWork {
+  double *XY, *As64, *sq64, *rhs, *sfsn, *W, *work, *Dg;
+  int* bad;
+};
+static int model_work(sbo_ctx* c, bool with_W, ModelWork& w) {
+  const ModelConst& mc = c->mc;
+  const size_t n = mc.n, q = mc.q, npad = mc.npad, nn = n * n;
+  const size_t nXY = n * mc.d + n * q, nAs = q * npad * mc.dpad, nsq = q * npad, nrhs = q * n;
+  const size_t ndiag = q * ((n + kPB - 1) / kPB) * (kPB * kPB);
+  const size_t total = nXY + nAs + nsq + nrhs + 2 * q + (with_W ? q * nn : 0) + q * nn + ndiag + q + 8;
+  int rc = ensure(c->mwork, sizeof(double) * total);
+  if (rc) return rc;
+  w.XY = (double*)c->mwork.p;
+  w.As64 = w.XY + nXY;
+  w.sq64 = w.As64 + nAs;
+  w.rhs = w.sq64 + nsq;
+  w.sfsn = w.rhs + nrhs;
+  w.W = w.sfsn + 2 * q;
+  w.work = w.W + (with_W ? q * nn : 0);
+  w.Dg = w.work + q * nn;
+  w.bad = (int*)(w.Dg + ndiag);
+  return SBO_OK;
+}
+static int stage_ensure(sbo_ctx* c, size_t bytes) {
+  if (c->h_stage_bytes >= bytes) return SBO_OK;
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  c->h_stage = nullptr;
+  c->h_stage_bytes = 0;
+  const size_t want = bytes + bytes / 2 + 4096;
+  if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) != hipSuccess) return fail(SBO_E_HIP, "hipHostMalloc (model staging)");
+  c->h_stage_bytes = want;
+  return SBO_OK;
+}
+template <typename T>
+static int model_prep_t(sbo_ctx* c, const double* X_norm, const double* Y_norm, const ModelWork& w) {
+  const ModelConst& mc = c->mc;
+  const size_t n = mc.n, q = mc.q, npad = mc.npad;
+  int rc;
+  if ((rc = stage_ensure(c, sizeof(double) * (n * mc.d + n * q + 2 * q)))) return rc;
+  double* hs = (double*)c->h_stage;
+  std::memcpy(hs, X_norm, sizeof(double) * n * mc.d);
+  if (Y_norm) std::memcpy(hs + n * mc.d, Y_norm, sizeof(double) * n * q);
+  SBO_HIP(hipMemcpyAsync(w.XY, hs, sizeof(double) * (n * mc.d + (Y_norm ? n * q : 0)), hipMemcpyHostToDevice, c->stream));
+  if ((rc = ensure(c->As, sizeof(T) * q * npad * mc.dpad))) return rc;
+  if ((rc = ensure(c->sqA, sizeof(T) * q * npad))) return rc;
+  if ((rc = ensure(c->Xn, sizeof(T) * npad * mc.dpad))) return rc;
+  hipLaunchKernelGGL((k_model_prep<T>), dim3((unsigned)((q * npad + 255) / 256)), dim3(256), 0, c->stream, mc, (const double*)w.XY,
+                     Y_norm ? (const double*)(w.XY + n * mc.d) : (const double*)nullptr, (T*)c->As.p, (T*)c->sqA.p, (T*)c->Xn.p, w.As64,
+                     w.sq64, w.rhs);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+int model_prep(sbo_ctx* c, const double* X_norm) {         // (after an append: the derived arrays with the new row)
+  ModelWork w;
+  int rc = model_work(c, false, w);
+  if (rc) return rc;
+  rc = c->dtype == SBO_F64 ? model_prep_t<double>(c, X_norm, nullptr, w) : model_prep_t<float>(c, X_norm, nullptr, w);
+  if (rc) return rc;
+  SBO_HIP(hipStreamSynchronize(c->stream));                 // (the staging area is free again)
+  return SBO_OK;
+}
+
+// Device side of sbo_model_set.  host_invK may be NULL (the library factors K itself).  On success Fpk (dtype T), alpha
+// (dtype T), the derived arrays As / sqA / Xn and the fp64 factor / alpha (Fplain, alpha64: leading dimension n / npad
+// until an append grows them) are in place.  One host synchronisation, at the end (the positive-definiteness verdict);
+// when a K1b-capable grid is resident the axis bases of the new model are built meanwhile on the second stream.
+template <typename T>
+static int model_build_t(sbo_ctx* c, const double* host_invK, const double* X_norm, const double* Y_norm) {
   const ModelConst& mc = c->mc;
   const int n = mc.n, npad = mc.npad, q = mc.q, nb = npad / 16;
   const size_t nn = (size_t)n * n;
   int rc;
-  // workspace: [W | work | F] (q n^2 each) + As + sqA + rhs + sf2 + sn2 + alpha + bad
-  const size_t small = (size_t)q * npad * mc.dpad + (size_t)q * npad + (size_t)q * n + 2 * (size_t)q + (size_t)q * npad;
-  const size_t ndiag = (size_t)q * ((n + kPB - 1) / kPB) * (kPB * kPB);   // factored diagonal blocks of the blocked form
-  if ((rc = ensure(c->fitwork, sizeof(double) * (3 * q * nn + small + ndiag) + sizeof(int) * q + 64))) return rc;
-  double* dW = (double*)c->fitwork.p;
-  double* dwork = dW + q * nn;
-  double* dF = dwork + q * nn;
-  double* dAs = dF + q * nn;
-  double* dsq = dAs + (size_t)q * npad * mc.dpad;
-  double* drhs = dsq + (size_t)q * npad;
-  double* dsf2 = drhs + (size_t)q * n;
-  double* dsn2 = dsf2 + q;
-  double* dalpha = dsn2 + q;
-  double* dDg = dalpha + (size_t)q * npad;
-  int* dbad = (int*)(dDg + ndiag);
-  if (host_invK) SBO_HIP(hipMemcpyAsync(dW, host_invK, sizeof(double) * q * nn, hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(dAs, As.data(), sizeof(double) * As.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(dsq, sqA.data(), sizeof(double) * sqA.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(drhs, rhs.data(), sizeof(double) * rhs.size(), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(dsf2, mc.sf2, sizeof(double) * q, hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemcpyAsync(dsn2, sn2, sizeof(double) * q, hipMemcpyHostToDevice, c->stream));
+  ModelWork w;
+  if ((rc = model_work(c, host_invK != nullptr, w))) return rc;
+  if ((rc = ensure(c->Fplain, sizeof(double) * (size_t)q * nn))) return rc;
+  if ((rc = ensure(c->alpha64, sizeof(double) * (size_t)q * npad))) return rc;
+  c->f_cap = n;
+  c->a_ld = npad;
+  double* dF = (double*)c->Fplain.p;
+  double* dalpha = (double*)c->alpha64.p;
+  if (host_invK) SBO_HIP(hipMemcpyAsync(w.W, host_invK, sizeof(double) * q * nn, hipMemcpyHostToDevice, c->stream));
+  if ((rc = model_prep_t<T>(c, X_norm, Y_norm, w))) return rc;
+  bool eager_basis = false;
+  if (bilinear_applicable(c)) {
+    // the bases need X_norm only: next to the factorisation, on the second stream
+    SBO_HIP(hipEventRecord(c->ev[6], c->stream));
+    SBO_HIP(hipStreamWaitEvent(c->stream2, c->ev[6], 0));
+    if ((rc = bilinear_basis_enqueue(c, c->stream2))) return rc;
+    eager_basis = true;
+  }
   SBO_HIP(hipMemsetAsync(dalpha, 0, sizeof(double) * (size_t)q * npad, c->stream));
+  SBO_HIP(hipMemsetAsync(w.bad, 0, sizeof(int) * q, c->stream));
   const int mode = host_invK ? 0 : 1;
+  const double* dsf2 = nullptr;   // (sf2 / sn2 travel in the kernel arguments)
+  (void)dsf2;
   if (n >= kBlockedFrom) {
     // blocked multi-workgroup factorisation: the single-workgroup loop is bound by the latency of its own updates
-    SBO_HIP(hipMemsetAsync(dbad, 0, sizeof(int) * q, c->stream));
-    hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)dW,
-                       (const double*)dAs, (const double*)dsq, (const double*)drhs, (const double*)dsf2, (const double*)dsn2, dwork,
-                       dF, dalpha);
+    hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
+                       (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha);
     for (int kb = 0; kb < n; kb += kPB) {
       const int kw = std::min(kPB, n - kb);
       const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
-      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, (ncols + 255) / 256), q), dim3(256), 0, c->stream, dwork, dF, mode, n,
-                         kb, dbad, dDg);
+      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, (ncols + 255) / 256), q), dim3(256), 0, c->stream, w.work, dF, mode, n,
+                         kb, w.bad, w.Dg);
       const int rest = n - kb - kw;
       if (rest > 0) {
         const unsigned ti = (unsigned)((rest + 31) / 32);
-        hipLaunchKernelGGL(k_chol_update, dim3(ti, ti, q), dim3(256), 0, c->stream, dwork, dF, 0, n, kb);
+        hipLaunchKernelGGL(k_chol_update, dim3(ti, ti, q), dim3(256), 0, c->stream, w.work, dF, 0, n, kb);
         if (mode)
-          hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((kb + kw + 31) / 32), ti, q), dim3(256), 0, c->stream, dwork, dF, 1, n, kb);
+          hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((kb + kw + 31) / 32), ti, q), dim3(256), 0, c->stream, w.work, dF, 1, n, kb);
       }
     }
-    hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, (const double*)drhs, dwork, dF, dalpha,
-                       (const double*)dDg);
+    hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, (const double*)w.rhs, w.work, dF, dalpha,
+                       (const double*)w.Dg);
   } else {
-    hipLaunchKernelGGL(k_model_build, dim3(q), dim3(1024), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)dW,
-                       (const double*)dAs, (const double*)dsq, (const double*)drhs, (const double*)dsf2, (const double*)dsn2, dwork, dF,
-                       dalpha, dbad);
+    hipLaunchKernelGGL(k_model_build, dim3(q), dim3(1024), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
+                       (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha, w.bad);
   }
   const size_t ntri = (size_t)nb * (nb + 1) / 2;
   c->fpk_stride = ntri * 4 * 64;
   if ((rc = ensure(c->Fpk, sizeof(T) * ((size_t)q * c->fpk_stride + 512)))) return rc;   // + padding: the K1g pipeline over-reads
-  SBO_HIP(hipMemsetAsync(c->Fpk.p, 0, sizeof(T) * ((size_t)q * c->fpk_stride + 512), c->stream));
+  // (k_pack_factor writes every element of the images, zeros included; only the over-read padding needs clearing)
+  SBO_HIP(hipMemsetAsync((T*)c->Fpk.p + (size_t)q * c->fpk_stride, 0, sizeof(T) * 512, c->stream));
   hipLaunchKernelGGL((k_pack_factor<T>), dim3((unsigned)std::min<size_t>((ntri * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
                      (const double*)dF, n, n, nn, nb, c->fpk_stride, (T*)c->Fpk.p);
   if ((rc = ensure(c->alpha, sizeof(T) * (size_t)q * npad))) return rc;
   hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)dalpha, npad, n, q, npad, (T*)c->alpha.p);
-  // fp64 factor and alpha stay resident (leading dimension f_cap) so that observations can be appended in O(n^2)
-  const int cap = std::min(SBO_MAX_N, (npad + 256 + 127) / 128 * 128);
-  if ((rc = ensure(c->Fplain, sizeof(double) * (size_t)q * cap * cap))) return rc;
-  if ((rc = ensure(c->alpha64, sizeof(double) * (size_t)q * cap))) return rc;
-  c->f_cap = cap;
-  for (int o = 0; o < q; ++o) {
-    SBO_HIP(hipMemcpy2DAsync((double*)c->Fplain.p + (size_t)o * cap * cap, sizeof(double) * cap, dF + (size_t)o * nn, sizeof(double) * n,
-                             sizeof(double) * n, n, hipMemcpyDeviceToDevice, c->stream));
-    SBO_HIP(hipMemcpyAsync((double*)c->alpha64.p + (size_t)o * cap, dalpha + (size_t)o * npad, sizeof(double) * n,
-                           hipMemcpyDeviceToDevice, c->stream));
-  }
   SBO_HIP(hipGetLastError());
-  std::vector<int> hbad(q, 0);
-  c->h_alpha.assign((size_t)q * npad, 0.0);
-  SBO_HIP(hipMemcpyAsync(hbad.data(), dbad, sizeof(int) * q, hipMemcpyDeviceToHost, c->stream));
-  SBO_HIP(hipMemcpyAsync(c->h_alpha.data(), dalpha, sizeof(double) * (size_t)q * npad, hipMemcpyDeviceToHost, c->stream));
+  int* hbad = (int*)(c->h_back + 4608);
+  SBO_HIP(hipMemcpyAsync(hbad, w.bad, sizeof(int) * q, hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
+  if (eager_basis) SBO_HIP(hipStreamSynchronize(c->stream2));
   for (int o = 0; o < q; ++o)
     if (hbad[o]) return fail(SBO_E_INVALID, host_invK ? "invK is not positive definite" : "K + sn2 I is not positive definite");
   return SBO_OK;
@@ -521,12 +600,8 @@ static int model_repack_t(sbo_ctx* c) {
   hipLaunchKernelGGL((k_pack_factor<T>), dim3((unsigned)std::min<size_t>((ntri * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
                      (const double*)c->Fplain.p, n, cap, (size_t)cap * cap, nb, c->fpk_stride, (T*)c->Fpk.p);
   if ((rc = ensure(c->alpha, sizeof(T) * (size_t)q * npad))) return rc;
-  hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)c->alpha64.p, cap, n, q, npad, (T*)c->alpha.p);
+  hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)c->alpha64.p, c->a_ld, n, q, npad, (T*)c->alpha.p);
   SBO_HIP(hipGetLastError());
-  c->h_alpha.assign((size_t)q * npad, 0.0);
-  for (int o = 0; o < q; ++o)
-    SBO_HIP(hipMemcpyAsync(&c->h_alpha[(size_t)o * npad], (const double*)c->alpha64.p + (size_t)o * cap, sizeof(double) * n,
-                           hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
   return SBO_OK;
 }
@@ -534,10 +609,36 @@ int model_repack(sbo_ctx* c) { return c->dtype == SBO_F64 ? model_repack_t<doubl
 
 // kvec [q][n] cross-covariances of the new point, kappa[q] = sf2 + sn2, rho[q] = y_norm_new - mp; appends row n.
 int model_append(sbo_ctx* c, const std::vector<double>& kvec, const double* kappa, const double* rho) {
-  const int n = c->mc.n, q = c->mc.q, cap = c->f_cap;
+  const int n = c->mc.n, q = c->mc.q;
   int rc;
-  if ((rc = ensure(c->fitwork, sizeof(double) * ((size_t)q * n + 2 * (size_t)q + 2 * (size_t)q * cap) + sizeof(int) * q))) return rc;
-  double* dk = (double*)c->fitwork.p;
+  if (n + 1 > c->f_cap || c->a_ld != c->f_cap) {
+    // a freshly built model keeps its factor tight (leading dimension n): make room for 256 more rows
+    const int cap = std::min(SBO_MAX_N, (c->mc.npad + 256 + 127) / 128 * 128);
+    if (n + 1 > cap) return fail(SBO_E_UNSUPPORTED, "model is at its capacity: rebuild it with sbo_model_set");
+    DevBuf F2, a2;
+    if ((rc = ensure(F2, sizeof(double) * (size_t)q * cap * cap))) return rc;
+    if ((rc = ensure(a2, sizeof(double) * (size_t)q * cap))) { release(F2); return rc; }
+    hipError_t e = hipMemsetAsync(F2.p, 0, sizeof(double) * (size_t)q * cap * cap, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(a2.p, 0, sizeof(double) * (size_t)q * cap, c->stream);
+    for (int o = 0; o < q && e == hipSuccess; ++o) {
+      e = hipMemcpy2DAsync((double*)F2.p + (size_t)o * cap * cap, sizeof(double) * cap, (const double*)c->Fplain.p + (size_t)o * c->f_cap * c->f_cap,
+                           sizeof(double) * c->f_cap, sizeof(double) * n, n, hipMemcpyDeviceToDevice, c->stream);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync((double*)a2.p + (size_t)o * cap, (const double*)c->alpha64.p + (size_t)o * c->a_ld, sizeof(double) * n,
+                           hipMemcpyDeviceToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { release(F2); release(a2); return hip_fail(e, "growing the resident factor"); }
+    release(c->Fplain);
+    release(c->alpha64);
+    c->Fplain = F2;
+    c->alpha64 = a2;
+    c->f_cap = cap;
+    c->a_ld = cap;
+  }
+  const int cap = c->f_cap;
+  if ((rc = ensure(c->mwork, sizeof(double) * ((size_t)q * n + 2 * (size_t)q + 2 * (size_t)q * cap) + sizeof(int) * q))) return rc;
+  double* dk = (double*)c->mwork.p;
   double* dkappa = dk + (size_t)q * n;
   double* drho = dkappa + q;
   double* dscratch = drho + q;
@@ -557,10 +658,8 @@ int model_append(sbo_ctx* c, const std::vector<double>& kvec, const double* kapp
   return SBO_OK;
 }
 
-int model_build(sbo_ctx* c, const double* host_invK, const std::vector<double>& As, const std::vector<double>& sqA,
-                const std::vector<double>& rhs, const double* sn2) {
-  return c->dtype == SBO_F64 ? model_build_t<double>(c, host_invK, As, sqA, rhs, sn2)
-                             : model_build_t<float>(c, host_invK, As, sqA, rhs, sn2);
+int model_build(sbo_ctx* c, const double* host_invK, const double* X_norm, const double* Y_norm) {
+  return c->dtype == SBO_F64 ? model_build_t<double>(c, host_invK, X_norm, Y_norm) : model_build_t<float>(c, host_invK, X_norm, Y_norm);
 }
 
 }  // namespace sbo
