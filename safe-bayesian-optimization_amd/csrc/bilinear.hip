@@ -231,22 +231,28 @@ __global__ __launch_bounds__(256) void k_bl_axes(const ModelConst mc, const Cand
 }
 
 // Basis of one axis family f_j(x) = exp(-1/2 (x vinv - A_j)^2), j < n, on the interval [a, b] (normalised coordinates),
-// one workgroup of 1024 threads per (output, axis):
+// one workgroup per (output, axis):
 //   1. Chebyshev interpolant of every f_j (degree raised 32 -> 128 until the last four coefficients are < 1e-14),
 //      coefficient rows c_j in R^rc by the discrete cosine sum;
 //   2. column-pivoted Gram-Schmidt on the rows (largest residual first, every direction re-orthogonalised twice against
 //      the ones before): directions q_0 .. q_{r-1}, stopped when the largest residual row is below 2e-16 ||coef||_F --
 //      the rank a singular value decomposition finds (or one less), at a fraction of its sequential depth (r steps instead
-//      of several hundred rotations rounds);
-//   3. U = coef Q [n x r] (from the unmodified coefficients), so that f_j(x) = sum_p U_jp S_p(x), S_p = sum_c Q_pc T_c(xi(x)).
+//      of several hundred rounds of rotations);
+//   3. U_jp = c_j . q_p, taken from the loop itself (the residual of row j is c_j minus its components along the earlier,
+//      orthogonal directions), so that f_j(x) = sum_p U_jp S_p(x), S_p = sum_c Q_pc T_c(xi(x)).
 // Outputs: U [r][n], Vs = Q [r][rc], sig = 1, info = (ok, r, rc).  ok = 0: the interpolant did not converge or the rank
-// exceeds kBlMaxR -- the caller keeps the separable-table kernel.
+// exceeds kBlMaxR -- the caller keeps the separable-table kernel; ok = 2: the small form ran out of LDS (degree > 64), the
+// caller runs the big one.
+// The pivot loop is a chain of short dependent phases, so operand latency is its duration: small problems (n <= 128: NT =
+// 256 threads, LDSRES) keep samples / residual rows in LDS, every problem keeps the directions there when rc <= 64.
 struct BlJobs {
   int n, dpad;
   double vinv[2 * kMaxQ], a[2], b[2];
 };
-constexpr int kBasisThreads = 1024;
+constexpr int kBasisQLds = 64 * 64;          // doubles of LDS for the directions (used when rc <= 64, row stride rc)
+constexpr int kBasisResLds = 64 * 128;       // doubles of LDS for samples / residual rows of the small variant
 
+template <int NT>
 __device__ __forceinline__ double bl_block_sum(double v, double* red) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -254,39 +260,130 @@ __device__ __forceinline__ double bl_block_sum(double v, double* red) {
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   double s = 0.0;
-  for (int w = 0; w < kBasisThreads / 64; ++w) s += red[w];
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) s += red[w];
   return s;                                             // (same order in every thread: deterministic)
 }
 
-__global__ __launch_bounds__(kBasisThreads) void k_bl_basis(const BlJobs jb, const double* __restrict__ Xn, double* __restrict__ work,
-                                                            size_t work_stride, double* __restrict__ Uout, double* __restrict__ Vsout,
-                                                            double* __restrict__ sigout, int* __restrict__ info) {
+// the pivot loop; res [rc][n] and Q [..][rc] may live in LDS (pointers derived from the dynamic LDS block at the call site)
+template <int NT, typename Stamp>
+__device__ __forceinline__ int basis_pivot_loop(int n, int rc, double* res, double* Q, double* __restrict__ U, double tol2, double* nrm2,
+                                                double* qv, double* cf, double* red, int* redi, bool& too_large, Stamp stamp) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rmax = rc < n ? rc : n;
+  int r = 0;
+  too_large = false;
+  // pivot of the first step: the row with the largest norm (ties -> lowest row)
+  double bv = -1.0;
+  int bi = 0x7fffffff;
+  for (int j = tid; j < n; j += NT)
+    if (nrm2[j] > bv) { bv = nrm2[j]; bi = j; }
+  for (;;) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double yv = __shfl_xor(bv, o);
+      const int yi = __shfl_xor(bi, o);
+      if (yv > bv || (yv == bv && yi < bi)) { bv = yv; bi = yi; }
+    }
+    if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    bv = red[0];
+    bi = redi[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w)
+      if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
+    if (!(bv > tol2) || r >= rmax) break;
+    if (r >= kBlMaxR) { too_large = true; break; }
+    const double inv0 = 1.0 / sqrt(bv);
+    if (tid < rc) qv[tid] = res[(size_t)tid * n + bi] * inv0;
+    __syncthreads();
+    // twice: remove what is left along the previous directions (the residual rows are only orthogonal to them to the
+    // rounding of the ORIGINAL rows, which is not small against a residual of 1e-12)
+    double mine = 0.0, nq = 1.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i = tid >> 4; i < r; i += NT / 16) {              // 16 lanes per previous direction
+        double s_ = 0.0;
+        for (int cidx = tid & 15; cidx < rc; cidx += 16) s_ += Q[(size_t)i * rc + cidx] * qv[cidx];
+        s_ += __shfl_xor(s_, 8);
+        s_ += __shfl_xor(s_, 4);
+        s_ += __shfl_xor(s_, 2);
+        s_ += __shfl_xor(s_, 1);
+        if ((tid & 15) == 0) cf[i] = s_;
+      }
+      __syncthreads();
+      if (tid < rc) {
+        mine = qv[tid];
+        for (int i = 0; i < r; ++i) mine -= cf[i] * Q[(size_t)i * rc + tid];
+      }
+      if (pass == 0) {
+        if (tid < rc) qv[tid] = mine;
+        __syncthreads();
+      } else {
+        nq = bl_block_sum<NT>(tid < rc ? mine * mine : 0.0, red);
+      }
+    }
+    if (nq < 0.25) break;                                  // mostly rounding of rows already covered: nothing left to add
+    if (tid < rc) {
+      mine /= sqrt(nq);
+      qv[tid] = mine;
+      Q[(size_t)r * rc + tid] = mine;
+    }
+    __syncthreads();
+    // residual rows: d_j = res_j . q (= U_j,r), res_j -= d_j q, norms recomputed from the updated rows, next pivot
+    bv = -1.0;
+    bi = 0x7fffffff;
+    for (int j = tid; j < n; j += NT) {
+      double d_ = 0.0;
+      for (int cidx = 0; cidx < rc; ++cidx) d_ += res[(size_t)cidx * n + j] * qv[cidx];
+      U[(size_t)r * n + j] = d_;
+      double nn = 0.0;
+      for (int cidx = 0; cidx < rc; ++cidx) {
+        const double v = res[(size_t)cidx * n + j] - d_ * qv[cidx];
+        res[(size_t)cidx * n + j] = v;
+        nn += v * v;
+      }
+      if (nn > bv) { bv = nn; bi = j; }
+    }
+    ++r;
+    __syncthreads();                                       // (red / redi / qv are rewritten by the next step)
+    stamp();
+  }
+  return r;
+}
+
+template <int NT, bool LDSRES>
+__global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* __restrict__ Xn, double* __restrict__ work,
+                                                 size_t work_stride, double* __restrict__ Uout, double* __restrict__ Vsout,
+                                                 double* __restrict__ sigout, int* __restrict__ info,
+                                                 long long* __restrict__ dbg /* nullptr, or 80 time stamps of job 0 */) {
+  extern __shared__ double bl_dyn[];          // [kBasisQLds directions | kBasisResLds samples / residual rows (LDSRES)]
   __shared__ double ct[4 * kBlMaxRc];        // cos(pi m / (2 rc)), m < 4 rc
   __shared__ double qv[kBlMaxRc];            // the direction being built
   __shared__ double cf[kBlMaxR];             // its coefficients along the previous directions
-  __shared__ double part[kBasisThreads];     // per-(chunk, row) partial sums of the residual update
-  __shared__ double nrm2[SBO_MAX_N];         // squared residual norm of every row
-  __shared__ double red[kBasisThreads / 64];
-  __shared__ int redi[kBasisThreads / 64];
-  __shared__ double sh_val;
-  __shared__ int sh_idx;
+  __shared__ double nrm2[SBO_MAX_N];         // squared norm of every row
+  __shared__ double red[NT / 64];
+  __shared__ int redi[NT / 64];
   const int job = blockIdx.x, axis = job & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = jb.n;
   const double vinv = jb.vinv[job], a = jb.a[axis], b = jb.b[axis];
-  double* fnT = work + (size_t)job * work_stride;      // [k][j] samples
-  double* coefT = fnT + (size_t)n * kBlMaxRc;          // [p][j] coefficients
-  double* resT = coefT + (size_t)n * kBlMaxRc;         // [p][j] residual rows
-  double* Q = resT + (size_t)n * kBlMaxRc;             // [i][c] directions (row stride kBlMaxRc)
+  double* wk = work + (size_t)job * work_stride;
+  double* fnT = LDSRES ? bl_dyn + kBasisQLds : wk;                          // [k][j] samples
+  double* resG = wk + (size_t)n * kBlMaxRc;                                // [p][j] residual rows (global form)
+  double* QG = resG + (size_t)n * kBlMaxRc;                                // directions (global form, rc > 64)
   int* inf = info + 4 * job;
   int rc = 0;
-  bool ok = false;
+  bool ok = false, out_of_lds = false;
+  int ndbg = 0;
+  auto stamp = [&]() { if (dbg && job == 0 && tid == 0 && ndbg < 80) dbg[ndbg++] = wall_clock64(); };
+  stamp();
   for (int trial = 0; trial < 5 && !ok; ++trial) {
     rc = trial == 0 ? 32 : (trial == 1 ? 48 : (trial == 2 ? 64 : (trial == 3 ? 96 : kBlMaxRc)));
+    if (LDSRES && rc * n > kBasisResLds) { out_of_lds = true; break; }
     __syncthreads();
-    for (int m = tid; m < 4 * rc; m += kBasisThreads) ct[m] = cospi((double)m / (2.0 * rc));
+    for (int m = tid; m < 4 * rc; m += NT) ct[m] = cospi((double)m / (2.0 * rc));
     __syncthreads();
     // samples at the Chebyshev points of the first kind, theta_k = pi (k + 1/2) / rc
-    for (int w = tid; w < rc * n; w += kBasisThreads) {
+    for (int w = tid; w < rc * n; w += NT) {
       const int k = w / n, j = w - k * n;
       const double x = 0.5 * (ct[2 * k + 1] * (b - a) + (a + b));
       const double df = x * vinv - Xn[(size_t)j * jb.dpad + axis] * vinv;
@@ -295,7 +392,7 @@ __global__ __launch_bounds__(kBasisThreads) void k_bl_basis(const BlJobs jb, con
     __syncthreads();
     // the last four coefficients decide whether this degree is enough
     double tail = 0.0;
-    for (int w = tid; w < 4 * n; w += kBasisThreads) {
+    for (int w = tid; w < 4 * n; w += NT) {
       const int p = rc - 4 + w / n, j = w % n;
       double s_ = 0.0;
       int m = p;
@@ -313,159 +410,88 @@ __global__ __launch_bounds__(kBasisThreads) void k_bl_basis(const BlJobs jb, con
     if (lane == 0) red[wave] = tail;
     __syncthreads();
     tail = 0.0;
-    for (int w = 0; w < kBasisThreads / 64; ++w) tail = red[w] > tail ? red[w] : tail;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) tail = red[w] > tail ? red[w] : tail;
     ok = tail <= 1e-14;
   }
   if (!ok) {
-    if (tid == 0) { inf[0] = 0; inf[1] = 0; inf[2] = rc; inf[3] = 0; }
+    if (tid == 0) { inf[0] = out_of_lds ? 2 : 0; inf[1] = 0; inf[2] = rc; inf[3] = 0; }
     return;
   }
-  // all coefficients: coef[j][p] = w_p / rc sum_k f_j(x_k) cos(p theta_k)
-  for (int w = tid; w < rc * n; w += kBasisThreads) {
-    const int p = w / n, j = w - p * n;
-    double s_ = 0.0;
-    int m = p;
-    for (int k = 0; k < rc; ++k) {
-      s_ += fnT[(size_t)k * n + j] * ct[m];
-      m += 2 * p;
-      if (m >= 4 * rc) m -= 4 * rc;
+  stamp();
+  // all coefficients: coef[j][p] = w_p / rc sum_k f_j(x_k) cos(p theta_k), straight into the residual rows.  The small
+  // variant reuses the samples' LDS: every thread holds its coefficients in registers until all sums are done.
+  double* res = LDSRES ? bl_dyn + kBasisQLds : resG;
+  constexpr int kKeep = LDSRES ? kBasisResLds / NT : 1;
+  double keep[kKeep];
+  if (LDSRES) {
+#pragma unroll
+    for (int it = 0; it < kKeep; ++it) {
+      const int w = tid + it * NT;
+      double s_ = 0.0;
+      if (w < rc * n) {
+        const int p = w / n, j = w - p * n;
+        int m = p;
+        for (int k = 0; k < rc; ++k) {
+          s_ += fnT[(size_t)k * n + j] * ct[m];
+          m += 2 * p;
+          if (m >= 4 * rc) m -= 4 * rc;
+        }
+        s_ *= (p == 0 ? 1.0 : 2.0) / rc;
+      }
+      keep[it] = s_;
     }
-    s_ *= (p == 0 ? 1.0 : 2.0) / rc;
-    coefT[w] = s_;
-    resT[w] = s_;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kKeep; ++it) {
+      const int w = tid + it * NT;
+      if (w < rc * n) res[w] = keep[it];
+    }
+  } else {
+    for (int w = tid; w < rc * n; w += NT) {
+      const int p = w / n, j = w - p * n;
+      double s_ = 0.0;
+      int m = p;
+      for (int k = 0; k < rc; ++k) {
+        s_ += fnT[(size_t)k * n + j] * ct[m];
+        m += 2 * p;
+        if (m >= 4 * rc) m -= 4 * rc;
+      }
+      res[w] = s_ * ((p == 0 ? 1.0 : 2.0) / rc);
+    }
   }
   __syncthreads();
   double fro2 = 0.0;
-  for (int j = tid; j < n; j += kBasisThreads) {
+  for (int j = tid; j < n; j += NT) {
     double s_ = 0.0;
-    for (int p = 0; p < rc; ++p) { const double v = resT[(size_t)p * n + j]; s_ += v * v; }
+    for (int p = 0; p < rc; ++p) { const double v = res[(size_t)p * n + j]; s_ += v * v; }
     nrm2[j] = s_;
     fro2 += s_;
   }
-  fro2 = bl_block_sum(fro2, red);
+  fro2 = bl_block_sum<NT>(fro2, red);
+  __syncthreads();
   const double tol2 = (2e-16 * 2e-16) * fro2;
-  // residual update geometry: thread t = g npow + j handles row j, columns of chunk g (G chunks)
-  int npow = 64;
-  while (npow < n) npow <<= 1;
-  const int G = npow >= kBasisThreads ? 1 : kBasisThreads / npow;
-  const int cchunk = (rc + G - 1) / G;
-  int r = 0;
-  const int rmax = rc < n ? rc : n;
+  stamp();
+  double* U = Uout + (size_t)job * kBlMaxR * n;
   bool too_large = false;
-  for (;;) {
-    // pivot: the row with the largest residual (ties -> lowest row)
-    double bv = -1.0;
-    int bi = 0x7fffffff;
-    for (int j = tid; j < n; j += kBasisThreads)
-      if (nrm2[j] > bv) { bv = nrm2[j]; bi = j; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double yv = __shfl_xor(bv, o);
-      const int yi = __shfl_xor(bi, o);
-      if (yv > bv || (yv == bv && yi < bi)) { bv = yv; bi = yi; }
-    }
-    __syncthreads();
-    if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-      double v = red[0];
-      int i = redi[0];
-      for (int w = 1; w < kBasisThreads / 64; ++w)
-        if (red[w] > v || (red[w] == v && redi[w] < i)) { v = red[w]; i = redi[w]; }
-      sh_val = v;
-      sh_idx = i;
-    }
-    __syncthreads();
-    if (!(sh_val > tol2) || r >= rmax) break;
-    if (r >= kBlMaxR) { too_large = true; break; }
-    const int jp = sh_idx;
-    const double inv0 = 1.0 / sqrt(sh_val);
-    if (tid < rc) qv[tid] = resT[(size_t)tid * n + jp] * inv0;
-    __syncthreads();
-    // twice: remove what is left along the previous directions (the residual rows are only orthogonal to them to the
-    // rounding of the ORIGINAL rows, which is not small against a residual of 1e-12)
-    bool noise = false;
-    for (int pass = 0; pass < 2; ++pass) {
-      for (int i = wave; i < r; i += kBasisThreads / 64) {
-        double s_ = 0.0;
-        for (int cidx = lane; cidx < rc; cidx += 64) s_ += Q[(size_t)i * kBlMaxRc + cidx] * qv[cidx];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
-        if (lane == 0) cf[i] = s_;
-      }
-      __syncthreads();
-      double mine = 0.0;
-      if (tid < rc) {
-        mine = qv[tid];
-        for (int i = 0; i < r; ++i) mine -= cf[i] * Q[(size_t)i * kBlMaxRc + tid];
-      }
-      const double nq = bl_block_sum(tid < rc ? mine * mine : 0.0, red);
-      if (pass == 0 && nq < 0.25) noise = true;          // mostly rounding of the rows already covered: nothing left to add
-      if (tid < rc) qv[tid] = mine / sqrt(nq);
-      __syncthreads();
-    }
-    if (noise) break;
-    if (tid < rc) Q[(size_t)r * kBlMaxRc + tid] = qv[tid];
-    // residual rows: res_j -= (res_j . q) q, norms recomputed from the updated rows
-    {
-      const int g = tid / npow, j = tid - g * npow;
-      const int c0 = g * cchunk, c1 = c0 + cchunk < rc ? c0 + cchunk : rc;
-      for (int j2 = j; j2 < n; j2 += (G == 1 ? kBasisThreads : npow)) {     // (G == 1: a thread may own two rows)
-        double s_ = 0.0;
-        if (g < G)
-          for (int cidx = c0; cidx < c1; ++cidx) s_ += resT[(size_t)cidx * n + j2] * qv[cidx];
-        if (G == 1) {
-          double nn = 0.0;
-          for (int cidx = 0; cidx < rc; ++cidx) {
-            const double v = resT[(size_t)cidx * n + j2] - s_ * qv[cidx];
-            resT[(size_t)cidx * n + j2] = v;
-            nn += v * v;
-          }
-          nrm2[j2] = nn;
-        } else {
-          part[tid] = s_;
-        }
-      }
-      if (G > 1) {
-        __syncthreads();
-        double d_ = 0.0, nn = 0.0;
-        if (j < n && g < G) {
-          for (int gg = 0; gg < G; ++gg) d_ += part[gg * npow + j];
-          for (int cidx = c0; cidx < c1; ++cidx) {
-            const double v = resT[(size_t)cidx * n + j] - d_ * qv[cidx];
-            resT[(size_t)cidx * n + j] = v;
-            nn += v * v;
-          }
-        }
-        __syncthreads();
-        part[tid] = nn;
-        __syncthreads();
-        if (g == 0 && j < n) {
-          double t_ = 0.0;
-          for (int gg = 0; gg < G; ++gg) t_ += part[gg * npow + j];
-          nrm2[j] = t_;
-        }
-      }
-    }
-    ++r;
-    __syncthreads();
-  }
+  int r;
+  if (rc <= 64)
+    r = basis_pivot_loop<NT>(n, rc, res, bl_dyn, U, tol2, nrm2, qv, cf, red, redi, too_large, stamp);
+  else
+    r = basis_pivot_loop<NT>(n, rc, res, QG, U, tol2, nrm2, qv, cf, red, redi, too_large, stamp);
   if (too_large || r < 1) {
     if (tid == 0) { inf[0] = 0; inf[1] = r; inf[2] = rc; inf[3] = 0; }
     return;
   }
   __syncthreads();
-  double* U = Uout + (size_t)job * kBlMaxR * n;
-  for (int w = tid; w < r * n; w += kBasisThreads) {
-    const int p = w / n, j = w - p * n;
-    double s_ = 0.0;
-    for (int cidx = 0; cidx < rc; ++cidx) s_ += coefT[(size_t)cidx * n + j] * Q[(size_t)p * kBlMaxRc + cidx];
-    U[w] = s_;
-  }
+  const double* Q = rc <= 64 ? bl_dyn : QG;
   double* Vs = Vsout + (size_t)job * kBlMaxR * kBlMaxRc;
-  for (int w = tid; w < r * rc; w += kBasisThreads) Vs[w] = Q[(size_t)(w / rc) * kBlMaxRc + (w % rc)];
+  for (int w = tid; w < r * rc; w += NT) Vs[w] = Q[w];
   if (tid < r) sigout[(size_t)job * kBlMaxR + tid] = 1.0;
   if (tid == 0) { inf[0] = 1; inf[1] = r; inf[2] = rc; inf[3] = 0; }
+  __syncthreads();
+  stamp();
+  if (dbg && job == 0 && tid == 0) dbg[80] = ndbg;
 }
 
 // Axis tables S[p][i] = sig_p sum_c Vs[p][c] T_c(xi_i) from the Chebyshev series of the bases (three-term recurrence, sum
@@ -945,7 +971,7 @@ static bool basis_intervals(const sbo_ctx* c, double (&ab)[4]) {
 // Enqueues the 2 q basis workgroups and the read-back of their (ok, r, rc) records on `st`; the caller synchronises.
 // Used by bilinear_setup, and ahead of time by sbo_model_set (next to the factorisation, on a second stream) when a grid
 // is already resident.
-int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st) {
+int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big) {
   const ModelConst& mc = c->mc;
   const int n = mc.n, q = mc.q;
   double ab[4];
@@ -993,9 +1019,34 @@ int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st) {
     for (int o = 0; o < q; ++o)
       for (int a = 0; a < 2; ++a) jb.vinv[2 * o + a] = mc.vinv[o][a];
     for (int a = 0; a < 2; ++a) { jb.a[a] = ab[2 * a]; jb.b[a] = ab[2 * a + 1]; }
-    hipLaunchKernelGGL(k_bl_basis, dim3((unsigned)(2 * q)), dim3(kBasisThreads), 0, st, jb, (const double*)c->Xn.p, base + L.work,
-                       L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info));
+    // n <= 128: 256 threads, samples / residual rows in LDS (degree <= 64 assumed: a larger one fails over to the big form)
+    const bool small = !force_big && n <= kBasisResLds / 64;
+    const size_t dyn = sizeof(double) * (kBasisQLds + (small ? kBasisResLds : 0));
+    long long* dbg = nullptr;
+    const bool phases = getenv("SBO_BL_TIMING") != nullptr;
+    if (phases && hipMalloc(&dbg, sizeof(long long) * 81) != hipSuccess) dbg = nullptr;
+    for (int rep = 0; rep < (dbg ? 2 : 1); ++rep) {       // (with SBO_BL_TIMING a second run records the phase stamps of job 0)
+      long long* dg = rep ? dbg : nullptr;
+      if (small) {
+        SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL((k_bl_basis<256, true>), dim3((unsigned)(2 * q)), dim3(256), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg);
+      } else {
+        SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL((k_bl_basis<1024, false>), dim3((unsigned)(2 * q)), dim3(1024), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg);
+      }
+    }
     SBO_HIP(hipGetLastError());
+    if (dbg) {
+      long long h[81];
+      if (hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+        fprintf(stderr, "[k_bl_basis] job 0 phases (us):");
+        for (int i = 1; i < (int)h[80]; ++i) fprintf(stderr, " %.1f", (double)(h[i] - h[i - 1]) / 100.0);
+        fprintf(stderr, "\n");
+      }
+      (void)hipFree(dbg);
+    }
   }
   SBO_HIP(hipMemcpyAsync(c->h_back + 4096, base + L.info, sizeof(int) * 8 * q, hipMemcpyDeviceToHost, st));
   for (int t = 0; t < 4; ++t) c->bl_basis_ab[t] = ab[t];
@@ -1031,17 +1082,23 @@ int bilinear_setup(sbo_ctx* c) {
   const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0, line0 = cs.first / cnt0;
   int rc;
   if (!basis_current(c)) {
-    if ((rc = bilinear_basis_enqueue(c, c->stream))) return rc;
+    if ((rc = bilinear_basis_enqueue(c, c->stream, false))) return rc;
     if (!c->bl_basis_ok) return SBO_OK;
     SBO_HIP(hipStreamSynchronize(c->stream));
   }
-  lap("bases");
   const int* inf = (const int*)(c->h_back + 4096);
+  for (int t = 0; t < 2 * q; ++t)
+    if (inf[4 * t] == 2) {                 // the small form of the basis kernel needs more LDS than it has: the big form
+      if ((rc = bilinear_basis_enqueue(c, c->stream, true))) return rc;
+      SBO_HIP(hipStreamSynchronize(c->stream));
+      break;
+    }
+  lap("bases");
   BlDims dm;
   memset(&dm, 0, sizeof(dm));
   int r0u = 0, r1u = 0, K0 = 0, K1 = 0, Rmax = 0;
   for (int o = 0; o < q; ++o) {
-    if (!inf[8 * o] || !inf[8 * o + 4]) return SBO_OK;            // a basis did not qualify
+    if (inf[8 * o] != 1 || inf[8 * o + 4] != 1) return SBO_OK;    // a basis did not qualify
     dm.r0[o] = inf[8 * o + 1]; dm.rc0[o] = inf[8 * o + 2];
     dm.r1[o] = inf[8 * o + 5]; dm.rc1[o] = inf[8 * o + 6];
     if (dm.r0[o] < 1 || dm.r0[o] > kBlMaxR || dm.r1[o] < 1 || dm.r1[o] > kBlMaxR) return SBO_OK;

@@ -170,7 +170,7 @@ int model_prep(sbo_ctx* c, const double* X_norm);
 int model_append(sbo_ctx* c, const std::vector<double>& kvec /*[q][n]*/, const double* kappa, const double* rho);
 int model_repack(sbo_ctx* c);
 bool bilinear_applicable(const sbo_ctx* c);
-int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st);
+int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big);
 int bilinear_setup(sbo_ctx* c);
 int launch_posterior_bilinear(sbo_ctx* c);
 }  // namespace sbo

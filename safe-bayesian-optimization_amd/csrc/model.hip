@@ -149,6 +149,11 @@ __global__ __launch_bounds__(1024) void k_model_build(int mode, int n, int npad,
 //                  the inverse companion left of and inside the panel (E = L^-1 rides along exactly as in factor_utu);
 //   k_chol_update: rank-kPB update of the trailing matrix (upper triangle) and of the trailing rows of E, tiled 32 x 32.
 constexpr int kPB = 32;
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {      // l: wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 constexpr int kBlockedFrom = 96;   // smallest n factorised by the blocked form (below: one workgroup does everything)
 
 __global__ __launch_bounds__(256) void k_chol_prep(int mode, int n, int npad, int dpad, int d, const double* __restrict__ W,
@@ -202,22 +207,39 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ work, d
     D[r][cc] = (r < kw && cc < kw && cc >= r) ? U[(size_t)(kb + r) * n + kb + cc] : 0.0;
   }
   __syncthreads();
-  for (int j = 0; j < kw; ++j) {                       // U^T U of the diagonal block, all threads in step
-    const double piv = D[j][j];
-    __syncthreads();
-    const double ljj = piv > 0.0 ? sqrt(piv) : 1.0;
-    if (tid == 0) {
-      if (!(piv > 0.0)) bad[o] = 1;
-      D[j][j] = ljj;
+  // U^T U of the diagonal block by ONE wave, a column per lane in registers: no workgroup barrier inside the 32 steps
+  // (the former all-threads loop spent ~30 us per panel in its 96 barriers).  Lane i holds D[k][i], k <= i; row j is
+  // broadcast lane by lane with v_readlane (the loops are fully unrolled, so every lane index is a constant).  Same
+  // operations in the same order per element as the plain loop: bit-identical factors.
+  if (tid < 64) {
+    const int lane = tid;
+    double col[kPB];
+#pragma unroll
+    for (int k = 0; k < kPB; ++k) col[k] = (lane < kPB && k <= lane) ? D[k][lane] : 0.0;
+    bool notpd = false;
+#pragma unroll
+    for (int j = 0; j < kPB; ++j) {
+      if (j < kw) {
+        const double piv = readlane_f64(col[j], j);
+        notpd = notpd || !(piv > 0.0);
+        const double ljj = piv > 0.0 ? sqrt(piv) : 1.0;
+        if (lane > j) col[j] /= ljj;
+        else if (lane == j) col[j] = ljj;
+#pragma unroll
+        for (int k = j + 1; k < kPB; ++k) {
+          const double ujk = readlane_f64(col[j], k);
+          if (lane >= k) col[k] -= ujk * col[j];
+        }
+      }
     }
-    if (tid > j && tid < kw) D[j][tid] /= ljj;
-    __syncthreads();
-    for (int idx = tid; idx < kw * kw; idx += blockDim.x) {
-      const int k = idx / kw, i = idx % kw;
-      if (k > j && i >= k) D[k][i] -= D[j][k] * D[j][i];
+    if (lane < kPB) {
+#pragma unroll
+      for (int k = 0; k < kPB; ++k)
+        if (k <= lane) D[k][lane] = col[k];
     }
-    __syncthreads();
+    if (lane == 0 && notpd) bad[o] = 1;
   }
+  __syncthreads();
   // The factored block goes to a side array, not back into U: the other workgroups of this launch may not have read
   // the unfactored block yet (a late one would factor it twice).  k_chol_finish picks it up from there.
   if (blockIdx.x == 0) {
@@ -537,7 +559,7 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const double* X_no
     // the bases need X_norm only: next to the factorisation, on the second stream
     SBO_HIP(hipEventRecord(c->ev[6], c->stream));
     SBO_HIP(hipStreamWaitEvent(c->stream2, c->ev[6], 0));
-    if ((rc = bilinear_basis_enqueue(c, c->stream2))) return rc;
+    if ((rc = bilinear_basis_enqueue(c, c->stream2, false))) return rc;
     eager_basis = true;
   }
   SBO_HIP(hipMemsetAsync(dalpha, 0, sizeof(double) * (size_t)q * npad, c->stream));
