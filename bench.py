@@ -164,7 +164,7 @@ def timed_iterations(eng, models, dtype, step, steps, warmup, barrier):
     for i in range(warmup):
         eng.set_model(models[i % 2], dtype=dtype, use_invK=use_invK)
         step()
-    t_set, t_sweep, builds, dev = [], [], [], []
+    t_set, t_sweep, builds, dev, k1, kinds = [], [], [], [], [], set()
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -178,20 +178,39 @@ def timed_iterations(eng, models, dtype, step, steps, warmup, barrier):
         t_sweep.append(tc - tb)
         builds.append(p["posterior_setup_ms"])
         dev.append(p["total_ms"])
+        k1.append(p["posterior_ms"])
+        kinds.add(K1_NAMES.get(p["posterior_kernel"], "?"))
     barrier()
     el = time.perf_counter() - t0
     return {"ms_per_step": el * 1e3 / steps, "steps": steps,
             "set_model_ms": float(np.mean(t_set)) * 1e3, "sweep_call_ms": float(np.mean(t_sweep)) * 1e3,
             "table_build_ms": float(np.mean(builds)), "sweep_device_ms": float(np.mean(dev)),
+            "k1_incl_tables_ms": float(np.mean(k1)), "k1_kernels": sorted(kinds), "ms_per_step_min": float(np.min(np.add(t_set, t_sweep))) * 1e3,
+            "ms_per_step_median": float(np.median(np.add(t_set, t_sweep))) * 1e3, "ms_per_step_max": float(np.max(np.add(t_set, t_sweep))) * 1e3,
+            "slow_steps": [(i, round(float(a + b) * 1e3, 3)) for i, (a, b) in enumerate(zip(t_set, t_sweep)) if a + b > 2.0 * np.median(np.add(t_set, t_sweep))],
             "definition": "two data sets alternate; every timed step = set_model (upload + factorisation on the device) + the "
                           "per-(model, grid) K1b table build + one full sweep; wall clock between barriers"}
 
 
-def extra_record(eng, name, kind, steps, barrier):
-    """Resident-model sweep rate + iteration cost of another single-GPU config, same process."""
+def make_configs(name, n=None):
+    """(config, alternate data set of the same config).  Built with a handful of BLAS threads and before any timed region:
+    the BLAS pool's idle workers spin for tens of milliseconds after a call, and on a box whose CPU quota is smaller than
+    its visible cores that gets the timing thread throttled."""
     from safebo_amd import synthetic
-    cfg = synthetic.make_config(name)
-    alt = synthetic.make_config(name, seed=synthetic.SEED0 + 100 + cfg["index"])
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=4)
+    except Exception:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx:
+        cfg = synthetic.make_config(name, n=n)
+        alt = synthetic.make_config(name, n=n, seed=synthetic.SEED0 + 100 + cfg["index"])
+    return cfg, alt
+
+
+def extra_record(eng, cfg, alt, name, kind, steps, barrier):
+    """Resident-model sweep rate + iteration cost of another single-GPU config, same process."""
     count = list(cfg["count"])
     n_total = int(np.prod(count))
     eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=(cfg["dtype"] == "f64"))
@@ -237,8 +256,10 @@ def main():
         from safebo_amd import distributed
         dist = distributed.init_gloo_from_env()   # rendezvous only (gloo over 127.0.0.1)
 
-    cfg = synthetic.make_config(args.config, n=args.n)
+    cfg, alt = make_configs(args.config, n=args.n)
     scattered = cfg["count"] is None                      # config E: explicit list of scattered candidates
+    extras = world == 1 and not args.no_extra and not scattered
+    extra_cfgs = {name: make_configs(name) for name in (("H", "C") if extras and args.config == "B" else ())}
     if scattered:
         per_rank = args.points if args.scaling == "weak" else args.points // world
         n_total = per_rank * world
@@ -318,9 +339,7 @@ def main():
                        "per_gpu_candidates": n_local, "sweep": args.sweep, "collectives": transport, "result": result},
             "roofline": roof,
         }
-        extras = world == 1 and not args.no_extra and not scattered
         if extras:
-            alt = synthetic.make_config(args.config, n=args.n, seed=synthetic.SEED0 + 100 + cfg["index"])
             it = timed_iterations(eng, [alt["ds"], cfg["ds"]], cfg["dtype"], step, max(10, args.steps // 4), 4, barrier)
             it["value"] = n_total / (it["ms_per_step"] * 1e-3)
             it["unit"] = "candidates/s"
@@ -337,7 +356,8 @@ def main():
                                    "value": n_total * 5 / el_t, "unit": "candidates/s", "achieved": rt["algorithmic"]["achieved"],
                                    "frac": rt["algorithmic"]["frac"], "frac_definition": "SURVEY.md 8(d) algorithmic flops / kernel time / peak"}
         if extras and args.config == "B":
-            out["extra"] = [extra_record(eng, "H", "safeopt", 40, barrier), extra_record(eng, "C", "goose", 40, barrier)]
+            out["extra"] = [extra_record(eng, *extra_cfgs["H"], "H", "safeopt", 40, barrier),
+                            extra_record(eng, *extra_cfgs["C"], "C", "goose", 40, barrier)]
         if world == 1 and args.cpu_sample > 0 and not scattered:
             out["cpu_baseline"] = cpu_baseline(cfg, count, args.cpu_sample)
         print(json.dumps(out))

@@ -1,14 +1,17 @@
 #!/bin/bash
-# Round bench + rocprofv3 recipe (run through gpurun from the repo root).  Writes under gpurun_out/.
+# Round bench + rocprofv3 recipe (run through gpurun from the repo root).  Writes under gpurun_out/<tag>/.
+#   bench.json           the default bench line (what the driver runs)
+#   trace/               rocprofv3 --kernel-trace --stats of the same command (resident-model sweeps only: --no-extra)
+#   pmc_fetch|write|sq/  counter passes, each in its own run (no tracing domains next to --pmc)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$1
+CFG=${2:-B}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err && cat $OUT/bench.json &&
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --cpu-sample 0 > $OUT/trace.log 2>&1 &&
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/pmc_fetch.log 2>&1 &&
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/pmc_write.log 2>&1 &&
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/pmc_sq.log 2>&1
+python3 $R/bench.py --config $CFG > $OUT/bench.json 2> $OUT/bench.err && cat $OUT/bench.json &&
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --config $CFG --cpu-sample 0 --no-extra > $OUT/trace.log 2>&1 &&
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --cpu-sample 0 --no-extra > $OUT/pmc_fetch.log 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --cpu-sample 0 --no-extra > $OUT/pmc_write.log 2>&1 &&
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --cpu-sample 0 --no-extra > $OUT/pmc_sq.log 2>&1
 echo "exit $?"
-find $OUT -name "*.csv" | head -30
