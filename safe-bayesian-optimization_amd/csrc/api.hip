@@ -79,6 +79,10 @@ int sbo_init(int device_id, sbo_ctx** out) {
     e = hipEventCreate(&ev);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipEventCreate"); }
   }
+  for (auto& ev : c->ev_join) {
+    e = hipEventCreate(&ev);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipEventCreate"); }
+  }
   if (hipHostMalloc((void**)&c->h_c1, sizeof(unsigned long long) * (1 + 2 * kMaxQ), hipHostMallocDefault) != hipSuccess) {
     delete c;
     return fail(SBO_E_HIP, "hipHostMalloc");
@@ -109,6 +113,8 @@ int sbo_shutdown(sbo_ctx* c) {
                     &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_basis, &c->mwork, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->ev_join)
     if (ev) (void)hipEventDestroy(ev);
   if (c->h_c1) (void)hipHostFree(c->h_c1);
   if (c->h_back) (void)hipHostFree(c->h_back);
@@ -153,6 +159,14 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   }
   if (!strcmp(key, "scan_blocks")) {
     c->scan_blocks = value ? 1 : 0;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "fuse_classify")) {
+    c->fuse_classify = value ? 1 : 0;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "set_overlap")) {
+    c->set_overlap = value ? 1 : 0;
     return SBO_OK;
   }
   if (!strcmp(key, "goose_pairs")) {

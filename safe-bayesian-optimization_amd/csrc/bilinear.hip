@@ -716,6 +716,7 @@ __global__ __launch_bounds__(256) void k_bl_sbf(const BlDims dm, const double* _
 //   phase 2  g0   = [V[1]; V[0]] . [S0; -xn0 S0]  (2 KSm)   gradient sum of axis 0 (the candidate's own xn0 sits in B)
 //   phase 3  g1   = V1x   . S0          (KSm)              gradient sum of axis 1 (xn1 of the line is folded into V1x)
 
+constexpr int kFuseRow = 3 + kMaxQ;     // = kClassifyRow of sets.hip: u* key, |S|, |U|, radius keys
 struct PostCtx {
   double* lds;
   int tid, lane, wave, rb0, cs0, nrb, ncs;
@@ -723,14 +724,34 @@ struct PostCtx {
   unsigned int ucnt0;
   long long nlines;
   bool full;          // the workgroup's 128 x 128 tile lies inside the grid: epilogues skip their bounds tests
+  // fused classification (one-constraint sweeps): the mean epilogue of the constraint's output reads back the variances this
+  // thread stored in the variance phase and writes the S / U bytes; null = off
+  const double* var_rd;
+  uint8_t *S, *U;
+  double bconf;
+  int cS, cU;         // this thread's counts
+  double rmax;        // max ucb over its safe candidates (-1: none; ucb >= lcb >= 0 on S)
 };
 
 // One GEMM phase of k_bpost on the workgroup's 128 x 128 tile: A images / B fragments of `KB` k-blocks per row block /
 // strip, `KS` k-steps run.  PH selects the epilogue: 0 variance, 1 mean, 2 / 3 gradient component of axis 0 / 1.
 // The accumulators belong to the caller: phase 2 does not start from zero but from phase 1's sums scaled by -xn0 of the
 // candidate's column, g0 = V1 . S0 - xn0 (V0 . S0) -- six k-steps instead of twelve for the stacked [V1; V0] operand.
+// S / U bits of one candidate from its stored mean / var: the arithmetic of k_classify (models/SafeOpt.py:37-43, 57-59, 73-77)
+__device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) {
+  const double v = cx.var_rd[g];
+  const double sd = mul_rn(cx.bconf, sqrt_rn(v));
+  const double lcb = sub_rn(m, sd), ucb = add_rn(m, sd);
+  const bool s_ = lcb >= 0.0, u_ = lcb <= 0.0;
+  cx.S[g] = s_;
+  cx.U[g] = u_;
+  cx.cS += s_;
+  cx.cU += u_;
+  if (s_ && ucb > cx.rmax) cx.rmax = ucb;
+}
+
 template <int PH>
-__device__ __forceinline__ void post_phase(const PostCtx& cx, const double* __restrict__ A, const double* __restrict__ B, int KB,
+__device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict__ A, const double* __restrict__ B, int KB,
                                            int KS, double* __restrict__ outp, double c0, double c1, double c2, double& gmax,
                                            d4_t (&acc)[2][8], const double* __restrict__ xn0) {
   const double* Ap = A + (size_t)cx.st_rb * KB * 256 + cx.st_off;
@@ -799,7 +820,32 @@ __device__ __forceinline__ void post_phase(const PostCtx& cx, const double* __re
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const unsigned int line = (unsigned int)(cx.rb0 + 2 * cx.wave + i) * 16u + 4u * t + row_in;
-        double* const rowp = outp + ((size_t)line * cx.ucnt0 + (unsigned int)cx.cs0 * 16u + col_in);
+        const size_t g0 = (size_t)line * cx.ucnt0 + (unsigned int)cx.cs0 * 16u + col_in;
+        double* const rowp = outp + g0;
+        if (PH == 1 && cx.S) {
+          // fused classification: the eight variances of this row first (all loads in flight; the byte stores below may
+          // alias anything as far as the compiler knows), then bounds, S / U bytes and the partial sums
+          double vr[8], mv[8];
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) vr[s2] = cx.var_rd[g0 + s2 * 16];
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            mv[s2] = (c0 + acc[i][s2][t]) * c1 + c2;
+            rowp[s2 * 16] = mv[s2];
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            const double sd = mul_rn(cx.bconf, sqrt_rn(vr[s2]));
+            const double lcb = sub_rn(mv[s2], sd), ucb = add_rn(mv[s2], sd);
+            const bool s_ = lcb >= 0.0, u_ = lcb <= 0.0;
+            cx.S[g0 + s2 * 16] = s_;
+            cx.U[g0 + s2 * 16] = u_;
+            cx.cS += s_;
+            cx.cU += u_;
+            if (s_ && ucb > cx.rmax) cx.rmax = ucb;
+          }
+          continue;
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) {
           const double v = acc[i][s2][t];
@@ -837,7 +883,9 @@ __device__ __forceinline__ void post_phase(const PostCtx& cx, const double* __re
           var = var > 0.0 ? var : 0.0;
           rowp[x0] = var * c1;                                              // :347
         } else if (PH == 1) {
-          rowp[x0] = (c0 + v) * c1 + c2;                                    // :342, :346
+          const double m = (c0 + v) * c1 + c2;                              // :342, :346
+          rowp[x0] = m;
+          if (cx.S) post_classify(cx, (size_t)line * cx.ucnt0 + x0, m);
         } else {
           // component of the gradient of the un-normalised mean (analytic jax.grad(self.mean), SafeOpt.py:68-71)
           double ga = c0 * v;
@@ -854,7 +902,8 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
                                                   size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
                                                   int KSm, int KBm2, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
                                                   double* __restrict__ var_out, double* __restrict__ Lpart,
-                                                  const double* __restrict__ xn0) {
+                                                  const double* __restrict__ xn0, uint8_t* __restrict__ Sfuse, uint8_t* __restrict__ Ufuse,
+                                                  double bconf, unsigned long long* __restrict__ cpart /* [waves of output 1][kFuseRow] */) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
   const int o = blockIdx.z;
   PostCtx cx;
@@ -880,6 +929,13 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
   const double sf2 = mc.sf2[o], ystd = mc.Y_std[o];
   double* const vo = var_out + (size_t)o * cs.n_local;
   double* const mo = mean_out + (size_t)o * cs.n_local;
+  const bool fuse = Sfuse != nullptr && o == 1;          // (offered by the host for one-constraint models only)
+  cx.var_rd = vo;
+  cx.S = fuse ? Sfuse : nullptr;
+  cx.U = Ufuse;
+  cx.bconf = bconf;
+  cx.cS = cx.cU = 0;
+  cx.rmax = -1.0;
   double gmax = 0.0;
   d4_t acc[2][8];
   post_phase<0>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0);
@@ -898,6 +954,27 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
   // the same time, so atomics on the q keys would queue up in L2 as the kernel's tail
   if (cx.lane == 0)
     Lpart[(((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + cx.wave] = gmax;
+  if (fuse) {
+    // per-wave partial row of the classification, merged by k_classify_final: [u* key (none here), |S|, |U|, radius keys]
+    int cS = cx.cS, cU = cx.cU;
+    double rm = cx.rmax;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      cS += __shfl_xor(cS, off);
+      cU += __shfl_xor(cU, off);
+      const double other = __shfl_xor(rm, off);
+      rm = other > rm ? other : rm;
+    }
+    if (cx.lane < kFuseRow) {
+      unsigned long long* row = cpart + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + cx.wave) * kFuseRow;
+      unsigned long long v = 0ull;
+      if (cx.lane == 0) v = ~0ull;
+      else if (cx.lane == 1) v = (unsigned long long)cS;
+      else if (cx.lane == 2) v = (unsigned long long)cU;
+      else if (cx.lane == 4) v = rm >= 0.0 ? ord_key(rm) : 0ull;       // radius key of constraint 1 (slot 3 + c)
+      row[cx.lane] = v;
+    }
+  }
 }
 
 // Lipschitz keys of a K1b launch: Lmax[o] = max of the per-wave partials (values >= 0, so the bit pattern orders them)
@@ -1213,11 +1290,23 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8), gy = (unsigned)((pl.nrb + 7) / 8);
   int rc;
   if ((rc = ensure(c->bl_lpart, sizeof(double) * 4 * (size_t)gx * gy * q))) return rc;
+  // a sweep may ask for the S / U bytes, |S|, |U| and the radius key straight from the mean epilogue of the constraint
+  // (one-constraint models; the masks are allocated by the sweep before it enqueues the posterior)
+  const bool fuse = c->fuse_request && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
+                    c->maskU.bytes >= (size_t)cs.n_local;
+  c->fuse_rows = 0;
+  if (fuse) {
+    c->fuse_rows = 4 * (int)(gx * gy);
+    // (room behind the rows for the partials of the objective pass, see sweep_common_front)
+    if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
+  }
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_bpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream,
                      mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
                      pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
-                     (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */);
+                     (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
+                     fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
+                     (unsigned long long*)c->cpart.p);
   // the K1 stop event rides on this launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
   // the next kernel waits ~6 us for
   hipExtLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, c->ev[1], 0, (const double*)c->bl_lpart.p,

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <hip/hip_ext.h>
 #include "device_common.hpp"
 
 namespace sbo {
@@ -254,6 +255,46 @@ __global__ __launch_bounds__(256) void k_classify_final(const unsigned long long
   if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
 }
 
+// Objective pass of a classification whose S / U bytes came out of the posterior kernel (K1b, one constraint): u* = min over
+// S of ucb_0, one partial row per workgroup behind the posterior's rows (mask-driven loop as k_minimizer)
+__device__ __forceinline__ bool tile_byte(unsigned long long w, int k, int lane);
+template <typename T>
+__global__ __launch_bounds__(256) void k_classify_obj(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b,
+                                                      const uint8_t* __restrict__ S, unsigned long long* __restrict__ part) {
+  unsigned long long umin = ~0ull;
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long ntiles = (((uintptr_t)S) & 7) == 0 ? n / 512 : 0;
+  auto take = [&](T m, T v) {
+    T lcb, ucb;
+    lcb_ucb(m, v, b, lcb, ucb);
+    const unsigned long long k = ord_key((double)ucb);
+    umin = k < umin ? k : umin;
+  };
+  for (long long t = wave; t < ntiles; t += nwaves) {
+    const long long base = t * 512;
+    const unsigned long long w = ((const unsigned long long*)(S + base))[lane];
+    if (__ballot(w != 0ull) == 0ull) continue;
+    T mu[8], va[8];
+    bool set[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      set[k] = tile_byte(w, k, lane);
+      const long long g = base + k * 64 + lane;
+      mu[k] = set[k] ? mean0[g] : (T)0;
+      va[k] = set[k] ? var0[g] : (T)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (set[k]) take(mu[k], va[k]);
+  }
+  for (long long g = ntiles * 512 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x)
+    if (S[g]) take(mean0[g], var0[g]);
+  umin = block_ext_u64<false>(umin);
+  unsigned long long* row = part + (size_t)blockIdx.x * kClassifyRow;
+  if (threadIdx.x < kClassifyRow) row[threadIdx.x] = threadIdx.x == 0 ? umin : 0ull;
+}
+
 // Mask-driven loops of K3b / K5.  A wave takes tiles of 512 consecutive candidates: every lane reads eight mask bytes
 // as one word, tiles without a set byte cost nothing more, and for the others the value loads (eight per lane, coalesced
 // across the wave, predicated on the candidate's own byte fetched by a shuffle) are all issued before the first
@@ -466,8 +507,25 @@ static int reduce_blocks(const sbo_ctx* c) {
   return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));   // (per-block reduction tails cost more than extra grid-stride turns: x4 measured best)
 }
 
-template <typename T>
-static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o) {
+// The set phase of a single-rank grid sweep forks after the classification: the side stream takes the merge of the
+// classification partials, the minimiser branch and the coarse transforms (small, latency-bound launches), the main
+// stream the fine transform; they meet again before the verdict kernel.  The fork event rides on k_classify as its stop
+// event and the join events on the last coarse launch of each constraint (a separate event record costs the stream a
+// ~6 us bubble).
+static bool set_phase_forks(const sbo_ctx* c) {
+  if (!c->set_overlap || multi_rank(c) || c->phase_events || c->mc.q < 2 || c->cs.kind != 1 || c->cs.d < 2) return false;
+  const long long n = c->cs.n_local;
+  long long plane = 1;
+  for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
+  if (n < (1ll << 16) || c->cs.first % plane != 0 || n % plane != 0) return false;
+  for (int a = 0; a < c->cs.d; ++a)
+    if ((a == c->cs.d - 1 ? n / plane : c->cs.count[a]) < 4 * kCoarse) return false;      // (the coarse transform's own condition)
+  return true;
+}
+
+// mask buffers of a sweep; called before the posterior is enqueued (K1b may write S / U itself) -- `b` is the sweep's
+// confidence multiplier, handed to the posterior with the request to classify
+static int sweep_masks(sbo_ctx* c, double b, bool may_fuse) {
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
@@ -478,12 +536,43 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o) {
   if ((rc = ensure(c->maskU, (size_t)npad_shard))) return rc;
   if ((rc = ensure(c->maskM, (size_t)n))) return rc;
   if ((rc = ensure(c->maskG, (size_t)n * std::max(1, q - 1)))) return rc;
+  c->fuse_request = may_fuse && c->fuse_classify && q == 2;
+  c->fuse_b = b;
+  c->fuse_rows = 0;
+  return SBO_OK;
+}
+
+template <typename T>
+static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, bool fork = false) {
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q;
+  int rc;
   if ((rc = ensure(c->scal, sizeof(SweepScalars)))) return rc;
   const int nb = reduce_blocks(c);
   if ((rc = ensure(c->partial, (sizeof(Best) + sizeof(long long)) * (size_t)nb))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int ncb = std::max(1, c->n_cu * 4);   // four workgroups per CU measured best (2: 24.6 us, 4: 21.5, 8: 27.1 on config B)
   if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kClassifyRow * (size_t)ncb))) return rc;
+  if (c->fuse_rows > 0 && n > 0) {
+    // S / U bytes, |S|, |U| and the radius key came out of the posterior kernel: only u* is left, over the safe candidates
+    const int nob = std::max(1, c->n_cu * 4);
+    unsigned long long* rows = (unsigned long long*)c->cpart.p;
+    hipLaunchKernelGGL(k_classify_obj<T>, dim3((unsigned)nob), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b,
+                       (const uint8_t*)c->maskS.p, rows + (size_t)c->fuse_rows * kClassifyRow);
+    hipLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)rows, c->fuse_rows + nob, q, sc);
+    c->amb_clean = true;
+    SBO_HIP(hipGetLastError());
+    return SBO_OK;
+  }
+  if (fork) {
+    hipExtLaunchKernelGGL(k_classify<T>, dim3((unsigned)ncb), dim3(256), 0, c->stream, nullptr, c->ev[7], 0, (const T*)c->mean.p,
+                          (const T*)c->var.p, n, q, (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
+    SBO_HIP(hipStreamWaitEvent(c->stream2, c->ev[7], 0));
+    hipLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream2, (const unsigned long long*)c->cpart.p, ncb, q, sc);
+    c->amb_clean = true;
+    SBO_HIP(hipGetLastError());
+    return SBO_OK;
+  }
   if (n > 0)
     hipLaunchKernelGGL(k_classify<T>, dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
                        (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
@@ -526,16 +615,17 @@ static int launch_exact_d(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lid
 static int sweep_exchange_wait(sbo_ctx* c);
 
 // G_c for constraint cidx (1..q-1) into G[n]
-static void launch_edt_axis0(sbo_ctx* c, const uint8_t* U, long long nlines, int count0, double h0, double* D) {
+static void launch_edt_axis0(sbo_ctx* c, const uint8_t* U, long long nlines, int count0, double h0, double* D, hipStream_t st = nullptr) {
+  if (!st) st = c->stream;
   if (count0 <= kAxis0Max && count0 >= 128)
-    hipLaunchKernelGGL(k_edt_axis0_wg<false>, dim3((unsigned)std::min<long long>(nlines, 1 << 20)), dim3(256), 0, c->stream, U, nlines,
+    hipLaunchKernelGGL(k_edt_axis0_wg<false>, dim3((unsigned)std::min<long long>(nlines, 1 << 20)), dim3(256), 0, st, U, nlines,
                        count0, h0, D, CoarseGrid{});
   else
-    hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, c->stream, U, nlines, count0, h0, D);
+    hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, st, U, nlines, count0, h0, D);
 }
 
 template <typename T>
-static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* G) {
+static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* G, bool fork = false) {
   const long long n = c->cs.n_local;
   if (n == 0) return SBO_OK;
   const int q = c->mc.q;
@@ -608,36 +698,45 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       h2 += c->cs.step[a] * c->cs.step[a];
       if (cg.count[a] < 4 * kCoarse) coarse_ok = false;
     }
+    hipStream_t cst = fork ? c->stream2 : c->stream;          // the coarse transform's stream
     if (coarse_ok) {
       cg.enabled = 1;
       cg.delta = (kCoarse - 1) * std::sqrt(h2) * (1.0 + 1e-9);
-      if ((rc = ensure(c->coarse, (size_t)nc * (1 + 2 * sizeof(double)) + 64))) return rc;
-      double* dc0 = (double*)c->coarse.p;
+      // (forked: every constraint has its own coarse arrays -- the side stream runs ahead of the verdict kernels that read them)
+      const size_t cbytes = ((size_t)nc * (1 + 2 * sizeof(double)) + 64 + 255) / 256 * 256;
+      if ((rc = ensure(c->coarse, cbytes * (fork ? std::max(1, q - 1) : 1)))) return rc;
+      double* dc0 = (double*)((char*)c->coarse.p + (fork ? cbytes * (size_t)(cidx - 1) : 0));
       double* dc1 = dc0 + nc;
       uint8_t* Uc = (uint8_t*)(dc1 + nc);
       const int cc0 = (int)cg.ccount[0];
       const long long clines = nc / cc0;
       if (cc0 <= kAxis0Max && cc0 >= 128) {
         // the coarse axis-0 pass forms the cells' bits from the fine mask itself
-        hipLaunchKernelGGL(k_edt_axis0_wg<true>, dim3((unsigned)std::min<long long>(clines, 1 << 20)), dim3(256), 0, c->stream, Uall,
+        hipLaunchKernelGGL(k_edt_axis0_wg<true>, dim3((unsigned)std::min<long long>(clines, 1 << 20)), dim3(256), 0, cst, Uall,
                            clines, cc0, c->cs.step[0] * kCoarse, dc0, cg);
       } else {
-        hipLaunchKernelGGL(k_coarsen_mask, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_coarsen_mask, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, cst,
                            Uall, cg, nc, Uc);
-        launch_edt_axis0(c, (const uint8_t*)Uc, clines, cc0, c->cs.step[0] * kCoarse, dc0);
+        launch_edt_axis0(c, (const uint8_t*)Uc, clines, cc0, c->cs.step[0] * kCoarse, dc0, cst);
       }
       long long cstride = cc0;
       double hmax = 0.0;
       for (int a = 0; a < d; ++a) hmax = std::max(hmax, c->cs.step[a]);
       const double cap_extra = 2.0 * cg.delta + 2.0 * kCoarse * hmax;
       for (int a = 1; a < d; ++a) {
-        hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
-                           (const double*)dc0, dc1, nc, cstride, (int)cg.ccount[a], c->cs.step[a] * kCoarse,
-                           (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, 0, cap_extra);
+        // (forked: the last coarse launch of this constraint carries the join event)
+        hipExtLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, cst, nullptr,
+                              (fork && a == d - 1) ? c->ev_join[cidx] : nullptr, 0, (const double*)dc0, dc1, nc, cstride,
+                              (int)cg.ccount[a], c->cs.step[a] * kCoarse, (const SweepScalars*)sc, cidx,
+                              (const unsigned long long*)c->Lmax.p, lidx, 0, cap_extra);
         std::swap(dc0, dc1);
         cstride *= cg.ccount[a];
       }
       cg.Dc = dc0;
+    }
+    if (fork) {
+      if (!coarse_ok) return fail(SBO_E_HIP, "internal: forked set phase without a coarse transform");
+      SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_join[cidx], 0));      // (placed before the verdict kernel below)
     }
     double xscale = 0.0;
     for (int a = 0; a < d; ++a) xscale = std::max(xscale, std::max(std::fabs(c->cs.lo[a]), std::fabs(c->cs.hi[a])));
@@ -832,10 +931,13 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   int rc;
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
+  if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
+  c->fuse_request = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
-  if ((rc = sweep_common_front<T>(c, o))) return rc;
+  const bool fork = set_phase_forks(c);
+  if ((rc = sweep_common_front<T>(c, o, fork))) return rc;
   if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
@@ -844,12 +946,12 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   if ((rc = ensure(c->partial, pstride * (size_t)q))) return rc;
   unsigned char* pbase = (unsigned char*)c->partial.p;
   if (n > 0)
-    hipLaunchKernelGGL((k_minimizer<T>), dim3(nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n,
+    hipLaunchKernelGGL((k_minimizer<T>), dim3(nb), dim3(256), 0, fork ? c->stream2 : c->stream, (const T*)c->mean.p, (const T*)c->var.p, n,
                        (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, sc, (Best*)pbase);
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
   for (int cc = 1; cc < q; ++cc) {
     uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
-    if ((rc = expander_set<T>(c, o, cc, G))) return rc;
+    if ((rc = expander_set<T>(c, o, cc, G, fork))) return rc;
   }
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   for (int cc = 1; cc < q; ++cc) {
@@ -1192,7 +1294,9 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   int rc;
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
+  if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
+  c->fuse_request = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
   if ((rc = sweep_common_front<T>(c, o))) return rc;
@@ -1336,7 +1440,9 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
   int rc;
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
+  if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
+  c->fuse_request = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
   if ((rc = sweep_common_front<T>(c, o))) return rc;

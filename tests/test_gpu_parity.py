@@ -776,6 +776,46 @@ def test_goose_transform_equals_pair_evaluation_with_coarse_bounds(engine, cfg_n
             assert bool(O[hidx]) == want, (c, int(hidx))
 
 
+@pytest.mark.parametrize("cfg_name,n,count", [("B", 128, [320, 300]), ("A", 64, [130, 70]), ("H", 300, [200, 144])])
+def test_fused_classification_equals_the_separate_pass(engine, cfg_name, n, count):
+    """One-constraint sweeps on the GEMM posterior take S / U, |S|, |U| and the radius key from the posterior kernel's mean
+    epilogue (option fuse_classify; ragged tiles included: 130 x 70, 200 x 144): every mask, count and index must
+    equal the separate classification pass, for the SafeOpt, GoOSE and trust-region sweeps."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    out = {}
+    try:
+        for fuse in (1, 0):
+            engine.set_option("fuse_classify", fuse)
+            engine.set_model(cfg["ds"])
+            engine.set_grid(lo, hi, count)
+            s_ = engine.sweep_safeopt(cfg["b"], want_masks=True)
+            assert engine.profile()["posterior_kernel"] == 4
+            masks = {k: engine.mask(k) for k in ("S", "U", "M")}
+            masks["G"] = engine.mask("G", 1)
+            engine.set_model(cfg["ds"])                       # a fresh posterior for each sweep kind: the fused path again
+            g_ = engine.sweep_goose(cfg["b"], want_masks=True)
+            masks["O"] = engine.mask("O", 1)
+            masks["S_g"], masks["U_g"] = engine.mask("S"), engine.mask("U")
+            engine.set_model(cfg["ds"])
+            t_ = engine.sweep_tr(cfg["b"], s_["minimizer_x"], 0.5)
+            out[fuse] = (s_, g_, t_, masks)
+    finally:
+        engine.set_option("fuse_classify", 0)
+    for k, v in out[1][3].items():
+        assert np.array_equal(v, out[0][3][k]), k
+    assert out[1][3]["S"].any() and out[1][3]["U"].any()
+    for which in (0, 1, 2):
+        a, b_ = out[1][which], out[0][which]
+        for k in a:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b_[k])), (which, k)
+    # and against the oracle where it is affordable
+    if count[0] * count[1] <= 20000:
+        ref = oracle.safeopt_sweep(oracle.grid_points(lo, hi, count), cfg["ds"], cfg["b"])
+        assert np.array_equal(out[1][3]["S"], ref["S"]) and np.array_equal(out[1][3]["G"], ref["G"][0])
+        assert out[1][0]["u_star"] == pytest.approx(ref["u_star"], rel=1e-10) and out[1][0]["count_U"] == int(ref["U"].sum())
+
+
 def test_repeated_sweeps_on_a_resident_posterior_are_idempotent(engine):
     """The host classes call several sweeps per iteration on one posterior (`posterior_ready=True`): SafeOpt, GoOSE
     (whose explore step parks its target next to the sweep scalars) and the trust-region step, in any order, must

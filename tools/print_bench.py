@@ -1,0 +1,13 @@
+"""Print the headline fields of bench.py JSON lines: python tools/print_bench.py file.json [...]"""
+import json, sys
+for f in sys.argv[1:]:
+    d = json.load(open(f))
+    r = d["roofline"]
+    line = f"{f}: value {d['value']:.4e} ms/step {d['ms_per_step']:.4f} K1 {r['kernel_ms']:.4f} device {r['device_ms_per_step']:.4f} set {r['hbm']['set_phase_ms']:.4f} frac {r['frac']:.3f} hbm {r['hbm']['frac']:.3f}"
+    if "iteration" in d:
+        it = d["iteration"]
+        line += f" | iteration {it['ms_per_step']:.3f} ms (set_model {it['set_model_ms']:.3f}, sweep {it['sweep_call_ms']:.3f}) slow {it.get('slow_steps')}"
+    print(line)
+    for e in d.get("extra", []):
+        it = e["iteration"]
+        print(f"   {e['config'][:28]}: value {e['value']:.4e} ms {e['ms_per_step']:.4f} frac {e['roofline']['frac']:.3f} hbm {e['roofline_hbm']['frac']:.3f} set {e['roofline_hbm']['set_phase_ms']:.3f} | iteration {it['ms_per_step']:.3f} ms (set_model {it['set_model_ms']:.3f}, sweep {it['sweep_call_ms']:.3f})")
