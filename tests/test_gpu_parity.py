@@ -462,24 +462,43 @@ def test_sweeps_on_grids_of_any_dimension(engine, d, count, n, off, ll, b):
     assert t["index"] == tref["index"] and t["count_T"] == int(tref["T"].sum())
 
 
-def test_fp32_sweep_masks_follow_the_fp32_posterior(engine):
-    """dtype f32: the classification runs in fp32 on the fp32 posterior; given those mean/var values the masks and the
-    acquisition are bit-exact functions of them (the oracle evaluates the same expressions in numpy float32)."""
+def test_fp32_sweep_masks_against_the_fp64_oracle(engine):
+    """dtype f32: the classification runs in fp32 on the fp32 posterior.  There is NO fp64 recheck band (SURVEY.md section 7
+    hard part 2 is not built), so the fp32 masks are the reference's fp64 masks only outside the band the fp32 posterior error
+    can move a deciding bound across its threshold.  This test pins exactly that, against the fp64 oracle: (1) the posterior
+    is within 1e-4; (2) every S / U / M difference from the fp64 oracle lies inside the band |bound - threshold| <= tau with
+    tau = 4 x the measured posterior difference (counted and bounded: a few candidates in 7680); (3) given the fp32 mean / var
+    the masks and the acquisition are exact functions of them (the oracle evaluates the same expressions in numpy float32)."""
     cfg = synthetic.make_config("B", n=128)
     lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [96, 80]
     pts = oracle.grid_points(lo, hi, count)
     engine.set_model(cfg["ds"], dtype="f32", use_invK=False)
     engine.set_grid(lo, hi, count)
     mean, var = _check_posterior(engine, cfg["ds"], pts, TOL32, dtype="f32")
-    ref = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"], mean_var=(mean, var))
     res = engine.sweep_safeopt(cfg["b"], want_masks=True, posterior_ready=True)
+    got = {k: engine.mask(k) for k in ("S", "U", "M")}
+    # (2) against the fp64 oracle
+    ref64 = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"])
+    b = cfg["b"]
+    dl = np.abs(mean.astype(np.float64) - ref64["mean"]) + b * np.abs(np.sqrt(var.astype(np.float64)) - np.sqrt(ref64["var"]))
+    tau = 4.0 * dl.max(axis=0)                                   # per output, raw units
+    near_S = np.abs(ref64["lcb"][:, 1]) <= tau[1]
+    near_M = near_S | (np.abs(ref64["lcb"][:, 0] - ref64["u_star"]) <= 2.0 * tau[0])
+    for k, near in (("S", near_S), ("U", near_S), ("M", near_M)):
+        diff = got[k] != ref64[k]
+        assert not (diff & ~near).any(), (k, int((diff & ~near).sum()))
+        assert diff.sum() <= 0.005 * pts.shape[0], (k, int(diff.sum()))
+    assert abs(res["u_star"] - ref64["u_star"]) <= 2.0 * tau[0]
+    # (3) exact functions of the fp32 posterior
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"], mean_var=(mean, var))
     for k in ("S", "U", "M"):
-        assert np.array_equal(engine.mask(k), ref[k]), k
+        assert np.array_equal(got[k], ref[k]), k
     assert res["minimizer_index"] == ref["minimizer_index"]
     assert res["u_star"] == float(ref["u_star"])
     # the expander set also depends on L (fp32 gradient on the device, fp64 in the oracle): compare away from ties
     G, Gref = engine.mask("G", 1), ref["G"][0]
     assert not (G & ~ref["S"]).any() and (G != Gref).sum() <= 2e-3 * max(1, Gref.sum())
+    assert (G != ref64["G"][0]).sum() <= 0.01 * max(1, ref64["G"][0].sum())
 
 
 def test_no_unsafe_witness_means_no_expander(engine):
