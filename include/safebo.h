@@ -246,7 +246,10 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  * fp64 2-D grids run the posterior as two GEMMs in a reduced basis when that is cheaper; 0: always the separable-table
  * kernel), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
  * "scan_waves" (1 default: open candidates of the expander query are scanned by half-waves), "goose_pairs" (1: pair
- * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile), "comm_selftest" (1: a one-rank world created
+ * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile), "bl_host_bases" (1: the axis bases of the GEMM posterior by
+ * the host SVD of bilinear_host.hpp instead of the device kernel), "fuse_classify" (1: one-constraint sweeps take S / U from
+ * the posterior kernel's epilogue) and "set_overlap" (1: small set-phase launches on a side stream) -- both measured no faster,
+ * default 0 --, "comm_selftest" (1: a one-rank world created
  * with sbo_comm_init(ctx, 1, 0, id) sends the collectives C1 / C2 / C3 through its RCCL communicator instead of skipping
  * them -- the sweep results must not change) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
