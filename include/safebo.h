@@ -146,6 +146,9 @@ typedef struct sbo_profile {
   int32_t posterior_kernel;      /* which K1 ran last: 1 generic, 2 generic chunked, 3 separable tables (K1g), 4 bilinear GEMMs (K1b) */
   double posterior_executed_flops; /* matrix-core flops the last K1 launch(es) actually issued (K1b: far below the algorithmic count) */
   double posterior_setup_ms;     /* host time of the last per-(model, grid) table build of K1b, 0 when none was needed        */
+  int64_t fp64_rechecks;         /* dtype SBO_F32 SafeOpt sweeps: candidates whose fp32 bounds could not decide S / U / u* / M / the
+                                    minimiser and were re-evaluated in fp64 (option "fp64_recheck"); 0 otherwise                  */
+  double recheck_ms;             /* device time of that step (band reductions, flagging, fp64 posterior of the list, scatter)    */
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */
@@ -249,7 +252,9 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile), "bl_host_bases" (1: the axis bases of the GEMM posterior by
  * the host SVD of bilinear_host.hpp instead of the device kernel), "fuse_classify" (1: one-constraint sweeps take S / U from
  * the posterior kernel's epilogue) and "set_overlap" (1: small set-phase launches on a side stream) -- both measured no faster,
- * default 0 --, "comm_selftest" (1: a one-rank world created
+ * default 0 --, "fp64_recheck" (1 default: dtype SBO_F32 single-rank SafeOpt sweeps re-evaluate in fp64 every
+ * candidate whose fp32 posterior -- within its 1e-4 contract -- cannot decide S, U, u*, M or the minimiser, so that those
+ * equal the fp64 result; 0: masks are functions of the fp32 posterior alone), "comm_selftest" (1: a one-rank world created
  * with sbo_comm_init(ctx, 1, 0, id) sends the collectives C1 / C2 / C3 through its RCCL communicator instead of skipping
  * them -- the sweep results must not change) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);

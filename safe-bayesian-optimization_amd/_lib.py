@@ -67,6 +67,7 @@ class Profile(C.Structure):
         ("argreduce_ms", C.c_double), ("comm_ms", C.c_double), ("total_ms", C.c_double),
         ("posterior_flops", C.c_double), ("candidates", C.c_int64), ("posterior_launches", C.c_int32),
         ("posterior_kernel", C.c_int32), ("posterior_executed_flops", C.c_double), ("posterior_setup_ms", C.c_double),
+        ("fp64_rechecks", C.c_int64), ("recheck_ms", C.c_double),
     ]
 
 

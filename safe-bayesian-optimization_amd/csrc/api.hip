@@ -104,13 +104,42 @@ int sbo_init(int device_id, sbo_ctx** out) {
 
 int sbo_comm_destroy_internal(sbo_ctx* ctx);
 
+// fp64 twin of an fp32 model: a context of its own (model arrays, candidate list, posterior buffers) on the owner's streams
+static int shadow_ensure(sbo_ctx* c) {
+  if (c->shadow) return SBO_OK;
+  sbo_ctx* s = new sbo_ctx();
+  s->is_shadow = true;
+  s->device = c->device;
+  s->n_cu = c->n_cu;
+  s->stream = c->stream;
+  s->stream2 = c->stream2;
+  for (int i = 0; i < 8; ++i) s->ev[i] = c->ev[i];
+  s->h_back = c->h_back;
+  s->fp64_recheck = 0;
+  s->bilinear = 0;
+  int rc = ensure(s->scal, 4096);
+  if (rc) { delete s; return rc; }
+  s->Lmax.p = (char*)s->scal.p + 3072;
+  s->Lmax.bytes = 512;
+  c->shadow = s;
+  return SBO_OK;
+}
+
 int sbo_shutdown(sbo_ctx* c) {
   if (!c) return SBO_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->shadow) {
+    sbo_ctx* s = c->shadow;
+    for (DevBuf* b : {&s->Fpk, &s->As, &s->sqA, &s->alpha, &s->Xn, &s->pts, &s->mean, &s->var, &s->scal, &s->mwork, &s->Fplain, &s->alpha64})
+      release(*b);
+    if (s->h_stage) (void)hipHostFree(s->h_stage);
+    delete s;
+    c->shadow = nullptr;
+  }
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_basis, &c->mwork, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Ufull, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -180,6 +209,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->posterior_valid = false;
     return SBO_OK;
   }
+  if (!strcmp(key, "fp64_recheck")) {
+    c->fp64_recheck = value ? 1 : 0;       // (takes effect at the next sbo_model_set: the fp64 twin is built there)
+    return SBO_OK;
+  }
   if (!strcmp(key, "comm_selftest")) {
     if (value && !c->comm && !c->relay_allreduce)
       return fail(SBO_E_INVALID, "comm_selftest needs a communicator: call sbo_comm_init(ctx, 1, 0, id) with a unique id first");
@@ -238,6 +271,19 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
   // derived arrays (As, sqA, Xn, rhs), factorisation, alpha and the fragment images of the factor: on the device (model.hip)
   int rc = model_build(c, invK, X_norm, Y_norm);
   if (rc) return rc;
+  if (dtype == SBO_F32 && c->fp64_recheck && !c->is_shadow) {
+    // the fp64 twin: same constants, double arrays and factor images (built from the same inputs)
+    if ((rc = shadow_ensure(c))) return rc;
+    sbo_ctx* s = c->shadow;
+    s->mc = c->mc;
+    s->dtype = SBO_F64;
+    s->has_model = false;
+    s->posterior_valid = false;
+    s->h_Xnorm = c->h_Xnorm;
+    ++s->model_serial;
+    if ((rc = model_build(s, invK, X_norm, Y_norm))) return rc;
+    s->has_model = true;
+  }
   c->has_model = true;
   return SBO_OK;
 }
@@ -279,6 +325,7 @@ int sbo_model_append(sbo_ctx* c, const double* x_norm_new, const double* y_norm_
   if ((rc = model_prep(c, c->h_Xnorm.data()))) return rc;
   if ((rc = model_repack(c))) return rc;
   ++c->model_serial;
+  if (c->shadow && c->shadow->has_model && (rc = sbo_model_append(c->shadow, x_norm_new, y_norm_new))) return rc;
   c->posterior_valid = false;
   c->masks_valid = false;
   c->bl.valid = false;

@@ -152,6 +152,13 @@ struct sbo_ctx {
   int phase_events = 0;    // 1: events between the set phases too (classify / expander / arg-reduce times in sbo_profile)
   int bilinear = 1;        // 1: fp64 2-D grids run the posterior as two GEMMs in a reduced basis when the bases qualify (K1b)
   int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
+  // fp32 models: an fp64 twin of the model (same arrays, double images) that re-evaluates the candidates the fp32 bounds
+  // cannot decide (option fp64_recheck); it shares this context's streams and pinned areas and holds explicit lists only
+  sbo_ctx* shadow = nullptr;
+  bool is_shadow = false;
+  int fp64_recheck = 1;
+  sbo::DevBuf rc_mean, rc_var;   // double [q][n_local]: the fp32 posterior widened, flagged entries replaced by fp64 values
+  sbo::DevBuf rc_list;           // flagged candidate indices (long long) + counters
   // comm
   void* comm = nullptr;  // ncclComm_t
   int world = 1, rank = 0;

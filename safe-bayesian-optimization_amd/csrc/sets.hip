@@ -1027,6 +1027,8 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   return SBO_OK;
 }
 
+#include "sets_recheck.inc.hpp"
+
 template <typename T, int D>
 static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8_t* src, uint8_t* O) {
   const long long n = c->cs.n_local;
@@ -1514,6 +1516,8 @@ int sbo_sweep_safeopt(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_safeopt_result
   if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
   SBO_HIP(hipSetDevice(c->device));
+  if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model && !multi_rank(c))
+    return sweep_safeopt_f32_recheck(c, opts, result);
   return c->dtype == SBO_F64 ? sweep_safeopt_t<double>(c, opts, result) : sweep_safeopt_t<float>(c, opts, result);
 }
 
