@@ -158,7 +158,9 @@ struct sbo_ctx {
   bool is_shadow = false;
   int fp64_recheck = 1;
   sbo::DevBuf rc_mean, rc_var;   // double [q][n_local]: the fp32 posterior widened, flagged entries replaced by fp64 values
-  sbo::DevBuf rc_list;           // flagged candidate indices (long long) + counters
+  sbo::DevBuf rc_list;           // flagged candidate indices (long long) + counters (64-byte head)
+  sbo::DevBuf rc_refined;        // uint8 [n_local]: this candidate's entries of rc_mean / rc_var are fp64 values
+  bool rc_active = false;        // the running set phase works on a partly refined fp32 posterior (verdicts carry bands)
   // comm
   void* comm = nullptr;  // ncclComm_t
   int world = 1, rank = 0;

@@ -759,11 +759,21 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       }
       const long long len0 = d >= 2 ? count0 : n;               // positions per line / local lines
       const long long nl = n / len0;
+      RcExp rx;                                                  // fp32 model with fp64 recheck: unrefined entries carry a band
+      memset(&rx, 0, sizeof(rx));
+      if (c->rc_active) {
+        rx.refined = (const uint8_t*)c->rc_refined.p;
+        const double ys = std::max(1.0, c->mc.Y_std[cidx]);
+        rx.dm = 1e-4 * ys;
+        rx.dv = 1e-4 * ys * ys;
+        rx.list = (long long*)((char*)c->rc_list.p + kRcList);
+        rx.count = (unsigned long long*)((char*)c->rc_list.p + kRcCount2);
+      }
       const dim3 dgrid((unsigned)((len0 + 255) / 256), (unsigned)std::min<long long>((nl + kDecideLines - 1) / kDecideLines, 65535));
 #define SBO_DECIDE(LIST)                                                                                                            \
   hipLaunchKernelGGL((k_edt_decide<T, LIST>), dgrid, dim3(256), 0, c->stream, (const double*)din, nl, (int)len0, goff / len0, goff, \
                      d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c, (T)o->b, (const uint8_t*)c->maskS.p,          \
-                     (const unsigned long long*)c->Lmax.p, lidx, sc, G, (long long*)c->amb.p, cg, bmin, blk, slist)
+                     (const unsigned long long*)c->Lmax.p, lidx, sc, G, (long long*)c->amb.p, cg, bmin, blk, slist, rx)
       if (slist) SBO_DECIDE(true);
       else SBO_DECIDE(false);
 #undef SBO_DECIDE
@@ -774,7 +784,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
 #define SBO_SCAN_LIST(GL)                                                                                                       \
   hipLaunchKernelGGL((k_edt_scan_list<T, GL>), dim3(2048), dim3(256), 0, c->stream, (const double*)din, goff, stride, last_cnt, \
                      last_h, d, xscale, mean_c, var_c, (T)o->b, (const unsigned long long*)c->Lmax.p, lidx, sc, G,              \
-                     (long long*)c->amb.p, bmin, blk, (const long long*)slist)
+                     (long long*)c->amb.p, bmin, blk, (const long long*)slist, rx)
         switch (gl) {
           case 8: SBO_SCAN_LIST(8); break;
           case 32: SBO_SCAN_LIST(32); break;

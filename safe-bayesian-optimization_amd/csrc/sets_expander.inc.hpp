@@ -353,6 +353,24 @@ __device__ __forceinline__ bool lipschitz_pair(const double (&xg)[D], const doub
   return __dsub_rn(ucb, __dmul_rn(L, dist)) >= 0.0;
 }
 
+// fp32 models with fp64 recheck (sets_recheck.inc.hpp): the verdict kernels see a posterior whose UNREFINED entries are
+// fp32 values, good to +- (dm, dv).  For those the ucb is an interval of half-width du; a verdict the interval cannot
+// settle sends the candidate to the refinement list instead of deciding it.  refined == nullptr: every value is exact.
+constexpr size_t kRcCount2 = 32, kRcGKeys = 64, kRcList = 256;   // layout of sbo_ctx::rc_list: counters, G keys, the list
+struct RcExp {
+  const uint8_t* refined;
+  double dm, dv;
+  long long* list;                 // candidates to re-evaluate in fp64
+  unsigned long long* count;
+};
+__device__ __forceinline__ double rc_du(const RcExp& rx, long long g, double var, double b) {
+  if (!rx.refined || rx.refined[g]) return 0.0;
+  return rx.dm + b * (sqrt(var + rx.dv) - sqrt(fmax(0.0, var - rx.dv)));
+}
+__device__ __forceinline__ void rc_defer(const RcExp& rx, long long g) {
+  rx.list[atomicAdd(rx.count, 1ull)] = g;
+}
+
 // last axis + decision.  For g in S: nearest-U distance dm (unshifted) -> G bit, or the ambiguous list when
 // ucb - L dm lies inside the band the "+1e-8" shift and rounding can move it across zero.
 // LIST: open candidates go to the scan list (the usual grid path); otherwise they are scanned here by their own thread.
@@ -364,7 +382,7 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
                                                     const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
                                                     uint8_t* __restrict__ G, long long* __restrict__ amb,
                                                     const CoarseGrid cg, const double* __restrict__ Bmin, int blk,
-                                                    long long* __restrict__ scanlist) {
+                                                    long long* __restrict__ scanlist, const RcExp rx) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const bool anyU = sc->count_U > 0;
   // launch: x over the positions of a grid line (len0 = count0; the whole range when d == 1), y over blocks of
@@ -421,19 +439,21 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
       T lcb, ucbT;
       lcb_ucb(mu[u], va[u], b, lcb, ucbT);
       const double ucb = (double)ucbT;
+      const double du = rc_du(rx, g, (double)va[u], (double)b);      // 0 unless this entry is an unrefined fp32 value
       if (!(L > 0)) {
         out = ucb >= 0.0;                         // radius unbounded: any U point is a witness
+        if (du > 0.0 && fabs(ucb) <= du) rc_defer(rx, g);
       } else {
         const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
-        const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
+        const double cap = (ucb + du) / L + 4.0 * eps_abs + 1e-9 * fabs((ucb + du) / L);
         const long long gg = goff + g;   // index in the transform (whole grid when ranks share it)
         const int ia = iav[u];
         if (cg.enabled) {
           const double dC = sqrt(dcv[u]);
           const double dhi = dC * (1.0 + 1e-9) + cg.delta, dlo = fmax(0.0, dC * (1.0 - 1e-9) - cg.delta);
-          const double tolc = 1e-12 * (fabs(ucb) + L * dhi);
-          if (ucb - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { G[g] = 1; return; }     // within the radius for sure
-          if (ucb - L * (dlo - eps_abs - 1e-11 * dlo) < -tolc) { G[g] = 0; return; }    // beyond it for sure
+          const double tolc = 1e-12 * (fabs(ucb) + du + L * dhi);
+          if (ucb - du - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { G[g] = 1; return; }     // within the radius for sure
+          if (ucb + du - L * (dlo - eps_abs - 1e-11 * dlo) < -tolc) { G[g] = 0; return; }    // beyond it for sure
         }
         if (LIST) {
           // the few candidates the coarse bounds leave open go to k_edt_scan_list (a group of lanes each): a lane
@@ -444,7 +464,7 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
           G[g] = 0;
           return;
         }
-        const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it the verdict is "sure true"
+        const double thr = (ucb - du) / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;   // inside it the verdict is "sure true"
         const double acc2 = thr > 0 ? thr * thr : -1.0;
         const double best = cnt <= 1 ? Din[gg]
                             : Bmin  ? edt_scan_blocked(Din, Bmin, gg - (long long)ia * stride, stride, cnt, ia, h, cap, acc2, blk)
@@ -452,12 +472,17 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
         if (best < 0.5 * kInfD) {
           const double dm = sqrt(best);
           const double eps = eps_abs + 1e-11 * dm;
-          const double tol = 1e-12 * (fabs(ucb) + L * dm);
-          const double lo = ucb - L * (dm + eps), hi = ucb - L * (dm - eps);
+          const double tol = 1e-12 * (fabs(ucb) + du + L * dm);
+          const double lo = ucb - du - L * (dm + eps), hi = ucb + du - L * (dm - eps);
           if (lo > tol) out = 1;
           else if (hi >= -tol) {
-            const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
-            amb[slot] = g;
+            if (du > 0.0) {
+              rc_defer(rx, g);                     // an fp32 value cannot settle it: re-evaluate, decide in the next pass
+              out = ucb - L * dm >= 0.0;
+            } else {
+              const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
+              amb[slot] = g;
+            }
           }
         }
       }
@@ -490,7 +515,7 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict_
                                                        const T* __restrict__ var_c, T b, const unsigned long long* Lkeys, int lidx,
                                                        SweepScalars* sc, uint8_t* __restrict__ G, long long* __restrict__ amb,
                                                        const double* __restrict__ Bmin, int blk,
-                                                       const long long* __restrict__ scanlist) {
+                                                       const long long* __restrict__ scanlist, const RcExp rx) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const long long nscan = sc->n_scan;
   const int lane = threadIdx.x & (GL - 1);
@@ -509,9 +534,10 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict_
   for (long long qi = (long long)blockIdx.x * (blockDim.x / GL) + threadIdx.x / GL; qi < nscan; qi += ngroups) {
     const long long g = scanlist[2 * qi];
     const double ucb = reinterpret_cast<const double*>(scanlist)[2 * qi + 1];
+    const double du = rx.refined ? rc_du(rx, g, (double)var_c[g], (double)b) : 0.0;
     const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
-    const double cap = ucb / L + 4.0 * eps_abs + 1e-9 * fabs(ucb / L);
-    const double thr = ucb / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;
+    const double cap = (ucb + du) / L + 4.0 * eps_abs + 1e-9 * fabs((ucb + du) / L);
+    const double thr = (ucb - du) / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;
     const double acc2 = thr > 0 ? thr * thr : -1.0;
     const long long gg = goff + g, p = gg % stride;
     const int ia = (int)((gg / stride) % cnt), b0 = ia / blk;
@@ -571,10 +597,17 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict_
       if (best < 0.5 * kInfD) {
         const double dm = sqrt(best);
         const double eps = eps_abs + 1e-11 * dm;
-        const double tol = 1e-12 * (fabs(ucb) + L * dm);
-        const double lo = ucb - L * (dm + eps), hi = ucb - L * (dm - eps);
+        const double tol = 1e-12 * (fabs(ucb) + du + L * dm);
+        const double lo = ucb - du - L * (dm + eps), hi = ucb + du - L * (dm - eps);
         if (lo > tol) out = 1;
-        else if (hi >= -tol) amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
+        else if (hi >= -tol) {
+          if (du > 0.0) {
+            rc_defer(rx, g);
+            out = ucb - L * dm >= 0.0;
+          } else {
+            amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
+          }
+        }
       }
       G[g] = out;
     }

@@ -11,14 +11,17 @@
 //   (iii) whether they hold the largest var_0 over M             (Minimizer's arg-max)
 // are listed, their posterior is re-evaluated in fp64 by the model's fp64 twin (generic K1 kernel on the compacted list),
 // and the whole set phase then runs in fp64 arithmetic on the widened fp32 posterior with the listed entries replaced.
-// S, U, u*, M and the minimiser are then those of an fp64 sweep; the expander sets still see the fp32 Lipschitz constant
-// and the fp32 ucb of unlisted candidates (their verdicts are fp32-accurate, not bit-exact).
+// S, U, u*, M and the minimiser are then those of an fp64 sweep.  The expander sets need two more things: the Lipschitz
+// constant in fp64 (k_rc_grad64: the mean gradient is O(n d) per candidate, no contraction) and verdict kernels that
+// carry the band of an unrefined ucb (RcExp in sets_expander.inc.hpp): a verdict the band cannot settle defers the
+// candidate, and so does an unrefined member of G_c that could hold its largest variance.  Deferred candidates are
+// re-evaluated and the set phase runs again, until nothing is deferred (each candidate is refined at most once).
 #pragma once
 
 struct RcBand {
   double dm[kMaxQ], dv[kMaxQ];
 };
-struct RcScal {                         // head of rc_list
+struct RcScal {                         // head of rc_list (256 bytes): this struct, the deferral counter at byte 32, G keys at 64
   unsigned long long ulo_key, uhi_key, vmax_key;
   long long count;
 };
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void k_rc_vmax(const float* __restrict__ mean,
 }
 // pass 3: the list of candidates the intervals cannot decide
 __global__ __launch_bounds__(256) void k_rc_flag(const float* __restrict__ mean, const float* __restrict__ var, long long n, int q, double b,
-                                                 const RcBand bd, RcScal* sc, long long* __restrict__ list) {
+                                                 const RcBand bd, RcScal* sc, long long* __restrict__ list, int all_possibly_safe) {
   __shared__ int wcount[4];
   __shared__ long long base;
   const bool have_hi = sc->uhi_key != ~0ull;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void k_rc_flag(const float* __restrict__ mean,
     if (g < n) {
       bool ps, ss, un;
       rc_safety(mean, var, n, g, q, b, bd, ps, ss, un);
-      flag = un;
+      flag = un || (all_possibly_safe && ps && q > 1);
       if (ps) {
         double ll, lh, ul, uh;
         rc_interval(mean[g], var[g], b, bd.dm[0], bd.dv[0], ll, lh, ul, uh);
@@ -149,14 +152,130 @@ __global__ __launch_bounds__(256) void k_rc_widen(const float* __restrict__ m32,
 }
 __global__ __launch_bounds__(256) void k_rc_scatter(const long long* __restrict__ list, long long nf, int q, long long n,
                                                     const double* __restrict__ ms, const double* __restrict__ vs, double* __restrict__ m64,
-                                                    double* __restrict__ v64) {
+                                                    double* __restrict__ v64, uint8_t* __restrict__ refined) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nf * q; i += (long long)gridDim.x * blockDim.x) {
     const long long k = i % nf;
     const int o = (int)(i / nf);
     const long long g = list[k];
     m64[(size_t)o * n + g] = ms[(size_t)o * nf + k];
     v64[(size_t)o * n + g] = vs[(size_t)o * nf + k];
+    if (o == 0) refined[g] = 1;
   }
+}
+
+// Lipschitz keys in fp64: max over the candidates of |d MEAN_i / d x_a| for every output (the analytic gradient of
+// models/SafeOpt.py:68-71 on the twin's double arrays; one thread per candidate)
+template <int D>
+__global__ __launch_bounds__(256) void k_rc_grad64(const ModelConst mc, const CandSpec cs, const double* __restrict__ As,
+                                                   const double* __restrict__ sqA, const double* __restrict__ alpha,
+                                                   const double* __restrict__ Xn, unsigned long long* __restrict__ Lmax) {
+  double gm[kMaxQ];
+#pragma unroll
+  for (int o = 0; o < kMaxQ; ++o) gm[o] = 0.0;
+  const int n = mc.n, npad = mc.npad;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < cs.n_local; g += (long long)gridDim.x * blockDim.x) {
+    double x[D], xn[D];
+    cand_coords<D>(cs, g, x);
+#pragma unroll
+    for (int a = 0; a < D; ++a) xn[a] = a < mc.d ? (x[a] - mc.X_mean[a]) / mc.X_std[a] : 0.0;
+    for (int o = 0; o < mc.q; ++o) {
+      double bq[D], sqb = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        bq[a] = a < mc.d ? xn[a] * mc.vinv[o][a] : 0.0;
+        sqb += bq[a] * bq[a];
+      }
+      const double* Ao = As + (size_t)o * npad * D;
+      const double* so = sqA + (size_t)o * npad;
+      const double* al = alpha + (size_t)o * npad;
+      double s0 = 0.0, sa[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) sa[a] = 0.0;
+      for (int j = 0; j < n; ++j) {
+        double dot = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) dot += Ao[(size_t)j * D + a] * bq[a];
+        const double w = al[j] * (mc.sf2[o] * exp(-0.5 * ((-2.0 * dot + so[j]) + sqb)));
+        s0 += w;
+#pragma unroll
+        for (int a = 0; a < D; ++a) sa[a] += w * Xn[(size_t)j * D + a];
+      }
+      double gn = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        if (a < mc.d) {
+          double ga = mc.Y_std[o] * (sa[a] - xn[a] * s0) * mc.inv_ell[o][a] * mc.X_rstd[a];
+          ga = ga < 0 ? -ga : ga;
+          gn = ga > gn ? ga : gn;
+        }
+      }
+      gm[o] = gn > gm[o] ? gn : gm[o];
+    }
+  }
+  for (int o = 0; o < mc.q; ++o) {
+    const unsigned long long k = block_ext_u64<true>((unsigned long long)__double_as_longlong(gm[o]));   // (values >= 0: bit order)
+    if (threadIdx.x == 0) atomicMax(&Lmax[o], k);
+    __syncthreads();
+  }
+}
+
+// guard of Expander's arg-max: gkeys[c] = max over G_c of the lower end of var_0, then every unrefined member of G_c whose
+// upper end reaches it is deferred
+__global__ __launch_bounds__(256) void k_rc_gmax(const uint8_t* __restrict__ G, const double* __restrict__ var0, const uint8_t* __restrict__ refined,
+                                                 long long n, double dv0, unsigned long long* __restrict__ gkeys) {
+  const int c = blockIdx.y;
+  const uint8_t* Gc = G + (size_t)c * n;
+  unsigned long long k = 0ull;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x)
+    if (Gc[g]) {
+      const unsigned long long kk = ord_key(refined[g] ? var0[g] : fmax(0.0, var0[g] - dv0));
+      k = kk > k ? kk : k;
+    }
+  k = block_ext_u64<true>(k);
+  if (threadIdx.x == 0 && k) atomicMax(&gkeys[c], k);
+}
+__global__ __launch_bounds__(256) void k_rc_gdefer(const uint8_t* __restrict__ G, const double* __restrict__ var0, const uint8_t* __restrict__ refined,
+                                                   long long n, double dv0, const unsigned long long* __restrict__ gkeys,
+                                                   long long* __restrict__ list, unsigned long long* __restrict__ count) {
+  const int c = blockIdx.y;
+  const uint8_t* Gc = G + (size_t)c * n;
+  if (!gkeys[c]) return;
+  const double vlo = ord_val(gkeys[c]);
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x)
+    if (Gc[g] && !refined[g] && var0[g] + dv0 >= vlo) list[atomicAdd(count, 1ull)] = g;
+}
+
+// re-evaluate list[0..nf) in fp64 on the twin and put the values in place
+static int rc_refine(sbo_ctx* c, const long long* list, long long nf) {
+  sbo_ctx* s = c->shadow;
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q, d = c->cs.d;
+  int rc;
+  if (nf <= 0) return SBO_OK;
+  if ((rc = ensure(s->pts, sizeof(double) * (size_t)nf * d))) return rc;
+  const unsigned nbf = (unsigned)std::max<long long>(1, std::min<long long>((nf + 255) / 256, 4096));
+  switch (c->mc.dpad) {
+    case 2: hipLaunchKernelGGL(k_rc_gather<2>, dim3(nbf), dim3(256), 0, c->stream, c->cs, list, nf, (double*)s->pts.p); break;
+    case 4: hipLaunchKernelGGL(k_rc_gather<4>, dim3(nbf), dim3(256), 0, c->stream, c->cs, list, nf, (double*)s->pts.p); break;
+    default: hipLaunchKernelGGL(k_rc_gather<8>, dim3(nbf), dim3(256), 0, c->stream, c->cs, list, nf, (double*)s->pts.p); break;
+  }
+  memset(&s->cs, 0, sizeof(s->cs));
+  s->cs.kind = 0;
+  s->cs.d = d;
+  s->cs.pts_dtype = SBO_F64;
+  s->cs.pts = s->pts.p;
+  s->cs.n_local = nf;
+  s->cs.first = 0;
+  s->grid_total = nf;
+  s->has_cand = true;
+  s->posterior_path = 0;
+  if ((rc = ensure(s->mean, sizeof(double) * (size_t)nf * q))) return rc;
+  if ((rc = ensure(s->var, sizeof(double) * (size_t)nf * q))) return rc;
+  if ((rc = launch_posterior(s))) return rc;
+  hipLaunchKernelGGL(k_rc_scatter, dim3(nbf), dim3(256), 0, c->stream, list, nf, q, n, (const double*)s->mean.p, (const double*)s->var.p,
+                     (double*)c->rc_mean.p, (double*)c->rc_var.p, (uint8_t*)c->rc_refined.p);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
 }
 
 static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_result* res) {
@@ -168,7 +287,7 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
   SBO_HIP(hipEventRecord(c->ev_join[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
-  if (c->k1_stop_attached) c->k1_stop_attached = false;            // (K1b never runs in fp32; kept for symmetry)
+  c->k1_stop_attached = false;
   SBO_HIP(hipEventRecord(c->ev_join[1], c->stream));
   // the fp32 contract as absolute bands per output
   RcBand bd;
@@ -178,70 +297,95 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
     bd.dm[i] = 1e-4 * ys;
     bd.dv[i] = 1e-4 * ys * ys;
   }
-  if ((rc = ensure(c->rc_list, sizeof(RcScal) + sizeof(long long) * (size_t)n))) return rc;
+  const size_t list_cap = (size_t)n * std::max(1, q);            // (a candidate can be deferred once per constraint)
+  if ((rc = ensure(c->rc_list, kRcList + sizeof(long long) * list_cap))) return rc;
   if ((rc = ensure(c->rc_mean, sizeof(double) * (size_t)q * n))) return rc;
   if ((rc = ensure(c->rc_var, sizeof(double) * (size_t)q * n))) return rc;
+  if ((rc = ensure(c->rc_refined, (size_t)n))) return rc;
   RcScal* sc = (RcScal*)c->rc_list.p;
-  long long* list = (long long*)((char*)c->rc_list.p + sizeof(RcScal));
+  unsigned long long* count2 = (unsigned long long*)((char*)c->rc_list.p + kRcCount2);
+  unsigned long long* gkeys = (unsigned long long*)((char*)c->rc_list.p + kRcGKeys);
+  long long* list = (long long*)((char*)c->rc_list.p + kRcList);
+  SBO_HIP(hipMemsetAsync(c->rc_list.p, 0, kRcList, c->stream));
   const RcScal init{~0ull, ~0ull, 0ull, 0};
   SBO_HIP(hipMemcpyAsync(sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemsetAsync(c->rc_refined.p, 0, (size_t)n, c->stream));
   const float* m32 = (const float*)c->mean.p;
   const float* v32 = (const float*)c->var.p;
   const unsigned nbk = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));
+  // candidate sets without a grid to transform decide their expanders by exhaustive pair evaluation on the ucb of every
+  // safe candidate: there all possibly-safe candidates are re-evaluated
+  long long plane = 1;
+  for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
+  const bool grid_expander = c->cs.kind == 1 && c->cs.first % plane == 0 && n % plane == 0;
   hipLaunchKernelGGL(k_rc_ustar, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc);
   hipLaunchKernelGGL(k_rc_vmax, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc);
-  hipLaunchKernelGGL(k_rc_flag, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc, list);
+  hipLaunchKernelGGL(k_rc_flag, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc, list, grid_expander ? 0 : 1);
   hipLaunchKernelGGL(k_rc_widen, dim3(nbk), dim3(256), 0, c->stream, m32, v32, (long long)q * n, (double*)c->rc_mean.p, (double*)c->rc_var.p);
   SBO_HIP(hipGetLastError());
-  RcScal* hsc = (RcScal*)(c->h_back + 5120);
-  SBO_HIP(hipMemcpyAsync(hsc, sc, sizeof(RcScal), hipMemcpyDeviceToHost, c->stream));
+  unsigned char* hb = c->h_back + 5120;                             // pinned landing area of the list lengths
+  SBO_HIP(hipMemcpyAsync(hb, sc, 64, hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
-  const long long nf = hsc->count;
-  if (nf > 0) {
-    // the listed candidates as an explicit fp64 list of the twin, its generic posterior kernel, and the values back in place
-    const int d = c->cs.d;
-    if ((rc = ensure(s->pts, sizeof(double) * (size_t)nf * d))) return rc;
-    const unsigned nbf = (unsigned)std::max<long long>(1, std::min<long long>((nf + 255) / 256, 4096));
+  long long total = ((const RcScal*)hb)->count;
+  if ((rc = rc_refine(c, list, total))) return rc;
+  if (q > 1) {
+    // Lipschitz keys in fp64 (the fp32 posterior kernel left fp32-accurate ones)
+    SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
+    const unsigned nbg = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8));
+#define SBO_GRAD(DD)                                                                                                              \
+  hipLaunchKernelGGL(k_rc_grad64<DD>, dim3(nbg), dim3(256), 0, c->stream, s->mc, c->cs, (const double*)s->As.p, (const double*)s->sqA.p, \
+                     (const double*)s->alpha.p, (const double*)s->Xn.p, (unsigned long long*)c->Lmax.p)
     switch (c->mc.dpad) {
-      case 2: hipLaunchKernelGGL(k_rc_gather<2>, dim3(nbf), dim3(256), 0, c->stream, c->cs, (const long long*)list, nf, (double*)s->pts.p); break;
-      case 4: hipLaunchKernelGGL(k_rc_gather<4>, dim3(nbf), dim3(256), 0, c->stream, c->cs, (const long long*)list, nf, (double*)s->pts.p); break;
-      default: hipLaunchKernelGGL(k_rc_gather<8>, dim3(nbf), dim3(256), 0, c->stream, c->cs, (const long long*)list, nf, (double*)s->pts.p); break;
+      case 2: SBO_GRAD(2); break;
+      case 4: SBO_GRAD(4); break;
+      default: SBO_GRAD(8); break;
     }
-    memset(&s->cs, 0, sizeof(s->cs));
-    s->cs.kind = 0;
-    s->cs.d = d;
-    s->cs.pts_dtype = SBO_F64;
-    s->cs.pts = s->pts.p;
-    s->cs.n_local = nf;
-    s->cs.first = 0;
-    s->grid_total = nf;
-    s->has_cand = true;
-    s->posterior_path = 0;
-    if ((rc = ensure(s->mean, sizeof(double) * (size_t)nf * q))) return rc;
-    if ((rc = ensure(s->var, sizeof(double) * (size_t)nf * q))) return rc;
-    if ((rc = launch_posterior(s))) return rc;
-    hipLaunchKernelGGL(k_rc_scatter, dim3(nbf), dim3(256), 0, c->stream, (const long long*)list, nf, q, n, (const double*)s->mean.p,
-                       (const double*)s->var.p, (double*)c->rc_mean.p, (double*)c->rc_var.p);
+#undef SBO_GRAD
     SBO_HIP(hipGetLastError());
   }
   SBO_HIP(hipEventRecord(c->ev_join[2], c->stream));
-  // the set phase in fp64 arithmetic on the widened + refined posterior (the fp32 arrays stay what sbo_posterior_get returns)
+  // the set phase in fp64 arithmetic on the widened + refined posterior (the fp32 arrays stay what sbo_posterior_get
+  // returns); repeated while verdicts are deferred
   const DevBuf keep_m = c->mean, keep_v = c->var;
   const int keep_dtype = c->dtype;
   const bool keep_valid = c->posterior_valid;
-  c->mean = c->rc_mean;
-  c->var = c->rc_var;
-  c->dtype = SBO_F64;
-  c->posterior_valid = true;
   sbo_sweep_opts o2 = *o;
   o2.posterior_ready = 1;
-  rc = sweep_safeopt_t<double>(c, &o2, res);
-  c->rc_mean = c->mean;          // (ensure() inside cannot have touched them, but keep the DevBufs in step)
-  c->rc_var = c->var;
-  c->mean = keep_m;
-  c->var = keep_v;
-  c->dtype = keep_dtype;
-  c->posterior_valid = keep_valid || !reuse;
+  float set_extra = 0.0f;
+  int passes = 0;
+  for (;; ++passes) {
+    SBO_HIP(hipMemsetAsync(count2, 0, 8 + sizeof(unsigned long long) * kMaxQ + 24, c->stream));     // deferral counter + G keys
+    c->mean = c->rc_mean;
+    c->var = c->rc_var;
+    c->dtype = SBO_F64;
+    c->posterior_valid = true;
+    c->rc_active = q > 1;
+    rc = sweep_safeopt_t<double>(c, &o2, res);
+    c->rc_active = false;
+    c->rc_mean = c->mean;
+    c->rc_var = c->var;
+    c->mean = keep_m;
+    c->var = keep_v;
+    c->dtype = keep_dtype;
+    c->posterior_valid = keep_valid || !reuse;
+    if (rc != SBO_OK || q == 1 || passes >= 6) break;
+    if (passes > 0) set_extra += (float)c->prof.total_ms;
+    // Expander's arg-max over every G_c must not hinge on an fp32 variance
+    const uint8_t* G = (const uint8_t*)c->maskG.p;
+    const double* var0 = (const double*)c->rc_var.p;
+    hipLaunchKernelGGL(k_rc_gmax, dim3(nbk, (unsigned)(q - 1)), dim3(256), 0, c->stream, G, var0, (const uint8_t*)c->rc_refined.p, n, bd.dv[0],
+                       gkeys);
+    hipLaunchKernelGGL(k_rc_gdefer, dim3(nbk, (unsigned)(q - 1)), dim3(256), 0, c->stream, G, var0, (const uint8_t*)c->rc_refined.p, n,
+                       bd.dv[0], (const unsigned long long*)gkeys, list, count2);
+    SBO_HIP(hipGetLastError());
+    SBO_HIP(hipMemcpyAsync(hb, c->rc_list.p, 64, hipMemcpyDeviceToHost, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+    const long long nd = (long long)*(const unsigned long long*)(hb + kRcCount2);
+    if (nd == 0) break;
+    if ((size_t)nd > list_cap) return fail(SBO_E_HIP, "internal: refinement list overflow");
+    if ((rc = rc_refine(c, list, nd))) return rc;
+    total += nd;
+  }
   float t01 = 0, t12 = 0, t04 = 0;
   (void)hipEventElapsedTime(&t01, c->ev_join[0], c->ev_join[1]);
   (void)hipEventElapsedTime(&t12, c->ev_join[1], c->ev_join[2]);
@@ -249,9 +393,10 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
   c->prof.posterior_ms = t01;
   c->prof.recheck_ms = t12;
   c->prof.total_ms = t04;
-  c->prof.fp64_rechecks = nf;
+  c->prof.fp64_rechecks = total;
   c->prof.posterior_launches = reuse ? 0 : 1;
   const double nn = c->mc.n, dd = c->mc.d;
   c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
+  (void)set_extra;
   return rc;
 }
