@@ -25,8 +25,9 @@ What the JSON line reports (N = 1 adds the last five):
                         (test/test_SafeOpt.py:144-179), so here two data sets alternate and every timed step is
                         set_model (upload + factorisation) + the per-(model, grid) table build of K1b + the sweep.
   table_kernel          the same resident-model sweep with the O(n^2)-per-candidate kernel K1g.
-  extra                 the other single-GPU configs: H (4096^2, n = 512, SafeOpt) and C (Williams-Otto, 1024^2, n = 256,
-                        q = 3, GoOSE), resident-model sweeps + their iteration cost.
+  extra                 the other BASELINE.json configs on the one GPU: H (4096^2, n = 512, SafeOpt) and C (Williams-Otto, 1024^2,
+                        n = 256, q = 3, GoOSE) with their iteration cost, D (128^4, the whole grid of the 8-GPU config), E (2 M
+                        scattered 6-D points, n = 2048, fp32 with the fp64 recheck).
   cpu_baseline          the NumPy oracle on the box's host cores, bounded prefix of the same grid.
 
 torch is used only as the launcher's rendezvous (gloo group: unique-id broadcast, barriers, max over
@@ -209,26 +210,40 @@ def make_configs(name, n=None):
     return cfg, alt
 
 
-def extra_record(eng, cfg, alt, name, kind, steps, barrier):
-    """Resident-model sweep rate + iteration cost of another single-GPU config, same process."""
-    count = list(cfg["count"])
-    n_total = int(np.prod(count))
-    eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=(cfg["dtype"] == "f64"))
-    eng.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None):
+    """Resident-model sweep rate (+ iteration cost for the 2-D grids) of another single-GPU config, same process.
+    ``points``: size of the explicit candidate list of a scattered config (E)."""
+    from safebo_amd import synthetic
+    use_invK = cfg["dtype"] == "f64"
+    eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=use_invK)
+    if cfg["count"] is None:
+        n_total = int(points)
+        eng.set_points(synthetic.scattered_points(cfg, n_total))
+        where = f"explicit list of {n_total} scattered candidates"
+    else:
+        count = list(cfg["count"])
+        n_total = int(np.prod(count))
+        eng.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+        where = f"implicit grid {'x'.join(map(str, count))} ({n_total} candidates)"
     step = sweep_fn(eng, kind, cfg["b"])
-    el, rows, res = timed_resident(eng, step, steps, max(3, steps // 5), barrier)
+    el, rows, res = timed_resident(eng, step, steps, max(1, steps // 5), barrier)
     mf, _ = mfma_roofline(cfg, rows, n_total)
-    set_ms = float(np.mean([p["total_ms"] - p["posterior_ms"] for p in rows]))
-    it = timed_iterations(eng, [alt["ds"], cfg["ds"]], cfg["dtype"], step, max(4, steps // 3), 2, barrier)
-    it["value"] = n_total / (it["ms_per_step"] * 1e-3)
-    it["unit"] = "candidates/s"
-    out = {"config": f"config {name}: {cfg['plant']} {cfg['d']}-D {kind} sweep, implicit grid {'x'.join(map(str, count))} ({n_total} candidates), "
-                     f"n={cfg['n']}, q={cfg['q']}, b={cfg['b']}, {cfg['dtype']}",
+    set_ms = float(np.mean([p["total_ms"] - p["posterior_ms"] - p["recheck_ms"] for p in rows]))
+    out = {"config": f"config {name}: {cfg['plant']} {cfg['d']}-D {kind} sweep, {where}, n={cfg['n']}, q={cfg['q']}, b={cfg['b']}, {cfg['dtype']}",
            "sweep": kind, "value": n_total * steps / el, "unit": "candidates/s", "steps": steps, "ms_per_step": el * 1e3 / steps,
            "roofline": {k: mf[k] for k in ("achieved", "peak", "frac", "kernel", "kernel_ms", "device_ms_per_step", "frac_definition")},
-           "roofline_hbm": hbm_roofline(cfg["q"], 8 if cfg["dtype"] == "f64" else 4, n_total, set_ms), "iteration": it}
+           "roofline_hbm": hbm_roofline(cfg["q"], 8 if cfg["dtype"] == "f64" else 4, n_total, set_ms)}
     out["roofline"]["executed_frac"] = mf["executed"]["frac"]
     out["roofline"]["algorithmic_frac"] = mf["algorithmic"]["frac"]
+    if cfg["dtype"] == "f32":
+        out["fp64_recheck"] = {"candidates_reevaluated": int(rows[-1]["fp64_rechecks"]), "ms": float(np.mean([p["recheck_ms"] for p in rows])),
+                               "note": "fp32 posterior; candidates its bounds cannot decide are re-evaluated in fp64 so that the masks "
+                                       "equal the fp64 result"}
+    if alt is not None and cfg["count"] is not None and cfg["d"] == 2:
+        it = timed_iterations(eng, [alt["ds"], cfg["ds"]], cfg["dtype"], step, max(4, steps // 3), 2, barrier)
+        it["value"] = n_total / (it["ms_per_step"] * 1e-3)
+        it["unit"] = "candidates/s"
+        out["iteration"] = it
     if kind == "safeopt":
         out["result"] = {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
                          "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}
@@ -259,7 +274,7 @@ def main():
     cfg, alt = make_configs(args.config, n=args.n)
     scattered = cfg["count"] is None                      # config E: explicit list of scattered candidates
     extras = world == 1 and not args.no_extra and not scattered
-    extra_cfgs = {name: make_configs(name) for name in (("H", "C") if extras and args.config == "B" else ())}
+    extra_cfgs = {name: make_configs(name) for name in (("H", "C", "D", "E") if extras and args.config == "B" else ())}
     if scattered:
         per_rank = args.points if args.scaling == "weak" else args.points // world
         n_total = per_rank * world
@@ -356,8 +371,12 @@ def main():
                                    "value": n_total * 5 / el_t, "unit": "candidates/s", "achieved": rt["algorithmic"]["achieved"],
                                    "frac": rt["algorithmic"]["frac"], "frac_definition": "SURVEY.md 8(d) algorithmic flops / kernel time / peak"}
         if extras and args.config == "B":
+            # every other BASELINE.json config on this one GPU: H (headline target shape), C (GoOSE on the Williams-Otto plant),
+            # D (the whole 128^4 grid of the 8-GPU config, O(n^2) kernel K1g: 4 sweeps), E (2 M of the 10^7 scattered fp32 points)
             out["extra"] = [extra_record(eng, *extra_cfgs["H"], "H", "safeopt", 40, barrier),
-                            extra_record(eng, *extra_cfgs["C"], "C", "goose", 40, barrier)]
+                            extra_record(eng, *extra_cfgs["C"], "C", "goose", 40, barrier),
+                            extra_record(eng, extra_cfgs["D"][0], None, "D", "safeopt", 4, barrier),
+                            extra_record(eng, extra_cfgs["E"][0], None, "E", "safeopt", 4, barrier, points=2_000_000)]
         if world == 1 and args.cpu_sample > 0 and not scattered:
             out["cpu_baseline"] = cpu_baseline(cfg, count, args.cpu_sample)
         print(json.dumps(out))

@@ -9,5 +9,10 @@ for f in sys.argv[1:]:
         line += f" | iteration {it['ms_per_step']:.3f} ms (set_model {it['set_model_ms']:.3f}, sweep {it['sweep_call_ms']:.3f}) slow {it.get('slow_steps')}"
     print(line)
     for e in d.get("extra", []):
-        it = e["iteration"]
-        print(f"   {e['config'][:28]}: value {e['value']:.4e} ms {e['ms_per_step']:.4f} frac {e['roofline']['frac']:.3f} hbm {e['roofline_hbm']['frac']:.3f} set {e['roofline_hbm']['set_phase_ms']:.3f} | iteration {it['ms_per_step']:.3f} ms (set_model {it['set_model_ms']:.3f}, sweep {it['sweep_call_ms']:.3f})")
+        line = f"   {e['config'][:28]}: value {e['value']:.4e} ms {e['ms_per_step']:.4f} K1 {e['roofline']['kernel_ms']:.3f} frac {e['roofline']['frac']:.3f} hbm {e['roofline_hbm']['frac']:.3f} set {e['roofline_hbm']['set_phase_ms']:.3f}"
+        if "iteration" in e:
+            it = e["iteration"]
+            line += f" | iteration {it['ms_per_step']:.3f} ms (set_model {it['set_model_ms']:.3f}, sweep {it['sweep_call_ms']:.3f})"
+        if "fp64_recheck" in e:
+            line += f" | fp64 recheck {e['fp64_recheck']['candidates_reevaluated']} candidates, {e['fp64_recheck']['ms']:.2f} ms"
+        print(line)
