@@ -184,6 +184,12 @@ int sbo_model_set(sbo_ctx* ctx, int dtype, const char* kernel, int n, int d, int
                   const double* X_mean, const double* X_std, const double* Y_mean, const double* Y_std,
                   const double* X_norm, const double* Y_norm, const double* hypopt, const double* invK);
 
+/* The same with invK as the reference holds it: `invKopt`, a list of q separate [n, n] arrays (models/GP_Safe.py:231-232,
+ * 244) -- no stacking copy on the host.  invK_list == NULL as above. */
+int sbo_model_set_list(sbo_ctx* ctx, int dtype, const char* kernel, int n, int d, int q, const double* X_mean,
+                       const double* X_std, const double* Y_mean, const double* Y_std, const double* X_norm,
+                       const double* Y_norm, const double* hypopt, const double* const* invK_list);
+
 /* ---- candidates (resident in HBM until replaced) ------------------------------------------- */
 /* One more observation (normalised coordinates / outputs, the caller's frozen X_mean, X_std, Y_mean, Y_std) under the
  * hyper-parameters of the last sbo_model_set: the lower factor gains one row and alpha is updated in O(n^2) on the

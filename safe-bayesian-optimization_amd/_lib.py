@@ -89,6 +89,7 @@ SYMBOLS = [
     ("sbo_comm_barrier", C.c_int, [_P]),
     ("sbo_comm_init_relay", C.c_int, [_P, C.c_int, C.c_int, RELAY_ALLREDUCE, RELAY_ALLGATHER, _P]),
     ("sbo_model_set", C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ("sbo_model_set_list", C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("sbo_model_append", C.c_int, [_P, _P, _P]),
     ("sbo_candidates_points", C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_int64]),
     ("sbo_candidates_grid", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int64, C.c_int64]),

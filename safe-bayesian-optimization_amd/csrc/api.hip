@@ -228,9 +228,9 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   return fail(SBO_E_INVALID, std::string("unknown option ") + key);
 }
 
-int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q, const double* X_mean,
-                  const double* X_std, const double* Y_mean, const double* Y_std, const double* X_norm,
-                  const double* Y_norm, const double* hypopt, const double* invK) {
+static int model_set_impl(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q, const double* X_mean,
+                          const double* X_std, const double* Y_mean, const double* Y_std, const double* X_norm,
+                          const double* Y_norm, const double* hypopt, const double* const* invK) {
   if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
   if (!kernel || strcmp(kernel, "RBF") != 0)      // models/GP_Safe.py:159-162
     return fail(SBO_E_INVALID, std::string("ERROR no kernel with name ") + (kernel ? kernel : "(null)"));
@@ -286,6 +286,24 @@ int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q
   }
   c->has_model = true;
   return SBO_OK;
+}
+
+int sbo_model_set(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q, const double* X_mean,
+                  const double* X_std, const double* Y_mean, const double* Y_std, const double* X_norm,
+                  const double* Y_norm, const double* hypopt, const double* invK) {
+  const double* parts[SBO_MAX_Q];
+  if (invK && q >= 1 && q <= SBO_MAX_Q && n >= 1)
+    for (int o = 0; o < q; ++o) parts[o] = invK + (size_t)o * n * n;
+  return model_set_impl(c, dtype, kernel, n, d, q, X_mean, X_std, Y_mean, Y_std, X_norm, Y_norm, hypopt, invK ? parts : nullptr);
+}
+
+int sbo_model_set_list(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q, const double* X_mean,
+                       const double* X_std, const double* Y_mean, const double* Y_std, const double* X_norm,
+                       const double* Y_norm, const double* hypopt, const double* const* invK_list) {
+  if (invK_list && q >= 1 && q <= SBO_MAX_Q)
+    for (int o = 0; o < q; ++o)
+      if (!invK_list[o]) return fail(SBO_E_INVALID, "invK_list holds a NULL matrix");
+  return model_set_impl(c, dtype, kernel, n, d, q, X_mean, X_std, Y_mean, Y_std, X_norm, Y_norm, hypopt, invK_list);
 }
 
 // one more observation under frozen hyper-parameters and normalisation, O(n^2) on the

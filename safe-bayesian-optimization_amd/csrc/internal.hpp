@@ -182,7 +182,7 @@ void release(DevBuf& b);
 // launchers implemented in the .hip files -----------------------------------------------------
 int launch_posterior(sbo_ctx* c);
 int launch_bound(sbo_ctx* c, double b, int index, int kind, void* dev_out);
-int model_build(sbo_ctx* c, const double* host_invK, const double* X_norm, const double* Y_norm);
+int model_build(sbo_ctx* c, const double* const* host_invK, const double* X_norm, const double* Y_norm);
 int model_prep(sbo_ctx* c, const double* X_norm);
 int model_append(sbo_ctx* c, const std::vector<double>& kvec /*[q][n]*/, const double* kappa, const double* rho);
 int model_repack(sbo_ctx* c);

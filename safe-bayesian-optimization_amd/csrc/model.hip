@@ -156,6 +156,51 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {      // l: wav
 }
 constexpr int kBlockedFrom = 96;   // smallest n factorised by the blocked form (below: one workgroup does everything)
 
+// mode 0 front end, coalesced (the all-in-one k_chol_prep below reads invK by columns: 133 us at n = 512):
+//   k_invk_alpha: alpha = invK rhs with the caller's matrix as given (GP_Safe.py:342), one wave per row;
+//   k_invk_reverse: U = upper triangle of J sym(invK) J in 32 x 32 tiles, the transposed partner of a tile through LDS
+__global__ __launch_bounds__(256) void k_invk_alpha(int n, int npad, const double* __restrict__ W, const double* __restrict__ rhs,
+                                                    double* __restrict__ alpha) {
+  const int o = blockIdx.y, lane = threadIdx.x & 63;
+  const double* Wo = W + (size_t)o * n * n;
+  const double* r = rhs + (size_t)o * n;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n; i += (gridDim.x * blockDim.x) >> 6) {
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) s += Wo[(size_t)i * n + j] * r[j];
+    s = wave_sum(s);
+    if (lane == 0) alpha[(size_t)o * npad + i] = s;
+  }
+}
+__global__ __launch_bounds__(256) void k_invk_reverse(int n, const double* __restrict__ W, double* __restrict__ work) {
+  __shared__ double Ta[32][33], Tb[32][33];
+  const int o = blockIdx.z, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const double* Wo = W + (size_t)o * n * n;
+  double* U = work + (size_t)o * n * n;
+  const int i0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  if (k0 + 31 < i0) {                                   // tile entirely below the diagonal: zeros
+    for (int rr = ty; rr < 32; rr += 8)
+      if (i0 + rr < n && k0 + tx < n) U[(size_t)(i0 + rr) * n + k0 + tx] = 0.0;
+    return;
+  }
+  // element (i, k) of the tile needs W[n-1-i][n-1-k] and W[n-1-k][n-1-i]: the blocks W[R..][C..] and W[C..][R..] with
+  // R = n-1-i0-31, C = n-1-k0-31 (rows / columns clipped at 0), read row-wise
+  const int R = n - 1 - i0 - 31, Cc = n - 1 - k0 - 31;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int ra = R + rr, ca = Cc + tx;
+    Ta[rr][tx] = (ra >= 0 && ra < n && ca >= 0 && ca < n) ? Wo[(size_t)ra * n + ca] : 0.0;
+    const int rb = Cc + rr, cb = R + tx;
+    Tb[rr][tx] = (rb >= 0 && rb < n && cb >= 0 && cb < n) ? Wo[(size_t)rb * n + cb] : 0.0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int i = i0 + rr, k = k0 + tx;
+    if (i < n && k < n) {
+      // W[n-1-i][n-1-k] = Ta[31 - rr][31 - tx];  W[n-1-k][n-1-i] = Tb[31 - tx][31 - rr]
+      U[(size_t)i * n + k] = k >= i ? 0.5 * (Ta[31 - rr][31 - tx] + Tb[31 - tx][31 - rr]) : 0.0;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_chol_prep(int mode, int n, int npad, int dpad, int d, const double* __restrict__ W,
                                                    const double* __restrict__ As, const double* __restrict__ sqA,
                                                    const double* __restrict__ rhs, const ModelConst mc, double* __restrict__ work,
@@ -539,7 +584,7 @@ int model_prep(sbo_ctx* c, const double* X_norm) {         // (after an append: 
 // until an append grows them) are in place.  One host synchronisation, at the end (the positive-definiteness verdict);
 // when a K1b-capable grid is resident the axis bases of the new model are built meanwhile on the second stream.
 template <typename T>
-static int model_build_t(sbo_ctx* c, const double* host_invK, const double* X_norm, const double* Y_norm) {
+static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrices, or nullptr */, const double* X_norm, const double* Y_norm) {
   const ModelConst& mc = c->mc;
   const int n = mc.n, npad = mc.npad, q = mc.q, nb = npad / 16;
   const size_t nn = (size_t)n * n;
@@ -552,7 +597,9 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const double* X_no
   c->a_ld = npad;
   double* dF = (double*)c->Fplain.p;
   double* dalpha = (double*)c->alpha64.p;
-  if (host_invK) SBO_HIP(hipMemcpyAsync(w.W, host_invK, sizeof(double) * q * nn, hipMemcpyHostToDevice, c->stream));
+  if (host_invK)                          // (the reference keeps them as a list of q arrays: one copy each, no stacking on the host)
+    for (int o = 0; o < q; ++o)
+      SBO_HIP(hipMemcpyAsync(w.W + (size_t)o * nn, host_invK[o], sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
   if ((rc = model_prep_t<T>(c, X_norm, Y_norm, w))) return rc;
   bool eager_basis = false;
   if (bilinear_applicable(c)) {
@@ -569,8 +616,15 @@ static int model_build_t(sbo_ctx* c, const double* host_invK, const double* X_no
   (void)dsf2;
   if (n >= kBlockedFrom) {
     // blocked multi-workgroup factorisation: the single-workgroup loop is bound by the latency of its own updates
-    hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
-                       (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha);
+    if (mode == 0) {
+      hipLaunchKernelGGL(k_invk_alpha, dim3((unsigned)((n + 3) / 4), q), dim3(256), 0, c->stream, n, npad, (const double*)w.W,
+                         (const double*)w.rhs, dalpha);
+      hipLaunchKernelGGL(k_invk_reverse, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), q), dim3(256), 0, c->stream, n,
+                         (const double*)w.W, w.work);
+    } else {
+      hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
+                         (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha);
+    }
     for (int kb = 0; kb < n; kb += kPB) {
       const int kw = std::min(kPB, n - kb);
       const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
@@ -680,7 +734,7 @@ int model_append(sbo_ctx* c, const std::vector<double>& kvec, const double* kapp
   return SBO_OK;
 }
 
-int model_build(sbo_ctx* c, const double* host_invK, const double* X_norm, const double* Y_norm) {
+int model_build(sbo_ctx* c, const double* const* host_invK, const double* X_norm, const double* Y_norm) {
   return c->dtype == SBO_F64 ? model_build_t<double>(c, host_invK, X_norm, Y_norm) : model_build_t<float>(c, host_invK, X_norm, Y_norm);
 }
 

@@ -91,17 +91,20 @@ class SweepEngine:
         hyp = _f64(ds["hypopt"])
         if hyp.shape != (d + 2, q):
             raise ValueError("ERROR W and X_norm dimension should be same")   # models/GP_Safe.py:134-135
-        invK = None
-        if use_invK:
-            invK = _f64(np.stack([np.asarray(a, dtype=np.float64) for a in ds["invKopt"]]))
-            if invK.shape != (q, n, n):
-                raise ValueError("invKopt must hold q matrices of shape [n, n]")
         arrs = [_f64(ds[k]) for k in ("X_mean", "X_std", "Y_mean", "Y_std")]
         if arrs[0].shape != (d,) or arrs[1].shape != (d,) or arrs[2].shape != (q,) or arrs[3].shape != (q,):
             raise ValueError("X_mean/X_std must be [d], Y_mean/Y_std must be [q]")
-        L.check(self._lib.sbo_model_set(self._ctx, self.tag, kernel.encode(), n, d, q, _ptr(arrs[0]), _ptr(arrs[1]),
-                                        _ptr(arrs[2]), _ptr(arrs[3]), _ptr(X_norm), _ptr(Y_norm), _ptr(hyp),
-                                        _ptr(invK)))
+        args = [self._ctx, self.tag, kernel.encode(), n, d, q, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]),
+                _ptr(X_norm), _ptr(Y_norm), _ptr(hyp)]
+        if use_invK:
+            # `invKopt` is a list of q separate [n, n] arrays in the reference (models/GP_Safe.py:231-232): handed over as such
+            parts = [_f64(a) for a in ds["invKopt"]]
+            if len(parts) != q or any(a.shape != (n, n) for a in parts):
+                raise ValueError("invKopt must hold q matrices of shape [n, n]")
+            ptrs = (C.c_void_p * q)(*[a.ctypes.data for a in parts])
+            L.check(self._lib.sbo_model_set_list(*args, ptrs))
+        else:
+            L.check(self._lib.sbo_model_set(*args, None))
         self.n, self.d, self.q = n, d, q
 
     def append_sample(self, x_norm_new, y_norm_new):
