@@ -265,6 +265,7 @@ def main():
 
     import safebo_amd
     from safebo_amd import synthetic
+    safebo_amd._lib.load()        # libsafebo.so (and the RCCL it is linked against) before torch maps its own copy
 
     dist = None
     if world > 1:

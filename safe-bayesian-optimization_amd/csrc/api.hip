@@ -186,16 +186,16 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->scan_waves = (int)value;   // 0: off; 8 / 16 / 32 / 64: lanes per listed candidate (anything else: the default, 16)
     return SBO_OK;
   }
+  if (!strcmp(key, "set_fuse")) {
+    c->set_fuse = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "scan_blocks")) {
     c->scan_blocks = value ? 1 : 0;
     return SBO_OK;
   }
   if (!strcmp(key, "fuse_classify")) {
     c->fuse_classify = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "set_overlap")) {
-    c->set_overlap = value ? 1 : 0;
     return SBO_OK;
   }
   if (!strcmp(key, "goose_pairs")) {

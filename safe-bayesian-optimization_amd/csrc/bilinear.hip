@@ -982,23 +982,7 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
 // Lipschitz keys of a K1b launch: Lmax[o] = max of the per-wave partials (values >= 0, so the bit pattern orders them)
 __global__ __launch_bounds__(256) void k_lmax_reduce(const double* __restrict__ Lpart, int per_out, unsigned long long* __restrict__ Lmax) {
   __shared__ double sh[4];
-  const int o = blockIdx.x;
-  double g = 0.0;
-  for (int i = threadIdx.x; i < per_out; i += blockDim.x) {
-    const double v = Lpart[(size_t)o * per_out + i];
-    g = v > g ? v : g;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double other = __shfl_xor(g, off);
-    g = other > g ? other : g;
-  }
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = g;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w) g = sh[w] > g ? sh[w] : g;
-    Lmax[o] = (unsigned long long)__double_as_longlong(g);
-  }
+  lmax_reduce_body((int)blockIdx.x, sh, Lpart, per_out, Lmax);
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------
@@ -1303,16 +1287,21 @@ int launch_posterior_bilinear(sbo_ctx* c) {
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
   }
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_bpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream,
-                     mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
-                     pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
-                     (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
-                     fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                     (unsigned long long*)c->cpart.p);
-  // the K1 stop event rides on this launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
-  // the next kernel waits ~6 us for
-  hipExtLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, c->ev[1], 0, (const double*)c->bl_lpart.p,
-                        (int)(4 * gx * gy), (unsigned long long*)c->Lmax.p);
+  // the K1 stop event rides on the last launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
+  // the next kernel waits ~6 us for.  A sweep merges the Lipschitz partials in its own first small kernel (lmax_defer).
+  hipExtLaunchKernelGGL(k_bpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream, nullptr, c->lmax_defer ? c->ev[1] : nullptr, 0,
+                        mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
+                        pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
+                        (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
+                        fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
+                        (unsigned long long*)c->cpart.p);
+  if (c->lmax_defer) {
+    c->lmax_pending = true;
+    c->lmax_per_out = (int)(4 * gx * gy);
+  } else {
+    hipExtLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, c->ev[1], 0, (const double*)c->bl_lpart.p,
+                          (int)(4 * gx * gy), (unsigned long long*)c->Lmax.p);
+  }
   c->k1_stop_attached = true;
   (void)line0;
   // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (KS0 + 3 KSm k-steps: the axis-0 gradient phase

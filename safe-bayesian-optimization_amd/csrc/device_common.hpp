@@ -148,4 +148,27 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Lipschitz key of output o from K1b's per-wave partials: Lmax[o] = max (values >= 0, so the bit pattern orders them);
+// one workgroup of 256 threads, `sh`: four doubles of LDS
+__device__ __forceinline__ void lmax_reduce_body(int o, double* sh, const double* __restrict__ Lpart, int per_out,
+                                                 unsigned long long* __restrict__ Lmax) {
+  double g = 0.0;
+  for (int i = threadIdx.x; i < per_out; i += blockDim.x) {
+    const double v = Lpart[(size_t)o * per_out + i];
+    g = v > g ? v : g;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double other = __shfl_xor(g, off);
+    g = other > g ? other : g;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = g;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) g = sh[w] > g ? sh[w] : g;
+    Lmax[o] = (unsigned long long)__double_as_longlong(g);
+  }
+}
+
 }  // namespace sbo

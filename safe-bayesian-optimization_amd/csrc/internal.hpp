@@ -120,6 +120,11 @@ struct sbo_ctx {
   bool fuse_request = false;
   double fuse_b = 0.0;
   int fuse_rows = 0;
+  // Lipschitz keys of K1b: a sweep sets lmax_defer before it enqueues the posterior; the posterior then leaves its per-wave
+  // partials (lmax_per_out per output) for the sweep's k_classify_final / k_edt_axis0_pair to merge (lmax_pending)
+  bool lmax_defer = false;
+  bool lmax_pending = false;
+  int lmax_per_out = 0;
   sbo::DevBuf Wfull;   // multi-rank GoOSE: source weights of the whole grid (all-gathered), T [grid_total]
   sbo::DevBuf Ufull;   // multi-rank: U mask of the whole grid (all-gathered), uint8 [grid_total]
   sbo::DevBuf gather;  // multi-rank: all-gather receive buffer [world][max_local]
@@ -140,14 +145,14 @@ struct sbo_ctx {
   // profile
   sbo_profile prof{};
   hipEvent_t ev[8]{};
-  hipEvent_t ev_join[SBO_MAX_Q]{};   // forked set phase: the coarse transform of constraint c is done (side stream -> main stream)
+  hipEvent_t ev_join[SBO_MAX_Q]{};   // phase marks of the fp32 recheck
   // options
   int k1_strips = 4;       // lines per K1g tile (4, or 8 for 2-D grids: tuning)
   int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
   int scan_waves = 1;      // 1: candidates the coarse bounds leave open are scanned one wave each (0: by their own thread)
   int scan_blocks = 1;     // 0: step-by-step last-axis scans (A/B against the blocked form)
+  int set_fuse = 1;        // 2-D grids: independent set-phase kernels share launches (k_edt_axis0_pair, k_set_mid); 0: one launch each
   int fuse_classify = 0;   // (A/B option, measured no faster: the f64 sqrt of the bounds costs the matrix kernel what the separate pass saves) 1: one-constraint sweeps on the K1b path take their S / U bytes from the posterior kernel's epilogue
-  int set_overlap = 0;     // (A/B option, measured slower: +8 us on config B) 1: single-rank grid sweeps run the small set-phase launches on the side stream next to the fine transform
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
   int phase_events = 0;    // 1: events between the set phases too (classify / expander / arg-reduce times in sbo_profile)
   int bilinear = 1;        // 1: fp64 2-D grids run the posterior as two GEMMs in a reduced basis when the bases qualify (K1b)

@@ -221,8 +221,20 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
 }
 
 // start of a sweep's scalar block: cleared, then u*, |S|, |U| and the radius keys merged from k_classify's partials
-__global__ __launch_bounds__(256) void k_classify_final(const unsigned long long* __restrict__ part, int nparts, int q,
-                                                        SweepScalars* sc) {
+struct FinalJob {
+  bool pending = false;
+  const unsigned long long* part = nullptr;   // k_classify's rows
+  int nparts = 0, q = 0;
+  SweepScalars* sc = nullptr;
+  const double* Lpart = nullptr;              // K1b's Lipschitz partials still to be merged (nullptr: Lmax is final)
+  int per_out = 0;
+  unsigned long long* Lmax = nullptr;
+};
+__device__ __forceinline__ void classify_final_body(const unsigned long long* __restrict__ part, int nparts, int q, SweepScalars* sc,
+                                                    const double* __restrict__ Lpart, int per_out, unsigned long long* Lmax) {
+  __shared__ double lsh[4];
+  if (Lpart)
+    for (int o = 0; o < q; ++o) lmax_reduce_body(o, lsh, Lpart, per_out, Lmax);
   unsigned long long* w = reinterpret_cast<unsigned long long*>(sc);       // (the struct is a multiple of 8 bytes)
   for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) w[i] = 0ull;
   __syncthreads();
@@ -253,6 +265,11 @@ __global__ __launch_bounds__(256) void k_classify_final(const unsigned long long
     for (int c = 1; c < kMaxQ; ++c) sc->rmax_key[c] = c < q ? rmax[c] : 0ull;
   }
   if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
+}
+__global__ __launch_bounds__(256) void k_classify_final(const unsigned long long* __restrict__ part, int nparts, int q,
+                                                        SweepScalars* sc, const double* __restrict__ Lpart, int per_out,
+                                                        unsigned long long* Lmax) {
+  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax);
 }
 
 // Objective pass of a classification whose S / U bytes came out of the posterior kernel (K1b, one constraint): u* = min over
@@ -306,14 +323,14 @@ __device__ __forceinline__ bool tile_byte(unsigned long long w, int k, int lane)
 
 // ---- K3b + K5: M mask and arg-max of var_0 over M -----------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, const T* __restrict__ var0, long long n,
-                                                   long long first, T b, const uint8_t* __restrict__ S,
-                                                   uint8_t* __restrict__ M, SweepScalars* sc, Best* partial) {
+__device__ __forceinline__ void minimizer_body(int bid, int nwg, const T* __restrict__ mean0, const T* __restrict__ var0, long long n,
+                                               long long first, T b, const uint8_t* __restrict__ S, uint8_t* __restrict__ M,
+                                               const SweepScalars* sc, Best* partial) {
   const T ustar = (T)ord_val(sc->ustar_key);
   Best best{0.0, -1};
   long long cM = 0;
   const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long wave = ((long long)bid * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)nwg * blockDim.x) >> 6;
   const long long ntiles = (((uintptr_t)S) & 7) == 0 ? n / 512 : 0;
   for (long long t = wave; t < ntiles; t += nwaves) {
     const long long base = t * 512;
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, 
       }
     }
   }
-  for (long long g = ntiles * 512 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+  for (long long g = ntiles * 512 + (long long)bid * blockDim.x + threadIdx.x; g < n; g += (long long)nwg * blockDim.x) {
     bool m = false;
     if (S[g]) {
       T lcb, ucb;
@@ -366,9 +383,15 @@ __global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, 
   best = block_best<true>(best);
   cM = block_sum_ll(cM);
   if (threadIdx.x == 0) {
-    partial[blockIdx.x] = best;
-    ((long long*)(partial + gridDim.x))[blockIdx.x] = cM;   // summed by k_arg_final (an atomic per workgroup on one counter serialises)
+    partial[bid] = best;
+    ((long long*)(partial + nwg))[bid] = cM;   // summed by the finals (an atomic per workgroup on one counter serialises)
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, const T* __restrict__ var0, long long n,
+                                                   long long first, T b, const uint8_t* __restrict__ S,
+                                                   uint8_t* __restrict__ M, SweepScalars* sc, Best* partial) {
+  minimizer_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, first, b, S, M, sc, partial);
 }
 
 // value sources of the masked arg-reductions: an array, or the value computed for the candidates whose mask byte is set
@@ -498,6 +521,49 @@ __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __res
 }
 
 #include "sets_expander.inc.hpp"
+
+// The middle of the set phase of a 2-D grid sweep in one launch: three jobs that need the classification's scalars (u*,
+// the radius keys) and the axis-0 passes but not each other -- the last-axis scan of the coarse transform (first in the
+// launch: its threads walk the longest chains of dependent loads), the M mask with its arg-max partials, the block minima
+// of the fine transform.  One after the other they took 11 + 10 + 7 us on config B, none of them filling the GPU.
+template <typename T>
+struct MidJobs {
+  const SweepScalars* sc;
+  const unsigned long long* Lkeys;
+  int ns;                                  // coarse scan: workgroups, in / out, cells, stride, count, step, constraint, L index
+  const double* dc_in;
+  double* dc_out;
+  long long nc, cstride;
+  int ccnt;
+  double hc;
+  int cidx, lidx;
+  double cap_extra;
+  int nb;                                  // minimiser (0: not in this launch)
+  const T* mean0;
+  const T* var0;
+  long long n, first;
+  T b;
+  const uint8_t* S;
+  uint8_t* M;
+  Best* partial;
+  int nm;                                  // block minima (0: none)
+  const double* din;
+  long long stride;
+  int cnt, blk;
+  double* bmin;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
+  __shared__ double part[4][64];
+  const int bid = (int)blockIdx.x;
+  if (bid < j.ns)
+    edt_scan_body(bid, j.ns, j.dc_in, j.dc_out, j.nc, j.cstride, j.ccnt, j.hc, j.sc, j.cidx, j.Lkeys, j.lidx, 0, j.cap_extra);
+  else if (bid < j.ns + j.nb)
+    minimizer_body<T>(bid - j.ns, j.nb, j.mean0, j.var0, j.n, j.first, j.b, j.S, j.M, j.sc, j.partial);
+  else
+    block_min_body(bid - j.ns - j.nb, j.nm, part, j.din, j.stride, j.cnt, j.blk, j.bmin);
+}
+
 #include "sets_exchange.inc.hpp"
 #include "sets_goose.inc.hpp"
 
@@ -505,22 +571,6 @@ __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __res
 static int reduce_blocks(const sbo_ctx* c) {
   const long long n = c->cs.n_local;
   return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));   // (per-block reduction tails cost more than extra grid-stride turns: x4 measured best)
-}
-
-// The set phase of a single-rank grid sweep forks after the classification: the side stream takes the merge of the
-// classification partials, the minimiser branch and the coarse transforms (small, latency-bound launches), the main
-// stream the fine transform; they meet again before the verdict kernel.  The fork event rides on k_classify as its stop
-// event and the join events on the last coarse launch of each constraint (a separate event record costs the stream a
-// ~6 us bubble).
-static bool set_phase_forks(const sbo_ctx* c) {
-  if (!c->set_overlap || multi_rank(c) || c->phase_events || c->mc.q < 2 || c->cs.kind != 1 || c->cs.d < 2) return false;
-  const long long n = c->cs.n_local;
-  long long plane = 1;
-  for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
-  if (n < (1ll << 16) || c->cs.first % plane != 0 || n % plane != 0) return false;
-  for (int a = 0; a < c->cs.d; ++a)
-    if ((a == c->cs.d - 1 ? n / plane : c->cs.count[a]) < 4 * kCoarse) return false;      // (the coarse transform's own condition)
-  return true;
 }
 
 // mask buffers of a sweep; called before the posterior is enqueued (K1b may write S / U itself) -- `b` is the sweep's
@@ -537,13 +587,24 @@ static int sweep_masks(sbo_ctx* c, double b, bool may_fuse) {
   if ((rc = ensure(c->maskM, (size_t)n))) return rc;
   if ((rc = ensure(c->maskG, (size_t)n * std::max(1, q - 1)))) return rc;
   c->fuse_request = may_fuse && c->fuse_classify && q == 2;
+  c->lmax_defer = may_fuse;        // (every sweep merges K1b's Lipschitz partials in its k_classify_final)
+  c->lmax_pending = false;
   c->fuse_b = b;
   c->fuse_rows = 0;
   return SBO_OK;
 }
 
+static void launch_final(sbo_ctx* c, FinalJob* fj) {
+  if (!fj || !fj->pending) return;
+  fj->pending = false;
+  hipLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, fj->part, fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out,
+                     fj->Lmax);
+}
+
+// `defer`: the merge of the classification's partials is handed back instead of launched (SafeOpt on one rank: it rides in
+// the expander's first launch, which reads the U mask only)
 template <typename T>
-static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, bool fork = false) {
+static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* defer = nullptr) {
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
@@ -551,6 +612,16 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, bool fork = f
   const int nb = reduce_blocks(c);
   if ((rc = ensure(c->partial, (sizeof(Best) + sizeof(long long)) * (size_t)nb))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
+  FinalJob fj;
+  fj.pending = true;
+  fj.q = q;
+  fj.sc = sc;
+  if (c->lmax_pending) {
+    fj.Lpart = (const double*)c->bl_lpart.p;
+    fj.per_out = c->lmax_per_out;
+    fj.Lmax = (unsigned long long*)c->Lmax.p;
+    c->lmax_pending = false;
+  }
   const int ncb = std::max(1, c->n_cu * 4);   // four workgroups per CU measured best (2: 24.6 us, 4: 21.5, 8: 27.1 on config B)
   if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kClassifyRow * (size_t)ncb))) return rc;
   if (c->fuse_rows > 0 && n > 0) {
@@ -559,16 +630,9 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, bool fork = f
     unsigned long long* rows = (unsigned long long*)c->cpart.p;
     hipLaunchKernelGGL(k_classify_obj<T>, dim3((unsigned)nob), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b,
                        (const uint8_t*)c->maskS.p, rows + (size_t)c->fuse_rows * kClassifyRow);
-    hipLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)rows, c->fuse_rows + nob, q, sc);
-    c->amb_clean = true;
-    SBO_HIP(hipGetLastError());
-    return SBO_OK;
-  }
-  if (fork) {
-    hipExtLaunchKernelGGL(k_classify<T>, dim3((unsigned)ncb), dim3(256), 0, c->stream, nullptr, c->ev[7], 0, (const T*)c->mean.p,
-                          (const T*)c->var.p, n, q, (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
-    SBO_HIP(hipStreamWaitEvent(c->stream2, c->ev[7], 0));
-    hipLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream2, (const unsigned long long*)c->cpart.p, ncb, q, sc);
+    fj.part = (const unsigned long long*)rows;
+    fj.nparts = c->fuse_rows + nob;
+    launch_final(c, &fj);
     c->amb_clean = true;
     SBO_HIP(hipGetLastError());
     return SBO_OK;
@@ -576,7 +640,10 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, bool fork = f
   if (n > 0)
     hipLaunchKernelGGL(k_classify<T>, dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
                        (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
-  hipLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, (const unsigned long long*)c->cpart.p, n > 0 ? ncb : 0, q, sc);
+  fj.part = (const unsigned long long*)c->cpart.p;
+  fj.nparts = n > 0 ? ncb : 0;
+  if (defer) *defer = fj;
+  else launch_final(c, &fj);
   c->amb_clean = true;
   SBO_HIP(hipGetLastError());
   return SBO_OK;
@@ -624,10 +691,27 @@ static void launch_edt_axis0(sbo_ctx* c, const uint8_t* U, long long nlines, int
     hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, st, U, nlines, count0, h0, D);
 }
 
+// the minimiser launch of a SafeOpt sweep, held back so that the first constraint's expander can take it into k_set_mid
+struct MinimizerJob {
+  bool pending = false;
+  int nb = 0;
+  Best* partial = nullptr;
+  FinalJob fin;                 // the classification's merge, when it too waits for the expander's first launch
+};
 template <typename T>
-static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* G, bool fork = false) {
+static void launch_minimizer(sbo_ctx* c, const sbo_sweep_opts* o, MinimizerJob* mj) {
+  if (mj) launch_final(c, &mj->fin);
+  if (!mj || !mj->pending) return;
+  mj->pending = false;
+  hipLaunchKernelGGL((k_minimizer<T>), dim3(mj->nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, c->cs.n_local,
+                     (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, (SweepScalars*)c->scal.p,
+                     mj->partial);
+}
+
+template <typename T>
+static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* G, MinimizerJob* mj = nullptr) {
   const long long n = c->cs.n_local;
-  if (n == 0) return SBO_OK;
+  if (n == 0) { launch_minimizer<T>(c, o, mj); return SBO_OK; }
   const int q = c->mc.q;
   const int lidx = o->reference_quirk_L_index ? q - 1 : cidx;   // models/SafeOpt.py:110 (loop-leaked i)
   SweepScalars* sc = (SweepScalars*)c->scal.p;
@@ -673,79 +757,132 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)nt))) return rc;
     const int count0 = d >= 2 ? (int)c->cs.count[0] : (int)nt;  // d == 1: the window is one line
     const long long nlines = nt / count0;
-    launch_edt_axis0(c, Uall, nlines, count0, c->cs.step[0], (double*)c->dist2.p);
-    double* din = (double*)c->dist2.p;
-    double* dout = (double*)c->dist2b.p;
-    long long stride = count0;
-    for (int a = 1; a < d - 1; ++a) {
-      hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nt + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
-                         (const double*)din, dout, nt, stride, (int)c->cs.count[a], c->cs.step[a],
-                         (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, 0, 0.0);
-      std::swap(din, dout);
-      stride *= c->cs.count[a];
-    }
-    // coarse transform of the window (uncapped, tiny): lets most candidates decide without the per-candidate scan
+    // coarse transform of the window (tiny): lets most candidates decide without the per-candidate scan
     CoarseGrid cg;
     memset(&cg, 0, sizeof(cg));
     cg.d = d;
     bool coarse_ok = d >= 2 && nt >= (1ll << 16);
     long long nc = 1;
-    double h2 = 0.0;
+    double h2 = 0.0, hmax = 0.0;
     for (int a = 0; a < d; ++a) {
       cg.count[a] = a == d - 1 ? wplanes : c->cs.count[a];
       cg.ccount[a] = (cg.count[a] + kCoarse - 1) / kCoarse;
       nc *= cg.ccount[a];
       h2 += c->cs.step[a] * c->cs.step[a];
+      hmax = std::max(hmax, c->cs.step[a]);
       if (cg.count[a] < 4 * kCoarse) coarse_ok = false;
     }
-    hipStream_t cst = fork ? c->stream2 : c->stream;          // the coarse transform's stream
+    double* dc0 = nullptr;
+    double* dc1 = nullptr;
+    uint8_t* Uc = nullptr;
+    const int cc0 = (int)cg.ccount[0];
+    const long long clines = nc / cc0;
     if (coarse_ok) {
       cg.enabled = 1;
       cg.delta = (kCoarse - 1) * std::sqrt(h2) * (1.0 + 1e-9);
-      // (forked: every constraint has its own coarse arrays -- the side stream runs ahead of the verdict kernels that read them)
       const size_t cbytes = ((size_t)nc * (1 + 2 * sizeof(double)) + 64 + 255) / 256 * 256;
-      if ((rc = ensure(c->coarse, cbytes * (fork ? std::max(1, q - 1) : 1)))) return rc;
-      double* dc0 = (double*)((char*)c->coarse.p + (fork ? cbytes * (size_t)(cidx - 1) : 0));
-      double* dc1 = dc0 + nc;
-      uint8_t* Uc = (uint8_t*)(dc1 + nc);
-      const int cc0 = (int)cg.ccount[0];
-      const long long clines = nc / cc0;
-      if (cc0 <= kAxis0Max && cc0 >= 128) {
-        // the coarse axis-0 pass forms the cells' bits from the fine mask itself
-        hipLaunchKernelGGL(k_edt_axis0_wg<true>, dim3((unsigned)std::min<long long>(clines, 1 << 20)), dim3(256), 0, cst, Uall,
-                           clines, cc0, c->cs.step[0] * kCoarse, dc0, cg);
-      } else {
-        hipLaunchKernelGGL(k_coarsen_mask, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, cst,
-                           Uall, cg, nc, Uc);
-        launch_edt_axis0(c, (const uint8_t*)Uc, clines, cc0, c->cs.step[0] * kCoarse, dc0, cst);
-      }
-      long long cstride = cc0;
-      double hmax = 0.0;
-      for (int a = 0; a < d; ++a) hmax = std::max(hmax, c->cs.step[a]);
-      const double cap_extra = 2.0 * cg.delta + 2.0 * kCoarse * hmax;
-      for (int a = 1; a < d; ++a) {
-        // (forked: the last coarse launch of this constraint carries the join event)
-        hipExtLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, cst, nullptr,
-                              (fork && a == d - 1) ? c->ev_join[cidx] : nullptr, 0, (const double*)dc0, dc1, nc, cstride,
-                              (int)cg.ccount[a], c->cs.step[a] * kCoarse, (const SweepScalars*)sc, cidx,
-                              (const unsigned long long*)c->Lmax.p, lidx, 0, cap_extra);
-        std::swap(dc0, dc1);
-        cstride *= cg.ccount[a];
-      }
-      cg.Dc = dc0;
+      if ((rc = ensure(c->coarse, cbytes))) return rc;
+      dc0 = (double*)c->coarse.p;
+      dc1 = dc0 + nc;
+      Uc = (uint8_t*)(dc1 + nc);
     }
-    if (fork) {
-      if (!coarse_ok) return fail(SBO_E_HIP, "internal: forked set phase without a coarse transform");
-      SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_join[cidx], 0));      // (placed before the verdict kernel below)
+    const double cap_extra = 2.0 * cg.delta + 2.0 * kCoarse * hmax;
+    const int last_cnt_ = d >= 2 ? (int)wplanes : 1;
+    const int blk_ = last_cnt_ >= 8192 ? 64 : 32;
+    const bool want_bmin = d >= 2 && last_cnt_ >= 4 * blk_ && c->scan_blocks;
+    // 2-D grids: the two axis-0 passes share a launch, and so do the coarse last-axis scan, the minimiser and the block minima
+    const bool paired = d == 2 && coarse_ok && c->set_fuse && count0 <= kAxis0Max && count0 >= 128 && cc0 >= 128;
+    bool bmin_done = false;
+    double* din = (double*)c->dist2.p;
+    double* dout = (double*)c->dist2b.p;
+    long long stride = count0;
+    if (paired) {
+      const int nfine = (int)std::min<long long>(nlines, 1 << 20), ncoarse = (int)std::min<long long>(clines, 1 << 20);
+      FinalJob fin;
+      if (mj && mj->fin.pending) {
+        fin = mj->fin;
+        mj->fin.pending = false;
+      }
+      hipLaunchKernelGGL(k_edt_axis0_pair, dim3((unsigned)(nfine + ncoarse + (fin.pending ? 1 : 0))), dim3(256), 0, c->stream, Uall,
+                         nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin);
+      MidJobs<T> j;
+      memset(&j, 0, sizeof(j));
+      j.sc = sc;
+      j.Lkeys = (const unsigned long long*)c->Lmax.p;
+      j.ns = (int)std::min<long long>((nc + 255) / 256, 1 << 16);
+      j.dc_in = dc0;
+      j.dc_out = dc1;
+      j.nc = nc;
+      j.cstride = cc0;
+      j.ccnt = (int)cg.ccount[1];
+      j.hc = c->cs.step[1] * kCoarse;
+      j.cidx = cidx;
+      j.lidx = lidx;
+      j.cap_extra = cap_extra;
+      if (mj && mj->pending) {
+        mj->pending = false;
+        j.nb = mj->nb;
+        j.mean0 = (const T*)c->mean.p;
+        j.var0 = (const T*)c->var.p;
+        j.n = n;
+        j.first = (long long)c->cs.first;
+        j.b = (T)o->b;
+        j.S = (const uint8_t*)c->maskS.p;
+        j.M = (uint8_t*)c->maskM.p;
+        j.partial = mj->partial;
+      }
+      if (want_bmin) {
+        const int nblocks = (last_cnt_ + blk_ - 1) / blk_;
+        if ((rc = ensure(c->blockmin, sizeof(double) * (size_t)nblocks * (size_t)stride))) return rc;
+        j.nm = (int)std::min<long long>((stride + 63) / 64 * nblocks, 1 << 20);
+        j.din = din;
+        j.stride = stride;
+        j.cnt = last_cnt_;
+        j.blk = blk_;
+        j.bmin = (double*)c->blockmin.p;
+        bmin_done = true;
+      }
+      hipLaunchKernelGGL((k_set_mid<T>), dim3((unsigned)(j.ns + j.nb + j.nm)), dim3(256), 0, c->stream, j);
+      cg.Dc = dc1;
+    } else {
+      launch_minimizer<T>(c, o, mj);
+      launch_edt_axis0(c, Uall, nlines, count0, c->cs.step[0], din);
+      for (int a = 1; a < d - 1; ++a) {
+        hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nt + 255) / 256, 1 << 20)), dim3(256), 0, c->stream,
+                           (const double*)din, dout, nt, stride, (int)c->cs.count[a], c->cs.step[a],
+                           (const SweepScalars*)sc, cidx, (const unsigned long long*)c->Lmax.p, lidx, 0, 0.0);
+        std::swap(din, dout);
+        stride *= c->cs.count[a];
+      }
+      if (coarse_ok) {
+        if (cc0 <= kAxis0Max && cc0 >= 128) {
+          // the coarse axis-0 pass forms the cells' bits from the fine mask itself
+          hipLaunchKernelGGL(k_edt_axis0_wg<true>, dim3((unsigned)std::min<long long>(clines, 1 << 20)), dim3(256), 0, c->stream, Uall,
+                             clines, cc0, c->cs.step[0] * kCoarse, dc0, cg);
+        } else {
+          hipLaunchKernelGGL(k_coarsen_mask, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
+                             Uall, cg, nc, Uc);
+          launch_edt_axis0(c, (const uint8_t*)Uc, clines, cc0, c->cs.step[0] * kCoarse, dc0);
+        }
+        long long cstride = cc0;
+        for (int a = 1; a < d; ++a) {
+          hipLaunchKernelGGL(k_edt_scan, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
+                             (const double*)dc0, dc1, nc, cstride, (int)cg.ccount[a], c->cs.step[a] * kCoarse, (const SweepScalars*)sc,
+                             cidx, (const unsigned long long*)c->Lmax.p, lidx, 0, cap_extra);
+          std::swap(dc0, dc1);
+          cstride *= cg.ccount[a];
+        }
+        cg.Dc = dc0;
+      }
     }
     double xscale = 0.0;
     for (int a = 0; a < d; ++a) xscale = std::max(xscale, std::max(std::fabs(c->cs.lo[a]), std::fabs(c->cs.hi[a])));
     const int last_cnt = d >= 2 ? (int)wplanes : 1;
     const double last_h = d >= 2 ? c->cs.step[d - 1] : 0.0;
     {
-      const double* bmin = nullptr;
-      const int blk = last_cnt >= 8192 ? 64 : 32;
-      if (d >= 2 && last_cnt >= 4 * blk && c->scan_blocks) {
+      const double* bmin = bmin_done ? (const double*)c->blockmin.p : nullptr;
+      const int blk = blk_;
+      if (!bmin_done && want_bmin) {
         const long long nb_ = (long long)((last_cnt + blk - 1) / blk) * stride;
         if ((rc = ensure(c->blockmin, sizeof(double) * (size_t)nb_))) return rc;
         hipLaunchKernelGGL(k_block_min, dim3((unsigned)std::min<long long>((stride + 63) / 64 * ((last_cnt + blk - 1) / blk), 1 << 20)), dim3(256), 0, c->stream,
@@ -796,6 +933,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     }
   } else {
     // explicit candidate lists, and grid ranges that are not whole hyper-planes: exhaustive evaluation
+    launch_minimizer<T>(c, o, mj);
     if (n > (1ll << 17))
       return fail(SBO_E_UNSUPPORTED, "expander sets need a grid of whole hyper-planes, or at most 131072 candidates (exhaustive)");
     if (multi_rank(c))
@@ -944,10 +1082,12 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   c->fuse_request = false;
+  c->lmax_defer = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
-  const bool fork = set_phase_forks(c);
-  if ((rc = sweep_common_front<T>(c, o, fork))) return rc;
+  MinimizerJob mj;
+  const bool defer = q >= 2 && !multi_rank(c) && c->set_fuse && n > 0;
+  if ((rc = sweep_common_front<T>(c, o, defer ? &mj.fin : nullptr))) return rc;
   if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
@@ -955,14 +1095,18 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   const size_t pstride = (sizeof(Best) + sizeof(long long)) * (size_t)nb;
   if ((rc = ensure(c->partial, pstride * (size_t)q))) return rc;
   unsigned char* pbase = (unsigned char*)c->partial.p;
-  if (n > 0)
-    hipLaunchKernelGGL((k_minimizer<T>), dim3(nb), dim3(256), 0, fork ? c->stream2 : c->stream, (const T*)c->mean.p, (const T*)c->var.p, n,
-                       (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, sc, (Best*)pbase);
+  // (single rank: the minimiser rides in the first constraint's k_set_mid; with ranks > 1 it is queued here, ahead of the
+  // host's wait for the C1 keys)
+  mj.pending = n > 0;
+  mj.nb = nb;
+  mj.partial = (Best*)pbase;
+  if (q < 2 || multi_rank(c)) launch_minimizer<T>(c, o, &mj);
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
   for (int cc = 1; cc < q; ++cc) {
     uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
-    if ((rc = expander_set<T>(c, o, cc, G, fork))) return rc;
+    if ((rc = expander_set<T>(c, o, cc, G, &mj))) return rc;
   }
+  launch_minimizer<T>(c, o, &mj);
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   for (int cc = 1; cc < q; ++cc) {
     const uint8_t* G = (const uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
@@ -1309,6 +1453,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   c->fuse_request = false;
+  c->lmax_defer = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
   if ((rc = sweep_common_front<T>(c, o))) return rc;
@@ -1455,6 +1600,7 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
   if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   c->fuse_request = false;
+  c->lmax_defer = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
   if ((rc = sweep_common_front<T>(c, o))) return rc;

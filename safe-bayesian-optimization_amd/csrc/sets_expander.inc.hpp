@@ -91,16 +91,22 @@ __device__ __forceinline__ bool coarse_cell_any(const uint8_t* __restrict__ U, c
 // COARSE: the lines are lines of coarse cells and the bit of a cell is formed here from the fine mask (no coarse mask in
 // memory, one launch less).
 constexpr int kAxis0Max = 65536;
+struct Axis0Lds {
+  unsigned long long words[kAxis0Max / 64];
+  int lastw[kAxis0Max / 64];    // index of the last set bit in words 0..w (-1: none)
+  int firstw[kAxis0Max / 64];   // index of the first set bit in words w.. (INT_MAX: none)
+};
+// (bid / nblk: this workgroup's index and the number of workgroups on this job -- the job may be one range of a launch)
 template <bool COARSE>
-__global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
-                                                      double* __restrict__ D, const CoarseGrid cg) {
-  __shared__ unsigned long long words[kAxis0Max / 64];
-  __shared__ int lastw[kAxis0Max / 64];    // index of the last set bit in words 0..w (-1: none)
-  __shared__ int firstw[kAxis0Max / 64];   // index of the first set bit in words w.. (INT_MAX: none)
+__device__ __forceinline__ void edt_axis0_wg_body(int bid, int nblk, Axis0Lds& lds, const uint8_t* __restrict__ U, long long nlines,
+                                                  int count0, double h0, double* __restrict__ D, const CoarseGrid& cg) {
+  unsigned long long* words = lds.words;
+  int* lastw = lds.lastw;
+  int* firstw = lds.firstw;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwords = (count0 + 63) >> 6;
   constexpr int kNone = 0x7fffffff;
-  for (long long line = blockIdx.x; line < nlines; line += gridDim.x) {
+  for (long long line = bid; line < nlines; line += nblk) {
     const uint8_t* u = U + line * count0;
     double* d = D + line * count0;
     for (int w = wave; w < nwords; w += 4) {
@@ -157,6 +163,24 @@ __global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict_
     __syncthreads();
   }
 }
+template <bool COARSE>
+__global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
+                                                      double* __restrict__ D, const CoarseGrid cg) {
+  __shared__ Axis0Lds lds;
+  edt_axis0_wg_body<COARSE>((int)blockIdx.x, (int)gridDim.x, lds, U, nlines, count0, h0, D, cg);
+}
+// fine and coarse axis-0 passes of a 2-D grid in one launch (both read the U mask only): workgroups [0, nfine) take the
+// fine lines, the rest the lines of coarse cells
+// (+ one workgroup for the merge of the classification's partials when `fin` is pending: nothing here reads the scalars)
+__global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
+                                                        double* __restrict__ D, int nfine, int ncoarse, long long clines, int cc0,
+                                                        double h0c, double* __restrict__ Dc, const CoarseGrid cg, const FinalJob fin) {
+  __shared__ Axis0Lds lds;
+  const int bid = (int)blockIdx.x;
+  if (bid < nfine) edt_axis0_wg_body<false>(bid, nfine, lds, U, nlines, count0, h0, D, cg);
+  else if (bid < nfine + ncoarse) edt_axis0_wg_body<true>(bid - nfine, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
+  else classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax);
+}
 
 // axes >= 1: D_out[g] = min_t D_in[g + t stride] + (h t)^2, searched outwards with the two exits
 //   (h t)^2 >= best  (nothing further can improve)  and  h t > cap  (beyond any radius that matters).
@@ -194,15 +218,14 @@ __device__ __forceinline__ double edt_scan_point(const double* __restrict__ Din,
 // with one load instead of `blk`; the candidates examined inside a block and their arithmetic are those of the
 // step-by-step scan, so the minimum (up to the same early exits) is identical.  This keeps the scan cost near
 // O(sqrt(radius in steps)) when the grid is much finer along the last axis than the radius (weak-scaling grids).
-__global__ __launch_bounds__(256) void k_block_min(const double* __restrict__ Din, long long stride, int cnt, int blk,
-                                                   double* __restrict__ Bmin) {
+__device__ __forceinline__ void block_min_body(int bid, int nwg, double (&part)[4][64], const double* __restrict__ Din, long long stride,
+                                               int cnt, int blk, double* __restrict__ Bmin) {
   // 64 in-plane positions x 4 quarters of a block per workgroup: a thread takes blk / 4 steps (all loads in flight),
   // the quarters meet in LDS
-  __shared__ double part[4][64];
   const int nblk = (cnt + blk - 1) / blk;
   const int px = threadIdx.x & 63, sub = threadIdx.x >> 6, per = (blk + 3) / 4;
   const long long ptiles = (stride + 63) / 64, total = ptiles * nblk;
-  for (long long w = blockIdx.x; w < total; w += gridDim.x) {
+  for (long long w = bid; w < total; w += nwg) {
     const long long p = (w % ptiles) * 64 + px;
     const int b = (int)(w / ptiles);
     const int j0 = b * blk + sub * per;
@@ -225,6 +248,11 @@ __global__ __launch_bounds__(256) void k_block_min(const double* __restrict__ Di
     }
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(256) void k_block_min(const double* __restrict__ Din, long long stride, int cnt, int blk,
+                                                   double* __restrict__ Bmin) {
+  __shared__ double part[4][64];
+  block_min_body((int)blockIdx.x, (int)gridDim.x, part, Din, stride, cnt, blk, Bmin);
 }
 
 // Euclidean form (values >= 0, exits as edt_scan_point: (h t)^2 >= best, h t > cap, best <= accept2).
@@ -310,19 +338,24 @@ __device__ __forceinline__ double edt_scan_blocked(const double* __restrict__ Di
   return best;
 }
 
-__global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din, double* __restrict__ Dout, long long n,
-                                                  long long stride, int cnt, double h, const SweepScalars* sc, int c,
-                                                  const unsigned long long* Lkeys, int lidx, int uncapped, double cap_extra) {
+__device__ __forceinline__ void edt_scan_body(int bid, int nwg, const double* __restrict__ Din, double* __restrict__ Dout, long long n,
+                                              long long stride, int cnt, double h, const SweepScalars* sc, int c,
+                                              const unsigned long long* Lkeys, int lidx, int uncapped, double cap_extra) {
   // cap: offsets beyond the largest radius that can matter are not examined.  The coarse transform passes
   // cap_extra = 2 delta + two coarse steps: a cell whose true distance lies beyond that cap is "beyond every radius" by
   // the sandwich dC -+ delta whether its stored value is the true minimum or a larger one.
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const double rmax = sc->rmax_key[c] ? ord_val(sc->rmax_key[c]) : 0.0;
   const double cap = (L > 0 && !uncapped) ? rmax / L * 1.000001 + 1e-6 + cap_extra : kInfD;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+  for (long long g = (long long)bid * blockDim.x + threadIdx.x; g < n; g += (long long)nwg * blockDim.x) {
     const int ia = (int)((g / stride) % cnt);
     Dout[g] = edt_scan_point(Din, g, stride, cnt, ia, h, cap);
   }
+}
+__global__ __launch_bounds__(256) void k_edt_scan(const double* __restrict__ Din, double* __restrict__ Dout, long long n,
+                                                  long long stride, int cnt, double h, const SweepScalars* sc, int c,
+                                                  const unsigned long long* Lkeys, int lidx, int uncapped, double cap_extra) {
+  edt_scan_body((int)blockIdx.x, (int)gridDim.x, Din, Dout, n, stride, cnt, h, sc, c, Lkeys, lidx, uncapped, cap_extra);
 }
 
 // Coarse pre-decision for the expander query.  The U mask is OR-reduced over cells of kCoarse^d candidates and the
