@@ -126,7 +126,10 @@ struct sbo_ctx {
   bool lmax_pending = false;
   int lmax_per_out = 0;
   sbo::DevBuf Wfull;   // multi-rank GoOSE: source weights of the whole grid (all-gathered), T [grid_total]
-  sbo::DevBuf Ufull;   // multi-rank: U mask of the whole grid (all-gathered), uint8 [grid_total]
+  sbo::DevBuf Uwin;    // multi-rank: U mask of the expander transform's window (own planes + halo), uint8
+  long long uwin_first = 0, uwin_n = 0;   // flat range the window covers
+  sbo::DevBuf ubits;                      // multi-rank: own U bits (gather_words words) followed by every rank's (all-gathered)
+  long long gather_words = 0;             // words per rank in ubits
   sbo::DevBuf gather;  // multi-rank: all-gather receive buffer [world][max_local]
   sbo::DevBuf xch;     // multi-rank: small exchange buffers (C1 keys, C3 rows)
   sbo::DevBuf shard_first;  // device copy of first_of[]

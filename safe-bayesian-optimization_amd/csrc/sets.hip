@@ -655,12 +655,12 @@ static int launch_exact(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lidx,
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const T* mean_c = (const T*)c->mean.p + (size_t)cidx * n;
   const T* var_c = (const T*)c->var.p + (size_t)cidx * n;
-  CandSpec csU = c->cs;          // the witness set: every candidate of every rank
+  CandSpec csU = c->cs;          // the witness set: every candidate that can matter (ranks > 1: the transform's window)
   const uint8_t* Uall = (const uint8_t*)c->maskU.p;
   if (multi_rank(c)) {
-    csU.first = 0;
-    csU.n_local = c->grid_total;
-    Uall = (const uint8_t*)c->Ufull.p;
+    csU.first = c->uwin_first;
+    csU.n_local = c->uwin_n;
+    Uall = (const uint8_t*)c->Uwin.p;
   }
   hipLaunchKernelGGL((k_expander_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, csU, mean_c, var_c, (T)o->b,
                      Uall, (const unsigned long long*)c->Lmax.p, lidx, sc,
@@ -752,7 +752,17 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     const long long wplanes = p1 - p0;
     const long long nt = wplanes * plane;
     const long long goff = (own0 - p0) * plane;                 // own candidates start here inside the window
-    const uint8_t* Uall = multi_rank(c) ? (const uint8_t*)c->Ufull.p + p0 * plane : (const uint8_t*)c->maskU.p;
+    const uint8_t* Uall = (const uint8_t*)c->maskU.p;
+    if (multi_rank(c)) {
+      // bytes of the window only, out of the all-gathered bit words (the gather itself was queued ahead of the host's wait)
+      if ((rc = ensure(c->Uwin, (size_t)nt))) return rc;
+      const unsigned long long* recvw = (const unsigned long long*)c->ubits.p + c->gather_words;
+      hipLaunchKernelGGL(k_unpack_shards, dim3((unsigned)std::min<long long>((nt + 255) / 256, 1 << 16)), dim3(256), 0, c->stream, recvw,
+                         c->gather_words, c->world, (const long long*)c->shard_first.p, p0 * plane, nt, (uint8_t*)c->Uwin.p);
+      c->uwin_first = p0 * plane;
+      c->uwin_n = nt;
+      Uall = (const uint8_t*)c->Uwin.p;
+    }
     if ((rc = ensure(c->dist2, sizeof(double) * (size_t)nt))) return rc;
     if (d > 2 && (rc = ensure(c->dist2b, sizeof(double) * (size_t)nt))) return rc;
     const int count0 = d >= 2 ? (int)c->cs.count[0] : (int)nt;  // d == 1: the window is one line
@@ -972,7 +982,7 @@ static void coords_of(const sbo_ctx* c, long long gidx, double* x) {
 
 int sbo_posterior_enqueue_(sbo_ctx* c);
 
-// (ranks > 1) C1: global u*, L and radius keys; C2: whole-grid U mask
+// (ranks > 1) C1: global u*, L and radius keys; C2: every rank's U mask as bit words
 template <typename T>
 static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U) {
   const int q = c->mc.q;
@@ -997,16 +1007,15 @@ static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U
     long long maxlocal = 0;
     for (int r = 0; r < c->world; ++r) maxlocal = std::max(maxlocal, c->first_of[r + 1] - c->first_of[r]);
     const long long words = (maxlocal + 63) / 64;
-    if ((rc = ensure(c->gather, sizeof(unsigned long long) * (size_t)words * (c->world + 1)))) return rc;
-    if ((rc = ensure(c->Ufull, (size_t)c->grid_total))) return rc;
-    unsigned long long* sendw = (unsigned long long*)c->gather.p;
+    // (their own buffer: the words are read again per constraint, after GoOSE's weight exchanges have used `gather`)
+    if ((rc = ensure(c->ubits, sizeof(unsigned long long) * (size_t)words * (c->world + 1)))) return rc;
+    c->gather_words = words;
+    unsigned long long* sendw = (unsigned long long*)c->ubits.p;
     unsigned long long* recvw = sendw + words;
     hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)std::min<long long>((words + 3) / 4, 1 << 16)), dim3(256), 0, c->stream,
                        (const uint8_t*)c->maskU.p, c->cs.n_local, words, sendw);
     if ((rc = comm_allgather_bytes(c, sendw, recvw, sizeof(unsigned long long) * (size_t)words))) return rc;
-    hipLaunchKernelGGL(k_unpack_shards, dim3((unsigned)std::min<long long>((c->grid_total + 255) / 256, 1 << 16)), dim3(256), 0,
-                       c->stream, (const unsigned long long*)recvw, words, c->world, (const long long*)c->shard_first.p,
-                       c->grid_total, (uint8_t*)c->Ufull.p);
+    (void)recvw;      // (expanded to bytes per constraint, window only: expander_set)
   }
   SBO_HIP(hipGetLastError());
   return SBO_OK;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_compact_shards(const E* __restrict__ re
     full[g] = recv[(size_t)r * maxlocal + (g - first_of[r])];
   }
 }
-// C2 (bit form): own mask -> one word per 64 candidates (zero beyond n); gathered words -> whole-grid byte mask
+// C2 (bit form): own mask -> one word per 64 candidates (zero beyond n); gathered words -> byte mask of a window
 __global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ U, long long n, long long words,
                                                    unsigned long long* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -35,14 +35,16 @@ __global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ U
     if (lane == 0) out[w] = m;
   }
 }
+// (only the flat range [g0, g0 + total) a rank's transform window covers is expanded to bytes: out[g - g0])
 __global__ __launch_bounds__(256) void k_unpack_shards(const unsigned long long* __restrict__ recv, long long words, int world,
-                                                       const long long* __restrict__ first_of, long long total,
-                                                       uint8_t* __restrict__ full) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+                                                       const long long* __restrict__ first_of, long long g0, long long total,
+                                                       uint8_t* __restrict__ out) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long g = g0 + t;
     int r = 0;
     while (r + 1 < world && g >= first_of[r + 1]) ++r;
     const long long l = g - first_of[r];
-    full[g] = (uint8_t)((recv[(size_t)r * words + (l >> 6)] >> (l & 63)) & 1ull);
+    out[t] = (uint8_t)((recv[(size_t)r * words + (l >> 6)] >> (l & 63)) & 1ull);
   }
 }
 // C3: each rank fills its own row of [world][kC3Row] doubles, one sum all-reduce delivers every row everywhere
