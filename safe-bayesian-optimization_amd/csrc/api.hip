@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <chrono>
 #include "internal.hpp"
 #include "device_common.hpp"
 
@@ -33,6 +34,20 @@ int ensure(DevBuf& b, size_t bytes) {
   b.bytes = bytes;
   return SBO_OK;
 }
+// The runtime's blocking wait parks the thread and wakes it through an interrupt (~15-25 us after the stream drained); a
+// sweep is 0.3 ms, so the host polls for up to 5 ms first and only then sleeps.
+hipError_t stream_wait(const sbo_ctx* c, hipStream_t st) {
+  if (c->spin_wait) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(st);
+      if (e != hipErrorNotReady) return e;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+  }
+  return hipStreamSynchronize(st);
+}
+
 void release(DevBuf& b) {
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr;
@@ -184,6 +199,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   }
   if (!strcmp(key, "scan_waves")) {
     c->scan_waves = (int)value;   // 0: off; 8 / 16 / 32 / 64: lanes per listed candidate (anything else: the default, 16)
+    return SBO_OK;
+  }
+  if (!strcmp(key, "spin_wait")) {
+    c->spin_wait = value ? 1 : 0;
     return SBO_OK;
   }
   if (!strcmp(key, "set_fuse")) {

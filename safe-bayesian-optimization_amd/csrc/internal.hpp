@@ -154,6 +154,7 @@ struct sbo_ctx {
   int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
   int scan_waves = 1;      // 1: candidates the coarse bounds leave open are scanned one wave each (0: by their own thread)
   int scan_blocks = 1;     // 0: step-by-step last-axis scans (A/B against the blocked form)
+  int spin_wait = 1;       // the host polls the stream at the end of a sweep / model build instead of sleeping in the runtime's wait (0: hipStreamSynchronize)
   int set_fuse = 1;        // 2-D grids: independent set-phase kernels share launches (k_edt_axis0_pair, k_set_mid); 0: one launch each
   int fuse_classify = 0;   // (A/B option, measured no faster: the f64 sqrt of the bounds costs the matrix kernel what the separate pass saves) 1: one-constraint sweeps on the K1b path take their S / U bytes from the posterior kernel's epilogue
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
@@ -185,6 +186,7 @@ inline bool multi_rank(const sbo_ctx* c) { return c->world > 1 || c->comm_selfte
 int fail(int code, const std::string& msg);
 int hip_fail(hipError_t e, const char* what);
 int ensure(DevBuf& b, size_t bytes);
+hipError_t stream_wait(const sbo_ctx* c, hipStream_t st);   // hipStreamSynchronize, polling first (option spin_wait)
 void release(DevBuf& b);
 
 // launchers implemented in the .hip files -----------------------------------------------------

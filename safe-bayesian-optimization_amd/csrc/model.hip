@@ -656,8 +656,8 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
   SBO_HIP(hipGetLastError());
   int* hbad = (int*)(c->h_back + 4608);
   SBO_HIP(hipMemcpyAsync(hbad, w.bad, sizeof(int) * q, hipMemcpyDeviceToHost, c->stream));
-  SBO_HIP(hipStreamSynchronize(c->stream));
-  if (eager_basis) SBO_HIP(hipStreamSynchronize(c->stream2));
+  SBO_HIP(stream_wait(c, c->stream));
+  if (eager_basis) SBO_HIP(stream_wait(c, c->stream2));
   for (int o = 0; o < q; ++o)
     if (hbad[o]) return fail(SBO_E_INVALID, host_invK ? "invK is not positive definite" : "K + sn2 I is not positive definite");
   return SBO_OK;

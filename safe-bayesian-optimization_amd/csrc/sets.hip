@@ -1042,7 +1042,7 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   if (!multi_rank(c)) {
     SBO_HIP(hipMemcpyAsync(c->h_back, sc, kBack, hipMemcpyDeviceToHost, c->stream));
     if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
-    SBO_HIP(hipStreamSynchronize(c->stream));
+    SBO_HIP(stream_wait(c, c->stream));
     memcpy(&h, c->h_back, sizeof(h));
     if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
     return SBO_OK;
@@ -1055,7 +1055,7 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   SBO_HIP(hipMemcpyAsync(c->h_back, sc, kBack, hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipMemcpyAsync(rows.data(), buf, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, c->stream));
   if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
-  SBO_HIP(hipStreamSynchronize(c->stream));
+  SBO_HIP(stream_wait(c, c->stream));
   memcpy(&h, c->h_back, sizeof(h));
   if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
   c->c1_pending = false;                       // (the whole stream has drained)
