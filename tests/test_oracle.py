@@ -213,3 +213,25 @@ def test_extended_precision_evaluation_brackets_the_fp64_oracle():
     gm, gv = extended.posterior_given_invK(pts, hard)
     e_formula = float(np.max(np.abs(ov - gv)))
     assert 1e-11 < e_formula < 1e-5
+
+
+@pytest.mark.parametrize("cfg_name,n,count,b", [("B", 40, [61, 47], 3.0), ("C", 64, [40, 33], 2.0), ("D", 48, [7, 6, 5, 4], 0.5)])
+def test_openmp_restatement_matches_the_numpy_oracle(cfg_name, n, count, b):
+    """oracle/c/sweep_omp.c (the multi-threaded CPU column of bench.py) against oracle.safeopt_sweep: posterior to rounding
+    (the sums of k^T invK run in another order), masks / u* / minimiser equal, whole grid and a ragged sub-range."""
+    from oracle import omp
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, count)
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], b)
+    got = omp.safeopt_sweep(lo, hi, count, cfg["ds"], b, want_posterior=True, want_masks=True)
+    ys = np.maximum(1.0, cfg["ds"]["Y_std"])
+    assert np.max(np.abs(got["mean"] - ref["mean"]) / ys) < 1e-10 and np.max(np.abs(got["var"] - ref["var"]) / ys ** 2) < 1e-10
+    for k in ("S", "U", "M"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert got["count_S"] == int(ref["S"].sum()) and got["count_M"] == int(ref["M"].sum())
+    assert got["minimizer_index"] == ref["minimizer_index"] and got["u_star"] == pytest.approx(ref["u_star"], rel=1e-10)
+    first, m = 37, 301
+    sub = omp.safeopt_sweep(lo, hi, count, cfg["ds"], b, first=first, n=m, want_posterior=True, want_masks=True)
+    assert np.array_equal(sub["mean"], got["mean"][first:first + m]) and np.array_equal(sub["S"], got["S"][first:first + m])
+    assert omp.threads() >= 1
