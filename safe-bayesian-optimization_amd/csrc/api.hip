@@ -201,6 +201,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->scan_waves = (int)value;   // 0: off; 8 / 16 / 32 / 64: lanes per listed candidate (anything else: the default, 16)
     return SBO_OK;
   }
+  if (!strcmp(key, "eager_tables")) {
+    c->eager_tables = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "spin_wait")) {
     c->spin_wait = value ? 1 : 0;
     return SBO_OK;
@@ -290,6 +294,10 @@ static int model_set_impl(sbo_ctx* c, int dtype, const char* kernel, int n, int 
   // derived arrays (As, sqA, Xn, rhs), factorisation, alpha and the fragment images of the factor: on the device (model.hip)
   int rc = model_build(c, invK, X_norm, Y_norm);
   if (rc) return rc;
+  // A grid is resident and qualifies for the GEMM posterior: its per-(model, grid) tables are enqueued now, so that they
+  // run while the caller is on its way from this call to the sweep (the bases' ranks came back with the build's own
+  // synchronisation; nothing here waits).  A grid change before the next sweep simply drops the plan.
+  if (c->eager_tables && !c->is_shadow && bilinear_applicable(c) && (rc = bilinear_setup(c))) return rc;
   if (dtype == SBO_F32 && c->fp64_recheck && !c->is_shadow) {
     // the fp64 twin: same constants, double arrays and factor images (built from the same inputs)
     if ((rc = shadow_ensure(c))) return rc;
