@@ -292,32 +292,38 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ work, d
     for (int idx = tid; idx < kPB * kPB; idx += blockDim.x) dg[idx] = D[idx / kPB][idx % kPB];
   }
   // columns: [kb + kw, n) of U, then (with E) [0, kb + kw) of E
+  // A column per half wave, a ROW per lane (lane r holds element r of the column and column r of the factored block): the
+  // forward substitution runs as kPB steps of "lane t divides, everyone below subtracts" with the finished element
+  // broadcast by v_readlane.  A thread per column walked the same 496 dependent multiply-adds and 32 divisions alone
+  // (26 us per panel at n = 512, eight waves on the whole GPU); here a column's chain is the 32 divisions, and the
+  // columns spread over as many waves as there are pairs of them.  Same operations in the same order per element.
   const int nright = n - kb - kw;
   const int ncols = nright + (with_E ? kb + kw : 0);
-  for (int x = blockIdx.x * blockDim.x + tid; x < ncols; x += gridDim.x * blockDim.x) {
-    double v[kPB];
+  const int lane = tid & 63, r = lane & 31, half = lane >> 5;
+  double dcol[kPB];
+#pragma unroll
+  for (int t = 0; t < kPB; ++t) dcol[t] = D[t][r];
+  const double drr = D[r][r];
+  const int pairs_total = (ncols + 1) / 2;
+  for (int pr = blockIdx.x * (blockDim.x >> 6) + (tid >> 6); pr < pairs_total; pr += gridDim.x * (blockDim.x >> 6)) {
+    const int x = 2 * pr + half;
+    const bool live = x < ncols && r < kw;
     const bool isU = x < nright;
     const int col = isU ? kb + kw + x : x - nright;
     double* base = isU ? U : E;
+    double acc = 0.0;
+    if (live) acc = (!isU && col >= kb) ? (col - kb == r ? 1.0 : 0.0) : base[(size_t)(kb + r) * n + col];
 #pragma unroll
-    for (int r = 0; r < kPB; ++r) {
-      double a = 0.0;
-      if (r < kw) a = (!isU && col >= kb) ? (col - kb == r ? 1.0 : 0.0) : base[(size_t)(kb + r) * n + col];
-      v[r] = a;
-    }
-#pragma unroll
-    for (int r = 0; r < kPB; ++r) {
-      if (r < kw) {
-        double acc = v[r];
-#pragma unroll
-        for (int t = 0; t < kPB; ++t)
-          if (t < r) acc -= D[t][r] * v[t];
-        v[r] = acc / D[r][r];
+    for (int t = 0; t < kPB; ++t) {
+      if (t < kw) {
+        if (r == t) acc = acc / drr;
+        // the finished element t of either half's column
+        const double v0 = readlane_f64(acc, t), v1 = readlane_f64(acc, 32 + t);
+        const double vt = half ? v1 : v0;
+        if (r > t) acc -= dcol[t] * vt;
       }
     }
-#pragma unroll
-    for (int r = 0; r < kPB; ++r)
-      if (r < kw && (isU || col <= kb + r)) base[(size_t)(kb + r) * n + col] = v[r];
+    if (live && (isU || col <= kb + r)) base[(size_t)(kb + r) * n + col] = acc;
   }
 }
 
@@ -628,8 +634,9 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
     for (int kb = 0; kb < n; kb += kPB) {
       const int kw = std::min(kPB, n - kb);
       const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
-      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, (ncols + 255) / 256), q), dim3(256), 0, c->stream, w.work, dF, mode, n,
-                         kb, w.bad, w.Dg);
+      // (a half wave per column: four pairs of columns per workgroup)
+      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, ((ncols + 1) / 2 + 3) / 4), q), dim3(256), 0, c->stream, w.work, dF, mode,
+                         n, kb, w.bad, w.Dg);
       const int rest = n - kb - kw;
       if (rest > 0) {
         const unsigned ti = (unsigned)((rest + 31) / 32);
