@@ -312,8 +312,17 @@ __device__ __forceinline__ int basis_pivot_loop(int n, int rc, double* res, doub
       }
       __syncthreads();
       if (tid < rc) {
-        mine = qv[tid];
-        for (int i = 0; i < r; ++i) mine -= cf[i] * Q[(size_t)i * rc + tid];
+        // (four partial sums: the chain of dependent multiply-adds, not their count, is what a step waits for)
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        int i = 0;
+        for (; i + 3 < r; i += 4) {
+          p0 += cf[i] * Q[(size_t)i * rc + tid];
+          p1 += cf[i + 1] * Q[(size_t)(i + 1) * rc + tid];
+          p2 += cf[i + 2] * Q[(size_t)(i + 2) * rc + tid];
+          p3 += cf[i + 3] * Q[(size_t)(i + 3) * rc + tid];
+        }
+        for (; i < r; ++i) p0 += cf[i] * Q[(size_t)i * rc + tid];
+        mine = qv[tid] - ((p0 + p1) + (p2 + p3));
       }
       if (pass == 0) {
         if (tid < rc) qv[tid] = mine;
@@ -333,15 +342,26 @@ __device__ __forceinline__ int basis_pivot_loop(int n, int rc, double* res, doub
     bv = -1.0;
     bi = 0x7fffffff;
     for (int j = tid; j < n; j += NT) {
-      double d_ = 0.0;
-      for (int cidx = 0; cidx < rc; ++cidx) d_ += res[(size_t)cidx * n + j] * qv[cidx];
-      U[(size_t)r * n + j] = d_;
-      double nn = 0.0;
-      for (int cidx = 0; cidx < rc; ++cidx) {
-        const double v = res[(size_t)cidx * n + j] - d_ * qv[cidx];
-        res[(size_t)cidx * n + j] = v;
-        nn += v * v;
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;         // (rc is a multiple of 16)
+      for (int cidx = 0; cidx < rc; cidx += 4) {
+        d0 += res[(size_t)cidx * n + j] * qv[cidx];
+        d1 += res[(size_t)(cidx + 1) * n + j] * qv[cidx + 1];
+        d2 += res[(size_t)(cidx + 2) * n + j] * qv[cidx + 2];
+        d3 += res[(size_t)(cidx + 3) * n + j] * qv[cidx + 3];
       }
+      const double d_ = (d0 + d1) + (d2 + d3);
+      U[(size_t)r * n + j] = d_;
+      double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+      for (int cidx = 0; cidx < rc; cidx += 4) {
+        const double v0 = res[(size_t)cidx * n + j] - d_ * qv[cidx], v1 = res[(size_t)(cidx + 1) * n + j] - d_ * qv[cidx + 1];
+        const double v2 = res[(size_t)(cidx + 2) * n + j] - d_ * qv[cidx + 2], v3 = res[(size_t)(cidx + 3) * n + j] - d_ * qv[cidx + 3];
+        res[(size_t)cidx * n + j] = v0;
+        res[(size_t)(cidx + 1) * n + j] = v1;
+        res[(size_t)(cidx + 2) * n + j] = v2;
+        res[(size_t)(cidx + 3) * n + j] = v3;
+        n0 += v0 * v0; n1 += v1 * v1; n2 += v2 * v2; n3 += v3 * v3;
+      }
+      const double nn = (n0 + n1) + (n2 + n3);
       if (nn > bv) { bv = nn; bi = j; }
     }
     ++r;
