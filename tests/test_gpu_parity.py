@@ -916,6 +916,44 @@ def test_fused_classification_equals_the_separate_pass(engine, cfg_name, n, coun
         assert out[1][0]["u_star"] == pytest.approx(ref["u_star"], rel=1e-10) and out[1][0]["count_U"] == int(ref["U"].sum())
 
 
+@pytest.mark.parametrize("cfg_name,n,count,b", [("B", 128, [1100, 1024], 3.0), ("C", 96, [1040, 1030], 2.0), ("H", 300, [1056, 1500], 3.0),
+                                                  ("B", 40, [1032, 1027], 1.0)])
+def test_shared_set_phase_launches_equal_one_launch_per_kernel(engine, cfg_name, n, count, b):
+    """On 2-D grids of one rank the independent kernels of the set phase share launches (k_edt_axis0_pair: both axis-0
+    passes + the merge of the classification partials and of K1b's Lipschitz partials; k_set_mid: coarse last-axis scan +
+    minimiser + block minima; option set_fuse, default on).  Every mask, count, index, u* and L must equal the sweep
+    with one launch per kernel -- one and two constraints, ragged line lengths -- and the model-change path with the
+    tables enqueued by sbo_model_set (eager_tables) must equal the one where the sweep builds them."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    q = cfg["q"]
+    out = {}
+    try:
+        for fuse, eager in ((1, 1), (0, 0)):
+            engine.set_option("set_fuse", fuse)
+            engine.set_option("eager_tables", eager)
+            engine.set_option("spin_wait", fuse)
+            engine.set_grid(lo, hi, count)
+            engine.set_model(cfg["ds"])
+            r = engine.sweep_safeopt(b, want_masks=True)
+            assert engine.profile()["posterior_kernel"] == 4
+            masks = {k: engine.mask(k) for k in ("S", "U", "M")}
+            masks.update({f"G{c}": engine.mask("G", c) for c in range(1, q)})
+            r2 = engine.sweep_safeopt(b, quirk_L_index=False, posterior_ready=True, want_masks=True)
+            masks.update({f"G{c}nq": engine.mask("G", c) for c in range(1, q)})
+            out[fuse] = (r, r2, masks)
+    finally:
+        for k in ("set_fuse", "eager_tables", "spin_wait"):
+            engine.set_option(k, 1)
+    for k, v in out[1][2].items():
+        assert np.array_equal(v, out[0][2][k]), k
+    assert out[1][2]["S"].any() and out[1][2]["U"].any() and out[1][2]["G1"].any()
+    for which in (0, 1):
+        a, b_ = out[1][which], out[0][which]
+        for k in a:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b_[k])), (which, k)
+
+
 def test_repeated_sweeps_on_a_resident_posterior_are_idempotent(engine):
     """The host classes call several sweeps per iteration on one posterior (`posterior_ready=True`): SafeOpt, GoOSE
     (whose explore step parks its target next to the sweep scalars) and the trust-region step, in any order, must
