@@ -1339,9 +1339,9 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     }
     const T* wbmax = nullptr;
     const int blk0 = 32;
-    if (c->scan_blocks && count0 >= 16 * blk0 && count0 <= 8192 && nt / count0 >= 2048) {
-      // one workgroup per line, the line in LDS (pays once there are enough lines to fill the chip: measured on 1024^2 it
-      // loses to the thread-per-position kernel, on 2048^2 it wins)
+    if (c->scan_blocks && count0 >= 16 * blk0 && count0 <= 8192 && nt / count0 >= 1024) {
+      // one workgroup per line, the line in LDS (pays once there are enough lines to fill the chip: from 1024 lines on --
+      // config C's 1024 x 1024 grid of the Williams-Otto plant: 33 -> 19 us per constraint against the thread-per-position kernel)
       const size_t lds = sizeof(double) * ((size_t)count0 + (count0 + kAnchor - 1) / kAnchor) + sizeof(int) * 2 * ((size_t)(count0 + kAnchor - 1) / kAnchor + 2);
       SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pdt_axis0_lds<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((k_pdt_axis0_lds<T>), dim3((unsigned)std::min<long long>(nt / count0, 1 << 16)), dim3(256), lds, c->stream, Wwin,
