@@ -106,6 +106,15 @@ struct sbo_ctx {
   sbo::DevBuf fitbuf, fitwork;   // hyper-parameter objective: inputs/outputs and the P x n x n factor workspace
   sbo::DevBuf coarse;  // coarse U mask + its distance transform (expander pre-decision)
   sbo::DevBuf scal;    // small device scalar block (keys, counters, arg-reduce results)
+  // Second lane of the set phase (models with two or more constraints, one rank): the per-constraint chains of a sweep are
+  // independent, so every other constraint is enqueued on stream2 with its own scratch and its own copy of the scalar block
+  // (the chains only write its recheck / scan counters).  The host swaps these in and out of the fields above around the
+  // calls that enqueue a lane-1 constraint (sets.hip: lane_swap).
+  struct SetLane {
+    sbo::DevBuf dist2, dist2b, coarse, blockmin, blockmax, scanlist, amb, gw, runmeta, scal;
+    bool amb_clean = false;
+  } lane1;
+  int set_lanes = 1;       // 0: all constraints on the main stream, one after the other
   sbo::DevBuf partial; // arg-reduce per-block partials
   sbo::DevBuf amb;     // ambiguous-index list for the exact recheck
   sbo::DevBuf runmeta; // GoOSE: per-run bounding boxes / radii of the coverage search

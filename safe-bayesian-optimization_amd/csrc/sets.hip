@@ -229,9 +229,11 @@ struct FinalJob {
   const double* Lpart = nullptr;              // K1b's Lipschitz partials still to be merged (nullptr: Lmax is final)
   int per_out = 0;
   unsigned long long* Lmax = nullptr;
+  SweepScalars* sc_copy = nullptr;            // the second lane's block: a snapshot of the merged scalars (nullptr: one lane)
 };
 __device__ __forceinline__ void classify_final_body(const unsigned long long* __restrict__ part, int nparts, int q, SweepScalars* sc,
-                                                    const double* __restrict__ Lpart, int per_out, unsigned long long* Lmax) {
+                                                    const double* __restrict__ Lpart, int per_out, unsigned long long* Lmax,
+                                                    SweepScalars* sc_copy = nullptr) {
   __shared__ double lsh[4];
   if (Lpart)
     for (int o = 0; o < q; ++o) lmax_reduce_body(o, lsh, Lpart, per_out, Lmax);
@@ -265,11 +267,19 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
     for (int c = 1; c < kMaxQ; ++c) sc->rmax_key[c] = c < q ? rmax[c] : 0ull;
   }
   if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
+  if (sc_copy) {
+    // The second lane's block is written HERE, not copied later on the lane's own stream: the main lane goes on to count
+    // its recheck / scan candidates in `sc`, and a later copy would pick those counters up half-way.
+    __syncthreads();
+    const unsigned long long* from = reinterpret_cast<const unsigned long long*>(sc);
+    unsigned long long* to = reinterpret_cast<unsigned long long*>(sc_copy);
+    for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) to[i] = from[i];
+  }
 }
 __global__ __launch_bounds__(256) void k_classify_final(const unsigned long long* __restrict__ part, int nparts, int q,
                                                         SweepScalars* sc, const double* __restrict__ Lpart, int per_out,
-                                                        unsigned long long* Lmax) {
-  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax);
+                                                        unsigned long long* Lmax, SweepScalars* sc_copy) {
+  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax, sc_copy);
 }
 
 // Objective pass of a classification whose S / U bytes came out of the posterior kernel (K1b, one constraint): u* = min over
@@ -500,7 +510,8 @@ __global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ part
 // GoOSE (!MAX): s = 0 arg-min of lcb_0 over S_t -> slot 0 (no count), s = c >= 1 over O_c -> slot c and |O_c|.
 template <bool MAX>
 __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts,
-                                                      SweepScalars* sc) {
+                                                      SweepScalars* sc, const SweepScalars* lane1 /* nullptr, or the second lane's block */) {
+  if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
   const int slot = blockIdx.x;
   const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
   Best best{0.0, -1};
@@ -594,11 +605,15 @@ static int sweep_masks(sbo_ctx* c, double b, bool may_fuse) {
   return SBO_OK;
 }
 
+// (second lane of the set phase, see sbo_ctx::lane1 and lane_swap below)
+static bool lanes_on(const sbo_ctx* c) { return c->set_lanes && !multi_rank(c) && c->mc.q >= 3 && c->cs.n_local > 0 && c->stream2; }
+
 static void launch_final(sbo_ctx* c, FinalJob* fj) {
   if (!fj || !fj->pending) return;
   fj->pending = false;
-  hipLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, fj->part, fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out,
-                     fj->Lmax);
+  // (with a second lane the fork event rides on this launch as its stop event: a separate record costs the stream a bubble)
+  hipExtLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, nullptr, fj->sc_copy ? c->ev_join[4] : nullptr, 0, fj->part,
+                        fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out, fj->Lmax, fj->sc_copy);
 }
 
 // `defer`: the merge of the classification's partials is handed back instead of launched (SafeOpt on one rank: it rides in
@@ -616,6 +631,10 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* def
   fj.pending = true;
   fj.q = q;
   fj.sc = sc;
+  if (lanes_on(c)) {
+    if ((rc = ensure(c->lane1.scal, 4096))) return rc;
+    fj.sc_copy = (SweepScalars*)c->lane1.scal.p;
+  }
   if (c->lmax_pending) {
     fj.Lpart = (const double*)c->bl_lpart.p;
     fj.per_out = c->lmax_per_out;
@@ -690,6 +709,41 @@ static void launch_edt_axis0(sbo_ctx* c, const uint8_t* U, long long nlines, int
   else
     hipLaunchKernelGGL(k_edt_axis0, dim3((unsigned)((nlines + 3) / 4)), dim3(256), 0, st, U, nlines, count0, h0, D);
 }
+
+// ---- second lane of the set phase (see sbo_ctx::lane1) ----------------------------------------------------------------
+static void lane_swap(sbo_ctx* c) {
+  auto& l = c->lane1;
+  std::swap(c->stream, c->stream2);
+  std::swap(c->dist2, l.dist2);
+  std::swap(c->dist2b, l.dist2b);
+  std::swap(c->coarse, l.coarse);
+  std::swap(c->blockmin, l.blockmin);
+  std::swap(c->blockmax, l.blockmax);
+  std::swap(c->scanlist, l.scanlist);
+  std::swap(c->amb, l.amb);
+  std::swap(c->gw, l.gw);
+  std::swap(c->runmeta, l.runmeta);
+  std::swap(c->scal, l.scal);
+  std::swap(c->amb_clean, l.amb_clean);
+}
+// after the classification's scalars are final on the main stream: lane 1 waits for them and takes its copy of the block
+// after the classification's scalars are final on the main stream (k_classify_final has written lane 1's snapshot of them)
+static int lanes_fork(sbo_ctx* c) {
+  SBO_HIP(hipStreamWaitEvent(c->stream2, c->ev_join[4], 0));          // (recorded by the k_classify_final launch)
+  c->lane1.amb_clean = true;
+  return SBO_OK;
+}
+static int lanes_join(sbo_ctx* c) {
+  SBO_HIP(hipEventRecord(c->ev_join[5], c->stream2));
+  SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_join[5], 0));
+  return SBO_OK;
+}
+struct LaneScope {          // enqueue-time view of lane 1 (odd lanes swap the context's stream / scratch in, and back out)
+  sbo_ctx* c;
+  bool on;
+  LaneScope(sbo_ctx* c_, bool on_) : c(c_), on(on_) { if (on) lane_swap(c); }
+  ~LaneScope() { if (on) lane_swap(c); }
+};
 
 // the minimiser launch of a SafeOpt sweep, held back so that the first constraint's expander can take it into k_set_mid
 struct MinimizerJob {
@@ -1095,7 +1149,8 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
   MinimizerJob mj;
-  const bool defer = q >= 2 && !multi_rank(c) && c->set_fuse && n > 0;
+  const bool lanes = lanes_on(c);
+  const bool defer = q >= 2 && !multi_rank(c) && c->set_fuse && n > 0 && !lanes;   // (lanes fork right behind the merge)
   if ((rc = sweep_common_front<T>(c, o, defer ? &mj.fin : nullptr))) return rc;
   if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
@@ -1111,11 +1166,14 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   mj.partial = (Best*)pbase;
   if (q < 2 || multi_rank(c)) launch_minimizer<T>(c, o, &mj);
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
+  if (lanes && (rc = lanes_fork(c))) return rc;
   for (int cc = 1; cc < q; ++cc) {
     uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
-    if ((rc = expander_set<T>(c, o, cc, G, &mj))) return rc;
+    LaneScope lane(c, lanes && ((cc - 1) & 1));              // constraints alternate between the two lanes
+    if ((rc = expander_set<T>(c, o, cc, G, lane.on ? nullptr : &mj))) return rc;
   }
   launch_minimizer<T>(c, o, &mj);
+  if (lanes && (rc = lanes_join(c))) return rc;
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   for (int cc = 1; cc < q; ++cc) {
     const uint8_t* G = (const uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
@@ -1124,7 +1182,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
                          (long long)c->cs.first, (Best*)(pbase + pstride * (size_t)cc));
   }
   hipLaunchKernelGGL(k_sweep_finals<true>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0,
-                     sc);
+                     sc, lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
@@ -1474,9 +1532,12 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   // Only expanders can cover an unsafe point: "g covers h" is the predicate that puts g into G_c.  So G_c is built
   // first (distance transform, cheap) and serves as the source set of the coverage search instead of all of S_t.
   if ((rc = ensure(c->maskG, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
+  const bool lanes = lanes_on(c);
+  if (lanes && (rc = lanes_fork(c))) return rc;
   for (int cc = 1; cc < q; ++cc) {
     uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
     uint8_t* O = (uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
+    LaneScope lane(c, lanes && ((cc - 1) & 1));              // constraints alternate between the two lanes
     // (a large explicit list has no transform to build G_c with: all of S_t stays the source set there)
     long long plane = 1;
     for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
@@ -1488,6 +1549,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     }
     if ((rc = goose_sets_d<T>(c, o, cc, src, O))) return rc;
   }
+  if (lanes && (rc = lanes_join(c))) return rc;
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   // arg-min of lcb_0 over S_t and over every O_c: the bound is computed for the masked candidates only
   const ValLcb<T> lcb0{(const T*)c->mean.p, (const T*)c->var.p, (T)o->b};
@@ -1504,7 +1566,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
                          (long long)c->cs.first, (Best*)(pbase + pstride * (size_t)cc));
   }
   hipLaunchKernelGGL(k_sweep_finals<false>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride,
-                     n > 0 ? nb : 0, sc);
+                     n > 0 ? nb : 0, sc, lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
   const int bid = (int)blockIdx.x;
   if (bid < nfine) edt_axis0_wg_body<false>(bid, nfine, lds, U, nlines, count0, h0, D, cg);
   else if (bid < nfine + ncoarse) edt_axis0_wg_body<true>(bid - nfine, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
-  else classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax);
+  else classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy);
 }
 
 // axes >= 1: D_out[g] = min_t D_in[g + t stride] + (h t)^2, searched outwards with the two exits

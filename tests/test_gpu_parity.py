@@ -954,6 +954,44 @@ def test_shared_set_phase_launches_equal_one_launch_per_kernel(engine, cfg_name,
             assert np.array_equal(np.asarray(a[k]), np.asarray(b_[k])), (which, k)
 
 
+def test_two_lanes_of_constraints_equal_one_after_the_other(engine):
+    """Models with two constraints on one rank: the per-constraint chains of a sweep (expander; GoOSE: + optimistic set)
+    run on two streams with their own scratch and their own snapshot of the scalar block (option set_lanes, default on).
+    SafeOpt and GoOSE results and masks must equal the one-lane sweep -- on a sequence of candidate sets of changing size
+    (small grid, larger explicit list, full-size grid, repeated), which is what exposes a lane reading the other's counters."""
+    cfg = synthetic.make_config("C", n=64)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    rng = np.random.default_rng(11)
+    lists = [rng.uniform(lo, hi, size=(m, 2)) for m in (3000, 700)]
+    steps = [("grid", [48, 40]), ("list", 0), ("grid", [1030, 1024]), ("list", 1), ("grid", [264, 256]), ("list", 0), ("grid", [48, 40])]
+    out = {}
+    try:
+        for lanes in (1, 0):
+            engine.set_option("set_lanes", lanes)
+            engine.set_model(cfg["ds"])
+            rows = []
+            for kind, arg in steps * 2:
+                if kind == "grid":
+                    engine.set_grid(lo, hi, arg)
+                else:
+                    engine.set_points(lists[arg])
+                s_ = engine.sweep_safeopt(cfg["b"], want_masks=True)
+                masks = [engine.mask(k) for k in ("S", "U", "M")] + [engine.mask("G", c) for c in (1, 2)]
+                g_ = engine.sweep_goose(cfg["b"], want_masks=True, posterior_ready=True)
+                masks += [engine.mask("O", c) for c in (1, 2)]
+                rows.append((s_, g_, masks))
+            out[lanes] = rows
+    finally:
+        engine.set_option("set_lanes", 1)
+    for (s1, g1, m1), (s0, g0, m0) in zip(out[1], out[0]):
+        for a, b_ in zip(m1, m0):
+            assert np.array_equal(a, b_)
+        for a, b_ in ((s1, s0), (g1, g0)):
+            for k in a:
+                assert np.array_equal(np.asarray(a[k]), np.asarray(b_[k])), k
+    assert any(m[3].any() and m[4].any() and m[5].any() for _, _, m in out[1])
+
+
 def test_repeated_sweeps_on_a_resident_posterior_are_idempotent(engine):
     """The host classes call several sweeps per iteration on one posterior (`posterior_ready=True`): SafeOpt, GoOSE
     (whose explore step parks its target next to the sweep scalars) and the trust-region step, in any order, must
