@@ -810,7 +810,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     if (multi_rank(c)) {
       // bytes of the window only, out of the all-gathered bit words (the gather itself was queued ahead of the host's wait)
       if ((rc = ensure(c->Uwin, (size_t)nt))) return rc;
-      const unsigned long long* recvw = (const unsigned long long*)c->ubits.p + c->gather_words;
+      const unsigned long long* recvw = (const unsigned long long*)c->ubits.p + c->gather_words + kC1Head;   // (past the own block and a head)
       hipLaunchKernelGGL(k_unpack_shards, dim3((unsigned)std::min<long long>((nt + 255) / 256, 1 << 16)), dim3(256), 0, c->stream, recvw,
                          c->gather_words, c->world, (const long long*)c->shard_first.p, p0 * plane, nt, (uint8_t*)c->Uwin.p);
       c->uwin_first = p0 * plane;
@@ -1036,7 +1036,7 @@ static void coords_of(const sbo_ctx* c, long long gidx, double* x) {
 
 int sbo_posterior_enqueue_(sbo_ctx* c);
 
-// (ranks > 1) C1: global u*, L and radius keys; C2: every rank's U mask as bit words
+// (ranks > 1) C1: global u*, L and radius keys; C2: every rank's U mask as bit words (one all-gather carries both)
 template <typename T>
 static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U) {
   const int q = c->mc.q;
@@ -1047,30 +1047,36 @@ static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U
     return fail(SBO_E_INVALID, "multi-rank sweeps with constraints need sbo_candidates_grid_sharded");
   if ((rc = ensure(c->xch, sizeof(double) * (size_t)(c->world * kC3Row + 64)))) return rc;
   unsigned long long* kb = (unsigned long long*)c->xch.p;
-  hipLaunchKernelGGL(k_pack_c1, dim3(1), dim3(64), 0, c->stream, (const SweepScalars*)sc, (const unsigned long long*)c->Lmax.p, kb);
-  if ((rc = comm_allreduce_max_u64(c, kb, 1 + 2 * kMaxQ))) return rc;
-  hipLaunchKernelGGL(k_unpack_c1, dim3(1), dim3(64), 0, c->stream, sc, (unsigned long long*)c->Lmax.p, (const unsigned long long*)kb);
+  if (need_U && q > 1) {
+    // C1 + C2 in ONE all-gather: every rank sends [its keys (kC1Head words) | its U mask as bits (one ballot word per 64
+    // candidates: 8x fewer bytes on the links than the byte mask)]; the keys are then max-reduced over the gathered heads by
+    // a small kernel on every rank -- one collective latency per sweep less than an all-reduce followed by an all-gather.
+    long long maxlocal = 0;
+    for (int r = 0; r < c->world; ++r) maxlocal = std::max(maxlocal, c->first_of[r + 1] - c->first_of[r]);
+    const long long words = (maxlocal + 63) / 64, stride = kC1Head + words;
+    // (their own buffer: the words are read again per constraint, after GoOSE's weight exchanges have used `gather`)
+    if ((rc = ensure(c->ubits, sizeof(unsigned long long) * (size_t)stride * (c->world + 1)))) return rc;
+    c->gather_words = stride;
+    unsigned long long* sendw = (unsigned long long*)c->ubits.p;
+    unsigned long long* recvw = sendw + stride;
+    hipLaunchKernelGGL(k_pack_c1, dim3(1), dim3(64), 0, c->stream, (const SweepScalars*)sc, (const unsigned long long*)c->Lmax.p, sendw);
+    hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)std::min<long long>((words + 3) / 4, 1 << 16)), dim3(256), 0, c->stream,
+                       (const uint8_t*)c->maskU.p, c->cs.n_local, words, sendw + kC1Head);
+    if ((rc = comm_allgather_bytes(c, sendw, recvw, sizeof(unsigned long long) * (size_t)stride))) return rc;
+    hipLaunchKernelGGL(k_unpack_c1_gathered, dim3(1), dim3(64), 0, c->stream, sc, (unsigned long long*)c->Lmax.p,
+                       (const unsigned long long*)recvw, stride, c->world, kb);
+    // (the bits are expanded to bytes per constraint, window only: expander_set)
+  } else {
+    hipLaunchKernelGGL(k_pack_c1, dim3(1), dim3(64), 0, c->stream, (const SweepScalars*)sc, (const unsigned long long*)c->Lmax.p, kb);
+    if ((rc = comm_allreduce_max_u64(c, kb, 1 + 2 * kMaxQ))) return rc;
+    hipLaunchKernelGGL(k_unpack_c1, dim3(1), dim3(64), 0, c->stream, sc, (unsigned long long*)c->Lmax.p, (const unsigned long long*)kb);
+  }
   // the host needs the global L and radius keys to size the halo of the expander transform: the read-back goes to
-  // pinned memory and is waited for only where the window is computed (sweep_exchange_wait), so the mask all-gather
-  // and the minimiser kernels are already queued behind it and the GPU does not idle through the round trip
+  // pinned memory and is waited for only where the window is computed (sweep_exchange_wait), so the minimiser kernels are
+  // already queued behind it and the GPU does not idle through the round trip
   SBO_HIP(hipMemcpyAsync(c->h_c1, kb, sizeof(unsigned long long) * (1 + 2 * kMaxQ), hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipEventRecord(c->ev[5], c->stream));
   c->c1_pending = true;
-  if (need_U && q > 1) {
-    // the mask travels as bits (one ballot word per 64 candidates): 8x fewer bytes on the links than the byte mask
-    long long maxlocal = 0;
-    for (int r = 0; r < c->world; ++r) maxlocal = std::max(maxlocal, c->first_of[r + 1] - c->first_of[r]);
-    const long long words = (maxlocal + 63) / 64;
-    // (their own buffer: the words are read again per constraint, after GoOSE's weight exchanges have used `gather`)
-    if ((rc = ensure(c->ubits, sizeof(unsigned long long) * (size_t)words * (c->world + 1)))) return rc;
-    c->gather_words = words;
-    unsigned long long* sendw = (unsigned long long*)c->ubits.p;
-    unsigned long long* recvw = sendw + words;
-    hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)std::min<long long>((words + 3) / 4, 1 << 16)), dim3(256), 0, c->stream,
-                       (const uint8_t*)c->maskU.p, c->cs.n_local, words, sendw);
-    if ((rc = comm_allgather_bytes(c, sendw, recvw, sizeof(unsigned long long) * (size_t)words))) return rc;
-    (void)recvw;      // (expanded to bytes per constraint, window only: expander_set)
-  }
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }

@@ -13,6 +13,24 @@ __global__ void k_unpack_c1(SweepScalars* sc, unsigned long long* Lkeys, const u
   if (t == 0) sc->ustar_key = ~buf[0];
   if (t < kMaxQ) { Lkeys[t] = buf[1 + t]; sc->rmax_key[t] = buf[1 + kMaxQ + t]; }
 }
+// C1 riding at the head of the C2 all-gather: block r of `recv` (stride words) starts with rank r's kC1Head key words;
+// their maxima go to the scalar block, the Lipschitz keys and (contiguously) to kb for the host's read-back
+constexpr int kC1Head = 32;      // >= 1 + 2 kMaxQ, keeps the bit words 256-byte aligned
+static_assert(kC1Head >= 1 + 2 * kMaxQ, "C1 head");
+__global__ void k_unpack_c1_gathered(SweepScalars* sc, unsigned long long* Lkeys, const unsigned long long* __restrict__ recv,
+                                     long long stride, int world, unsigned long long* __restrict__ kb) {
+  const int t = threadIdx.x;
+  if (t >= 1 + 2 * kMaxQ) return;
+  unsigned long long m = 0ull;
+  for (int r = 0; r < world; ++r) {
+    const unsigned long long v = recv[(size_t)r * stride + t];
+    m = v > m ? v : m;
+  }
+  kb[t] = m;
+  if (t == 0) sc->ustar_key = ~m;
+  else if (t < 1 + kMaxQ) Lkeys[t - 1] = m;
+  else sc->rmax_key[t - 1 - kMaxQ] = m;
+}
 // C2: all-gathered padded shards -> contiguous whole-grid mask
 template <typename E>
 __global__ __launch_bounds__(256) void k_compact_shards(const E* __restrict__ recv, long long maxlocal, int world,
