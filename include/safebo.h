@@ -135,7 +135,8 @@ typedef struct sbo_tr_result {
  * library's stream (feeds bench.py's roofline.achieved) */
 typedef struct sbo_profile {
   double posterior_ms;     /* K1: fused cross-covariance + contraction + mean/var                          */
-  double classify_ms;      /* K3: bounds, S/U/M masks, u*, reductions     (these three: 0 unless option     */
+  double classify_ms;      /* K3: bounds, S/U masks, u* (with "set_fuse" the merge of the partials and the M mask
+                              ride in the expander's first launches and are counted there)  (these three: 0 unless option */
   double expander_ms;      /* K4: distance transform + G_c / O_c decisions  "phase_events" is 1 -- an event  */
   double argreduce_ms;     /* K5: masked arg-max / arg-min                   costs a ~6 us bubble per record) */
   double comm_ms;          /* RCCL collectives                                                             */
