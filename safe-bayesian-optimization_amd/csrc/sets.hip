@@ -745,6 +745,8 @@ struct LaneScope {          // enqueue-time view of lane 1 (odd lanes swap the c
   ~LaneScope() { if (on) lane_swap(c); }
 };
 
+constexpr long long kListExpanderMax = 1ll << 21;     // explicit lists: largest candidate set with exhaustive expander sets
+
 // the minimiser launch of a SafeOpt sweep, held back so that the first constraint's expander can take it into k_set_mid
 struct MinimizerJob {
   bool pending = false;
@@ -998,8 +1000,10 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
   } else {
     // explicit candidate lists, and grid ranges that are not whole hyper-planes: exhaustive evaluation
     launch_minimizer<T>(c, o, mj);
-    if (n > (1ll << 17))
-      return fail(SBO_E_UNSUPPORTED, "expander sets need a grid of whole hyper-planes, or at most 131072 candidates (exhaustive)");
+    // (quadratic: every safe candidate against every U point, like the reference's vmap -- fine for the lists a campaign
+    // uses, seconds at the cap)
+    if (n > kListExpanderMax)
+      return fail(SBO_E_UNSUPPORTED, "expander sets need a grid of whole hyper-planes, or at most 2097152 candidates (exhaustive)");
     if (multi_rank(c))
       return fail(SBO_E_UNSUPPORTED, "expander sets on explicit candidate lists are single-rank");
     hipLaunchKernelGGL(k_list_safe, dim3(nb), dim3(256), 0, c->stream, (const uint8_t*)c->maskS.p, n, sc, G,
@@ -1547,7 +1551,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     // (a large explicit list has no transform to build G_c with: all of S_t stays the source set there)
     long long plane = 1;
     for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
-    const bool can_expand = n <= (1ll << 17) || (c->cs.kind == 1 && c->cs.first % plane == 0 && n % plane == 0);
+    const bool can_expand = n <= (1ll << 17) || (c->cs.kind == 1 && c->cs.first % plane == 0 && n % plane == 0);   // (larger lists: S_t is the source set)
     const uint8_t* src = (const uint8_t*)c->maskS.p;
     if (can_expand) {
       if ((rc = expander_set<T>(c, o, cc, G))) return rc;

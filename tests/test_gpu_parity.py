@@ -369,6 +369,32 @@ def test_goose_sweep_explicit_points(engine):
     assert res["explore_index"] == ref["explore_index"]
 
 
+def test_large_explicit_list_expander_equals_the_grid_transform(engine):
+    """Explicit lists above 131 072 points (round 1's cap) take the exhaustive expander evaluation too (cap now 2 M, cost
+    quadratic): a 640 x 480 grid handed over point by point must give the masks and indices of the same grid swept through
+    the distance transform."""
+    import time
+    cfg = synthetic.make_config("B", n=48)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    count = [640, 480]
+    engine.set_model(cfg["ds"])
+    engine.set_grid(lo, hi, count)
+    ref = engine.sweep_safeopt(cfg["b"], want_masks=True)
+    rm = {k: engine.mask(k) for k in ("S", "U", "M")}
+    rm["G"] = engine.mask("G", 1)
+    engine.set_points(oracle.grid_points(lo, hi, count))
+    t0 = time.perf_counter()
+    res = engine.sweep_safeopt(cfg["b"], want_masks=True)
+    dt = time.perf_counter() - t0
+    for k in ("S", "U", "M"):
+        assert np.array_equal(engine.mask(k), rm[k]), k
+    assert np.array_equal(engine.mask("G", 1), rm["G"]) and rm["G"].any()
+    for k in ("minimizer_index", "expander_index", "count_S", "count_M"):
+        assert res[k] == ref[k], k
+    assert list(res["count_G"]) == list(ref["count_G"])
+    assert dt < 30.0
+
+
 def test_safeopt_sweep_explicit_points_exhaustive_expander(engine):
     cfg = synthetic.make_config("A")
     lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
