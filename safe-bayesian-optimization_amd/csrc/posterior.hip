@@ -487,8 +487,10 @@ __device__ __forceinline__ int top_row_of_wave(int w, int nb) {
   return best;
 }
 
+// (three workgroups per CU asked for at D = 4: that instance needs 175 registers unconstrained, 7 above the limit for the
+// occupancy the D = 2 instance runs at)
 template <typename T, int S, int D>
-__global__ __launch_bounds__(256) void k_posterior_grid(const ModelConst mc, const CandSpec cs, const GridTables gt,
+__global__ __launch_bounds__(256, (D == 4 ? 3 : 1)) void k_posterior_grid(const ModelConst mc, const CandSpec cs, const GridTables gt,
                                                         const T* __restrict__ Fpk, size_t fpk_stride,
                                                         const T* __restrict__ E0f, const T* __restrict__ Er,
                                                         const T* __restrict__ AXg, unsigned int ntiles,
