@@ -770,10 +770,10 @@ __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) {
   if (s_ && ucb > cx.rmax) cx.rmax = ucb;
 }
 
-template <int PH>
+template <int PH, int RB>
 __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict__ A, const double* __restrict__ B, int KB,
                                            int KS, double* __restrict__ outp, double c0, double c1, double c2, double& gmax,
-                                           d4_t (&acc)[2][8], const double* __restrict__ xn0) {
+                                           d4_t (&acc)[RB][8], const double* __restrict__ xn0) {
   const double* Ap = A + (size_t)cx.st_rb * KB * 256 + cx.st_off;
   const double* Bp = B + (size_t)cx.st_cs * KB * 256 + cx.st_off;
   const int nkb = (KS + 3) >> 2;
@@ -790,11 +790,11 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
       const unsigned int x = (unsigned int)(cx.cs0 + s2) * 16u + (cx.lane & 15);
       const double f = x < cx.ucnt0 ? -xn0[x] : 0.0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][s2] = d4_t{acc[i][s2][0] * f, acc[i][s2][1] * f, acc[i][s2][2] * f, acc[i][s2][3] * f};
+      for (int i = 0; i < RB; ++i) acc[i][s2] = d4_t{acc[i][s2][0] * f, acc[i][s2][1] * f, acc[i][s2][2] * f, acc[i][s2][3] * f};
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
       for (int s2 = 0; s2 < 8; ++s2) acc[i][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
   }
@@ -812,19 +812,26 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
       rb0v = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256);
       rb1v = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256 + 4);
     }
-    const double* LA = lds + cur * 4096 + (2 * cx.wave) * 256 + cx.a_rd;
+    const double* LA = lds + cur * 4096 + (RB * cx.wave) * 256 + cx.a_rd;
     const double* LB = lds + cur * 4096 + 2048 + cx.lane;
     const int kkn = KS - kb * 4 < 4 ? KS - kb * 4 : 4;
 #pragma unroll 1
     for (int kk = 0; kk < kkn; ++kk) {
-      const d2_t l0 = *reinterpret_cast<const d2_t*>(LA + kk * 64), h0 = *reinterpret_cast<const d2_t*>(LA + kk * 64 + 32);
-      const d2_t l1 = *reinterpret_cast<const d2_t*>(LA + 256 + kk * 64), h1 = *reinterpret_cast<const d2_t*>(LA + 256 + kk * 64 + 32);
-      const d4_t a0 = d4_t{l0[0], l0[1], h0[0], h0[1]}, a1 = d4_t{l1[0], l1[1], h1[0], h1[1]};
+      if constexpr (RB == 2) {
+        const d2_t l0 = *reinterpret_cast<const d2_t*>(LA + kk * 64), h0 = *reinterpret_cast<const d2_t*>(LA + kk * 64 + 32);
+        const d2_t l1 = *reinterpret_cast<const d2_t*>(LA + 256 + kk * 64), h1 = *reinterpret_cast<const d2_t*>(LA + 256 + kk * 64 + 32);
+        const d4_t a0 = d4_t{l0[0], l0[1], h0[0], h0[1]}, a1 = d4_t{l1[0], l1[1], h1[0], h1[1]};
 #pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2) {
-        const double b = LB[(s2 * 4 + kk) * 64];
-        acc[0][s2] = MM<double>::mfma(a0, b, acc[0][s2]);
-        acc[1][s2] = MM<double>::mfma(a1, b, acc[1][s2]);
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const double b = LB[(s2 * 4 + kk) * 64];
+          acc[0][s2] = MM<double>::mfma(a0, b, acc[0][s2]);
+          acc[1][s2] = MM<double>::mfma(a1, b, acc[1][s2]);
+        }
+      } else {
+        const d2_t l0 = *reinterpret_cast<const d2_t*>(LA + kk * 64), h0 = *reinterpret_cast<const d2_t*>(LA + kk * 64 + 32);
+        const d4_t a0 = d4_t{l0[0], l0[1], h0[0], h0[1]};
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) acc[0][s2] = MM<double>::mfma(a0, LB[(s2 * 4 + kk) * 64], acc[0][s2]);
       }
     }
     if (kb + 1 < nkb) stage(lds + (cur ^ 1) * 4096, ra0, ra1, rb0v, rb1v);
@@ -836,10 +843,10 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
     // interior tile: no bounds tests, one pointer per row, the eight strips at immediate offsets.  The matrix cores
     // share the f64 VALU datapath, so every instruction saved here is matrix time.
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const unsigned int line = (unsigned int)(cx.rb0 + 2 * cx.wave + i) * 16u + 4u * t + row_in;
+        const unsigned int line = (unsigned int)(cx.rb0 + RB * cx.wave + i) * 16u + 4u * t + row_in;
         const size_t g0 = (size_t)line * cx.ucnt0 + (unsigned int)cx.cs0 * 16u + col_in;
         double* const rowp = outp + g0;
         if (PH == 1 && cx.S) {
@@ -885,8 +892,8 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rb = cx.rb0 + 2 * cx.wave + i;
+  for (int i = 0; i < RB; ++i) {
+    const int rb = cx.rb0 + RB * cx.wave + i;
     if (rb >= cx.nrb) continue;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -917,6 +924,10 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
   }
 }
 
+// RB: row blocks per wave.  2 = the 128 x 128 tile above; 1 = a 64 x 128 tile for grids whose 128 x 128 tiles would leave
+// CUs without a workgroup (1024 x 1024 x 3 outputs: 192 tiles on 256 CUs) -- half the reuse of a B fragment, twice the
+// workgroups.
+template <int RB>
 __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
                                                   const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
                                                   size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
@@ -929,10 +940,10 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
   PostCtx cx;
   cx.lds = lds;
   cx.tid = threadIdx.x; cx.lane = cx.tid & 63; cx.wave = cx.tid >> 6;
-  cx.rb0 = blockIdx.y * 8; cx.cs0 = blockIdx.x * 8; cx.nrb = nrb; cx.ncs = ncs;
+  cx.rb0 = blockIdx.y * (4 * RB); cx.cs0 = blockIdx.x * 8; cx.nrb = nrb; cx.ncs = ncs;
   cx.ucnt0 = (unsigned int)cs.count[0];
   cx.nlines = nlines;
-  cx.full = (long long)(cx.rb0 + 8) * 16 <= nlines && (long long)(cx.cs0 + 8) * 16 <= cs.count[0];
+  cx.full = (long long)(cx.rb0 + 4 * RB) * 16 <= nlines && (long long)(cx.cs0 + 8) * 16 <= cs.count[0];
   // staging role of this thread: 64 bytes of one A image and 64 bytes of one B strip per k-block.
   // LDS image of an A block: per k-step the 16 lane-chunks are split into their first and second 16 bytes
   // ([16 x 16 B][16 x 16 B]) so that both ds_read_b128 of a fragment load touch 256 contiguous bytes (no bank conflicts)
@@ -959,13 +970,13 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
   double gmax = 0.0;
   // (Tried: odd outputs running the three short phases first and the variance phase last, so that the two workgroups of a
   // CU do not reach their phase changes together -- no gain on config B, 2.5 % slower on H; one order for all.)
-  d4_t acc[2][8];
-  post_phase<0>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0);
-  post_phase<1>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0);
+  d4_t acc[RB][8];
+  post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0);
+  post_phase<1, RB>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0);
   // phase 2 continues on phase 1's sums: only the V1 half (the first KSm k-steps) of the stacked operands is run
-  post_phase<2>(cx, VAo + (size_t)nrb * KBm * 256, SBo + (size_t)ncs * KBm * 256, KBm2, KSm, nullptr,
+  post_phase<2, RB>(cx, VAo + (size_t)nrb * KBm * 256, SBo + (size_t)ncs * KBm * 256, KBm2, KSm, nullptr,
                 ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax, acc, xn0);
-  post_phase<3>(cx, VAo + (size_t)nrb * (KBm + KBm2) * 256, SBo, KBm, KSm, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0,
+  post_phase<3, RB>(cx, VAo + (size_t)nrb * (KBm + KBm2) * 256, SBo, KBm, KSm, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0,
                 gmax, acc, xn0);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -1293,7 +1304,10 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                      (double*)c->bl_BtA.p, pl.sBtA);
   // stage 2 (fused): variance, mean, Lipschitz keys
   const size_t lds = sizeof(double) * 2 * 4096;
-  const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8), gy = (unsigned)((pl.nrb + 7) / 8);
+  // (64 x 128 tiles when the 128 x 128 ones would not give every CU a workgroup)
+  const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8);
+  const int rbw = (long long)gx * ((pl.nrb + 7) / 8) * q < c->n_cu ? 1 : 2;
+  const unsigned gy = (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
   int rc;
   if ((rc = ensure(c->bl_lpart, sizeof(double) * 4 * (size_t)gx * gy * q))) return rc;
   // a sweep may ask for the S / U bytes, |S|, |U| and the radius key straight from the mean epilogue of the constraint
@@ -1306,10 +1320,11 @@ int launch_posterior_bilinear(sbo_ctx* c) {
     // (room behind the rows for the partials of the objective pass, see sweep_common_front)
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
   }
-  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kpost = rbw == 1 ? k_bpost<1> : k_bpost<2>;
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // the K1 stop event rides on the last launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
   // the next kernel waits ~6 us for.  A sweep merges the Lipschitz partials in its own first small kernel (lmax_defer).
-  hipExtLaunchKernelGGL(k_bpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream, nullptr, c->lmax_defer ? c->ev[1] : nullptr, 0,
+  hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream, nullptr, c->lmax_defer ? c->ev[1] : nullptr, 0,
                         mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
                         pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
                         (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
