@@ -371,11 +371,116 @@ __device__ __forceinline__ int basis_pivot_loop(int n, int rc, double* res, doub
   return r;
 }
 
+// ---- front end of the bases, spread over the chip -------------------------------------------------------------------------
+// k_bl_basis is one workgroup per (output, axis): its pivot loop is sequential by nature, but the two passes in front of it
+// (Chebyshev samples + degree test, all coefficients) are not, and on a single CU they took 54 of config B's 182 us and 184
+// of H's 520.  k_bl_degree finds the smallest degree of the ladder 32 / 48 / 64 / 96 / 128 whose last four coefficients are
+// below 1e-14 for every row (a thread per row, the ladder walked per workgroup, one atomicMax per workgroup and job);
+// k_bl_coef writes the coefficient rows of that degree straight into the job's residual-row workspace (a workgroup per 32
+// rows: its samples in LDS, the sums in the order the single-workgroup pass uses -- the same values bit for bit).
+constexpr int kCoefRows = 32;
+__device__ __forceinline__ int bl_degree_of(int trial) { return trial == 0 ? 32 : (trial == 1 ? 48 : (trial == 2 ? 64 : (trial == 3 ? 96 : kBlMaxRc))); }
+
+__global__ __launch_bounds__(256) void k_bl_degree(const BlJobs jb, const double* __restrict__ Xn, int* __restrict__ rc_job) {
+  // four lanes per row (64 rows per workgroup): each takes every fourth sample -- a thread alone walks up to 80 exp() before
+  // the ladder stops at degree 48
+  __shared__ double ct[4 * kBlMaxRc];
+  __shared__ double red[4];
+  const int job = blockIdx.y, axis = job & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = jb.n, j = blockIdx.x * 64 + (tid >> 2), sub = tid & 3;
+  const double vinv = jb.vinv[job], a = jb.a[axis], b = jb.b[axis];
+  const double xj = j < n ? Xn[(size_t)j * jb.dpad + axis] * vinv : 0.0;
+  int pass = 0;                                                    // 0: no degree of the ladder is enough
+  for (int trial = 0; trial < 5; ++trial) {
+    const int rc = bl_degree_of(trial);
+    __syncthreads();
+    for (int m = tid; m < 4 * rc; m += 256) ct[m] = cospi((double)m / (2.0 * rc));
+    __syncthreads();
+    double s_[4] = {0.0, 0.0, 0.0, 0.0};
+    if (j < n) {
+      int m_[4], st_[4];                                           // angle index p (2 k + 1) mod 4 rc and its step for k += 4
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pq = rc - 4 + u;
+        m_[u] = (pq * (2 * sub + 1)) % (4 * rc);
+        st_[u] = (pq * 8) % (4 * rc);
+      }
+      for (int k = sub; k < rc; k += 4) {
+        const double x = 0.5 * (ct[2 * k + 1] * (b - a) + (a + b));
+        const double df = x * vinv - xj;
+        const double f = exp(-0.5 * (df * df));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s_[u] += f * ct[m_[u]];
+          m_[u] += st_[u];
+          if (m_[u] >= 4 * rc) m_[u] -= 4 * rc;
+        }
+      }
+    }
+    double tail = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      double v = s_[u];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      const double t_ = fabs(v * (2.0 / rc));
+      tail = t_ > tail ? t_ : tail;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(tail, o); tail = y > tail ? y : tail; }
+    __syncthreads();
+    if (lane == 0) red[wave] = tail;
+    __syncthreads();
+    tail = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (tail <= 1e-14) { pass = rc; break; }                       // (uniform: every thread sees the same maximum)
+  }
+  if (tid == 0) atomicMax(&rc_job[job], pass ? pass : 0x7fffffff);
+}
+
+__global__ __launch_bounds__(256) void k_bl_coef(const BlJobs jb, const double* __restrict__ Xn, const int* __restrict__ rc_job,
+                                                 double* __restrict__ work, size_t work_stride) {
+  __shared__ double ct[4 * kBlMaxRc];
+  __shared__ double fs[kBlMaxRc * kCoefRows];                       // samples [k][row of the tile]
+  const int job = blockIdx.y, axis = job & 1, tid = threadIdx.x;
+  const int n = jb.n, rc = rc_job[job];
+  if (rc <= 0 || rc > kBlMaxRc) return;                             // no degree qualified: k_bl_basis reports it
+  const int j0 = blockIdx.x * kCoefRows;
+  const double vinv = jb.vinv[job], a = jb.a[axis], b = jb.b[axis];
+  double* res = work + (size_t)job * work_stride + (size_t)n * kBlMaxRc;   // the job's residual rows (resG of k_bl_basis)
+  for (int m = tid; m < 4 * rc; m += 256) ct[m] = cospi((double)m / (2.0 * rc));
+  __syncthreads();
+  for (int w = tid; w < rc * kCoefRows; w += 256) {
+    const int k = w / kCoefRows, jl = w % kCoefRows, j = j0 + jl;
+    double f = 0.0;
+    if (j < n) {
+      const double x = 0.5 * (ct[2 * k + 1] * (b - a) + (a + b));
+      const double df = x * vinv - Xn[(size_t)j * jb.dpad + axis] * vinv;
+      f = exp(-0.5 * (df * df));
+    }
+    fs[w] = f;
+  }
+  __syncthreads();
+  for (int w = tid; w < rc * kCoefRows; w += 256) {
+    const int p = w / kCoefRows, jl = w % kCoefRows, j = j0 + jl;
+    if (j >= n) continue;
+    double s_ = 0.0;
+    int m = p;
+    for (int k = 0; k < rc; ++k) {
+      s_ += fs[k * kCoefRows + jl] * ct[m];
+      m += 2 * p;
+      if (m >= 4 * rc) m -= 4 * rc;
+    }
+    res[(size_t)p * n + j] = s_ * ((p == 0 ? 1.0 : 2.0) / rc);
+  }
+}
+
 template <int NT, bool LDSRES>
 __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* __restrict__ Xn, double* __restrict__ work,
                                                  size_t work_stride, double* __restrict__ Uout, double* __restrict__ Vsout,
                                                  double* __restrict__ sigout, int* __restrict__ info,
-                                                 long long* __restrict__ dbg /* nullptr, or 80 time stamps of job 0 */) {
+                                                 long long* __restrict__ dbg /* nullptr, or 80 time stamps of job 0 */,
+                                                 const int* __restrict__ rc_pre /* nullptr, or the degree per job from k_bl_degree
+                                                                                    (its coefficient rows are in the workspace) */) {
   extern __shared__ double bl_dyn[];          // [kBasisQLds directions | kBasisResLds samples / residual rows (LDSRES)]
   __shared__ double ct[4 * kBlMaxRc];        // cos(pi m / (2 rc)), m < 4 rc
   __shared__ double qv[kBlMaxRc];            // the direction being built
@@ -396,7 +501,16 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
   int ndbg = 0;
   auto stamp = [&]() { if (dbg && job == 0 && tid == 0 && ndbg < 80) dbg[ndbg++] = wall_clock64(); };
   stamp();
-  for (int trial = 0; trial < 5 && !ok; ++trial) {
+  if (rc_pre) {
+    rc = rc_pre[job];
+    ok = rc > 0 && rc <= kBlMaxRc;
+    if (ok && LDSRES && rc * n > kBasisResLds) { ok = false; out_of_lds = true; }
+    if (ok && LDSRES) {                                            // the rows move from the workspace into LDS
+      for (int w = tid; w < rc * n; w += NT) (bl_dyn + kBasisQLds)[w] = resG[w];
+    }
+    __syncthreads();
+  }
+  for (int trial = 0; trial < 5 && !ok && !rc_pre; ++trial) {
     rc = trial == 0 ? 32 : (trial == 1 ? 48 : (trial == 2 ? 64 : (trial == 3 ? 96 : kBlMaxRc)));
     if (LDSRES && rc * n > kBasisResLds) { out_of_lds = true; break; }
     __syncthreads();
@@ -444,7 +558,9 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
   double* res = LDSRES ? bl_dyn + kBasisQLds : resG;
   constexpr int kKeep = LDSRES ? kBasisResLds / NT : 1;
   double keep[kKeep];
-  if (LDSRES) {
+  if (rc_pre) {
+    // (the coefficient rows were written by k_bl_coef)
+  } else if (LDSRES) {
 #pragma unroll
     for (int it = 0; it < kKeep; ++it) {
       const int w = tid + it * NT;
@@ -1036,7 +1152,7 @@ bool bilinear_applicable(const sbo_ctx* c) {
 // layout of bl_basis (doubles): U [2q][kBlMaxR][n] | Vs [2q][kBlMaxR][kBlMaxRc] | sig [2q][kBlMaxR] | info (ints, 2q x 4, in
 // 4 q doubles) | work [2q][3 n kBlMaxRc + kBlMaxR kBlMaxRc]
 struct BasisLayout {
-  size_t U, Vs, sig, info, work, work_stride, total;
+  size_t U, Vs, sig, info, rcjob, work, work_stride, total;
 };
 static BasisLayout basis_layout(int n, int q) {
   BasisLayout L;
@@ -1044,7 +1160,8 @@ static BasisLayout basis_layout(int n, int q) {
   L.Vs = L.U + (size_t)2 * q * kBlMaxR * n;
   L.sig = L.Vs + (size_t)2 * q * kBlMaxR * kBlMaxRc;
   L.info = L.sig + (size_t)2 * q * kBlMaxR;
-  L.work = L.info + (size_t)4 * q;
+  L.rcjob = L.info + (size_t)4 * q;                 // ints, 2 q (in q doubles): the degree k_bl_degree found per job
+  L.work = L.rcjob + (size_t)q;
   L.work_stride = (size_t)3 * n * kBlMaxRc + (size_t)kBlMaxR * kBlMaxRc;
   L.total = L.work + (size_t)2 * q * L.work_stride;
   return L;
@@ -1119,16 +1236,25 @@ int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big) {
     long long* dbg = nullptr;
     const bool phases = getenv("SBO_BL_TIMING") != nullptr;
     if (phases && hipMalloc(&dbg, sizeof(long long) * 81) != hipSuccess) dbg = nullptr;
+    // front end on the whole chip: degree per job, then its coefficient rows into the jobs' workspaces
+    int* rcjob = (int*)(base + L.rcjob);
+    SBO_HIP(hipMemsetAsync(rcjob, 0, sizeof(int) * 2 * q, st));
+    hipLaunchKernelGGL(k_bl_degree, dim3((unsigned)((n + 63) / 64), (unsigned)(2 * q)), dim3(256), 0, st, jb, (const double*)c->Xn.p, rcjob);
+    hipLaunchKernelGGL(k_bl_coef, dim3((unsigned)((n + kCoefRows - 1) / kCoefRows), (unsigned)(2 * q)), dim3(256), 0, st, jb,
+                       (const double*)c->Xn.p, (const int*)rcjob, base + L.work, L.work_stride);
     for (int rep = 0; rep < (dbg ? 2 : 1); ++rep) {       // (with SBO_BL_TIMING a second run records the phase stamps of job 0)
       long long* dg = rep ? dbg : nullptr;
+      if (rep)      // (the pivot loop consumed the rows in place)
+        hipLaunchKernelGGL(k_bl_coef, dim3((unsigned)((n + kCoefRows - 1) / kCoefRows), (unsigned)(2 * q)), dim3(256), 0, st, jb,
+                           (const double*)c->Xn.p, (const int*)rcjob, base + L.work, L.work_stride);
       if (small) {
         SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL((k_bl_basis<256, true>), dim3((unsigned)(2 * q)), dim3(256), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
-                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg);
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob);
       } else {
         SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL((k_bl_basis<1024, false>), dim3((unsigned)(2 * q)), dim3(1024), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
-                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg);
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob);
       }
     }
     SBO_HIP(hipGetLastError());
