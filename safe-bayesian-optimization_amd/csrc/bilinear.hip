@@ -895,8 +895,10 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
   const int nkb = (KS + 3) >> 2;
   double* const lds = cx.lds;
   auto stage = [&](double* buf, const d4_t& r0, const d4_t& r1, const d4_t& q0, const d4_t& q1) {
-    *reinterpret_cast<d4_t*>(buf + cx.a_lo) = d4_t{r0[0], r0[1], r1[0], r1[1]};
-    *reinterpret_cast<d4_t*>(buf + cx.a_lo + 32) = d4_t{r0[2], r0[3], r1[2], r1[3]};
+    if (RB == 2 || cx.a_lo >= 0) {
+      *reinterpret_cast<d4_t*>(buf + cx.a_lo) = d4_t{r0[0], r0[1], r1[0], r1[1]};
+      *reinterpret_cast<d4_t*>(buf + cx.a_lo + 32) = d4_t{r0[2], r0[3], r1[2], r1[3]};
+    }
     *reinterpret_cast<d4_t*>(buf + cx.b_st) = q0;
     *reinterpret_cast<d4_t*>(buf + cx.b_st + 4) = q1;
   };
@@ -914,7 +916,9 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
 #pragma unroll
       for (int s2 = 0; s2 < 8; ++s2) acc[i][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
   }
-  d4_t ra0 = *reinterpret_cast<const d4_t*>(Ap), ra1 = *reinterpret_cast<const d4_t*>(Ap + 4);
+  const bool stage_a = RB == 2 || cx.a_lo >= 0;
+  d4_t ra0 = d4_t{0.0, 0.0, 0.0, 0.0}, ra1 = ra0;
+  if (stage_a) { ra0 = *reinterpret_cast<const d4_t*>(Ap); ra1 = *reinterpret_cast<const d4_t*>(Ap + 4); }
   d4_t rb0v = *reinterpret_cast<const d4_t*>(Bp), rb1v = *reinterpret_cast<const d4_t*>(Bp + 4);
   __syncthreads();                             // the previous phase has finished reading the buffers
   stage(lds, ra0, ra1, rb0v, rb1v);
@@ -923,13 +927,16 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
   for (int kb = 0; kb < nkb; ++kb) {
     const int cur = kb & 1;
     if (kb + 1 < nkb) {
-      ra0 = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256);
-      ra1 = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256 + 4);
+      if (stage_a) {
+        ra0 = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256);
+        ra1 = *reinterpret_cast<const d4_t*>(Ap + (size_t)(kb + 1) * 256 + 4);
+      }
       rb0v = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256);
       rb1v = *reinterpret_cast<const d4_t*>(Bp + (size_t)(kb + 1) * 256 + 4);
     }
-    const double* LA = lds + cur * 4096 + (RB * cx.wave) * 256 + cx.a_rd;
-    const double* LB = lds + cur * 4096 + 2048 + cx.lane;
+    constexpr int BUF = RB == 2 ? 4096 : 3072, BOFF = RB == 2 ? 2048 : 1024;   // doubles per buffer: 4 RB A images, 8 B strips
+    const double* LA = lds + cur * BUF + (RB * cx.wave) * 256 + cx.a_rd;
+    const double* LB = lds + cur * BUF + BOFF + cx.lane;
     const int kkn = KS - kb * 4 < 4 ? KS - kb * 4 : 4;
 #pragma unroll 1
     for (int kk = 0; kk < kkn; ++kk) {
@@ -950,7 +957,7 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
         for (int s2 = 0; s2 < 8; ++s2) acc[0][s2] = MM<double>::mfma(a0, LB[(s2 * 4 + kk) * 64], acc[0][s2]);
       }
     }
-    if (kb + 1 < nkb) stage(lds + (cur ^ 1) * 4096, ra0, ra1, rb0v, rb1v);
+    if (kb + 1 < nkb) stage(lds + (cur ^ 1) * BUF, ra0, ra1, rb0v, rb1v);
     __syncthreads();
   }
   // epilogue: accumulator element t of lane l is row 4 t + (l >> 4), column l & 15 of its 16 x 16 tile
@@ -1044,7 +1051,7 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
 // CUs without a workgroup (1024 x 1024 x 3 outputs: 192 tiles on 256 CUs) -- half the reuse of a B fragment, twice the
 // workgroups.
 template <int RB>
-__global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
+__global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
                                                   const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
                                                   size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
                                                   int KSm, int KBm2, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
@@ -1067,8 +1074,8 @@ __global__ __launch_bounds__(256, 2) void k_bpost(const ModelConst mc, const Can
   cx.st_off = st_j * 8;
   cx.st_rb = cx.rb0 + st_i < nrb ? cx.rb0 + st_i : nrb - 1;
   cx.st_cs = cx.cs0 + st_i < ncs ? cx.cs0 + st_i : ncs - 1;
-  cx.a_lo = st_i * 256 + (st_j >> 3) * 64 + (st_j & 7) * 4;
-  cx.b_st = 2048 + st_i * 256 + cx.st_off;
+  cx.a_lo = st_i < 4 * RB ? st_i * 256 + (st_j >> 3) * 64 + (st_j & 7) * 4 : -1;   // (RB = 1: four images, half the threads stage one)
+  cx.b_st = (RB == 2 ? 2048 : 1024) + st_i * 256 + cx.st_off;
   cx.a_rd = (((cx.lane >> 4) << 2) + (cx.lane & 3)) * 2;
   // per-output operands; VA holds [V0 | V1;V0 | V1x] as three image sets, SBf holds [S0 | S0;-xn0 S0] as two fragment sets
   const double* VAo = VA + (size_t)o * sVA;
@@ -1429,10 +1436,12 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                      c->stream, (const double*)c->bl_P1A.p, pl.sP1A, (const double*)c->bl_T4f.p, pl.sT4f, pl.KB1, pl.nrb, pl.KB0,
                      (double*)c->bl_BtA.p, pl.sBtA);
   // stage 2 (fused): variance, mean, Lipschitz keys
-  const size_t lds = sizeof(double) * 2 * 4096;
   // (64 x 128 tiles when the 128 x 128 ones would not give every CU a workgroup)
   const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8);
+  // (the 64 x 128 form on every grid -- three workgroups per CU with its smaller LDS block -- measured 8 % slower on config B
+  // and 3 % on H: the 128 x 128 tile's reuse of a B fragment is worth more than the third wave per SIMD)
   const int rbw = (long long)gx * ((pl.nrb + 7) / 8) * q < c->n_cu ? 1 : 2;
+  const size_t lds = sizeof(double) * 2 * (rbw == 2 ? 4096 : 3072);
   const unsigned gy = (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
   int rc;
   if ((rc = ensure(c->bl_lpart, sizeof(double) * 4 * (size_t)gx * gy * q))) return rc;
