@@ -176,10 +176,12 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
                                                         double* __restrict__ D, int nfine, int ncoarse, long long clines, int cc0,
                                                         double h0c, double* __restrict__ Dc, const CoarseGrid cg, const FinalJob fin) {
   __shared__ Axis0Lds lds;
-  const int bid = (int)blockIdx.x;
-  if (bid < nfine) edt_axis0_wg_body<false>(bid, nfine, lds, U, nlines, count0, h0, D, cg);
-  else if (bid < nfine + ncoarse) edt_axis0_wg_body<true>(bid - nfine, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
-  else classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy);
+  // (order of the ranges: the merge and the coarse lines first -- few workgroups with longer chains that should start with the
+  // launch, not in the slots the fine lines leave at its end)
+  const int nfin = (int)gridDim.x - nfine - ncoarse, bid = (int)blockIdx.x;
+  if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy);
+  else if (bid < nfin + ncoarse) edt_axis0_wg_body<true>(bid - nfin, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
+  else edt_axis0_wg_body<false>(bid - nfin - ncoarse, nfine, lds, U, nlines, count0, h0, D, cg);
 }
 
 // axes >= 1: D_out[g] = min_t D_in[g + t stride] + (h t)^2, searched outwards with the two exits
