@@ -980,12 +980,14 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       if (slist) SBO_DECIDE(true);
       else SBO_DECIDE(false);
 #undef SBO_DECIDE
+      // (workgroups of the list scan: 2048 on config B's 4 M candidates, 4096 on H's 16 M -- -8 us there)
+      const int scan_wgs = (int)std::min<long long>(4096, std::max<long long>(1024, n / 2048));
       if (slist) {
         // lanes per listed candidate: 16 by default (more candidates in flight beat shorter rounds: 53 k open candidates
         // of config B take 19 us with 16 lanes, 32 us with 32), never more than a wave, 64 for 64-step blocks on request
         const int gl = c->scan_waves == 8 || c->scan_waves == 32 || c->scan_waves == 64 ? c->scan_waves : 16;
 #define SBO_SCAN_LIST(GL)                                                                                                       \
-  hipLaunchKernelGGL((k_edt_scan_list<T, GL>), dim3(2048), dim3(256), 0, c->stream, (const double*)din, goff, stride, last_cnt, \
+  hipLaunchKernelGGL((k_edt_scan_list<T, GL>), dim3(scan_wgs), dim3(256), 0, c->stream, (const double*)din, goff, stride, last_cnt, \
                      last_h, d, xscale, mean_c, var_c, (T)o->b, (const unsigned long long*)c->Lmax.p, lidx, sc, G,              \
                      (long long*)c->amb.p, bmin, blk, (const long long*)slist, rx)
         switch (gl) {
