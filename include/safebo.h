@@ -261,7 +261,8 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  * the posterior kernel's epilogue; measured no faster, default 0), "set_fuse" (1 default: on 2-D grids of one rank the
  * independent kernels of the set phase share launches; 0: one launch per kernel, same results), "set_lanes" (1 default: on one rank the constraints of a sweep alternate between two
  * streams -- their expander / optimistic-set chains are independent --, 0: one after the other), "eager_tables" (1 default:
- * sbo_model_set enqueues the GEMM posterior's per-(model, grid) tables for the resident grid itself), "spin_wait" (1 default:
+ * sbo_model_set enqueues the GEMM posterior's per-(model, grid) tables for the resident grid itself), "result_mirror" (1 default: the last kernel of a one-rank SafeOpt
+ * sweep writes the result block into pinned host memory itself and carries the end event; 0: a copy behind it), "spin_wait" (1 default:
  * the host polls the stream for up to 5 ms at the end of a sweep / model build before it sleeps in the runtime's wait), "fp64_recheck" (1 default: dtype SBO_F32 single-rank SafeOpt sweeps re-evaluate in fp64 every
  * candidate whose fp32 posterior -- within its 1e-4 contract -- cannot decide S, U, u*, M or the minimiser, so that those
  * equal the fp64 result; 0: masks are functions of the fp32 posterior alone), "comm_selftest" (1: a one-rank world created

@@ -210,6 +210,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->eager_tables = value ? 1 : 0;
     return SBO_OK;
   }
+  if (!strcmp(key, "result_mirror")) {
+    c->result_mirror = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "spin_wait")) {
     c->spin_wait = value ? 1 : 0;
     return SBO_OK;

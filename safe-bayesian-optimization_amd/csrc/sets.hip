@@ -510,8 +510,28 @@ __global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ part
 // GoOSE (!MAX): s = 0 arg-min of lcb_0 over S_t -> slot 0 (no count), s = c >= 1 over O_c -> slot c and |O_c|.
 template <bool MAX>
 __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts,
-                                                      SweepScalars* sc, const SweepScalars* lane1 /* nullptr, or the second lane's block */) {
+                                                      SweepScalars* sc, const SweepScalars* lane1 /* nullptr, or the second lane's block */,
+                                                      unsigned char* mirror /* nullptr, or the host's pinned landing area */,
+                                                      const unsigned long long* Lkeys) {
   if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
+  // `mirror`: the results go straight to the pinned host block the read-back would have filled (SweepScalars at 0, the
+  // Lipschitz keys at 3072) -- every workgroup its own slot, workgroup 0 the fields earlier kernels finished --, and the
+  // sweep's end event rides on this launch: no copy kernel and no barrier packet behind the last kernel.
+  SweepScalars* hm = reinterpret_cast<SweepScalars*>(mirror);
+  if (mirror && blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      hm->ustar_key = sc->ustar_key;
+      hm->count_S = sc->count_S;
+      hm->count_U = sc->count_U;
+      hm->n_amb = sc->n_amb;
+      hm->n_amb_total = sc->n_amb_total;
+      hm->n_scan = sc->n_scan;
+    }
+    if (threadIdx.x < kMaxQ) {
+      hm->rmax_key[threadIdx.x] = sc->rmax_key[threadIdx.x];
+      reinterpret_cast<unsigned long long*>(mirror + 3072)[threadIdx.x] = Lkeys[threadIdx.x];
+    }
+  }
   const int slot = blockIdx.x;
   const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
   Best best{0.0, -1};
@@ -528,6 +548,12 @@ __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __res
     sc->arg_idx[slot] = best.i;
     if (slot == 0) { if (MAX) sc->count_M += cnt; }
     else sc->count_set[slot - 1] += cnt;
+    if (mirror) {
+      hm->arg_val[slot] = best.v;
+      hm->arg_idx[slot] = best.i;
+      if (slot == 0) hm->count_M = sc->count_M;
+      else hm->count_set[slot - 1] = sc->count_set[slot - 1];
+    }
   }
 }
 
@@ -1097,7 +1123,7 @@ static int sweep_exchange_wait(sbo_ctx* c) {
 
 // C3 + host merge: every rank's slots and counters -> global ones.  slot_is_max[i] selects arg-max / arg-min.
 static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_max, unsigned long long* Lk = nullptr,
-                               hipEvent_t done_ev = nullptr) {
+                               hipEvent_t done_ev = nullptr, bool mirrored = false /* the last kernel wrote h_back and carries done_ev */) {
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   // (the Lipschitz keys ride in the same read-back: one synchronisation per sweep)
   // (pinned landing area: pageable destinations are staged by the runtime, ~20 us per copy)
@@ -1106,8 +1132,10 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   constexpr size_t kBack = 3072 + sizeof(unsigned long long) * kMaxQ;
   const unsigned long long* Lk_pinned = (const unsigned long long*)(c->h_back + 3072);
   if (!multi_rank(c)) {
-    SBO_HIP(hipMemcpyAsync(c->h_back, sc, kBack, hipMemcpyDeviceToHost, c->stream));
-    if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
+    if (!mirrored) {
+      SBO_HIP(hipMemcpyAsync(c->h_back, sc, kBack, hipMemcpyDeviceToHost, c->stream));
+      if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
+    }
     SBO_HIP(stream_wait(c, c->stream));
     memcpy(&h, c->h_back, sizeof(h));
     if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
@@ -1193,14 +1221,17 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
       hipLaunchKernelGGL((k_arg_masked<T, true, ValArray<T>>), dim3(nb), dim3(256), 0, c->stream, ValArray<T>{(const T*)c->var.p}, G, n,
                          (long long)c->cs.first, (Best*)(pbase + pstride * (size_t)cc));
   }
-  hipLaunchKernelGGL(k_sweep_finals<true>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0,
-                     sc, lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr);
+  const bool mirrored = !multi_rank(c) && c->result_mirror;
+  hipExtLaunchKernelGGL(k_sweep_finals<true>, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, mirrored ? c->ev[4] : nullptr, 0,
+                        (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, sc,
+                        lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr,
+                        mirrored ? c->h_back : (unsigned char*)nullptr, (const unsigned long long*)c->Lmax.p);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
   for (int t = 0; t < kArgSlots; ++t) is_max[t] = true;
   unsigned long long Lk[kMaxQ];
-  if ((rc = sweep_exchange_back(c, h, is_max, Lk, c->ev[4]))) return rc;
+  if ((rc = sweep_exchange_back(c, h, is_max, Lk, c->ev[4], mirrored))) return rc;
   c->masks_valid = true;
   c->last_sweep = 1;
   if (getenv("SBO_DEBUG_SCAN")) fprintf(stderr, "[safebo] open candidates scanned (last constraint) %lld, exact rechecks %lld\n", h.n_scan, h.n_amb_total);
@@ -1578,7 +1609,8 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
                          (long long)c->cs.first, (Best*)(pbase + pstride * (size_t)cc));
   }
   hipLaunchKernelGGL(k_sweep_finals<false>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride,
-                     n > 0 ? nb : 0, sc, lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr);
+                     n > 0 ? nb : 0, sc, lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr,
+                     (unsigned char*)nullptr, (const unsigned long long*)nullptr);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
