@@ -259,7 +259,8 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile), "bl_host_bases" (1: the axis bases of the GEMM posterior by
  * the host SVD of bilinear_host.hpp instead of the device kernel), "fuse_classify" (1: one-constraint sweeps take S / U from
  * the posterior kernel's epilogue; measured no faster, default 0), "set_fuse" (1 default: on 2-D grids of one rank the
- * independent kernels of the set phase share launches; 0: one launch per kernel, same results), "set_lanes" (1 default: on one rank the constraints of a sweep alternate between two
+ * independent kernels of the set phase share launches; 0: one launch per kernel, same results), "dist_u16" (1 default: on that path the fine distance image holds 16-bit step counts instead of
+ * squared distances as doubles -- same verdicts, a quarter of the bytes), "set_lanes" (1 default: on one rank the constraints of a sweep alternate between two
  * streams -- their expander / optimistic-set chains are independent --, 0: one after the other), "eager_tables" (1 default:
  * sbo_model_set enqueues the GEMM posterior's per-(model, grid) tables for the resident grid itself), "result_mirror" (1 default: the last kernel of a one-rank SafeOpt
  * sweep writes the result block into pinned host memory itself and carries the end event; 0: a copy behind it), "spin_wait" (1 default:

@@ -218,6 +218,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->spin_wait = value ? 1 : 0;
     return SBO_OK;
   }
+  if (!strcmp(key, "dist_u16")) {
+    c->dist_u16 = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "set_fuse")) {
     c->set_fuse = value ? 1 : 0;
     return SBO_OK;

@@ -583,13 +583,14 @@ struct MidJobs {
   const uint8_t* S;
   uint8_t* M;
   Best* partial;
-  int nm;                                  // block minima (0: none)
+  int nm;                                  // block minima (0: none); din: the axis-0 image (doubles, or step counts with h0)
+  double h0;
   const double* din;
   long long stride;
   int cnt, blk;
   double* bmin;
 };
-template <typename T>
+template <typename T, bool U16>
 __global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
   __shared__ double part[4][64];
   const int bid = (int)blockIdx.x;
@@ -597,8 +598,10 @@ __global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
     edt_scan_body(bid, j.ns, j.dc_in, j.dc_out, j.nc, j.cstride, j.ccnt, j.hc, j.sc, j.cidx, j.Lkeys, j.lidx, 0, j.cap_extra);
   else if (bid < j.ns + j.nb)
     minimizer_body<T>(bid - j.ns, j.nb, j.mean0, j.var0, j.n, j.first, j.b, j.S, j.M, j.sc, j.partial);
+  else if (U16)
+    block_min_body(bid - j.ns - j.nb, j.nm, part, DistU16{reinterpret_cast<const unsigned short*>(j.din), j.h0}, j.stride, j.cnt, j.blk, j.bmin);
   else
-    block_min_body(bid - j.ns - j.nb, j.nm, part, j.din, j.stride, j.cnt, j.blk, j.bmin);
+    block_min_body(bid - j.ns - j.nb, j.nm, part, DistF64{j.din, 0.0}, j.stride, j.cnt, j.blk, j.bmin);
 }
 
 #include "sets_exchange.inc.hpp"
@@ -884,7 +887,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     const bool want_bmin = d >= 2 && last_cnt_ >= 4 * blk_ && c->scan_blocks;
     // 2-D grids: the two axis-0 passes share a launch, and so do the coarse last-axis scan, the minimiser and the block minima
     const bool paired = d == 2 && coarse_ok && c->set_fuse && count0 <= kAxis0Max && count0 >= 128 && cc0 >= 128;
-    bool bmin_done = false;
+    bool bmin_done = false, u16 = false;
     double* din = (double*)c->dist2.p;
     double* dout = (double*)c->dist2b.p;
     long long stride = count0;
@@ -895,8 +898,13 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
         fin = mj->fin;
         mj->fin.pending = false;
       }
-      hipLaunchKernelGGL(k_edt_axis0_pair, dim3((unsigned)(nfine + ncoarse + (fin.pending ? 1 : 0))), dim3(256), 0, c->stream, Uall,
-                         nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin);
+      u16 = c->dist_u16 && count0 < 65535;           // the fine image as 16-bit step counts (0xffff: no U point on the line)
+      if (u16)
+        hipLaunchKernelGGL(k_edt_axis0_pair<true>, dim3((unsigned)(nfine + ncoarse + (fin.pending ? 1 : 0))), dim3(256), 0, c->stream, Uall,
+                           nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin);
+      else
+        hipLaunchKernelGGL(k_edt_axis0_pair<false>, dim3((unsigned)(nfine + ncoarse + (fin.pending ? 1 : 0))), dim3(256), 0, c->stream, Uall,
+                           nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin);
       MidJobs<T> j;
       memset(&j, 0, sizeof(j));
       j.sc = sc;
@@ -934,7 +942,9 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
         j.bmin = (double*)c->blockmin.p;
         bmin_done = true;
       }
-      hipLaunchKernelGGL((k_set_mid<T>), dim3((unsigned)(j.ns + j.nb + j.nm)), dim3(256), 0, c->stream, j);
+      j.h0 = c->cs.step[0];
+      if (u16) hipLaunchKernelGGL((k_set_mid<T, true>), dim3((unsigned)(j.ns + j.nb + j.nm)), dim3(256), 0, c->stream, j);
+      else hipLaunchKernelGGL((k_set_mid<T, false>), dim3((unsigned)(j.ns + j.nb + j.nm)), dim3(256), 0, c->stream, j);
       cg.Dc = dc1;
     } else {
       launch_minimizer<T>(c, o, mj);
@@ -1013,7 +1023,13 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
         // of config B take 19 us with 16 lanes, 32 us with 32), never more than a wave, 64 for 64-step blocks on request
         const int gl = c->scan_waves == 8 || c->scan_waves == 32 || c->scan_waves == 64 ? c->scan_waves : 16;
 #define SBO_SCAN_LIST(GL)                                                                                                       \
-  hipLaunchKernelGGL((k_edt_scan_list<T, GL>), dim3(scan_wgs), dim3(256), 0, c->stream, (const double*)din, goff, stride, last_cnt, \
+  if (u16)                                                                                                                      \
+    hipLaunchKernelGGL((k_edt_scan_list<T, GL, DistU16>), dim3(scan_wgs), dim3(256), 0, c->stream,                              \
+                       DistU16{reinterpret_cast<const unsigned short*>(din), c->cs.step[0]}, goff, stride, last_cnt,            \
+                       last_h, d, xscale, mean_c, var_c, (T)o->b, (const unsigned long long*)c->Lmax.p, lidx, sc, G,            \
+                       (long long*)c->amb.p, bmin, blk, (const long long*)slist, rx);                                           \
+  else                                                                                                                          \
+  hipLaunchKernelGGL((k_edt_scan_list<T, GL, DistF64>), dim3(scan_wgs), dim3(256), 0, c->stream, DistF64{(const double*)din, 0.0}, goff, stride, last_cnt, \
                      last_h, d, xscale, mean_c, var_c, (T)o->b, (const unsigned long long*)c->Lmax.p, lidx, sc, G,              \
                      (long long*)c->amb.p, bmin, blk, (const long long*)slist, rx)
         switch (gl) {

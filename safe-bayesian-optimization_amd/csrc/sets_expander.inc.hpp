@@ -44,6 +44,23 @@ __global__ __launch_bounds__(256) void k_edt_axis0(const uint8_t* __restrict__ U
   }
 }
 
+// The image of the fine axis-0 pass: squared distances as doubles, or -- on the shared-launch path of 2-D grids -- the step
+// counts themselves as 16-bit integers (0xffff: no U point on the line), a quarter of the bytes written by the pass and read
+// by the block minima and the list scan; the readers rebuild (h0 t)^2 exactly as the pass computes it.
+struct DistF64 {
+  const double* p;
+  double h0;
+  __device__ __forceinline__ double operator()(long long i) const { return p[i]; }
+};
+struct DistU16 {
+  const unsigned short* p;
+  double h0;
+  __device__ __forceinline__ double operator()(long long i) const {
+    const unsigned t = p[i];
+    const double dt = h0 * (double)t;
+    return t == 0xffffu ? kInfD : dt * dt;
+  }
+};
 constexpr int kCoarse = 8;
 constexpr int kDecideLines = 4;   // lines per workgroup of k_edt_decide / k_pdt_decide (2: 21.8 us, 4: 19.5, 8: 20.8, 16: 27.1 on config B)
 struct CoarseGrid {
@@ -97,7 +114,7 @@ struct Axis0Lds {
   int firstw[kAxis0Max / 64];   // index of the first set bit in words w.. (INT_MAX: none)
 };
 // (bid / nblk: this workgroup's index and the number of workgroups on this job -- the job may be one range of a launch)
-template <bool COARSE>
+template <bool COARSE, bool U16 = false>
 __device__ __forceinline__ void edt_axis0_wg_body(int bid, int nblk, Axis0Lds& lds, const uint8_t* __restrict__ U, long long nlines,
                                                   int count0, double h0, double* __restrict__ D, const CoarseGrid& cg) {
   unsigned long long* words = lds.words;
@@ -109,6 +126,7 @@ __device__ __forceinline__ void edt_axis0_wg_body(int bid, int nblk, Axis0Lds& l
   for (long long line = bid; line < nlines; line += nblk) {
     const uint8_t* u = U + line * count0;
     double* d = D + line * count0;
+    unsigned short* d16 = reinterpret_cast<unsigned short*>(D) + line * count0;     // (U16: the image holds step counts)
     for (int w = wave; w < nwords; w += 4) {
       const int i = w * 64 + lane;
       const unsigned long long m = __ballot(i < count0 && (COARSE ? coarse_cell_any(U, cg, line * count0 + i) : u[i] != 0));
@@ -152,12 +170,16 @@ __device__ __forceinline__ void edt_axis0_wg_body(int bid, int nblk, Axis0Lds& l
         int t = -1;
         if (li >= 0) t = i - li;
         if (ri != kNone && (t < 0 || ri - i < t)) t = ri - i;
-        double v = kInfD;
-        if (t >= 0) {
-          const double dt = h0 * (double)t;
-          v = dt * dt;
+        if (U16) {
+          d16[i] = t >= 0 ? (unsigned short)t : (unsigned short)0xffffu;
+        } else {
+          double v = kInfD;
+          if (t >= 0) {
+            const double dt = h0 * (double)t;
+            v = dt * dt;
+          }
+          d[i] = v;
         }
-        d[i] = v;
       }
     }
     __syncthreads();
@@ -172,6 +194,7 @@ __global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict_
 // fine and coarse axis-0 passes of a 2-D grid in one launch (both read the U mask only): workgroups [0, nfine) take the
 // fine lines, the rest the lines of coarse cells
 // (+ one workgroup for the merge of the classification's partials when `fin` is pending: nothing here reads the scalars)
+template <bool U16>
 __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
                                                         double* __restrict__ D, int nfine, int ncoarse, long long clines, int cc0,
                                                         double h0c, double* __restrict__ Dc, const CoarseGrid cg, const FinalJob fin) {
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
   const int nfin = (int)gridDim.x - nfine - ncoarse, bid = (int)blockIdx.x;
   if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy);
   else if (bid < nfin + ncoarse) edt_axis0_wg_body<true>(bid - nfin, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
-  else edt_axis0_wg_body<false>(bid - nfin - ncoarse, nfine, lds, U, nlines, count0, h0, D, cg);
+  else edt_axis0_wg_body<false, U16>(bid - nfin - ncoarse, nfine, lds, U, nlines, count0, h0, D, cg);
 }
 
 // axes >= 1: D_out[g] = min_t D_in[g + t stride] + (h t)^2, searched outwards with the two exits
@@ -220,7 +243,8 @@ __device__ __forceinline__ double edt_scan_point(const double* __restrict__ Din,
 // with one load instead of `blk`; the candidates examined inside a block and their arithmetic are those of the
 // step-by-step scan, so the minimum (up to the same early exits) is identical.  This keeps the scan cost near
 // O(sqrt(radius in steps)) when the grid is much finer along the last axis than the radius (weak-scaling grids).
-__device__ __forceinline__ void block_min_body(int bid, int nwg, double (&part)[4][64], const double* __restrict__ Din, long long stride,
+template <typename DS>
+__device__ __forceinline__ void block_min_body(int bid, int nwg, double (&part)[4][64], const DS Din, long long stride,
                                                int cnt, int blk, double* __restrict__ Bmin) {
   // 64 in-plane positions x 4 quarters of a block per workgroup: a thread takes blk / 4 steps (all loads in flight),
   // the quarters meet in LDS
@@ -237,7 +261,7 @@ __device__ __forceinline__ void block_min_body(int bid, int nwg, double (&part)[
     if (p < stride) {
 #pragma unroll 8
       for (int j = j0; j < j1; ++j) {
-        const double v = Din[(long long)j * stride + p];
+        const double v = Din((long long)j * stride + p);
         m = v < m ? v : m;
       }
     }
@@ -254,7 +278,7 @@ __device__ __forceinline__ void block_min_body(int bid, int nwg, double (&part)[
 __global__ __launch_bounds__(256) void k_block_min(const double* __restrict__ Din, long long stride, int cnt, int blk,
                                                    double* __restrict__ Bmin) {
   __shared__ double part[4][64];
-  block_min_body((int)blockIdx.x, (int)gridDim.x, part, Din, stride, cnt, blk, Bmin);
+  block_min_body((int)blockIdx.x, (int)gridDim.x, part, DistF64{Din, 0.0}, stride, cnt, blk, Bmin);
 }
 
 // Euclidean form (values >= 0, exits as edt_scan_point: (h t)^2 >= best, h t > cap, best <= accept2).
@@ -544,8 +568,8 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
 // candidate: the lanes take GL blocks (bounds) or the steps of one block at a time and combine with group minima -- the
 // same candidates and arithmetic as edt_scan_blocked, with the dependent-load chain cut from ~100 to ~5 per candidate.
 // (The two halves of a wave follow their own trip counts; every cross-lane operation stays inside one half.)
-template <typename T, int GL>
-__global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict__ Din, long long goff, long long stride, int cnt,
+template <typename T, int GL, typename DS>
+__global__ __launch_bounds__(256) void k_edt_scan_list(const DS Din, long long goff, long long stride, int cnt,
                                                        double h, int d, double xscale, const T* __restrict__ mean_c,
                                                        const T* __restrict__ var_c, T b, const unsigned long long* Lkeys, int lidx,
                                                        SweepScalars* sc, uint8_t* __restrict__ G, long long* __restrict__ amb,
@@ -576,7 +600,7 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict_
     const double acc2 = thr > 0 ? thr * thr : -1.0;
     const long long gg = goff + g, p = gg % stride;
     const int ia = (int)((gg / stride) % cnt), b0 = ia / blk;
-    double best = Din[(long long)ia * stride + p];
+    double best = Din((long long)ia * stride + p);
     // blocks within reach of the radius
     const int kmax = (int)fmin((double)nblk, floor(cap / (h * (double)blk)) + 2.0);
     const int blo = b0 - kmax > 0 ? b0 - kmax : 0, bhi = b0 + kmax < nblk - 1 ? b0 + kmax : nblk - 1;
@@ -595,7 +619,7 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const double* __restrict_
         if (s0 + lane < blk && jn < cnt) {
           const double dt = h * (double)(jn > ia ? jn - ia : ia - jn);
           if (dt <= cap) {
-            const double v = Din[(long long)jn * stride + p] + dt * dt;
+            const double v = Din((long long)jn * stride + p) + dt * dt;
             cnd = v < cnd ? v : cnd;
           }
         }
