@@ -150,6 +150,12 @@ typedef struct sbo_profile {
   int64_t fp64_rechecks;         /* dtype SBO_F32 SafeOpt sweeps: candidates whose fp32 bounds could not decide S / U / u* / M / the
                                     minimiser and were re-evaluated in fp64 (option "fp64_recheck"); 0 otherwise                  */
   double recheck_ms;             /* device time of that step (band reductions, flagging, fp64 posterior of the list, scatter)    */
+  /* overlapped sweeps (option "k1_split"): the constraints' outputs leave K1b first and the constraint-only part of the set
+   * phase runs beside the objective's GEMM on a second stream */
+  double set_chain_ms;           /* device time of that chain: stop of the constraints' K1b launch -> its last kernel (0: not split) */
+  double set_exposed_ms;         /* K1 stop event (the objective's launch) -> end of the sweep: what the set phase adds to K1     */
+  int32_t k1_split;              /* 1: the last sweep ran overlapped                                                              */
+  int32_t host_syncs;            /* host waits on the device inside the last sweep call (1 = the result read-back only)          */
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */
@@ -257,8 +263,11 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  * kernel), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
  * "scan_waves" (1 default: open candidates of the expander query are scanned by half-waves), "goose_pairs" (1: pair
  * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile), "bl_host_bases" (1: the axis bases of the GEMM posterior by
- * the host SVD of bilinear_host.hpp instead of the device kernel), "fuse_classify" (1: one-constraint sweeps take S / U from
- * the posterior kernel's epilogue; measured no faster, default 0), "set_fuse" (1 default: on 2-D grids of one rank the
+ * the host SVD of bilinear_host.hpp instead of the device kernel), "fuse_classify" (one-constraint sweeps take S / U from
+ * the GEMM posterior's mean epilogue, with sign tests that need no square root: 1 always, 0 never, -1 default: when that launch has at least
+ * four workgroups per CU), "k1_split" (1: sweeps of constrained models on the GEMM posterior of one rank run the constraints' outputs first
+ * and the constraint-only part of their set phase on a second stream beside the objective's GEMM; identical results, measured slower: default 0;
+ * "split_rb": tile height of those launches), "set_fuse" (1 default: on 2-D grids of one rank the
  * independent kernels of the set phase share launches; 0: one launch per kernel, same results), "dist_u16" (1 default: on that path the fine distance image holds 16-bit step counts instead of
  * squared distances as doubles -- same verdicts, a quarter of the bytes), "set_lanes" (1 default: on one rank the constraints of a sweep alternate between two
  * streams -- their expander / optimistic-set chains are independent --, 0: one after the other), "eager_tables" (1 default:

@@ -68,6 +68,7 @@ class Profile(C.Structure):
         ("posterior_flops", C.c_double), ("candidates", C.c_int64), ("posterior_launches", C.c_int32),
         ("posterior_kernel", C.c_int32), ("posterior_executed_flops", C.c_double), ("posterior_setup_ms", C.c_double),
         ("fp64_rechecks", C.c_int64), ("recheck_ms", C.c_double),
+        ("set_chain_ms", C.c_double), ("set_exposed_ms", C.c_double), ("k1_split", C.c_int32), ("host_syncs", C.c_int32),
     ]
 
 

@@ -48,6 +48,14 @@ hipError_t stream_wait(const sbo_ctx* c, hipStream_t st) {
   return hipStreamSynchronize(st);
 }
 
+// after a failed call: nothing of it may still be running on the side streams when the caller comes back (a later call
+// synchronises the main stream only and would race with orphaned kernels on the shared scratch)
+void drain_streams(sbo_ctx* c) {
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+}
+
 void release(DevBuf& b) {
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr;
@@ -89,6 +97,13 @@ int sbo_init(int device_id, sbo_ctx** out) {
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    // the chain stream of an overlapped sweep carries many short kernels next to one long GEMM launch: highest priority,
+    // so that its workgroups are placed ahead of the GEMM's when both queues have work
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    e = hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, greatest);
+  }
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
   for (auto& ev : c->ev) {
     e = hipEventCreate(&ev);
@@ -128,6 +143,8 @@ static int shadow_ensure(sbo_ctx* c) {
   s->n_cu = c->n_cu;
   s->stream = c->stream;
   s->stream2 = c->stream2;
+  s->stream3 = c->stream3;
+  s->k1_split = 0;
   for (int i = 0; i < 8; ++i) s->ev[i] = c->ev[i];
   s->h_back = c->h_back;
   s->fp64_recheck = 0;
@@ -145,6 +162,7 @@ int sbo_shutdown(sbo_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->shadow) {
     sbo_ctx* s = c->shadow;
     for (DevBuf* b : {&s->Fpk, &s->As, &s->sqA, &s->alpha, &s->Xn, &s->pts, &s->mean, &s->var, &s->scal, &s->mwork, &s->Fplain, &s->alpha64})
@@ -155,7 +173,7 @@ int sbo_shutdown(sbo_ctx* c) {
   }
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->upart, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -164,6 +182,7 @@ int sbo_shutdown(sbo_ctx* c) {
   if (c->h_c1) (void)hipHostFree(c->h_c1);
   if (c->h_back) (void)hipHostFree(c->h_back);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -187,6 +206,15 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "k1_wgs_per_cu")) {
     if (value < 0 || value > 64) return fail(SBO_E_INVALID, "k1_wgs_per_cu out of range");
     c->k1_wgs_per_cu = (int)value;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "k1_split")) {
+    c->k1_split = value ? 1 : 0;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "split_rb")) {
+    if (value < 0 || value > 2) return fail(SBO_E_INVALID, "split_rb must be 0 (auto), 1 or 2");
+    c->split_rb = (int)value;
     return SBO_OK;
   }
   if (!strcmp(key, "bilinear")) {
@@ -231,7 +259,8 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     return SBO_OK;
   }
   if (!strcmp(key, "fuse_classify")) {
-    c->fuse_classify = value ? 1 : 0;
+    if (value < -1 || value > 1) return fail(SBO_E_INVALID, "fuse_classify must be -1 (auto), 0 or 1");
+    c->fuse_classify = (int)value;
     return SBO_OK;
   }
   if (!strcmp(key, "goose_pairs")) {

@@ -864,7 +864,7 @@ struct PostCtx {
   // thread stored in the variance phase and writes the S / U bytes; null = off
   const double* var_rd;
   uint8_t *S, *U;
-  double bconf;
+  double bconf, bb;   // confidence multiplier and its square
   int cS, cU;         // this thread's counts
   double rmax;        // max ucb over its safe candidates (-1: none; ucb >= lcb >= 0 on S)
 };
@@ -874,17 +874,21 @@ struct PostCtx {
 // The accumulators belong to the caller: phase 2 does not start from zero but from phase 1's sums scaled by -xn0 of the
 // candidate's column, g0 = V1 . S0 - xn0 (V0 . S0) -- six k-steps instead of twelve for the stacked [V1; V0] operand.
 // S / U bits of one candidate from its stored mean / var: the arithmetic of k_classify (models/SafeOpt.py:37-43, 57-59, 73-77)
-__device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) {
-  const double v = cx.var_rd[g];
-  const double sd = mul_rn(cx.bconf, sqrt_rn(v));
-  const double lcb = sub_rn(m, sd), ucb = add_rn(m, sd);
-  const bool s_ = lcb >= 0.0, u_ = lcb <= 0.0;
-  cx.S[g] = s_;
-  cx.U[g] = u_;
-  cx.cS += s_;
-  cx.cU += u_;
-  if (s_ && ucb > cx.rmax) cx.rmax = ucb;
+// (the sign of lcb without the square root -- lcb_sign, device_common.hpp -- and the exact ucb, for the radius key, only when
+// its cheap upper bound beats this thread's running maximum: the IEEE f64 square root is a dozen dependent instructions on the
+// datapath the matrix cores use, which is what made this epilogue cost the kernel as much as the separate pass saved)
+__device__ __forceinline__ void post_classify_mv(PostCtx& cx, size_t g, double m, double v) {
+  const LcbSign sg = lcb_sign(m, v, cx.bconf, cx.bb);
+  cx.S[g] = sg.ge;
+  cx.U[g] = sg.le;
+  cx.cS += sg.ge;
+  cx.cU += sg.le;
+  if (sg.ge && !(ucb_upper(m, v, cx.bconf) <= cx.rmax)) {
+    const double ucb = add_rn(m, mul_rn(cx.bconf, sqrt_rn(v)));
+    if (ucb > cx.rmax) cx.rmax = ucb;
+  }
 }
+__device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) { post_classify_mv(cx, g, m, cx.var_rd[g]); }
 
 template <int PH, int RB>
 __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict__ A, const double* __restrict__ B, int KB,
@@ -984,16 +988,7 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
             rowp[s2 * 16] = mv[s2];
           }
 #pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) {
-            const double sd = mul_rn(cx.bconf, sqrt_rn(vr[s2]));
-            const double lcb = sub_rn(mv[s2], sd), ucb = add_rn(mv[s2], sd);
-            const bool s_ = lcb >= 0.0, u_ = lcb <= 0.0;
-            cx.S[g0 + s2 * 16] = s_;
-            cx.U[g0 + s2 * 16] = u_;
-            cx.cS += s_;
-            cx.cU += u_;
-            if (s_ && ucb > cx.rmax) cx.rmax = ucb;
-          }
+          for (int s2 = 0; s2 < 8; ++s2) post_classify_mv(cx, g0 + s2 * 16, mv[s2], vr[s2]);
           continue;
         }
 #pragma unroll
@@ -1057,9 +1052,10 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
                                                   int KSm, int KBm2, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
                                                   double* __restrict__ var_out, double* __restrict__ Lpart,
                                                   const double* __restrict__ xn0, uint8_t* __restrict__ Sfuse, uint8_t* __restrict__ Ufuse,
-                                                  double bconf, unsigned long long* __restrict__ cpart /* [waves of output 1][kFuseRow] */) {
+                                                  double bconf, unsigned long long* __restrict__ cpart /* [waves of output 1][kFuseRow] */,
+                                                  int o_base /* first output of this launch (split sweeps: constraints, then the objective) */) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
-  const int o = blockIdx.z;
+  const int o = blockIdx.z + o_base;
   PostCtx cx;
   cx.lds = lds;
   cx.tid = threadIdx.x; cx.lane = cx.tid & 63; cx.wave = cx.tid >> 6;
@@ -1088,6 +1084,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   cx.S = fuse ? Sfuse : nullptr;
   cx.U = Ufuse;
   cx.bconf = bconf;
+  cx.bb = bconf * bconf;
   cx.cS = cx.cU = 0;
   cx.rmax = -1.0;
   double gmax = 0.0;
@@ -1440,14 +1437,23 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8);
   // (the 64 x 128 form on every grid -- three workgroups per CU with its smaller LDS block -- measured 8 % slower on config B
   // and 3 % on H: the 128 x 128 tile's reuse of a B fragment is worth more than the third wave per SIMD)
-  const int rbw = (long long)gx * ((pl.nrb + 7) / 8) * q < c->n_cu ? 1 : 2;
+  // Split sweeps (sbo_ctx::split_request): the constraints' outputs in a first launch, the objective's in a second -- the
+  // constraint-only part of the set phase then runs beside the second one.  Each launch should still give every CU two
+  // workgroups, so the 64 x 128 tiles are taken already when the 128 x 128 ones of the smaller launch number fewer than that.
+  const bool split = c->split_request && q >= 2;
+  const long long wgs_rb2 = (long long)gx * ((pl.nrb + 7) / 8);    // workgroups per output with 128 x 128 tiles
+  int rbw = wgs_rb2 * q < c->n_cu ? 1 : 2;
+  if (split) rbw = c->split_rb ? c->split_rb : (wgs_rb2 < 2ll * c->n_cu ? 1 : 2);
   const size_t lds = sizeof(double) * 2 * (rbw == 2 ? 4096 : 3072);
   const unsigned gy = (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
   int rc;
   if ((rc = ensure(c->bl_lpart, sizeof(double) * 4 * (size_t)gx * gy * q))) return rc;
   // a sweep may ask for the S / U bytes, |S|, |U| and the radius key straight from the mean epilogue of the constraint
   // (one-constraint models; the masks are allocated by the sweep before it enqueues the posterior)
-  const bool fuse = c->fuse_request && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
+  // (r03: with the sqrt-free sign tests the fused epilogue saves the separate pass 76 us on config H and costs the GEMM 36;
+  // on config B, two workgroups per CU, the two cancel -- "auto" asks for at least four workgroups per CU)
+  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
+  const bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
                     c->maskU.bytes >= (size_t)cs.n_local;
   c->fuse_rows = 0;
   if (fuse) {
@@ -1459,12 +1465,22 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // the K1 stop event rides on the last launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
   // the next kernel waits ~6 us for.  A sweep merges the Lipschitz partials in its own first small kernel (lmax_defer).
-  hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream, nullptr, c->lmax_defer ? c->ev[1] : nullptr, 0,
-                        mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
-                        pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
-                        (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
-                        fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                        (unsigned long long*)c->cpart.p);
+  auto post = [&](int o_base, int nz, hipEvent_t stop) {
+    hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)nz), dim3(256), lds, c->stream, nullptr, stop, 0,
+                          mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
+                          pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
+                          (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
+                          fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
+                          (unsigned long long*)c->cpart.p, o_base);
+  };
+  c->split_done = false;
+  if (split && c->lmax_defer) {
+    post(1, q - 1, c->ev_join[6]);
+    post(0, 1, c->ev[1]);
+    c->split_done = true;
+  } else {
+    post(0, q, c->lmax_defer ? c->ev[1] : nullptr);
+  }
   if (c->lmax_defer) {
     c->lmax_pending = true;
     c->lmax_per_out = (int)(4 * gx * gy);

@@ -90,6 +90,44 @@ __device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, 
 __device__ __forceinline__ double sqrt_rn(double a) { return __dsqrt_rn(a); }
 __device__ __forceinline__ float sqrt_rn(float a) { return __fsqrt_rn(a); }
 
+// Sign of lcb = fl(m - sd), sd = fl(b fl(sqrt v)) (models/SafeOpt.py:40-45) WITHOUT the square root where that is safe.
+// A difference of two doubles has the sign of the exact difference, so lcb >= 0 <=> m >= sd and lcb <= 0 <=> m <= sd, and sd
+// lies within 2.0001 * 2^-53 (relative) of b sqrt(v): comparing m^2 with b^2 v decides every candidate whose bound is not
+// within a few ulp of zero; only those take the IEEE square root (a dozen dependent f64 instructions on the datapath the
+// matrix cores share).  The decisions are the reference's bit for bit.  bb = fl(b b).
+struct LcbSign {
+  bool ge, le;      // lcb >= 0 (the S test, models/SafeOpt.py:57-59), lcb <= 0 (the U test, :73-77)
+};
+__device__ __forceinline__ LcbSign lcb_sign(double m, double v, double b, double bb) {
+  if (b >= 0.0 && v >= 0.0) {
+    if (m < 0.0) return LcbSign{false, true};                       // sd >= 0 > m
+    const double P = m * m, Q = bb * v;                              // three roundings between them: relative 3 * 2^-53
+    constexpr double c = 1.0 + 0x1p-48, tiny = 1e-250, huge = 1e300;
+    if (P < huge && Q < huge) {
+      if (P > tiny && P >= Q * c) return LcbSign{true, false};      // m > sd for sure
+      if (Q > tiny && P * c <= Q) return LcbSign{false, true};      // m < sd for sure
+    }
+  }
+  const double sd = mul_rn(b, sqrt_rn(v));
+  return LcbSign{m >= sd, m <= sd};
+}
+// bounds of ucb = fl(m + fl(b fl(sqrt v))) from a single-precision square root: the reductions over ucb (largest ucb_c over
+// S, smallest ucb_0 over S) evaluate the exact bound only for candidates that could move the running extremum
+__device__ __forceinline__ double ucb_upper(double m, double v, double b) {
+  const float sf = __fsqrt_rn((float)v);                            // (v beyond the float range: inf -- the exact path is taken)
+  const double s_up = (double)sf * (1.0 + 0x1p-20) + 1e-18;
+  const double x = m + b * s_up;
+  return x + (x < 0 ? -x : x) * 0x1p-50;
+}
+__device__ __forceinline__ double ucb_lower(double m, double v, double b) {
+  const float sf = __fsqrt_rn((float)v);
+  double s_lo = (double)sf * (1.0 - 0x1p-20) - 1e-18;
+  s_lo = s_lo > 0.0 ? s_lo : 0.0;
+  if (!(sf < 3.0e38f)) s_lo = 0.0;                                  // (inf / NaN: no information)
+  const double x = m + b * s_lo;
+  return x - (x < 0 ? -x : x) * 0x1p-50;
+}
+
 // order-preserving map double -> uint64 (for atomicMin / atomicMax on signed values)
 __host__ __device__ __forceinline__ unsigned long long ord_key(double v) {
   unsigned long long b;

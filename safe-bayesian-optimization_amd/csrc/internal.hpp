@@ -61,6 +61,7 @@ struct sbo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // side stream: the K1b axis bases of a new model run next to its factorisation
+  hipStream_t stream3 = nullptr;   // chain stream of an overlapped sweep (k1_split): the constraints' set phase next to the objective's K1b
   int n_cu = 256;
   // model
   bool has_model = false;
@@ -124,9 +125,11 @@ struct sbo_ctx {
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
   sbo::DevBuf bl_lpart; // K1b: per-wave Lipschitz partials of k_bpost
   sbo::DevBuf cpart;   // per-workgroup partials of k_classify
+  sbo::DevBuf upart;   // overlapped sweeps: per-workgroup u* keys of k_obj_front
+  int host_syncs = 0;  // host waits on the device inside the running sweep call (sbo_profile.host_syncs)
   // classification fused into the posterior (K1b, one constraint): a sweep sets fuse_request / fuse_b before it enqueues the
   // posterior; fuse_rows > 0 afterwards = the kernel wrote S / U and that many partial rows at the head of cpart
-  bool fuse_request = false;
+  int fuse_request = 0;    // 0 no, 1 yes, 2 when the GEMM launch is large enough for it to pay (option fuse_classify = -1)
   double fuse_b = 0.0;
   int fuse_rows = 0;
   // Lipschitz keys of K1b: a sweep sets lmax_defer before it enqueues the posterior; the posterior then leaves its per-wave
@@ -134,6 +137,14 @@ struct sbo_ctx {
   bool lmax_defer = false;
   bool lmax_pending = false;
   int lmax_per_out = 0;
+  // Overlapped sweep (option k1_split, K1b on one rank, q >= 2): a sweep sets split_request before it enqueues the posterior;
+  // K1b then runs the constraints' outputs first (stop event ev_join[6]) and the objective's output last (stop event
+  // ev[1]), and sets split_done: the sweep runs the constraint-only part of its set phase -- S / U, distance transforms,
+  // expander / optimistic-set verdicts: everything but u*, the M mask and the arg-reductions over var_0 / lcb_0 -- on
+  // stream3 behind ev_join[6], next to the objective's GEMM, and joins the main stream for the objective-dependent tail.
+  bool split_request = false;
+  bool split_done = false;
+  int split_rb = 0;        // option: tile height of the split launches (0 auto: 64 x 128 tiles when 128 x 128 ones leave fewer than two workgroups per CU; 1 / 2 forced)
   sbo::DevBuf Wfull;   // multi-rank GoOSE: source weights of the whole grid (all-gathered), T [grid_total]
   sbo::DevBuf Uwin;    // multi-rank: U mask of the expander transform's window (own planes + halo), uint8
   long long uwin_first = 0, uwin_n = 0;   // flat range the window covers
@@ -168,9 +179,10 @@ struct sbo_ctx {
   int spin_wait = 1;       // the host polls the stream at the end of a sweep / model build instead of sleeping in the runtime's wait (0: hipStreamSynchronize)
   int dist_u16 = 1;        // shared-launch path of 2-D grids: the fine axis-0 image as 16-bit step counts (0: squared distances as doubles)
   int set_fuse = 1;        // 2-D grids: independent set-phase kernels share launches (k_edt_axis0_pair, k_set_mid); 0: one launch each
-  int fuse_classify = 0;   // (A/B option, measured no faster: the f64 sqrt of the bounds costs the matrix kernel what the separate pass saves) 1: one-constraint sweeps on the K1b path take their S / U bytes from the posterior kernel's epilogue
+  int fuse_classify = -1;  // one-constraint sweeps on the K1b path take their S / U bytes from the posterior kernel's mean epilogue: 1 always, 0 never, -1 (default) when the launch has at least four workgroups per CU (r03, sqrt-free sign tests: config H -40 us, config B +-0)
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
   int phase_events = 0;    // 1: events between the set phases too (classify / expander / arg-reduce times in sbo_profile)
+  int k1_split = 0;        // (A/B option, measured slower: f64 matrix and vector instructions share a datapath the GEMM already keeps ~75 % busy) 1: K1b sweeps of constrained models on one rank run the constraints' set phase beside the objective's GEMM
   int bilinear = 1;        // 1: fp64 2-D grids run the posterior as two GEMMs in a reduced basis when the bases qualify (K1b)
   int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
   // fp32 models: an fp64 twin of the model (same arrays, double images) that re-evaluates the candidates the fp32 bounds
@@ -200,6 +212,7 @@ int hip_fail(hipError_t e, const char* what);
 int ensure(DevBuf& b, size_t bytes);
 hipError_t stream_wait(const sbo_ctx* c, hipStream_t st);   // hipStreamSynchronize, polling first (option spin_wait)
 void release(DevBuf& b);
+void drain_streams(sbo_ctx* c);   // after a failed call: wait for whatever it left on the main and side streams
 
 // launchers implemented in the .hip files -----------------------------------------------------
 int launch_posterior(sbo_ctx* c);

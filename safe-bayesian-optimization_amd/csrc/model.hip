@@ -742,7 +742,9 @@ int model_append(sbo_ctx* c, const std::vector<double>& kvec, const double* kapp
 }
 
 int model_build(sbo_ctx* c, const double* const* host_invK, const double* X_norm, const double* Y_norm) {
-  return c->dtype == SBO_F64 ? model_build_t<double>(c, host_invK, X_norm, Y_norm) : model_build_t<float>(c, host_invK, X_norm, Y_norm);
+  const int rc = c->dtype == SBO_F64 ? model_build_t<double>(c, host_invK, X_norm, Y_norm) : model_build_t<float>(c, host_invK, X_norm, Y_norm);
+  if (rc != SBO_OK) drain_streams(c);     // (the bases may still be running on the second stream)
+  return rc;
 }
 
 }  // namespace sbo

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include "device_common.hpp"
 
@@ -28,6 +29,13 @@ int comm_allreduce_sum_f64(sbo_ctx* c, double* dev, int count);
 int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_per_rank);
 
 constexpr double kInfD = 1.0e300;
+// Set-phase kernels that may run beside a GEMM launch (overlapped sweeps) raise their waves' issue priority: they are short,
+// latency-bound chains, and f64 matrix instructions of a co-resident GEMM wave otherwise keep the shared datapath busy
+#ifdef SBO_NO_CHAIN_PRIO
+#define SBO_CHAIN_PRIO() ((void)0)
+#else
+#define SBO_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
 constexpr int kArgSlots = 16;
 
 // small device-resident scalar block of one sweep
@@ -124,42 +132,70 @@ __device__ __forceinline__ void lcb_ucb(T m, T v, T b, T& lcb, T& ucb) {
 constexpr int kClassifyRow = 3 + kMaxQ;   // u* key, |S|, |U|, radius keys
 
 // ---- K3a: S / U masks, u* --------------------------------------------------------------------------
-template <typename T>
+// OBJ = false: the constraints' outputs only (overlapped sweeps: the objective's posterior is still being computed) -- S / U
+// bytes, |S|, |U| and the radius keys; u* is then reduced over S by k_obj_front once the objective is there.
+template <typename T, bool OBJ>
 __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, const T* __restrict__ var, long long n,
                                                   int q, T b, uint8_t* __restrict__ S, uint8_t* __restrict__ U,
                                                   unsigned long long* __restrict__ part /* [gridDim.x][kClassifyRow] */) {
   __shared__ unsigned long long rmax_sh[kMaxQ];   // max over S of ucb_c: bounds the expander search radius
+  SBO_CHAIN_PRIO();
   if (threadIdx.x < kMaxQ) rmax_sh[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long umin = ~0ull;
   long long cS = 0, cU = 0;
   // constraints first (S / U bits, ucb_c for the radius keys); the objective's mean / var are read for safe candidates
   // only -- S is a fifth of config B's grid, so the kernel streams (q - 1) / q of the posterior plus that fifth
+  // fp64: the sign of every lcb_c without the square root (lcb_sign), and the exact ucb_c -- for the radius keys -- only of
+  // safe candidates whose cheap upper bound beats the workgroup's running maximum
+  constexpr bool kFast = std::is_same<T, double>::value;
+  const double bb = (double)b * (double)b;
   auto constraints = [&](const T* mv /* [2 * q]: mean_c, var_c (entries of output 0 unused) */, T* ucbc) {
     bool s_ = true, u = true;
 #pragma unroll
     for (int c = 1; c < kMaxQ; ++c) {
       if (c < q) {
-        T lcb;
-        lcb_ucb(mv[2 * c], mv[2 * c + 1], b, lcb, ucbc[c]);   // one sqrt per (candidate, constraint)
-        s_ = s_ && (lcb >= T(0));
-        u = u && (lcb <= T(0));
+        if constexpr (kFast) {
+          const LcbSign sg = lcb_sign((double)mv[2 * c], (double)mv[2 * c + 1], (double)b, bb);
+          s_ = s_ && sg.ge;
+          u = u && sg.le;
+        } else {
+          T lcb;
+          lcb_ucb(mv[2 * c], mv[2 * c + 1], b, lcb, ucbc[c]);   // one sqrt per (candidate, constraint)
+          s_ = s_ && (lcb >= T(0));
+          u = u && (lcb <= T(0));
+        }
       }
     }
     cS += s_;
     cU += u;
     return (unsigned)(s_ ? 1u : 0u) | (unsigned)(u ? 2u : 0u);
   };
-  auto objective = [&](T m0, T v0, const T* ucbc) {       // a safe candidate: u* key and radius keys
-    T lcb, ucb;
-    lcb_ucb(m0, v0, b, lcb, ucb);
-    const unsigned long long k = ord_key((double)ucb);
-    umin = k < umin ? k : umin;
+  auto objective = [&](T m0, T v0, const T* mv, const T* ucbc) {       // a safe candidate: u* key and radius keys
+    if (OBJ) {
+      bool need = true;
+      if constexpr (kFast) need = !(ord_key(ucb_lower((double)m0, (double)v0, (double)b)) >= umin);
+      if (need) {
+        T lcb, ucb;
+        lcb_ucb(m0, v0, b, lcb, ucb);
+        const unsigned long long k = ord_key((double)ucb);
+        umin = k < umin ? k : umin;
+      }
+    }
 #pragma unroll
     for (int c = 1; c < kMaxQ; ++c) {
       if (c < q) {
-        const unsigned long long kc = ord_key((double)ucbc[c]);
-        if (kc > rmax_sh[c]) atomicMax(&rmax_sh[c], kc);
+        if constexpr (kFast) {
+          if (!(ord_key(ucb_upper((double)mv[2 * c], (double)mv[2 * c + 1], (double)b)) <= rmax_sh[c])) {
+            T lcb, ucb;
+            lcb_ucb(mv[2 * c], mv[2 * c + 1], b, lcb, ucb);
+            const unsigned long long kc = ord_key((double)ucb);
+            if (kc > rmax_sh[c]) atomicMax(&rmax_sh[c], kc);
+          }
+        } else {
+          const unsigned long long kc = ord_key((double)ucbc[c]);
+          if (kc > rmax_sh[c]) atomicMax(&rmax_sh[c], kc);
+        }
       }
     }
   };
@@ -185,10 +221,13 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
       }
       const unsigned r0 = constraints(mv0, uc0), r1 = constraints(mv1, uc1);
       if ((r0 | r1) & 1u) {
-        const T2 m2 = *reinterpret_cast<const T2*>(mean + 2 * pi);
-        const T2 v2 = *reinterpret_cast<const T2*>(var + 2 * pi);
-        if (r0 & 1u) objective(m2[0], v2[0], uc0);
-        if (r1 & 1u) objective(m2[1], v2[1], uc1);
+        T2 m2 = T2{T(0), T(0)}, v2 = m2;
+        if (OBJ) {
+          m2 = *reinterpret_cast<const T2*>(mean + 2 * pi);
+          v2 = *reinterpret_cast<const T2*>(var + 2 * pi);
+        }
+        if (r0 & 1u) objective(m2[0], v2[0], mv0, uc0);
+        if (r1 & 1u) objective(m2[1], v2[1], mv1, uc1);
       }
       *reinterpret_cast<unsigned short*>(S + 2 * pi) = (unsigned short)((r0 & 1u) | ((r1 & 1u) << 8));
       *reinterpret_cast<unsigned short*>(U + 2 * pi) = (unsigned short)(((r0 >> 1) & 1u) | (((r1 >> 1) & 1u) << 8));
@@ -200,7 +239,7 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
       for (int c = 1; c < kMaxQ; ++c)
         if (c < q) { mv[2 * c] = mean[(size_t)c * n + g]; mv[2 * c + 1] = var[(size_t)c * n + g]; }
       const unsigned r = constraints(mv, uc);
-      if (r & 1u) objective(mean[g], var[g], uc);
+      if (r & 1u) objective(OBJ ? mean[g] : T(0), OBJ ? var[g] : T(0), mv, uc);
       S[g] = (uint8_t)(r & 1u);
       U[g] = (uint8_t)((r >> 1) & 1u);
     }
@@ -228,15 +267,16 @@ struct FinalJob {
   SweepScalars* sc = nullptr;
   const double* Lpart = nullptr;              // K1b's Lipschitz partials still to be merged (nullptr: Lmax is final)
   int per_out = 0;
+  int o_first = 0;                            // first output whose Lipschitz partials are merged here (overlapped sweeps: 1 -- the objective's follow in k_obj_front)
   unsigned long long* Lmax = nullptr;
   SweepScalars* sc_copy = nullptr;            // the second lane's block: a snapshot of the merged scalars (nullptr: one lane)
 };
 __device__ __forceinline__ void classify_final_body(const unsigned long long* __restrict__ part, int nparts, int q, SweepScalars* sc,
                                                     const double* __restrict__ Lpart, int per_out, unsigned long long* Lmax,
-                                                    SweepScalars* sc_copy = nullptr) {
+                                                    SweepScalars* sc_copy = nullptr, int o_first = 0) {
   __shared__ double lsh[4];
   if (Lpart)
-    for (int o = 0; o < q; ++o) lmax_reduce_body(o, lsh, Lpart, per_out, Lmax);
+    for (int o = o_first; o < q; ++o) lmax_reduce_body(o, lsh, Lpart, per_out, Lmax);
   unsigned long long* w = reinterpret_cast<unsigned long long*>(sc);       // (the struct is a multiple of 8 bytes)
   for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) w[i] = 0ull;
   __syncthreads();
@@ -278,21 +318,23 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
 }
 __global__ __launch_bounds__(256) void k_classify_final(const unsigned long long* __restrict__ part, int nparts, int q,
                                                         SweepScalars* sc, const double* __restrict__ Lpart, int per_out,
-                                                        unsigned long long* Lmax, SweepScalars* sc_copy) {
-  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax, sc_copy);
+                                                        unsigned long long* Lmax, SweepScalars* sc_copy, int o_first) {
+  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax, sc_copy, o_first);
 }
 
 // Objective pass of a classification whose S / U bytes came out of the posterior kernel (K1b, one constraint): u* = min over
 // S of ucb_0, one partial row per workgroup behind the posterior's rows (mask-driven loop as k_minimizer)
 __device__ __forceinline__ bool tile_byte(unsigned long long w, int k, int lane);
 template <typename T>
-__global__ __launch_bounds__(256) void k_classify_obj(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b,
-                                                      const uint8_t* __restrict__ S, unsigned long long* __restrict__ part) {
+__device__ __forceinline__ unsigned long long ustar_partial_body(int bid, int nwg, const T* __restrict__ mean0, const T* __restrict__ var0,
+                                                                 long long n, T b, const uint8_t* __restrict__ S) {
   unsigned long long umin = ~0ull;
   const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long wave = ((long long)bid * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)nwg * blockDim.x) >> 6;
   const long long ntiles = (((uintptr_t)S) & 7) == 0 ? n / 512 : 0;
   auto take = [&](T m, T v) {
+    // (fp64: the exact bound only when the cheap lower bound could beat the running minimum)
+    if (std::is_same<T, double>::value && ord_key(ucb_lower((double)m, (double)v, (double)b)) >= umin) return;
     T lcb, ucb;
     lcb_ucb(m, v, b, lcb, ucb);
     const unsigned long long k = ord_key((double)ucb);
@@ -315,11 +357,33 @@ __global__ __launch_bounds__(256) void k_classify_obj(const T* __restrict__ mean
     for (int k = 0; k < 8; ++k)
       if (set[k]) take(mu[k], va[k]);
   }
-  for (long long g = ntiles * 512 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x)
+  for (long long g = ntiles * 512 + (long long)bid * blockDim.x + threadIdx.x; g < n; g += (long long)nwg * blockDim.x)
     if (S[g]) take(mean0[g], var0[g]);
-  umin = block_ext_u64<false>(umin);
+  return block_ext_u64<false>(umin);   // valid in thread 0
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_classify_obj(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b,
+                                                      const uint8_t* __restrict__ S, unsigned long long* __restrict__ part) {
+  const unsigned long long umin = ustar_partial_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, b, S);
   unsigned long long* row = part + (size_t)blockIdx.x * kClassifyRow;
   if (threadIdx.x < kClassifyRow) row[threadIdx.x] = threadIdx.x == 0 ? umin : 0ull;
+}
+
+// First kernel of an overlapped sweep's tail (the objective's posterior has arrived, the constraints' set phase is done):
+// workgroups [0, gridDim.x - 1) reduce u* = min over S of ucb_0 to one key each (upart), the last workgroup merges the
+// Lipschitz partials of the objective's K1b launch (Lpart == nullptr: nothing to merge).
+template <typename T>
+__global__ __launch_bounds__(256) void k_obj_front(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b,
+                                                   const uint8_t* __restrict__ S, unsigned long long* __restrict__ upart,
+                                                   const double* __restrict__ Lpart, int per_out, unsigned long long* Lmax) {
+  const int nu = (int)gridDim.x - 1;
+  if ((int)blockIdx.x == nu) {
+    __shared__ double lsh[4];
+    if (Lpart) lmax_reduce_body(0, lsh, Lpart, per_out, Lmax);
+    return;
+  }
+  const unsigned long long umin = ustar_partial_body<T>((int)blockIdx.x, nu, mean0, var0, n, b, S);
+  if (threadIdx.x == 0) upart[blockIdx.x] = umin;
 }
 
 // Mask-driven loops of K3b / K5.  A wave takes tiles of 512 consecutive candidates: every lane reads eight mask bytes
@@ -335,8 +399,8 @@ __device__ __forceinline__ bool tile_byte(unsigned long long w, int k, int lane)
 template <typename T>
 __device__ __forceinline__ void minimizer_body(int bid, int nwg, const T* __restrict__ mean0, const T* __restrict__ var0, long long n,
                                                long long first, T b, const uint8_t* __restrict__ S, uint8_t* __restrict__ M,
-                                               const SweepScalars* sc, Best* partial) {
-  const T ustar = (T)ord_val(sc->ustar_key);
+                                               unsigned long long ustar_key, Best* partial) {
+  const T ustar = (T)ord_val(ustar_key);
   Best best{0.0, -1};
   long long cM = 0;
   const int lane = threadIdx.x & 63;
@@ -401,7 +465,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, const T* __restrict__ var0, long long n,
                                                    long long first, T b, const uint8_t* __restrict__ S,
                                                    uint8_t* __restrict__ M, SweepScalars* sc, Best* partial) {
-  minimizer_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, first, b, S, M, sc, partial);
+  minimizer_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, first, b, S, M, sc->ustar_key, partial);
 }
 
 // value sources of the masked arg-reductions: an array, or the value computed for the candidates whose mask byte is set
@@ -443,12 +507,12 @@ struct ValDist {           // Euclidean distance to the target, as scipy.spatial
 
 // generic masked arg-max / arg-min of a value source, plus the mask population
 template <typename T, bool MAX, typename V>
-__global__ __launch_bounds__(256) void k_arg_masked(const V val, const uint8_t* __restrict__ mask, long long n,
-                                                    long long first, Best* partial) {
+__device__ __forceinline__ void arg_masked_body(int bid, int nwg, const V& val, const uint8_t* __restrict__ mask, long long n,
+                                                long long first, Best* partial) {
   Best best{0.0, -1};
   long long cnt = 0;
   const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long wave = ((long long)bid * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)nwg * blockDim.x) >> 6;
   const long long ntiles = (((uintptr_t)mask) & 7) == 0 ? n / 512 : 0;
   for (long long t = wave; t < ntiles; t += nwaves) {
     const long long base = t * 512;
@@ -470,7 +534,7 @@ __global__ __launch_bounds__(256) void k_arg_masked(const V val, const uint8_t* 
       }
     }
   }
-  for (long long g = ntiles * 512 + (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+  for (long long g = ntiles * 512 + (long long)bid * blockDim.x + threadIdx.x; g < n; g += (long long)nwg * blockDim.x) {
     if (mask[g]) {
       ++cnt;
       const Best cand{(double)val(g), first + g};
@@ -480,8 +544,48 @@ __global__ __launch_bounds__(256) void k_arg_masked(const V val, const uint8_t* 
   best = block_best<MAX>(best);
   cnt = block_sum_ll(cnt);
   if (threadIdx.x == 0) {
-    partial[blockIdx.x] = best;
-    ((long long*)(partial + gridDim.x))[blockIdx.x] = cnt;
+    partial[bid] = best;
+    ((long long*)(partial + nwg))[bid] = cnt;
+  }
+}
+template <typename T, bool MAX, typename V>
+__global__ __launch_bounds__(256) void k_arg_masked(const V val, const uint8_t* __restrict__ mask, long long n,
+                                                    long long first, Best* partial) {
+  arg_masked_body<T, MAX, V>((int)blockIdx.x, (int)gridDim.x, val, mask, n, first, partial);
+}
+// the same for several masks in one launch: blockIdx.y = s selects slot slot0 + s -- mask0 for slot 0, masks + (slot - 1) n
+// otherwise -- and region slot of the partials (stride pstride bytes); the reductions are independent of each other
+template <typename T, bool MAX, typename V>
+__global__ __launch_bounds__(256) void k_arg_masked_multi(const V val, const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ masks,
+                                                          long long n, long long first, unsigned char* pbase, size_t pstride, int slot0) {
+  const int slot = slot0 + (int)blockIdx.y;
+  const uint8_t* mask = slot == 0 ? mask0 : masks + (size_t)(slot - 1) * n;
+  arg_masked_body<T, MAX, V>((int)blockIdx.x, (int)gridDim.x, val, mask, n, first, reinterpret_cast<Best*>(pbase + pstride * (size_t)slot));
+}
+
+// Second kernel of an overlapped SafeOpt sweep's tail: every workgroup merges the u* keys of k_obj_front (nu of them, a few
+// KB out of L2) for itself; row y = 0 of the launch then runs the minimiser (M mask, arg-max of var_0 over M), row y = c
+// the arg-max of var_0 over G_c -- the reductions of models/SafeOpt.py:55-66, 117-124 side by side.
+template <typename T>
+__global__ __launch_bounds__(256) void k_obj_tail(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, long long first,
+                                                  T b, const uint8_t* __restrict__ S, uint8_t* __restrict__ M, const uint8_t* __restrict__ G,
+                                                  const unsigned long long* __restrict__ upart, int nu, SweepScalars* sc,
+                                                  unsigned char* pbase, size_t pstride) {
+  const int slot = (int)blockIdx.y;
+  if (slot == 0) {
+    __shared__ unsigned long long ukey;
+    unsigned long long u = ~0ull;
+    for (int i = threadIdx.x; i < nu; i += blockDim.x) u = upart[i] < u ? upart[i] : u;
+    u = block_ext_u64<false>(u);
+    if (threadIdx.x == 0) {
+      ukey = u;
+      if (blockIdx.x == 0) sc->ustar_key = u;
+    }
+    __syncthreads();
+    minimizer_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, first, b, S, M, ukey, reinterpret_cast<Best*>(pbase));
+  } else {
+    arg_masked_body<T, true, ValArray<T>>((int)blockIdx.x, (int)gridDim.x, ValArray<T>{var0}, G + (size_t)(slot - 1) * n, n, first,
+                                          reinterpret_cast<Best*>(pbase + pstride * (size_t)slot));
   }
 }
 
@@ -512,7 +616,12 @@ template <bool MAX>
 __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts,
                                                       SweepScalars* sc, const SweepScalars* lane1 /* nullptr, or the second lane's block */,
                                                       unsigned char* mirror /* nullptr, or the host's pinned landing area */,
-                                                      const unsigned long long* Lkeys) {
+                                                      const unsigned long long* Lkeys, const double* __restrict__ Lpart0 = nullptr,
+                                                      int per_out = 0, unsigned long long* Lmax = nullptr) {
+  if (Lpart0 && blockIdx.x == 0) {       // overlapped GoOSE sweeps: the objective's Lipschitz partials are merged here (no mirror then)
+    __shared__ double lsh[4];
+    lmax_reduce_body(0, lsh, Lpart0, per_out, Lmax);
+  }
   if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
   // `mirror`: the results go straight to the pinned host block the read-back would have filled (SweepScalars at 0, the
   // Lipschitz keys at 3072) -- every workgroup its own slot, workgroup 0 the fields earlier kernels finished --, and the
@@ -593,11 +702,12 @@ struct MidJobs {
 template <typename T, bool U16>
 __global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
   __shared__ double part[4][64];
+  SBO_CHAIN_PRIO();
   const int bid = (int)blockIdx.x;
   if (bid < j.ns)
     edt_scan_body(bid, j.ns, j.dc_in, j.dc_out, j.nc, j.cstride, j.ccnt, j.hc, j.sc, j.cidx, j.Lkeys, j.lidx, 0, j.cap_extra);
   else if (bid < j.ns + j.nb)
-    minimizer_body<T>(bid - j.ns, j.nb, j.mean0, j.var0, j.n, j.first, j.b, j.S, j.M, j.sc, j.partial);
+    minimizer_body<T>(bid - j.ns, j.nb, j.mean0, j.var0, j.n, j.first, j.b, j.S, j.M, j.sc->ustar_key, j.partial);
   else if (U16)
     block_min_body(bid - j.ns - j.nb, j.nm, part, DistU16{reinterpret_cast<const unsigned short*>(j.din), j.h0}, j.stride, j.cnt, j.blk, j.bmin);
   else
@@ -615,7 +725,7 @@ static int reduce_blocks(const sbo_ctx* c) {
 
 // mask buffers of a sweep; called before the posterior is enqueued (K1b may write S / U itself) -- `b` is the sweep's
 // confidence multiplier, handed to the posterior with the request to classify
-static int sweep_masks(sbo_ctx* c, double b, bool may_fuse) {
+static int sweep_masks(sbo_ctx* c, double b, bool may_fuse, bool may_split = false) {
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
@@ -626,7 +736,12 @@ static int sweep_masks(sbo_ctx* c, double b, bool may_fuse) {
   if ((rc = ensure(c->maskU, (size_t)npad_shard))) return rc;
   if ((rc = ensure(c->maskM, (size_t)n))) return rc;
   if ((rc = ensure(c->maskG, (size_t)n * std::max(1, q - 1)))) return rc;
-  c->fuse_request = may_fuse && c->fuse_classify && q == 2;
+  c->fuse_request = (may_fuse && q == 2) ? (c->fuse_classify < 0 ? 2 : c->fuse_classify) : 0;
+  // overlapped sweep: K1b is asked to finish the constraints' outputs first (see sbo_ctx::split_request); it answers with
+  // split_done when it ran that way (it does not on the other posterior paths)
+  c->split_request = may_fuse && may_split && c->k1_split && q >= 2 && !multi_rank(c) && !c->phase_events && !c->rc_active &&
+                     c->stream3 && n > 0;
+  c->split_done = false;
   c->lmax_defer = may_fuse;        // (every sweep merges K1b's Lipschitz partials in its k_classify_final)
   c->lmax_pending = false;
   c->fuse_b = b;
@@ -642,13 +757,15 @@ static void launch_final(sbo_ctx* c, FinalJob* fj) {
   fj->pending = false;
   // (with a second lane the fork event rides on this launch as its stop event: a separate record costs the stream a bubble)
   hipExtLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, nullptr, fj->sc_copy ? c->ev_join[4] : nullptr, 0, fj->part,
-                        fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out, fj->Lmax, fj->sc_copy);
+                        fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out, fj->Lmax, fj->sc_copy, fj->o_first);
 }
 
 // `defer`: the merge of the classification's partials is handed back instead of launched (SafeOpt on one rank: it rides in
 // the expander's first launch, which reads the U mask only)
+// `with_obj` = false (overlapped sweeps): the objective's posterior is not there yet -- S / U, |S|, |U| and the radius keys
+// only; u* follows in the sweep's tail (k_obj_front), and so do the objective's Lipschitz partials
 template <typename T>
-static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* defer = nullptr) {
+static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* defer = nullptr, bool with_obj = true) {
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
@@ -668,26 +785,34 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* def
     fj.Lpart = (const double*)c->bl_lpart.p;
     fj.per_out = c->lmax_per_out;
     fj.Lmax = (unsigned long long*)c->Lmax.p;
-    c->lmax_pending = false;
+    fj.o_first = with_obj ? 0 : 1;
+    c->lmax_pending = !with_obj;                // (the tail merges output 0)
   }
   const int ncb = std::max(1, c->n_cu * 4);   // four workgroups per CU measured best (2: 24.6 us, 4: 21.5, 8: 27.1 on config B)
   if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kClassifyRow * (size_t)ncb))) return rc;
   if (c->fuse_rows > 0 && n > 0) {
     // S / U bytes, |S|, |U| and the radius key came out of the posterior kernel: only u* is left, over the safe candidates
-    const int nob = std::max(1, c->n_cu * 4);
+    const int nob = with_obj ? std::max(1, c->n_cu * 4) : 0;
     unsigned long long* rows = (unsigned long long*)c->cpart.p;
-    hipLaunchKernelGGL(k_classify_obj<T>, dim3((unsigned)nob), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b,
-                       (const uint8_t*)c->maskS.p, rows + (size_t)c->fuse_rows * kClassifyRow);
+    if (with_obj)
+      hipLaunchKernelGGL(k_classify_obj<T>, dim3((unsigned)nob), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b,
+                         (const uint8_t*)c->maskS.p, rows + (size_t)c->fuse_rows * kClassifyRow);
     fj.part = (const unsigned long long*)rows;
     fj.nparts = c->fuse_rows + nob;
-    launch_final(c, &fj);
+    if (defer) *defer = fj;
+    else launch_final(c, &fj);
     c->amb_clean = true;
     SBO_HIP(hipGetLastError());
     return SBO_OK;
   }
-  if (n > 0)
-    hipLaunchKernelGGL(k_classify<T>, dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
-                       (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
+  if (n > 0) {
+    if (with_obj)
+      hipLaunchKernelGGL((k_classify<T, true>), dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
+                         (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
+    else
+      hipLaunchKernelGGL((k_classify<T, false>), dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
+                         (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
+  }
   fj.part = (const unsigned long long*)c->cpart.p;
   fj.nparts = n > 0 ? ncb : 0;
   if (defer) *defer = fj;
@@ -898,7 +1023,10 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
         fin = mj->fin;
         mj->fin.pending = false;
       }
-      u16 = c->dist_u16 && count0 < 65535;           // the fine image as 16-bit step counts (0xffff: no U point on the line)
+      // the fine image as 16-bit step counts (0xffff: no U point on the line) -- only when its readers are the block minima
+      // and the list scan, which decode it: without the list (short last axis, options scan_blocks / scan_waves = 0) the
+      // verdict kernel scans the image itself and expects squared distances as doubles
+      u16 = c->dist_u16 && count0 < 65535 && want_bmin && blk_ <= 64 && c->scan_waves;
       if (u16)
         hipLaunchKernelGGL(k_edt_axis0_pair<true>, dim3((unsigned)(nfine + ncoarse + (fin.pending ? 1 : 0))), dim3(256), 0, c->stream, Uall,
                            nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin);
@@ -1133,6 +1261,7 @@ static int sweep_exchange_wait(sbo_ctx* c) {
   if (c->c1_pending) {
     SBO_HIP(hipEventSynchronize(c->ev[5]));
     c->c1_pending = false;
+    ++c->host_syncs;
   }
   return SBO_OK;
 }
@@ -1153,6 +1282,7 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
       if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
     }
     SBO_HIP(stream_wait(c, c->stream));
+    ++c->host_syncs;
     memcpy(&h, c->h_back, sizeof(h));
     if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
     return SBO_OK;
@@ -1166,6 +1296,7 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   SBO_HIP(hipMemcpyAsync(rows.data(), buf, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, c->stream));
   if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
   SBO_HIP(stream_wait(c, c->stream));
+  ++c->host_syncs;
   memcpy(&h, c->h_back, sizeof(h));
   if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
   c->c1_pending = false;                       // (the whole stream has drained)
@@ -1191,57 +1322,126 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   return SBO_OK;
 }
 
+// Overlapped sweeps: while the scope is on, the context's stream is the chain stream (stream3), which waits for the
+// constraints' K1b launch (ev_join[6]); end() marks the chain's end (ev_join[7]), makes the main stream wait for it and
+// puts the main stream back.  The objective's K1b launch is already queued on the main stream and runs meanwhile.
+struct ChainScope {
+  sbo_ctx* c;
+  bool on;
+  ChainScope(sbo_ctx* c_, bool on_) : c(c_), on(on_) {
+    if (on) std::swap(c->stream, c->stream3);
+  }
+  int begin() {
+    if (on) SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_join[6], 0));
+    return SBO_OK;
+  }
+  int end() {
+    if (!on) return SBO_OK;
+    on = false;
+    std::swap(c->stream, c->stream3);
+    SBO_HIP(hipEventRecord(c->ev_join[7], c->stream3));
+    SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_join[7], 0));
+    return SBO_OK;
+  }
+  ~ChainScope() {
+    if (on) std::swap(c->stream, c->stream3);     // (an error return inside the chain: the entry point drains the streams)
+  }
+};
+
+// u* partials of an overlapped sweep's tail: workgroups of k_obj_front (+ 1 for the Lipschitz merge)
+static int obj_front_blocks(const sbo_ctx* c) { return std::max(1, c->n_cu * 4); }
+
+template <typename T>
+static int launch_obj_front(sbo_ctx* c, const sbo_sweep_opts* o, int* nu_out) {
+  const int nu = obj_front_blocks(c);
+  int rc;
+  if ((rc = ensure(c->upart, sizeof(unsigned long long) * (size_t)nu))) return rc;
+  const bool lp = c->lmax_pending;
+  c->lmax_pending = false;
+  hipLaunchKernelGGL((k_obj_front<T>), dim3((unsigned)(nu + 1)), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, c->cs.n_local,
+                     (T)o->b, (const uint8_t*)c->maskS.p, (unsigned long long*)c->upart.p, lp ? (const double*)c->bl_lpart.p : (const double*)nullptr,
+                     c->lmax_per_out, (unsigned long long*)c->Lmax.p);
+  *nu_out = nu;
+  return SBO_OK;
+}
+
+static void sweep_times(sbo_ctx* c, bool ov) {
+  float tc = 0, te = 0;
+  if (ov) (void)hipEventElapsedTime(&tc, c->ev_join[6], c->ev_join[7]);
+  (void)hipEventElapsedTime(&te, c->ev[1], c->ev[4]);
+  c->prof.set_chain_ms = tc;
+  c->prof.set_exposed_ms = te;
+  c->prof.k1_split = ov ? 1 : 0;
+  c->prof.host_syncs = c->host_syncs;
+}
+
 template <typename T>
 static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_result* res) {
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
+  c->host_syncs = 0;
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
-  if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
+  if ((rc = sweep_masks(c, o->b, !reuse, true))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
-  c->fuse_request = false;
+  c->fuse_request = 0;
   c->lmax_defer = false;
+  c->split_request = false;
+  const bool ov = c->split_done;     // the constraints' outputs are ahead of the objective's: their set phase runs beside it
+  c->split_done = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
   MinimizerJob mj;
-  const bool lanes = lanes_on(c);
-  const bool defer = q >= 2 && !multi_rank(c) && c->set_fuse && n > 0 && !lanes;   // (lanes fork right behind the merge)
-  if ((rc = sweep_common_front<T>(c, o, defer ? &mj.fin : nullptr))) return rc;
-  if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
-  SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
   // partials of the q arg-max reductions side by side: merged by one launch at the end (k_safeopt_finals)
   const size_t pstride = (sizeof(Best) + sizeof(long long)) * (size_t)nb;
   if ((rc = ensure(c->partial, pstride * (size_t)q))) return rc;
   unsigned char* pbase = (unsigned char*)c->partial.p;
-  // (single rank: the minimiser rides in the first constraint's k_set_mid; with ranks > 1 it is queued here, ahead of the
-  // host's wait for the C1 keys)
-  mj.pending = n > 0;
-  mj.nb = nb;
-  mj.partial = (Best*)pbase;
-  if (q < 2 || multi_rank(c)) launch_minimizer<T>(c, o, &mj);
-  if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
-  if (lanes && (rc = lanes_fork(c))) return rc;
-  for (int cc = 1; cc < q; ++cc) {
-    uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
-    LaneScope lane(c, lanes && ((cc - 1) & 1));              // constraints alternate between the two lanes
-    if ((rc = expander_set<T>(c, o, cc, G, lane.on ? nullptr : &mj))) return rc;
+  const bool lanes = lanes_on(c);
+  {
+    ChainScope chain(c, ov);
+    if ((rc = chain.begin())) return rc;
+    const bool defer = q >= 2 && !multi_rank(c) && c->set_fuse && n > 0 && !lanes;   // (lanes fork right behind the merge)
+    if ((rc = sweep_common_front<T>(c, o, defer ? &mj.fin : nullptr, !ov))) return rc;
+    if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
+    // (single rank: the minimiser rides in the first constraint's k_set_mid; with ranks > 1 it is queued here, ahead of the
+    // host's wait for the C1 keys; overlapped sweeps run it in their tail, once u* is known)
+    mj.pending = n > 0 && !ov;
+    mj.nb = nb;
+    mj.partial = (Best*)pbase;
+    if (q < 2 || multi_rank(c)) launch_minimizer<T>(c, o, &mj);
+    if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
+    if (lanes && (rc = lanes_fork(c))) return rc;
+    for (int cc = 1; cc < q; ++cc) {
+      uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
+      LaneScope lane(c, lanes && ((cc - 1) & 1));              // constraints alternate between the two lanes
+      if ((rc = expander_set<T>(c, o, cc, G, lane.on ? nullptr : &mj))) return rc;
+    }
+    launch_minimizer<T>(c, o, &mj);
+    if (lanes && (rc = lanes_join(c))) return rc;
+    if ((rc = chain.end())) return rc;
   }
-  launch_minimizer<T>(c, o, &mj);
-  if (lanes && (rc = lanes_join(c))) return rc;
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
-  for (int cc = 1; cc < q; ++cc) {
-    const uint8_t* G = (const uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
-    if (n > 0)
-      hipLaunchKernelGGL((k_arg_masked<T, true, ValArray<T>>), dim3(nb), dim3(256), 0, c->stream, ValArray<T>{(const T*)c->var.p}, G, n,
-                         (long long)c->cs.first, (Best*)(pbase + pstride * (size_t)cc));
+  if (ov) {
+    // tail: u* over S, then the minimiser and the expanders' arg-max reductions side by side
+    int nu = 0;
+    if ((rc = launch_obj_front<T>(c, o, &nu))) return rc;
+    hipLaunchKernelGGL((k_obj_tail<T>), dim3((unsigned)nb, (unsigned)q), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n,
+                       (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, (const uint8_t*)c->maskG.p,
+                       (const unsigned long long*)c->upart.p, nu, sc, pbase, pstride);
+  } else if (n > 0 && q > 1) {
+    hipLaunchKernelGGL((k_arg_masked_multi<T, true, ValArray<T>>), dim3((unsigned)nb, (unsigned)(q - 1)), dim3(256), 0, c->stream,
+                       ValArray<T>{(const T*)c->var.p}, (const uint8_t*)nullptr, (const uint8_t*)c->maskG.p, n, (long long)c->cs.first, pbase,
+                       pstride, 1);
   }
   const bool mirrored = !multi_rank(c) && c->result_mirror;
   hipExtLaunchKernelGGL(k_sweep_finals<true>, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, mirrored ? c->ev[4] : nullptr, 0,
                         (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, sc,
                         lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr,
-                        mirrored ? c->h_back : (unsigned char*)nullptr, (const unsigned long long*)c->Lmax.p);
+                        mirrored ? c->h_back : (unsigned char*)nullptr, (const unsigned long long*)c->Lmax.p, (const double*)nullptr, 0,
+                        (unsigned long long*)nullptr);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
@@ -1270,6 +1470,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   c->prof.posterior_launches = (!reuse && n > 0) ? 1 : 0;
   const double nn = c->mc.n, dd = c->mc.d;
   c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
+  sweep_times(c, ov);
 
   memset(res, 0, sizeof(*res));
   res->count_S = h.count_S;
@@ -1574,59 +1775,68 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
+  c->host_syncs = 0;
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
-  if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
+  if ((rc = sweep_masks(c, o->b, !reuse, true))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
-  c->fuse_request = false;
+  c->fuse_request = 0;
   c->lmax_defer = false;
+  c->split_request = false;
+  // overlapped: everything up to the optimistic sets O_c depends on the constraints' posterior only (models/GoOSE.py:80-101);
+  // the objective enters with the arg-min reductions of lcb_0 (:63-67, :106-112)
+  const bool ov = c->split_done;
+  c->split_done = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
-  if ((rc = sweep_common_front<T>(c, o))) return rc;
-  if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
-  if ((rc = ensure(c->maskO, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
-  SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);
-  if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
-  // Only expanders can cover an unsafe point: "g covers h" is the predicate that puts g into G_c.  So G_c is built
-  // first (distance transform, cheap) and serves as the source set of the coverage search instead of all of S_t.
-  if ((rc = ensure(c->maskG, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
   const bool lanes = lanes_on(c);
-  if (lanes && (rc = lanes_fork(c))) return rc;
-  for (int cc = 1; cc < q; ++cc) {
-    uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
-    uint8_t* O = (uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
-    LaneScope lane(c, lanes && ((cc - 1) & 1));              // constraints alternate between the two lanes
-    // (a large explicit list has no transform to build G_c with: all of S_t stays the source set there)
-    long long plane = 1;
-    for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
-    const bool can_expand = n <= (1ll << 17) || (c->cs.kind == 1 && c->cs.first % plane == 0 && n % plane == 0);   // (larger lists: S_t is the source set)
-    const uint8_t* src = (const uint8_t*)c->maskS.p;
-    if (can_expand) {
-      if ((rc = expander_set<T>(c, o, cc, G))) return rc;
-      src = G;
+  {
+    ChainScope chain(c, ov);
+    if ((rc = chain.begin())) return rc;
+    if ((rc = sweep_common_front<T>(c, o, nullptr, !ov))) return rc;
+    if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
+    if ((rc = ensure(c->maskO, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
+    if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
+    // Only expanders can cover an unsafe point: "g covers h" is the predicate that puts g into G_c.  So G_c is built
+    // first (distance transform, cheap) and serves as the source set of the coverage search instead of all of S_t.
+    if ((rc = ensure(c->maskG, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
+    if (lanes && (rc = lanes_fork(c))) return rc;
+    for (int cc = 1; cc < q; ++cc) {
+      uint8_t* G = (uint8_t*)c->maskG.p + (size_t)(cc - 1) * n;
+      uint8_t* O = (uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
+      LaneScope lane(c, lanes && ((cc - 1) & 1));              // constraints alternate between the two lanes
+      // (a large explicit list has no transform to build G_c with: all of S_t stays the source set there)
+      long long plane = 1;
+      for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
+      const bool can_expand = n <= (1ll << 17) || (c->cs.kind == 1 && c->cs.first % plane == 0 && n % plane == 0);   // (larger lists: S_t is the source set)
+      const uint8_t* src = (const uint8_t*)c->maskS.p;
+      if (can_expand) {
+        if ((rc = expander_set<T>(c, o, cc, G))) return rc;
+        src = G;
+      }
+      if ((rc = goose_sets_d<T>(c, o, cc, src, O))) return rc;
     }
-    if ((rc = goose_sets_d<T>(c, o, cc, src, O))) return rc;
+    if (lanes && (rc = lanes_join(c))) return rc;
+    if ((rc = chain.end())) return rc;
   }
-  if (lanes && (rc = lanes_join(c))) return rc;
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
-  // arg-min of lcb_0 over S_t and over every O_c: the bound is computed for the masked candidates only
+  // arg-min of lcb_0 over S_t and over every O_c: the bound is computed for the masked candidates only; one launch, the q
+  // reductions side by side
   const ValLcb<T> lcb0{(const T*)c->mean.p, (const T*)c->var.p, (T)o->b};
   const size_t pstride = (sizeof(Best) + sizeof(long long)) * (size_t)nb;     // q regions of partials, one merge launch
   if ((rc = ensure(c->partial, pstride * (size_t)q))) return rc;
   unsigned char* pbase = (unsigned char*)c->partial.p;
   if (n > 0)
-    hipLaunchKernelGGL((k_arg_masked<T, false, ValLcb<T>>), dim3(nb), dim3(256), 0, c->stream, lcb0, (const uint8_t*)c->maskS.p, n,
-                       (long long)c->cs.first, (Best*)pbase);
-  for (int cc = 1; cc < q; ++cc) {
-    const uint8_t* O = (const uint8_t*)c->maskO.p + (size_t)(cc - 1) * n;
-    if (n > 0)
-      hipLaunchKernelGGL((k_arg_masked<T, false, ValLcb<T>>), dim3(nb), dim3(256), 0, c->stream, lcb0, O, n,
-                         (long long)c->cs.first, (Best*)(pbase + pstride * (size_t)cc));
-  }
+    hipLaunchKernelGGL((k_arg_masked_multi<T, false, ValLcb<T>>), dim3((unsigned)nb, (unsigned)q), dim3(256), 0, c->stream, lcb0,
+                       (const uint8_t*)c->maskS.p, (const uint8_t*)c->maskO.p, n, (long long)c->cs.first, pbase, pstride, 0);
+  const bool lp = ov && c->lmax_pending;
+  c->lmax_pending = false;
   hipLaunchKernelGGL(k_sweep_finals<false>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride,
                      n > 0 ? nb : 0, sc, lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr,
-                     (unsigned char*)nullptr, (const unsigned long long*)nullptr);
+                     (unsigned char*)nullptr, (const unsigned long long*)nullptr, lp ? (const double*)c->bl_lpart.p : (const double*)nullptr,
+                     c->lmax_per_out, (unsigned long long*)c->Lmax.p);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
@@ -1718,6 +1928,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   c->prof.posterior_launches = (!reuse && n > 0) ? 1 : 0;
   const double nn = c->mc.n, dd = c->mc.d;
   c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
+  sweep_times(c, ov);
   return SBO_OK;
 }
 
@@ -1730,7 +1941,7 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
-  c->fuse_request = false;
+  c->fuse_request = 0;
   c->lmax_defer = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
@@ -1803,9 +2014,13 @@ int sbo_sweep_safeopt(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_safeopt_result
   if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
   SBO_HIP(hipSetDevice(c->device));
+  int rc;
   if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model && !multi_rank(c))
-    return sweep_safeopt_f32_recheck(c, opts, result);
-  return c->dtype == SBO_F64 ? sweep_safeopt_t<double>(c, opts, result) : sweep_safeopt_t<float>(c, opts, result);
+    rc = sweep_safeopt_f32_recheck(c, opts, result);
+  else
+    rc = c->dtype == SBO_F64 ? sweep_safeopt_t<double>(c, opts, result) : sweep_safeopt_t<float>(c, opts, result);
+  if (rc != SBO_OK && rc != SBO_E_EMPTY_SAFE_SET) drain_streams(c);   // (kernels of the failed call may still sit on the side streams)
+  return rc;
 }
 
 int sbo_sweep_goose(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_goose_result* result) {
@@ -1814,7 +2029,9 @@ int sbo_sweep_goose(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_goose_result* re
   if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
   SBO_HIP(hipSetDevice(c->device));
-  return c->dtype == SBO_F64 ? sweep_goose_t<double>(c, opts, result) : sweep_goose_t<float>(c, opts, result);
+  const int rc = c->dtype == SBO_F64 ? sweep_goose_t<double>(c, opts, result) : sweep_goose_t<float>(c, opts, result);
+  if (rc != SBO_OK && rc != SBO_E_EMPTY_SAFE_SET) drain_streams(c);
+  return rc;
 }
 
 int sbo_sweep_tr(sbo_ctx* c, const sbo_sweep_opts* opts, const double* x_0, double r, sbo_tr_result* result) {

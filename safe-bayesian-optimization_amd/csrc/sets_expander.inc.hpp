@@ -199,10 +199,11 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
                                                         double* __restrict__ D, int nfine, int ncoarse, long long clines, int cc0,
                                                         double h0c, double* __restrict__ Dc, const CoarseGrid cg, const FinalJob fin) {
   __shared__ Axis0Lds lds;
+  SBO_CHAIN_PRIO();
   // (order of the ranges: the merge and the coarse lines first -- few workgroups with longer chains that should start with the
   // launch, not in the slots the fine lines leave at its end)
   const int nfin = (int)gridDim.x - nfine - ncoarse, bid = (int)blockIdx.x;
-  if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy);
+  if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy, fin.o_first);
   else if (bid < nfin + ncoarse) edt_axis0_wg_body<true>(bid - nfin, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
   else edt_axis0_wg_body<false, U16>(bid - nfin - ncoarse, nfine, lds, U, nlines, count0, h0, D, cg);
 }
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
                                                     uint8_t* __restrict__ G, long long* __restrict__ amb,
                                                     const CoarseGrid cg, const double* __restrict__ Bmin, int blk,
                                                     long long* __restrict__ scanlist, const RcExp rx) {
+  SBO_CHAIN_PRIO();
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const bool anyU = sc->count_U > 0;
   // launch: x over the positions of a grid line (len0 = count0; the whole range when d == 1), y over blocks of
@@ -575,6 +577,7 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const DS Din, long long g
                                                        SweepScalars* sc, uint8_t* __restrict__ G, long long* __restrict__ amb,
                                                        const double* __restrict__ Bmin, int blk,
                                                        const long long* __restrict__ scanlist, const RcExp rx) {
+  SBO_CHAIN_PRIO();
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const long long nscan = sc->n_scan;
   const int lane = threadIdx.x & (GL - 1);

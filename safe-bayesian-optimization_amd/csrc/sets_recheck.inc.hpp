@@ -297,7 +297,9 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
     bd.dm[i] = 1e-4 * ys;
     bd.dv[i] = 1e-4 * ys * ys;
   }
-  const size_t list_cap = (size_t)n * std::max(1, q);            // (a candidate can be deferred once per constraint)
+  // (one pass can list a candidate once per constraint in the verdict kernels and once more per constraint in k_rc_gdefer;
+  // the first list -- k_rc_flag -- holds every candidate at most once)
+  const size_t list_cap = (size_t)n * (size_t)(2 * std::max(1, q - 1) + 1);
   if ((rc = ensure(c->rc_list, kRcList + sizeof(long long) * list_cap))) return rc;
   if ((rc = ensure(c->rc_mean, sizeof(double) * (size_t)q * n))) return rc;
   if ((rc = ensure(c->rc_var, sizeof(double) * (size_t)q * n))) return rc;
@@ -368,7 +370,7 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
     c->var = keep_v;
     c->dtype = keep_dtype;
     c->posterior_valid = keep_valid || !reuse;
-    if (rc != SBO_OK || q == 1 || passes >= 6) break;
+    if (rc != SBO_OK || q == 1) break;
     if (passes > 0) set_extra += (float)c->prof.total_ms;
     // Expander's arg-max over every G_c must not hinge on an fp32 variance
     const uint8_t* G = (const uint8_t*)c->maskG.p;
@@ -383,6 +385,8 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
     const long long nd = (long long)*(const unsigned long long*)(hb + kRcCount2);
     if (nd == 0) break;
     if ((size_t)nd > list_cap) return fail(SBO_E_HIP, "internal: refinement list overflow");
+    // (every candidate is refined at most once, so the passes end; six without an end would be a defect, not a slow case)
+    if (passes >= 6) return fail(SBO_E_UNSUPPORTED, "fp64 recheck: verdicts still deferred after 7 passes of the set phase");
     if ((rc = rc_refine(c, list, nd))) return rc;
     total += nd;
   }

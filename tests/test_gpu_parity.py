@@ -927,7 +927,7 @@ def test_fused_classification_equals_the_separate_pass(engine, cfg_name, n, coun
             t_ = engine.sweep_tr(cfg["b"], s_["minimizer_x"], 0.5)
             out[fuse] = (s_, g_, t_, masks)
     finally:
-        engine.set_option("fuse_classify", 0)
+        engine.set_option("fuse_classify", -1)
     for k, v in out[1][3].items():
         assert np.array_equal(v, out[0][3][k]), k
     assert out[1][3]["S"].any() and out[1][3]["U"].any()
@@ -978,6 +978,107 @@ def test_shared_set_phase_launches_equal_one_launch_per_kernel(engine, cfg_name,
         a, b_ = out[1][which], out[0][which]
         for k in a:
             assert np.array_equal(np.asarray(a[k]), np.asarray(b_[k])), (which, k)
+
+
+def _sweep_bundle(engine, cfg, b, q, goose=True):
+    """SafeOpt (+ GoOSE) sweep of the resident model / grid, each on a FRESH posterior (so that the posterior kernels run inside
+    the sweep, which is what the overlapped path needs): results, masks and the profile flag."""
+    engine.set_model(cfg["ds"])
+    r = engine.sweep_safeopt(b, want_masks=True)
+    prof = engine.profile()
+    masks = {k: engine.mask(k) for k in ("S", "U", "M")}
+    masks.update({f"G{c}": engine.mask("G", c) for c in range(1, q)})
+    g = None
+    if goose:
+        engine.set_model(cfg["ds"])
+        g = engine.sweep_goose(b, want_masks=True)
+        masks.update({f"O{c}": engine.mask("O", c) for c in range(1, q)})
+        masks["S_g"], masks["U_g"] = engine.mask("S"), engine.mask("U")
+    return r, g, masks, prof
+
+
+def _assert_same_bundle(a, b_):
+    for k, v in a[2].items():
+        assert np.array_equal(v, b_[2][k]), k
+    for which in (0, 1):
+        if a[which] is None:
+            continue
+        for k in a[which]:
+            assert np.array_equal(np.asarray(a[which][k]), np.asarray(b_[which][k])), (which, k)
+
+
+@pytest.mark.parametrize("cfg_name,n,count,b", [("B", 128, [1100, 1024], 3.0), ("C", 96, [1040, 1030], 2.0), ("H", 300, [1056, 1500], 3.0),
+                                                  ("B", 64, [320, 300], 3.0), ("A", 64, [130, 70], 3.0), ("B", 128, [2048, 2048], 3.0)])
+def test_overlapped_sweep_equals_the_sequential_one(engine, cfg_name, n, count, b):
+    """Option k1_split (default off -- measured slower): on the GEMM posterior of one rank the constraints' outputs leave K1b first and the
+    constraint-only part of the set phase (S / U, transforms, expander / optimistic-set verdicts) runs on a second stream
+    beside the objective's GEMM; u*, M and the arg-reductions follow in a short tail.  Every mask, count, index, u* and L of
+    the SafeOpt and GoOSE sweeps must equal the sequential sweep (k1_split = 0) -- one and two constraints (two lanes), ragged
+    tiles, grids below the shared-launch sizes, both tile heights of the split launches, and with the classification fused
+    into the constraint's GEMM epilogue."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    q = cfg["q"]
+    engine.set_grid(lo, hi, count)
+    out = {}
+    try:
+        for key, opts in (("seq", dict(k1_split=0, fuse_classify=0)), ("ov", dict(k1_split=1, fuse_classify=0)), ("ov_rb1", dict(k1_split=1, split_rb=1)),
+                          ("ov_rb2", dict(k1_split=1, split_rb=2)), ("ov_fuse", dict(k1_split=1, fuse_classify=1))):
+            if key == "ov_fuse" and q != 2:
+                continue
+            for k, v in opts.items():
+                engine.set_option(k, v)
+            out[key] = _sweep_bundle(engine, cfg, b, q)
+            assert out[key][3]["posterior_kernel"] == 4
+            assert out[key][3]["k1_split"] == (0 if key == "seq" else 1), key
+            assert out[key][3]["host_syncs"] == 1
+            for k in opts:
+                engine.set_option(k, -1 if k == "fuse_classify" else 0)
+    finally:
+        engine.set_option("k1_split", 0)
+        engine.set_option("split_rb", 0)
+        engine.set_option("fuse_classify", -1)
+    assert out["seq"][2]["S"].any() and out["seq"][2]["U"].any() and out["seq"][2]["G1"].any()
+    for key in out:
+        if key != "seq":
+            _assert_same_bundle(out[key], out["seq"])
+    if count[0] * count[1] <= 20000:
+        ref = oracle.safeopt_sweep(oracle.grid_points(lo, hi, count), cfg["ds"], b)
+        assert np.array_equal(out["ov"][2]["S"], ref["S"]) and np.array_equal(out["ov"][2]["G1"], ref["G"][0])
+        assert np.array_equal(out["ov"][2]["M"], ref["M"]) and out["ov"][0]["minimizer_index"] == ref["minimizer_index"]
+        assert out["ov"][0]["u_star"] == pytest.approx(ref["u_star"], rel=1e-10)
+
+
+@pytest.mark.parametrize("count,opts", [([1024, 36], {}), ([1024, 36], {"dist_u16": 0}), ([2048, 100], {}), ([2048, 2048], {"scan_waves": 0}),
+                                        ([2048, 2048], {"scan_blocks": 0}), ([2048, 2048], {"dist_u16": 0}),
+                                        ([2048, 2048], {"result_mirror": 0}), ([1100, 1024], {"scan_waves": 0, "k1_split": 1})])
+def test_shared_launch_path_with_plain_scans_and_short_last_axes(engine, count, opts):
+    """The 16-bit image of the fine axis-0 pass (option dist_u16) is decoded by the block minima and the list scan only: where
+    the verdict kernel scans the image itself -- last axes too short for block minima (1024 x 36, 2048 x 100), or the options
+    scan_waves / scan_blocks = 0 -- the shared-launch path must keep squared distances as doubles.  G masks, counts and indices
+    must equal the one-launch-per-kernel sweep (set_fuse = 0) in every combination, and the oracle's where it is affordable;
+    dist_u16 and result_mirror are toggled too."""
+    cfg = synthetic.make_config("B", n=128)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    engine.set_grid(lo, hi, count)
+    out = {}
+    defaults = {"dist_u16": 1, "scan_waves": 1, "scan_blocks": 1, "result_mirror": 1, "k1_split": 0, "set_fuse": 1}
+    try:
+        for key, o in (("opt", opts), ("plain", {"set_fuse": 0, "k1_split": 0})):
+            for k, v in o.items():
+                engine.set_option(k, v)
+            out[key] = _sweep_bundle(engine, cfg, cfg["b"], 2, goose=False)
+            for k in o:
+                engine.set_option(k, defaults[k])
+    finally:
+        for k, v in defaults.items():
+            engine.set_option(k, v)
+    assert out["opt"][2]["G1"].any() and out["opt"][2]["U"].any()
+    _assert_same_bundle(out["opt"], out["plain"])
+    if count[0] * count[1] <= 40000:
+        ref = oracle.safeopt_sweep(oracle.grid_points(lo, hi, count), cfg["ds"], cfg["b"])
+        assert np.array_equal(out["opt"][2]["S"], ref["S"]) and np.array_equal(out["opt"][2]["G1"], ref["G"][0])
+        assert list(out["opt"][0]["expander_index_c"])[:1] == list(ref["expander_index"])
 
 
 def test_two_lanes_of_constraints_equal_one_after_the_other(engine):
