@@ -54,6 +54,22 @@ void drain_streams(sbo_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+  if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+}
+
+// The reverse Cholesky factor of a caller's invK may still be in the making (sbo_ctx::factor_pending): every consumer of
+// Fpk / Fplain waits here first.  The positive-definiteness verdict arrives with it.
+int factor_sync(sbo_ctx* c) {
+  if (!c->factor_pending) return SBO_OK;
+  SBO_HIP(hipEventSynchronize(c->ev_factor));
+  c->factor_pending = false;
+  const int* hbad = (const int*)(c->h_back + 4864);
+  for (int o = 0; o < c->mc.q; ++o)
+    if (hbad[o]) {
+      c->has_model = false;
+      return fail(SBO_E_INVALID, "invK is not positive definite (its factor was needed by this call)");
+    }
+  return SBO_OK;
 }
 
 void release(DevBuf& b) {
@@ -103,6 +119,9 @@ int sbo_init(int device_id, sbo_ctx** out) {
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
     e = hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming);
   }
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
   for (auto& ev : c->ev) {
@@ -144,6 +163,10 @@ static int shadow_ensure(sbo_ctx* c) {
   s->stream = c->stream;
   s->stream2 = c->stream2;
   s->stream3 = c->stream3;
+  s->stream4 = c->stream4;
+  s->ev_factor = c->ev_factor;
+  s->ev_w = c->ev_w;
+  s->chol_async = 0;
   s->k1_split = 0;
   for (int i = 0; i < 8; ++i) s->ev[i] = c->ev[i];
   s->h_back = c->h_back;
@@ -163,6 +186,7 @@ int sbo_shutdown(sbo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+  if (c->stream4) (void)hipStreamSynchronize(c->stream4);
   if (c->shadow) {
     sbo_ctx* s = c->shadow;
     for (DevBuf* b : {&s->Fpk, &s->As, &s->sqA, &s->alpha, &s->Xn, &s->pts, &s->mean, &s->var, &s->scal, &s->mwork, &s->Fplain, &s->alpha64})
@@ -173,7 +197,7 @@ int sbo_shutdown(sbo_ctx* c) {
   }
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->upart, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->upart, &c->invk_img, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg})
     release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -182,6 +206,9 @@ int sbo_shutdown(sbo_ctx* c) {
   if (c->h_c1) (void)hipHostFree(c->h_c1);
   if (c->h_back) (void)hipHostFree(c->h_back);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->ev_factor) (void)hipEventDestroy(c->ev_factor);
+  if (c->ev_w) (void)hipEventDestroy(c->ev_w);
+  if (c->stream4) (void)hipStreamDestroy(c->stream4);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -192,6 +219,10 @@ int sbo_shutdown(sbo_ctx* c) {
 int sbo_synchronize(sbo_ctx* c) {
   if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
   SBO_HIP(hipStreamSynchronize(c->stream));
+  // (everything the library may still have in flight for this context: a deferred factorisation, the bases of a model)
+  if (c->stream2) SBO_HIP(hipStreamSynchronize(c->stream2));
+  if (c->stream3) SBO_HIP(hipStreamSynchronize(c->stream3));
+  if (c->stream4) SBO_HIP(hipStreamSynchronize(c->stream4));
   return SBO_OK;
 }
 
@@ -206,6 +237,14 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "k1_wgs_per_cu")) {
     if (value < 0 || value > 64) return fail(SBO_E_INVALID, "k1_wgs_per_cu out of range");
     c->k1_wgs_per_cu = (int)value;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "chol_async")) {
+    c->chol_async = value ? 1 : 0;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "chol_fused")) {
+    c->chol_fused = value ? 1 : 0;
     return SBO_OK;
   }
   if (!strcmp(key, "k1_split")) {
@@ -385,6 +424,8 @@ int sbo_model_append(sbo_ctx* c, const double* x_norm_new, const double* y_norm_
   const int n = mc.n, d = mc.d, q = mc.q;
   if (n + 1 > SBO_MAX_N) return fail(SBO_E_UNSUPPORTED, "model is at its capacity: rebuild it with sbo_model_set");
   SBO_HIP(hipSetDevice(c->device));
+  { const int rcf = factor_sync(c); if (rcf) return rcf; }     // (the update works on the resident factor)
+  c->invk_img_valid = false;                                    // (the images of the caller's invK do not follow an append)
   // cross-covariances of the new point with the expanded distance of the reference (GP_Safe.py:115-119, 166)
   std::vector<double> kvec((size_t)q * n);
   double kappa[kMaxQ], rho[kMaxQ];

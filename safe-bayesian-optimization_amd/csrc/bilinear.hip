@@ -683,8 +683,9 @@ __global__ __launch_bounds__(256) void k_bl_zf(const BlDims dm, const double* __
   }
 }
 // T4qq^T as B fragments over the columns k0: [KB0][KB1 * 4][64], element (k1, k0) = sf2^2 / 2 (G[(p,s),(p',s')] + G[(p',s),(p,s')])
+// (sym: G is symmetric only up to rounding -- the form with a caller's invK -- and both transposed entries are averaged in)
 __global__ __launch_bounds__(256) void k_bl_t4f(const BlDims dm, const double* __restrict__ Gall, long long ldg, size_t sT4f,
-                                                double* __restrict__ T4fall) {
+                                                double* __restrict__ T4fall, int sym) {
   const int o = blockIdx.y, r0 = dm.r0[o], r1 = dm.r1[o], KB0 = dm.KB0, KB1 = dm.KB1;
   const int K0 = r0 * (r0 + 1) / 2, K1 = r1 * (r1 + 1) / 2;
   const double* G = Gall + (size_t)o * ldg * ldg;
@@ -702,7 +703,9 @@ __global__ __launch_bounds__(256) void k_bl_t4f(const BlDims dm, const double* _
       int p, pp, s1, ss;
       pair_of(k0, r0, p, pp);
       pair_of(k1, r1, s1, ss);
-      v = scale * 0.5 * (G[(size_t)(p * r1 + s1) * ldg + (pp * r1 + ss)] + G[(size_t)(pp * r1 + s1) * ldg + (p * r1 + ss)]);
+      const size_t a1 = (size_t)(p * r1 + s1), b1 = (size_t)(pp * r1 + ss), a2 = (size_t)(pp * r1 + s1), b2 = (size_t)(p * r1 + ss);
+      v = sym ? scale * 0.25 * ((G[a1 * ldg + b1] + G[b1 * ldg + a1]) + (G[a2 * ldg + b2] + G[b2 * ldg + a2]))
+              : scale * 0.5 * (G[a1 * ldg + b1] + G[a2 * ldg + b2]);
     }
     T4f[i] = v;
   }
@@ -1394,14 +1397,26 @@ int bilinear_setup(sbo_ctx* c) {
   hipLaunchKernelGGL(k_bl_stab, blocks((size_t)std::max(r0u * cnt0, r1u * nlines), 2 * uq), dim3(256), 0, c->stream, dm, dVs, dsig,
                      (const double*)dxn0, (const double*)dxn1, dS0, dS1);
   hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, c->stream, dm, dU, nZf, Zf);
-  // C = M Z with the model's packed triangular factor; written as fragments (k = observation) and as images of C^T
-  hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, c->stream,
-                     (const double*)c->Fpk.p, c->fpk_stride, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
-  // G = C^T C  (R x R, row-major)
-  hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
-                     (const double*)CtA, nZf, (const double*)Cf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
+  // G = Z^T invK Z.  With the library's own Cholesky factor (M = L^-1): C = M Z from the packed triangular images, written as
+  // fragments (k = observation) and as images of C^T, then G = C^T C.  With a CALLER's invK (sbo_ctx::invk_img, r03): W =
+  // invK Z with the matrix as given -- the contraction the reference itself performs, models/GP_Safe.py:341-343, no
+  // factorisation of an ill-conditioned inverse in between --, then G^T = W^T Z; k_bl_t4f symmetrises what rounding leaves.
+  const bool direct = mc.factor == SBO_FACTOR_INVK && c->invk_img_valid;
+  if (!direct && (rc = factor_sync(c))) return rc;
+  if (direct) {
+    hipLaunchKernelGGL((k_bgemm<4, 0, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, c->stream,
+                       (const double*)c->invk_img.p, (size_t)mc.npad * mc.npad, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
+    hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
+                       (const double*)CtA, nZf, (const double*)Zf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
+  } else {
+    hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, c->stream,
+                       (const double*)c->Fpk.p, c->fpk_stride, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
+    // G = C^T C  (R x R, row-major)
+    hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
+                       (const double*)CtA, nZf, (const double*)Cf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
+  }
   hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f, uq), dim3(256), 0, c->stream, dm, (const double*)G, (long long)ldg, pl.sT4f,
-                     (double*)c->bl_T4f.p);
+                     (double*)c->bl_T4f.p, direct ? 1 : 0);
   hipLaunchKernelGGL((k_bl_pairs<1>), blocks(pl.sP0f, uq), dim3(256), 0, c->stream, dm, (const double*)dS0, pl.sP0f, (double*)c->bl_P0f.p);
   hipLaunchKernelGGL((k_bl_pairs<0>), blocks(pl.sP1A, uq), dim3(256), 0, c->stream, dm, (const double*)dS1, pl.sP1A, (double*)c->bl_P1A.p);
   // mean phases: Mb (forms of alpha, alpha Xn_0, alpha Xn_1) -> Vb = Mb S1 -> A images [V0 | V1;V0 | V1x], B fragments

@@ -61,6 +61,7 @@ struct sbo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // side stream: the K1b axis bases of a new model run next to its factorisation
+  hipStream_t stream4 = nullptr;   // the deferred factorisation of a caller's invK (chol_async): off the critical path of a model change
   hipStream_t stream3 = nullptr;   // chain stream of an overlapped sweep (k1_split): the constraints' set phase next to the objective's K1b
   int n_cu = 256;
   // model
@@ -82,6 +83,15 @@ struct sbo_ctx {
   int f_cap = 0;                 // leading dimension / capacity of Fplain: n after a build, n + 256.. once an append has grown it
   int a_ld = 0;                  // stride of alpha64: npad after a build, f_cap after an append
   sbo::DevBuf mwork;             // model build workspace (uploads, fp64 copies of the derived arrays, the factorisation's scratch)
+  // Caller's invK on a K1b-capable grid (option chol_async): the GEMM posterior's tables contract with invK itself -- packed
+  // here as full matrix-core images, exactly the matrix of models/GP_Safe.py:341-343 -- so the reverse Cholesky factor M (needed
+  // by the O(n^2) kernels K1g / K1 / K1c and by sbo_model_append only) is built on stream4 while the caller goes on; whoever
+  // needs it calls factor_sync first, which also delivers the positive-definiteness verdict
+  sbo::DevBuf invk_img;            // [q][npad / 16][npad / 16][256] A images of the full invK (fp64)
+  bool invk_img_valid = false;
+  bool factor_pending = false;     // the factor chain of the current model is (possibly) still running; ev_factor marks its end
+  hipEvent_t ev_factor = nullptr, ev_w = nullptr;
+  int chol_async = 1;
   sbo::BilinearPlan bl;
   sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work;
   sbo::DevBuf bl_basis;            // K1b: the 2 q axis bases (U, Chebyshev series, ranks) and the workspace of their kernel
@@ -182,6 +192,7 @@ struct sbo_ctx {
   int fuse_classify = -1;  // one-constraint sweeps on the K1b path take their S / U bytes from the posterior kernel's mean epilogue: 1 always, 0 never, -1 (default) when the launch has at least four workgroups per CU (r03, sqrt-free sign tests: config H -40 us, config B +-0)
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
   int phase_events = 0;    // 1: events between the set phases too (classify / expander / arg-reduce times in sbo_profile)
+  int chol_fused = 1;      // blocked model build: one launch per panel (k_chol_step: look-ahead update, four-wave diagonal block, reciprocal pivots); 0: the two-launch form of round 2
   int k1_split = 0;        // (A/B option, measured slower: f64 matrix and vector instructions share a datapath the GEMM already keeps ~75 % busy) 1: K1b sweeps of constrained models on one rank run the constraints' set phase beside the objective's GEMM
   int bilinear = 1;        // 1: fp64 2-D grids run the posterior as two GEMMs in a reduced basis when the bases qualify (K1b)
   int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
@@ -212,7 +223,8 @@ int hip_fail(hipError_t e, const char* what);
 int ensure(DevBuf& b, size_t bytes);
 hipError_t stream_wait(const sbo_ctx* c, hipStream_t st);   // hipStreamSynchronize, polling first (option spin_wait)
 void release(DevBuf& b);
-void drain_streams(sbo_ctx* c);   // after a failed call: wait for whatever it left on the main and side streams
+void drain_streams(sbo_ctx* c);
+int factor_sync(sbo_ctx* c);      // wait for a deferred factorisation (sbo_ctx::factor_pending); SBO_E_INVALID when invK was not positive definite   // after a failed call: wait for whatever it left on the main and side streams
 
 // launchers implemented in the .hip files -----------------------------------------------------
 int launch_posterior(sbo_ctx* c);

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <vector>
 #include "device_common.hpp"
 
@@ -363,6 +364,163 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ work, 
   }
 }
 
+// ---- r03: one launch per panel ------------------------------------------------------------------------------------------
+// k_chol_panel + k_chol_update above are two dependent launches per panel (n = 512: 16 x (19-25 + 7-10) us, and what a panel
+// launch waits for is the pivot chain of its 32 x 32 diagonal block: IEEE sqrt + IEEE division per pivot and ~90 lane
+// broadcasts per step on ONE wave).  k_chol_step is the same right-looking factorisation with the trailing update one
+// launch late ("look-ahead"): the launch of panel kb
+//   role A (workgroups [0, nA)): applies the PENDING rank-32 update of panel kb - 32 to the diagonal block and to its own
+//          columns of the panel rows, factors the block with all four waves in LDS (four elements per thread, one barrier
+//          per pivot; the pivot's reciprocal square root by v_rsq_f64 + two Newton steps instead of sqrt and division),
+//          then the forward substitution of its columns, a row per lane, multiplying by the stored reciprocals;
+//   role B (the rest): the pending update of panel kb - 32 on the rows BELOW the current panel (k_chol_update's tiles).
+// Every element receives the same updates in the same order as before (sum over a panel's 32 rows, then one subtraction);
+// the factors differ from the two-launch form only through the reciprocal pivots (a few ulp).
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double r = __builtin_amdgcn_rsq(x);                       // v_rsq_f64: ~2^-23 relative
+  const double h = 0.5 * x;
+  r = fma(r, fma(-h * r, r, 0.5), r);                       // r (1.5 - h r^2), twice: ~2^-45, then rounding
+  r = fma(r, fma(-h * r, r, 0.5), r);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ work, double* __restrict__ F, int with_E, int n, int kb, int nA,
+                                                   int ti, int* __restrict__ bad, double* __restrict__ Dg) {
+  __shared__ double D[kPB][kPB + 1];      // role A: working copy of the diagonal block (upper triangle)
+  __shared__ double Uf[kPB][kPB + 1];     // role A: its factor
+  __shared__ double P[kPB][kPB + 1];      // role A: P[t][r] = U[kbp + t][kb + r];  role B: the tile's rows of the pending panel
+  __shared__ double Qx[kPB][kPB + 1];     // role B: the tile's columns of the pending panel
+  __shared__ double rinv_sh[kPB];
+  const int o = blockIdx.y, tid = threadIdx.x, bid = blockIdx.x;
+  double* U = work + (size_t)o * n * n;
+  double* E = F + (size_t)o * n * n;
+  const int kw = n - kb < kPB ? n - kb : kPB;
+  const int kbp = kb - kPB;                                  // the pending panel (kb > 0): always a full one
+  if (bid >= nA) {
+    // ---- role B: pending update of panel kbp on rows >= kb + kw (k_chol_update's arithmetic) ----
+    int b = bid - nA, part = 0;
+    if (b >= ti * ti) { b -= ti * ti; part = 1; }
+    const int bx = part == 0 ? b % ti : b / ti, by = part == 0 ? b / ti : b % ti;
+    const int i0 = kb + kw + by * 32;
+    const int x0 = part == 0 ? kb + kw + bx * 32 : bx * 32;
+    if (i0 >= n) return;
+    if (part == 0 && x0 + 31 < i0) return;                   // tile entirely below the diagonal
+    const double* Q = part == 0 ? U : E;
+    for (int idx = tid; idx < kPB * 32; idx += blockDim.x) {
+      const int r = idx / 32, t = idx % 32;
+      P[r][t] = i0 + t < n ? U[(size_t)(kbp + r) * n + i0 + t] : 0.0;
+      const int xc = x0 + t;
+      const bool xin = part == 0 ? xc < n : xc < kb;
+      // rows of E inside a panel are lower triangular: entries right of their diagonal are zero
+      Qx[r][t] = (xin && (part == 0 || xc <= kbp + r)) ? Q[(size_t)(kbp + r) * n + xc] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid % 32, ty = tid / 32;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int il = ty + 8 * rr, i = i0 + il, xc = x0 + tx;
+      if (i >= n) continue;
+      if (part == 0 ? (xc >= n || xc < i) : (xc >= kb)) continue;
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < kPB; ++r) acc += P[r][il] * Qx[r][tx];
+      double* dst = (part == 0 ? U : E) + (size_t)i * n + xc;
+      *dst -= acc;
+    }
+    return;
+  }
+  // ---- role A ----
+  for (int idx = tid; idx < kPB * kPB; idx += blockDim.x) {
+    const int r = idx / kPB, cc = idx % kPB;
+    D[r][cc] = (r < kw && cc < kw && cc >= r) ? U[(size_t)(kb + r) * n + kb + cc] : 0.0;
+    P[r][cc] = (kb > 0 && cc < kw) ? U[(size_t)(kbp + r) * n + kb + cc] : 0.0;
+  }
+  __syncthreads();
+  const int cc = tid & 31, r0 = tid >> 5;                    // this thread's four elements: column cc, rows r0 + 8 m
+  if (kb > 0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int r = r0 + 8 * m;
+      if (r <= cc && cc < kw) {
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < kPB; ++t) acc += P[t][r] * P[t][cc];
+        D[r][cc] -= acc;
+      }
+    }
+    __syncthreads();
+  }
+  bool notpd = false;
+  for (int j = 0; j < kw; ++j) {
+    const double piv = D[j][j];
+    notpd = notpd || !(piv > 0.0);
+    const double x = piv > 0.0 ? piv : 1.0;
+    const double rv = rsqrt_nr(x);
+    double ljj = x * rv;
+    ljj = fma(0.5 * rv, fma(-ljj, ljj, x), ljj);             // one correction step: sqrt(x) to ~1 ulp
+    const double ujc = D[j][cc] * rv;                        // entry of the scaled pivot row in this thread's column
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int r = r0 + 8 * m;
+      if (r > j && cc >= r) D[r][cc] -= (D[j][r] * rv) * ujc;
+      if (r == j) Uf[j][cc] = cc > j ? ujc : (cc == j ? ljj : 0.0);
+    }
+    if (tid == 0) rinv_sh[j] = rv;
+    __syncthreads();
+  }
+  for (int idx = tid; idx < kPB * kPB; idx += blockDim.x)     // rows / columns beyond a short last panel
+    if (idx / kPB >= kw || idx % kPB >= kw) Uf[idx / kPB][idx % kPB] = 0.0;
+  if (tid >= kw && tid < kPB) rinv_sh[tid] = 1.0;
+  if (tid == 0 && notpd) bad[o] = 1;
+  __syncthreads();
+  // the factored block goes to the side array k_chol_finish reads (never back into U: see k_chol_panel)
+  if (bid == 0) {
+    double* dg = Dg + ((size_t)o * ((n + kPB - 1) / kPB) + kb / kPB) * (kPB * kPB);
+    for (int idx = tid; idx < kPB * kPB; idx += blockDim.x) dg[idx] = Uf[idx / kPB][idx % kPB];
+  }
+  // columns [kb + kw, n) of U, then (with E) [0, kb + kw) of E: a column per half wave, a row per lane
+  const int nright = n - kb - kw;
+  const int ncols = nright + (with_E ? kb + kw : 0);
+  const int lane = tid & 63, r = lane & 31, half = lane >> 5;
+  double dcol[kPB];
+#pragma unroll
+  for (int t = 0; t < kPB; ++t) dcol[t] = Uf[t][r];
+  const double myrinv = rinv_sh[r];
+  const int pairs_total = (ncols + 1) / 2;
+  for (int pr = bid * (blockDim.x >> 6) + (tid >> 6); pr < pairs_total; pr += nA * (blockDim.x >> 6)) {
+    const int xcol = 2 * pr + half;
+    const bool live = xcol < ncols && r < kw;
+    const bool isU = xcol < nright;
+    const int col = isU ? kb + kw + xcol : xcol - nright;
+    double* base = isU ? U : E;
+    double acc = 0.0;
+    if (live) acc = (!isU && col >= kb) ? (col - kb == r ? 1.0 : 0.0) : base[(size_t)(kb + r) * n + col];
+    if (kb > 0) {
+      // pending update: acc -= sum_t P[t][r] X[kbp + t][col]; lane t of a half fetches X[kbp + t][col] (rows of E inside the
+      // pending panel are zero right of their diagonal, and so for every column of the current panel's own block)
+      double xr = 0.0;
+      if (xcol < ncols && (isU || col <= kbp + r)) xr = base[(size_t)(kbp + r) * n + col];
+      double pend = 0.0;
+#pragma unroll
+      for (int t = 0; t < kPB; ++t) {
+        const double x0 = readlane_f64(xr, t), x1 = readlane_f64(xr, 32 + t);
+        pend += P[t][r] * (half ? x1 : x0);
+      }
+      if (live && (isU || col < kb)) acc -= pend;
+    }
+#pragma unroll
+    for (int t = 0; t < kPB; ++t) {
+      if (t < kw) {
+        if (r == t) acc = acc * myrinv;
+        const double v0 = readlane_f64(acc, t), v1 = readlane_f64(acc, 32 + t);
+        const double vt = half ? v1 : v0;
+        if (r > t) acc -= dcol[t] * vt;
+      }
+    }
+    if (live && (isU || col <= kb + r)) base[(size_t)(kb + r) * n + col] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_chol_finish(int mode, int n, int npad, const double* __restrict__ rhs,
                                                      double* __restrict__ work, double* __restrict__ F, double* __restrict__ alpha,
                                                      const double* __restrict__ Dg) {
@@ -419,6 +577,21 @@ __global__ __launch_bounds__(256) void k_pack_factor(const double* __restrict__ 
     MM<T>::unpack_pos(e, r, k, kk);
     const int row = 16 * I + r, col = 16 * J + MM<T>::jslot(kk, k);
     dst[idx] = (row < n && col < n && col <= row) ? (T)Fo[(size_t)row * ld + col] : T(0);
+  }
+}
+
+// the caller's invK [q][n][n] (row-major, as given) -> full A images [q][nb][nb][256] for the table GEMM of the K1b plan
+__global__ __launch_bounds__(256) void k_pack_full(const double* __restrict__ W, int n, int nb, double* __restrict__ img) {
+  const int o = blockIdx.y;
+  const double* Wo = W + (size_t)o * n * n;
+  double* dst = img + (size_t)o * nb * nb * 256;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)nb * nb * 256; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = idx >> 8;
+    const int e = (int)(idx & 255), I = (int)(blk / nb), J = (int)(blk % nb);
+    int r, k, kk;
+    MM<double>::unpack_pos(e, r, k, kk);
+    const int row = 16 * I + r, col = 16 * J + MM<double>::jslot(kk, k);
+    dst[idx] = (row < n && col < n) ? Wo[(size_t)row * n + col] : 0.0;
   }
 }
 
@@ -595,6 +768,11 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
   const int n = mc.n, npad = mc.npad, q = mc.q, nb = npad / 16;
   const size_t nn = (size_t)n * n;
   int rc;
+  if (c->factor_pending) {                // (the previous model's deferred factor chain works in the buffers reused below)
+    SBO_HIP(hipEventSynchronize(c->ev_factor));
+    c->factor_pending = false;
+  }
+  c->invk_img_valid = false;
   ModelWork w;
   if ((rc = model_work(c, host_invK != nullptr, w))) return rc;
   if ((rc = ensure(c->Fplain, sizeof(double) * (size_t)q * nn))) return rc;
@@ -603,21 +781,28 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
   c->a_ld = npad;
   double* dF = (double*)c->Fplain.p;
   double* dalpha = (double*)c->alpha64.p;
-  if (host_invK)                          // (the reference keeps them as a list of q arrays: one copy each, no stacking on the host)
-    for (int o = 0; o < q; ++o)
-      SBO_HIP(hipMemcpyAsync(w.W + (size_t)o * nn, host_invK[o], sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
   if ((rc = model_prep_t<T>(c, X_norm, Y_norm, w))) return rc;
   bool eager_basis = false;
   if (bilinear_applicable(c)) {
-    // the bases need X_norm only: next to the factorisation, on the second stream
+    // the bases need X_norm only: next to the factorisation, on the second stream -- and ahead of the upload of invK
+    // (4 MB at n = 512, ~0.15 ms of pageable copies the host sits in): their pivot loop is the longest chain of a model change
     SBO_HIP(hipEventRecord(c->ev[6], c->stream));
     SBO_HIP(hipStreamWaitEvent(c->stream2, c->ev[6], 0));
     if ((rc = bilinear_basis_enqueue(c, c->stream2, false))) return rc;
     eager_basis = true;
   }
+  if (host_invK)                          // (the reference keeps them as a list of q arrays: one copy each, no stacking on the host)
+    for (int o = 0; o < q; ++o)
+      SBO_HIP(hipMemcpyAsync(w.W + (size_t)o * nn, host_invK[o], sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemsetAsync(dalpha, 0, sizeof(double) * (size_t)q * npad, c->stream));
   SBO_HIP(hipMemsetAsync(w.bad, 0, sizeof(int) * q, c->stream));
   const int mode = host_invK ? 0 : 1;
+  // A caller's invK on a K1b-capable grid: the GEMM posterior's tables take invK itself (k_pack_full), so the reverse
+  // Cholesky factor is only needed by the O(n^2) kernels and by sbo_model_append -- it is built on stream4 and nobody waits
+  // for it here (n = 512: 16 dependent panel launches, ~0.43 ms off the critical path of a model change)
+  const bool deferred = mode == 0 && n >= kBlockedFrom && c->chol_async && !c->is_shadow && eager_basis && c->stream4 &&
+                        std::is_same<T, double>::value;
+  hipStream_t fs = deferred ? c->stream4 : c->stream;     // the factor chain's stream
   const double* dsf2 = nullptr;   // (sf2 / sn2 travel in the kernel arguments)
   (void)dsf2;
   if (n >= kBlockedFrom) {
@@ -625,27 +810,47 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
     if (mode == 0) {
       hipLaunchKernelGGL(k_invk_alpha, dim3((unsigned)((n + 3) / 4), q), dim3(256), 0, c->stream, n, npad, (const double*)w.W,
                          (const double*)w.rhs, dalpha);
-      hipLaunchKernelGGL(k_invk_reverse, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), q), dim3(256), 0, c->stream, n,
+      if (deferred) {
+        if ((rc = ensure(c->invk_img, sizeof(double) * (size_t)q * npad * npad))) return rc;
+        hipLaunchKernelGGL(k_pack_full, dim3((unsigned)std::min<size_t>(((size_t)nb * nb * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
+                           (const double*)w.W, n, nb, (double*)c->invk_img.p);
+        c->invk_img_valid = true;
+        SBO_HIP(hipEventRecord(c->ev_w, c->stream));
+        SBO_HIP(hipStreamWaitEvent(fs, c->ev_w, 0));
+      }
+      hipLaunchKernelGGL(k_invk_reverse, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), q), dim3(256), 0, fs, n,
                          (const double*)w.W, w.work);
     } else {
       hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
                          (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha);
     }
+    if (c->chol_fused) {
+      // one launch per panel: the pending update of the previous panel rides in the panel's own launch (k_chol_step)
+      for (int kb = 0; kb < n; kb += kPB) {
+        const int kw = std::min(kPB, n - kb);
+        const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
+        const int nA = std::max(1, ((ncols + 1) / 2 + 3) / 4);
+        const int ti = kb > 0 ? (n - kb - kw + 31) / 32 : 0;
+        const int nB = ti * ti + (mode && kb > 0 ? ((kb + 31) / 32) * ti : 0);
+        hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + nB), q), dim3(256), 0, fs, w.work, dF, mode, n, kb, nA, ti, w.bad, w.Dg);
+      }
+    } else {
     for (int kb = 0; kb < n; kb += kPB) {
-      const int kw = std::min(kPB, n - kb);
-      const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
-      // (a half wave per column: four pairs of columns per workgroup)
-      hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, ((ncols + 1) / 2 + 3) / 4), q), dim3(256), 0, c->stream, w.work, dF, mode,
-                         n, kb, w.bad, w.Dg);
-      const int rest = n - kb - kw;
-      if (rest > 0) {
-        const unsigned ti = (unsigned)((rest + 31) / 32);
-        hipLaunchKernelGGL(k_chol_update, dim3(ti, ti, q), dim3(256), 0, c->stream, w.work, dF, 0, n, kb);
-        if (mode)
-          hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((kb + kw + 31) / 32), ti, q), dim3(256), 0, c->stream, w.work, dF, 1, n, kb);
+        const int kw = std::min(kPB, n - kb);
+        const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
+        // (a half wave per column: four pairs of columns per workgroup)
+        hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, ((ncols + 1) / 2 + 3) / 4), q), dim3(256), 0, fs, w.work, dF, mode,
+                           n, kb, w.bad, w.Dg);
+        const int rest = n - kb - kw;
+        if (rest > 0) {
+          const unsigned ti = (unsigned)((rest + 31) / 32);
+          hipLaunchKernelGGL(k_chol_update, dim3(ti, ti, q), dim3(256), 0, fs, w.work, dF, 0, n, kb);
+          if (mode)
+            hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((kb + kw + 31) / 32), ti, q), dim3(256), 0, fs, w.work, dF, 1, n, kb);
+        }
       }
     }
-    hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, (const double*)w.rhs, w.work, dF, dalpha,
+    hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, fs, mode, n, npad, (const double*)w.rhs, w.work, dF, dalpha,
                        (const double*)w.Dg);
   } else {
     hipLaunchKernelGGL(k_model_build, dim3(q), dim3(1024), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
@@ -655,16 +860,21 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
   c->fpk_stride = ntri * 4 * 64;
   if ((rc = ensure(c->Fpk, sizeof(T) * ((size_t)q * c->fpk_stride + 512)))) return rc;   // + padding: the K1g pipeline over-reads
   // (k_pack_factor writes every element of the images, zeros included; only the over-read padding needs clearing)
-  SBO_HIP(hipMemsetAsync((T*)c->Fpk.p + (size_t)q * c->fpk_stride, 0, sizeof(T) * 512, c->stream));
-  hipLaunchKernelGGL((k_pack_factor<T>), dim3((unsigned)std::min<size_t>((ntri * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
+  SBO_HIP(hipMemsetAsync((T*)c->Fpk.p + (size_t)q * c->fpk_stride, 0, sizeof(T) * 512, fs));
+  hipLaunchKernelGGL((k_pack_factor<T>), dim3((unsigned)std::min<size_t>((ntri * 256 + 255) / 256, 4096), q), dim3(256), 0, fs,
                      (const double*)dF, n, n, nn, nb, c->fpk_stride, (T*)c->Fpk.p);
   if ((rc = ensure(c->alpha, sizeof(T) * (size_t)q * npad))) return rc;
   hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)dalpha, npad, n, q, npad, (T*)c->alpha.p);
   SBO_HIP(hipGetLastError());
-  int* hbad = (int*)(c->h_back + 4608);
-  SBO_HIP(hipMemcpyAsync(hbad, w.bad, sizeof(int) * q, hipMemcpyDeviceToHost, c->stream));
+  int* hbad = (int*)(c->h_back + (deferred ? 4864 : 4608));
+  SBO_HIP(hipMemcpyAsync(hbad, w.bad, sizeof(int) * q, hipMemcpyDeviceToHost, fs));
+  if (deferred) {
+    SBO_HIP(hipEventRecord(c->ev_factor, fs));
+    c->factor_pending = true;
+  }
   SBO_HIP(stream_wait(c, c->stream));
   if (eager_basis) SBO_HIP(stream_wait(c, c->stream2));
+  if (deferred) return SBO_OK;            // (the verdict on invK comes with the factor: factor_sync)
   for (int o = 0; o < q; ++o)
     if (hbad[o]) return fail(SBO_E_INVALID, host_invK ? "invK is not positive definite" : "K + sn2 I is not positive definite");
   return SBO_OK;

@@ -900,6 +900,7 @@ int launch_posterior(sbo_ctx* c) {
         return launch_posterior_bilinear(c);       // (writes the Lipschitz keys itself)
       }
     }
+    { const int rcf = factor_sync(c); if (rcf) return rcf; }     // (the O(n^2) kernels contract with the factor images)
     SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
     c->last_k1 = 3;
     c->last_k1_flops = tri_flops;
@@ -907,6 +908,7 @@ int launch_posterior(sbo_ctx* c) {
   }
   // generic candidates: the single-phase kernel while the whole K* tile of 64 candidates fits LDS with two workgroups
   // per CU, the chunked kernel beyond that (and on request: posterior_path 2)
+  { const int rcf = factor_sync(c); if (rcf) return rcf; }
   SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
   const size_t tile_bytes = (c->dtype == SBO_F64 ? 8u : 4u) * (size_t)c->mc.npad * 64;
   c->last_k1_flops = tri_flops;

@@ -1299,14 +1299,17 @@ def test_comm_init_failure_leaves_the_context_single_rank(engine):
 
 
 @pytest.mark.parametrize("use_invK", [True, False])
-def test_blocked_model_build_repeats_bitwise(engine, use_invK):
-    """n >= 256 builds the model with the multi-workgroup blocked factorisation (many launches, workgroups sharing the
-    panel's diagonal block): repeated builds of one data set must give the same posterior bit for bit (a workgroup that
-    read a block another one had already factored once made every few builds fail)."""
-    cfg = synthetic.make_config("H", n=512)
+@pytest.mark.parametrize("n", [512, 300, 128])
+def test_blocked_model_build_repeats_bitwise(engine, use_invK, n):
+    """n >= 96 builds the model with the multi-workgroup blocked factorisation (one launch per panel, workgroups sharing the
+    panel's diagonal block and the pending update of the previous panel): repeated builds of one data set must give the same
+    posterior bit for bit (a workgroup that read a block another one had already factored once made every few builds fail),
+    full and ragged last panels (300 = 9 x 32 + 12).  And the one-launch-per-panel form (option chol_fused, reciprocal
+    pivots) must reproduce the two-launch form of round 2 (IEEE sqrt and division) to a few ulp of the posterior."""
+    cfg = synthetic.make_config("H", n=n)
     lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
     first = None
-    for rep in range(12):
+    for rep in range(8):
         engine.set_model(cfg["ds"], use_invK=use_invK)
         engine.set_grid(lo, hi, [48, 40])
         mean, var = engine.posterior()
@@ -1315,6 +1318,89 @@ def test_blocked_model_build_repeats_bitwise(engine, use_invK):
             _check_posterior(engine, cfg["ds"], oracle.grid_points(lo, hi, [48, 40]), TOL64)
         else:
             assert np.array_equal(mean, first[0]) and np.array_equal(var, first[1]), rep
+    try:
+        engine.set_option("chol_fused", 0)
+        engine.set_model(cfg["ds"], use_invK=use_invK)
+        engine.set_grid(lo, hi, [48, 40])
+        m0, v0 = engine.posterior()
+    finally:
+        engine.set_option("chol_fused", 1)
+    ys = np.maximum(1.0, cfg["ds"]["Y_std"])
+    assert np.max(np.abs(m0 - first[0]) / ys) < 1e-12 and np.max(np.abs(v0 - first[1]) / ys ** 2) < 1e-12
+
+
+@pytest.mark.parametrize("cfg_name,n,count", [("H", 512, [96, 80]), ("B", 128, [96, 80]), ("C", 256, [80, 96]), ("H", 300, [70, 66])])
+def test_caller_invK_tables_and_deferred_factor(engine, cfg_name, n, count):
+    """A caller's invK on a grid the GEMM posterior takes (option chol_async, default on): the tables contract with invK as
+    given (W = invK Z, models/GP_Safe.py:341-343) and the reverse Cholesky factor -- needed by the O(n^2) kernels and by
+    sbo_model_append only -- is built on a side stream after sbo_model_set has returned.  (a) The posterior equals the
+    factor-based tables (chol_async = 0) to rounding and the oracle within the bar; (b) a consumer of the factor right behind
+    the model change (K1g posterior; an append) waits for it and is correct; (c) a new model right behind a model change
+    (its deferred chain still running) is correct too."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_grid(lo, hi, count)
+    engine.set_model(cfg["ds"])                                  # deferred factor, direct tables
+    m1, v1 = _check_posterior(engine, cfg["ds"], pts, TOL64)
+    assert engine.profile()["posterior_kernel"] == 4
+    try:
+        engine.set_option("chol_async", 0)
+        engine.set_model(cfg["ds"])
+        m0, v0 = _check_posterior(engine, cfg["ds"], pts, TOL64)
+        assert engine.profile()["posterior_kernel"] == 4
+    finally:
+        engine.set_option("chol_async", 1)
+    ys = np.maximum(1.0, cfg["ds"]["Y_std"])
+    assert np.max(np.abs(m0 - m1) / ys) < 1e-11 and np.max(np.abs(v0 - v1) / ys ** 2) < 1e-11
+    # (b) the factor's consumers right behind the model change
+    try:
+        engine.set_model(cfg["ds"])
+        engine.set_option("bilinear", 0)                         # K1g: contracts with the factor images
+        mg, vg = _check_posterior(engine, cfg["ds"], pts, TOL64)
+        assert engine.profile()["posterior_kernel"] == 3
+    finally:
+        engine.set_option("bilinear", 1)
+    assert np.max(np.abs(mg - m1) / ys) < 1e-11 and np.max(np.abs(vg - v1) / ys ** 2) < 1e-11
+    # (c) model changes back to back, then a sweep against the oracle
+    alt = synthetic.make_config(cfg_name, n=n, seed=synthetic.SEED0 + 321)
+    for ds in (alt["ds"], cfg["ds"], alt["ds"], cfg["ds"]):
+        engine.set_model(ds)
+    res = engine.sweep_safeopt(cfg["b"], want_masks=True)
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"])
+    assert np.array_equal(engine.mask("S"), ref["S"]) and np.array_equal(engine.mask("M"), ref["M"])
+    assert res["minimizer_index"] == ref["minimizer_index"] and list(res["expander_index_c"]) == list(ref["expander_index"])
+
+
+def test_deferred_factor_reports_an_indefinite_invK_where_it_is_needed(engine):
+    """With the factor deferred, sbo_model_set cannot say that invK is not positive definite -- the GEMM posterior does not need
+    it to be (neither does the reference: var is clipped at 0, models/GP_Safe.py:343).  The O(n^2) kernels do: the error
+    surfaces, as ValueError, at the first call that needs the factor."""
+    cfg = synthetic.make_config("B", n=128)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    ds = dict(cfg["ds"])
+    bad = [a.copy() for a in ds["invKopt"]]
+    bad[1][5, 5] = -abs(bad[1][5, 5])                             # an indefinite "inverse"
+    ds["invKopt"] = bad
+    engine.set_grid(lo, hi, [96, 80])
+    engine.set_model(ds)                                          # accepted: nothing on this path factors it
+    mean, var = engine.posterior()
+    assert engine.profile()["posterior_kernel"] == 4 and np.all(var >= 0) and np.all(np.isfinite(mean))
+    om, ov = oracle.gp_inference(oracle.grid_points(lo, hi, [96, 80]), ds)
+    assert _nerr(mean, om, ds["Y_std"], 1) < 1e-9 and _nerr(var, ov, ds["Y_std"], 2) < 1e-9
+    try:
+        engine.set_option("bilinear", 0)
+        with pytest.raises(ValueError, match="not positive definite"):
+            engine.posterior_run()
+    finally:
+        engine.set_option("bilinear", 1)
+    try:
+        engine.set_option("chol_async", 0)
+        with pytest.raises(ValueError, match="not positive definite"):
+            engine.set_model(ds)
+    finally:
+        engine.set_option("chol_async", 1)
+    engine.set_model(cfg["ds"])                                   # and the context is usable again
 
 
 @pytest.mark.parametrize("use_invK,dtype", [(True, "f64"), (False, "f64"), (False, "f32")])
