@@ -6,10 +6,11 @@ driver launches one rank per GPU with ``torch.distributed.run``.  One *step* is 
 (K1 posterior, S/U/M masks, u*, Lipschitz bound, expander sets, masked arg-max, result to host) over the
 candidates resident in HBM.
 
-Workload at N = 1: BASELINE.json configs[1] -- Benoit 2-D, 2048 x 2048 implicit grid, n = 128 observations,
-q = 2 outputs, fp64.  For N > 1 the grid grows along its slowest axis (2048 x 2048 N): each rank sweeps
-2048^2 candidates ("weak" scaling); the ranks exchange u*/L (one RCCL max all-reduce), the fully-unsafe
-mask (one all-gather) and the arg-max candidates (one sum all-reduce).
+Workload at every N: the configuration the north-star target is quoted on -- config H, Benoit 2-D, 4096 x 4096 implicit
+grid, n = 512 observations, q = 2 outputs, fp64 -- STRONG-scaled: the grid is sharded over the ranks by whole rows of its
+slowest axis; the ranks exchange u* / L / radius keys and the fully-unsafe mask (one all-gather) and the arg-max candidates
+(one sum all-reduce).  BASELINE.json configs[1] (config B, 2048 x 2048, n = 128) and the other configs are measured in
+``extra`` of the same process at N = 1; at N > 1 ``extra`` holds config D (128^4, BASELINE.json configs[3]) strong-scaled.
 
 What the JSON line reports (N = 1 adds the last five):
   value / ms_per_step   sweeps of ONE RESIDENT MODEL (the metric of BASELINE.json: device time of the whole sweep with the
@@ -21,18 +22,21 @@ What the JSON line reports (N = 1 adds the last five):
   roofline.hbm          HBM side: the set phase K3-K5 (classification, minimiser, expander transform, arg-max) --
                         SURVEY.md 8(d) bytes (2 q s + 4 per candidate) / set-phase device time, against 8.0 TB/s
                         (datasheet) and 6.29 TB/s (measured copy rate of the guide).
+  comm                  (N > 1) collectives per sweep: calls, bytes a rank sends, event-timed microseconds per call (from a few
+                        extra sweeps with option comm_events, outside the timed region).
   iteration             what ONE SafeOpt ITERATION costs: the reference refits and sweeps once per model
                         (test/test_SafeOpt.py:144-179), so here two data sets alternate and every timed step is
-                        set_model (upload + factorisation) + the per-(model, grid) table build of K1b + the sweep.
-  table_kernel          the same resident-model sweep with the O(n^2)-per-candidate kernel K1g.
-  extra                 the other BASELINE.json configs on the one GPU: H (4096^2, n = 512, SafeOpt) and C (Williams-Otto, 1024^2,
-                        n = 256, q = 3, GoOSE) with their iteration cost, D (128^4, the whole grid of the 8-GPU config), E (2 M
-                        scattered 6-D points, n = 2048, fp32 with the fp64 recheck).
-  cpu_baseline          the C + OpenMP restatement of the same sweep on the box's host cores (whole grid; `numpy`: the NumPy
-                        oracle on a bounded prefix).
+                        set_model (upload + alpha on the device; the reverse factor of the caller's invK is deferred) + the
+                        per-(model, grid) table build of K1b + the sweep.
+  table_kernel          the same resident-model sweep with the O(n^2)-per-candidate kernel K1g (on config B).
+  extra                 the other BASELINE.json configs on the one GPU: B (2048^2, n = 128; with its iteration cost and K1g figure),
+                        C (Williams-Otto, 1024^2, n = 256, q = 3: GoOSE and SafeOpt, with iteration costs), D (128^4, the whole
+                        grid of the 8-GPU config), E (10^7 scattered 6-D points, n = 2048, fp32 with the fp64 recheck).
+  cpu_baseline          the C + OpenMP restatement of the same sweep on the box's host cores (`numpy`: the NumPy
+                        oracle on a bounded prefix), on config B's grid (a bounded sample of CPU work).
 
-torch is used only as the launcher's rendezvous (gloo group: unique-id broadcast, barriers, max over
-ranks); device memory, streams and the collectives on the data path belong to libsafebo.so.
+No torch anywhere: the ranks of the launcher meet through safebo_amd.distributed.TcpGroup (stdlib sockets: unique-id
+broadcast, barriers, max over ranks); device memory, streams and the collectives on the data path belong to libsafebo.so.
 """
 from __future__ import annotations
 
@@ -61,12 +65,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="B", help="synthetic config (B = BASELINE.json configs[1]; H = 4096^2, n = 512)")
+    ap.add_argument("--config", default="H", help="synthetic config (H = 4096^2, n = 512: the north-star target's; B = BASELINE.json configs[1])")
     ap.add_argument("--n", type=int, default=None, help="override the number of observations")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="candidates timed by the CPU baseline (0 = skip)")
     ap.add_argument("--points", type=int, default=10_000_000, help="candidates per rank for the scattered config E")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: the grid's slowest axis grows with the ranks (default); strong: fixed grid, sharded")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong: fixed grid, sharded over the ranks (default); weak: the grid's slowest axis grows with the ranks")
     ap.add_argument("--posterior", choices=["auto", "table"], default="auto",
                     help="auto: fp64 2-D grids use the bilinear GEMM posterior (K1b) when its bases qualify; "
                          "table: force the separable-table kernel (K1g), the O(n^2)-per-candidate contraction")
@@ -249,11 +253,34 @@ def make_configs(name, n=None):
     return cfg, alt
 
 
-def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None):
-    """Resident-model sweep rate (+ iteration cost for the 2-D grids) of another single-GPU config, same process.
-    ``points``: size of the explicit candidate list of a scattered config (E)."""
+def max_over_ranks(group, x):
+    return float(group.all_reduce(np.array([x], dtype=np.float64), "max")[0]) if group is not None else x
+
+
+def comm_record(eng, step, transport):
+    """Collectives of one sweep on this rank: calls, bytes handed over, event-timed microseconds (three extra sweeps with an
+    event pair around every collective -- option comm_events -- outside the timed region: the pairs cost bubbles)."""
+    eng.set_option("comm_events", 1)
+    rows = []
+    for _ in range(3):
+        step()
+        rows.append(eng.profile())
+    eng.set_option("comm_events", 0)
+    calls = int(rows[-1]["comm_calls"])
+    ms = float(np.mean([p["comm_ms"] for p in rows]))
+    return {"transport": transport, "collectives_per_sweep": calls, "bytes_sent_per_rank": int(rows[-1]["comm_bytes"]),
+            "us_per_sweep": ms * 1e3, "us_per_collective": ms * 1e3 / calls if calls else 0.0, "host_syncs_per_sweep": int(rows[-1]["host_syncs"]),
+            "definition": "event pairs around every RCCL call of a sweep on the library's stream (rank 0); for the host relay of one-GPU "
+                          "rehearsals the wall clock of the staged calls"}
+
+
+def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None, group=None, table_kernel=False, transport="none"):
+    """Resident-model sweep rate (+ iteration cost for the 2-D grids) of another config, same process.  ``points``: size of the
+    explicit candidate list of a scattered config (E).  ``group``: the ranks of an N > 1 run -- the grid is then sharded over
+    them (strong scaling) and the time is the slowest rank's."""
     from safebo_amd import synthetic
     use_invK = cfg["dtype"] == "f64"
+    world = group.get_world_size() if group is not None else 1
     eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=use_invK)
     if cfg["count"] is None:
         n_total = int(points)
@@ -262,26 +289,42 @@ def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None):
     else:
         count = list(cfg["count"])
         n_total = int(np.prod(count))
-        eng.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
-        where = f"implicit grid {'x'.join(map(str, count))} ({n_total} candidates)"
+        if group is not None:
+            eng.set_grid_sharded(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+        else:
+            eng.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+        where = f"implicit grid {'x'.join(map(str, count))} ({n_total} candidates" + (f", sharded over {world} ranks)" if group is not None else ")")
     step = sweep_fn(eng, kind, cfg["b"])
     el, rows, res = timed_resident(eng, step, steps, max(1, steps // 5), barrier)
-    mf, _ = mfma_roofline(cfg, rows, n_total)
+    el = max_over_ranks(group, el)
+    mf, _ = mfma_roofline(cfg, rows, n_total // world)
     out = {"config": f"config {name}: {cfg['plant']} {cfg['d']}-D {kind} sweep, {where}, n={cfg['n']}, q={cfg['q']}, b={cfg['b']}, {cfg['dtype']}",
            "sweep": kind, "value": n_total * steps / el, "unit": "candidates/s", "steps": steps, "ms_per_step": el * 1e3 / steps,
            "roofline": {k: mf[k] for k in ("achieved", "peak", "frac", "kernel", "kernel_ms", "device_ms_per_step", "frac_definition")},
-           "roofline_hbm": hbm_roofline(cfg["q"], 8 if cfg["dtype"] == "f64" else 4, n_total, rows)}
+           "roofline_hbm": hbm_roofline(cfg["q"], 8 if cfg["dtype"] == "f64" else 4, n_total // world, rows)}
+    if group is not None:
+        out["n_gpus"], out["scaling"] = world, "strong"
+        out["comm"] = comm_record(eng, step, transport)
     out["roofline"]["executed_frac"] = mf["executed"]["frac"]
     out["roofline"]["algorithmic_frac"] = mf["algorithmic"]["frac"]
     if cfg["dtype"] == "f32":
         out["fp64_recheck"] = {"candidates_reevaluated": int(rows[-1]["fp64_rechecks"]), "ms": float(np.mean([p["recheck_ms"] for p in rows])),
                                "note": "fp32 posterior; candidates its bounds cannot decide are re-evaluated in fp64 so that the masks "
                                        "equal the fp64 result"}
-    if alt is not None and cfg["count"] is not None and cfg["d"] == 2:
+    if alt is not None and cfg["count"] is not None and cfg["d"] == 2 and group is None:
         it = timed_iterations(eng, [alt["ds"], cfg["ds"]], cfg["dtype"], step, max(4, steps // 3), 2, barrier)
         it["value"] = n_total / (it["ms_per_step"] * 1e-3)
         it["unit"] = "candidates/s"
         out["iteration"] = it
+    if table_kernel and mf["kernel"].startswith("k_bpost"):
+        # the same sweep with the separable-table kernel (the O(n^2)-per-candidate contraction on MFMA), same run
+        eng.set_option("bilinear", 0)
+        el_t, rows_t, _ = timed_resident(eng, step, 5, 2, barrier)
+        eng.set_option("bilinear", 1)
+        rt, _ = mfma_roofline(cfg, rows_t, n_total)
+        out["table_kernel"] = {"kernel": "k_posterior_grid", "device_ms_per_step": rt["device_ms_per_step"], "kernel_ms": rt["kernel_ms"],
+                               "value": n_total * 5 / el_t, "unit": "candidates/s", "achieved": rt["algorithmic"]["achieved"],
+                               "frac": rt["algorithmic"]["frac"], "frac_definition": "SURVEY.md 8(d) algorithmic flops / kernel time / peak"}
     if kind == "safeopt":
         out["result"] = {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
                          "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}
@@ -303,17 +346,19 @@ def main():
 
     import safebo_amd
     from safebo_amd import synthetic
-    safebo_amd._lib.load()        # libsafebo.so (and the RCCL it is linked against) before torch maps its own copy
+    safebo_amd._lib.load()        # libsafebo.so (and the RCCL it is linked against)
 
-    dist = None
+    group = None
     if world > 1:
         from safebo_amd import distributed
-        dist = distributed.init_gloo_from_env()   # rendezvous only (gloo over 127.0.0.1)
+        group = distributed.init_from_env()       # stdlib TCP rendezvous among the launcher's ranks (no torch)
 
     cfg, alt = make_configs(args.config, n=args.n)
     scattered = cfg["count"] is None                      # config E: explicit list of scattered candidates
+    default_run = args.config == "H" and args.n is None and args.sweep == "safeopt" and args.posterior == "auto"
     extras = world == 1 and not args.no_extra and not scattered
-    extra_cfgs = {name: make_configs(name) for name in (("H", "C", "D", "E") if extras and args.config == "B" else ())}
+    extra_cfgs = {name: make_configs(name) for name in (("B", "C", "D", "E") if extras and default_run else ())}
+    dcfg = make_configs("D")[0] if (world > 1 and not args.no_extra and default_run and args.scaling == "strong") else None
     if scattered:
         per_rank = args.points if args.scaling == "weak" else args.points // world
         n_total = per_rank * world
@@ -333,9 +378,9 @@ def main():
     transport = "none"
     if world > 1:
         # RCCL (unique id broadcast from rank 0).  Only a one-GPU rehearsal of the N > 1 plumbing (SBO_BENCH_DEVICE pins
-        # every rank to one card, which RCCL refuses) may fall back to the gloo relay; ranks on distinct devices that
+        # every rank to one card, which RCCL refuses) may fall back to the host relay; ranks on distinct devices that
         # cannot form the communicator fail the run.
-        transport = distributed.join_with_fallback(eng, allow_relay="SBO_BENCH_DEVICE" in os.environ)
+        transport = distributed.join_with_fallback(eng, group, allow_relay="SBO_BENCH_DEVICE" in os.environ)
     eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=(cfg["dtype"] == "f64"))
     if scattered:
         pts = synthetic.scattered_points(cfg, n_total)[rank * per_rank:(rank + 1) * per_rank]
@@ -345,19 +390,18 @@ def main():
 
     def barrier():
         eng.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if group is not None:
+            group.barrier()
         eng.synchronize()
 
     step = sweep_fn(eng, args.sweep, cfg["b"])
     if args.posterior == "table":
         eng.set_option("bilinear", 0)
     elapsed, rows, res = timed_resident(eng, step, args.steps, args.warmup, barrier)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = max_over_ranks(group, elapsed)
+    comm = comm_record(eng, step, transport) if world > 1 else None
+    # N > 1: config D (BASELINE.json configs[3]) strong-scaled over the same ranks, every rank takes part
+    d_rec = extra_record(eng, dcfg, None, "D", "safeopt", 3, barrier, group=group, transport=transport) if dcfg is not None else None
 
     if rank == 0:
         n_local = n_total // world
@@ -367,7 +411,7 @@ def main():
         # HBM bytes of the K1 launch(es) are NOT measured by this run: they come from separate rocprofv3 --pmc passes of the
         # same command (tools/gpu_bench_profile.sh), committed with the kernel they belong to; null when no record matches
         roof["traffic"], roof["traffic_source"] = None, None
-        if os.path.exists(PMC_TRAFFIC_FILE):
+        if os.path.exists(PMC_TRAFFIC_FILE) and world == 1:
             key = f"{args.config}:n={cfg['ds']['X_norm'].shape[0]}" + (":K1b" if k1_kind == 4 else "")
             rec = json.load(open(PMC_TRAFFIC_FILE)).get(key)
             if rec:
@@ -388,10 +432,15 @@ def main():
             "config": {"workload": f"config {args.config}: {cfg['plant']} {cfg['d']}-D {args.sweep} sweep of one RESIDENT model, "
                                    + (f"explicit list of {n_total} scattered candidates" if scattered else
                                       f"implicit grid {'x'.join(str(c) for c in count)} ({n_total} candidates)")
-                                   + f", n={cfg['ds']['X_norm'].shape[0]} observations, q={cfg['q']} outputs, b={cfg['b']}",
+                                   + f", n={cfg['ds']['X_norm'].shape[0]} observations, q={cfg['q']} outputs, b={cfg['b']}"
+                                   + (f", sharded over {world} ranks by rows of the slowest axis" if world > 1 else ""),
                        "per_gpu_candidates": n_local, "sweep": args.sweep, "collectives": transport, "result": result},
             "roofline": roof,
         }
+        if comm is not None:
+            out["comm"] = comm
+        if d_rec is not None:
+            out["extra"] = [d_rec]
         if extras:
             it = timed_iterations(eng, [alt["ds"], cfg["ds"]], cfg["dtype"], step, max(10, args.steps // 4), 4, barrier)
             it["value"] = n_total / (it["ms_per_step"] * 1e-3)
@@ -399,28 +448,24 @@ def main():
             out["iteration"] = it
             if k1_kind == 4:
                 roof["table_build_ms"] = it["table_build_ms"]
-        if extras and k1_kind == 4:
-            # the same sweep with the separable-table kernel (the O(n^2)-per-candidate contraction on MFMA), same run
-            eng.set_option("bilinear", 0)
-            el_t, rows_t, _ = timed_resident(eng, step, 5, 2, barrier)
-            eng.set_option("bilinear", 1)
-            rt, _ = mfma_roofline(cfg, rows_t, n_local)
-            out["table_kernel"] = {"kernel": "k_posterior_grid", "device_ms_per_step": rt["device_ms_per_step"], "kernel_ms": rt["kernel_ms"],
-                                   "value": n_total * 5 / el_t, "unit": "candidates/s", "achieved": rt["algorithmic"]["achieved"],
-                                   "frac": rt["algorithmic"]["frac"], "frac_definition": "SURVEY.md 8(d) algorithmic flops / kernel time / peak"}
-        if extras and args.config == "B":
-            # every other BASELINE.json config on this one GPU: H (headline target shape), C (GoOSE on the Williams-Otto plant),
-            # D (the whole 128^4 grid of the 8-GPU config, O(n^2) kernel K1g: 4 sweeps), E (2 M of the 10^7 scattered fp32 points)
-            out["extra"] = [extra_record(eng, *extra_cfgs["H"], "H", "safeopt", 40, barrier),
+        if extras and default_run:
+            # every other BASELINE.json config on this one GPU: B (configs[1], with its K1g figure), C (the Williams-Otto plant: GoOSE
+            # and SafeOpt), D (the whole 128^4 grid of the 8-GPU config, O(n^2) kernel K1g: 4 sweeps), E (10^7 scattered fp32 points)
+            out["extra"] = [extra_record(eng, *extra_cfgs["B"], "B", "safeopt", 100, barrier, table_kernel=True),
                             extra_record(eng, *extra_cfgs["C"], "C", "goose", 40, barrier),
+                            extra_record(eng, *extra_cfgs["C"], "C", "safeopt", 40, barrier),
                             extra_record(eng, extra_cfgs["D"][0], None, "D", "safeopt", 4, barrier),
-                            extra_record(eng, extra_cfgs["E"][0], None, "E", "safeopt", 4, barrier, points=2_000_000)]
+                            extra_record(eng, extra_cfgs["E"][0], None, "E", "safeopt", 3, barrier, points=10_000_000)]
         if world == 1 and args.cpu_sample > 0 and not scattered:
-            out["cpu_baseline"] = cpu_baseline(cfg, count, args.cpu_sample)
+            # (a bounded sample of CPU work: config B's grid -- a quarter of H's candidates at a sixteenth of its flops per candidate)
+            ccfg = extra_cfgs["B"][0] if "B" in extra_cfgs else cfg
+            ccount = list(ccfg["count"])
+            out["cpu_baseline"] = cpu_baseline(ccfg, ccount, args.cpu_sample)
+            out["cpu_baseline"]["config"] = f"config {'B' if 'B' in extra_cfgs else args.config}: n={ccfg['n']}, grid {'x'.join(map(str, ccount))}"
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if group is not None:
+        group.barrier()
+        group.destroy()
     eng.close()
 
 

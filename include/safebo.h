@@ -139,7 +139,7 @@ typedef struct sbo_profile {
                               ride in the expander's first launches and are counted there)  (these three: 0 unless option */
   double expander_ms;      /* K4: distance transform + G_c / O_c decisions  "phase_events" is 1 -- an event  */
   double argreduce_ms;     /* K5: masked arg-max / arg-min                   costs a ~6 us bubble per record) */
-  double comm_ms;          /* RCCL collectives                                                             */
+  double comm_ms;          /* RCCL collectives (option "comm_events": an event pair around every call -- bubbles, so off by default) */
   double total_ms;         /* first launch to last completion                                              */
   double posterior_flops;  /* algorithmic flops of the K1 launch(es): q (n^2 + (2d+10) n) per candidate    */
   int64_t candidates;      /* candidates swept by this rank                                                */
@@ -156,6 +156,9 @@ typedef struct sbo_profile {
   double set_exposed_ms;         /* K1 stop event (the objective's launch) -> end of the sweep: what the set phase adds to K1     */
   int32_t k1_split;              /* 1: the last sweep ran overlapped                                                              */
   int32_t host_syncs;            /* host waits on the device inside the last sweep call (1 = the result read-back only)          */
+  int64_t comm_bytes;            /* multi-rank sweeps: bytes this rank handed to the collectives of the last sweep (send side)     */
+  int32_t comm_calls;            /* collectives of the last sweep; comm_ms is their event-timed sum when option "comm_events" is 1 */
+  int32_t reserved2;
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */

@@ -69,6 +69,7 @@ class Profile(C.Structure):
         ("posterior_kernel", C.c_int32), ("posterior_executed_flops", C.c_double), ("posterior_setup_ms", C.c_double),
         ("fp64_rechecks", C.c_int64), ("recheck_ms", C.c_double),
         ("set_chain_ms", C.c_double), ("set_exposed_ms", C.c_double), ("k1_split", C.c_int32), ("host_syncs", C.c_int32),
+        ("comm_bytes", C.c_int64), ("comm_calls", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 

@@ -60,6 +60,10 @@ void drain_streams(sbo_ctx* c) {
 // The reverse Cholesky factor of a caller's invK may still be in the making (sbo_ctx::factor_pending): every consumer of
 // Fpk / Fplain waits here first.  The positive-definiteness verdict arrives with it.
 int factor_sync(sbo_ctx* c) {
+  if (c->factor_todo) {                   // (not even enqueued: a model change that failed half-way)
+    const int rc = model_factor_enqueue(c);
+    if (rc) return rc;
+  }
   if (!c->factor_pending) return SBO_OK;
   SBO_HIP(hipEventSynchronize(c->ev_factor));
   c->factor_pending = false;
@@ -237,6 +241,21 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "k1_wgs_per_cu")) {
     if (value < 0 || value > 64) return fail(SBO_E_INVALID, "k1_wgs_per_cu out of range");
     c->k1_wgs_per_cu = (int)value;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "comm_events")) {
+    c->comm_events = value ? 1 : 0;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "table_streams")) {
+    c->table_streams = value ? 1 : 0;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "basis_reg")) {
+    c->basis_reg = value ? 1 : 0;
+    c->bl.valid = false;
+    c->bl_basis_ok = false;
+    c->posterior_valid = false;
     return SBO_OK;
   }
   if (!strcmp(key, "chol_async")) {
@@ -579,6 +598,7 @@ int sbo_posterior_run(sbo_ctx* c) {
   if ((rc = sbo_posterior_enqueue(c))) return rc;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
+  if ((rc = model_factor_enqueue(c))) return rc;           // (a deferred factor chain: enqueued while the posterior runs)
   SBO_HIP(hipEventSynchronize(c->ev[1]));
   float ms = 0;
   SBO_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));

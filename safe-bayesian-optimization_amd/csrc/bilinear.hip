@@ -371,6 +371,124 @@ __device__ __forceinline__ int basis_pivot_loop(int n, int rc, double* res, doub
   return r;
 }
 
+// The same loop with the residual rows in REGISTERS (r03): two threads per row, each holding half of its rc coefficients
+// (rc = 32 / 48 / 64, n <= NT / 2).  A step of the loop above re-reads and re-writes every residual row through LDS (n <= 128)
+// or global memory (n > 128: 13 us per step at n = 512, 22 steps); here the pivot row is published once to LDS and every
+// thread updates its own registers -- the step is left with the barriers of the re-orthogonalisation.  Same algorithm and
+// stopping rules; sums are grouped differently (per half row), which moves U by a few ulp.
+template <int NT, int RCH>
+__device__ __forceinline__ int basis_pivot_loop_reg(int n, const double* __restrict__ resG, double* Q, double* __restrict__ U, double* qv, double* cf,
+                                                    double* red, int* redi, bool& too_large, double& fro2_out) {
+  constexpr int rc = 2 * RCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = tid >> 1, half = tid & 1;
+  const bool row = j < n;
+  double rr[RCH];
+#pragma unroll
+  for (int k = 0; k < RCH; ++k) rr[k] = row ? resG[(size_t)(half * RCH + k) * n + j] : 0.0;
+  auto row_norm = [&]() {
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < RCH; k += 4) { n0 += rr[k] * rr[k]; n1 += rr[k + 1] * rr[k + 1]; n2 += rr[k + 2] * rr[k + 2]; n3 += rr[k + 3] * rr[k + 3]; }
+    double nn = (n0 + n1) + (n2 + n3);
+    nn += __shfl_xor(nn, 1);
+    return nn;
+  };
+  double nn = row_norm();
+  const double fro2 = bl_block_sum<NT>((row && half == 0) ? nn : 0.0, red);
+  fro2_out = fro2;
+  __syncthreads();
+  const double tol2 = (2e-16 * 2e-16) * fro2;
+  const int rmax = rc < n ? rc : n;
+  int r = 0;
+  too_large = false;
+  double bv = (row && half == 0) ? nn : -1.0;
+  int bi = (row && half == 0) ? j : 0x7fffffff;
+  for (;;) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double yv = __shfl_xor(bv, o);
+      const int yi = __shfl_xor(bi, o);
+      if (yv > bv || (yv == bv && yi < bi)) { bv = yv; bi = yi; }
+    }
+    if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    bv = red[0];
+    bi = redi[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w)
+      if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
+    if (!(bv > tol2) || r >= rmax) break;
+    if (r >= kBlMaxR) { too_large = true; break; }
+    const double inv0 = 1.0 / sqrt(bv);
+    if (j == bi) {
+#pragma unroll
+      for (int k = 0; k < RCH; ++k) qv[half * RCH + k] = rr[k] * inv0;
+    }
+    __syncthreads();
+    double mine = 0.0, nq = 1.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i = tid >> 4; i < r; i += NT / 16) {              // 16 lanes per previous direction
+        double s_ = 0.0;
+        for (int cidx = tid & 15; cidx < rc; cidx += 16) s_ += Q[(size_t)i * rc + cidx] * qv[cidx];
+        s_ += __shfl_xor(s_, 8);
+        s_ += __shfl_xor(s_, 4);
+        s_ += __shfl_xor(s_, 2);
+        s_ += __shfl_xor(s_, 1);
+        if ((tid & 15) == 0) cf[i] = s_;
+      }
+      __syncthreads();
+      if (tid < rc) {
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        int i = 0;
+        for (; i + 3 < r; i += 4) {
+          p0 += cf[i] * Q[(size_t)i * rc + tid];
+          p1 += cf[i + 1] * Q[(size_t)(i + 1) * rc + tid];
+          p2 += cf[i + 2] * Q[(size_t)(i + 2) * rc + tid];
+          p3 += cf[i + 3] * Q[(size_t)(i + 3) * rc + tid];
+        }
+        for (; i < r; ++i) p0 += cf[i] * Q[(size_t)i * rc + tid];
+        mine = qv[tid] - ((p0 + p1) + (p2 + p3));
+      }
+      if (pass == 0) {
+        __syncthreads();                                         // (everyone has read qv / cf of this pass)
+        if (tid < rc) qv[tid] = mine;
+        __syncthreads();
+      } else {
+        nq = bl_block_sum<NT>(tid < rc ? mine * mine : 0.0, red);
+      }
+    }
+    if (nq < 0.25) break;                                  // mostly rounding of rows already covered: nothing left to add
+    if (tid < rc) {
+      mine /= sqrt(nq);
+      qv[tid] = mine;
+      Q[(size_t)r * rc + tid] = mine;
+    }
+    __syncthreads();
+    // residual rows in registers: d_j = res_j . q (= U_j,r), res_j -= d_j q, norms recomputed from the updated rows
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+    const double* qh = qv + half * RCH;
+#pragma unroll
+    for (int k = 0; k < RCH; k += 4) {
+      d0 += rr[k] * qh[k];
+      d1 += rr[k + 1] * qh[k + 1];
+      d2 += rr[k + 2] * qh[k + 2];
+      d3 += rr[k + 3] * qh[k + 3];
+    }
+    double d_ = (d0 + d1) + (d2 + d3);
+    d_ += __shfl_xor(d_, 1);
+    if (row && half == 0) U[(size_t)r * n + j] = d_;
+#pragma unroll
+    for (int k = 0; k < RCH; ++k) rr[k] -= d_ * qh[k];
+    nn = row_norm();
+    bv = (row && half == 0) ? nn : -1.0;
+    bi = (row && half == 0) ? j : 0x7fffffff;
+    ++r;
+    __syncthreads();                                       // (red / redi / qv are rewritten by the next step)
+  }
+  return r;
+}
+
 // ---- front end of the bases, spread over the chip -------------------------------------------------------------------------
 // k_bl_basis is one workgroup per (output, axis): its pivot loop is sequential by nature, but the two passes in front of it
 // (Chebyshev samples + degree test, all coefficients) are not, and on a single CU they took 54 of config B's 182 us and 184
@@ -480,7 +598,8 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
                                                  double* __restrict__ sigout, int* __restrict__ info,
                                                  long long* __restrict__ dbg /* nullptr, or 80 time stamps of job 0 */,
                                                  const int* __restrict__ rc_pre /* nullptr, or the degree per job from k_bl_degree
-                                                                                    (its coefficient rows are in the workspace) */) {
+                                                                                    (its coefficient rows are in the workspace) */,
+                                                 int no_reg /* 1: never the register form of the pivot loop (A/B) */) {
   extern __shared__ double bl_dyn[];          // [kBasisQLds directions | kBasisResLds samples / residual rows (LDSRES)]
   __shared__ double ct[4 * kBlMaxRc];        // cos(pi m / (2 rc)), m < 4 rc
   __shared__ double qv[kBlMaxRc];            // the direction being built
@@ -497,15 +616,17 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
   double* QG = resG + (size_t)n * kBlMaxRc;                                // directions (global form, rc > 64)
   int* inf = info + 4 * job;
   int rc = 0;
-  bool ok = false, out_of_lds = false;
+  bool ok = false, out_of_lds = false, regpath = false;
   int ndbg = 0;
   auto stamp = [&]() { if (dbg && job == 0 && tid == 0 && ndbg < 80) dbg[ndbg++] = wall_clock64(); };
   stamp();
   if (rc_pre) {
     rc = rc_pre[job];
     ok = rc > 0 && rc <= kBlMaxRc;
-    if (ok && LDSRES && rc * n > kBasisResLds) { ok = false; out_of_lds = true; }
-    if (ok && LDSRES) {                                            // the rows move from the workspace into LDS
+    // rows in registers, two threads per row (the 1024-thread form has 128 registers per thread: degree 64 would spill)
+    regpath = ok && n <= NT / 2 && (rc == 32 || rc == 48 || (rc == 64 && NT <= 256)) && !no_reg;
+    if (ok && LDSRES && !regpath && rc * n > kBasisResLds) { ok = false; out_of_lds = true; }
+    if (ok && LDSRES && !regpath) {                                // the rows move from the workspace into LDS
       for (int w = tid; w < rc * n; w += NT) (bl_dyn + kBasisQLds)[w] = resG[w];
     }
     __syncthreads();
@@ -597,6 +718,17 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
     }
   }
   __syncthreads();
+  double* U = Uout + (size_t)job * kBlMaxR * n;
+  bool too_large = false;
+  int r;
+  if (regpath) {
+    double fro2r = 0.0;
+    if (rc == 32) r = basis_pivot_loop_reg<NT, 16>(n, resG, bl_dyn, U, qv, cf, red, redi, too_large, fro2r);
+    else if (rc == 48) r = basis_pivot_loop_reg<NT, 24>(n, resG, bl_dyn, U, qv, cf, red, redi, too_large, fro2r);
+    else if constexpr (NT <= 256) r = basis_pivot_loop_reg<NT, 32>(n, resG, bl_dyn, U, qv, cf, red, redi, too_large, fro2r);
+    else r = 0;
+    stamp();
+  } else {
   double fro2 = 0.0;
   for (int j = tid; j < n; j += NT) {
     double s_ = 0.0;
@@ -608,13 +740,11 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
   __syncthreads();
   const double tol2 = (2e-16 * 2e-16) * fro2;
   stamp();
-  double* U = Uout + (size_t)job * kBlMaxR * n;
-  bool too_large = false;
-  int r;
   if (rc <= 64)
     r = basis_pivot_loop<NT>(n, rc, res, bl_dyn, U, tol2, nrm2, qv, cf, red, redi, too_large, stamp);
   else
     r = basis_pivot_loop<NT>(n, rc, res, QG, U, tol2, nrm2, qv, cf, red, redi, too_large, stamp);
+  }
   if (too_large || r < 1) {
     if (tid == 0) { inf[0] = 0; inf[1] = r; inf[2] = rc; inf[3] = 0; }
     return;
@@ -1257,11 +1387,11 @@ int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big) {
       if (small) {
         SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL((k_bl_basis<256, true>), dim3((unsigned)(2 * q)), dim3(256), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
-                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob);
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, c->basis_reg ? 0 : 1);
       } else {
         SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL((k_bl_basis<1024, false>), dim3((unsigned)(2 * q)), dim3(1024), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
-                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob);
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, c->basis_reg ? 0 : 1);
       }
     }
     SBO_HIP(hipGetLastError());
@@ -1392,11 +1522,31 @@ int bilinear_setup(sbo_ctx* c) {
   double* G = CtA + (size_t)q * nZf;
   auto blocks = [&](size_t total, unsigned y) { return dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16), y); };
   const unsigned uq = (unsigned)q;
-  hipLaunchKernelGGL(k_bl_axes, dim3((unsigned)std::min<long long>((cnt0 + nlines + 255) / 256, 4096)), dim3(256), 0, c->stream, mc, cs,
+  // Two independent chains (r03): X = the form T4 of the variance phase (Z fragments -> two GEMMs -> gather: the long one,
+  // ~0.11 ms on config H), Y = everything made from the axis tables (normalised axes, S0 / S1, their pair tables, the mean
+  // phases' operands: eight small launches, ~0.09 ms).  Y runs on the second stream beside X and joins before stage 1.
+  hipStream_t xs = c->stream, ys = (c->table_streams && c->stream2 && !c->is_shadow) ? c->stream2 : c->stream;
+  if (ys != xs) {
+    SBO_HIP(hipEventRecord(c->ev[7], xs));                 // (alpha, Xn and the bases are in place at this point of the main stream)
+    SBO_HIP(hipStreamWaitEvent(ys, c->ev[7], 0));
+  }
+  hipLaunchKernelGGL(k_bl_axes, dim3((unsigned)std::min<long long>((cnt0 + nlines + 255) / 256, 4096)), dim3(256), 0, ys, mc, cs,
                      cnt0, line0, nlines, dxn0, dxn1);
-  hipLaunchKernelGGL(k_bl_stab, blocks((size_t)std::max(r0u * cnt0, r1u * nlines), 2 * uq), dim3(256), 0, c->stream, dm, dVs, dsig,
+  hipLaunchKernelGGL(k_bl_stab, blocks((size_t)std::max(r0u * cnt0, r1u * nlines), 2 * uq), dim3(256), 0, ys, dm, dVs, dsig,
                      (const double*)dxn0, (const double*)dxn1, dS0, dS1);
-  hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, c->stream, dm, dU, nZf, Zf);
+  hipLaunchKernelGGL((k_bl_pairs<1>), blocks(pl.sP0f, uq), dim3(256), 0, ys, dm, (const double*)dS0, pl.sP0f, (double*)c->bl_P0f.p);
+  hipLaunchKernelGGL((k_bl_pairs<0>), blocks(pl.sP1A, uq), dim3(256), 0, ys, dm, (const double*)dS1, pl.sP1A, (double*)c->bl_P1A.p);
+  // mean phases: Mb (forms of alpha, alpha Xn_0, alpha Xn_1) -> Vb = Mb S1 -> A images [V0 | V1;V0 | V1x], B fragments
+  // [S0 | S0;-xn0 S0]
+  hipLaunchKernelGGL(k_bl_mb, blocks((size_t)3 * r0u * r1u * 64, uq), dim3(256), 0, ys, dm, dU, (const double*)c->alpha64.p,
+                     c->a_ld, (const double*)c->Xn.p, mc.dpad, dMb);
+  hipLaunchKernelGGL(k_bl_vb, blocks((size_t)3 * r0u * nlines, uq), dim3(256), 0, ys, dm, (const double*)dMb, (const double*)dS1, dVb);
+  hipLaunchKernelGGL(k_bl_va, blocks(pl.sVA, uq), dim3(256), 0, ys, dm, (const double*)dVb, (const double*)dxn1, pl.sVA,
+                     (double*)c->bl_VA.p);
+  hipLaunchKernelGGL(k_bl_sbf, blocks(pl.sSBf, uq), dim3(256), 0, ys, dm, (const double*)dS0, (const double*)dxn0, pl.sSBf,
+                     (double*)c->bl_SBf.p);
+  if (ys != xs) SBO_HIP(hipEventRecord(c->ev_join[3], ys));
+  hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, xs, dm, dU, nZf, Zf);
   // G = Z^T invK Z.  With the library's own Cholesky factor (M = L^-1): C = M Z from the packed triangular images, written as
   // fragments (k = observation) and as images of C^T, then G = C^T C.  With a CALLER's invK (sbo_ctx::invk_img, r03): W =
   // invK Z with the matrix as given -- the contraction the reference itself performs, models/GP_Safe.py:341-343, no
@@ -1417,17 +1567,7 @@ int bilinear_setup(sbo_ctx* c) {
   }
   hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f, uq), dim3(256), 0, c->stream, dm, (const double*)G, (long long)ldg, pl.sT4f,
                      (double*)c->bl_T4f.p, direct ? 1 : 0);
-  hipLaunchKernelGGL((k_bl_pairs<1>), blocks(pl.sP0f, uq), dim3(256), 0, c->stream, dm, (const double*)dS0, pl.sP0f, (double*)c->bl_P0f.p);
-  hipLaunchKernelGGL((k_bl_pairs<0>), blocks(pl.sP1A, uq), dim3(256), 0, c->stream, dm, (const double*)dS1, pl.sP1A, (double*)c->bl_P1A.p);
-  // mean phases: Mb (forms of alpha, alpha Xn_0, alpha Xn_1) -> Vb = Mb S1 -> A images [V0 | V1;V0 | V1x], B fragments
-  // [S0 | S0;-xn0 S0]
-  hipLaunchKernelGGL(k_bl_mb, blocks((size_t)3 * r0u * r1u * 64, uq), dim3(256), 0, c->stream, dm, dU, (const double*)c->alpha64.p,
-                     c->a_ld, (const double*)c->Xn.p, mc.dpad, dMb);
-  hipLaunchKernelGGL(k_bl_vb, blocks((size_t)3 * r0u * nlines, uq), dim3(256), 0, c->stream, dm, (const double*)dMb, (const double*)dS1, dVb);
-  hipLaunchKernelGGL(k_bl_va, blocks(pl.sVA, uq), dim3(256), 0, c->stream, dm, (const double*)dVb, (const double*)dxn1, pl.sVA,
-                     (double*)c->bl_VA.p);
-  hipLaunchKernelGGL(k_bl_sbf, blocks(pl.sSBf, uq), dim3(256), 0, c->stream, dm, (const double*)dS0, (const double*)dxn0, pl.sSBf,
-                     (double*)c->bl_SBf.p);
+  if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
   SBO_HIP(hipGetLastError());
   lap("enqueue");
   pl.usable = true;       // (nothing to wait for: the tables are made in stream order ahead of the posterior kernels)

@@ -1,6 +1,7 @@
 // comm.hip -- RCCL plumbing: one process per GPU, ranks joined over xGMI with a broadcast unique id.
 // The reference has no communication layer at all; these collectives exist only
 // because the candidate set is sharded across the GPUs of a node.
+#include <chrono>
 #include <cstring>
 #include <vector>
 #include <rccl/rccl.h>
@@ -15,6 +16,29 @@ static int nccl_fail(ncclResult_t r, const char* what) {
     ncclResult_t r__ = (x);                                \
     if (r__ != ncclSuccess) return sbo::nccl_fail(r__, #x); \
   } while (0)
+
+// accounting of one collective (sbo_profile.comm_*): bytes on the send side, and with option comm_events an event pair
+struct CommScope {
+  sbo_ctx* c;
+  int slot = -1;
+  std::chrono::steady_clock::time_point t0;
+  CommScope(sbo_ctx* c_, size_t bytes) : c(c_) {
+    c->comm_bytes += (long long)bytes;
+    ++c->comm_calls;
+    t0 = std::chrono::steady_clock::now();
+    if (c->comm_events && c->comm && c->comm_nev + 2 <= 16) {
+      slot = c->comm_nev;
+      c->comm_nev += 2;
+      for (int k = 0; k < 2; ++k)
+        if (!c->comm_ev[slot + k] && hipEventCreate(&c->comm_ev[slot + k]) != hipSuccess) slot = -1;
+      if (slot >= 0) (void)hipEventRecord(c->comm_ev[slot], c->stream);
+    }
+  }
+  ~CommScope() {
+    if (slot >= 0) (void)hipEventRecord(c->comm_ev[slot + 1], c->stream);
+    if (!c->comm) c->comm_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
 
 // host-staged collective for the rehearsal transport
 static int relay_reduce(sbo_ctx* c, void* dev, size_t count, int elem, int op) {
@@ -32,24 +56,28 @@ static int relay_reduce(sbo_ctx* c, void* dev, size_t count, int elem, int op) {
 // in-place all-reduce helpers used by the sweeps (no-ops for a single rank)
 int comm_allreduce_max_u64(sbo_ctx* c, unsigned long long* dev, int count) {
   if (!multi_rank(c)) return SBO_OK;
+  CommScope cs_(c, sizeof(unsigned long long) * (size_t)count);
   if (!c->comm) return relay_reduce(c, dev, count, 0, 1);
   SBO_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclMax, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
 int comm_allreduce_min_u64(sbo_ctx* c, unsigned long long* dev, int count) {
   if (!multi_rank(c)) return SBO_OK;
+  CommScope cs_(c, sizeof(unsigned long long) * (size_t)count);
   if (!c->comm) return relay_reduce(c, dev, count, 0, 2);
   SBO_NCCL(ncclAllReduce(dev, dev, count, ncclUint64, ncclMin, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
 int comm_allreduce_sum_f64(sbo_ctx* c, double* dev, int count) {
   if (!multi_rank(c)) return SBO_OK;
+  CommScope cs_(c, sizeof(double) * (size_t)count);
   if (!c->comm) return relay_reduce(c, dev, count, 1, 0);
   SBO_NCCL(ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
   return SBO_OK;
 }
 int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_per_rank) {
   if (!multi_rank(c)) return SBO_OK;
+  CommScope cs_(c, bytes_per_rank);
   if (!c->comm) {
     if (!c->relay_allgather) return fail(SBO_E_COMM, "no transport: neither an RCCL communicator nor relay callbacks are installed");
     std::vector<unsigned char> hs(bytes_per_rank), hr(bytes_per_rank * c->world);
@@ -138,6 +166,9 @@ int sbo_comm_barrier(sbo_ctx* c) {
 }
 
 int sbo_comm_destroy_internal(sbo_ctx* c) {
+  if (c)
+    for (auto& ev : c->comm_ev)
+      if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
   if (c && c->comm) {
     ncclCommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;

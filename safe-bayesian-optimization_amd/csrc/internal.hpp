@@ -89,9 +89,12 @@ struct sbo_ctx {
   // needs it calls factor_sync first, which also delivers the positive-definiteness verdict
   sbo::DevBuf invk_img;            // [q][npad / 16][npad / 16][256] A images of the full invK (fp64)
   bool invk_img_valid = false;
+  bool factor_todo = false;        // the chain has not been enqueued yet (sbo_model_set does that last: model_factor_enqueue)
   bool factor_pending = false;     // the factor chain of the current model is (possibly) still running; ev_factor marks its end
   hipEvent_t ev_factor = nullptr, ev_w = nullptr;
   int chol_async = 1;
+  int table_streams = 1;   // K1b plan build: the axis-table chain on the second stream beside the T4 GEMMs (0: one stream)
+  int basis_reg = 1;       // K1b axis bases: residual rows of the pivot loop in registers (n <= 512, degree <= 64); 0: through LDS / memory (round 2)
   sbo::BilinearPlan bl;
   sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work;
   sbo::DevBuf bl_basis;            // K1b: the 2 q axis bases (U, Chebyshev series, ranks) and the workspace of their kernel
@@ -136,6 +139,12 @@ struct sbo_ctx {
   sbo::DevBuf bl_lpart; // K1b: per-wave Lipschitz partials of k_bpost
   sbo::DevBuf cpart;   // per-workgroup partials of k_classify
   sbo::DevBuf upart;   // overlapped sweeps: per-workgroup u* keys of k_obj_front
+  long long comm_bytes = 0;   // collectives of the running sweep: bytes handed over (send side), calls, and -- option comm_events --
+  int comm_calls = 0;         // an event pair per call (comm_ev, created on first use) whose elapsed times sbo_profile.comm_ms sums
+  int comm_events = 0;
+  int comm_nev = 0;
+  double comm_host_ms = 0.0;  // (relay transport: wall clock of the staged collectives)
+  hipEvent_t comm_ev[16]{};
   int host_syncs = 0;  // host waits on the device inside the running sweep call (sbo_profile.host_syncs)
   // classification fused into the posterior (K1b, one constraint): a sweep sets fuse_request / fuse_b before it enqueues the
   // posterior; fuse_rows > 0 afterwards = the kernel wrote S / U and that many partial rows at the head of cpart
@@ -231,6 +240,7 @@ int launch_posterior(sbo_ctx* c);
 int launch_bound(sbo_ctx* c, double b, int index, int kind, void* dev_out);
 int model_build(sbo_ctx* c, const double* const* host_invK, const double* X_norm, const double* Y_norm);
 int model_prep(sbo_ctx* c, const double* X_norm);
+int model_factor_enqueue(sbo_ctx* c);   // the deferred factor chain of a caller's invK, behind everything on the critical path
 int model_append(sbo_ctx* c, const std::vector<double>& kvec /*[q][n]*/, const double* kappa, const double* rho);
 int model_repack(sbo_ctx* c);
 bool bilinear_applicable(const sbo_ctx* c);

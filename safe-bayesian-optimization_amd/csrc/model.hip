@@ -758,6 +758,65 @@ int model_prep(sbo_ctx* c, const double* X_norm) {         // (after an append: 
   return SBO_OK;
 }
 
+// The factorisation proper on stream `fs`: front end (mode 0: reversed symmetrised copy of invK -- alpha is made by the caller of
+// this function from the matrix as given --; mode 1: K from the expanded distance), the panels, the finish, the fragment images.
+template <typename T>
+static int factor_chain_enqueue(sbo_ctx* c, const ModelWork& w, int mode, hipStream_t fs) {
+  const ModelConst& mc = c->mc;
+  const int n = mc.n, npad = mc.npad, q = mc.q, nb = npad / 16;
+  const size_t nn = (size_t)n * n;
+  double* dF = (double*)c->Fplain.p;
+  double* dalpha = (double*)c->alpha64.p;
+  if (n >= kBlockedFrom) {
+    // blocked multi-workgroup factorisation: the single-workgroup loop is bound by the latency of its own updates
+    if (mode == 0) {
+      hipLaunchKernelGGL(k_invk_reverse, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), q), dim3(256), 0, fs, n,
+                         (const double*)w.W, w.work);
+    } else {
+      hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, fs, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
+                         (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha);
+    }
+    if (c->chol_fused) {
+      // one launch per panel: the pending update of the previous panel rides in the panel's own launch (k_chol_step)
+      for (int kb = 0; kb < n; kb += kPB) {
+        const int kw = std::min(kPB, n - kb);
+        const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
+        const int nA = std::max(1, ((ncols + 1) / 2 + 3) / 4);
+        const int ti = kb > 0 ? (n - kb - kw + 31) / 32 : 0;
+        const int nB = ti * ti + (mode && kb > 0 ? ((kb + 31) / 32) * ti : 0);
+        hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + nB), q), dim3(256), 0, fs, w.work, dF, mode, n, kb, nA, ti, w.bad, w.Dg);
+      }
+    } else {
+      for (int kb = 0; kb < n; kb += kPB) {
+        const int kw = std::min(kPB, n - kb);
+        const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
+        // (a half wave per column: four pairs of columns per workgroup)
+        hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, ((ncols + 1) / 2 + 3) / 4), q), dim3(256), 0, fs, w.work, dF, mode,
+                           n, kb, w.bad, w.Dg);
+        const int rest = n - kb - kw;
+        if (rest > 0) {
+          const unsigned ti = (unsigned)((rest + 31) / 32);
+          hipLaunchKernelGGL(k_chol_update, dim3(ti, ti, q), dim3(256), 0, fs, w.work, dF, 0, n, kb);
+          if (mode)
+            hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((kb + kw + 31) / 32), ti, q), dim3(256), 0, fs, w.work, dF, 1, n, kb);
+        }
+      }
+    }
+    hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, fs, mode, n, npad, (const double*)w.rhs, w.work, dF, dalpha,
+                       (const double*)w.Dg);
+  } else {
+    hipLaunchKernelGGL(k_model_build, dim3(q), dim3(1024), 0, fs, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
+                       (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha, w.bad);
+  }
+  const size_t ntri = (size_t)nb * (nb + 1) / 2;
+  // (k_pack_factor writes every element of the images, zeros included; only the over-read padding needs clearing)
+  SBO_HIP(hipMemsetAsync((T*)c->Fpk.p + (size_t)q * c->fpk_stride, 0, sizeof(T) * 512, fs));
+  hipLaunchKernelGGL((k_pack_factor<T>), dim3((unsigned)std::min<size_t>((ntri * 256 + 255) / 256, 4096), q), dim3(256), 0, fs,
+                     (const double*)dF, n, n, nn, nb, c->fpk_stride, (T*)c->Fpk.p);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
 // Device side of sbo_model_set.  host_invK may be NULL (the library factors K itself).  On success Fpk (dtype T), alpha
 // (dtype T), the derived arrays As / sqA / Xn and the fp64 factor / alpha (Fplain, alpha64: leading dimension n / npad
 // until an append grows them) are in place.  One host synchronisation, at the end (the positive-definiteness verdict);
@@ -773,6 +832,7 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
     c->factor_pending = false;
   }
   c->invk_img_valid = false;
+  c->factor_todo = false;
   ModelWork w;
   if ((rc = model_work(c, host_invK != nullptr, w))) return rc;
   if ((rc = ensure(c->Fplain, sizeof(double) * (size_t)q * nn))) return rc;
@@ -799,84 +859,58 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
   const int mode = host_invK ? 0 : 1;
   // A caller's invK on a K1b-capable grid: the GEMM posterior's tables take invK itself (k_pack_full), so the reverse
   // Cholesky factor is only needed by the O(n^2) kernels and by sbo_model_append -- it is built on stream4 and nobody waits
-  // for it here (n = 512: 16 dependent panel launches, ~0.43 ms off the critical path of a model change)
+  // for it here (n = 512: 16 dependent panel launches, ~0.43 ms off the critical path of a model change).  Its launches are
+  // not even enqueued here (the host needs ~0.1 ms for them): the next sweep does that while it waits for its own result
+  // (model_factor_enqueue), a consumer of the factor before that enqueues and waits (factor_sync), and a model replaced
+  // before anyone asked never factors at all.
   const bool deferred = mode == 0 && n >= kBlockedFrom && c->chol_async && !c->is_shadow && eager_basis && c->stream4 &&
                         std::is_same<T, double>::value;
-  hipStream_t fs = deferred ? c->stream4 : c->stream;     // the factor chain's stream
-  const double* dsf2 = nullptr;   // (sf2 / sn2 travel in the kernel arguments)
-  (void)dsf2;
-  if (n >= kBlockedFrom) {
-    // blocked multi-workgroup factorisation: the single-workgroup loop is bound by the latency of its own updates
-    if (mode == 0) {
-      hipLaunchKernelGGL(k_invk_alpha, dim3((unsigned)((n + 3) / 4), q), dim3(256), 0, c->stream, n, npad, (const double*)w.W,
-                         (const double*)w.rhs, dalpha);
-      if (deferred) {
-        if ((rc = ensure(c->invk_img, sizeof(double) * (size_t)q * npad * npad))) return rc;
-        hipLaunchKernelGGL(k_pack_full, dim3((unsigned)std::min<size_t>(((size_t)nb * nb * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
-                           (const double*)w.W, n, nb, (double*)c->invk_img.p);
-        c->invk_img_valid = true;
-        SBO_HIP(hipEventRecord(c->ev_w, c->stream));
-        SBO_HIP(hipStreamWaitEvent(fs, c->ev_w, 0));
-      }
-      hipLaunchKernelGGL(k_invk_reverse, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), q), dim3(256), 0, fs, n,
-                         (const double*)w.W, w.work);
-    } else {
-      hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
-                         (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha);
-    }
-    if (c->chol_fused) {
-      // one launch per panel: the pending update of the previous panel rides in the panel's own launch (k_chol_step)
-      for (int kb = 0; kb < n; kb += kPB) {
-        const int kw = std::min(kPB, n - kb);
-        const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
-        const int nA = std::max(1, ((ncols + 1) / 2 + 3) / 4);
-        const int ti = kb > 0 ? (n - kb - kw + 31) / 32 : 0;
-        const int nB = ti * ti + (mode && kb > 0 ? ((kb + 31) / 32) * ti : 0);
-        hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + nB), q), dim3(256), 0, fs, w.work, dF, mode, n, kb, nA, ti, w.bad, w.Dg);
-      }
-    } else {
-    for (int kb = 0; kb < n; kb += kPB) {
-        const int kw = std::min(kPB, n - kb);
-        const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
-        // (a half wave per column: four pairs of columns per workgroup)
-        hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, ((ncols + 1) / 2 + 3) / 4), q), dim3(256), 0, fs, w.work, dF, mode,
-                           n, kb, w.bad, w.Dg);
-        const int rest = n - kb - kw;
-        if (rest > 0) {
-          const unsigned ti = (unsigned)((rest + 31) / 32);
-          hipLaunchKernelGGL(k_chol_update, dim3(ti, ti, q), dim3(256), 0, fs, w.work, dF, 0, n, kb);
-          if (mode)
-            hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((kb + kw + 31) / 32), ti, q), dim3(256), 0, fs, w.work, dF, 1, n, kb);
-        }
-      }
-    }
-    hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, fs, mode, n, npad, (const double*)w.rhs, w.work, dF, dalpha,
-                       (const double*)w.Dg);
-  } else {
-    hipLaunchKernelGGL(k_model_build, dim3(q), dim3(1024), 0, c->stream, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
-                       (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha, w.bad);
-  }
   const size_t ntri = (size_t)nb * (nb + 1) / 2;
   c->fpk_stride = ntri * 4 * 64;
   if ((rc = ensure(c->Fpk, sizeof(T) * ((size_t)q * c->fpk_stride + 512)))) return rc;   // + padding: the K1g pipeline over-reads
-  // (k_pack_factor writes every element of the images, zeros included; only the over-read padding needs clearing)
-  SBO_HIP(hipMemsetAsync((T*)c->Fpk.p + (size_t)q * c->fpk_stride, 0, sizeof(T) * 512, fs));
-  hipLaunchKernelGGL((k_pack_factor<T>), dim3((unsigned)std::min<size_t>((ntri * 256 + 255) / 256, 4096), q), dim3(256), 0, fs,
-                     (const double*)dF, n, n, nn, nb, c->fpk_stride, (T*)c->Fpk.p);
   if ((rc = ensure(c->alpha, sizeof(T) * (size_t)q * npad))) return rc;
+  if (n >= kBlockedFrom && mode == 0) {
+    hipLaunchKernelGGL(k_invk_alpha, dim3((unsigned)((n + 3) / 4), q), dim3(256), 0, c->stream, n, npad, (const double*)w.W,
+                       (const double*)w.rhs, dalpha);
+    if (deferred) {
+      if ((rc = ensure(c->invk_img, sizeof(double) * (size_t)q * npad * npad))) return rc;
+      hipLaunchKernelGGL(k_pack_full, dim3((unsigned)std::min<size_t>(((size_t)nb * nb * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
+                         (const double*)w.W, n, nb, (double*)c->invk_img.p);
+      c->invk_img_valid = true;
+      SBO_HIP(hipEventRecord(c->ev_w, c->stream));
+      hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)dalpha, npad, n, q, npad, (T*)c->alpha.p);
+      SBO_HIP(hipGetLastError());
+      c->factor_todo = true;
+      SBO_HIP(stream_wait(c, c->stream));
+      if (eager_basis) SBO_HIP(stream_wait(c, c->stream2));
+      return SBO_OK;                      // (the verdict on invK comes with the factor: factor_sync)
+    }
+  }
+  if ((rc = factor_chain_enqueue<T>(c, w, mode, c->stream))) return rc;
   hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)dalpha, npad, n, q, npad, (T*)c->alpha.p);
   SBO_HIP(hipGetLastError());
-  int* hbad = (int*)(c->h_back + (deferred ? 4864 : 4608));
-  SBO_HIP(hipMemcpyAsync(hbad, w.bad, sizeof(int) * q, hipMemcpyDeviceToHost, fs));
-  if (deferred) {
-    SBO_HIP(hipEventRecord(c->ev_factor, fs));
-    c->factor_pending = true;
-  }
+  int* hbad = (int*)(c->h_back + 4608);
+  SBO_HIP(hipMemcpyAsync(hbad, w.bad, sizeof(int) * q, hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(stream_wait(c, c->stream));
   if (eager_basis) SBO_HIP(stream_wait(c, c->stream2));
-  if (deferred) return SBO_OK;            // (the verdict on invK comes with the factor: factor_sync)
   for (int o = 0; o < q; ++o)
     if (hbad[o]) return fail(SBO_E_INVALID, host_invK ? "invK is not positive definite" : "K + sn2 I is not positive definite");
+  return SBO_OK;
+}
+
+// The deferred factor chain of a caller's invK (see model_build_t): enqueued on stream4 behind the upload of invK (ev_w),
+// ended by ev_factor; the positive-definiteness flags land in the pinned block for factor_sync.
+int model_factor_enqueue(sbo_ctx* c) {
+  if (!c->factor_todo) return SBO_OK;
+  c->factor_todo = false;
+  ModelWork w;
+  int rc = model_work(c, true, w);
+  if (rc) return rc;
+  SBO_HIP(hipStreamWaitEvent(c->stream4, c->ev_w, 0));
+  if ((rc = factor_chain_enqueue<double>(c, w, 0, c->stream4))) return rc;
+  SBO_HIP(hipMemcpyAsync(c->h_back + 4864, w.bad, sizeof(int) * c->mc.q, hipMemcpyDeviceToHost, c->stream4));
+  SBO_HIP(hipEventRecord(c->ev_factor, c->stream4));
+  c->factor_pending = true;
   return SBO_OK;
 }
 

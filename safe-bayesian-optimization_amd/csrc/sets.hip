@@ -1281,6 +1281,9 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
       SBO_HIP(hipMemcpyAsync(c->h_back, sc, kBack, hipMemcpyDeviceToHost, c->stream));
       if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
     }
+    // (a caller's invK whose reverse factor is still to be made: its ~20 launches are enqueued now, on their own stream,
+    // while the host would otherwise only wait for the sweep -- model.hip: model_factor_enqueue)
+    { const int rcf = model_factor_enqueue(c); if (rcf) return rcf; }
     SBO_HIP(stream_wait(c, c->stream));
     ++c->host_syncs;
     memcpy(&h, c->h_back, sizeof(h));
@@ -1373,6 +1376,21 @@ static void sweep_times(sbo_ctx* c, bool ov) {
   c->prof.set_exposed_ms = te;
   c->prof.k1_split = ov ? 1 : 0;
   c->prof.host_syncs = c->host_syncs;
+  c->prof.comm_bytes = c->comm_bytes;
+  c->prof.comm_calls = c->comm_calls;
+  double cms = c->comm_host_ms;
+  for (int k = 0; k + 1 < c->comm_nev; k += 2) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, c->comm_ev[k], c->comm_ev[k + 1]) == hipSuccess) cms += t;
+  }
+  c->prof.comm_ms = cms;
+}
+static void sweep_comm_reset(sbo_ctx* c) {
+  c->host_syncs = 0;
+  c->comm_bytes = 0;
+  c->comm_calls = 0;
+  c->comm_nev = 0;
+  c->comm_host_ms = 0.0;
 }
 
 template <typename T>
@@ -1380,7 +1398,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
-  c->host_syncs = 0;
+  sweep_comm_reset(c);
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if ((rc = sweep_masks(c, o->b, !reuse, true))) return rc;
@@ -1775,7 +1793,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
-  c->host_syncs = 0;
+  sweep_comm_reset(c);
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if ((rc = sweep_masks(c, o->b, !reuse, true))) return rc;

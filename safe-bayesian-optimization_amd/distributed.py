@@ -1,13 +1,20 @@
 """Rank plumbing for multi-GPU sweeps: one process per GPU.
 
-``torch.distributed`` (gloo) is used only as the launcher-side rendezvous -- broadcasting the RCCL unique id,
-barriers, and, for rehearsals on a 1-GPU box, carrying the library's collectives through host memory
-(``relay=True``).  The data path of a real multi-GPU run is RCCL inside libsafebo.so.
+The data path of a multi-GPU run is RCCL inside libsafebo.so.  What the host side needs besides is a rendezvous among the
+ranks a launcher started (``torch.distributed.run`` or anything else that sets RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT):
+broadcasting the 128-byte RCCL unique id, barriers, a max over the ranks' timings, and -- for rehearsals on a 1-GPU box only
+-- carrying the library's collectives through host memory.  ``TcpGroup`` does that with the standard library (a star over TCP
+through rank 0): no PyTorch in the product package.  ``HostRelay`` and ``join`` accept any group object with the same five
+methods (the CPU tests drive them with a torch.distributed / gloo adapter that lives under tests/).
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
+import pickle
+import socket
+import struct
+import time
 
 import numpy as np
 
@@ -38,31 +45,168 @@ def merge_slots(rows, is_max):
     return out
 
 
-class GlooRelay:
-    """Callbacks for sbo_comm_init_relay backed by a torch.distributed (gloo) group."""
+_MAGIC = b"SBO-RDZV1"
+_OPS = {"sum": np.add, "max": np.maximum, "min": np.minimum}
 
-    def __init__(self, group=None):
-        import torch
-        import torch.distributed as dist
-        self._torch, self._dist, self._group = torch, dist, group
+
+def _send(sock, payload: bytes):
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_exact(sock, n: int) -> bytes:
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv(sock) -> bytes:
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class TcpGroup:
+    """Star rendezvous over TCP: rank 0 listens on the first free port of [base + 1, base + 64] (base = MASTER_PORT, which the
+    launcher's own store occupies) and the others find it by a handshake (magic, base port, world size); every collective is
+    "send to rank 0, combine there, send back".  Small payloads only: ids, scalars, and the rehearsal relay."""
+
+    def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", base_port: int = 29500, timeout: float = 120.0):
+        self.rank, self.world, self._peers, self._sock = rank, world, [], None
+        token = _MAGIC + struct.pack("<II", base_port, world)
+        deadline = time.time() + timeout
+        if world == 1:
+            return
+        if rank == 0:
+            srv = None
+            for k in range(1, 65):
+                try:
+                    srv = socket.create_server((addr, base_port + k), reuse_port=False)
+                    break
+                except OSError:
+                    continue
+            if srv is None:
+                raise OSError(f"no free rendezvous port in [{base_port + 1}, {base_port + 64}]")
+            srv.settimeout(1.0)
+            peers = {}
+            while len(peers) < world - 1:
+                if time.time() > deadline:
+                    raise TimeoutError(f"rendezvous: {world - 1 - len(peers)} rank(s) did not arrive")
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                conn.settimeout(timeout)
+                try:
+                    hello = _recv(conn)
+                    if not hello.startswith(token):
+                        conn.close()
+                        continue
+                    (r,) = struct.unpack("<I", hello[len(token):len(token) + 4])
+                    _send(conn, token)
+                except (OSError, ConnectionError, struct.error):
+                    conn.close()
+                    continue
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                peers[r] = conn
+            srv.close()
+            self._peers = [peers[r] for r in range(1, world)]
+        else:
+            while self._sock is None:
+                for k in range(1, 65):
+                    try:
+                        s_ = socket.create_connection((addr, base_port + k), timeout=2.0)
+                    except OSError:
+                        continue
+                    try:
+                        s_.settimeout(5.0)
+                        _send(s_, token + struct.pack("<I", rank))
+                        if _recv(s_) == token:
+                            s_.settimeout(timeout)
+                            s_.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                            self._sock = s_
+                            break
+                    except (OSError, ConnectionError, struct.error):
+                        pass
+                    s_.close()
+                if self._sock is None:
+                    if time.time() > deadline:
+                        raise TimeoutError("rendezvous: rank 0 was not found")
+                    time.sleep(0.05)
+
+    # -- the five methods a "group" has ----------------------------------------------------------------------------------
+    def get_rank(self) -> int:
+        return self.rank
+
+    def get_world_size(self) -> int:
+        return self.world
+
+    def _exchange(self, payload: bytes, combine):
+        """every rank contributes `payload`; rank 0 computes combine([payload_0, ..]) -> list of per-rank answers"""
+        if self.world == 1:
+            return combine([payload])[0]
+        if self.rank == 0:
+            parts = [payload] + [_recv(p) for p in self._peers]
+            answers = combine(parts)
+            for p, a in zip(self._peers, answers[1:]):
+                _send(p, a)
+            return answers[0]
+        _send(self._sock, payload)
+        return _recv(self._sock)
+
+    def barrier(self):
+        self._exchange(b"", lambda parts: [b""] * len(parts))
+
+    def broadcast_object(self, obj, src: int = 0):
+        def combine(parts):
+            return [parts[src]] * len(parts)
+        return pickle.loads(self._exchange(pickle.dumps(obj), combine))
+
+    def all_reduce(self, arr: np.ndarray, op: str = "sum") -> np.ndarray:
+        """element-wise sum / max / min over the ranks of a NumPy array (same shape and dtype everywhere)"""
+        a = np.ascontiguousarray(arr)
+        fn = _OPS[op]
+
+        def combine(parts):
+            acc = np.frombuffer(parts[0], dtype=a.dtype).copy()
+            for p_ in parts[1:]:
+                acc = fn(acc, np.frombuffer(p_, dtype=a.dtype))
+            return [acc.tobytes()] * len(parts)
+        return np.frombuffer(self._exchange(a.tobytes(), combine), dtype=a.dtype).reshape(a.shape).copy()
+
+    def all_gather_bytes(self, payload: bytes) -> list:
+        def combine(parts):
+            blob = pickle.dumps(parts)
+            return [blob] * len(parts)
+        return pickle.loads(self._exchange(bytes(payload), combine))
+
+    def destroy(self):
+        for p in self._peers:
+            p.close()
+        if self._sock is not None:
+            self._sock.close()
+        self._peers, self._sock = [], None
+
+
+class HostRelay:
+    """Callbacks for sbo_comm_init_relay: the library's collectives staged through host memory and carried by a group object
+    (TcpGroup, or the gloo adapter of the CPU tests).  A rehearsal transport -- RCCL over xGMI is the production one."""
+
+    def __init__(self, group):
+        self._group = group
         self.allreduce = L.RELAY_ALLREDUCE(self._allreduce)
         self.allgather = L.RELAY_ALLGATHER(self._allgather)
 
     def _allreduce(self, user, buf, count, elem, op):
         try:
-            torch, dist = self._torch, self._dist
-            ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}
-            if elem == 0:   # uint64 compared through an order-preserving int64 image
+            opname = {0: "sum", 1: "max", 2: "min"}[op]
+            if elem == 0:
                 arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint64)), shape=(count,))
-                img = (arr ^ np.uint64(1 << 63)).view(np.int64).copy()
-                t = torch.from_numpy(img)
-                dist.all_reduce(t, op=ops[op], group=self._group)
-                arr[:] = t.numpy().view(np.uint64) ^ np.uint64(1 << 63)
             else:
                 arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
-                t = torch.from_numpy(arr.copy())
-                dist.all_reduce(t, op=ops[op], group=self._group)
-                arr[:] = t.numpy()
+            arr[:] = self._group.all_reduce(arr.copy(), opname)
             return 0
         except Exception as exc:   # never let an exception cross the C boundary
             print("relay all-reduce failed:", exc)
@@ -70,74 +214,64 @@ class GlooRelay:
 
     def _allgather(self, user, send, recv, nbytes):
         try:
-            torch, dist = self._torch, self._dist
-            world = dist.get_world_size(self._group)
+            world = self._group.get_world_size()
             src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
             dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
-            outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
-            dist.all_gather(outs, torch.from_numpy(src.copy()), group=self._group)
-            for r, t in enumerate(outs):
-                dst[r * nbytes:(r + 1) * nbytes] = t.numpy()
+            for r, part in enumerate(self._group.all_gather_bytes(src.tobytes())):
+                dst[r * nbytes:(r + 1) * nbytes] = np.frombuffer(part, dtype=np.uint8)
             return 0
         except Exception as exc:
             print("relay all-gather failed:", exc)
             return 1
 
 
-def join(engine, relay: bool = False, group=None):
-    """Join ``engine`` to the ranks of the initialised torch.distributed group: RCCL by default
-    (unique id broadcast from rank 0), or the host relay for rehearsals."""
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+def join(engine, group, relay: bool = False):
+    """Join ``engine`` to the ranks of ``group``: RCCL by default (unique id broadcast from rank 0), or the host relay for
+    rehearsals."""
+    world, rank = group.get_world_size(), group.get_rank()
     if relay:
-        cb = GlooRelay(group)
+        cb = HostRelay(group)
         engine._relay = cb   # keep the ctypes thunks alive as long as the engine
         L.check(engine._lib.sbo_comm_init_relay(engine._ctx, world, rank, cb.allreduce, cb.allgather, None))
         engine.world, engine.rank = world, rank
         return
     # the broadcast always happens, also when rank 0 could not create the id: every rank then raises the same error
     # instead of some of them waiting in the broadcast for a rank that has already left
-    uid = [None]
+    uid = None
     if rank == 0:
         try:
-            uid[0] = engine.comm_unique_id()
+            uid = engine.comm_unique_id()
         except Exception as exc:                  # noqa: BLE001
-            uid[0] = ("error", str(exc))
-    dist.broadcast_object_list(uid, src=0, group=group)
-    if isinstance(uid[0], tuple):
-        raise L.SafeBOError(L.SBO_E_COMM, f"rank 0 could not create the RCCL unique id: {uid[0][1]}")
-    engine.comm_init(world, rank, uid[0])
+            uid = ("error", str(exc))
+    uid = group.broadcast_object(uid, src=0)
+    if isinstance(uid, tuple):
+        raise L.SafeBOError(L.SBO_E_COMM, f"rank 0 could not create the RCCL unique id: {uid[1]}")
+    engine.comm_init(world, rank, uid)
 
 
-def join_with_fallback(engine, group=None, allow_relay: bool = True) -> str:
+def join_with_fallback(engine, group, allow_relay: bool = True) -> str:
     """RCCL if every rank can form the communicator.  Otherwise, with ``allow_relay`` (one-GPU rehearsals of the N > 1
-    plumbing, where RCCL refuses two ranks on one device), every rank falls back to the gloo relay; without it every rank
+    plumbing, where RCCL refuses two ranks on one device), every rank falls back to the host relay; without it every rank
     raises -- a real multi-GPU run must never publish a relay-speed number.  Returns the transport used."""
-    import torch
-    import torch.distributed as dist
     ok, err = 1, None
     try:
-        join(engine, relay=False, group=group)
+        join(engine, group, relay=False)
     except Exception as exc:                      # noqa: BLE001 - any failure means "no RCCL here"
         err = exc
         ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    flag = group.all_reduce(np.array([ok], dtype=np.int64), "min")
     if int(flag[0]) == 1:
         return "rccl"
     if not allow_relay:
-        raise L.SafeBOError(L.SBO_E_COMM, f"[rank {dist.get_rank(group)}] the RCCL communicator could not be formed on every rank"
+        raise L.SafeBOError(L.SBO_E_COMM, f"[rank {group.get_rank()}] the RCCL communicator could not be formed on every rank"
                             + (f" (this rank: {err})" if err is not None else " (this rank was fine)"))
     if err is not None:
-        print(f"[rank {dist.get_rank(group)}] RCCL communicator failed ({err}); using the gloo relay")
-    join(engine, relay=True, group=group)
-    return "gloo-relay"
+        print(f"[rank {group.get_rank()}] RCCL communicator failed ({err}); using the host relay")
+    join(engine, group, relay=True)
+    return "host-relay"
 
 
-def init_gloo_from_env():
-    """init_process_group(gloo) from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if not dist.is_initialized():
-        dist.init_process_group(backend="gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
-    return dist
+def init_from_env(timeout: float = 120.0) -> TcpGroup:
+    """The ranks of a launcher (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, as torch.distributed.run sets them) as a TcpGroup."""
+    return TcpGroup(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+                    os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")), timeout)

@@ -1,8 +1,9 @@
-"""Worker for tests/test_distributed_cpu.py (world_size-2 gloo rehearsal of the shard / exchange protocol).
+"""Worker for tests/test_distributed_cpu.py (world_size-2 rehearsal of the shard / exchange protocol over gloo, or -- argv[5] ==
+"tcp" -- over the package's own stdlib rendezvous).
 
 Each rank evaluates its own shard with the NumPy oracle standing in for the HIP kernels (there is no GPU
 in the CPU test environment), then runs the *same* exchange steps libsafebo.so performs -- C1 max of order
-keys, C2 all-gather of the padded U mask, C3 sum of per-rank rows -- through the GlooRelay callbacks the
+keys, C2 all-gather of the padded U mask, C3 sum of per-rank rows -- through the HostRelay callbacks the
 1-GPU rehearsal transport uses, and merges with the host rule.  Rank 0 writes the merged result.
 """
 import ctypes as C
@@ -30,13 +31,17 @@ def ord_val(k):
 def main():
     rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
     import oracle
     from safebo_amd import synthetic
-    from safebo_amd.distributed import GlooRelay, merge_slots, shard_planes, init_gloo_from_env
+    from safebo_amd.distributed import HostRelay, merge_slots, shard_planes, init_from_env
 
-    init_gloo_from_env()
-    relay = GlooRelay()
+    if len(sys.argv) > 5 and sys.argv[5] == "tcp":
+        dist = init_from_env()
+    else:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from _gloo_group import GlooGroup
+        dist = GlooGroup()
+    relay = HostRelay(dist)
     cfg = synthetic.make_config("A", n=20)
     count = [30, 23]                                   # 23 planes over 2 ranks: uneven shards
     lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
@@ -103,7 +108,7 @@ def main():
         json.dump({"u_star": u_star, "L": L.tolist(), "minimizer": merged[0][1], "expander": merged[1][1],
                    "count_S": counts[0], "count_M": counts[1], "count_G": counts[2], "first_of": first_of}, open(out_path, "w"))
     dist.barrier()
-    dist.destroy_process_group()
+    dist.destroy()
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """Worker for the 2-rank GPU rehearsal in tests/test_gpu_parity.py: both ranks drive the single GPU of the
-test box (RCCL refuses duplicate devices, so the collectives ride the gloo relay transport); the sweep code
+test box (RCCL refuses duplicate devices, so the collectives ride the host relay over the package's TCP rendezvous); the sweep code
 path -- shard offsets, whole-grid U mask, exchange kernels, host merge -- is the multi-GPU one."""
 import json
 import os
@@ -18,10 +18,10 @@ def main():
     import safebo_amd
     from safebo_amd import synthetic, distributed
 
-    dist = distributed.init_gloo_from_env()
+    dist = distributed.init_from_env()
     cfg = synthetic.make_config(cfg_name, n=n)
     eng = safebo_amd.SweepEngine(0)
-    distributed.join(eng, relay=True)
+    distributed.join(eng, dist, relay=True)
     eng.set_model(cfg["ds"], dtype="f64")
     eng.set_grid_sharded(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
     res = eng.sweep_safeopt(b, want_masks=True)
@@ -41,7 +41,7 @@ def main():
         json.dump({**plain(res), "goose": plain(gres) if gres is not None else None}, open(out_path, "w"))
     dist.barrier()
     eng.close()
-    dist.destroy_process_group()
+    dist.destroy()
 
 
 if __name__ == "__main__":

@@ -150,6 +150,27 @@ def test_posterior_over_the_hyper_parameter_range(engine, seed):
         assert np.max(np.abs(mean - m_t) / ystd) < TOL64 and np.max(np.abs(var - v_t) / ystd ** 2) < TOL64
 
 
+@pytest.mark.parametrize("cfg_name,n", [("B", 128), ("H", 512), ("H", 300), ("C", 256), ("A", 64)])
+def test_basis_rows_in_registers_equal_the_lds_and_memory_forms(engine, cfg_name, n):
+    """Option basis_reg (default on): the pivot loop of the axis bases keeps the residual rows in registers, two threads per row
+    (n <= 512, degree <= 64) -- same pivots, same ranks; the posterior of the GEMM kernels moves by rounding only."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    count = [96, 80]
+    engine.set_grid(lo, hi, count)
+    out = {}
+    try:
+        for reg in (1, 0):
+            engine.set_option("basis_reg", reg)
+            engine.set_model(cfg["ds"])
+            out[reg] = _check_posterior(engine, cfg["ds"], oracle.grid_points(lo, hi, count), TOL64)
+            assert engine.profile()["posterior_kernel"] == 4
+    finally:
+        engine.set_option("basis_reg", 1)
+    ys = np.maximum(1.0, cfg["ds"]["Y_std"])
+    assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < 1e-12 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < 1e-12
+
+
 def test_bilinear_rank_range_and_declines(engine):
     """Short length-scales need larger bases (r up to 64, inner dimension up to 2080): still the GEMM path when that is
     cheaper than the O(n^2) contraction (n = 512 here), and still within tolerance.  Bases beyond 64 directions, grids on
