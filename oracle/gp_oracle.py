@@ -25,7 +25,7 @@ __all__ = [
     "data_normalization", "squared_seuclidean", "cov_mat", "calc_cov_mat", "build_invK",
     "make_inference_dataset", "cast_dataset", "mean_prior", "gp_inference", "bounds",
     "grid_axes", "grid_points", "mean_grad", "mean_grad_infnorm", "shifted_norm",
-    "safeopt_sweep", "goose_sweep", "tr_sweep", "update_TR", "FLOAT32_EPS",
+    "safeopt_sweep", "goose_sweep", "tr_sweep", "update_TR", "FLOAT32_EPS", "negative_loglikelihood",
 ]
 
 FLOAT32_EPS = float(np.finfo(np.float32).eps)  # jitter of the stored inverse, models/GP_Safe.py:229
@@ -79,6 +79,29 @@ def build_invK(X_norm, hypopt):
         K = cov_mat(X_norm, X_norm, ell, sf2) + sn2 * np.eye(n)
         out.append(np.linalg.inv(K))
     return out
+
+
+def negative_loglikelihood(hyper, X_norm, y):
+    """models/GP_Safe.py:169-192 -- the objective the reference's DE fit minimises for one output:
+    K = sf2 exp(-1/2 D) + (sn2 + 1e-8) I (jitter 1e-8 here, float32 eps in the stored inverse, :184 vs :229), symmetrised
+    (:185), L = chol(K) (:186), NLL = y^T K^-1 y + log|K| with K^-1 y by two triangular solves (:187-190) -- no 1/2, no constant.
+    ``hyper`` = (log ell_0.., log sigma_f, log sigma_n), consumed as exp(2 h) (:180-182); ``y`` one column of Y_norm, [n] or [n, 1].
+    Returns +inf when K is not positive definite in floating point (jnp.linalg.cholesky yields NaN there)."""
+    from scipy.linalg import solve_triangular
+    X_norm = np.asarray(X_norm, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
+    n, d = X_norm.shape
+    hyper = np.asarray(hyper, dtype=np.float64)
+    W, sf2, sn2 = np.exp(2 * hyper[:d]), np.exp(2 * hyper[d]), np.exp(2 * hyper[d + 1])
+    K = cov_mat(X_norm, X_norm, W, sf2) + (sn2 + 1e-8) * np.eye(n)
+    K = (K + K.T) * 0.5
+    try:
+        L = np.linalg.cholesky(K)
+    except np.linalg.LinAlgError:
+        return np.inf
+    logdet = 2 * np.sum(np.log(np.diag(L)))
+    alpha = solve_triangular(L.T, solve_triangular(L, y, lower=True), lower=False)
+    return float(np.dot(y.T, alpha)[0][0] + logdet)
 
 
 def make_inference_dataset(X, Y, hypopt):

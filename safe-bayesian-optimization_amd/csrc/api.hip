@@ -243,6 +243,11 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->k1_wgs_per_cu = (int)value;
     return SBO_OK;
   }
+  if (!strcmp(key, "halo_spec")) {
+    c->halo_spec = value ? 1 : 0;
+    for (auto& g : c->halo_guess) g = -1;
+    return SBO_OK;
+  }
   if (!strcmp(key, "comm_events")) {
     c->comm_events = value ? 1 : 0;
     return SBO_OK;
@@ -445,6 +450,7 @@ int sbo_model_append(sbo_ctx* c, const double* x_norm_new, const double* y_norm_
   SBO_HIP(hipSetDevice(c->device));
   { const int rcf = factor_sync(c); if (rcf) return rcf; }     // (the update works on the resident factor)
   c->invk_img_valid = false;                                    // (the images of the caller's invK do not follow an append)
+  c->invk_w_valid = false;
   // cross-covariances of the new point with the expanded distance of the reference (GP_Safe.py:115-119, 166)
   std::vector<double> kvec((size_t)q * n);
   double kappa[kMaxQ], rho[kMaxQ];
@@ -533,6 +539,7 @@ int sbo_candidates_grid(sbo_ctx* c, int d, const double* lo, const double* hi, c
   }
   for (int a = d; a < kMaxD; ++a) c->cs.count[a] = 1;
   c->grid_total = (long long)total;
+  for (auto& g : c->halo_guess) g = -1;
   c->sharded = false;
   c->has_cand = true;
   c->bl.valid = false;

@@ -1551,7 +1551,8 @@ int bilinear_setup(sbo_ctx* c) {
   // fragments (k = observation) and as images of C^T, then G = C^T C.  With a CALLER's invK (sbo_ctx::invk_img, r03): W =
   // invK Z with the matrix as given -- the contraction the reference itself performs, models/GP_Safe.py:341-343, no
   // factorisation of an ill-conditioned inverse in between --, then G^T = W^T Z; k_bl_t4f symmetrises what rounding leaves.
-  const bool direct = mc.factor == SBO_FACTOR_INVK && c->invk_img_valid;
+  if (mc.factor == SBO_FACTOR_INVK && c->chol_async && !c->invk_img_valid && c->invk_w_valid && (rc = model_pack_invk(c))) return rc;
+  const bool direct = mc.factor == SBO_FACTOR_INVK && c->chol_async && c->invk_img_valid;
   if (!direct && (rc = factor_sync(c))) return rc;
   if (direct) {
     hipLaunchKernelGGL((k_bgemm<4, 0, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, c->stream,

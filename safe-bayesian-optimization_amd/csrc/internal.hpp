@@ -89,6 +89,7 @@ struct sbo_ctx {
   // needs it calls factor_sync first, which also delivers the positive-definiteness verdict
   sbo::DevBuf invk_img;            // [q][npad / 16][npad / 16][256] A images of the full invK (fp64)
   bool invk_img_valid = false;
+  bool invk_w_valid = false;       // the uploaded invK of the current model is still in the build workspace (images can be packed later)
   bool factor_todo = false;        // the chain has not been enqueued yet (sbo_model_set does that last: model_factor_enqueue)
   bool factor_pending = false;     // the factor chain of the current model is (possibly) still running; ev_factor marks its end
   hipEvent_t ev_factor = nullptr, ev_w = nullptr;
@@ -176,6 +177,11 @@ struct sbo_ctx {
   bool sharded = false;     // candidates were set with the canonical plane sharding
   std::vector<long long> first_of;   // [world + 1] flat offsets of the rank shards
   unsigned long long* h_c1 = nullptr;     // pinned host copy of the C1 keys (global u*, L, radius) of the running sweep
+  // Speculative halo (ranks > 1, option halo_spec): the host sizes the transform window of constraint c from the keys of the
+  // PREVIOUS sweep (with a margin) instead of waiting for this sweep's; the device checks the guess against the keys it
+  // gathered (SweepScalars::halo_short) and a short guess reruns the set phase the waiting way.  -1: no guess yet.
+  long long halo_guess[SBO_MAX_Q] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  int halo_spec = 1;
   bool c1_pending = false;                // the read-back of h_c1 has been enqueued (event ev[5]) but not yet waited for
   void* h_stage = nullptr;                // pinned staging of the K1b table build's single upload
   size_t h_stage_bytes = 0;
@@ -240,7 +246,8 @@ int launch_posterior(sbo_ctx* c);
 int launch_bound(sbo_ctx* c, double b, int index, int kind, void* dev_out);
 int model_build(sbo_ctx* c, const double* const* host_invK, const double* X_norm, const double* Y_norm);
 int model_prep(sbo_ctx* c, const double* X_norm);
-int model_factor_enqueue(sbo_ctx* c);   // the deferred factor chain of a caller's invK, behind everything on the critical path
+int model_factor_enqueue(sbo_ctx* c);
+int model_pack_invk(sbo_ctx* c);         // images of the caller's invK for the K1b tables, when the grid arrived after the model   // the deferred factor chain of a caller's invK, behind everything on the critical path
 int model_append(sbo_ctx* c, const std::vector<double>& kvec /*[q][n]*/, const double* kappa, const double* rho);
 int model_repack(sbo_ctx* c);
 bool bilinear_applicable(const sbo_ctx* c);

@@ -832,6 +832,7 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
     c->factor_pending = false;
   }
   c->invk_img_valid = false;
+  c->invk_w_valid = false;
   c->factor_todo = false;
   ModelWork w;
   if ((rc = model_work(c, host_invK != nullptr, w))) return rc;
@@ -851,9 +852,11 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
     if ((rc = bilinear_basis_enqueue(c, c->stream2, false))) return rc;
     eager_basis = true;
   }
-  if (host_invK)                          // (the reference keeps them as a list of q arrays: one copy each, no stacking on the host)
+  if (host_invK) {                        // (the reference keeps them as a list of q arrays: one copy each, no stacking on the host)
     for (int o = 0; o < q; ++o)
       SBO_HIP(hipMemcpyAsync(w.W + (size_t)o * nn, host_invK[o], sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
+    c->invk_w_valid = std::is_same<T, double>::value && !c->is_shadow;
+  }
   SBO_HIP(hipMemsetAsync(dalpha, 0, sizeof(double) * (size_t)q * npad, c->stream));
   SBO_HIP(hipMemsetAsync(w.bad, 0, sizeof(int) * q, c->stream));
   const int mode = host_invK ? 0 : 1;
@@ -895,6 +898,23 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
   if (eager_basis) SBO_HIP(stream_wait(c, c->stream2));
   for (int o = 0; o < q; ++o)
     if (hbad[o]) return fail(SBO_E_INVALID, host_invK ? "invK is not positive definite" : "K + sn2 I is not positive definite");
+  return SBO_OK;
+}
+
+// A grid that arrived after the model: the images of the caller's invK for the K1b tables are packed now, from the upload that
+// still sits in the build workspace -- so that the GEMM posterior contracts with invK as given whatever the order of the calls.
+int model_pack_invk(sbo_ctx* c) {
+  if (c->invk_img_valid) return SBO_OK;
+  if (!c->invk_w_valid) return fail(SBO_E_INVALID, "internal: the uploaded invK is gone");
+  ModelWork w;
+  int rc = model_work(c, true, w);
+  if (rc) return rc;
+  const int n = c->mc.n, npad = c->mc.npad, q = c->mc.q, nb = npad / 16;
+  if ((rc = ensure(c->invk_img, sizeof(double) * (size_t)q * npad * npad))) return rc;
+  hipLaunchKernelGGL(k_pack_full, dim3((unsigned)std::min<size_t>(((size_t)nb * nb * 256 + 255) / 256, 4096), q), dim3(256), 0, c->stream,
+                     (const double*)w.W, n, nb, (double*)c->invk_img.p);
+  SBO_HIP(hipGetLastError());
+  c->invk_img_valid = true;
   return SBO_OK;
 }
 

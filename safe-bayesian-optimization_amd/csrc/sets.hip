@@ -46,6 +46,7 @@ struct SweepScalars {
   long long count_set[kMaxQ];              // |G_c| or |O_c|
   long long n_amb, n_amb_total;
   long long n_scan;                        // candidates handed from the coarse decision to the wave-per-candidate scan
+  long long halo_short;                    // ranks > 1: a speculative transform window was narrower than this sweep's keys need
   double arg_val[kArgSlots];
   long long arg_idx[kArgSlots];
 };
@@ -854,6 +855,58 @@ static int launch_exact_d(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lid
 
 static int sweep_exchange_wait(sbo_ctx* c);
 
+// Halo of a rank's transform window in hyper-planes of the slowest axis: witnesses (expanders) / sources (GoOSE) further than
+// the largest radius rmax / L cannot change a verdict.  One formula for the host (keys read back) and the device (the check
+// of a speculative window against the keys of the running sweep).
+__host__ __device__ __forceinline__ long long halo_planes(double L, double rmax, double hl, long long planes_total) {
+  long long H = planes_total;
+  if (L > 0 && hl > 0) {
+    const double cap = rmax / L * 1.000001 + 1e-6;
+    const double hp = ceil(cap / hl) + 2.0;
+    if (hp < (double)planes_total) H = (long long)hp;
+  }
+  return H;
+}
+__global__ void k_halo_check(SweepScalars* sc, const unsigned long long* Lkeys, int lidx, int cidx, double hl, long long H_used,
+                             long long planes_total) {
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const double rmax = sc->rmax_key[cidx] ? ord_val(sc->rmax_key[cidx]) : 0.0;
+  if (halo_planes(L, rmax, hl, planes_total) > H_used) sc->halo_short = 1;
+}
+// the window's halo for constraint cidx: the guess from the previous sweep (checked on the device), or the keys of this one
+// (the host waits for their read-back)
+static int halo_for(sbo_ctx* c, int cidx, int lidx, double hl, long long planes_total, long long* H_out) {
+  if (c->halo_spec && c->halo_guess[cidx] >= 0) {
+    const long long H = std::min(planes_total, c->halo_guess[cidx]);
+    hipLaunchKernelGGL(k_halo_check, dim3(1), dim3(1), 0, c->stream, (SweepScalars*)c->scal.p, (const unsigned long long*)c->Lmax.p, lidx, cidx,
+                       hl, H, planes_total);
+    *H_out = H;
+    return SBO_OK;
+  }
+  int rc;
+  if ((rc = sweep_exchange_wait(c))) return rc;
+  double L, rmax = 0.0;
+  memcpy(&L, &c->h_c1[1 + lidx], 8);
+  if (c->h_c1[1 + kMaxQ + cidx]) rmax = ord_val(c->h_c1[1 + kMaxQ + cidx]);
+  *H_out = halo_planes(L, rmax, hl, planes_total);
+  return SBO_OK;
+}
+// after a sweep: next sweep's guesses from this sweep's global keys (a quarter more, so that a slowly growing radius stays inside)
+static void halo_learn(sbo_ctx* c, const SweepScalars& h, const unsigned long long* Lk, int quirk) {
+  if (!multi_rank(c) || c->cs.kind != 1) return;
+  const int q = c->mc.q, d = c->cs.d;
+  const double hl = d >= 2 ? c->cs.step[d - 1] : c->cs.step[0];
+  const long long planes_total = c->cs.count[d - 1];
+  for (int cc = 1; cc < q; ++cc) {
+    const int lidx = quirk ? q - 1 : cc;
+    double L;
+    memcpy(&L, &Lk[lidx], 8);
+    const double rmax = h.rmax_key[cc] ? ord_val(h.rmax_key[cc]) : 0.0;
+    const long long H = halo_planes(L, rmax, hl, planes_total);
+    c->halo_guess[cc] = H >= planes_total ? planes_total : std::min(planes_total, H + H / 4 + 2);
+  }
+}
+
 // G_c for constraint cidx (1..q-1) into G[n]
 static void launch_edt_axis0(sbo_ctx* c, const uint8_t* U, long long nlines, int count0, double h0, double* D, hipStream_t st = nullptr) {
   if (!st) st = c->stream;
@@ -945,17 +998,9 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     long long p0 = multi_rank(c) ? c->cs.first / plane : 0, p1 = p0 + n / plane;
     const long long own0 = p0;
     if (multi_rank(c)) {
-      if ((rc = sweep_exchange_wait(c))) return rc;
-      double L, rmax = 0.0;
-      memcpy(&L, &c->h_c1[1 + lidx], 8);
-      if (c->h_c1[1 + kMaxQ + cidx]) rmax = ord_val(c->h_c1[1 + kMaxQ + cidx]);
       const double hl = d >= 2 ? c->cs.step[d - 1] : c->cs.step[0];
-      long long H = planes_total;
-      if (L > 0 && hl > 0) {
-        const double cap = rmax / L * 1.000001 + 1e-6;
-        const double hp = std::ceil(cap / hl) + 2.0;
-        if (hp < (double)planes_total) H = (long long)hp;
-      }
+      long long H;
+      if ((rc = halo_for(c, cidx, lidx, hl, planes_total, &H))) return rc;
       p0 = std::max(0ll, p0 - H);
       p1 = std::min(planes_total, p1 + H);
     }
@@ -1466,6 +1511,17 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   for (int t = 0; t < kArgSlots; ++t) is_max[t] = true;
   unsigned long long Lk[kMaxQ];
   if ((rc = sweep_exchange_back(c, h, is_max, Lk, c->ev[4], mirrored))) return rc;
+  if (multi_rank(c)) {
+    if (h.halo_short) {
+      // a speculative window was too narrow for this sweep's radii (every rank sees the same keys and the same guess): the set
+      // phase again, this time waiting for the keys
+      for (auto& g : c->halo_guess) g = -1;
+      sbo_sweep_opts o2 = *o;
+      o2.posterior_ready = 1;
+      return sweep_safeopt_t<T>(c, &o2, res);
+    }
+    halo_learn(c, h, Lk, o->reference_quirk_L_index);
+  }
   c->masks_valid = true;
   c->last_sweep = 1;
   if (getenv("SBO_DEBUG_SCAN")) fprintf(stderr, "[safebo] open candidates scanned (last constraint) %lld, exact rechecks %lld\n", h.n_scan, h.n_amb_total);
@@ -1556,16 +1612,9 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
     const long long planes_total = c->cs.count[d - 1];
     long long p0 = c->cs.first / plane, p1 = (c->cs.first + n + plane - 1) / plane;
     const long long own0 = p0, own1 = p1;
-    if ((rc = sweep_exchange_wait(c))) return rc;
-    double L, rmax = 0.0;
-    memcpy(&L, &c->h_c1[1 + lidx], 8);
-    if (c->h_c1[1 + kMaxQ + cidx]) rmax = ord_val(c->h_c1[1 + kMaxQ + cidx]);
     const double hl = c->cs.step[d - 1];
-    long long H = planes_total;
-    if (L > 0 && hl > 0) {
-      const double hp = std::ceil((rmax / L * 1.000001 + 1e-6) / hl) + 2.0;
-      if (hp < (double)planes_total) H = (long long)hp;
-    }
+    long long H;
+    if ((rc = halo_for(c, cidx, lidx, hl, planes_total, &H))) return rc;
     p0 = std::max(0ll, p0 - H);
     p1 = std::min(planes_total, p1 + H);
     win_p0 = p0;
@@ -1877,6 +1926,15 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   }
   unsigned long long Lk[kMaxQ];
   if ((rc = sweep_exchange_back(c, h, is_max, Lk))) return rc;
+  if (multi_rank(c)) {
+    if (h.halo_short) {                     // (see sweep_safeopt_t)
+      for (auto& g : c->halo_guess) g = -1;
+      sbo_sweep_opts o2 = *o;
+      o2.posterior_ready = 1;
+      return sweep_goose_t<T>(c, &o2, res);
+    }
+    halo_learn(c, h, Lk, o->reference_quirk_L_index);
+  }
   c->masks_valid = true;
   c->last_sweep = 2;
 

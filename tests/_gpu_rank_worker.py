@@ -13,7 +13,9 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, out_path, cfg_name, n, count, b = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4],
-                                                          sys.argv[5], int(sys.argv[6]), json.loads(sys.argv[7]), float(sys.argv[8]))
+                                                          sys.argv[5], int(sys.argv[6]), json.loads(sys.argv[7]), json.loads(sys.argv[8]))
+    if isinstance(b, list):
+        return sequence(rank, world, port, out_path, cfg_name, n, count, b)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import safebo_amd
     from safebo_amd import synthetic, distributed
@@ -39,6 +41,44 @@ def main():
         def plain(r):
             return {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
         json.dump({**plain(res), "goose": plain(gres) if gres is not None else None}, open(out_path, "w"))
+    dist.barrier()
+    eng.close()
+    dist.destroy()
+
+
+def sequence(rank, world, port, out_path, cfg_name, n, count, bs):
+    """Several sweeps in a row on one sharded grid, each with its own confidence multiplier (a larger b = larger radii): the
+    first sizes its halo windows from its own keys (the host waits for them), the later ones from the previous sweep's keys
+    (speculative: no wait inside the sweep; a window that turns out too narrow reruns the set phase)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    import safebo_amd
+    from safebo_amd import synthetic, distributed
+
+    dist = distributed.init_from_env()
+    cfg = synthetic.make_config(cfg_name, n=n)
+    eng = safebo_amd.SweepEngine(0)
+    distributed.join(eng, dist, relay=True)
+    eng.set_grid_sharded(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    rows, masks = [], {}
+    for i, b in enumerate(bs):
+        eng.set_model(cfg["ds"], dtype="f64")
+        res = eng.sweep_safeopt(b, want_masks=True)
+        p = eng.profile()
+        for k in ("S", "M"):
+            masks[f"{i}_{k}"] = eng.mask(k)
+        for c in range(1, cfg["q"]):
+            masks[f"{i}_G{c}"] = eng.mask("G", c)
+        g = eng.sweep_goose(b, want_masks=True, posterior_ready=True)
+        pg = eng.profile()
+        for c in range(1, cfg["q"]):
+            masks[f"{i}_O{c}"] = eng.mask("O", c)
+        rows.append({"b": b, "host_syncs": int(p["host_syncs"]), "goose_host_syncs": int(pg["host_syncs"]),
+                     "minimizer_index": res["minimizer_index"], "expander_index": res["expander_index"], "count_S": res["count_S"],
+                     "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]], "u_star": res["u_star"],
+                     "target_index": g["target_index"], "explore_index": g["explore_index"], "count_O": [int(x) for x in g["count_O"]]})
+    np.savez(out_path + f".rank{rank}.npz", **masks)
+    if rank == 0:
+        json.dump(rows, open(out_path, "w"))
     dist.barrier()
     eng.close()
     dist.destroy()

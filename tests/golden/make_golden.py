@@ -28,8 +28,26 @@ CASES = [
 ]
 
 
+def nll_case(n, d, P=40):
+    """inputs / outputs of the hyper-parameter objective (oracle.negative_loglikelihood, models/GP_Safe.py:169-192): a
+    population inside the reference's search box (:205-206) on a seeded data set"""
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-1, 1, size=(n, d))
+    Xn = (X - X.mean(0)) / X.std(0)
+    y = np.sin(Xn.sum(1))
+    y = (y - y.mean()) / y.std()
+    H = np.column_stack([rng.uniform(-1.5, 1.5, size=(P, d + 1)), rng.uniform(-5.0, -2.0, size=P)])
+    return Xn, y, H, np.array([oracle.negative_loglikelihood(h, Xn, y) for h in H])
+
+
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    rec = {}
+    for n, d in ((4, 2), (20, 2), (45, 2), (128, 4), (300, 3)):
+        Xn, y, H, f = nll_case(n, d)
+        rec.update({f"X_{n}_{d}": Xn, f"y_{n}_{d}": y, f"H_{n}_{d}": H, f"nll_{n}_{d}": f})
+    np.savez_compressed(os.path.join(out_dir, "nll_population.npz"), **rec)
+    print("nll_population", {k: v.shape for k, v in rec.items() if k.startswith("nll")})
     for name, cfg_name, n, count, b, quirk in CASES:
         cfg = synthetic.make_config(cfg_name, n=n)
         lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]

@@ -1,5 +1,7 @@
 """Host-side mirrors of the reference classes (GP_Safe.GP, SafeOpt.BO, GoOSE.BO): CPU logic here, device-backed
 behaviour under the gpu marker."""
+import os
+
 import numpy as np
 import pytest
 
@@ -41,6 +43,22 @@ def test_gp_state_matches_oracle_restatement():
     assert m.n_point == 12 and m.nx_dim == 2 and m.ny_dim == 2 and m.n_fun == 2
     # every sample lies in the ball of radius 0.3 around x_0 (models/GP_Safe.py:30-50)
     assert np.all(np.linalg.norm(m.X - np.array([1.4, -.8]), axis=1) <= 0.3 + 1e-12)
+
+
+def test_oracle_nll_matches_its_fixture_and_the_host_objective():
+    """oracle.negative_loglikelihood (the checker of the device objective) against tests/golden/nll_population.npz, and the
+    product class's own NumPy objective against the oracle -- on the CPU, no device involved."""
+    import oracle
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nll_population.npz"))
+    for n, d in ((4, 2), (20, 2), (45, 2)):
+        Xn, y, H, golden = fx[f"X_{n}_{d}"], fx[f"y_{n}_{d}"], fx[f"H_{n}_{d}"], fx[f"nll_{n}_{d}"]
+        want = np.array([oracle.negative_loglikelihood(h, Xn, y) for h in H])
+        ok = np.isfinite(golden)
+        assert np.array_equal(np.isfinite(want), ok) and np.allclose(want[ok], golden[ok], rtol=1e-11, atol=1e-11)
+        m = GP([lambda u, noise=0: 0.0])
+        m.kernel, m.nx_dim, m.n_point = "RBF", d, n
+        host = np.array([m.negative_loglikelihood(h, Xn, y[:, None]) for h in H])
+        assert np.allclose(host[ok], want[ok], rtol=1e-11, atol=1e-11)
 
 
 def test_nll_matches_direct_formula():
@@ -196,23 +214,25 @@ def test_goose_methods_follow_oracle():
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,d", [(4, 2), (20, 2), (45, 2), (128, 4), (300, 3)])
 def test_device_nll_matches_host_objective(engine, n, d):
-    """sbo_nll_batch against the NumPy objective (models/GP_Safe.py:169-192) over a population inside the
-    reference's search box (:205-206), plus a member that is not positive definite in floating point."""
-    rng = np.random.default_rng(n)
-    X = rng.uniform(-1, 1, size=(n, d))
-    m = GP([lambda u, noise=0: 0.0])
-    m.kernel, m.nx_dim, m.n_point = "RBF", d, n
-    Xn = (X - X.mean(0)) / X.std(0)
-    y = np.sin(Xn.sum(1))[:, None]
-    y = (y - y.mean()) / y.std()
-    H = np.column_stack([rng.uniform(-1.5, 1.5, size=(40, d + 1)), rng.uniform(-5.0, -2.0, size=40)])
-    got = engine.nll_batch(Xn, y[:, 0], H)
-    want = np.array([m.negative_loglikelihood(h, Xn, y) for h in H])
+    """sbo_nll_batch against the oracle's restatement of the reference objective (oracle.negative_loglikelihood,
+    models/GP_Safe.py:169-192) and against the committed fixture tests/golden/nll_population.npz (made by
+    tests/golden/make_golden.py from the same oracle): a population inside the reference's search box (:205-206)."""
+    import oracle
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nll_population.npz"))
+    Xn, y, H, golden = fx[f"X_{n}_{d}"], fx[f"y_{n}_{d}"], fx[f"H_{n}_{d}"], fx[f"nll_{n}_{d}"]
+    got = engine.nll_batch(Xn, y, H)
+    want = np.array([oracle.negative_loglikelihood(h, Xn, y) for h in H])
     ok = np.isfinite(want)
     assert ok.sum() >= 35
-    assert np.allclose(got[ok], want[ok], rtol=1e-9, atol=1e-9)
+    assert np.allclose(want[ok], golden[ok], rtol=1e-11, atol=1e-11)          # the oracle against its fixture
+    assert np.allclose(got[ok], golden[ok], rtol=1e-9, atol=1e-9)             # the device against the fixture
+    # and the host class's own objective (what SciPy's DE calls when the fit stays on the host) is the same function
+    m = GP([lambda u, noise=0: 0.0])
+    m.kernel, m.nx_dim, m.n_point = "RBF", d, n
+    host = np.array([m.negative_loglikelihood(h, Xn, y[:, None]) for h in H])
+    assert np.allclose(host[ok], want[ok], rtol=1e-11, atol=1e-11)
     with pytest.raises(ValueError):
-        engine.nll_batch(Xn, y[:, 0], H[:, :-1])
+        engine.nll_batch(Xn, y, H[:, :-1])
 
 
 @pytest.mark.gpu

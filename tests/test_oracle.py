@@ -9,7 +9,7 @@ import pytest
 import oracle
 from safebo_amd import synthetic
 
-GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if "contour_reference" not in p)
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if "contour_reference" not in p and "nll_population" not in p)
 
 
 def _small(n=12, d=2, q=2, seed=3):
