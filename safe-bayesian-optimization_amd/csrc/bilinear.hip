@@ -118,7 +118,8 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 template <int S>
 __global__ __launch_bounds__(256) void k_bstage1(const double* __restrict__ A, size_t a_stride_o, const double* __restrict__ Bf,
                                                  size_t b_stride_o, int KB, int nrb, int ncs, double* __restrict__ out,
-                                                 size_t out_stride_o) {
+                                                 size_t out_stride_o, const int* __restrict__ eff /* nullptr, or the Chebyshev core's
+                                                 per-output counts: [4 o + 1] strips to produce, [4 o + 2] k-blocks to run */) {
   __shared__ double Bs[2][4 * S * 64];          // [buffer][(kk S + s) 64 + lane]
   // A: a wave's 16 x 16 block image goes through LDS too.  Read straight from memory, a fragment load has the four
   // lanes of a quad fetch the same 32 bytes (8 KB of lane traffic for a 2 KB image per k-block, which is what the
@@ -129,6 +130,8 @@ __global__ __launch_bounds__(256) void k_bstage1(const double* __restrict__ A, s
   const int lane = tid & 63, wave = tid >> 6;
   const int rb = blockIdx.y * 4 + wave, rbl = rb < nrb ? rb : nrb - 1;
   const int cs0 = blockIdx.x * S;
+  const int KBrun = eff ? eff[4 * o + 2] : KB;            // (KB stays the layout's stride)
+  if (eff && cs0 >= eff[4 * o + 1]) return;               // strips behind the last degree that matters: never read
   const double* Ablk = A + (size_t)o * a_stride_o + (size_t)rbl * KB * 256 + lane * 4;   // this lane's 32 bytes of an image
   const double* Bo = Bf + (size_t)o * b_stride_o;
   // staging role: element e = tid + 256 j (j < S) of the k-block's [4][S][64] fragment set
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void k_bstage1(const double* __restrict__ A, s
   // one k-block: prefetch block kb + 1 (registers), multiply block kb out of LDS buffer CUR, park the prefetch in the
   // other buffer (its last readers passed the previous barrier).  Written twice so that the buffers are compile-time names.
   auto step = [&](int kb, const double* bs_cur, double* bs_nxt, const double* as_cur, double* as_nxt) {
-    const bool more = kb + 1 < KB;
+    const bool more = kb + 1 < KBrun;
     if (more) {
 #pragma unroll
       for (int j = 0; j < S; ++j) breg[j] = Bo[goff[j] + (size_t)(kb + 1) * 256];
@@ -175,9 +178,9 @@ __global__ __launch_bounds__(256) void k_bstage1(const double* __restrict__ A, s
     }
     __syncthreads();
   };
-  for (int kb = 0; kb < KB; kb += 2) {
+  for (int kb = 0; kb < KBrun; kb += 2) {
     step(kb, Bs[0], Bs[1], As[0][wave], As[1][wave]);
-    if (kb + 1 < KB) step(kb + 1, Bs[1], Bs[0], As[1][wave], As[0][wave]);
+    if (kb + 1 < KBrun) step(kb + 1, Bs[1], Bs[0], As[1][wave], As[0][wave]);
   }
   if (rb >= nrb) return;
   const int col_in = lane & 15, row_in = lane >> 4;
@@ -201,6 +204,8 @@ struct BlDims {                          // plan dimensions, by value
   int q, n, KBn;
   int r0[kMaxQ], r1[kMaxQ], rc0[kMaxQ], rc1[kMaxQ];
   int r0u, r1u, r0p, KB0, KB1, KBm, KBm2, ncs0, nrb, ncsR;
+  int K0m, K1m;                          // largest pair counts over the outputs (Chebyshev core: rows of the pair-coefficient matrices)
+  int D0m, D1m;                          // Chebyshev core: padded degrees (16 KB0, 16 KB1)
   long long cnt0, nlines;
   double a[2], b[2];                     // interval of each axis in normalised coordinates
   double sf2[kMaxQ];
@@ -1186,7 +1191,8 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
                                                   double* __restrict__ var_out, double* __restrict__ Lpart,
                                                   const double* __restrict__ xn0, uint8_t* __restrict__ Sfuse, uint8_t* __restrict__ Ufuse,
                                                   double bconf, unsigned long long* __restrict__ cpart /* [waves of output 1][kFuseRow] */,
-                                                  int o_base /* first output of this launch (split sweeps: constraints, then the objective) */) {
+                                                  int o_base /* first output of this launch (split sweeps: constraints, then the objective) */,
+                                                  const int* __restrict__ eff /* nullptr, or the Chebyshev core's k-steps of the variance phase at [4 o] */) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
   const int o = blockIdx.z + o_base;
   PostCtx cx;
@@ -1224,7 +1230,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   // (Tried: odd outputs running the three short phases first and the variance phase last, so that the two workgroups of a
   // CU do not reach their phase changes together -- no gain on config B, 2.5 % slower on H; one order for all.)
   d4_t acc[RB][8];
-  post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0);
+  post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, eff ? eff[4 * o] : KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0);
   post_phase<1, RB>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0);
   // phase 2 continues on phase 1's sums: only the V1 half (the first KSm k-steps) of the stacked operands is run
   post_phase<2, RB>(cx, VAo + (size_t)nrb * KBm * 256, SBo + (size_t)ncs * KBm * 256, KBm2, KSm, nullptr,
@@ -1267,6 +1273,200 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
 __global__ __launch_bounds__(256) void k_lmax_reduce(const double* __restrict__ Lpart, int per_out, unsigned long long* __restrict__ Lmax) {
   __shared__ double sh[4];
   lmax_reduce_body((int)blockIdx.x, sh, Lpart, per_out, Lmax);
+}
+
+// ---- Chebyshev core of the variance phase (r03) ---------------------------------------------------------------------------
+// The pair form above contracts  quad = sum_{k0, k1} T4[k0][k1] P0_k0(x0) P1_k1(x1)  over K = r (r + 1) / 2 ~ 276 pair products
+// per axis.  But the pair products are not independent functions: S_p is a Chebyshev series of degree < rc on the axis, so
+// every P_k = c S_p S_p' is a polynomial of degree <= 2 rc - 2, and quad is a polynomial of that degree in each variable --
+//     quad(x0, x1) = sum_{a < D0, b < D1} Chat[a][b] T_a(xi0) T_b(xi1),      Chat = PC0^T T4 PC1,
+// with PC[k][m] the Chebyshev coefficients of P_k (product formula T_a T_b = (T_{a+b} + T_|a-b|) / 2: exact, no sampling).
+// The same two GEMMs then run with the Chebyshev polynomials of the grid positions as operand tables (no dependence on the
+// data at all) and the inner dimensions D <= 2 rc - 1 = 95 instead of 276 -- and Chat decays: the variance surface of the
+// BASELINE hyper-parameters needs degree ~50 for 1e-15, so the kernels stop at the degree behind which every coefficient is
+// below 4e-15 of the largest (k_cheb_trunc writes the k-step / k-block counts per output; stage 1 and k_bpost read them from
+// memory: no host round trip).  Where the coefficients do not decay that far -- ill-conditioned models, whose Chat carries the
+// rounding of the reference formula itself -- nothing is dropped.
+// PC[job][k][m] = Chebyshev coefficient m of P_k, job = 2 o + axis; rows k >= K and columns m >= 2 rc - 1 are zero
+__global__ __launch_bounds__(256) void k_cheb_pairs(const BlDims dm, const double* __restrict__ Vsall, const double* __restrict__ sigall,
+                                                    size_t sPC0, size_t sPC1, double* __restrict__ PC0all, double* __restrict__ PC1all) {
+  const int job = blockIdx.y, o = job >> 1, axis = job & 1;
+  const int r = axis ? dm.r1[o] : dm.r0[o], rc = axis ? dm.rc1[o] : dm.rc0[o];
+  const int K = r * (r + 1) / 2, Km = axis ? dm.K1m : dm.K0m, Dm = axis ? dm.D1m : dm.D0m;
+  const double* Vs = Vsall + (size_t)job * kBlMaxR * kBlMaxRc;
+  const double* sig = sigall + (size_t)job * kBlMaxR;
+  double* PC = axis ? PC1all + (size_t)o * sPC1 : PC0all + (size_t)o * sPC0;
+  const long long total = (long long)Km * Dm;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / Dm), m = (int)(i % Dm);
+    double v = 0.0;
+    if (k < K && m <= 2 * rc - 2) {
+      int p, pp;
+      pair_of(k, r, p, pp);
+      const double* va = Vs + (size_t)p * rc;
+      const double* vb = Vs + (size_t)pp * rc;
+      // T_a T_b = (T_{a+b} + T_|a-b|) / 2
+      double s1 = 0.0, s2 = 0.0;
+      for (int a = (m - rc + 1 > 0 ? m - rc + 1 : 0); a <= m && a < rc; ++a) s1 += va[a] * vb[m - a];          // a + b = m
+      if (m == 0) {
+        for (int a = 0; a < rc; ++a) s2 += va[a] * vb[a];
+      } else {
+        for (int a = 0; a + m < rc; ++a) s2 += va[a + m] * vb[a] + va[a] * vb[a + m];                          // |a - b| = m
+      }
+      v = (p == pp ? 0.5 : 1.0) * (sig[p] * sig[pp]) * (s1 + s2);       // (1 | 2) * 1/2
+    }
+    PC[i] = v;
+  }
+}
+// T4 as a plain matrix [K0m][K1m] (the entries k_bl_t4f gathers, same formula)
+__global__ __launch_bounds__(256) void k_cheb_t4(const BlDims dm, const double* __restrict__ Gall, long long ldg, double* __restrict__ T4all,
+                                                 int sym) {
+  const int o = blockIdx.y, r0 = dm.r0[o], r1 = dm.r1[o];
+  const int K0 = r0 * (r0 + 1) / 2, K1 = r1 * (r1 + 1) / 2;
+  const double* G = Gall + (size_t)o * ldg * ldg;
+  double* T4 = T4all + (size_t)o * dm.K0m * dm.K1m;
+  const double scale = dm.sf2[o] * dm.sf2[o];
+  const long long total = (long long)dm.K0m * dm.K1m;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k0 = (int)(i / dm.K1m), k1 = (int)(i % dm.K1m);
+    double v = 0.0;
+    if (k0 < K0 && k1 < K1) {
+      int p, pp, s1, ss;
+      pair_of(k0, r0, p, pp);
+      pair_of(k1, r1, s1, ss);
+      const size_t a1 = (size_t)(p * r1 + s1), b1 = (size_t)(pp * r1 + ss), a2 = (size_t)(pp * r1 + s1), b2 = (size_t)(p * r1 + ss);
+      v = sym ? scale * 0.25 * ((G[a1 * ldg + b1] + G[b1 * ldg + a1]) + (G[a2 * ldg + b2] + G[b2 * ldg + a2]))
+              : scale * 0.5 * (G[a1 * ldg + b1] + G[a2 * ldg + b2]);
+    }
+    T4[i] = v;
+  }
+}
+// C = A^T B for small matrices, A [K][M], B [K][N] row-major (k-major); 32 x 32 outputs per workgroup, plain fp64 sums in
+// ascending k.  TRANS: C stored transposed ([N][M]).  blockIdx.z = output.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_small_tn(const double* __restrict__ Aall, size_t sA, const double* __restrict__ Ball, size_t sB, int K,
+                                                  int M, int N, double* __restrict__ Call, size_t sC) {
+  __shared__ double As[16][33], Bs[16][33];
+  const int o = blockIdx.z, tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const double* A = Aall + (size_t)o * sA;
+  const double* B = Ball + (size_t)o * sB;
+  double* C = Call + (size_t)o * sC;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int e = tid; e < 16 * 32; e += 256) {
+      const int kk = e >> 5, c = e & 31;
+      As[kk][c] = (k0 + kk < K && m0 + c < M) ? A[(size_t)(k0 + kk) * M + m0 + c] : 0.0;
+      Bs[kk][c] = (k0 + kk < K && n0 + c < N) ? B[(size_t)(k0 + kk) * N + n0 + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const double b = Bs[kk][tx];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += As[kk][ty + 8 * u] * b;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int m = m0 + ty + 8 * u, n = n0 + tx;
+    if (m < M && n < N) C[TRANS ? (size_t)n * M + m : (size_t)m * N + n] = acc[u];
+  }
+}
+// degrees the kernels run to, per output: behind them every |Chat| is below thr of the largest.  eff[4 o + 0] = k-steps of
+// the variance phase (axis 0, four degrees each), [1] = its 16-blocks (strips of stage 1), [2] = 16-blocks of axis 1 (inner
+// dimension of stage 1), [3] = 0.  One workgroup per output.
+__global__ __launch_bounds__(256) void k_cheb_trunc(const BlDims dm, const double* __restrict__ Chat_all, double thr, int* __restrict__ eff) {
+  __shared__ double red[4];
+  __shared__ int redi[4][2];
+  const int o = blockIdx.x, tid = threadIdx.x, D0 = dm.D0m, D1 = dm.D1m;
+  const double* Ch = Chat_all + (size_t)o * D0 * D1;
+  double mx = 0.0;
+  for (int i = tid; i < D0 * D1; i += 256) { const double v = fabs(Ch[i]); mx = v > mx ? v : mx; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const double y = __shfl_xor(mx, off); mx = y > mx ? y : mx; }
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  const double cut = thr * mx;
+  int a_hi = 0, b_hi = 0;                          // 1 + largest index holding an entry above the cut
+  for (int i = tid; i < D0 * D1; i += 256) {
+    if (fabs(Ch[i]) > cut) {
+      const int a = i / D1, b = i % D1;
+      a_hi = a + 1 > a_hi ? a + 1 : a_hi;
+      b_hi = b + 1 > b_hi ? b + 1 : b_hi;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int ya = __shfl_xor(a_hi, off), yb = __shfl_xor(b_hi, off);
+    a_hi = ya > a_hi ? ya : a_hi;
+    b_hi = yb > b_hi ? yb : b_hi;
+  }
+  if ((tid & 63) == 0) { redi[tid >> 6][0] = a_hi; redi[tid >> 6][1] = b_hi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) { a_hi = redi[w][0] > a_hi ? redi[w][0] : a_hi; b_hi = redi[w][1] > b_hi ? redi[w][1] : b_hi; }
+    a_hi = a_hi < 1 ? 1 : a_hi;
+    b_hi = b_hi < 1 ? 1 : b_hi;
+    eff[4 * o + 0] = (a_hi + 3) / 4;
+    eff[4 * o + 1] = (a_hi + 15) / 16;
+    eff[4 * o + 2] = (b_hi + 15) / 16;
+    eff[4 * o + 3] = 0;
+  }
+}
+// Chat [D0m][D1m] -> the B fragments of stage 1 (T4f layout: k = axis-1 degree, column = axis-0 degree)
+__global__ __launch_bounds__(256) void k_cheb_t4f(const BlDims dm, const double* __restrict__ Chat_all, size_t sT4f, double* __restrict__ T4fall) {
+  const int o = blockIdx.y, KB0 = dm.KB0, KB1 = dm.KB1;
+  const double* Ch = Chat_all + (size_t)o * dm.D0m * dm.D1m;
+  double* T4f = T4fall + (size_t)o * sT4f;
+  const long long total = (long long)KB0 * KB1 * 4 * 64;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const long long fr = i >> 6;
+    const int ks = (int)(fr % (KB1 * 4)), cs = (int)(fr / (KB1 * 4));
+    const int k1 = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
+    const int k0 = cs * 16 + (l & 15);
+    T4f[i] = Ch[(size_t)k0 * dm.D1m + k1];
+  }
+}
+// Chebyshev polynomials of the grid positions in the operand layouts of the two GEMMs (k_bl_pairs' layouts): FRAG 1: B
+// fragments [ncs0][KB0 * 4][64] of axis 0; FRAG 0: A images [nrb][KB1][256] of axis 1.  A thread per position walks the
+// three-term recurrence once (the argument exactly as k_bl_stab forms it); the same table serves every output.
+template <int FRAG>
+__global__ __launch_bounds__(256) void k_cheb_tab(const BlDims dm, const double* __restrict__ xn, double* __restrict__ out) {
+  const int KB = FRAG ? dm.KB0 : dm.KB1, nblk = FRAG ? dm.ncs0 : dm.nrb;
+  const long long count = FRAG ? dm.cnt0 : dm.nlines;
+  const double a = dm.a[FRAG ? 0 : 1], b = dm.b[FRAG ? 0 : 1];
+  for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < (long long)nblk * 16; x += (long long)gridDim.x * blockDim.x) {
+    double xi = 0.0;
+    if (x < count) {
+      xi = (2.0 * xn[x] - (a + b)) / (b - a);
+      xi = xi < 1.0 ? xi : 1.0;
+      xi = xi > -1.0 ? xi : -1.0;
+    }
+    double t0 = 1.0, t1 = xi;
+    for (int k = 0; k < KB * 16; ++k) {
+      double v = k == 0 ? t0 : t1;
+      if (k >= 2) {
+        v = 2.0 * xi * t1 - t0;
+        t0 = t1;
+        t1 = v;
+      }
+      if (x >= count) v = 0.0;
+      size_t idx;
+      if (FRAG) {
+        // fragment (strip = x / 16, k-step ks = k / 4 ... ): element of k-block kb = k / 16 with jslot(kk, slot) = k % 16
+        const int kb = k >> 4, j = k & 15, kk = j >> 2, slot = j & 3;      // MM<double>::jslot(kk, slot) = 4 kk + slot
+        idx = (((size_t)(x >> 4) * (KB * 4) + (size_t)(kb * 4 + kk)) << 6) + (size_t)(slot * 16 + (x & 15));
+      } else {
+        const int kb = k >> 4, j = k & 15, kk = j >> 2, slot = j & 3;
+        idx = (((size_t)(x >> 4) * KB + kb) << 8) + (size_t)MM<double>::pack_pos((int)(x & 15), slot, kk);
+      }
+      out[idx] = v;
+    }
+  }
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------
@@ -1453,7 +1653,7 @@ int bilinear_setup(sbo_ctx* c) {
   lap("bases");
   BlDims dm;
   memset(&dm, 0, sizeof(dm));
-  int r0u = 0, r1u = 0, K0 = 0, K1 = 0, Rmax = 0;
+  int r0u = 0, r1u = 0, K0 = 0, K1 = 0, Rmax = 0, rc0m = 0, rc1m = 0;
   for (int o = 0; o < q; ++o) {
     if (inf[8 * o] != 1 || inf[8 * o + 4] != 1) return SBO_OK;    // a basis did not qualify
     dm.r0[o] = inf[8 * o + 1]; dm.rc0[o] = inf[8 * o + 2];
@@ -1464,12 +1664,19 @@ int bilinear_setup(sbo_ctx* c) {
     K0 = std::max(K0, bl::pair_count(dm.r0[o]));
     K1 = std::max(K1, bl::pair_count(dm.r1[o]));
     Rmax = std::max(Rmax, dm.r0[o] * dm.r1[o]);
+    rc0m = std::max(rc0m, dm.rc0[o]);
+    rc1m = std::max(rc1m, dm.rc1[o]);
     dm.sf2[o] = mc.sf2[o];
     pl.r0[o] = dm.r0[o];
     pl.r1[o] = dm.r1[o];
     if (timing) fprintf(stderr, "[K1b setup] output %d: r0 %d (degree %d), r1 %d (degree %d)%s\n", o, dm.r0[o], dm.rc0[o], dm.r1[o], dm.rc1[o],
                         c->bl_host_bases ? "  [host bases]" : "");
   }
+  // inner dimensions of the two GEMMs of the variance phase: pair products (K = r (r + 1) / 2), or -- Chebyshev core, r03 -- the
+  // degrees of quad as a polynomial of the axis (D = 2 rc - 1, cut on the device where its coefficients have decayed)
+  const bool cheb = c->cheb_core != 0;
+  const int K0m = K0, K1m = K1;
+  if (cheb) { K0 = 2 * rc0m - 1; K1 = 2 * rc1m - 1; }
   const int KB0 = (K0 + 15) / 16, KB1 = (K1 + 15) / 16;
   const int ncs0 = (int)((cnt0 + 15) / 16), nrb = (int)((nlines + 15) / 16);
   {
@@ -1480,8 +1687,10 @@ int bilinear_setup(sbo_ctx* c) {
   }
   const long long nlines_pad = (long long)nrb * 16;
   pl.KB0 = KB0; pl.KB1 = KB1; pl.r0u = r0u; pl.ncs0 = ncs0; pl.nrb = nrb; pl.nlines_pad = nlines_pad;
-  pl.sP0f = (size_t)ncs0 * KB0 * 4 * 64;
-  pl.sP1A = (size_t)nrb * KB1 * 256;
+  pl.cheb = cheb;
+  pl.sP0f = cheb ? 0 : (size_t)ncs0 * KB0 * 4 * 64;        // (Chebyshev core: one table of polynomials for every output)
+  pl.sP1A = cheb ? 0 : (size_t)nrb * KB1 * 256;
+  const size_t nP0f = (size_t)ncs0 * KB0 * 4 * 64, nP1A = (size_t)nrb * KB1 * 256;
   pl.sT4f = (size_t)KB0 * KB1 * 4 * 64;
   pl.sBtA = (size_t)nrb * KB0 * 256;
   // mean phases: K = r0p (basis size rounded to whole k-steps); the axis-0 gradient phase concatenates two such operands
@@ -1490,11 +1699,15 @@ int bilinear_setup(sbo_ctx* c) {
   pl.KBm = KBm;
   pl.KBm2 = KBm2;
   pl.KSm = r0p / 4;
-  pl.KS0 = (K0 + 3) / 4;
+  pl.KS0 = cheb ? KB0 * 4 : (K0 + 3) / 4;
   pl.sVA = (size_t)nrb * (2 * KBm + KBm2) * 256;     // image sets  V0 | [V1; V0] | V1x
   pl.sSBf = (size_t)ncs0 * (KBm + KBm2) * 256;      // fragment sets  S0 | [S0; -xn0 S0]
-  if ((rc = ensure(c->bl_P0f, sizeof(double) * pl.sP0f * q))) return rc;
-  if ((rc = ensure(c->bl_P1A, sizeof(double) * pl.sP1A * q))) return rc;
+  if ((rc = ensure(c->bl_P0f, sizeof(double) * nP0f * (cheb ? 1 : q)))) return rc;
+  if ((rc = ensure(c->bl_P1A, sizeof(double) * nP1A * (cheb ? 1 : q)))) return rc;
+  // Chebyshev core scratch: PC0 | PC1 | T4 plain | Y^T | Chat | eff (ints)
+  const size_t D0m = (size_t)KB0 * 16, D1m = (size_t)KB1 * 16;
+  const size_t nPC0 = (size_t)K0m * D0m, nPC1 = (size_t)K1m * D1m, nT4p = (size_t)K0m * K1m, nYt = (size_t)K1m * D0m, nCh = D0m * D1m;
+  if (cheb && (rc = ensure(c->bl_cheb, sizeof(double) * (size_t)q * (nPC0 + nPC1 + nT4p + nYt + nCh) + 256))) return rc;
   if ((rc = ensure(c->bl_T4f, sizeof(double) * pl.sT4f * q))) return rc;
   if ((rc = ensure(c->bl_SBf, sizeof(double) * pl.sSBf * q))) return rc;     // mean-phase B fragments
   if ((rc = ensure(c->bl_VA, sizeof(double) * pl.sVA * q))) return rc;      // mean-phase A images
@@ -1507,6 +1720,7 @@ int bilinear_setup(sbo_ctx* c) {
   const size_t oS0 = (size_t)cnt0 + (size_t)nlines, oS1 = oS0 + (size_t)q * r0u * cnt0, oMb = oS1 + (size_t)q * r1u * nlines,
                oVb = oMb + (size_t)q * 3 * r0u * r1u, oEnd = oVb + (size_t)q * 3 * r0u * nlines;
   if ((rc = ensure(c->bl_small, sizeof(double) * oEnd))) return rc;
+  dm.K0m = K0m; dm.K1m = K1m; dm.D0m = (int)D0m; dm.D1m = (int)D1m;
   dm.q = q; dm.n = n; dm.KBn = KBn;
   dm.r0u = r0u; dm.r1u = r1u; dm.r0p = r0p; dm.KB0 = KB0; dm.KB1 = KB1; dm.KBm = KBm; dm.KBm2 = KBm2;
   dm.ncs0 = ncs0; dm.nrb = nrb; dm.ncsR = ncsR; dm.cnt0 = cnt0; dm.nlines = nlines;
@@ -1534,8 +1748,13 @@ int bilinear_setup(sbo_ctx* c) {
                      cnt0, line0, nlines, dxn0, dxn1);
   hipLaunchKernelGGL(k_bl_stab, blocks((size_t)std::max(r0u * cnt0, r1u * nlines), 2 * uq), dim3(256), 0, ys, dm, dVs, dsig,
                      (const double*)dxn0, (const double*)dxn1, dS0, dS1);
-  hipLaunchKernelGGL((k_bl_pairs<1>), blocks(pl.sP0f, uq), dim3(256), 0, ys, dm, (const double*)dS0, pl.sP0f, (double*)c->bl_P0f.p);
-  hipLaunchKernelGGL((k_bl_pairs<0>), blocks(pl.sP1A, uq), dim3(256), 0, ys, dm, (const double*)dS1, pl.sP1A, (double*)c->bl_P1A.p);
+  if (cheb) {
+    hipLaunchKernelGGL((k_cheb_tab<1>), dim3((unsigned)((ncs0 * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn0, (double*)c->bl_P0f.p);
+    hipLaunchKernelGGL((k_cheb_tab<0>), dim3((unsigned)((nrb * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn1, (double*)c->bl_P1A.p);
+  } else {
+    hipLaunchKernelGGL((k_bl_pairs<1>), blocks(nP0f, uq), dim3(256), 0, ys, dm, (const double*)dS0, pl.sP0f, (double*)c->bl_P0f.p);
+    hipLaunchKernelGGL((k_bl_pairs<0>), blocks(nP1A, uq), dim3(256), 0, ys, dm, (const double*)dS1, pl.sP1A, (double*)c->bl_P1A.p);
+  }
   // mean phases: Mb (forms of alpha, alpha Xn_0, alpha Xn_1) -> Vb = Mb S1 -> A images [V0 | V1;V0 | V1x], B fragments
   // [S0 | S0;-xn0 S0]
   hipLaunchKernelGGL(k_bl_mb, blocks((size_t)3 * r0u * r1u * 64, uq), dim3(256), 0, ys, dm, dU, (const double*)c->alpha64.p,
@@ -1566,8 +1785,30 @@ int bilinear_setup(sbo_ctx* c) {
     hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
                        (const double*)CtA, nZf, (const double*)Cf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
   }
-  hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f, uq), dim3(256), 0, c->stream, dm, (const double*)G, (long long)ldg, pl.sT4f,
-                     (double*)c->bl_T4f.p, direct ? 1 : 0);
+  if (cheb) {
+    double* PC0 = (double*)c->bl_cheb.p;
+    double* PC1 = PC0 + (size_t)q * nPC0;
+    double* T4p = PC1 + (size_t)q * nPC1;
+    double* Yt = T4p + (size_t)q * nT4p;
+    double* Chat = Yt + (size_t)q * nYt;
+    int* eff = (int*)(Chat + (size_t)q * nCh);
+    hipLaunchKernelGGL(k_cheb_pairs, blocks(std::max(nPC0, nPC1), 2 * uq), dim3(256), 0, xs, dm, dVs, dsig, nPC0, nPC1, PC0, PC1);
+    hipLaunchKernelGGL(k_cheb_t4, blocks(nT4p, uq), dim3(256), 0, xs, dm, (const double*)G, (long long)ldg, T4p, direct ? 1 : 0);
+    // Y^T = (PC0^T T4)^T  [K1m][D0m];  Chat = Y PC1  [D0m][D1m]
+    hipLaunchKernelGGL((k_small_tn<true>), dim3((unsigned)((K1m + 31) / 32), (unsigned)((D0m + 31) / 32), uq), dim3(256), 0, xs, (const double*)PC0,
+                       nPC0, (const double*)T4p, nT4p, K0m, (int)D0m, K1m, Yt, nYt);
+    hipLaunchKernelGGL((k_small_tn<false>), dim3((unsigned)((D1m + 31) / 32), (unsigned)((D0m + 31) / 32), uq), dim3(256), 0, xs, (const double*)Yt,
+                       nYt, (const double*)PC1, nPC1, K1m, (int)D0m, (int)D1m, Chat, nCh);
+    hipLaunchKernelGGL(k_cheb_trunc, dim3(uq), dim3(256), 0, xs, dm, (const double*)Chat, c->cheb_tol, eff);
+    hipLaunchKernelGGL(k_cheb_t4f, blocks(pl.sT4f, uq), dim3(256), 0, xs, dm, (const double*)Chat, pl.sT4f, (double*)c->bl_T4f.p);
+    // (the counts also travel to the host, unwaited: the profile's flop count reads them after the next sweep's own sync)
+    SBO_HIP(hipMemcpyAsync(c->h_back + 5376, eff, sizeof(int) * 4 * q, hipMemcpyDeviceToHost, xs));
+    pl.eff = eff;
+  } else {
+    pl.eff = nullptr;
+    hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f, uq), dim3(256), 0, c->stream, dm, (const double*)G, (long long)ldg, pl.sT4f,
+                       (double*)c->bl_T4f.p, direct ? 1 : 0);
+  }
   if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
   SBO_HIP(hipGetLastError());
   lap("enqueue");
@@ -1587,7 +1828,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   constexpr int S1 = 3;
   hipLaunchKernelGGL((k_bstage1<S1>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256), 0,
                      c->stream, (const double*)c->bl_P1A.p, pl.sP1A, (const double*)c->bl_T4f.p, pl.sT4f, pl.KB1, pl.nrb, pl.KB0,
-                     (double*)c->bl_BtA.p, pl.sBtA);
+                     (double*)c->bl_BtA.p, pl.sBtA, (const int*)pl.eff);
   // stage 2 (fused): variance, mean, Lipschitz keys
   // (64 x 128 tiles when the 128 x 128 ones would not give every CU a workgroup)
   const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8);
@@ -1627,7 +1868,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                           pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
                           (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
                           fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                          (unsigned long long*)c->cpart.p, o_base);
+                          (unsigned long long*)c->cpart.p, o_base, (const int*)pl.eff);
   };
   c->split_done = false;
   if (split && c->lmax_defer) {
@@ -1650,6 +1891,20 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   // runs on the mean phase's sums; 16 x 16 x 4 steps, 2 flops per multiply-add)
   const double tiles2 = (double)pl.nrb * pl.ncs0, tiles1 = (double)pl.nrb * pl.KB0;
   c->last_k1_flops = (double)q * 2.0 * 1024.0 * (4.0 * tiles1 * pl.KB1 + tiles2 * (pl.KS0 + 3 * pl.KSm));
+  if (pl.eff) {
+    // Chebyshev core: the counts the kernels actually run to (k_cheb_trunc; copied to the pinned block when the plan was built --
+    // they have arrived long before a sweep's result is read: a plan build is followed by the sweep's own synchronisation
+    // before anyone asks for the profile).  Until then the upper bound above stands.
+    const int* he = (const int*)(c->h_back + 5376);
+    double f = 0.0;
+    bool ok = true;
+    for (int o = 0; o < q; ++o) {
+      const int ks = he[4 * o], kb0 = he[4 * o + 1], kb1 = he[4 * o + 2];
+      if (ks < 1 || ks > pl.KS0 || kb0 < 1 || kb0 > pl.KB0 || kb1 < 1 || kb1 > pl.KB1) { ok = false; break; }
+      f += 2.0 * 1024.0 * (4.0 * (double)pl.nrb * kb0 * kb1 + tiles2 * (ks + 3 * pl.KSm));
+    }
+    if (ok) c->last_k1_flops = f;
+  }
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }

@@ -53,6 +53,8 @@ struct BilinearPlan {
   size_t sP0f = 0, sP1A = 0, sT4f = 0, sBtA = 0;   // per-output strides (elements)
   int r0[kMaxQ] = {0}, r1[kMaxQ] = {0};
   double setup_ms = 0.0;
+  bool cheb = false;     // variance phase on the Chebyshev core (degrees as inner dimensions) instead of the pair products
+  int* eff = nullptr;    // device: per-output counts the kernels run to (k_cheb_trunc), nullptr for the pair form
 };
 
 }  // namespace sbo
@@ -94,10 +96,12 @@ struct sbo_ctx {
   bool factor_pending = false;     // the factor chain of the current model is (possibly) still running; ev_factor marks its end
   hipEvent_t ev_factor = nullptr, ev_w = nullptr;
   int chol_async = 1;
+  int cheb_core = 1;       // K1b variance phase: Chebyshev core (inner dimensions = polynomial degrees, cut where the coefficients have decayed); 0: pair products (round 2)
+  double cheb_tol = 4e-15; // ... relative size below which trailing coefficients are not run (option cheb_tol_e17, in units of 1e-17)
   int table_streams = 1;   // K1b plan build: the axis-table chain on the second stream beside the T4 GEMMs (0: one stream)
   int basis_reg = 1;       // K1b axis bases: residual rows of the pivot loop in registers (n <= 512, degree <= 64); 0: through LDS / memory (round 2)
   sbo::BilinearPlan bl;
-  sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work;
+  sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work, bl_cheb;
   sbo::DevBuf bl_basis;            // K1b: the 2 q axis bases (U, Chebyshev series, ranks) and the workspace of their kernel
   bool bl_basis_ok = false;        // bases enqueued for (bl_basis_serial, bl_basis_ab); their (ok, r, rc) records land at h_back + 4096
   unsigned long long bl_basis_serial = 0;

@@ -171,12 +171,45 @@ def test_basis_rows_in_registers_equal_the_lds_and_memory_forms(engine, cfg_name
     assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < 1e-12 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < 1e-12
 
 
+@pytest.mark.parametrize("cfg_name,n,count,ll", [("B", 128, [160, 96], None), ("H", 512, [96, 80], None), ("C", 256, [130, 70], None),
+                                                    ("B", 128, [96, 80], -1.4), ("B", 128, [96, 80], 1.2), ("H", 300, [64, 72], -1.0)])
+def test_chebyshev_core_equals_the_pair_form(engine, cfg_name, n, count, ll):
+    """Option cheb_core (default on): the variance phase of the GEMM posterior contracts over the degrees of quad as a
+    polynomial of the axes (Chat = PC0^T T4 PC1, inner dimension <= 2 rc - 1, cut on the device where the coefficients have
+    decayed below 4e-15 of the largest) instead of over the ~276 pair products.  Same function: mean identical, variance equal
+    to the pair form to rounding, both within the bar of the oracle -- BASELINE, short and long length scales, ragged tiles."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    ds = cfg["ds"]
+    if ll is not None:
+        h = ds["hypopt"].copy()
+        h[:2, :] = ll
+        ds = oracle.make_inference_dataset(cfg["X"], cfg["Y"], h)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    pts = oracle.grid_points(lo, hi, count)
+    engine.set_grid(lo, hi, count)
+    out, kern = {}, {}
+    try:
+        for core in (1, 0):
+            engine.set_option("cheb_core", core)
+            engine.set_model(ds)
+            out[core] = _check_posterior(engine, ds, pts, TOL64)
+            kern[core] = engine.profile()["posterior_kernel"]
+    finally:
+        engine.set_option("cheb_core", 1)
+    assert kern[1] == 4                   # (the pair form may decline a small grid with large bases: K1g is then the comparison)
+    ys = np.maximum(1.0, ds["Y_std"])
+    if kern[0] == 4:
+        assert np.array_equal(out[1][0], out[0][0])              # the mean phases are untouched
+    assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < 2e-12 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < 2e-12
+
+
 def test_bilinear_rank_range_and_declines(engine):
-    """Short length-scales need larger bases (r up to 64, inner dimension up to 2080): still the GEMM path when that is
-    cheaper than the O(n^2) contraction (n = 512 here), and still within tolerance.  Bases beyond 64 directions, grids on
-    which the GEMMs would not pay, and fp32 models stay on the separable-table kernel."""
+    """Short length-scales need larger bases (r up to 64) and higher degrees: still the GEMM path when that is cheaper than
+    the O(n^2) contraction, and still within tolerance -- with the Chebyshev core (inner dimension 2 rc - 1 <= 255 instead of up
+    to 2080 pair products) that now includes n = 128 at log ell = -1.5 on a small grid.  Bases beyond 64 directions and fp32
+    models stay on the separable-table kernel."""
     lo_count = [96, 80]
-    for cfg_name, n, shift, kernel in (("H", 512, -1.0, 4), ("B", 128, -1.0, 3), ("B", 128, -2.2, 3)):
+    for cfg_name, n, shift, kernel in (("H", 512, -1.0, 4), ("B", 128, -1.0, 4), ("B", 128, -2.2, 3)):
         cfg = synthetic.make_config(cfg_name, n=n)
         lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
         pts = oracle.grid_points(lo, hi, lo_count)
