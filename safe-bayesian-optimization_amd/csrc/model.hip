@@ -840,7 +840,6 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
   if ((rc = ensure(c->alpha64, sizeof(double) * (size_t)q * npad))) return rc;
   c->f_cap = n;
   c->a_ld = npad;
-  double* dF = (double*)c->Fplain.p;
   double* dalpha = (double*)c->alpha64.p;
   if ((rc = model_prep_t<T>(c, X_norm, Y_norm, w))) return rc;
   bool eager_basis = false;

@@ -1582,6 +1582,10 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   return SBO_OK;
 }
 
+template <typename T>
+static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* res);
+template <typename T>
+static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, double r, sbo_tr_result* res);
 #include "sets_recheck.inc.hpp"
 
 template <typename T, int D>
@@ -2091,7 +2095,7 @@ int sbo_sweep_safeopt(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_safeopt_result
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
   SBO_HIP(hipSetDevice(c->device));
   int rc;
-  if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model && !multi_rank(c))
+  if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model)
     rc = sweep_safeopt_f32_recheck(c, opts, result);
   else
     rc = c->dtype == SBO_F64 ? sweep_safeopt_t<double>(c, opts, result) : sweep_safeopt_t<float>(c, opts, result);
@@ -2105,7 +2109,11 @@ int sbo_sweep_goose(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_goose_result* re
   if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
   SBO_HIP(hipSetDevice(c->device));
-  const int rc = c->dtype == SBO_F64 ? sweep_goose_t<double>(c, opts, result) : sweep_goose_t<float>(c, opts, result);
+  int rc;
+  if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model && !multi_rank(c))
+    rc = sweep_goose_f32_recheck(c, opts, result);
+  else
+    rc = c->dtype == SBO_F64 ? sweep_goose_t<double>(c, opts, result) : sweep_goose_t<float>(c, opts, result);
   if (rc != SBO_OK && rc != SBO_E_EMPTY_SAFE_SET) drain_streams(c);
   return rc;
 }
@@ -2117,6 +2125,8 @@ int sbo_sweep_tr(sbo_ctx* c, const sbo_sweep_opts* opts, const double* x_0, doub
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
   if (!(r >= 0.0)) return fail(SBO_E_INVALID, "trust-region radius must be >= 0");
   SBO_HIP(hipSetDevice(c->device));
+  if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model && !multi_rank(c))
+    return sweep_tr_f32_recheck(c, opts, x_0, r, result);
   return c->dtype == SBO_F64 ? sweep_tr_t<double>(c, opts, x_0, r, result) : sweep_tr_t<float>(c, opts, x_0, r, result);
 }
 

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_rc_flag(const float* __restrict__ mean,
       bool ps, ss, un;
       rc_safety(mean, var, n, g, q, b, bd, ps, ss, un);
       flag = un || (all_possibly_safe && ps && q > 1);
-      if (ps) {
+      if (ps && all_possibly_safe != 2) {
         double ll, lh, ul, uh;
         rc_interval(mean[g], var[g], b, bd.dm[0], bd.dv[0], ll, lh, ul, uh);
         const bool maybe_m = ll <= u_hi;
@@ -283,7 +283,7 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
-  if (n == 0) return sweep_safeopt_t<float>(c, o, res);
+  if (n == 0 && !multi_rank(c)) return sweep_safeopt_t<float>(c, o, res);
   SBO_HIP(hipEventRecord(c->ev_join[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
@@ -321,7 +321,10 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
   for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
   const bool grid_expander = c->cs.kind == 1 && c->cs.first % plane == 0 && n % plane == 0;
   hipLaunchKernelGGL(k_rc_ustar, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc);
+  // (ranks > 1: the interval of u* and the variance guard are global quantities -- three keys through the collectives)
+  if ((rc = comm_allreduce_min_u64(c, &sc->ulo_key, 2))) return rc;
   hipLaunchKernelGGL(k_rc_vmax, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc);
+  if ((rc = comm_allreduce_max_u64(c, &sc->vmax_key, 1))) return rc;
   hipLaunchKernelGGL(k_rc_flag, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc, list, grid_expander ? 0 : 1);
   hipLaunchKernelGGL(k_rc_widen, dim3(nbk), dim3(256), 0, c->stream, m32, v32, (long long)q * n, (double*)c->rc_mean.p, (double*)c->rc_var.p);
   SBO_HIP(hipGetLastError());
@@ -377,13 +380,25 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
     const double* var0 = (const double*)c->rc_var.p;
     hipLaunchKernelGGL(k_rc_gmax, dim3(nbk, (unsigned)(q - 1)), dim3(256), 0, c->stream, G, var0, (const uint8_t*)c->rc_refined.p, n, bd.dv[0],
                        gkeys);
+    if ((rc = comm_allreduce_max_u64(c, gkeys, q - 1))) return rc;        // (the expanders' arg-max is over all ranks)
     hipLaunchKernelGGL(k_rc_gdefer, dim3(nbk, (unsigned)(q - 1)), dim3(256), 0, c->stream, G, var0, (const uint8_t*)c->rc_refined.p, n,
                        bd.dv[0], (const unsigned long long*)gkeys, list, count2);
     SBO_HIP(hipGetLastError());
     SBO_HIP(hipMemcpyAsync(hb, c->rc_list.p, 64, hipMemcpyDeviceToHost, c->stream));
     SBO_HIP(hipStreamSynchronize(c->stream));
     const long long nd = (long long)*(const unsigned long long*)(hb + kRcCount2);
-    if (nd == 0) break;
+    // (ranks > 1: every rank runs the set phase the same number of times -- its collectives are inside --, so "nothing deferred"
+    // is a global statement: the largest count over the ranks)
+    unsigned long long* dcount = (unsigned long long*)((char*)c->rc_list.p + kRcCount2 + 8);   // scratch word behind the counter
+    long long nd_all = nd;
+    if (multi_rank(c)) {
+      SBO_HIP(hipMemcpyAsync(dcount, hb + kRcCount2, 8, hipMemcpyHostToDevice, c->stream));
+      if ((rc = comm_allreduce_max_u64(c, dcount, 1))) return rc;
+      SBO_HIP(hipMemcpyAsync(hb + 56, dcount, 8, hipMemcpyDeviceToHost, c->stream));
+      SBO_HIP(hipStreamSynchronize(c->stream));
+      nd_all = (long long)*(const unsigned long long*)(hb + 56);
+    }
+    if (nd_all == 0) break;
     if ((size_t)nd > list_cap) return fail(SBO_E_HIP, "internal: refinement list overflow");
     // (every candidate is refined at most once, so the passes end; six without an end would be a defect, not a slow case)
     if (passes >= 6) return fail(SBO_E_UNSUPPORTED, "fp64 recheck: verdicts still deferred after 7 passes of the set phase");
@@ -402,5 +417,239 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
   const double nn = c->mc.n, dd = c->mc.d;
   c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
   (void)set_extra;
+  return rc;
+}
+
+// ---- GoOSE and trust-region sweeps of fp32 models (r03) -------------------------------------------------------------------------
+// Coarser than the SafeOpt scheme above, and sufficient: with constraints, EVERY possibly-safe candidate is re-evaluated in
+// fp64 (the sources of the optimistic sets are the expanders, whose radii ucb_c / L must be exact, and arg-min lcb_0 over S_t
+// wants every safe candidate's bound) together with the candidates whose S / U membership the fp32 bounds cannot decide; the
+// set phase then runs in fp64 arithmetic on exact values wherever a value enters a decision -- except the target, arg-min
+// lcb_0 over the optimistic sets O_c (unsafe candidates, not re-evaluated): its contenders are found from the intervals
+// afterwards, re-evaluated, and the set phase runs once more if there were any.  Without constraints (q = 1) only the
+// contenders of the one arg-min (over all candidates, or over the trust region's ball) are re-evaluated.
+// min over the (unrefined: widened) members of `mask` of the upper end of lcb_0 -> key;  refined entries count exactly
+__global__ __launch_bounds__(256) void k_rc_lmin(const double* __restrict__ m0, const double* __restrict__ v0, const uint8_t* __restrict__ refined,
+                                                 const uint8_t* __restrict__ mask /* nullptr: all */, int nmask, long long n, double b, double dm,
+                                                 double dv, unsigned long long* key) {
+  unsigned long long k = ~0ull;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    bool in = mask == nullptr;
+    for (int t = 0; t < nmask && !in; ++t) in = mask[(size_t)t * n + g] != 0;
+    if (!in) continue;
+    const double md = m0[g], vd = v0[g];
+    const double hi = refined[g] ? md - b * sqrt(vd) : (md + dm) - b * sqrt(fmax(0.0, vd - dv));
+    const unsigned long long kk = ord_key(hi);
+    k = kk < k ? kk : k;
+  }
+  k = block_ext_u64<false>(k);
+  if (threadIdx.x == 0) atomicMin(key, k);
+}
+// ... and the unrefined members whose lower end reaches it: they may hold the minimum
+__global__ __launch_bounds__(256) void k_rc_lflag(const double* __restrict__ m0, const double* __restrict__ v0, const uint8_t* __restrict__ refined,
+                                                  const uint8_t* __restrict__ mask, int nmask, long long n, double b, double dm, double dv,
+                                                  const unsigned long long* key, long long* __restrict__ list, unsigned long long* count) {
+  if (*key == ~0ull) return;
+  const double best_hi = ord_val(*key);
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    if (refined[g]) continue;
+    bool in = mask == nullptr;
+    for (int t = 0; t < nmask && !in; ++t) in = mask[(size_t)t * n + g] != 0;
+    if (!in) continue;
+    const double lo = (m0[g] - dm) - b * sqrt(v0[g] + dv);
+    if (lo <= best_hi) list[atomicAdd(count, 1ull)] = g;
+  }
+}
+// trust region without constraints: the ball as a byte mask (geometry: exact)
+template <int D>
+__global__ void k_rc_ball(const CandSpec cs, long long n, const double* __restrict__ x0, double r, uint8_t* __restrict__ out) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+    double x[D];
+    cand_coords<D>(cs, g, x);
+    double ss = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+      if (a < cs.d) { const double df = x[a] - x0[a]; ss = (a == 0) ? df * df : ss + df * df; }
+    out[g] = sqrt(ss) <= r;
+  }
+}
+
+struct RcView {                        // the context looks at the widened + refined fp64 posterior while the scope lives
+  sbo_ctx* c;
+  DevBuf keep_m, keep_v;
+  int keep_dtype;
+  bool keep_valid;
+  RcView(sbo_ctx* c_) : c(c_), keep_m(c_->mean), keep_v(c_->var), keep_dtype(c_->dtype), keep_valid(c_->posterior_valid) {
+    c->mean = c->rc_mean;
+    c->var = c->rc_var;
+    c->dtype = SBO_F64;
+    c->posterior_valid = true;
+  }
+  ~RcView() {
+    c->rc_mean = c->mean;
+    c->rc_var = c->var;
+    c->mean = keep_m;
+    c->var = keep_v;
+    c->dtype = keep_dtype;
+    c->posterior_valid = keep_valid;
+  }
+};
+
+// front end shared by the GoOSE / trust-region rechecks: fp32 posterior, widened copy, first refinement list (q > 1: every
+// possibly-safe or undecided candidate), fp64 Lipschitz keys.  Leaves the list buffers ready for further rounds.
+static int rc_front_all(sbo_ctx* c, const sbo_sweep_opts* o, RcBand& bd, long long* total) {
+  sbo_ctx* s = c->shadow;
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q;
+  int rc;
+  const bool reuse = o->posterior_ready && c->posterior_valid;
+  if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
+  c->k1_stop_attached = false;
+  memset(&bd, 0, sizeof(bd));
+  for (int i = 0; i < q; ++i) {
+    const double ys = std::max(1.0, c->mc.Y_std[i]);
+    bd.dm[i] = 1e-4 * ys;
+    bd.dv[i] = 1e-4 * ys * ys;
+  }
+  if ((rc = ensure(c->rc_list, kRcList + sizeof(long long) * (size_t)std::max<long long>(n, 1) * 2))) return rc;
+  if ((rc = ensure(c->rc_mean, sizeof(double) * (size_t)q * std::max<long long>(n, 1)))) return rc;
+  if ((rc = ensure(c->rc_var, sizeof(double) * (size_t)q * std::max<long long>(n, 1)))) return rc;
+  if ((rc = ensure(c->rc_refined, (size_t)std::max<long long>(n, 1)))) return rc;
+  RcScal* sc = (RcScal*)c->rc_list.p;
+  long long* list = (long long*)((char*)c->rc_list.p + kRcList);
+  SBO_HIP(hipMemsetAsync(c->rc_list.p, 0, kRcList, c->stream));
+  const RcScal init{~0ull, ~0ull, 0ull, 0};
+  SBO_HIP(hipMemcpyAsync(sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  SBO_HIP(hipMemsetAsync(c->rc_refined.p, 0, (size_t)std::max<long long>(n, 1), c->stream));
+  const float* m32 = (const float*)c->mean.p;
+  const float* v32 = (const float*)c->var.p;
+  const unsigned nbk = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));
+  *total = 0;
+  if (q > 1) {
+    // (ulo / uhi / vmax stay at their initial values: only the "undecided or possibly safe" rule of the flag pass fires)
+    hipLaunchKernelGGL(k_rc_flag, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc, list, 2);
+  }
+  hipLaunchKernelGGL(k_rc_widen, dim3(nbk), dim3(256), 0, c->stream, m32, v32, (long long)q * n, (double*)c->rc_mean.p, (double*)c->rc_var.p);
+  SBO_HIP(hipGetLastError());
+  unsigned char* hb = c->h_back + 5120;
+  SBO_HIP(hipMemcpyAsync(hb, sc, 64, hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  *total = ((const RcScal*)hb)->count;
+  if ((rc = rc_refine(c, list, *total))) return rc;
+  if (q > 1) {
+    SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
+    const unsigned nbg = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8));
+#define SBO_GRAD(DD)                                                                                                              \
+  hipLaunchKernelGGL(k_rc_grad64<DD>, dim3(nbg), dim3(256), 0, c->stream, s->mc, c->cs, (const double*)s->As.p, (const double*)s->sqA.p, \
+                     (const double*)s->alpha.p, (const double*)s->Xn.p, (unsigned long long*)c->Lmax.p)
+    switch (c->mc.dpad) {
+      case 2: SBO_GRAD(2); break;
+      case 4: SBO_GRAD(4); break;
+      default: SBO_GRAD(8); break;
+    }
+#undef SBO_GRAD
+    SBO_HIP(hipGetLastError());
+  }
+  return SBO_OK;
+}
+
+// contenders of arg-min lcb_0 over `mask` (nmask stacked byte masks, nullptr: every candidate): re-evaluated in fp64; returns
+// how many there were (0: the arg-min already rests on exact values)
+static int rc_argmin_contenders(sbo_ctx* c, const sbo_sweep_opts* o, const RcBand& bd, const uint8_t* mask, int nmask, long long* found) {
+  const long long n = c->cs.n_local;
+  int rc;
+  unsigned long long* key = (unsigned long long*)((char*)c->rc_list.p + kRcCount2 + 8);
+  unsigned long long* count2 = (unsigned long long*)((char*)c->rc_list.p + kRcCount2);
+  long long* list = (long long*)((char*)c->rc_list.p + kRcList);
+  const unsigned long long init[2] = {0ull, ~0ull};
+  SBO_HIP(hipMemcpyAsync(count2, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  const unsigned nbk = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));
+  const double* m0 = (const double*)c->rc_mean.p;
+  const double* v0 = (const double*)c->rc_var.p;
+  hipLaunchKernelGGL(k_rc_lmin, dim3(nbk), dim3(256), 0, c->stream, m0, v0, (const uint8_t*)c->rc_refined.p, mask, nmask, n, o->b, bd.dm[0], bd.dv[0], key);
+  hipLaunchKernelGGL(k_rc_lflag, dim3(nbk), dim3(256), 0, c->stream, m0, v0, (const uint8_t*)c->rc_refined.p, mask, nmask, n, o->b, bd.dm[0], bd.dv[0],
+                     (const unsigned long long*)key, list, count2);
+  SBO_HIP(hipGetLastError());
+  unsigned char* hb = c->h_back + 5120;
+  SBO_HIP(hipMemcpyAsync(hb, c->rc_list.p, 64, hipMemcpyDeviceToHost, c->stream));
+  SBO_HIP(hipStreamSynchronize(c->stream));
+  *found = (long long)*(const unsigned long long*)(hb + kRcCount2);
+  if ((rc = rc_refine(c, list, *found))) return rc;
+  return SBO_OK;
+}
+
+static int sweep_goose_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* res) {
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q;
+  if (n == 0) return sweep_goose_t<float>(c, o, res);
+  int rc;
+  SBO_HIP(hipEventRecord(c->ev_join[0], c->stream));
+  const bool reuse = o->posterior_ready && c->posterior_valid;
+  RcBand bd;
+  long long total = 0, more = 0;
+  if ((rc = rc_front_all(c, o, bd, &total))) return rc;
+  SBO_HIP(hipEventRecord(c->ev_join[1], c->stream));
+  sbo_sweep_opts o2 = *o;
+  o2.posterior_ready = 1;
+  o2.want_masks = 1;
+  if (q == 1) {
+    // arg-min lcb_0 over every candidate: its contenders, then one fp64 set phase
+    if ((rc = rc_argmin_contenders(c, o, bd, nullptr, 0, &more))) return rc;
+    total += more;
+    RcView view(c);
+    rc = sweep_goose_t<double>(c, &o2, res);
+  } else {
+    for (int pass = 0; pass < 3; ++pass) {
+      {
+        RcView view(c);
+        rc = sweep_goose_t<double>(c, &o2, res);
+      }
+      if (rc != SBO_OK) break;
+      // the target: arg-min lcb_0 over the union of the optimistic sets (members are unsafe candidates, so far fp32 values)
+      if ((rc = rc_argmin_contenders(c, o, bd, (const uint8_t*)c->maskO.p, q - 1, &more))) return rc;
+      total += more;
+      if (more == 0) break;
+    }
+  }
+  c->posterior_valid = c->posterior_valid || !reuse;
+  c->prof.fp64_rechecks = total;
+  c->prof.posterior_launches = reuse ? 0 : 1;
+  float t01 = 0;
+  (void)hipEventElapsedTime(&t01, c->ev_join[0], c->ev_join[1]);
+  c->prof.recheck_ms = t01;
+  return rc;
+}
+
+static int sweep_tr_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, double r, sbo_tr_result* res) {
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q;
+  if (n == 0) return sweep_tr_t<float>(c, o, x0, r, res);
+  int rc;
+  const bool reuse = o->posterior_ready && c->posterior_valid;
+  RcBand bd;
+  long long total = 0, more = 0;
+  if ((rc = rc_front_all(c, o, bd, &total))) return rc;
+  sbo_sweep_opts o2 = *o;
+  o2.posterior_ready = 1;
+  if (q == 1) {
+    // arg-min lcb_0 over the ball: the ball as a mask (exact geometry), then the contenders inside it
+    if ((rc = ensure(c->maskM, (size_t)n))) return rc;
+    double* dev_x0 = (double*)c->scal.p + 256;
+    SBO_HIP(hipMemcpyAsync(dev_x0, x0, sizeof(double) * c->cs.d, hipMemcpyHostToDevice, c->stream));
+    const unsigned nbk = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));
+    switch (c->mc.dpad) {
+      case 2: hipLaunchKernelGGL((k_rc_ball<2>), dim3(nbk), dim3(256), 0, c->stream, c->cs, n, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
+      case 4: hipLaunchKernelGGL((k_rc_ball<4>), dim3(nbk), dim3(256), 0, c->stream, c->cs, n, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
+      default: hipLaunchKernelGGL((k_rc_ball<8>), dim3(nbk), dim3(256), 0, c->stream, c->cs, n, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
+    }
+    if ((rc = rc_argmin_contenders(c, o, bd, (const uint8_t*)c->maskM.p, 1, &more))) return rc;
+    total += more;
+  }
+  {
+    RcView view(c);
+    rc = sweep_tr_t<double>(c, &o2, x0, r, res);
+  }
+  c->posterior_valid = c->posterior_valid || !reuse;
+  c->prof.fp64_rechecks = total;
   return rc;
 }

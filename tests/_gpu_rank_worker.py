@@ -21,16 +21,20 @@ def main():
     from safebo_amd import synthetic, distributed
 
     dist = distributed.init_from_env()
+    dtype = "f64"
+    if cfg_name.endswith(":f32"):                      # an fp32 model (library Cholesky), SafeOpt only: the fp64 recheck across ranks
+        cfg_name, dtype = cfg_name[:-4], "f32"
     cfg = synthetic.make_config(cfg_name, n=n)
     eng = safebo_amd.SweepEngine(0)
     distributed.join(eng, dist, relay=True)
-    eng.set_model(cfg["ds"], dtype="f64")
+    eng.set_model(cfg["ds"], dtype=dtype, use_invK=(dtype == "f64"))
     eng.set_grid_sharded(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
     res = eng.sweep_safeopt(b, want_masks=True)
+    res["fp64_rechecks"] = int(eng.profile()["fp64_rechecks"])
     masks = {k: eng.mask(k) for k in ("S", "U", "M")}
     masks.update({f"G{c}": eng.mask("G", c) for c in range(1, cfg["q"])})
     gres = None
-    if cfg["q"] > 1:
+    if cfg["q"] > 1 and dtype == "f64":
         try:
             gres = eng.sweep_goose(b, want_masks=True, posterior_ready=True)
             masks.update({f"O{c}": eng.mask("O", c) for c in range(1, cfg["q"])})

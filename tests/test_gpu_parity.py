@@ -623,6 +623,58 @@ def test_fp32_unconstrained_scattered_sweep_equals_the_fp64_oracle(engine):
     assert res["expander_best_c"] == 0
 
 
+@pytest.mark.parametrize("case", ["benoit_grid", "wo3_grid", "benoit_list", "rosen4_grid", "sines6_list"])
+def test_fp32_goose_and_trust_region_sweeps_equal_the_fp64_oracle(engine, case):
+    """GoOSE (models/GoOSE.py:63-119) and trust-region (models/GP_TR.py:43-51) sweeps of fp32 models: every possibly-safe
+    candidate (the sources of the optimistic sets need exact radii), every candidate whose S / U membership the fp32 bounds
+    cannot decide, and the contenders of the target's arg-min over the optimistic sets are re-evaluated in fp64; without
+    constraints only the contenders of the one arg-min.  S, U, O_c, the safe minimum, the targets, the explore index, L, and
+    the trust-region arg-min must be the fp64 oracle's."""
+    if case == "benoit_grid":
+        cfg, count, b, pts = synthetic.make_config("B", n=128), [96, 80], 3.0, None
+    elif case == "wo3_grid":
+        cfg, count, b, pts = synthetic.make_config("C", n=64), [72, 64], 2.0, None
+    elif case == "benoit_list":
+        cfg, count, b = synthetic.make_config("A", n=20), None, 3.0
+        pts = oracle.grid_points(cfg["bound"][:, 0], cfg["bound"][:, 1], [45, 40])
+    elif case == "rosen4_grid":
+        cfg, count, b, pts = synthetic.make_config("D", n=128), [10, 9, 8, 7], 0.5, None
+    else:
+        cfg, count, b = synthetic.make_config("E", n=300), None, 2.0
+        pts = synthetic.scattered_points(cfg, 20000).astype(np.float64)
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    q = cfg["q"]
+    engine.set_model(cfg["ds"], dtype="f32", use_invK=False)
+    if count is None:
+        engine.set_points(pts)
+    else:
+        pts = oracle.grid_points(lo, hi, count)
+        engine.set_grid(lo, hi, count)
+    ref = oracle.goose_sweep(pts, cfg["ds"], b)
+    assert not ref["empty_safe_set"]
+    g = engine.sweep_goose(b, want_masks=True)
+    assert engine.profile()["fp64_rechecks"] > 0
+    assert np.array_equal(engine.mask("S"), ref["S"]) and np.array_equal(engine.mask("U"), ref["U"])
+    for c in range(1, q):
+        assert np.array_equal(engine.mask("O", c), ref["O"][c - 1]), f"O{c}"
+    assert g["safe_min_index"] == ref["safe_min_index"] and g["safe_min_lcb"] == pytest.approx(ref["safe_min_lcb"], rel=1e-9, abs=1e-12)
+    if q > 1:
+        assert list(g["target_index_c"])[:q - 1] == list(ref["target_index_c"]) and g["target_index"] == ref["target_index"]
+        assert g["explore_index"] == ref["explore_index"] and g["choose_safe_min"] == ref["choose_safe_min"]
+        assert np.allclose(g["L"][:q], ref["L"], rtol=1e-9)
+    # trust region around the safe minimum: a ball that cuts through S
+    x0 = pts[ref["safe_min_index"]]
+    r = 0.25 * float(np.max(hi - lo))
+    tref = oracle.tr_sweep(pts, cfg["ds"], b, x0, r)
+    t = engine.sweep_tr(b, x0, r)
+    assert t["index"] == tref["index"] and t["lcb"] == pytest.approx(tref["lcb_min"], rel=1e-9, abs=1e-12)
+    assert (t["count_S"], t["count_T"]) == (int(tref["S"].sum()), int(tref["T"].sum()))
+    # and the sweeps a caller interleaves on one posterior stay consistent with each other
+    s_ = engine.sweep_safeopt(b, posterior_ready=True)
+    sref = oracle.safeopt_sweep(pts, cfg["ds"], b)
+    assert s_["minimizer_index"] == sref["minimizer_index"] and s_["count_S"] == int(sref["S"].sum())
+
+
 def test_fp32_sweep_without_recheck_follows_the_fp32_posterior(engine):
     """Option fp64_recheck = 0: the classification is a function of the fp32 posterior alone.  Against the fp64 oracle the
     masks may then differ, but only inside the band the fp32 posterior error can move a deciding bound across its threshold
@@ -1290,6 +1342,29 @@ def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_
     for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c"):
         assert g[k] == gref[k], k
     assert g["count_O"] == gref["count_O"].tolist() and g["target_index_c"] == gref["target_index_c"].tolist()
+
+
+@pytest.mark.parametrize("world,cfg_name,n,count,b", [(2, "B", 128, [96, 81], 3.0), (3, "C", 64, [72, 65], 2.0)])
+def test_multi_rank_fp32_sweep_with_fp64_recheck_equals_the_fp64_oracle(tmp_path, world, cfg_name, n, count, b):
+    """fp32 models across ranks: the interval of u* and the variance guards are global quantities (three keys through the
+    collectives), the undecided lists are per rank, and the number of set-phase passes is agreed on by all ranks -- every mask
+    and index of the sharded fp32 sweep must be the fp64 oracle's."""
+    port, out = _free_port(), str(tmp_path / "res.json")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), str(world), port, out, cfg_name + ":f32",
+                               str(n), json.dumps(count), str(b)]) for r in range(world)]
+    assert _wait_ranks(procs) == [0] * world
+    cfg = synthetic.make_config(cfg_name, n=n)
+    pts = oracle.grid_points(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    ref = oracle.safeopt_sweep(pts, cfg["ds"], b)
+    res = json.load(open(out))
+    parts = [np.load(out + f".rank{r}.npz") for r in range(world)]
+    for k in ("S", "U", "M"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), ref[k]), k
+    for c in range(1, cfg["q"]):
+        assert np.array_equal(np.concatenate([p[f"G{c}"] for p in parts]), ref["G"][c - 1]), f"G{c}"
+    assert res["minimizer_index"] == ref["minimizer_index"] and res["expander_index_c"][:cfg["q"] - 1] == [int(x) for x in ref["expander_index"]]
+    assert res["u_star"] == pytest.approx(ref["u_star"], rel=1e-10) and res["fp64_rechecks"] > 0
+    assert np.allclose(res["L"][:cfg["q"]], ref["L"], rtol=1e-9)
 
 
 @pytest.mark.parametrize("world,cfg_name,n,count,bs", [(2, "B", 128, [320, 600], [2.0, 2.0, 3.5, 3.5, 1.0]),
