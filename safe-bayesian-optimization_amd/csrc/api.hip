@@ -259,6 +259,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->posterior_valid = false;
     return SBO_OK;
   }
+  if (!strcmp(key, "exact_lazy")) {
+    c->exact_lazy = value < 0 || value > 2 ? 1 : (int)value;      // 2: the late-recheck path runs on every sweep (test)
+    return SBO_OK;
+  }
   if (!strcmp(key, "table_streams")) {
     c->table_streams = value ? 1 : 0;
     return SBO_OK;

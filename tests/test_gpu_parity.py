@@ -1187,6 +1187,24 @@ def test_shared_launch_path_with_plain_scans_and_short_last_axes(engine, count, 
         assert list(out["opt"][0]["expander_index_c"])[:1] == list(ref["expander_index"])
 
 
+@pytest.mark.parametrize("cfg_name,n,count", [("B", 128, [1100, 1024]), ("A", 20, [50, 50]), ("H", 300, [200, 144])])
+def test_late_exact_recheck_path_equals_the_eager_one(engine, cfg_name, n, count):
+    """One-constraint SafeOpt sweeps on one rank launch the exhaustive recheck of in-band candidates only when the result
+    block reports any (option exact_lazy, default 1).  The late path -- recheck, expanders' arg-max and finals once more --
+    forced on every sweep (exact_lazy = 2) must give what the eager launch order (exact_lazy = 0) gives."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    out = {}
+    try:
+        for lazy in (2, 1, 0):
+            engine.set_option("exact_lazy", lazy)
+            out[lazy] = _sweep_bundle(engine, cfg, cfg["b"], 2, goose=False)
+    finally:
+        engine.set_option("exact_lazy", 1)
+    _assert_same_bundle(out[2], out[0])
+    _assert_same_bundle(out[1], out[0])
+
+
 def test_two_lanes_of_constraints_equal_one_after_the_other(engine):
     """Models with two constraints on one rank: the per-constraint chains of a sweep (expander; GoOSE: + optimistic set)
     run on two streams with their own scratch and their own snapshot of the scalar block (option set_lanes, default on).
