@@ -1287,35 +1287,75 @@ __global__ __launch_bounds__(256) void k_lmax_reduce(const double* __restrict__ 
 // below 4e-15 of the largest (k_cheb_trunc writes the k-step / k-block counts per output; stage 1 and k_bpost read them from
 // memory: no host round trip).  Where the coefficients do not decay that far -- ill-conditioned models, whose Chat carries the
 // rounding of the reference formula itself -- nothing is dropped.
-// PC[job][k][m] = Chebyshev coefficient m of P_k, job = 2 o + axis; rows k >= K and columns m >= 2 rc - 1 are zero
+// PC[job][k][m] = Chebyshev coefficient m of P_k, job = 2 o + axis; rows k >= K and columns m >= 2 rc - 1 are zero.
+// One workgroup per pair: the two coefficient rows go to LDS once, a thread per degree m sums its two convolutions from
+// there (four independent partial sums each: read straight from memory, a thread waited out ~150 dependent loads, 21 us).
 __global__ __launch_bounds__(256) void k_cheb_pairs(const BlDims dm, const double* __restrict__ Vsall, const double* __restrict__ sigall,
                                                     size_t sPC0, size_t sPC1, double* __restrict__ PC0all, double* __restrict__ PC1all) {
-  const int job = blockIdx.y, o = job >> 1, axis = job & 1;
+  __shared__ double va[kBlMaxRc], vb[kBlMaxRc];
+  const int job = blockIdx.y, o = job >> 1, axis = job & 1, k = blockIdx.x, tid = threadIdx.x;
   const int r = axis ? dm.r1[o] : dm.r0[o], rc = axis ? dm.rc1[o] : dm.rc0[o];
   const int K = r * (r + 1) / 2, Km = axis ? dm.K1m : dm.K0m, Dm = axis ? dm.D1m : dm.D0m;
+  if (k >= (Km + 15) / 16 * 16) return;
+  // Output in the operand layouts of the two MFMA GEMMs that form Chat^T = (PC1^T T4^T) PC0:
+  //   axis 1: A images of PC1^T  [D1m / 16][KBp][256]   (row = degree m, inner index = pair k)
+  //   axis 0: B fragments of PC0 [D0m / 16][KBp * 4][64] (inner index = pair k, column = degree m)
+  double* PC = axis ? PC1all + (size_t)o * sPC1 : PC0all + (size_t)o * sPC0;
+  const int KBp = (Km + 15) / 16;
+  auto put = [&](int m, double v) {
+    const int kb = k >> 4, j = k & 15, kk = j >> 2, slot = j & 3;          // MM<double>::jslot(kk, slot) = 4 kk + slot
+    if (axis) PC[(((size_t)(m >> 4) * KBp + kb) << 8) + (size_t)MM<double>::pack_pos(m & 15, slot, kk)] = v;
+    else PC[(((size_t)(m >> 4) * (KBp * 4) + (size_t)(kb * 4 + kk)) << 6) + (size_t)(slot * 16 + (m & 15))] = v;
+  };
+  if (k >= K) {
+    for (int m = tid; m < Dm; m += blockDim.x) put(m, 0.0);
+    return;
+  }
   const double* Vs = Vsall + (size_t)job * kBlMaxR * kBlMaxRc;
   const double* sig = sigall + (size_t)job * kBlMaxR;
-  double* PC = axis ? PC1all + (size_t)o * sPC1 : PC0all + (size_t)o * sPC0;
-  const long long total = (long long)Km * Dm;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i / Dm), m = (int)(i % Dm);
+  int p, pp;
+  pair_of(k, r, p, pp);
+  for (int a = tid; a < rc; a += blockDim.x) {
+    va[a] = Vs[(size_t)p * rc + a];
+    vb[a] = Vs[(size_t)pp * rc + a];
+  }
+  __syncthreads();
+  const double scale = (p == pp ? 0.5 : 1.0) * (sig[p] * sig[pp]);       // (1 | 2) * 1/2
+  for (int m = tid; m < Dm; m += blockDim.x) {
     double v = 0.0;
-    if (k < K && m <= 2 * rc - 2) {
-      int p, pp;
-      pair_of(k, r, p, pp);
-      const double* va = Vs + (size_t)p * rc;
-      const double* vb = Vs + (size_t)pp * rc;
+    if (m <= 2 * rc - 2) {
       // T_a T_b = (T_{a+b} + T_|a-b|) / 2
-      double s1 = 0.0, s2 = 0.0;
-      for (int a = (m - rc + 1 > 0 ? m - rc + 1 : 0); a <= m && a < rc; ++a) s1 += va[a] * vb[m - a];          // a + b = m
-      if (m == 0) {
-        for (int a = 0; a < rc; ++a) s2 += va[a] * vb[a];
-      } else {
-        for (int a = 0; a + m < rc; ++a) s2 += va[a + m] * vb[a] + va[a] * vb[a + m];                          // |a - b| = m
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      const int a0 = m - rc + 1 > 0 ? m - rc + 1 : 0, a1 = m < rc - 1 ? m : rc - 1;      // a + b = m, both below rc
+      int a = a0;
+      for (; a + 3 <= a1; a += 4) {
+        s0 += va[a] * vb[m - a];
+        s1 += va[a + 1] * vb[m - a - 1];
+        s2 += va[a + 2] * vb[m - a - 2];
+        s3 += va[a + 3] * vb[m - a - 3];
       }
-      v = (p == pp ? 0.5 : 1.0) * (sig[p] * sig[pp]) * (s1 + s2);       // (1 | 2) * 1/2
+      for (; a <= a1; ++a) s0 += va[a] * vb[m - a];
+      if (m == 0) {
+        for (a = 0; a + 3 < rc; a += 4) {
+          s0 += va[a] * vb[a];
+          s1 += va[a + 1] * vb[a + 1];
+          s2 += va[a + 2] * vb[a + 2];
+          s3 += va[a + 3] * vb[a + 3];
+        }
+        for (; a < rc; ++a) s0 += va[a] * vb[a];
+      } else {
+        const int lim = rc - m;                                        // |a - b| = m
+        for (a = 0; a + 1 < lim; a += 2) {
+          s0 += va[a + m] * vb[a];
+          s1 += va[a] * vb[a + m];
+          s2 += va[a + 1 + m] * vb[a + 1];
+          s3 += va[a + 1] * vb[a + 1 + m];
+        }
+        for (; a < lim; ++a) { s0 += va[a + m] * vb[a]; s1 += va[a] * vb[a + m]; }
+      }
+      v = scale * ((s0 + s1) + (s2 + s3));
     }
-    PC[i] = v;
+    put(m, v);
   }
 }
 // T4 as a plain matrix [K0m][K1m] (the entries k_bl_t4f gathers, same formula)
@@ -1341,27 +1381,31 @@ __global__ __launch_bounds__(256) void k_cheb_t4(const BlDims dm, const double* 
     T4[i] = v;
   }
 }
-// C = A^T B for small matrices, A [K][M], B [K][N] row-major (k-major); 32 x 32 outputs per workgroup, plain fp64 sums in
-// ascending k.  TRANS: C stored transposed ([N][M]).  blockIdx.z = output.
+// C = A^T B for small matrices, A [K][M], B [K][N] row-major (k-major); 32 x 32 outputs per workgroup, 64-deep k tiles (the
+// 16-deep form waited out 18 load -> barrier round trips for K = 276: 40 us), plain fp64 sums in ascending k.  TRANS: C stored
+// transposed ([N][M]).  blockIdx.z = output.  rowmax / colmax (nullptr: none): max |C| of every row and column as bit
+// patterns (non-negative doubles order like their bits), for k_cheb_trunc.
 template <bool TRANS>
 __global__ __launch_bounds__(256) void k_small_tn(const double* __restrict__ Aall, size_t sA, const double* __restrict__ Ball, size_t sB, int K,
-                                                  int M, int N, double* __restrict__ Call, size_t sC) {
-  __shared__ double As[16][33], Bs[16][33];
+                                                  int M, int N, double* __restrict__ Call, size_t sC, unsigned long long* __restrict__ rowmax,
+                                                  unsigned long long* __restrict__ colmax) {
+  constexpr int KT = 64;
+  __shared__ double As[KT][33], Bs[KT][33];
   const int o = blockIdx.z, tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
   const double* A = Aall + (size_t)o * sA;
   const double* B = Ball + (size_t)o * sB;
   double* C = Call + (size_t)o * sC;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    for (int e = tid; e < 16 * 32; e += 256) {
+  for (int k0 = 0; k0 < K; k0 += KT) {
+    for (int e = tid; e < KT * 32; e += 256) {
       const int kk = e >> 5, c = e & 31;
       As[kk][c] = (k0 + kk < K && m0 + c < M) ? A[(size_t)(k0 + kk) * M + m0 + c] : 0.0;
       Bs[kk][c] = (k0 + kk < K && n0 + c < N) ? B[(size_t)(k0 + kk) * N + n0 + c] : 0.0;
     }
     __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll 16
+    for (int kk = 0; kk < KT; ++kk) {
       const double b = Bs[kk][tx];
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[u] += As[kk][ty + 8 * u] * b;
@@ -1371,29 +1415,38 @@ __global__ __launch_bounds__(256) void k_small_tn(const double* __restrict__ Aal
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int m = m0 + ty + 8 * u, n = n0 + tx;
-    if (m < M && n < N) C[TRANS ? (size_t)n * M + m : (size_t)m * N + n] = acc[u];
+    if (m < M && n < N) {
+      C[TRANS ? (size_t)n * M + m : (size_t)m * N + n] = acc[u];
+      if (rowmax) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(acc[u]));
+        atomicMax(&rowmax[(size_t)o * M + m], key);
+        atomicMax(&colmax[(size_t)o * N + n], key);
+      }
+    }
   }
 }
-// degrees the kernels run to, per output: behind them every |Chat| is below thr of the largest.  eff[4 o + 0] = k-steps of
-// the variance phase (axis 0, four degrees each), [1] = its 16-blocks (strips of stage 1), [2] = 16-blocks of axis 1 (inner
-// dimension of stage 1), [3] = 0.  One workgroup per output.
-__global__ __launch_bounds__(256) void k_cheb_trunc(const BlDims dm, const double* __restrict__ Chat_all, double thr, int* __restrict__ eff) {
-  __shared__ double red[4];
-  __shared__ int redi[4][2];
+// degrees the kernels run to, per output: behind them every |Chat| is below thr of the largest.  ChatT [D1m][D0m] row-major
+// (the GEMMs deliver the transpose).  eff[4 o + 0] = k-steps of the variance phase (axis 0, four degrees each), [1] = its
+// 16-blocks (strips of stage 1), [2] = 16-blocks of axis 1 (inner dimension of stage 1), [3] = 0.  One workgroup of 1024.
+__global__ __launch_bounds__(1024) void k_cheb_trunc(const BlDims dm, const double* __restrict__ ChatT_all, double thr, int* __restrict__ eff) {
+  __shared__ double red[16];
+  __shared__ int redi[16][2];
   const int o = blockIdx.x, tid = threadIdx.x, D0 = dm.D0m, D1 = dm.D1m;
-  const double* Ch = Chat_all + (size_t)o * D0 * D1;
+  const double* Ch = ChatT_all + (size_t)o * D0 * D1;
   double mx = 0.0;
-  for (int i = tid; i < D0 * D1; i += 256) { const double v = fabs(Ch[i]); mx = v > mx ? v : mx; }
+  for (int i = tid; i < D0 * D1; i += 1024) { const double v = fabs(Ch[i]); mx = v > mx ? v : mx; }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const double y = __shfl_xor(mx, off); mx = y > mx ? y : mx; }
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
-  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  mx = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) mx = red[w] > mx ? red[w] : mx;
   const double cut = thr * mx;
   int a_hi = 0, b_hi = 0;                          // 1 + largest index holding an entry above the cut
-  for (int i = tid; i < D0 * D1; i += 256) {
+  for (int i = tid; i < D0 * D1; i += 1024) {
     if (fabs(Ch[i]) > cut) {
-      const int a = i / D1, b = i % D1;
+      const int b = i / D0, a = i % D0;            // ChatT[b][a]
       a_hi = a + 1 > a_hi ? a + 1 : a_hi;
       b_hi = b + 1 > b_hi ? b + 1 : b_hi;
     }
@@ -1407,7 +1460,7 @@ __global__ __launch_bounds__(256) void k_cheb_trunc(const BlDims dm, const doubl
   if ((tid & 63) == 0) { redi[tid >> 6][0] = a_hi; redi[tid >> 6][1] = b_hi; }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w) { a_hi = redi[w][0] > a_hi ? redi[w][0] : a_hi; b_hi = redi[w][1] > b_hi ? redi[w][1] : b_hi; }
+    for (int w = 1; w < 16; ++w) { a_hi = redi[w][0] > a_hi ? redi[w][0] : a_hi; b_hi = redi[w][1] > b_hi ? redi[w][1] : b_hi; }
     a_hi = a_hi < 1 ? 1 : a_hi;
     b_hi = b_hi < 1 ? 1 : b_hi;
     eff[4 * o + 0] = (a_hi + 3) / 4;
@@ -1416,7 +1469,7 @@ __global__ __launch_bounds__(256) void k_cheb_trunc(const BlDims dm, const doubl
     eff[4 * o + 3] = 0;
   }
 }
-// Chat [D0m][D1m] -> the B fragments of stage 1 (T4f layout: k = axis-1 degree, column = axis-0 degree)
+// ChatT [D1m][D0m] -> the B fragments of stage 1 (T4f layout: k = axis-1 degree, column = axis-0 degree)
 __global__ __launch_bounds__(256) void k_cheb_t4f(const BlDims dm, const double* __restrict__ Chat_all, size_t sT4f, double* __restrict__ T4fall) {
   const int o = blockIdx.y, KB0 = dm.KB0, KB1 = dm.KB1;
   const double* Ch = Chat_all + (size_t)o * dm.D0m * dm.D1m;
@@ -1428,7 +1481,7 @@ __global__ __launch_bounds__(256) void k_cheb_t4f(const BlDims dm, const double*
     const int ks = (int)(fr % (KB1 * 4)), cs = (int)(fr / (KB1 * 4));
     const int k1 = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
     const int k0 = cs * 16 + (l & 15);
-    T4f[i] = Ch[(size_t)k0 * dm.D1m + k1];
+    T4f[i] = Ch[(size_t)k1 * dm.D0m + k0];
   }
 }
 // Chebyshev polynomials of the grid positions in the operand layouts of the two GEMMs (k_bl_pairs' layouts): FRAG 1: B
@@ -1706,7 +1759,11 @@ int bilinear_setup(sbo_ctx* c) {
   if ((rc = ensure(c->bl_P1A, sizeof(double) * nP1A * (cheb ? 1 : q)))) return rc;
   // Chebyshev core scratch: PC0 | PC1 | T4 plain | Y^T | Chat | eff (ints)
   const size_t D0m = (size_t)KB0 * 16, D1m = (size_t)KB1 * 16;
-  const size_t nPC0 = (size_t)K0m * D0m, nPC1 = (size_t)K1m * D1m, nT4p = (size_t)K0m * K1m, nYt = (size_t)K1m * D0m, nCh = D0m * D1m;
+  // (PC0 as B fragments [D0m / 16][KBp0 * 4][64], PC1^T as A images [D1m / 16][KBp1][256], T4^T as B fragments [KBp0][KBp1 * 4][64],
+  // Y' = PC1^T T4^T as A images [D1m / 16][KBp0][256], Chat^T [D1m][D0m] row-major)
+  const int KBp0 = (K0m + 15) / 16, KBp1 = (K1m + 15) / 16;
+  const size_t nPC0 = D0m * (size_t)KBp0 * 16, nPC1 = D1m * (size_t)KBp1 * 16, nT4p = (size_t)KBp0 * KBp1 * 256, nYt = D1m * (size_t)KBp0 * 16,
+               nCh = D0m * D1m;
   if (cheb && (rc = ensure(c->bl_cheb, sizeof(double) * (size_t)q * (nPC0 + nPC1 + nT4p + nYt + nCh) + 256))) return rc;
   if ((rc = ensure(c->bl_T4f, sizeof(double) * pl.sT4f * q))) return rc;
   if ((rc = ensure(c->bl_SBf, sizeof(double) * pl.sSBf * q))) return rc;     // mean-phase B fragments
@@ -1792,14 +1849,21 @@ int bilinear_setup(sbo_ctx* c) {
     double* Yt = T4p + (size_t)q * nT4p;
     double* Chat = Yt + (size_t)q * nYt;
     int* eff = (int*)(Chat + (size_t)q * nCh);
-    hipLaunchKernelGGL(k_cheb_pairs, blocks(std::max(nPC0, nPC1), 2 * uq), dim3(256), 0, xs, dm, dVs, dsig, nPC0, nPC1, PC0, PC1);
-    hipLaunchKernelGGL(k_cheb_t4, blocks(nT4p, uq), dim3(256), 0, xs, dm, (const double*)G, (long long)ldg, T4p, direct ? 1 : 0);
-    // Y^T = (PC0^T T4)^T  [K1m][D0m];  Chat = Y PC1  [D0m][D1m]
-    hipLaunchKernelGGL((k_small_tn<true>), dim3((unsigned)((K1m + 31) / 32), (unsigned)((D0m + 31) / 32), uq), dim3(256), 0, xs, (const double*)PC0,
-                       nPC0, (const double*)T4p, nT4p, K0m, (int)D0m, K1m, Yt, nYt);
-    hipLaunchKernelGGL((k_small_tn<false>), dim3((unsigned)((D1m + 31) / 32), (unsigned)((D0m + 31) / 32), uq), dim3(256), 0, xs, (const double*)Yt,
-                       nYt, (const double*)PC1, nPC1, K1m, (int)D0m, (int)D1m, Chat, nCh);
-    hipLaunchKernelGGL(k_cheb_trunc, dim3(uq), dim3(256), 0, xs, dm, (const double*)Chat, c->cheb_tol, eff);
+    // Chat^T = (PC1^T T4^T) PC0 on the matrix cores: PC1^T as A images and PC0 as B fragments straight out of k_cheb_pairs, T4^T
+    // as B fragments -- which is what k_bl_t4f writes for the pair form --; Y' = PC1^T T4^T comes out as A images (k_bgemm OMODE 0)
+    hipLaunchKernelGGL(k_cheb_pairs, dim3((unsigned)(std::max(KBp0, KBp1) * 16), 2 * uq), dim3(128), 0, xs, dm, dVs, dsig, nPC0, nPC1, PC0, PC1);
+    {
+      BlDims dp = dm;                    // (the pair form's block counts for the gather)
+      dp.KB0 = KBp0;
+      dp.KB1 = KBp1;
+      hipLaunchKernelGGL(k_bl_t4f, blocks(nT4p, uq), dim3(256), 0, xs, dp, (const double*)G, (long long)ldg, nT4p, T4p, direct ? 1 : 0);
+    }
+    const int nrbD1 = (int)(D1m / 16), ncsD0 = (int)(D0m / 16);
+    hipLaunchKernelGGL((k_bgemm<4, 0, 0>), dim3((unsigned)((KBp0 + 3) / 4), (unsigned)((nrbD1 + 3) / 4), uq), dim3(256), 0, xs, (const double*)PC1,
+                       nPC1, (const double*)T4p, nT4p, KBp1, nrbD1, KBp0, Yt, nYt, (double*)nullptr, 0ll);
+    hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsD0 + 3) / 4), (unsigned)((nrbD1 + 3) / 4), uq), dim3(256), 0, xs, (const double*)Yt,
+                       nYt, (const double*)PC0, nPC0, KBp0, nrbD1, ncsD0, Chat, nCh, (double*)nullptr, (long long)D0m);
+    hipLaunchKernelGGL(k_cheb_trunc, dim3(uq), dim3(1024), 0, xs, dm, (const double*)Chat, c->cheb_tol, eff);
     hipLaunchKernelGGL(k_cheb_t4f, blocks(pl.sT4f, uq), dim3(256), 0, xs, dm, (const double*)Chat, pl.sT4f, (double*)c->bl_T4f.p);
     // (the counts also travel to the host, unwaited: the profile's flop count reads them after the next sweep's own sync)
     SBO_HIP(hipMemcpyAsync(c->h_back + 5376, eff, sizeof(int) * 4 * q, hipMemcpyDeviceToHost, xs));
