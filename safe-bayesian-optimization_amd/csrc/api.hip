@@ -259,6 +259,12 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->posterior_valid = false;
     return SBO_OK;
   }
+  if (!strcmp(key, "post_rb")) {
+    if (value < 0 || value > 2) return fail(SBO_E_INVALID, "post_rb must be 0 (auto), 1 or 2");
+    c->post_rb = (int)value;
+    c->posterior_valid = false;
+    return SBO_OK;
+  }
   if (!strcmp(key, "exact_lazy")) {
     c->exact_lazy = value < 0 || value > 2 ? 1 : (int)value;      // 2: the late-recheck path runs on every sweep (test)
     return SBO_OK;

@@ -1903,7 +1903,11 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   // workgroups, so the 64 x 128 tiles are taken already when the 128 x 128 ones of the smaller launch number fewer than that.
   const bool split = c->split_request && q >= 2;
   const long long wgs_rb2 = (long long)gx * ((pl.nrb + 7) / 8);    // workgroups per output with 128 x 128 tiles
-  int rbw = wgs_rb2 * q < c->n_cu ? 1 : 2;
+  // (r03, Chebyshev core: the variance phase is 12 k-steps instead of 69 and no longer dominates; with four short phases the
+  // third workgroup per CU of the 64 x 128 form is worth more than the B-fragment reuse of the 128 x 128 one -- config B 0.204 ->
+  // 0.189 ms per sweep with the classification fused, H 0.547 -> 0.543)
+  int rbw = (pl.cheb || wgs_rb2 * q < c->n_cu) ? 1 : 2;
+  if (c->post_rb) rbw = c->post_rb;                       // (tuning option)
   if (split) rbw = c->split_rb ? c->split_rb : (wgs_rb2 < 2ll * c->n_cu ? 1 : 2);
   const size_t lds = sizeof(double) * 2 * (rbw == 2 ? 4096 : 3072);
   const unsigned gy = (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
