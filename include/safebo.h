@@ -270,7 +270,18 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  * the GEMM posterior's mean epilogue, with sign tests that need no square root: 1 always, 0 never, -1 default: when that launch has at least
  * four workgroups per CU), "k1_split" (1: sweeps of constrained models on the GEMM posterior of one rank run the constraints' outputs first
  * and the constraint-only part of their set phase on a second stream beside the objective's GEMM; identical results, measured slower: default 0;
- * "split_rb": tile height of those launches), "set_fuse" (1 default: on 2-D grids of one rank the
+ * "split_rb": tile height of those launches), "cheb_core" (1 default: the variance phase of the GEMM posterior contracts over the degrees
+ * of the quadratic form as a polynomial of the axes -- its 2-D Chebyshev coefficients, cut on the device where they have decayed below
+ * "cheb_tol_e17" x 1e-17 (default 400) of the largest -- instead of over the ~r^2/2 pair products of the basis functions; 0: pair form),
+ * "post_rb" (tile height of the fused posterior kernel: 0 auto, 1 = 64 x 128, 2 = 128 x 128), "chol_async" (1 default: a caller's invK on
+ * a grid the GEMM posterior takes is contracted as given and its reverse Cholesky factor -- needed by the O(n^2) kernels and
+ * sbo_model_append only -- is built on a side stream after sbo_model_set has returned; SBO_E_INVALID for an indefinite invK then comes
+ * from the first call that needs the factor), "chol_fused" (1 default: one launch per Cholesky panel), "basis_reg" (1 default: the axis
+ * bases' pivot loop keeps its residual rows in registers), "table_streams" (1 default: the GEMM posterior's tables are built as two
+ * chains on two streams), "exact_lazy" (1 default: one-constraint sweeps launch the exhaustive recheck of in-band expander verdicts only
+ * when the result block reports any; 2: that late path on every sweep, a test hook; 0: always launched), "halo_spec" (1 default: ranks > 1
+ * size their transform windows from the previous sweep's global keys, checked on the device -- no host wait inside a sweep),
+ * "comm_events" (1: an event pair around every collective, sbo_profile.comm_ms), "set_fuse" (1 default: on 2-D grids of one rank the
  * independent kernels of the set phase share launches; 0: one launch per kernel, same results), "dist_u16" (1 default: on that path the fine distance image holds 16-bit step counts instead of
  * squared distances as doubles -- same verdicts, a quarter of the bytes), "set_lanes" (1 default: on one rank the constraints of a sweep alternate between two
  * streams -- their expander / optimistic-set chains are independent --, 0: one after the other), "eager_tables" (1 default:
