@@ -259,6 +259,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->posterior_valid = false;
     return SBO_OK;
   }
+  if (!strcmp(key, "decide_wide")) {
+    c->decide_wide = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "post_rb")) {
     if (value < 0 || value > 2) return fail(SBO_E_INVALID, "post_rb must be 0 (auto), 1 or 2");
     c->post_rb = (int)value;

@@ -1194,7 +1194,14 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
   hipLaunchKernelGGL((k_edt_decide<T, LIST>), dgrid, dim3(256), 0, c->stream, (const double*)din, nl, (int)len0, goff / len0, goff, \
                      d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c, (T)o->b, (const uint8_t*)c->maskS.p,          \
                      (const unsigned long long*)c->Lmax.p, lidx, sc, G, (long long*)c->amb.p, cg, bmin, blk, slist, rx)
-      if (slist) SBO_DECIDE(true);
+      // (grids whose lines are whole 8-byte mask words: eight candidates per lane, see k_edt_decide8)
+      const bool wide = slist && c->decide_wide && len0 % 8 == 0 && d >= 2 && cg.enabled && ((uintptr_t)G & 7) == 0 &&
+                        ((uintptr_t)c->maskS.p & 7) == 0;
+      if (wide) {
+        const dim3 g8((unsigned)((len0 / 8 + 255) / 256), (unsigned)std::min<long long>(nl, 65535));
+        hipLaunchKernelGGL((k_edt_decide8<T>), g8, dim3(256), 0, c->stream, nl, (int)len0, goff / len0, goff, d, xscale, mean_c, var_c, (T)o->b,
+                           (const uint8_t*)c->maskS.p, (const unsigned long long*)c->Lmax.p, lidx, sc, G, cg, slist, rx);
+      } else if (slist) SBO_DECIDE(true);
       else SBO_DECIDE(false);
 #undef SBO_DECIDE
       // (workgroups of the list scan: 2048 on config B's 4 M candidates, 4096 on H's 16 M -- -8 us there)

@@ -127,10 +127,25 @@ __device__ __forceinline__ void edt_axis0_wg_body(int bid, int nblk, Axis0Lds& l
     const uint8_t* u = U + line * count0;
     double* d = D + line * count0;
     unsigned short* d16 = reinterpret_cast<unsigned short*>(D) + line * count0;     // (U16: the image holds step counts)
-    for (int w = wave; w < nwords; w += 4) {
-      const int i = w * 64 + lane;
-      const unsigned long long m = __ballot(i < count0 && (COARSE ? coarse_cell_any(U, cg, line * count0 + i) : u[i] != 0));
-      if (lane == 0) words[w] = m;
+    if (!COARSE && (count0 & 63) == 0 && (((uintptr_t)u) & 7) == 0) {
+      // fine lines of whole words (r03): a lane reads eight mask bytes at once and drops their eight bits into LDS as one byte
+      // of the word array (bit i of word w = position 64 w + i: little-endian bytes are exactly that order) -- 2 loads per lane
+      // for a 4096-long line instead of 16 single-byte loads and ballots
+      uint8_t* wb = reinterpret_cast<uint8_t*>(words);
+      for (int t = threadIdx.x; t < (count0 >> 3); t += blockDim.x) {
+        unsigned long long x = reinterpret_cast<const unsigned long long*>(u)[t];
+        x |= x >> 4;                         // any bit of a byte -> its bit 0 (the masks hold 0 / 1, but nothing relies on it)
+        x |= x >> 2;
+        x |= x >> 1;
+        x &= 0x0101010101010101ull;
+        wb[t] = (uint8_t)((x * 0x0102040810204080ull) >> 56);
+      }
+    } else {
+      for (int w = wave; w < nwords; w += 4) {
+        const int i = w * 64 + lane;
+        const unsigned long long m = __ballot(i < count0 && (COARSE ? coarse_cell_any(U, cg, line * count0 + i) : u[i] != 0));
+        if (lane == 0) words[w] = m;
+      }
     }
     __syncthreads();
     if (wave == 0) {
@@ -563,6 +578,100 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
     }
   }
   __syncthreads();
+  }
+}
+
+// The same verdicts with EIGHT consecutive candidates of a grid line per lane (r03; LIST form only, line length a multiple of
+// 8).  Four fifths of a grid are not safe: a lane of k_edt_decide then loads one zero mask byte and stores one zero byte per
+// candidate, and that path was most of the kernel (76 us on config H).  Here a lane reads the eight S bytes as one word and
+// stores the eight G bytes as one word; a zero word costs two instructions.  Eight positions along axis 0 are exactly one coarse
+// cell (kCoarse = 8), so the coarse distance is one load per lane; the mean / var loads of the set bytes are issued together
+// before the first verdict.  Same arithmetic per candidate, identical masks and lists (as sets: the list order differs).
+template <typename T>
+__global__ __launch_bounds__(256) void k_edt_decide8(long long nl, int len0, long long line0, long long goff, int d, double xscale,
+                                                     const T* __restrict__ mean_c, const T* __restrict__ var_c, T b,
+                                                     const uint8_t* __restrict__ S, const unsigned long long* Lkeys, int lidx,
+                                                     SweepScalars* sc, uint8_t* __restrict__ G, const CoarseGrid cg,
+                                                     long long* __restrict__ scanlist, const RcExp rx) {
+  SBO_CHAIN_PRIO();
+  static_assert(kCoarse == 8, "a lane's eight candidates are one coarse cell");
+  constexpr int kCap = 1024;                     // open candidates a workgroup collects in LDS (beyond: straight to the list)
+  __shared__ long long sl[kCap];
+  __shared__ double su[kCap];
+  __shared__ int scnt;
+  __shared__ long long sbase;
+  const double L = __longlong_as_double((long long)Lkeys[lidx]);
+  const bool anyU = sc->count_U > 0;
+  const int t8 = blockIdx.x * blockDim.x + threadIdx.x;          // this lane's cell along axis 0
+  const bool active = (long long)t8 * 8 < len0;
+  const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
+  for (long long ln = blockIdx.y; ln < nl; ln += gridDim.y) {
+    if (threadIdx.x == 0) scnt = 0;
+    __syncthreads();
+    if (active) {
+      const long long g0 = ln * len0 + (long long)t8 * 8;
+      const unsigned long long w = anyU ? *reinterpret_cast<const unsigned long long*>(S + g0) : 0ull;
+      unsigned long long gw = 0ull;
+      if (w != 0ull) {
+        // coarse cell of this lane (axes >= 1 from the line index, as k_edt_decide)
+        long long f = line0 + ln, cell = t8, ccs = cg.ccount[0];
+        for (int a = 1; a < d; ++a) {
+          const long long ix = a == d - 1 ? f : f % cg.count[a];
+          f = a == d - 1 ? 0 : f / cg.count[a];
+          cell += (ix / kCoarse) * ccs;
+          ccs *= cg.ccount[a];
+        }
+        const double dC = cg.enabled ? sqrt(cg.Dc[cell]) : 0.0;
+        const double dhi = dC * (1.0 + 1e-9) + cg.delta, dlo = fmax(0.0, dC * (1.0 - 1e-9) - cg.delta);
+        T mu[8], va[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const bool on = ((w >> (8 * k)) & 0xffull) != 0ull;
+          mu[k] = on ? mean_c[g0 + k] : (T)0;
+          va[k] = on ? var_c[g0 + k] : (T)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (((w >> (8 * k)) & 0xffull) == 0ull) continue;
+          const long long g = g0 + k;
+          T lcb, ucbT;
+          lcb_ucb(mu[k], va[k], b, lcb, ucbT);
+          const double ucb = (double)ucbT;
+          const double du = rc_du(rx, g, (double)va[k], (double)b);      // 0 unless this entry is an unrefined fp32 value
+          if (!(L > 0)) {
+            if (ucb >= 0.0) gw |= 1ull << (8 * k);                      // radius unbounded: any U point is a witness
+            if (du > 0.0 && fabs(ucb) <= du) rc_defer(rx, g);
+            continue;
+          }
+          if (cg.enabled) {
+            const double tolc = 1e-12 * (fabs(ucb) + du + L * dhi);
+            if (ucb - du - L * (dhi + eps_abs + 1e-11 * dhi) > tolc) { gw |= 1ull << (8 * k); continue; }   // within the radius for sure
+            if (ucb + du - L * (dlo - eps_abs - 1e-11 * dlo) < -tolc) continue;                              // beyond it for sure
+          }
+          const int slot = atomicAdd(&scnt, 1);
+          if (slot < kCap) {
+            sl[slot] = g;
+            su[slot] = ucb;
+          } else {                                                       // (a workgroup with more than kCap open candidates)
+            const long long gs = (long long)atomicAdd((unsigned long long*)&sc->n_scan, 1ull);
+            scanlist[2 * gs] = g;
+            reinterpret_cast<double*>(scanlist)[2 * gs + 1] = ucb;
+          }
+        }
+      }
+      *reinterpret_cast<unsigned long long*>(G + g0) = gw;
+    }
+    __syncthreads();
+    const int cntl = scnt < kCap ? scnt : kCap;
+    if (cntl > 0) {
+      if (threadIdx.x == 0) sbase = (long long)atomicAdd((unsigned long long*)&sc->n_scan, (unsigned long long)cntl);
+      __syncthreads();
+      for (int k = threadIdx.x; k < cntl; k += blockDim.x) {      // entries: (candidate, ucb) pairs of 16 bytes
+        scanlist[2 * (sbase + k)] = sl[k];
+        reinterpret_cast<double*>(scanlist)[2 * (sbase + k) + 1] = su[k];
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -1205,6 +1205,27 @@ def test_late_exact_recheck_path_equals_the_eager_one(engine, cfg_name, n, count
     _assert_same_bundle(out[1], out[0])
 
 
+@pytest.mark.parametrize("cfg_name,n,count,b", [("B", 128, [2048, 2048], 3.0), ("C", 96, [1040, 1032], 2.0), ("H", 300, [1056, 1500], 3.0),
+                                                  ("D", 128, [40, 36, 34, 33], 0.5), ("B", 40, [1032, 1027], 1.0)])
+def test_eight_candidates_per_lane_verdicts_equal_the_plain_ones(engine, cfg_name, n, count, b):
+    """Option decide_wide (default on): the expander verdict kernel reads eight S bytes and writes eight G bytes per lane
+    (k_edt_decide8; line lengths that are multiples of 8) -- every G mask, count, index and the number of exact rechecks must
+    equal the one-candidate-per-lane kernel, on 2-D grids with one and two constraints, a 4-D grid, and a line length the
+    wide form does not take (1032 x 1027 runs it, 1027-long lines would not: the grid is transposed in the last case)."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    q = cfg["q"]
+    engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    out = {}
+    try:
+        for wide in (1, 0):
+            engine.set_option("decide_wide", wide)
+            out[wide] = _sweep_bundle(engine, cfg, b, q, goose=(len(count) == 2))
+    finally:
+        engine.set_option("decide_wide", 1)
+    assert out[1][2]["G1"].any()
+    _assert_same_bundle(out[1], out[0])
+
+
 def test_two_lanes_of_constraints_equal_one_after_the_other(engine):
     """Models with two constraints on one rank: the per-constraint chains of a sweep (expander; GoOSE: + optimistic set)
     run on two streams with their own scratch and their own snapshot of the scalar block (option set_lanes, default on).
