@@ -1476,7 +1476,11 @@ def test_rccl_collectives_on_a_one_rank_communicator(engine, cfg_name, n, count)
         eng.set_model(cfg["ds"])
         eng.set_grid_sharded(lo, hi, count)
         assert (eng.first, eng.n_local) == (0, int(np.prod(count)))
+        eng.set_option("comm_events", 1)                         # an event pair around every RCCL call (sbo_profile.comm_*)
         res = eng.sweep_safeopt(cfg["b"], want_masks=True)
+        prof = eng.profile()
+        assert prof["comm_calls"] == 2 and prof["comm_bytes"] > 0 and 0.0 < prof["comm_ms"] < 50.0, prof
+        eng.set_option("comm_events", 0)
         for k in ("S", "U", "M"):
             assert np.array_equal(eng.mask(k), rmask[k]), k
         for c in range(1, q):
