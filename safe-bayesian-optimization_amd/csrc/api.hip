@@ -259,6 +259,11 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->posterior_valid = false;
     return SBO_OK;
   }
+  if (!strcmp(key, "classify_wgs")) {
+    if (value < 0 || value > 65535) return fail(SBO_E_INVALID, "classify_wgs out of range");
+    c->classify_wgs = (int)value;
+    return SBO_OK;
+  }
   if (!strcmp(key, "decide_wide")) {
     c->decide_wide = value ? 1 : 0;
     return SBO_OK;

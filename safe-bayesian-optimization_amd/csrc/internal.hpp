@@ -96,6 +96,7 @@ struct sbo_ctx {
   bool factor_pending = false;     // the factor chain of the current model is (possibly) still running; ev_factor marks its end
   hipEvent_t ev_factor = nullptr, ev_w = nullptr;
   int chol_async = 1;
+  int classify_wgs = 0;    // tuning: workgroups of k_classify (0: from the candidate count)
   int decide_wide = 1;     // expander verdicts with eight candidates per lane (k_edt_decide8); 0: one candidate per lane
   int post_rb = 0;         // tuning: tile height of k_bpost (0 auto: 128 x 128 unless the grid is small; 1: 64 x 128; 2: 128 x 128)
   int exact_lazy = 1;      // one-constraint SafeOpt sweeps on one rank: k_expander_exact only when the result block reports in-band candidates

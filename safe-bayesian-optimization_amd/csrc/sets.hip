@@ -795,7 +795,10 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* def
     fj.o_first = with_obj ? 0 : 1;
     c->lmax_pending = !with_obj;                // (the tail merges output 0)
   }
-  const int ncb = std::max(1, c->n_cu * 4);   // four workgroups per CU measured best (2: 24.6 us, 4: 21.5, 8: 27.1 on config B)
+  // four workgroups per CU measured best (2: 24.6 us, 4: 21.5, 8: 27.1 on config B's 4 M candidates; on config C's 1 M: 1024 /
+  // 512 / 256 workgroups 0.1455 / 0.1463 / 0.1530 ms per sweep -- fewer is not better there either); option classify_wgs overrides
+  int ncb = std::max(1, c->n_cu * 4);
+  if (c->classify_wgs > 0) ncb = c->classify_wgs;
   if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kClassifyRow * (size_t)ncb))) return rc;
   if (c->fuse_rows > 0 && n > 0) {
     // S / U bytes, |S|, |U| and the radius key came out of the posterior kernel: only u* is left, over the safe candidates
