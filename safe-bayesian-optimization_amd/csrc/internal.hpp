@@ -106,6 +106,17 @@ struct sbo_ctx {
   int basis_reg = 1;       // K1b axis bases: residual rows of the pivot loop in registers (n <= 512, degree <= 64); 0: through LDS / memory (round 2)
   sbo::BilinearPlan bl;
   sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work, bl_cheb;
+  // K1t (tensor.hip): fp64 grids of three / four axes by Chebyshev interpolation from exact node values
+  int tensor_cheb = 1;             // option: 0 = always K1g
+  bool tensor_busy = false;        // the exact node / probe launch of K1t is running through launch_posterior
+  sbo::DevBuf tn_pts, tn_vals, tn_work, tn_W0t, tn_W1t, tn_probe, tn_scr;
+  sbo::DevBuf tn_W[SBO_MAX_D];
+  size_t tn_work_half = 0;
+  bool tn_valid = false, tn_usable = false;     // plan decided for (tn_model, grid below) / it passed its accuracy probe
+  unsigned long long tn_model = 0;
+  long long tn_first = 0, tn_nlocal = 0, tn_count[4] = {0, 0, 0, 0};
+  double tn_lo[4] = {0, 0, 0, 0}, tn_hi[4] = {0, 0, 0, 0};
+  int tn_level[4] = {0, 0, 0, 0};
   sbo::DevBuf bl_basis;            // K1b: the 2 q axis bases (U, Chebyshev series, ranks) and the workspace of their kernel
   bool bl_basis_ok = false;        // bases enqueued for (bl_basis_serial, bl_basis_ab); their (ok, r, rc) records land at h_back + 4096
   unsigned long long bl_basis_serial = 0;
@@ -262,6 +273,8 @@ bool bilinear_applicable(const sbo_ctx* c);
 int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big);
 int bilinear_setup(sbo_ctx* c);
 int launch_posterior_bilinear(sbo_ctx* c);
+bool tensor_applicable(const sbo_ctx* c);
+int launch_posterior_tensor(sbo_ctx* c, bool* declined);
 }  // namespace sbo
 
 #define SBO_HIP(x)                                                   \

@@ -900,6 +900,12 @@ int launch_posterior(sbo_ctx* c) {
         return launch_posterior_bilinear(c);       // (writes the Lipschitz keys itself)
       }
     }
+    // fp64 grids of three / four axes: exact values at Chebyshev nodes, interpolated to the grid (K1t) when the plan qualifies
+    if (!c->tensor_busy && tensor_applicable(c)) {
+      bool declined = true;
+      const int rct = launch_posterior_tensor(c, &declined);
+      if (rct || !declined) return rct;
+    }
     { const int rcf = factor_sync(c); if (rcf) return rcf; }     // (the O(n^2) kernels contract with the factor images)
     SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
     c->last_k1 = 3;

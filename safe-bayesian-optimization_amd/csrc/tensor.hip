@@ -1,0 +1,629 @@
+// tensor.hip -- K1t: the posterior on fp64 tensor grids of three or four axes by Chebyshev interpolation (r03).
+//
+// The O(n^2)-per-candidate kernel K1g evaluates GP_inference (models/GP_Safe.py:310-352) at every grid point: 216 ms for the
+// 268 M candidates of BASELINE.json configs[3] (128^4, n = 128).  But with the separable RBF-ARD kernel the posterior mean, the
+// quadratic form of the variance and the mean's gradient are analytic functions of the candidate whose variation along an axis
+// is set by the length scale, not by the grid: on [lo_a, hi_a] each of them is, to rounding, a polynomial of degree < Dn_a
+// (Dn ~ 48 for the BASELINE hyper-parameters -- the degree the 2-D path's Chebyshev core runs to).  So:
+//   1. the exact posterior (generic kernel K1, `launch_posterior` on an explicit list) and the signed gradient components of
+//      the mean (k_t_grad_nodes, O(n d) per node) at the Dn_0 x .. x Dn_{d-1} Chebyshev nodes of the first kind -- 5.3 M
+//      points for 48^4, 2 % of the grid;
+//   2. interpolation to the grid, one axis at a time: g(.., x_a, ..) = sum_k W_a[x_a][k] g(.., node k, ..) with
+//      W_a[x][k] = (1 / Dn) sum_m w_m T_m(xi_x) T_m(xi_k)  (the discrete Chebyshev transform and the series evaluation in one
+//      matrix).  Axes d-1 .. 2 are contracted by k_t_mode on the small tensors, the last two -- where the data grow to grid
+//      size -- by k_t_final, a workgroup per (x_2, x_3) plane: out = W_0 M W_1^T with the plane's Dn_0 x Dn_1 core M in LDS,
+//      written in grid order (axis 0 fastest) or, for the gradient components, reduced to max |.| on the fly (Lipschitz keys).
+// Accuracy is checked, not assumed: when a plan is built for a (model, grid) pair, 2048 grid points are also evaluated exactly
+// and compared with the interpolated values; a plan that misses 2e-11 (normalised units) retries one step up the degree ladder
+// and then declines (K1g runs).  Values differ from K1g's by the rounding of the interpolation sums (~1e-13).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "internal.hpp"
+#include "device_common.hpp"
+
+namespace sbo {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+constexpr int kTMaxD = 4;
+constexpr int kTProbes = 2048;
+
+struct TensorDims {                  // by value
+  int d, q;
+  int Dn[kTMaxD];                    // nodes per axis
+  long long cnt[kTMaxD];             // grid counts per axis (last: local hyper-planes)
+  long long first_last;              // first local index along the last axis
+  double mid[kTMaxD], half[kTMaxD];  // axis intervals in raw coordinates
+};
+
+// node coordinates as an explicit candidate list [Nn][d], x = mid + half cos(pi (k + 1/2) / Dn); the low DM x DM digits of the node
+// index enumerate (k0, k1) in the packed-image order k_t_final reads (core_pos), the digits of the further axes follow
+template <int DM>
+__global__ __launch_bounds__(256) void k_t_nodes(const TensorDims td, long long Nn, double* __restrict__ pts);
+// interpolation matrix of axis a: W[x][k], x over the (local) grid positions of the axis; transposed copy Wt[k][x] for axis 0
+__global__ __launch_bounds__(256) void k_t_wmat(const TensorDims td, const CandSpec cs, int a, long long nx, long long x_first,
+                                                double* __restrict__ W, double* __restrict__ Wt) {
+  const int Dn = td.Dn[a];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx * Dn; i += (long long)gridDim.x * blockDim.x) {
+    const long long xl = i / Dn;
+    const int k = (int)(i % Dn);
+    const long long ix = x_first + xl, tot = cs.count[a];
+    const double x = (ix == tot - 1 && tot > 1) ? cs.hi[a] : __dadd_rn(cs.lo[a], __dmul_rn((double)ix, cs.step[a]));   // cand_coords
+    double xi = (x - td.mid[a]) / td.half[a];
+    xi = xi < 1.0 ? xi : 1.0;
+    xi = xi > -1.0 ? xi : -1.0;
+    // sum_m w_m T_m(xi) T_m(xi_k), T_m(xi_k) = cos(m pi (k + 1/2) / Dn); T_m(xi) by the three-term recurrence
+    double t0 = 1.0, t1 = xi, s_ = 1.0;
+    const double th = ((double)k + 0.5) / (double)Dn;
+    if (Dn > 1) s_ += 2.0 * t1 * cospi(th);
+    for (int m = 2; m < Dn; ++m) {
+      const double t = 2.0 * xi * t1 - t0;
+      s_ += 2.0 * t * cospi((double)m * th);
+      t0 = t1;
+      t1 = t;
+    }
+    const double v = s_ / (double)Dn;
+    W[xl * Dn + k] = v;
+    if (Wt) Wt[(size_t)k * nx + xl] = v;
+  }
+}
+
+// signed gradient components of the un-normalised mean at explicit points (the analytic form of jax.grad(self.mean),
+// models/SafeOpt.py:68-71; k_rc_grad64's arithmetic): out[(o d + a) N + g]
+template <int D>
+__global__ __launch_bounds__(256) void k_t_grad_nodes(const ModelConst mc, const double* __restrict__ pts, long long N,
+                                                      const double* __restrict__ As, const double* __restrict__ sqA,
+                                                      const double* __restrict__ alpha, const double* __restrict__ Xn,
+                                                      double* __restrict__ out) {
+  const int n = mc.n, npad = mc.npad;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < N; g += (long long)gridDim.x * blockDim.x) {
+    double xn[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) xn[a] = a < mc.d ? (pts[g * mc.d + a] - mc.X_mean[a]) / mc.X_std[a] : 0.0;
+    for (int o = 0; o < mc.q; ++o) {
+      double bq[D], sqb = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        bq[a] = a < mc.d ? xn[a] * mc.vinv[o][a] : 0.0;
+        sqb += bq[a] * bq[a];
+      }
+      const double* Ao = As + (size_t)o * npad * D;
+      const double* so = sqA + (size_t)o * npad;
+      const double* al = alpha + (size_t)o * npad;
+      double s0 = 0.0, sa[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) sa[a] = 0.0;
+      for (int j = 0; j < n; ++j) {
+        double dot = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) dot += Ao[(size_t)j * D + a] * bq[a];
+        const double w = al[j] * (mc.sf2[o] * exp(-0.5 * ((-2.0 * dot + so[j]) + sqb)));
+        s0 += w;
+#pragma unroll
+        for (int a = 0; a < D; ++a) sa[a] += w * Xn[(size_t)j * D + a];
+      }
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+        if (a < mc.d) out[((size_t)o * mc.d + a) * N + g] = mc.Y_std[o] * (sa[a] - xn[a] * s0) * mc.inv_ell[o][a] * mc.X_rstd[a];
+    }
+  }
+}
+
+// contraction of one axis that is not the fastest: out[p + pre (x + nx t)] = sum_m W[x][m] in[p + pre (m + DM t)], for nq
+// stacked quantities (strides sin / sout).  A thread per (p, t): its DM inputs in registers, W through LDS in chunks of rows.
+template <int DM>
+__global__ __launch_bounds__(256) void k_t_mode(const double* __restrict__ in, size_t sin, double* __restrict__ out, size_t sout,
+                                                const double* __restrict__ W, long long pre, int Dm, long long nx, long long post) {
+  constexpr int kRows = 32;
+  __shared__ double Ws[kRows][DM];
+  const int qi = blockIdx.y;
+  const double* I = in + (size_t)qi * sin;
+  double* O = out + (size_t)qi * sout;
+  const long long total = pre * post;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = e < total;
+  const long long p = live ? e % pre : 0, t = live ? e / pre : 0;
+  double v[DM];
+#pragma unroll
+  for (int m = 0; m < DM; ++m) v[m] = (live && m < Dm) ? I[p + pre * ((long long)m + (long long)Dm * t)] : 0.0;
+  for (long long x0 = 0; x0 < nx; x0 += kRows) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kRows * DM; i += blockDim.x) {
+      const int r = i / DM, m = i % DM;
+      Ws[r][m] = (x0 + r < nx && m < Dm) ? W[(x0 + r) * Dm + m] : 0.0;
+    }
+    __syncthreads();
+    const int rows = nx - x0 < kRows ? (int)(nx - x0) : kRows;
+    for (int r = 0; r < rows; ++r) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int m = 0; m < DM; m += 4) {
+        s0 = fma(Ws[r][m], v[m], s0);
+        s1 = fma(Ws[r][m + 1], v[m + 1], s1);
+        s2 = fma(Ws[r][m + 2], v[m + 2], s2);
+        s3 = fma(Ws[r][m + 3], v[m + 3], s3);
+      }
+      if (live) O[p + pre * ((x0 + r) + nx * t)] = (s0 + s1) + (s2 + s3);
+    }
+  }
+}
+
+// The last two axes, where the data grow to grid size: out[x0][x1] = sum_{a,b} W0[x0][a] M[a][b] W1[x1][b] per (x_2, .., x_{d-1})
+// plane, all quantities in one launch, on the matrix cores (fragment conventions of device_common.hpp: four v_mfma_f64_4x4x4
+// per 16 x 16 x 4 step).  Plain multiply-adds run at the same FP64 rate on gfx950, but an 8 x 8 register tile per thread needs
+// 128 B / clk / CU of LDS operands -- all the LDS delivers (measured: 0.34 of the rate); a matrix-core step shares its operands
+// across the lanes in hardware.
+// A persistent workgroup of four waves; wave w owns the 32 positions x0 = 128 t0 + 32 w .. + 31 (two strips of 16) and keeps
+// W0 of them as B fragments in registers (KS x 2 doubles per lane); W1 of a chunk of 16 CS positions x1 sits in LDS as B
+// fragments for all four waves.  Units (quantity, plane):
+//   step 1 T^T[b][x0] = sum_a M^T[b][a] W0^T[a][x0]: the A images come straight from memory -- the node tensors are stored
+//          with the (k0, k1) digits in packed-image order (core_pos) for exactly this, 2 KB contiguous per image;
+//          the accumulators go to the wave's own LDS area as the A images of step 2 (rows x0, inner index b)
+//   step 2 out[x0][x1] = sum_b T[x0][b] W1[x1][b]: 2 x CS accumulator tiles per wave
+//   epilogue: gradient components reduce max |.| -> Lmax[o] (the bit pattern orders non-negative doubles); mean / variance
+//          tiles turn through a 16 x 32 LDS patch so that a lane stores 64 contiguous bytes of a grid row (axis 0 fastest).
+// Nothing is shared between the waves but the read-only W1 fragments: no barriers in the unit loop when n1 fits one chunk.
+// Quantity qi: mean of output qi (qi < q), variance (qi < 2 q, clipped at zero), gradient component (o, a) = (qi - 2 q) / d, % d.
+template <int DM>
+__host__ __device__ __forceinline__ void core_pos(int p, int& a, int& b) {      // position p of a plane's DM x DM core -> (a, b)
+  constexpr int KB = DM / 16;
+  const int blk = p >> 8, bb = blk / KB, ab = blk % KB;
+  int r, k, kk;
+  MM<double>::unpack_pos(p & 255, r, k, kk);
+  b = bb * 16 + r;
+  a = ab * 16 + kk * 4 + k;
+}
+
+template <int DM>
+__global__ __launch_bounds__(256) void k_t_nodes(const TensorDims td, long long Nn, double* __restrict__ pts) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < Nn; g += (long long)gridDim.x * blockDim.x) {
+    int k[kTMaxD];
+    core_pos<DM>((int)(g % (DM * DM)), k[0], k[1]);
+    long long f = g / (DM * DM);
+    for (int a = 2; a < td.d; ++a) {
+      k[a] = (int)(f % td.Dn[a]);
+      f /= td.Dn[a];
+    }
+    for (int a = 0; a < td.d; ++a) pts[g * td.d + a] = td.mid[a] + td.half[a] * cospi(((double)k[a] + 0.5) / (double)td.Dn[a]);
+  }
+}
+
+template <int DM, int CS>
+__global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ in, size_t stride_q, const double* __restrict__ W0t,
+                                                    const double* __restrict__ W1t, long long n0, long long n1, long long planes, int q, int d,
+                                                    int nq, double* __restrict__ mean, double* __restrict__ var, size_t n_local,
+                                                    unsigned long long* __restrict__ Lmax) {
+  constexpr int KS = DM / 4, KB = DM / 16, SP = 36;   // k-steps, k-blocks; row stride of the store patch
+  extern __shared__ __attribute__((aligned(32))) double sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* W1f = sm;                                                       // [KS][CS][64]
+  double* Timg = sm + KS * CS * 64 + (size_t)wave * (2 * KB * 256);       // [strip 2][kb][256]
+  double* stg = sm + KS * CS * 64 + 4 * (2 * KB * 256) + (size_t)wave * (16 * SP);   // [x1 16][SP]
+  const int kq = lane >> 4, col = lane & 15;
+  const long long tiles0 = (n0 + 127) / 128, chunks1 = (n1 + 16 * CS - 1) / (16 * CS);
+  const long long per_tile = planes * nq, units = per_tile * tiles0;      // t0 slowest: the W0 fragments change once per tile
+  // every wave runs the same number of iterations (the chunk loads of W1 are workgroup-wide); a wave without a unit idles
+  const long long iters = (units + gridDim.x - 1) / gridDim.x;
+  long long cur_t0 = -1, cur_c1 = -1;
+  double bw0[KS][2];
+  for (long long it = 0; it < iters; ++it) {
+    const long long u = blockIdx.x + it * gridDim.x;
+    const bool have = u < units;
+    const long long uu = have ? u : units - 1;
+    const long long t0 = uu / per_tile, rest = uu % per_tile;
+    const int qi = (int)(rest % nq);
+    const long long plane = rest / nq;
+    const long long x0w = t0 * 128 + wave * 32;                          // first position of this wave
+    if (t0 != cur_t0) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          const long long x0 = x0w + s_ * 16 + col;
+          bw0[ks][s_] = x0 < n0 ? W0t[(size_t)(ks * 4 + kq) * n0 + x0] : 0.0;
+        }
+      cur_t0 = t0;
+    }
+    // step 1
+    const double* I = in + (size_t)qi * stride_q + (size_t)plane * DM * DM;
+    {
+      d4_t acc1[KB][2];
+#pragma unroll
+      for (int bb = 0; bb < KB; ++bb) acc1[bb][0] = acc1[bb][1] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int bb = 0; bb < KB; ++bb) {
+          const d4_t am = MM<double>::load_a(I + (size_t)(bb * KB + (ks >> 2)) * 256, lane, ks & 3);
+          acc1[bb][0] = MM<double>::mfma(am, bw0[ks][0], acc1[bb][0]);
+          acc1[bb][1] = MM<double>::mfma(am, bw0[ks][1], acc1[bb][1]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();     // (the previous unit's step 2 reads of T are issued)
+      // element t of acc1[bb][s] at lane l: b = 16 bb + 4 t + kq, x0 = 16 s + col  ->  image (strip s, k-block bb),
+      // pack_pos(col, kq, t) = 64 t + (4 kq + (col & 3)) 4 + (col >> 2)
+      const int tp = (kq * 4 + (col & 3)) * 4 + (col >> 2);
+#pragma unroll
+      for (int bb = 0; bb < KB; ++bb)
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Timg[(size_t)(s_ * KB + bb) * 256 + t * 64 + tp] = acc1[bb][s_][t];
+      __builtin_amdgcn_wave_barrier();
+    }
+    const int kind = qi < q ? 0 : (qi < 2 * q ? 1 : 2);
+    double* O = kind == 0 ? mean + (size_t)qi * n_local : (kind == 1 ? var + (size_t)(qi - q) * n_local : nullptr);
+    if (O) O += (size_t)plane * n0 * n1;
+    double gmax = 0.0;
+    for (long long c1 = 0; c1 < chunks1; ++c1) {
+      if (c1 != cur_c1) {                  // (workgroup-uniform: every wave sees the same chunk sequence)
+        if (cur_c1 >= 0) __syncthreads();
+        for (int e = tid; e < KS * CS * 64; e += 256) {
+          const int l = e & 63, cs = (e >> 6) % CS, ks = (e >> 6) / CS;
+          const long long x1 = c1 * (16 * CS) + cs * 16 + (l & 15);
+          W1f[e] = x1 < n1 ? W1t[(size_t)(ks * 4 + (l >> 4)) * n1 + x1] : 0.0;
+        }
+        cur_c1 = c1;
+        __syncthreads();
+      }
+      d4_t acc[2][CS];
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) acc[s_][cs] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int ks = 0; ks < KS; ++ks) {
+        const d4_t a0 = MM<double>::load_a(Timg + (size_t)(0 * KB + (ks >> 2)) * 256, lane, ks & 3);
+        const d4_t a1 = MM<double>::load_a(Timg + (size_t)(1 * KB + (ks >> 2)) * 256, lane, ks & 3);
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+          const double w = W1f[(ks * CS + cs) * 64 + lane];
+          acc[0][cs] = MM<double>::mfma(a0, w, acc[0][cs]);
+          acc[1][cs] = MM<double>::mfma(a1, w, acc[1][cs]);
+        }
+      }
+      // element t of acc[s][cs] at lane l: x0 = x0w + 16 s + 4 t + kq, x1 = c1 16 CS + 16 cs + col
+      if (!have) continue;
+      if (kind == 2) {
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+          const bool live1 = c1 * (16 * CS) + cs * 16 + col < n1;
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const double v = acc[s_][cs][t], av = v < 0 ? -v : v;
+              gmax = (live1 && x0w + s_ * 16 + 4 * t + kq < n0 && av > gmax) ? av : gmax;
+            }
+        }
+      } else {
+        const bool vec = (n0 & 3) == 0;
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const double v = acc[s_][cs][t];
+              stg[col * SP + s_ * 16 + 4 * t + kq] = kind == 1 ? (v > 0.0 ? v : 0.0) : v;
+            }
+          __builtin_amdgcn_wave_barrier();
+          const int xr = lane >> 2, xc = (lane & 3) * 8;                  // patch row (x1), first of eight x0
+          const d4_t v0 = *reinterpret_cast<const d4_t*>(stg + xr * SP + xc), v1 = *reinterpret_cast<const d4_t*>(stg + xr * SP + xc + 4);
+          const long long x1 = c1 * (16 * CS) + cs * 16 + xr, x0 = x0w + xc;
+          if (x1 < n1) {
+            double* row = O + (size_t)x1 * n0;
+            if (vec) {
+              if (x0 < n0) *reinterpret_cast<d4_t*>(row + x0) = v0;
+              if (x0 + 4 < n0) *reinterpret_cast<d4_t*>(row + x0 + 4) = v1;
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (x0 + i < n0) row[x0 + i] = v0[i];
+                if (x0 + 4 + i < n0) row[x0 + 4 + i] = v1[i];
+              }
+            }
+          }
+        }
+      }
+    }
+    if (kind == 2 && have) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double y = __shfl_xor(gmax, off);
+        gmax = y > gmax ? y : gmax;
+      }
+      if (lane == 0 && gmax > 0.0) atomicMax(Lmax + (qi - 2 * q) / d, (unsigned long long)__double_as_longlong(gmax));
+    }
+  }
+}
+
+// values of stacked quantities at listed grid points (the plan's accuracy probe): out[qi np + i] = arr[qi stride + idx[i]]
+__global__ void k_t_pick(const double* __restrict__ arr, size_t stride, const long long* __restrict__ idx, int np, double* __restrict__ out) {
+  const int qi = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) out[(size_t)qi * np + i] = arr[(size_t)qi * stride + idx[i]];
+}
+template <int D>
+__global__ void k_t_probe_pts(const CandSpec cs, const long long* __restrict__ idx, int np, double* __restrict__ pts) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
+    double x[D];
+    cand_coords<D>(cs, idx[i], x);
+    for (int a = 0; a < cs.d; ++a) pts[(size_t)i * cs.d + a] = x[a];
+  }
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------------
+static const int kLadder[4] = {32, 48, 64, 96};
+
+bool tensor_applicable(const sbo_ctx* c) {
+  if (!c->tensor_cheb || c->is_shadow || c->dtype != SBO_F64 || c->cs.kind != 1) return false;
+  const int d = c->cs.d;
+  if (d < 3 || d > kTMaxD) return false;
+  long long plane = 1;
+  for (int a = 0; a < d - 1; ++a) plane *= c->cs.count[a];
+  if (c->cs.n_local <= 0 || c->cs.first % plane != 0 || c->cs.n_local % plane != 0) return false;
+  for (int a = 0; a < d; ++a)
+    if (c->cs.count[a] < 64) return false;
+  return c->grid_total >= (1ll << 22);
+}
+
+template <int DM>
+static void launch_mode(hipStream_t st, const double* in, size_t sin, double* out, size_t sout, const double* W, long long pre, int Dm,
+                        long long nx, long long post, int nq) {
+  const long long total = pre * post;
+  hipLaunchKernelGGL((k_t_mode<DM>), dim3((unsigned)((total + 255) / 256), (unsigned)nq), dim3(256), 0, st, in, sin, out, sout, W, pre, Dm, nx, post);
+}
+static int mode_dispatch(hipStream_t st, int DM, const double* in, size_t sin, double* out, size_t sout, const double* W, long long pre, int Dm,
+                         long long nx, long long post, int nq) {
+  switch (DM) {
+    case 32: launch_mode<32>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq); break;
+    case 48: launch_mode<48>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq); break;
+    case 64: launch_mode<64>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq); break;
+    case 96: launch_mode<96>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq); break;
+    default: return fail(SBO_E_UNSUPPORTED, "internal: interpolation degree");
+  }
+  return SBO_OK;
+}
+// the exact posterior of the generic kernel on an explicit fp64 list, into caller-given arrays (the context's candidate
+// description and posterior buffers are swapped for the call)
+static int exact_on_list(sbo_ctx* c, const double* pts, long long N, double* mean_out, double* var_out) {
+  const CandSpec keep_cs = c->cs;
+  const DevBuf keep_m = c->mean, keep_v = c->var, keep_l = c->Lmax;
+  const int keep_k1 = c->last_k1;
+  const double keep_flops = c->last_k1_flops;
+  memset(&c->cs, 0, sizeof(c->cs));
+  c->cs.kind = 0;
+  c->cs.d = keep_cs.d;
+  c->cs.pts_dtype = SBO_F64;
+  c->cs.pts = pts;
+  c->cs.n_local = N;
+  c->cs.first = 0;
+  c->mean.p = mean_out;
+  c->var.p = var_out;
+  c->Lmax.p = c->tn_scr.p;                     // (the Lipschitz keys of the list are of no interest; the grid's come from k_t_final)
+  c->tensor_busy = true;                       // (launch_posterior must not come back here)
+  const int rc = launch_posterior(c);
+  c->tensor_busy = false;
+  c->cs = keep_cs;
+  c->mean = keep_m;
+  c->var = keep_v;
+  c->Lmax = keep_l;
+  c->last_k1 = keep_k1;
+  c->last_k1_flops = keep_flops;
+  return rc;
+}
+
+template <int DM, int CS>
+static int launch_final(sbo_ctx* c, const double* in, size_t stride_q, const TensorDims& td, long long planes, int nq) {
+  const size_t lds = sizeof(double) * ((size_t)(DM / 4) * CS * 64 + 4 * (size_t)(2 * (DM / 16) * 256) + 4 * 16 * 36);
+  auto kern = k_t_final<DM, CS>;
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long long units = planes * nq * ((td.cnt[0] + 127) / 128);
+  const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(units, (long long)c->n_cu));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, in, stride_q, (const double*)c->tn_W0t.p, (const double*)c->tn_W1t.p, td.cnt[0],
+                     td.cnt[1], planes, td.q, td.d, nq, (double*)c->mean.p, (double*)c->var.p, (size_t)c->cs.n_local, (unsigned long long*)c->Lmax.p);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+// all `nq` stacked node tensors (stride Nn: q means, q variances, q d gradient components) to the grid
+static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, long long Nn, int nq) {
+  const int d = td.d;
+  int rc;
+  // axes d-1 .. 2 on the small tensors (ping-pong in tn_work), then the planes
+  const double* cur = nodes;
+  size_t cur_stride = (size_t)Nn;
+  long long pre = 1;
+  for (int a = 0; a < d - 1; ++a) pre *= td.Dn[a];          // product of the node counts below the axis being contracted
+  long long post = 1;
+  double* bufA = (double*)c->tn_work.p;
+  double* bufB = bufA + c->tn_work_half;
+  bool toA = true;
+  for (int a = d - 1; a >= 2; --a) {
+    const long long nx = td.cnt[a];
+    double* dst = toA ? bufA : bufB;
+    const size_t dst_stride = (size_t)pre * nx * post;
+    if ((rc = mode_dispatch(c->stream, td.Dn[a] <= 32 ? 32 : (td.Dn[a] <= 48 ? 48 : (td.Dn[a] <= 64 ? 64 : 96)), cur, cur_stride, dst, dst_stride,
+                            (const double*)c->tn_W[a].p, pre, td.Dn[a], nx, post, nq)))
+      return rc;
+    cur = dst;
+    cur_stride = dst_stride;
+    post *= nx;
+    pre /= td.Dn[a - 1];
+    toA = !toA;
+  }
+  // now cur = [DM][DM][planes = post] per quantity
+  SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
+  switch (td.Dn[0]) {
+    case 32: return launch_final<32, 8>(c, cur, cur_stride, td, post, nq);
+    case 48: return launch_final<48, 8>(c, cur, cur_stride, td, post, nq);
+    case 64: return launch_final<64, 8>(c, cur, cur_stride, td, post, nq);
+  }
+  return fail(SBO_E_UNSUPPORTED, "internal: interpolation degree");
+}
+
+// SBO_OK with *declined = true: the plan does not qualify (K1g runs)
+int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
+  *declined = true;
+  const ModelConst& mc = c->mc;
+  const CandSpec& cs = c->cs;
+  const int d = cs.d, q = mc.q;
+  int rc;
+  long long plane = 1;
+  for (int a = 0; a < d - 1; ++a) plane *= cs.count[a];
+  TensorDims td;
+  memset(&td, 0, sizeof(td));
+  td.d = d;
+  td.q = q;
+  for (int a = 0; a < d; ++a) {
+    td.cnt[a] = a == d - 1 ? cs.n_local / plane : cs.count[a];
+    td.mid[a] = 0.5 * (cs.lo[a] + cs.hi[a]);
+    td.half[a] = 0.5 * (cs.hi[a] - cs.lo[a]);
+    if (!(td.half[a] > 0.0)) return SBO_OK;
+  }
+  td.first_last = cs.first / plane;
+  // plan: degrees per axis, decided once per (model, grid) with an accuracy probe
+  const bool same_grid = c->tn_valid && c->tn_model == c->model_serial && c->tn_first == cs.first && c->tn_nlocal == cs.n_local &&
+                         !memcmp(c->tn_count, cs.count, sizeof(long long) * kTMaxD) && !memcmp(c->tn_lo, cs.lo, sizeof(double) * kTMaxD) &&
+                         !memcmp(c->tn_hi, cs.hi, sizeof(double) * kTMaxD);
+  int level0[kTMaxD];
+  if (same_grid) {
+    if (!c->tn_usable) return SBO_OK;
+    for (int a = 0; a < d; ++a) level0[a] = c->tn_level[a];
+  } else {
+    // first guess from the shortest length scale of the axis: degree ~ 8.3 x (normalised interval / ell), as the 2-D path's ladder
+    for (int a = 0; a < d; ++a) {
+      double tmax = 0.0;
+      for (int o = 0; o < q; ++o) tmax = std::max(tmax, 2.0 * td.half[a] / mc.X_std[a] * std::sqrt(mc.inv_ell[o][a]));
+      int lv = 0;
+      while (lv < 3 && kLadder[lv] < 8.3 * tmax) ++lv;
+      level0[a] = lv;
+    }
+  }
+  for (int attempt = 0; attempt < (same_grid ? 1 : 2); ++attempt) {
+    long long Nn = 1;
+    bool ok_dims = true;
+    for (int a = 0; a < d; ++a) {
+      const int lv = std::min(3, level0[a] + attempt);
+      td.Dn[a] = kLadder[lv];
+    }
+    td.Dn[0] = td.Dn[1] = std::max(td.Dn[0], td.Dn[1]);      // (k_t_final: one square core per plane)
+    for (int a = 0; a < d; ++a) {
+      if (td.Dn[a] > 64 && a < 2) ok_dims = false;          // (k_t_final's LDS: cores up to 64 x 64)
+      if (td.Dn[a] * 4 > 3 * cs.count[a]) ok_dims = false;   // not worth it: the grid is hardly finer than the nodes
+      Nn *= td.Dn[a];
+    }
+    if (!ok_dims || Nn > (1ll << 24)) break;
+    // buffers: node list, node values (mean, var: q each; gradient: q d), interpolation matrices, ping-pong work
+    const int nqg = q * d;
+    if ((rc = ensure(c->tn_pts, sizeof(double) * (size_t)Nn * d))) return rc;
+    if ((rc = ensure(c->tn_vals, sizeof(double) * (size_t)Nn * (2 * q + nqg)))) return rc;
+    size_t half_elems = 0;
+    {
+      long long pre = 1, post = 1;
+      for (int a = 0; a < d - 1; ++a) pre *= td.Dn[a];
+      for (int a = d - 1; a >= 2; --a) {
+        half_elems = std::max(half_elems, (size_t)(pre * td.cnt[a] * post) * (size_t)(2 * q + nqg));
+        post *= td.cnt[a];
+        pre /= td.Dn[a - 1];
+      }
+    }
+    c->tn_work_half = half_elems;
+    if ((rc = ensure(c->tn_work, sizeof(double) * 2 * std::max<size_t>(half_elems, 16)))) return rc;
+    for (int a = 0; a < d; ++a)
+      if ((rc = ensure(c->tn_W[a], sizeof(double) * (size_t)td.cnt[a] * td.Dn[a]))) return rc;
+    if ((rc = ensure(c->tn_W0t, sizeof(double) * (size_t)td.cnt[0] * td.Dn[0]))) return rc;
+    if ((rc = ensure(c->tn_W1t, sizeof(double) * (size_t)td.cnt[1] * td.Dn[1]))) return rc;
+    if ((rc = ensure(c->tn_scr, 512))) return rc;
+    {
+      const dim3 gn((unsigned)std::min<long long>((Nn + 255) / 256, 1 << 16));
+      if (td.Dn[0] == 32) hipLaunchKernelGGL(k_t_nodes<32>, gn, dim3(256), 0, c->stream, td, Nn, (double*)c->tn_pts.p);
+      else if (td.Dn[0] == 48) hipLaunchKernelGGL(k_t_nodes<48>, gn, dim3(256), 0, c->stream, td, Nn, (double*)c->tn_pts.p);
+      else hipLaunchKernelGGL(k_t_nodes<64>, gn, dim3(256), 0, c->stream, td, Nn, (double*)c->tn_pts.p);
+    }
+    for (int a = 0; a < d; ++a)
+      hipLaunchKernelGGL(k_t_wmat, dim3((unsigned)std::min<long long>((td.cnt[a] * td.Dn[a] + 255) / 256, 4096)), dim3(256), 0, c->stream, td, cs, a,
+                         td.cnt[a], a == d - 1 ? td.first_last : 0ll, (double*)c->tn_W[a].p, a == 0 ? (double*)c->tn_W0t.p : (a == 1 ? (double*)c->tn_W1t.p : (double*)nullptr));
+    // exact values at the nodes
+    double* nmean = (double*)c->tn_vals.p;
+    double* nvar = nmean + (size_t)q * Nn;
+    double* ngrad = nvar + (size_t)q * Nn;
+    if ((rc = exact_on_list(c, (const double*)c->tn_pts.p, Nn, nmean, nvar))) return rc;
+    {
+      const unsigned nbg = (unsigned)std::max<long long>(1, std::min<long long>((Nn + 255) / 256, (long long)c->n_cu * 16));
+      if (mc.dpad == 4)
+        hipLaunchKernelGGL((k_t_grad_nodes<4>), dim3(nbg), dim3(256), 0, c->stream, mc, (const double*)c->tn_pts.p, Nn, (const double*)c->As.p,
+                           (const double*)c->sqA.p, (const double*)c->alpha.p, (const double*)c->Xn.p, ngrad);
+      else
+        return fail(SBO_E_UNSUPPORTED, "internal: K1t expects three or four axes");
+    }
+    // interpolation: mean, variance (clipped at zero), gradient components -> Lipschitz keys max_a max_x |d MEAN_o / d x_a|
+    (void)ngrad;
+    if ((rc = interpolate(c, td, nmean, Nn, 2 * q + nqg))) return rc;
+    if (!same_grid) {
+      // accuracy probe: 2048 grid points, exact against interpolated
+      std::vector<long long> idx(kTProbes);
+      unsigned long long sd = 0x9e3779b97f4a7c15ull ^ (unsigned long long)c->model_serial;
+      for (int i = 0; i < kTProbes; ++i) {
+        sd = sd * 6364136223846793005ull + 1442695040888963407ull;
+        idx[i] = (long long)((sd >> 11) % (unsigned long long)cs.n_local);
+      }
+      const size_t pbytes = sizeof(long long) * kTProbes + sizeof(double) * (size_t)kTProbes * (d + 4 * q);
+      if ((rc = ensure(c->tn_probe, pbytes))) return rc;
+      long long* didx = (long long*)c->tn_probe.p;
+      double* ppts = (double*)(didx + kTProbes);
+      double* pexm = ppts + (size_t)kTProbes * d;          // exact mean [q][np], exact var, interpolated mean, interpolated var
+      double* pexv = pexm + (size_t)q * kTProbes;
+      double* pinm = pexv + (size_t)q * kTProbes;
+      double* pinv = pinm + (size_t)q * kTProbes;
+      SBO_HIP(hipMemcpyAsync(didx, idx.data(), sizeof(long long) * kTProbes, hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL((k_t_probe_pts<4>), dim3(8), dim3(256), 0, c->stream, cs, (const long long*)didx, kTProbes, ppts);
+      if ((rc = exact_on_list(c, ppts, kTProbes, pexm, pexv))) return rc;
+      hipLaunchKernelGGL(k_t_pick, dim3(8, q), dim3(256), 0, c->stream, (const double*)c->mean.p, (size_t)cs.n_local, (const long long*)didx, kTProbes, pinm);
+      hipLaunchKernelGGL(k_t_pick, dim3(8, q), dim3(256), 0, c->stream, (const double*)c->var.p, (size_t)cs.n_local, (const long long*)didx, kTProbes, pinv);
+      std::vector<double> h((size_t)4 * q * kTProbes);
+      SBO_HIP(hipMemcpyAsync(h.data(), pexm, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+      SBO_HIP(hipStreamSynchronize(c->stream));
+      double err = 0.0;
+      for (int o = 0; o < q; ++o) {
+        const double ys = std::max(1.0, mc.Y_std[o]);
+        for (int i = 0; i < kTProbes; ++i) {
+          err = std::max(err, std::fabs(h[((size_t)2 * q + o) * kTProbes + i] - h[(size_t)o * kTProbes + i]) / ys);
+          err = std::max(err, std::fabs(h[((size_t)3 * q + o) * kTProbes + i] - h[((size_t)q + o) * kTProbes + i]) / (ys * ys));
+        }
+      }
+      if (getenv("SBO_DEBUG_TENSOR"))
+        fprintf(stderr, "[K1t] nodes %d x %d x %d x %d = %lld, probe error %.2e (attempt %d)\n", td.Dn[0], td.Dn[1], td.Dn[2], d > 3 ? td.Dn[3] : 1, Nn,
+                err, attempt);
+      c->tn_valid = true;
+      c->tn_model = c->model_serial;
+      c->tn_first = cs.first;
+      c->tn_nlocal = cs.n_local;
+      memcpy(c->tn_count, cs.count, sizeof(long long) * kTMaxD);
+      memcpy(c->tn_lo, cs.lo, sizeof(double) * kTMaxD);
+      memcpy(c->tn_hi, cs.hi, sizeof(double) * kTMaxD);
+      for (int a = 0; a < d; ++a) c->tn_level[a] = std::min(3, level0[a] + attempt);
+      c->tn_usable = err <= 2e-11;
+      if (!c->tn_usable) continue;           // one step up the ladder, or give up
+    }
+    *declined = false;
+    c->last_k1 = 5;
+    // flops issued (vector units; no matrix cores on this path): node posterior (triangular contraction) + interpolation sums
+    c->last_k1_flops = (double)q * mc.npad * (mc.npad + 16.0) * (double)Nn;
+    return SBO_OK;
+  }
+  c->tn_valid = true;
+  c->tn_usable = false;
+  c->tn_model = c->model_serial;
+  c->tn_first = cs.first;
+  c->tn_nlocal = cs.n_local;
+  memcpy(c->tn_count, cs.count, sizeof(long long) * kTMaxD);
+  memcpy(c->tn_lo, cs.lo, sizeof(double) * kTMaxD);
+  memcpy(c->tn_hi, cs.hi, sizeof(double) * kTMaxD);
+  return SBO_OK;
+}
+
+}  // namespace sbo
