@@ -108,6 +108,8 @@ struct sbo_ctx {
   sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work, bl_cheb;
   // K1t (tensor.hip): fp64 grids of three / four axes by Chebyshev interpolation from exact node values
   int tensor_cheb = 1;             // option: 0 = always K1g
+  const double* k1g_axc = nullptr; // K1g launch arguments of launch_posterior_on_axes (explicit axis positions, gradient output)
+  void* k1g_grad = nullptr;
   bool tensor_busy = false;        // the exact node / probe launch of K1t is running through launch_posterior
   sbo::DevBuf tn_pts, tn_vals, tn_work, tn_W0t, tn_W1t, tn_probe, tn_scr;
   sbo::DevBuf tn_W[SBO_MAX_D];
@@ -275,6 +277,8 @@ int bilinear_setup(sbo_ctx* c);
 int launch_posterior_bilinear(sbo_ctx* c);
 bool tensor_applicable(const sbo_ctx* c);
 int launch_posterior_tensor(sbo_ctx* c, bool* declined);
+int launch_posterior_on_axes(sbo_ctx* c, int d, const long long* count, const double* axc, double* mean_out, double* var_out, double* grad_out,
+                             unsigned long long* lmax);
 }  // namespace sbo
 
 #define SBO_HIP(x)                                                   \

@@ -426,7 +426,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_build_tables(const ModelConst mc, const CandSpec cs, const T* __restrict__ As,
                                                       int D, T* __restrict__ E0f, size_t e0_stride, T* __restrict__ Er,
                                                       size_t er_stride_o, size_t er_off1, size_t er_off2, size_t er_off3,
-                                                      size_t er_off4, size_t er_off5, size_t er_off6, size_t er_off7) {
+                                                      size_t er_off4, size_t er_off5, size_t er_off6, size_t er_off7,
+                                                      const double* __restrict__ axc /* nullptr, or explicit axis positions (K1t's
+                                                      Chebyshev nodes): axis a at offset sum_{a' < a} count[a'] */) {
   const int o = blockIdx.y;
   const int nfr = mc.npad >> 2;
   const long long cnt0 = cs.count[0];
@@ -458,7 +460,12 @@ __global__ __launch_bounds__(256) void k_build_tables(const ModelConst mc, const
       dst = Er + (size_t)o * er_stride_o + er_off[a] + u;
     }
     const long long cnt = cs.count[a];
-    const double x = (i == cnt - 1 && cnt > 1) ? cs.hi[a] : cs.lo[a] + (double)i * cs.step[a];
+    double x = (i == cnt - 1 && cnt > 1) ? cs.hi[a] : cs.lo[a] + (double)i * cs.step[a];
+    if (axc) {
+      long long off = 0;
+      for (int a2 = 0; a2 < a; ++a2) off += cs.count[a2];
+      x = axc[off + i];
+    }
     const T xn = ((T)x - (T)mc.X_mean[a]) / (T)mc.X_std[a];
     const T diff = xn * (T)mc.vinv[o][a] - As[((size_t)o * mc.npad + j) * D + a];
     *dst = exp_t<T>(T(-0.5) * (diff * diff));
@@ -489,13 +496,15 @@ __device__ __forceinline__ int top_row_of_wave(int w, int nb) {
 
 // (three workgroups per CU asked for at D = 4: that instance needs 175 registers unconstrained, 7 above the limit for the
 // occupancy the D = 2 instance runs at)
-template <typename T, int S, int D>
+template <typename T, int S, int D, bool AX>
 __global__ __launch_bounds__(256, (D == 4 ? 3 : 1)) void k_posterior_grid(const ModelConst mc, const CandSpec cs, const GridTables gt,
                                                         const T* __restrict__ Fpk, size_t fpk_stride,
                                                         const T* __restrict__ E0f, const T* __restrict__ Er,
                                                         const T* __restrict__ AXg, unsigned int ntiles,
                                                         T* __restrict__ mean_out, T* __restrict__ var_out,
-                                                        unsigned long long* __restrict__ Lmax) {
+                                                        unsigned long long* __restrict__ Lmax,
+                                                        const double* __restrict__ axc, T* __restrict__ grad_out /* both nullptr,
+                                                        or: explicit axis positions, signed gradient components [q][d][n_local] */) {
   using acc_t = typename MM<T>::acc_t;
   using a_t = typename MM<T>::a_t;
   constexpr int P = 16 * S;
@@ -682,10 +691,16 @@ __global__ __launch_bounds__(256, (D == 4 ? 3 : 1)) void k_posterior_grid(const 
           if (a < mc.d) {
             const unsigned int ia = a == 0 ? g0 : line_row[par][s][a];
             const long long cnt = cs.count[a];
-            const double x = (ia == cnt - 1 && cnt > 1) ? cs.hi[a] : cs.lo[a] + (double)ia * cs.step[a];
+            double x = (ia == cnt - 1 && cnt > 1) ? cs.hi[a] : cs.lo[a] + (double)ia * cs.step[a];
+            if (AX) {
+              long long off = 0;
+              for (int a2 = 0; a2 < a; ++a2) off += cs.count[a2];
+              x = axc[off + ia];
+            }
             const T rstd = (T)mc.X_rstd[a];
             const T xn = ((T)x - (T)mc.X_mean[a]) * rstd;
             T ga = ystd * (sums[2 + a] - xn * sums[1]) * (T)mc.inv_ell[out][a] * rstd;
+            if (AX) grad_out[((size_t)out * mc.d + a) * cs.n_local + g] = ga;
             ga = ga < 0 ? -ga : ga;
             gn = ga > gn ? ga : gn;
           }
@@ -839,12 +854,15 @@ static int launch_posterior_grid_ts(sbo_ctx* c) {
   const long long total = (long long)gt.e0_stride + (long long)gt.er_stride_o;
   hipLaunchKernelGGL((k_build_tables<T>), dim3((unsigned)std::min<long long>((total + 255) / 256, 4096), q), dim3(256), 0,
                      c->stream, mc, cs, (const T*)c->As.p, mc.dpad, (T*)c->E0f.p, gt.e0_stride, (T*)c->Er.p, gt.er_stride_o,
-                     gt.er_off[1], gt.er_off[2], gt.er_off[3], gt.er_off[4], gt.er_off[5], gt.er_off[6], gt.er_off[7]);
+                     gt.er_off[1], gt.er_off[2], gt.er_off[3], gt.er_off[4], gt.er_off[5], gt.er_off[6], gt.er_off[7], c->k1g_axc);
   if ((rc = ensure(c->AXg, sizeof(T) * (size_t)q * npad * (1 + D)))) return rc;
   hipLaunchKernelGGL((k_build_ax<T>), dim3(1, q), dim3(256), 0, c->stream, mc, (const T*)c->alpha.p, (const T*)c->Xn.p, D,
                      (T*)c->AXg.p);
   const size_t lds = sizeof(T) * ((size_t)S * npad + 8 + (size_t)(2 + D) * kWaves * 4 * P);
-  auto kern = k_posterior_grid<T, S, D>;
+  // (explicit axis positions + gradient output: its own instance, fp64 grids of up to four axes only -- the plain one keeps its registers)
+  const bool ax = c->k1g_axc != nullptr;
+  if (ax && !(sizeof(T) == 8 && D == 4 && S == 4)) return fail(SBO_E_UNSUPPORTED, "internal: explicit axes are an fp64 path of three / four axes");
+  auto kern = ax ? k_posterior_grid<T, S, D, (sizeof(T) == 8 && D == 4 && S == 4)> : k_posterior_grid<T, S, D, false>;
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long long tiles = ntile0 * ((gt.nlines + S - 1) / S);
   if (tiles > 0x7fffffffLL) return fail(SBO_E_UNSUPPORTED, "too many candidate tiles for one launch");
@@ -857,7 +875,7 @@ static int launch_posterior_grid_ts(sbo_ctx* c) {
   const long long wgs = std::min<long long>(tiles, ((long long)c->n_cu * per_cu + q - 1) / q);
   hipLaunchKernelGGL(kern, dim3((unsigned)std::max<long long>(wgs, 1), (unsigned)q), dim3(256), lds, c->stream, mc, cs, gt,
                      (const T*)c->Fpk.p, c->fpk_stride, (const T*)c->E0f.p, (const T*)c->Er.p, (const T*)c->AXg.p,
-                     (unsigned int)tiles, (T*)c->mean.p, (T*)c->var.p, (unsigned long long*)c->Lmax.p);
+                     (unsigned int)tiles, (T*)c->mean.p, (T*)c->var.p, (unsigned long long*)c->Lmax.p, c->k1g_axc, (T*)c->k1g_grad);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
@@ -922,6 +940,38 @@ int launch_posterior(sbo_ctx* c) {
   if (c->posterior_path == 2 || tile_bytes > 64 * 1024)
     return c->dtype == SBO_F64 ? launch_posterior_chunked<double>(c) : launch_posterior_chunked<float>(c);
   return c->dtype == SBO_F64 ? launch_posterior_s<double>(c) : launch_posterior_s<float>(c);
+}
+
+// K1g on a tensor grid with explicit axis positions (fp64 models; K1t's Chebyshev nodes), into caller-given arrays: mean / var
+// [q][N], signed gradient components of the mean [q][d][N], N = prod count, axis 0 fastest.  The context's candidate description
+// and posterior buffers are swapped for the call; `lmax` receives the Lipschitz keys of this point set.
+int launch_posterior_on_axes(sbo_ctx* c, int d, const long long* count, const double* axc, double* mean_out, double* var_out, double* grad_out,
+                             unsigned long long* lmax) {
+  if (c->dtype != SBO_F64) return fail(SBO_E_UNSUPPORTED, "internal: explicit axes are an fp64 path");
+  { const int rcf = factor_sync(c); if (rcf) return rcf; }
+  const CandSpec keep_cs = c->cs;
+  const DevBuf keep_m = c->mean, keep_v = c->var, keep_l = c->Lmax;
+  memset(&c->cs, 0, sizeof(c->cs));
+  c->cs.kind = 1;
+  c->cs.d = d;
+  long long N = 1;
+  for (int a = 0; a < d; ++a) { c->cs.count[a] = count[a]; N *= count[a]; }
+  for (int a = d; a < kMaxD; ++a) c->cs.count[a] = 1;
+  c->cs.n_local = N;
+  c->mean.p = mean_out;
+  c->var.p = var_out;
+  c->Lmax.p = lmax;
+  c->k1g_axc = axc;
+  c->k1g_grad = grad_out;
+  int rc = hipMemsetAsync(lmax, 0, sizeof(unsigned long long) * kMaxQ, c->stream) == hipSuccess ? SBO_OK : fail(SBO_E_HIP, "memset of the key scratch");
+  if (!rc) rc = launch_posterior_grid<double>(c);
+  c->k1g_axc = nullptr;
+  c->k1g_grad = nullptr;
+  c->cs = keep_cs;
+  c->mean = keep_m;
+  c->var = keep_v;
+  c->Lmax = keep_l;
+  return rc;
 }
 
 int launch_bound(sbo_ctx* c, double b, int index, int kind, void* dev_out) {

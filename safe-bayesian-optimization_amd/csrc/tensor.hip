@@ -4,18 +4,21 @@
 // 268 M candidates of BASELINE.json configs[3] (128^4, n = 128).  But with the separable RBF-ARD kernel the posterior mean, the
 // quadratic form of the variance and the mean's gradient are analytic functions of the candidate whose variation along an axis
 // is set by the length scale, not by the grid: on [lo_a, hi_a] each of them is, to rounding, a polynomial of degree < Dn_a
-// (Dn ~ 48 for the BASELINE hyper-parameters -- the degree the 2-D path's Chebyshev core runs to).  So:
-//   1. the exact posterior (generic kernel K1, `launch_posterior` on an explicit list) and the signed gradient components of
-//      the mean (k_t_grad_nodes, O(n d) per node) at the Dn_0 x .. x Dn_{d-1} Chebyshev nodes of the first kind -- 5.3 M
-//      points for 48^4, 2 % of the grid;
+// (Dn = 48 for the BASELINE hyper-parameters -- the degree the 2-D path's Chebyshev core runs to).  So:
+//   1. K1g itself on the Dn_0 x .. x Dn_{d-1} tensor grid of Chebyshev nodes of the first kind (explicit axis positions,
+//      launch_posterior_on_axes): mean, variance and the signed gradient components of the mean at 5.3 M points for 48^4 --
+//      2 % of the grid;
 //   2. interpolation to the grid, one axis at a time: g(.., x_a, ..) = sum_k W_a[x_a][k] g(.., node k, ..) with
 //      W_a[x][k] = (1 / Dn) sum_m w_m T_m(xi_x) T_m(xi_k)  (the discrete Chebyshev transform and the series evaluation in one
 //      matrix).  Axes d-1 .. 2 are contracted by k_t_mode on the small tensors, the last two -- where the data grow to grid
-//      size -- by k_t_final, a workgroup per (x_2, x_3) plane: out = W_0 M W_1^T with the plane's Dn_0 x Dn_1 core M in LDS,
-//      written in grid order (axis 0 fastest) or, for the gradient components, reduced to max |.| on the fly (Lipschitz keys).
-// Accuracy is checked, not assumed: when a plan is built for a (model, grid) pair, 2048 grid points are also evaluated exactly
-// and compared with the interpolated values; a plan that misses 2e-11 (normalised units) retries one step up the degree ladder
-// and then declines (K1g runs).  Values differ from K1g's by the rounding of the interpolation sums (~1e-13).
+//      size -- by k_t_final on the matrix cores, a (quantity, plane) unit at a time: out = W_0 M W_1^T with the plane's Dn_0 x
+//      Dn_1 core M, written in grid order (axis 0 fastest) or, for the gradient components, reduced to max |.| on the fly (the
+//      Lipschitz keys).
+// Accuracy is checked, not assumed: when a plan is built for a (model, grid) pair, 2048 grid points are also evaluated by the
+// generic exact kernel and compared with the interpolated values; a plan that misses 2e-11 (normalised units) retries one step
+// up the degree ladder and then declines (K1g runs on the whole grid).  Values differ from K1g's by the rounding of the
+// interpolation sums (~1e-13 normalised).  Config D: 216.6 -> 15.9 ms (nodes 5.2, small contractions 2.2, planes 9.1 = 0.6 of
+// the FP64 rate).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -37,10 +40,15 @@ struct TensorDims {                  // by value
   double mid[kTMaxD], half[kTMaxD];  // axis intervals in raw coordinates
 };
 
-// node coordinates as an explicit candidate list [Nn][d], x = mid + half cos(pi (k + 1/2) / Dn); the low DM x DM digits of the node
-// index enumerate (k0, k1) in the packed-image order k_t_final reads (core_pos), the digits of the further axes follow
-template <int DM>
-__global__ __launch_bounds__(256) void k_t_nodes(const TensorDims td, long long Nn, double* __restrict__ pts);
+// Chebyshev nodes of the first kind per axis, concatenated (axis a at offset sum_{a' < a} Dn): x = mid + half cos(pi (k + 1/2) / Dn)
+__global__ void k_t_axes(const TensorDims td, double* __restrict__ axc) {
+  int off = 0;
+  for (int a = 0; a < td.d; ++a) {
+    for (int k = threadIdx.x; k < td.Dn[a]; k += blockDim.x) axc[off + k] = td.mid[a] + td.half[a] * cospi(((double)k + 0.5) / (double)td.Dn[a]);
+    off += td.Dn[a];
+  }
+}
+
 // interpolation matrix of axis a: W[x][k], x over the (local) grid positions of the axis; transposed copy Wt[k][x] for axis 0
 __global__ __launch_bounds__(256) void k_t_wmat(const TensorDims td, const CandSpec cs, int a, long long nx, long long x_first,
                                                 double* __restrict__ W, double* __restrict__ Wt) {
@@ -69,52 +77,23 @@ __global__ __launch_bounds__(256) void k_t_wmat(const TensorDims td, const CandS
   }
 }
 
-// signed gradient components of the un-normalised mean at explicit points (the analytic form of jax.grad(self.mean),
-// models/SafeOpt.py:68-71; k_rc_grad64's arithmetic): out[(o d + a) N + g]
-template <int D>
-__global__ __launch_bounds__(256) void k_t_grad_nodes(const ModelConst mc, const double* __restrict__ pts, long long N,
-                                                      const double* __restrict__ As, const double* __restrict__ sqA,
-                                                      const double* __restrict__ alpha, const double* __restrict__ Xn,
-                                                      double* __restrict__ out) {
-  const int n = mc.n, npad = mc.npad;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < N; g += (long long)gridDim.x * blockDim.x) {
-    double xn[D];
-#pragma unroll
-    for (int a = 0; a < D; ++a) xn[a] = a < mc.d ? (pts[g * mc.d + a] - mc.X_mean[a]) / mc.X_std[a] : 0.0;
-    for (int o = 0; o < mc.q; ++o) {
-      double bq[D], sqb = 0.0;
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        bq[a] = a < mc.d ? xn[a] * mc.vinv[o][a] : 0.0;
-        sqb += bq[a] * bq[a];
-      }
-      const double* Ao = As + (size_t)o * npad * D;
-      const double* so = sqA + (size_t)o * npad;
-      const double* al = alpha + (size_t)o * npad;
-      double s0 = 0.0, sa[D];
-#pragma unroll
-      for (int a = 0; a < D; ++a) sa[a] = 0.0;
-      for (int j = 0; j < n; ++j) {
-        double dot = 0.0;
-#pragma unroll
-        for (int a = 0; a < D; ++a) dot += Ao[(size_t)j * D + a] * bq[a];
-        const double w = al[j] * (mc.sf2[o] * exp(-0.5 * ((-2.0 * dot + so[j]) + sqb)));
-        s0 += w;
-#pragma unroll
-        for (int a = 0; a < D; ++a) sa[a] += w * Xn[(size_t)j * D + a];
-      }
-#pragma unroll
-      for (int a = 0; a < D; ++a)
-        if (a < mc.d) out[((size_t)o * mc.d + a) * N + g] = mc.Y_std[o] * (sa[a] - xn[a] * s0) * mc.inv_ell[o][a] * mc.X_rstd[a];
-    }
-  }
+// position p of a plane's dmc x dmc core in the packed-image order k_t_final reads its A operand in (M^T: rows b, inner index a;
+// images [b block][a block][256]) -> (a, b)
+__device__ __forceinline__ void core_pos(int p, int dmc, int& a, int& b) {
+  const int kb = dmc >> 4, blk = p >> 8, bb = blk / kb, ab = blk % kb;
+  int r, k, kk;
+  MM<double>::unpack_pos(p & 255, r, k, kk);
+  b = bb * 16 + r;
+  a = ab * 16 + kk * 4 + k;
 }
 
 // contraction of one axis that is not the fastest: out[p + pre (x + nx t)] = sum_m W[x][m] in[p + pre (m + DM t)], for nq
 // stacked quantities (strides sin / sout).  A thread per (p, t): its DM inputs in registers, W through LDS in chunks of rows.
+// dmc > 0 (the first contraction): the (k0, k1) digits of the output go into packed-image order -- the node tensors arrive
+// in grid order (k0 fastest) --, i.e. the thread of output position p reads input position a + dmc b, (a, b) = core_pos(p).
 template <int DM>
 __global__ __launch_bounds__(256) void k_t_mode(const double* __restrict__ in, size_t sin, double* __restrict__ out, size_t sout,
-                                                const double* __restrict__ W, long long pre, int Dm, long long nx, long long post) {
+                                                const double* __restrict__ W, long long pre, int Dm, long long nx, long long post, int dmc) {
   constexpr int kRows = 32;
   __shared__ double Ws[kRows][DM];
   const int qi = blockIdx.y;
@@ -124,9 +103,16 @@ __global__ __launch_bounds__(256) void k_t_mode(const double* __restrict__ in, s
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = e < total;
   const long long p = live ? e % pre : 0, t = live ? e / pre : 0;
+  long long pin = p;
+  if (dmc > 0) {
+    const int cc = dmc * dmc;
+    int a, b;
+    core_pos((int)(p % cc), dmc, a, b);
+    pin = (p / cc) * cc + a + dmc * b;
+  }
   double v[DM];
 #pragma unroll
-  for (int m = 0; m < DM; ++m) v[m] = (live && m < Dm) ? I[p + pre * ((long long)m + (long long)Dm * t)] : 0.0;
+  for (int m = 0; m < DM; ++m) v[m] = (live && m < Dm) ? I[pin + pre * ((long long)m + (long long)Dm * t)] : 0.0;
   for (long long x0 = 0; x0 < nx; x0 += kRows) {
     __syncthreads();
     for (int i = threadIdx.x; i < kRows * DM; i += blockDim.x) {
@@ -165,30 +151,6 @@ __global__ __launch_bounds__(256) void k_t_mode(const double* __restrict__ in, s
 //          tiles turn through a 16 x 32 LDS patch so that a lane stores 64 contiguous bytes of a grid row (axis 0 fastest).
 // Nothing is shared between the waves but the read-only W1 fragments: no barriers in the unit loop when n1 fits one chunk.
 // Quantity qi: mean of output qi (qi < q), variance (qi < 2 q, clipped at zero), gradient component (o, a) = (qi - 2 q) / d, % d.
-template <int DM>
-__host__ __device__ __forceinline__ void core_pos(int p, int& a, int& b) {      // position p of a plane's DM x DM core -> (a, b)
-  constexpr int KB = DM / 16;
-  const int blk = p >> 8, bb = blk / KB, ab = blk % KB;
-  int r, k, kk;
-  MM<double>::unpack_pos(p & 255, r, k, kk);
-  b = bb * 16 + r;
-  a = ab * 16 + kk * 4 + k;
-}
-
-template <int DM>
-__global__ __launch_bounds__(256) void k_t_nodes(const TensorDims td, long long Nn, double* __restrict__ pts) {
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < Nn; g += (long long)gridDim.x * blockDim.x) {
-    int k[kTMaxD];
-    core_pos<DM>((int)(g % (DM * DM)), k[0], k[1]);
-    long long f = g / (DM * DM);
-    for (int a = 2; a < td.d; ++a) {
-      k[a] = (int)(f % td.Dn[a]);
-      f /= td.Dn[a];
-    }
-    for (int a = 0; a < td.d; ++a) pts[g * td.d + a] = td.mid[a] + td.half[a] * cospi(((double)k[a] + 0.5) / (double)td.Dn[a]);
-  }
-}
-
 template <int DM, int CS>
 __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ in, size_t stride_q, const double* __restrict__ W0t,
                                                     const double* __restrict__ W1t, long long n0, long long n1, long long planes, int q, int d,
@@ -201,6 +163,11 @@ __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ i
   double* W1f = sm;                                                       // [KS][CS][64]
   double* Timg = sm + KS * CS * 64 + (size_t)wave * (2 * KB * 256);       // [strip 2][kb][256]
   double* stg = sm + KS * CS * 64 + 4 * (2 * KB * 256) + (size_t)wave * (16 * SP);   // [x1 16][SP]
+  // the plane's core for all four waves, double-buffered: the next unit's 18 KB are fetched into registers during step 2 and
+  // parked here behind the unit's only barrier, so step 1 never waits for memory (DM <= 48; the LDS has no room at 64)
+  constexpr bool PF = DM <= 48;
+  constexpr int PFN = DM * DM / 256;
+  double* Mimg = sm + KS * CS * 64 + 4 * (2 * KB * 256) + 4 * (16 * SP);              // [2][DM * DM]
   const int kq = lane >> 4, col = lane & 15;
   const long long tiles0 = (n0 + 127) / 128, chunks1 = (n1 + 16 * CS - 1) / (16 * CS);
   const long long per_tile = planes * nq, units = per_tile * tiles0;      // t0 slowest: the W0 fragments change once per tile
@@ -208,6 +175,17 @@ __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ i
   const long long iters = (units + gridDim.x - 1) / gridDim.x;
   long long cur_t0 = -1, cur_c1 = -1;
   double bw0[KS][2];
+  double pf[PFN];
+  auto core_of = [&](long long it_) {
+    const long long u_ = blockIdx.x + it_ * gridDim.x, uu_ = u_ < units ? u_ : units - 1, rest_ = uu_ % per_tile;
+    return in + (size_t)(rest_ % nq) * stride_q + (size_t)(rest_ / nq) * DM * DM;
+  };
+  if (PF) {
+    const double* I0 = core_of(0);
+#pragma unroll
+    for (int j = 0; j < PFN; ++j) Mimg[tid + 256 * j] = I0[tid + 256 * j];
+    __syncthreads();
+  }
   for (long long it = 0; it < iters; ++it) {
     const long long u = blockIdx.x + it * gridDim.x;
     const bool have = u < units;
@@ -227,18 +205,26 @@ __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ i
       cur_t0 = t0;
     }
     // step 1
-    const double* I = in + (size_t)qi * stride_q + (size_t)plane * DM * DM;
+    const double* I = PF ? Mimg + (size_t)(it & 1) * (DM * DM) : in + (size_t)qi * stride_q + (size_t)plane * DM * DM;
     {
       d4_t acc1[KB][2];
 #pragma unroll
       for (int bb = 0; bb < KB; ++bb) acc1[bb][0] = acc1[bb][1] = d4_t{0.0, 0.0, 0.0, 0.0};
+      // operands of k-step ks + 1 are requested before the products of ks are issued (one wave per SIMD: nothing else hides the
+      // LDS latency)
+      d4_t am[2][KB];
+#pragma unroll
+      for (int bb = 0; bb < KB; ++bb) am[0][bb] = MM<double>::load_a(I + (size_t)(bb * KB) * 256, lane, 0);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+#pragma unroll
+          for (int bb = 0; bb < KB; ++bb) am[(ks + 1) & 1][bb] = MM<double>::load_a(I + (size_t)(bb * KB + ((ks + 1) >> 2)) * 256, lane, (ks + 1) & 3);
+        }
 #pragma unroll
         for (int bb = 0; bb < KB; ++bb) {
-          const d4_t am = MM<double>::load_a(I + (size_t)(bb * KB + (ks >> 2)) * 256, lane, ks & 3);
-          acc1[bb][0] = MM<double>::mfma(am, bw0[ks][0], acc1[bb][0]);
-          acc1[bb][1] = MM<double>::mfma(am, bw0[ks][1], acc1[bb][1]);
+          acc1[bb][0] = MM<double>::mfma(am[ks & 1][bb], bw0[ks][0], acc1[bb][0]);
+          acc1[bb][1] = MM<double>::mfma(am[ks & 1][bb], bw0[ks][1], acc1[bb][1]);
         }
       }
       __builtin_amdgcn_wave_barrier();     // (the previous unit's step 2 reads of T are issued)
@@ -252,6 +238,11 @@ __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ i
 #pragma unroll
           for (int t = 0; t < 4; ++t) Timg[(size_t)(s_ * KB + bb) * 256 + t * 64 + tp] = acc1[bb][s_][t];
       __builtin_amdgcn_wave_barrier();
+    }
+    if (PF && it + 1 < iters) {
+      const double* In = core_of(it + 1);
+#pragma unroll
+      for (int j = 0; j < PFN; ++j) pf[j] = In[tid + 256 * j];
     }
     const int kind = qi < q ? 0 : (qi < 2 * q ? 1 : 2);
     double* O = kind == 0 ? mean + (size_t)qi * n_local : (kind == 1 ? var + (size_t)(qi - q) * n_local : nullptr);
@@ -273,33 +264,64 @@ __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ i
       for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) acc[s_][cs] = d4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
+      d4_t at[2][2];
+      double wv[2][CS];
+      at[0][0] = MM<double>::load_a(Timg, lane, 0);
+      at[0][1] = MM<double>::load_a(Timg + (size_t)KB * 256, lane, 0);
+#pragma unroll
+      for (int cs = 0; cs < CS; ++cs) wv[0][cs] = W1f[cs * 64 + lane];
+#pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const d4_t a0 = MM<double>::load_a(Timg + (size_t)(0 * KB + (ks >> 2)) * 256, lane, ks & 3);
-        const d4_t a1 = MM<double>::load_a(Timg + (size_t)(1 * KB + (ks >> 2)) * 256, lane, ks & 3);
+        if (ks + 1 < KS) {
+          at[(ks + 1) & 1][0] = MM<double>::load_a(Timg + (size_t)((ks + 1) >> 2) * 256, lane, (ks + 1) & 3);
+          at[(ks + 1) & 1][1] = MM<double>::load_a(Timg + (size_t)(KB + ((ks + 1) >> 2)) * 256, lane, (ks + 1) & 3);
+#pragma unroll
+          for (int cs = 0; cs < CS; ++cs) wv[(ks + 1) & 1][cs] = W1f[((ks + 1) * CS + cs) * 64 + lane];
+        }
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) {
-          const double w = W1f[(ks * CS + cs) * 64 + lane];
-          acc[0][cs] = MM<double>::mfma(a0, w, acc[0][cs]);
-          acc[1][cs] = MM<double>::mfma(a1, w, acc[1][cs]);
+          acc[0][cs] = MM<double>::mfma(at[ks & 1][0], wv[ks & 1][cs], acc[0][cs]);
+          acc[1][cs] = MM<double>::mfma(at[ks & 1][1], wv[ks & 1][cs], acc[1][cs]);
         }
+      }
+      // park the prefetched core before this unit's stores are issued: loads and stores return through one in-order counter,
+      // so a wait placed behind the stores would wait for them to reach memory
+      if (PF && c1 == 0 && it + 1 < iters) {
+#pragma unroll
+        for (int j = 0; j < PFN; ++j) Mimg[(size_t)((it + 1) & 1) * (DM * DM) + tid + 256 * j] = pf[j];
+        __syncthreads();
       }
       // element t of acc[s][cs] at lane l: x0 = x0w + 16 s + 4 t + kq, x1 = c1 16 CS + 16 cs + col
       if (!have) continue;
       if (kind == 2) {
+        const bool full = x0w + 32 <= n0 && (c1 + 1) * (16 * CS) <= n1;       // (wave-uniform)
+        if (full) {
+          double g0 = gmax, g1 = 0.0, g2 = 0.0, g3 = 0.0;                      // one v_max_f64 with |.| per element, four chains
 #pragma unroll
-        for (int cs = 0; cs < CS; ++cs) {
-          const bool live1 = c1 * (16 * CS) + cs * 16 + col < n1;
+          for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
-          for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const double v = acc[s_][cs][t], av = v < 0 ? -v : v;
-              gmax = (live1 && x0w + s_ * 16 + 4 * t + kq < n0 && av > gmax) ? av : gmax;
+            for (int s_ = 0; s_ < 2; ++s_) {
+              g0 = fmax(g0, fabs(acc[s_][cs][0]));
+              g1 = fmax(g1, fabs(acc[s_][cs][1]));
+              g2 = fmax(g2, fabs(acc[s_][cs][2]));
+              g3 = fmax(g3, fabs(acc[s_][cs][3]));
             }
+          gmax = fmax(fmax(g0, g1), fmax(g2, g3));
+        } else {
+#pragma unroll
+          for (int cs = 0; cs < CS; ++cs) {
+            const bool live1 = c1 * (16 * CS) + cs * 16 + col < n1;
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const double v = acc[s_][cs][t], av = v < 0 ? -v : v;
+                gmax = (live1 && x0w + s_ * 16 + 4 * t + kq < n0 && av > gmax) ? av : gmax;
+              }
+          }
         }
       } else {
-        const bool vec = (n0 & 3) == 0;
+        const bool vec = (n0 & 1) == 0;
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) {
           __builtin_amdgcn_wave_barrier();
@@ -311,19 +333,21 @@ __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ i
               stg[col * SP + s_ * 16 + 4 * t + kq] = kind == 1 ? (v > 0.0 ? v : 0.0) : v;
             }
           __builtin_amdgcn_wave_barrier();
-          const int xr = lane >> 2, xc = (lane & 3) * 8;                  // patch row (x1), first of eight x0
-          const d4_t v0 = *reinterpret_cast<const d4_t*>(stg + xr * SP + xc), v1 = *reinterpret_cast<const d4_t*>(stg + xr * SP + xc + 4);
-          const long long x1 = c1 * (16 * CS) + cs * 16 + xr, x0 = x0w + xc;
-          if (x1 < n1) {
-            double* row = O + (size_t)x1 * n0;
-            if (vec) {
-              if (x0 < n0) *reinterpret_cast<d4_t*>(row + x0) = v0;
-              if (x0 + 4 < n0) *reinterpret_cast<d4_t*>(row + x0 + 4) = v1;
-            } else {
+          // read back as rows: lane (l >> 4, l & 15) takes two x0 of patch rows l >> 4, 4 + (l >> 4), ..: one store instruction
+          // writes four whole 256-byte row pieces
+          const int xc = col * 2;
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                if (x0 + i < n0) row[x0 + i] = v0[i];
-                if (x0 + 4 + i < n0) row[x0 + 4 + i] = v1[i];
+          for (int r = 0; r < 4; ++r) {
+            const int xr = r * 4 + kq;
+            const d2_t v = *reinterpret_cast<const d2_t*>(stg + xr * SP + xc);
+            const long long x1 = c1 * (16 * CS) + cs * 16 + xr, x0 = x0w + xc;
+            if (x1 < n1) {
+              double* row = O + (size_t)x1 * n0;
+              if (vec) {
+                if (x0 < n0) *reinterpret_cast<d2_t*>(row + x0) = v;
+              } else {
+                if (x0 < n0) row[x0] = v[0];
+                if (x0 + 1 < n0) row[x0 + 1] = v[1];
               }
             }
           }
@@ -372,17 +396,17 @@ bool tensor_applicable(const sbo_ctx* c) {
 
 template <int DM>
 static void launch_mode(hipStream_t st, const double* in, size_t sin, double* out, size_t sout, const double* W, long long pre, int Dm,
-                        long long nx, long long post, int nq) {
+                        long long nx, long long post, int nq, int dmc) {
   const long long total = pre * post;
-  hipLaunchKernelGGL((k_t_mode<DM>), dim3((unsigned)((total + 255) / 256), (unsigned)nq), dim3(256), 0, st, in, sin, out, sout, W, pre, Dm, nx, post);
+  hipLaunchKernelGGL((k_t_mode<DM>), dim3((unsigned)((total + 255) / 256), (unsigned)nq), dim3(256), 0, st, in, sin, out, sout, W, pre, Dm, nx, post, dmc);
 }
 static int mode_dispatch(hipStream_t st, int DM, const double* in, size_t sin, double* out, size_t sout, const double* W, long long pre, int Dm,
-                         long long nx, long long post, int nq) {
+                         long long nx, long long post, int nq, int dmc) {
   switch (DM) {
-    case 32: launch_mode<32>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq); break;
-    case 48: launch_mode<48>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq); break;
-    case 64: launch_mode<64>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq); break;
-    case 96: launch_mode<96>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq); break;
+    case 32: launch_mode<32>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc); break;
+    case 48: launch_mode<48>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc); break;
+    case 64: launch_mode<64>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc); break;
+    case 96: launch_mode<96>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc); break;
     default: return fail(SBO_E_UNSUPPORTED, "internal: interpolation degree");
   }
   return SBO_OK;
@@ -418,7 +442,7 @@ static int exact_on_list(sbo_ctx* c, const double* pts, long long N, double* mea
 
 template <int DM, int CS>
 static int launch_final(sbo_ctx* c, const double* in, size_t stride_q, const TensorDims& td, long long planes, int nq) {
-  const size_t lds = sizeof(double) * ((size_t)(DM / 4) * CS * 64 + 4 * (size_t)(2 * (DM / 16) * 256) + 4 * 16 * 36);
+  const size_t lds = sizeof(double) * ((size_t)(DM / 4) * CS * 64 + 4 * (size_t)(2 * (DM / 16) * 256) + 4 * 16 * 36 + (DM <= 48 ? 2 * DM * DM : 0));
   auto kern = k_t_final<DM, CS>;
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long long units = planes * nq * ((td.cnt[0] + 127) / 128);
@@ -447,7 +471,7 @@ static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, lo
     double* dst = toA ? bufA : bufB;
     const size_t dst_stride = (size_t)pre * nx * post;
     if ((rc = mode_dispatch(c->stream, td.Dn[a] <= 32 ? 32 : (td.Dn[a] <= 48 ? 48 : (td.Dn[a] <= 64 ? 64 : 96)), cur, cur_stride, dst, dst_stride,
-                            (const double*)c->tn_W[a].p, pre, td.Dn[a], nx, post, nq)))
+                            (const double*)c->tn_W[a].p, pre, td.Dn[a], nx, post, nq, a == d - 1 ? td.Dn[0] : 0)))
       return rc;
     cur = dst;
     cur_stride = dst_stride;
@@ -494,12 +518,12 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     if (!c->tn_usable) return SBO_OK;
     for (int a = 0; a < d; ++a) level0[a] = c->tn_level[a];
   } else {
-    // first guess from the shortest length scale of the axis: degree ~ 8.3 x (normalised interval / ell), as the 2-D path's ladder
+    // first guess from the shortest length scale of the axis: degree ~ 7.6 x (normalised interval / ell); the probe below corrects a short guess
     for (int a = 0; a < d; ++a) {
       double tmax = 0.0;
       for (int o = 0; o < q; ++o) tmax = std::max(tmax, 2.0 * td.half[a] / mc.X_std[a] * std::sqrt(mc.inv_ell[o][a]));
       int lv = 0;
-      while (lv < 3 && kLadder[lv] < 8.3 * tmax) ++lv;
+      while (lv < 3 && kLadder[lv] < 7.6 * tmax) ++lv;
       level0[a] = lv;
     }
   }
@@ -519,7 +543,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     if (!ok_dims || Nn > (1ll << 24)) break;
     // buffers: node list, node values (mean, var: q each; gradient: q d), interpolation matrices, ping-pong work
     const int nqg = q * d;
-    if ((rc = ensure(c->tn_pts, sizeof(double) * (size_t)Nn * d))) return rc;
+    if ((rc = ensure(c->tn_pts, sizeof(double) * 4 * 128))) return rc;       // the node positions of the axes
     if ((rc = ensure(c->tn_vals, sizeof(double) * (size_t)Nn * (2 * q + nqg)))) return rc;
     size_t half_elems = 0;
     {
@@ -538,12 +562,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     if ((rc = ensure(c->tn_W0t, sizeof(double) * (size_t)td.cnt[0] * td.Dn[0]))) return rc;
     if ((rc = ensure(c->tn_W1t, sizeof(double) * (size_t)td.cnt[1] * td.Dn[1]))) return rc;
     if ((rc = ensure(c->tn_scr, 512))) return rc;
-    {
-      const dim3 gn((unsigned)std::min<long long>((Nn + 255) / 256, 1 << 16));
-      if (td.Dn[0] == 32) hipLaunchKernelGGL(k_t_nodes<32>, gn, dim3(256), 0, c->stream, td, Nn, (double*)c->tn_pts.p);
-      else if (td.Dn[0] == 48) hipLaunchKernelGGL(k_t_nodes<48>, gn, dim3(256), 0, c->stream, td, Nn, (double*)c->tn_pts.p);
-      else hipLaunchKernelGGL(k_t_nodes<64>, gn, dim3(256), 0, c->stream, td, Nn, (double*)c->tn_pts.p);
-    }
+    hipLaunchKernelGGL(k_t_axes, dim3(1), dim3(128), 0, c->stream, td, (double*)c->tn_pts.p);
     for (int a = 0; a < d; ++a)
       hipLaunchKernelGGL(k_t_wmat, dim3((unsigned)std::min<long long>((td.cnt[a] * td.Dn[a] + 255) / 256, 4096)), dim3(256), 0, c->stream, td, cs, a,
                          td.cnt[a], a == d - 1 ? td.first_last : 0ll, (double*)c->tn_W[a].p, a == 0 ? (double*)c->tn_W0t.p : (a == 1 ? (double*)c->tn_W1t.p : (double*)nullptr));
@@ -551,17 +570,12 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     double* nmean = (double*)c->tn_vals.p;
     double* nvar = nmean + (size_t)q * Nn;
     double* ngrad = nvar + (size_t)q * Nn;
-    if ((rc = exact_on_list(c, (const double*)c->tn_pts.p, Nn, nmean, nvar))) return rc;
     {
-      const unsigned nbg = (unsigned)std::max<long long>(1, std::min<long long>((Nn + 255) / 256, (long long)c->n_cu * 16));
-      if (mc.dpad == 4)
-        hipLaunchKernelGGL((k_t_grad_nodes<4>), dim3(nbg), dim3(256), 0, c->stream, mc, (const double*)c->tn_pts.p, Nn, (const double*)c->As.p,
-                           (const double*)c->sqA.p, (const double*)c->alpha.p, (const double*)c->Xn.p, ngrad);
-      else
-        return fail(SBO_E_UNSUPPORTED, "internal: K1t expects three or four axes");
+      long long cnt[kTMaxD];
+      for (int a = 0; a < d; ++a) cnt[a] = td.Dn[a];
+      if ((rc = launch_posterior_on_axes(c, d, cnt, (const double*)c->tn_pts.p, nmean, nvar, ngrad, (unsigned long long*)c->tn_scr.p))) return rc;
     }
     // interpolation: mean, variance (clipped at zero), gradient components -> Lipschitz keys max_a max_x |d MEAN_o / d x_a|
-    (void)ngrad;
     if ((rc = interpolate(c, td, nmean, Nn, 2 * q + nqg))) return rc;
     if (!same_grid) {
       // accuracy probe: 2048 grid points, exact against interpolated

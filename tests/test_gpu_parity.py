@@ -203,6 +203,83 @@ def test_chebyshev_core_equals_the_pair_form(engine, cfg_name, n, count, ll):
     assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < 2e-12 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < 2e-12
 
 
+def _tensor_model(d, n, log_ell, seed=7):
+    """A smooth two-output problem on [-2, 2]^d (objective + one constraint, safe near the origin) with fixed hyper-parameters."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-2.0, 2.0, size=(n, d))
+    Y = np.stack([np.sum(X ** 2, axis=1) + np.sin(2.0 * X[:, 0]), 3.0 - 0.5 * np.sum(X ** 2, axis=1) + X[:, 1]], axis=1)
+    return synthetic.make_dataset(X, Y, synthetic.default_hypopt(d, 2, log_ell=log_ell))
+
+
+@pytest.mark.parametrize("d,count,n,log_ell,kernel", [
+    (4, [64, 64, 64, 64], 128, -0.5, 5),        # BASELINE configs[3] hyper-parameters: 48 nodes per axis
+    (3, [160, 168, 160], 96, -0.5, 5),          # three axes, ragged tiles (168 = 128 + 40)
+    (3, [176, 160, 152], 64, 0.3, 5),           # long length scale: 32 nodes
+    (3, [160, 160, 168], 64, -1.3, 3),          # short length scale: more than 64 nodes on the first axes -- declined, K1g runs
+])
+def test_tensor_interpolation_equals_the_grid_kernel(engine, d, count, n, log_ell, kernel):
+    """K1t (option tensor_cheb, default on): fp64 grids of three / four axes take the exact posterior at a tensor grid of
+    Chebyshev nodes (K1g with explicit axis positions) and interpolate it to the candidates on the matrix cores.  Same function
+    as K1g on the whole grid: posterior equal to rounding, Lipschitz constants too, sweep results and masks identical, and a
+    sample of the grid within the bar of the NumPy oracle."""
+    ds = _tensor_model(d, n, log_ell)
+    lo, hi = np.full(d, -2.0), np.full(d, 2.0)
+    engine.set_model(ds)
+    out = {}
+    try:
+        for opt in (0, 1):
+            engine.set_option("tensor_cheb", opt)
+            engine.set_grid(lo, hi, count)
+            mean, var = engine.posterior()
+            kern = engine.profile()["posterior_kernel"]
+            res = engine.sweep_safeopt(2.0, want_masks=True)
+            masks = {k: engine.mask(k) for k in ("S", "U", "M")}
+            masks["G"] = engine.mask("G", 1)
+            out[opt] = (mean, var, kern, res, masks)
+    finally:
+        engine.set_option("tensor_cheb", 1)
+    assert out[0][2] == 3 and out[1][2] == kernel
+    ys = np.maximum(1.0, ds["Y_std"])
+    assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < 2e-11 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < 2e-11
+    r0, r1 = out[0][3], out[1][3]
+    for k in ("minimizer_index", "expander_index", "count_S", "count_U", "count_M", "choose_minimizer"):
+        assert r0[k] == r1[k], k
+    assert np.array_equal(r0["count_G"], r1["count_G"]) and np.array_equal(r0["expander_index_c"], r1["expander_index_c"])
+    assert np.allclose(r0["L"], r1["L"], rtol=1e-11, atol=0.0) and abs(r0["u_star"] - r1["u_star"]) <= 1e-10 * ys[0]
+    for k in ("S", "U", "M", "G"):
+        assert np.array_equal(out[0][4][k], out[1][4][k]), k
+    # a sample of the grid against the oracle
+    rng = np.random.default_rng(3)
+    total = int(np.prod(count))
+    idx = np.unique(np.concatenate([rng.integers(0, total, size=3000), [0, total - 1, count[0] - 1, total - count[0]]]))
+    axes = oracle.grid_axes(lo, hi, count)
+    sub = np.empty((idx.size, d))
+    f = idx.copy()
+    for a in range(d):
+        sub[:, a] = axes[a][f % count[a]]
+        f //= count[a]
+    om, ov = oracle.gp_inference(sub, ds)
+    assert _nerr(out[1][0][idx], om, ds["Y_std"], 1) < TOL64 and _nerr(out[1][1][idx], ov, ds["Y_std"], 2) < TOL64
+
+
+def test_tensor_interpolation_shards_reproduce_the_whole_grid_bitwise(engine):
+    """A rank's shard (whole hyper-planes of the last axis) interpolates the same node values with its own rows of the last
+    axis' matrix: the same sums, bit for bit."""
+    ds = _tensor_model(3, 64, -0.5)
+    lo, hi = np.full(3, -2.0), np.full(3, 2.0)
+    count = [160, 168, 160]
+    engine.set_model(ds)
+    engine.set_grid(lo, hi, count)
+    m, v = engine.posterior()
+    assert engine.profile()["posterior_kernel"] == 5
+    plane = count[0] * count[1]
+    for first, nloc in [(0, 80 * plane), (80 * plane, 80 * plane), (37 * plane, 64 * plane)]:
+        engine.set_grid(lo, hi, count, first=first, n_local=nloc)
+        ms, vs = engine.posterior()
+        assert engine.profile()["posterior_kernel"] == 5
+        assert np.array_equal(ms, m[first:first + nloc]) and np.array_equal(vs, v[first:first + nloc])
+
+
 def test_bilinear_rank_range_and_declines(engine):
     """Short length-scales need larger bases (r up to 64) and higher degrees: still the GEMM path when that is cheaper than
     the O(n^2) contraction, and still within tolerance -- with the Chebyshev core (inner dimension 2 rc - 1 <= 255 instead of up
