@@ -57,7 +57,8 @@ FP64_MFMA_MEASURED_TFLOPS = {"v_mfma_f64_4x4x4_4b_f64": 75.6, "v_mfma_f64_16x16x
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, f32-input MFMA
 HBM_PEAK_TBS, HBM_MEASURED_TBS = 8.0, 6.29    # MI355X_MICROARCH.md: datasheet / measured float4 copy
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per K1 launch from rocprofv3 --pmc
-K1_NAMES = {1: "k_posterior", 2: "k_posterior_chunked", 3: "k_posterior_grid", 4: "k_bpost (+ k_bstage1, stage 1)"}
+K1_NAMES = {1: "k_posterior", 2: "k_posterior_chunked", 3: "k_posterior_grid", 4: "k_bpost (+ k_bstage1, stage 1)",
+            5: "k_t_final (+ k_posterior_grid on the Chebyshev nodes, k_t_mode)"}
 
 
 def parse_args():
@@ -311,16 +312,17 @@ def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None, group=N
         out["fp64_recheck"] = {"candidates_reevaluated": int(rows[-1]["fp64_rechecks"]), "ms": float(np.mean([p["recheck_ms"] for p in rows])),
                                "note": "fp32 posterior; candidates its bounds cannot decide are re-evaluated in fp64 so that the masks "
                                        "equal the fp64 result"}
-    if alt is not None and cfg["count"] is not None and cfg["d"] == 2 and group is None:
+    if alt is not None and cfg["count"] is not None and group is None:
         it = timed_iterations(eng, [alt["ds"], cfg["ds"]], cfg["dtype"], step, max(4, steps // 3), 2, barrier)
         it["value"] = n_total / (it["ms_per_step"] * 1e-3)
         it["unit"] = "candidates/s"
         out["iteration"] = it
-    if table_kernel and mf["kernel"].startswith("k_bpost"):
+    if table_kernel and (mf["kernel"].startswith("k_bpost") or mf["kernel"].startswith("k_t_final")):
         # the same sweep with the separable-table kernel (the O(n^2)-per-candidate contraction on MFMA), same run
-        eng.set_option("bilinear", 0)
+        opt = "bilinear" if mf["kernel"].startswith("k_bpost") else "tensor_cheb"
+        eng.set_option(opt, 0)
         el_t, rows_t, _ = timed_resident(eng, step, 5, 2, barrier)
-        eng.set_option("bilinear", 1)
+        eng.set_option(opt, 1)
         rt, _ = mfma_roofline(cfg, rows_t, n_total)
         out["table_kernel"] = {"kernel": "k_posterior_grid", "device_ms_per_step": rt["device_ms_per_step"], "kernel_ms": rt["kernel_ms"],
                                "value": n_total * 5 / el_t, "unit": "candidates/s", "achieved": rt["algorithmic"]["achieved"],
@@ -450,11 +452,11 @@ def main():
                 roof["table_build_ms"] = it["table_build_ms"]
         if extras and default_run:
             # every other BASELINE.json config on this one GPU: B (configs[1], with its K1g figure), C (the Williams-Otto plant: GoOSE
-            # and SafeOpt), D (the whole 128^4 grid of the 8-GPU config, O(n^2) kernel K1g: 4 sweeps), E (10^7 scattered fp32 points)
+            # and SafeOpt), D (the whole 128^4 grid of the 8-GPU config: Chebyshev-node interpolation K1t, with its K1g figure), E (10^7 scattered fp32 points)
             out["extra"] = [extra_record(eng, *extra_cfgs["B"], "B", "safeopt", 100, barrier, table_kernel=True),
                             extra_record(eng, *extra_cfgs["C"], "C", "goose", 40, barrier),
                             extra_record(eng, *extra_cfgs["C"], "C", "safeopt", 40, barrier),
-                            extra_record(eng, extra_cfgs["D"][0], None, "D", "safeopt", 4, barrier),
+                            extra_record(eng, *extra_cfgs["D"], "D", "safeopt", 10, barrier, table_kernel=True),
                             extra_record(eng, extra_cfgs["E"][0], None, "E", "safeopt", 3, barrier, points=10_000_000)]
         if world == 1 and args.cpu_sample > 0 and not scattered:
             # (a bounded sample of CPU work: config B's grid -- a quarter of H's candidates at a sixteenth of its flops per candidate)

@@ -144,7 +144,8 @@ typedef struct sbo_profile {
   double posterior_flops;  /* algorithmic flops of the K1 launch(es): q (n^2 + (2d+10) n) per candidate    */
   int64_t candidates;      /* candidates swept by this rank                                                */
   int32_t posterior_launches;
-  int32_t posterior_kernel;      /* which K1 ran last: 1 generic, 2 generic chunked, 3 separable tables (K1g), 4 bilinear GEMMs (K1b) */
+  int32_t posterior_kernel;      /* which K1 ran last: 1 generic, 2 generic chunked, 3 separable tables (K1g), 4 bilinear GEMMs (K1b),
+                                    5 Chebyshev-node interpolation on 3-D / 4-D grids (K1t) */
   double posterior_executed_flops; /* matrix-core flops the last K1 launch(es) actually issued (K1b: far below the algorithmic count) */
   double posterior_setup_ms;     /* host time of the last per-(model, grid) table build of K1b, 0 when none was needed        */
   int64_t fp64_rechecks;         /* dtype SBO_F32 SafeOpt sweeps: candidates whose fp32 bounds could not decide S / U / u* / M / the
@@ -263,7 +264,9 @@ int sbo_plant_wo(sbo_ctx* ctx, int64_t n, const double* u, double* out);
 int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
 /* tuning / diagnostics knobs: "posterior_path" (0 auto, 1 generic single-phase, 2 generic chunked), "bilinear" (1 default:
  * fp64 2-D grids run the posterior as two GEMMs in a reduced basis when that is cheaper; 0: always the separable-table
- * kernel), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
+ * kernel), "tensor_cheb" (1 default: fp64 grids of three / four axes with at least 64 positions per axis take the exact posterior on a
+ * tensor grid of Chebyshev nodes and interpolate it to the candidates on the matrix cores when a probe of 2048 exactly evaluated grid
+ * points confirms 2e-11; 0: always the separable-table kernel), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
  * "scan_waves" (1 default: open candidates of the expander query are scanned by half-waves), "goose_pairs" (1: pair
  * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile), "bl_host_bases" (1: the axis bases of the GEMM posterior by
  * the host SVD of bilinear_host.hpp instead of the device kernel), "fuse_classify" (one-constraint sweeps take S / U from

@@ -114,6 +114,7 @@ struct sbo_ctx {
   sbo::DevBuf tn_pts, tn_vals, tn_work, tn_W0t, tn_W1t, tn_probe, tn_scr;
   sbo::DevBuf tn_W[SBO_MAX_D];
   size_t tn_work_half = 0;
+  double tn_flops = 0.0;           // multiply-add flops of the last interpolation pass
   bool tn_valid = false, tn_usable = false;     // plan decided for (tn_model, grid below) / it passed its accuracy probe
   unsigned long long tn_model = 0;
   long long tn_first = 0, tn_nlocal = 0, tn_count[4] = {0, 0, 0, 0};

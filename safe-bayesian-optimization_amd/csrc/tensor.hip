@@ -473,6 +473,7 @@ static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, lo
     if ((rc = mode_dispatch(c->stream, td.Dn[a] <= 32 ? 32 : (td.Dn[a] <= 48 ? 48 : (td.Dn[a] <= 64 ? 64 : 96)), cur, cur_stride, dst, dst_stride,
                             (const double*)c->tn_W[a].p, pre, td.Dn[a], nx, post, nq, a == d - 1 ? td.Dn[0] : 0)))
       return rc;
+    c->tn_flops += 2.0 * (double)pre * td.Dn[a] * (double)nx * (double)post * nq;
     cur = dst;
     cur_stride = dst_stride;
     post *= nx;
@@ -480,6 +481,7 @@ static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, lo
     toA = !toA;
   }
   // now cur = [DM][DM][planes = post] per quantity
+  c->tn_flops += 2.0 * (double)post * nq * ((double)td.cnt[0] * td.Dn[0] * td.Dn[1] + (double)td.cnt[0] * td.cnt[1] * td.Dn[1]);
   SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
   switch (td.Dn[0]) {
     case 32: return launch_final<32, 8>(c, cur, cur_stride, td, post, nq);
@@ -576,6 +578,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       if ((rc = launch_posterior_on_axes(c, d, cnt, (const double*)c->tn_pts.p, nmean, nvar, ngrad, (unsigned long long*)c->tn_scr.p))) return rc;
     }
     // interpolation: mean, variance (clipped at zero), gradient components -> Lipschitz keys max_a max_x |d MEAN_o / d x_a|
+    c->tn_flops = 0.0;
     if ((rc = interpolate(c, td, nmean, Nn, 2 * q + nqg))) return rc;
     if (!same_grid) {
       // accuracy probe: 2048 grid points, exact against interpolated
@@ -625,8 +628,8 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     }
     *declined = false;
     c->last_k1 = 5;
-    // flops issued (vector units; no matrix cores on this path): node posterior (triangular contraction) + interpolation sums
-    c->last_k1_flops = (double)q * mc.npad * (mc.npad + 16.0) * (double)Nn;
+    // flops issued: node posterior (block-triangular contraction) + interpolation sums
+    c->last_k1_flops = (double)q * mc.npad * (mc.npad + 16.0) * (double)Nn + c->tn_flops;
     return SBO_OK;
   }
   c->tn_valid = true;
