@@ -1080,23 +1080,41 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
     const double* LA = lds + cur * BUF + (RB * cx.wave) * 256 + cx.a_rd;
     const double* LB = lds + cur * BUF + BOFF + cx.lane;
     const int kkn = KS - kb * 4 < 4 ? KS - kb * 4 : 4;
+    // operands of k-step kk + 1 are requested before the products of kk are issued (two register sets, no copies): the LDS
+    // latency of a k-step's ten reads otherwise sits in front of its 64 matrix instructions
+    d4_t fa[2][RB];
+    double fb[2][8];
+    auto ld = [&](int kk, d4_t (&a)[RB], double (&b)[8]) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const d2_t l = *reinterpret_cast<const d2_t*>(LA + i * 256 + kk * 64), h = *reinterpret_cast<const d2_t*>(LA + i * 256 + kk * 64 + 32);
+        a[i] = d4_t{l[0], l[1], h[0], h[1]};
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) b[s2] = LB[(s2 * 4 + kk) * 64];
+    };
+    auto mm = [&](const d4_t (&a)[RB], const double (&b)[8]) {
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+        for (int i = 0; i < RB; ++i) acc[i][s2] = MM<double>::mfma(a[i], b[s2], acc[i][s2]);
+    };
+    if constexpr (RB == 2) {
+      ld(0, fa[0], fb[0]);
+      int kk = 0;
 #pragma unroll 1
-    for (int kk = 0; kk < kkn; ++kk) {
-      if constexpr (RB == 2) {
-        const d2_t l0 = *reinterpret_cast<const d2_t*>(LA + kk * 64), h0 = *reinterpret_cast<const d2_t*>(LA + kk * 64 + 32);
-        const d2_t l1 = *reinterpret_cast<const d2_t*>(LA + 256 + kk * 64), h1 = *reinterpret_cast<const d2_t*>(LA + 256 + kk * 64 + 32);
-        const d4_t a0 = d4_t{l0[0], l0[1], h0[0], h0[1]}, a1 = d4_t{l1[0], l1[1], h1[0], h1[1]};
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-          const double b = LB[(s2 * 4 + kk) * 64];
-          acc[0][s2] = MM<double>::mfma(a0, b, acc[0][s2]);
-          acc[1][s2] = MM<double>::mfma(a1, b, acc[1][s2]);
-        }
-      } else {
-        const d2_t l0 = *reinterpret_cast<const d2_t*>(LA + kk * 64), h0 = *reinterpret_cast<const d2_t*>(LA + kk * 64 + 32);
-        const d4_t a0 = d4_t{l0[0], l0[1], h0[0], h0[1]};
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) acc[0][s2] = MM<double>::mfma(a0, LB[(s2 * 4 + kk) * 64], acc[0][s2]);
+      for (; kk + 1 < kkn; kk += 2) {
+        ld(kk + 1, fa[1], fb[1]);
+        mm(fa[0], fb[0]);
+        if (kk + 2 < kkn) ld(kk + 2, fa[0], fb[0]);
+        mm(fa[1], fb[1]);
+      }
+      if (kk < kkn) mm(fa[0], fb[0]);
+    } else {                               // (three workgroups per CU and 168 registers: no room for a second operand set)
+#pragma unroll 1
+      for (int kk = 0; kk < kkn; ++kk) {
+        ld(kk, fa[0], fb[0]);
+        mm(fa[0], fb[0]);
       }
     }
     if (kb + 1 < nkb) stage(lds + (cur ^ 1) * BUF, ra0, ra1, rb0v, rb1v);
