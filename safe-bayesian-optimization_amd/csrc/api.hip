@@ -276,7 +276,7 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     return SBO_OK;
   }
   if (!strcmp(key, "post_rb")) {
-    if (value < 0 || value > 2) return fail(SBO_E_INVALID, "post_rb must be 0 (auto), 1 or 2");
+    if (value < 0 || value > 3) return fail(SBO_E_INVALID, "post_rb must be 0 (auto), 1, 2 or 3");
     c->post_rb = (int)value;
     c->posterior_valid = false;
     return SBO_OK;

@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cmath>
 #include <vector>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include "bilinear_host.hpp"
 #include "device_common.hpp"
@@ -1028,6 +1029,88 @@ __device__ __forceinline__ void post_classify_mv(PostCtx& cx, size_t g, double m
 }
 __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) { post_classify_mv(cx, g, m, cx.var_rd[g]); }
 
+// Epilogue of phase PH for the RB x 8 accumulator tiles of a wave (row blocks cx.rb0 + RB cx.wave + i, strips cx.cs0 + s2)
+template <int PH, int RB>
+__device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ outp, double c0, double c1, double c2, double& gmax,
+                                              d4_t (&acc)[RB][8]) {
+  // epilogue: accumulator element t of lane l is row 4 t + (l >> 4), column l & 15 of its 16 x 16 tile
+  const unsigned int col_in = cx.lane & 15, row_in = cx.lane >> 4;
+  if (cx.full) {
+    // interior tile: no bounds tests, one pointer per row, the eight strips at immediate offsets.  The matrix cores
+    // share the f64 VALU datapath, so every instruction saved here is matrix time.
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const unsigned int line = (unsigned int)(cx.rb0 + RB * cx.wave + i) * 16u + 4u * t + row_in;
+        const size_t g0 = (size_t)line * cx.ucnt0 + (unsigned int)cx.cs0 * 16u + col_in;
+        double* const rowp = outp + g0;
+        if (PH == 1 && cx.S) {
+          // fused classification: the eight variances of this row first (all loads in flight; the byte stores below may
+          // alias anything as far as the compiler knows), then bounds, S / U bytes and the partial sums
+          double vr[8], mv[8];
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) vr[s2] = cx.var_rd[g0 + s2 * 16];
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            mv[s2] = (c0 + acc[i][s2][t]) * c1 + c2;
+            rowp[s2 * 16] = mv[s2];
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) post_classify_mv(cx, g0 + s2 * 16, mv[s2], vr[s2]);
+          continue;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const double v = acc[i][s2][t];
+          if (PH == 0) {
+            double var = c0 - v;
+            var = var > 0.0 ? var : 0.0;
+            rowp[s2 * 16] = var * c1;
+          } else if (PH == 1) {
+            rowp[s2 * 16] = (c0 + v) * c1 + c2;
+          } else {
+            double ga = c0 * v;
+            ga = ga < 0 ? -ga : ga;
+            gmax = ga > gmax ? ga : gmax;
+          }
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int rb = cx.rb0 + RB * cx.wave + i;
+    if (rb >= cx.nrb) continue;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned int line = (unsigned int)rb * 16u + 4u * t + row_in;
+      if ((long long)line >= cx.nlines) continue;
+      double* const rowp = outp + (size_t)line * cx.ucnt0;
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        const unsigned int x0 = (unsigned int)(cx.cs0 + s2) * 16u + col_in;
+        if (cx.cs0 + s2 >= cx.ncs || x0 >= cx.ucnt0) continue;
+        const double v = acc[i][s2][t];
+        if (PH == 0) {
+          double var = c0 - v;                                              // models/GP_Safe.py:343, clipped at 0
+          var = var > 0.0 ? var : 0.0;
+          rowp[x0] = var * c1;                                              // :347
+        } else if (PH == 1) {
+          const double m = (c0 + v) * c1 + c2;                              // :342, :346
+          rowp[x0] = m;
+          if (cx.S) post_classify(cx, (size_t)line * cx.ucnt0 + x0, m);
+        } else {
+          // component of the gradient of the un-normalised mean (analytic jax.grad(self.mean), SafeOpt.py:68-71)
+          double ga = c0 * v;
+          ga = ga < 0 ? -ga : ga;
+          gmax = ga > gmax ? ga : gmax;
+        }
+      }
+    }
+  }
+}
+
 template <int PH, int RB>
 __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict__ A, const double* __restrict__ B, int KB,
                                            int KS, double* __restrict__ outp, double c0, double c1, double c2, double& gmax,
@@ -1120,82 +1203,7 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
     if (kb + 1 < nkb) stage(lds + (cur ^ 1) * BUF, ra0, ra1, rb0v, rb1v);
     __syncthreads();
   }
-  // epilogue: accumulator element t of lane l is row 4 t + (l >> 4), column l & 15 of its 16 x 16 tile
-  const unsigned int col_in = cx.lane & 15, row_in = cx.lane >> 4;
-  if (cx.full) {
-    // interior tile: no bounds tests, one pointer per row, the eight strips at immediate offsets.  The matrix cores
-    // share the f64 VALU datapath, so every instruction saved here is matrix time.
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const unsigned int line = (unsigned int)(cx.rb0 + RB * cx.wave + i) * 16u + 4u * t + row_in;
-        const size_t g0 = (size_t)line * cx.ucnt0 + (unsigned int)cx.cs0 * 16u + col_in;
-        double* const rowp = outp + g0;
-        if (PH == 1 && cx.S) {
-          // fused classification: the eight variances of this row first (all loads in flight; the byte stores below may
-          // alias anything as far as the compiler knows), then bounds, S / U bytes and the partial sums
-          double vr[8], mv[8];
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) vr[s2] = cx.var_rd[g0 + s2 * 16];
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) {
-            mv[s2] = (c0 + acc[i][s2][t]) * c1 + c2;
-            rowp[s2 * 16] = mv[s2];
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) post_classify_mv(cx, g0 + s2 * 16, mv[s2], vr[s2]);
-          continue;
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-          const double v = acc[i][s2][t];
-          if (PH == 0) {
-            double var = c0 - v;
-            var = var > 0.0 ? var : 0.0;
-            rowp[s2 * 16] = var * c1;
-          } else if (PH == 1) {
-            rowp[s2 * 16] = (c0 + v) * c1 + c2;
-          } else {
-            double ga = c0 * v;
-            ga = ga < 0 ? -ga : ga;
-            gmax = ga > gmax ? ga : gmax;
-          }
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < RB; ++i) {
-    const int rb = cx.rb0 + RB * cx.wave + i;
-    if (rb >= cx.nrb) continue;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const unsigned int line = (unsigned int)rb * 16u + 4u * t + row_in;
-      if ((long long)line >= cx.nlines) continue;
-      double* const rowp = outp + (size_t)line * cx.ucnt0;
-#pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2) {
-        const unsigned int x0 = (unsigned int)(cx.cs0 + s2) * 16u + col_in;
-        if (cx.cs0 + s2 >= cx.ncs || x0 >= cx.ucnt0) continue;
-        const double v = acc[i][s2][t];
-        if (PH == 0) {
-          double var = c0 - v;                                              // models/GP_Safe.py:343, clipped at 0
-          var = var > 0.0 ? var : 0.0;
-          rowp[x0] = var * c1;                                              // :347
-        } else if (PH == 1) {
-          const double m = (c0 + v) * c1 + c2;                              // :342, :346
-          rowp[x0] = m;
-          if (cx.S) post_classify(cx, (size_t)line * cx.ucnt0 + x0, m);
-        } else {
-          // component of the gradient of the un-normalised mean (analytic jax.grad(self.mean), SafeOpt.py:68-71)
-          double ga = c0 * v;
-          ga = ga < 0 ? -ga : ga;
-          gmax = ga > gmax ? ga : gmax;
-        }
-      }
-    }
-  }
+  post_epilogue<PH, RB>(cx, outp, c0, c1, c2, gmax, acc);
 }
 
 // RB: row blocks per wave.  2 = the 128 x 128 tile above; 1 = a 64 x 128 tile for grids whose 128 x 128 tiles would leave
@@ -1283,6 +1291,173 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
       else if (cx.lane == 2) v = (unsigned long long)cU;
       else if (cx.lane == 4) v = rm >= 0.0 ? ord_key(rm) : 0ull;       // radius key of constraint 1 (slot 3 + c)
       row[cx.lane] = v;
+    }
+  }
+}
+
+// k_bpost_res -- the same four phases with nothing staged per tile (r03).  Switching parts of k_bpost off on config H showed
+// where its 257 us go: 102 are matrix instructions, 58 are the phases' prologues (a global -> LDS staging round and two
+// barriers in front of each of the four short loops of every tile) and 65-75 the epilogues.  Here a workgroup of EIGHT waves owns
+// an (output, block of 128 axis-0 positions) pair for the whole launch and keeps that pair's B fragments -- the variance
+// phase's P0 (up to `cap0` k-steps) and the S0 rows all three short phases multiply by -- resident in LDS (72 KB at the
+// BASELINE sizes); a wave takes row blocks of 16 lines, 8 strips wide, and streams only its A images, straight from memory
+// into registers one k-block (2 KB) ahead -- across phase and row-block boundaries, so no loop ever starts cold.  No barrier
+// after the preload.  Sums, epilogue arithmetic and therefore every output bit are those of k_bpost.
+// grid (workgroups per pair, column blocks, outputs); Lpart / cpart rows: ((o ncb + cb) wgs + wg) 8 + wave.
+__global__ __launch_bounds__(512, 1) void k_bpost_res(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
+                                                      const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA, size_t sVA,
+                                                      const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm, int KSm, int KBm2,
+                                                      int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
+                                                      double* __restrict__ var_out, double* __restrict__ Lpart, const double* __restrict__ xn0,
+                                                      uint8_t* __restrict__ Sfuse, uint8_t* __restrict__ Ufuse, double bconf,
+                                                      unsigned long long* __restrict__ cpart, const int* __restrict__ eff, int cap0) {
+  extern __shared__ double lds[];               // [cap0][8][64] variance-phase fragments | [KSm][8][64] S0 fragments
+  const int o = blockIdx.z, cb = blockIdx.y, wg = blockIdx.x, wgs = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KS0e = eff ? eff[4 * o] : KS0;
+  const int cap = cap0 < KS0e ? cap0 : KS0e;
+  double* const B0 = lds;
+  double* const Bm = lds + (size_t)cap0 * 512;
+  const double* P0o = P0f + (size_t)o * sP0f;
+  const double* SBo = SBf + (size_t)o * sSBf;
+  const double* VAo = VA + (size_t)o * sVA;
+  const int cs0 = cb * 8;
+  // preload (strips behind the grid: the last one again -- the epilogue skips them)
+  for (int e = tid; e < (cap + KSm) * 512; e += 512) {
+    const int l = e & 63, s2 = (e >> 6) & 7, ks = e >> 9;
+    const int csx = cs0 + s2 < ncs ? cs0 + s2 : ncs - 1;
+    if (ks < cap) B0[e] = P0o[((size_t)csx * KB0 * 4 + ks) * 64 + l];
+    else Bm[(size_t)(ks - cap) * 512 + (s2 << 6) + l] = SBo[((size_t)csx * KBm * 4 + (ks - cap)) * 64 + l];
+  }
+  __syncthreads();
+  PostCtx cx;
+  cx.lds = lds;
+  cx.tid = tid; cx.lane = lane; cx.wave = 0;
+  cx.cs0 = cs0; cx.nrb = nrb; cx.ncs = ncs;
+  cx.ucnt0 = (unsigned int)cs.count[0];
+  cx.nlines = nlines;
+  const double sf2 = mc.sf2[o], ystd = mc.Y_std[o];
+  double* const vo = var_out + (size_t)o * cs.n_local;
+  double* const mo = mean_out + (size_t)o * cs.n_local;
+  const bool fuse = Sfuse != nullptr && o == 1;
+  cx.var_rd = vo;
+  cx.S = fuse ? Sfuse : nullptr;
+  cx.U = Ufuse;
+  cx.bconf = bconf;
+  cx.bb = bconf * bconf;
+  cx.cS = cx.cU = 0;
+  cx.rmax = -1.0;
+  double gmax = 0.0;
+  // the A operands of the four phases: images [nrb][KB][256] per set
+  const double* const A0 = BtA + (size_t)o * sBtA;
+  const double* const A2 = VAo + (size_t)nrb * KBm * 256;
+  const double* const A3 = VAo + (size_t)nrb * (KBm + KBm2) * 256;
+  const int a_off = (((lane >> 4) << 2) + (lane & 3)) * 4;          // this lane's 32 bytes of a k-step (MM<double>::load_a)
+  auto load_blk = [&](int ph, int rb, int kb, d4_t (&a)[4]) {        // (ph is a constant at every call site)
+    const double* base = ph == 0 ? A0 : (ph == 1 ? VAo : (ph == 2 ? A2 : A3));
+    const int akb = ph == 0 ? KB0 : (ph == 2 ? KBm2 : KBm);
+    const double* img = base + ((size_t)rb * akb + kb) * 256 + a_off;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) a[kk] = *reinterpret_cast<const d4_t*>(img + kk * 64);
+  };
+  const int stride = wgs * 8;
+  int rb = wg * 8 + wave;
+  d4_t ac[4];                                   // A fragments of the k-block being multiplied; refilled in place for the next one
+  if (rb < nrb) load_blk(0, rb, 0, ac);
+  d4_t acc[1][8];
+  for (; rb < nrb; rb += stride) {
+    cx.rb0 = rb;
+    cx.full = (long long)(rb + 1) * 16 <= nlines && (long long)(cs0 + 8) * 16 <= cs.count[0];
+    auto phase = [&](auto phc) {
+      constexpr int ph = decltype(phc)::value;
+      const int KS = ph == 0 ? KS0e : KSm, nkb = (KS + 3) >> 2;
+      if (ph == 2) {
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const unsigned int x = (unsigned int)(cs0 + s2) * 16u + (lane & 15);
+          const double f = x < cx.ucnt0 ? -xn0[x] : 0.0;
+          acc[0][s2] = d4_t{acc[0][s2][0] * f, acc[0][s2][1] * f, acc[0][s2][2] * f, acc[0][s2][3] * f};
+        }
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) acc[0][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
+      }
+      const double* const Bres = ph == 0 ? B0 : Bm;
+      auto load_b = [&](int ks, double (&b)[8]) {
+        if (ph != 0 || ks < cap) {
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) b[s2] = Bres[(size_t)ks * 512 + (s2 << 6) + lane];
+        } else {                                // variance-phase k-steps beyond the resident ones (long expansions): from memory
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            const int csx = cs0 + s2 < ncs ? cs0 + s2 : ncs - 1;
+            b[s2] = P0o[((size_t)csx * KB0 * 4 + ks) * 64 + lane];
+          }
+        }
+      };
+      double b0[8], b1[8];                      // the fragments of the k-step being multiplied / of the next one, alternating
+      load_b(0, b0);
+#pragma unroll 1
+      for (int kb = 0; kb < nkb; ++kb) {
+        // the k-block after this one in the sequence: this phase's next, the next phase's first, or the next row block's first;
+        // its fragment kk is requested into ac[kk] as soon as this block's k-step kk has been issued (three k-steps ahead)
+        const bool last = kb + 1 == nkb;
+        const double* nimg = last ? (ph == 0 ? VAo + (size_t)rb * KBm * 256
+                                     : ph == 1 ? A2 + (size_t)rb * KBm2 * 256
+                                     : ph == 2 ? A3 + (size_t)rb * KBm * 256
+                                               : A0 + (size_t)(rb + stride < nrb ? rb + stride : rb) * KB0 * 256)
+                                  : (ph == 0 ? A0 + ((size_t)rb * KB0 + kb + 1) * 256
+                                     : ph == 1 ? VAo + ((size_t)rb * KBm + kb + 1) * 256
+                                     : ph == 2 ? A2 + ((size_t)rb * KBm2 + kb + 1) * 256
+                                               : A3 + ((size_t)rb * KBm + kb + 1) * 256);
+        nimg += a_off;
+        const int ks0 = kb * 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (ks0 + kk < KS) {                  // (uniform)
+            if (ks0 + kk + 1 < KS) load_b(ks0 + kk + 1, (kk & 1) ? b0 : b1);
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) acc[0][s2] = MM<double>::mfma(ac[kk], (kk & 1) ? b1[s2] : b0[s2], acc[0][s2]);
+          }
+          ac[kk] = *reinterpret_cast<const d4_t*>(nimg + kk * 64);
+        }
+      }
+      if constexpr (ph == 0) post_epilogue<0, 1>(cx, vo, sf2, ystd * ystd, 0.0, gmax, acc);
+      else if constexpr (ph == 1) post_epilogue<1, 1>(cx, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc);
+      else if constexpr (ph == 2) post_epilogue<2, 1>(cx, nullptr, ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax, acc);
+      else post_epilogue<3, 1>(cx, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0, gmax, acc);
+    };
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double other = __shfl_xor(gmax, off);
+    gmax = other > gmax ? other : gmax;
+  }
+  const size_t prow = (((size_t)o * gridDim.y + cb) * wgs + wg) * 8 + wave;
+  if (lane == 0) Lpart[prow] = gmax;
+  if (fuse) {
+    int cS = cx.cS, cU = cx.cU;
+    double rm = cx.rmax;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      cS += __shfl_xor(cS, off);
+      cU += __shfl_xor(cU, off);
+      const double other = __shfl_xor(rm, off);
+      rm = other > rm ? other : rm;
+    }
+    if (lane < kFuseRow) {
+      unsigned long long* row = cpart + ((((size_t)cb * wgs + wg) * 8 + wave)) * kFuseRow;
+      unsigned long long v = 0ull;
+      if (lane == 0) v = ~0ull;
+      else if (lane == 1) v = (unsigned long long)cS;
+      else if (lane == 2) v = (unsigned long long)cU;
+      else if (lane == 4) v = rm >= 0.0 ? ord_key(rm) : 0ull;
+      row[lane] = v;
     }
   }
 }
@@ -1927,28 +2102,47 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   int rbw = (pl.cheb || wgs_rb2 * q < c->n_cu) ? 1 : 2;
   if (c->post_rb) rbw = c->post_rb;                       // (tuning option)
   if (split) rbw = c->split_rb ? c->split_rb : (wgs_rb2 < 2ll * c->n_cu ? 1 : 2);
-  const size_t lds = sizeof(double) * 2 * (rbw == 2 ? 4096 : 3072);
-  const unsigned gy = (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
+  // resident form (k_bpost_res, post_rb = 3): a workgroup of eight waves per (output, 128 positions of axis 0) pair and share of
+  // the row blocks; needs a launch that is not split and enough row blocks to give every wave work
+  const unsigned ncb = gx;
+  const int cap0 = std::max(1, std::min(pl.KS0, 36 - pl.KSm));
+  const long long pairs = (long long)ncb * q;
+  const unsigned wgs_res = (unsigned)std::max<long long>(1, std::min<long long>(std::max<long long>(1, c->n_cu / pairs), (pl.nrb + 7) / 8));
+  const bool res = rbw == 3 && !split && pl.KSm <= 24;
+  if (rbw == 3 && !res) rbw = 1;
+  const size_t lds = res ? sizeof(double) * 512 * (size_t)(cap0 + pl.KSm) : sizeof(double) * 2 * (rbw == 2 ? 4096 : 3072);
+  const unsigned gy = res ? ncb : (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
+  const unsigned rows_x = res ? 2 * wgs_res : gx;          // per-wave partial rows per output: 4 rows_x gy
   int rc;
-  if ((rc = ensure(c->bl_lpart, sizeof(double) * 4 * (size_t)gx * gy * q))) return rc;
+  if ((rc = ensure(c->bl_lpart, sizeof(double) * 4 * (size_t)rows_x * gy * q))) return rc;
   // a sweep may ask for the S / U bytes, |S|, |U| and the radius key straight from the mean epilogue of the constraint
   // (one-constraint models; the masks are allocated by the sweep before it enqueues the posterior)
   // (r03: with the sqrt-free sign tests the fused epilogue saves the separate pass 76 us on config H and costs the GEMM 36;
   // on config B, two workgroups per CU, the two cancel -- "auto" asks for at least four workgroups per CU)
-  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
+  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (res || (long long)gx * gy * q >= 4ll * c->n_cu));
   const bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
                     c->maskU.bytes >= (size_t)cs.n_local;
   c->fuse_rows = 0;
   if (fuse) {
-    c->fuse_rows = 4 * (int)(gx * gy);
+    c->fuse_rows = 4 * (int)(rows_x * gy);
     // (room behind the rows for the partials of the objective pass, see sweep_common_front)
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
   }
-  auto kpost = rbw == 1 ? k_bpost<1> : k_bpost<2>;
-  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kpost = rbw == 2 ? k_bpost<2> : k_bpost<1>;
+  if (!res) SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // the K1 stop event rides on the last launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
   // the next kernel waits ~6 us for.  A sweep merges the Lipschitz partials in its own first small kernel (lmax_defer).
+  if (res) SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost_res), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   auto post = [&](int o_base, int nz, hipEvent_t stop) {
+    if (res) {
+      hipExtLaunchKernelGGL(k_bpost_res, dim3(wgs_res, ncb, (unsigned)nz), dim3(512), lds, c->stream, nullptr, stop, 0,
+                            mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
+                            pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
+                            (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
+                            fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
+                            (unsigned long long*)c->cpart.p, (const int*)pl.eff, cap0);
+      return;
+    }
     hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)nz), dim3(256), lds, c->stream, nullptr, stop, 0,
                           mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
                           pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
@@ -1966,10 +2160,10 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   }
   if (c->lmax_defer) {
     c->lmax_pending = true;
-    c->lmax_per_out = (int)(4 * gx * gy);
+    c->lmax_per_out = (int)(4 * rows_x * gy);
   } else {
     hipExtLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, c->ev[1], 0, (const double*)c->bl_lpart.p,
-                          (int)(4 * gx * gy), (unsigned long long*)c->Lmax.p);
+                          (int)(4 * rows_x * gy), (unsigned long long*)c->Lmax.p);
   }
   c->k1_stop_attached = true;
   (void)line0;

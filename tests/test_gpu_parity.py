@@ -1190,6 +1190,36 @@ def _assert_same_bundle(a, b_):
             assert np.array_equal(np.asarray(a[which][k]), np.asarray(b_[which][k])), (which, k)
 
 
+@pytest.mark.parametrize("cfg_name,n,count,b,ll", [("B", 128, [1100, 1024], 3.0, None), ("C", 96, [1040, 1030], 2.0, None), ("H", 300, [1056, 1500], 3.0, None),
+                                                     ("B", 64, [320, 300], 3.0, None), ("A", 64, [130, 70], 3.0, None), ("H", 512, [2048, 1200], 3.0, None),
+                                                     ("B", 128, [700, 520], 3.0, -1.4), ("B", 128, [520, 700], 3.0, 1.0)])
+def test_resident_posterior_kernel_equals_the_tiled_one(engine, cfg_name, n, count, b, ll):
+    """Option post_rb = 3 (k_bpost_res): the fused GEMM posterior with a workgroup per (output, 128 axis-0 positions) pair that keeps
+    the pair's B fragments in LDS for the whole launch and streams only A images -- the same sums in the same order, the same
+    epilogues: posterior, Lipschitz constants, fused S / U bytes, every sweep result and mask bit for bit those of the tiled
+    kernel (post_rb = 1), on ragged grids, three outputs, short (long expansions: variance k-steps beyond the resident ones) and
+    long length scales."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    if ll is not None:
+        h = cfg["ds"]["hypopt"].copy()
+        h[:2, :] = ll
+        cfg = dict(cfg, ds=oracle.make_inference_dataset(cfg["X"], cfg["Y"], h))
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    engine.set_grid(lo, hi, count)
+    out = {}
+    try:
+        for rb in (1, 3):
+            engine.set_option("post_rb", rb)
+            engine.set_model(cfg["ds"])
+            mean, var = engine.posterior()
+            assert engine.profile()["posterior_kernel"] == 4
+            out[rb] = (mean, var, _sweep_bundle(engine, cfg, b, cfg["q"]))
+    finally:
+        engine.set_option("post_rb", 0)
+    assert np.array_equal(out[1][0], out[3][0]) and np.array_equal(out[1][1], out[3][1])
+    _assert_same_bundle(out[1][2], out[3][2])
+
+
 @pytest.mark.parametrize("cfg_name,n,count,b", [("B", 128, [1100, 1024], 3.0), ("C", 96, [1040, 1030], 2.0), ("H", 300, [1056, 1500], 3.0),
                                                   ("B", 64, [320, 300], 3.0), ("A", 64, [130, 70], 3.0), ("B", 128, [2048, 2048], 3.0)])
 def test_overlapped_sweep_equals_the_sequential_one(engine, cfg_name, n, count, b):
