@@ -1031,8 +1031,21 @@ __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) {
 
 // Epilogue of phase PH for the RB x 8 accumulator tiles of a wave (row blocks cx.rb0 + RB cx.wave + i, strips cx.cs0 + s2)
 template <int PH, int RB>
-__device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ outp, double c0, double c1, double c2, double& gmax,
+__device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ outp, double c0, double c1, double c2, double& gmax_io,
                                               d4_t (&acc)[RB][8]) {
+  // gradient phases: max |c0 v| = fl(|c0| max |v|) -- rounding is monotone --, so the tile keeps max |v| (one v_max_f64 with
+  // |.| modifiers per element on the datapath the matrix cores share) and scales once
+  double gmax = 0.0;
+  struct Fold {
+    double& io; const double& raw; double c0; bool on;
+    __device__ ~Fold() {
+      if (on) {
+        double ga = c0 * raw;
+        ga = ga < 0 ? -ga : ga;
+        io = ga > io ? ga : io;
+      }
+    }
+  } fold{gmax_io, gmax, c0, PH >= 2};
   // epilogue: accumulator element t of lane l is row 4 t + (l >> 4), column l & 15 of its 16 x 16 tile
   const unsigned int col_in = cx.lane & 15, row_in = cx.lane >> 4;
   if (cx.full) {
@@ -1070,9 +1083,7 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
           } else if (PH == 1) {
             rowp[s2 * 16] = (c0 + v) * c1 + c2;
           } else {
-            double ga = c0 * v;
-            ga = ga < 0 ? -ga : ga;
-            gmax = ga > gmax ? ga : gmax;
+            gmax = fmax(gmax, fabs(v));
           }
         }
       }
@@ -1102,9 +1113,7 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
           if (cx.S) post_classify(cx, (size_t)line * cx.ucnt0 + x0, m);
         } else {
           // component of the gradient of the un-normalised mean (analytic jax.grad(self.mean), SafeOpt.py:68-71)
-          double ga = c0 * v;
-          ga = ga < 0 ? -ga : ga;
-          gmax = ga > gmax ? ga : gmax;
+          gmax = fmax(gmax, fabs(v));
         }
       }
     }

@@ -235,10 +235,17 @@ def test_tensor_interpolation_equals_the_grid_kernel(engine, d, count, n, log_el
             res = engine.sweep_safeopt(2.0, want_masks=True)
             masks = {k: engine.mask(k) for k in ("S", "U", "M")}
             masks["G"] = engine.mask("G", 1)
-            out[opt] = (mean, var, kern, res, masks)
+            goose = engine.sweep_goose(2.0, want_masks=True, posterior_ready=True)       # (the other sweeps read the same posterior)
+            masks["O"] = engine.mask("O", 1)
+            tr = engine.sweep_tr(2.0, np.zeros(d), 1.25, posterior_ready=True)
+            out[opt] = (mean, var, kern, res, masks, goose, tr)
     finally:
         engine.set_option("tensor_cheb", 1)
     assert out[0][2] == 3 and out[1][2] == kernel
+    for which in (5, 6):
+        for k, v in out[0][which].items():
+            if isinstance(v, (int, bool, np.integer)) or (isinstance(v, np.ndarray) and v.dtype.kind in "iub"):
+                assert np.array_equal(np.asarray(v), np.asarray(out[1][which][k])), (which, k)
     ys = np.maximum(1.0, ds["Y_std"])
     assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < 2e-11 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < 2e-11
     r0, r1 = out[0][3], out[1][3]
@@ -246,7 +253,7 @@ def test_tensor_interpolation_equals_the_grid_kernel(engine, d, count, n, log_el
         assert r0[k] == r1[k], k
     assert np.array_equal(r0["count_G"], r1["count_G"]) and np.array_equal(r0["expander_index_c"], r1["expander_index_c"])
     assert np.allclose(r0["L"], r1["L"], rtol=1e-11, atol=0.0) and abs(r0["u_star"] - r1["u_star"]) <= 1e-10 * ys[0]
-    for k in ("S", "U", "M", "G"):
+    for k in ("S", "U", "M", "G", "O"):
         assert np.array_equal(out[0][4][k], out[1][4][k]), k
     # a sample of the grid against the oracle
     rng = np.random.default_rng(3)
@@ -1454,7 +1461,8 @@ def test_multi_rank_sweep_on_one_gpu_matches_oracle(tmp_path, world, cfg_name, n
     assert g["count_O"] == [int(x) for x in gref["O"].sum(1)]
 
 
-@pytest.mark.parametrize("world,cfg_name,n,count,b", [(3, "C", 64, [256, 300], 2.0), (2, "D", 128, [34, 33, 32, 70], 0.5)])
+@pytest.mark.parametrize("world,cfg_name,n,count,b", [(3, "C", 64, [256, 300], 2.0), (2, "D", 128, [34, 33, 32, 70], 0.5),
+                                                      (2, "D", 128, [64, 64, 64, 64], 3.0)])     # (the last: Chebyshev-node posterior K1t on the shards)
 def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_name, n, count, b):
     """Shards big enough for the coarse cell bounds inside each rank's halo window: every mask and index must equal the
     single-rank sweep of the whole grid (itself pinned to the oracle by the tests above)."""
