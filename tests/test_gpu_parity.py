@@ -204,11 +204,17 @@ def test_chebyshev_core_equals_the_pair_form(engine, cfg_name, n, count, ll):
 
 
 def _tensor_model(d, n, log_ell, seed=7):
-    """A smooth two-output problem on [-2, 2]^d (objective + one constraint, safe near the origin) with fixed hyper-parameters."""
+    """A smooth problem on [-2, 2]^d (objective + one constraint, safe near the origin; a second constraint and per-axis /
+    per-output length scales when ``log_ell`` is a [d, 3] table) with fixed hyper-parameters."""
     rng = np.random.default_rng(seed)
     X = rng.uniform(-2.0, 2.0, size=(n, d))
-    Y = np.stack([np.sum(X ** 2, axis=1) + np.sin(2.0 * X[:, 0]), 3.0 - 0.5 * np.sum(X ** 2, axis=1) + X[:, 1]], axis=1)
-    return synthetic.make_dataset(X, Y, synthetic.default_hypopt(d, 2, log_ell=log_ell))
+    cols = [np.sum(X ** 2, axis=1) + np.sin(2.0 * X[:, 0]), 3.0 - 0.5 * np.sum(X ** 2, axis=1) + X[:, 1]]
+    if np.ndim(log_ell) == 2:
+        cols.append(2.5 - 0.4 * np.sum((X - 0.3) ** 2, axis=1))
+        hyp = synthetic.default_hypopt(d, 3)
+        hyp[:d, :] = np.asarray(log_ell, dtype=np.float64)
+        return synthetic.make_dataset(X, np.stack(cols, axis=1), hyp)
+    return synthetic.make_dataset(X, np.stack(cols, axis=1), synthetic.default_hypopt(d, 2, log_ell=log_ell))
 
 
 @pytest.mark.parametrize("d,count,n,log_ell,kernel", [
@@ -216,6 +222,7 @@ def _tensor_model(d, n, log_ell, seed=7):
     (3, [160, 168, 160], 96, -0.5, 5),          # three axes, ragged tiles (168 = 128 + 40)
     (3, [176, 160, 152], 64, 0.3, 5),           # long length scale: 32 nodes
     (3, [160, 160, 168], 64, -1.3, 3),          # short length scale: more than 64 nodes on the first axes -- declined, K1g runs
+    (3, [136, 176, 192], 80, [[-0.5, 0.3, -0.1], [0.4, -0.2, 0.2], [-0.8, 0.1, -0.6]], 5),   # three outputs, a length scale per axis and output (48 x 48 x 64 nodes)
 ])
 def test_tensor_interpolation_equals_the_grid_kernel(engine, d, count, n, log_ell, kernel):
     """K1t (option tensor_cheb, default on): fp64 grids of three / four axes take the exact posterior at a tensor grid of
@@ -235,6 +242,8 @@ def test_tensor_interpolation_equals_the_grid_kernel(engine, d, count, n, log_el
             res = engine.sweep_safeopt(2.0, want_masks=True)
             masks = {k: engine.mask(k) for k in ("S", "U", "M")}
             masks["G"] = engine.mask("G", 1)
+            if ds["hypopt"].shape[1] == 3:
+                masks["G2"] = engine.mask("G", 2)
             goose = engine.sweep_goose(2.0, want_masks=True, posterior_ready=True)       # (the other sweeps read the same posterior)
             masks["O"] = engine.mask("O", 1)
             tr = engine.sweep_tr(2.0, np.zeros(d), 1.25, posterior_ready=True)
@@ -253,7 +262,7 @@ def test_tensor_interpolation_equals_the_grid_kernel(engine, d, count, n, log_el
         assert r0[k] == r1[k], k
     assert np.array_equal(r0["count_G"], r1["count_G"]) and np.array_equal(r0["expander_index_c"], r1["expander_index_c"])
     assert np.allclose(r0["L"], r1["L"], rtol=1e-11, atol=0.0) and abs(r0["u_star"] - r1["u_star"]) <= 1e-10 * ys[0]
-    for k in ("S", "U", "M", "G", "O"):
+    for k in out[0][4]:
         assert np.array_equal(out[0][4][k], out[1][4][k]), k
     # a sample of the grid against the oracle
     rng = np.random.default_rng(3)
