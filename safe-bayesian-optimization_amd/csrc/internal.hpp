@@ -120,6 +120,7 @@ struct sbo_ctx {
   long long tn_first = 0, tn_nlocal = 0, tn_count[4] = {0, 0, 0, 0};
   double tn_lo[4] = {0, 0, 0, 0}, tn_hi[4] = {0, 0, 0, 0};
   int tn_level[4] = {0, 0, 0, 0};
+  int tn_bump = 0;                 // ladder steps added to the first guess on this grid (a previous model's plan needed its second attempt)
   sbo::DevBuf bl_basis;            // K1b: the 2 q axis bases (U, Chebyshev series, ranks) and the workspace of their kernel
   bool bl_basis_ok = false;        // bases enqueued for (bl_basis_serial, bl_basis_ab); their (ok, r, rc) records land at h_back + 4096
   unsigned long long bl_basis_serial = 0;

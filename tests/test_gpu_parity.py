@@ -220,6 +220,7 @@ def _tensor_model(d, n, log_ell, seed=7):
 @pytest.mark.parametrize("d,count,n,log_ell,kernel", [
     (4, [64, 64, 64, 64], 128, -0.5, 5),        # BASELINE configs[3] hyper-parameters: 48 nodes per axis
     (3, [160, 168, 160], 96, -0.5, 5),          # three axes, ragged tiles (168 = 128 + 40)
+    (3, [161, 165, 163], 64, -0.5, 5),          # odd counts: scalar stores, ragged everything
     (3, [176, 160, 152], 64, 0.3, 5),           # long length scale: 32 nodes
     (3, [160, 160, 168], 64, -1.3, 3),          # short length scale: more than 64 nodes on the first axes -- declined, K1g runs
     (3, [136, 176, 192], 80, [[-0.5, 0.3, -0.1], [0.4, -0.2, 0.2], [-0.8, 0.1, -0.6]], 5),   # three outputs, a length scale per axis and output (48 x 48 x 64 nodes)
