@@ -17,7 +17,7 @@
 // Accuracy is checked, not assumed: when a plan is built for a (model, grid) pair, 2048 grid points are also evaluated by the
 // generic exact kernel and compared with the interpolated values; a plan that misses 2e-11 (normalised units) retries one step
 // up the degree ladder and then declines (K1g runs on the whole grid).  Values differ from K1g's by the rounding of the
-// interpolation sums (~1e-13 normalised).  Config D: 216.6 -> 15.9 ms (nodes 5.2, small contractions 2.2, planes 9.1 = 0.6 of
+// interpolation sums (~1e-13 normalised).  Config D: 216.6 -> 13.8 ms (nodes 3.2, small contractions 1.9, planes 8.7 = 0.62 of
 // the FP64 rate).
 #include <algorithm>
 #include <cmath>
