@@ -266,7 +266,8 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  * fp64 2-D grids run the posterior as two GEMMs in a reduced basis when that is cheaper; 0: always the separable-table
  * kernel), "tensor_cheb" (1 default: fp64 grids of three / four axes with at least 64 positions per axis take the exact posterior on a
  * tensor grid of Chebyshev nodes and interpolate it to the candidates on the matrix cores when a probe of 2048 exactly evaluated grid
- * points confirms 2e-11; 0: always the separable-table kernel), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
+ * points confirms 2e-11; 0: always the separable-table kernel; "tensor_guess_pct", default 100, scales the first guess of the node counts --
+ * a test hook for the probe's second attempt), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
  * "scan_waves" (1 default: open candidates of the expander query are scanned by half-waves), "goose_pairs" (1: pair
  * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile), "bl_host_bases" (1: the axis bases of the GEMM posterior by
  * the host SVD of bilinear_host.hpp instead of the device kernel), "fuse_classify" (one-constraint sweeps take S / U from

@@ -108,6 +108,7 @@ struct sbo_ctx {
   sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work, bl_cheb;
   // K1t (tensor.hip): fp64 grids of three / four axes by Chebyshev interpolation from exact node values
   int tensor_cheb = 1;             // option: 0 = always K1g
+  int tensor_guess_pct = 100;      // option (test hook): scales the first guess of the node counts; a short guess exercises the probe's second attempt
   const double* k1g_axc = nullptr; // K1g launch arguments of launch_posterior_on_axes (explicit axis positions, gradient output)
   void* k1g_grad = nullptr;
   bool tensor_busy = false;        // the exact node / probe launch of K1t is running through launch_posterior
@@ -120,6 +121,7 @@ struct sbo_ctx {
   long long tn_first = 0, tn_nlocal = 0, tn_count[4] = {0, 0, 0, 0};
   double tn_lo[4] = {0, 0, 0, 0}, tn_hi[4] = {0, 0, 0, 0};
   int tn_level[4] = {0, 0, 0, 0};
+  int tn_dn[4] = {0, 0, 0, 0};     // node counts of the plan in use
   int tn_bump = 0;                 // ladder steps added to the first guess on this grid (a previous model's plan needed its second attempt)
   sbo::DevBuf bl_basis;            // K1b: the 2 q axis bases (U, Chebyshev series, ranks) and the workspace of their kernel
   bool bl_basis_ok = false;        // bases enqueued for (bl_basis_serial, bl_basis_ab); their (ok, r, rc) records land at h_back + 4096

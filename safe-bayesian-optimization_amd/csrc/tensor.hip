@@ -382,9 +382,9 @@ __global__ void k_t_probe_pts(const CandSpec cs, const long long* __restrict__ i
 // ---- host ----------------------------------------------------------------------------------------------------------------
 // node counts: the first two axes in matrix-core k-blocks (k_t_final), the further ones in steps of eight (k_t_mode takes any)
 static const int kLadder01[4] = {32, 48, 64, 96};
-static const int kLadderN[8] = {24, 32, 40, 48, 56, 64, 80, 96};
-static int ladder_size(int a) { return a < 2 ? 4 : 8; }
-static int ladder_at(int a, int lv) { return a < 2 ? kLadder01[std::min(lv, 3)] : kLadderN[std::min(lv, 7)]; }
+static const int kLadderN[7] = {32, 40, 48, 56, 64, 80, 96};
+static int ladder_size(int a) { return a < 2 ? 4 : 7; }
+static int ladder_at(int a, int lv) { return a < 2 ? kLadder01[std::min(lv, 3)] : kLadderN[std::min(lv, 6)]; }
 
 bool tensor_applicable(const sbo_ctx* c) {
   if (!c->tensor_cheb || c->is_shadow || c->dtype != SBO_F64 || c->cs.kind != 1) return false;
@@ -523,7 +523,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
   const bool same_box = c->tn_valid && c->tn_first == cs.first && c->tn_nlocal == cs.n_local && !memcmp(c->tn_count, cs.count, sizeof(long long) * kTMaxD) &&
                         !memcmp(c->tn_lo, cs.lo, sizeof(double) * kTMaxD) && !memcmp(c->tn_hi, cs.hi, sizeof(double) * kTMaxD);
   if (!same_box) c->tn_bump = 0;
-  int level0[kTMaxD];
+  int level0[kTMaxD], base0[kTMaxD] = {0, 0, 0, 0};
   if (same_grid) {
     if (!c->tn_usable) return SBO_OK;
     for (int a = 0; a < d; ++a) level0[a] = c->tn_level[a];
@@ -533,9 +533,10 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       double tmax = 0.0;
       for (int o = 0; o < q; ++o) tmax = std::max(tmax, 2.0 * td.half[a] / mc.X_std[a] * std::sqrt(mc.inv_ell[o][a]));
       // (the further axes' ladder is finer and their guess tighter: 40 nodes measured 1e-13 where this rule gives 39.4)
-      const double want = (a < 2 ? 7.6 : 6.9) * tmax;
+      const double want = (a < 2 ? 7.6 : 6.9) * tmax * (0.01 * c->tensor_guess_pct);     // (option: a test hook for the second attempt)
       int lv = 0;
       while (lv < ladder_size(a) - 1 && ladder_at(a, lv) < want) ++lv;
+      base0[a] = lv;
       level0[a] = lv + (same_box ? c->tn_bump : 0);     // (the previous model on this grid needed the second attempt: start there)
     }
   }
@@ -543,7 +544,9 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     long long Nn = 1;
     bool ok_dims = true;
     for (int a = 0; a < d; ++a) {
-      td.Dn[a] = ladder_at(a, level0[a] + attempt);
+      td.Dn[a] = same_grid ? c->tn_dn[a] : ladder_at(a, level0[a] + attempt);
+      // (steps beyond the first guess: the first two axes stay within what k_t_final takes -- the error may well sit on the others)
+      if (!same_grid && a < 2 && td.Dn[a] > 64 && ladder_at(a, base0[a]) <= 64) td.Dn[a] = 64;
     }
     td.Dn[0] = td.Dn[1] = std::max(td.Dn[0], td.Dn[1]);      // (k_t_final: one square core per plane)
     for (int a = 0; a < d; ++a) {
@@ -631,7 +634,10 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       memcpy(c->tn_count, cs.count, sizeof(long long) * kTMaxD);
       memcpy(c->tn_lo, cs.lo, sizeof(double) * kTMaxD);
       memcpy(c->tn_hi, cs.hi, sizeof(double) * kTMaxD);
-      for (int a = 0; a < d; ++a) c->tn_level[a] = std::min(ladder_size(a) - 1, level0[a] + attempt);
+      for (int a = 0; a < d; ++a) {
+        c->tn_level[a] = std::min(ladder_size(a) - 1, level0[a] + attempt);
+        c->tn_dn[a] = td.Dn[a];
+      }
       c->tn_usable = err <= 2e-11;
       if (!c->tn_usable) continue;           // one step up the ladder, or give up
       if (attempt > 0) c->tn_bump = std::min(2, c->tn_bump + 1);

@@ -279,6 +279,90 @@ def test_tensor_interpolation_equals_the_grid_kernel(engine, d, count, n, log_el
     assert _nerr(out[1][0][idx], om, ds["Y_std"], 1) < TOL64 and _nerr(out[1][1][idx], ov, ds["Y_std"], 2) < TOL64
 
 
+@pytest.mark.parametrize("seed", [31, 32, 33, 34, 35, 36])
+def test_tensor_interpolation_random_models(engine, seed):
+    """Random data, sizes and hyper-parameters from the box of the reference's fit (length scales per axis and output, signal
+    and noise levels), three-axis grids of 4-5 M candidates: whatever the plan decides -- node counts per axis, a second
+    attempt, declining to K1g -- the posterior equals K1g's to rounding and the SafeOpt sweep (masks, counts, arg-max indices) is
+    identical; a sample of the grid is within the bar of the NumPy oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    d, n = 3, int(rng.integers(24, 160))
+    X = rng.uniform(-2.0, 2.0, size=(n, d))
+    w = rng.normal(size=(2, d))
+    Y = np.stack([np.sum((X - 0.2 * w[0]) ** 2, axis=1) + np.sin(X @ w[0]), 2.5 + 0.5 * np.cos(X @ w[1]) - 0.45 * np.sum(X ** 2, axis=1)], axis=1)
+    hyp = np.empty((d + 2, 2))
+    hyp[:d] = rng.uniform(-0.9, 0.8, size=(d, 2))
+    hyp[d] = rng.uniform(-0.5, 0.5, size=2)
+    hyp[d + 1] = rng.uniform(-3.0, -1.5, size=2)
+    ds = synthetic.make_dataset(X, Y, hyp)
+    count = [int(c) for c in rng.integers(150, 176, size=3)]
+    b = float(rng.uniform(1.0, 3.0))
+    lo, hi = np.full(d, -2.0), np.full(d, 2.0)
+    engine.set_model(ds)
+    out = {}
+    try:
+        for opt in (0, 1):
+            engine.set_option("tensor_cheb", opt)
+            engine.set_grid(lo, hi, count)
+            mean, var = engine.posterior()
+            kern = engine.profile()["posterior_kernel"]
+            try:
+                res = engine.sweep_safeopt(b, want_masks=True, posterior_ready=True)
+                masks = {k: engine.mask(k) for k in ("S", "U", "M")}
+                masks["G"] = engine.mask("G", 1)
+            except safebo_amd.EmptySafeSetError:
+                res, masks = None, {}
+            out[opt] = (mean, var, kern, res, masks)
+    finally:
+        engine.set_option("tensor_cheb", 1)
+    assert out[0][2] == 3 and out[1][2] in (3, 5)
+    ys = np.maximum(1.0, ds["Y_std"])
+    assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < 2e-11 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < 2e-11
+    assert (out[0][3] is None) == (out[1][3] is None)
+    if out[0][3] is not None:
+        for k in ("minimizer_index", "expander_index", "count_S", "count_U", "count_M", "choose_minimizer"):
+            assert out[0][3][k] == out[1][3][k], k
+        assert np.allclose(out[0][3]["L"], out[1][3]["L"], rtol=1e-10, atol=0.0)
+        for k in out[0][4]:
+            assert np.array_equal(out[0][4][k], out[1][4][k]), k
+    total = int(np.prod(count))
+    idx = np.unique(rng.integers(0, total, size=2000))
+    axes = oracle.grid_axes(lo, hi, count)
+    sub = np.empty((idx.size, d))
+    f = idx.copy()
+    for a in range(d):
+        sub[:, a] = axes[a][f % count[a]]
+        f //= count[a]
+    om, ov = oracle.gp_inference(sub, ds)
+    assert _nerr(out[1][0][idx], om, ds["Y_std"], 1) < TOL64 and _nerr(out[1][1][idx], ov, ds["Y_std"], 2) < TOL64
+
+
+def test_tensor_interpolation_second_attempt_and_decline(engine):
+    """The plan's accuracy probe at work (option tensor_guess_pct scales the first guess of the node counts): a guess that is
+    too short fails the probe, the second attempt one ladder step up passes -- and the next model on the same grid starts
+    there --; a guess far too short fails twice and the O(n^2) kernel runs.  The posterior is K1g's to rounding every time."""
+    lo, hi, count = np.full(3, -2.0), np.full(3, 2.0), [160, 168, 160]
+    engine.set_grid(lo, hi, count)
+    try:
+        for log_ell, cases in ((-0.5, ((100, 5), (78, 5), (30, 5))), (-0.75, ((100, 5), (30, 3)))):
+            ds = _tensor_model(3, 64, log_ell)
+            ys = np.maximum(1.0, ds["Y_std"])
+            engine.set_model(ds)
+            engine.set_option("tensor_cheb", 0)
+            m0, v0 = engine.posterior()
+            engine.set_option("tensor_cheb", 1)
+            for pct, kernel in cases:
+                engine.set_option("tensor_guess_pct", pct)
+                for rep in range(2):                          # (the second model build on the grid starts from the sticky bump)
+                    engine.set_model(ds)
+                    m, v = engine.posterior()
+                    assert engine.profile()["posterior_kernel"] == kernel, (log_ell, pct, rep)
+                    assert np.max(np.abs(m - m0) / ys) < 2e-11 and np.max(np.abs(v - v0) / ys ** 2) < 2e-11, (log_ell, pct, rep)
+    finally:
+        engine.set_option("tensor_guess_pct", 100)
+        engine.set_option("tensor_cheb", 1)
+
+
 def test_tensor_interpolation_shards_reproduce_the_whole_grid_bitwise(engine):
     """A rank's shard (whole hyper-planes of the last axis) interpolates the same node values with its own rows of the last
     axis' matrix: the same sums, bit for bit."""
