@@ -596,9 +596,20 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       // accuracy probe: 2048 grid points, exact against interpolated
       std::vector<long long> idx(kTProbes);
       unsigned long long sd = 0x9e3779b97f4a7c15ull ^ (unsigned long long)c->model_serial;
+      // pseudo-random local candidates; the first ones pinned to the ends of the axes (corners of the local box, then points on
+      // its faces), where a polynomial interpolant errs most
       for (int i = 0; i < kTProbes; ++i) {
-        sd = sd * 6364136223846793005ull + 1442695040888963407ull;
-        idx[i] = (long long)((sd >> 11) % (unsigned long long)cs.n_local);
+        long long f = 0, mul = 1;
+        for (int a = 0; a < d; ++a) {
+          sd = sd * 6364136223846793005ull + 1442695040888963407ull;
+          const long long cnt = td.cnt[a];
+          long long k = (long long)((sd >> 11) % (unsigned long long)cnt);
+          if (i < (1 << d)) k = ((i >> a) & 1) ? cnt - 1 : 0;
+          else if (i < 512 && a == i % d) k = (i & 64) ? cnt - 1 : 0;
+          f += k * mul;
+          mul *= cnt;
+        }
+        idx[i] = f;
       }
       const size_t pbytes = sizeof(long long) * kTProbes + sizeof(double) * (size_t)kTProbes * (d + 4 * q);
       if ((rc = ensure(c->tn_probe, pbytes))) return rc;
