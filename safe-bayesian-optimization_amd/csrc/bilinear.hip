@@ -1029,6 +1029,54 @@ __device__ __forceinline__ void post_classify_mv(PostCtx& cx, size_t g, double m
 }
 __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) { post_classify_mv(cx, g, m, cx.var_rd[g]); }
 
+// End of a posterior kernel: the waves' Lipschitz maxima (already reduced over the lanes) and, with the fused classification,
+// their counts and radius maxima, merged through LDS into ONE value / row per workgroup.  `sh`: NW x 4 doubles of LDS nobody
+// reads any more (barrier first).
+template <int NW>
+__device__ __forceinline__ void post_partials(double* sh, int lane, int wave, double gmax, bool fuse, int cS_, int cU_, double rmax_,
+                                              double* __restrict__ lrow, unsigned long long* __restrict__ crow) {
+  int cS = cS_, cU = cU_;
+  double rm = rmax_;
+  if (fuse) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      cS += __shfl_xor(cS, off);
+      cU += __shfl_xor(cU, off);
+      const double other = __shfl_xor(rm, off);
+      rm = other > rm ? other : rm;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    sh[wave * 4 + 0] = gmax;
+    sh[wave * 4 + 1] = rm;
+    reinterpret_cast<int*>(sh + wave * 4 + 2)[0] = cS;
+    reinterpret_cast<int*>(sh + wave * 4 + 2)[1] = cU;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double g = sh[0], r = sh[1];
+    long long s_ = 0, u_ = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      g = sh[w * 4] > g ? sh[w * 4] : g;
+      r = sh[w * 4 + 1] > r ? sh[w * 4 + 1] : r;
+      s_ += reinterpret_cast<const int*>(sh + w * 4 + 2)[0];
+      u_ += reinterpret_cast<const int*>(sh + w * 4 + 2)[1];
+    }
+    if (lane == 0) *lrow = g;
+    if (fuse && lane < kFuseRow) {
+      // partial row of the classification, merged by k_classify_final: [u* key (none here), |S|, |U|, radius keys]
+      unsigned long long v = 0ull;
+      if (lane == 0) v = ~0ull;
+      else if (lane == 1) v = (unsigned long long)s_;
+      else if (lane == 2) v = (unsigned long long)u_;
+      else if (lane == 4) v = r >= 0.0 ? ord_key(r) : 0ull;       // radius key of constraint 1 (slot 3 + c)
+      crow[lane] = v;
+    }
+  }
+}
+
 // Epilogue of phase PH for the RB x 8 accumulator tiles of a wave (row blocks cx.rb0 + RB cx.wave + i, strips cx.cs0 + s2)
 template <int PH, int RB>
 __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ outp, double c0, double c1, double c2, double& gmax_io,
@@ -1277,31 +1325,11 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
     const double other = __shfl_xor(gmax, off);
     gmax = other > gmax ? other : gmax;
   }
-  // one plain store per wave, merged by k_lmax_reduce: every workgroup of this launch is resident at once and ends at
-  // the same time, so atomics on the q keys would queue up in L2 as the kernel's tail
-  if (cx.lane == 0)
-    Lpart[(((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + cx.wave] = gmax;
-  if (fuse) {
-    // per-wave partial row of the classification, merged by k_classify_final: [u* key (none here), |S|, |U|, radius keys]
-    int cS = cx.cS, cU = cx.cU;
-    double rm = cx.rmax;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      cS += __shfl_xor(cS, off);
-      cU += __shfl_xor(cU, off);
-      const double other = __shfl_xor(rm, off);
-      rm = other > rm ? other : rm;
-    }
-    if (cx.lane < kFuseRow) {
-      unsigned long long* row = cpart + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + cx.wave) * kFuseRow;
-      unsigned long long v = 0ull;
-      if (cx.lane == 0) v = ~0ull;
-      else if (cx.lane == 1) v = (unsigned long long)cS;
-      else if (cx.lane == 2) v = (unsigned long long)cU;
-      else if (cx.lane == 4) v = rm >= 0.0 ? ord_key(rm) : 0ull;       // radius key of constraint 1 (slot 3 + c)
-      row[cx.lane] = v;
-    }
-  }
+  // one plain store per WORKGROUP, merged by k_lmax_reduce / the classification's final merge: every workgroup of this launch
+  // is resident at once and ends at the same time, so atomics on the q keys would queue up in L2 as the kernel's tail -- and
+  // a row per wave made that merge (one workgroup, 16384 rows of 88 bytes on config H) the longest job of the launch it shares
+  post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, fuse, cx.cS, cx.cU, cx.rmax, Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+                   cpart + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kFuseRow);
 }
 
 // k_bpost_res -- the same four phases with nothing staged per tile (r03).  Switching parts of k_bpost off on config H showed
@@ -1312,7 +1340,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
 // BASELINE sizes); a wave takes row blocks of 16 lines, 8 strips wide, and streams only its A images, straight from memory
 // into registers one k-block (2 KB) ahead -- across phase and row-block boundaries, so no loop ever starts cold.  No barrier
 // after the preload.  Sums, epilogue arithmetic and therefore every output bit are those of k_bpost.
-// grid (workgroups per pair, column blocks, outputs); Lpart / cpart rows: ((o ncb + cb) wgs + wg) 8 + wave.
+// grid (workgroups per pair, column blocks, outputs); Lpart / cpart rows: (o ncb + cb) wgs + wg.
 __global__ __launch_bounds__(512, 1) void k_bpost_res(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
                                                       const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA, size_t sVA,
                                                       const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm, int KSm, int KBm2,
@@ -1447,28 +1475,9 @@ __global__ __launch_bounds__(512, 1) void k_bpost_res(const ModelConst mc, const
     const double other = __shfl_xor(gmax, off);
     gmax = other > gmax ? other : gmax;
   }
-  const size_t prow = (((size_t)o * gridDim.y + cb) * wgs + wg) * 8 + wave;
-  if (lane == 0) Lpart[prow] = gmax;
-  if (fuse) {
-    int cS = cx.cS, cU = cx.cU;
-    double rm = cx.rmax;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      cS += __shfl_xor(cS, off);
-      cU += __shfl_xor(cU, off);
-      const double other = __shfl_xor(rm, off);
-      rm = other > rm ? other : rm;
-    }
-    if (lane < kFuseRow) {
-      unsigned long long* row = cpart + ((((size_t)cb * wgs + wg) * 8 + wave)) * kFuseRow;
-      unsigned long long v = 0ull;
-      if (lane == 0) v = ~0ull;
-      else if (lane == 1) v = (unsigned long long)cS;
-      else if (lane == 2) v = (unsigned long long)cU;
-      else if (lane == 4) v = rm >= 0.0 ? ord_key(rm) : 0ull;
-      row[lane] = v;
-    }
-  }
+  __shared__ double psh[8 * 4];
+  post_partials<8>(psh, lane, wave, gmax, fuse, cx.cS, cx.cU, cx.rmax, Lpart + ((size_t)o * gridDim.y + cb) * wgs + wg,
+                   cpart + ((size_t)cb * wgs + wg) * kFuseRow);
 }
 
 // Lipschitz keys of a K1b launch: Lmax[o] = max of the per-wave partials (values >= 0, so the bit pattern orders them)
@@ -2121,9 +2130,9 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   if (rbw == 3 && !res) rbw = 1;
   const size_t lds = res ? sizeof(double) * 512 * (size_t)(cap0 + pl.KSm) : sizeof(double) * 2 * (rbw == 2 ? 4096 : 3072);
   const unsigned gy = res ? ncb : (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
-  const unsigned rows_x = res ? 2 * wgs_res : gx;          // per-wave partial rows per output: 4 rows_x gy
+  const unsigned rows_out = res ? wgs_res * ncb : gx * (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));   // partial rows per output: one per workgroup
   int rc;
-  if ((rc = ensure(c->bl_lpart, sizeof(double) * 4 * (size_t)rows_x * gy * q))) return rc;
+  if ((rc = ensure(c->bl_lpart, sizeof(double) * (size_t)rows_out * q))) return rc;
   // a sweep may ask for the S / U bytes, |S|, |U| and the radius key straight from the mean epilogue of the constraint
   // (one-constraint models; the masks are allocated by the sweep before it enqueues the posterior)
   // (r03: with the sqrt-free sign tests the fused epilogue saves the separate pass 76 us on config H and costs the GEMM 36;
@@ -2133,7 +2142,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                     c->maskU.bytes >= (size_t)cs.n_local;
   c->fuse_rows = 0;
   if (fuse) {
-    c->fuse_rows = 4 * (int)(rows_x * gy);
+    c->fuse_rows = (int)rows_out;
     // (room behind the rows for the partials of the objective pass, see sweep_common_front)
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
   }
@@ -2169,10 +2178,10 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   }
   if (c->lmax_defer) {
     c->lmax_pending = true;
-    c->lmax_per_out = (int)(4 * rows_x * gy);
+    c->lmax_per_out = (int)rows_out;
   } else {
     hipExtLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, c->ev[1], 0, (const double*)c->bl_lpart.p,
-                          (int)(4 * rows_x * gy), (unsigned long long*)c->Lmax.p);
+                          (int)rows_out, (unsigned long long*)c->Lmax.p);
   }
   c->k1_stop_attached = true;
   (void)line0;

@@ -1073,7 +1073,10 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     double* dout = (double*)c->dist2b.p;
     long long stride = count0;
     if (paired) {
-      const int nfine = (int)std::min<long long>(nlines, 1 << 20), ncoarse = (int)std::min<long long>(clines, 1 << 20);
+      // fine lines of whole words, up to 4096 positions: a wave per line (option axis0_waves)
+      const int wave_lines = (c->axis0_waves && (count0 & 63) == 0 && count0 <= 4096 && nlines < (1ll << 22)) ? 1 : 0;
+      const int nfine = wave_lines ? (int)((nlines + 3) / 4) : (int)std::min<long long>(nlines, 1 << 20);
+      const int ncoarse = (int)std::min<long long>(clines, 1 << 20);
       FinalJob fin;
       if (mj && mj->fin.pending) {
         fin = mj->fin;
@@ -1085,10 +1088,10 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       u16 = c->dist_u16 && count0 < 65535 && want_bmin && blk_ <= 64 && c->scan_waves;
       if (u16)
         hipLaunchKernelGGL(k_edt_axis0_pair<true>, dim3((unsigned)(nfine + ncoarse + (fin.pending ? 1 : 0))), dim3(256), 0, c->stream, Uall,
-                           nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin);
+                           nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin, wave_lines);
       else
         hipLaunchKernelGGL(k_edt_axis0_pair<false>, dim3((unsigned)(nfine + ncoarse + (fin.pending ? 1 : 0))), dim3(256), 0, c->stream, Uall,
-                           nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin);
+                           nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin, wave_lines);
       MidJobs<T> j;
       memset(&j, 0, sizeof(j));
       j.sc = sc;

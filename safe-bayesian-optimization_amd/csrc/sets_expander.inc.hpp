@@ -85,6 +85,16 @@ __device__ __forceinline__ bool coarse_cell_any(const uint8_t* __restrict__ U, c
     if (a > 0) nsub *= len[a];
   }
   bool any = false;
+  if (cg.d == 2 && len[0] == 8 && len[1] == 8 && ((((uintptr_t)U) + i0[0] + i0[1] * fstride[1]) & 7) == 0 && (fstride[1] & 7) == 0) {
+    // a whole 8 x 8 cell of a 2-D grid: its eight words at once (independent loads; the early exit below makes each line wait
+    // for the one before)
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(U + i0[0] + i0[1] * fstride[1]);
+    const long long ws = fstride[1] >> 3;
+    unsigned long long acc = 0ull;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc |= w[r * ws];
+    return acc != 0ull;
+  }
   for (long long sline = 0; sline < nsub && !any; ++sline) {
     long long r = sline, base = i0[0];
     for (int a = 1; a < cg.d; ++a) {
@@ -200,6 +210,66 @@ __device__ __forceinline__ void edt_axis0_wg_body(int bid, int nblk, Axis0Lds& l
     __syncthreads();
   }
 }
+// axis 0 of a fine line by ONE wave, no barriers (r03): lines of whole 64-bit words, at most 4096 positions (<= 64 words: a
+// word per lane).  The eight-byte loads drop their bits into the wave's own 512 bytes of LDS as above, lane w then holds word
+// w; the nearest set bit before / after every word is a wave scan (six shuffle steps each way); the output loop walks the
+// words -- word k and the two carries around it broadcast from lanes k, k - 1, k + 1 -- and lane l writes position 64 k + l:
+// coalesced stores, the same values as the workgroup form.  Four independent lines per workgroup instead of one line behind
+// three barriers.
+template <bool U16>
+__device__ __forceinline__ void edt_axis0_wave_body(long long line, unsigned long long* wlds /* this wave's 64 words */,
+                                                    const uint8_t* __restrict__ U, int count0, double h0, double* __restrict__ D) {
+  const int lane = threadIdx.x & 63;
+  const int nwords = count0 >> 6;
+  constexpr int kNone = 0x7fffffff;
+  const uint8_t* u = U + line * count0;
+  uint8_t* wb = reinterpret_cast<uint8_t*>(wlds);
+  for (int t = lane; t < (count0 >> 3); t += 64) {
+    unsigned long long x = reinterpret_cast<const unsigned long long*>(u)[t];
+    x |= x >> 4;
+    x |= x >> 2;
+    x |= x >> 1;
+    x &= 0x0101010101010101ull;
+    wb[t] = (uint8_t)((x * 0x0102040810204080ull) >> 56);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long m = lane < nwords ? wlds[lane] : 0ull;
+  __builtin_amdgcn_wave_barrier();                      // (the next line of this wave overwrites the words)
+  int last = m ? lane * 64 + (63 - __clzll((long long)m)) : -1;            // -> last set bit in words 0 .. lane
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(last, o); if (lane >= o && t > last) last = t; }
+  int first = m ? lane * 64 + (__ffsll((long long)m) - 1) : kNone;        // -> first set bit in words lane ..
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(first, o); if (lane + o < 64 && t < first) first = t; }
+  const unsigned int mlo = (unsigned int)m, mhi = (unsigned int)(m >> 32);
+  double* d = D + line * count0;
+  unsigned short* d16 = reinterpret_cast<unsigned short*>(D) + line * count0;
+  const unsigned long long le_mask = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+  for (int k = 0; k < nwords; ++k) {                      // (k is uniform: the broadcasts are v_readlane)
+    const unsigned long long mk = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)mhi, k) << 32) |
+                                  (unsigned int)__builtin_amdgcn_readlane((int)mlo, k);
+    const int lprev = k > 0 ? __builtin_amdgcn_readlane(last, k - 1) : -1;
+    const int fnext = k + 1 < nwords ? __builtin_amdgcn_readlane(first, k + 1) : kNone;
+    const int i = k * 64 + lane;
+    const unsigned long long lower = mk & le_mask, upper = mk >> lane;
+    const int li = lower ? k * 64 + (63 - __clzll((long long)lower)) : lprev;
+    const int ri = upper ? i + (__ffsll((long long)upper) - 1) : fnext;
+    int t = -1;
+    if (li >= 0) t = i - li;
+    if (ri != kNone && (t < 0 || ri - i < t)) t = ri - i;
+    if (U16) {
+      d16[i] = t >= 0 ? (unsigned short)t : (unsigned short)0xffffu;
+    } else {
+      double v = kInfD;
+      if (t >= 0) {
+        const double dt = h0 * (double)t;
+        v = dt * dt;
+      }
+      d[i] = v;
+    }
+  }
+}
+
 template <bool COARSE>
 __global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
                                                       double* __restrict__ D, const CoarseGrid cg) {
@@ -212,7 +282,8 @@ __global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict_
 template <bool U16>
 __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
                                                         double* __restrict__ D, int nfine, int ncoarse, long long clines, int cc0,
-                                                        double h0c, double* __restrict__ Dc, const CoarseGrid cg, const FinalJob fin) {
+                                                        double h0c, double* __restrict__ Dc, const CoarseGrid cg, const FinalJob fin,
+                                                        int wave_lines /* 1: a fine workgroup is four waves with a line each */) {
   __shared__ Axis0Lds lds;
   SBO_CHAIN_PRIO();
   // (order of the ranges: the merge and the coarse lines first -- few workgroups with longer chains that should start with the
@@ -220,7 +291,10 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
   const int nfin = (int)gridDim.x - nfine - ncoarse, bid = (int)blockIdx.x;
   if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy, fin.o_first);
   else if (bid < nfin + ncoarse) edt_axis0_wg_body<true>(bid - nfin, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
-  else edt_axis0_wg_body<false, U16>(bid - nfin - ncoarse, nfine, lds, U, nlines, count0, h0, D, cg);
+  else if (wave_lines) {
+    const long long line = (long long)(bid - nfin - ncoarse) * 4 + (threadIdx.x >> 6);
+    if (line < nlines) edt_axis0_wave_body<U16>(line, lds.words + (threadIdx.x >> 6) * 64, U, count0, h0, D);
+  } else edt_axis0_wg_body<false, U16>(bid - nfin - ncoarse, nfine, lds, U, nlines, count0, h0, D, cg);
 }
 
 // axes >= 1: D_out[g] = min_t D_in[g + t stride] + (h t)^2, searched outwards with the two exits

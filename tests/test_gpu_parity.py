@@ -1291,6 +1291,29 @@ def _assert_same_bundle(a, b_):
             assert np.array_equal(np.asarray(a[which][k]), np.asarray(b_[which][k])), (which, k)
 
 
+@pytest.mark.parametrize("cfg_name,n,count,b", [("B", 128, [2048, 1100], 3.0), ("H", 300, [4096, 700], 3.0), ("C", 96, [1024, 1030], 2.0),
+                                                  ("B", 64, [320, 300], 3.0), ("B", 128, [1088, 520], 2.0), ("A", 64, [128, 700], 3.0)])
+def test_wave_per_line_axis0_pass_equals_the_workgroup_form(engine, cfg_name, n, count, b):
+    """Option axis0_waves (default on): on 2-D grids whose lines are whole 64-bit words of at most 4096 positions the fine axis-0
+    pass of the distance transform runs a wave per line (bits through the wave's own LDS words, wave scans, broadcast words) instead
+    of a workgroup per line behind three barriers -- the same step counts, so every mask, count and index of the SafeOpt and
+    GoOSE sweeps is identical (16-bit and double images, one and two constraints)."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    out = {}
+    try:
+        for u16 in (1, 0):
+            engine.set_option("dist_u16", u16)
+            for w in (0, 1):
+                engine.set_option("axis0_waves", w)
+                out[(u16, w)] = _sweep_bundle(engine, cfg, b, cfg["q"])
+    finally:
+        engine.set_option("axis0_waves", 1)
+        engine.set_option("dist_u16", 1)
+    for u16 in (1, 0):
+        _assert_same_bundle(out[(u16, 0)], out[(u16, 1)])
+
+
 @pytest.mark.parametrize("cfg_name,n,count,b,ll", [("B", 128, [1100, 1024], 3.0, None), ("C", 96, [1040, 1030], 2.0, None), ("H", 300, [1056, 1500], 3.0, None),
                                                      ("B", 64, [320, 300], 3.0, None), ("A", 64, [130, 70], 3.0, None), ("H", 512, [2048, 1200], 3.0, None),
                                                      ("B", 128, [700, 520], 3.0, -1.4), ("B", 128, [520, 700], 3.0, 1.0)])
