@@ -285,13 +285,29 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
   long long cS = 0, cU = 0;
 #pragma unroll
   for (int c = 0; c < kMaxQ; ++c) rmax[c] = 0ull;
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    const unsigned long long* row = part + (size_t)i * kClassifyRow;
-    umin = row[0] < umin ? row[0] : umin;
-    cS += (long long)row[1];
-    cU += (long long)row[2];
+  // (one workgroup walks all rows: four rows' loads in flight per thread and only the q columns that carry anything -- with a
+  // row at a time the 16 rounds of eleven strided loads were the longest job of the launch this merge shares on config H)
+  for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * blockDim.x) {
+    unsigned long long v0[4], v1[4], v2[4], vr[4][kMaxQ];
 #pragma unroll
-    for (int c = 0; c < kMaxQ; ++c) rmax[c] = row[3 + c] > rmax[c] ? row[3 + c] : rmax[c];
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + j * blockDim.x;
+      const bool on = i < nparts;
+      const unsigned long long* row = part + (size_t)(on ? i : i0) * kClassifyRow;
+      v0[j] = on ? row[0] : ~0ull;
+      v1[j] = on ? row[1] : 0ull;
+      v2[j] = on ? row[2] : 0ull;
+#pragma unroll
+      for (int c = 1; c < kMaxQ; ++c) vr[j][c] = (on && c < q) ? row[3 + c] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      umin = v0[j] < umin ? v0[j] : umin;
+      cS += (long long)v1[j];
+      cU += (long long)v2[j];
+#pragma unroll
+      for (int c = 1; c < kMaxQ; ++c) rmax[c] = vr[j][c] > rmax[c] ? vr[j][c] : rmax[c];
+    }
   }
   umin = block_ext_u64<false>(umin);
   cS = block_sum_ll(cS);
@@ -341,9 +357,20 @@ __device__ __forceinline__ unsigned long long ustar_partial_body(int bid, int nw
     const unsigned long long k = ord_key((double)ucb);
     umin = k < umin ? k : umin;
   };
-  for (long long t = wave; t < ntiles; t += nwaves) {
+  // (the mask words of four of this wave's tiles are requested together: the tile loop is a chain of dependent loads -- mask word,
+  // then the gathered posterior -- and most tiles end at the first link)
+  for (long long t0 = wave; t0 < ntiles; t0 += 4 * nwaves) {
+    unsigned long long w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long t = t0 + j * nwaves;
+      w4[j] = t < ntiles ? ((const unsigned long long*)(S + t * 512))[lane] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+    const long long t = t0 + j * nwaves;
     const long long base = t * 512;
-    const unsigned long long w = ((const unsigned long long*)(S + base))[lane];
+    const unsigned long long w = w4[j];
     if (__ballot(w != 0ull) == 0ull) continue;
     T mu[8], va[8];
     bool set[8];
@@ -357,6 +384,7 @@ __device__ __forceinline__ unsigned long long ustar_partial_body(int bid, int nw
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       if (set[k]) take(mu[k], va[k]);
+    }
   }
   for (long long g = ntiles * 512 + (long long)bid * blockDim.x + threadIdx.x; g < n; g += (long long)nwg * blockDim.x)
     if (S[g]) take(mean0[g], var0[g]);
@@ -1075,8 +1103,10 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     if (paired) {
       // fine lines of whole words, up to 4096 positions: a wave per line (option axis0_waves)
       const int wave_lines = (c->axis0_waves && (count0 & 63) == 0 && count0 <= 4096 && nlines < (1ll << 22)) ? 1 : 0;
-      const int nfine = wave_lines ? (int)((nlines + 3) / 4) : (int)std::min<long long>(nlines, 1 << 20);
       const int ncoarse = (int)std::min<long long>(clines, 1 << 20);
+      // (wave form: four workgroups of 39 KB LDS fit a CU; no more fine workgroups than are resident beside the coarse ones)
+      const int nfine = wave_lines ? (int)std::min<long long>((nlines + 3) / 4, std::max<long long>(c->n_cu, 4ll * c->n_cu - ncoarse - 1))
+                                   : (int)std::min<long long>(nlines, 1 << 20);
       FinalJob fin;
       if (mj && mj->fin.pending) {
         fin = mj->fin;

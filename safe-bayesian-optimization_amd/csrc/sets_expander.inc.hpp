@@ -270,6 +270,79 @@ __device__ __forceinline__ void edt_axis0_wave_body(long long line, unsigned lon
   }
 }
 
+// The 16-bit image of a fine line by one wave, a word per lane walked bit by bit (r03): the broadcast form above spends ~40
+// instructions per element, half of them 64-bit shifts and bit searches (35 us on config H); here a lane carries two counters
+// over its own 64 positions -- steps since the last set bit going up, steps to the next one going down: F(i) = bit_i ? 0 : F(i - 1) + 1,
+// three 32-bit instructions per step with the bit as a sign-extended field --, seeded by the wave scans' carries, and the 32 packed
+// words of a lane turn through the wave's LDS patch so that the stores are whole 1 KB runs.  Same step counts.
+constexpr int kA0Big = 1 << 20;       // "no set bit on this side" (stays far above 65535 through 64 increments)
+constexpr int kA0Row = 36;            // words per lane row of the patch (16-byte aligned rows)
+__device__ __forceinline__ void edt_axis0_wave_seq(long long line, unsigned long long* wlds, unsigned int* patch /* [64][kA0Row] */,
+                                                   const uint8_t* __restrict__ U, int count0, double* __restrict__ D) {
+  const int lane = threadIdx.x & 63;
+  const int nwords = count0 >> 6;
+  constexpr int kNone = 0x7fffffff;
+  const uint8_t* u = U + line * count0;
+  uint8_t* wb = reinterpret_cast<uint8_t*>(wlds);
+  for (int t = lane; t < (count0 >> 3); t += 64) {
+    unsigned long long x = reinterpret_cast<const unsigned long long*>(u)[t];
+    x |= x >> 4;
+    x |= x >> 2;
+    x |= x >> 1;
+    x &= 0x0101010101010101ull;
+    wb[t] = (uint8_t)((x * 0x0102040810204080ull) >> 56);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long m = lane < nwords ? wlds[lane] : 0ull;
+  __builtin_amdgcn_wave_barrier();
+  int last = m ? lane * 64 + (63 - __clzll((long long)m)) : -1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(last, o); if (lane >= o && t > last) last = t; }
+  int first = m ? lane * 64 + (__ffsll((long long)m) - 1) : kNone;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(first, o); if (lane + o < 64 && t < first) first = t; }
+  const int lprev = __shfl_up(last, 1), fnext = __shfl_down(first, 1);
+  // F(-1): steps from the last position of the previous word to the last set bit before this word; D(64) likewise upwards
+  int f = (lane > 0 && lprev >= 0) ? lane * 64 - 1 - lprev : kA0Big;
+  int dn = (lane + 1 < nwords && fnext != kNone) ? fnext - (lane * 64 + 64) : kA0Big;
+  const unsigned int nlo = ~(unsigned int)m, nhi = ~(unsigned int)(m >> 32);     // bit clear -> 1
+  int F[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const unsigned int h = i < 32 ? nlo : nhi;
+    const int keep = (int)(h << (31 - (i & 31))) >> 31;        // -1 when position i holds no U point
+    f = (f + 1) & keep;
+    F[i] = f;
+  }
+  unsigned int packed[32];
+#pragma unroll
+  for (int i = 63; i >= 0; --i) {
+    const unsigned int h = i < 32 ? nlo : nhi;
+    const int keep = (int)(h << (31 - (i & 31))) >> 31;
+    dn = (dn + 1) & keep;
+    int t = F[i] < dn ? F[i] : dn;
+    t = t > 0xffff ? 0xffff : t;
+    if (i & 1) packed[i >> 1] = (unsigned int)t << 16;
+    else packed[i >> 1] |= (unsigned int)t;
+  }
+  if (lane < nwords) {
+    unsigned int* row = patch + lane * kA0Row;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      *reinterpret_cast<uint4*>(row + 4 * j) = make_uint4(packed[4 * j], packed[4 * j + 1], packed[4 * j + 2], packed[4 * j + 3]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // lane l of store j writes the four words 256 j + 4 l .. + 3 of the line: row 8 j + (l >> 3), words 4 (l & 7) .. + 3
+  uint4* out = reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(D) + line * count0);
+  const int nst = count0 >> 9;                                   // stores of 512 positions; a tail of 64 .. 448 positions below
+  for (int j = 0; j < nst; ++j)
+    out[j * 64 + lane] = *reinterpret_cast<const uint4*>(patch + (8 * j + (lane >> 3)) * kA0Row + 4 * (lane & 7));
+  const int rem_rows = nwords - 8 * nst;                           // whole words left (count0 is a multiple of 64)
+  if (rem_rows > 0 && (lane >> 3) < rem_rows)
+    out[nst * 64 + lane] = *reinterpret_cast<const uint4*>(patch + (8 * nst + (lane >> 3)) * kA0Row + 4 * (lane & 7));
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool COARSE>
 __global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
                                                       double* __restrict__ D, const CoarseGrid cg) {
@@ -284,7 +357,11 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
                                                         double* __restrict__ D, int nfine, int ncoarse, long long clines, int cc0,
                                                         double h0c, double* __restrict__ Dc, const CoarseGrid cg, const FinalJob fin,
                                                         int wave_lines /* 1: a fine workgroup is four waves with a line each */) {
-  __shared__ Axis0Lds lds;
+  // one block of LDS for the roles a workgroup can have: the workgroup-per-line form's words and carries (16 KB), or four
+  // waves' 64 words + store patches (2 + 36 KB)
+  constexpr size_t kWaveBytes = 4 * 512 + (U16 ? 4 * 64 * kA0Row * 4 : 0);
+  __shared__ __attribute__((aligned(16))) unsigned char a0mem[sizeof(Axis0Lds) > kWaveBytes ? sizeof(Axis0Lds) : kWaveBytes];
+  Axis0Lds& lds = *reinterpret_cast<Axis0Lds*>(a0mem);
   SBO_CHAIN_PRIO();
   // (order of the ranges: the merge and the coarse lines first -- few workgroups with longer chains that should start with the
   // launch, not in the slots the fine lines leave at its end)
@@ -292,8 +369,12 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
   if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy, fin.o_first);
   else if (bid < nfin + ncoarse) edt_axis0_wg_body<true>(bid - nfin, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
   else if (wave_lines) {
-    const long long line = (long long)(bid - nfin - ncoarse) * 4 + (threadIdx.x >> 6);
-    if (line < nlines) edt_axis0_wave_body<U16>(line, lds.words + (threadIdx.x >> 6) * 64, U, count0, h0, D);
+    // (the waves of the fine workgroups stride over the lines: the host sizes the launch to what is resident at once)
+    unsigned long long* wwords = reinterpret_cast<unsigned long long*>(a0mem) + (threadIdx.x >> 6) * 64;
+    for (long long line = (long long)(bid - nfin - ncoarse) * 4 + (threadIdx.x >> 6); line < nlines; line += (long long)nfine * 4) {
+      if constexpr (U16) edt_axis0_wave_seq(line, wwords, reinterpret_cast<unsigned int*>(a0mem + 4 * 512) + (threadIdx.x >> 6) * 64 * kA0Row, U, count0, D);
+      else edt_axis0_wave_body<false>(line, wwords, U, count0, h0, D);
+    }
   } else edt_axis0_wg_body<false, U16>(bid - nfin - ncoarse, nfine, lds, U, nlines, count0, h0, D, cg);
 }
 
