@@ -260,6 +260,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->posterior_valid = false;
     return SBO_OK;
   }
+  if (!strcmp(key, "goose_tail")) {
+    c->goose_tail = value ? 1 : 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "axis0_waves")) {
     c->axis0_waves = value ? 1 : 0;
     return SBO_OK;

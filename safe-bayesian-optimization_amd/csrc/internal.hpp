@@ -227,6 +227,7 @@ struct sbo_ctx {
   int eager_tables = 1;    // sbo_model_set enqueues the K1b tables of the resident grid itself (0: the next posterior launch does)
   int result_mirror = 1;   // SafeOpt sweeps on one rank: the last kernel writes the results into the pinned host block itself (0: a copy behind it)
   int spin_wait = 1;       // the host polls the stream at the end of a sweep / model build instead of sleeping in the runtime's wait (0: hipStreamSynchronize)
+  int goose_tail = 1;      // single-rank GoOSE sweeps: finals + target choice in one launch, the last merge writes the host's result block (0: four launches and a copy)
   int axis0_waves = 1;     // 2-D grids, lines of whole 64-bit words up to 4096 positions: the fine axis-0 pass runs a wave per line without barriers (0: a workgroup per line)
   int dist_u16 = 1;        // shared-launch path of 2-D grids: the fine axis-0 image as 16-bit step counts (0: squared distances as doubles)
   int set_fuse = 1;        // 2-D grids: independent set-phase kernels share launches (k_edt_axis0_pair, k_set_mid); 0: one launch each

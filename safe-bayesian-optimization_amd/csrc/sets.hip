@@ -752,6 +752,66 @@ __global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
 #include "sets_exchange.inc.hpp"
 #include "sets_goose.inc.hpp"
 
+// Tail of a single-rank GoOSE sweep, two launches instead of four and no copy behind them (r03):
+// k_goose_finals = k_sweep_finals<false> for all q slots in ONE workgroup (the regions are small) followed by k_pick_target;
+// k_arg_final_mirror = k_arg_final<false> of the explore slot, which then writes the whole result block and the Lipschitz keys
+// into the host's pinned landing area and carries the sweep's end event (as k_sweep_finals does for SafeOpt).
+template <int D>
+__global__ __launch_bounds__(256) void k_goose_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts, int q, SweepScalars* sc,
+                                                      const SweepScalars* lane1, const double* __restrict__ Lpart0, int per_out,
+                                                      unsigned long long* Lmax, const CandSpec cs, double* __restrict__ target) {
+  if (Lpart0) {
+    __shared__ double lsh[4];
+    lmax_reduce_body(0, lsh, Lpart0, per_out, Lmax);
+  }
+  if (lane1 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
+  for (int slot = 0; slot < q; ++slot) {
+    const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
+    Best best{0.0, -1};
+    long long cnt = 0;
+    const long long* pc = (const long long*)(partial + nparts);
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+      if (better<false>(partial[i], best)) best = partial[i];
+      cnt += pc[i];
+    }
+    best = block_best<false>(best);
+    cnt = block_sum_ll(cnt);
+    if (threadIdx.x == 0) {
+      sc->arg_val[slot] = best.v;
+      sc->arg_idx[slot] = best.i;
+      if (slot > 0) sc->count_set[slot - 1] += cnt;
+    }
+  }
+  if (threadIdx.x == 0) {                    // (thread 0 wrote the slots itself: models/GoOSE.py:110-112, the first minimum wins)
+    int best_c = 0;
+    double bestv = 0.0;
+    for (int cc = 1; cc < q; ++cc)
+      if (sc->arg_idx[cc] >= 0 && (best_c == 0 || sc->arg_val[cc] < bestv)) { best_c = cc; bestv = sc->arg_val[cc]; }
+    double x[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) x[a] = 0.0;
+    if (best_c) cand_coords<D>(cs, sc->arg_idx[best_c] - cs.first, x);
+#pragma unroll
+    for (int a = 0; a < D; ++a) target[a] = x[a];
+  }
+}
+__global__ __launch_bounds__(256) void k_arg_final_mirror(const Best* __restrict__ partial, int nparts, SweepScalars* sc, int slot,
+                                                          unsigned char* mirror, const unsigned long long* __restrict__ Lkeys) {
+  Best best{0.0, -1};
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x)
+    if (better<false>(partial[i], best)) best = partial[i];
+  best = block_best<false>(best);
+  if (threadIdx.x == 0) {
+    sc->arg_val[slot] = best.v;
+    sc->arg_idx[slot] = best.i;
+  }
+  __syncthreads();
+  const unsigned long long* from = reinterpret_cast<const unsigned long long*>(sc);
+  unsigned long long* to = reinterpret_cast<unsigned long long*>(mirror);
+  for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) to[i] = from[i];
+  if (threadIdx.x < kMaxQ) reinterpret_cast<unsigned long long*>(mirror + 3072)[threadIdx.x] = Lkeys[threadIdx.x];
+}
+
 // ---- host orchestration -------------------------------------------------------------------------------
 static int reduce_blocks(const sbo_ctx* c) {
   const long long n = c->cs.n_local;
@@ -1976,11 +2036,6 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
                        (const uint8_t*)c->maskS.p, (const uint8_t*)c->maskO.p, n, (long long)c->cs.first, pbase, pstride, 0);
   const bool lp = ov && c->lmax_pending;
   c->lmax_pending = false;
-  hipLaunchKernelGGL(k_sweep_finals<false>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride,
-                     n > 0 ? nb : 0, sc, lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr,
-                     (unsigned char*)nullptr, (const unsigned long long*)nullptr, lp ? (const double*)c->bl_lpart.p : (const double*)nullptr,
-                     c->lmax_per_out, (unsigned long long*)c->Lmax.p);
-  SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
   for (int t = 0; t < kArgSlots; ++t) is_max[t] = false;
@@ -1988,20 +2043,40 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   // round trip per sweep; ranks > 1 need the merged target slots first and take a second one below.
   const bool fused_explore = !multi_rank(c) && q > 1;
   double* dev_t = (double*)c->scal.p + 256;
-  if (fused_explore) {
+  // (one rank, option goose_tail: the finals and the target choice in one launch, the last merge writes the host's block itself)
+  const bool short_tail = fused_explore && c->goose_tail && c->result_mirror && (c->mc.dpad == 2 || c->mc.dpad == 4 || c->mc.dpad == 8);
+  const SweepScalars* l1 = lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr;
+  const double* lp0 = lp ? (const double*)c->bl_lpart.p : (const double*)nullptr;
+  if (short_tail) {
     switch (c->mc.dpad) {
-      case 2: hipLaunchKernelGGL((k_pick_target<2>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
-      case 4: hipLaunchKernelGGL((k_pick_target<4>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
-      default: hipLaunchKernelGGL((k_pick_target<8>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
+      case 2: hipLaunchKernelGGL((k_goose_finals<2>), dim3(1), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
+      case 4: hipLaunchKernelGGL((k_goose_finals<4>), dim3(1), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
+      default: hipLaunchKernelGGL((k_goose_finals<8>), dim3(1), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
     }
-    if (n > 0) {
-      launch_argmin_dist<T>(c, dev_t, nb);
+    if (n > 0) launch_argmin_dist<T>(c, dev_t, nb);
+    hipExtLaunchKernelGGL(k_arg_final_mirror, dim3(1), dim3(256), 0, c->stream, nullptr, c->ev[4], 0, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
+                          kArgSlots - 1, c->h_back, (const unsigned long long*)c->Lmax.p);
+    SBO_HIP(hipGetLastError());
+  } else {
+    hipLaunchKernelGGL(k_sweep_finals<false>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride,
+                       n > 0 ? nb : 0, sc, l1, (unsigned char*)nullptr, (const unsigned long long*)nullptr, lp0,
+                       c->lmax_per_out, (unsigned long long*)c->Lmax.p);
+    SBO_HIP(hipGetLastError());
+    if (fused_explore) {
+      switch (c->mc.dpad) {
+        case 2: hipLaunchKernelGGL((k_pick_target<2>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
+        case 4: hipLaunchKernelGGL((k_pick_target<4>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
+        default: hipLaunchKernelGGL((k_pick_target<8>), dim3(1), dim3(1), 0, c->stream, c->cs, (const SweepScalars*)sc, q, dev_t); break;
+      }
+      if (n > 0) {
+        launch_argmin_dist<T>(c, dev_t, nb);
+      }
+      hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
+                         kArgSlots - 1, (long long*)nullptr);
     }
-    hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
-                       kArgSlots - 1, (long long*)nullptr);
   }
   unsigned long long Lk[kMaxQ];
-  if ((rc = sweep_exchange_back(c, h, is_max, Lk))) return rc;
+  if ((rc = sweep_exchange_back(c, h, is_max, Lk, short_tail ? c->ev[4] : nullptr, short_tail))) return rc;
   if (multi_rank(c)) {
     if (h.halo_short) {                     // (see sweep_safeopt_t)
       for (auto& g : c->halo_guess) g = -1;
@@ -2060,8 +2135,10 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     coords_of(c, res->explore_index, res->explore_x);
     }
   }
-  SBO_HIP(hipEventRecord(c->ev[4], c->stream));
-  SBO_HIP(hipEventSynchronize(c->ev[4]));
+  if (!short_tail) {                       // (short tail: the end event rode on the last merge and has been waited for)
+    SBO_HIP(hipEventRecord(c->ev[4], c->stream));
+    SBO_HIP(hipEventSynchronize(c->ev[4]));
+  }
   float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t04 = 0;
   SBO_HIP(hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
   if (c->phase_events) {

@@ -1291,6 +1291,25 @@ def _assert_same_bundle(a, b_):
             assert np.array_equal(np.asarray(a[which][k]), np.asarray(b_[which][k])), (which, k)
 
 
+@pytest.mark.parametrize("cfg_name,n,count,b", [("C", 96, [1024, 1030], 2.0), ("B", 64, [320, 300], 3.0), ("C", 64, [130, 70], 2.0),
+                                                  ("D", 128, [9, 8, 7, 6], 0.5), ("A", 20, [50, 50], 3.0)])
+def test_short_goose_tail_equals_the_long_one(engine, cfg_name, n, count, b):
+    """Option goose_tail (default on): a single-rank GoOSE sweep merges its q arg-min regions and chooses the target in one
+    launch, and the explore slot's merge writes the result block into the host's pinned area itself -- the same results as the
+    four launches and the copy they replace (one and two constraints, 2-D and 4-D grids, small and large)."""
+    cfg = synthetic.make_config(cfg_name, n=n)
+    engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+    out = {}
+    try:
+        for tail in (0, 1):
+            engine.set_option("goose_tail", tail)
+            out[tail] = _sweep_bundle(engine, cfg, b, cfg["q"])
+    finally:
+        engine.set_option("goose_tail", 1)
+    _assert_same_bundle(out[0], out[1])
+    assert out[1][1]["explore_index"] >= 0 or out[1][1]["target_index"] < 0
+
+
 @pytest.mark.parametrize("cfg_name,n,count,b", [("B", 128, [2048, 1100], 3.0), ("H", 300, [4096, 700], 3.0), ("C", 96, [1024, 1030], 2.0),
                                                   ("B", 64, [320, 300], 3.0), ("B", 128, [1088, 520], 2.0), ("A", 64, [128, 700], 3.0)])
 def test_wave_per_line_axis0_pass_equals_the_workgroup_form(engine, cfg_name, n, count, b):
