@@ -1171,7 +1171,8 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
 template <int PH, int RB>
 __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict__ A, const double* __restrict__ B, int KB,
                                            int KS, double* __restrict__ outp, double c0, double c1, double c2, double& gmax,
-                                           d4_t (&acc)[RB][8], const double* __restrict__ xn0) {
+                                           d4_t (&acc)[RB][8], const double* __restrict__ xn0, d4_t (&pre)[4],
+                                           const double* __restrict__ An, const double* __restrict__ Bn, int KBn) {
   const double* Ap = A + (size_t)cx.st_rb * KB * 256 + cx.st_off;
   const double* Bp = B + (size_t)cx.st_cs * KB * 256 + cx.st_off;
   const int nkb = (KS + 3) >> 2;
@@ -1199,9 +1200,16 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
       for (int s2 = 0; s2 < 8; ++s2) acc[i][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
   }
   const bool stage_a = RB == 2 || cx.a_lo >= 0;
-  d4_t ra0 = d4_t{0.0, 0.0, 0.0, 0.0}, ra1 = ra0;
-  if (stage_a) { ra0 = *reinterpret_cast<const d4_t*>(Ap); ra1 = *reinterpret_cast<const d4_t*>(Ap + 4); }
-  d4_t rb0v = *reinterpret_cast<const d4_t*>(Bp), rb1v = *reinterpret_cast<const d4_t*>(Bp + 4);
+  // the first k-block's 64 + 64 bytes of this thread: requested by the previous phase before its epilogue (`pre`), so that
+  // their latency runs under that epilogue instead of in front of this loop; phase 0 asks here
+  // (128 x 128 tiles only: the 64 x 128 form runs three workgroups per CU on 168 registers and would spill the four)
+  d4_t &ra0 = pre[0], &ra1 = pre[1], &rb0v = pre[2], &rb1v = pre[3];
+  if (PH == 0 || RB == 1) {
+    ra0 = ra1 = d4_t{0.0, 0.0, 0.0, 0.0};
+    if (stage_a) { ra0 = *reinterpret_cast<const d4_t*>(Ap); ra1 = *reinterpret_cast<const d4_t*>(Ap + 4); }
+    rb0v = *reinterpret_cast<const d4_t*>(Bp);
+    rb1v = *reinterpret_cast<const d4_t*>(Bp + 4);
+  }
   __syncthreads();                             // the previous phase has finished reading the buffers
   stage(lds, ra0, ra1, rb0v, rb1v);
   __syncthreads();
@@ -1260,6 +1268,13 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
     if (kb + 1 < nkb) stage(lds + (cur ^ 1) * BUF, ra0, ra1, rb0v, rb1v);
     __syncthreads();
   }
+  if (RB == 2 && An) {
+    const double* Apn = An + (size_t)cx.st_rb * KBn * 256 + cx.st_off;
+    const double* Bpn = Bn + (size_t)cx.st_cs * KBn * 256 + cx.st_off;
+    if (stage_a) { ra0 = *reinterpret_cast<const d4_t*>(Apn); ra1 = *reinterpret_cast<const d4_t*>(Apn + 4); }
+    rb0v = *reinterpret_cast<const d4_t*>(Bpn);
+    rb1v = *reinterpret_cast<const d4_t*>(Bpn + 4);
+  }
   post_epilogue<PH, RB>(cx, outp, c0, c1, c2, gmax, acc);
 }
 
@@ -1313,13 +1328,16 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   // (Tried: odd outputs running the three short phases first and the variance phase last, so that the two workgroups of a
   // CU do not reach their phase changes together -- no gain on config B, 2.5 % slower on H; one order for all.)
   d4_t acc[RB][8];
-  post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, eff ? eff[4 * o] : KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0);
-  post_phase<1, RB>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0);
+  d4_t pre[4];
+  const double* const A2 = VAo + (size_t)nrb * KBm * 256;
+  const double* const B2 = SBo + (size_t)ncs * KBm * 256;
+  const double* const A3 = VAo + (size_t)nrb * (KBm + KBm2) * 256;
+  post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, eff ? eff[4 * o] : KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0, pre,
+                    VAo, SBo, KBm);
+  post_phase<1, RB>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0, pre, A2, B2, KBm2);
   // phase 2 continues on phase 1's sums: only the V1 half (the first KSm k-steps) of the stacked operands is run
-  post_phase<2, RB>(cx, VAo + (size_t)nrb * KBm * 256, SBo + (size_t)ncs * KBm * 256, KBm2, KSm, nullptr,
-                ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax, acc, xn0);
-  post_phase<3, RB>(cx, VAo + (size_t)nrb * (KBm + KBm2) * 256, SBo, KBm, KSm, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0,
-                gmax, acc, xn0);
+  post_phase<2, RB>(cx, A2, B2, KBm2, KSm, nullptr, ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax, acc, xn0, pre, A3, SBo, KBm);
+  post_phase<3, RB>(cx, A3, SBo, KBm, KSm, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const double other = __shfl_xor(gmax, off);
