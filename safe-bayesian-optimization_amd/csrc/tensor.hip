@@ -4,10 +4,10 @@
 // 268 M candidates of BASELINE.json configs[3] (128^4, n = 128).  But with the separable RBF-ARD kernel the posterior mean, the
 // quadratic form of the variance and the mean's gradient are analytic functions of the candidate whose variation along an axis
 // is set by the length scale, not by the grid: on [lo_a, hi_a] each of them is, to rounding, a polynomial of degree < Dn_a
-// (Dn = 48 for the BASELINE hyper-parameters -- the degree the 2-D path's Chebyshev core runs to).  So:
+// (Dn = 40 .. 48 for the BASELINE hyper-parameters -- the degree the 2-D path's Chebyshev core runs to).  So:
 //   1. K1g itself on the Dn_0 x .. x Dn_{d-1} tensor grid of Chebyshev nodes of the first kind (explicit axis positions,
-//      launch_posterior_on_axes): mean, variance and the signed gradient components of the mean at 5.3 M points for 48^4 --
-//      2 % of the grid;
+//      launch_posterior_on_axes): mean, variance and the signed gradient components of the mean at 48 x 48 x 40 x 40 = 3.7 M
+//      points for config D -- 1.4 % of the grid;
 //   2. interpolation to the grid, one axis at a time: g(.., x_a, ..) = sum_k W_a[x_a][k] g(.., node k, ..) with
 //      W_a[x][k] = (1 / Dn) sum_m w_m T_m(xi_x) T_m(xi_k)  (the discrete Chebyshev transform and the series evaluation in one
 //      matrix).  Axes d-1 .. 2 are contracted by k_t_mode on the small tensors, the last two -- where the data grow to grid
@@ -49,7 +49,7 @@ __global__ void k_t_axes(const TensorDims td, double* __restrict__ axc) {
   }
 }
 
-// interpolation matrix of axis a: W[x][k], x over the (local) grid positions of the axis; transposed copy Wt[k][x] for axis 0
+// interpolation matrix of axis a: W[x][k], x over the (local) grid positions of the axis; transposed copy Wt[k][x] for axes 0 and 1
 __global__ __launch_bounds__(256) void k_t_wmat(const TensorDims td, const CandSpec cs, int a, long long nx, long long x_first,
                                                 double* __restrict__ W, double* __restrict__ Wt) {
   const int Dn = td.Dn[a];
