@@ -49,6 +49,7 @@ struct SweepScalars {
   long long halo_short;                    // ranks > 1: a speculative transform window was narrower than this sweep's keys need
   double arg_val[kArgSlots];
   long long arg_idx[kArgSlots];
+  unsigned long long ticket;               // workgroups of k_goose_finals that have finished their slot (zeroed with the block)
 };
 
 struct Best {
@@ -753,46 +754,54 @@ __global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
 #include "sets_goose.inc.hpp"
 
 // Tail of a single-rank GoOSE sweep, two launches instead of four and no copy behind them (r03):
-// k_goose_finals = k_sweep_finals<false> for all q slots in ONE workgroup (the regions are small) followed by k_pick_target;
+// k_goose_finals = k_sweep_finals<false> (a workgroup per slot) whose last workgroup to finish also does k_pick_target's job;
 // k_arg_final_mirror = k_arg_final<false> of the explore slot, which then writes the whole result block and the Lipschitz keys
 // into the host's pinned landing area and carries the sweep's end event (as k_sweep_finals does for SafeOpt).
 template <int D>
 __global__ __launch_bounds__(256) void k_goose_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts, int q, SweepScalars* sc,
                                                       const SweepScalars* lane1, const double* __restrict__ Lpart0, int per_out,
                                                       unsigned long long* Lmax, const CandSpec cs, double* __restrict__ target) {
-  if (Lpart0) {
+  // workgroup s merges slot s (as k_sweep_finals<false>); the one that finishes last chooses the target
+  if (Lpart0 && blockIdx.x == 0) {
     __shared__ double lsh[4];
     lmax_reduce_body(0, lsh, Lpart0, per_out, Lmax);
   }
-  if (lane1 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
-  for (int slot = 0; slot < q; ++slot) {
-    const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
-    Best best{0.0, -1};
-    long long cnt = 0;
-    const long long* pc = (const long long*)(partial + nparts);
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-      if (better<false>(partial[i], best)) best = partial[i];
-      cnt += pc[i];
-    }
-    best = block_best<false>(best);
-    cnt = block_sum_ll(cnt);
-    if (threadIdx.x == 0) {
-      sc->arg_val[slot] = best.v;
-      sc->arg_idx[slot] = best.i;
-      if (slot > 0) sc->count_set[slot - 1] += cnt;
-    }
+  if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
+  const int slot = blockIdx.x;
+  const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
+  Best best{0.0, -1};
+  long long cnt = 0;
+  const long long* pc = (const long long*)(partial + nparts);
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    if (better<false>(partial[i], best)) best = partial[i];
+    cnt += pc[i];
   }
-  if (threadIdx.x == 0) {                    // (thread 0 wrote the slots itself: models/GoOSE.py:110-112, the first minimum wins)
-    int best_c = 0;
-    double bestv = 0.0;
-    for (int cc = 1; cc < q; ++cc)
-      if (sc->arg_idx[cc] >= 0 && (best_c == 0 || sc->arg_val[cc] < bestv)) { best_c = cc; bestv = sc->arg_val[cc]; }
-    double x[D];
+  best = block_best<false>(best);
+  cnt = block_sum_ll(cnt);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&sc->arg_val[slot], best.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sc->arg_idx[slot], best.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slot > 0) sc->count_set[slot - 1] += cnt;
+    __threadfence();
+    const unsigned long long t = atomicAdd(&sc->ticket, 1ull);
+    if (t == (unsigned long long)(q - 1)) {      // every slot is in memory (models/GoOSE.py:110-112, the first minimum wins)
+      __threadfence();
+      __hip_atomic_store(&sc->ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int best_c = 0;
+      double bestv = 0.0;
+      long long besti = -1;
+      for (int cc = 1; cc < q; ++cc) {
+        const long long ai = __hip_atomic_load(&sc->arg_idx[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double av = __hip_atomic_load(&sc->arg_val[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ai >= 0 && (best_c == 0 || av < bestv)) { best_c = cc; bestv = av; besti = ai; }
+      }
+      double x[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) x[a] = 0.0;
-    if (best_c) cand_coords<D>(cs, sc->arg_idx[best_c] - cs.first, x);
+      for (int a = 0; a < D; ++a) x[a] = 0.0;
+      if (best_c) cand_coords<D>(cs, besti - cs.first, x);
 #pragma unroll
-    for (int a = 0; a < D; ++a) target[a] = x[a];
+      for (int a = 0; a < D; ++a) target[a] = x[a];
+    }
   }
 }
 __global__ __launch_bounds__(256) void k_arg_final_mirror(const Best* __restrict__ partial, int nparts, SweepScalars* sc, int slot,
@@ -1843,12 +1852,11 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
       double* lo1 = lo0 + nc;
       double* hi0 = lo1 + nc;
       double* hi1 = hi0 + nc;
-      const unsigned gridc = (unsigned)std::min<long long>((nc + 255) / 256, 1 << 16);
-      hipLaunchKernelGGL((k_pdt_cell_min<T>), dim3(gridc), dim3(256), 0, c->stream, Wwin, cg, nc,
+      hipLaunchKernelGGL((k_pdt_cell_min<T>), dim3((unsigned)std::min<long long>((nc * 8 + 255) / 256, 1 << 18)), dim3(256), 0, c->stream, Wwin, cg, nc,
                          (const unsigned long long*)c->Lmax.p, lidx, lo0, hi0);
       long long cstride = 1;
       for (int a = 0; a < d; ++a) {
-        hipLaunchKernelGGL(k_pdt_coarse_scan, dim3(2 * gridc), dim3(256), 0, c->stream, (const double*)lo0, lo1, (const double*)hi0,
+        hipLaunchKernelGGL(k_pdt_coarse_scan, dim3((unsigned)std::min<long long>((2 * nc * 8 + 255) / 256, 1 << 18)), dim3(256), 0, c->stream, (const double*)lo0, lo1, (const double*)hi0,
                            hi1, nc, cstride, (int)cg.ccount[a], c->cs.step[a], (const SweepScalars*)sc, cidx,
                            (const unsigned long long*)c->Lmax.p, lidx, d, xscale);
         std::swap(lo0, lo1);
@@ -2049,9 +2057,9 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   const double* lp0 = lp ? (const double*)c->bl_lpart.p : (const double*)nullptr;
   if (short_tail) {
     switch (c->mc.dpad) {
-      case 2: hipLaunchKernelGGL((k_goose_finals<2>), dim3(1), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
-      case 4: hipLaunchKernelGGL((k_goose_finals<4>), dim3(1), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
-      default: hipLaunchKernelGGL((k_goose_finals<8>), dim3(1), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
+      case 2: hipLaunchKernelGGL((k_goose_finals<2>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
+      case 4: hipLaunchKernelGGL((k_goose_finals<4>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
+      default: hipLaunchKernelGGL((k_goose_finals<8>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
     }
     if (n > 0) launch_argmin_dist<T>(c, dev_t, nb);
     hipExtLaunchKernelGGL(k_arg_final_mirror, dim3(1), dim3(256), 0, c->stream, nullptr, c->ev[4], 0, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,

@@ -233,15 +233,20 @@ __device__ __forceinline__ PdtParams pdt_params(const SweepScalars* sc, int c, c
 // covered and its axis-0 values cannot matter either (they are >= P); upper side < -band: every U point is covered.
 // Fmin of every coarse cell: one thread per cell walks its kCoarse^d candidates (axis 0 innermost); cells without a
 // source get +inf.  Written to both bound arrays (they start from the same values).
+// (r03: eight lanes per cell, each walking every eighth line of the cell -- a thread per cell ran its kCoarse^(d-1) lines of
+// eight loads one after the other, 12 us of pure load latency on config C's 16384 cells; the maximum does not depend on the order)
 template <typename T>
 __global__ __launch_bounds__(256) void k_pdt_cell_min(const T* __restrict__ W, const CoarseGrid cg, long long nc,
                                                       const unsigned long long* Lkeys, int lidx, double* __restrict__ lo,
                                                       double* __restrict__ hi) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const double invL = L > 0 ? 1.0 / L : 0.0;
-  for (long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x; cell < nc; cell += (long long)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & 7;
+  const long long ncr = (nc + 31) / 32 * 32;               // whole groups of eight lanes up to the end of the last wave's cells
+  for (long long cell = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; cell < ncr; cell += ((long long)gridDim.x * blockDim.x) >> 3) {
+    const bool on = cell < nc;
     // fine index of the cell origin and the cell's extent per axis
-    long long f = cell, stride = 1, origin = 0, len[kMaxD], fstride[kMaxD], total = 1;
+    long long f = on ? cell : 0, stride = 1, origin = 0, len[kMaxD], fstride[kMaxD], total = 1;
     for (int a = 0; a < cg.d; ++a) {
       const long long ci = f % cg.ccount[a];
       f /= cg.ccount[a];
@@ -253,8 +258,8 @@ __global__ __launch_bounds__(256) void k_pdt_cell_min(const T* __restrict__ W, c
       total *= len[a];
     }
     double wmax = -1.0;
-    const long long nsub = total / len[0];             // lines of <= kCoarse consecutive candidates along axis 0
-    for (long long sline = 0; sline < nsub; ++sline) {
+    const long long nsub = on ? total / len[0] : 0;        // lines of <= kCoarse consecutive candidates along axis 0
+    for (long long sline = sub; sline < nsub; sline += 8) {
       long long u = sline, g = origin;
       for (int a = 1; a < cg.d; ++a) {
         g += (u % len[a]) * fstride[a];
@@ -266,53 +271,52 @@ __global__ __launch_bounds__(256) void k_pdt_cell_min(const T* __restrict__ W, c
 #pragma unroll
       for (int k = 0; k < kCoarse; ++k) wmax = w[k] > wmax ? w[k] : wmax;
     }
-    double v = kInfD;
-    if (wmax >= 0.0) { const double r = wmax * invL; v = -(r * r); }
-    lo[cell] = v;
-    hi[cell] = v;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      const double y = __shfl_xor(wmax, o);
+      wmax = y > wmax ? y : wmax;
+    }
+    if (on && sub == 0) {
+      double v = kInfD;
+      if (wmax >= 0.0) { const double r = wmax * invL; v = -(r * r); }
+      lo[cell] = v;
+      hi[cell] = v;
+    }
   }
 }
 // one axis of both coarse bound transforms (lower-bound costs on the first array, upper-bound costs on the second)
+// (r03: eight lanes per cell and bound, lane j takes the offsets t = j, j + 8, .. -- a thread per cell walked up to `cnt` offsets
+// with two dependent loads each, 13 us on config C's 128 x 128 cells; the minimum over the offsets inside the band is the same)
 __global__ __launch_bounds__(256) void k_pdt_coarse_scan(const double* __restrict__ LoIn, double* __restrict__ LoOut,
                                                          const double* __restrict__ HiIn, double* __restrict__ HiOut, long long nc,
                                                          long long stride, int cnt, double h, const SweepScalars* sc, int c,
                                                          const unsigned long long* Lkeys, int lidx, int d, double xscale) {
   const PdtParams pp = pdt_params(sc, c, Lkeys, lidx, d, xscale);
-  for (long long g2 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g2 < 2 * nc; g2 += (long long)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & 7;
+  for (long long g2 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; g2 < 2 * nc; g2 += ((long long)gridDim.x * blockDim.x) >> 3) {
     const int upper = g2 >= nc;                          // first half of the index space: lower bounds, second half: upper
     const long long g = upper ? g2 - nc : g2;
     const double* Pin = upper ? HiIn : LoIn;
     const int ia = (int)((g / stride) % cnt);
-    // four steps (eight loads) per round of exit tests, as edt_scan_point: a step examined beyond an exit cannot lower
-    // the minimum (its candidate is >= dd^2 - rmax2 >= best) or only between values above the band
     double best = kInfD;
-    for (int t0 = 0; t0 < cnt; t0 += 4) {
-      {
-        const double steps_lo = t0 == 0 ? 0.0 : (double)((t0 - 1) * kCoarse + 1);
-        const double steps = upper ? (double)((t0 + 1) * kCoarse - 1) : steps_lo;
-        const double dl = h * steps_lo, dd = h * steps;
-        const double floor_ = dl * dl - pp.rmax2;        // no source that far can bring any candidate below the band
-        if (floor_ > pp.band || dd * dd - pp.rmax2 >= best) break;
-        if (ia - t0 < 0 && ia + t0 >= cnt) break;
-      }
-      double c1[4], c2[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = t0 + u;
-        c1[u] = ia - t >= 0 ? Pin[g - (long long)t * stride] : kInfD;
-        c2[u] = ia + t < cnt ? Pin[g + (long long)t * stride] : kInfD;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = t0 + u;
-        const double steps_lo = t == 0 ? 0.0 : (double)((t - 1) * kCoarse + 1);
-        const double steps = upper ? (double)((t + 1) * kCoarse - 1) : steps_lo;
-        const double dl = h * steps_lo, dd = h * steps;
-        const double cnd = (c1[u] < c2[u] ? c1[u] : c2[u]) + dd * dd;
-        if (!(dl * dl - pp.rmax2 > pp.band) && cnd < best) best = cnd;
-      }
+    for (int t = sub; t < cnt; t += 8) {
+      const double steps_lo = t == 0 ? 0.0 : (double)((t - 1) * kCoarse + 1);
+      const double steps = upper ? (double)((t + 1) * kCoarse - 1) : steps_lo;
+      const double dl = h * steps_lo, dd = h * steps;
+      if (dl * dl - pp.rmax2 > pp.band) break;           // no source that far can bring any candidate below the band
+      if (dd * dd - pp.rmax2 >= best) break;             // nor improve this lane's minimum (the values are >= -rmax2)
+      if (ia - t < 0 && ia + t >= cnt) break;
+      const double c1 = ia - t >= 0 ? Pin[g - (long long)t * stride] : kInfD;
+      const double c2 = ia + t < cnt ? Pin[g + (long long)t * stride] : kInfD;
+      const double cnd = (c1 < c2 ? c1 : c2) + dd * dd;
+      if (cnd < best) best = cnd;
     }
-    (upper ? HiOut : LoOut)[g] = best;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      const double y = __shfl_xor(best, o);
+      best = y < best ? y : best;
+    }
+    if (sub == 0) (upper ? HiOut : LoOut)[g] = best;
   }
 }
 __device__ __forceinline__ long long coarse_cell(const CoarseGrid& cg, long long gg) {
