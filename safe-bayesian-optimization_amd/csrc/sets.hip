@@ -1016,7 +1016,10 @@ static void halo_learn(sbo_ctx* c, const SweepScalars& h, const unsigned long lo
 // G_c for constraint cidx (1..q-1) into G[n]
 static void launch_edt_axis0(sbo_ctx* c, const uint8_t* U, long long nlines, int count0, double h0, double* D, hipStream_t st = nullptr) {
   if (!st) st = c->stream;
-  if (count0 <= kAxis0Max && count0 >= 128)
+  if (c->axis0_waves && (count0 & 63) == 0 && count0 <= 4096 && ((uintptr_t)U & 7) == 0)
+    hipLaunchKernelGGL(k_edt_axis0_waves, dim3((unsigned)std::max<long long>(1, std::min<long long>((nlines + 3) / 4, (long long)c->n_cu * 16))), dim3(256), 0,
+                       st, U, nlines, count0, h0, D);
+  else if (count0 <= kAxis0Max && count0 >= 128)
     hipLaunchKernelGGL(k_edt_axis0_wg<false>, dim3((unsigned)std::min<long long>(nlines, 1 << 20)), dim3(256), 0, st, U, nlines,
                        count0, h0, D, CoarseGrid{});
   else

@@ -349,6 +349,16 @@ __global__ __launch_bounds__(256) void k_edt_axis0_wg(const uint8_t* __restrict_
   __shared__ Axis0Lds lds;
   edt_axis0_wg_body<COARSE>((int)blockIdx.x, (int)gridDim.x, lds, U, nlines, count0, h0, D, cg);
 }
+// axis 0 as squared distances (grids of three and more axes, and 2-D grids outside the paired launch), a wave per line: lines of
+// whole 64-bit words up to 4096 positions.  Config D has 2.1 M lines of 128 positions: a workgroup per line spent three barriers
+// on two words of mask (1.6 ms); a wave needs a load, two scans and two rounds of stores.
+__global__ __launch_bounds__(256) void k_edt_axis0_waves(const uint8_t* __restrict__ U, long long nlines, int count0, double h0,
+                                                         double* __restrict__ D) {
+  __shared__ unsigned long long wl[4][64];
+  const int wave = threadIdx.x >> 6;
+  for (long long line = (long long)blockIdx.x * 4 + wave; line < nlines; line += (long long)gridDim.x * 4)
+    edt_axis0_wave_body<false>(line, wl[wave], U, count0, h0, D);
+}
 // fine and coarse axis-0 passes of a 2-D grid in one launch (both read the U mask only): workgroups [0, nfine) take the
 // fine lines, the rest the lines of coarse cells
 // (+ one workgroup for the merge of the classification's partials when `fin` is pending: nothing here reads the scalars)

@@ -1311,12 +1311,14 @@ def test_short_goose_tail_equals_the_long_one(engine, cfg_name, n, count, b):
 
 
 @pytest.mark.parametrize("cfg_name,n,count,b", [("B", 128, [2048, 1100], 3.0), ("H", 300, [4096, 700], 3.0), ("C", 96, [1024, 1030], 2.0),
-                                                  ("B", 64, [320, 300], 3.0), ("B", 128, [1088, 520], 2.0), ("A", 64, [128, 700], 3.0)])
+                                                  ("B", 64, [320, 300], 3.0), ("B", 128, [1088, 520], 2.0), ("A", 64, [128, 700], 3.0),
+                                                  ("D", 128, [64, 9, 8, 7], 0.5), ("D", 128, [128, 6, 5, 9], 0.5), ("D", 128, [192, 40, 33, 3], 0.5)])
 def test_wave_per_line_axis0_pass_equals_the_workgroup_form(engine, cfg_name, n, count, b):
     """Option axis0_waves (default on): on 2-D grids whose lines are whole 64-bit words of at most 4096 positions the fine axis-0
     pass of the distance transform runs a wave per line (bits through the wave's own LDS words, wave scans, broadcast words) instead
     of a workgroup per line behind three barriers -- the same step counts, so every mask, count and index of the SafeOpt and
-    GoOSE sweeps is identical (16-bit and double images, one and two constraints)."""
+    GoOSE sweeps is identical (16-bit and double images, one and two constraints; the last three cases: four-axis grids, whose
+    short lines take the squared-distance form of the pass)."""
     cfg = synthetic.make_config(cfg_name, n=n)
     engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
     out = {}
