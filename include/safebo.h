@@ -285,7 +285,10 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  * chains on two streams), "exact_lazy" (1 default: one-constraint sweeps launch the exhaustive recheck of in-band expander verdicts only
  * when the result block reports any; 2: that late path on every sweep, a test hook; 0: always launched), "halo_spec" (1 default: ranks > 1
  * size their transform windows from the previous sweep's global keys, checked on the device -- no host wait inside a sweep),
- * "comm_events" (1: an event pair around every collective, sbo_profile.comm_ms), "set_fuse" (1 default: on 2-D grids of one rank the
+ * "comm_events" (1: an event pair around every collective, sbo_profile.comm_ms), "axis0_waves" (1 default: the axis-0 pass of the distance
+ * transform runs a wave per grid line when the lines are whole 64-bit words of at most 4096 positions; 0: a workgroup per line), "goose_tail"
+ * (1 default: a single-rank GoOSE sweep ends with two launches -- finals + target choice, explore merge writing the host's result block -- instead of
+ * four and a copy), "set_fuse" (1 default: on 2-D grids of one rank the
  * independent kernels of the set phase share launches; 0: one launch per kernel, same results), "dist_u16" (1 default: on that path the fine distance image holds 16-bit step counts instead of
  * squared distances as doubles -- same verdicts, a quarter of the bytes), "set_lanes" (1 default: on one rank the constraints of a sweep alternate between two
  * streams -- their expander / optimistic-set chains are independent --, 0: one after the other), "eager_tables" (1 default:
