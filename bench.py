@@ -145,27 +145,16 @@ def sweep_fn(eng, kind, b):
 
 def hbm_roofline(q, es, n_local, rows):
     """the classification / expander / arg-max passes are HBM-bound, ~ 2 q s + 4 bytes per candidate
-    (mean and var of every output read once, three mask bytes and the transform's verdict written), no reuse.
-
-    Overlapped sweeps (sbo_profile.k1_split) run the constraint-only part of the set phase beside the objective's GEMM:
-    ``set_phase_ms`` is then that chain's own duration (stop of the constraints' K1b launch -> its last kernel) plus the tail
-    behind the K1 stop event -- the figure comparable with earlier rounds -- and ``exposed`` prices the same bytes over the
-    tail alone, which is what the set phase still adds to the sweep."""
+    (mean and var of every output read once, three mask bytes and the transform's verdict written), no reuse;
+    ``set_phase_ms`` = device time between the K1 stop event and the end of the sweep."""
     per_cand = 2 * q * es + 4
     byts = float(per_cand) * n_local
-    exposed = float(np.mean([p["total_ms"] - p["posterior_ms"] - p["recheck_ms"] for p in rows]))
-    chain = float(np.mean([p["set_chain_ms"] for p in rows]))
-    set_ms = chain + exposed
+    set_ms = float(np.mean([p["total_ms"] - p["posterior_ms"] - p["recheck_ms"] for p in rows]))
     tbs = byts / (set_ms * 1e-3) / 1e12 if set_ms > 0 else 0.0
-    tbe = byts / (exposed * 1e-3) / 1e12 if exposed > 0 else 0.0
     return {"bound": "hbm", "kernels": "set phase K3-K5: classification, distance transforms, verdicts, arg-reductions",
             "bytes_per_candidate": per_cand, "bytes": byts, "set_phase_ms": set_ms, "achieved": tbs, "unit": "TB/s",
             "peak": HBM_PEAK_TBS, "frac": tbs / HBM_PEAK_TBS, "frac_vs_measured_copy": tbs / HBM_MEASURED_TBS,
-            "overlapped": bool(rows[-1]["k1_split"]), "chain_ms": chain,
-            "exposed": {"ms": exposed, "achieved": tbe, "frac": tbe / HBM_PEAK_TBS,
-                        "definition": "the same bytes / device time between the K1 stop event and the end of the sweep"},
-            "definition": "SURVEY.md 8(d): (2 q s + 4) bytes per candidate / set-phase device time (chain beside the objective's "
-                          "GEMM + tail behind it when overlapped)"}
+            "definition": "SURVEY.md 8(d): (2 q s + 4) bytes per candidate / device time between the K1 stop event and the end of the sweep"}
 
 
 def mfma_roofline(cfg, prof_rows, n_local):

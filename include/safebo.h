@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SBO_ABI_VERSION 1
+#define SBO_ABI_VERSION 2
 #define SBO_MAX_D 8        /* input dimension limit (reference problems use d = 2)          */
 #define SBO_MAX_Q 8        /* modelled outputs: objective + constraints                      */
 #define SBO_MAX_N 2048     /* observations                                                   */
@@ -151,15 +151,10 @@ typedef struct sbo_profile {
   int64_t fp64_rechecks;         /* dtype SBO_F32 SafeOpt sweeps: candidates whose fp32 bounds could not decide S / U / u* / M / the
                                     minimiser and were re-evaluated in fp64 (option "fp64_recheck"); 0 otherwise                  */
   double recheck_ms;             /* device time of that step (band reductions, flagging, fp64 posterior of the list, scatter)    */
-  /* overlapped sweeps (option "k1_split"): the constraints' outputs leave K1b first and the constraint-only part of the set
-   * phase runs beside the objective's GEMM on a second stream */
-  double set_chain_ms;           /* device time of that chain: stop of the constraints' K1b launch -> its last kernel (0: not split) */
-  double set_exposed_ms;         /* K1 stop event (the objective's launch) -> end of the sweep: what the set phase adds to K1     */
-  int32_t k1_split;              /* 1: the last sweep ran overlapped                                                              */
+  double set_phase_ms;           /* K1 stop event -> end of the sweep: what the set phase (K3-K5 + collectives) adds to K1          */
   int32_t host_syncs;            /* host waits on the device inside the last sweep call (1 = the result read-back only)          */
-  int64_t comm_bytes;            /* multi-rank sweeps: bytes this rank handed to the collectives of the last sweep (send side)     */
   int32_t comm_calls;            /* collectives of the last sweep; comm_ms is their event-timed sum when option "comm_events" is 1 */
-  int32_t reserved2;
+  int64_t comm_bytes;            /* multi-rank sweeps: bytes this rank handed to the collectives of the last sweep (send side)     */
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */
@@ -262,43 +257,26 @@ int sbo_plant_wo(sbo_ctx* ctx, int64_t n, const double* u, double* out);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
-/* tuning / diagnostics knobs: "posterior_path" (0 auto, 1 generic single-phase, 2 generic chunked), "bilinear" (1 default:
- * fp64 2-D grids run the posterior as two GEMMs in a reduced basis when that is cheaper; 0: always the separable-table
- * kernel), "tensor_cheb" (1 default: fp64 grids of three / four axes with at least 64 positions per axis take the exact posterior on a
- * tensor grid of Chebyshev nodes and interpolate it to the candidates on the matrix cores when a probe of 2048 exactly evaluated grid
- * points confirms 2e-11; 0: always the separable-table kernel; "tensor_guess_pct", default 100, scales the first guess of the node counts --
- * a test hook for the probe's second attempt), "k1_wgs_per_cu", "k1_strips" (4 | 8), "scan_blocks" (1 default: blocked last-axis scans),
- * "scan_waves" (1 default: open candidates of the expander query are scanned by half-waves), "goose_pairs" (1: pair
- * evaluation instead of the transform on grids), "phase_events" (1: time the set phases separately, see sbo_profile), "bl_host_bases" (1: the axis bases of the GEMM posterior by
- * the host SVD of bilinear_host.hpp instead of the device kernel), "fuse_classify" (one-constraint sweeps take S / U from
- * the GEMM posterior's mean epilogue, with sign tests that need no square root: 1 always, 0 never, -1 default: when that launch has at least
- * four workgroups per CU), "k1_split" (1: sweeps of constrained models on the GEMM posterior of one rank run the constraints' outputs first
- * and the constraint-only part of their set phase on a second stream beside the objective's GEMM; identical results, measured slower: default 0;
- * "split_rb": tile height of those launches), "cheb_core" (1 default: the variance phase of the GEMM posterior contracts over the degrees
- * of the quadratic form as a polynomial of the axes -- its 2-D Chebyshev coefficients, cut on the device where they have decayed below
- * "cheb_tol_e17" x 1e-17 (default 400) of the largest -- instead of over the ~r^2/2 pair products of the basis functions; 0: pair form),
- * "post_rb" (tile height of the fused posterior kernel: 0 auto, 1 = 64 x 128, 2 = 128 x 128), "chol_async" (1 default: a caller's invK on
- * a grid the GEMM posterior takes is contracted as given and its reverse Cholesky factor -- needed by the O(n^2) kernels and
- * sbo_model_append only -- is built on a side stream after sbo_model_set has returned; SBO_E_INVALID for an indefinite invK then comes
- * from the first call that needs the factor), "chol_fused" (1 default: one launch per Cholesky panel), "basis_reg" (1 default: the axis
- * bases' pivot loop keeps its residual rows in registers), "table_streams" (1 default: the GEMM posterior's tables are built as two
- * chains on two streams), "exact_lazy" (1 default: one-constraint sweeps launch the exhaustive recheck of in-band expander verdicts only
- * when the result block reports any; 2: that late path on every sweep, a test hook; 0: always launched), "halo_spec" (1 default: ranks > 1
- * size their transform windows from the previous sweep's global keys, checked on the device -- no host wait inside a sweep),
- * "comm_events" (1: an event pair around every collective, sbo_profile.comm_ms), "axis0_waves" (1 default: the axis-0 pass of the distance
- * transform runs a wave per grid line when the lines are whole 64-bit words of at most 4096 positions; 0: a workgroup per line), "goose_tail"
- * (1 default: a single-rank GoOSE sweep ends with two launches -- finals + target choice, explore merge writing the host's result block -- instead of
- * four and a copy), "set_fuse" (1 default: on 2-D grids of one rank the
- * independent kernels of the set phase share launches; 0: one launch per kernel, same results), "dist_u16" (1 default: on that path the fine distance image holds 16-bit step counts instead of
- * squared distances as doubles -- same verdicts, a quarter of the bytes), "set_lanes" (1 default: on one rank the constraints of a sweep alternate between two
- * streams -- their expander / optimistic-set chains are independent --, 0: one after the other), "eager_tables" (1 default:
- * sbo_model_set enqueues the GEMM posterior's per-(model, grid) tables for the resident grid itself), "result_mirror" (1 default: the last kernel of a one-rank SafeOpt
- * sweep writes the result block into pinned host memory itself and carries the end event; 0: a copy behind it), "spin_wait" (1 default:
- * the host polls the stream for up to 5 ms at the end of a sweep / model build before it sleeps in the runtime's wait), "fp64_recheck" (1 default: dtype SBO_F32 single-rank SafeOpt sweeps re-evaluate in fp64 every
- * candidate whose fp32 posterior -- within its 1e-4 contract -- cannot decide S, U, u*, M or the minimiser, so that those
- * equal the fp64 result; 0: masks are functions of the fp32 posterior alone), "comm_selftest" (1: a one-rank world created
- * with sbo_comm_init(ctx, 1, 0, id) sends the collectives C1 / C2 / C3 through its RCCL communicator instead of skipping
- * them -- the sweep results must not change) */
+/* Diagnostics / test knobs (every default is the measured-best path; DESIGN.md "Options" has the A/B record of each):
+ *   "posterior_path"   0 auto | 1 generic single-phase kernel (K1) | 2 generic chunked kernel (K1c)
+ *   "bilinear"         1: fp64 2-D grids run the posterior as two GEMMs on a Chebyshev core (K1b) when the bases qualify; 0: K1g
+ *   "cheb_tol_e17"     K1b: coefficients below this x 1e-17 of the largest are not run (default 400 = 4e-15)
+ *   "tensor_cheb"      1: fp64 3-D / 4-D grids interpolate the exact posterior from a tensor grid of Chebyshev nodes (K1t); 0: K1g
+ *   "tensor_guess_pct" K1t test hook: scales the first guess of the node counts (a short guess exercises the probe's retry)
+ *   "fuse_classify"    one-constraint K1b sweeps take S / U from the posterior's mean epilogue: 1 | 0 | -1 auto (default)
+ *   "chol_async"       1: a caller's invK is contracted as given by K1b and its reverse Cholesky factor built off the critical path
+ *   "scan_blocks"      1: blocked last-axis scans of the distance transforms; 0: step by step (A/B checker)
+ *   "scan_waves"       1: open candidates of the verdict kernels are listed and scanned by groups of 16 lanes (8 | 32 | 64: lanes); 0: own thread
+ *   "goose_pairs"      1: GoOSE coverage by pruned pair evaluation on grids too (A/B checker of the power transform)
+ *   "set_fuse"         1: 2-D grids of one rank share launches between independent set-phase kernels; 0: one launch per kernel
+ *   "set_lanes"        1: constraints of a one-rank sweep alternate between two streams; 0: one after the other
+ *   "exact_lazy"       1: one-constraint sweeps launch the exhaustive recheck only when in-band verdicts were listed; 2: always that late path (test); 0: eager
+ *   "result_mirror"    1: the last kernel of a one-rank sweep writes the result block into pinned host memory; 0: a copy behind it
+ *   "phase_events"     1: events between the set phases too (sbo_profile.classify_ms / expander_ms / argreduce_ms; ~6 us bubble each)
+ *   "halo_spec"        1: ranks > 1 size their transform windows from the previous sweep's keys (device-checked); 0: wait for this sweep's
+ *   "comm_events"      1: an event pair around every collective (sbo_profile.comm_ms)
+ *   "comm_selftest"    1: a one-rank communicator still sends C1 / C2 / C3 through RCCL (results must not change)
+ *   "fp64_recheck"     1: fp32 models re-evaluate in fp64 every candidate their 1e-4 contract cannot decide; 0: masks of the fp32 posterior */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

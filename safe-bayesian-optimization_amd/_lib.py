@@ -68,8 +68,7 @@ class Profile(C.Structure):
         ("posterior_flops", C.c_double), ("candidates", C.c_int64), ("posterior_launches", C.c_int32),
         ("posterior_kernel", C.c_int32), ("posterior_executed_flops", C.c_double), ("posterior_setup_ms", C.c_double),
         ("fp64_rechecks", C.c_int64), ("recheck_ms", C.c_double),
-        ("set_chain_ms", C.c_double), ("set_exposed_ms", C.c_double), ("k1_split", C.c_int32), ("host_syncs", C.c_int32),
-        ("comm_bytes", C.c_int64), ("comm_calls", C.c_int32), ("reserved2", C.c_int32),
+        ("set_phase_ms", C.c_double), ("host_syncs", C.c_int32), ("comm_calls", C.c_int32), ("comm_bytes", C.c_int64),
     ]
 
 
@@ -146,8 +145,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.sbo_version() != 1:
-        raise ImportError(f"libsafebo ABI version {lib.sbo_version()} != 1")
+    if lib.sbo_version() != 2:
+        raise ImportError(f"libsafebo ABI version {lib.sbo_version()} != 2")
     _lib = lib
     return lib
 

@@ -37,7 +37,7 @@ int ensure(DevBuf& b, size_t bytes) {
 // The runtime's blocking wait parks the thread and wakes it through an interrupt (~15-25 us after the stream drained); a
 // sweep is 0.3 ms, so the host polls for up to 5 ms first and only then sleeps.
 hipError_t stream_wait(const sbo_ctx* c, hipStream_t st) {
-  if (c->spin_wait) {
+  {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
       const hipError_t e = hipStreamQuery(st);
@@ -171,7 +171,6 @@ static int shadow_ensure(sbo_ctx* c) {
   s->ev_factor = c->ev_factor;
   s->ev_w = c->ev_w;
   s->chol_async = 0;
-  s->k1_split = 0;
   for (int i = 0; i < 8; ++i) s->ev[i] = c->ev[i];
   s->h_back = c->h_back;
   s->fp64_recheck = 0;
@@ -201,7 +200,7 @@ int sbo_shutdown(sbo_ctx* c) {
   }
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_cheb, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->upart, &c->invk_img, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg, &c->tn_pts, &c->tn_vals, &c->tn_work, &c->tn_W0t, &c->tn_W1t, &c->tn_probe, &c->tn_scr})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_cheb, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->invk_img, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg, &c->tn_pts, &c->tn_vals, &c->tn_work, &c->tn_W0t, &c->tn_W1t, &c->tn_probe, &c->tn_scr})
     release(*b);
   for (auto& b : c->tn_W) release(b);
   for (auto& ev : c->ev)
@@ -233,17 +232,6 @@ int sbo_synchronize(sbo_ctx* c) {
 
 int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   if (!c || !key) return fail(SBO_E_INVALID, "ctx/key is NULL");
-  if (!strcmp(key, "k1_strips")) {
-    if (value != 4 && value != 8) return fail(SBO_E_INVALID, "k1_strips must be 4 or 8");
-    c->k1_strips = (int)value;
-    c->posterior_valid = false;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "k1_wgs_per_cu")) {
-    if (value < 0 || value > 64) return fail(SBO_E_INVALID, "k1_wgs_per_cu out of range");
-    c->k1_wgs_per_cu = (int)value;
-    return SBO_OK;
-  }
   if (!strcmp(key, "halo_spec")) {
     c->halo_spec = value ? 1 : 0;
     for (auto& g : c->halo_guess) g = -1;
@@ -253,19 +241,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->comm_events = value ? 1 : 0;
     return SBO_OK;
   }
-  if (!strcmp(key, "cheb_core") || !strcmp(key, "cheb_tol_e17")) {
-    if (!strcmp(key, "cheb_core")) c->cheb_core = value ? 1 : 0;
-    else c->cheb_tol = (double)value * 1e-17;
+  if (!strcmp(key, "cheb_tol_e17")) {
+    c->cheb_tol = (double)value * 1e-17;
     c->bl.valid = false;
     c->posterior_valid = false;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "goose_tail")) {
-    c->goose_tail = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "axis0_waves")) {
-    c->axis0_waves = value ? 1 : 0;
     return SBO_OK;
   }
   if (!strcmp(key, "tensor_guess_pct")) {
@@ -282,51 +261,12 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->posterior_valid = false;
     return SBO_OK;
   }
-  if (!strcmp(key, "classify_wgs")) {
-    if (value < 0 || value > 65535) return fail(SBO_E_INVALID, "classify_wgs out of range");
-    c->classify_wgs = (int)value;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "decide_wide")) {
-    c->decide_wide = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "post_rb")) {
-    if (value < 0 || value > 3) return fail(SBO_E_INVALID, "post_rb must be 0 (auto), 1, 2 or 3");
-    c->post_rb = (int)value;
-    c->posterior_valid = false;
-    return SBO_OK;
-  }
   if (!strcmp(key, "exact_lazy")) {
     c->exact_lazy = value < 0 || value > 2 ? 1 : (int)value;      // 2: the late-recheck path runs on every sweep (test)
     return SBO_OK;
   }
-  if (!strcmp(key, "table_streams")) {
-    c->table_streams = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "basis_reg")) {
-    c->basis_reg = value ? 1 : 0;
-    c->bl.valid = false;
-    c->bl_basis_ok = false;
-    c->posterior_valid = false;
-    return SBO_OK;
-  }
   if (!strcmp(key, "chol_async")) {
     c->chol_async = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "chol_fused")) {
-    c->chol_fused = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "k1_split")) {
-    c->k1_split = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "split_rb")) {
-    if (value < 0 || value > 2) return fail(SBO_E_INVALID, "split_rb must be 0 (auto), 1 or 2");
-    c->split_rb = (int)value;
     return SBO_OK;
   }
   if (!strcmp(key, "bilinear")) {
@@ -346,20 +286,8 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->set_lanes = value ? 1 : 0;
     return SBO_OK;
   }
-  if (!strcmp(key, "eager_tables")) {
-    c->eager_tables = value ? 1 : 0;
-    return SBO_OK;
-  }
   if (!strcmp(key, "result_mirror")) {
     c->result_mirror = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "spin_wait")) {
-    c->spin_wait = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "dist_u16")) {
-    c->dist_u16 = value ? 1 : 0;
     return SBO_OK;
   }
   if (!strcmp(key, "set_fuse")) {
@@ -377,13 +305,6 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   }
   if (!strcmp(key, "goose_pairs")) {
     c->goose_pairs = value ? 1 : 0;
-    return SBO_OK;
-  }
-  if (!strcmp(key, "bl_host_bases")) {
-    c->bl_host_bases = value ? 1 : 0;
-    c->bl.valid = false;
-    c->bl_basis_ok = false;
-    c->posterior_valid = false;
     return SBO_OK;
   }
   if (!strcmp(key, "fp64_recheck")) {
@@ -451,7 +372,7 @@ static int model_set_impl(sbo_ctx* c, int dtype, const char* kernel, int n, int 
   // A grid is resident and qualifies for the GEMM posterior: its per-(model, grid) tables are enqueued now, so that they
   // run while the caller is on its way from this call to the sweep (the bases' ranks came back with the build's own
   // synchronisation; nothing here waits).  A grid change before the next sweep simply drops the plan.
-  if (c->eager_tables && !c->is_shadow && bilinear_applicable(c) && (rc = bilinear_setup(c))) return rc;
+  if (!c->is_shadow && bilinear_applicable(c) && (rc = bilinear_setup(c))) return rc;
   if (dtype == SBO_F32 && c->fp64_recheck && !c->is_shadow) {
     // the fp64 twin: same constants, double arrays and factor images (built from the same inputs)
     if ((rc = shadow_ensure(c))) return rc;

@@ -21,7 +21,6 @@
 #include <vector>
 #include <type_traits>
 #include <hip/hip_ext.h>
-#include "bilinear_host.hpp"
 #include "device_common.hpp"
 
 namespace sbo {
@@ -198,8 +197,9 @@ __global__ __launch_bounds__(256) void k_bstage1(const double* __restrict__ A, s
 // A model change costs: the 2 q axis bases (k_bl_basis, one workgroup each), then a dozen launches batched over the outputs
 // (blockIdx.y / .z = output) that turn the bases into the operand tables of the two GEMMs.  The host only reads the bases'
 // ranks back (to size the GEMMs) -- no host numerics, no staging upload.
-constexpr int kBlMaxR = bl::kMaxRank;    // 64
-constexpr int kBlMaxRc = bl::kMaxCheb;   // 128
+constexpr int kBlMaxR = 64;             // largest rank of an axis basis
+constexpr int kBlMaxRc = 128;           // largest Chebyshev degree of an axis family
+static inline int pair_count(int r) { return r * (r + 1) / 2; }
 
 struct BlDims {                          // plan dimensions, by value
   int q, n, KBn;
@@ -212,7 +212,7 @@ struct BlDims {                          // plan dimensions, by value
   double sf2[kMaxQ];
 };
 
-// pair index k -> (p <= p'), pairs enumerated row by row (bl::pair_map): row p starts at p (2 r - p + 1) / 2
+// pair index k -> (p <= p'), pairs enumerated row by row : row p starts at p (2 r - p + 1) / 2
 __device__ __forceinline__ void pair_of(int k, int r, int& p, int& pp) {
   const double t = 2.0 * r + 1.0;
   int g = (int)((t - sqrt(t * t - 8.0 * k)) * 0.5);
@@ -846,45 +846,6 @@ __global__ __launch_bounds__(256) void k_bl_t4f(const BlDims dm, const double* _
     T4f[i] = v;
   }
 }
-// pair products of an axis table S [r][count]: P[(p <= p')][x] = w S_p S_p' (w = 1 diagonal, 2 off it); blockIdx.y = o
-//   FRAG 1: axis 0, as B fragments [ncs0][KB0 * 4][64] (columns = positions);  FRAG 0: axis 1, transposed as A images
-//   [nrb][KB1][256] (rows = lines)
-template <int FRAG>
-__global__ __launch_bounds__(256) void k_bl_pairs(const BlDims dm, const double* __restrict__ Sall, size_t sout, double* __restrict__ outall) {
-  const int o = blockIdx.y;
-  const int r = FRAG ? dm.r0[o] : dm.r1[o], KB = FRAG ? dm.KB0 : dm.KB1, nblk = FRAG ? dm.ncs0 : dm.nrb;
-  const long long count = FRAG ? dm.cnt0 : dm.nlines;
-  const int K = r * (r + 1) / 2;
-  const double* Stab = Sall + (size_t)o * (FRAG ? dm.r0u : dm.r1u) * count;
-  double* out = outall + (size_t)o * sout;
-  const long long total = (long long)nblk * KB * 256;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    int k;
-    long long x;
-    if (FRAG) {
-      const int l = (int)(i & 63);
-      const long long fr = i >> 6;
-      const int ks = (int)(fr % (KB * 4));
-      k = (ks >> 2) * 16 + MM<double>::jslot(ks & 3, l >> 4);
-      x = (fr / (KB * 4)) * 16 + (l & 15);
-    } else {
-      // invert pack_pos(r, slot, kk) = kk * 64 + (slot * 4 + (r & 3)) * 4 + (r >> 2)
-      const int e = (int)(i & 255);
-      const long long blk = i >> 8;
-      const int kk = e >> 6, rem = e & 63, slot = rem >> 4, rr = ((rem >> 2) & 3) + 4 * (rem & 3);
-      k = (int)(blk % KB) * 16 + MM<double>::jslot(kk, slot);
-      x = (blk / KB) * 16 + rr;
-    }
-    double v = 0.0;
-    if (k < K && x < count) {
-      int p, pp;
-      pair_of(k, r, p, pp);
-      v = (p == pp ? 1.0 : 2.0) * Stab[(size_t)p * count + x] * Stab[(size_t)pp * count + x];
-    }
-    out[i] = v;
-  }
-}
-
 // ---- mean-phase operands -------------------------------------------------------------------------------------------------
 // Mb[o][b][p r1 + s] = sf2 sum_j beta_b[j] U0_jp U1_js, beta = (alpha, alpha Xn_0, alpha Xn_1): the bilinear forms of the
 // mean and of its two gradient sums.  One wave per (b, p, s), lanes over the observations; blockIdx.y = o
@@ -1289,10 +1250,9 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
                                                   double* __restrict__ var_out, double* __restrict__ Lpart,
                                                   const double* __restrict__ xn0, uint8_t* __restrict__ Sfuse, uint8_t* __restrict__ Ufuse,
                                                   double bconf, unsigned long long* __restrict__ cpart /* [waves of output 1][kFuseRow] */,
-                                                  int o_base /* first output of this launch (split sweeps: constraints, then the objective) */,
                                                   const int* __restrict__ eff /* nullptr, or the Chebyshev core's k-steps of the variance phase at [4 o] */) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
-  const int o = blockIdx.z + o_base;
+  const int o = blockIdx.z;
   PostCtx cx;
   cx.lds = lds;
   cx.tid = threadIdx.x; cx.lane = cx.tid & 63; cx.wave = cx.tid >> 6;
@@ -1348,154 +1308,6 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   // a row per wave made that merge (one workgroup, 16384 rows of 88 bytes on config H) the longest job of the launch it shares
   post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, fuse, cx.cS, cx.cU, cx.rmax, Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
                    cpart + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kFuseRow);
-}
-
-// k_bpost_res -- the same four phases with nothing staged per tile (r03).  Switching parts of k_bpost off on config H showed
-// where its 257 us go: 102 are matrix instructions, 58 are the phases' prologues (a global -> LDS staging round and two
-// barriers in front of each of the four short loops of every tile) and 65-75 the epilogues.  Here a workgroup of EIGHT waves owns
-// an (output, block of 128 axis-0 positions) pair for the whole launch and keeps that pair's B fragments -- the variance
-// phase's P0 (up to `cap0` k-steps) and the S0 rows all three short phases multiply by -- resident in LDS (72 KB at the
-// BASELINE sizes); a wave takes row blocks of 16 lines, 8 strips wide, and streams only its A images, straight from memory
-// into registers one k-block (2 KB) ahead -- across phase and row-block boundaries, so no loop ever starts cold.  No barrier
-// after the preload.  Sums, epilogue arithmetic and therefore every output bit are those of k_bpost.
-// grid (workgroups per pair, column blocks, outputs); Lpart / cpart rows: (o ncb + cb) wgs + wg.
-__global__ __launch_bounds__(512, 1) void k_bpost_res(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
-                                                      const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA, size_t sVA,
-                                                      const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm, int KSm, int KBm2,
-                                                      int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
-                                                      double* __restrict__ var_out, double* __restrict__ Lpart, const double* __restrict__ xn0,
-                                                      uint8_t* __restrict__ Sfuse, uint8_t* __restrict__ Ufuse, double bconf,
-                                                      unsigned long long* __restrict__ cpart, const int* __restrict__ eff, int cap0) {
-  extern __shared__ double lds[];               // [cap0][8][64] variance-phase fragments | [KSm][8][64] S0 fragments
-  const int o = blockIdx.z, cb = blockIdx.y, wg = blockIdx.x, wgs = gridDim.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int KS0e = eff ? eff[4 * o] : KS0;
-  const int cap = cap0 < KS0e ? cap0 : KS0e;
-  double* const B0 = lds;
-  double* const Bm = lds + (size_t)cap0 * 512;
-  const double* P0o = P0f + (size_t)o * sP0f;
-  const double* SBo = SBf + (size_t)o * sSBf;
-  const double* VAo = VA + (size_t)o * sVA;
-  const int cs0 = cb * 8;
-  // preload (strips behind the grid: the last one again -- the epilogue skips them)
-  for (int e = tid; e < (cap + KSm) * 512; e += 512) {
-    const int l = e & 63, s2 = (e >> 6) & 7, ks = e >> 9;
-    const int csx = cs0 + s2 < ncs ? cs0 + s2 : ncs - 1;
-    if (ks < cap) B0[e] = P0o[((size_t)csx * KB0 * 4 + ks) * 64 + l];
-    else Bm[(size_t)(ks - cap) * 512 + (s2 << 6) + l] = SBo[((size_t)csx * KBm * 4 + (ks - cap)) * 64 + l];
-  }
-  __syncthreads();
-  PostCtx cx;
-  cx.lds = lds;
-  cx.tid = tid; cx.lane = lane; cx.wave = 0;
-  cx.cs0 = cs0; cx.nrb = nrb; cx.ncs = ncs;
-  cx.ucnt0 = (unsigned int)cs.count[0];
-  cx.nlines = nlines;
-  const double sf2 = mc.sf2[o], ystd = mc.Y_std[o];
-  double* const vo = var_out + (size_t)o * cs.n_local;
-  double* const mo = mean_out + (size_t)o * cs.n_local;
-  const bool fuse = Sfuse != nullptr && o == 1;
-  cx.var_rd = vo;
-  cx.S = fuse ? Sfuse : nullptr;
-  cx.U = Ufuse;
-  cx.bconf = bconf;
-  cx.bb = bconf * bconf;
-  cx.cS = cx.cU = 0;
-  cx.rmax = -1.0;
-  double gmax = 0.0;
-  // the A operands of the four phases: images [nrb][KB][256] per set
-  const double* const A0 = BtA + (size_t)o * sBtA;
-  const double* const A2 = VAo + (size_t)nrb * KBm * 256;
-  const double* const A3 = VAo + (size_t)nrb * (KBm + KBm2) * 256;
-  const int a_off = (((lane >> 4) << 2) + (lane & 3)) * 4;          // this lane's 32 bytes of a k-step (MM<double>::load_a)
-  auto load_blk = [&](int ph, int rb, int kb, d4_t (&a)[4]) {        // (ph is a constant at every call site)
-    const double* base = ph == 0 ? A0 : (ph == 1 ? VAo : (ph == 2 ? A2 : A3));
-    const int akb = ph == 0 ? KB0 : (ph == 2 ? KBm2 : KBm);
-    const double* img = base + ((size_t)rb * akb + kb) * 256 + a_off;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) a[kk] = *reinterpret_cast<const d4_t*>(img + kk * 64);
-  };
-  const int stride = wgs * 8;
-  int rb = wg * 8 + wave;
-  d4_t ac[4];                                   // A fragments of the k-block being multiplied; refilled in place for the next one
-  if (rb < nrb) load_blk(0, rb, 0, ac);
-  d4_t acc[1][8];
-  for (; rb < nrb; rb += stride) {
-    cx.rb0 = rb;
-    cx.full = (long long)(rb + 1) * 16 <= nlines && (long long)(cs0 + 8) * 16 <= cs.count[0];
-    auto phase = [&](auto phc) {
-      constexpr int ph = decltype(phc)::value;
-      const int KS = ph == 0 ? KS0e : KSm, nkb = (KS + 3) >> 2;
-      if (ph == 2) {
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-          const unsigned int x = (unsigned int)(cs0 + s2) * 16u + (lane & 15);
-          const double f = x < cx.ucnt0 ? -xn0[x] : 0.0;
-          acc[0][s2] = d4_t{acc[0][s2][0] * f, acc[0][s2][1] * f, acc[0][s2][2] * f, acc[0][s2][3] * f};
-        }
-      } else {
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) acc[0][s2] = d4_t{0.0, 0.0, 0.0, 0.0};
-      }
-      const double* const Bres = ph == 0 ? B0 : Bm;
-      auto load_b = [&](int ks, double (&b)[8]) {
-        if (ph != 0 || ks < cap) {
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) b[s2] = Bres[(size_t)ks * 512 + (s2 << 6) + lane];
-        } else {                                // variance-phase k-steps beyond the resident ones (long expansions): from memory
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) {
-            const int csx = cs0 + s2 < ncs ? cs0 + s2 : ncs - 1;
-            b[s2] = P0o[((size_t)csx * KB0 * 4 + ks) * 64 + lane];
-          }
-        }
-      };
-      double b0[8], b1[8];                      // the fragments of the k-step being multiplied / of the next one, alternating
-      load_b(0, b0);
-#pragma unroll 1
-      for (int kb = 0; kb < nkb; ++kb) {
-        // the k-block after this one in the sequence: this phase's next, the next phase's first, or the next row block's first;
-        // its fragment kk is requested into ac[kk] as soon as this block's k-step kk has been issued (three k-steps ahead)
-        const bool last = kb + 1 == nkb;
-        const double* nimg = last ? (ph == 0 ? VAo + (size_t)rb * KBm * 256
-                                     : ph == 1 ? A2 + (size_t)rb * KBm2 * 256
-                                     : ph == 2 ? A3 + (size_t)rb * KBm * 256
-                                               : A0 + (size_t)(rb + stride < nrb ? rb + stride : rb) * KB0 * 256)
-                                  : (ph == 0 ? A0 + ((size_t)rb * KB0 + kb + 1) * 256
-                                     : ph == 1 ? VAo + ((size_t)rb * KBm + kb + 1) * 256
-                                     : ph == 2 ? A2 + ((size_t)rb * KBm2 + kb + 1) * 256
-                                               : A3 + ((size_t)rb * KBm + kb + 1) * 256);
-        nimg += a_off;
-        const int ks0 = kb * 4;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          if (ks0 + kk < KS) {                  // (uniform)
-            if (ks0 + kk + 1 < KS) load_b(ks0 + kk + 1, (kk & 1) ? b0 : b1);
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) acc[0][s2] = MM<double>::mfma(ac[kk], (kk & 1) ? b1[s2] : b0[s2], acc[0][s2]);
-          }
-          ac[kk] = *reinterpret_cast<const d4_t*>(nimg + kk * 64);
-        }
-      }
-      if constexpr (ph == 0) post_epilogue<0, 1>(cx, vo, sf2, ystd * ystd, 0.0, gmax, acc);
-      else if constexpr (ph == 1) post_epilogue<1, 1>(cx, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc);
-      else if constexpr (ph == 2) post_epilogue<2, 1>(cx, nullptr, ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax, acc);
-      else post_epilogue<3, 1>(cx, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0, gmax, acc);
-    };
-    phase(std::integral_constant<int, 0>{});
-    phase(std::integral_constant<int, 1>{});
-    phase(std::integral_constant<int, 2>{});
-    phase(std::integral_constant<int, 3>{});
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double other = __shfl_xor(gmax, off);
-    gmax = other > gmax ? other : gmax;
-  }
-  __shared__ double psh[8 * 4];
-  post_partials<8>(psh, lane, wave, gmax, fuse, cx.cS, cx.cU, cx.rmax, Lpart + ((size_t)o * gridDim.y + cb) * wgs + wg,
-                   cpart + ((size_t)cb * wgs + wg) * kFuseRow);
 }
 
 // Lipschitz keys of a K1b launch: Lmax[o] = max of the per-wave partials (values >= 0, so the bit pattern orders them)
@@ -1811,37 +1623,7 @@ int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big) {
   int rc;
   if ((rc = ensure(c->bl_basis, sizeof(double) * L.total))) return rc;
   double* base = (double*)c->bl_basis.p;
-  if (c->bl_host_bases) {
-    // A/B path: the bases of bilinear_host.hpp (Chebyshev + Householder QR + one-sided Jacobi SVD on host threads),
-    // uploaded in the layout the device kernel writes
-    std::vector<double> xs0((size_t)c->cs.count[0]), xs1((size_t)c->cs.count[1]);
-    for (long long i = 0; i < c->cs.count[0]; ++i) xs0[(size_t)i] = axis_position(c, 0, i);
-    for (long long i = 0; i < c->cs.count[1]; ++i) xs1[(size_t)i] = axis_position(c, 1, i);
-    std::vector<bl::AxisBasis> bs(2 * q);
-    std::vector<char> ok(2 * q, 0);
-    bl::parallel_ranges(2 * q, [&](int lo_, int hi_) {
-      std::vector<double> col(n);
-      for (int t = lo_; t < hi_; ++t) {
-        const int o = t / 2, a = t % 2;
-        for (int j = 0; j < n; ++j) col[j] = c->h_Xnorm[(size_t)j * mc.d + a] * mc.vinv[o][a];     // GP_Safe.py:115
-        const std::vector<double>& xs = a == 0 ? xs0 : xs1;
-        ok[t] = bl::axis_basis(n, col.data(), mc.vinv[o][a], xs.data(), (int)xs.size(), bs[t], /*tabulate=*/false) ? 1 : 0;
-      }
-    });
-    std::vector<double> up(L.work, 0.0);
-    int* inf = (int*)(up.data() + L.info);
-    for (int t = 0; t < 2 * q; ++t) {
-      inf[4 * t] = ok[t];
-      if (!ok[t]) continue;
-      inf[4 * t + 1] = bs[t].r;
-      inf[4 * t + 2] = bs[t].rc;
-      memcpy(up.data() + L.U + (size_t)t * kBlMaxR * n, bs[t].U.data(), sizeof(double) * bs[t].U.size());
-      memcpy(up.data() + L.Vs + (size_t)t * kBlMaxR * kBlMaxRc, bs[t].Vs.data(), sizeof(double) * bs[t].Vs.size());
-      memcpy(up.data() + L.sig + (size_t)t * kBlMaxR, bs[t].sig.data(), sizeof(double) * bs[t].sig.size());
-    }
-    SBO_HIP(hipMemcpyAsync(base, up.data(), sizeof(double) * L.work, hipMemcpyHostToDevice, st));
-    SBO_HIP(hipStreamSynchronize(st));                 // (`up` goes out of scope)
-  } else {
+  {
     BlJobs jb;
     memset(&jb, 0, sizeof(jb));
     jb.n = n;
@@ -1869,11 +1651,11 @@ int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big) {
       if (small) {
         SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL((k_bl_basis<256, true>), dim3((unsigned)(2 * q)), dim3(256), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
-                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, c->basis_reg ? 0 : 1);
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, 0);
       } else {
         SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL((k_bl_basis<1024, false>), dim3((unsigned)(2 * q)), dim3(1024), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
-                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, c->basis_reg ? 0 : 1);
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, 0);
       }
     }
     SBO_HIP(hipGetLastError());
@@ -1943,22 +1725,21 @@ int bilinear_setup(sbo_ctx* c) {
     if (dm.r0[o] < 1 || dm.r0[o] > kBlMaxR || dm.r1[o] < 1 || dm.r1[o] > kBlMaxR) return SBO_OK;
     r0u = std::max(r0u, dm.r0[o]);
     r1u = std::max(r1u, dm.r1[o]);
-    K0 = std::max(K0, bl::pair_count(dm.r0[o]));
-    K1 = std::max(K1, bl::pair_count(dm.r1[o]));
+    K0 = std::max(K0, pair_count(dm.r0[o]));
+    K1 = std::max(K1, pair_count(dm.r1[o]));
     Rmax = std::max(Rmax, dm.r0[o] * dm.r1[o]);
     rc0m = std::max(rc0m, dm.rc0[o]);
     rc1m = std::max(rc1m, dm.rc1[o]);
     dm.sf2[o] = mc.sf2[o];
     pl.r0[o] = dm.r0[o];
     pl.r1[o] = dm.r1[o];
-    if (timing) fprintf(stderr, "[K1b setup] output %d: r0 %d (degree %d), r1 %d (degree %d)%s\n", o, dm.r0[o], dm.rc0[o], dm.r1[o], dm.rc1[o],
-                        c->bl_host_bases ? "  [host bases]" : "");
+    if (timing) fprintf(stderr, "[K1b setup] output %d: r0 %d (degree %d), r1 %d (degree %d)\n", o, dm.r0[o], dm.rc0[o], dm.r1[o], dm.rc1[o]);
   }
-  // inner dimensions of the two GEMMs of the variance phase: pair products (K = r (r + 1) / 2), or -- Chebyshev core, r03 -- the
-  // degrees of quad as a polynomial of the axis (D = 2 rc - 1, cut on the device where its coefficients have decayed)
-  const bool cheb = c->cheb_core != 0;
+  // inner dimensions of the two GEMMs of the variance phase: the degrees of quad as a polynomial of the axis (D = 2 rc - 1, cut
+  // on the device where its coefficients have decayed); K0m / K1m: the pair counts r (r + 1) / 2 the core is contracted from
   const int K0m = K0, K1m = K1;
-  if (cheb) { K0 = 2 * rc0m - 1; K1 = 2 * rc1m - 1; }
+  K0 = 2 * rc0m - 1;
+  K1 = 2 * rc1m - 1;
   const int KB0 = (K0 + 15) / 16, KB1 = (K1 + 15) / 16;
   const int ncs0 = (int)((cnt0 + 15) / 16), nrb = (int)((nlines + 15) / 16);
   {
@@ -1969,9 +1750,8 @@ int bilinear_setup(sbo_ctx* c) {
   }
   const long long nlines_pad = (long long)nrb * 16;
   pl.KB0 = KB0; pl.KB1 = KB1; pl.r0u = r0u; pl.ncs0 = ncs0; pl.nrb = nrb; pl.nlines_pad = nlines_pad;
-  pl.cheb = cheb;
-  pl.sP0f = cheb ? 0 : (size_t)ncs0 * KB0 * 4 * 64;        // (Chebyshev core: one table of polynomials for every output)
-  pl.sP1A = cheb ? 0 : (size_t)nrb * KB1 * 256;
+  pl.sP0f = 0;                                              // (one table of Chebyshev polynomials for every output)
+  pl.sP1A = 0;
   const size_t nP0f = (size_t)ncs0 * KB0 * 4 * 64, nP1A = (size_t)nrb * KB1 * 256;
   pl.sT4f = (size_t)KB0 * KB1 * 4 * 64;
   pl.sBtA = (size_t)nrb * KB0 * 256;
@@ -1981,11 +1761,11 @@ int bilinear_setup(sbo_ctx* c) {
   pl.KBm = KBm;
   pl.KBm2 = KBm2;
   pl.KSm = r0p / 4;
-  pl.KS0 = cheb ? KB0 * 4 : (K0 + 3) / 4;
+  pl.KS0 = KB0 * 4;
   pl.sVA = (size_t)nrb * (2 * KBm + KBm2) * 256;     // image sets  V0 | [V1; V0] | V1x
   pl.sSBf = (size_t)ncs0 * (KBm + KBm2) * 256;      // fragment sets  S0 | [S0; -xn0 S0]
-  if ((rc = ensure(c->bl_P0f, sizeof(double) * nP0f * (cheb ? 1 : q)))) return rc;
-  if ((rc = ensure(c->bl_P1A, sizeof(double) * nP1A * (cheb ? 1 : q)))) return rc;
+  if ((rc = ensure(c->bl_P0f, sizeof(double) * nP0f))) return rc;
+  if ((rc = ensure(c->bl_P1A, sizeof(double) * nP1A))) return rc;
   // Chebyshev core scratch: PC0 | PC1 | T4 plain | Y^T | Chat | eff (ints)
   const size_t D0m = (size_t)KB0 * 16, D1m = (size_t)KB1 * 16;
   // (PC0 as B fragments [D0m / 16][KBp0 * 4][64], PC1^T as A images [D1m / 16][KBp1][256], T4^T as B fragments [KBp0][KBp1 * 4][64],
@@ -1993,7 +1773,7 @@ int bilinear_setup(sbo_ctx* c) {
   const int KBp0 = (K0m + 15) / 16, KBp1 = (K1m + 15) / 16;
   const size_t nPC0 = D0m * (size_t)KBp0 * 16, nPC1 = D1m * (size_t)KBp1 * 16, nT4p = (size_t)KBp0 * KBp1 * 256, nYt = D1m * (size_t)KBp0 * 16,
                nCh = D0m * D1m;
-  if (cheb && (rc = ensure(c->bl_cheb, sizeof(double) * (size_t)q * (nPC0 + nPC1 + nT4p + nYt + nCh) + 256))) return rc;
+  if ((rc = ensure(c->bl_cheb, sizeof(double) * (size_t)q * (nPC0 + nPC1 + nT4p + nYt + nCh) + 256))) return rc;
   if ((rc = ensure(c->bl_T4f, sizeof(double) * pl.sT4f * q))) return rc;
   if ((rc = ensure(c->bl_SBf, sizeof(double) * pl.sSBf * q))) return rc;     // mean-phase B fragments
   if ((rc = ensure(c->bl_VA, sizeof(double) * pl.sVA * q))) return rc;      // mean-phase A images
@@ -2025,7 +1805,7 @@ int bilinear_setup(sbo_ctx* c) {
   // Two independent chains (r03): X = the form T4 of the variance phase (Z fragments -> two GEMMs -> gather: the long one,
   // ~0.11 ms on config H), Y = everything made from the axis tables (normalised axes, S0 / S1, their pair tables, the mean
   // phases' operands: eight small launches, ~0.09 ms).  Y runs on the second stream beside X and joins before stage 1.
-  hipStream_t xs = c->stream, ys = (c->table_streams && c->stream2 && !c->is_shadow) ? c->stream2 : c->stream;
+  hipStream_t xs = c->stream, ys = (c->stream2 && !c->is_shadow) ? c->stream2 : c->stream;
   if (ys != xs) {
     SBO_HIP(hipEventRecord(c->ev[7], xs));                 // (alpha, Xn and the bases are in place at this point of the main stream)
     SBO_HIP(hipStreamWaitEvent(ys, c->ev[7], 0));
@@ -2034,13 +1814,8 @@ int bilinear_setup(sbo_ctx* c) {
                      cnt0, line0, nlines, dxn0, dxn1);
   hipLaunchKernelGGL(k_bl_stab, blocks((size_t)std::max(r0u * cnt0, r1u * nlines), 2 * uq), dim3(256), 0, ys, dm, dVs, dsig,
                      (const double*)dxn0, (const double*)dxn1, dS0, dS1);
-  if (cheb) {
-    hipLaunchKernelGGL((k_cheb_tab<1>), dim3((unsigned)((ncs0 * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn0, (double*)c->bl_P0f.p);
-    hipLaunchKernelGGL((k_cheb_tab<0>), dim3((unsigned)((nrb * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn1, (double*)c->bl_P1A.p);
-  } else {
-    hipLaunchKernelGGL((k_bl_pairs<1>), blocks(nP0f, uq), dim3(256), 0, ys, dm, (const double*)dS0, pl.sP0f, (double*)c->bl_P0f.p);
-    hipLaunchKernelGGL((k_bl_pairs<0>), blocks(nP1A, uq), dim3(256), 0, ys, dm, (const double*)dS1, pl.sP1A, (double*)c->bl_P1A.p);
-  }
+  hipLaunchKernelGGL((k_cheb_tab<1>), dim3((unsigned)((ncs0 * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn0, (double*)c->bl_P0f.p);
+  hipLaunchKernelGGL((k_cheb_tab<0>), dim3((unsigned)((nrb * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn1, (double*)c->bl_P1A.p);
   // mean phases: Mb (forms of alpha, alpha Xn_0, alpha Xn_1) -> Vb = Mb S1 -> A images [V0 | V1;V0 | V1x], B fragments
   // [S0 | S0;-xn0 S0]
   hipLaunchKernelGGL(k_bl_mb, blocks((size_t)3 * r0u * r1u * 64, uq), dim3(256), 0, ys, dm, dU, (const double*)c->alpha64.p,
@@ -2071,7 +1846,7 @@ int bilinear_setup(sbo_ctx* c) {
     hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
                        (const double*)CtA, nZf, (const double*)Cf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
   }
-  if (cheb) {
+  {
     double* PC0 = (double*)c->bl_cheb.p;
     double* PC1 = PC0 + (size_t)q * nPC0;
     double* T4p = PC1 + (size_t)q * nPC1;
@@ -2097,10 +1872,6 @@ int bilinear_setup(sbo_ctx* c) {
     // (the counts also travel to the host, unwaited: the profile's flop count reads them after the next sweep's own sync)
     SBO_HIP(hipMemcpyAsync(c->h_back + 5376, eff, sizeof(int) * 4 * q, hipMemcpyDeviceToHost, xs));
     pl.eff = eff;
-  } else {
-    pl.eff = nullptr;
-    hipLaunchKernelGGL(k_bl_t4f, blocks(pl.sT4f, uq), dim3(256), 0, c->stream, dm, (const double*)G, (long long)ldg, pl.sT4f,
-                       (double*)c->bl_T4f.p, direct ? 1 : 0);
   }
   if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
   SBO_HIP(hipGetLastError());
@@ -2122,40 +1893,21 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   hipLaunchKernelGGL((k_bstage1<S1>), dim3((unsigned)((pl.KB0 + S1 - 1) / S1), (unsigned)((pl.nrb + 3) / 4), (unsigned)q), dim3(256), 0,
                      c->stream, (const double*)c->bl_P1A.p, pl.sP1A, (const double*)c->bl_T4f.p, pl.sT4f, pl.KB1, pl.nrb, pl.KB0,
                      (double*)c->bl_BtA.p, pl.sBtA, (const int*)pl.eff);
-  // stage 2 (fused): variance, mean, Lipschitz keys
-  // (64 x 128 tiles when the 128 x 128 ones would not give every CU a workgroup)
+  // stage 2 (fused): variance, mean, Lipschitz keys.  64 x 128 tiles (k_bpost<1>, three workgroups per CU): with the Chebyshev
+  // core the variance phase is ~12 k-steps and no longer dominates, and the third workgroup per CU is worth more than the
+  // B-fragment reuse of a 128 x 128 tile (r03: config B 0.204 -> 0.189 ms per sweep, H 0.547 -> 0.543)
   const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8);
-  // (the 64 x 128 form on every grid -- three workgroups per CU with its smaller LDS block -- measured 8 % slower on config B
-  // and 3 % on H: the 128 x 128 tile's reuse of a B fragment is worth more than the third wave per SIMD)
-  // Split sweeps (sbo_ctx::split_request): the constraints' outputs in a first launch, the objective's in a second -- the
-  // constraint-only part of the set phase then runs beside the second one.  Each launch should still give every CU two
-  // workgroups, so the 64 x 128 tiles are taken already when the 128 x 128 ones of the smaller launch number fewer than that.
-  const bool split = c->split_request && q >= 2;
-  const long long wgs_rb2 = (long long)gx * ((pl.nrb + 7) / 8);    // workgroups per output with 128 x 128 tiles
-  // (r03, Chebyshev core: the variance phase is 12 k-steps instead of 69 and no longer dominates; with four short phases the
-  // third workgroup per CU of the 64 x 128 form is worth more than the B-fragment reuse of the 128 x 128 one -- config B 0.204 ->
-  // 0.189 ms per sweep with the classification fused, H 0.547 -> 0.543)
-  int rbw = (pl.cheb || wgs_rb2 * q < c->n_cu) ? 1 : 2;
-  if (c->post_rb) rbw = c->post_rb;                       // (tuning option)
-  if (split) rbw = c->split_rb ? c->split_rb : (wgs_rb2 < 2ll * c->n_cu ? 1 : 2);
-  // resident form (k_bpost_res, post_rb = 3): a workgroup of eight waves per (output, 128 positions of axis 0) pair and share of
-  // the row blocks; needs a launch that is not split and enough row blocks to give every wave work
-  const unsigned ncb = gx;
-  const int cap0 = std::max(1, std::min(pl.KS0, 36 - pl.KSm));
-  const long long pairs = (long long)ncb * q;
-  const unsigned wgs_res = (unsigned)std::max<long long>(1, std::min<long long>(std::max<long long>(1, c->n_cu / pairs), (pl.nrb + 7) / 8));
-  const bool res = rbw == 3 && !split && pl.KSm <= 24;
-  if (rbw == 3 && !res) rbw = 1;
-  const size_t lds = res ? sizeof(double) * 512 * (size_t)(cap0 + pl.KSm) : sizeof(double) * 2 * (rbw == 2 ? 4096 : 3072);
-  const unsigned gy = res ? ncb : (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
-  const unsigned rows_out = res ? wgs_res * ncb : gx * (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));   // partial rows per output: one per workgroup
+  constexpr int rbw = 1;
+  const size_t lds = sizeof(double) * 2 * 3072;
+  const unsigned gy = (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
+  const unsigned rows_out = gx * gy;                      // partial rows per output: one per workgroup
   int rc;
   if ((rc = ensure(c->bl_lpart, sizeof(double) * (size_t)rows_out * q))) return rc;
   // a sweep may ask for the S / U bytes, |S|, |U| and the radius key straight from the mean epilogue of the constraint
   // (one-constraint models; the masks are allocated by the sweep before it enqueues the posterior)
   // (r03: with the sqrt-free sign tests the fused epilogue saves the separate pass 76 us on config H and costs the GEMM 36;
   // on config B, two workgroups per CU, the two cancel -- "auto" asks for at least four workgroups per CU)
-  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (res || (long long)gx * gy * q >= 4ll * c->n_cu));
+  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
   const bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
                     c->maskU.bytes >= (size_t)cs.n_local;
   c->fuse_rows = 0;
@@ -2164,36 +1916,16 @@ int launch_posterior_bilinear(sbo_ctx* c) {
     // (room behind the rows for the partials of the objective pass, see sweep_common_front)
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
   }
-  auto kpost = rbw == 2 ? k_bpost<2> : k_bpost<1>;
-  if (!res) SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kpost = k_bpost<rbw>;
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // the K1 stop event rides on the last launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
   // the next kernel waits ~6 us for.  A sweep merges the Lipschitz partials in its own first small kernel (lmax_defer).
-  if (res) SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost_res), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  auto post = [&](int o_base, int nz, hipEvent_t stop) {
-    if (res) {
-      hipExtLaunchKernelGGL(k_bpost_res, dim3(wgs_res, ncb, (unsigned)nz), dim3(512), lds, c->stream, nullptr, stop, 0,
-                            mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
-                            pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
-                            (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
-                            fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                            (unsigned long long*)c->cpart.p, (const int*)pl.eff, cap0);
-      return;
-    }
-    hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)nz), dim3(256), lds, c->stream, nullptr, stop, 0,
-                          mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
-                          pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
-                          (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
-                          fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                          (unsigned long long*)c->cpart.p, o_base, (const int*)pl.eff);
-  };
-  c->split_done = false;
-  if (split && c->lmax_defer) {
-    post(1, q - 1, c->ev_join[6]);
-    post(0, 1, c->ev[1]);
-    c->split_done = true;
-  } else {
-    post(0, q, c->lmax_defer ? c->ev[1] : nullptr);
-  }
+  hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream, nullptr, c->lmax_defer ? c->ev[1] : nullptr, 0,
+                        mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
+                        pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
+                        (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
+                        fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
+                        (unsigned long long*)c->cpart.p, (const int*)pl.eff);
   if (c->lmax_defer) {
     c->lmax_pending = true;
     c->lmax_per_out = (int)rows_out;

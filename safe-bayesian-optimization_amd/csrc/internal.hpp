@@ -53,8 +53,7 @@ struct BilinearPlan {
   size_t sP0f = 0, sP1A = 0, sT4f = 0, sBtA = 0;   // per-output strides (elements)
   int r0[kMaxQ] = {0}, r1[kMaxQ] = {0};
   double setup_ms = 0.0;
-  bool cheb = false;     // variance phase on the Chebyshev core (degrees as inner dimensions) instead of the pair products
-  int* eff = nullptr;    // device: per-output counts the kernels run to (k_cheb_trunc), nullptr for the pair form
+  int* eff = nullptr;    // device: per-output counts the kernels run to (k_cheb_trunc)
 };
 
 }  // namespace sbo
@@ -64,7 +63,7 @@ struct sbo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // side stream: the K1b axis bases of a new model run next to its factorisation
   hipStream_t stream4 = nullptr;   // the deferred factorisation of a caller's invK (chol_async): off the critical path of a model change
-  hipStream_t stream3 = nullptr;   // chain stream of an overlapped sweep (k1_split): the constraints' set phase next to the objective's K1b
+  hipStream_t stream3 = nullptr;   // spare high-priority stream (drained with the others)
   int n_cu = 256;
   // model
   bool has_model = false;
@@ -96,14 +95,8 @@ struct sbo_ctx {
   bool factor_pending = false;     // the factor chain of the current model is (possibly) still running; ev_factor marks its end
   hipEvent_t ev_factor = nullptr, ev_w = nullptr;
   int chol_async = 1;
-  int classify_wgs = 0;    // tuning: workgroups of k_classify (0: from the candidate count)
-  int decide_wide = 1;     // expander verdicts with eight candidates per lane (k_edt_decide8); 0: one candidate per lane
-  int post_rb = 0;         // tuning: tile height of k_bpost (0 auto: 128 x 128 unless the grid is small; 1: 64 x 128; 2: 128 x 128)
   int exact_lazy = 1;      // one-constraint SafeOpt sweeps on one rank: k_expander_exact only when the result block reports in-band candidates
-  int cheb_core = 1;       // K1b variance phase: Chebyshev core (inner dimensions = polynomial degrees, cut where the coefficients have decayed); 0: pair products (round 2)
   double cheb_tol = 4e-15; // ... relative size below which trailing coefficients are not run (option cheb_tol_e17, in units of 1e-17)
-  int table_streams = 1;   // K1b plan build: the axis-table chain on the second stream beside the T4 GEMMs (0: one stream)
-  int basis_reg = 1;       // K1b axis bases: residual rows of the pivot loop in registers (n <= 512, degree <= 64); 0: through LDS / memory (round 2)
   sbo::BilinearPlan bl;
   sbo::DevBuf bl_P0f, bl_P1A, bl_T4f, bl_BtA, bl_SBf, bl_VA, bl_small, bl_work, bl_cheb;
   // K1t (tensor.hip): fp64 grids of three / four axes by Chebyshev interpolation from exact node values
@@ -128,7 +121,6 @@ struct sbo_ctx {
   unsigned long long bl_basis_serial = 0;
   double bl_basis_ab[4] = {0, 0, 0, 0};
   unsigned long long model_serial = 0;   // bumped by every sbo_model_set / sbo_model_append
-  int bl_host_bases = 0;           // option: 1 = bases by the host SVD of bilinear_host.hpp (A/B against the device kernel)
   // candidates
   bool has_cand = false;
   sbo::CandSpec cs{};
@@ -164,7 +156,6 @@ struct sbo_ctx {
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
   sbo::DevBuf bl_lpart; // K1b: per-wave Lipschitz partials of k_bpost
   sbo::DevBuf cpart;   // per-workgroup partials of k_classify
-  sbo::DevBuf upart;   // overlapped sweeps: per-workgroup u* keys of k_obj_front
   long long comm_bytes = 0;   // collectives of the running sweep: bytes handed over (send side), calls, and -- option comm_events --
   int comm_calls = 0;         // an event pair per call (comm_ev, created on first use) whose elapsed times sbo_profile.comm_ms sums
   int comm_events = 0;
@@ -182,14 +173,6 @@ struct sbo_ctx {
   bool lmax_defer = false;
   bool lmax_pending = false;
   int lmax_per_out = 0;
-  // Overlapped sweep (option k1_split, K1b on one rank, q >= 2): a sweep sets split_request before it enqueues the posterior;
-  // K1b then runs the constraints' outputs first (stop event ev_join[6]) and the objective's output last (stop event
-  // ev[1]), and sets split_done: the sweep runs the constraint-only part of its set phase -- S / U, distance transforms,
-  // expander / optimistic-set verdicts: everything but u*, the M mask and the arg-reductions over var_0 / lcb_0 -- on
-  // stream3 behind ev_join[6], next to the objective's GEMM, and joins the main stream for the objective-dependent tail.
-  bool split_request = false;
-  bool split_done = false;
-  int split_rb = 0;        // option: tile height of the split launches (0 auto: 64 x 128 tiles when 128 x 128 ones leave fewer than two workgroups per CU; 1 / 2 forced)
   sbo::DevBuf Wfull;   // multi-rank GoOSE: source weights of the whole grid (all-gathered), T [grid_total]
   sbo::DevBuf Uwin;    // multi-rank: U mask of the expander transform's window (own planes + halo), uint8
   long long uwin_first = 0, uwin_n = 0;   // flat range the window covers
@@ -220,22 +203,13 @@ struct sbo_ctx {
   hipEvent_t ev[8]{};
   hipEvent_t ev_join[SBO_MAX_Q]{};   // phase marks of the fp32 recheck
   // options
-  int k1_strips = 4;       // lines per K1g tile (4, or 8 for 2-D grids: tuning)
-  int k1_wgs_per_cu = 0;   // 0 = from the occupancy query; > 0 overrides the persistent grid size (tuning)
   int scan_waves = 1;      // 1: candidates the coarse bounds leave open are scanned one wave each (0: by their own thread)
   int scan_blocks = 1;     // 0: step-by-step last-axis scans (A/B against the blocked form)
-  int eager_tables = 1;    // sbo_model_set enqueues the K1b tables of the resident grid itself (0: the next posterior launch does)
   int result_mirror = 1;   // SafeOpt sweeps on one rank: the last kernel writes the results into the pinned host block itself (0: a copy behind it)
-  int spin_wait = 1;       // the host polls the stream at the end of a sweep / model build instead of sleeping in the runtime's wait (0: hipStreamSynchronize)
-  int goose_tail = 1;      // single-rank GoOSE sweeps: finals + target choice in one launch, the last merge writes the host's result block (0: four launches and a copy)
-  int axis0_waves = 1;     // 2-D grids, lines of whole 64-bit words up to 4096 positions: the fine axis-0 pass runs a wave per line without barriers (0: a workgroup per line)
-  int dist_u16 = 1;        // shared-launch path of 2-D grids: the fine axis-0 image as 16-bit step counts (0: squared distances as doubles)
   int set_fuse = 1;        // 2-D grids: independent set-phase kernels share launches (k_edt_axis0_pair, k_set_mid); 0: one launch each
   int fuse_classify = -1;  // one-constraint sweeps on the K1b path take their S / U bytes from the posterior kernel's mean epilogue: 1 always, 0 never, -1 (default) when the launch has at least four workgroups per CU (r03, sqrt-free sign tests: config H -40 us, config B +-0)
   int goose_pairs = 0;     // 1: GoOSE coverage by pruned pair evaluation on grids too (A/B against the transform)
   int phase_events = 0;    // 1: events between the set phases too (classify / expander / arg-reduce times in sbo_profile)
-  int chol_fused = 1;      // blocked model build: one launch per panel (k_chol_step: look-ahead update, four-wave diagonal block, reciprocal pivots); 0: the two-launch form of round 2
-  int k1_split = 0;        // (A/B option, measured slower: f64 matrix and vector instructions share a datapath the GEMM already keeps ~75 % busy) 1: K1b sweeps of constrained models on one rank run the constraints' set phase beside the objective's GEMM
   int bilinear = 1;        // 1: fp64 2-D grids run the posterior as two GEMMs in a reduced basis when the bases qualify (K1b)
   int posterior_path = 0;  // 0 auto (separable tables on aligned grids), 1 force the generic exp() kernel
   // fp32 models: an fp64 twin of the model (same arrays, double images) that re-evaluates the candidates the fp32 bounds

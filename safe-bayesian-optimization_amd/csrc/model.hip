@@ -241,131 +241,8 @@ __global__ __launch_bounds__(256) void k_chol_prep(int mode, int n, int npad, in
   }
 }
 
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ work, double* __restrict__ F, int with_E, int n, int kb,
-                                                    int* __restrict__ bad, double* __restrict__ Dg) {
-  __shared__ double D[kPB][kPB + 1];
-  const int o = blockIdx.y, tid = threadIdx.x;
-  double* U = work + (size_t)o * n * n;
-  double* E = F + (size_t)o * n * n;
-  const int kw = n - kb < kPB ? n - kb : kPB;
-  for (int idx = tid; idx < kPB * kPB; idx += blockDim.x) {
-    const int r = idx / kPB, cc = idx % kPB;
-    D[r][cc] = (r < kw && cc < kw && cc >= r) ? U[(size_t)(kb + r) * n + kb + cc] : 0.0;
-  }
-  __syncthreads();
-  // U^T U of the diagonal block by ONE wave, a column per lane in registers: no workgroup barrier inside the 32 steps
-  // (the former all-threads loop spent ~30 us per panel in its 96 barriers).  Lane i holds D[k][i], k <= i; row j is
-  // broadcast lane by lane with v_readlane (the loops are fully unrolled, so every lane index is a constant).  Same
-  // operations in the same order per element as the plain loop: bit-identical factors.
-  if (tid < 64) {
-    const int lane = tid;
-    double col[kPB];
-#pragma unroll
-    for (int k = 0; k < kPB; ++k) col[k] = (lane < kPB && k <= lane) ? D[k][lane] : 0.0;
-    bool notpd = false;
-#pragma unroll
-    for (int j = 0; j < kPB; ++j) {
-      if (j < kw) {
-        const double piv = readlane_f64(col[j], j);
-        notpd = notpd || !(piv > 0.0);
-        const double ljj = piv > 0.0 ? sqrt(piv) : 1.0;
-        if (lane > j) col[j] /= ljj;
-        else if (lane == j) col[j] = ljj;
-#pragma unroll
-        for (int k = j + 1; k < kPB; ++k) {
-          const double ujk = readlane_f64(col[j], k);
-          if (lane >= k) col[k] -= ujk * col[j];
-        }
-      }
-    }
-    if (lane < kPB) {
-#pragma unroll
-      for (int k = 0; k < kPB; ++k)
-        if (k <= lane) D[k][lane] = col[k];
-    }
-    if (lane == 0 && notpd) bad[o] = 1;
-  }
-  __syncthreads();
-  // The factored block goes to a side array, not back into U: the other workgroups of this launch may not have read
-  // the unfactored block yet (a late one would factor it twice).  k_chol_finish picks it up from there.
-  if (blockIdx.x == 0) {
-    double* dg = Dg + ((size_t)o * ((n + kPB - 1) / kPB) + kb / kPB) * (kPB * kPB);
-    for (int idx = tid; idx < kPB * kPB; idx += blockDim.x) dg[idx] = D[idx / kPB][idx % kPB];
-  }
-  // columns: [kb + kw, n) of U, then (with E) [0, kb + kw) of E
-  // A column per half wave, a ROW per lane (lane r holds element r of the column and column r of the factored block): the
-  // forward substitution runs as kPB steps of "lane t divides, everyone below subtracts" with the finished element
-  // broadcast by v_readlane.  A thread per column walked the same 496 dependent multiply-adds and 32 divisions alone
-  // (26 us per panel at n = 512, eight waves on the whole GPU); here a column's chain is the 32 divisions, and the
-  // columns spread over as many waves as there are pairs of them.  Same operations in the same order per element.
-  const int nright = n - kb - kw;
-  const int ncols = nright + (with_E ? kb + kw : 0);
-  const int lane = tid & 63, r = lane & 31, half = lane >> 5;
-  double dcol[kPB];
-#pragma unroll
-  for (int t = 0; t < kPB; ++t) dcol[t] = D[t][r];
-  const double drr = D[r][r];
-  const int pairs_total = (ncols + 1) / 2;
-  for (int pr = blockIdx.x * (blockDim.x >> 6) + (tid >> 6); pr < pairs_total; pr += gridDim.x * (blockDim.x >> 6)) {
-    const int x = 2 * pr + half;
-    const bool live = x < ncols && r < kw;
-    const bool isU = x < nright;
-    const int col = isU ? kb + kw + x : x - nright;
-    double* base = isU ? U : E;
-    double acc = 0.0;
-    if (live) acc = (!isU && col >= kb) ? (col - kb == r ? 1.0 : 0.0) : base[(size_t)(kb + r) * n + col];
-#pragma unroll
-    for (int t = 0; t < kPB; ++t) {
-      if (t < kw) {
-        if (r == t) acc = acc / drr;
-        // the finished element t of either half's column
-        const double v0 = readlane_f64(acc, t), v1 = readlane_f64(acc, 32 + t);
-        const double vt = half ? v1 : v0;
-        if (r > t) acc -= dcol[t] * vt;
-      }
-    }
-    if (live && (isU || col <= kb + r)) base[(size_t)(kb + r) * n + col] = acc;
-  }
-}
-
-// part 0: U[i][j] -= sum_r U[kb+r][i] U[kb+r][j]  (kb+kw <= i <= j < n);  part 1: E[i][c] -= sum_r U[kb+r][i] E[kb+r][c]
-// (i >= kb+kw, c < kb+kw).  32 x 32 output tiles, 4 outputs per thread.
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ work, double* __restrict__ F, int part, int n, int kb) {
-  __shared__ double Pi[kPB][33], Qx[kPB][33];
-  const int o = blockIdx.z, tid = threadIdx.x;
-  double* U = work + (size_t)o * n * n;
-  double* E = F + (size_t)o * n * n;
-  const int kw = n - kb < kPB ? n - kb : kPB;
-  const int i0 = kb + kw + blockIdx.y * 32;
-  const int x0 = part == 0 ? kb + kw + blockIdx.x * 32 : blockIdx.x * 32;
-  if (i0 >= n) return;
-  if (part == 0 && x0 + 31 < i0) return;                 // tile entirely below the diagonal
-  const double* Q = part == 0 ? U : E;
-  for (int idx = tid; idx < kPB * 32; idx += blockDim.x) {
-    const int r = idx / 32, t = idx % 32;
-    Pi[r][t] = (r < kw && i0 + t < n) ? U[(size_t)(kb + r) * n + i0 + t] : 0.0;
-    const int xc = x0 + t;
-    const bool xin = part == 0 ? xc < n : xc < kb + kw;
-    // rows of E inside the panel are lower triangular: entries right of their diagonal are zero
-    Qx[r][t] = (r < kw && xin && (part == 0 || xc <= kb + r)) ? Q[(size_t)(kb + r) * n + xc] : 0.0;
-  }
-  __syncthreads();
-  const int tx = tid % 32, ty = tid / 32;                // ty: 0..7 -> rows ty, ty+8, ty+16, ty+24
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int il = ty + 8 * rr, i = i0 + il, xc = x0 + tx;
-    if (i >= n) continue;
-    if (part == 0 ? (xc >= n || xc < i) : (xc >= kb + kw)) continue;
-    double acc = 0.0;
-#pragma unroll
-    for (int r = 0; r < kPB; ++r) acc += Pi[r][il] * Qx[r][tx];
-    double* dst = (part == 0 ? U : E) + (size_t)i * n + xc;
-    *dst -= acc;
-  }
-}
-
 // ---- r03: one launch per panel ------------------------------------------------------------------------------------------
-// k_chol_panel + k_chol_update above are two dependent launches per panel (n = 512: 16 x (19-25 + 7-10) us, and what a panel
+// The two-launch form of round 2 (a panel kernel + a trailing update, removed in r04) took 16 x (19-25 + 7-10) us at n = 512, and what a panel
 // launch waits for is the pivot chain of its 32 x 32 diagonal block: IEEE sqrt + IEEE division per pivot and ~90 lane
 // broadcasts per step on ONE wave).  k_chol_step is the same right-looking factorisation with the trailing update one
 // launch late ("look-ahead"): the launch of panel kb
@@ -776,7 +653,7 @@ static int factor_chain_enqueue(sbo_ctx* c, const ModelWork& w, int mode, hipStr
       hipLaunchKernelGGL(k_chol_prep, dim3(256, q), dim3(256), 0, fs, mode, n, npad, mc.dpad, mc.d, (const double*)w.W,
                          (const double*)w.As64, (const double*)w.sq64, (const double*)w.rhs, mc, w.work, dF, dalpha);
     }
-    if (c->chol_fused) {
+    {
       // one launch per panel: the pending update of the previous panel rides in the panel's own launch (k_chol_step)
       for (int kb = 0; kb < n; kb += kPB) {
         const int kw = std::min(kPB, n - kb);
@@ -785,21 +662,6 @@ static int factor_chain_enqueue(sbo_ctx* c, const ModelWork& w, int mode, hipStr
         const int ti = kb > 0 ? (n - kb - kw + 31) / 32 : 0;
         const int nB = ti * ti + (mode && kb > 0 ? ((kb + 31) / 32) * ti : 0);
         hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nA + nB), q), dim3(256), 0, fs, w.work, dF, mode, n, kb, nA, ti, w.bad, w.Dg);
-      }
-    } else {
-      for (int kb = 0; kb < n; kb += kPB) {
-        const int kw = std::min(kPB, n - kb);
-        const int ncols = (n - kb - kw) + (mode ? kb + kw : 0);
-        // (a half wave per column: four pairs of columns per workgroup)
-        hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, ((ncols + 1) / 2 + 3) / 4), q), dim3(256), 0, fs, w.work, dF, mode,
-                           n, kb, w.bad, w.Dg);
-        const int rest = n - kb - kw;
-        if (rest > 0) {
-          const unsigned ti = (unsigned)((rest + 31) / 32);
-          hipLaunchKernelGGL(k_chol_update, dim3(ti, ti, q), dim3(256), 0, fs, w.work, dF, 0, n, kb);
-          if (mode)
-            hipLaunchKernelGGL(k_chol_update, dim3((unsigned)((kb + kw + 31) / 32), ti, q), dim3(256), 0, fs, w.work, dF, 1, n, kb);
-        }
       }
     }
     hipLaunchKernelGGL(k_chol_finish, dim3(256, q), dim3(256), 0, fs, mode, n, npad, (const double*)w.rhs, w.work, dF, dalpha,

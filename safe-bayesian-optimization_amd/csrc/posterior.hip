@@ -870,7 +870,6 @@ static int launch_posterior_grid_ts(sbo_ctx* c) {
   int per_cu = 0;
   SBO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
   per_cu = std::max(1, std::min(per_cu, 4));
-  if (c->k1_wgs_per_cu > 0) per_cu = c->k1_wgs_per_cu;
   // the q outputs are separate grid rows: share the CU slots between them
   const long long wgs = std::min<long long>(tiles, ((long long)c->n_cu * per_cu + q - 1) / q);
   hipLaunchKernelGGL(kern, dim3((unsigned)std::max<long long>(wgs, 1), (unsigned)q), dim3(256), lds, c->stream, mc, cs, gt,
@@ -882,7 +881,6 @@ static int launch_posterior_grid_ts(sbo_ctx* c) {
 
 template <typename T, int D>
 static int launch_posterior_grid_t(sbo_ctx* c) {
-  if (c->k1_strips == 8 && D == 2) return launch_posterior_grid_ts<T, 2, 8>(c);   // tuning knob, 2-D only
   return launch_posterior_grid_ts<T, D, 4>(c);
 }
 

@@ -29,13 +29,6 @@ int comm_allreduce_sum_f64(sbo_ctx* c, double* dev, int count);
 int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_per_rank);
 
 constexpr double kInfD = 1.0e300;
-// Set-phase kernels that may run beside a GEMM launch (overlapped sweeps) raise their waves' issue priority: they are short,
-// latency-bound chains, and f64 matrix instructions of a co-resident GEMM wave otherwise keep the shared datapath busy
-#ifdef SBO_NO_CHAIN_PRIO
-#define SBO_CHAIN_PRIO() ((void)0)
-#else
-#define SBO_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
-#endif
 constexpr int kArgSlots = 16;
 
 // small device-resident scalar block of one sweep
@@ -134,14 +127,11 @@ __device__ __forceinline__ void lcb_ucb(T m, T v, T b, T& lcb, T& ucb) {
 constexpr int kClassifyRow = 3 + kMaxQ;   // u* key, |S|, |U|, radius keys
 
 // ---- K3a: S / U masks, u* --------------------------------------------------------------------------
-// OBJ = false: the constraints' outputs only (overlapped sweeps: the objective's posterior is still being computed) -- S / U
-// bytes, |S|, |U| and the radius keys; u* is then reduced over S by k_obj_front once the objective is there.
-template <typename T, bool OBJ>
+template <typename T>
 __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, const T* __restrict__ var, long long n,
                                                   int q, T b, uint8_t* __restrict__ S, uint8_t* __restrict__ U,
                                                   unsigned long long* __restrict__ part /* [gridDim.x][kClassifyRow] */) {
   __shared__ unsigned long long rmax_sh[kMaxQ];   // max over S of ucb_c: bounds the expander search radius
-  SBO_CHAIN_PRIO();
   if (threadIdx.x < kMaxQ) rmax_sh[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long umin = ~0ull;
@@ -174,15 +164,13 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
     return (unsigned)(s_ ? 1u : 0u) | (unsigned)(u ? 2u : 0u);
   };
   auto objective = [&](T m0, T v0, const T* mv, const T* ucbc) {       // a safe candidate: u* key and radius keys
-    if (OBJ) {
-      bool need = true;
-      if constexpr (kFast) need = !(ord_key(ucb_lower((double)m0, (double)v0, (double)b)) >= umin);
-      if (need) {
-        T lcb, ucb;
-        lcb_ucb(m0, v0, b, lcb, ucb);
-        const unsigned long long k = ord_key((double)ucb);
-        umin = k < umin ? k : umin;
-      }
+    bool need = true;
+    if constexpr (kFast) need = !(ord_key(ucb_lower((double)m0, (double)v0, (double)b)) >= umin);
+    if (need) {
+      T lcb, ucb;
+      lcb_ucb(m0, v0, b, lcb, ucb);
+      const unsigned long long k = ord_key((double)ucb);
+      umin = k < umin ? k : umin;
     }
 #pragma unroll
     for (int c = 1; c < kMaxQ; ++c) {
@@ -223,11 +211,8 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
       }
       const unsigned r0 = constraints(mv0, uc0), r1 = constraints(mv1, uc1);
       if ((r0 | r1) & 1u) {
-        T2 m2 = T2{T(0), T(0)}, v2 = m2;
-        if (OBJ) {
-          m2 = *reinterpret_cast<const T2*>(mean + 2 * pi);
-          v2 = *reinterpret_cast<const T2*>(var + 2 * pi);
-        }
+        const T2 m2 = *reinterpret_cast<const T2*>(mean + 2 * pi);
+        const T2 v2 = *reinterpret_cast<const T2*>(var + 2 * pi);
         if (r0 & 1u) objective(m2[0], v2[0], mv0, uc0);
         if (r1 & 1u) objective(m2[1], v2[1], mv1, uc1);
       }
@@ -241,7 +226,7 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
       for (int c = 1; c < kMaxQ; ++c)
         if (c < q) { mv[2 * c] = mean[(size_t)c * n + g]; mv[2 * c + 1] = var[(size_t)c * n + g]; }
       const unsigned r = constraints(mv, uc);
-      if (r & 1u) objective(OBJ ? mean[g] : T(0), OBJ ? var[g] : T(0), mv, uc);
+      if (r & 1u) objective(mean[g], var[g], mv, uc);
       S[g] = (uint8_t)(r & 1u);
       U[g] = (uint8_t)((r >> 1) & 1u);
     }
@@ -269,16 +254,15 @@ struct FinalJob {
   SweepScalars* sc = nullptr;
   const double* Lpart = nullptr;              // K1b's Lipschitz partials still to be merged (nullptr: Lmax is final)
   int per_out = 0;
-  int o_first = 0;                            // first output whose Lipschitz partials are merged here (overlapped sweeps: 1 -- the objective's follow in k_obj_front)
   unsigned long long* Lmax = nullptr;
   SweepScalars* sc_copy = nullptr;            // the second lane's block: a snapshot of the merged scalars (nullptr: one lane)
 };
 __device__ __forceinline__ void classify_final_body(const unsigned long long* __restrict__ part, int nparts, int q, SweepScalars* sc,
                                                     const double* __restrict__ Lpart, int per_out, unsigned long long* Lmax,
-                                                    SweepScalars* sc_copy = nullptr, int o_first = 0) {
+                                                    SweepScalars* sc_copy = nullptr) {
   __shared__ double lsh[4];
   if (Lpart)
-    for (int o = o_first; o < q; ++o) lmax_reduce_body(o, lsh, Lpart, per_out, Lmax);
+    for (int o = 0; o < q; ++o) lmax_reduce_body(o, lsh, Lpart, per_out, Lmax);
   unsigned long long* w = reinterpret_cast<unsigned long long*>(sc);       // (the struct is a multiple of 8 bytes)
   for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) w[i] = 0ull;
   __syncthreads();
@@ -336,8 +320,8 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
 }
 __global__ __launch_bounds__(256) void k_classify_final(const unsigned long long* __restrict__ part, int nparts, int q,
                                                         SweepScalars* sc, const double* __restrict__ Lpart, int per_out,
-                                                        unsigned long long* Lmax, SweepScalars* sc_copy, int o_first) {
-  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax, sc_copy, o_first);
+                                                        unsigned long long* Lmax, SweepScalars* sc_copy) {
+  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax, sc_copy);
 }
 
 // Objective pass of a classification whose S / U bytes came out of the posterior kernel (K1b, one constraint): u* = min over
@@ -397,23 +381,6 @@ __global__ __launch_bounds__(256) void k_classify_obj(const T* __restrict__ mean
   const unsigned long long umin = ustar_partial_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, b, S);
   unsigned long long* row = part + (size_t)blockIdx.x * kClassifyRow;
   if (threadIdx.x < kClassifyRow) row[threadIdx.x] = threadIdx.x == 0 ? umin : 0ull;
-}
-
-// First kernel of an overlapped sweep's tail (the objective's posterior has arrived, the constraints' set phase is done):
-// workgroups [0, gridDim.x - 1) reduce u* = min over S of ucb_0 to one key each (upart), the last workgroup merges the
-// Lipschitz partials of the objective's K1b launch (Lpart == nullptr: nothing to merge).
-template <typename T>
-__global__ __launch_bounds__(256) void k_obj_front(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b,
-                                                   const uint8_t* __restrict__ S, unsigned long long* __restrict__ upart,
-                                                   const double* __restrict__ Lpart, int per_out, unsigned long long* Lmax) {
-  const int nu = (int)gridDim.x - 1;
-  if ((int)blockIdx.x == nu) {
-    __shared__ double lsh[4];
-    if (Lpart) lmax_reduce_body(0, lsh, Lpart, per_out, Lmax);
-    return;
-  }
-  const unsigned long long umin = ustar_partial_body<T>((int)blockIdx.x, nu, mean0, var0, n, b, S);
-  if (threadIdx.x == 0) upart[blockIdx.x] = umin;
 }
 
 // Mask-driven loops of K3b / K5.  A wave takes tiles of 512 consecutive candidates: every lane reads eight mask bytes
@@ -593,32 +560,6 @@ __global__ __launch_bounds__(256) void k_arg_masked_multi(const V val, const uin
   arg_masked_body<T, MAX, V>((int)blockIdx.x, (int)gridDim.x, val, mask, n, first, reinterpret_cast<Best*>(pbase + pstride * (size_t)slot));
 }
 
-// Second kernel of an overlapped SafeOpt sweep's tail: every workgroup merges the u* keys of k_obj_front (nu of them, a few
-// KB out of L2) for itself; row y = 0 of the launch then runs the minimiser (M mask, arg-max of var_0 over M), row y = c
-// the arg-max of var_0 over G_c -- the reductions of models/SafeOpt.py:55-66, 117-124 side by side.
-template <typename T>
-__global__ __launch_bounds__(256) void k_obj_tail(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, long long first,
-                                                  T b, const uint8_t* __restrict__ S, uint8_t* __restrict__ M, const uint8_t* __restrict__ G,
-                                                  const unsigned long long* __restrict__ upart, int nu, SweepScalars* sc,
-                                                  unsigned char* pbase, size_t pstride) {
-  const int slot = (int)blockIdx.y;
-  if (slot == 0) {
-    __shared__ unsigned long long ukey;
-    unsigned long long u = ~0ull;
-    for (int i = threadIdx.x; i < nu; i += blockDim.x) u = upart[i] < u ? upart[i] : u;
-    u = block_ext_u64<false>(u);
-    if (threadIdx.x == 0) {
-      ukey = u;
-      if (blockIdx.x == 0) sc->ustar_key = u;
-    }
-    __syncthreads();
-    minimizer_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, first, b, S, M, ukey, reinterpret_cast<Best*>(pbase));
-  } else {
-    arg_masked_body<T, true, ValArray<T>>((int)blockIdx.x, (int)gridDim.x, ValArray<T>{var0}, G + (size_t)(slot - 1) * n, n, first,
-                                          reinterpret_cast<Best*>(pbase + pstride * (size_t)slot));
-  }
-}
-
 // partial: Best[nparts] followed by the workgroups' mask populations long long[nparts]; their sum is added to *count
 template <bool MAX>
 __global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ partial, int nparts, SweepScalars* sc, int slot,
@@ -646,12 +587,7 @@ template <bool MAX>
 __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts,
                                                       SweepScalars* sc, const SweepScalars* lane1 /* nullptr, or the second lane's block */,
                                                       unsigned char* mirror /* nullptr, or the host's pinned landing area */,
-                                                      const unsigned long long* Lkeys, const double* __restrict__ Lpart0 = nullptr,
-                                                      int per_out = 0, unsigned long long* Lmax = nullptr) {
-  if (Lpart0 && blockIdx.x == 0) {       // overlapped GoOSE sweeps: the objective's Lipschitz partials are merged here (no mirror then)
-    __shared__ double lsh[4];
-    lmax_reduce_body(0, lsh, Lpart0, per_out, Lmax);
-  }
+                                                      const unsigned long long* Lkeys) {
   if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
   // `mirror`: the results go straight to the pinned host block the read-back would have filled (SweepScalars at 0, the
   // Lipschitz keys at 3072) -- every workgroup its own slot, workgroup 0 the fields earlier kernels finished --, and the
@@ -738,7 +674,6 @@ struct MidJobs {
 template <typename T, bool U16>
 __global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
   __shared__ double part[4][64];
-  SBO_CHAIN_PRIO();
   const int bid = (int)blockIdx.x;
   if (bid < j.ns)
     edt_scan_body(bid, j.ns, j.dc_in, j.dc_out, j.nc, j.cstride, j.ccnt, j.hc, j.sc, j.cidx, j.Lkeys, j.lidx, 0, j.cap_extra);
@@ -759,13 +694,8 @@ __global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
 // into the host's pinned landing area and carries the sweep's end event (as k_sweep_finals does for SafeOpt).
 template <int D>
 __global__ __launch_bounds__(256) void k_goose_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts, int q, SweepScalars* sc,
-                                                      const SweepScalars* lane1, const double* __restrict__ Lpart0, int per_out,
-                                                      unsigned long long* Lmax, const CandSpec cs, double* __restrict__ target) {
+                                                      const SweepScalars* lane1, const CandSpec cs, double* __restrict__ target) {
   // workgroup s merges slot s (as k_sweep_finals<false>); the one that finishes last chooses the target
-  if (Lpart0 && blockIdx.x == 0) {
-    __shared__ double lsh[4];
-    lmax_reduce_body(0, lsh, Lpart0, per_out, Lmax);
-  }
   if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
   const int slot = blockIdx.x;
   const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
@@ -829,7 +759,7 @@ static int reduce_blocks(const sbo_ctx* c) {
 
 // mask buffers of a sweep; called before the posterior is enqueued (K1b may write S / U itself) -- `b` is the sweep's
 // confidence multiplier, handed to the posterior with the request to classify
-static int sweep_masks(sbo_ctx* c, double b, bool may_fuse, bool may_split = false) {
+static int sweep_masks(sbo_ctx* c, double b, bool may_fuse) {
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
@@ -841,11 +771,6 @@ static int sweep_masks(sbo_ctx* c, double b, bool may_fuse, bool may_split = fal
   if ((rc = ensure(c->maskM, (size_t)n))) return rc;
   if ((rc = ensure(c->maskG, (size_t)n * std::max(1, q - 1)))) return rc;
   c->fuse_request = (may_fuse && q == 2) ? (c->fuse_classify < 0 ? 2 : c->fuse_classify) : 0;
-  // overlapped sweep: K1b is asked to finish the constraints' outputs first (see sbo_ctx::split_request); it answers with
-  // split_done when it ran that way (it does not on the other posterior paths)
-  c->split_request = may_fuse && may_split && c->k1_split && q >= 2 && !multi_rank(c) && !c->phase_events && !c->rc_active &&
-                     c->stream3 && n > 0;
-  c->split_done = false;
   c->lmax_defer = may_fuse;        // (every sweep merges K1b's Lipschitz partials in its k_classify_final)
   c->lmax_pending = false;
   c->fuse_b = b;
@@ -861,15 +786,13 @@ static void launch_final(sbo_ctx* c, FinalJob* fj) {
   fj->pending = false;
   // (with a second lane the fork event rides on this launch as its stop event: a separate record costs the stream a bubble)
   hipExtLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, nullptr, fj->sc_copy ? c->ev_join[4] : nullptr, 0, fj->part,
-                        fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out, fj->Lmax, fj->sc_copy, fj->o_first);
+                        fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out, fj->Lmax, fj->sc_copy);
 }
 
 // `defer`: the merge of the classification's partials is handed back instead of launched (SafeOpt on one rank: it rides in
 // the expander's first launch, which reads the U mask only)
-// `with_obj` = false (overlapped sweeps): the objective's posterior is not there yet -- S / U, |S|, |U| and the radius keys
-// only; u* follows in the sweep's tail (k_obj_front), and so do the objective's Lipschitz partials
 template <typename T>
-static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* defer = nullptr, bool with_obj = true) {
+static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* defer = nullptr) {
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
@@ -889,21 +812,18 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* def
     fj.Lpart = (const double*)c->bl_lpart.p;
     fj.per_out = c->lmax_per_out;
     fj.Lmax = (unsigned long long*)c->Lmax.p;
-    fj.o_first = with_obj ? 0 : 1;
-    c->lmax_pending = !with_obj;                // (the tail merges output 0)
+    c->lmax_pending = false;
   }
   // four workgroups per CU measured best (2: 24.6 us, 4: 21.5, 8: 27.1 on config B's 4 M candidates; on config C's 1 M: 1024 /
-  // 512 / 256 workgroups 0.1455 / 0.1463 / 0.1530 ms per sweep -- fewer is not better there either); option classify_wgs overrides
+  // 512 / 256 workgroups 0.1455 / 0.1463 / 0.1530 ms per sweep -- fewer is not better there either)
   int ncb = std::max(1, c->n_cu * 4);
-  if (c->classify_wgs > 0) ncb = c->classify_wgs;
   if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kClassifyRow * (size_t)ncb))) return rc;
   if (c->fuse_rows > 0 && n > 0) {
     // S / U bytes, |S|, |U| and the radius key came out of the posterior kernel: only u* is left, over the safe candidates
-    const int nob = with_obj ? std::max(1, c->n_cu * 4) : 0;
+    const int nob = std::max(1, c->n_cu * 4);
     unsigned long long* rows = (unsigned long long*)c->cpart.p;
-    if (with_obj)
-      hipLaunchKernelGGL(k_classify_obj<T>, dim3((unsigned)nob), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b,
-                         (const uint8_t*)c->maskS.p, rows + (size_t)c->fuse_rows * kClassifyRow);
+    hipLaunchKernelGGL(k_classify_obj<T>, dim3((unsigned)nob), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b,
+                       (const uint8_t*)c->maskS.p, rows + (size_t)c->fuse_rows * kClassifyRow);
     fj.part = (const unsigned long long*)rows;
     fj.nparts = c->fuse_rows + nob;
     if (defer) *defer = fj;
@@ -912,14 +832,9 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* def
     SBO_HIP(hipGetLastError());
     return SBO_OK;
   }
-  if (n > 0) {
-    if (with_obj)
-      hipLaunchKernelGGL((k_classify<T, true>), dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
-                         (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
-    else
-      hipLaunchKernelGGL((k_classify<T, false>), dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
-                         (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
-  }
+  if (n > 0)
+    hipLaunchKernelGGL((k_classify<T>), dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
+                       (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
   fj.part = (const unsigned long long*)c->cpart.p;
   fj.nparts = n > 0 ? ncb : 0;
   if (defer) *defer = fj;
@@ -1016,7 +931,7 @@ static void halo_learn(sbo_ctx* c, const SweepScalars& h, const unsigned long lo
 // G_c for constraint cidx (1..q-1) into G[n]
 static void launch_edt_axis0(sbo_ctx* c, const uint8_t* U, long long nlines, int count0, double h0, double* D, hipStream_t st = nullptr) {
   if (!st) st = c->stream;
-  if (c->axis0_waves && (count0 & 63) == 0 && count0 <= 4096 && ((uintptr_t)U & 7) == 0)
+  if ((count0 & 63) == 0 && count0 <= 4096 && ((uintptr_t)U & 7) == 0)
     hipLaunchKernelGGL(k_edt_axis0_waves, dim3((unsigned)std::max<long long>(1, std::min<long long>((nlines + 3) / 4, (long long)c->n_cu * 16))), dim3(256), 0,
                        st, U, nlines, count0, h0, D);
   else if (count0 <= kAxis0Max && count0 >= 128)
@@ -1173,8 +1088,8 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
     double* dout = (double*)c->dist2b.p;
     long long stride = count0;
     if (paired) {
-      // fine lines of whole words, up to 4096 positions: a wave per line (option axis0_waves)
-      const int wave_lines = (c->axis0_waves && (count0 & 63) == 0 && count0 <= 4096 && nlines < (1ll << 22)) ? 1 : 0;
+      // fine lines of whole words, up to 4096 positions: a wave per line
+      const int wave_lines = ((count0 & 63) == 0 && count0 <= 4096 && nlines < (1ll << 22)) ? 1 : 0;
       const int ncoarse = (int)std::min<long long>(clines, 1 << 20);
       // (wave form: four workgroups of 39 KB LDS fit a CU; no more fine workgroups than are resident beside the coarse ones)
       const int nfine = wave_lines ? (int)std::min<long long>((nlines + 3) / 4, std::max<long long>(c->n_cu, 4ll * c->n_cu - ncoarse - 1))
@@ -1187,7 +1102,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
       // the fine image as 16-bit step counts (0xffff: no U point on the line) -- only when its readers are the block minima
       // and the list scan, which decode it: without the list (short last axis, options scan_blocks / scan_waves = 0) the
       // verdict kernel scans the image itself and expects squared distances as doubles
-      u16 = c->dist_u16 && count0 < 65535 && want_bmin && blk_ <= 64 && c->scan_waves;
+      u16 = count0 < 65535 && want_bmin && blk_ <= 64 && c->scan_waves;
       if (u16)
         hipLaunchKernelGGL(k_edt_axis0_pair<true>, dim3((unsigned)(nfine + ncoarse + (fin.pending ? 1 : 0))), dim3(256), 0, c->stream, Uall,
                            nlines, count0, c->cs.step[0], din, nfine, ncoarse, clines, cc0, c->cs.step[0] * kCoarse, dc0, cg, fin, wave_lines);
@@ -1303,7 +1218,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
                      d >= 2 ? stride : 1, last_cnt, last_h, d, xscale, mean_c, var_c, (T)o->b, (const uint8_t*)c->maskS.p,          \
                      (const unsigned long long*)c->Lmax.p, lidx, sc, G, (long long*)c->amb.p, cg, bmin, blk, slist, rx)
       // (grids whose lines are whole 8-byte mask words: eight candidates per lane, see k_edt_decide8)
-      const bool wide = slist && c->decide_wide && len0 % 8 == 0 && d >= 2 && cg.enabled && ((uintptr_t)G & 7) == 0 &&
+      const bool wide = slist && len0 % 8 == 0 && d >= 2 && cg.enabled && ((uintptr_t)G & 7) == 0 &&
                         ((uintptr_t)c->maskS.p & 7) == 0;
       if (wide) {
         const dim3 g8((unsigned)((len0 / 8 + 255) / 256), (unsigned)std::min<long long>(nl, 65535));
@@ -1494,56 +1409,10 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   return SBO_OK;
 }
 
-// Overlapped sweeps: while the scope is on, the context's stream is the chain stream (stream3), which waits for the
-// constraints' K1b launch (ev_join[6]); end() marks the chain's end (ev_join[7]), makes the main stream wait for it and
-// puts the main stream back.  The objective's K1b launch is already queued on the main stream and runs meanwhile.
-struct ChainScope {
-  sbo_ctx* c;
-  bool on;
-  ChainScope(sbo_ctx* c_, bool on_) : c(c_), on(on_) {
-    if (on) std::swap(c->stream, c->stream3);
-  }
-  int begin() {
-    if (on) SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_join[6], 0));
-    return SBO_OK;
-  }
-  int end() {
-    if (!on) return SBO_OK;
-    on = false;
-    std::swap(c->stream, c->stream3);
-    SBO_HIP(hipEventRecord(c->ev_join[7], c->stream3));
-    SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_join[7], 0));
-    return SBO_OK;
-  }
-  ~ChainScope() {
-    if (on) std::swap(c->stream, c->stream3);     // (an error return inside the chain: the entry point drains the streams)
-  }
-};
-
-// u* partials of an overlapped sweep's tail: workgroups of k_obj_front (+ 1 for the Lipschitz merge)
-static int obj_front_blocks(const sbo_ctx* c) { return std::max(1, c->n_cu * 4); }
-
-template <typename T>
-static int launch_obj_front(sbo_ctx* c, const sbo_sweep_opts* o, int* nu_out) {
-  const int nu = obj_front_blocks(c);
-  int rc;
-  if ((rc = ensure(c->upart, sizeof(unsigned long long) * (size_t)nu))) return rc;
-  const bool lp = c->lmax_pending;
-  c->lmax_pending = false;
-  hipLaunchKernelGGL((k_obj_front<T>), dim3((unsigned)(nu + 1)), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, c->cs.n_local,
-                     (T)o->b, (const uint8_t*)c->maskS.p, (unsigned long long*)c->upart.p, lp ? (const double*)c->bl_lpart.p : (const double*)nullptr,
-                     c->lmax_per_out, (unsigned long long*)c->Lmax.p);
-  *nu_out = nu;
-  return SBO_OK;
-}
-
-static void sweep_times(sbo_ctx* c, bool ov) {
-  float tc = 0, te = 0;
-  if (ov) (void)hipEventElapsedTime(&tc, c->ev_join[6], c->ev_join[7]);
+static void sweep_times(sbo_ctx* c) {
+  float te = 0;
   (void)hipEventElapsedTime(&te, c->ev[1], c->ev[4]);
-  c->prof.set_chain_ms = tc;
-  c->prof.set_exposed_ms = te;
-  c->prof.k1_split = ov ? 1 : 0;
+  c->prof.set_phase_ms = te;
   c->prof.host_syncs = c->host_syncs;
   c->prof.comm_bytes = c->comm_bytes;
   c->prof.comm_calls = c->comm_calls;
@@ -1570,13 +1439,10 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   sweep_comm_reset(c);
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
-  if ((rc = sweep_masks(c, o->b, !reuse, true))) return rc;
+  if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   c->fuse_request = 0;
   c->lmax_defer = false;
-  c->split_request = false;
-  const bool ov = c->split_done;     // the constraints' outputs are ahead of the objective's: their set phase runs beside it
-  c->split_done = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
   MinimizerJob mj;
@@ -1593,14 +1459,12 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   unsigned char* pbase = (unsigned char*)c->partial.p;
   const bool lanes = lanes_on(c);
   {
-    ChainScope chain(c, ov);
-    if ((rc = chain.begin())) return rc;
     const bool defer = q >= 2 && !multi_rank(c) && c->set_fuse && n > 0 && !lanes;   // (lanes fork right behind the merge)
-    if ((rc = sweep_common_front<T>(c, o, defer ? &mj.fin : nullptr, !ov))) return rc;
+    if ((rc = sweep_common_front<T>(c, o, defer ? &mj.fin : nullptr))) return rc;
     if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
     // (single rank: the minimiser rides in the first constraint's k_set_mid; with ranks > 1 it is queued here, ahead of the
-    // host's wait for the C1 keys; overlapped sweeps run it in their tail, once u* is known)
-    mj.pending = n > 0 && !ov;
+    // host's wait for the C1 keys)
+    mj.pending = n > 0;
     mj.nb = nb;
     mj.partial = (Best*)pbase;
     if (q < 2 || multi_rank(c)) launch_minimizer<T>(c, o, &mj);
@@ -1613,18 +1477,10 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
     }
     launch_minimizer<T>(c, o, &mj);
     if (lanes && (rc = lanes_join(c))) return rc;
-    if ((rc = chain.end())) return rc;
   }
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
-  if (ov) {
-    // tail: u* over S, then the minimiser and the expanders' arg-max reductions side by side
-    int nu = 0;
-    if ((rc = launch_obj_front<T>(c, o, &nu))) return rc;
-    hipLaunchKernelGGL((k_obj_tail<T>), dim3((unsigned)nb, (unsigned)q), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n,
-                       (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, (const uint8_t*)c->maskG.p,
-                       (const unsigned long long*)c->upart.p, nu, sc, pbase, pstride);
-  } else if (n > 0 && q > 1) {
+  if (n > 0 && q > 1) {
     hipLaunchKernelGGL((k_arg_masked_multi<T, true, ValArray<T>>), dim3((unsigned)nb, (unsigned)(q - 1)), dim3(256), 0, c->stream,
                        ValArray<T>{(const T*)c->var.p}, (const uint8_t*)nullptr, (const uint8_t*)c->maskG.p, n, (long long)c->cs.first, pbase,
                        pstride, 1);
@@ -1633,8 +1489,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   hipExtLaunchKernelGGL(k_sweep_finals<true>, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, mirrored ? c->ev[4] : nullptr, 0,
                         (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, sc,
                         lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr,
-                        mirrored ? c->h_back : (unsigned char*)nullptr, (const unsigned long long*)c->Lmax.p, (const double*)nullptr, 0,
-                        (unsigned long long*)nullptr);
+                        mirrored ? c->h_back : (unsigned char*)nullptr, (const unsigned long long*)c->Lmax.p);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
@@ -1651,7 +1506,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
     hipLaunchKernelGGL(k_sweep_clear_slot, dim3(1), dim3(1), 0, c->stream, sc, 1);
     hipExtLaunchKernelGGL(k_sweep_finals<true>, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, c->ev[4], 0,
                           (const unsigned char*)pbase, pstride, nb, sc, (const SweepScalars*)nullptr, c->h_back,
-                          (const unsigned long long*)c->Lmax.p, (const double*)nullptr, 0, (unsigned long long*)nullptr);
+                          (const unsigned long long*)c->Lmax.p);
     SBO_HIP(hipGetLastError());
     if ((rc = sweep_exchange_back(c, h, is_max, Lk, c->ev[4], true))) return rc;
   }
@@ -1688,7 +1543,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   c->prof.posterior_launches = (!reuse && n > 0) ? 1 : 0;
   const double nn = c->mc.n, dd = c->mc.d;
   c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
-  sweep_times(c, ov);
+  sweep_times(c);
 
   memset(res, 0, sizeof(*res));
   res->count_S = h.count_S;
@@ -1992,23 +1847,16 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   sweep_comm_reset(c);
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
-  if ((rc = sweep_masks(c, o->b, !reuse, true))) return rc;
+  if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   c->fuse_request = 0;
   c->lmax_defer = false;
-  c->split_request = false;
-  // overlapped: everything up to the optimistic sets O_c depends on the constraints' posterior only (models/GoOSE.py:80-101);
-  // the objective enters with the arg-min reductions of lcb_0 (:63-67, :106-112)
-  const bool ov = c->split_done;
-  c->split_done = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
   const int nb = reduce_blocks(c);
   const bool lanes = lanes_on(c);
   {
-    ChainScope chain(c, ov);
-    if ((rc = chain.begin())) return rc;
-    if ((rc = sweep_common_front<T>(c, o, nullptr, !ov))) return rc;
+    if ((rc = sweep_common_front<T>(c, o, nullptr))) return rc;
     if ((rc = sweep_exchange_front<T>(c, o, true))) return rc;
     if ((rc = ensure(c->maskO, (size_t)std::max<long long>(n, 1) * std::max(1, q - 1)))) return rc;
     if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[2], c->stream));
@@ -2032,7 +1880,6 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
       if ((rc = goose_sets_d<T>(c, o, cc, src, O))) return rc;
     }
     if (lanes && (rc = lanes_join(c))) return rc;
-    if ((rc = chain.end())) return rc;
   }
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
@@ -2045,7 +1892,6 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   if (n > 0)
     hipLaunchKernelGGL((k_arg_masked_multi<T, false, ValLcb<T>>), dim3((unsigned)nb, (unsigned)q), dim3(256), 0, c->stream, lcb0,
                        (const uint8_t*)c->maskS.p, (const uint8_t*)c->maskO.p, n, (long long)c->cs.first, pbase, pstride, 0);
-  const bool lp = ov && c->lmax_pending;
   c->lmax_pending = false;
   SweepScalars h;
   bool is_max[kArgSlots];
@@ -2054,15 +1900,14 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   // round trip per sweep; ranks > 1 need the merged target slots first and take a second one below.
   const bool fused_explore = !multi_rank(c) && q > 1;
   double* dev_t = (double*)c->scal.p + 256;
-  // (one rank, option goose_tail: the finals and the target choice in one launch, the last merge writes the host's block itself)
-  const bool short_tail = fused_explore && c->goose_tail && c->result_mirror && (c->mc.dpad == 2 || c->mc.dpad == 4 || c->mc.dpad == 8);
+  // (one rank: the finals and the target choice in one launch, the last merge writes the host's block itself)
+  const bool short_tail = fused_explore && c->result_mirror && (c->mc.dpad == 2 || c->mc.dpad == 4 || c->mc.dpad == 8);
   const SweepScalars* l1 = lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr;
-  const double* lp0 = lp ? (const double*)c->bl_lpart.p : (const double*)nullptr;
   if (short_tail) {
     switch (c->mc.dpad) {
-      case 2: hipLaunchKernelGGL((k_goose_finals<2>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
-      case 4: hipLaunchKernelGGL((k_goose_finals<4>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
-      default: hipLaunchKernelGGL((k_goose_finals<8>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, lp0, c->lmax_per_out, (unsigned long long*)c->Lmax.p, c->cs, dev_t); break;
+      case 2: hipLaunchKernelGGL((k_goose_finals<2>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, c->cs, dev_t); break;
+      case 4: hipLaunchKernelGGL((k_goose_finals<4>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, c->cs, dev_t); break;
+      default: hipLaunchKernelGGL((k_goose_finals<8>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, c->cs, dev_t); break;
     }
     if (n > 0) launch_argmin_dist<T>(c, dev_t, nb);
     hipExtLaunchKernelGGL(k_arg_final_mirror, dim3(1), dim3(256), 0, c->stream, nullptr, c->ev[4], 0, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
@@ -2070,8 +1915,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
     SBO_HIP(hipGetLastError());
   } else {
     hipLaunchKernelGGL(k_sweep_finals<false>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride,
-                       n > 0 ? nb : 0, sc, l1, (unsigned char*)nullptr, (const unsigned long long*)nullptr, lp0,
-                       c->lmax_per_out, (unsigned long long*)c->Lmax.p);
+                       n > 0 ? nb : 0, sc, l1, (unsigned char*)nullptr, (const unsigned long long*)nullptr);
     SBO_HIP(hipGetLastError());
     if (fused_explore) {
       switch (c->mc.dpad) {
@@ -2168,7 +2012,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   c->prof.posterior_launches = (!reuse && n > 0) ? 1 : 0;
   const double nn = c->mc.n, dd = c->mc.d;
   c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
-  sweep_times(c, ov);
+  sweep_times(c);
   return SBO_OK;
 }
 

@@ -372,11 +372,10 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
   constexpr size_t kWaveBytes = 4 * 512 + (U16 ? 4 * 64 * kA0Row * 4 : 0);
   __shared__ __attribute__((aligned(16))) unsigned char a0mem[sizeof(Axis0Lds) > kWaveBytes ? sizeof(Axis0Lds) : kWaveBytes];
   Axis0Lds& lds = *reinterpret_cast<Axis0Lds*>(a0mem);
-  SBO_CHAIN_PRIO();
   // (order of the ranges: the merge and the coarse lines first -- few workgroups with longer chains that should start with the
   // launch, not in the slots the fine lines leave at its end)
   const int nfin = (int)gridDim.x - nfine - ncoarse, bid = (int)blockIdx.x;
-  if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy, fin.o_first);
+  if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy);
   else if (bid < nfin + ncoarse) edt_axis0_wg_body<true>(bid - nfin, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
   else if (wave_lines) {
     // (the waves of the fine workgroups stride over the lines: the host sizes the launch to what is resident at once)
@@ -623,7 +622,6 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
                                                     uint8_t* __restrict__ G, long long* __restrict__ amb,
                                                     const CoarseGrid cg, const double* __restrict__ Bmin, int blk,
                                                     long long* __restrict__ scanlist, const RcExp rx) {
-  SBO_CHAIN_PRIO();
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const bool anyU = sc->count_U > 0;
   // launch: x over the positions of a grid line (len0 = count0; the whole range when d == 1), y over blocks of
@@ -758,7 +756,6 @@ __global__ __launch_bounds__(256) void k_edt_decide8(long long nl, int len0, lon
                                                      const uint8_t* __restrict__ S, const unsigned long long* Lkeys, int lidx,
                                                      SweepScalars* sc, uint8_t* __restrict__ G, const CoarseGrid cg,
                                                      long long* __restrict__ scanlist, const RcExp rx) {
-  SBO_CHAIN_PRIO();
   static_assert(kCoarse == 8, "a lane's eight candidates are one coarse cell");
   constexpr int kCap = 1024;                     // open candidates a workgroup collects in LDS (beyond: straight to the list)
   __shared__ long long sl[kCap];
@@ -851,7 +848,6 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const DS Din, long long g
                                                        SweepScalars* sc, uint8_t* __restrict__ G, long long* __restrict__ amb,
                                                        const double* __restrict__ Bmin, int blk,
                                                        const long long* __restrict__ scanlist, const RcExp rx) {
-  SBO_CHAIN_PRIO();
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const long long nscan = sc->n_scan;
   const int lane = threadIdx.x & (GL - 1);
