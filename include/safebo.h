@@ -103,6 +103,14 @@ typedef struct sbo_safeopt_result {
   int64_t count_G[SBO_MAX_Q];            /* [c-1]                                                         */
   int64_t n_exact_rechecks;              /* expander decisions that fell in the +1e-8 ambiguity band and
                                             were re-decided by exhaustive evaluation                      */
+  /* Guard band of an approximating posterior kernel (K1b: Chebyshev core, K1t: Chebyshev-node interpolation; zero for the exact
+   * kernels): decisions of the first pass that the band +- (sbo_profile.guard_dm, guard_dv) left open; when non-zero the
+   * candidates concerned were re-evaluated by the exact kernel and the set phase ran again, so that every mask and index
+   * returned is that of the exact posterior                                                                              */
+  int64_t guard_band;                    /* decisions inside the band on the first pass (0: the first pass is the result)  */
+  int64_t guard_rechecks;                /* candidates re-evaluated by the exact kernel                                     */
+  int32_t guard_passes;                  /* set-phase passes of the re-evaluation (0: none was needed)                      */
+  int32_t reserved_g;
 } sbo_safeopt_result;
 
 typedef struct sbo_goose_result {
@@ -122,6 +130,8 @@ typedef struct sbo_goose_result {
   int64_t count_S, count_U;
   int64_t count_O[SBO_MAX_Q];
   int64_t n_exact_rechecks;              /* candidates decided by the exhaustive reference predicate (expanders + coverage) */
+  int64_t guard_band, guard_rechecks;    /* as in sbo_safeopt_result                                                        */
+  int32_t guard_passes, reserved_g;
 } sbo_goose_result;
 
 typedef struct sbo_tr_result {
@@ -129,6 +139,8 @@ typedef struct sbo_tr_result {
   double  x[SBO_MAX_D];
   double  lcb;
   int64_t count_S, count_T;      /* |S_t|, |S_t intersected with the ball|                                                  */
+  int64_t guard_band, guard_rechecks;    /* as in sbo_safeopt_result                                                        */
+  int32_t guard_passes, reserved_g;
 } sbo_tr_result;
 
 /* per-kernel device time of the last sweep / posterior call, measured with HIP events on the
@@ -155,6 +167,9 @@ typedef struct sbo_profile {
   int32_t host_syncs;            /* host waits on the device inside the last sweep call (1 = the result read-back only)          */
   int32_t comm_calls;            /* collectives of the last sweep; comm_ms is their event-timed sum when option "comm_events" is 1 */
   int64_t comm_bytes;            /* multi-rank sweeps: bytes this rank handed to the collectives of the last sweep (send side)     */
+  /* guard band of the posterior kernel that ran last (un-normalised units; zero for the exact kernels K1 / K1c / K1g)             */
+  double guard_dm[SBO_MAX_Q], guard_dv[SBO_MAX_Q], guard_rl[SBO_MAX_Q];   /* |mean - exact|, |var - exact|, relative band of L       */
+  double guard_ms;               /* device + host time of the last sweep's re-evaluation (0: none was needed)                      */
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */
@@ -276,7 +291,9 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  *   "halo_spec"        1: ranks > 1 size their transform windows from the previous sweep's keys (device-checked); 0: wait for this sweep's
  *   "comm_events"      1: an event pair around every collective (sbo_profile.comm_ms)
  *   "comm_selftest"    1: a one-rank communicator still sends C1 / C2 / C3 through RCCL (results must not change)
- *   "fp64_recheck"     1: fp32 models re-evaluate in fp64 every candidate their 1e-4 contract cannot decide; 0: masks of the fp32 posterior */
+ *   "fp64_recheck"     1: fp32 models re-evaluate in fp64 every candidate their 1e-4 contract cannot decide; 0: masks of the fp32 posterior
+ *   "guard_band"       1: sweeps on an approximating posterior (K1b / K1t) count the decisions inside its band and re-evaluate exactly
+ *                      when there are any; 0: masks of the approximating posterior as they come; 2: the re-evaluation on every sweep (test) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

@@ -42,6 +42,7 @@ class SafeOptResult(C.Structure):
         ("expander_std", C.c_double), ("choose_minimizer", C.c_int32), ("u_star", C.c_double),
         ("L", C.c_double * SBO_MAX_Q), ("count_S", C.c_int64), ("count_U", C.c_int64), ("count_M", C.c_int64),
         ("count_G", C.c_int64 * SBO_MAX_Q), ("n_exact_rechecks", C.c_int64),
+        ("guard_band", C.c_int64), ("guard_rechecks", C.c_int64), ("guard_passes", C.c_int32), ("reserved_g", C.c_int32),
     ]
 
 
@@ -53,12 +54,14 @@ class GooseResult(C.Structure):
         ("target_lcb", C.c_double), ("explore_index", C.c_int64), ("explore_x", C.c_double * SBO_MAX_D),
         ("choose_safe_min", C.c_int32), ("L", C.c_double * SBO_MAX_Q), ("count_S", C.c_int64),
         ("count_U", C.c_int64), ("count_O", C.c_int64 * SBO_MAX_Q), ("n_exact_rechecks", C.c_int64),
+        ("guard_band", C.c_int64), ("guard_rechecks", C.c_int64), ("guard_passes", C.c_int32), ("reserved_g", C.c_int32),
     ]
 
 
 class TRResult(C.Structure):
     _fields_ = [("index", C.c_int64), ("x", C.c_double * SBO_MAX_D), ("lcb", C.c_double), ("count_S", C.c_int64),
-                ("count_T", C.c_int64)]
+                ("count_T", C.c_int64), ("guard_band", C.c_int64), ("guard_rechecks", C.c_int64), ("guard_passes", C.c_int32),
+                ("reserved_g", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -69,6 +72,8 @@ class Profile(C.Structure):
         ("posterior_kernel", C.c_int32), ("posterior_executed_flops", C.c_double), ("posterior_setup_ms", C.c_double),
         ("fp64_rechecks", C.c_int64), ("recheck_ms", C.c_double),
         ("set_phase_ms", C.c_double), ("host_syncs", C.c_int32), ("comm_calls", C.c_int32), ("comm_bytes", C.c_int64),
+        ("guard_dm", C.c_double * SBO_MAX_Q), ("guard_dv", C.c_double * SBO_MAX_Q), ("guard_rl", C.c_double * SBO_MAX_Q),
+        ("guard_ms", C.c_double),
     ]
 
 

@@ -200,7 +200,7 @@ int sbo_shutdown(sbo_ctx* c) {
   }
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_cheb, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->invk_img, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg, &c->tn_pts, &c->tn_vals, &c->tn_work, &c->tn_W0t, &c->tn_W1t, &c->tn_probe, &c->tn_scr})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_cheb, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->invk_img, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg, &c->tn_pts, &c->tn_vals, &c->tn_work, &c->tn_W0t, &c->tn_W1t, &c->tn_probe, &c->tn_scr, &c->gb, &c->gb_pts, &c->gb_vals, &c->gb_probe, &c->list_scr})
     release(*b);
   for (auto& b : c->tn_W) release(b);
   for (auto& ev : c->ev)
@@ -305,6 +305,14 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   }
   if (!strcmp(key, "goose_pairs")) {
     c->goose_pairs = value ? 1 : 0;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "guard_band")) {
+    if (value < 0 || value > 2) return fail(SBO_E_INVALID, "guard_band must be 0 (off), 1 (on) or 2 (re-evaluate on every sweep)");
+    c->guard_band = (int)value;
+    c->bl.valid = false;                    // (plans measure their band when they are built)
+    c->tn_valid = false;
+    c->posterior_valid = false;
     return SBO_OK;
   }
   if (!strcmp(key, "fp64_recheck")) {
@@ -638,6 +646,15 @@ int sbo_profile_get(sbo_ctx* c, sbo_profile* out) {
   out->posterior_kernel = c->last_k1;
   out->posterior_executed_flops = c->prof.posterior_launches ? c->last_k1_flops : 0.0;
   out->posterior_setup_ms = c->bl.setup_ms;
+  // the guard band of the posterior that is resident (K1b measures it on the device: a small read-back, off the hot path)
+  for (int o = 0; o < SBO_MAX_Q; ++o) out->guard_dm[o] = out->guard_dv[o] = out->guard_rl[o] = 0.0;
+  if (c->gb_active && c->guard_band && c->gb.p && c->posterior_valid) {
+    GuardBand hb;
+    SBO_HIP(hipSetDevice(c->device));
+    SBO_HIP(hipMemcpyAsync(&hb, c->gb.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+    for (int o = 0; o < c->mc.q; ++o) { out->guard_dm[o] = hb.dm[o]; out->guard_dv[o] = hb.dv[o]; out->guard_rl[o] = hb.rl[o]; }
+  }
   return SBO_OK;
 }
 

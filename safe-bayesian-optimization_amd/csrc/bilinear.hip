@@ -952,7 +952,9 @@ __global__ __launch_bounds__(256) void k_bl_sbf(const BlDims dm, const double* _
 //   phase 2  g0   = [V[1]; V[0]] . [S0; -xn0 S0]  (2 KSm)   gradient sum of axis 0 (the candidate's own xn0 sits in B)
 //   phase 3  g1   = V1x   . S0          (KSm)              gradient sum of axis 1 (xn1 of the line is folded into V1x)
 
-constexpr int kFuseRow = 3 + kMaxQ;     // = kClassifyRow of sets.hip: u* key, |S|, |U|, radius keys
+// = kClassifyRow of sets.hip: u* key, |S|, |U|, decisions inside the guard band, min-variance keys over S, radius keys
+constexpr int kFuseRow = 4 + 2 * kMaxQ;
+constexpr int kFuseVmin = 4, kFuseRmax = 4 + kMaxQ;
 struct PostCtx {
   double* lds;
   int tid, lane, wave, rb0, cs0, nrb, ncs;
@@ -967,6 +969,10 @@ struct PostCtx {
   double bconf, bb;   // confidence multiplier and its square
   int cS, cU;         // this thread's counts
   double rmax;        // max ucb over its safe candidates (-1: none; ucb >= lcb >= 0 on S)
+  // guard band of this posterior (guard.hip): sign tests the band of the constraint's output could move are counted, and the
+  // smallest variance over the thread's safe candidates is kept (gdm < 0: no band in force)
+  double gdm, gdv, vminS;
+  int cB;
 };
 
 // One GEMM phase of k_bpost on the workgroup's 128 x 128 tile: A images / B fragments of `KB` k-blocks per row block /
@@ -983,6 +989,10 @@ __device__ __forceinline__ void post_classify_mv(PostCtx& cx, size_t g, double m
   cx.U[g] = sg.le;
   cx.cS += sg.ge;
   cx.cU += sg.le;
+  if (cx.gdm >= 0.0) {
+    cx.cB += lcb_near_zero(m, v, cx.bb, cx.gdm, cx.gdv);
+    if (sg.ge) cx.vminS = v < cx.vminS ? v : cx.vminS;
+  }
   if (sg.ge && !(ucb_upper(m, v, cx.bconf) <= cx.rmax)) {
     const double ucb = add_rn(m, mul_rn(cx.bconf, sqrt_rn(v)));
     if (ucb > cx.rmax) cx.rmax = ucb;
@@ -995,44 +1005,54 @@ __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) {
 // reads any more (barrier first).
 template <int NW>
 __device__ __forceinline__ void post_partials(double* sh, int lane, int wave, double gmax, bool fuse, int cS_, int cU_, double rmax_,
-                                              double* __restrict__ lrow, unsigned long long* __restrict__ crow) {
-  int cS = cS_, cU = cU_;
-  double rm = rmax_;
+                                              int cB_, double vmin_, double* __restrict__ lrow, unsigned long long* __restrict__ crow) {
+  int cS = cS_, cU = cU_, cB = cB_;
+  double rm = rmax_, vm = vmin_;
   if (fuse) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       cS += __shfl_xor(cS, off);
       cU += __shfl_xor(cU, off);
+      cB += __shfl_xor(cB, off);
       const double other = __shfl_xor(rm, off);
       rm = other > rm ? other : rm;
+      const double ov = __shfl_xor(vm, off);
+      vm = ov < vm ? ov : vm;
     }
   }
   __syncthreads();
   if (lane == 0) {
-    sh[wave * 4 + 0] = gmax;
-    sh[wave * 4 + 1] = rm;
-    reinterpret_cast<int*>(sh + wave * 4 + 2)[0] = cS;
-    reinterpret_cast<int*>(sh + wave * 4 + 2)[1] = cU;
+    sh[wave * 6 + 0] = gmax;
+    sh[wave * 6 + 1] = rm;
+    reinterpret_cast<int*>(sh + wave * 6 + 2)[0] = cS;
+    reinterpret_cast<int*>(sh + wave * 6 + 2)[1] = cU;
+    reinterpret_cast<int*>(sh + wave * 6 + 3)[0] = cB;
+    sh[wave * 6 + 4] = vm;
   }
   __syncthreads();
   if (wave == 0) {
-    double g = sh[0], r = sh[1];
-    long long s_ = 0, u_ = 0;
+    double g = sh[0], r = sh[1], vmn = sh[4];
+    long long s_ = 0, u_ = 0, b_ = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      g = sh[w * 4] > g ? sh[w * 4] : g;
-      r = sh[w * 4 + 1] > r ? sh[w * 4 + 1] : r;
-      s_ += reinterpret_cast<const int*>(sh + w * 4 + 2)[0];
-      u_ += reinterpret_cast<const int*>(sh + w * 4 + 2)[1];
+      g = sh[w * 6] > g ? sh[w * 6] : g;
+      r = sh[w * 6 + 1] > r ? sh[w * 6 + 1] : r;
+      vmn = sh[w * 6 + 4] < vmn ? sh[w * 6 + 4] : vmn;
+      s_ += reinterpret_cast<const int*>(sh + w * 6 + 2)[0];
+      u_ += reinterpret_cast<const int*>(sh + w * 6 + 2)[1];
+      b_ += reinterpret_cast<const int*>(sh + w * 6 + 3)[0];
     }
     if (lane == 0) *lrow = g;
     if (fuse && lane < kFuseRow) {
-      // partial row of the classification, merged by k_classify_final: [u* key (none here), |S|, |U|, radius keys]
+      // partial row of the classification, merged by k_classify_final: [u* key (none here), |S|, |U|, decisions inside the guard
+      // band, min-variance keys over S (output 1 only), radius keys (constraint 1 only)]
       unsigned long long v = 0ull;
       if (lane == 0) v = ~0ull;
       else if (lane == 1) v = (unsigned long long)s_;
       else if (lane == 2) v = (unsigned long long)u_;
-      else if (lane == 4) v = r >= 0.0 ? ord_key(r) : 0ull;       // radius key of constraint 1 (slot 3 + c)
+      else if (lane == 3) v = (unsigned long long)b_;
+      else if (lane >= kFuseVmin && lane < kFuseRmax) v = (lane == kFuseVmin + 1 && vmn < 1e300) ? ord_key(vmn) : ~0ull;
+      else if (lane == kFuseRmax + 1) v = r >= 0.0 ? ord_key(r) : 0ull;       // radius key of constraint 1
       crow[lane] = v;
     }
   }
@@ -1249,7 +1269,8 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
                                                   int KSm, int KBm2, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
                                                   double* __restrict__ var_out, double* __restrict__ Lpart,
                                                   const double* __restrict__ xn0, uint8_t* __restrict__ Sfuse, uint8_t* __restrict__ Ufuse,
-                                                  double bconf, unsigned long long* __restrict__ cpart /* [waves of output 1][kFuseRow] */,
+                                                  double bconf, unsigned long long* __restrict__ cpart /* [workgroups of output 1][kFuseRow] */,
+                                                  const GuardBand* __restrict__ gb /* nullptr: no guard band (the first launch of a plan measures it afterwards) */,
                                                   const int* __restrict__ eff /* nullptr, or the Chebyshev core's k-steps of the variance phase at [4 o] */) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
   const int o = blockIdx.z;
@@ -1282,8 +1303,11 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   cx.U = Ufuse;
   cx.bconf = bconf;
   cx.bb = bconf * bconf;
-  cx.cS = cx.cU = 0;
+  cx.cS = cx.cU = cx.cB = 0;
   cx.rmax = -1.0;
+  cx.gdm = (fuse && gb) ? gb->dm[1] : -1.0;
+  cx.gdv = (fuse && gb) ? gb->dv[1] : 0.0;
+  cx.vminS = 1e300;
   double gmax = 0.0;
   // (Tried: odd outputs running the three short phases first and the variance phase last, so that the two workgroups of a
   // CU do not reach their phase changes together -- no gain on config B, 2.5 % slower on H; one order for all.)
@@ -1306,7 +1330,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   // one plain store per WORKGROUP, merged by k_lmax_reduce / the classification's final merge: every workgroup of this launch
   // is resident at once and ends at the same time, so atomics on the q keys would queue up in L2 as the kernel's tail -- and
   // a row per wave made that merge (one workgroup, 16384 rows of 88 bytes on config H) the longest job of the launch it shares
-  post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, fuse, cx.cS, cx.cU, cx.rmax, Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+  post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, fuse, cx.cS, cx.cU, cx.rmax, cx.cB, cx.vminS, Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
                    cpart + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kFuseRow);
 }
 
@@ -1469,6 +1493,8 @@ __global__ __launch_bounds__(256) void k_small_tn(const double* __restrict__ Aal
 // degrees the kernels run to, per output: behind them every |Chat| is below thr of the largest.  ChatT [D1m][D0m] row-major
 // (the GEMMs deliver the transpose).  eff[4 o + 0] = k-steps of the variance phase (axis 0, four degrees each), [1] = its
 // 16-blocks (strips of stage 1), [2] = 16-blocks of axis 1 (inner dimension of stage 1), [3] = 0.  One workgroup of 1024.
+// tail[o] (behind the q x 4 counts): the sum of |Chat| over the entries the kernels do NOT run -- a bound on what the truncation
+// moves the quadratic form by (|T_a T_b| <= 1), part of K1b's guard band (guard.hip).
 __global__ __launch_bounds__(1024) void k_cheb_trunc(const BlDims dm, const double* __restrict__ ChatT_all, double thr, int* __restrict__ eff) {
   __shared__ double red[16];
   __shared__ int redi[16][2];
@@ -1500,6 +1526,7 @@ __global__ __launch_bounds__(1024) void k_cheb_trunc(const BlDims dm, const doub
   }
   if ((tid & 63) == 0) { redi[tid >> 6][0] = a_hi; redi[tid >> 6][1] = b_hi; }
   __syncthreads();
+  __shared__ int run_ab[2];
   if (tid == 0) {
     for (int w = 1; w < 16; ++w) { a_hi = redi[w][0] > a_hi ? redi[w][0] : a_hi; b_hi = redi[w][1] > b_hi ? redi[w][1] : b_hi; }
     a_hi = a_hi < 1 ? 1 : a_hi;
@@ -1508,6 +1535,24 @@ __global__ __launch_bounds__(1024) void k_cheb_trunc(const BlDims dm, const doub
     eff[4 * o + 1] = (a_hi + 15) / 16;
     eff[4 * o + 2] = (b_hi + 15) / 16;
     eff[4 * o + 3] = 0;
+    run_ab[0] = (a_hi + 3) / 4 * 4;              // degrees the two GEMMs run: axis 0 in k-steps of four, axis 1 in blocks of 16
+    run_ab[1] = (b_hi + 15) / 16 * 16;
+  }
+  __syncthreads();
+  double ts = 0.0;
+  for (int i = tid; i < D0 * D1; i += 1024) {
+    const int b = i / D0, a = i % D0;
+    if (a >= run_ab[0] || b >= run_ab[1]) ts += fabs(Ch[i]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ts += __shfl_xor(ts, off);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = ts;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    reinterpret_cast<double*>(eff + 4 * dm.q)[o] = s;
   }
 }
 // ChatT [D1m][D0m] -> the B fragments of stage 1 (T4f layout: k = axis-1 degree, column = axis-0 degree)
@@ -1690,6 +1735,7 @@ int bilinear_setup(sbo_ctx* c) {
   BilinearPlan& pl = c->bl;
   pl.valid = true;
   pl.usable = false;
+  pl.band_ready = false;
   pl.setup_ms = 0.0;
   const auto t_begin = std::chrono::steady_clock::now();
   const bool timing = getenv("SBO_BL_TIMING") != nullptr;
@@ -1908,7 +1954,8 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   // (r03: with the sqrt-free sign tests the fused epilogue saves the separate pass 76 us on config H and costs the GEMM 36;
   // on config B, two workgroups per CU, the two cancel -- "auto" asks for at least four workgroups per CU)
   const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
-  const bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
+  const bool band_first = c->guard_band && !c->is_shadow && !c->bl.band_ready;
+  const bool fuse = fuse_wanted && !band_first && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
                     c->maskU.bytes >= (size_t)cs.n_local;
   c->fuse_rows = 0;
   if (fuse) {
@@ -1916,6 +1963,9 @@ int launch_posterior_bilinear(sbo_ctx* c) {
     // (room behind the rows for the partials of the objective pass, see sweep_common_front)
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
   }
+  // The fused classification counts its sign tests inside the guard band -- which exists only once the plan's first launch has
+  // been probed: that first launch does not fuse (the separate pass follows the band kernels and reads the band they wrote).
+  const GuardBand* gb_fused = (c->guard_band && !c->is_shadow && c->bl.band_ready && c->gb.p) ? (const GuardBand*)c->gb.p : nullptr;
   auto kpost = k_bpost<rbw>;
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // the K1 stop event rides on the last launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
@@ -1925,7 +1975,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                         pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
                         (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
                         fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                        (unsigned long long*)c->cpart.p, (const int*)pl.eff);
+                        (unsigned long long*)c->cpart.p, gb_fused, (const int*)pl.eff);
   if (c->lmax_defer) {
     c->lmax_pending = true;
     c->lmax_per_out = (int)rows_out;
@@ -1935,6 +1985,15 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   }
   c->k1_stop_attached = true;
   (void)line0;
+  // guard band of this plan (guard.hip): measured once per (model, grid) behind its first posterior launch, on the device
+  if (c->guard_band && !c->is_shadow) {
+    if (!c->bl.band_ready) {
+      if ((rc = guard_band_bilinear(c))) return rc;
+      c->bl.band_ready = true;
+      c->k1_stop_attached = false;      // (the band kernels follow the stop event's launch: the sweep records its own)
+    }
+    c->gb_active = true;
+  }
   // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (KS0 + 3 KSm k-steps: the axis-0 gradient phase
   // runs on the mean phase's sums; 16 x 16 x 4 steps, 2 flops per multiply-add)
   const double tiles2 = (double)pl.nrb * pl.ncs0, tiles1 = (double)pl.nrb * pl.KB0;

@@ -111,6 +111,31 @@ __device__ __forceinline__ LcbSign lcb_sign(double m, double v, double b, double
   const double sd = mul_rn(b, sqrt_rn(v));
   return LcbSign{m >= sd, m <= sd};
 }
+// ---- guard band of an approximating posterior (r04) ---------------------------------------------------------------------------
+// K1b (Chebyshev core) and K1t (Chebyshev-node interpolation) deliver mean / var within (dm[o], dv[o]) of the exact fp64 kernel
+// (un-normalised units; measured per plan against exactly evaluated probe points, plus the analytic truncation tail) and the
+// Lipschitz keys within a relative rl[o].  Every decision of a sweep that such a deviation could move -- the sign of a
+// constraint's lcb, lcb_0 <= u*, an arg-max / arg-min, an expander / optimistic-set verdict -- is COUNTED on the fast path
+// (SweepScalars::n_guard); a sweep with a non-zero count re-evaluates the candidates concerned with the exact kernel and runs
+// its set phase again (sets_recheck.inc.hpp), so that the masks and indices it returns are those of the exact posterior.
+// The block lives in device memory: K1b computes its band on the device (no host round trip in a model change).
+struct GuardBand {
+  double dm[kMaxQ], dv[kMaxQ], rl[kMaxQ];
+};
+// |sqrt(v') - sqrt(v)| for |v' - v| <= dv (both clipped at zero): dv / sqrt(v) while v >= dv, sqrt(dv) below
+__device__ __forceinline__ double gb_dsqrt(double v, double dv) {
+  return v >= dv ? dv / __dsqrt_rn(v) : __dsqrt_rn(dv);
+}
+// could a deviation of (dm, dv) move the sign of lcb = m - b sqrt(v) (either test of LcbSign)?  Sqrt-free and conservative:
+// with P = m^2, Q = b^2 v the sign of m - b sqrt(v) for m >= 0 is that of P - Q, and P - Q moves by at most
+// 2 |m| dm + dm^2 + b^2 dv; for m < -dm the sign is settled (b sqrt(v) >= 0), and a flagged candidate there is a false alarm.
+__device__ __forceinline__ bool lcb_near_zero(double m, double v, double bb, double dm, double dv) {
+  const double P = m * m, Q = bb * v, am = m < 0 ? -m : m;
+  const double band = fma(2.0 * am, dm, fma(dm, dm, bb * dv));
+  const double gap = P > Q ? P - Q : Q - P;
+  return !(gap > band * (1.0 + 0x1p-40) + 0x1p-49 * (P + Q));     // (NaN operands count as near)
+}
+
 // bounds of ucb = fl(m + fl(b fl(sqrt v))) from a single-precision square root: the reductions over ucb (largest ucb_c over
 // S, smallest ucb_0 over S) evaluate the exact bound only for candidates that could move the running extremum
 __device__ __forceinline__ double ucb_upper(double m, double v, double b) {

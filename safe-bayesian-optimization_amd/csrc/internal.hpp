@@ -53,7 +53,8 @@ struct BilinearPlan {
   size_t sP0f = 0, sP1A = 0, sT4f = 0, sBtA = 0;   // per-output strides (elements)
   int r0[kMaxQ] = {0}, r1[kMaxQ] = {0};
   double setup_ms = 0.0;
-  int* eff = nullptr;    // device: per-output counts the kernels run to (k_cheb_trunc)
+  int* eff = nullptr;    // device: per-output counts the kernels run to (k_cheb_trunc), followed by the truncation tails (q doubles)
+  bool band_ready = false;   // the guard band of this plan has been measured (guard.hip: guard_band_bilinear)
 };
 
 }  // namespace sbo
@@ -115,7 +116,21 @@ struct sbo_ctx {
   double tn_lo[4] = {0, 0, 0, 0}, tn_hi[4] = {0, 0, 0, 0};
   int tn_level[4] = {0, 0, 0, 0};
   int tn_dn[4] = {0, 0, 0, 0};     // node counts of the plan in use
+  double tn_band[3 * SBO_MAX_Q] = {0};   // the plan's guard band (dm | dv | rl per output), from its probe
   int tn_bump = 0;                 // ladder steps added to the first guess on this grid (a previous model's plan needed its second attempt)
+  // Guard band of the approximating posteriors K1b / K1t (device_common.hpp: GuardBand; guard.hip)
+  int guard_band = 1;              // option: 1 count + re-evaluate exactly when the count is non-zero; 0 off; 2 re-evaluate on every sweep (test)
+  bool gb_active = false;          // the posterior in mean / var came from an approximating kernel; `gb` holds (or will hold, in stream order) its band
+  bool gb_off = false;             // a recheck's inner sweep on fully refined values: no band
+  bool gb_slow = false;            // the re-evaluation path of the SafeOpt sweep is running (Lipschitz keys exact, lists in use)
+  sbo::DevBuf gb;                  // GuardBand of the resident posterior
+  long long guard_first = 0;       // decisions the first pass of the running sweep left open
+  sbo::DevBuf gb_pts, gb_vals;     // re-evaluation: coordinates and exact values of the listed candidates
+  sbo::DevBuf gb_probe;            // K1b: probe indices / coordinates / reference values of the running plan
+  sbo::DevBuf list_scr;            // key scratch of launch_posterior_on_list
+  unsigned long long gb_plan_model = 0;   // K1b: the model whose band `gb` holds (0: none)
+  long long gb_plan_first = -1, gb_plan_n = -1;
+  const double* invk_plain = nullptr;     // the caller's invK as uploaded, [q][n][n] (valid while invk_w_valid)
   sbo::DevBuf bl_basis;            // K1b: the 2 q axis bases (U, Chebyshev series, ranks) and the workspace of their kernel
   bool bl_basis_ok = false;        // bases enqueued for (bl_basis_serial, bl_basis_ab); their (ok, r, rc) records land at h_back + 4096
   unsigned long long bl_basis_serial = 0;
@@ -259,6 +274,14 @@ bool tensor_applicable(const sbo_ctx* c);
 int launch_posterior_tensor(sbo_ctx* c, bool* declined);
 int launch_posterior_on_axes(sbo_ctx* c, int d, const long long* count, const double* axc, double* mean_out, double* var_out, double* grad_out,
                              unsigned long long* lmax);
+// the exact posterior of the generic kernel on an explicit fp64 list [N][d] (device), into caller-given arrays [q][N]
+int launch_posterior_on_list(sbo_ctx* c, const double* pts, long long N, double* mean_out, double* var_out);
+// guard.hip: the exact evaluator that the band of the resident posterior was measured against, on a list; K1b's band (device,
+// enqueued behind the first posterior launch of a plan); a host-known band (K1t) or "none" (exact kernels)
+int guard_exact_list(sbo_ctx* c, const double* pts, long long N, double* mean_out, double* var_out);
+int guard_exact_grad_list(sbo_ctx* c, const double* pts, long long N, double* grad_out /* [q][d][N] */);
+int guard_band_bilinear(sbo_ctx* c);
+int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl);
 }  // namespace sbo
 
 #define SBO_HIP(x)                                                   \

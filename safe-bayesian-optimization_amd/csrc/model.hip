@@ -717,6 +717,7 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
     for (int o = 0; o < q; ++o)
       SBO_HIP(hipMemcpyAsync(w.W + (size_t)o * nn, host_invK[o], sizeof(double) * nn, hipMemcpyHostToDevice, c->stream));
     c->invk_w_valid = std::is_same<T, double>::value && !c->is_shadow;
+    c->invk_plain = w.W;
   }
   SBO_HIP(hipMemsetAsync(dalpha, 0, sizeof(double) * (size_t)q * npad, c->stream));
   SBO_HIP(hipMemsetAsync(w.bad, 0, sizeof(int) * q, c->stream));

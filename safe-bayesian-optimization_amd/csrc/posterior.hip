@@ -904,6 +904,7 @@ static bool grid_path_ok(const sbo_ctx* c) {
 }
 
 int launch_posterior(sbo_ctx* c) {
+  c->gb_active = false;                    // (the approximating paths K1b / K1t switch their guard band on themselves)
   // block-triangular contraction as issued: npad (npad + 16) / 2 multiply-adds per candidate and output
   const double tri_flops = (double)c->mc.q * c->mc.npad * (c->mc.npad + 16.0) * (double)c->cs.n_local;
   if (grid_path_ok(c)) {
@@ -969,6 +970,40 @@ int launch_posterior_on_axes(sbo_ctx* c, int d, const long long* count, const do
   c->mean = keep_m;
   c->var = keep_v;
   c->Lmax = keep_l;
+  return rc;
+}
+
+// the exact posterior of the generic kernel on an explicit fp64 list, into caller-given arrays (the context's candidate
+// description and posterior buffers are swapped for the call; its plans and flags are left as they were)
+int launch_posterior_on_list(sbo_ctx* c, const double* pts, long long N, double* mean_out, double* var_out) {
+  if (c->dtype != SBO_F64) return fail(SBO_E_UNSUPPORTED, "internal: exact lists are an fp64 path");
+  const CandSpec keep_cs = c->cs;
+  const DevBuf keep_m = c->mean, keep_v = c->var, keep_l = c->Lmax;
+  const int keep_k1 = c->last_k1;
+  const double keep_flops = c->last_k1_flops;
+  const bool keep_gb = c->gb_active, keep_busy = c->tensor_busy;
+  int rc;
+  if ((rc = ensure(c->list_scr, 512))) return rc;
+  memset(&c->cs, 0, sizeof(c->cs));
+  c->cs.kind = 0;
+  c->cs.d = keep_cs.d;
+  c->cs.pts_dtype = SBO_F64;
+  c->cs.pts = pts;
+  c->cs.n_local = N;
+  c->cs.first = 0;
+  c->mean.p = mean_out;
+  c->var.p = var_out;
+  c->Lmax.p = c->list_scr.p;                   // (the Lipschitz keys of the list are of no interest)
+  c->tensor_busy = true;                       // (launch_posterior must not come back to the tensor path)
+  rc = launch_posterior(c);
+  c->tensor_busy = keep_busy;
+  c->cs = keep_cs;
+  c->mean = keep_m;
+  c->var = keep_v;
+  c->Lmax = keep_l;
+  c->last_k1 = keep_k1;
+  c->last_k1_flops = keep_flops;
+  c->gb_active = keep_gb;
   return rc;
 }
 

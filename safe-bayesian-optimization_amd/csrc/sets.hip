@@ -43,19 +43,64 @@ struct SweepScalars {
   double arg_val[kArgSlots];
   long long arg_idx[kArgSlots];
   unsigned long long ticket;               // workgroups of k_goose_finals that have finished their slot (zeroed with the block)
+  // Guard band of an approximating posterior (device_common.hpp: GuardBand); all zero when the posterior kernel is exact.
+  // n_guard: decisions of this sweep inside the band, from the classification (set by its merge) and the verdict kernels
+  // (atomics: rare); guard_slot[s]: the same from slot s of the final reductions (M-band members, an undecided arg-reduction).
+  long long n_guard, n_guard_cls;          // (n_guard_cls: the classification's share, the value n_guard starts from)
+  long long guard_slot[kArgSlots];
+  long long guard_nb0;                     // slot 0's share that is not its arg-reduction (members of M inside the band): ranks > 1 sum it
+  unsigned long long vmin_key[kMaxQ];      // min over S of ord_key(var_o): bounds the band of a bound's square root on S
+  double gb_du[kMaxQ];                     // band of ucb_o / lcb_o on S: dm_o + b |d sqrt(var_o)| at the smallest variance over S
+  double gb_rl[kMaxQ];                     // relative band of the Lipschitz keys
+  double arg_d[kArgSlots], arg_e1[kArgSlots], arg_e2[kArgSlots];   // arg-reductions: the winner's band and the two extreme far
+  long long arg_ei[kArgSlots];             //   ends over all candidates (ranks > 1: merged by the host, see sweep_exchange_back)
 };
 
+// Result of a masked arg-reduction over values known to +- d.  (v, i): the winner, ties -> lowest flat index; d: its band;
+// e1 / e2: the two most extreme FAR ends over all candidates (v + d for an arg-max: how high could it be; v - d for an
+// arg-min), ei: the candidate e1 belongs to.  The reduction is settled when no candidate other than the winner has a far end
+// beyond the winner's near end (arg_near); with d = 0 everywhere that is "no exact tie", which the index rule decides.
 struct Best {
   double v;
   long long i;   // global flat index, -1 = none
+  double d;
+  double e1, e2;
+  long long ei;
 };
+template <bool MAX>
+__host__ __device__ __forceinline__ Best best_none() { return Best{0.0, -1, 0.0, MAX ? -kInfD : kInfD, MAX ? -kInfD : kInfD, -1}; }
 
 template <bool MAX>
-__device__ __forceinline__ bool better(const Best& a, const Best& b) {
+__host__ __device__ __forceinline__ bool better(const Best& a, const Best& b) {
   if (a.i < 0) return false;
   if (b.i < 0) return true;
   if (MAX ? (a.v > b.v) : (a.v < b.v)) return true;
   return a.v == b.v && a.i < b.i;   // ties -> lowest flat index
+}
+template <bool MAX>
+__host__ __device__ __forceinline__ void ends_take(Best& B, double end, long long i) {
+  if (MAX ? (end > B.e1) : (end < B.e1)) { B.e2 = B.e1; B.e1 = end; B.ei = i; }
+  else if (MAX ? (end > B.e2) : (end < B.e2)) B.e2 = end;
+}
+// candidate i with value v +- d
+template <bool MAX>
+__host__ __device__ __forceinline__ void best_take(Best& B, double v, double d, long long i) {
+  if (B.i < 0 || (MAX ? (v > B.v) : (v < B.v)) || (v == B.v && i < B.i)) { B.v = v; B.i = i; B.d = d; }
+  ends_take<MAX>(B, MAX ? v + d : v - d, i);
+}
+template <bool MAX>
+__host__ __device__ __forceinline__ Best best_merge(const Best& a, const Best& b) {
+  Best r = a;
+  if (better<MAX>(b, a)) { r.v = b.v; r.i = b.i; r.d = b.d; }
+  ends_take<MAX>(r, b.e1, b.ei);           // (no-op for an empty b: its ends are the sentinels)
+  if (MAX ? (b.e2 > r.e2) : (b.e2 < r.e2)) r.e2 = b.e2;
+  return r;
+}
+template <bool MAX>
+__host__ __device__ __forceinline__ bool arg_near(const Best& w) {
+  if (w.i < 0) return false;
+  const double other = w.ei == w.i ? w.e2 : w.e1;          // the most extreme far end among the OTHER candidates
+  return MAX ? !(other < w.v - w.d) : !(other > w.v + w.d);
 }
 
 template <bool MAX>
@@ -65,7 +110,11 @@ __device__ __forceinline__ Best wave_best(Best x) {
     Best y;
     y.v = __shfl_xor(x.v, o);
     y.i = __shfl_xor(x.i, o);
-    if (better<MAX>(y, x)) x = y;
+    y.d = __shfl_xor(x.d, o);
+    y.e1 = __shfl_xor(x.e1, o);
+    y.e2 = __shfl_xor(x.e2, o);
+    y.ei = __shfl_xor(x.ei, o);
+    x = best_merge<MAX>(x, y);
   }
   return x;
 }
@@ -79,7 +128,7 @@ __device__ __forceinline__ Best block_best(Best x) {
   if (lane == 0) sh[wave] = x;
   __syncthreads();
   if (wave == 0) {
-    Best y = lane < nw ? sh[lane] : Best{0.0, -1};
+    Best y = lane < nw ? sh[lane] : best_none<MAX>();
     y = wave_best<MAX>(y);
     x = y;
   }
@@ -124,18 +173,31 @@ __device__ __forceinline__ void lcb_ucb(T m, T v, T b, T& lcb, T& ucb) {
   ucb = add_rn(m, sd);
 }
 
-constexpr int kClassifyRow = 3 + kMaxQ;   // u* key, |S|, |U|, radius keys
+// a workgroup's partial row of the classification: u* key, |S|, |U|, decisions inside the guard band, min-variance keys over S
+// per output (~0: none), radius keys per constraint
+constexpr int kClassifyRow = 4 + 2 * kMaxQ;
+constexpr int kRowVmin = 4, kRowRmax = 4 + kMaxQ;
 
 // ---- K3a: S / U masks, u* --------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, const T* __restrict__ var, long long n,
                                                   int q, T b, uint8_t* __restrict__ S, uint8_t* __restrict__ U,
-                                                  unsigned long long* __restrict__ part /* [gridDim.x][kClassifyRow] */) {
+                                                  unsigned long long* __restrict__ part /* [gridDim.x][kClassifyRow] */,
+                                                  const GuardBand* __restrict__ gb /* nullptr: the posterior is exact */) {
   __shared__ unsigned long long rmax_sh[kMaxQ];   // max over S of ucb_c: bounds the expander search radius
   if (threadIdx.x < kMaxQ) rmax_sh[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long umin = ~0ull;
-  long long cS = 0, cU = 0;
+  long long cS = 0, cU = 0, cB = 0;
+  // guard band (fp64 approximating posteriors): sign tests that the band could move are counted, and the smallest variance over
+  // S is kept per output (it bounds the band of sqrt(var) on S for the kernels that follow)
+  double gdm[kMaxQ], gdv[kMaxQ], vmin[kMaxQ];
+#pragma unroll
+  for (int c = 0; c < kMaxQ; ++c) {
+    gdm[c] = (gb && c < q) ? gb->dm[c] : 0.0;
+    gdv[c] = (gb && c < q) ? gb->dv[c] : 0.0;
+    vmin[c] = kInfD;
+  }
   // constraints first (S / U bits, ucb_c for the radius keys); the objective's mean / var are read for safe candidates
   // only -- S is a fifth of config B's grid, so the kernel streams (q - 1) / q of the posterior plus that fifth
   // fp64: the sign of every lcb_c without the square root (lcb_sign), and the exact ucb_c -- for the radius keys -- only of
@@ -151,6 +213,7 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
           const LcbSign sg = lcb_sign((double)mv[2 * c], (double)mv[2 * c + 1], (double)b, bb);
           s_ = s_ && sg.ge;
           u = u && sg.le;
+          if (gb) cB += lcb_near_zero((double)mv[2 * c], (double)mv[2 * c + 1], bb, gdm[c], gdv[c]);
         } else {
           T lcb;
           lcb_ucb(mv[2 * c], mv[2 * c + 1], b, lcb, ucbc[c]);   // one sqrt per (candidate, constraint)
@@ -164,6 +227,12 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
     return (unsigned)(s_ ? 1u : 0u) | (unsigned)(u ? 2u : 0u);
   };
   auto objective = [&](T m0, T v0, const T* mv, const T* ucbc) {       // a safe candidate: u* key and radius keys
+    if (gb) {
+      vmin[0] = fmin(vmin[0], (double)v0);
+#pragma unroll
+      for (int c = 1; c < kMaxQ; ++c)
+        if (c < q) vmin[c] = fmin(vmin[c], (double)mv[2 * c + 1]);
+    }
     bool need = true;
     if constexpr (kFast) need = !(ord_key(ucb_lower((double)m0, (double)v0, (double)b)) >= umin);
     if (need) {
@@ -234,6 +303,15 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
   umin = block_ext_u64<false>(umin);
   cS = block_sum_ll(cS);
   cU = block_sum_ll(cU);
+  unsigned long long vk[kMaxQ];
+#pragma unroll
+  for (int c = 0; c < kMaxQ; ++c) vk[c] = ~0ull;
+  if (gb) {
+    cB = block_sum_ll(cB);
+#pragma unroll
+    for (int c = 0; c < kMaxQ; ++c)
+      if (c < q) vk[c] = block_ext_u64<false>(vmin[c] < kInfD ? ord_key(vmin[c]) : ~0ull);
+  }
   __syncthreads();
   // per-workgroup partials, merged by k_classify_final (atomics of every workgroup on one cache line serialise in L2:
   // ~10 ns each, which was most of this kernel's time)
@@ -242,8 +320,11 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
     row[0] = umin;
     row[1] = (unsigned long long)cS;
     row[2] = (unsigned long long)cU;
+    row[3] = (unsigned long long)cB;
+#pragma unroll
+    for (int c = 0; c < kMaxQ; ++c) row[kRowVmin + c] = vk[c];
   }
-  if (threadIdx.x < kMaxQ) row[3 + threadIdx.x] = rmax_sh[threadIdx.x];
+  if (threadIdx.x < kMaxQ) row[kRowRmax + threadIdx.x] = rmax_sh[threadIdx.x];
 }
 
 // start of a sweep's scalar block: cleared, then u*, |S|, |U| and the radius keys merged from k_classify's partials
@@ -256,20 +337,22 @@ struct FinalJob {
   int per_out = 0;
   unsigned long long* Lmax = nullptr;
   SweepScalars* sc_copy = nullptr;            // the second lane's block: a snapshot of the merged scalars (nullptr: one lane)
+  const GuardBand* gb = nullptr;              // band of an approximating posterior (nullptr: exact)
+  double b = 0.0;                             // the sweep's confidence multiplier (enters the band of the bounds)
 };
 __device__ __forceinline__ void classify_final_body(const unsigned long long* __restrict__ part, int nparts, int q, SweepScalars* sc,
                                                     const double* __restrict__ Lpart, int per_out, unsigned long long* Lmax,
-                                                    SweepScalars* sc_copy = nullptr) {
+                                                    SweepScalars* sc_copy, const GuardBand* gb, double b) {
   __shared__ double lsh[4];
   if (Lpart)
     for (int o = 0; o < q; ++o) lmax_reduce_body(o, lsh, Lpart, per_out, Lmax);
   unsigned long long* w = reinterpret_cast<unsigned long long*>(sc);       // (the struct is a multiple of 8 bytes)
   for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) w[i] = 0ull;
   __syncthreads();
-  unsigned long long umin = ~0ull, rmax[kMaxQ];
-  long long cS = 0, cU = 0;
+  unsigned long long umin = ~0ull, rmax[kMaxQ], vmin[kMaxQ];
+  long long cS = 0, cU = 0, cB = 0;
 #pragma unroll
-  for (int c = 0; c < kMaxQ; ++c) rmax[c] = 0ull;
+  for (int c = 0; c < kMaxQ; ++c) { rmax[c] = 0ull; vmin[c] = ~0ull; }
   // (one workgroup walks all rows: four rows' loads in flight per thread and only the q columns that carry anything -- with a
   // row at a time the 16 rounds of eleven strided loads were the longest job of the launch this merge shares on config H)
   for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * blockDim.x) {
@@ -283,7 +366,7 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
       v1[j] = on ? row[1] : 0ull;
       v2[j] = on ? row[2] : 0ull;
 #pragma unroll
-      for (int c = 1; c < kMaxQ; ++c) vr[j][c] = (on && c < q) ? row[3 + c] : 0ull;
+      for (int c = 1; c < kMaxQ; ++c) vr[j][c] = (on && c < q) ? row[kRowRmax + c] : 0ull;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -293,6 +376,18 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
 #pragma unroll
       for (int c = 1; c < kMaxQ; ++c) rmax[c] = vr[j][c] > rmax[c] ? vr[j][c] : rmax[c];
     }
+    if (gb) {                                   // (the band's columns: read only when a band is in force)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * blockDim.x;
+        if (i >= nparts) continue;
+        const unsigned long long* row = part + (size_t)i * kClassifyRow;
+        cB += (long long)row[3];
+#pragma unroll
+        for (int c = 0; c < kMaxQ; ++c)
+          if (c < q) { const unsigned long long k = row[kRowVmin + c]; vmin[c] = k < vmin[c] ? k : vmin[c]; }
+      }
+    }
   }
   umin = block_ext_u64<false>(umin);
   cS = block_sum_ll(cS);
@@ -300,6 +395,12 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
 #pragma unroll
   for (int c = 1; c < kMaxQ; ++c)
     if (c < q) rmax[c] = block_ext_u64<true>(rmax[c]);
+  if (gb) {
+    cB = block_sum_ll(cB);
+#pragma unroll
+    for (int c = 0; c < kMaxQ; ++c)
+      if (c < q) vmin[c] = block_ext_u64<false>(vmin[c]);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     sc->ustar_key = umin;
@@ -307,6 +408,20 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
     sc->count_U = cU;
 #pragma unroll
     for (int c = 1; c < kMaxQ; ++c) sc->rmax_key[c] = c < q ? rmax[c] : 0ull;
+    if (gb) {
+      // the band of every bound on S from the smallest variance over S (the band of a square root grows as its argument shrinks)
+      sc->n_guard = cB;
+      sc->n_guard_cls = cB;
+#pragma unroll
+      for (int c = 0; c < kMaxQ; ++c) {
+        if (c < q) {
+          sc->vmin_key[c] = vmin[c];
+          const double vm = vmin[c] != ~0ull ? fmax(0.0, ord_val(vmin[c])) : 0.0;
+          sc->gb_du[c] = gb->dm[c] + b * gb_dsqrt(vm, gb->dv[c]);
+          sc->gb_rl[c] = gb->rl[c];
+        }
+      }
+    }
   }
   if (threadIdx.x < kArgSlots) sc->arg_idx[threadIdx.x] = -1;
   if (sc_copy) {
@@ -320,8 +435,8 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
 }
 __global__ __launch_bounds__(256) void k_classify_final(const unsigned long long* __restrict__ part, int nparts, int q,
                                                         SweepScalars* sc, const double* __restrict__ Lpart, int per_out,
-                                                        unsigned long long* Lmax, SweepScalars* sc_copy) {
-  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax, sc_copy);
+                                                        unsigned long long* Lmax, SweepScalars* sc_copy, const GuardBand* gb, double b) {
+  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax, sc_copy, gb, b);
 }
 
 // Objective pass of a classification whose S / U bytes came out of the posterior kernel (K1b, one constraint): u* = min over
@@ -329,8 +444,9 @@ __global__ __launch_bounds__(256) void k_classify_final(const unsigned long long
 __device__ __forceinline__ bool tile_byte(unsigned long long w, int k, int lane);
 template <typename T>
 __device__ __forceinline__ unsigned long long ustar_partial_body(int bid, int nwg, const T* __restrict__ mean0, const T* __restrict__ var0,
-                                                                 long long n, T b, const uint8_t* __restrict__ S) {
+                                                                 long long n, T b, const uint8_t* __restrict__ S, double& vmin0) {
   unsigned long long umin = ~0ull;
+  vmin0 = kInfD;                                    // smallest var_0 over S seen by this thread (guard band, see k_classify)
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)bid * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)nwg * blockDim.x) >> 6;
   const long long ntiles = (((uintptr_t)S) & 7) == 0 ? n / 512 : 0;
@@ -368,19 +484,27 @@ __device__ __forceinline__ unsigned long long ustar_partial_body(int bid, int nw
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (set[k]) take(mu[k], va[k]);
+      if (set[k]) { vmin0 = fmin(vmin0, (double)va[k]); take(mu[k], va[k]); }
     }
   }
   for (long long g = ntiles * 512 + (long long)bid * blockDim.x + threadIdx.x; g < n; g += (long long)nwg * blockDim.x)
-    if (S[g]) take(mean0[g], var0[g]);
+    if (S[g]) { const T v = var0[g]; vmin0 = fmin(vmin0, (double)v); take(mean0[g], v); }
   return block_ext_u64<false>(umin);   // valid in thread 0
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_classify_obj(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b,
                                                       const uint8_t* __restrict__ S, unsigned long long* __restrict__ part) {
-  const unsigned long long umin = ustar_partial_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, b, S);
+  double vmin0;
+  const unsigned long long umin = ustar_partial_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, b, S, vmin0);
+  const unsigned long long vk = block_ext_u64<false>(vmin0 < kInfD ? ord_key(vmin0) : ~0ull);
+  __shared__ unsigned long long keys[2];
+  if (threadIdx.x == 0) { keys[0] = umin; keys[1] = vk; }
+  __syncthreads();
   unsigned long long* row = part + (size_t)blockIdx.x * kClassifyRow;
-  if (threadIdx.x < kClassifyRow) row[threadIdx.x] = threadIdx.x == 0 ? umin : 0ull;
+  if (threadIdx.x < kClassifyRow) {
+    const int t = threadIdx.x;
+    row[t] = t == 0 ? keys[0] : (t == kRowVmin ? keys[1] : ((t > kRowVmin && t < kRowRmax) ? ~0ull : 0ull));
+  }
 }
 
 // Mask-driven loops of K3b / K5.  A wave takes tiles of 512 consecutive candidates: every lane reads eight mask bytes
@@ -396,10 +520,14 @@ __device__ __forceinline__ bool tile_byte(unsigned long long w, int k, int lane)
 template <typename T>
 __device__ __forceinline__ void minimizer_body(int bid, int nwg, const T* __restrict__ mean0, const T* __restrict__ var0, long long n,
                                                long long first, T b, const uint8_t* __restrict__ S, uint8_t* __restrict__ M,
-                                               unsigned long long ustar_key, Best* partial) {
+                                               unsigned long long ustar_key, Best* partial, const SweepScalars* sc,
+                                               const GuardBand* __restrict__ gb) {
   const T ustar = (T)ord_val(ustar_key);
-  Best best{0.0, -1};
-  long long cM = 0;
+  Best best = best_none<true>();
+  long long cM = 0, cB = 0;
+  // guard band: u* and every lcb_0 on S are known to +- gb_du[0], so |lcb_0 - u*| <= 2 gb_du[0] leaves "lcb_0 <= u*" open;
+  // var_0 is known to +- dv[0] (the arg-max's band)
+  const double dM = gb ? 2.0 * sc->gb_du[0] * (1.0 + 0x1p-40) : -1.0, dv0 = gb ? gb->dv[0] : 0.0;
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)bid * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)nwg * blockDim.x) >> 6;
   const long long ntiles = (((uintptr_t)S) & 7) == 0 ? n / 512 : 0;
@@ -428,12 +556,13 @@ __device__ __forceinline__ void minimizer_body(int bid, int nwg, const T* __rest
         T lcb, ucb;
         lcb_ucb(mu[k], va[k], b, lcb, ucb);
         m = lcb <= ustar;                     // models/SafeOpt.py:62
+        const double gap = (double)lcb - (double)ustar;
+        cB += (gap < 0 ? -gap : gap) <= dM;
       }
       M[g] = m;
       if (m) {
         ++cM;
-        const Best cand{(double)va[k], first + g};
-        if (better<true>(cand, best)) best = cand;
+        best_take<true>(best, (double)va[k], dv0, first + g);
       }
     }
   }
@@ -443,43 +572,53 @@ __device__ __forceinline__ void minimizer_body(int bid, int nwg, const T* __rest
       T lcb, ucb;
       lcb_ucb(mean0[g], var0[g], b, lcb, ucb);
       m = lcb <= ustar;                       // models/SafeOpt.py:62
+      const double gap = (double)lcb - (double)ustar;
+      cB += (gap < 0 ? -gap : gap) <= dM;
     }
     M[g] = m;
     if (m) {
       ++cM;
-      const Best cand{(double)var0[g], first + g};
-      if (better<true>(cand, best)) best = cand;
+      best_take<true>(best, (double)var0[g], dv0, first + g);
     }
   }
   best = block_best<true>(best);
   cM = block_sum_ll(cM);
+  cB = block_sum_ll(cB);
   if (threadIdx.x == 0) {
     partial[bid] = best;
     ((long long*)(partial + nwg))[bid] = cM;   // summed by the finals (an atomic per workgroup on one counter serialises)
+    ((long long*)(partial + nwg))[nwg + bid] = cB;
   }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, const T* __restrict__ var0, long long n,
                                                    long long first, T b, const uint8_t* __restrict__ S,
-                                                   uint8_t* __restrict__ M, SweepScalars* sc, Best* partial) {
-  minimizer_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, first, b, S, M, sc->ustar_key, partial);
+                                                   uint8_t* __restrict__ M, SweepScalars* sc, Best* partial, const GuardBand* gb) {
+  minimizer_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, first, b, S, M, sc->ustar_key, partial, sc, gb);
 }
 
 // value sources of the masked arg-reductions: an array, or the value computed for the candidates whose mask byte is set
 // only (no pass over all candidates to fill an array first)
+// (`d`: the band of the value under the guard band of an approximating posterior -- bind() loads the band's scalars once)
 template <typename T>
-struct ValArray {
+struct ValArray {          // var_0
   const T* p;
-  __device__ __forceinline__ T operator()(long long g) const { return p[g]; }
+  double dv;
+  __device__ __forceinline__ void bind(const GuardBand* gb) { dv = gb ? gb->dv[0] : 0.0; }
+  __device__ __forceinline__ T operator()(long long g, double& d) const { d = dv; return p[g]; }
 };
 template <typename T>
 struct ValLcb {            // lcb_0 = mean_0 - b sqrt(var_0), models/GoOSE.py:72, models/GP_TR.py:45
   const T* m;
   const T* v;
   T b;
-  __device__ __forceinline__ T operator()(long long g) const {
+  double dm, dv;
+  __device__ __forceinline__ void bind(const GuardBand* gb) { dm = gb ? gb->dm[0] : 0.0; dv = gb ? gb->dv[0] : 0.0; }
+  __device__ __forceinline__ T operator()(long long g, double& d) const {
     T lcb, ucb;
-    lcb_ucb(m[g], v[g], b, lcb, ucb);
+    const T vv = v[g];
+    lcb_ucb(m[g], vv, b, lcb, ucb);
+    d = dv > 0.0 ? dm + (double)b * gb_dsqrt((double)vv, dv) : dm;
     return lcb;
   }
 };
@@ -487,7 +626,9 @@ template <typename T, int D>
 struct ValDist {           // Euclidean distance to the target, as scipy.spatial.distance.cdist computes it (models/GoOSE.py:117)
   CandSpec cs;
   const double* target;
-  __device__ __forceinline__ T operator()(long long g) const {
+  __device__ __forceinline__ void bind(const GuardBand*) {}
+  __device__ __forceinline__ T operator()(long long g, double& d) const {
+    d = 0.0;                               // (geometry: exact)
     double x[D];
     cand_coords<D>(cs, g, x);
     double ss = 0.0;
@@ -504,9 +645,11 @@ struct ValDist {           // Euclidean distance to the target, as scipy.spatial
 
 // generic masked arg-max / arg-min of a value source, plus the mask population
 template <typename T, bool MAX, typename V>
-__device__ __forceinline__ void arg_masked_body(int bid, int nwg, const V& val, const uint8_t* __restrict__ mask, long long n,
-                                                long long first, Best* partial) {
-  Best best{0.0, -1};
+__device__ __forceinline__ void arg_masked_body(int bid, int nwg, const V& val_in, const uint8_t* __restrict__ mask, long long n,
+                                                long long first, Best* partial, const GuardBand* __restrict__ gb) {
+  V val = val_in;
+  val.bind(gb);
+  Best best = best_none<MAX>();
   long long cnt = 0;
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)bid * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)nwg * blockDim.x) >> 6;
@@ -516,26 +659,28 @@ __device__ __forceinline__ void arg_masked_body(int bid, int nwg, const V& val, 
     const unsigned long long w = ((const unsigned long long*)(mask + base))[lane];
     if (__ballot(w != 0ull) == 0ull) continue;
     T v[8];
+    double dd[8];
     bool set[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       set[k] = tile_byte(w, k, lane);
-      v[k] = set[k] ? val(base + k * 64 + lane) : (T)0;
+      dd[k] = 0.0;
+      v[k] = set[k] ? val(base + k * 64 + lane, dd[k]) : (T)0;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (set[k]) {
         ++cnt;
-        const Best cand{(double)v[k], first + base + k * 64 + lane};
-        if (better<MAX>(cand, best)) best = cand;
+        best_take<MAX>(best, (double)v[k], dd[k], first + base + k * 64 + lane);
       }
     }
   }
   for (long long g = ntiles * 512 + (long long)bid * blockDim.x + threadIdx.x; g < n; g += (long long)nwg * blockDim.x) {
     if (mask[g]) {
       ++cnt;
-      const Best cand{(double)val(g), first + g};
-      if (better<MAX>(cand, best)) best = cand;
+      double d = 0.0;
+      const T v = val(g, d);
+      best_take<MAX>(best, (double)v, d, first + g);
     }
   }
   best = block_best<MAX>(best);
@@ -543,39 +688,64 @@ __device__ __forceinline__ void arg_masked_body(int bid, int nwg, const V& val, 
   if (threadIdx.x == 0) {
     partial[bid] = best;
     ((long long*)(partial + nwg))[bid] = cnt;
+    ((long long*)(partial + nwg))[nwg + bid] = 0;
   }
 }
 template <typename T, bool MAX, typename V>
 __global__ __launch_bounds__(256) void k_arg_masked(const V val, const uint8_t* __restrict__ mask, long long n,
-                                                    long long first, Best* partial) {
-  arg_masked_body<T, MAX, V>((int)blockIdx.x, (int)gridDim.x, val, mask, n, first, partial);
+                                                    long long first, Best* partial, const GuardBand* gb) {
+  arg_masked_body<T, MAX, V>((int)blockIdx.x, (int)gridDim.x, val, mask, n, first, partial, gb);
 }
 // the same for several masks in one launch: blockIdx.y = s selects slot slot0 + s -- mask0 for slot 0, masks + (slot - 1) n
 // otherwise -- and region slot of the partials (stride pstride bytes); the reductions are independent of each other
 template <typename T, bool MAX, typename V>
 __global__ __launch_bounds__(256) void k_arg_masked_multi(const V val, const uint8_t* __restrict__ mask0, const uint8_t* __restrict__ masks,
-                                                          long long n, long long first, unsigned char* pbase, size_t pstride, int slot0) {
+                                                          long long n, long long first, unsigned char* pbase, size_t pstride, int slot0,
+                                                          const GuardBand* gb) {
   const int slot = slot0 + (int)blockIdx.y;
   const uint8_t* mask = slot == 0 ? mask0 : masks + (size_t)(slot - 1) * n;
-  arg_masked_body<T, MAX, V>((int)blockIdx.x, (int)gridDim.x, val, mask, n, first, reinterpret_cast<Best*>(pbase + pstride * (size_t)slot));
+  arg_masked_body<T, MAX, V>((int)blockIdx.x, (int)gridDim.x, val, mask, n, first, reinterpret_cast<Best*>(pbase + pstride * (size_t)slot), gb);
 }
 
-// partial: Best[nparts] followed by the workgroups' mask populations long long[nparts]; their sum is added to *count
+// A region of partials: Best[nparts], then the workgroups' mask populations long long[nparts], then their guard-band counts
+// long long[nparts] (members of M inside the band of lcb_0 <= u*; zero for the plain arg-reductions).
+__host__ __device__ __forceinline__ size_t partial_stride(int nparts) { return (sizeof(Best) + 2 * sizeof(long long)) * (size_t)nparts; }
+// merge of one region by a workgroup; the results are valid in thread 0
 template <bool MAX>
-__global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ partial, int nparts, SweepScalars* sc, int slot,
-                                                   long long* count) {
-  Best best{0.0, -1};
-  long long cnt = 0;
+__device__ __forceinline__ void merge_region(const Best* __restrict__ partial, int nparts, Best& best, long long& cnt, long long& nb) {
+  best = best_none<MAX>();
+  cnt = 0;
+  nb = 0;
   const long long* pc = (const long long*)(partial + nparts);
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    if (better<MAX>(partial[i], best)) best = partial[i];
+    best = best_merge<MAX>(best, partial[i]);
     cnt += pc[i];
+    nb += pc[nparts + i];
   }
   best = block_best<MAX>(best);
   cnt = block_sum_ll(cnt);
+  nb = block_sum_ll(nb);
+}
+// thread 0 of a merging workgroup: the slot's results, and what the guard band leaves open in it (gb_on: a band is in force)
+template <bool MAX>
+__device__ __forceinline__ void store_slot(SweepScalars* sc, int slot, const Best& best, long long nb, bool gb_on) {
+  sc->arg_val[slot] = best.v;
+  sc->arg_idx[slot] = best.i;
+  sc->arg_d[slot] = best.d;
+  sc->arg_e1[slot] = best.e1;
+  sc->arg_e2[slot] = best.e2;
+  sc->arg_ei[slot] = best.ei;
+  sc->guard_slot[slot] = gb_on ? nb + (arg_near<MAX>(best) ? 1 : 0) : 0;
+  if (slot == 0) sc->guard_nb0 = gb_on ? nb : 0;
+}
+template <bool MAX>
+__global__ __launch_bounds__(256) void k_arg_final(const Best* __restrict__ partial, int nparts, SweepScalars* sc, int slot,
+                                                   long long* count, int gb_on) {
+  Best best;
+  long long cnt, nb;
+  merge_region<MAX>(partial, nparts, best, cnt, nb);
   if (threadIdx.x == 0) {
-    sc->arg_val[slot] = best.v;
-    sc->arg_idx[slot] = best.i;
+    store_slot<MAX>(sc, slot, best, nb, gb_on != 0);
     if (count) *count += cnt;
   }
 }
@@ -587,8 +757,11 @@ template <bool MAX>
 __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts,
                                                       SweepScalars* sc, const SweepScalars* lane1 /* nullptr, or the second lane's block */,
                                                       unsigned char* mirror /* nullptr, or the host's pinned landing area */,
-                                                      const unsigned long long* Lkeys) {
-  if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
+                                                      const unsigned long long* Lkeys, int gb_on) {
+  if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) {
+    sc->n_amb_total += lane1->n_amb_total;
+    sc->n_guard += lane1->n_guard - lane1->n_guard_cls;      // (the lane's block started as a snapshot: its own additions only)
+  }
   // `mirror`: the results go straight to the pinned host block the read-back would have filled (SweepScalars at 0, the
   // Lipschitz keys at 3072) -- every workgroup its own slot, workgroup 0 the fields earlier kernels finished --, and the
   // sweep's end event rides on this launch: no copy kernel and no barrier packet behind the last kernel.
@@ -601,31 +774,28 @@ __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __res
       hm->n_amb = sc->n_amb;
       hm->n_amb_total = sc->n_amb_total;
       hm->n_scan = sc->n_scan;
+      hm->n_guard = sc->n_guard;
     }
     if (threadIdx.x < kMaxQ) {
       hm->rmax_key[threadIdx.x] = sc->rmax_key[threadIdx.x];
+      hm->gb_du[threadIdx.x] = sc->gb_du[threadIdx.x];
       reinterpret_cast<unsigned long long*>(mirror + 3072)[threadIdx.x] = Lkeys[threadIdx.x];
     }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kArgSlots && (int)threadIdx.x - 64 >= (int)gridDim.x) hm->guard_slot[threadIdx.x - 64] = 0;
   }
   const int slot = blockIdx.x;
-  const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
-  Best best{0.0, -1};
-  long long cnt = 0;
-  const long long* pc = (const long long*)(partial + nparts);
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    if (better<MAX>(partial[i], best)) best = partial[i];
-    cnt += pc[i];
-  }
-  best = block_best<MAX>(best);
-  cnt = block_sum_ll(cnt);
+  Best best;
+  long long cnt, nb;
+  merge_region<MAX>(reinterpret_cast<const Best*>(regions + (size_t)slot * stride), nparts, best, cnt, nb);
   if (threadIdx.x == 0) {
-    sc->arg_val[slot] = best.v;
-    sc->arg_idx[slot] = best.i;
+    store_slot<MAX>(sc, slot, best, nb, gb_on != 0);
     if (slot == 0) { if (MAX) sc->count_M += cnt; }
     else sc->count_set[slot - 1] += cnt;
     if (mirror) {
       hm->arg_val[slot] = best.v;
       hm->arg_idx[slot] = best.i;
+      hm->arg_d[slot] = best.d;
+      hm->guard_slot[slot] = sc->guard_slot[slot];
       if (slot == 0) hm->count_M = sc->count_M;
       else hm->count_set[slot - 1] = sc->count_set[slot - 1];
     }
@@ -664,6 +834,7 @@ struct MidJobs {
   const uint8_t* S;
   uint8_t* M;
   Best* partial;
+  const GuardBand* gb;
   int nm;                                  // block minima (0: none); din: the axis-0 image (doubles, or step counts with h0)
   double h0;
   const double* din;
@@ -678,7 +849,7 @@ __global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
   if (bid < j.ns)
     edt_scan_body(bid, j.ns, j.dc_in, j.dc_out, j.nc, j.cstride, j.ccnt, j.hc, j.sc, j.cidx, j.Lkeys, j.lidx, 0, j.cap_extra);
   else if (bid < j.ns + j.nb)
-    minimizer_body<T>(bid - j.ns, j.nb, j.mean0, j.var0, j.n, j.first, j.b, j.S, j.M, j.sc->ustar_key, j.partial);
+    minimizer_body<T>(bid - j.ns, j.nb, j.mean0, j.var0, j.n, j.first, j.b, j.S, j.M, j.sc->ustar_key, j.partial, j.sc, j.gb);
   else if (U16)
     block_min_body(bid - j.ns - j.nb, j.nm, part, DistU16{reinterpret_cast<const unsigned short*>(j.din), j.h0}, j.stride, j.cnt, j.blk, j.bmin);
   else
@@ -694,23 +865,21 @@ __global__ __launch_bounds__(256) void k_set_mid(const MidJobs<T> j) {
 // into the host's pinned landing area and carries the sweep's end event (as k_sweep_finals does for SafeOpt).
 template <int D>
 __global__ __launch_bounds__(256) void k_goose_finals(const unsigned char* __restrict__ regions, size_t stride, int nparts, int q, SweepScalars* sc,
-                                                      const SweepScalars* lane1, const CandSpec cs, double* __restrict__ target) {
+                                                      const SweepScalars* lane1, const CandSpec cs, double* __restrict__ target, int gb_on) {
   // workgroup s merges slot s (as k_sweep_finals<false>); the one that finishes last chooses the target
-  if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) sc->n_amb_total += lane1->n_amb_total;
-  const int slot = blockIdx.x;
-  const Best* partial = reinterpret_cast<const Best*>(regions + (size_t)slot * stride);
-  Best best{0.0, -1};
-  long long cnt = 0;
-  const long long* pc = (const long long*)(partial + nparts);
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    if (better<false>(partial[i], best)) best = partial[i];
-    cnt += pc[i];
+  if (lane1 && blockIdx.x == 0 && threadIdx.x == 0) {
+    sc->n_amb_total += lane1->n_amb_total;
+    sc->n_guard += lane1->n_guard - lane1->n_guard_cls;
   }
-  best = block_best<false>(best);
-  cnt = block_sum_ll(cnt);
+  const int slot = blockIdx.x;
+  Best best;
+  long long cnt, nb;
+  merge_region<false>(reinterpret_cast<const Best*>(regions + (size_t)slot * stride), nparts, best, cnt, nb);
   if (threadIdx.x == 0) {
+    store_slot<false>(sc, slot, best, nb, gb_on != 0);
     __hip_atomic_store(&sc->arg_val[slot], best.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&sc->arg_idx[slot], best.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sc->arg_d[slot], best.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (slot > 0) sc->count_set[slot - 1] += cnt;
     __threadfence();
     const unsigned long long t = atomicAdd(&sc->ticket, 1ull);
@@ -718,12 +887,23 @@ __global__ __launch_bounds__(256) void k_goose_finals(const unsigned char* __res
       __threadfence();
       __hip_atomic_store(&sc->ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int best_c = 0;
-      double bestv = 0.0;
+      double bestv = 0.0, bestd = 0.0;
       long long besti = -1;
       for (int cc = 1; cc < q; ++cc) {
         const long long ai = __hip_atomic_load(&sc->arg_idx[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double av = __hip_atomic_load(&sc->arg_val[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ai >= 0 && (best_c == 0 || av < bestv)) { best_c = cc; bestv = av; besti = ai; }
+        if (ai >= 0 && (best_c == 0 || av < bestv)) { best_c = cc; bestv = av; besti = ai; bestd = __hip_atomic_load(&sc->arg_d[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      // the choice among the constraints' targets is itself a decision the band can leave open
+      if (gb_on && best_c) {
+        for (int cc = 1; cc < q; ++cc) {
+          if (cc == best_c) continue;
+          const long long ai = __hip_atomic_load(&sc->arg_idx[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double av = __hip_atomic_load(&sc->arg_val[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double ad = __hip_atomic_load(&sc->arg_d[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (the same candidate in two optimistic sets ties with itself under any posterior: the first minimum wins either way)
+          if (ai >= 0 && ai != besti && !(av - ad > bestv + bestd)) { atomicAdd((unsigned long long*)&sc->n_guard, 1ull); break; }
+        }
       }
       double x[D];
 #pragma unroll
@@ -735,15 +915,11 @@ __global__ __launch_bounds__(256) void k_goose_finals(const unsigned char* __res
   }
 }
 __global__ __launch_bounds__(256) void k_arg_final_mirror(const Best* __restrict__ partial, int nparts, SweepScalars* sc, int slot,
-                                                          unsigned char* mirror, const unsigned long long* __restrict__ Lkeys) {
-  Best best{0.0, -1};
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x)
-    if (better<false>(partial[i], best)) best = partial[i];
-  best = block_best<false>(best);
-  if (threadIdx.x == 0) {
-    sc->arg_val[slot] = best.v;
-    sc->arg_idx[slot] = best.i;
-  }
+                                                          unsigned char* mirror, const unsigned long long* __restrict__ Lkeys, int gb_on) {
+  Best best;
+  long long cnt, nb;
+  merge_region<false>(partial, nparts, best, cnt, nb);
+  if (threadIdx.x == 0) store_slot<false>(sc, slot, best, nb, gb_on != 0);
   __syncthreads();
   const unsigned long long* from = reinterpret_cast<const unsigned long long*>(sc);
   unsigned long long* to = reinterpret_cast<unsigned long long*>(mirror);
@@ -781,12 +957,17 @@ static int sweep_masks(sbo_ctx* c, double b, bool may_fuse) {
 // (second lane of the set phase, see sbo_ctx::lane1 and lane_swap below)
 static bool lanes_on(const sbo_ctx* c) { return c->set_lanes && !multi_rank(c) && c->mc.q >= 3 && c->cs.n_local > 0 && c->stream2; }
 
+// the guard band in force for the running sweep: the posterior in the mean / var buffers came from an approximating kernel
+// (K1b / K1t) -- nullptr for the exact kernels and for fp32 models (whose own recheck covers them)
+static const GuardBand* gb_of(const sbo_ctx* c) {
+  return (c->gb_active && !c->gb_off && c->guard_band && c->dtype == SBO_F64 && c->gb.p) ? (const GuardBand*)c->gb.p : nullptr;
+}
 static void launch_final(sbo_ctx* c, FinalJob* fj) {
   if (!fj || !fj->pending) return;
   fj->pending = false;
   // (with a second lane the fork event rides on this launch as its stop event: a separate record costs the stream a bubble)
   hipExtLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, nullptr, fj->sc_copy ? c->ev_join[4] : nullptr, 0, fj->part,
-                        fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out, fj->Lmax, fj->sc_copy);
+                        fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out, fj->Lmax, fj->sc_copy, fj->gb, fj->b);
 }
 
 // `defer`: the merge of the classification's partials is handed back instead of launched (SafeOpt on one rank: it rides in
@@ -798,12 +979,14 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* def
   int rc;
   if ((rc = ensure(c->scal, sizeof(SweepScalars)))) return rc;
   const int nb = reduce_blocks(c);
-  if ((rc = ensure(c->partial, (sizeof(Best) + sizeof(long long)) * (size_t)nb))) return rc;
+  if ((rc = ensure(c->partial, partial_stride(nb)))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   FinalJob fj;
   fj.pending = true;
   fj.q = q;
   fj.sc = sc;
+  fj.gb = gb_of(c);
+  fj.b = o->b;
   if (lanes_on(c)) {
     if ((rc = ensure(c->lane1.scal, 4096))) return rc;
     fj.sc_copy = (SweepScalars*)c->lane1.scal.p;
@@ -834,7 +1017,7 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* def
   }
   if (n > 0)
     hipLaunchKernelGGL((k_classify<T>), dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
-                       (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p);
+                       (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p, gb_of(c));
   fj.part = (const unsigned long long*)c->cpart.p;
   fj.nparts = n > 0 ? ncb : 0;
   if (defer) *defer = fj;
@@ -992,7 +1175,7 @@ static void launch_minimizer(sbo_ctx* c, const sbo_sweep_opts* o, MinimizerJob* 
   mj->pending = false;
   hipLaunchKernelGGL((k_minimizer<T>), dim3(mj->nb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, c->cs.n_local,
                      (long long)c->cs.first, (T)o->b, (const uint8_t*)c->maskS.p, (uint8_t*)c->maskM.p, (SweepScalars*)c->scal.p,
-                     mj->partial);
+                     mj->partial, gb_of(c));
 }
 
 // `lazy_exact`: the exhaustive recheck of in-band candidates (k_expander_exact) is NOT launched -- the caller looks at the
@@ -1134,6 +1317,7 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
         j.S = (const uint8_t*)c->maskS.p;
         j.M = (uint8_t*)c->maskM.p;
         j.partial = mj->partial;
+        j.gb = gb_of(c);
       }
       if (want_bmin) {
         const int nblocks = (last_cnt_ + blk_ - 1) / blk_;
@@ -1211,6 +1395,10 @@ static int expander_set(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, uint8_t* 
         rx.dv = 1e-4 * ys * ys;
         rx.list = (long long*)((char*)c->rc_list.p + kRcList);
         rx.count = (unsigned long long*)((char*)c->rc_list.p + kRcCount2);
+      }
+      if (gb_of(c)) {                                            // guard band of an approximating fp64 posterior (fast path: no list)
+        rx.gb_c = cidx;
+        rx.gb_l = c->gb_slow ? -1 : lidx;                        // (the slow path has recomputed the Lipschitz keys exactly)
       }
       const dim3 dgrid((unsigned)((len0 + 255) / 256), (unsigned)std::min<long long>((nl + kDecideLines - 1) / kDecideLines, 65535));
 #define SBO_DECIDE(LIST)                                                                                                            \
@@ -1328,7 +1516,7 @@ static int sweep_exchange_front(sbo_ctx* c, const sbo_sweep_opts* o, bool need_U
     // (the bits are expanded to bytes per constraint, window only: expander_set)
   } else {
     hipLaunchKernelGGL(k_pack_c1, dim3(1), dim3(64), 0, c->stream, (const SweepScalars*)sc, (const unsigned long long*)c->Lmax.p, kb);
-    if ((rc = comm_allreduce_max_u64(c, kb, 1 + 2 * kMaxQ))) return rc;
+    if ((rc = comm_allreduce_max_u64(c, kb, kC1Words))) return rc;
     hipLaunchKernelGGL(k_unpack_c1, dim3(1), dim3(64), 0, c->stream, sc, (unsigned long long*)c->Lmax.p, (const unsigned long long*)kb);
   }
   // the host needs the global L and radius keys to size the halo of the expander transform: the read-back goes to
@@ -1372,6 +1560,10 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
     ++c->host_syncs;
     memcpy(&h, c->h_back, sizeof(h));
     if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
+    // decisions the guard band of an approximating posterior leaves open: the classification's and the verdict kernels' count
+    // plus what the final reductions found in their slots
+    if (c->gb_active) for (int t = 0; t < kArgSlots; ++t) h.n_guard += h.guard_slot[t];
+    else h.n_guard = 0;
     return SBO_OK;
   }
   double* buf = (double*)c->xch.p + 64;
@@ -1387,25 +1579,32 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   memcpy(&h, c->h_back, sizeof(h));
   if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
   c->c1_pending = false;                       // (the whole stream has drained)
-  h.count_S = h.count_U = h.count_M = h.n_amb_total = 0;
+  h.count_S = h.count_U = h.count_M = h.n_amb_total = h.n_guard = 0;
   for (int t = 0; t < kMaxQ; ++t) h.count_set[t] = 0;
-  for (int t = 0; t < kArgSlots; ++t) { h.arg_idx[t] = -1; h.arg_val[t] = 0.0; }
+  Best merged[kArgSlots];
+  for (int t = 0; t < kArgSlots; ++t) merged[t] = slot_is_max[t] ? best_none<true>() : best_none<false>();
   for (int r = 0; r < c->world; ++r) {
     const double* row = &rows[(size_t)r * kC3Row];
     for (int t = 0; t < kArgSlots; ++t) {
       const long long idx = (long long)row[kArgSlots + t];
       if (idx < 0) continue;
-      const double v = row[t];
-      const bool mx = slot_is_max[t];
-      const bool take = h.arg_idx[t] < 0 || (mx ? v > h.arg_val[t] : v < h.arg_val[t]) || (v == h.arg_val[t] && idx < h.arg_idx[t]);
-      if (take) { h.arg_val[t] = v; h.arg_idx[t] = idx; }
+      const Best rb{row[t], idx, row[2 * kArgSlots + t], row[3 * kArgSlots + t], row[4 * kArgSlots + t], (long long)row[5 * kArgSlots + t]};
+      merged[t] = slot_is_max[t] ? best_merge<true>(merged[t], rb) : best_merge<false>(merged[t], rb);
     }
-    h.count_S += (long long)row[2 * kArgSlots + 0];
-    h.count_U += (long long)row[2 * kArgSlots + 1];
-    h.count_M += (long long)row[2 * kArgSlots + 2];
-    h.n_amb_total += (long long)row[2 * kArgSlots + 3];
-    for (int t = 0; t < kMaxQ; ++t) h.count_set[t] += (long long)row[2 * kArgSlots + 4 + t];
+    h.count_S += (long long)row[kC3Counts + 0];
+    h.count_U += (long long)row[kC3Counts + 1];
+    h.count_M += (long long)row[kC3Counts + 2];
+    h.n_amb_total += (long long)row[kC3Counts + 3];
+    h.n_guard += (long long)row[kC3Counts + 4];
+    for (int t = 0; t < kMaxQ; ++t) h.count_set[t] += (long long)row[kC3Counts + 5 + t];
   }
+  for (int t = 0; t < kArgSlots; ++t) {
+    h.arg_val[t] = merged[t].i >= 0 ? merged[t].v : 0.0;
+    h.arg_idx[t] = merged[t].i;
+    h.arg_d[t] = merged[t].d;
+    if (c->gb_active && (slot_is_max[t] ? arg_near<true>(merged[t]) : arg_near<false>(merged[t]))) ++h.n_guard;
+  }
+  if (!c->gb_active) h.n_guard = 0;
   return SBO_OK;
 }
 
@@ -1454,7 +1653,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   const bool lazy_exact = c->exact_lazy && q == 2 && !multi_rank(c) && !c->rc_active && c->result_mirror && n > 0 && c->cs.kind == 1 &&
                           c->cs.first % plane_ == 0 && n % plane_ == 0;      // (grids: lists decide every expander exhaustively)
   // partials of the q arg-max reductions side by side: merged by one launch at the end (k_safeopt_finals)
-  const size_t pstride = (sizeof(Best) + sizeof(long long)) * (size_t)nb;
+  const size_t pstride = partial_stride(nb);
   if ((rc = ensure(c->partial, pstride * (size_t)q))) return rc;
   unsigned char* pbase = (unsigned char*)c->partial.p;
   const bool lanes = lanes_on(c);
@@ -1482,14 +1681,14 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   if (n > 0 && q > 1) {
     hipLaunchKernelGGL((k_arg_masked_multi<T, true, ValArray<T>>), dim3((unsigned)nb, (unsigned)(q - 1)), dim3(256), 0, c->stream,
-                       ValArray<T>{(const T*)c->var.p}, (const uint8_t*)nullptr, (const uint8_t*)c->maskG.p, n, (long long)c->cs.first, pbase,
-                       pstride, 1);
+                       ValArray<T>{(const T*)c->var.p, 0.0}, (const uint8_t*)nullptr, (const uint8_t*)c->maskG.p, n, (long long)c->cs.first, pbase,
+                       pstride, 1, gb_of(c));
   }
   const bool mirrored = !multi_rank(c) && c->result_mirror;
   hipExtLaunchKernelGGL(k_sweep_finals<true>, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, mirrored ? c->ev[4] : nullptr, 0,
                         (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, sc,
                         lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr,
-                        mirrored ? c->h_back : (unsigned char*)nullptr, (const unsigned long long*)c->Lmax.p);
+                        mirrored ? c->h_back : (unsigned char*)nullptr, (const unsigned long long*)c->Lmax.p, gb_of(c) ? 1 : 0);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
@@ -1501,12 +1700,12 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
     const int lidx = o->reference_quirk_L_index ? q - 1 : 1;
     if ((rc = launch_exact_d<T>(c, o, 1, lidx, (uint8_t*)c->maskG.p))) return rc;
     hipLaunchKernelGGL((k_arg_masked_multi<T, true, ValArray<T>>), dim3((unsigned)nb, 1u), dim3(256), 0, c->stream,
-                       ValArray<T>{(const T*)c->var.p}, (const uint8_t*)nullptr, (const uint8_t*)c->maskG.p, n, (long long)c->cs.first, pbase,
-                       pstride, 1);
+                       ValArray<T>{(const T*)c->var.p, 0.0}, (const uint8_t*)nullptr, (const uint8_t*)c->maskG.p, n, (long long)c->cs.first, pbase,
+                       pstride, 1, gb_of(c));
     hipLaunchKernelGGL(k_sweep_clear_slot, dim3(1), dim3(1), 0, c->stream, sc, 1);
     hipExtLaunchKernelGGL(k_sweep_finals<true>, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, c->ev[4], 0,
                           (const unsigned char*)pbase, pstride, nb, sc, (const SweepScalars*)nullptr, c->h_back,
-                          (const unsigned long long*)c->Lmax.p);
+                          (const unsigned long long*)c->Lmax.p, gb_of(c) ? 1 : 0);
     SBO_HIP(hipGetLastError());
     if ((rc = sweep_exchange_back(c, h, is_max, Lk, c->ev[4], true))) return rc;
   }
@@ -1550,6 +1749,8 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   res->count_U = h.count_U;
   res->count_M = h.count_M;
   res->n_exact_rechecks = h.n_amb_total;
+  res->guard_band = h.n_guard;
+  c->guard_first = h.n_guard;
   for (int i = 0; i < q; ++i) memcpy(&res->L[i], &Lk[i], 8);
   res->minimizer_index = -1;
   res->expander_index = -1;
@@ -1578,6 +1779,19 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
     coords_of(c, res->expander_index, res->expander_x);
   }
   res->choose_minimizer = res->minimizer_std > res->expander_std;   // test/test_SafeOpt.py:153
+  if (gb_of(c)) {
+    // the choices among the reductions' winners are decisions too: which constraint's expander is kept (largest var_0), and
+    // minimiser against expander (std_min > std_exp) -- var_0 is known to +- arg_d
+    long long near = 0;
+    // (one candidate that wins two reductions ties with itself under any posterior: those comparisons are settled)
+    for (int cc = 1; cc < q && best_c; ++cc)
+      if (cc != best_c && h.arg_idx[cc] >= 0 && h.arg_idx[cc] != h.arg_idx[best_c] &&
+          !(h.arg_val[cc] + h.arg_d[cc] < h.arg_val[best_c] - h.arg_d[best_c])) ++near;
+    if (best_c && h.arg_idx[0] >= 0 && h.arg_idx[0] != h.arg_idx[best_c] &&
+        std::fabs(h.arg_val[0] - h.arg_val[best_c]) <= h.arg_d[0] + h.arg_d[best_c]) ++near;
+    res->guard_band += near;
+    c->guard_first += near;
+  }
   return SBO_OK;
 }
 
@@ -1823,15 +2037,15 @@ static void launch_argmin_dist(sbo_ctx* c, const double* dev_target, int nb) {
   switch (c->mc.dpad) {
     case 2:
       hipLaunchKernelGGL((k_arg_masked<T, false, ValDist<T, 2>>), dim3(nb), dim3(256), 0, c->stream, ValDist<T, 2>{c->cs, dev_target}, S, n,
-                         (long long)c->cs.first, (Best*)c->partial.p);
+                         (long long)c->cs.first, (Best*)c->partial.p, (const GuardBand*)nullptr);
       break;
     case 4:
       hipLaunchKernelGGL((k_arg_masked<T, false, ValDist<T, 4>>), dim3(nb), dim3(256), 0, c->stream, ValDist<T, 4>{c->cs, dev_target}, S, n,
-                         (long long)c->cs.first, (Best*)c->partial.p);
+                         (long long)c->cs.first, (Best*)c->partial.p, (const GuardBand*)nullptr);
       break;
     default:
       hipLaunchKernelGGL((k_arg_masked<T, false, ValDist<T, 8>>), dim3(nb), dim3(256), 0, c->stream, ValDist<T, 8>{c->cs, dev_target}, S, n,
-                         (long long)c->cs.first, (Best*)c->partial.p);
+                         (long long)c->cs.first, (Best*)c->partial.p, (const GuardBand*)nullptr);
       break;
   }
 }
@@ -1885,13 +2099,13 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   if (c->phase_events) SBO_HIP(hipEventRecord(c->ev[3], c->stream));
   // arg-min of lcb_0 over S_t and over every O_c: the bound is computed for the masked candidates only; one launch, the q
   // reductions side by side
-  const ValLcb<T> lcb0{(const T*)c->mean.p, (const T*)c->var.p, (T)o->b};
-  const size_t pstride = (sizeof(Best) + sizeof(long long)) * (size_t)nb;     // q regions of partials, one merge launch
+  const ValLcb<T> lcb0{(const T*)c->mean.p, (const T*)c->var.p, (T)o->b, 0.0, 0.0};
+  const size_t pstride = partial_stride(nb);     // q regions of partials, one merge launch
   if ((rc = ensure(c->partial, pstride * (size_t)q))) return rc;
   unsigned char* pbase = (unsigned char*)c->partial.p;
   if (n > 0)
     hipLaunchKernelGGL((k_arg_masked_multi<T, false, ValLcb<T>>), dim3((unsigned)nb, (unsigned)q), dim3(256), 0, c->stream, lcb0,
-                       (const uint8_t*)c->maskS.p, (const uint8_t*)c->maskO.p, n, (long long)c->cs.first, pbase, pstride, 0);
+                       (const uint8_t*)c->maskS.p, (const uint8_t*)c->maskO.p, n, (long long)c->cs.first, pbase, pstride, 0, gb_of(c));
   c->lmax_pending = false;
   SweepScalars h;
   bool is_max[kArgSlots];
@@ -1901,21 +2115,22 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   const bool fused_explore = !multi_rank(c) && q > 1;
   double* dev_t = (double*)c->scal.p + 256;
   // (one rank: the finals and the target choice in one launch, the last merge writes the host's block itself)
+  const int gbon = gb_of(c) ? 1 : 0;
   const bool short_tail = fused_explore && c->result_mirror && (c->mc.dpad == 2 || c->mc.dpad == 4 || c->mc.dpad == 8);
   const SweepScalars* l1 = lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr;
   if (short_tail) {
     switch (c->mc.dpad) {
-      case 2: hipLaunchKernelGGL((k_goose_finals<2>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, c->cs, dev_t); break;
-      case 4: hipLaunchKernelGGL((k_goose_finals<4>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, c->cs, dev_t); break;
-      default: hipLaunchKernelGGL((k_goose_finals<8>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, c->cs, dev_t); break;
+      case 2: hipLaunchKernelGGL((k_goose_finals<2>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, c->cs, dev_t, gbon); break;
+      case 4: hipLaunchKernelGGL((k_goose_finals<4>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, c->cs, dev_t, gbon); break;
+      default: hipLaunchKernelGGL((k_goose_finals<8>), dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride, n > 0 ? nb : 0, q, sc, l1, c->cs, dev_t, gbon); break;
     }
     if (n > 0) launch_argmin_dist<T>(c, dev_t, nb);
     hipExtLaunchKernelGGL(k_arg_final_mirror, dim3(1), dim3(256), 0, c->stream, nullptr, c->ev[4], 0, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
-                          kArgSlots - 1, c->h_back, (const unsigned long long*)c->Lmax.p);
+                          kArgSlots - 1, c->h_back, (const unsigned long long*)c->Lmax.p, 0);
     SBO_HIP(hipGetLastError());
   } else {
     hipLaunchKernelGGL(k_sweep_finals<false>, dim3((unsigned)q), dim3(256), 0, c->stream, (const unsigned char*)pbase, pstride,
-                       n > 0 ? nb : 0, sc, l1, (unsigned char*)nullptr, (const unsigned long long*)nullptr);
+                       n > 0 ? nb : 0, sc, l1, (unsigned char*)nullptr, (const unsigned long long*)nullptr, gbon);
     SBO_HIP(hipGetLastError());
     if (fused_explore) {
       switch (c->mc.dpad) {
@@ -1927,7 +2142,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
         launch_argmin_dist<T>(c, dev_t, nb);
       }
       hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
-                         kArgSlots - 1, (long long*)nullptr);
+                         kArgSlots - 1, (long long*)nullptr, 0);
     }
   }
   unsigned long long Lk[kMaxQ];
@@ -1948,6 +2163,8 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   res->count_S = h.count_S;
   res->count_U = h.count_U;
   res->n_exact_rechecks = h.n_amb_total;
+  res->guard_band = h.n_guard;
+  c->guard_first = h.n_guard;
   for (int i = 0; i < q; ++i) memcpy(&res->L[i], &Lk[i], 8);
   res->safe_min_index = res->target_index = res->explore_index = -1;
   for (int cc = 1; cc < q; ++cc) res->target_index_c[cc - 1] = -1;
@@ -1970,6 +2187,17 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   res->target_best_c = best_c;
   res->target_lcb = best_c ? best_lcb : INFINITY;
   res->choose_safe_min = best_c ? (res->safe_min_lcb <= res->target_lcb) : 1;   // test/test_GoOSE.py:158
+  if (gb_of(c) && best_c) {
+    // choices among the winners (the short tail judged the targets' one on the device): which constraint's target, and safe
+    // minimum against target (min_safe_lcb <= target_lcb) -- lcb_0 is known to +- arg_d
+    long long near = 0;
+    for (int cc = 1; cc < q && !short_tail; ++cc)
+      if (cc != best_c && h.arg_idx[cc] >= 0 && h.arg_idx[cc] != h.arg_idx[best_c] &&
+          !(h.arg_val[cc] - h.arg_d[cc] > h.arg_val[best_c] + h.arg_d[best_c])) ++near;
+    if (h.arg_idx[0] >= 0 && std::fabs(h.arg_val[0] - h.arg_val[best_c]) <= h.arg_d[0] + h.arg_d[best_c]) ++near;
+    res->guard_band += near;
+    c->guard_first += near;
+  }
   if (best_c) {
     res->target_index = res->target_index_c[best_c - 1];
     coords_of(c, res->target_index, res->target_x);
@@ -1983,7 +2211,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
       launch_argmin_dist<T>(c, dev_t, nb);
     }
     hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc,
-                       kArgSlots - 1, (long long*)nullptr);
+                       kArgSlots - 1, (long long*)nullptr, 0);
     SweepScalars h2;
     if ((rc = sweep_exchange_back(c, h2, is_max))) return rc;
     res->explore_index = h2.arg_idx[kArgSlots - 1];
@@ -2041,10 +2269,10 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
       default: hipLaunchKernelGGL((k_ball_mask<8>), dim3(nb), dim3(256), 0, c->stream, c->cs, n, (const uint8_t*)c->maskS.p, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
     }
     hipLaunchKernelGGL((k_arg_masked<T, false, ValLcb<T>>), dim3(nb), dim3(256), 0, c->stream,
-                       ValLcb<T>{(const T*)c->mean.p, (const T*)c->var.p, (T)o->b}, (const uint8_t*)c->maskM.p, n,
-                       (long long)c->cs.first, (Best*)c->partial.p);
+                       ValLcb<T>{(const T*)c->mean.p, (const T*)c->var.p, (T)o->b, 0.0, 0.0}, (const uint8_t*)c->maskM.p, n,
+                       (long long)c->cs.first, (Best*)c->partial.p, gb_of(c));
   }
-  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0, &sc->count_M);
+  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, 0, &sc->count_M, gb_of(c) ? 1 : 0);
   SBO_HIP(hipGetLastError());
   SweepScalars h;
   bool is_max[kArgSlots];
@@ -2070,6 +2298,8 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
   const double nn = c->mc.n, dd = c->mc.d;
   c->prof.posterior_flops = reuse ? 0.0 : c->mc.q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
   memset(res, 0, sizeof(*res));
+  res->guard_band = h.n_guard;
+  c->guard_first = h.n_guard;
   res->count_S = h.count_S;
   res->count_T = h.count_M;
   res->index = h.arg_idx[0];
@@ -2098,11 +2328,19 @@ int sbo_sweep_safeopt(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_safeopt_result
   if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
   SBO_HIP(hipSetDevice(c->device));
+  if (!(opts->b >= 0.0) || !std::isfinite(opts->b)) return fail(SBO_E_INVALID, "confidence multiplier b must be finite and >= 0");
   int rc;
+  c->guard_first = 0;
   if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model)
-    rc = sweep_safeopt_f32_recheck(c, opts, result);
+    rc = sweep_safeopt_recheck<float>(c, opts, result);
   else
     rc = c->dtype == SBO_F64 ? sweep_safeopt_t<double>(c, opts, result) : sweep_safeopt_t<float>(c, opts, result);
+  // an approximating posterior (K1b / K1t) whose band left decisions of that pass open: re-evaluate exactly, decide again
+  if ((rc == SBO_OK || rc == SBO_E_EMPTY_SAFE_SET) && c->dtype == SBO_F64 && gb_of(c) && (c->guard_first > 0 || c->guard_band == 2)) {
+    const long long first = c->guard_first;
+    rc = sweep_safeopt_recheck<double>(c, opts, result);
+    if (rc == SBO_OK || rc == SBO_E_EMPTY_SAFE_SET) result->guard_band = first;
+  }
   if (rc != SBO_OK && rc != SBO_E_EMPTY_SAFE_SET) drain_streams(c);   // (kernels of the failed call may still sit on the side streams)
   return rc;
 }
@@ -2113,11 +2351,18 @@ int sbo_sweep_goose(sbo_ctx* c, const sbo_sweep_opts* opts, sbo_goose_result* re
   if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
   SBO_HIP(hipSetDevice(c->device));
+  if (!(opts->b >= 0.0) || !std::isfinite(opts->b)) return fail(SBO_E_INVALID, "confidence multiplier b must be finite and >= 0");
   int rc;
-  if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model && !multi_rank(c))
-    rc = sweep_goose_f32_recheck(c, opts, result);
+  c->guard_first = 0;
+  if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model)
+    rc = sweep_goose_recheck<float>(c, opts, result);
   else
     rc = c->dtype == SBO_F64 ? sweep_goose_t<double>(c, opts, result) : sweep_goose_t<float>(c, opts, result);
+  if ((rc == SBO_OK || rc == SBO_E_EMPTY_SAFE_SET) && c->dtype == SBO_F64 && gb_of(c) && (c->guard_first > 0 || c->guard_band == 2)) {
+    const long long first = c->guard_first;
+    rc = sweep_goose_recheck<double>(c, opts, result);
+    if (rc == SBO_OK || rc == SBO_E_EMPTY_SAFE_SET) result->guard_band = first;
+  }
   if (rc != SBO_OK && rc != SBO_E_EMPTY_SAFE_SET) drain_streams(c);
   return rc;
 }
@@ -2128,10 +2373,18 @@ int sbo_sweep_tr(sbo_ctx* c, const sbo_sweep_opts* opts, const double* x_0, doub
   if (!c->has_cand) return fail(SBO_E_NO_CANDIDATES, "no candidates resident");
   if (c->cs.d != c->mc.d) return fail(SBO_E_INVALID, "ERROR W and X_norm dimension should be same");
   if (!(r >= 0.0)) return fail(SBO_E_INVALID, "trust-region radius must be >= 0");
+  if (!(opts->b >= 0.0) || !std::isfinite(opts->b)) return fail(SBO_E_INVALID, "confidence multiplier b must be finite and >= 0");
   SBO_HIP(hipSetDevice(c->device));
-  if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model && !multi_rank(c))
-    return sweep_tr_f32_recheck(c, opts, x_0, r, result);
-  return c->dtype == SBO_F64 ? sweep_tr_t<double>(c, opts, x_0, r, result) : sweep_tr_t<float>(c, opts, x_0, r, result);
+  c->guard_first = 0;
+  if (c->dtype == SBO_F32 && c->fp64_recheck && c->shadow && c->shadow->has_model)
+    return sweep_tr_recheck<float>(c, opts, x_0, r, result);
+  int rc = c->dtype == SBO_F64 ? sweep_tr_t<double>(c, opts, x_0, r, result) : sweep_tr_t<float>(c, opts, x_0, r, result);
+  if (rc == SBO_OK && c->dtype == SBO_F64 && gb_of(c) && (c->guard_first > 0 || c->guard_band == 2)) {
+    const long long first = c->guard_first;
+    rc = sweep_tr_recheck<double>(c, opts, x_0, r, result);
+    if (rc == SBO_OK) result->guard_band = first;
+  }
+  return rc;
 }
 
 int sbo_masks_get(sbo_ctx* c, int which, int cidx, uint8_t* out) {

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
   // (order of the ranges: the merge and the coarse lines first -- few workgroups with longer chains that should start with the
   // launch, not in the slots the fine lines leave at its end)
   const int nfin = (int)gridDim.x - nfine - ncoarse, bid = (int)blockIdx.x;
-  if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy);
+  if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy, fin.gb, fin.b);
   else if (bid < nfin + ncoarse) edt_axis0_wg_body<true>(bid - nfin, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
   else if (wave_lines) {
     // (the waves of the fine workgroups stride over the lines: the host sizes the launch to what is resident at once)
@@ -596,18 +596,34 @@ __device__ __forceinline__ bool lipschitz_pair(const double (&xg)[D], const doub
 // fp32 values, good to +- (dm, dv).  For those the ucb is an interval of half-width du; a verdict the interval cannot
 // settle sends the candidate to the refinement list instead of deciding it.  refined == nullptr: every value is exact.
 constexpr size_t kRcCount2 = 32, kRcGKeys = 64, kRcList = 256;   // layout of sbo_ctx::rc_list: counters, G keys, the list
+// The guard band of an approximating fp64 posterior (device_common.hpp: GuardBand) rides on the same mechanism: gb_c >= 1 names
+// the constraint whose band SweepScalars::gb_du[gb_c] (one bound for every candidate of S) and relative Lipschitz band gb_rl
+// apply to entries that are not `refined`; on the fast path there is no list and an unsettled verdict is only counted
+// (SweepScalars::n_guard).
 struct RcExp {
   const uint8_t* refined;
   double dm, dv;
-  long long* list;                 // candidates to re-evaluate in fp64
+  long long* list;                 // candidates to re-evaluate exactly (nullptr: count only)
   unsigned long long* count;
+  int gb_c, gb_l;                  // guard band: constraint / Lipschitz index (0: no guard band)
 };
-__device__ __forceinline__ double rc_du(const RcExp& rx, long long g, double var, double b) {
-  if (!rx.refined || rx.refined[g]) return 0.0;
+struct RcBandK {                   // per-kernel constants of the guard band (loaded once from the scalar block)
+  double du, rl;
+};
+__device__ __forceinline__ RcBandK rc_band(const RcExp& rx, const SweepScalars* sc) {
+  RcBandK k{0.0, 0.0};
+  if (rx.gb_c > 0) { k.du = sc->gb_du[rx.gb_c]; k.rl = rx.gb_l >= 0 ? sc->gb_rl[rx.gb_l] : 0.0; }
+  return k;
+}
+__device__ __forceinline__ double rc_du(const RcExp& rx, const RcBandK& bk, long long g, double var, double b, double ucb) {
+  if (rx.refined && rx.refined[g]) return 0.0;
+  if (rx.gb_c > 0) return bk.du + bk.rl * (ucb < 0 ? -ucb : ucb);      // (a relative band of L moves L dist by at most rl ucb at the boundary)
+  if (!rx.refined) return 0.0;
   return rx.dm + b * (sqrt(var + rx.dv) - sqrt(fmax(0.0, var - rx.dv)));
 }
-__device__ __forceinline__ void rc_defer(const RcExp& rx, long long g) {
-  rx.list[atomicAdd(rx.count, 1ull)] = g;
+__device__ __forceinline__ void rc_defer(const RcExp& rx, SweepScalars* sc, long long g) {
+  if (rx.list) rx.list[atomicAdd(rx.count, 1ull)] = g;
+  else atomicAdd((unsigned long long*)&sc->n_guard, 1ull);
 }
 
 // last axis + decision.  For g in S: nearest-U distance dm (unshifted) -> G bit, or the ambiguous list when
@@ -624,6 +640,7 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
                                                     long long* __restrict__ scanlist, const RcExp rx) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const bool anyU = sc->count_U > 0;
+  const RcBandK bk = rc_band(rx, sc);
   // launch: x over the positions of a grid line (len0 = count0; the whole range when d == 1), y over blocks of
   // kDecideLines local lines -- the line index is uniform per workgroup and a 2-D grid needs no division to split a
   // candidate index.  Open candidates are collected in LDS and appended to the scan list with one atomic per
@@ -678,10 +695,10 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
       T lcb, ucbT;
       lcb_ucb(mu[u], va[u], b, lcb, ucbT);
       const double ucb = (double)ucbT;
-      const double du = rc_du(rx, g, (double)va[u], (double)b);      // 0 unless this entry is an unrefined fp32 value
+      const double du = rc_du(rx, bk, g, (double)va[u], (double)b, ucb);   // 0 unless this entry is an unrefined fp32 value / carries a guard band
       if (!(L > 0)) {
         out = ucb >= 0.0;                         // radius unbounded: any U point is a witness
-        if (du > 0.0 && fabs(ucb) <= du) rc_defer(rx, g);
+        if (du > 0.0 && fabs(ucb) <= du) rc_defer(rx, sc, g);
       } else {
         const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
         const double cap = (ucb + du) / L + 4.0 * eps_abs + 1e-9 * fabs((ucb + du) / L);
@@ -715,10 +732,11 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
           const double lo = ucb - du - L * (dm + eps), hi = ucb + du - L * (dm - eps);
           if (lo > tol) out = 1;
           else if (hi >= -tol) {
-            if (du > 0.0) {
-              rc_defer(rx, g);                     // an fp32 value cannot settle it: re-evaluate, decide in the next pass
+            if (du > 0.0 && rx.list) {
+              rc_defer(rx, sc, g);                 // an fp32 value cannot settle it: re-evaluate, decide in the next pass
               out = ucb - L * dm >= 0.0;
             } else {
+              if (du > 0.0) rc_defer(rx, sc, g);   // (guard band, fast path: counted; the exhaustive recheck still decides it)
               const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
               amb[slot] = g;
             }
@@ -764,6 +782,7 @@ __global__ __launch_bounds__(256) void k_edt_decide8(long long nl, int len0, lon
   __shared__ long long sbase;
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const bool anyU = sc->count_U > 0;
+  const RcBandK bk = rc_band(rx, sc);
   const int t8 = blockIdx.x * blockDim.x + threadIdx.x;          // this lane's cell along axis 0
   const bool active = (long long)t8 * 8 < len0;
   const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
@@ -799,10 +818,10 @@ __global__ __launch_bounds__(256) void k_edt_decide8(long long nl, int len0, lon
           T lcb, ucbT;
           lcb_ucb(mu[k], va[k], b, lcb, ucbT);
           const double ucb = (double)ucbT;
-          const double du = rc_du(rx, g, (double)va[k], (double)b);      // 0 unless this entry is an unrefined fp32 value
+          const double du = rc_du(rx, bk, g, (double)va[k], (double)b, ucb);   // 0 unless this entry is an unrefined fp32 value / carries a guard band
           if (!(L > 0)) {
             if (ucb >= 0.0) gw |= 1ull << (8 * k);                      // radius unbounded: any U point is a witness
-            if (du > 0.0 && fabs(ucb) <= du) rc_defer(rx, g);
+            if (du > 0.0 && fabs(ucb) <= du) rc_defer(rx, sc, g);
             continue;
           }
           if (cg.enabled) {
@@ -850,6 +869,7 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const DS Din, long long g
                                                        const long long* __restrict__ scanlist, const RcExp rx) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const long long nscan = sc->n_scan;
+  const RcBandK bk = rc_band(rx, sc);
   const int lane = threadIdx.x & (GL - 1);
   const int sub = (threadIdx.x & 63) / GL;
   const long long ngroups = (long long)gridDim.x * (blockDim.x / GL);
@@ -866,7 +886,7 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const DS Din, long long g
   for (long long qi = (long long)blockIdx.x * (blockDim.x / GL) + threadIdx.x / GL; qi < nscan; qi += ngroups) {
     const long long g = scanlist[2 * qi];
     const double ucb = reinterpret_cast<const double*>(scanlist)[2 * qi + 1];
-    const double du = rx.refined ? rc_du(rx, g, (double)var_c[g], (double)b) : 0.0;
+    const double du = (rx.refined || rx.gb_c > 0) ? rc_du(rx, bk, g, (rx.refined && !(rx.gb_c > 0)) ? (double)var_c[g] : 0.0, (double)b, ucb) : 0.0;
     const double eps_abs = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13;
     const double cap = (ucb + du) / L + 4.0 * eps_abs + 1e-9 * fabs((ucb + du) / L);
     const double thr = (ucb - du) / L * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;
@@ -933,10 +953,11 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const DS Din, long long g
         const double lo = ucb - du - L * (dm + eps), hi = ucb + du - L * (dm - eps);
         if (lo > tol) out = 1;
         else if (hi >= -tol) {
-          if (du > 0.0) {
-            rc_defer(rx, g);
+          if (du > 0.0 && rx.list) {
+            rc_defer(rx, sc, g);
             out = ucb - L * dm >= 0.0;
           } else {
+            if (du > 0.0) rc_defer(rx, sc, g);     // (guard band, fast path: counted)
             amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
           }
         }

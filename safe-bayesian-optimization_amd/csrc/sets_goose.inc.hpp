@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void k_goose_optimistic(const CandSpec cs, con
 //   (h t)^2 - rmax^2 > band   (no source that far can matter)   and   (h t)^2 - rmax^2 >= best   (cannot improve).
 struct PdtParams {
   double invL, rmax2, band;    // 1/L, (max source radius)^2, ambiguity band on P
+  double gband;                // the part of `band` that comes from the guard band of an approximating posterior (0: none)
   int L_positive;
 };
 __device__ __forceinline__ PdtParams pdt_params(const SweepScalars* sc, int c, const unsigned long long* Lkeys, int lidx, int d,
@@ -222,6 +223,11 @@ __device__ __forceinline__ PdtParams pdt_params(const SweepScalars* sc, int c, c
   const double eps = 1.01e-8 * sqrt((double)d) + 1e-14 * xscale + 1e-13 + 1e-10 * rm;
   p.rmax2 = rm * rm;
   p.band = 3.03 * rm * eps + eps * eps + 1e-13 * (xscale * xscale + p.rmax2);
+  // guard band: a source's radius r = ucb_c / L is known to dr = du / L + rl r, so r^2 -- and with it P -- to 2 r dr + dr^2; the
+  // band is widened by that much, and a verdict inside the widened band is counted (SweepScalars::n_guard)
+  const double dr = sc->gb_du[c] * p.invL + sc->gb_rl[lidx] * rm;
+  p.gband = dr > 0.0 ? (2.0 * rm * dr + dr * dr) * (1.0 + 1e-9) : 0.0;
+  p.band += p.gband;
   return p;
 }
 
@@ -729,6 +735,7 @@ __global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ P
                                       : pdt_scan_point(Pin, gg, stride, cnt, ia, h, pp, true);
           if (best < -pp.band) out = 1;
           else if (best <= pp.band) {
+            if (pp.gband > 0.0) atomicAdd((unsigned long long*)&sc->n_guard, 1ull);
             const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
             amb[slot] = g;
           }
@@ -830,7 +837,10 @@ __global__ __launch_bounds__(256) void k_pdt_scan_list(const double* __restrict_
     if (lane == 0) {
       uint8_t out = 0;
       if (best < -pp.band) out = 1;
-      else if (best <= pp.band) amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
+      else if (best <= pp.band) {
+        if (pp.gband > 0.0) atomicAdd((unsigned long long*)&sc->n_guard, 1ull);
+        amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
+      }
       O[g] = out;
     }
   }

@@ -16,6 +16,11 @@
 // carry the band of an unrefined ucb (RcExp in sets_expander.inc.hpp): a verdict the band cannot settle defers the
 // candidate, and so does an unrefined member of G_c that could hold its largest variance.  Deferred candidates are
 // re-evaluated and the set phase runs again, until nothing is deferred (each candidate is refined at most once).
+//
+// r04: the same machinery serves the GUARD BAND of an approximating fp64 posterior (K1b / K1t, device_common.hpp: GuardBand): a
+// sweep whose fast pass counted decisions inside the band (SweepScalars::n_guard) comes here with TP = double -- the intervals
+// are +- (dm, dv) of the plan's band, the listed candidates are re-evaluated by the exact kernel (guard_exact_list) and their
+// values replace the approximate ones IN PLACE, the Lipschitz keys are recomputed exactly, and the set phase runs again.
 #pragma once
 
 struct RcBand {
@@ -26,7 +31,7 @@ struct RcScal {                         // head of rc_list (256 bytes): this str
   long long count;
 };
 
-__device__ __forceinline__ void rc_interval(float m, float v, double b, double dm, double dv, double& lcb_lo, double& lcb_hi, double& ucb_lo,
+__device__ __forceinline__ void rc_interval(double m, double v, double b, double dm, double dv, double& lcb_lo, double& lcb_hi, double& ucb_lo,
                                             double& ucb_hi) {
   const double md = (double)m, vd = (double)v;
   const double s_hi = b * sqrt(vd + dv), s_lo = b * sqrt(fmax(0.0, vd - dv));
@@ -37,13 +42,14 @@ __device__ __forceinline__ void rc_interval(float m, float v, double b, double d
 }
 
 // possibly / surely safe from the constraints' intervals; `undecided`: some constraint's lcb interval contains zero
-__device__ __forceinline__ void rc_safety(const float* __restrict__ mean, const float* __restrict__ var, long long n, long long g, int q,
+template <typename TP>
+__device__ __forceinline__ void rc_safety(const TP* __restrict__ mean, const TP* __restrict__ var, long long n, long long g, int q,
                                           double b, const RcBand& bd, bool& possibly, bool& surely, bool& undecided) {
   possibly = surely = true;
   undecided = false;
   for (int c = 1; c < q; ++c) {
     double ll, lh, ul, uh;
-    rc_interval(mean[(size_t)c * n + g], var[(size_t)c * n + g], b, bd.dm[c], bd.dv[c], ll, lh, ul, uh);
+    rc_interval((double)mean[(size_t)c * n + g], (double)var[(size_t)c * n + g], b, bd.dm[c], bd.dv[c], ll, lh, ul, uh);
     possibly = possibly && lh >= 0.0;
     surely = surely && ll >= 0.0;
     undecided = undecided || (ll <= 0.0 && lh >= 0.0);
@@ -51,7 +57,8 @@ __device__ __forceinline__ void rc_safety(const float* __restrict__ mean, const 
 }
 
 // pass 1: u_lo = min over possibly-safe of ucb0_lo, u_hi = min over surely-safe of ucb0_hi
-__global__ __launch_bounds__(256) void k_rc_ustar(const float* __restrict__ mean, const float* __restrict__ var, long long n, int q, double b,
+template <typename TP>
+__global__ __launch_bounds__(256) void k_rc_ustar(const TP* __restrict__ mean, const TP* __restrict__ var, long long n, int q, double b,
                                                   const RcBand bd, RcScal* sc) {
   unsigned long long klo = ~0ull, khi = ~0ull;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256) void k_rc_ustar(const float* __restrict__ mean
     rc_safety(mean, var, n, g, q, b, bd, ps, ss, un);
     if (!ps) continue;
     double ll, lh, ul, uh;
-    rc_interval(mean[g], var[g], b, bd.dm[0], bd.dv[0], ll, lh, ul, uh);
+    rc_interval((double)mean[g], (double)var[g], b, bd.dm[0], bd.dv[0], ll, lh, ul, uh);
     const unsigned long long a = ord_key(ul), h = ord_key(uh);
     klo = a < klo ? a : klo;
     if (ss) khi = h < khi ? h : khi;
@@ -72,7 +79,8 @@ __global__ __launch_bounds__(256) void k_rc_ustar(const float* __restrict__ mean
   }
 }
 // pass 2: vmax_lo = max over surely-in-M (surely safe, lcb0_hi <= u_lo) of max(0, var0 - dv)
-__global__ __launch_bounds__(256) void k_rc_vmax(const float* __restrict__ mean, const float* __restrict__ var, long long n, int q, double b,
+template <typename TP>
+__global__ __launch_bounds__(256) void k_rc_vmax(const TP* __restrict__ mean, const TP* __restrict__ var, long long n, int q, double b,
                                                  const RcBand bd, RcScal* sc) {
   const double u_lo = ord_val(sc->ulo_key);
   unsigned long long kv = 0ull;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void k_rc_vmax(const float* __restrict__ mean,
     rc_safety(mean, var, n, g, q, b, bd, ps, ss, un);
     if (!ss) continue;
     double ll, lh, ul, uh;
-    rc_interval(mean[g], var[g], b, bd.dm[0], bd.dv[0], ll, lh, ul, uh);
+    rc_interval((double)mean[g], (double)var[g], b, bd.dm[0], bd.dv[0], ll, lh, ul, uh);
     if (lh <= u_lo) {
       const unsigned long long k = ord_key(fmax(0.0, (double)var[g] - bd.dv[0]));
       kv = k > kv ? k : kv;
@@ -91,7 +99,8 @@ __global__ __launch_bounds__(256) void k_rc_vmax(const float* __restrict__ mean,
   if (threadIdx.x == 0) atomicMax(&sc->vmax_key, kv);
 }
 // pass 3: the list of candidates the intervals cannot decide
-__global__ __launch_bounds__(256) void k_rc_flag(const float* __restrict__ mean, const float* __restrict__ var, long long n, int q, double b,
+template <typename TP>
+__global__ __launch_bounds__(256) void k_rc_flag(const TP* __restrict__ mean, const TP* __restrict__ var, long long n, int q, double b,
                                                  const RcBand bd, RcScal* sc, long long* __restrict__ list, int all_possibly_safe) {
   __shared__ int wcount[4];
   __shared__ long long base;
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256) void k_rc_flag(const float* __restrict__ mean,
       flag = un || (all_possibly_safe && ps && q > 1);
       if (ps && all_possibly_safe != 2) {
         double ll, lh, ul, uh;
-        rc_interval(mean[g], var[g], b, bd.dm[0], bd.dv[0], ll, lh, ul, uh);
+        rc_interval((double)mean[g], (double)var[g], b, bd.dm[0], bd.dv[0], ll, lh, ul, uh);
         const bool maybe_m = ll <= u_hi;
         flag = flag || ul <= u_hi;                                     // may attain u*
         flag = flag || (maybe_m && lh >= u_lo);                        // lcb_0 <= u* undecided
@@ -245,19 +254,32 @@ __global__ __launch_bounds__(256) void k_rc_gdefer(const uint8_t* __restrict__ G
     if (Gc[g] && !refined[g] && var0[g] + dv0 >= vlo) list[atomicAdd(count, 1ull)] = g;
 }
 
-// re-evaluate list[0..nf) in fp64 on the twin and put the values in place
-static int rc_refine(sbo_ctx* c, const long long* list, long long nf) {
-  sbo_ctx* s = c->shadow;
+// re-evaluate list[0..nf) exactly and put the values in place.  fp32 models: the fp64 twin's generic kernel, into the widened
+// copy rc_mean / rc_var; guard band of an approximating fp64 posterior (`guard`): the exact evaluator of the same model
+// (guard.hip: guard_exact_list), into the posterior buffers themselves.
+static int rc_refine(sbo_ctx* c, const long long* list, long long nf, bool guard = false) {
+  sbo_ctx* s = guard ? c : c->shadow;
   const long long n = c->cs.n_local;
   const int q = c->mc.q, d = c->cs.d;
   int rc;
   if (nf <= 0) return SBO_OK;
-  if ((rc = ensure(s->pts, sizeof(double) * (size_t)nf * d))) return rc;
+  DevBuf& pbuf = guard ? c->gb_pts : s->pts;
+  if ((rc = ensure(pbuf, sizeof(double) * (size_t)nf * d))) return rc;
   const unsigned nbf = (unsigned)std::max<long long>(1, std::min<long long>((nf + 255) / 256, 4096));
   switch (c->mc.dpad) {
-    case 2: hipLaunchKernelGGL(k_rc_gather<2>, dim3(nbf), dim3(256), 0, c->stream, c->cs, list, nf, (double*)s->pts.p); break;
-    case 4: hipLaunchKernelGGL(k_rc_gather<4>, dim3(nbf), dim3(256), 0, c->stream, c->cs, list, nf, (double*)s->pts.p); break;
-    default: hipLaunchKernelGGL(k_rc_gather<8>, dim3(nbf), dim3(256), 0, c->stream, c->cs, list, nf, (double*)s->pts.p); break;
+    case 2: hipLaunchKernelGGL(k_rc_gather<2>, dim3(nbf), dim3(256), 0, c->stream, c->cs, list, nf, (double*)pbuf.p); break;
+    case 4: hipLaunchKernelGGL(k_rc_gather<4>, dim3(nbf), dim3(256), 0, c->stream, c->cs, list, nf, (double*)pbuf.p); break;
+    default: hipLaunchKernelGGL(k_rc_gather<8>, dim3(nbf), dim3(256), 0, c->stream, c->cs, list, nf, (double*)pbuf.p); break;
+  }
+  if (guard) {
+    if ((rc = ensure(c->gb_vals, sizeof(double) * 2 * (size_t)nf * q))) return rc;
+    double* em = (double*)c->gb_vals.p;
+    double* ev = em + (size_t)nf * q;
+    if ((rc = guard_exact_list(c, (const double*)pbuf.p, nf, em, ev))) return rc;
+    hipLaunchKernelGGL(k_rc_scatter, dim3(nbf), dim3(256), 0, c->stream, list, nf, q, n, (const double*)em, (const double*)ev,
+                       (double*)c->mean.p, (double*)c->var.p, (uint8_t*)c->rc_refined.p);
+    SBO_HIP(hipGetLastError());
+    return SBO_OK;
   }
   memset(&s->cs, 0, sizeof(s->cs));
   s->cs.kind = 0;
@@ -278,32 +300,73 @@ static int rc_refine(sbo_ctx* c, const long long* list, long long nf) {
   return SBO_OK;
 }
 
-static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_result* res) {
-  sbo_ctx* s = c->shadow;
+// Lipschitz keys in fp64 from the double arrays of `s` (the twin of an fp32 model, or the fp64 model itself) over the
+// candidates of `c`
+static int rc_lipschitz64(sbo_ctx* c, const sbo_ctx* s) {
   const long long n = c->cs.n_local;
-  const int q = c->mc.q;
-  int rc;
-  if (n == 0 && !multi_rank(c)) return sweep_safeopt_t<float>(c, o, res);
-  SBO_HIP(hipEventRecord(c->ev_join[0], c->stream));
-  const bool reuse = o->posterior_ready && c->posterior_valid;
-  if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
-  c->k1_stop_attached = false;
-  SBO_HIP(hipEventRecord(c->ev_join[1], c->stream));
-  // the fp32 contract as absolute bands per output
-  RcBand bd;
+  SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
+  const unsigned nbg = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8));
+#define SBO_GRAD(DD)                                                                                                              \
+  hipLaunchKernelGGL(k_rc_grad64<DD>, dim3(nbg), dim3(256), 0, c->stream, s->mc, c->cs, (const double*)s->As.p, (const double*)s->sqA.p, \
+                     (const double*)s->alpha.p, (const double*)s->Xn.p, (unsigned long long*)c->Lmax.p)
+  switch (c->mc.dpad) {
+    case 2: SBO_GRAD(2); break;
+    case 4: SBO_GRAD(4); break;
+    default: SBO_GRAD(8); break;
+  }
+#undef SBO_GRAD
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+// the bands of the intervals: the fp32 contract (1e-4 normalised), or the plan's guard band read back from the device
+static int rc_bands(sbo_ctx* c, bool guard, RcBand& bd) {
   memset(&bd, 0, sizeof(bd));
+  const int q = c->mc.q;
+  if (guard) {
+    GuardBand hb;
+    SBO_HIP(hipMemcpyAsync(&hb, c->gb.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < q; ++i) {
+      if (!(hb.dm[i] >= 0.0) || !(hb.dv[i] >= 0.0)) return fail(SBO_E_HIP, "internal: guard band is not finite");
+      bd.dm[i] = hb.dm[i];
+      bd.dv[i] = hb.dv[i];
+    }
+    return SBO_OK;
+  }
   for (int i = 0; i < q; ++i) {
     const double ys = std::max(1.0, c->mc.Y_std[i]);
     bd.dm[i] = 1e-4 * ys;
     bd.dv[i] = 1e-4 * ys * ys;
   }
+  return SBO_OK;
+}
+
+// TP = float: an fp32 model (posterior in fp32, the fp64 twin re-evaluates); TP = double: the guard band of an approximating fp64
+// posterior (the posterior is resident and valid; its listed entries are replaced in place by exact values)
+template <typename TP>
+static int sweep_safeopt_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_result* res) {
+  constexpr bool kGuard = std::is_same<TP, double>::value;
+  const long long n = c->cs.n_local;
+  const int q = c->mc.q;
+  int rc;
+  if (!kGuard && n == 0 && !multi_rank(c)) return sweep_safeopt_t<float>(c, o, res);
+  SBO_HIP(hipEventRecord(c->ev_join[0], c->stream));
+  const bool reuse = kGuard || (o->posterior_ready && c->posterior_valid);
+  if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
+  c->k1_stop_attached = false;
+  SBO_HIP(hipEventRecord(c->ev_join[1], c->stream));
+  RcBand bd;
+  if ((rc = rc_bands(c, kGuard, bd))) return rc;
   // (one pass can list a candidate once per constraint in the verdict kernels and once more per constraint in k_rc_gdefer;
   // the first list -- k_rc_flag -- holds every candidate at most once)
-  const size_t list_cap = (size_t)n * (size_t)(2 * std::max(1, q - 1) + 1);
+  const size_t list_cap = (size_t)std::max<long long>(n, 1) * (size_t)(2 * std::max(1, q - 1) + 1);
   if ((rc = ensure(c->rc_list, kRcList + sizeof(long long) * list_cap))) return rc;
-  if ((rc = ensure(c->rc_mean, sizeof(double) * (size_t)q * n))) return rc;
-  if ((rc = ensure(c->rc_var, sizeof(double) * (size_t)q * n))) return rc;
-  if ((rc = ensure(c->rc_refined, (size_t)n))) return rc;
+  if (!kGuard) {
+    if ((rc = ensure(c->rc_mean, sizeof(double) * (size_t)q * std::max<long long>(n, 1)))) return rc;
+    if ((rc = ensure(c->rc_var, sizeof(double) * (size_t)q * std::max<long long>(n, 1)))) return rc;
+  }
+  if ((rc = ensure(c->rc_refined, (size_t)std::max<long long>(n, 1)))) return rc;
   RcScal* sc = (RcScal*)c->rc_list.p;
   unsigned long long* count2 = (unsigned long long*)((char*)c->rc_list.p + kRcCount2);
   unsigned long long* gkeys = (unsigned long long*)((char*)c->rc_list.p + kRcGKeys);
@@ -311,46 +374,35 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
   SBO_HIP(hipMemsetAsync(c->rc_list.p, 0, kRcList, c->stream));
   const RcScal init{~0ull, ~0ull, 0ull, 0};
   SBO_HIP(hipMemcpyAsync(sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-  SBO_HIP(hipMemsetAsync(c->rc_refined.p, 0, (size_t)n, c->stream));
-  const float* m32 = (const float*)c->mean.p;
-  const float* v32 = (const float*)c->var.p;
+  SBO_HIP(hipMemsetAsync(c->rc_refined.p, 0, (size_t)std::max<long long>(n, 1), c->stream));
+  const TP* m32 = (const TP*)c->mean.p;
+  const TP* v32 = (const TP*)c->var.p;
   const unsigned nbk = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));
   // candidate sets without a grid to transform decide their expanders by exhaustive pair evaluation on the ucb of every
   // safe candidate: there all possibly-safe candidates are re-evaluated
   long long plane = 1;
   for (int a = 0; a < c->cs.d - 1; ++a) plane *= c->cs.count[a];
   const bool grid_expander = c->cs.kind == 1 && c->cs.first % plane == 0 && n % plane == 0;
-  hipLaunchKernelGGL(k_rc_ustar, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc);
+  hipLaunchKernelGGL(k_rc_ustar<TP>, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc);
   // (ranks > 1: the interval of u* and the variance guard are global quantities -- three keys through the collectives)
   if ((rc = comm_allreduce_min_u64(c, &sc->ulo_key, 2))) return rc;
-  hipLaunchKernelGGL(k_rc_vmax, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc);
+  hipLaunchKernelGGL(k_rc_vmax<TP>, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc);
   if ((rc = comm_allreduce_max_u64(c, &sc->vmax_key, 1))) return rc;
-  hipLaunchKernelGGL(k_rc_flag, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc, list, grid_expander ? 0 : 1);
-  hipLaunchKernelGGL(k_rc_widen, dim3(nbk), dim3(256), 0, c->stream, m32, v32, (long long)q * n, (double*)c->rc_mean.p, (double*)c->rc_var.p);
+  hipLaunchKernelGGL(k_rc_flag<TP>, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc, list, grid_expander ? 0 : 1);
+  if (!kGuard)
+    hipLaunchKernelGGL(k_rc_widen, dim3(nbk), dim3(256), 0, c->stream, (const float*)c->mean.p, (const float*)c->var.p, (long long)q * n,
+                       (double*)c->rc_mean.p, (double*)c->rc_var.p);
   SBO_HIP(hipGetLastError());
   unsigned char* hb = c->h_back + 5120;                             // pinned landing area of the list lengths
   SBO_HIP(hipMemcpyAsync(hb, sc, 64, hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
   long long total = ((const RcScal*)hb)->count;
-  if ((rc = rc_refine(c, list, total))) return rc;
-  if (q > 1) {
-    // Lipschitz keys in fp64 (the fp32 posterior kernel left fp32-accurate ones)
-    SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
-    const unsigned nbg = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8));
-#define SBO_GRAD(DD)                                                                                                              \
-  hipLaunchKernelGGL(k_rc_grad64<DD>, dim3(nbg), dim3(256), 0, c->stream, s->mc, c->cs, (const double*)s->As.p, (const double*)s->sqA.p, \
-                     (const double*)s->alpha.p, (const double*)s->Xn.p, (unsigned long long*)c->Lmax.p)
-    switch (c->mc.dpad) {
-      case 2: SBO_GRAD(2); break;
-      case 4: SBO_GRAD(4); break;
-      default: SBO_GRAD(8); break;
-    }
-#undef SBO_GRAD
-    SBO_HIP(hipGetLastError());
-  }
+  if ((rc = rc_refine(c, list, total, kGuard))) return rc;
+  // Lipschitz keys in fp64 (the fp32 posterior kernel left fp32-accurate ones, an approximating one its own band)
+  if (q > 1 && (rc = rc_lipschitz64(c, kGuard ? c : c->shadow))) return rc;
   SBO_HIP(hipEventRecord(c->ev_join[2], c->stream));
-  // the set phase in fp64 arithmetic on the widened + refined posterior (the fp32 arrays stay what sbo_posterior_get
-  // returns); repeated while verdicts are deferred
+  // the set phase in fp64 arithmetic on the refined posterior (fp32: the widened copy -- the fp32 arrays stay what
+  // sbo_posterior_get returns); repeated while verdicts are deferred
   const DevBuf keep_m = c->mean, keep_v = c->var;
   const int keep_dtype = c->dtype;
   const bool keep_valid = c->posterior_valid;
@@ -360,24 +412,30 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
   int passes = 0;
   for (;; ++passes) {
     SBO_HIP(hipMemsetAsync(count2, 0, 8 + sizeof(unsigned long long) * kMaxQ + 24, c->stream));     // deferral counter + G keys
-    c->mean = c->rc_mean;
-    c->var = c->rc_var;
+    if (!kGuard) {
+      c->mean = c->rc_mean;
+      c->var = c->rc_var;
+    }
     c->dtype = SBO_F64;
     c->posterior_valid = true;
     c->rc_active = q > 1;
+    c->gb_slow = kGuard;                   // (guard: the band stays in force for unrefined entries; L is exact now)
     rc = sweep_safeopt_t<double>(c, &o2, res);
     c->rc_active = false;
-    c->rc_mean = c->mean;
-    c->rc_var = c->var;
-    c->mean = keep_m;
-    c->var = keep_v;
+    c->gb_slow = false;
+    if (!kGuard) {
+      c->rc_mean = c->mean;
+      c->rc_var = c->var;
+      c->mean = keep_m;
+      c->var = keep_v;
+    }
     c->dtype = keep_dtype;
     c->posterior_valid = keep_valid || !reuse;
     if (rc != SBO_OK || q == 1) break;
     if (passes > 0) set_extra += (float)c->prof.total_ms;
-    // Expander's arg-max over every G_c must not hinge on an fp32 variance
+    // Expander's arg-max over every G_c must not hinge on an unrefined variance
     const uint8_t* G = (const uint8_t*)c->maskG.p;
-    const double* var0 = (const double*)c->rc_var.p;
+    const double* var0 = kGuard ? (const double*)c->var.p : (const double*)c->rc_var.p;
     hipLaunchKernelGGL(k_rc_gmax, dim3(nbk, (unsigned)(q - 1)), dim3(256), 0, c->stream, G, var0, (const uint8_t*)c->rc_refined.p, n, bd.dv[0],
                        gkeys);
     if ((rc = comm_allreduce_max_u64(c, gkeys, q - 1))) return rc;        // (the expanders' arg-max is over all ranks)
@@ -401,21 +459,27 @@ static int sweep_safeopt_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_sa
     if (nd_all == 0) break;
     if ((size_t)nd > list_cap) return fail(SBO_E_HIP, "internal: refinement list overflow");
     // (every candidate is refined at most once, so the passes end; six without an end would be a defect, not a slow case)
-    if (passes >= 6) return fail(SBO_E_UNSUPPORTED, "fp64 recheck: verdicts still deferred after 7 passes of the set phase");
-    if ((rc = rc_refine(c, list, nd))) return rc;
+    if (passes >= 6) return fail(SBO_E_UNSUPPORTED, "recheck: verdicts still deferred after 7 passes of the set phase");
+    if ((rc = rc_refine(c, list, nd, kGuard))) return rc;
     total += nd;
   }
   float t01 = 0, t12 = 0, t04 = 0;
   (void)hipEventElapsedTime(&t01, c->ev_join[0], c->ev_join[1]);
   (void)hipEventElapsedTime(&t12, c->ev_join[1], c->ev_join[2]);
   (void)hipEventElapsedTime(&t04, c->ev_join[0], c->ev[4]);
-  c->prof.posterior_ms = t01;
-  c->prof.recheck_ms = t12;
-  c->prof.total_ms = t04;
-  c->prof.fp64_rechecks = total;
-  c->prof.posterior_launches = reuse ? 0 : 1;
-  const double nn = c->mc.n, dd = c->mc.d;
-  c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
+  if (kGuard) {
+    c->prof.guard_ms = t04;
+    res->guard_rechecks = total;
+    res->guard_passes = passes + 1;
+  } else {
+    c->prof.posterior_ms = t01;
+    c->prof.recheck_ms = t12;
+    c->prof.total_ms = t04;
+    c->prof.fp64_rechecks = total;
+    c->prof.posterior_launches = reuse ? 0 : 1;
+    const double nn = c->mc.n, dd = c->mc.d;
+    c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
+  }
   (void)set_extra;
   return rc;
 }
@@ -474,46 +538,51 @@ __global__ void k_rc_ball(const CandSpec cs, long long n, const double* __restri
   }
 }
 
-struct RcView {                        // the context looks at the widened + refined fp64 posterior while the scope lives
-  sbo_ctx* c;
+struct RcView {                        // the context looks at the refined fp64 posterior while the scope lives: the widened copy
+  sbo_ctx* c;                          // of an fp32 posterior, or (guard) the fp64 posterior itself, refined in place
+  bool guard;
   DevBuf keep_m, keep_v;
   int keep_dtype;
   bool keep_valid;
-  RcView(sbo_ctx* c_) : c(c_), keep_m(c_->mean), keep_v(c_->var), keep_dtype(c_->dtype), keep_valid(c_->posterior_valid) {
-    c->mean = c->rc_mean;
-    c->var = c->rc_var;
+  RcView(sbo_ctx* c_, bool guard_) : c(c_), guard(guard_), keep_m(c_->mean), keep_v(c_->var), keep_dtype(c_->dtype), keep_valid(c_->posterior_valid) {
+    if (!guard) {
+      c->mean = c->rc_mean;
+      c->var = c->rc_var;
+    }
     c->dtype = SBO_F64;
     c->posterior_valid = true;
+    c->gb_off = true;                  // (every value that enters a decision is exact by now: no band)
   }
   ~RcView() {
-    c->rc_mean = c->mean;
-    c->rc_var = c->var;
-    c->mean = keep_m;
-    c->var = keep_v;
+    if (!guard) {
+      c->rc_mean = c->mean;
+      c->rc_var = c->var;
+      c->mean = keep_m;
+      c->var = keep_v;
+    }
     c->dtype = keep_dtype;
     c->posterior_valid = keep_valid;
+    c->gb_off = false;
   }
 };
 
-// front end shared by the GoOSE / trust-region rechecks: fp32 posterior, widened copy, first refinement list (q > 1: every
+// front end shared by the GoOSE / trust-region rechecks: posterior, (fp32) widened copy, first refinement list (q > 1: every
 // possibly-safe or undecided candidate), fp64 Lipschitz keys.  Leaves the list buffers ready for further rounds.
+template <typename TP>
 static int rc_front_all(sbo_ctx* c, const sbo_sweep_opts* o, RcBand& bd, long long* total) {
-  sbo_ctx* s = c->shadow;
+  constexpr bool kGuard = std::is_same<TP, double>::value;
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
   int rc;
-  const bool reuse = o->posterior_ready && c->posterior_valid;
+  const bool reuse = kGuard || (o->posterior_ready && c->posterior_valid);
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   c->k1_stop_attached = false;
-  memset(&bd, 0, sizeof(bd));
-  for (int i = 0; i < q; ++i) {
-    const double ys = std::max(1.0, c->mc.Y_std[i]);
-    bd.dm[i] = 1e-4 * ys;
-    bd.dv[i] = 1e-4 * ys * ys;
-  }
+  if ((rc = rc_bands(c, kGuard, bd))) return rc;
   if ((rc = ensure(c->rc_list, kRcList + sizeof(long long) * (size_t)std::max<long long>(n, 1) * 2))) return rc;
-  if ((rc = ensure(c->rc_mean, sizeof(double) * (size_t)q * std::max<long long>(n, 1)))) return rc;
-  if ((rc = ensure(c->rc_var, sizeof(double) * (size_t)q * std::max<long long>(n, 1)))) return rc;
+  if (!kGuard) {
+    if ((rc = ensure(c->rc_mean, sizeof(double) * (size_t)q * std::max<long long>(n, 1)))) return rc;
+    if ((rc = ensure(c->rc_var, sizeof(double) * (size_t)q * std::max<long long>(n, 1)))) return rc;
+  }
   if ((rc = ensure(c->rc_refined, (size_t)std::max<long long>(n, 1)))) return rc;
   RcScal* sc = (RcScal*)c->rc_list.p;
   long long* list = (long long*)((char*)c->rc_list.p + kRcList);
@@ -521,41 +590,31 @@ static int rc_front_all(sbo_ctx* c, const sbo_sweep_opts* o, RcBand& bd, long lo
   const RcScal init{~0ull, ~0ull, 0ull, 0};
   SBO_HIP(hipMemcpyAsync(sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   SBO_HIP(hipMemsetAsync(c->rc_refined.p, 0, (size_t)std::max<long long>(n, 1), c->stream));
-  const float* m32 = (const float*)c->mean.p;
-  const float* v32 = (const float*)c->var.p;
+  const TP* m32 = (const TP*)c->mean.p;
+  const TP* v32 = (const TP*)c->var.p;
   const unsigned nbk = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));
   *total = 0;
   if (q > 1) {
     // (ulo / uhi / vmax stay at their initial values: only the "undecided or possibly safe" rule of the flag pass fires)
-    hipLaunchKernelGGL(k_rc_flag, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc, list, 2);
+    hipLaunchKernelGGL(k_rc_flag<TP>, dim3(nbk), dim3(256), 0, c->stream, m32, v32, n, q, o->b, bd, sc, list, 2);
   }
-  hipLaunchKernelGGL(k_rc_widen, dim3(nbk), dim3(256), 0, c->stream, m32, v32, (long long)q * n, (double*)c->rc_mean.p, (double*)c->rc_var.p);
+  if (!kGuard)
+    hipLaunchKernelGGL(k_rc_widen, dim3(nbk), dim3(256), 0, c->stream, (const float*)c->mean.p, (const float*)c->var.p, (long long)q * n,
+                       (double*)c->rc_mean.p, (double*)c->rc_var.p);
   SBO_HIP(hipGetLastError());
   unsigned char* hb = c->h_back + 5120;
   SBO_HIP(hipMemcpyAsync(hb, sc, 64, hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
   *total = ((const RcScal*)hb)->count;
-  if ((rc = rc_refine(c, list, *total))) return rc;
-  if (q > 1) {
-    SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
-    const unsigned nbg = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8));
-#define SBO_GRAD(DD)                                                                                                              \
-  hipLaunchKernelGGL(k_rc_grad64<DD>, dim3(nbg), dim3(256), 0, c->stream, s->mc, c->cs, (const double*)s->As.p, (const double*)s->sqA.p, \
-                     (const double*)s->alpha.p, (const double*)s->Xn.p, (unsigned long long*)c->Lmax.p)
-    switch (c->mc.dpad) {
-      case 2: SBO_GRAD(2); break;
-      case 4: SBO_GRAD(4); break;
-      default: SBO_GRAD(8); break;
-    }
-#undef SBO_GRAD
-    SBO_HIP(hipGetLastError());
-  }
+  if ((rc = rc_refine(c, list, *total, kGuard))) return rc;
+  if (q > 1 && (rc = rc_lipschitz64(c, kGuard ? c : c->shadow))) return rc;
   return SBO_OK;
 }
 
-// contenders of arg-min lcb_0 over `mask` (nmask stacked byte masks, nullptr: every candidate): re-evaluated in fp64; returns
+// contenders of arg-min lcb_0 over `mask` (nmask stacked byte masks, nullptr: every candidate): re-evaluated exactly; returns
 // how many there were (0: the arg-min already rests on exact values)
-static int rc_argmin_contenders(sbo_ctx* c, const sbo_sweep_opts* o, const RcBand& bd, const uint8_t* mask, int nmask, long long* found) {
+static int rc_argmin_contenders(sbo_ctx* c, const sbo_sweep_opts* o, const RcBand& bd, const uint8_t* mask, int nmask, long long* found,
+                                bool guard) {
   const long long n = c->cs.n_local;
   int rc;
   unsigned long long* key = (unsigned long long*)((char*)c->rc_list.p + kRcCount2 + 8);
@@ -564,71 +623,94 @@ static int rc_argmin_contenders(sbo_ctx* c, const sbo_sweep_opts* o, const RcBan
   const unsigned long long init[2] = {0ull, ~0ull};
   SBO_HIP(hipMemcpyAsync(count2, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   const unsigned nbk = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)c->n_cu * 4));
-  const double* m0 = (const double*)c->rc_mean.p;
-  const double* v0 = (const double*)c->rc_var.p;
+  const double* m0 = guard ? (const double*)c->mean.p : (const double*)c->rc_mean.p;
+  const double* v0 = guard ? (const double*)c->var.p : (const double*)c->rc_var.p;
   hipLaunchKernelGGL(k_rc_lmin, dim3(nbk), dim3(256), 0, c->stream, m0, v0, (const uint8_t*)c->rc_refined.p, mask, nmask, n, o->b, bd.dm[0], bd.dv[0], key);
+  if ((rc = comm_allreduce_min_u64(c, key, 1))) return rc;             // (ranks > 1: the arg-min is over all ranks)
   hipLaunchKernelGGL(k_rc_lflag, dim3(nbk), dim3(256), 0, c->stream, m0, v0, (const uint8_t*)c->rc_refined.p, mask, nmask, n, o->b, bd.dm[0], bd.dv[0],
                      (const unsigned long long*)key, list, count2);
   SBO_HIP(hipGetLastError());
   unsigned char* hb = c->h_back + 5120;
   SBO_HIP(hipMemcpyAsync(hb, c->rc_list.p, 64, hipMemcpyDeviceToHost, c->stream));
   SBO_HIP(hipStreamSynchronize(c->stream));
-  *found = (long long)*(const unsigned long long*)(hb + kRcCount2);
-  if ((rc = rc_refine(c, list, *found))) return rc;
+  const long long mine = (long long)*(const unsigned long long*)(hb + kRcCount2);
+  *found = mine;
+  if (multi_rank(c)) {                   // every rank goes round the same number of times: the largest count decides
+    unsigned long long* dcount = (unsigned long long*)((char*)c->rc_list.p + kRcCount2 + 16);
+    SBO_HIP(hipMemcpyAsync(dcount, hb + kRcCount2, 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = comm_allreduce_max_u64(c, dcount, 1))) return rc;
+    SBO_HIP(hipMemcpyAsync(hb + 56, dcount, 8, hipMemcpyDeviceToHost, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));
+    *found = (long long)*(const unsigned long long*)(hb + 56);
+  }
+  if ((rc = rc_refine(c, list, mine, guard))) return rc;
   return SBO_OK;
 }
 
-static int sweep_goose_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* res) {
+template <typename TP>
+static int sweep_goose_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* res) {
+  constexpr bool kGuard = std::is_same<TP, double>::value;
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
-  if (n == 0) return sweep_goose_t<float>(c, o, res);
+  if (n == 0) return kGuard ? sweep_goose_t<double>(c, o, res) : sweep_goose_t<float>(c, o, res);
   int rc;
   SBO_HIP(hipEventRecord(c->ev_join[0], c->stream));
-  const bool reuse = o->posterior_ready && c->posterior_valid;
+  const bool reuse = kGuard || (o->posterior_ready && c->posterior_valid);
   RcBand bd;
   long long total = 0, more = 0;
-  if ((rc = rc_front_all(c, o, bd, &total))) return rc;
+  if ((rc = rc_front_all<TP>(c, o, bd, &total))) return rc;
   SBO_HIP(hipEventRecord(c->ev_join[1], c->stream));
   sbo_sweep_opts o2 = *o;
   o2.posterior_ready = 1;
   o2.want_masks = 1;
+  int passes = 0;
   if (q == 1) {
     // arg-min lcb_0 over every candidate: its contenders, then one fp64 set phase
-    if ((rc = rc_argmin_contenders(c, o, bd, nullptr, 0, &more))) return rc;
+    if ((rc = rc_argmin_contenders(c, o, bd, nullptr, 0, &more, kGuard))) return rc;
     total += more;
-    RcView view(c);
+    RcView view(c, kGuard);
     rc = sweep_goose_t<double>(c, &o2, res);
+    passes = 1;
   } else {
     for (int pass = 0; pass < 3; ++pass) {
       {
-        RcView view(c);
+        RcView view(c, kGuard);
         rc = sweep_goose_t<double>(c, &o2, res);
       }
+      ++passes;
       if (rc != SBO_OK) break;
-      // the target: arg-min lcb_0 over the union of the optimistic sets (members are unsafe candidates, so far fp32 values)
-      if ((rc = rc_argmin_contenders(c, o, bd, (const uint8_t*)c->maskO.p, q - 1, &more))) return rc;
+      // the target: arg-min lcb_0 over the union of the optimistic sets (members are unsafe candidates, so far unrefined values)
+      if ((rc = rc_argmin_contenders(c, o, bd, (const uint8_t*)c->maskO.p, q - 1, &more, kGuard))) return rc;
       total += more;
       if (more == 0) break;
     }
   }
-  c->posterior_valid = c->posterior_valid || !reuse;
-  c->prof.fp64_rechecks = total;
-  c->prof.posterior_launches = reuse ? 0 : 1;
   float t01 = 0;
   (void)hipEventElapsedTime(&t01, c->ev_join[0], c->ev_join[1]);
-  c->prof.recheck_ms = t01;
+  if (kGuard) {
+    res->guard_rechecks = total;
+    res->guard_passes = passes;
+    c->prof.guard_ms = t01;
+  } else {
+    c->posterior_valid = c->posterior_valid || !reuse;
+    c->prof.fp64_rechecks = total;
+    c->prof.posterior_launches = reuse ? 0 : 1;
+    c->prof.recheck_ms = t01;
+  }
   return rc;
 }
 
-static int sweep_tr_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, double r, sbo_tr_result* res) {
+template <typename TP>
+static int sweep_tr_recheck(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, double r, sbo_tr_result* res) {
+  constexpr bool kGuard = std::is_same<TP, double>::value;
   const long long n = c->cs.n_local;
   const int q = c->mc.q;
-  if (n == 0) return sweep_tr_t<float>(c, o, x0, r, res);
+  if (n == 0) return kGuard ? sweep_tr_t<double>(c, o, x0, r, res) : sweep_tr_t<float>(c, o, x0, r, res);
   int rc;
-  const bool reuse = o->posterior_ready && c->posterior_valid;
+  const bool reuse = kGuard || (o->posterior_ready && c->posterior_valid);
   RcBand bd;
   long long total = 0, more = 0;
-  if ((rc = rc_front_all(c, o, bd, &total))) return rc;
+  if ((rc = rc_front_all<TP>(c, o, bd, &total))) return rc;
   sbo_sweep_opts o2 = *o;
   o2.posterior_ready = 1;
   if (q == 1) {
@@ -642,14 +724,19 @@ static int sweep_tr_f32_recheck(sbo_ctx* c, const sbo_sweep_opts* o, const doubl
       case 4: hipLaunchKernelGGL((k_rc_ball<4>), dim3(nbk), dim3(256), 0, c->stream, c->cs, n, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
       default: hipLaunchKernelGGL((k_rc_ball<8>), dim3(nbk), dim3(256), 0, c->stream, c->cs, n, (const double*)dev_x0, r, (uint8_t*)c->maskM.p); break;
     }
-    if ((rc = rc_argmin_contenders(c, o, bd, (const uint8_t*)c->maskM.p, 1, &more))) return rc;
+    if ((rc = rc_argmin_contenders(c, o, bd, (const uint8_t*)c->maskM.p, 1, &more, kGuard))) return rc;
     total += more;
   }
   {
-    RcView view(c);
+    RcView view(c, kGuard);
     rc = sweep_tr_t<double>(c, &o2, x0, r, res);
   }
-  c->posterior_valid = c->posterior_valid || !reuse;
-  c->prof.fp64_rechecks = total;
+  if (kGuard) {
+    res->guard_rechecks = total;
+    res->guard_passes = 1;
+  } else {
+    c->posterior_valid = c->posterior_valid || !reuse;
+    c->prof.fp64_rechecks = total;
+  }
   return rc;
 }

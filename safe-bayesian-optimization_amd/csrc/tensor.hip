@@ -379,7 +379,30 @@ __global__ void k_t_probe_pts(const CandSpec cs, const long long* __restrict__ i
   }
 }
 
+// the interpolant of quantity qi at listed grid points, from the tensor the small contractions leave (cores [planes][DM x DM] in
+// packed-image order per quantity): out[(qi - q_first) np + i] = W0[x0] . M . W1[x1].  A wave per (point, quantity).  Used by the
+// plan's probe for the gradient components, which k_t_final reduces to their maximum without ever storing them.
+__global__ __launch_bounds__(256) void k_t_probe_core(const double* __restrict__ cur, size_t stride_q, int DM, const double* __restrict__ W0,
+                                                      const double* __restrict__ W1, long long n0, long long n1,
+                                                      const long long* __restrict__ idx, int np, int q_first, int nq, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, total = (long long)np * nq;
+  if (w >= total) return;
+  const int i = (int)(w % np), qi = q_first + (int)(w / np);
+  const long long g = idx[i], x0 = g % n0, x1 = (g / n0) % n1, plane = g / (n0 * n1);
+  const double* M = cur + (size_t)qi * stride_q + (size_t)plane * DM * DM;
+  double s = 0.0;
+  for (int p = lane; p < DM * DM; p += 64) {
+    int a, b;
+    core_pos(p, DM, a, b);
+    s = fma(W0[x0 * DM + a] * W1[x1 * DM + b], M[p], s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[(size_t)(qi - q_first) * np + i] = s;
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------------------
+int comm_allreduce_min_u64(sbo_ctx* c, unsigned long long* dev, int count);
 // node counts: the first two axes in matrix-core k-blocks (k_t_final), the further ones in steps of eight (k_t_mode takes any)
 static const int kLadder01[4] = {32, 48, 64, 96};
 static const int kLadderN[7] = {32, 40, 48, 56, 64, 80, 96};
@@ -415,35 +438,6 @@ static int mode_dispatch(hipStream_t st, int DM, const double* in, size_t sin, d
   }
   return SBO_OK;
 }
-// the exact posterior of the generic kernel on an explicit fp64 list, into caller-given arrays (the context's candidate
-// description and posterior buffers are swapped for the call)
-static int exact_on_list(sbo_ctx* c, const double* pts, long long N, double* mean_out, double* var_out) {
-  const CandSpec keep_cs = c->cs;
-  const DevBuf keep_m = c->mean, keep_v = c->var, keep_l = c->Lmax;
-  const int keep_k1 = c->last_k1;
-  const double keep_flops = c->last_k1_flops;
-  memset(&c->cs, 0, sizeof(c->cs));
-  c->cs.kind = 0;
-  c->cs.d = keep_cs.d;
-  c->cs.pts_dtype = SBO_F64;
-  c->cs.pts = pts;
-  c->cs.n_local = N;
-  c->cs.first = 0;
-  c->mean.p = mean_out;
-  c->var.p = var_out;
-  c->Lmax.p = c->tn_scr.p;                     // (the Lipschitz keys of the list are of no interest; the grid's come from k_t_final)
-  c->tensor_busy = true;                       // (launch_posterior must not come back here)
-  const int rc = launch_posterior(c);
-  c->tensor_busy = false;
-  c->cs = keep_cs;
-  c->mean = keep_m;
-  c->var = keep_v;
-  c->Lmax = keep_l;
-  c->last_k1 = keep_k1;
-  c->last_k1_flops = keep_flops;
-  return rc;
-}
-
 template <int DM, int CS>
 static int launch_final(sbo_ctx* c, const double* in, size_t stride_q, const TensorDims& td, long long planes, int nq) {
   const size_t lds = sizeof(double) * ((size_t)(DM / 4) * CS * 64 + 4 * (size_t)(2 * (DM / 16) * 256) + 4 * 16 * 36 + (DM <= 48 ? 2 * DM * DM : 0));
@@ -458,7 +452,7 @@ static int launch_final(sbo_ctx* c, const double* in, size_t stride_q, const Ten
 }
 
 // all `nq` stacked node tensors (stride Nn: q means, q variances, q d gradient components) to the grid
-static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, long long Nn, int nq) {
+static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, long long Nn, int nq, const double** cur_out, size_t* stride_out) {
   const int d = td.d;
   int rc;
   // axes d-1 .. 2 on the small tensors (ping-pong in tn_work), then the planes
@@ -485,6 +479,8 @@ static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, lo
     toA = !toA;
   }
   // now cur = [DM][DM][planes = post] per quantity
+  *cur_out = cur;
+  *stride_out = cur_stride;
   c->tn_flops += 2.0 * (double)post * nq * ((double)td.cnt[0] * td.Dn[0] * td.Dn[1] + (double)td.cnt[0] * td.cnt[1] * td.Dn[1]);
   SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
   switch (td.Dn[0]) {
@@ -558,7 +554,8 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     // buffers: node list, node values (mean, var: q each; gradient: q d), interpolation matrices, ping-pong work
     const int nqg = q * d;
     if ((rc = ensure(c->tn_pts, sizeof(double) * 4 * 128))) return rc;       // the node positions of the axes
-    if ((rc = ensure(c->tn_vals, sizeof(double) * (size_t)Nn * (2 * q + nqg)))) return rc;
+    // (the two large buffers: running out of memory for them is a reason to decline -- K1g needs neither --, not to fail the sweep)
+    if ((rc = ensure(c->tn_vals, sizeof(double) * (size_t)Nn * (2 * q + nqg)))) { if (rc == SBO_E_NOMEM) break; return rc; }
     size_t half_elems = 0;
     {
       long long pre = 1, post = 1;
@@ -570,7 +567,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       }
     }
     c->tn_work_half = half_elems;
-    if ((rc = ensure(c->tn_work, sizeof(double) * 2 * std::max<size_t>(half_elems, 16)))) return rc;
+    if ((rc = ensure(c->tn_work, sizeof(double) * 2 * std::max<size_t>(half_elems, 16)))) { if (rc == SBO_E_NOMEM) break; return rc; }
     for (int a = 0; a < d; ++a)
       if ((rc = ensure(c->tn_W[a], sizeof(double) * (size_t)td.cnt[a] * td.Dn[a]))) return rc;
     if ((rc = ensure(c->tn_W0t, sizeof(double) * (size_t)td.cnt[0] * td.Dn[0]))) return rc;
@@ -591,7 +588,9 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     }
     // interpolation: mean, variance (clipped at zero), gradient components -> Lipschitz keys max_a max_x |d MEAN_o / d x_a|
     c->tn_flops = 0.0;
-    if ((rc = interpolate(c, td, nmean, Nn, 2 * q + nqg))) return rc;
+    const double* cur = nullptr;
+    size_t cur_stride = 0;
+    if ((rc = interpolate(c, td, nmean, Nn, 2 * q + nqg, &cur, &cur_stride))) return rc;
     if (!same_grid) {
       // accuracy probe: 2048 grid points, exact against interpolated
       std::vector<long long> idx(kTProbes);
@@ -611,7 +610,8 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
         }
         idx[i] = f;
       }
-      const size_t pbytes = sizeof(long long) * kTProbes + sizeof(double) * (size_t)kTProbes * (d + 4 * q);
+      // probe buffers: indices | points | exact mean, var | interpolated mean, var | exact gradient, interpolated gradient [q d] | keys
+      const size_t pbytes = sizeof(long long) * kTProbes + sizeof(double) * ((size_t)kTProbes * (d + 4 * q + 2 * nqg) + kMaxQ);
       if ((rc = ensure(c->tn_probe, pbytes))) return rc;
       long long* didx = (long long*)c->tn_probe.p;
       double* ppts = (double*)(didx + kTProbes);
@@ -619,25 +619,68 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       double* pexv = pexm + (size_t)q * kTProbes;
       double* pinm = pexv + (size_t)q * kTProbes;
       double* pinv = pinm + (size_t)q * kTProbes;
+      double* pexg = pinv + (size_t)q * kTProbes;          // exact / interpolated signed gradient components [q d][np]
+      double* ping = pexg + (size_t)nqg * kTProbes;
+      double* pkeys = ping + (size_t)nqg * kTProbes;       // the Lipschitz keys k_t_final has just reduced
       SBO_HIP(hipMemcpyAsync(didx, idx.data(), sizeof(long long) * kTProbes, hipMemcpyHostToDevice, c->stream));
       hipLaunchKernelGGL((k_t_probe_pts<4>), dim3(8), dim3(256), 0, c->stream, cs, (const long long*)didx, kTProbes, ppts);
-      if ((rc = exact_on_list(c, ppts, kTProbes, pexm, pexv))) return rc;
+      if ((rc = launch_posterior_on_list(c, ppts, kTProbes, pexm, pexv))) return rc;
+      if ((rc = guard_exact_grad_list(c, ppts, kTProbes, pexg))) return rc;
       hipLaunchKernelGGL(k_t_pick, dim3(8, q), dim3(256), 0, c->stream, (const double*)c->mean.p, (size_t)cs.n_local, (const long long*)didx, kTProbes, pinm);
       hipLaunchKernelGGL(k_t_pick, dim3(8, q), dim3(256), 0, c->stream, (const double*)c->var.p, (size_t)cs.n_local, (const long long*)didx, kTProbes, pinv);
-      std::vector<double> h((size_t)4 * q * kTProbes);
+      hipLaunchKernelGGL(k_t_probe_core, dim3((unsigned)(((long long)kTProbes * nqg * 64 + 255) / 256)), dim3(256), 0, c->stream, cur, cur_stride,
+                         td.Dn[0], (const double*)c->tn_W[0].p, (const double*)c->tn_W[1].p, td.cnt[0], td.cnt[1], (const long long*)didx, kTProbes,
+                         2 * q, nqg, ping);
+      SBO_HIP(hipMemcpyAsync(pkeys, c->Lmax.p, sizeof(double) * kMaxQ, hipMemcpyDeviceToDevice, c->stream));
+      std::vector<double> h((size_t)(4 * q + 2 * nqg) * kTProbes + kMaxQ);
       SBO_HIP(hipMemcpyAsync(h.data(), pexm, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
       SBO_HIP(hipStreamSynchronize(c->stream));
-      double err = 0.0;
+      // deviations per output (un-normalised: the band's units) and the probe error in normalised units (the plan's gate);
+      // a value that is not finite fails the gate (NaN compares false)
+      double err = 0.0, em[kMaxQ], ev[kMaxQ], eg[kMaxQ], am[kMaxQ], av[kMaxQ];
+      bool finite = true;
       for (int o = 0; o < q; ++o) {
         const double ys = std::max(1.0, mc.Y_std[o]);
+        em[o] = ev[o] = eg[o] = am[o] = av[o] = 0.0;
         for (int i = 0; i < kTProbes; ++i) {
-          err = std::max(err, std::fabs(h[((size_t)2 * q + o) * kTProbes + i] - h[(size_t)o * kTProbes + i]) / ys);
-          err = std::max(err, std::fabs(h[((size_t)3 * q + o) * kTProbes + i] - h[((size_t)q + o) * kTProbes + i]) / (ys * ys));
+          const double xm = h[(size_t)o * kTProbes + i], xv = h[((size_t)q + o) * kTProbes + i];
+          const double dmv = std::fabs(h[((size_t)2 * q + o) * kTProbes + i] - xm), dvv = std::fabs(h[((size_t)3 * q + o) * kTProbes + i] - xv);
+          finite = finite && std::isfinite(dmv) && std::isfinite(dvv);
+          em[o] = std::max(em[o], dmv);
+          ev[o] = std::max(ev[o], dvv);
+          am[o] = std::max(am[o], std::fabs(xm));
+          av[o] = std::max(av[o], std::fabs(xv));
         }
+        for (int a = 0; a < d; ++a)
+          for (int i = 0; i < kTProbes; ++i) {
+            const double dg = std::fabs(h[((size_t)4 * q + nqg + (size_t)o * d + a) * kTProbes + i] - h[((size_t)4 * q + (size_t)o * d + a) * kTProbes + i]);
+            finite = finite && std::isfinite(dg);
+            eg[o] = std::max(eg[o], dg);
+          }
+        err = std::max(err, std::max(em[o] / ys, ev[o] / (ys * ys)));
       }
       if (getenv("SBO_DEBUG_TENSOR"))
-        fprintf(stderr, "[K1t] nodes %d x %d x %d x %d = %lld, probe error %.2e (attempt %d)\n", td.Dn[0], td.Dn[1], td.Dn[2], d > 3 ? td.Dn[3] : 1, Nn,
-                err, attempt);
+        fprintf(stderr, "[K1t] nodes %d x %d x %d x %d = %lld, probe error %.2e (gradient %.2e / %.2e) (attempt %d)\n", td.Dn[0], td.Dn[1], td.Dn[2],
+                d > 3 ? td.Dn[3] : 1, Nn, err, eg[0], q > 1 ? eg[1] : 0.0, attempt);
+      // ranks > 1: the plan is ONE decision -- a rank whose shard misses the gate takes every rank to the next attempt / to K1g
+      // (results must not depend on the world size)
+      unsigned long long ok_local = (finite && err <= 2e-11) ? 1ull : 0ull, ok_all = ok_local;
+      {
+        unsigned long long* dkey = reinterpret_cast<unsigned long long*>(pkeys) + kMaxQ - 1;    // (a spare word of the probe block)
+        SBO_HIP(hipMemcpyAsync(dkey, &ok_local, 8, hipMemcpyHostToDevice, c->stream));
+        if ((rc = comm_allreduce_min_u64(c, dkey, 1))) return rc;
+        SBO_HIP(hipMemcpyAsync(&ok_all, dkey, 8, hipMemcpyDeviceToHost, c->stream));
+        SBO_HIP(hipStreamSynchronize(c->stream));
+      }
+      // the plan's guard band (guard.hip): 16 x the largest probe deviation + a rounding floor; the Lipschitz keys' relative band
+      // from the gradient components' deviation
+      const double eps = 2.220446049250313e-16, safety = 16.0;
+      for (int o = 0; o < q; ++o) {
+        const double Lo = h[(size_t)(4 * q + 2 * nqg) * kTProbes + o];
+        c->tn_band[o] = safety * em[o] + 64.0 * eps * std::max(am[o], std::fabs(mc.Y_mean[o]) + mc.Y_std[o]);
+        c->tn_band[kMaxQ + o] = safety * ev[o] + 64.0 * eps * std::max(av[o], mc.sf2[o] * mc.Y_std[o] * mc.Y_std[o]);
+        c->tn_band[2 * kMaxQ + o] = (Lo > 0.0 ? safety * eg[o] / Lo : 0.0) + 1e-13;
+      }
       c->tn_valid = true;
       c->tn_model = c->model_serial;
       c->tn_first = cs.first;
@@ -649,12 +692,16 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
         c->tn_level[a] = std::min(ladder_size(a) - 1, level0[a] + attempt);
         c->tn_dn[a] = td.Dn[a];
       }
-      c->tn_usable = err <= 2e-11;
+      c->tn_usable = ok_all != 0ull;
       if (!c->tn_usable) continue;           // one step up the ladder, or give up
       if (attempt > 0) c->tn_bump = std::min(2, c->tn_bump + 1);
     }
     *declined = false;
     c->last_k1 = 5;
+    if (c->guard_band) {
+      if ((rc = guard_band_host(c, c->tn_band, c->tn_band + kMaxQ, c->tn_band + 2 * kMaxQ))) return rc;   // (192 bytes: whoever used the block last)
+      c->gb_active = true;
+    }
     // flops issued: node posterior (block-triangular contraction) + interpolation sums
     c->last_k1_flops = (double)q * mc.npad * (mc.npad + 16.0) * (double)Nn + c->tn_flops;
     return SBO_OK;

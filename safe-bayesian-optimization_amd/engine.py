@@ -192,7 +192,8 @@ class SweepEngine:
             "choose_minimizer": bool(res.choose_minimizer), "u_star": float(res.u_star),
             "L": np.array(res.L[:q]), "count_S": int(res.count_S), "count_U": int(res.count_U),
             "count_M": int(res.count_M), "count_G": np.array(res.count_G[:q - 1], dtype=np.int64),
-            "n_exact_rechecks": int(res.n_exact_rechecks),
+            "n_exact_rechecks": int(res.n_exact_rechecks), "guard_band": int(res.guard_band),
+            "guard_rechecks": int(res.guard_rechecks), "guard_passes": int(res.guard_passes),
         }
 
     def sweep_goose(self, b: float, quirk_L_index: bool = True, want_masks: bool = False,
@@ -211,6 +212,7 @@ class SweepEngine:
             "explore_x": np.array(res.explore_x[:d]), "choose_safe_min": bool(res.choose_safe_min),
             "L": np.array(res.L[:q]), "count_S": int(res.count_S), "count_U": int(res.count_U),
             "count_O": np.array(res.count_O[:q - 1], dtype=np.int64), "n_exact_rechecks": int(res.n_exact_rechecks),
+            "guard_band": int(res.guard_band), "guard_rechecks": int(res.guard_rechecks), "guard_passes": int(res.guard_passes),
         }
 
     def sweep_tr(self, b: float, x_0, r: float, posterior_ready: bool = False) -> dict:
@@ -222,7 +224,8 @@ class SweepEngine:
             raise ValueError("x_0 must have shape [d]")
         L.check(self._lib.sbo_sweep_tr(self._ctx, C.byref(opts), _ptr(x0), float(r), C.byref(res)))
         return {"index": int(res.index), "x": np.array(res.x[:self.d]), "lcb": float(res.lcb),
-                "count_S": int(res.count_S), "count_T": int(res.count_T)}
+                "count_S": int(res.count_S), "count_T": int(res.count_T), "guard_band": int(res.guard_band),
+                "guard_rechecks": int(res.guard_rechecks), "guard_passes": int(res.guard_passes)}
 
     def mask(self, which: str, c: int = 0) -> np.ndarray:
         w = {"S": L.SBO_MASK_S, "U": L.SBO_MASK_U, "M": L.SBO_MASK_M, "G": L.SBO_MASK_G, "O": L.SBO_MASK_O}[which]
@@ -269,4 +272,5 @@ class SweepEngine:
     def profile(self) -> dict:
         p = L.Profile()
         L.check(self._lib.sbo_profile_get(self._ctx, C.byref(p)))
-        return {name: getattr(p, name) for name, _ in L.Profile._fields_}
+        return {name: (list(getattr(p, name)) if name in ("guard_dm", "guard_dv", "guard_rl") else getattr(p, name))
+                for name, _ in L.Profile._fields_}

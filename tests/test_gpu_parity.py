@@ -204,7 +204,7 @@ def test_tensor_interpolation_equals_the_grid_kernel(engine, d, count, n, log_el
             if isinstance(v, (int, bool, np.integer)) or (isinstance(v, np.ndarray) and v.dtype.kind in "iub"):
                 assert np.array_equal(np.asarray(v), np.asarray(out[1][which][k])), (which, k)
     ys = np.maximum(1.0, ds["Y_std"])
-    assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < 2e-11 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < 2e-11
+    assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < TOL64 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < TOL64
     r0, r1 = out[0][3], out[1][3]
     for k in ("minimizer_index", "expander_index", "count_S", "count_U", "count_M", "choose_minimizer"):
         assert r0[k] == r1[k], k
@@ -264,7 +264,7 @@ def test_tensor_interpolation_random_models(engine, seed):
         engine.set_option("tensor_cheb", 1)
     assert out[0][2] == 3 and out[1][2] in (3, 5)
     ys = np.maximum(1.0, ds["Y_std"])
-    assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < 2e-11 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < 2e-11
+    assert np.max(np.abs(out[1][0] - out[0][0]) / ys) < TOL64 and np.max(np.abs(out[1][1] - out[0][1]) / ys ** 2) < TOL64
     assert (out[0][3] is None) == (out[1][3] is None)
     if out[0][3] is not None:
         for k in ("minimizer_index", "expander_index", "count_S", "count_U", "count_M", "choose_minimizer"):
