@@ -200,7 +200,7 @@ int sbo_shutdown(sbo_ctx* c) {
   }
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_cheb, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->invk_img, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg, &c->tn_pts, &c->tn_vals, &c->tn_work, &c->tn_W0t, &c->tn_W1t, &c->tn_probe, &c->tn_scr, &c->gb, &c->gb_pts, &c->gb_vals, &c->gb_probe, &c->list_scr})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_cheb, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->invk_img, &c->bl_lpart, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg, &c->tn_pts, &c->tn_vals, &c->tn_work, &c->tn_W0t, &c->tn_W1t, &c->tn_probe, &c->tn_scr, &c->gb, &c->gb_pts, &c->gb_vals, &c->gb_probe, &c->gb_part, &c->list_scr})
     release(*b);
   for (auto& b : c->tn_W) release(b);
   for (auto& ev : c->ev)
@@ -649,11 +649,19 @@ int sbo_profile_get(sbo_ctx* c, sbo_profile* out) {
   // the guard band of the posterior that is resident (K1b measures it on the device: a small read-back, off the hot path)
   for (int o = 0; o < SBO_MAX_Q; ++o) out->guard_dm[o] = out->guard_dv[o] = out->guard_rl[o] = 0.0;
   if (c->gb_active && c->guard_band && c->gb.p && c->posterior_valid) {
-    GuardBand hb;
-    SBO_HIP(hipSetDevice(c->device));
-    SBO_HIP(hipMemcpyAsync(&hb, c->gb.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
-    SBO_HIP(hipStreamSynchronize(c->stream));
-    for (int o = 0; o < c->mc.q; ++o) { out->guard_dm[o] = hb.dm[o]; out->guard_dv[o] = hb.dv[o]; out->guard_rl[o] = hb.rl[o]; }
+    if (!c->gb_host_valid) {               // (once per plan: the profile is read after every sweep of a timing loop)
+      GuardBand hb;
+      SBO_HIP(hipSetDevice(c->device));
+      SBO_HIP(hipMemcpyAsync(&hb, c->gb.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+      SBO_HIP(hipStreamSynchronize(c->stream));
+      for (int o = 0; o < SBO_MAX_Q; ++o) { c->gb_host[o] = hb.dm[o]; c->gb_host[SBO_MAX_Q + o] = hb.dv[o]; c->gb_host[2 * SBO_MAX_Q + o] = hb.rl[o]; }
+      c->gb_host_valid = true;
+    }
+    for (int o = 0; o < c->mc.q; ++o) {
+      out->guard_dm[o] = c->gb_host[o];
+      out->guard_dv[o] = c->gb_host[SBO_MAX_Q + o];
+      out->guard_rl[o] = c->gb_host[2 * SBO_MAX_Q + o];
+    }
   }
   return SBO_OK;
 }

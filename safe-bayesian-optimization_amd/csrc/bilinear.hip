@@ -971,7 +971,9 @@ struct PostCtx {
   double rmax;        // max ucb over its safe candidates (-1: none; ucb >= lcb >= 0 on S)
   // guard band of this posterior (guard.hip): sign tests the band of the constraint's output could move are counted, and the
   // smallest variance over the thread's safe candidates is kept (gdm < 0: no band in force)
-  double gdm, gdv, vminS;
+  LcbBand lband;
+  bool gb_on;
+  double vminS;
   int cB;
 };
 
@@ -984,18 +986,17 @@ struct PostCtx {
 // its cheap upper bound beats this thread's running maximum: the IEEE f64 square root is a dozen dependent instructions on the
 // datapath the matrix cores use, which is what made this epilogue cost the kernel as much as the separate pass saved)
 __device__ __forceinline__ void post_classify_mv(PostCtx& cx, size_t g, double m, double v) {
-  const LcbSign sg = lcb_sign(m, v, cx.bconf, cx.bb);
+  const LcbSign sg = cx.gb_on ? lcb_sign_gb(m, v, cx.bconf, cx.bb, cx.lband, cx.cB) : lcb_sign(m, v, cx.bconf, cx.bb);
   cx.S[g] = sg.ge;
   cx.U[g] = sg.le;
   cx.cS += sg.ge;
   cx.cU += sg.le;
-  if (cx.gdm >= 0.0) {
-    cx.cB += lcb_near_zero(m, v, cx.bb, cx.gdm, cx.gdv);
-    if (sg.ge) cx.vminS = v < cx.vminS ? v : cx.vminS;
-  }
-  if (sg.ge && !(ucb_upper(m, v, cx.bconf) <= cx.rmax)) {
-    const double ucb = add_rn(m, mul_rn(cx.bconf, sqrt_rn(v)));
-    if (ucb > cx.rmax) cx.rmax = ucb;
+  if (sg.ge) {
+    cx.vminS = v < cx.vminS ? v : cx.vminS;
+    if (!(ucb_upper(m, v, cx.bconf) <= cx.rmax)) {
+      const double ucb = add_rn(m, mul_rn(cx.bconf, sqrt_rn(v)));
+      if (ucb > cx.rmax) cx.rmax = ucb;
+    }
   }
 }
 __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) { post_classify_mv(cx, g, m, cx.var_rd[g]); }
@@ -1005,7 +1006,8 @@ __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) {
 // reads any more (barrier first).
 template <int NW>
 __device__ __forceinline__ void post_partials(double* sh, int lane, int wave, double gmax, bool fuse, int cS_, int cU_, double rmax_,
-                                              int cB_, double vmin_, double* __restrict__ lrow, unsigned long long* __restrict__ crow) {
+                                              int cB_, double vmin_, double* __restrict__ lrow, unsigned long long* __restrict__ crow /* this
+                                              workgroup's row of the field-major partials */, int pcap) {
   int cS = cS_, cU = cU_, cB = cB_;
   double rm = rmax_, vm = vmin_;
   if (fuse) {
@@ -1053,7 +1055,7 @@ __device__ __forceinline__ void post_partials(double* sh, int lane, int wave, do
       else if (lane == 3) v = (unsigned long long)b_;
       else if (lane >= kFuseVmin && lane < kFuseRmax) v = (lane == kFuseVmin + 1 && vmn < 1e300) ? ord_key(vmn) : ~0ull;
       else if (lane == kFuseRmax + 1) v = r >= 0.0 ? ord_key(r) : 0ull;       // radius key of constraint 1
-      crow[lane] = v;
+      crow[(size_t)lane * pcap] = v;
     }
   }
 }
@@ -1269,7 +1271,8 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
                                                   int KSm, int KBm2, int nrb, int ncs, long long nlines, double* __restrict__ mean_out,
                                                   double* __restrict__ var_out, double* __restrict__ Lpart,
                                                   const double* __restrict__ xn0, uint8_t* __restrict__ Sfuse, uint8_t* __restrict__ Ufuse,
-                                                  double bconf, unsigned long long* __restrict__ cpart /* [workgroups of output 1][kFuseRow] */,
+                                                  double bconf, unsigned long long* __restrict__ cpart /* [kFuseRow][pcap]: a row per workgroup of output 1 */,
+                                                  int pcap,
                                                   const GuardBand* __restrict__ gb /* nullptr: no guard band (the first launch of a plan measures it afterwards) */,
                                                   const int* __restrict__ eff /* nullptr, or the Chebyshev core's k-steps of the variance phase at [4 o] */) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
@@ -1305,8 +1308,8 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   cx.bb = bconf * bconf;
   cx.cS = cx.cU = cx.cB = 0;
   cx.rmax = -1.0;
-  cx.gdm = (fuse && gb) ? gb->dm[1] : -1.0;
-  cx.gdv = (fuse && gb) ? gb->dv[1] : 0.0;
+  cx.gb_on = fuse && gb != nullptr;
+  cx.lband = cx.gb_on ? lcb_band(cx.bb, gb->dm[1], gb->dv[1]) : LcbBand{0.0, 0.0};
   cx.vminS = 1e300;
   double gmax = 0.0;
   // (Tried: odd outputs running the three short phases first and the variance phase last, so that the two workgroups of a
@@ -1331,7 +1334,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   // is resident at once and ends at the same time, so atomics on the q keys would queue up in L2 as the kernel's tail -- and
   // a row per wave made that merge (one workgroup, 16384 rows of 88 bytes on config H) the longest job of the launch it shares
   post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, fuse, cx.cS, cx.cU, cx.rmax, cx.cB, cx.vminS, Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
-                   cpart + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kFuseRow);
+                   cpart + ((size_t)blockIdx.y * gridDim.x + blockIdx.x), pcap);
 }
 
 // Lipschitz keys of a K1b launch: Lmax[o] = max of the per-wave partials (values >= 0, so the bit pattern orders them)
@@ -1608,6 +1611,58 @@ __global__ __launch_bounds__(256) void k_cheb_tab(const BlDims dm, const double*
   }
 }
 
+// K1b's own representation at the probe points of its guard band (guard.hip), from the plan's tables -- the sums the two GEMMs
+// of a posterior launch form, term by term in another order (the difference is their rounding, which the band's floor covers):
+//   quad = sum_{a < A, b < B} ChatT[b][a] T_a(xi0) T_b(xi1)   over the degrees the kernels run (eff), T by the tables' recurrence
+//   mean = mp + sum_p Vb0[p][line] S0[p][x0]
+// A wave per (probe, output): lane l takes the rows b = l, l + 64, .. of ChatT (its T_b by the recurrence up to b, then the row's
+// sum over a with T_a walked along), the lanes' shares meet in a wave sum.  (A thread per probe walked 2304 dependent steps: 105 us.)
+__global__ __launch_bounds__(256) void k_gb_probe_k1b(const ModelConst mc, const CandSpec cs, const BlDims dm, const double* __restrict__ ChatT_all,
+                                                      const int* __restrict__ eff, const double* __restrict__ xn0, const double* __restrict__ xn1,
+                                                      const double* __restrict__ S0all, const double* __restrict__ Vball,
+                                                      double* __restrict__ pm, double* __restrict__ pv) {
+  const int o = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D0 = dm.D0m;
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= kGbProbes) return;                      // (no barriers in this kernel)
+  const int A = eff[4 * o] * 4, B = eff[4 * o + 2] * 16;
+  const double* Ch = ChatT_all + (size_t)o * D0 * dm.D1m;
+  long long x0, x1;
+  gb_probe_xy(cs, dm.nlines, p, x0, x1);
+  auto xi_of = [&](double xn, int axis) {
+    double xi = (2.0 * xn - (dm.a[axis] + dm.b[axis])) / (dm.b[axis] - dm.a[axis]);
+    xi = xi < 1.0 ? xi : 1.0;
+    return xi > -1.0 ? xi : -1.0;
+  };
+  const double xi0 = xi_of(xn0[x0], 0), xi1 = xi_of(xn1[x1], 1);
+  double quad = 0.0;
+  for (int b = lane; b < B; b += 64) {
+    double tb0 = 1.0, tb1 = xi1, tb = b == 0 ? 1.0 : xi1;
+    for (int k = 2; k <= b; ++k) { tb = 2.0 * xi1 * tb1 - tb0; tb0 = tb1; tb1 = tb; }
+    const double* rowp = Ch + (size_t)b * D0;
+    double row = 0.0, ta0 = 1.0, ta1 = xi0;
+    for (int a = 0; a < A; ++a) {
+      double ta = a == 0 ? 1.0 : xi0;
+      if (a >= 2) { ta = 2.0 * xi0 * ta1 - ta0; ta0 = ta1; ta1 = ta; }
+      row = fma(rowp[a], ta, row);
+    }
+    quad = fma(row, tb, quad);
+  }
+  quad = wave_sum(quad);
+  const int r0 = dm.r0[o];
+  const double* S0 = S0all + (size_t)o * dm.r0u * dm.cnt0;
+  const double* Vb = Vball + (size_t)o * 3 * dm.r0u * dm.nlines;
+  double ms = 0.0;
+  for (int pp = lane; pp < r0; pp += 64) ms = fma(Vb[(size_t)pp * dm.nlines + x1], S0[(size_t)pp * dm.cnt0 + x0], ms);
+  ms = wave_sum(ms);
+  if (lane == 0) {
+    double var = mc.sf2[o] - quad;
+    var = var > 0.0 ? var : 0.0;
+    const double ys = mc.Y_std[o];
+    pm[(size_t)o * kGbProbes + p] = (mc.mp[o] + ms) * ys + mc.Y_mean[o];
+    pv[(size_t)o * kGbProbes + p] = var * (ys * ys);
+  }
+}
+
 // ---- plan ------------------------------------------------------------------------------------------------
 static double axis_position(const sbo_ctx* c, int a, long long i) {
   const CandSpec& cs = c->cs;
@@ -1871,6 +1926,10 @@ int bilinear_setup(sbo_ctx* c) {
                      (double*)c->bl_VA.p);
   hipLaunchKernelGGL(k_bl_sbf, blocks(pl.sSBf, uq), dim3(256), 0, ys, dm, (const double*)dS0, (const double*)dxn0, pl.sSBf,
                      (double*)c->bl_SBf.p);
+  // guard band of this plan (guard.hip): the exact evaluator at the probe points runs here, beside the core's GEMM chain
+  const bool band = c->guard_band && !c->is_shadow;
+  double *gref_m = nullptr, *gref_v = nullptr;
+  if (band && (rc = guard_probe_reference(c, ys, &gref_m, &gref_v))) return rc;
   if (ys != xs) SBO_HIP(hipEventRecord(c->ev_join[3], ys));
   hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, xs, dm, dU, nZf, Zf);
   // G = Z^T invK Z.  With the library's own Cholesky factor (M = L^-1): C = M Z from the packed triangular images, written as
@@ -1920,6 +1979,17 @@ int bilinear_setup(sbo_ctx* c) {
     pl.eff = eff;
   }
   if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
+  if (band) {
+    // ... K1b's own values at the probes from the tables just made, and the band from the deviations: in place before the
+    // plan's first posterior launch, whose fused classification reads it
+    double* pm = gref_m + 2 * (size_t)q * kGbProbes;
+    double* pv = pm + (size_t)q * kGbProbes;
+    const double* Chat = (const double*)c->bl_cheb.p + (size_t)q * (nPC0 + nPC1 + nT4p + nYt);
+    hipLaunchKernelGGL(k_gb_probe_k1b, dim3((unsigned)((kGbProbes + 3) / 4), uq), dim3(256), 0, xs, mc, cs, dm, Chat, (const int*)pl.eff,
+                       (const double*)dxn0, (const double*)dxn1, (const double*)dS0, (const double*)dVb, pm, pv);
+    if ((rc = guard_band_from_probes(c, pm, pv, gref_m, gref_v, reinterpret_cast<const double*>(pl.eff + 4 * q)))) return rc;
+    pl.band_ready = true;
+  }
   SBO_HIP(hipGetLastError());
   lap("enqueue");
   pl.usable = true;       // (nothing to wait for: the tables are made in stream order ahead of the posterior kernels)
@@ -1954,17 +2024,16 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   // (r03: with the sqrt-free sign tests the fused epilogue saves the separate pass 76 us on config H and costs the GEMM 36;
   // on config B, two workgroups per CU, the two cancel -- "auto" asks for at least four workgroups per CU)
   const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
-  const bool band_first = c->guard_band && !c->is_shadow && !c->bl.band_ready;
-  const bool fuse = fuse_wanted && !band_first && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
+  const bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
                     c->maskU.bytes >= (size_t)cs.n_local;
   c->fuse_rows = 0;
   if (fuse) {
     c->fuse_rows = (int)rows_out;
     // (room behind the rows for the partials of the objective pass, see sweep_common_front)
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
+    c->cpart_cap = (int)(c->cpart.bytes / (sizeof(unsigned long long) * kFuseRow));
   }
-  // The fused classification counts its sign tests inside the guard band -- which exists only once the plan's first launch has
-  // been probed: that first launch does not fuse (the separate pass follows the band kernels and reads the band they wrote).
+  // (the fused classification counts its sign tests inside the plan's guard band)
   const GuardBand* gb_fused = (c->guard_band && !c->is_shadow && c->bl.band_ready && c->gb.p) ? (const GuardBand*)c->gb.p : nullptr;
   auto kpost = k_bpost<rbw>;
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1975,7 +2044,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                         pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
                         (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
                         fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                        (unsigned long long*)c->cpart.p, gb_fused, (const int*)pl.eff);
+                        (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused, (const int*)pl.eff);
   if (c->lmax_defer) {
     c->lmax_pending = true;
     c->lmax_per_out = (int)rows_out;
@@ -1985,15 +2054,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   }
   c->k1_stop_attached = true;
   (void)line0;
-  // guard band of this plan (guard.hip): measured once per (model, grid) behind its first posterior launch, on the device
-  if (c->guard_band && !c->is_shadow) {
-    if (!c->bl.band_ready) {
-      if ((rc = guard_band_bilinear(c))) return rc;
-      c->bl.band_ready = true;
-      c->k1_stop_attached = false;      // (the band kernels follow the stop event's launch: the sweep records its own)
-    }
-    c->gb_active = true;
-  }
+  c->gb_active = c->guard_band && !c->is_shadow && c->bl.band_ready;     // (the band came with the plan: bilinear_setup)
   // flops issued on the matrix cores: stage 1 + the four phases of stage 2 (KS0 + 3 KSm k-steps: the axis-0 gradient phase
   // runs on the mean phase's sums; 16 x 16 x 4 steps, 2 flops per multiply-add)
   const double tiles2 = (double)pl.nrb * pl.ncs0, tiles1 = (double)pl.nrb * pl.KB0;

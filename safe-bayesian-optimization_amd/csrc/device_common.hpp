@@ -122,18 +122,47 @@ __device__ __forceinline__ LcbSign lcb_sign(double m, double v, double b, double
 struct GuardBand {
   double dm[kMaxQ], dv[kMaxQ], rl[kMaxQ];
 };
+// K1b's probe points: a kGbProbe1 x kGbProbe1 tensor of the grid positions nearest to the Chebyshev extrema of each axis (ends
+// included -- a polynomial surrogate errs most there); local index of probe p on the resident grid
+constexpr int kGbProbe1 = 12;
+constexpr int kGbProbes = kGbProbe1 * kGbProbe1;
+__device__ __forceinline__ void gb_probe_xy(const CandSpec& cs, long long nlines, int p, long long& x0, long long& x1) {
+  const int i0 = p % kGbProbe1, i1 = p / kGbProbe1;
+  x0 = (long long)llrint(0.5 * (1.0 - cospi((double)i0 / (double)(kGbProbe1 - 1))) * (double)(cs.count[0] - 1));
+  x1 = (long long)llrint(0.5 * (1.0 - cospi((double)i1 / (double)(kGbProbe1 - 1))) * (double)(nlines - 1));
+}
+__device__ __forceinline__ long long gb_probe_index(const CandSpec& cs, long long nlines, int p) {
+  long long x0, x1;
+  gb_probe_xy(cs, nlines, p, x0, x1);
+  return x1 * cs.count[0] + x0;
+}
 // |sqrt(v') - sqrt(v)| for |v' - v| <= dv (both clipped at zero): dv / sqrt(v) while v >= dv, sqrt(dv) below
 __device__ __forceinline__ double gb_dsqrt(double v, double dv) {
   return v >= dv ? dv / __dsqrt_rn(v) : __dsqrt_rn(dv);
 }
-// could a deviation of (dm, dv) move the sign of lcb = m - b sqrt(v) (either test of LcbSign)?  Sqrt-free and conservative:
-// with P = m^2, Q = b^2 v the sign of m - b sqrt(v) for m >= 0 is that of P - Q, and P - Q moves by at most
-// 2 |m| dm + dm^2 + b^2 dv; for m < -dm the sign is settled (b sqrt(v) >= 0), and a flagged candidate there is a false alarm.
-__device__ __forceinline__ bool lcb_near_zero(double m, double v, double bb, double dm, double dv) {
-  const double P = m * m, Q = bb * v, am = m < 0 ? -m : m;
-  const double band = fma(2.0 * am, dm, fma(dm, dm, bb * dv));
-  const double gap = P > Q ? P - Q : Q - P;
-  return !(gap > band * (1.0 + 0x1p-40) + 0x1p-49 * (P + Q));     // (NaN operands count as near)
+// Could a deviation of (dm, dv) move the sign of lcb = m - b sqrt(v) (either test of LcbSign)?  Sqrt-free and conservative: with
+// P = m^2, Q = b^2 v the sign of m - b sqrt(v) for m >= 0 is that of P - Q, and P - Q moves by at most 2 |m| dm + dm^2 + b^2 dv;
+// for m < -dm the sign is settled (b sqrt(v) >= 0), and a flagged candidate there is a false alarm.  The band's floor (64 eps of
+// the values' scale, guard.hip) is ~50 x the rounding of P and Q themselves; the constants carry another 10 %.
+struct LcbBand {
+  double c1, c0;      // |P - Q| <= |m| c1 + c0  <=>  "near"
+};
+__device__ __forceinline__ LcbBand lcb_band(double bb, double dm, double dv) { return LcbBand{2.2 * dm, 1.1 * fma(dm, dm, bb * dv)}; }
+// lcb_sign with the band test sharing its products (the fused epilogue of the GEMM posterior pays for every f64 instruction)
+__device__ __forceinline__ LcbSign lcb_sign_gb(double m, double v, double b, double bb, const LcbBand& lb, int& near) {
+  const double P = m * m, Q = bb * v;
+  const double gap = P > Q ? P - Q : Q - P, am = m < 0 ? -m : m;
+  near += !(gap > fma(am, lb.c1, lb.c0));                              // (NaN operands count as near)
+  if (b >= 0.0 && v >= 0.0) {
+    if (m < 0.0) return LcbSign{false, true};                         // sd >= 0 > m
+    constexpr double c = 1.0 + 0x1p-48, tiny = 1e-250, huge = 1e300;
+    if (P < huge && Q < huge) {
+      if (P > tiny && P >= Q * c) return LcbSign{true, false};        // m > sd for sure
+      if (Q > tiny && P * c <= Q) return LcbSign{false, true};        // m < sd for sure
+    }
+  }
+  const double sd = mul_rn(b, sqrt_rn(v));
+  return LcbSign{m >= sd, m <= sd};
 }
 
 // bounds of ucb = fl(m + fl(b fl(sqrt v))) from a single-precision square root: the reductions over ucb (largest ucb_c over

@@ -11,7 +11,7 @@
 //
 // "Exact" is the evaluator the band was measured against, so that a re-evaluated value and its neighbours' approximate values
 // are consistent to within the band:
-//   K1b on a caller's invK (chol_async): the reference formula itself, k^T invK k with the matrix as given
+//   K1b on a caller's invK (chol_async): the reference formula itself, (k^T invK) k with the matrix as given
 //        (models/GP_Safe.py:341-343) -- k_ref_list, no factor of invK is needed (it may not exist yet);
 //   otherwise (library Cholesky, K1t): the generic fp64 kernel K1 with the model's factor (launch_posterior_on_list).
 #include <algorithm>
@@ -22,39 +22,28 @@
 
 namespace sbo {
 
-constexpr int kRefPer = 4;          // candidates per workgroup of k_ref_list (the matrix is read once for all of them)
-constexpr int kGbProbe1 = 16;       // K1b: probe positions per axis (a 16 x 16 tensor of near-Chebyshev grid positions)
-constexpr int kGbProbes = kGbProbe1 * kGbProbe1;
+constexpr int kRefPer = 16;         // candidates per workgroup of k_ref_list (a matrix element is read once for all of them: the
+                                    // kernel is bound by the L2 traffic of re-reading the matrix per group of candidates)
 constexpr double kGbSafety = 16.0;  // band = safety x the largest probe deviation (+ truncation tail + rounding floor)
 constexpr double kInfBand = 1.0e300; // a probe that is not finite: everything is "inside the band"
 
-// local index of K1b probe p on the resident grid: positions nearest to the Chebyshev extrema of each axis (ends included --
-// a polynomial surrogate errs most there)
-__device__ __forceinline__ long long gb_probe_index(const CandSpec& cs, long long nlines, int p) {
-  const int i0 = p % kGbProbe1, i1 = p / kGbProbe1;
-  const long long c0 = cs.count[0];
-  const long long x0 = (long long)llrint(0.5 * (1.0 - cospi((double)i0 / (double)(kGbProbe1 - 1))) * (double)(c0 - 1));
-  const long long x1 = (long long)llrint(0.5 * (1.0 - cospi((double)i1 / (double)(kGbProbe1 - 1))) * (double)(nlines - 1));
-  return x1 * c0 + x0;
-}
-
-// The reference formula on a list: mean_i = mp_i + k . alpha_i, var_i = max(0, sf2 - quad) with quad = k^T invK k (MODE 0: the
-// caller's matrix as given, row-major [n][ld]) or ||M k||^2 (MODE 1: the lower-triangular factor, M^T M = invK), k from the
-// expanded distance (models/GP_Safe.py:112-119, 166, 326-347).  One workgroup per (kRefPer candidates, output): the k vectors in
-// LDS, a wave per matrix row with its lanes along the row (coalesced), kRefPer dot products per row read.
-// pts == nullptr: the candidates are K1b's probe points of the resident grid (gb_probe_index).
-template <int D, int MODE>
+// The reference formula on a list: mean_i = mp_i + k . alpha_i, var_i = max(0, sf2 - (k^T invK) k) with the caller's matrix as
+// given (row-major [n][n]), k from the expanded distance (models/GP_Safe.py:112-119, 166, 326-347).  A workgroup takes kRefPer
+// candidates, one output and a chunk of `ccols` matrix columns (a multiple of 64): the k vectors go to LDS; lane l of wave w
+// accumulates (k^T invK)_j for column j = chunk base + 64 t + l over the rows of its quarter of the matrix -- the loads of a row
+// are coalesced across the lanes and none depends on another (a wave per row with a reduction per row kept ONE row in flight: 440 us
+// for 256 probes at n = 512) --, the four quarters meet in LDS, and the chunk's share of (k^T invK) k and of k . alpha is written
+// as a partial; k_ref_finish sums the chunks.  pts == nullptr: the candidates are K1b's probe points (gb_probe_index).
+template <int D>
 __global__ __launch_bounds__(256) void k_ref_list(const ModelConst mc, const CandSpec cs, const double* __restrict__ pts, long long N,
                                                   long long nlines, const double* __restrict__ As, const double* __restrict__ sqA,
                                                   const double* __restrict__ alpha, int ald, const double* __restrict__ Mx, size_t mstride,
-                                                  int ld, double* __restrict__ mean_out, double* __restrict__ var_out) {
-  extern __shared__ double kv[];                 // [kRefPer][npad]
-  __shared__ double red[4][kRefPer];
-  __shared__ double msum[4][kRefPer];
-  const int o = blockIdx.y, n = mc.n, npad = mc.npad;
+                                                  int ccols, double* __restrict__ part /* [chunks][2][q][N] */) {
+  extern __shared__ double kv[];                 // [kRefPer][npad] | [4][64][kRefPer] quarter sums
+  const int o = blockIdx.y, chunk = blockIdx.z, n = mc.n, npad = mc.npad, q = mc.q;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* wq = kv + (size_t)kRefPer * npad;
   const long long c0 = (long long)blockIdx.x * kRefPer;
-  // k vectors
   for (int e = tid; e < kRefPer * npad; e += blockDim.x) {
     const int cc = e / npad, j = e % npad;
     const long long ci = c0 + cc;
@@ -80,52 +69,76 @@ __global__ __launch_bounds__(256) void k_ref_list(const ModelConst mc, const Can
   }
   __syncthreads();
   const double* Mo = Mx + (size_t)o * mstride;
+  const int rq = (n + 3) / 4, i0 = wave * rq, i1 = (i0 + rq < n) ? i0 + rq : n;     // this wave's rows
   double quad[kRefPer], ms[kRefPer];
 #pragma unroll
   for (int cc = 0; cc < kRefPer; ++cc) { quad[cc] = 0.0; ms[cc] = 0.0; }
-  for (int i = wave; i < n; i += 4) {
-    const double* row = Mo + (size_t)i * ld;
-    const int jend = MODE == 1 ? i + 1 : n;
-    double s[kRefPer];
+  for (int jb = chunk * ccols; jb < (chunk + 1) * ccols && jb < n; jb += 64) {
+    const int j = jb + lane;
+    double w[kRefPer];
 #pragma unroll
-    for (int cc = 0; cc < kRefPer; ++cc) s[cc] = 0.0;
-    for (int j = lane; j < jend; j += 64) {
-      const double mij = row[j];
+    for (int cc = 0; cc < kRefPer; ++cc) w[cc] = 0.0;
+    if (j < n) {
+      const double* col = Mo + j;
+#pragma unroll 32
+      for (int i = i0; i < i1; ++i) {                      // (a quarter of the rows: 32 loads in flight per lane)
+        const double mij = col[(size_t)i * n];
 #pragma unroll
-      for (int cc = 0; cc < kRefPer; ++cc) s[cc] = fma(mij, kv[cc * npad + j], s[cc]);
+        for (int cc = 0; cc < kRefPer; ++cc) w[cc] = fma(kv[cc * npad + i], mij, w[cc]);
+      }
     }
+    __syncthreads();                               // (the previous block of columns has been summed)
 #pragma unroll
-    for (int cc = 0; cc < kRefPer; ++cc) {
-      const double w = wave_sum(s[cc]);
-      quad[cc] += MODE == 1 ? w * w : kv[cc * npad + i] * w;
-    }
-  }
-  // mean: k . alpha (wave 0's lanes along j), then the waves' quad shares
-  if (wave == 0) {
-    double s[kRefPer];
-#pragma unroll
-    for (int cc = 0; cc < kRefPer; ++cc) s[cc] = 0.0;
-    for (int j = lane; j < n; j += 64) {
+    for (int cc = 0; cc < kRefPer; ++cc) wq[(wave * 64 + lane) * kRefPer + cc] = w[cc];
+    __syncthreads();
+    if (wave == 0 && j < n) {
       const double aj = alpha[(size_t)o * ald + j];
 #pragma unroll
-      for (int cc = 0; cc < kRefPer; ++cc) s[cc] = fma(aj, kv[cc * npad + j], s[cc]);
+      for (int cc = 0; cc < kRefPer; ++cc) {
+        const double wj = (wq[lane * kRefPer + cc] + wq[(64 + lane) * kRefPer + cc]) + (wq[(128 + lane) * kRefPer + cc] + wq[(192 + lane) * kRefPer + cc]);
+        quad[cc] = fma(wj, kv[cc * npad + j], quad[cc]);
+        ms[cc] = fma(aj, kv[cc * npad + j], ms[cc]);
+      }
     }
-#pragma unroll
-    for (int cc = 0; cc < kRefPer; ++cc) ms[cc] = wave_sum(s[cc]);
   }
-  if (lane == 0) {
+  if (wave == 0) {
 #pragma unroll
-    for (int cc = 0; cc < kRefPer; ++cc) { red[wave][cc] = quad[cc]; msum[wave][cc] = ms[cc]; }
+    for (int cc = 0; cc < kRefPer; ++cc) {
+      const double qs = wave_sum(quad[cc]), m_ = wave_sum(ms[cc]);
+      if (lane == 0 && c0 + cc < N) {
+        part[(((size_t)chunk * 2 + 0) * q + o) * N + c0 + cc] = qs;
+        part[(((size_t)chunk * 2 + 1) * q + o) * N + c0 + cc] = m_;
+      }
+    }
   }
-  __syncthreads();
-  if (tid < kRefPer && c0 + tid < N) {
-    const double q_ = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+__global__ __launch_bounds__(256) void k_ref_finish(const ModelConst mc, long long N, int chunks, const double* __restrict__ part,
+                                                    double* __restrict__ mean_out, double* __restrict__ var_out) {
+  const int q = mc.q;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < N * q; e += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(e / N);
+    const long long i = e % N;
+    double q_ = 0.0, m_ = 0.0;
+    for (int ch = 0; ch < chunks; ++ch) {
+      q_ += part[(((size_t)ch * 2 + 0) * q + o) * N + i];
+      m_ += part[(((size_t)ch * 2 + 1) * q + o) * N + i];
+    }
     double var = mc.sf2[o] - q_;                                        // models/GP_Safe.py:343
     var = var > 0.0 ? var : 0.0;
-    const double mean = mc.mp[o] + msum[0][tid];                        // :342
-    mean_out[(size_t)o * N + c0 + tid] = mean * mc.Y_std[o] + mc.Y_mean[o];      // :346
-    var_out[(size_t)o * N + c0 + tid] = var * (mc.Y_std[o] * mc.Y_std[o]);       // :347
+    const double mean = mc.mp[o] + m_;                                  // :342
+    mean_out[(size_t)o * N + i] = mean * mc.Y_std[o] + mc.Y_mean[o];    // :346
+    var_out[(size_t)o * N + i] = var * (mc.Y_std[o] * mc.Y_std[o]);     // :347
   }
+}
+
+// coordinates of K1b's probe points (for the generic kernel, which takes explicit lists)
+__global__ void k_gb_probe_pts(const CandSpec cs, long long nlines, double* __restrict__ pts) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= kGbProbes) return;
+  double x[2];
+  cand_coords<2>(cs, gb_probe_index(cs, nlines, p), x);
+  pts[2 * p] = x[0];
+  pts[2 * p + 1] = x[1];
 }
 
 // signed components of the gradient of the un-normalised mean at listed points (the analytic form of jax.grad(self.mean),
@@ -165,23 +178,21 @@ __global__ __launch_bounds__(256) void k_grad_list(const ModelConst mc, const do
   }
 }
 
-// K1b's band from its probes: one workgroup.  ref_m / ref_v [q][P]: the exact evaluator at the probe points; mean / var: the
-// posterior K1b has just written; tail[o]: sum of the Chebyshev coefficients of the variance's quadratic form that the kernels
-// do not run (normalised variance units; k_cheb_trunc).  rl: K1b's Lipschitz keys come from the same reduced-basis mean whose
-// values are probed here -- the gradient sums are exact GEMMs on it --; 1e-9 relative is three decades above what the parity
-// tests measure against K1g (1e-12).
-__global__ __launch_bounds__(256) void k_gb_band(const ModelConst mc, const CandSpec cs, long long nlines, const double* __restrict__ mean,
-                                                 const double* __restrict__ var, const double* __restrict__ ref_m,
-                                                 const double* __restrict__ ref_v, const double* __restrict__ tail, GuardBand* gb) {
+// K1b's band from its probes: one workgroup.  ref_m / ref_v [q][P]: the exact evaluator at the probe points; pm / pv: K1b's own
+// representation evaluated there (bilinear.hip: k_gb_probe_k1b -- the sums the two GEMMs form, in another order); tail[o]: sum of
+// the Chebyshev coefficients of the variance's quadratic form that the kernels do not run (normalised variance units;
+// k_cheb_trunc).  rl: K1b's Lipschitz keys come from the same reduced-basis mean whose values are probed here -- the gradient sums
+// are exact GEMMs on it --; 1e-9 relative is three decades above what the parity tests measure against K1g (1e-12).
+__global__ __launch_bounds__(256) void k_gb_band(const ModelConst mc, const double* __restrict__ pm, const double* __restrict__ pv,
+                                                 const double* __restrict__ ref_m, const double* __restrict__ ref_v,
+                                                 const double* __restrict__ tail, GuardBand* gb) {
   __shared__ double sh[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long long n = cs.n_local;
   for (int o = 0; o < mc.q; ++o) {
     double em = 0.0, ev = 0.0, am = 0.0, av = 0.0;
     bool bad = false;
     for (int p = tid; p < kGbProbes; p += blockDim.x) {
-      const long long g = gb_probe_index(cs, nlines, p);
-      const double m = mean[(size_t)o * n + g], v = var[(size_t)o * n + g];
+      const double m = pm[(size_t)o * kGbProbes + p], v = pv[(size_t)o * kGbProbes + p];
       const double rm = ref_m[(size_t)o * kGbProbes + p], rv = ref_v[(size_t)o * kGbProbes + p];
       const double dm = fabs(m - rm), dv = fabs(v - rv);
       bad = bad || !(dm < kInfBand) || !(dv < kInfBand);
@@ -218,21 +229,26 @@ static bool ref_direct(const sbo_ctx* c) {
 }
 
 template <int D>
-static int launch_ref(sbo_ctx* c, const double* pts, long long N, long long nlines, double* mean_out, double* var_out, bool direct) {
+static int launch_ref(sbo_ctx* c, hipStream_t st, const double* pts, long long N, long long nlines, double* mean_out, double* var_out) {
   const ModelConst& mc = c->mc;
-  const size_t lds = sizeof(double) * kRefPer * (size_t)mc.npad;
-  const dim3 grid((unsigned)((N + kRefPer - 1) / kRefPer), (unsigned)mc.q);
-  if (direct) {
-    auto kern = k_ref_list<D, 0>;
-    SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, mc, c->cs, pts, N, nlines, (const double*)c->As.p, (const double*)c->sqA.p,
-                       (const double*)c->alpha64.p, c->a_ld, c->invk_plain, (size_t)mc.n * mc.n, mc.n, mean_out, var_out);
-  } else {
-    auto kern = k_ref_list<D, 1>;
-    SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, mc, c->cs, pts, N, nlines, (const double*)c->As.p, (const double*)c->sqA.p,
-                       (const double*)c->alpha64.p, c->a_ld, (const double*)c->Fplain.p, (size_t)c->f_cap * c->f_cap, c->f_cap, mean_out, var_out);
-  }
+  const int q = mc.q;
+  const long long groups = (N + kRefPer - 1) / kRefPer;
+  // column chunks: as many as it takes to put ~2 workgroups on every CU (a short list is latency-bound: 128 dependent-free loads
+  // per lane and chunk of 64 columns at n = 512), one chunk for long lists
+  const int nblk = (mc.n + 63) / 64;
+  int chunks = (int)std::max<long long>(1, std::min<long long>(nblk, (2ll * c->n_cu) / std::max<long long>(1, groups * q)));
+  const int ccols = ((nblk + chunks - 1) / chunks) * 64;
+  chunks = (mc.n + ccols - 1) / ccols;
+  int rc;
+  if ((rc = ensure(c->gb_part, sizeof(double) * 2 * (size_t)chunks * q * (size_t)N))) return rc;
+  const size_t lds = sizeof(double) * ((size_t)kRefPer * mc.npad + 256 * kRefPer);
+  auto kern = k_ref_list<D>;
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)q, (unsigned)chunks), dim3(256), lds, st, mc, c->cs, pts, N, nlines,
+                     (const double*)c->As.p, (const double*)c->sqA.p, (const double*)c->alpha64.p, c->a_ld, c->invk_plain,
+                     (size_t)mc.n * mc.n, ccols, (double*)c->gb_part.p);
+  hipLaunchKernelGGL(k_ref_finish, dim3((unsigned)std::max<long long>(1, std::min<long long>((N * q + 255) / 256, 1024))), dim3(256), 0, st,
+                     mc, N, chunks, (const double*)c->gb_part.p, mean_out, var_out);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
@@ -241,9 +257,9 @@ int guard_exact_list(sbo_ctx* c, const double* pts, long long N, double* mean_ou
   if (N <= 0) return SBO_OK;
   if (c->last_k1 == 4 && ref_direct(c)) {
     switch (c->mc.dpad) {
-      case 2: return launch_ref<2>(c, pts, N, 0, mean_out, var_out, true);
-      case 4: return launch_ref<4>(c, pts, N, 0, mean_out, var_out, true);
-      default: return launch_ref<8>(c, pts, N, 0, mean_out, var_out, true);
+      case 2: return launch_ref<2>(c, c->stream, pts, N, 0, mean_out, var_out);
+      case 4: return launch_ref<4>(c, c->stream, pts, N, 0, mean_out, var_out);
+      default: return launch_ref<8>(c, c->stream, pts, N, 0, mean_out, var_out);
     }
   }
   return launch_posterior_on_list(c, pts, N, mean_out, var_out);
@@ -266,36 +282,40 @@ int guard_exact_grad_list(sbo_ctx* c, const double* pts, long long N, double* gr
 int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl) {
   int rc;
   if ((rc = ensure(c->gb, sizeof(GuardBand)))) return rc;
+  c->gb_host_valid = false;
   GuardBand hb;
   memset(&hb, 0, sizeof(hb));
   for (int o = 0; o < c->mc.q && dm; ++o) { hb.dm[o] = dm[o]; hb.dv[o] = dv[o]; hb.rl[o] = rl[o]; }
   // (pageable source: the runtime stages it before the call returns)
   SBO_HIP(hipMemcpyAsync(c->gb.p, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
+  for (int o = 0; o < SBO_MAX_Q; ++o) { c->gb_host[o] = hb.dm[o]; c->gb_host[SBO_MAX_Q + o] = hb.dv[o]; c->gb_host[2 * SBO_MAX_Q + o] = hb.rl[o]; }
+  c->gb_host_valid = true;
   return SBO_OK;
 }
 
-// K1b: behind the posterior launch of a plan that has no band yet -- the exact evaluator at the probe points, then the band
-// from the deviations (both on the device, in stream order; nothing waits for the host)
-int guard_band_bilinear(sbo_ctx* c) {
-  const ModelConst& mc = c->mc;
-  const CandSpec& cs = c->cs;
-  const int q = mc.q;
-  const long long nlines = cs.n_local / cs.count[0];
+// K1b's band, built with the plan (bilinear_setup): the exact evaluator at the probe points -- on `side`, the stream the plan's
+// axis tables are made on, beside the GEMM chain of the Chebyshev core -- and, once K1b's own values at the probes are there
+// (pm / pv, bilinear.hip), the band from the deviations.  Everything on the device, in stream order: nothing waits for the host,
+// and the band is in place before the plan's first posterior launch (whose fused classification reads it).
+int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double** ref_v) {
+  const int q = c->mc.q;
+  const long long nlines = c->cs.n_local / c->cs.count[0];
   int rc;
   if ((rc = ensure(c->gb, sizeof(GuardBand)))) return rc;
-  if ((rc = ensure(c->gb_probe, sizeof(double) * 2 * (size_t)q * kGbProbes))) return rc;
-  double* ref_m = (double*)c->gb_probe.p;
-  double* ref_v = ref_m + (size_t)q * kGbProbes;
-  const bool direct = ref_direct(c);
-  if (!direct && (rc = factor_sync(c))) return rc;          // (library Cholesky: the factor is there; a caller's invK without chol_async: it is waited for)
-  if ((rc = launch_ref<2>(c, nullptr, kGbProbes, nlines, ref_m, ref_v, direct))) return rc;
-  const double* tail = c->bl.eff ? reinterpret_cast<const double*>(c->bl.eff + 4 * q) : nullptr;
-  hipLaunchKernelGGL(k_gb_band, dim3(1), dim3(256), 0, c->stream, mc, cs, nlines, (const double*)c->mean.p, (const double*)c->var.p,
-                     (const double*)ref_m, (const double*)ref_v, tail, (GuardBand*)c->gb.p);
+  c->gb_host_valid = false;
+  if ((rc = ensure(c->gb_probe, sizeof(double) * (4 * (size_t)q + 2) * kGbProbes))) return rc;
+  *ref_m = (double*)c->gb_probe.p;
+  *ref_v = *ref_m + (size_t)q * kGbProbes;
+  if (ref_direct(c)) return launch_ref<2>(c, side, nullptr, kGbProbes, nlines, *ref_m, *ref_v);
+  // (library Cholesky, or a caller's invK without chol_async: the factor is there, the generic kernel takes the probe list --
+  // on the main stream: it is the context's launcher)
+  double* ppts = *ref_m + 4 * (size_t)q * kGbProbes;
+  hipLaunchKernelGGL(k_gb_probe_pts, dim3(1), dim3(kGbProbes), 0, c->stream, c->cs, nlines, ppts);
+  return launch_posterior_on_list(c, ppts, kGbProbes, *ref_m, *ref_v);
+}
+int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail) {
+  hipLaunchKernelGGL(k_gb_band, dim3(1), dim3(256), 0, c->stream, c->mc, pm, pv, ref_m, ref_v, tail, (GuardBand*)c->gb.p);
   SBO_HIP(hipGetLastError());
-  c->gb_plan_model = c->model_serial;
-  c->gb_plan_first = cs.first;
-  c->gb_plan_n = cs.n_local;
   return SBO_OK;
 }
 

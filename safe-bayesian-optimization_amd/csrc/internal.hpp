@@ -125,7 +125,10 @@ struct sbo_ctx {
   bool gb_slow = false;            // the re-evaluation path of the SafeOpt sweep is running (Lipschitz keys exact, lists in use)
   sbo::DevBuf gb;                  // GuardBand of the resident posterior
   long long guard_first = 0;       // decisions the first pass of the running sweep left open
+  bool gb_host_valid = false;      // gb_host mirrors `gb` (read back on demand by sbo_profile_get; dropped when a plan writes the block)
+  double gb_host[3 * SBO_MAX_Q] = {0};
   sbo::DevBuf gb_pts, gb_vals;     // re-evaluation: coordinates and exact values of the listed candidates
+  sbo::DevBuf gb_part;             // k_ref_list: per-column-chunk partial sums
   sbo::DevBuf gb_probe;            // K1b: probe indices / coordinates / reference values of the running plan
   sbo::DevBuf list_scr;            // key scratch of launch_posterior_on_list
   unsigned long long gb_plan_model = 0;   // K1b: the model whose band `gb` holds (0: none)
@@ -170,7 +173,8 @@ struct sbo_ctx {
   sbo::DevBuf blockmin; // per-block minima along the last axis (blocked last-axis scans)
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
   sbo::DevBuf bl_lpart; // K1b: per-wave Lipschitz partials of k_bpost
-  sbo::DevBuf cpart;   // per-workgroup partials of k_classify
+  sbo::DevBuf cpart;   // per-workgroup partials of k_classify, field-major [kClassifyRow][cpart_cap]
+  int cpart_cap = 0;   // row capacity the last writer of cpart laid its rows out with
   long long comm_bytes = 0;   // collectives of the running sweep: bytes handed over (send side), calls, and -- option comm_events --
   int comm_calls = 0;         // an event pair per call (comm_ev, created on first use) whose elapsed times sbo_profile.comm_ms sums
   int comm_events = 0;
@@ -280,7 +284,8 @@ int launch_posterior_on_list(sbo_ctx* c, const double* pts, long long N, double*
 // enqueued behind the first posterior launch of a plan); a host-known band (K1t) or "none" (exact kernels)
 int guard_exact_list(sbo_ctx* c, const double* pts, long long N, double* mean_out, double* var_out);
 int guard_exact_grad_list(sbo_ctx* c, const double* pts, long long N, double* grad_out /* [q][d][N] */);
-int guard_band_bilinear(sbo_ctx* c);
+int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double** ref_v);       // -> gb_probe: [q][P] each; K1b's own values follow at + 2 q P
+int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail);
 int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl);
 }  // namespace sbo
 

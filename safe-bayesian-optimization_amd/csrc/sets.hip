@@ -31,7 +31,8 @@ int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_
 constexpr double kInfD = 1.0e300;
 constexpr int kArgSlots = 16;
 
-// small device-resident scalar block of one sweep
+// small device-resident scalar block of one sweep.  The fields up to kScalHost are what the host reads back (from pinned,
+// uncached memory: every cache line of it costs the sweep's tail), the rest stays on the device.
 struct SweepScalars {
   unsigned long long ustar_key;            // min over S of ord_key(ucb_0)
   unsigned long long rmax_key[kMaxQ];      // max over S of ord_key(ucb_c)
@@ -42,19 +43,24 @@ struct SweepScalars {
   long long halo_short;                    // ranks > 1: a speculative transform window was narrower than this sweep's keys need
   double arg_val[kArgSlots];
   long long arg_idx[kArgSlots];
-  unsigned long long ticket;               // workgroups of k_goose_finals that have finished their slot (zeroed with the block)
   // Guard band of an approximating posterior (device_common.hpp: GuardBand); all zero when the posterior kernel is exact.
   // n_guard: decisions of this sweep inside the band, from the classification (set by its merge) and the verdict kernels
-  // (atomics: rare); guard_slot[s]: the same from slot s of the final reductions (M-band members, an undecided arg-reduction).
-  long long n_guard, n_guard_cls;          // (n_guard_cls: the classification's share, the value n_guard starts from)
+  // (atomics: rare); guard_slot[s]: the same from slot s of the final reductions (M-band members, an undecided arg-reduction);
+  // arg_d: the band of a slot's winner
+  double arg_d[kArgSlots];
+  long long n_guard;
   long long guard_slot[kArgSlots];
+  // ---- device only ----
+  unsigned long long ticket;               // workgroups of k_goose_finals that have finished their slot (zeroed with the block)
+  long long n_guard_cls;                   // the classification's share of n_guard, the value it starts from
   long long guard_nb0;                     // slot 0's share that is not its arg-reduction (members of M inside the band): ranks > 1 sum it
   unsigned long long vmin_key[kMaxQ];      // min over S of ord_key(var_o): bounds the band of a bound's square root on S
   double gb_du[kMaxQ];                     // band of ucb_o / lcb_o on S: dm_o + b |d sqrt(var_o)| at the smallest variance over S
   double gb_rl[kMaxQ];                     // relative band of the Lipschitz keys
-  double arg_d[kArgSlots], arg_e1[kArgSlots], arg_e2[kArgSlots];   // arg-reductions: the winner's band and the two extreme far
-  long long arg_ei[kArgSlots];             //   ends over all candidates (ranks > 1: merged by the host, see sweep_exchange_back)
+  double arg_e1[kArgSlots], arg_e2[kArgSlots];   // arg-reductions: the two extreme far ends over all candidates and the first one's
+  long long arg_ei[kArgSlots];             //   candidate (ranks > 1: merged by the host from the C3 rows)
 };
+constexpr size_t kScalHost = offsetof(SweepScalars, ticket);
 
 // Result of a masked arg-reduction over values known to +- d.  (v, i): the winner, ties -> lowest flat index; d: its band;
 // e1 / e2: the two most extreme FAR ends over all candidates (v + d for an arg-max: how high could it be; v - d for an
@@ -135,6 +141,58 @@ __device__ __forceinline__ Best block_best(Best x) {
   return x;   // valid in wave 0
 }
 
+// The same reduction for values whose band d is ONE number (var_0 +- dv: the arg-max reductions of a SafeOpt sweep): a thread
+// only tracks the winner and the runner-up VALUE (in e2), half the fields to carry through the shuffles; block_best_uni puts
+// the general form back together (e1 = the winner's own far end, e2 = the runner-up's).
+template <bool MAX>
+__device__ __forceinline__ void best_take_uni(Best& B, double v, long long i) {
+  if (B.i < 0 || (MAX ? (v > B.v) : (v < B.v)) || (v == B.v && i < B.i)) {
+    if (B.i >= 0) B.e2 = MAX ? (B.v > B.e2 ? B.v : B.e2) : (B.v < B.e2 ? B.v : B.e2);
+    B.v = v;
+    B.i = i;
+  } else {
+    B.e2 = MAX ? (v > B.e2 ? v : B.e2) : (v < B.e2 ? v : B.e2);
+  }
+}
+template <bool MAX>
+__device__ __forceinline__ Best wave_best_uni(Best x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Best y;
+    y.v = __shfl_xor(x.v, o);
+    y.i = __shfl_xor(x.i, o);
+    y.e2 = __shfl_xor(x.e2, o);
+    const bool yb = better<MAX>(y, x);
+    const double lose = yb ? x.v : y.v;                      // the loser's value joins the runner-up contest (when it exists)
+    const bool lose_on = yb ? x.i >= 0 : y.i >= 0;
+    double e2 = MAX ? (y.e2 > x.e2 ? y.e2 : x.e2) : (y.e2 < x.e2 ? y.e2 : x.e2);
+    if (lose_on) e2 = MAX ? (lose > e2 ? lose : e2) : (lose < e2 ? lose : e2);
+    if (yb) { x.v = y.v; x.i = y.i; }
+    x.e2 = e2;
+  }
+  return x;
+}
+template <bool MAX>
+__device__ __forceinline__ Best block_best_uni(Best x, double d) {
+  __shared__ Best shu[16];
+  x = wave_best_uni<MAX>(x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) shu[wave] = x;
+  __syncthreads();
+  if (wave == 0) {
+    Best y = lane < nw ? shu[lane] : best_none<MAX>();
+    y = wave_best_uni<MAX>(y);
+    // back to the general form: far ends = value +- d
+    y.d = d;
+    y.e1 = y.i >= 0 ? (MAX ? y.v + d : y.v - d) : (MAX ? -kInfD : kInfD);
+    y.ei = y.i;
+    if (MAX ? y.e2 > -kInfD : y.e2 < kInfD) y.e2 = MAX ? y.e2 + d : y.e2 - d;
+    x = y;
+  }
+  return x;   // valid in wave 0
+}
+
 __device__ __forceinline__ long long block_sum_ll(long long v) {
   __shared__ long long sh[16];
 #pragma unroll
@@ -174,7 +232,9 @@ __device__ __forceinline__ void lcb_ucb(T m, T v, T b, T& lcb, T& ucb) {
 }
 
 // a workgroup's partial row of the classification: u* key, |S|, |U|, decisions inside the guard band, min-variance keys over S
-// per output (~0: none), radius keys per constraint
+// per output (~0: none), radius keys per constraint.  Stored field-major -- part[field * pcap + row], pcap = the row capacity
+// of the buffer --, so that the one workgroup that merges the rows reads every field with coalesced loads (row-major rows of
+// 160 bytes made that merge the longest job of the launch it shares: +14 us on config H).
 constexpr int kClassifyRow = 4 + 2 * kMaxQ;
 constexpr int kRowVmin = 4, kRowRmax = 4 + kMaxQ;
 
@@ -182,7 +242,7 @@ constexpr int kRowVmin = 4, kRowRmax = 4 + kMaxQ;
 template <typename T>
 __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, const T* __restrict__ var, long long n,
                                                   int q, T b, uint8_t* __restrict__ S, uint8_t* __restrict__ U,
-                                                  unsigned long long* __restrict__ part /* [gridDim.x][kClassifyRow] */,
+                                                  unsigned long long* __restrict__ part /* [kClassifyRow][pcap] */, int pcap,
                                                   const GuardBand* __restrict__ gb /* nullptr: the posterior is exact */) {
   __shared__ unsigned long long rmax_sh[kMaxQ];   // max over S of ucb_c: bounds the expander search radius
   if (threadIdx.x < kMaxQ) rmax_sh[threadIdx.x] = 0;
@@ -191,11 +251,12 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
   long long cS = 0, cU = 0, cB = 0;
   // guard band (fp64 approximating posteriors): sign tests that the band could move are counted, and the smallest variance over
   // S is kept per output (it bounds the band of sqrt(var) on S for the kernels that follow)
-  double gdm[kMaxQ], gdv[kMaxQ], vmin[kMaxQ];
+  LcbBand lband[kMaxQ];
+  double vmin[kMaxQ];
+  int cBi = 0;
 #pragma unroll
   for (int c = 0; c < kMaxQ; ++c) {
-    gdm[c] = (gb && c < q) ? gb->dm[c] : 0.0;
-    gdv[c] = (gb && c < q) ? gb->dv[c] : 0.0;
+    lband[c] = (gb && c < q) ? lcb_band((double)b * (double)b, gb->dm[c], gb->dv[c]) : LcbBand{0.0, 0.0};
     vmin[c] = kInfD;
   }
   // constraints first (S / U bits, ucb_c for the radius keys); the objective's mean / var are read for safe candidates
@@ -210,10 +271,10 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
     for (int c = 1; c < kMaxQ; ++c) {
       if (c < q) {
         if constexpr (kFast) {
-          const LcbSign sg = lcb_sign((double)mv[2 * c], (double)mv[2 * c + 1], (double)b, bb);
+          const LcbSign sg = gb ? lcb_sign_gb((double)mv[2 * c], (double)mv[2 * c + 1], (double)b, bb, lband[c], cBi)
+                                : lcb_sign((double)mv[2 * c], (double)mv[2 * c + 1], (double)b, bb);
           s_ = s_ && sg.ge;
           u = u && sg.le;
-          if (gb) cB += lcb_near_zero((double)mv[2 * c], (double)mv[2 * c + 1], bb, gdm[c], gdv[c]);
         } else {
           T lcb;
           lcb_ucb(mv[2 * c], mv[2 * c + 1], b, lcb, ucbc[c]);   // one sqrt per (candidate, constraint)
@@ -307,7 +368,7 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
 #pragma unroll
   for (int c = 0; c < kMaxQ; ++c) vk[c] = ~0ull;
   if (gb) {
-    cB = block_sum_ll(cB);
+    cB = block_sum_ll((long long)cBi);
 #pragma unroll
     for (int c = 0; c < kMaxQ; ++c)
       if (c < q) vk[c] = block_ext_u64<false>(vmin[c] < kInfD ? ord_key(vmin[c]) : ~0ull);
@@ -315,23 +376,23 @@ __global__ __launch_bounds__(256) void k_classify(const T* __restrict__ mean, co
   __syncthreads();
   // per-workgroup partials, merged by k_classify_final (atomics of every workgroup on one cache line serialise in L2:
   // ~10 ns each, which was most of this kernel's time)
-  unsigned long long* row = part + (size_t)blockIdx.x * kClassifyRow;
+  unsigned long long* row = part + blockIdx.x;
   if (threadIdx.x == 0) {
     row[0] = umin;
-    row[1] = (unsigned long long)cS;
-    row[2] = (unsigned long long)cU;
-    row[3] = (unsigned long long)cB;
+    row[(size_t)1 * pcap] = (unsigned long long)cS;
+    row[(size_t)2 * pcap] = (unsigned long long)cU;
+    row[(size_t)3 * pcap] = (unsigned long long)cB;
 #pragma unroll
-    for (int c = 0; c < kMaxQ; ++c) row[kRowVmin + c] = vk[c];
+    for (int c = 0; c < kMaxQ; ++c) row[(size_t)(kRowVmin + c) * pcap] = vk[c];
   }
-  if (threadIdx.x < kMaxQ) row[kRowRmax + threadIdx.x] = rmax_sh[threadIdx.x];
+  if (threadIdx.x < kMaxQ) row[(size_t)(kRowRmax + threadIdx.x) * pcap] = rmax_sh[threadIdx.x];
 }
 
 // start of a sweep's scalar block: cleared, then u*, |S|, |U| and the radius keys merged from k_classify's partials
 struct FinalJob {
   bool pending = false;
-  const unsigned long long* part = nullptr;   // k_classify's rows
-  int nparts = 0, q = 0;
+  const unsigned long long* part = nullptr;   // k_classify's rows (field-major)
+  int nparts = 0, pcap = 0, q = 0;
   SweepScalars* sc = nullptr;
   const double* Lpart = nullptr;              // K1b's Lipschitz partials still to be merged (nullptr: Lmax is final)
   int per_out = 0;
@@ -340,7 +401,7 @@ struct FinalJob {
   const GuardBand* gb = nullptr;              // band of an approximating posterior (nullptr: exact)
   double b = 0.0;                             // the sweep's confidence multiplier (enters the band of the bounds)
 };
-__device__ __forceinline__ void classify_final_body(const unsigned long long* __restrict__ part, int nparts, int q, SweepScalars* sc,
+__device__ __forceinline__ void classify_final_body(const unsigned long long* __restrict__ part, int nparts, int pcap, int q, SweepScalars* sc,
                                                     const double* __restrict__ Lpart, int per_out, unsigned long long* Lmax,
                                                     SweepScalars* sc_copy, const GuardBand* gb, double b) {
   __shared__ double lsh[4];
@@ -353,20 +414,20 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
   long long cS = 0, cU = 0, cB = 0;
 #pragma unroll
   for (int c = 0; c < kMaxQ; ++c) { rmax[c] = 0ull; vmin[c] = ~0ull; }
-  // (one workgroup walks all rows: four rows' loads in flight per thread and only the q columns that carry anything -- with a
-  // row at a time the 16 rounds of eleven strided loads were the longest job of the launch this merge shares on config H)
+  // (one workgroup walks all rows: four rows' loads in flight per thread and only the q columns that carry anything; the
+  // fields are stored field-major, so a load instruction of the workgroup reads 2 KB in a row)
   for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * blockDim.x) {
     unsigned long long v0[4], v1[4], v2[4], vr[4][kMaxQ];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = i0 + j * blockDim.x;
       const bool on = i < nparts;
-      const unsigned long long* row = part + (size_t)(on ? i : i0) * kClassifyRow;
+      const unsigned long long* row = part + (on ? i : i0);
       v0[j] = on ? row[0] : ~0ull;
-      v1[j] = on ? row[1] : 0ull;
-      v2[j] = on ? row[2] : 0ull;
+      v1[j] = on ? row[(size_t)1 * pcap] : 0ull;
+      v2[j] = on ? row[(size_t)2 * pcap] : 0ull;
 #pragma unroll
-      for (int c = 1; c < kMaxQ; ++c) vr[j][c] = (on && c < q) ? row[kRowRmax + c] : 0ull;
+      for (int c = 1; c < kMaxQ; ++c) vr[j][c] = (on && c < q) ? row[(size_t)(kRowRmax + c) * pcap] : 0ull;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -381,11 +442,11 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
       for (int j = 0; j < 4; ++j) {
         const int i = i0 + j * blockDim.x;
         if (i >= nparts) continue;
-        const unsigned long long* row = part + (size_t)i * kClassifyRow;
-        cB += (long long)row[3];
+        const unsigned long long* row = part + i;
+        cB += (long long)row[(size_t)3 * pcap];
 #pragma unroll
         for (int c = 0; c < kMaxQ; ++c)
-          if (c < q) { const unsigned long long k = row[kRowVmin + c]; vmin[c] = k < vmin[c] ? k : vmin[c]; }
+          if (c < q) { const unsigned long long k = row[(size_t)(kRowVmin + c) * pcap]; vmin[c] = k < vmin[c] ? k : vmin[c]; }
       }
     }
   }
@@ -433,10 +494,10 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
     for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) to[i] = from[i];
   }
 }
-__global__ __launch_bounds__(256) void k_classify_final(const unsigned long long* __restrict__ part, int nparts, int q,
+__global__ __launch_bounds__(256) void k_classify_final(const unsigned long long* __restrict__ part, int nparts, int pcap, int q,
                                                         SweepScalars* sc, const double* __restrict__ Lpart, int per_out,
                                                         unsigned long long* Lmax, SweepScalars* sc_copy, const GuardBand* gb, double b) {
-  classify_final_body(part, nparts, q, sc, Lpart, per_out, Lmax, sc_copy, gb, b);
+  classify_final_body(part, nparts, pcap, q, sc, Lpart, per_out, Lmax, sc_copy, gb, b);
 }
 
 // Objective pass of a classification whose S / U bytes came out of the posterior kernel (K1b, one constraint): u* = min over
@@ -493,17 +554,18 @@ __device__ __forceinline__ unsigned long long ustar_partial_body(int bid, int nw
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_classify_obj(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b,
-                                                      const uint8_t* __restrict__ S, unsigned long long* __restrict__ part) {
+                                                      const uint8_t* __restrict__ S, unsigned long long* __restrict__ part /* first row of this pass */,
+                                                      int pcap) {
   double vmin0;
   const unsigned long long umin = ustar_partial_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, b, S, vmin0);
   const unsigned long long vk = block_ext_u64<false>(vmin0 < kInfD ? ord_key(vmin0) : ~0ull);
   __shared__ unsigned long long keys[2];
   if (threadIdx.x == 0) { keys[0] = umin; keys[1] = vk; }
   __syncthreads();
-  unsigned long long* row = part + (size_t)blockIdx.x * kClassifyRow;
+  unsigned long long* row = part + blockIdx.x;
   if (threadIdx.x < kClassifyRow) {
     const int t = threadIdx.x;
-    row[t] = t == 0 ? keys[0] : (t == kRowVmin ? keys[1] : ((t > kRowVmin && t < kRowRmax) ? ~0ull : 0ull));
+    row[(size_t)t * pcap] = t == 0 ? keys[0] : (t == kRowVmin ? keys[1] : ((t > kRowVmin && t < kRowRmax) ? ~0ull : 0ull));
   }
 }
 
@@ -562,7 +624,7 @@ __device__ __forceinline__ void minimizer_body(int bid, int nwg, const T* __rest
       M[g] = m;
       if (m) {
         ++cM;
-        best_take<true>(best, (double)va[k], dv0, first + g);
+        best_take_uni<true>(best, (double)va[k], first + g);
       }
     }
   }
@@ -578,10 +640,10 @@ __device__ __forceinline__ void minimizer_body(int bid, int nwg, const T* __rest
     M[g] = m;
     if (m) {
       ++cM;
-      best_take<true>(best, (double)var0[g], dv0, first + g);
+      best_take_uni<true>(best, (double)var0[g], first + g);
     }
   }
-  best = block_best<true>(best);
+  best = block_best_uni<true>(best, dv0);
   cM = block_sum_ll(cM);
   cB = block_sum_ll(cB);
   if (threadIdx.x == 0) {
@@ -602,13 +664,17 @@ __global__ __launch_bounds__(256) void k_minimizer(const T* __restrict__ mean0, 
 // (`d`: the band of the value under the guard band of an approximating posterior -- bind() loads the band's scalars once)
 template <typename T>
 struct ValArray {          // var_0
+  static constexpr bool kUniform = true;   // one band for every value (uni())
   const T* p;
   double dv;
+  __device__ __forceinline__ double uni() const { return dv; }
   __device__ __forceinline__ void bind(const GuardBand* gb) { dv = gb ? gb->dv[0] : 0.0; }
   __device__ __forceinline__ T operator()(long long g, double& d) const { d = dv; return p[g]; }
 };
 template <typename T>
 struct ValLcb {            // lcb_0 = mean_0 - b sqrt(var_0), models/GoOSE.py:72, models/GP_TR.py:45
+  static constexpr bool kUniform = false;  // the band of a bound depends on the candidate's variance
+  __device__ __forceinline__ double uni() const { return 0.0; }
   const T* m;
   const T* v;
   T b;
@@ -624,6 +690,8 @@ struct ValLcb {            // lcb_0 = mean_0 - b sqrt(var_0), models/GoOSE.py:72
 };
 template <typename T, int D>
 struct ValDist {           // Euclidean distance to the target, as scipy.spatial.distance.cdist computes it (models/GoOSE.py:117)
+  static constexpr bool kUniform = true;
+  __device__ __forceinline__ double uni() const { return 0.0; }
   CandSpec cs;
   const double* target;
   __device__ __forceinline__ void bind(const GuardBand*) {}
@@ -671,7 +739,8 @@ __device__ __forceinline__ void arg_masked_body(int bid, int nwg, const V& val_i
     for (int k = 0; k < 8; ++k) {
       if (set[k]) {
         ++cnt;
-        best_take<MAX>(best, (double)v[k], dd[k], first + base + k * 64 + lane);
+        if constexpr (V::kUniform) best_take_uni<MAX>(best, (double)v[k], first + base + k * 64 + lane);
+        else best_take<MAX>(best, (double)v[k], dd[k], first + base + k * 64 + lane);
       }
     }
   }
@@ -680,10 +749,12 @@ __device__ __forceinline__ void arg_masked_body(int bid, int nwg, const V& val_i
       ++cnt;
       double d = 0.0;
       const T v = val(g, d);
-      best_take<MAX>(best, (double)v, d, first + g);
+      if constexpr (V::kUniform) best_take_uni<MAX>(best, (double)v, first + g);
+      else best_take<MAX>(best, (double)v, d, first + g);
     }
   }
-  best = block_best<MAX>(best);
+  if constexpr (V::kUniform) best = block_best_uni<MAX>(best, val.uni());
+  else best = block_best<MAX>(best);
   cnt = block_sum_ll(cnt);
   if (threadIdx.x == 0) {
     partial[bid] = best;
@@ -778,7 +849,6 @@ __global__ __launch_bounds__(256) void k_sweep_finals(const unsigned char* __res
     }
     if (threadIdx.x < kMaxQ) {
       hm->rmax_key[threadIdx.x] = sc->rmax_key[threadIdx.x];
-      hm->gb_du[threadIdx.x] = sc->gb_du[threadIdx.x];
       reinterpret_cast<unsigned long long*>(mirror + 3072)[threadIdx.x] = Lkeys[threadIdx.x];
     }
     if (threadIdx.x >= 64 && threadIdx.x < 64 + kArgSlots && (int)threadIdx.x - 64 >= (int)gridDim.x) hm->guard_slot[threadIdx.x - 64] = 0;
@@ -923,7 +993,7 @@ __global__ __launch_bounds__(256) void k_arg_final_mirror(const Best* __restrict
   __syncthreads();
   const unsigned long long* from = reinterpret_cast<const unsigned long long*>(sc);
   unsigned long long* to = reinterpret_cast<unsigned long long*>(mirror);
-  for (unsigned i = threadIdx.x; i < sizeof(SweepScalars) / 8; i += blockDim.x) to[i] = from[i];
+  for (unsigned i = threadIdx.x; i < kScalHost / 8; i += blockDim.x) to[i] = from[i];     // (the host's part of the block)
   if (threadIdx.x < kMaxQ) reinterpret_cast<unsigned long long*>(mirror + 3072)[threadIdx.x] = Lkeys[threadIdx.x];
 }
 
@@ -967,7 +1037,7 @@ static void launch_final(sbo_ctx* c, FinalJob* fj) {
   fj->pending = false;
   // (with a second lane the fork event rides on this launch as its stop event: a separate record costs the stream a bubble)
   hipExtLaunchKernelGGL(k_classify_final, dim3(1), dim3(256), 0, c->stream, nullptr, fj->sc_copy ? c->ev_join[4] : nullptr, 0, fj->part,
-                        fj->nparts, fj->q, fj->sc, fj->Lpart, fj->per_out, fj->Lmax, fj->sc_copy, fj->gb, fj->b);
+                        fj->nparts, fj->pcap, fj->q, fj->sc, fj->Lpart, fj->per_out, fj->Lmax, fj->sc_copy, fj->gb, fj->b);
 }
 
 // `defer`: the merge of the classification's partials is handed back instead of launched (SafeOpt on one rank: it rides in
@@ -1000,26 +1070,30 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* def
   // four workgroups per CU measured best (2: 24.6 us, 4: 21.5, 8: 27.1 on config B's 4 M candidates; on config C's 1 M: 1024 /
   // 512 / 256 workgroups 0.1455 / 0.1463 / 0.1530 ms per sweep -- fewer is not better there either)
   int ncb = std::max(1, c->n_cu * 4);
-  if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kClassifyRow * (size_t)ncb))) return rc;
   if (c->fuse_rows > 0 && n > 0) {
-    // S / U bytes, |S|, |U| and the radius key came out of the posterior kernel: only u* is left, over the safe candidates
+    // S / U bytes, |S|, |U| and the radius key came out of the posterior kernel (which sized the row buffer: cpart_cap): only u*
+    // is left, over the safe candidates
     const int nob = std::max(1, c->n_cu * 4);
     unsigned long long* rows = (unsigned long long*)c->cpart.p;
     hipLaunchKernelGGL(k_classify_obj<T>, dim3((unsigned)nob), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b,
-                       (const uint8_t*)c->maskS.p, rows + (size_t)c->fuse_rows * kClassifyRow);
+                       (const uint8_t*)c->maskS.p, rows + c->fuse_rows, c->cpart_cap);
     fj.part = (const unsigned long long*)rows;
     fj.nparts = c->fuse_rows + nob;
+    fj.pcap = c->cpart_cap;
     if (defer) *defer = fj;
     else launch_final(c, &fj);
     c->amb_clean = true;
     SBO_HIP(hipGetLastError());
     return SBO_OK;
   }
+  if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kClassifyRow * (size_t)ncb))) return rc;
+  c->cpart_cap = (int)(c->cpart.bytes / (sizeof(unsigned long long) * kClassifyRow));
   if (n > 0)
     hipLaunchKernelGGL((k_classify<T>), dim3((unsigned)ncb), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, q,
-                       (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p, gb_of(c));
+                       (T)o->b, (uint8_t*)c->maskS.p, (uint8_t*)c->maskU.p, (unsigned long long*)c->cpart.p, c->cpart_cap, gb_of(c));
   fj.part = (const unsigned long long*)c->cpart.p;
   fj.nparts = n > 0 ? ncb : 0;
+  fj.pcap = c->cpart_cap;
   if (defer) *defer = fj;
   else launch_final(c, &fj);
   c->amb_clean = true;
@@ -1558,7 +1632,8 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
     { const int rcf = model_factor_enqueue(c); if (rcf) return rcf; }
     SBO_HIP(stream_wait(c, c->stream));
     ++c->host_syncs;
-    memcpy(&h, c->h_back, sizeof(h));
+    memset(&h, 0, sizeof(h));
+    memcpy(&h, c->h_back, kScalHost);
     if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
     // decisions the guard band of an approximating posterior leaves open: the classification's and the verdict kernels' count
     // plus what the final reductions found in their slots
@@ -1576,7 +1651,8 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   if (done_ev) SBO_HIP(hipEventRecord(done_ev, c->stream));
   SBO_HIP(stream_wait(c, c->stream));
   ++c->host_syncs;
-  memcpy(&h, c->h_back, sizeof(h));
+  memset(&h, 0, sizeof(h));
+  memcpy(&h, c->h_back, kScalHost);
   if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
   c->c1_pending = false;                       // (the whole stream has drained)
   h.count_S = h.count_U = h.count_M = h.n_amb_total = h.n_guard = 0;

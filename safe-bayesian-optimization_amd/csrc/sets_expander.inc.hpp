@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k_edt_axis0_pair(const uint8_t* __restric
   // (order of the ranges: the merge and the coarse lines first -- few workgroups with longer chains that should start with the
   // launch, not in the slots the fine lines leave at its end)
   const int nfin = (int)gridDim.x - nfine - ncoarse, bid = (int)blockIdx.x;
-  if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy, fin.gb, fin.b);
+  if (bid < nfin) classify_final_body(fin.part, fin.nparts, fin.pcap, fin.q, fin.sc, fin.Lpart, fin.per_out, fin.Lmax, fin.sc_copy, fin.gb, fin.b);
   else if (bid < nfin + ncoarse) edt_axis0_wg_body<true>(bid - nfin, ncoarse, lds, U, clines, cc0, h0c, Dc, cg);
   else if (wave_lines) {
     // (the waves of the fine workgroups stride over the lines: the host sizes the launch to what is resident at once)
