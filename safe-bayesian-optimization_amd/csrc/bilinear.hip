@@ -1273,8 +1273,11 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
                                                   const double* __restrict__ xn0, uint8_t* __restrict__ Sfuse, uint8_t* __restrict__ Ufuse,
                                                   double bconf, unsigned long long* __restrict__ cpart /* [kFuseRow][pcap]: a row per workgroup of output 1 */,
                                                   int pcap,
-                                                  const GuardBand* __restrict__ gb /* nullptr: no guard band (the first launch of a plan measures it afterwards) */,
-                                                  const int* __restrict__ eff /* nullptr, or the Chebyshev core's k-steps of the variance phase at [4 o] */) {
+                                                  const GuardBand* __restrict__ gb /* nullptr: no guard band */,
+                                                  const int* __restrict__ eff /* nullptr, or the Chebyshev core's k-steps of the variance phase at [4 o] */,
+                                                  const double* __restrict__ gtmax /* nullptr (every tile runs the gradient phases), or the plan's
+                                                  largest gradient samples per tile [q][2][tiles], followed by the slacks [q][2] */,
+                                                  const unsigned long long* __restrict__ gkey /* the grid's largest samples [q][2] */) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
   const int o = blockIdx.z;
   PostCtx cx;
@@ -1321,10 +1324,29 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   const double* const A3 = VAo + (size_t)nrb * (KBm + KBm2) * 256;
   post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, eff ? eff[4 * o] : KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0, pre,
                     VAo, SBo, KBm);
-  post_phase<1, RB>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0, pre, A2, B2, KBm2);
+  // The gradient phases (their maxima are the Lipschitz keys, models/SafeOpt.py:68-83) run on the tiles that can hold the grid's
+  // maximum: the tile's largest coarse sample + the plan's bound on what lies between the samples reaches the grid's largest
+  // sample (k_bl_gradbound / k_bl_gradcoarse above).  Every tile folds its own samples in (true grid values).  NaN: run.
+  const double cg0 = ystd * mc.inv_ell[o][0] * mc.X_rstd[0], cg1 = ystd * mc.inv_ell[o][1] * mc.X_rstd[1];
+  bool run2 = true, run3 = true;
+  double gfold = 0.0;                       // (uniform: scalar registers -- folded in behind the phases)
+  if (gtmax) {
+    const size_t nt = (size_t)gridDim.x * gridDim.y, tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const double* slack = gtmax + (size_t)gridDim.z * 2 * nt;
+    const double t0 = gtmax[((size_t)o * 2 + 0) * nt + tile], t1 = gtmax[((size_t)o * 2 + 1) * nt + tile];
+    const double G0 = __longlong_as_double((long long)gkey[2 * o + 0]), G1 = __longlong_as_double((long long)gkey[2 * o + 1]);
+    run2 = !(t0 + slack[2 * o + 0] < G0 * (1.0 - 1e-12));
+    run3 = !(t1 + slack[2 * o + 1] < G1 * (1.0 - 1e-12));
+    const double f0 = fabs(cg0 * t0), f1 = fabs(cg1 * t1);
+    gfold = fmax(f0, f1);
+  }
+  // (the mean phase requests the first operands of whichever phase follows it)
+  post_phase<1, RB>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0, pre, run2 ? A2 : A3, run2 ? B2 : SBo,
+                    run2 ? KBm2 : KBm);
   // phase 2 continues on phase 1's sums: only the V1 half (the first KSm k-steps) of the stacked operands is run
-  post_phase<2, RB>(cx, A2, B2, KBm2, KSm, nullptr, ystd * mc.inv_ell[o][0] * mc.X_rstd[0], 0.0, 0.0, gmax, acc, xn0, pre, A3, SBo, KBm);
-  post_phase<3, RB>(cx, A3, SBo, KBm, KSm, nullptr, ystd * mc.inv_ell[o][1] * mc.X_rstd[1], 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
+  if (run2) post_phase<2, RB>(cx, A2, B2, KBm2, KSm, nullptr, cg0, 0.0, 0.0, gmax, acc, xn0, pre, A3, SBo, KBm);
+  if (run3) post_phase<3, RB>(cx, A3, SBo, KBm, KSm, nullptr, cg1, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
+  gmax = fmax(gmax, gfold);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const double other = __shfl_xor(gmax, off);
@@ -1663,6 +1685,136 @@ __global__ __launch_bounds__(256) void k_gb_probe_k1b(const ModelConst mc, const
   }
 }
 
+// ---- Lipschitz keys without the gradient phases on every tile (r04) ------------------------------------------------------------
+// L_i = max over the grid of ||grad MEAN_i||_inf (models/SafeOpt.py:68-83) took two of k_bpost's four GEMM phases on EVERY tile
+// -- ~90 of its 257 us on config H -- for two scalars per output.  The gradient sums are polynomials of the axes' Chebyshev
+// variables (degree <= rc per axis, the degree of the bases), so:
+//   (1) k_bl_gradbound, per plan: the Chebyshev coefficients C[a][b] of g_0 = f_1 - xn0 f_0 and g_1 = f_2 - xn1 f_0 (f_b the
+//       three bilinear forms of the mean phases) and from them sum |C| a^2, sum |C| b^2 >= max |dg / dxi| (|T_a'| <= a^2) -> a
+//       bound `slack` on how far |g| can move over half a sampling cell;
+//   (2) k_bl_gradcoarse, per plan: g at the centres of kGradStep x kGradStep cells of the grid (direct sums over the rank,
+//       1 / 64 of the candidates) -> the largest sample of every k_bpost tile and of the whole grid;
+//   (3) k_bpost runs a gradient phase only on the tiles whose largest sample + slack reaches the grid's largest sample: no
+//       other tile can hold the maximum.  The key is still the maximum of the FINE-grid values of phases 2 / 3 (on those tiles),
+//       i.e. the same number as before, to the last bit.  Config H: ~1-7 % of the tiles qualify.
+constexpr int kGradStep = 8;
+// coefficient bounds: one workgroup per output.  W_b[p][c1] = sum_s Mb_b[p][s] sig1_s Vs1[s][c1] (scratch), then entry (a, c1) of
+// C_b = sum_p sig0_p Vs0[p][a] W_b[p][c1]; the product with xn = mid + half xi by xi T_a = (T_{a+1} + T_|a-1|) / 2.
+__global__ __launch_bounds__(256) void k_bl_gradbound(const BlDims dm, const double* __restrict__ Vsall, const double* __restrict__ sigall,
+                                                      const double* __restrict__ Mball, double* __restrict__ Wscr /* [q][3][kBlMaxR][kBlMaxRc] */,
+                                                      double dxi0, double dxi1 /* half a sampling cell in xi units */,
+                                                      double* __restrict__ slack /* [q][2] */) {
+  __shared__ double red[4][4];
+  const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = dm.r0[o], r1 = dm.r1[o], rc0 = dm.rc0[o], rc1 = dm.rc1[o];
+  const double* Vs0 = Vsall + (size_t)(2 * o) * kBlMaxR * kBlMaxRc;
+  const double* Vs1 = Vsall + (size_t)(2 * o + 1) * kBlMaxR * kBlMaxRc;
+  const double* sig0 = sigall + (size_t)(2 * o) * kBlMaxR;
+  const double* sig1 = sigall + (size_t)(2 * o + 1) * kBlMaxR;
+  const double* Mb = Mball + (size_t)o * 3 * dm.r0u * dm.r1u;
+  double* W = Wscr + (size_t)o * 3 * kBlMaxR * kBlMaxRc;
+  for (int e = tid; e < 3 * r0 * rc1; e += blockDim.x) {
+    const int c1 = e % rc1, p = (e / rc1) % r0, b = e / (rc1 * r0);
+    double s = 0.0;
+    for (int s_ = 0; s_ < r1; ++s_) s += Mb[((size_t)b * r0 + p) * r1 + s_] * (sig1[s_] * Vs1[(size_t)s_ * rc1 + c1]);
+    W[((size_t)b * kBlMaxR + p) * kBlMaxRc + c1] = s;
+  }
+  __syncthreads();
+  auto Cb = [&](int b, int a, int c1) {          // coefficient (a, c1) of f_b; zero outside the degrees
+    if (a < 0 || a >= rc0) return 0.0;
+    double s = 0.0;
+    for (int p = 0; p < r0; ++p) s += (sig0[p] * Vs0[(size_t)p * rc0 + a]) * W[((size_t)b * kBlMaxR + p) * kBlMaxRc + c1];
+    return s;
+  };
+  const double mid0 = 0.5 * (dm.a[0] + dm.b[0]), half0 = 0.5 * (dm.b[0] - dm.a[0]);
+  const double mid1 = 0.5 * (dm.a[1] + dm.b[1]), half1 = 0.5 * (dm.b[1] - dm.a[1]);
+  double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;       // [component][axis]: sum |C| deg^2
+  // component 0: g_0 = f_1 - (mid0 + half0 xi0) f_0, degree rc0 in xi0; component 1: g_1 = f_2 - (mid1 + half1 xi1) f_0
+  for (int e = tid; e < (rc0 + 1) * (rc1 + 1); e += blockDim.x) {
+    const int a = e / (rc1 + 1), c1 = e % (rc1 + 1);
+    // xi F, F = sum C_a T_a:  xi T_0 = T_1, xi T_k = (T_{k+1} + T_{k-1}) / 2  ->  D_0 = C_1 / 2, D_1 = C_0 + C_2 / 2, D_a = (C_{a-1} + C_{a+1}) / 2
+    auto xi_shift0 = [&](int aa, int cc) {
+      if (cc >= rc1) return 0.0;
+      double v = 0.5 * Cb(0, aa + 1, cc);
+      if (aa == 1) v += Cb(0, 0, cc);
+      else if (aa >= 2) v += 0.5 * Cb(0, aa - 1, cc);
+      return v;
+    };
+    const double g0c = (c1 < rc1 ? Cb(1, a, c1) - mid0 * Cb(0, a, c1) : 0.0) - half0 * xi_shift0(a, c1);
+    // xi1 f_0: the same shift along the second index
+    double sh1 = 0.0;
+    if (a < rc0) {
+      auto C0 = [&](int cc) { return (cc >= 0 && cc < rc1) ? Cb(0, a, cc) : 0.0; };
+      sh1 = 0.5 * C0(c1 + 1);
+      if (c1 == 1) sh1 += C0(0);
+      else if (c1 >= 2) sh1 += 0.5 * C0(c1 - 1);
+    }
+    const double g1c = ((a < rc0 && c1 < rc1) ? Cb(2, a, c1) - mid1 * Cb(0, a, c1) : 0.0) - half1 * sh1;
+    const double a2 = (double)a * a, c2 = (double)c1 * c1;
+    b00 += fabs(g0c) * a2;
+    b01 += fabs(g0c) * c2;
+    b10 += fabs(g1c) * a2;
+    b11 += fabs(g1c) * c2;
+  }
+  b00 = wave_sum(b00); b01 = wave_sum(b01); b10 = wave_sum(b10); b11 = wave_sum(b11);
+  if (lane == 0) { red[wave][0] = b00; red[wave][1] = b01; red[wave][2] = b10; red[wave][3] = b11; }
+  __syncthreads();
+  if (tid == 0) {
+    double s[4];
+    for (int k = 0; k < 4; ++k) s[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    // |g| moves by at most max |dg/dxi0| dxi0 + max |dg/dxi1| dxi1 between a candidate and the centre of its sampling cell
+    slack[2 * o + 0] = (s[0] * dxi0 + s[1] * dxi1) * (1.0 + 1e-9);
+    slack[2 * o + 1] = (s[2] * dxi0 + s[3] * dxi1) * (1.0 + 1e-9);
+  }
+}
+// the gradient sums at the cell centres of one k_bpost tile (TL lines x 128 positions): a workgroup per (tile, output);
+// tmax[(o 2 + comp) ntiles + tile] = the tile's largest |g_comp| sample, gkey[o 2 + comp] = the grid's (bit pattern: values >= 0)
+__global__ __launch_bounds__(256) void k_bl_gradcoarse(const BlDims dm, const double* __restrict__ S0all, const double* __restrict__ Vball,
+                                                       const double* __restrict__ xn0, const double* __restrict__ xn1, int TL, int ntx,
+                                                       double* __restrict__ tmax, unsigned long long* __restrict__ gkey) {
+  __shared__ double red[4][2];
+  const int o = blockIdx.y, tile = blockIdx.x, bx = tile % ntx, by = tile / ntx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = dm.r0[o];
+  const double* S0 = S0all + (size_t)o * dm.r0u * dm.cnt0;
+  const double* Vb = Vball + (size_t)o * 3 * dm.r0u * dm.nlines;
+  const int npx = 128 / kGradStep, npl = TL / kGradStep;
+  double m0 = 0.0, m1 = 0.0;
+  for (int e = tid; e < npx * npl; e += blockDim.x) {
+    // the centre of the cell, or the last candidate of a cell the grid ends in: every candidate within kGradStep / 2 of a sample
+    long long x0 = (long long)bx * 128 + (e % npx) * kGradStep, l = (long long)by * TL + (e / npx) * kGradStep;
+    if (x0 >= dm.cnt0 || l >= dm.nlines) continue;
+    x0 = x0 + kGradStep / 2 < dm.cnt0 ? x0 + kGradStep / 2 : dm.cnt0 - 1;
+    l = l + kGradStep / 2 < dm.nlines ? l + kGradStep / 2 : dm.nlines - 1;
+    const double x0n = xn0[x0], x1n = xn1[l];
+    double g0 = 0.0, g1 = 0.0;
+    for (int p = 0; p < r0; ++p) {
+      const double s0 = S0[(size_t)p * dm.cnt0 + x0];
+      const double v0 = Vb[((size_t)0 * dm.r0u + p) * dm.nlines + l], v1 = Vb[((size_t)1 * dm.r0u + p) * dm.nlines + l],
+                   v2 = Vb[((size_t)2 * dm.r0u + p) * dm.nlines + l];
+      g0 = fma(v1 - x0n * v0, s0, g0);
+      g1 = fma(v2 - x1n * v0, s0, g1);
+    }
+    m0 = fmax(m0, fabs(g0));
+    m1 = fmax(m1, fabs(g1));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m0 = fmax(m0, __shfl_xor(m0, off));
+    m1 = fmax(m1, __shfl_xor(m1, off));
+  }
+  if (lane == 0) { red[wave][0] = m0; red[wave][1] = m1; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) { m0 = fmax(m0, red[w][0]); m1 = fmax(m1, red[w][1]); }
+    const size_t nt = (size_t)gridDim.x;
+    tmax[((size_t)o * 2 + 0) * nt + tile] = m0;
+    tmax[((size_t)o * 2 + 1) * nt + tile] = m1;
+    atomicMax(&gkey[2 * o + 0], (unsigned long long)__double_as_longlong(m0));
+    atomicMax(&gkey[2 * o + 1], (unsigned long long)__double_as_longlong(m1));
+  }
+}
+
 // ---- plan ------------------------------------------------------------------------------------------------
 static double axis_position(const sbo_ctx* c, int a, long long i) {
   const CandSpec& cs = c->cs;
@@ -1926,6 +2078,31 @@ int bilinear_setup(sbo_ctx* c) {
                      (double*)c->bl_VA.p);
   hipLaunchKernelGGL(k_bl_sbf, blocks(pl.sSBf, uq), dim3(256), 0, ys, dm, (const double*)dS0, (const double*)dxn0, pl.sSBf,
                      (double*)c->bl_SBf.p);
+  // where the gradient phases of k_bpost have to run (k_bl_gradbound / k_bl_gradcoarse): [q][2][tiles] largest samples | [q][2]
+  // slacks | [q][2] keys of the grid's largest samples | scratch of the coefficient kernel
+  pl.gtmax = nullptr;
+  pl.gkey = nullptr;
+  {
+    constexpr int TL = 64;                                   // lines of a k_bpost<1> tile
+    const int ntx = (ncs0 + 7) / 8, nty = (nrb + 3) / 4;
+    const size_t nt = (size_t)ntx * nty, head = (size_t)q * 2 * nt + 4 * (size_t)q;
+    if ((rc = ensure(c->bl_grad, sizeof(double) * (head + (size_t)q * 3 * kBlMaxR * kBlMaxRc)))) return rc;
+    double* gt = (double*)c->bl_grad.p;
+    double* slack = gt + (size_t)q * 2 * nt;
+    unsigned long long* gkey = (unsigned long long*)(slack + 2 * q);
+    // half a sampling cell in the Chebyshev variable of each axis: kGradStep / 2 grid steps
+    const double half0 = 0.5 * (dm.b[0] - dm.a[0]), half1 = 0.5 * (dm.b[1] - dm.a[1]);
+    const double dxi0 = cs.count[0] > 1 ? 0.5 * kGradStep * std::fabs(cs.step[0] / mc.X_std[0]) / half0 : 0.0;
+    const double dxi1 = cs.count[1] > 1 ? 0.5 * kGradStep * std::fabs(cs.step[1] / mc.X_std[1]) / half1 : 0.0;
+    SBO_HIP(hipMemsetAsync(gkey, 0, sizeof(unsigned long long) * 2 * q, ys));
+    hipLaunchKernelGGL(k_bl_gradbound, dim3(uq), dim3(256), 0, ys, dm, dVs, dsig, (const double*)dMb, (double*)(gkey + 2 * q), dxi0, dxi1, slack);
+    hipLaunchKernelGGL(k_bl_gradcoarse, dim3((unsigned)nt, uq), dim3(256), 0, ys, dm, (const double*)dS0, (const double*)dVb, (const double*)dxn0,
+                       (const double*)dxn1, TL, ntx, gt, gkey);
+    if (std::isfinite(dxi0) && std::isfinite(dxi1)) {
+      pl.gtmax = gt;
+      pl.gkey = gkey;
+    }
+  }
   // guard band of this plan (guard.hip): the exact evaluator at the probe points runs here, beside the core's GEMM chain
   const bool band = c->guard_band && !c->is_shadow;
   double *gref_m = nullptr, *gref_v = nullptr;
@@ -1992,6 +2169,23 @@ int bilinear_setup(sbo_ctx* c) {
   }
   SBO_HIP(hipGetLastError());
   lap("enqueue");
+  if (timing && pl.gtmax) {
+    // (diagnostic: how many tiles keep their gradient phases)
+    const int ntx = (ncs0 + 7) / 8, nty = (nrb + 3) / 4;
+    const size_t nt = (size_t)ntx * nty;
+    std::vector<double> h((size_t)q * 2 * nt + 4 * (size_t)q);
+    SBO_HIP(hipStreamSynchronize(xs));
+    SBO_HIP(hipMemcpy(h.data(), pl.gtmax, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    const double* sl = h.data() + (size_t)q * 2 * nt;
+    for (int o = 0; o < q; ++o)
+      for (int k = 0; k < 2; ++k) {
+        double G;
+        memcpy(&G, sl + 2 * q + 2 * o + k, 8);
+        size_t run = 0;
+        for (size_t i = 0; i < nt; ++i) run += !(h[((size_t)o * 2 + k) * nt + i] + sl[2 * o + k] < G * (1.0 - 1e-12));
+        fprintf(stderr, "[K1b setup] gradient phase %d of output %d: %zu of %zu tiles (largest sample %.6e, slack %.3e)\n", k, o, run, nt, G, sl[2 * o + k]);
+      }
+  }
   pl.usable = true;       // (nothing to wait for: the tables are made in stream order ahead of the posterior kernels)
   pl.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return SBO_OK;
@@ -2044,7 +2238,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                         pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
                         (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
                         fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                        (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused, (const int*)pl.eff);
+                        (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused, (const int*)pl.eff, pl.gtmax, pl.gkey);
   if (c->lmax_defer) {
     c->lmax_pending = true;
     c->lmax_per_out = (int)rows_out;
@@ -2069,7 +2263,8 @@ int launch_posterior_bilinear(sbo_ctx* c) {
     for (int o = 0; o < q; ++o) {
       const int ks = he[4 * o], kb0 = he[4 * o + 1], kb1 = he[4 * o + 2];
       if (ks < 1 || ks > pl.KS0 || kb0 < 1 || kb0 > pl.KB0 || kb1 < 1 || kb1 > pl.KB1) { ok = false; break; }
-      f += 2.0 * 1024.0 * (4.0 * (double)pl.nrb * kb0 * kb1 + tiles2 * (ks + 3 * pl.KSm));
+      // (the gradient phases run on the few tiles that can hold the maximum: not counted)
+      f += 2.0 * 1024.0 * (4.0 * (double)pl.nrb * kb0 * kb1 + tiles2 * (ks + (pl.gtmax ? 1 : 3) * pl.KSm));
     }
     if (ok) c->last_k1_flops = f;
   }

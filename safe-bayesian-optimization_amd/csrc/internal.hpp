@@ -54,6 +54,8 @@ struct BilinearPlan {
   int r0[kMaxQ] = {0}, r1[kMaxQ] = {0};
   double setup_ms = 0.0;
   int* eff = nullptr;    // device: per-output counts the kernels run to (k_cheb_trunc), followed by the truncation tails (q doubles)
+  const double* gtmax = nullptr;              // device: largest gradient samples per k_bpost tile + slacks (k_bl_gradcoarse), or none
+  const unsigned long long* gkey = nullptr;   // device: the grid's largest gradient samples
   bool band_ready = false;   // the guard band of this plan has been measured (guard.hip: guard_band_bilinear)
 };
 
@@ -172,6 +174,7 @@ struct sbo_ctx {
   sbo::DevBuf blockmax; // per-block largest source weight along axis 0 (blocked axis-0 pass of the power transform)
   sbo::DevBuf blockmin; // per-block minima along the last axis (blocked last-axis scans)
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
+  sbo::DevBuf bl_grad;  // K1b: which tiles run the gradient phases (per plan)
   sbo::DevBuf bl_lpart; // K1b: per-wave Lipschitz partials of k_bpost
   sbo::DevBuf cpart;   // per-workgroup partials of k_classify, field-major [kClassifyRow][cpart_cap]
   int cpart_cap = 0;   // row capacity the last writer of cpart laid its rows out with
