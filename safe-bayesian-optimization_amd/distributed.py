@@ -4,14 +4,16 @@ The data path of a multi-GPU run is RCCL inside libsafebo.so.  What the host sid
 ranks a launcher started (``torch.distributed.run`` or anything else that sets RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT):
 broadcasting the 128-byte RCCL unique id, barriers, a max over the ranks' timings, and -- for rehearsals on a 1-GPU box only
 -- carrying the library's collectives through host memory.  ``TcpGroup`` does that with the standard library (a star over TCP
-through rank 0): no PyTorch in the product package.  ``HostRelay`` and ``join`` accept any group object with the same five
+through rank 0, struct-framed byte strings, connections accepted on an HMAC challenge over the job's secret): no PyTorch in the
+product package.  ``HostRelay`` and ``join`` accept any group object with the same five
 methods (the CPU tests drive them with a torch.distributed / gloo adapter that lives under tests/).
 """
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import time
@@ -45,8 +47,10 @@ def merge_slots(rows, is_max):
     return out
 
 
-_MAGIC = b"SBO-RDZV1"
+_MAGIC = b"SBO-RDZV2"
 _OPS = {"sum": np.add, "max": np.maximum, "min": np.minimum}
+_MAX_FRAME = 1 << 30          # no message of this rendezvous is anywhere near it: a larger length word is a stranger or a bug
+_HELLO_TIMEOUT = 2.0          # seconds a connection gets to say who it is
 
 
 def _send(sock, payload: bytes):
@@ -63,77 +67,130 @@ def _recv_exact(sock, n: int) -> bytes:
     return bytes(buf)
 
 
-def _recv(sock) -> bytes:
+def _recv(sock, limit: int = _MAX_FRAME) -> bytes:
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > limit:
+        raise ConnectionError(f"rendezvous frame of {n} bytes refused (limit {limit})")
     return _recv_exact(sock, n)
 
 
+def _pack_list(parts) -> bytes:
+    """[bytes] -> count, lengths, bodies (fixed little-endian framing: nothing on this wire is ever unpickled)"""
+    return struct.pack("<I", len(parts)) + b"".join(struct.pack("<Q", len(p_)) for p_ in parts) + b"".join(parts)
+
+
+def _unpack_list(blob: bytes) -> list:
+    (n,) = struct.unpack_from("<I", blob, 0)
+    if 4 + 8 * n > len(blob):
+        raise ValueError("rendezvous list frame is truncated")
+    lens = struct.unpack_from(f"<{n}Q", blob, 4)
+    off, out = 4 + 8 * n, []
+    if off + sum(lens) != len(blob):
+        raise ValueError("rendezvous list frame has the wrong length")
+    for ln in lens:
+        out.append(blob[off:off + ln])
+        off += ln
+    return out
+
+
+def job_secret(base_port: int, world: int) -> bytes:
+    """The key both sides of the hello prove they hold.  SBO_RDZV_SECRET (set by whoever launches the ranks; required on a host
+    shared with users you do not trust) or, failing that, the launcher's run id -- mixed with the job's port and size so that
+    two jobs never accept each other's ranks."""
+    raw = os.environ.get("SBO_RDZV_SECRET") or os.environ.get("TORCHELASTIC_RUN_ID") or "safebo-rendezvous"
+    return hashlib.sha256(raw.encode() + struct.pack("<II", base_port, world)).digest()
+
+
+def rendezvous_port(base_port: int) -> int:
+    """ONE port, known to every rank before anyone connects: SBO_RDZV_PORT, else MASTER_PORT + 1 (MASTER_PORT itself belongs to
+    the launcher's store).  No scanning: a rank never talks to whoever happens to listen nearby."""
+    return int(os.environ.get("SBO_RDZV_PORT", base_port + 1))
+
+
 class TcpGroup:
-    """Star rendezvous over TCP: rank 0 listens on the first free port of [base + 1, base + 64] (base = MASTER_PORT, which the
-    launcher's own store occupies) and the others find it by a handshake (magic, base port, world size); every collective is
-    "send to rank 0, combine there, send back".  Small payloads only: ids, scalars, and the rehearsal relay."""
+    """Star rendezvous over TCP: rank 0 listens on `rendezvous_port`, the others connect to it; each connection is accepted
+    only after a challenge-response on the job's secret (HMAC-SHA256 over a fresh nonce, both directions), a rank in
+    [1, world) and no rank twice.  Every collective is "send to rank 0, combine there, send back", framed with struct: byte
+    strings and NumPy buffers only.  Small payloads: ids, scalars, and the rehearsal relay."""
 
     def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", base_port: int = 29500, timeout: float = 120.0):
+        if world < 1 or not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside a world of {world}")
         self.rank, self.world, self._peers, self._sock = rank, world, [], None
-        token = _MAGIC + struct.pack("<II", base_port, world)
+        key = job_secret(base_port, world)
+        port = rendezvous_port(base_port)
         deadline = time.time() + timeout
         if world == 1:
             return
+
+        def mac(*parts):
+            return hmac.new(key, b"".join(parts), hashlib.sha256).digest()
+
         if rank == 0:
-            srv = None
-            for k in range(1, 65):
-                try:
-                    srv = socket.create_server((addr, base_port + k), reuse_port=False)
-                    break
-                except OSError:
-                    continue
-            if srv is None:
-                raise OSError(f"no free rendezvous port in [{base_port + 1}, {base_port + 64}]")
-            srv.settimeout(1.0)
+            try:
+                srv = socket.create_server((addr, port), reuse_port=False)
+            except OSError as exc:
+                raise OSError(f"rendezvous port {port} on {addr} is taken ({exc}); set SBO_RDZV_PORT on every rank") from exc
+            srv.settimeout(0.25)
             peers = {}
-            while len(peers) < world - 1:
-                if time.time() > deadline:
-                    raise TimeoutError(f"rendezvous: {world - 1 - len(peers)} rank(s) did not arrive")
-                try:
-                    conn, _ = srv.accept()
-                except socket.timeout:
-                    continue
-                conn.settimeout(timeout)
-                try:
-                    hello = _recv(conn)
-                    if not hello.startswith(token):
+            try:
+                while len(peers) < world - 1:
+                    if time.time() > deadline:
+                        raise TimeoutError(f"rendezvous: {world - 1 - len(peers)} rank(s) did not arrive")
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        continue
+                    # a connection has _HELLO_TIMEOUT to prove itself; silence, strangers and repeats are dropped and cost
+                    # the others that much at most
+                    conn.settimeout(_HELLO_TIMEOUT)
+                    try:
+                        nonce = os.urandom(32)
+                        conn.sendall(_MAGIC + nonce)
+                        hello = _recv_exact(conn, len(_MAGIC) + 4 + 32 + 32)
+                        r = struct.unpack_from("<I", hello, len(_MAGIC))[0]
+                        theirs = hello[len(_MAGIC) + 4:len(_MAGIC) + 36]
+                        good = (hello.startswith(_MAGIC) and 1 <= r < world and r not in peers and
+                                hmac.compare_digest(hello[-32:], mac(b"rank", nonce, theirs, struct.pack("<I", r))))
+                        if not good:
+                            conn.close()
+                            continue
+                        conn.sendall(mac(b"root", theirs, nonce))
+                    except (OSError, ConnectionError, struct.error):
                         conn.close()
                         continue
-                    (r,) = struct.unpack("<I", hello[len(token):len(token) + 4])
-                    _send(conn, token)
-                except (OSError, ConnectionError, struct.error):
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    peers[r] = conn
+            except BaseException:
+                for conn in peers.values():
                     conn.close()
-                    continue
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                peers[r] = conn
-            srv.close()
+                raise
+            finally:
+                srv.close()
             self._peers = [peers[r] for r in range(1, world)]
         else:
             while self._sock is None:
-                for k in range(1, 65):
-                    try:
-                        s_ = socket.create_connection((addr, base_port + k), timeout=2.0)
-                    except OSError:
-                        continue
-                    try:
-                        s_.settimeout(5.0)
-                        _send(s_, token + struct.pack("<I", rank))
-                        if _recv(s_) == token:
-                            s_.settimeout(timeout)
-                            s_.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                            self._sock = s_
-                            break
-                    except (OSError, ConnectionError, struct.error):
-                        pass
-                    s_.close()
-                if self._sock is None:
+                s_ = None
+                try:
+                    s_ = socket.create_connection((addr, port), timeout=_HELLO_TIMEOUT)
+                    s_.settimeout(_HELLO_TIMEOUT)
+                    first = _recv_exact(s_, len(_MAGIC) + 32)
+                    if not first.startswith(_MAGIC):
+                        raise ConnectionError(f"port {port} on {addr} does not speak this rendezvous")
+                    nonce, mine = first[len(_MAGIC):], os.urandom(32)
+                    rk = struct.pack("<I", rank)
+                    s_.sendall(_MAGIC + rk + mine + mac(b"rank", nonce, mine, rk))
+                    if not hmac.compare_digest(_recv_exact(s_, 32), mac(b"root", mine, nonce)):
+                        raise ConnectionError("rank 0 did not prove the job secret")
+                    s_.settimeout(timeout)
+                    s_.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self._sock = s_
+                except (OSError, ConnectionError, struct.error) as exc:
+                    if s_ is not None:
+                        s_.close()
                     if time.time() > deadline:
-                        raise TimeoutError("rendezvous: rank 0 was not found")
+                        raise TimeoutError(f"rendezvous: rank 0 was not reached on {addr}:{port} ({exc})") from exc
                     time.sleep(0.05)
 
     # -- the five methods a "group" has ----------------------------------------------------------------------------------
@@ -159,10 +216,14 @@ class TcpGroup:
     def barrier(self):
         self._exchange(b"", lambda parts: [b""] * len(parts))
 
-    def broadcast_object(self, obj, src: int = 0):
+    def broadcast_bytes(self, payload, src: int = 0) -> bytes:
+        """the byte string of rank `src` on every rank (the other ranks' argument is ignored)"""
+        if not 0 <= src < self.world:
+            raise ValueError(f"broadcast source {src} outside a world of {self.world}")
+
         def combine(parts):
             return [parts[src]] * len(parts)
-        return pickle.loads(self._exchange(pickle.dumps(obj), combine))
+        return self._exchange(bytes(payload) if self.rank == src else b"", combine)
 
     def all_reduce(self, arr: np.ndarray, op: str = "sum") -> np.ndarray:
         """element-wise sum / max / min over the ranks of a NumPy array (same shape and dtype everywhere)"""
@@ -170,17 +231,25 @@ class TcpGroup:
         fn = _OPS[op]
 
         def combine(parts):
+            if any(len(p_) != a.nbytes for p_ in parts):
+                raise ValueError("all_reduce: the ranks sent buffers of different sizes")
             acc = np.frombuffer(parts[0], dtype=a.dtype).copy()
             for p_ in parts[1:]:
                 acc = fn(acc, np.frombuffer(p_, dtype=a.dtype))
             return [acc.tobytes()] * len(parts)
-        return np.frombuffer(self._exchange(a.tobytes(), combine), dtype=a.dtype).reshape(a.shape).copy()
+        out = self._exchange(a.tobytes(), combine)
+        if len(out) != a.nbytes:
+            raise ValueError("all_reduce: answer of the wrong size")
+        return np.frombuffer(out, dtype=a.dtype).reshape(a.shape).copy()
 
     def all_gather_bytes(self, payload: bytes) -> list:
         def combine(parts):
-            blob = pickle.dumps(parts)
+            blob = _pack_list(parts)
             return [blob] * len(parts)
-        return pickle.loads(self._exchange(bytes(payload), combine))
+        out = _unpack_list(self._exchange(bytes(payload), combine))
+        if len(out) != self.world:
+            raise ValueError("all_gather: answer with the wrong number of parts")
+        return out
 
     def destroy(self):
         for p in self._peers:
@@ -237,15 +306,16 @@ def join(engine, group, relay: bool = False):
         return
     # the broadcast always happens, also when rank 0 could not create the id: every rank then raises the same error
     # instead of some of them waiting in the broadcast for a rank that has already left
-    uid = None
+    msg = b""
     if rank == 0:
         try:
-            uid = engine.comm_unique_id()
+            msg = b"\x00" + bytes(engine.comm_unique_id())
         except Exception as exc:                  # noqa: BLE001
-            uid = ("error", str(exc))
-    uid = group.broadcast_object(uid, src=0)
-    if isinstance(uid, tuple):
-        raise L.SafeBOError(L.SBO_E_COMM, f"rank 0 could not create the RCCL unique id: {uid[1]}")
+            msg = b"\x01" + str(exc).encode("utf-8", "replace")
+    msg = group.broadcast_bytes(msg, src=0)
+    if msg[:1] != b"\x00":
+        raise L.SafeBOError(L.SBO_E_COMM, f"rank 0 could not create the RCCL unique id: {msg[1:].decode('utf-8', 'replace')}")
+    uid = msg[1:]
     engine.comm_init(world, rank, uid)
 
 

@@ -24,10 +24,14 @@ class GlooGroup:
     def barrier(self):
         self._dist.barrier()
 
-    def broadcast_object(self, obj, src=0):
-        box = [obj]
-        self._dist.broadcast_object_list(box, src=src)
-        return box[0]
+    def broadcast_bytes(self, payload, src=0):
+        torch, dist = self._torch, self._dist
+        n = torch.tensor([len(payload) if dist.get_rank() == src else 0], dtype=torch.int64)
+        dist.broadcast(n, src=src)
+        buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8) if dist.get_rank() == src and len(payload) else torch.empty(int(n[0]), dtype=torch.uint8)
+        if int(n[0]):
+            dist.broadcast(buf, src=src)
+        return bytes(buf.numpy().tobytes())
 
     def all_reduce(self, arr, op="sum"):
         torch, dist = self._torch, self._dist

@@ -70,7 +70,7 @@ def _tcp_rank(rank, world, port, q):
     from safebo_amd.distributed import TcpGroup
     g = TcpGroup(rank, world, "127.0.0.1", port, timeout=60.0)
     out = {}
-    out["bcast"] = g.broadcast_object({"id": b"x" * 128, "n": 7} if rank == 0 else None, src=0)
+    out["bcast"] = g.broadcast_bytes(b"\x00" + b"x" * 128 if rank == 0 else b"", src=0)
     out["sum"] = g.all_reduce(np.array([rank + 1.5, 2.0 * rank]), "sum").tolist()
     out["max_u64"] = g.all_reduce(np.array([(1 << 63) + rank, 5 - rank], dtype=np.uint64), "max").tolist()
     out["min_i64"] = g.all_reduce(np.array([rank - 1], dtype=np.int64), "min").tolist()
@@ -99,7 +99,95 @@ def test_tcp_rendezvous_collectives_three_ranks():
                 p.kill()
     for r in range(3):
         o = got[r]
-        assert o["bcast"] == {"id": b"x" * 128, "n": 7}
+        assert o["bcast"] == b"\x00" + b"x" * 128
         assert o["sum"] == [1.5 + 2.5 + 3.5, 0.0 + 2.0 + 4.0]
         assert o["max_u64"] == [(1 << 63) + 2, 5] and o["min_i64"] == [-1]
         assert o["gather"] == [b"\x00", b"\x01\x01", b"\x02\x02\x02"]
+
+
+def test_tcp_rendezvous_refuses_strangers_bad_ranks_and_repeats(monkeypatch):
+    """rank 0 accepts a connection only after the HMAC hello on the job's secret, with a rank in [1, world) that has
+    not joined yet; a silent connection costs the others the 2 s hello timeout, not the job's; nothing on the wire is unpickled
+    (struct framing)."""
+    import hashlib
+    import hmac
+    import socket
+    import struct
+    import threading
+    import time
+    from safebo_amd import distributed as D
+    assert "pickle" not in open(D.__file__).read().replace("unpickled", "")
+    monkeypatch.setenv("SBO_RDZV_SECRET", "job-4711")
+    port = int(_free_port())
+    world = 3
+    key = D.job_secret(port, world)
+    out = {}
+
+    def root():
+        out[0] = D.TcpGroup(0, world, "127.0.0.1", port, timeout=60.0)
+
+    th = threading.Thread(target=root)
+    th.start()
+
+    def hello(rank, secret=key, silent=False):
+        deadline = time.time() + 20
+        while True:
+            try:
+                s_ = socket.create_connection(("127.0.0.1", D.rendezvous_port(port)), timeout=5.0)
+                break
+            except OSError:
+                assert time.time() < deadline
+                time.sleep(0.05)
+        s_.settimeout(6.0)
+        first = D._recv_exact(s_, len(D._MAGIC) + 32)
+        if silent:
+            return s_
+        nonce, mine, rk = first[len(D._MAGIC):], b"m" * 32, struct.pack("<I", rank)
+        s_.sendall(D._MAGIC + rk + mine + hmac.new(secret, b"rank" + nonce + mine + rk, hashlib.sha256).digest())
+        try:
+            return s_ if len(D._recv_exact(s_, 32)) == 32 else None
+        except (ConnectionError, OSError):
+            s_.close()
+            return None
+
+    t0 = time.time()
+    quiet = hello(1, silent=True)                       # says nothing: dropped after the hello timeout
+    assert hello(1, secret=b"k" * 32) is None           # wrong secret
+    assert hello(0) is None and hello(world) is None    # right secret, impossible ranks
+    ranks = {}
+
+    def member(r):
+        ranks[r] = D.TcpGroup(r, world, "127.0.0.1", port, timeout=60.0)
+
+    m1 = threading.Thread(target=member, args=(1,))
+    m1.start()
+    m1.join(30)
+    assert 1 in ranks
+    assert hello(1) is None                             # rank 1 again: refused, the first one keeps its seat
+    m2 = threading.Thread(target=member, args=(2,))
+    m2.start()
+    m2.join(30)
+    th.join(30)
+    assert not th.is_alive() and 0 in out and 2 in ranks
+    assert time.time() - t0 < 25.0
+    quiet.close()
+    res = {}
+
+    def work(g):
+        res[g.rank] = (g.all_gather_bytes(bytes([g.rank + 65]) * g.rank), g.broadcast_bytes(b"uid" if g.rank == 0 else b"", 0))
+
+    ths = [threading.Thread(target=work, args=(g,)) for g in (out[0], ranks[1], ranks[2])]
+    for x in ths:
+        x.start()
+    for x in ths:
+        x.join(30)
+    for r in range(3):
+        assert res[r] == ([b"", b"B", b"CC"], b"uid")
+    for g in (out[0], ranks[1], ranks[2]):
+        g.destroy()
+    # frames beyond the limit and malformed lists are refused, not allocated
+    import pytest
+    with pytest.raises(ValueError):
+        D._unpack_list(struct.pack("<I", 3) + b"\x00" * 8)
+    with pytest.raises(ValueError):
+        TcpBad = D.TcpGroup(3, 3)

@@ -6,11 +6,4 @@ SBO_DEBUG_TENSOR=1 timeout -k 10 400 python tools/dev_tensor.py > gpurun_out/ten
 cd /tmp && export TMPDIR=/tmp
 DEV_TENSOR_ONLY=128 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/tensor_prof -o t -- python3 $GRAFT_REPO_ROOT/tools/dev_tensor.py > $GRAFT_REPO_ROOT/gpurun_out/tensor_prof.log 2>&1
 cd $GRAFT_REPO_ROOT
-python3 tools/db_kernels.py gpurun_out/tensor_prof/t_results.db 30; exit 0
-import csv, glob
-f = glob.glob('gpurun_out/tensor_prof/**/*kernel_stats.csv', recursive=True)
-if f:
-    rows = list(csv.DictReader(open(f[0])))
-    for r in rows[:14]:
-        print(r['Name'][:60], r['Calls'], r['TotalDurationNs'], r['AverageNs'])
-PY
+python3 tools/db_kernels.py gpurun_out/tensor_prof/t_results.db 30
