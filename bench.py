@@ -28,12 +28,15 @@ What the JSON line reports (N = 1 adds the last five):
                         (test/test_SafeOpt.py:144-179), so here two data sets alternate and every timed step is
                         set_model (upload + alpha on the device; the reverse factor of the caller's invK is deferred) + the
                         per-(model, grid) table build of K1b + the sweep.
-  table_kernel          the same resident-model sweep with the O(n^2)-per-candidate kernel K1g (on config B).
+  table_kernel          the same resident-model sweep with the exact O(n^2)-per-candidate kernel K1g (here on H; B and D in
+                        `extra`), with `agreement`: every count and index of the two posteriors' results compared.
+  config.result         counts, indices and the guard-band bookkeeping (`guard_band` = decisions the approximating posterior
+                        could not make unconditionally on the fast path; 0 on every BASELINE config).
   extra                 the other BASELINE.json configs on the one GPU: B (2048^2, n = 128; with its iteration cost and K1g figure),
                         C (Williams-Otto, 1024^2, n = 256, q = 3: GoOSE and SafeOpt, with iteration costs), D (128^4, the whole
                         grid of the 8-GPU config), E (10^7 scattered 6-D points, n = 2048, fp32 with the fp64 recheck).
-  cpu_baseline          the C + OpenMP restatement of the same sweep on the box's host cores (`numpy`: the NumPy
-                        oracle on a bounded prefix), on config B's grid (a bounded sample of CPU work).
+  cpu_baseline          the C + OpenMP restatement of the same sweep on the box's host cores (`numpy`: the NumPy oracle on a
+                        bounded prefix) on the first 2^21 candidates of config H's own grid (n = 512); `config_B`: config B's whole grid.
 
 No torch anywhere: the ranks of the launcher meet through safebo_amd.distributed.TcpGroup (stdlib sockets: unique-id
 broadcast, barriers, max over ranks); device memory, streams and the collectives on the data path belong to libsafebo.so.
@@ -80,8 +83,9 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, count, sample):
-    """The CPU restatement of the same sweep on the box's host cores (rank 0, N = 1 only).
+def cpu_baseline(cfg, count, sample, prefix=None):
+    """The CPU restatement of the same sweep on the box's host cores (rank 0, N = 1 only).  ``prefix``: the C + OpenMP column runs
+    on the first `prefix` candidates of the grid instead of all of it (config H: a whole sweep would be minutes of CPU work).
 
     Main figure: oracle/c/sweep_omp.c -- the reference formulation (explicit invK, k^T invK per candidate, models/GP_Safe.py:
     310-352; bounds, S / U / M masks, u*, arg-max, models/SafeOpt.py:34-66) in C + OpenMP over the WHOLE grid, best of the
@@ -96,21 +100,24 @@ def cpu_baseline(cfg, count, sample):
         from oracle import omp
         omp.safeopt_sweep(lo, hi, count, cfg["ds"], cfg["b"], n=min(total, 1 << 16))        # build + warm the thread pool
         best = None
+        done = total if prefix is None else min(int(prefix), total)
         for th in sorted({min(visible, t) for t in (16, 32, 64, 128)}):
             omp.set_threads(th)
             t0 = time.perf_counter()
-            r = omp.safeopt_sweep(lo, hi, count, cfg["ds"], cfg["b"])
+            r = omp.safeopt_sweep(lo, hi, count, cfg["ds"], cfg["b"], n=done) if done < total else omp.safeopt_sweep(lo, hi, count, cfg["ds"], cfg["b"])
             dt = time.perf_counter() - t0
-            if best is None or total / dt > best[0]:
-                best = (total / dt, th, dt, r)
+            if best is None or done / dt > best[0]:
+                best = (done / dt, th, dt, r)
         rate, th, dt, r = best
         out = {"value": rate, "unit": "candidates/s", "cores": th, "kind": "port",
-               "sample": f"all {total} candidates of the same grid: posterior + bounds + S/U/M masks + u* + arg-max in C + OpenMP "
+               "sample": (f"all {total}" if done == total else f"the first {done} of the {total}") + " candidates of the same grid: posterior + bounds + S/U/M masks + u* + arg-max in C + OpenMP "
                          f"(oracle/c/sweep_omp.c, {th} threads -- the best of 16/32/64/128 --, {visible} cores visible), {dt:.2f} s; "
                          f"|S| = {r['count_S']}, minimiser {r['minimizer_index']}; the quadratic brute-force expander is excluded"}
     except Exception as e:           # (no compiler on the box and no prebuilt library: the NumPy column alone)
         print(f"[bench] C + OpenMP CPU column unavailable ({type(e).__name__}: {e}); reporting the NumPy oracle only", file=sys.stderr)
     sample = min(sample, total)
+    if sample <= 0 and out is not None:
+        return out
     pts = oracle.grid_points(lo, hi, count, first=0, n=sample)
     oracle.gp_inference(pts[:4096], cfg["ds"])           # warm the BLAS threads
     t0 = time.perf_counter()
@@ -137,6 +144,42 @@ def cpu_baseline(cfg, count, sample):
         return {**rec, "kind": "port", "sample": rec["sample"] + "; posterior + bounds + S/U/M masks + u* + arg-max, expander excluded"}
     out["numpy"] = rec
     return out
+
+
+def result_record(res, kind):
+    """What a sweep returned, with the guard-band bookkeeping of the approximating posteriors (K1b / K1t): `guard_band` =
+    decisions that fell inside the band of the posterior's measured deviation on the fast path (0: every mask byte and index is
+    the exact evaluator's, unconditionally), `guard_rechecks` = candidates re-evaluated with the exact formula when it was not."""
+    if kind == "safeopt":
+        out = {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
+               "minimizer_index": res["minimizer_index"], "expander_index": res["expander_index"],
+               "expander_index_c": [int(x) for x in res["expander_index_c"]]}
+    else:
+        out = {"count_S": res["count_S"], "count_O": [int(x) for x in res["count_O"]], "safe_min_index": res["safe_min_index"],
+               "target_index": res["target_index"], "explore_index": res["explore_index"]}
+    out.update({"exact_rechecks": res["n_exact_rechecks"], "guard_band": int(res["guard_band"]), "guard_rechecks": int(res["guard_rechecks"]),
+                "guard_passes": int(res["guard_passes"])})
+    return out
+
+
+def table_kernel_record(eng, cfg, step, kind, res, kernel_name, n_total, barrier, steps=5):
+    """The same resident-model sweep with the exact O(n^2)-per-candidate separable-table kernel K1g, same process, and whether
+    the two posteriors' sweeps AGREE: every count and every index of the result records must be equal."""
+    opt = "bilinear" if kernel_name.startswith("k_bpost") else "tensor_cheb"
+    eng.set_option(opt, 0)
+    el_t, rows_t, res_t = timed_resident(eng, step, steps, 1, barrier)
+    eng.set_option(opt, 1)
+    rt, _ = mfma_roofline(cfg, rows_t, n_total)
+    a, b_ = result_record(res, kind), result_record(res_t, kind)
+    keys = [k for k in a if not k.startswith("guard_") and k != "exact_rechecks"]
+    diff = [k for k in keys if a[k] != b_[k]]
+    return {"kernel": "k_posterior_grid", "device_ms_per_step": rt["device_ms_per_step"], "kernel_ms": rt["kernel_ms"],
+            "value": n_total * steps / el_t, "unit": "candidates/s", "achieved": rt["algorithmic"]["achieved"],
+            "frac": rt["algorithmic"]["frac"], "frac_definition": "SURVEY.md 8(d) algorithmic flops / kernel time / peak",
+            "agreement": {"verdict": "identical" if not diff else "DIFFERENT: " + ", ".join(diff), "compared": keys,
+                          "table_kernel_result": {k: b_[k] for k in keys},
+                          "note": "counts (|S|, |M|, |G_i| or |O_i|) and indices of this config's sweep with " + kernel_name.split(" ")[0]
+                                  + " against the exact table kernel's, same model and grid, same run"}}
 
 
 def sweep_fn(eng, kind, b):
@@ -308,20 +351,8 @@ def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None, group=N
         out["iteration"] = it
     if table_kernel and (mf["kernel"].startswith("k_bpost") or mf["kernel"].startswith("k_t_final")):
         # the same sweep with the separable-table kernel (the O(n^2)-per-candidate contraction on MFMA), same run
-        opt = "bilinear" if mf["kernel"].startswith("k_bpost") else "tensor_cheb"
-        eng.set_option(opt, 0)
-        el_t, rows_t, _ = timed_resident(eng, step, 5, 2, barrier)
-        eng.set_option(opt, 1)
-        rt, _ = mfma_roofline(cfg, rows_t, n_total)
-        out["table_kernel"] = {"kernel": "k_posterior_grid", "device_ms_per_step": rt["device_ms_per_step"], "kernel_ms": rt["kernel_ms"],
-                               "value": n_total * 5 / el_t, "unit": "candidates/s", "achieved": rt["algorithmic"]["achieved"],
-                               "frac": rt["algorithmic"]["frac"], "frac_definition": "SURVEY.md 8(d) algorithmic flops / kernel time / peak"}
-    if kind == "safeopt":
-        out["result"] = {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
-                         "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}
-    else:
-        out["result"] = {"count_S": res["count_S"], "count_O": [int(x) for x in res["count_O"]], "safe_min_index": res["safe_min_index"],
-                         "target_index": res["target_index"], "explore_index": res["explore_index"], "exact_rechecks": res["n_exact_rechecks"]}
+        out["table_kernel"] = table_kernel_record(eng, cfg, step, kind, res, mf["kernel"], n_total, barrier, steps=5 if n_total <= 1 << 23 else 3)
+    out["result"] = result_record(res, kind)
     return out
 
 
@@ -409,12 +440,7 @@ def main():
                 roof["traffic"] = rec["hbm_bytes_per_launch"]
                 roof["traffic_source"] = (f"OFFLINE: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                                           f"profiles/pmc_traffic.json[{key}] ({rec.get('kernel')}; collected {rec.get('collected', 'round 1')})")
-        if args.sweep == "safeopt":
-            result = {"count_S": res["count_S"], "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]],
-                      "minimizer_index": res["minimizer_index"], "exact_rechecks": res["n_exact_rechecks"]}
-        else:
-            result = {"count_S": res["count_S"], "count_O": [int(x) for x in res["count_O"]], "target_index": res["target_index"],
-                      "explore_index": res["explore_index"], "exact_rechecks": res["n_exact_rechecks"]}
+        result = result_record(res, args.sweep)
         out = {
             "metric": "candidate-points/sec, SafeOpt posterior+safe-set sweep",
             "value": n_total * args.steps / elapsed, "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -437,8 +463,11 @@ def main():
             it["value"] = n_total / (it["ms_per_step"] * 1e-3)
             it["unit"] = "candidates/s"
             out["iteration"] = it
+            out["config"]["iteration_ms"] = it["ms_per_step"]        # (one iteration of the reference loop: new model + tables + sweep)
             if k1_kind == 4:
                 roof["table_build_ms"] = it["table_build_ms"]
+            if k1_kind in (4, 5) and default_run:
+                out["table_kernel"] = table_kernel_record(eng, cfg, step, args.sweep, res, roof["kernel"], n_total, barrier, steps=3)
         if extras and default_run:
             # every other BASELINE.json config on this one GPU: B (configs[1], with its K1g figure), C (the Williams-Otto plant: GoOSE
             # and SafeOpt), D (the whole 128^4 grid of the 8-GPU config: Chebyshev-node interpolation K1t, with its K1g figure), E (10^7 scattered fp32 points)
@@ -448,11 +477,16 @@ def main():
                             extra_record(eng, *extra_cfgs["D"], "D", "safeopt", 10, barrier, table_kernel=True),
                             extra_record(eng, extra_cfgs["E"][0], None, "E", "safeopt", 3, barrier, points=10_000_000)]
         if world == 1 and args.cpu_sample > 0 and not scattered:
-            # (a bounded sample of CPU work: config B's grid -- a quarter of H's candidates at a sixteenth of its flops per candidate)
-            ccfg = extra_cfgs["B"][0] if "B" in extra_cfgs else cfg
-            ccount = list(ccfg["count"])
-            out["cpu_baseline"] = cpu_baseline(ccfg, ccount, args.cpu_sample)
-            out["cpu_baseline"]["config"] = f"config {'B' if 'B' in extra_cfgs else args.config}: n={ccfg['n']}, grid {'x'.join(map(str, ccount))}"
+            # the workload of `value` itself: a prefix of this config's grid (a bounded sample -- H whole would be minutes of CPU
+            # work: n = 512 costs 16 x config B's flops per candidate), and beside it config B's whole grid as in earlier rounds
+            whole = n_total <= 1 << 22
+            out["cpu_baseline"] = cpu_baseline(cfg, count, min(args.cpu_sample, 1 << 18 if not whole else args.cpu_sample),
+                                               prefix=None if whole else max(1 << 20, min(args.cpu_sample, 1 << 21)))
+            out["cpu_baseline"]["config"] = f"config {args.config}: n={cfg['n']}, grid {'x'.join(map(str, count))}"
+            if "B" in extra_cfgs and args.config != "B":
+                bc = extra_cfgs["B"][0]
+                out["cpu_baseline"]["config_B"] = cpu_baseline(bc, list(bc["count"]), 0)
+                out["cpu_baseline"]["config_B"]["config"] = f"config B: n={bc['n']}, grid {'x'.join(map(str, bc['count']))}"
         print(json.dumps(out))
     if group is not None:
         group.barrier()

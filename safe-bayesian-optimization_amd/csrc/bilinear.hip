@@ -1689,7 +1689,7 @@ __global__ __launch_bounds__(256) void k_gb_probe_k1b(const ModelConst mc, const
 // L_i = max over the grid of ||grad MEAN_i||_inf (models/SafeOpt.py:68-83) took two of k_bpost's four GEMM phases on EVERY tile
 // -- ~90 of its 257 us on config H -- for two scalars per output.  The gradient sums are polynomials of the axes' Chebyshev
 // variables (degree <= rc per axis, the degree of the bases), so:
-//   (1) k_bl_gradbound, per plan: the Chebyshev coefficients C[a][b] of g_0 = f_1 - xn0 f_0 and g_1 = f_2 - xn1 f_0 (f_b the
+//   (1) k_bl_gradw / k_bl_gradrow / k_bl_gradslack, per plan: the Chebyshev coefficients C[a][b] of g_0 = f_1 - xn0 f_0 and g_1 = f_2 - xn1 f_0 (f_b the
 //       three bilinear forms of the mean phases) and from them sum |C| a^2, sum |C| b^2 >= max |dg / dxi| (|T_a'| <= a^2) -> a
 //       bound `slack` on how far |g| can move over half a sampling cell;
 //   (2) k_bl_gradcoarse, per plan: g at the centres of kGradStep x kGradStep cells of the grid (direct sums over the rank,
@@ -1698,105 +1698,131 @@ __global__ __launch_bounds__(256) void k_gb_probe_k1b(const ModelConst mc, const
 //       other tile can hold the maximum.  The key is still the maximum of the FINE-grid values of phases 2 / 3 (on those tiles),
 //       i.e. the same number as before, to the last bit.  Config H: ~1-7 % of the tiles qualify.
 constexpr int kGradStep = 8;
-// coefficient bounds: one workgroup per output.  W_b[p][c1] = sum_s Mb_b[p][s] sig1_s Vs1[s][c1] (scratch), then entry (a, c1) of
-// C_b = sum_p sig0_p Vs0[p][a] W_b[p][c1]; the product with xn = mid + half xi by xi T_a = (T_{a+1} + T_|a-1|) / 2.
-__global__ __launch_bounds__(256) void k_bl_gradbound(const BlDims dm, const double* __restrict__ Vsall, const double* __restrict__ sigall,
-                                                      const double* __restrict__ Mball, double* __restrict__ Wscr /* [q][3][kBlMaxR][kBlMaxRc] */,
-                                                      double dxi0, double dxi1 /* half a sampling cell in xi units */,
-                                                      double* __restrict__ slack /* [q][2] */) {
-  __shared__ double red[4][4];
-  const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = dm.r0[o], r1 = dm.r1[o], rc0 = dm.rc0[o], rc1 = dm.rc1[o];
-  const double* Vs0 = Vsall + (size_t)(2 * o) * kBlMaxR * kBlMaxRc;
+// coefficient bounds in three small launches (one workgroup per output took 0.21 ms of the plan build):
+//   k_bl_gradw      W_b[p][c1] = sum_s Mb_b[p][s] sig1_s Vs1[s][c1]                       grid (3 r0u, q), a thread per c1
+//   k_bl_gradrow    row a of the coefficient matrices C_b[a][c1] = sum_p sig0_p Vs0[p][a] W_b[p][c1] (C_0 also for a - 1, a + 1),
+//                   the products with xn = mid + half xi by  xi T_0 = T_1, xi T_k = (T_{k+1} + T_{k-1}) / 2,  and the row's part
+//                   of sum |C| a^2, sum |C| c1^2 for both gradient components                 grid (rc0m + 1, q)
+//   k_bl_gradslack  the rows' parts summed in a fixed order -> slack[o][component]            grid (q)
+__global__ __launch_bounds__(128) void k_bl_gradw(const BlDims dm, const double* __restrict__ Vsall, const double* __restrict__ sigall,
+                                                  const double* __restrict__ Mball, double* __restrict__ Wscr /* [q][3][kBlMaxR][kBlMaxRc] */) {
+  const int o = blockIdx.y, b = blockIdx.x / dm.r0u, p = blockIdx.x % dm.r0u, c1 = threadIdx.x;
+  const int r0 = dm.r0[o], r1 = dm.r1[o], rc1 = dm.rc1[o];
+  if (p >= r0 || c1 >= rc1) return;
   const double* Vs1 = Vsall + (size_t)(2 * o + 1) * kBlMaxR * kBlMaxRc;
-  const double* sig0 = sigall + (size_t)(2 * o) * kBlMaxR;
   const double* sig1 = sigall + (size_t)(2 * o + 1) * kBlMaxR;
-  const double* Mb = Mball + (size_t)o * 3 * dm.r0u * dm.r1u;
-  double* W = Wscr + (size_t)o * 3 * kBlMaxR * kBlMaxRc;
-  for (int e = tid; e < 3 * r0 * rc1; e += blockDim.x) {
-    const int c1 = e % rc1, p = (e / rc1) % r0, b = e / (rc1 * r0);
-    double s = 0.0;
-    for (int s_ = 0; s_ < r1; ++s_) s += Mb[((size_t)b * r0 + p) * r1 + s_] * (sig1[s_] * Vs1[(size_t)s_ * rc1 + c1]);
-    W[((size_t)b * kBlMaxR + p) * kBlMaxRc + c1] = s;
-  }
-  __syncthreads();
-  auto Cb = [&](int b, int a, int c1) {          // coefficient (a, c1) of f_b; zero outside the degrees
-    if (a < 0 || a >= rc0) return 0.0;
-    double s = 0.0;
-    for (int p = 0; p < r0; ++p) s += (sig0[p] * Vs0[(size_t)p * rc0 + a]) * W[((size_t)b * kBlMaxR + p) * kBlMaxRc + c1];
-    return s;
-  };
-  const double mid0 = 0.5 * (dm.a[0] + dm.b[0]), half0 = 0.5 * (dm.b[0] - dm.a[0]);
-  const double mid1 = 0.5 * (dm.a[1] + dm.b[1]), half1 = 0.5 * (dm.b[1] - dm.a[1]);
-  double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;       // [component][axis]: sum |C| deg^2
-  // component 0: g_0 = f_1 - (mid0 + half0 xi0) f_0, degree rc0 in xi0; component 1: g_1 = f_2 - (mid1 + half1 xi1) f_0
-  for (int e = tid; e < (rc0 + 1) * (rc1 + 1); e += blockDim.x) {
-    const int a = e / (rc1 + 1), c1 = e % (rc1 + 1);
-    // xi F, F = sum C_a T_a:  xi T_0 = T_1, xi T_k = (T_{k+1} + T_{k-1}) / 2  ->  D_0 = C_1 / 2, D_1 = C_0 + C_2 / 2, D_a = (C_{a-1} + C_{a+1}) / 2
-    auto xi_shift0 = [&](int aa, int cc) {
-      if (cc >= rc1) return 0.0;
-      double v = 0.5 * Cb(0, aa + 1, cc);
-      if (aa == 1) v += Cb(0, 0, cc);
-      else if (aa >= 2) v += 0.5 * Cb(0, aa - 1, cc);
-      return v;
-    };
-    const double g0c = (c1 < rc1 ? Cb(1, a, c1) - mid0 * Cb(0, a, c1) : 0.0) - half0 * xi_shift0(a, c1);
-    // xi1 f_0: the same shift along the second index
-    double sh1 = 0.0;
-    if (a < rc0) {
-      auto C0 = [&](int cc) { return (cc >= 0 && cc < rc1) ? Cb(0, a, cc) : 0.0; };
-      sh1 = 0.5 * C0(c1 + 1);
-      if (c1 == 1) sh1 += C0(0);
-      else if (c1 >= 2) sh1 += 0.5 * C0(c1 - 1);
+  const double* Mb = Mball + (size_t)o * 3 * dm.r0u * dm.r1u + ((size_t)b * r0 + p) * r1;
+  double s = 0.0;
+  for (int s_ = 0; s_ < r1; ++s_) s += Mb[s_] * (sig1[s_] * Vs1[(size_t)s_ * rc1 + c1]);
+  Wscr[(((size_t)o * 3 + b) * kBlMaxR + p) * kBlMaxRc + c1] = s;
+}
+__global__ __launch_bounds__(256) void k_bl_gradrow(const BlDims dm, const double* __restrict__ Vsall, const double* __restrict__ sigall,
+                                                    const double* __restrict__ Wscr, double* __restrict__ part /* [q][gridDim.x][4] */) {
+  __shared__ double c0row[kBlMaxRc + 3];                 // C_0[a][-1 .. rc1 + 1] (zero outside the degrees)
+  __shared__ double red[4][4];
+  const int o = blockIdx.y, a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c1 = tid;
+  const int r0 = dm.r0[o], rc0 = dm.rc0[o], rc1 = dm.rc1[o];
+  double b00 = 0.0, b01 = 0.0, b10 = 0.0, b11 = 0.0;       // [component][axis]: |coefficient| degree^2
+  const bool row = a <= rc0;                               // (uniform: the products with xi reach one degree further)
+  if (row) {
+    const double* Vs0 = Vsall + (size_t)(2 * o) * kBlMaxR * kBlMaxRc;
+    const double* sig0 = sigall + (size_t)(2 * o) * kBlMaxR;
+    const double* W = Wscr + (size_t)o * 3 * kBlMaxR * kBlMaxRc;
+    // C_0 at rows a - 1, a, a + 1, C_1 and C_2 at row a, column c1 of this thread
+    double c0m = 0.0, c0 = 0.0, c0p = 0.0, c1v = 0.0, c2v = 0.0;
+    if (c1 < rc1)
+      for (int p = 0; p < r0; ++p) {
+        const double w0 = W[((size_t)0 * kBlMaxR + p) * kBlMaxRc + c1], w1 = W[((size_t)1 * kBlMaxR + p) * kBlMaxRc + c1],
+                     w2 = W[((size_t)2 * kBlMaxR + p) * kBlMaxRc + c1];
+        const double* v = Vs0 + (size_t)p * rc0;
+        const double sg = sig0[p];
+        const double am = a >= 1 ? sg * v[a - 1] : 0.0, aa = a < rc0 ? sg * v[a] : 0.0, ap = a + 1 < rc0 ? sg * v[a + 1] : 0.0;
+        c0m += am * w0;
+        c0 += aa * w0;
+        c0p += ap * w0;
+        c1v += aa * w1;
+        c2v += aa * w2;
+      }
+    if (c1 <= rc1 + 2) c0row[c1] = 0.0;
+    __syncthreads();
+    if (c1 < rc1) c0row[c1 + 1] = c0;
+    __syncthreads();
+    if (c1 <= rc1) {
+      const double mid0 = 0.5 * (dm.a[0] + dm.b[0]), half0 = 0.5 * (dm.b[0] - dm.a[0]);
+      const double mid1 = 0.5 * (dm.a[1] + dm.b[1]), half1 = 0.5 * (dm.b[1] - dm.a[1]);
+      // (xi F)_a along the first index: D_0 = C_1 / 2, D_1 = C_0 + C_2 / 2, D_a = (C_{a-1} + C_{a+1}) / 2
+      const double sh0 = a == 0 ? 0.5 * c0p : (a == 1 ? c0m + 0.5 * c0p : 0.5 * (c0m + c0p));
+      const double lo = c0row[c1], hi = c0row[c1 + 2];     // C_0[a][c1 - 1], C_0[a][c1 + 1]
+      const double sh1 = c1 == 0 ? 0.5 * hi : (c1 == 1 ? lo + 0.5 * hi : 0.5 * (lo + hi));
+      const double g0c = c1v - mid0 * c0 - half0 * sh0;    // coefficient (a, c1) of g_0 = f_1 - xn0 f_0
+      const double g1c = c2v - mid1 * c0 - half1 * sh1;    //                     of g_1 = f_2 - xn1 f_0
+      const double a2 = (double)a * a, c2 = (double)c1 * c1;
+      b00 = fabs(g0c) * a2;
+      b01 = fabs(g0c) * c2;
+      b10 = fabs(g1c) * a2;
+      b11 = fabs(g1c) * c2;
     }
-    const double g1c = ((a < rc0 && c1 < rc1) ? Cb(2, a, c1) - mid1 * Cb(0, a, c1) : 0.0) - half1 * sh1;
-    const double a2 = (double)a * a, c2 = (double)c1 * c1;
-    b00 += fabs(g0c) * a2;
-    b01 += fabs(g0c) * c2;
-    b10 += fabs(g1c) * a2;
-    b11 += fabs(g1c) * c2;
   }
   b00 = wave_sum(b00); b01 = wave_sum(b01); b10 = wave_sum(b10); b11 = wave_sum(b11);
   if (lane == 0) { red[wave][0] = b00; red[wave][1] = b01; red[wave][2] = b10; red[wave][3] = b11; }
   __syncthreads();
-  if (tid == 0) {
-    double s[4];
-    for (int k = 0; k < 4; ++k) s[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-    // |g| moves by at most max |dg/dxi0| dxi0 + max |dg/dxi1| dxi1 between a candidate and the centre of its sampling cell
-    slack[2 * o + 0] = (s[0] * dxi0 + s[1] * dxi1) * (1.0 + 1e-9);
-    slack[2 * o + 1] = (s[2] * dxi0 + s[3] * dxi1) * (1.0 + 1e-9);
-  }
+  if (tid < 4) part[((size_t)o * gridDim.x + a) * 4 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
-// the gradient sums at the cell centres of one k_bpost tile (TL lines x 128 positions): a workgroup per (tile, output);
+__global__ __launch_bounds__(64) void k_bl_gradslack(const double* __restrict__ part, int rows, double dxi0, double dxi1 /* half a sampling cell
+                                                     in xi units */, double* __restrict__ slack /* [q][2] */) {
+  const int o = blockIdx.x, k = threadIdx.x;
+  if (k >= 4) return;
+  double s = 0.0;
+  for (int a = 0; a < rows; ++a) s += part[((size_t)o * rows + a) * 4 + k];
+  // |g| moves by at most max |dg/dxi0| dxi0 + max |dg/dxi1| dxi1 between a candidate and the sample of its cell
+  const double t = s * ((k & 1) ? dxi1 : dxi0);
+  const double other = __shfl_xor(t, 1);
+  if ((k & 1) == 0) slack[2 * o + (k >> 1)] = (t + other) * (1.0 + 1e-9);
+}
+// the gradient sums at the cell centres of one k_bpost tile (TL lines x 128 positions): a workgroup per (tile, output); the
+// tile's columns of S0 and lines of Vb go through LDS (read straight from memory, strided by the cell: 0.11 ms on config H).
 // tmax[(o 2 + comp) ntiles + tile] = the tile's largest |g_comp| sample, gkey[o 2 + comp] = the grid's (bit pattern: values >= 0)
-__global__ __launch_bounds__(256) void k_bl_gradcoarse(const BlDims dm, const double* __restrict__ S0all, const double* __restrict__ Vball,
-                                                       const double* __restrict__ xn0, const double* __restrict__ xn1, int TL, int ntx,
+constexpr int kGradTL = 64, kGradNpx = 128 / kGradStep, kGradNpl = kGradTL / kGradStep;
+__global__ __launch_bounds__(128) void k_bl_gradcoarse(const BlDims dm, const double* __restrict__ S0all, const double* __restrict__ Vball,
+                                                       const double* __restrict__ xn0, const double* __restrict__ xn1, int ntx,
                                                        double* __restrict__ tmax, unsigned long long* __restrict__ gkey) {
-  __shared__ double red[4][2];
+  __shared__ double sS[kBlMaxR][kGradNpx];
+  __shared__ double sV[3][kBlMaxR][kGradNpl];
+  __shared__ double red[2][2];
   const int o = blockIdx.y, tile = blockIdx.x, bx = tile % ntx, by = tile / ntx;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = dm.r0[o];
   const double* S0 = S0all + (size_t)o * dm.r0u * dm.cnt0;
   const double* Vb = Vball + (size_t)o * 3 * dm.r0u * dm.nlines;
-  const int npx = 128 / kGradStep, npl = TL / kGradStep;
+  // the centre of the cell, or the last candidate of a cell the grid ends in: every candidate within kGradStep / 2 of a sample
+  auto xs = [&](int i) { const long long x = (long long)bx * 128 + i * kGradStep; return x >= dm.cnt0 ? -1ll : (x + kGradStep / 2 < dm.cnt0 ? x + kGradStep / 2 : dm.cnt0 - 1); };
+  auto ls = [&](int j) { const long long l = (long long)by * kGradTL + j * kGradStep; return l >= dm.nlines ? -1ll : (l + kGradStep / 2 < dm.nlines ? l + kGradStep / 2 : dm.nlines - 1); };
+  for (int e = tid; e < r0 * kGradNpx; e += blockDim.x) {
+    const int p = e / kGradNpx, i = e % kGradNpx;
+    const long long x = xs(i);
+    sS[p][i] = x >= 0 ? S0[(size_t)p * dm.cnt0 + x] : 0.0;
+  }
+  for (int e = tid; e < 3 * r0 * kGradNpl; e += blockDim.x) {
+    const int j = e % kGradNpl, p = (e / kGradNpl) % r0, b = e / (kGradNpl * r0);
+    const long long l = ls(j);
+    sV[b][p][j] = l >= 0 ? Vb[((size_t)b * dm.r0u + p) * dm.nlines + l] : 0.0;
+  }
+  __syncthreads();
   double m0 = 0.0, m1 = 0.0;
-  for (int e = tid; e < npx * npl; e += blockDim.x) {
-    // the centre of the cell, or the last candidate of a cell the grid ends in: every candidate within kGradStep / 2 of a sample
-    long long x0 = (long long)bx * 128 + (e % npx) * kGradStep, l = (long long)by * TL + (e / npx) * kGradStep;
-    if (x0 >= dm.cnt0 || l >= dm.nlines) continue;
-    x0 = x0 + kGradStep / 2 < dm.cnt0 ? x0 + kGradStep / 2 : dm.cnt0 - 1;
-    l = l + kGradStep / 2 < dm.nlines ? l + kGradStep / 2 : dm.nlines - 1;
-    const double x0n = xn0[x0], x1n = xn1[l];
-    double g0 = 0.0, g1 = 0.0;
-    for (int p = 0; p < r0; ++p) {
-      const double s0 = S0[(size_t)p * dm.cnt0 + x0];
-      const double v0 = Vb[((size_t)0 * dm.r0u + p) * dm.nlines + l], v1 = Vb[((size_t)1 * dm.r0u + p) * dm.nlines + l],
-                   v2 = Vb[((size_t)2 * dm.r0u + p) * dm.nlines + l];
-      g0 = fma(v1 - x0n * v0, s0, g0);
-      g1 = fma(v2 - x1n * v0, s0, g1);
+  {
+    const int i = tid % kGradNpx, j = tid / kGradNpx;      // 16 x 8 samples: one per thread
+    const long long x = xs(i), l = ls(j);
+    if (x >= 0 && l >= 0) {
+      const double x0n = xn0[x], x1n = xn1[l];
+      double g0 = 0.0, g1 = 0.0;
+      for (int p = 0; p < r0; ++p) {
+        const double s0 = sS[p][i], v0 = sV[0][p][j];
+        g0 = fma(sV[1][p][j] - x0n * v0, s0, g0);
+        g1 = fma(sV[2][p][j] - x1n * v0, s0, g1);
+      }
+      m0 = fabs(g0);
+      m1 = fabs(g1);
     }
-    m0 = fmax(m0, fabs(g0));
-    m1 = fmax(m1, fabs(g1));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -1806,12 +1832,15 @@ __global__ __launch_bounds__(256) void k_bl_gradcoarse(const BlDims dm, const do
   if (lane == 0) { red[wave][0] = m0; red[wave][1] = m1; }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w) { m0 = fmax(m0, red[w][0]); m1 = fmax(m1, red[w][1]); }
+    m0 = fmax(m0, red[1][0]);
+    m1 = fmax(m1, red[1][1]);
     const size_t nt = (size_t)gridDim.x;
     tmax[((size_t)o * 2 + 0) * nt + tile] = m0;
     tmax[((size_t)o * 2 + 1) * nt + tile] = m1;
-    atomicMax(&gkey[2 * o + 0], (unsigned long long)__double_as_longlong(m0));
-    atomicMax(&gkey[2 * o + 1], (unsigned long long)__double_as_longlong(m1));
+    // (4096 workgroups on four addresses: the atomics queued up in L2 for 0.1 ms; a tile below the maximum so far only reads)
+    const unsigned long long k0 = (unsigned long long)__double_as_longlong(m0), k1 = (unsigned long long)__double_as_longlong(m1);
+    if (k0 > __hip_atomic_load(&gkey[2 * o + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gkey[2 * o + 0], k0);
+    if (k1 > __hip_atomic_load(&gkey[2 * o + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gkey[2 * o + 1], k1);
   }
 }
 
@@ -2083,10 +2112,11 @@ int bilinear_setup(sbo_ctx* c) {
   pl.gtmax = nullptr;
   pl.gkey = nullptr;
   {
-    constexpr int TL = 64;                                   // lines of a k_bpost<1> tile
+    static_assert(kGradNpx * kGradNpl == 128, "k_bl_gradcoarse: one sample per thread");
     const int ntx = (ncs0 + 7) / 8, nty = (nrb + 3) / 4;
     const size_t nt = (size_t)ntx * nty, head = (size_t)q * 2 * nt + 4 * (size_t)q;
-    if ((rc = ensure(c->bl_grad, sizeof(double) * (head + (size_t)q * 3 * kBlMaxR * kBlMaxRc)))) return rc;
+    const int rows = std::max(rc0m, 1) + 1;                  // coefficient rows 0 .. largest degree + 1
+    if ((rc = ensure(c->bl_grad, sizeof(double) * (head + (size_t)q * (3 * kBlMaxR * kBlMaxRc + 4 * (size_t)rows))))) return rc;
     double* gt = (double*)c->bl_grad.p;
     double* slack = gt + (size_t)q * 2 * nt;
     unsigned long long* gkey = (unsigned long long*)(slack + 2 * q);
@@ -2095,9 +2125,13 @@ int bilinear_setup(sbo_ctx* c) {
     const double dxi0 = cs.count[0] > 1 ? 0.5 * kGradStep * std::fabs(cs.step[0] / mc.X_std[0]) / half0 : 0.0;
     const double dxi1 = cs.count[1] > 1 ? 0.5 * kGradStep * std::fabs(cs.step[1] / mc.X_std[1]) / half1 : 0.0;
     SBO_HIP(hipMemsetAsync(gkey, 0, sizeof(unsigned long long) * 2 * q, ys));
-    hipLaunchKernelGGL(k_bl_gradbound, dim3(uq), dim3(256), 0, ys, dm, dVs, dsig, (const double*)dMb, (double*)(gkey + 2 * q), dxi0, dxi1, slack);
-    hipLaunchKernelGGL(k_bl_gradcoarse, dim3((unsigned)nt, uq), dim3(256), 0, ys, dm, (const double*)dS0, (const double*)dVb, (const double*)dxn0,
-                       (const double*)dxn1, TL, ntx, gt, gkey);
+    double* Wscr = (double*)(gkey + 2 * q);
+    double* part = Wscr + (size_t)q * 3 * kBlMaxR * kBlMaxRc;
+    hipLaunchKernelGGL(k_bl_gradw, dim3((unsigned)(3 * r0u), uq), dim3(128), 0, ys, dm, dVs, dsig, (const double*)dMb, Wscr);
+    hipLaunchKernelGGL(k_bl_gradrow, dim3((unsigned)rows, uq), dim3(256), 0, ys, dm, dVs, dsig, (const double*)Wscr, part);
+    hipLaunchKernelGGL(k_bl_gradslack, dim3(uq), dim3(64), 0, ys, (const double*)part, rows, dxi0, dxi1, slack);
+    hipLaunchKernelGGL(k_bl_gradcoarse, dim3((unsigned)nt, uq), dim3(128), 0, ys, dm, (const double*)dS0, (const double*)dVb, (const double*)dxn0,
+                       (const double*)dxn1, ntx, gt, gkey);
     if (std::isfinite(dxi0) && std::isfinite(dxi1)) {
       pl.gtmax = gt;
       pl.gkey = gkey;

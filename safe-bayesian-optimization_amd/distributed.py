@@ -101,14 +101,21 @@ def job_secret(base_port: int, world: int) -> bytes:
     return hashlib.sha256(raw.encode() + struct.pack("<II", base_port, world)).digest()
 
 
-def rendezvous_port(base_port: int) -> int:
-    """ONE port, known to every rank before anyone connects: SBO_RDZV_PORT, else MASTER_PORT + 1 (MASTER_PORT itself belongs to
-    the launcher's store).  No scanning: a rank never talks to whoever happens to listen nearby."""
-    return int(os.environ.get("SBO_RDZV_PORT", base_port + 1))
+_PORT_WINDOW = 16
+
+
+def rendezvous_ports(base_port: int) -> list:
+    """Where rank 0 listens, known to every rank before anyone connects: exactly SBO_RDZV_PORT when the launcher sets it; else
+    the first port of [MASTER_PORT + 1, MASTER_PORT + 16] that rank 0 can bind (MASTER_PORT itself belongs to the launcher's
+    store; a neighbour in the ephemeral range may be somebody's outgoing connection).  Whoever else listens in that window is
+    harmless: a rank joins only the listener that proves the job's secret (and only struct-framed bytes ever cross)."""
+    if "SBO_RDZV_PORT" in os.environ:
+        return [int(os.environ["SBO_RDZV_PORT"])]
+    return [base_port + k for k in range(1, _PORT_WINDOW + 1)]
 
 
 class TcpGroup:
-    """Star rendezvous over TCP: rank 0 listens on `rendezvous_port`, the others connect to it; each connection is accepted
+    """Star rendezvous over TCP: rank 0 listens on the first free port of `rendezvous_ports`, the others connect to it; each connection is accepted
     only after a challenge-response on the job's secret (HMAC-SHA256 over a fresh nonce, both directions), a rank in
     [1, world) and no rank twice.  Every collective is "send to rank 0, combine there, send back", framed with struct: byte
     strings and NumPy buffers only.  Small payloads: ids, scalars, and the rehearsal relay."""
@@ -118,7 +125,7 @@ class TcpGroup:
             raise ValueError(f"rank {rank} outside a world of {world}")
         self.rank, self.world, self._peers, self._sock = rank, world, [], None
         key = job_secret(base_port, world)
-        port = rendezvous_port(base_port)
+        ports = rendezvous_ports(base_port)
         deadline = time.time() + timeout
         if world == 1:
             return
@@ -127,10 +134,15 @@ class TcpGroup:
             return hmac.new(key, b"".join(parts), hashlib.sha256).digest()
 
         if rank == 0:
-            try:
-                srv = socket.create_server((addr, port), reuse_port=False)
-            except OSError as exc:
-                raise OSError(f"rendezvous port {port} on {addr} is taken ({exc}); set SBO_RDZV_PORT on every rank") from exc
+            srv, why = None, None
+            for port in ports:
+                try:
+                    srv = socket.create_server((addr, port), reuse_port=False)
+                    break
+                except OSError as exc:
+                    why = exc
+            if srv is None:
+                raise OSError(f"no rendezvous port free on {addr} among {ports[0]}..{ports[-1]} ({why}); set SBO_RDZV_PORT on every rank")
             srv.settimeout(0.25)
             peers = {}
             try:
@@ -170,8 +182,11 @@ class TcpGroup:
                 srv.close()
             self._peers = [peers[r] for r in range(1, world)]
         else:
+            attempt = 0
             while self._sock is None:
                 s_ = None
+                port = ports[attempt % len(ports)]
+                attempt += 1
                 try:
                     s_ = socket.create_connection((addr, port), timeout=_HELLO_TIMEOUT)
                     s_.settimeout(_HELLO_TIMEOUT)
@@ -190,8 +205,9 @@ class TcpGroup:
                     if s_ is not None:
                         s_.close()
                     if time.time() > deadline:
-                        raise TimeoutError(f"rendezvous: rank 0 was not reached on {addr}:{port} ({exc})") from exc
-                    time.sleep(0.05)
+                        raise TimeoutError(f"rendezvous: rank 0 was not reached on {addr}:{ports[0]}..{ports[-1]} ({exc})") from exc
+                    if attempt % len(ports) == 0:
+                        time.sleep(0.05)
 
     # -- the five methods a "group" has ----------------------------------------------------------------------------------
     def get_rank(self) -> int:
