@@ -166,6 +166,9 @@ def table_kernel_record(eng, cfg, step, kind, res, kernel_name, n_total, barrier
     """The same resident-model sweep with the exact O(n^2)-per-candidate separable-table kernel K1g, same process, and whether
     the two posteriors' sweeps AGREE: every count and every index of the result records must be equal."""
     opt = "bilinear" if kernel_name.startswith("k_bpost") else "tensor_cheb"
+    # (the iteration record before this one alternated two models: this config's own model again, and a fresh result of it)
+    eng.set_model(cfg["ds"], dtype=cfg["dtype"], use_invK=cfg["dtype"] == "f64")
+    res = step()
     eng.set_option(opt, 0)
     el_t, rows_t, res_t = timed_resident(eng, step, steps, 1, barrier)
     eng.set_option(opt, 1)

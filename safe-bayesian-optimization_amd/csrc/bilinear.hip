@@ -1261,6 +1261,25 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
   post_epilogue<PH, RB>(cx, outp, c0, c1, c2, gmax, acc);
 }
 
+#ifdef SBO_PHASE_CLOCKS
+// Diagnostic build only (make phaseclk -> libsafebo_phaseclk.so, tools/dev_phase_clocks.py): the constant 100 MHz counter at the
+// phase boundaries of every k_bpost workgroup, a row per workgroup (same-address atomics from 4096 workgroups would themselves
+// take 0.1 ms); [4] = gradient phases the workgroup ran.  The host sums the rows.
+constexpr int kPhaseClkRows = 1 << 14;
+__device__ unsigned long long g_phase_clk[kPhaseClkRows][8];
+#define SBO_CLK(i)                                                                                \
+  do {                                                                                           \
+    __syncthreads();                                                                             \
+    if (threadIdx.x == 0) {                                                                      \
+      const unsigned long long now_ = wall_clock64();                                            \
+      g_phase_clk[clk_row_ & (kPhaseClkRows - 1)][i] += now_ - clk_;                             \
+      clk_ = now_;                                                                               \
+    }                                                                                            \
+  } while (0)
+#else
+#define SBO_CLK(i) do { } while (0)
+#endif
+
 // RB: row blocks per wave.  2 = the 128 x 128 tile above; 1 = a 64 x 128 tile for grids whose 128 x 128 tiles would leave
 // CUs without a workgroup (1024 x 1024 x 3 outputs: 192 tiles on 256 CUs) -- half the reuse of a B fragment, twice the
 // workgroups.
@@ -1322,8 +1341,13 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   const double* const A2 = VAo + (size_t)nrb * KBm * 256;
   const double* const B2 = SBo + (size_t)ncs * KBm * 256;
   const double* const A3 = VAo + (size_t)nrb * (KBm + KBm2) * 256;
+#ifdef SBO_PHASE_CLOCKS
+  unsigned long long clk_ = wall_clock64();
+  const unsigned int clk_row_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#endif
   post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, eff ? eff[4 * o] : KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0, pre,
                     VAo, SBo, KBm);
+  SBO_CLK(0);
   // The gradient phases (their maxima are the Lipschitz keys, models/SafeOpt.py:68-83) run on the tiles that can hold the grid's
   // maximum: the tile's largest coarse sample + the plan's bound on what lies between the samples reaches the grid's largest
   // sample (k_bl_gradbound / k_bl_gradcoarse above).  Every tile folds its own samples in (true grid values).  NaN: run.
@@ -1343,10 +1367,12 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   // (the mean phase requests the first operands of whichever phase follows it)
   post_phase<1, RB>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0, pre, run2 ? A2 : A3, run2 ? B2 : SBo,
                     run2 ? KBm2 : KBm);
+  SBO_CLK(1);
   // phase 2 continues on phase 1's sums: only the V1 half (the first KSm k-steps) of the stacked operands is run
   if (run2) post_phase<2, RB>(cx, A2, B2, KBm2, KSm, nullptr, cg0, 0.0, 0.0, gmax, acc, xn0, pre, A3, SBo, KBm);
   if (run3) post_phase<3, RB>(cx, A3, SBo, KBm, KSm, nullptr, cg1, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
   gmax = fmax(gmax, gfold);
+  SBO_CLK(2);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const double other = __shfl_xor(gmax, off);
@@ -1357,7 +1383,29 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   // a row per wave made that merge (one workgroup, 16384 rows of 88 bytes on config H) the longest job of the launch it shares
   post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, fuse, cx.cS, cx.cU, cx.rmax, cx.cB, cx.vminS, Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
                    cpart + ((size_t)blockIdx.y * gridDim.x + blockIdx.x), pcap);
+  SBO_CLK(3);
+#ifdef SBO_PHASE_CLOCKS
+  if (threadIdx.x == 0) {
+    g_phase_clk[clk_row_ & (kPhaseClkRows - 1)][4] += (unsigned long long)((run2 ? 1 : 0) + (run3 ? 1 : 0));
+    g_phase_clk[clk_row_ & (kPhaseClkRows - 1)][5] += 1ull;
+  }
+#endif
 }
+#ifdef SBO_PHASE_CLOCKS
+extern "C" int sbo_debug_phase_clocks(unsigned long long* out /* [8]: sums over the rows */, int reset) {
+  std::vector<unsigned long long> h((size_t)kPhaseClkRows * 8);
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_phase_clk), sizeof(unsigned long long) * h.size()) != hipSuccess) return 1;
+  for (int k = 0; k < 8; ++k) out[k] = 0;
+  for (size_t r = 0; r < (size_t)kPhaseClkRows; ++r)
+    for (int k = 0; k < 8; ++k) out[k] += h[r * 8 + k];
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), h.data(), sizeof(unsigned long long) * h.size()) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+
 
 // Lipschitz keys of a K1b launch: Lmax[o] = max of the per-wave partials (values >= 0, so the bit pattern orders them)
 __global__ __launch_bounds__(256) void k_lmax_reduce(const double* __restrict__ Lpart, int per_out, unsigned long long* __restrict__ Lmax) {
