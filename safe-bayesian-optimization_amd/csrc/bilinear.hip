@@ -2136,10 +2136,40 @@ int bilinear_setup(sbo_ctx* c) {
   // ~0.11 ms on config H), Y = everything made from the axis tables (normalised axes, S0 / S1, their pair tables, the mean
   // phases' operands: eight small launches, ~0.09 ms).  Y runs on the second stream beside X and joins before stage 1.
   hipStream_t xs = c->stream, ys = (c->stream2 && !c->is_shadow) ? c->stream2 : c->stream;
+  // (r04) Z = the guard band's reference values at the probe points (guard.hip: the reference formula itself, 0.12 ms on config
+  // H and independent of everything here): a third stream, or Y -- now also carrying the gradient gate -- becomes the long chain
+  hipStream_t zs = (ys != xs && c->stream3) ? c->stream3 : ys;
   if (ys != xs) {
     SBO_HIP(hipEventRecord(c->ev[7], xs));                 // (alpha, Xn and the bases are in place at this point of the main stream)
     SBO_HIP(hipStreamWaitEvent(ys, c->ev[7], 0));
+    if (zs != ys) SBO_HIP(hipStreamWaitEvent(zs, c->ev[7], 0));
   }
+  // (enqueue order: with a caller's invK the head of the long chain X goes first -- twelve short launches of Y ahead of it cost
+  // X ~60 us of host time; with the library's own factor X starts with a host wait for the factorisation, and Y goes first)
+  hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, xs, dm, dU, nZf, Zf);
+  // G = Z^T invK Z.  With the library's own Cholesky factor (M = L^-1): C = M Z from the packed triangular images, written as
+  // fragments (k = observation) and as images of C^T, then G = C^T C.  With a CALLER's invK (sbo_ctx::invk_img, r03): W =
+  // invK Z with the matrix as given -- the contraction the reference itself performs, models/GP_Safe.py:341-343, no
+  // factorisation of an ill-conditioned inverse in between --, then G^T = W^T Z; k_bl_t4f symmetrises what rounding leaves.
+  if (mc.factor == SBO_FACTOR_INVK && c->chol_async && !c->invk_img_valid && c->invk_w_valid && (rc = model_pack_invk(c))) return rc;
+  const bool direct = mc.factor == SBO_FACTOR_INVK && c->chol_async && c->invk_img_valid;
+  auto x_head = [&]() -> int {
+  if (!direct && (rc = factor_sync(c))) return rc;
+  if (direct) {
+    hipLaunchKernelGGL((k_bgemm<4, 0, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, c->stream,
+                       (const double*)c->invk_img.p, (size_t)mc.npad * mc.npad, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
+    hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
+                       (const double*)CtA, nZf, (const double*)Zf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
+  } else {
+    hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, c->stream,
+                       (const double*)c->Fpk.p, c->fpk_stride, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
+    // G = C^T C  (R x R, row-major)
+    hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
+                       (const double*)CtA, nZf, (const double*)Cf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
+  }
+  return SBO_OK;
+  };
+  if (direct && (rc = x_head())) return rc;
   hipLaunchKernelGGL(k_bl_axes, dim3((unsigned)std::min<long long>((cnt0 + nlines + 255) / 256, 4096)), dim3(256), 0, ys, mc, cs,
                      cnt0, line0, nlines, dxn0, dxn1);
   hipLaunchKernelGGL(k_bl_stab, blocks((size_t)std::max(r0u * cnt0, r1u * nlines), 2 * uq), dim3(256), 0, ys, dm, dVs, dsig,
@@ -2188,28 +2218,10 @@ int bilinear_setup(sbo_ctx* c) {
   // guard band of this plan (guard.hip): the exact evaluator at the probe points runs here, beside the core's GEMM chain
   const bool band = c->guard_band && !c->is_shadow;
   double *gref_m = nullptr, *gref_v = nullptr;
-  if (band && (rc = guard_probe_reference(c, ys, &gref_m, &gref_v))) return rc;
+  if (band && (rc = guard_probe_reference(c, zs, &gref_m, &gref_v))) return rc;
+  if (band && zs != ys) SBO_HIP(hipEventRecord(c->ev_join[6], zs));
   if (ys != xs) SBO_HIP(hipEventRecord(c->ev_join[3], ys));
-  hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, xs, dm, dU, nZf, Zf);
-  // G = Z^T invK Z.  With the library's own Cholesky factor (M = L^-1): C = M Z from the packed triangular images, written as
-  // fragments (k = observation) and as images of C^T, then G = C^T C.  With a CALLER's invK (sbo_ctx::invk_img, r03): W =
-  // invK Z with the matrix as given -- the contraction the reference itself performs, models/GP_Safe.py:341-343, no
-  // factorisation of an ill-conditioned inverse in between --, then G^T = W^T Z; k_bl_t4f symmetrises what rounding leaves.
-  if (mc.factor == SBO_FACTOR_INVK && c->chol_async && !c->invk_img_valid && c->invk_w_valid && (rc = model_pack_invk(c))) return rc;
-  const bool direct = mc.factor == SBO_FACTOR_INVK && c->chol_async && c->invk_img_valid;
-  if (!direct && (rc = factor_sync(c))) return rc;
-  if (direct) {
-    hipLaunchKernelGGL((k_bgemm<4, 0, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, c->stream,
-                       (const double*)c->invk_img.p, (size_t)mc.npad * mc.npad, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
-    hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
-                       (const double*)CtA, nZf, (const double*)Zf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
-  } else {
-    hipLaunchKernelGGL((k_bgemm<4, 1, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, c->stream,
-                       (const double*)c->Fpk.p, c->fpk_stride, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
-    // G = C^T C  (R x R, row-major)
-    hipLaunchKernelGGL((k_bgemm<4, 0, 2>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((ncsR + 3) / 4), uq), dim3(256), 0, c->stream,
-                       (const double*)CtA, nZf, (const double*)Cf, nZf, KBn, ncsR, ncsR, G, ldg * ldg, (double*)nullptr, (long long)ldg);
-  }
+  if (!direct && (rc = x_head())) return rc;
   {
     double* PC0 = (double*)c->bl_cheb.p;
     double* PC1 = PC0 + (size_t)q * nPC0;
@@ -2238,6 +2250,7 @@ int bilinear_setup(sbo_ctx* c) {
     pl.eff = eff;
   }
   if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
+  if (band && zs != ys) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[6], 0));
   if (band) {
     // ... K1b's own values at the probes from the tables just made, and the band from the deviations: in place before the
     // plan's first posterior launch, whose fused classification reads it
