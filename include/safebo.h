@@ -170,6 +170,9 @@ typedef struct sbo_profile {
   /* guard band of the posterior kernel that ran last (un-normalised units; zero for the exact kernels K1 / K1c / K1g)             */
   double guard_dm[SBO_MAX_Q], guard_dv[SBO_MAX_Q], guard_rl[SBO_MAX_Q];   /* |mean - exact|, |var - exact|, relative band of L       */
   double guard_ms;               /* device + host time of the last sweep's re-evaluation (0: none was needed)                      */
+  int32_t halo_reruns;           /* multi-rank: set phases run again because SOME rank's speculative halo window was too narrow
+                                    (the decision is global; host_syncs / comm_* include the discarded pass)                        */
+  int32_t reserved_p;
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */

@@ -73,7 +73,7 @@ class Profile(C.Structure):
         ("fp64_rechecks", C.c_int64), ("recheck_ms", C.c_double),
         ("set_phase_ms", C.c_double), ("host_syncs", C.c_int32), ("comm_calls", C.c_int32), ("comm_bytes", C.c_int64),
         ("guard_dm", C.c_double * SBO_MAX_Q), ("guard_dv", C.c_double * SBO_MAX_Q), ("guard_rl", C.c_double * SBO_MAX_Q),
-        ("guard_ms", C.c_double),
+        ("guard_ms", C.c_double), ("halo_reruns", C.c_int32), ("reserved_p", C.c_int32),
     ]
 
 

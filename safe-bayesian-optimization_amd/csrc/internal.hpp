@@ -212,6 +212,8 @@ struct sbo_ctx {
   // gathered (SweepScalars::halo_short) and a short guess reruns the set phase the waiting way.  -1: no guess yet.
   long long halo_guess[SBO_MAX_Q] = {-1, -1, -1, -1, -1, -1, -1, -1};
   int halo_spec = 1;
+  int halo_reruns = 0;            // set phases of the current sweep call discarded for a short window (global decision)
+  bool in_halo_rerun = false;
   bool c1_pending = false;                // the read-back of h_c1 has been enqueued (event ev[5]) but not yet waited for
   void* h_stage = nullptr;                // pinned staging of the K1b table build's single upload
   size_t h_stage_bytes = 0;

@@ -1155,7 +1155,10 @@ __global__ void k_halo_check(SweepScalars* sc, const unsigned long long* Lkeys, 
 // (the host waits for their read-back)
 static int halo_for(sbo_ctx* c, int cidx, int lidx, double hl, long long planes_total, long long* H_out) {
   if (c->halo_spec && c->halo_guess[cidx] >= 0) {
-    const long long H = std::min(planes_total, c->halo_guess[cidx]);
+    long long H = std::min(planes_total, c->halo_guess[cidx]);
+    // (test hook: this rank alone guesses one plane -- tests/test_gpu_parity.py: the rerun must be every rank's decision)
+    static const bool test_short = getenv("SBO_TEST_HALO_SHORT") != nullptr;
+    if (test_short) H = std::min<long long>(H, 1);
     hipLaunchKernelGGL(k_halo_check, dim3(1), dim3(1), 0, c->stream, (SweepScalars*)c->scal.p, (const unsigned long long*)c->Lmax.p, lidx, cidx,
                        hl, H, planes_total);
     *H_out = H;
@@ -1656,6 +1659,7 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
   if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
   c->c1_pending = false;                       // (the whole stream has drained)
   h.count_S = h.count_U = h.count_M = h.n_amb_total = h.n_guard = 0;
+  h.halo_short = 0;                            // GLOBAL: a rank that alone reran its set phase would leave the others in a collective
   for (int t = 0; t < kMaxQ; ++t) h.count_set[t] = 0;
   Best merged[kArgSlots];
   for (int t = 0; t < kArgSlots; ++t) merged[t] = slot_is_max[t] ? best_none<true>() : best_none<false>();
@@ -1673,6 +1677,7 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
     h.n_amb_total += (long long)row[kC3Counts + 3];
     h.n_guard += (long long)row[kC3Counts + 4];
     for (int t = 0; t < kMaxQ; ++t) h.count_set[t] += (long long)row[kC3Counts + 5 + t];
+    h.halo_short += (long long)row[kC3Halo];
   }
   for (int t = 0; t < kArgSlots; ++t) {
     h.arg_val[t] = merged[t].i >= 0 ? merged[t].v : 0.0;
@@ -1691,6 +1696,7 @@ static void sweep_times(sbo_ctx* c) {
   c->prof.host_syncs = c->host_syncs;
   c->prof.comm_bytes = c->comm_bytes;
   c->prof.comm_calls = c->comm_calls;
+  c->prof.halo_reruns = c->halo_reruns;
   double cms = c->comm_host_ms;
   for (int k = 0; k + 1 < c->comm_nev; k += 2) {
     float t = 0;
@@ -1699,6 +1705,8 @@ static void sweep_times(sbo_ctx* c) {
   c->prof.comm_ms = cms;
 }
 static void sweep_comm_reset(sbo_ctx* c) {
+  if (c->in_halo_rerun) return;                // (the counters of the discarded pass stay in the sweep's record)
+  c->halo_reruns = 0;
   c->host_syncs = 0;
   c->comm_bytes = 0;
   c->comm_calls = 0;
@@ -1792,7 +1800,11 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
       for (auto& g : c->halo_guess) g = -1;
       sbo_sweep_opts o2 = *o;
       o2.posterior_ready = 1;
-      return sweep_safeopt_t<T>(c, &o2, res);
+      ++c->halo_reruns;
+      c->in_halo_rerun = true;
+      const int rr = sweep_safeopt_t<T>(c, &o2, res);
+      c->in_halo_rerun = false;
+      return rr;
     }
     halo_learn(c, h, Lk, o->reference_quirk_L_index);
   }
@@ -2228,7 +2240,11 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
       for (auto& g : c->halo_guess) g = -1;
       sbo_sweep_opts o2 = *o;
       o2.posterior_ready = 1;
-      return sweep_goose_t<T>(c, &o2, res);
+      ++c->halo_reruns;
+      c->in_halo_rerun = true;
+      const int rr = sweep_goose_t<T>(c, &o2, res);
+      c->in_halo_rerun = false;
+      return rr;
     }
     halo_learn(c, h, Lk, o->reference_quirk_L_index);
   }

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void k_unpack_shards(const unsigned long long*
 // indices, then per slot the winner's band and the two extreme far ends with the first one's candidate (guard band of an
 // approximating posterior: the host merges them like the values), counts, the guard-band count, |G_c| / |O_c|
 constexpr int kC3Counts = 6 * kArgSlots;
-constexpr int kC3Row = kC3Counts + 5 + kMaxQ;
+constexpr int kC3Row = kC3Counts + 6 + kMaxQ;
+constexpr int kC3Halo = kC3Counts + 5 + kMaxQ;             // some rank's speculative halo window was too narrow
 __global__ void k_pack_c3(const SweepScalars* sc, double* buf, int world, int rank) {
   for (int i = threadIdx.x; i < world * kC3Row; i += blockDim.x) buf[i] = 0.0;
   __syncthreads();
@@ -103,4 +104,5 @@ __global__ void k_pack_c3(const SweepScalars* sc, double* buf, int world, int ra
     row[kC3Counts + 4] = (double)(sc->n_guard + sc->guard_nb0);
   }
   if (t < kMaxQ) row[kC3Counts + 5 + t] = (double)sc->count_set[t];
+  if (t == 0) row[kC3Halo] = (double)sc->halo_short;
 }

@@ -21,30 +21,42 @@ def main():
     from safebo_amd import synthetic, distributed
 
     dist = distributed.init_from_env()
-    dtype = "f64"
-    if cfg_name.endswith(":f32"):                      # an fp32 model (library Cholesky), SafeOpt only: the fp64 recheck across ranks
+    dtype, guard = "f64", None
+    if cfg_name.endswith(":f32"):                      # an fp32 model (library Cholesky): the fp64 recheck across ranks
         cfg_name, dtype = cfg_name[:-4], "f32"
+    if cfg_name.endswith(":guard"):                    # every sweep re-evaluates its guard-band candidates (option guard_band 2)
+        cfg_name, guard = cfg_name[:-6], 2
     cfg = synthetic.make_config(cfg_name, n=n)
     eng = safebo_amd.SweepEngine(0)
     distributed.join(eng, dist, relay=True)
+    if guard is not None:
+        eng.set_option("guard_band", guard)
     eng.set_model(cfg["ds"], dtype=dtype, use_invK=(dtype == "f64"))
     eng.set_grid_sharded(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
     res = eng.sweep_safeopt(b, want_masks=True)
     res["fp64_rechecks"] = int(eng.profile()["fp64_rechecks"])
+    res["posterior_kernel"] = int(eng.profile()["posterior_kernel"])
     masks = {k: eng.mask(k) for k in ("S", "U", "M")}
     masks.update({f"G{c}": eng.mask("G", c) for c in range(1, cfg["q"])})
     gres = None
-    if cfg["q"] > 1 and dtype == "f64":
+    tres = None
+    if cfg["q"] > 1:
         try:
-            gres = eng.sweep_goose(b, want_masks=True, posterior_ready=True)
+            gres = eng.sweep_goose(b, want_masks=True, posterior_ready=(dtype == "f64" and guard is None))
+            gres["fp64_rechecks"] = int(eng.profile()["fp64_rechecks"])
             masks.update({f"O{c}": eng.mask("O", c) for c in range(1, cfg["q"])})
         except safebo_amd.EmptySafeSetError:
             gres = {"empty_safe_set": True}
+    if dtype == "f32" or guard is not None:
+        # the trust-region sweep of GP_TR (ball of radius 0.3 of the box around its centre) across the ranks
+        x0 = cfg["bound"].mean(axis=1)
+        tres = eng.sweep_tr(b, x0, 0.3 * float(np.min(cfg["bound"][:, 1] - cfg["bound"][:, 0])))
     np.savez(out_path + f".rank{rank}.npz", first=eng.first, n_local=eng.n_local, **masks)
     if rank == 0:
         def plain(r):
             return {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
-        json.dump({**plain(res), "goose": plain(gres) if gres is not None else None}, open(out_path, "w"))
+        json.dump({**plain(res), "goose": plain(gres) if gres is not None else None, "tr": plain(tres) if tres is not None else None},
+                  open(out_path, "w"))
     dist.barrier()
     eng.close()
     dist.destroy()
@@ -72,11 +84,15 @@ def sequence(rank, world, port, out_path, cfg_name, n, count, bs):
             masks[f"{i}_{k}"] = eng.mask(k)
         for c in range(1, cfg["q"]):
             masks[f"{i}_G{c}"] = eng.mask("G", c)
-        g = eng.sweep_goose(b, want_masks=True, posterior_ready=True)
-        pg = eng.profile()
-        for c in range(1, cfg["q"]):
-            masks[f"{i}_O{c}"] = eng.mask("O", c)
+        if os.environ.get("SBO_TEST_SEQ_SAFEOPT_ONLY"):
+            g, pg = {"target_index": -1, "explore_index": -1, "count_O": []}, p
+        else:
+            g = eng.sweep_goose(b, want_masks=True, posterior_ready=True)
+            pg = eng.profile()
+            for c in range(1, cfg["q"]):
+                masks[f"{i}_O{c}"] = eng.mask("O", c)
         rows.append({"b": b, "host_syncs": int(p["host_syncs"]), "goose_host_syncs": int(pg["host_syncs"]),
+                     "halo_reruns": int(p["halo_reruns"]), "goose_halo_reruns": int(pg["halo_reruns"]), "comm_calls": int(p["comm_calls"]),
                      "minimizer_index": res["minimizer_index"], "expander_index": res["expander_index"], "count_S": res["count_S"],
                      "count_M": res["count_M"], "count_G": [int(x) for x in res["count_G"]], "u_star": res["u_star"],
                      "target_index": g["target_index"], "explore_index": g["explore_index"], "count_O": [int(x) for x in g["count_O"]]})

@@ -1462,6 +1462,73 @@ def test_multi_rank_fp32_sweep_with_fp64_recheck_equals_the_fp64_oracle(tmp_path
     assert res["minimizer_index"] == ref["minimizer_index"] and res["expander_index_c"][:cfg["q"] - 1] == [int(x) for x in ref["expander_index"]]
     assert res["u_star"] == pytest.approx(ref["u_star"], rel=1e-10) and res["fp64_rechecks"] > 0
     assert np.allclose(res["L"][:cfg["q"]], ref["L"], rtol=1e-9)
+    # (r04) the GoOSE and trust-region sweeps of the fp32 model across the ranks: rechecked in fp64 like the SafeOpt sweep --
+    # optimistic sets, targets and the trust-region argmin are the fp64 oracle's, whatever the world size
+    _assert_goose_tr(res, parts, cfg, pts, b)
+
+
+def _assert_goose_tr(res, parts, cfg, pts, b):
+    gref = oracle.goose_sweep(pts, cfg["ds"], b)
+    g = res["goose"]
+    assert g is not None and not g.get("empty_safe_set", False)
+    for c in range(1, cfg["q"]):
+        assert np.array_equal(np.concatenate([p[f"O{c}"] for p in parts]), gref["O"][c - 1]), f"O{c}"
+    assert g["safe_min_index"] == gref["safe_min_index"]
+    assert g["target_index_c"][:cfg["q"] - 1] == [int(x) for x in gref["target_index_c"]]
+    assert g["target_index"] == gref["target_index"] and g["explore_index"] == gref["explore_index"]
+    assert g["choose_safe_min"] == gref["choose_safe_min"] and g["count_O"][:cfg["q"] - 1] == [int(x) for x in gref["O"].sum(1)]
+    x0 = cfg["bound"].mean(axis=1)
+    tref = oracle.tr_sweep(pts, cfg["ds"], b, x0, 0.3 * float(np.min(cfg["bound"][:, 1] - cfg["bound"][:, 0])))
+    assert res["tr"]["index"] == tref["index"] and res["tr"]["count_T"] == int(tref["T"].sum())
+
+
+@pytest.mark.parametrize("world,cfg_name,n,count,b", [(2, "B", 128, [300, 257], 3.0), (3, "C", 64, [272, 265], 2.0),
+                                                      (2, "D", 128, [64, 64, 64, 64], 3.0)])
+def test_multi_rank_forced_guard_reevaluation_equals_the_exact_kernel(engine, tmp_path, world, cfg_name, n, count, b):
+    """(r04) The guard band of the approximating posteriors (K1b on the 2-D shards, K1t on the 4-D ones) across ranks: with
+    guard_band = 2 every sweep -- SafeOpt, GoOSE, trust region -- re-evaluates its in-band candidates with the exact kernel;
+    band widths and pass counts are agreed on through the collectives, and every mask and index is what ONE rank gets with
+    the exact table kernel K1g on the whole grid (itself pinned to the oracle by the single-rank tests)."""
+    port, out = _free_port(), str(tmp_path / "res.json")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), str(world), port, out, cfg_name + ":guard",
+                               str(n), json.dumps(count), str(b)]) for r in range(world)]
+    try:
+        cfg = synthetic.make_config(cfg_name, n=n)
+        engine.set_option("bilinear", 0)
+        engine.set_option("tensor_cheb", 0)
+        engine.set_model(cfg["ds"])
+        engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+        ref = engine.sweep_safeopt(b, want_masks=True)
+        assert engine.profile()["posterior_kernel"] == 3
+        rmask = {k: engine.mask(k) for k in ("S", "U", "M")}
+        rmask.update({f"G{c}": engine.mask("G", c) for c in range(1, cfg["q"])})
+        gref = engine.sweep_goose(b, want_masks=True, posterior_ready=True)
+        rmask.update({f"O{c}": engine.mask("O", c) for c in range(1, cfg["q"])})
+        x0 = cfg["bound"].mean(axis=1)
+        tref = engine.sweep_tr(b, x0, 0.3 * float(np.min(cfg["bound"][:, 1] - cfg["bound"][:, 0])), posterior_ready=True)
+    except BaseException:
+        for p in procs:
+            p.kill()
+            p.wait()
+        raise
+    finally:
+        engine.set_option("bilinear", 1)
+        engine.set_option("tensor_cheb", 1)
+    assert _wait_ranks(procs) == [0] * world
+    res = json.load(open(out))
+    assert res["posterior_kernel"] in (4, 5), "the shards must run an approximating posterior for this test to mean anything"
+    assert res["guard_passes"] >= 1
+    parts = [np.load(out + f".rank{r}.npz") for r in range(world)]
+    for k, want in rmask.items():
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), want), k
+    for k in ("minimizer_index", "expander_index", "count_S", "count_M"):
+        assert res[k] == ref[k], k
+    assert res["count_G"] == ref["count_G"].tolist() and res["expander_index_c"] == ref["expander_index_c"].tolist()
+    g = res["goose"]
+    for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c"):
+        assert g[k] == gref[k], k
+    assert g["count_O"] == gref["count_O"].tolist() and g["target_index_c"] == gref["target_index_c"].tolist()
+    assert res["tr"]["index"] == tref["index"] and res["tr"]["count_T"] == tref["count_T"]
 
 
 @pytest.mark.parametrize("world,cfg_name,n,count,bs", [(2, "B", 128, [320, 600], [2.0, 2.0, 3.5, 3.5, 1.0]),
@@ -1506,6 +1573,44 @@ def test_multi_rank_speculative_halo_has_no_wait_inside_the_sweep(engine, tmp_pa
     assert rows[0]["host_syncs"] >= 2
     assert rows[1]["host_syncs"] == 1 and rows[3]["host_syncs"] == 1, [x["host_syncs"] for x in rows]
     assert rows[-1]["host_syncs"] == 1                  # smaller radii: the old window is wider than needed, still exact
+
+
+def test_multi_rank_short_halo_guess_on_one_rank_reruns_every_rank(engine, tmp_path):
+    """the rerun after a speculative window that was too narrow is a GLOBAL decision (the flag travels in the C3 row):
+    rank 1 alone guesses one plane (test hook SBO_TEST_HALO_SHORT) -- the others' windows are fine --, and still every rank runs
+    the set phase again, the job neither hangs nor diverges, the results equal the single-rank sweep, and the profile says what
+    happened (halo_reruns, with the discarded pass's collectives and waits kept in the counters).  SafeOpt sweeps only: the
+    sizes of the GoOSE sweep's all-gather follow the window, so ranks whose guesses differ -- which the library never produces:
+    guesses are functions of the global keys alone -- cannot even enter it."""
+    world, cfg_name, n, count, bs = 3, "C", 64, [256, 300], [2.0, 2.0, 2.0]
+    port, out = _free_port(), str(tmp_path / "seq.json")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), str(world), port, out, cfg_name,
+                               str(n), json.dumps(count), json.dumps(bs)],
+                              env={**os.environ, "SBO_TEST_SEQ_SAFEOPT_ONLY": "1", **({"SBO_TEST_HALO_SHORT": "1"} if r == 1 else {})})
+             for r in range(world)]
+    try:
+        cfg = synthetic.make_config(cfg_name, n=n)
+        engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+        engine.set_model(cfg["ds"])
+        r = engine.sweep_safeopt(bs[0], want_masks=True)
+        m = {k: engine.mask(k) for k in ("S", "M")}
+        m.update({f"G{c}": engine.mask("G", c) for c in range(1, cfg["q"])})
+    except BaseException:
+        for p in procs:
+            p.kill()
+            p.wait()
+        raise
+    assert _wait_ranks(procs) == [0] * world
+    rows = json.load(open(out))
+    parts = [np.load(out + f".rank{r}.npz") for r in range(world)]
+    for i, row in enumerate(rows):
+        for k, want in m.items():
+            assert np.array_equal(np.concatenate([p[f"{i}_{k}"] for p in parts]), want), (i, k)
+        assert row["minimizer_index"] == r["minimizer_index"] and row["expander_index"] == r["expander_index"], i
+    # rank 0 reports: its own guess was fine, and yet sweeps 2 and 3 (the speculative ones) ran their set phase twice
+    assert rows[0]["halo_reruns"] == 0
+    assert rows[1]["halo_reruns"] == 1 and rows[2]["halo_reruns"] == 1, [x["halo_reruns"] for x in rows]
+    assert rows[1]["host_syncs"] >= 2 and rows[1]["comm_calls"] > rows[0]["comm_calls"]
 
 
 @pytest.mark.parametrize("cfg_name,n,count", [("B", 128, [320, 300]), ("C", 64, [256, 300]), ("D", 128, [20, 18, 17, 24])])
