@@ -109,6 +109,7 @@ struct sbo_ctx {
   void* k1g_grad = nullptr;
   bool tensor_busy = false;        // the exact node / probe launch of K1t is running through launch_posterior
   sbo::DevBuf tn_pts, tn_vals, tn_work, tn_W0t, tn_W1t, tn_probe, tn_scr;
+  sbo::DevBuf tn_gather;     // ranks > 1: this rank's slab of the node tensors | every rank's (all-gather)
   sbo::DevBuf tn_W[SBO_MAX_D];
   size_t tn_work_half = 0;
   double tn_flops = 0.0;           // multiply-add flops of the last interpolation pass

@@ -49,6 +49,26 @@ __global__ void k_t_axes(const TensorDims td, double* __restrict__ axc) {
   }
 }
 
+// ranks > 1: the nodes are shared out along the LAST axis -- rank r evaluates node planes [r per, (r + 1) per) (the last
+// ranks repeat plane Dn - 1 where the count does not divide) --: the axes' positions with the last axis cut to that slab ...
+__global__ void k_t_axes_slab(const TensorDims td, const double* __restrict__ axc, int k_first, int per, double* __restrict__ out) {
+  int off = 0;
+  for (int a = 0; a < td.d - 1; ++a) {
+    for (int k = threadIdx.x; k < td.Dn[a]; k += blockDim.x) out[off + k] = axc[off + k];
+    off += td.Dn[a];
+  }
+  const int last = td.Dn[td.d - 1];
+  for (int j = threadIdx.x; j < per; j += blockDim.x) out[off + j] = axc[off + (k_first + j < last ? k_first + j : last - 1)];
+}
+// ... and the gathered slabs [rank][quantity][per planes of `pre` nodes] back into the stacked node tensors [quantity][Nn]
+__global__ __launch_bounds__(256) void k_t_unslab(const double* __restrict__ G, int nq, long long pre, int per, int Dn_last, double* __restrict__ out) {
+  const long long Nn = pre * Dn_last, Nl = pre * per, total = Nn * nq;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long qi = e / Nn, rem = e % Nn, k = rem / pre, p = rem % pre;
+    out[e] = G[((k / per) * nq + qi) * Nl + (k % per) * pre + p];
+  }
+}
+
 // interpolation matrix of axis a: W[x][k], x over the (local) grid positions of the axis; transposed copy Wt[k][x] for axes 0 and 1
 __global__ __launch_bounds__(256) void k_t_wmat(const TensorDims td, const CandSpec cs, int a, long long nx, long long x_first,
                                                 double* __restrict__ W, double* __restrict__ Wt) {
@@ -403,6 +423,7 @@ __global__ __launch_bounds__(256) void k_t_probe_core(const double* __restrict__
 
 // ---- host ----------------------------------------------------------------------------------------------------------------
 int comm_allreduce_min_u64(sbo_ctx* c, unsigned long long* dev, int count);
+int comm_allgather_bytes(sbo_ctx* c, const void* send, void* recv, size_t bytes_per_rank);
 // node counts: the first two axes in matrix-core k-blocks (k_t_final), the further ones in steps of eight (k_t_mode takes any)
 static const int kLadder01[4] = {32, 48, 64, 96};
 static const int kLadderN[7] = {32, 40, 48, 56, 64, 80, 96};
@@ -553,7 +574,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     if (!ok_dims || Nn > (1ll << 24)) break;
     // buffers: node list, node values (mean, var: q each; gradient: q d), interpolation matrices, ping-pong work
     const int nqg = q * d;
-    if ((rc = ensure(c->tn_pts, sizeof(double) * 4 * 128))) return rc;       // the node positions of the axes
+    if ((rc = ensure(c->tn_pts, sizeof(double) * 8 * 128))) return rc;       // the node positions of the axes (+ a rank's slab of them)
     // (the two large buffers: running out of memory for them is a reason to decline -- K1g needs neither --, not to fail the sweep)
     if ((rc = ensure(c->tn_vals, sizeof(double) * (size_t)Nn * (2 * q + nqg)))) { if (rc == SBO_E_NOMEM) break; return rc; }
     size_t half_elems = 0;
@@ -581,7 +602,29 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     double* nmean = (double*)c->tn_vals.p;
     double* nvar = nmean + (size_t)q * Nn;
     double* ngrad = nvar + (size_t)q * Nn;
-    {
+    const int W = c->world;
+    if (W > 1 && td.Dn[d - 1] >= W) {
+      // (r04) every rank used to evaluate ALL the nodes -- 3.2 of config D's 13.8 ms that no number of GPUs made shorter.  A slab
+      // of the last axis' node planes per rank, one all-gather of the slabs (12 quantities x 3.7 M nodes x 8 B = 354 MB in all
+      // for config D: ~1 ms over xGMI at 8 ranks), and the stacked tensors are put together again on every rank.
+      const int nq_all = 2 * q + nqg, per = (td.Dn[d - 1] + W - 1) / W;
+      long long pre_all = 1;
+      for (int a = 0; a < d - 1; ++a) pre_all *= td.Dn[a];
+      const long long Nl = pre_all * per;
+      if ((rc = ensure(c->tn_gather, sizeof(double) * (size_t)nq_all * (size_t)Nl * (size_t)(W + 1)))) { if (rc == SBO_E_NOMEM) break; return rc; }
+      double* slab = (double*)c->tn_gather.p;
+      double* gathered = slab + (size_t)nq_all * Nl;
+      double* axl = (double*)c->tn_pts.p + 4 * 128;
+      hipLaunchKernelGGL(k_t_axes_slab, dim3(1), dim3(128), 0, c->stream, td, (const double*)c->tn_pts.p, c->rank * per, per, axl);
+      long long cnt[kTMaxD];
+      for (int a = 0; a < d; ++a) cnt[a] = a == d - 1 ? per : td.Dn[a];
+      if ((rc = launch_posterior_on_axes(c, d, cnt, (const double*)axl, slab, slab + (size_t)q * Nl, slab + (size_t)2 * q * Nl,
+                                         (unsigned long long*)c->tn_scr.p)))
+        return rc;
+      if ((rc = comm_allgather_bytes(c, slab, gathered, sizeof(double) * (size_t)nq_all * Nl))) return rc;
+      hipLaunchKernelGGL(k_t_unslab, dim3((unsigned)std::min<long long>((Nn * nq_all + 255) / 256, 1 << 16)), dim3(256), 0, c->stream,
+                         (const double*)gathered, nq_all, pre_all, per, td.Dn[d - 1], nmean);
+    } else {
       long long cnt[kTMaxD];
       for (int a = 0; a < d; ++a) cnt[a] = td.Dn[a];
       if ((rc = launch_posterior_on_axes(c, d, cnt, (const double*)c->tn_pts.p, nmean, nvar, ngrad, (unsigned long long*)c->tn_scr.p))) return rc;
@@ -703,7 +746,8 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       c->gb_active = true;
     }
     // flops issued: node posterior (block-triangular contraction) + interpolation sums
-    c->last_k1_flops = (double)q * mc.npad * (mc.npad + 16.0) * (double)Nn + c->tn_flops;
+    c->last_k1_flops = (double)q * mc.npad * (mc.npad + 16.0) * (double)Nn / (double)((c->world > 1 && td.Dn[d - 1] >= c->world) ? c->world : 1) +
+                       c->tn_flops;
     return SBO_OK;
   }
   c->tn_valid = true;

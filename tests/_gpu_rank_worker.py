@@ -36,6 +36,7 @@ def main():
     res = eng.sweep_safeopt(b, want_masks=True)
     res["fp64_rechecks"] = int(eng.profile()["fp64_rechecks"])
     res["posterior_kernel"] = int(eng.profile()["posterior_kernel"])
+    res["comm_bytes"], res["comm_calls"] = int(eng.profile()["comm_bytes"]), int(eng.profile()["comm_calls"])
     masks = {k: eng.mask(k) for k in ("S", "U", "M")}
     masks.update({f"G{c}": eng.mask("G", c) for c in range(1, cfg["q"])})
     gres = None

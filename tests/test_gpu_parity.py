@@ -1439,6 +1439,12 @@ def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_
     for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c"):
         assert g[k] == gref[k], k
     assert g["count_O"] == gref["count_O"].tolist() and g["target_index_c"] == gref["target_index_c"].tolist()
+    if count == [64, 64, 64, 64]:
+        assert res["posterior_kernel"] == 5
+    if res["posterior_kernel"] == 5:
+        # (r04) K1t across ranks: each rank evaluates a slab of the Chebyshev nodes and one all-gather puts the node tensors
+        # together -- the sweep's collectives carry at least this rank's slab (12 quantities x >= 32^3 x 16 nodes x 8 bytes)
+        assert res["comm_bytes"] > 12 * 32 ** 3 * 16 * 8, res["comm_bytes"]
 
 
 @pytest.mark.parametrize("world,cfg_name,n,count,b", [(2, "B", 128, [96, 81], 3.0), (3, "C", 64, [72, 65], 2.0)])
