@@ -244,6 +244,7 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "cheb_tol_e17")) {
     c->cheb_tol = (double)value * 1e-17;
     c->bl.valid = false;
+    c->bi.valid = false;
     c->posterior_valid = false;
     return SBO_OK;
   }
@@ -270,7 +271,10 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     return SBO_OK;
   }
   if (!strcmp(key, "bilinear")) {
-    c->bilinear = value ? 1 : 0;
+    if (value < 0 || value > 2) return fail(SBO_E_INVALID, "bilinear must be 0 (off), 1 (on; a model's first sweep by node interpolation) or 2 (on, K1b's plan from the first sweep)");
+    c->bilinear = (int)value;
+    c->bl.valid = false;
+    c->bi.valid = false;
     c->posterior_valid = false;
     return SBO_OK;
   }
@@ -310,7 +314,8 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "guard_band")) {
     if (value < 0 || value > 2) return fail(SBO_E_INVALID, "guard_band must be 0 (off), 1 (on) or 2 (re-evaluate on every sweep)");
     c->guard_band = (int)value;
-    c->bl.valid = false;                    // (plans measure their band when they are built)
+    c->bl.valid = false;
+    c->bi.valid = false;                    // (plans measure their band when they are built)
     c->tn_valid = false;
     c->posterior_valid = false;
     return SBO_OK;
@@ -373,6 +378,7 @@ static int model_set_impl(sbo_ctx* c, int dtype, const char* kernel, int n, int 
   }
   c->dtype = dtype;
   c->bl.valid = false;
+    c->bi.valid = false;
   ++c->model_serial;
   // derived arrays (As, sqA, Xn, rhs), factorisation, alpha and the fragment images of the factor: on the device (model.hip)
   int rc = model_build(c, invK, X_norm, Y_norm);
@@ -380,7 +386,9 @@ static int model_set_impl(sbo_ctx* c, int dtype, const char* kernel, int n, int 
   // A grid is resident and qualifies for the GEMM posterior: its per-(model, grid) tables are enqueued now, so that they
   // run while the caller is on its way from this call to the sweep (the bases' ranks came back with the build's own
   // synchronisation; nothing here waits).  A grid change before the next sweep simply drops the plan.
-  if (!c->is_shadow && bilinear_applicable(c) && (rc = bilinear_setup(c))) return rc;
+  if (!c->is_shadow && interp_applicable(c)) {
+    if ((rc = interp_setup(c))) return rc;
+  } else if (!c->is_shadow && bilinear_applicable(c) && (rc = bilinear_setup(c))) return rc;
   if (dtype == SBO_F32 && c->fp64_recheck && !c->is_shadow) {
     // the fp64 twin: same constants, double arrays and factor images (built from the same inputs)
     if ((rc = shadow_ensure(c))) return rc;
@@ -460,6 +468,7 @@ int sbo_model_append(sbo_ctx* c, const double* x_norm_new, const double* y_norm_
   c->posterior_valid = false;
   c->masks_valid = false;
   c->bl.valid = false;
+    c->bi.valid = false;
   return SBO_OK;
 }
 
@@ -492,6 +501,7 @@ int sbo_candidates_points(sbo_ctx* c, const void* points, int points_dtype, int6
   c->sharded = false;
   c->has_cand = true;
   c->bl.valid = false;
+    c->bi.valid = false;
   c->posterior_valid = false;
   c->masks_valid = false;
   return SBO_OK;
@@ -521,6 +531,7 @@ int sbo_candidates_grid(sbo_ctx* c, int d, const double* lo, const double* hi, c
   c->sharded = false;
   c->has_cand = true;
   c->bl.valid = false;
+    c->bi.valid = false;
   c->posterior_valid = false;
   c->masks_valid = false;
   return SBO_OK;
@@ -583,7 +594,6 @@ int sbo_posterior_run(sbo_ctx* c) {
   if ((rc = sbo_posterior_enqueue(c))) return rc;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
-  if ((rc = model_factor_enqueue(c))) return rc;           // (a deferred factor chain: enqueued while the posterior runs)
   SBO_HIP(hipEventSynchronize(c->ev[1]));
   float ms = 0;
   SBO_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));

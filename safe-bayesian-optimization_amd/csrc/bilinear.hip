@@ -962,6 +962,7 @@ struct PostCtx {
   unsigned int ucnt0;
   long long nlines;
   bool full;          // the workgroup's 128 x 128 tile lies inside the grid: epilogues skip their bounds tests
+  bool imode;         // K1i: every phase is a plain GEMM on its own Chebyshev coefficients (the gradient phases start from zero)
   // fused classification (one-constraint sweeps): the mean epilogue of the constraint's output reads back the variances this
   // thread stored in the variance phase and writes the S / U bytes; null = off
   const double* var_rd;
@@ -1168,7 +1169,7 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
     *reinterpret_cast<d4_t*>(buf + cx.b_st) = q0;
     *reinterpret_cast<d4_t*>(buf + cx.b_st + 4) = q1;
   };
-  if (PH == 2) {
+  if (PH == 2 && !cx.imode) {
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) {
       const unsigned int x = (unsigned int)(cx.cs0 + s2) * 16u + (cx.lane & 15);
@@ -1296,7 +1297,10 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
                                                   const int* __restrict__ eff /* nullptr, or the Chebyshev core's k-steps of the variance phase at [4 o] */,
                                                   const double* __restrict__ gtmax /* nullptr (every tile runs the gradient phases), or the plan's
                                                   largest gradient samples per tile [q][2][tiles], followed by the slacks [q][2] */,
-                                                  const unsigned long long* __restrict__ gkey /* the grid's largest samples [q][2] */) {
+                                                  const unsigned long long* __restrict__ gkey /* the grid's largest samples [q][2] */,
+                                                  int imode /* K1i (interpolation from Chebyshev nodes): BtA / VA hold the stage-1 images of four
+                                                  coefficient sets per output (quadratic form, mean sum, two gradient sums), SBf the Chebyshev table
+                                                  P0f; the k-steps of every phase come from eff[4 (4 o + phase)] */) {
   extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
   const int o = blockIdx.z;
   PostCtx cx;
@@ -1306,6 +1310,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   cx.ucnt0 = (unsigned int)cs.count[0];
   cx.nlines = nlines;
   cx.full = (long long)(cx.rb0 + 4 * RB) * 16 <= nlines && (long long)(cx.cs0 + 8) * 16 <= cs.count[0];
+  cx.imode = imode != 0;
   // staging role of this thread: 64 bytes of one A image and 64 bytes of one B strip per k-block.
   // LDS image of an A block: per k-step the 16 lane-chunks are split into their first and second 16 bytes
   // ([16 x 16 B][16 x 16 B]) so that both ds_read_b128 of a fragment load touch 256 contiguous bytes (no bank conflicts)
@@ -1339,13 +1344,15 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   d4_t acc[RB][8];
   d4_t pre[4];
   const double* const A2 = VAo + (size_t)nrb * KBm * 256;
-  const double* const B2 = SBo + (size_t)ncs * KBm * 256;
+  const double* const B2 = imode ? SBo : SBo + (size_t)ncs * KBm * 256;
   const double* const A3 = VAo + (size_t)nrb * (KBm + KBm2) * 256;
+  const int es = imode ? 4 : 1;
+  const int KS1 = imode ? eff[4 * (4 * o + 1)] : KSm, KS2 = imode ? eff[4 * (4 * o + 2)] : KSm, KS3 = imode ? eff[4 * (4 * o + 3)] : KSm;
 #ifdef SBO_PHASE_CLOCKS
   unsigned long long clk_ = wall_clock64();
   const unsigned int clk_row_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 #endif
-  post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, eff ? eff[4 * o] : KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0, pre,
+  post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, eff ? eff[4 * o * es] : KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0, pre,
                     VAo, SBo, KBm);
   SBO_CLK(0);
   // The gradient phases (their maxima are the Lipschitz keys, models/SafeOpt.py:68-83) run on the tiles that can hold the grid's
@@ -1365,12 +1372,12 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
     gfold = fmax(f0, f1);
   }
   // (the mean phase requests the first operands of whichever phase follows it)
-  post_phase<1, RB>(cx, VAo, SBo, KBm, KSm, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0, pre, run2 ? A2 : A3, run2 ? B2 : SBo,
+  post_phase<1, RB>(cx, VAo, SBo, KBm, KS1, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0, pre, run2 ? A2 : A3, run2 ? B2 : SBo,
                     run2 ? KBm2 : KBm);
   SBO_CLK(1);
   // phase 2 continues on phase 1's sums: only the V1 half (the first KSm k-steps) of the stacked operands is run
-  if (run2) post_phase<2, RB>(cx, A2, B2, KBm2, KSm, nullptr, cg0, 0.0, 0.0, gmax, acc, xn0, pre, A3, SBo, KBm);
-  if (run3) post_phase<3, RB>(cx, A3, SBo, KBm, KSm, nullptr, cg1, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
+  if (run2) post_phase<2, RB>(cx, A2, B2, KBm2, KS2, nullptr, cg0, 0.0, 0.0, gmax, acc, xn0, pre, A3, SBo, KBm);
+  if (run3) post_phase<3, RB>(cx, A3, SBo, KBm, KS3, nullptr, cg1, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
   gmax = fmax(gmax, gfold);
   SBO_CLK(2);
 #pragma unroll
@@ -1885,11 +1892,19 @@ __global__ __launch_bounds__(128) void k_bl_gradcoarse(const BlDims dm, const do
     const size_t nt = (size_t)gridDim.x;
     tmax[((size_t)o * 2 + 0) * nt + tile] = m0;
     tmax[((size_t)o * 2 + 1) * nt + tile] = m1;
-    // (4096 workgroups on four addresses: the atomics queued up in L2 for 0.1 ms; a tile below the maximum so far only reads)
-    const unsigned long long k0 = (unsigned long long)__double_as_longlong(m0), k1 = (unsigned long long)__double_as_longlong(m1);
-    if (k0 > __hip_atomic_load(&gkey[2 * o + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gkey[2 * o + 0], k0);
-    if (k1 > __hip_atomic_load(&gkey[2 * o + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gkey[2 * o + 1], k1);
+    // (the grid's largest samples: k_bl_gradmax -- 4096 workgroups on four addresses queue their atomics up in L2)
   }
+}
+__global__ __launch_bounds__(256) void k_bl_gradmax(const double* __restrict__ tmax, int nt, unsigned long long* __restrict__ gkey) {
+  __shared__ double red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  double m = 0.0;
+  for (int i = tid; i < nt; i += blockDim.x) m = fmax(m, tmax[(size_t)row * nt + i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) gkey[row] = (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------
@@ -2210,6 +2225,7 @@ int bilinear_setup(sbo_ctx* c) {
     hipLaunchKernelGGL(k_bl_gradslack, dim3(uq), dim3(64), 0, ys, (const double*)part, rows, dxi0, dxi1, slack);
     hipLaunchKernelGGL(k_bl_gradcoarse, dim3((unsigned)nt, uq), dim3(128), 0, ys, dm, (const double*)dS0, (const double*)dVb, (const double*)dxn0,
                        (const double*)dxn1, ntx, gt, gkey);
+    hipLaunchKernelGGL(k_bl_gradmax, dim3(2 * uq), dim3(256), 0, ys, (const double*)gt, (int)nt, gkey);
     if (std::isfinite(dxi0) && std::isfinite(dxi1)) {
       pl.gtmax = gt;
       pl.gkey = gkey;
@@ -2286,6 +2302,521 @@ int bilinear_setup(sbo_ctx* c) {
   return SBO_OK;
 }
 
+
+// ---- K1i: the first sweep of a model by interpolation from Chebyshev nodes (r04) -----------------------------------------------
+// The reference refits its models after every sample (models/GP_Safe.py:283-304) and sweeps each of them ONCE
+// (test/test_SafeOpt.py:144-179), so what an iteration pays for K1b is its plan: axis bases by pivoted Gram-Schmidt (0.16 ms the
+// host has to wait for -- their ranks size everything after them), the core's contraction over rank^2 columns, guard probes:
+// ~0.45 ms of a 1.07 ms iteration on config H.  K1b's own evaluation stage does not care where its Chebyshev coefficients come
+// from.  So, for the first sweep of a model with a caller's invK:
+//   1. the posterior's two scalar fields per output -- quad = k*^T invK k* and s1 = k*^T alpha -- EXACTLY (the reference formula,
+//      models/GP_Safe.py:341-343, with the matrix as given) at the Dn x Dn tensor grid of Chebyshev nodes of the first kind on the
+//      grid's box: K*^T as B fragments from two n x Dn tables of axis factors (the kernel is separable), C = invK K*^T on the matrix
+//      cores (k_bgemm on the packed images of invK), then column dots quad_c = Z_c . C_c, s1_c = Z_c . alpha;
+//   2. a 2-D discrete cosine transform of each field -> its Chebyshev coefficients, and those of the two gradient sums of the mean
+//      by the derivative recurrence (d_{m-1} = d_{m+1} + 2 m c_m);
+//   3. the coefficients through k_cheb_trunc / k_cheb_t4f / k_bstage1 / k_bpost as K1b's core goes: four coefficient sets per output.
+// Nothing of this needs a number from the device on the host: the plan is enqueued by sbo_model_set behind the upload and the
+// first sweep follows in stream order; the bases and K1b's own plan are built when the same model is swept a second time.
+// Accuracy: Dn from the length scales as K1t chooses it (32 / 48 / 64); measured on the BASELINE models 1e-13 (mean) and 1e-12
+// (variance: the rounding of the reference formula itself) -- and measured again for every plan at the guard band's probe points
+// (values and gradient), so the sweep's decisions stay those of the exact kernel whatever the interpolation error is.
+constexpr int kIMaxDn = 64;
+constexpr double kGbInf = 1.0e300;          // a probe that is not finite: everything is "inside the band" (guard.hip)
+struct InterpDims {
+  int Dn, q, n, npad, dpad;
+  double mid[2], half[2];                  // node interval of each axis, normalised coordinates
+};
+// E[(2 o + axis)][p][j] = (axis == 0 ? sf2 : 1) exp(-1/2 (As_j,axis - xn_p vinv)^2)   (k_bl_zf multiplies the two axes)
+__global__ __launch_bounds__(256) void k_i_etab(const ModelConst mc, const InterpDims id, const double* __restrict__ As, double* __restrict__ E) {
+  const int job = blockIdx.y, o = job >> 1, axis = job & 1;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < id.Dn * id.n; e += gridDim.x * blockDim.x) {
+    const int p = e / id.n, j = e % id.n;
+    const double xn = id.mid[axis] + id.half[axis] * cospi(((double)p + 0.5) / (double)id.Dn);
+    const double dlt = As[((size_t)o * id.npad + j) * id.dpad + axis] - xn * mc.vinv[o][axis];
+    E[((size_t)job * kBlMaxR + p) * id.n + j] = (axis == 0 ? mc.sf2[o] : 1.0) * exp(-0.5 * dlt * dlt);
+  }
+}
+// node values from the fragments of Z = K*^T and C = invK Z ([ncsR][KBn * 4][64], k = observation): V[o][0][c] = sum_j Z_jc C_jc,
+// V[o][1][c] = sum_j Z_jc alpha_j.  A wave per strip of 16 columns.
+__global__ __launch_bounds__(64) void k_i_nodevals(int KBn, int n, const double* __restrict__ Zfall, const double* __restrict__ Cfall, size_t nZf,
+                                                   const double* __restrict__ alpha, int ald, int ncols, double* __restrict__ V) {
+  const int o = blockIdx.y, cs = blockIdx.x, l = threadIdx.x;
+  const double* Zf = Zfall + (size_t)o * nZf + (size_t)cs * KBn * 256;
+  const double* Cf = Cfall + (size_t)o * nZf + (size_t)cs * KBn * 256;
+  double aq[4] = {0.0, 0.0, 0.0, 0.0}, am[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int ks = 0; ks < KBn * 4; ks += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = ks + u, j = (k >> 2) * 16 + MM<double>::jslot(k & 3, l >> 4);
+      const double z = Zf[(size_t)k * 64 + l];
+      aq[u] = fma(z, Cf[(size_t)k * 64 + l], aq[u]);
+      am[u] = fma(z, j < n ? alpha[(size_t)o * ald + j] : 0.0, am[u]);
+    }
+  }
+  double sq = (aq[0] + aq[1]) + (aq[2] + aq[3]), sm = (am[0] + am[1]) + (am[2] + am[3]);
+  sq += __shfl_xor(sq, 16); sm += __shfl_xor(sm, 16);
+  sq += __shfl_xor(sq, 32); sm += __shfl_xor(sm, 32);
+  const int c = cs * 16 + l;
+  if (l < 16 && c < ncols) {
+    V[((size_t)o * 2 + 0) * ncols + c] = sq;
+    V[((size_t)o * 2 + 1) * ncols + c] = sm;
+  }
+}
+// Chebyshev coefficients of the node fields, ChatT[4 o + f][b][a] (b: degree along axis 1, a: along axis 0; the layout k_cheb_trunc /
+// k_cheb_t4f read): f = 0 quad, 1 s1, 2 / 3 the gradient sums g_a = (d s1 / d xn_a) / inv_ell_a of the two axes (k_bpost scales by
+// Y_std inv_ell X_rstd).  One workgroup per output; node c = p Dn + s (p: axis 0).  T[m][k] = w_m cos(m pi (k + 1/2) / Dn) / Dn.
+__global__ __launch_bounds__(1024) void k_i_dct(const ModelConst mc, const InterpDims id, const double* __restrict__ V, double* __restrict__ ChatT_all) {
+  extern __shared__ double sh[];                 // T [Dn][Dn + 1] | field [Dn][Dn + 1] | tmp [Dn][Dn + 1]  (rows padded: column walks)
+  const int Dn = id.Dn, o = blockIdx.x >> 1, f = blockIdx.x & 1, tid = threadIdx.x, N2 = Dn * Dn, P = Dn + 1;
+  double *T = sh, *F = sh + Dn * P, *W = sh + 2 * Dn * P;
+  for (int e = tid; e < N2; e += blockDim.x) {
+    const int m = e / Dn, k = e % Dn;
+    T[m * P + k] = (m == 0 ? 1.0 : 2.0) / (double)Dn * cospi((double)m * ((double)k + 0.5) / (double)Dn);
+    F[m * P + k] = V[((size_t)o * 2 + f) * N2 + e];                                         // F[p][s]
+  }
+  __syncthreads();
+  for (int e = tid; e < N2; e += blockDim.x) {                                                // W[a][s] = sum_p T[a][p] F[p][s]
+    const int a = e / Dn, s_ = e % Dn;
+    double a0 = 0.0, a1 = 0.0;
+    for (int p = 0; p + 1 < Dn; p += 2) {
+      a0 = fma(T[a * P + p], F[p * P + s_], a0);
+      a1 = fma(T[a * P + p + 1], F[(p + 1) * P + s_], a1);
+    }
+    W[a * P + s_] = a0 + a1;
+  }
+  __syncthreads();
+  double* out = ChatT_all + (size_t)(4 * o + f) * N2;
+  for (int e = tid; e < N2; e += blockDim.x) {                                                // C[a][b] = sum_s W[a][s] T[b][s]
+    const int b = e / Dn, a = e % Dn;
+    double a0 = 0.0, a1 = 0.0;
+    for (int s_ = 0; s_ + 1 < Dn; s_ += 2) {
+      a0 = fma(W[a * P + s_], T[b * P + s_], a0);
+      a1 = fma(W[a * P + s_ + 1], T[b * P + s_ + 1], a1);
+    }
+    out[e] = a0 + a1;                                                                         // ChatT[b][a]
+    F[b * P + a] = a0 + a1;
+  }
+  if (f == 0) return;                            // (uniform: the workgroup of the mean sum goes on to its derivatives)
+  __syncthreads();
+  // derivative series of s1: along axis 0 (index a) for g_0, along axis 1 (index b) for g_1; d xi / d xn = 1 / half
+  double* g0 = ChatT_all + (size_t)(4 * o + 2) * N2;
+  double* g1 = ChatT_all + (size_t)(4 * o + 3) * N2;
+  const double sc0 = 1.0 / (id.half[0] * mc.inv_ell[o][0]), sc1 = 1.0 / (id.half[1] * mc.inv_ell[o][1]);
+  for (int r = tid; r < 2 * Dn; r += blockDim.x) {
+    const int line = r % Dn;
+    const bool along0 = r < Dn;
+    // coefficients c_m of this line: along axis 0 the line is a row b of F (stride 1), along axis 1 a column a (stride P)
+    const int fb = along0 ? line * P : line, fs = along0 ? 1 : P;
+    const int ob = along0 ? line * Dn : line, os = along0 ? 1 : Dn;
+    double* dst = along0 ? g0 : g1;
+    const double sc = along0 ? sc0 : sc1;
+    double d2 = 0.0, d1 = 0.0;                  // d_{m+1}, d_m while walking m = Dn - 1 .. 1
+    dst[ob + (Dn - 1) * os] = 0.0;
+    for (int m = Dn - 1; m >= 1; --m) {
+      const double dm1 = d2 + 2.0 * (double)m * F[fb + m * fs];            // d_{m-1}
+      dst[ob + (m - 1) * os] = (m == 1 ? 0.5 * dm1 : dm1) * sc;
+      d2 = d1;
+      d1 = dm1;
+    }
+  }
+}
+// ---- K1i: where the gradient phases have to run (as k_bl_gradcoarse does it for K1b) -------------------------------------------
+// The coarse kernel of K1b takes a rank-r0 bilinear form sum_p Vb[p][line] S0[p][x0]; a Chebyshev series is one with
+// S0[a][x0] = T_a(xi0(x0)) and Vb[comp][a][line] = sum_b ChatT_comp[b][a] T_b(xi1(line)).
+__global__ __launch_bounds__(256) void k_i_ttab(const BlDims dm, const double* __restrict__ xn0, double* __restrict__ S0all) {
+  const int Dn = dm.D0m;
+  for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < dm.cnt0; x += (long long)gridDim.x * blockDim.x) {
+    double xi = (2.0 * xn0[x] - (dm.a[0] + dm.b[0])) / (dm.b[0] - dm.a[0]);
+    xi = xi < 1.0 ? xi : 1.0;
+    xi = xi > -1.0 ? xi : -1.0;
+    double t0 = 1.0, t1 = xi;
+    for (int a = 0; a < Dn; ++a) {
+      double v = a == 0 ? 1.0 : xi;
+      if (a >= 2) { v = 2.0 * xi * t1 - t0; t0 = t1; t1 = v; }
+      for (int o = 0; o < dm.q / 4; ++o) S0all[((size_t)o * Dn + a) * dm.cnt0 + x] = v;
+    }
+  }
+}
+// Vb[o][comp + 1][a][line] for the two gradient sums (comp 0: zero -- the slot K1b's form multiplies by xn); blockIdx.y = o.
+// A thread per (line, eight degrees a -- blockIdx.z): its T_b(xi1) in registers, the coefficients through LDS.
+template <int DM>
+__global__ __launch_bounds__(256) void k_i_rtab(const BlDims dm, const double* __restrict__ ChatT_all, const int* __restrict__ eff,
+                                                const double* __restrict__ xn1, double* __restrict__ Vball) {
+  __shared__ double Cs[DM * DM];
+  const int o = blockIdx.y, Dn = dm.D0m;
+  const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double tb[DM];
+  {
+    double xi = 0.0;
+    if (line < dm.nlines) {
+      xi = (2.0 * xn1[line] - (dm.a[1] + dm.b[1])) / (dm.b[1] - dm.a[1]);
+      xi = xi < 1.0 ? xi : 1.0;
+      xi = xi > -1.0 ? xi : -1.0;
+    }
+    tb[0] = 1.0;
+    if (DM > 1) tb[1] = xi;
+#pragma unroll
+    for (int b = 2; b < DM; ++b) tb[b] = 2.0 * xi * tb[b - 1] - tb[b - 2];
+  }
+  double* Vb = Vball + (size_t)o * 3 * Dn * dm.nlines;
+  for (int comp = 0; comp < 2; ++comp) {
+    const double* Ch = ChatT_all + (size_t)(4 * o + 2 + comp) * Dn * Dn;
+    const int B = eff[4 * (4 * o + 2 + comp) + 2] * 16;                    // degrees of axis 1 the kernels run
+    __syncthreads();
+    for (int e = threadIdx.x; e < Dn * Dn; e += blockDim.x) Cs[e] = Ch[e];
+    __syncthreads();
+    if (line < dm.nlines) {
+      for (int a = blockIdx.z * 8; a < (int)blockIdx.z * 8 + 8 && a < Dn; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < DM; ++b)
+          if (b < B) s = fma(Cs[b * Dn + a], tb[b], s);
+        Vb[((size_t)(comp + 1) * Dn + a) * dm.nlines + line] = s;
+        if (comp == 0) Vb[(size_t)a * dm.nlines + line] = 0.0;
+      }
+    }
+  }
+}
+// bound on what a gradient sum moves by over half a sampling cell, from its coefficients: sum |C| a^2 dxi0 + sum |C| b^2 dxi1
+__global__ __launch_bounds__(256) void k_i_gradslack(const BlDims dm, const double* __restrict__ ChatT_all, double dxi0, double dxi1,
+                                                     double* __restrict__ slack /* [q][2] */) {
+  __shared__ double red[4][2];
+  const int oc = blockIdx.x, o = oc >> 1, comp = oc & 1, Dn = dm.D0m, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* Ch = ChatT_all + (size_t)(4 * o + 2 + comp) * Dn * Dn;
+  double sa = 0.0, sb = 0.0;
+  for (int e = tid; e < Dn * Dn; e += blockDim.x) {
+    const double v = fabs(Ch[e]), a = (double)(e % Dn), b = (double)(e / Dn);
+    sa = fma(v, a * a, sa);
+    sb = fma(v, b * b, sb);
+  }
+  sa = wave_sum(sa);
+  sb = wave_sum(sb);
+  if (lane == 0) { red[wave][0] = sa; red[wave][1] = sb; }
+  __syncthreads();
+  if (tid == 0) {
+    sa = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    sb = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    slack[oc] = (sa * dxi0 + sb * dxi1) * (1.0 + 1e-9);
+  }
+}
+// the plan's own values at the guard band's probe points: raw[f][p] = sum over the degrees the kernels run of ChatT T_a(xi0) T_b(xi1),
+// a wave per (probe, coefficient set)
+__global__ __launch_bounds__(256) void k_gb_probe_series(const CandSpec cs, const BlDims dm, const double* __restrict__ ChatT_all,
+                                                         const int* __restrict__ eff, const double* __restrict__ xn0, const double* __restrict__ xn1,
+                                                         double* __restrict__ raw) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D0 = dm.D0m;
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= kGbProbes) return;
+  const int A = eff[4 * f] * 4, B = eff[4 * f + 2] * 16;
+  const double* Ch = ChatT_all + (size_t)f * D0 * dm.D1m;
+  long long x0, x1;
+  gb_probe_xy(cs, dm.nlines, p, x0, x1);
+  auto xi_of = [&](double xn, int axis) {
+    double xi = (2.0 * xn - (dm.a[axis] + dm.b[axis])) / (dm.b[axis] - dm.a[axis]);
+    xi = xi < 1.0 ? xi : 1.0;
+    return xi > -1.0 ? xi : -1.0;
+  };
+  const double xi0 = xi_of(xn0[x0], 0), xi1 = xi_of(xn1[x1], 1);
+  double sum = 0.0;
+  for (int b = lane; b < B; b += 64) {
+    double tb0 = 1.0, tb1 = xi1, tb = b == 0 ? 1.0 : xi1;
+    for (int k = 2; k <= b; ++k) { tb = 2.0 * xi1 * tb1 - tb0; tb0 = tb1; tb1 = tb; }
+    const double* rowp = Ch + (size_t)b * D0;
+    double row = 0.0, ta0 = 1.0, ta1 = xi0;
+    for (int a = 0; a < A; ++a) {
+      double ta = a == 0 ? 1.0 : xi0;
+      if (a >= 2) { ta = 2.0 * xi0 * ta1 - ta0; ta0 = ta1; ta1 = ta; }
+      row = fma(rowp[a], ta, row);
+    }
+    sum = fma(row, tb, sum);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) raw[(size_t)f * kGbProbes + p] = sum;
+}
+// K1i's band from its probes (as guard.hip's k_gb_band, with the mean's truncation tail and a MEASURED band of the Lipschitz
+// keys: the gradient sums are derivatives of an interpolant).  raw [4 q][P]; ref_g [q][2][P] the exact gradient components.
+__global__ __launch_bounds__(256) void k_gb_band_i(const ModelConst mc, const double* __restrict__ raw, const double* __restrict__ ref_m,
+                                                   const double* __restrict__ ref_v, const double* __restrict__ ref_g,
+                                                   const double* __restrict__ tail /* [4 q] */, GuardBand* gb) {
+  __shared__ double sh[4][6];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int o = 0; o < mc.q; ++o) {
+    const double ys = mc.Y_std[o];
+    double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // |dm|, |dv|, |m|, |v|, |dg|, |g|
+    bool bad = false;
+    for (int p = tid; p < kGbProbes; p += blockDim.x) {
+      double var = mc.sf2[o] - raw[(size_t)(4 * o) * kGbProbes + p];
+      var = (var > 0.0 ? var : 0.0) * (ys * ys);
+      const double m = (mc.mp[o] + raw[(size_t)(4 * o + 1) * kGbProbes + p]) * ys + mc.Y_mean[o];
+      const double rm = ref_m[(size_t)o * kGbProbes + p], rv = ref_v[(size_t)o * kGbProbes + p];
+      const double dm_ = fabs(m - rm), dv_ = fabs(var - rv);
+      bad = bad || !(dm_ < kGbInf) || !(dv_ < kGbInf);
+      e[0] = fmax(e[0], dm_); e[1] = fmax(e[1], dv_); e[2] = fmax(e[2], fabs(rm)); e[3] = fmax(e[3], fabs(rv));
+      for (int a = 0; a < 2; ++a) {
+        const double g = ys * mc.inv_ell[o][a] * mc.X_rstd[a] * raw[(size_t)(4 * o + 2 + a) * kGbProbes + p];
+        const double rg = ref_g[((size_t)o * 2 + a) * kGbProbes + p];
+        bad = bad || !(fabs(g - rg) < kGbInf);
+        e[4] = fmax(e[4], fabs(g - rg));
+        e[5] = fmax(e[5], fabs(rg));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) e[k] = fmax(e[k], __shfl_xor(e[k], off));
+    __syncthreads();
+    if (lane == 0)
+      for (int k = 0; k < 6; ++k) sh[wave][k] = e[k];
+    if (lane == 1 && bad) sh[wave][0] = kGbInf;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        for (int k = 0; k < 6; ++k) e[k] = fmax(e[k], sh[w][k]);
+      e[0] = fmax(e[0], sh[0][0]);
+      const double eps = 2.220446049250313e-16;
+      const bool inf = !(e[0] < kGbInf);
+      gb->dm[o] = inf ? kGbInf : 16.0 * e[0] + tail[4 * o + 1] * ys + 64.0 * eps * fmax(e[2], fabs(mc.Y_mean[o]) + ys);
+      gb->dv[o] = inf ? kGbInf : 16.0 * e[1] + tail[4 * o] * ys * ys + 64.0 * eps * fmax(e[3], mc.sf2[o] * ys * ys);
+      gb->rl[o] = (e[5] > 0.0 && !inf) ? 16.0 * e[4] / e[5] + 1e-9 : 1e-3;
+    }
+    __syncthreads();
+  }
+}
+
+bool interp_applicable(const sbo_ctx* c) {
+  if (c->bilinear != 1 || c->is_shadow || !bilinear_applicable(c)) return false;
+  // (the node values come from the reference formula on the caller's matrix: the packed images sbo_model_set made of it)
+  // (a grid that arrived after the model: the images are packed on demand from the upload that still sits in the build workspace)
+  return c->mc.factor == SBO_FACTOR_INVK && c->chol_async && (c->invk_img_valid || c->invk_w_valid) && c->mc.npad % 16 == 0 &&
+         c->dtype == SBO_F64;
+}
+
+// Enqueues the plan for the current (model, grid) on the context's streams; nothing waits for the device.
+int interp_setup(sbo_ctx* c) {
+  InterpPlan& ip = c->bi;
+  ip.valid = true;
+  ip.usable = false;
+  ip.used = false;
+  ip.serial = c->model_serial;
+  const ModelConst& mc = c->mc;
+  const CandSpec& cs = c->cs;
+  const int n = mc.n, q = mc.q;
+  const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0, line0 = cs.first / cnt0;
+  double ab[4];
+  if (!basis_intervals(c, ab)) return SBO_OK;
+  // nodes per axis from the shortest length scale (tensor.hip's rule for its first two axes), one count for both
+  int Dn = 32;
+  for (int a = 0; a < 2; ++a) {
+    double tmax = 0.0;
+    for (int o = 0; o < q; ++o) tmax = std::max(tmax, (ab[2 * a + 1] - ab[2 * a]) * std::sqrt(mc.inv_ell[o][a]));
+    const double want = 7.6 * tmax;
+    const int need = want <= 32 ? 32 : (want <= 48 ? 48 : (want <= 64 ? 64 : 1 << 20));
+    Dn = std::max(Dn, need);
+  }
+  if (Dn > kIMaxDn || 2 * Dn > cnt0 || 2 * Dn > cs.count[1]) return SBO_OK;      // (not worth it / not resolvable: K1b's plan takes over)
+  const int QP = 4 * q;
+  if (QP > 4 * kMaxQ) return SBO_OK;
+  int rc;
+  if (!c->invk_img_valid && (rc = model_pack_invk(c))) return rc;
+  BlDims dm;
+  memset(&dm, 0, sizeof(dm));
+  const int KB = Dn / 16, KBn = mc.npad / 16, ncols = Dn * Dn, ncsR = ncols / 16;
+  const int ncs0 = (int)((cnt0 + 15) / 16), nrb = (int)((nlines + 15) / 16);
+  dm.q = QP; dm.n = n; dm.KBn = KBn; dm.ncsR = ncsR;
+  for (int o = 0; o < kMaxQ; ++o) { dm.r0[o] = Dn; dm.r1[o] = Dn; dm.rc0[o] = Dn; dm.rc1[o] = Dn; }
+  dm.r0u = dm.r1u = Dn; dm.KB0 = dm.KB1 = KB; dm.D0m = dm.D1m = Dn; dm.ncs0 = ncs0; dm.nrb = nrb; dm.cnt0 = cnt0; dm.nlines = nlines;
+  for (int a = 0; a < 2; ++a) { dm.a[a] = ab[2 * a]; dm.b[a] = ab[2 * a + 1]; }
+  InterpDims id;
+  id.Dn = Dn; id.q = q; id.n = n; id.npad = mc.npad; id.dpad = mc.dpad;
+  for (int a = 0; a < 2; ++a) { id.mid[a] = 0.5 * (ab[2 * a] + ab[2 * a + 1]); id.half[a] = 0.5 * (ab[2 * a + 1] - ab[2 * a]); }
+  ip.Dn = Dn; ip.KB = KB; ip.ncs0 = ncs0; ip.nrb = nrb;
+  ip.sT4f = (size_t)KB * KB * 256;
+  ip.sBtA = (size_t)nrb * KB * 256;
+  const size_t nP0f = (size_t)ncs0 * KB * 256, nP1A = (size_t)nrb * KB * 256, nZf = (size_t)ncsR * KBn * 256;
+  if ((rc = ensure(c->bl_P0f, sizeof(double) * nP0f))) return rc;
+  if ((rc = ensure(c->bl_P1A, sizeof(double) * nP1A))) return rc;
+  if ((rc = ensure(c->bl_T4f, sizeof(double) * ip.sT4f * QP))) return rc;
+  if ((rc = ensure(c->bl_BtA, sizeof(double) * ip.sBtA * QP))) return rc;
+  if ((rc = ensure(c->bl_small, sizeof(double) * ((size_t)cnt0 + (size_t)nlines)))) return rc;
+  // bl_work: E tables [2 q][kBlMaxR][n] | Zf | Cf | CtA (3 x q x nZf) | node fields [q][2][Dn^2]
+  const size_t nE = (size_t)2 * q * kBlMaxR * n;
+  if ((rc = ensure(c->bl_work, sizeof(double) * (nE + 3 * (size_t)q * nZf + (size_t)q * 2 * ncols)))) return rc;
+  // bl_cheb: ChatT [4 q][Dn^2] | eff (4 QP ints) + tails (QP doubles)
+  if ((rc = ensure(c->bl_cheb, sizeof(double) * ((size_t)QP * ncols + 4 * (size_t)QP + 16)))) return rc;
+  double* E = (double*)c->bl_work.p;
+  double* Zf = E + nE;
+  double* Cf = Zf + (size_t)q * nZf;
+  double* CtA = Cf + (size_t)q * nZf;
+  double* V = CtA + (size_t)q * nZf;
+  double* Chat = (double*)c->bl_cheb.p;
+  int* eff = (int*)(Chat + (size_t)QP * ncols);
+  double* dxn0 = (double*)c->bl_small.p;
+  double* dxn1 = dxn0 + cnt0;
+  const unsigned uq = (unsigned)q;
+  auto blocks = [&](size_t total, unsigned y) { return dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16), y); };
+  hipStream_t xs = c->stream, ys = c->stream2 ? c->stream2 : c->stream, zs = (ys != xs && c->stream3) ? c->stream3 : ys;
+  if (ys != xs) {
+    SBO_HIP(hipEventRecord(c->ev[7], xs));                 // (the model's arrays are in place at this point of the main stream)
+    SBO_HIP(hipStreamWaitEvent(ys, c->ev[7], 0));
+    if (zs != ys) SBO_HIP(hipStreamWaitEvent(zs, c->ev[7], 0));
+  }
+  // X: node fields and their coefficients
+  hipLaunchKernelGGL(k_i_etab, blocks((size_t)Dn * n, 2 * uq), dim3(256), 0, xs, mc, id, (const double*)c->As.p, E);
+  hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, xs, dm, (const double*)E, nZf, Zf);
+  hipLaunchKernelGGL((k_bgemm<4, 0, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, xs,
+                     (const double*)c->invk_img.p, (size_t)mc.npad * mc.npad, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
+  hipLaunchKernelGGL(k_i_nodevals, dim3((unsigned)ncsR, uq), dim3(64), 0, xs, KBn, n, (const double*)Zf, (const double*)Cf, nZf,
+                     (const double*)c->alpha64.p, c->a_ld, ncols, V);
+  {
+    const size_t lds = sizeof(double) * 3 * (size_t)Dn * (Dn + 1);
+    SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_i_dct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_i_dct, dim3(2 * uq), dim3(1024), lds, xs, mc, id, (const double*)V, Chat);
+  }
+  hipLaunchKernelGGL(k_cheb_trunc, dim3((unsigned)QP), dim3(1024), 0, xs, dm, (const double*)Chat, c->cheb_tol, eff);
+  hipLaunchKernelGGL(k_cheb_t4f, blocks(ip.sT4f, (unsigned)QP), dim3(256), 0, xs, dm, (const double*)Chat, ip.sT4f, (double*)c->bl_T4f.p);
+  SBO_HIP(hipMemcpyAsync(c->h_back + 5376, eff, sizeof(int) * 4 * std::min(QP, 8), hipMemcpyDeviceToHost, xs));
+  // ... and which tiles of k_bpost can hold the largest gradient component (the gate of K1b's gradient phases, fed from the series)
+  ip.gtmax = nullptr;
+  ip.gkey = nullptr;
+  {
+    const int ntx = (ncs0 + 7) / 8, nty = (nrb + 3) / 4;
+    const size_t nt = (size_t)ntx * nty, head = (size_t)q * 2 * nt + 4 * (size_t)q;
+    const size_t nS0 = (size_t)q * Dn * cnt0, nVb = (size_t)q * 3 * Dn * nlines;
+    if ((rc = ensure(c->bl_grad, sizeof(double) * (head + nS0 + nVb)))) return rc;
+    double* gt = (double*)c->bl_grad.p;
+    double* slack = gt + (size_t)q * 2 * nt;
+    unsigned long long* gkey = (unsigned long long*)(slack + 2 * q);
+    double* S0i = (double*)(gkey + 2 * q);
+    double* Vbi = S0i + nS0;
+    const double dxi0 = cs.count[0] > 1 ? 0.5 * kGradStep * std::fabs(cs.step[0] / mc.X_std[0]) / id.half[0] : 0.0;
+    const double dxi1 = cs.count[1] > 1 ? 0.5 * kGradStep * std::fabs(cs.step[1] / mc.X_std[1]) / id.half[1] : 0.0;
+    BlDims dg = dm;                       // (k_bl_gradcoarse: a form of rank Dn)
+    dg.q = QP;
+    SBO_HIP(hipMemsetAsync(gkey, 0, sizeof(unsigned long long) * 2 * q, xs));
+    hipLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, xs, dm, (const double*)Chat, dxi0, dxi1, slack);
+    ip.grad_S0 = S0i;
+    ip.grad_Vb = Vbi;
+    ip.grad_gt = gt;
+    ip.grad_key = gkey;
+    if (std::isfinite(dxi0) && std::isfinite(dxi1)) {
+      ip.gtmax = gt;
+      ip.gkey = gkey;
+    }
+  }
+  // Y: the tables of the grid positions
+  hipLaunchKernelGGL(k_bl_axes, dim3((unsigned)std::min<long long>((cnt0 + nlines + 255) / 256, 4096)), dim3(256), 0, ys, mc, cs, cnt0, line0,
+                     nlines, dxn0, dxn1);
+  hipLaunchKernelGGL((k_cheb_tab<1>), dim3((unsigned)((ncs0 * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn0, (double*)c->bl_P0f.p);
+  hipLaunchKernelGGL((k_cheb_tab<0>), dim3((unsigned)((nrb * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn1, (double*)c->bl_P1A.p);
+  hipLaunchKernelGGL(k_i_ttab, dim3((unsigned)std::min<long long>((cnt0 + 255) / 256, 4096)), dim3(256), 0, ys, dm, (const double*)dxn0, ip.grad_S0);
+  if (ys != xs) SBO_HIP(hipEventRecord(c->ev_join[3], ys));
+  // Z: the guard band's references at the probe points -- the reference formula (guard.hip) and the exact gradient
+  const bool band = c->guard_band != 0;
+  double *gref_m = nullptr, *gref_v = nullptr, *raw = nullptr, *pgrad = nullptr;
+  if (band) {
+    // probe buffers: raw [4 q][P] | points [P][2] | exact gradient [q][2][P]
+    if ((rc = ensure(c->gb_pts, sizeof(double) * ((size_t)QP * kGbProbes + 2 * (size_t)kGbProbes + 2 * (size_t)q * kGbProbes)))) return rc;
+    raw = (double*)c->gb_pts.p;
+    double* ppts = raw + (size_t)QP * kGbProbes;
+    pgrad = ppts + 2 * (size_t)kGbProbes;
+    if ((rc = guard_probe_reference(c, zs, &gref_m, &gref_v))) return rc;
+    if ((rc = guard_probe_gradients(c, zs, ppts, pgrad))) return rc;
+    if (zs != ys) SBO_HIP(hipEventRecord(c->ev_join[6], zs));
+  }
+  if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
+  // (X again, with the tables of Y: the lines' sums of the gradient series and the sums at the cell centres of every tile)
+  if (ip.gtmax) {
+    const int ntx = (ncs0 + 7) / 8, nty = (nrb + 3) / 4;
+    BlDims dg = dm;
+    dg.q = QP;
+    dg.r0u = Dn;
+    switch (Dn) {
+      case 32: hipLaunchKernelGGL((k_i_rtab<32>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, xs, dg, (const double*)Chat, (const int*)eff, (const double*)dxn1, ip.grad_Vb); break;
+      case 48: hipLaunchKernelGGL((k_i_rtab<48>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, xs, dg, (const double*)Chat, (const int*)eff, (const double*)dxn1, ip.grad_Vb); break;
+      default: hipLaunchKernelGGL((k_i_rtab<64>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, xs, dg, (const double*)Chat, (const int*)eff, (const double*)dxn1, ip.grad_Vb); break;
+    }
+    hipLaunchKernelGGL(k_bl_gradcoarse, dim3((unsigned)(ntx * nty), uq), dim3(128), 0, xs, dg, (const double*)ip.grad_S0, (const double*)ip.grad_Vb,
+                       (const double*)dxn0, (const double*)dxn1, ntx, ip.grad_gt, ip.grad_key);
+    hipLaunchKernelGGL(k_bl_gradmax, dim3(2 * uq), dim3(256), 0, xs, (const double*)ip.grad_gt, ntx * nty, ip.grad_key);
+  }
+  if (band) {
+    if (zs != ys) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[6], 0));
+    hipLaunchKernelGGL(k_gb_probe_series, dim3((unsigned)((kGbProbes + 3) / 4), (unsigned)QP), dim3(256), 0, xs, cs, dm, (const double*)Chat,
+                       (const int*)eff, (const double*)dxn0, (const double*)dxn1, raw);
+    hipLaunchKernelGGL(k_gb_band_i, dim3(1), dim3(256), 0, xs, mc, (const double*)raw, (const double*)gref_m, (const double*)gref_v,
+                       (const double*)pgrad, reinterpret_cast<const double*>(eff + 4 * QP), (GuardBand*)c->gb.p);
+    c->gb_host_valid = false;
+  }
+  SBO_HIP(hipGetLastError());
+  ip.eff = eff;
+  ip.band_ready = band;
+  ip.usable = true;
+  return SBO_OK;
+}
+
+int launch_posterior_interp(sbo_ctx* c) {
+  InterpPlan& ip = c->bi;
+  const ModelConst& mc = c->mc;
+  const CandSpec& cs = c->cs;
+  const int q = mc.q, QP = 4 * q, KB = ip.KB;
+  const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0;
+  ip.used = true;
+  constexpr int S1 = 3;
+  hipLaunchKernelGGL((k_bstage1<S1>), dim3((unsigned)((KB + S1 - 1) / S1), (unsigned)((ip.nrb + 3) / 4), (unsigned)QP), dim3(256), 0, c->stream,
+                     (const double*)c->bl_P1A.p, (size_t)0, (const double*)c->bl_T4f.p, ip.sT4f, KB, ip.nrb, KB, (double*)c->bl_BtA.p, ip.sBtA,
+                     (const int*)ip.eff);
+  const unsigned gx = (unsigned)((ip.ncs0 + 7) / 8), gy = (unsigned)((ip.nrb + 3) / 4);
+  const unsigned rows_out = gx * gy;
+  const size_t lds = sizeof(double) * 2 * 3072;
+  int rc;
+  if ((rc = ensure(c->bl_lpart, sizeof(double) * (size_t)rows_out * q))) return rc;
+  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
+  const bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local && c->maskU.bytes >= (size_t)cs.n_local;
+  c->fuse_rows = 0;
+  if (fuse) {
+    c->fuse_rows = (int)rows_out;
+    if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
+    c->cpart_cap = (int)(c->cpart.bytes / (sizeof(unsigned long long) * kFuseRow));
+  }
+  const GuardBand* gb_fused = (c->guard_band && ip.band_ready && c->gb.p) ? (const GuardBand*)c->gb.p : nullptr;
+  auto kpost = k_bpost<1>;
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const double* BtA = (const double*)c->bl_BtA.p;
+  hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream, nullptr, c->lmax_defer ? c->ev[1] : nullptr, 0, mc, cs, BtA,
+                        4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, BtA + ip.sBtA, 4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, KB,
+                        KB * 4, KB, KB * 4, KB, ip.nrb, ip.ncs0, nlines, (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p,
+                        (const double*)c->bl_small.p /* xn0 */, fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr,
+                        fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b, (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused,
+                        (const int*)ip.eff, ip.gtmax, ip.gkey, 1);
+  if (c->lmax_defer) {
+    c->lmax_pending = true;
+    c->lmax_per_out = (int)rows_out;
+  } else {
+    hipExtLaunchKernelGGL(k_lmax_reduce, dim3((unsigned)q), dim3(256), 0, c->stream, nullptr, c->ev[1], 0, (const double*)c->bl_lpart.p,
+                          (int)rows_out, (unsigned long long*)c->Lmax.p);
+  }
+  c->k1_stop_attached = true;
+  c->gb_active = c->guard_band && ip.band_ready;
+  // flops issued: stage 1 of four coefficient sets per output + four full phases of stage 2 (upper bound: the counts the kernels run
+  // to live on the device)
+  const double tiles2 = (double)ip.nrb * ip.ncs0;
+  c->last_k1_flops = (double)q * 2.0 * 1024.0 * 4.0 * (4.0 * (double)ip.nrb * KB * KB + tiles2 * KB * 4);
+  const int* he = (const int*)(c->h_back + 5376);
+  if (QP <= 8) {
+    double f = 0.0;
+    bool ok = true;
+    for (int z = 0; z < QP; ++z) {
+      const int ks = he[4 * z], kb0 = he[4 * z + 1], kb1 = he[4 * z + 2];
+      if (ks < 1 || ks > KB * 4 || kb0 < 1 || kb0 > KB || kb1 < 1 || kb1 > KB) { ok = false; break; }
+      f += 2.0 * 1024.0 * (4.0 * (double)ip.nrb * kb0 * kb1 + tiles2 * ks);
+    }
+    if (ok) c->last_k1_flops = f;
+  }
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
 int launch_posterior_bilinear(sbo_ctx* c) {
   const BilinearPlan& pl = c->bl;
   const ModelConst& mc = c->mc;
@@ -2333,7 +2864,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                         pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
                         (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
                         fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                        (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused, (const int*)pl.eff, pl.gtmax, pl.gkey);
+                        (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused, (const int*)pl.eff, pl.gtmax, pl.gkey, 0);
   if (c->lmax_defer) {
     c->lmax_pending = true;
     c->lmax_per_out = (int)rows_out;

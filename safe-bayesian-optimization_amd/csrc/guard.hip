@@ -178,6 +178,46 @@ __global__ __launch_bounds__(256) void k_grad_list(const ModelConst mc, const do
   }
 }
 
+// the same for a SHORT list (the probe points of a plan): a wave per point, lanes over the observations (a thread per point walks
+// q n exponentials: 0.25 ms for 144 points at n = 512)
+template <int D>
+__global__ __launch_bounds__(256) void k_grad_list_w(const ModelConst mc, const double* __restrict__ pts, long long N,
+                                                     const double* __restrict__ As, const double* __restrict__ sqA,
+                                                     const double* __restrict__ alpha, const double* __restrict__ Xn, double* __restrict__ out) {
+  const int n = mc.n, npad = mc.npad, lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  double xn[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) xn[a] = a < mc.d ? (pts[(size_t)i * mc.d + a] - mc.X_mean[a]) / mc.X_std[a] : 0.0;
+  for (int o = 0; o < mc.q; ++o) {
+    double bq[D], sqb = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      bq[a] = a < mc.d ? xn[a] * mc.vinv[o][a] : 0.0;
+      sqb += bq[a] * bq[a];
+    }
+    double s0 = 0.0, sa[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) sa[a] = 0.0;
+    for (int j = lane; j < n; j += 64) {
+      double dot = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) dot += As[((size_t)o * npad + j) * D + a] * bq[a];
+      const double w = alpha[(size_t)o * npad + j] * (mc.sf2[o] * exp(-0.5 * ((-2.0 * dot + sqA[(size_t)o * npad + j]) + sqb)));
+      s0 += w;
+#pragma unroll
+      for (int a = 0; a < D; ++a) sa[a] += w * Xn[(size_t)j * D + a];
+    }
+    s0 = wave_sum(s0);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const double s = wave_sum(sa[a]);
+      if (lane == 0 && a < mc.d) out[((size_t)o * mc.d + a) * N + i] = mc.Y_std[o] * (s - xn[a] * s0) * mc.inv_ell[o][a] * mc.X_rstd[a];
+    }
+  }
+}
+
 // K1b's band from its probes: one workgroup.  ref_m / ref_v [q][P]: the exact evaluator at the probe points; pm / pv: K1b's own
 // representation evaluated there (bilinear.hip: k_gb_probe_k1b -- the sums the two GEMMs form, in another order); tail[o]: sum of
 // the Chebyshev coefficients of the variance's quadratic form that the kernels do not run (normalised variance units;
@@ -255,7 +295,7 @@ static int launch_ref(sbo_ctx* c, hipStream_t st, const double* pts, long long N
 
 int guard_exact_list(sbo_ctx* c, const double* pts, long long N, double* mean_out, double* var_out) {
   if (N <= 0) return SBO_OK;
-  if (c->last_k1 == 4 && ref_direct(c)) {
+  if ((c->last_k1 == 4 || c->last_k1 == 6) && ref_direct(c)) {
     switch (c->mc.dpad) {
       case 2: return launch_ref<2>(c, c->stream, pts, N, 0, mean_out, var_out);
       case 4: return launch_ref<4>(c, c->stream, pts, N, 0, mean_out, var_out);
@@ -312,6 +352,15 @@ int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double**
   double* ppts = *ref_m + 4 * (size_t)q * kGbProbes;
   hipLaunchKernelGGL(k_gb_probe_pts, dim3(1), dim3(kGbProbes), 0, c->stream, c->cs, nlines, ppts);
   return launch_posterior_on_list(c, ppts, kGbProbes, *ref_m, *ref_v);
+}
+// the probe points as a list [P][d] and the exact gradient components of the mean there ([q][d][P]), on `st` (2-D grids)
+int guard_probe_gradients(sbo_ctx* c, hipStream_t st, double* ppts, double* grad_out) {
+  if (c->dtype != SBO_F64 || c->mc.dpad != 2) return fail(SBO_E_UNSUPPORTED, "internal: probe gradients are an fp64 2-D path");
+  hipLaunchKernelGGL(k_gb_probe_pts, dim3(1), dim3(kGbProbes), 0, st, c->cs, c->cs.n_local / c->cs.count[0], ppts);
+  hipLaunchKernelGGL(k_grad_list_w<2>, dim3((kGbProbes + 3) / 4), dim3(256), 0, st, c->mc, (const double*)ppts, (long long)kGbProbes,
+                     (const double*)c->As.p, (const double*)c->sqA.p, (const double*)c->alpha.p, (const double*)c->Xn.p, grad_out);
+  SBO_HIP(hipGetLastError());
+  return SBO_OK;
 }
 int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail) {
   hipLaunchKernelGGL(k_gb_band, dim3(1), dim3(256), 0, c->stream, c->mc, pm, pv, ref_m, ref_v, tail, (GuardBand*)c->gb.p);

@@ -59,6 +59,22 @@ struct BilinearPlan {
   bool band_ready = false;   // the guard band of this plan has been measured (guard.hip: guard_band_bilinear)
 };
 
+// K1i: the first sweep of a model by interpolation from Chebyshev nodes (bilinear.hip)
+struct InterpPlan {
+  bool valid = false;    // enqueued (or found not applicable) for model `serial` and the current grid
+  bool usable = false;
+  bool used = false;     // a sweep has run on it: the next one builds K1b's own plan
+  bool band_ready = false;
+  unsigned long long serial = 0;
+  int Dn = 0, KB = 0, ncs0 = 0, nrb = 0;
+  size_t sT4f = 0, sBtA = 0;
+  int* eff = nullptr;    // device: per coefficient set (4 per output) the counts the kernels run to, then the truncation tails
+  const double* gtmax = nullptr;              // which tiles run the gradient phases (as BilinearPlan's)
+  const unsigned long long* gkey = nullptr;
+  double *grad_S0 = nullptr, *grad_Vb = nullptr, *grad_gt = nullptr;
+  unsigned long long* grad_key = nullptr;
+};
+
 }  // namespace sbo
 
 struct sbo_ctx {
@@ -175,6 +191,7 @@ struct sbo_ctx {
   sbo::DevBuf blockmax; // per-block largest source weight along axis 0 (blocked axis-0 pass of the power transform)
   sbo::DevBuf blockmin; // per-block minima along the last axis (blocked last-axis scans)
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
+  sbo::InterpPlan bi;   // K1i plan (first sweep of a model)
   sbo::DevBuf bl_grad;  // K1b: which tiles run the gradient phases (per plan)
   sbo::DevBuf bl_lpart; // K1b: per-wave Lipschitz partials of k_bpost
   sbo::DevBuf cpart;   // per-workgroup partials of k_classify, field-major [kClassifyRow][cpart_cap]
@@ -278,6 +295,10 @@ int model_append(sbo_ctx* c, const std::vector<double>& kvec /*[q][n]*/, const d
 int model_repack(sbo_ctx* c);
 bool bilinear_applicable(const sbo_ctx* c);
 int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big);
+bool interp_applicable(const sbo_ctx* c);
+int interp_setup(sbo_ctx* c);
+int launch_posterior_interp(sbo_ctx* c);
+int guard_probe_gradients(sbo_ctx* c, hipStream_t st, double* ppts, double* grad_out);
 int bilinear_setup(sbo_ctx* c);
 int launch_posterior_bilinear(sbo_ctx* c);
 bool tensor_applicable(const sbo_ctx* c);

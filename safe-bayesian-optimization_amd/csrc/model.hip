@@ -705,7 +705,11 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
   double* dalpha = (double*)c->alpha64.p;
   if ((rc = model_prep_t<T>(c, X_norm, Y_norm, w))) return rc;
   bool eager_basis = false;
-  if (bilinear_applicable(c)) {
+  // (r04) a caller's invK on a K1b-capable grid: the model's first sweep runs on interpolated node values (K1i, bilinear.hip), which
+  // needs no bases -- they are made when the model is swept a second time
+  const bool interp_first = bilinear_applicable(c) && c->bilinear == 1 && host_invK != nullptr && n >= kBlockedFrom && c->chol_async &&
+                            !c->is_shadow && c->stream4 && std::is_same<T, double>::value && c->mc.npad % 16 == 0;
+  if (bilinear_applicable(c) && !interp_first) {
     // the bases need X_norm only: next to the factorisation, on the second stream -- and ahead of the upload of invK
     // (4 MB at n = 512, ~0.15 ms of pageable copies the host sits in): their pivot loop is the longest chain of a model change
     SBO_HIP(hipEventRecord(c->ev[6], c->stream));
@@ -728,7 +732,7 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
   // not even enqueued here (the host needs ~0.1 ms for them): the next sweep does that while it waits for its own result
   // (model_factor_enqueue), a consumer of the factor before that enqueues and waits (factor_sync), and a model replaced
   // before anyone asked never factors at all.
-  const bool deferred = mode == 0 && n >= kBlockedFrom && c->chol_async && !c->is_shadow && eager_basis && c->stream4 &&
+  const bool deferred = mode == 0 && n >= kBlockedFrom && c->chol_async && !c->is_shadow && (eager_basis || interp_first) && c->stream4 &&
                         std::is_same<T, double>::value;
   const size_t ntri = (size_t)nb * (nb + 1) / 2;
   c->fpk_stride = ntri * 4 * 64;

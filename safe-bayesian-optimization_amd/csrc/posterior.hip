@@ -911,6 +911,15 @@ int launch_posterior(sbo_ctx* c) {
     // fp64 2-D grids: two GEMMs in a reduced basis (K1b) when the axis bases qualify, else the separable tables (K1g)
     if (bilinear_applicable(c)) {
       int rc;
+      // the first sweep of a model: interpolation from Chebyshev nodes (K1i, enqueued by sbo_model_set -- or here, when the grid
+      // came after the model); K1b's plan is built when the same model is swept again
+      if (!c->bl.valid && interp_applicable(c)) {
+        if (!(c->bi.valid && c->bi.serial == c->model_serial) && (rc = interp_setup(c))) return rc;
+        if (c->bi.usable && !c->bi.used) {
+          c->last_k1 = 6;
+          return launch_posterior_interp(c);
+        }
+      }
       if (!c->bl.valid && (rc = bilinear_setup(c))) return rc;
       if (c->bl.usable) {
         c->last_k1 = 4;

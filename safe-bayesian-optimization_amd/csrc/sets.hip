@@ -1632,7 +1632,9 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
     }
     // (a caller's invK whose reverse factor is still to be made: its ~20 launches are enqueued now, on their own stream,
     // while the host would otherwise only wait for the sweep -- model.hip: model_factor_enqueue)
-    { const int rcf = model_factor_enqueue(c); if (rcf) return rcf; }
+    // (r04: no longer -- the chain's twenty launches run BESIDE the next model's upload, plan and sweep and cost them CUs: k_bpost
+    // 206 -> 217 us, the plan's small kernels up to 4 x; the GEMM posteriors never need the factor, and whoever does --
+    // the O(n^2) kernels, sbo_model_append -- enqueues it and waits in factor_sync)
     SBO_HIP(stream_wait(c, c->stream));
     ++c->host_syncs;
     memset(&h, 0, sizeof(h));

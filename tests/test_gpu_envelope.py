@@ -84,9 +84,11 @@ def test_posterior_over_the_whole_reference_box(engine, cfg_name, n, log_sn, log
     assert 3 in seen
 
 
-def test_fitted_campaign_models_match_the_oracle():
+@pytest.mark.parametrize("bilinear,gemm_kernel", [(1, 6), (2, 4)])
+def test_fitted_campaign_models_match_the_oracle(bilinear, gemm_kernel):
     """The reference's SafeOpt loop (test/test_SafeOpt.py:135-186) with its own DE fit after every sample, n = 4 ... 17:
-    every fitted model swept on the device and by the oracle."""
+    every fitted model swept on the device and by the oracle.  Every model of the loop is swept ONCE: with the default options that
+    is the node-interpolation posterior K1i (kernel 6); option bilinear = 2 builds K1b's plan for the first sweep (kernel 4)."""
     def benoit_f(u, noise=0):
         return u[0] ** 2 + u[1] ** 2 + u[0] * u[1]
 
@@ -97,6 +99,7 @@ def test_fitted_campaign_models_match_the_oracle():
     grid = (72, 70)
     m = SafeOpt.BO([benoit_f, benoit_g], bound, 3.0, grid=grid, seed=7)
     m.de_options = {"seed": 3, "maxiter": 40, "tol": 1e-3}
+    m.engine.set_option("bilinear", bilinear)
     X, Y = m.Data_sampling(4, np.array([1.4, -.8]), 0.3)            # test/test_SafeOpt.py:28-31
     m.GP_initialization(X, Y, "RBF", multi_hyper=5, var_out=True)
     pts = oracle.grid_points(bound[:, 0], bound[:, 1], list(grid))
@@ -131,7 +134,7 @@ def test_fitted_campaign_models_match_the_oracle():
         x_new = res["minimizer_x"] if res["choose_minimizer"] else res["expander_x"]
         m.add_sample(x_new, m.calculate_plant_outputs(x_new))
     assert worst_cond > 1e6          # the campaign really reaches the ill-conditioned regime every fitted model lives in
-    assert kernels == {3, 4}         # the first tiny models run K1g, the rest the GEMM posterior
+    assert kernels == {3, gemm_kernel}   # the first tiny models run K1g, the rest the GEMM posterior
     assert near_total == 0           # (reported: no candidate of this campaign sits inside the rounding band)
 
 

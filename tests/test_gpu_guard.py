@@ -63,10 +63,12 @@ def _same_decisions(a, b_, ystd0, what, floats=True):
                 assert np.array_equal(np.asarray(v), np.asarray(w)), (what, sweep, k, v, w)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("cfg_name,n,count,b,use_invK", [("B", 128, [320, 300], 3.0, True), ("H", 300, [200, 144], 3.0, True),
                                                            ("C", 96, [260, 250], 2.0, True), ("B", 64, [130, 70], 3.0, False)])
-def test_guard_band_forced_reevaluation_equals_the_first_pass_2d(engine, cfg_name, n, count, b, use_invK):
-    """K1b on 2-D grids.  The band is measured per plan on the device (256 probes against the reference formula with the caller's
+def test_guard_band_forced_reevaluation_equals_the_first_pass_2d(engine, cfg_name, n, count, b, use_invK, mode):
+    """The GEMM posteriors on 2-D grids: option bilinear = 1 sweeps a new model with a caller's invK on interpolated node values
+    first (K1i, kernel 6), bilinear = 2 on K1b's own plan (kernel 4; also what 1 does with the library's factor).  The band is measured per plan on the device (256 probes against the reference formula with the caller's
     invK as given, or the generic kernel with the library's factor) and reported by the profile; on these models no decision of
     a sweep falls inside it (guard_band == 0: the first pass is the result).  Forcing the re-evaluation path (option guard_band =
     2: interval passes, exact list evaluation in place, exact Lipschitz keys, second set phase) must reproduce every mask, count
@@ -81,16 +83,16 @@ def test_guard_band_forced_reevaluation_equals_the_first_pass_2d(engine, cfg_nam
         engine.set_grid(lo, hi, count)
         for key, opts in (("fast", dict(guard_band=1)), ("forced", dict(guard_band=2)), ("off", dict(guard_band=0)),
                           ("k1g", dict(bilinear=0))):
+            engine.set_option("bilinear", mode)
             for k, v in opts.items():
                 engine.set_option(k, v)
             engine.set_model(cfg["ds"], use_invK=use_invK)
             out[key] = _bundle(engine, cfg, b, q, d, fresh=False)
             engine.set_option("guard_band", 1)
-            engine.set_option("bilinear", 1)
     finally:
         engine.set_option("guard_band", 1)
         engine.set_option("bilinear", 1)
-    assert out["fast"]["prof"]["posterior_kernel"] == 4 and out["k1g"]["prof"]["posterior_kernel"] == 3
+    assert out["fast"]["prof"]["posterior_kernel"] == (6 if mode == 1 and use_invK else 4) and out["k1g"]["prof"]["posterior_kernel"] == 3
     ys = np.maximum(1.0, cfg["ds"]["Y_std"])
     dm, dv = np.array(out["fast"]["prof"]["guard_dm"][:q]), np.array(out["fast"]["prof"]["guard_dv"][:q])
     assert np.all(dm > 0) and np.all(dv > 0) and np.all(dm / ys < 1e-10) and np.all(dv / ys ** 2 < 1e-10), (dm, dv)
@@ -104,9 +106,10 @@ def test_guard_band_forced_reevaluation_equals_the_first_pass_2d(engine, cfg_nam
     _same_decisions(out["fast"], out["k1g"], ys[0], "k1g")
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("cfg_name,n,count,b,tol_e17", [("B", 128, [320, 300], 3.0, 10 ** 11), ("H", 300, [400, 344], 3.0, 10 ** 12),
                                                           ("C", 96, [260, 250], 2.0, 10 ** 11)])
-def test_guard_band_restores_the_exact_masks_under_a_coarse_chebyshev_cut(engine, cfg_name, n, count, b, tol_e17):
+def test_guard_band_restores_the_exact_masks_under_a_coarse_chebyshev_cut(engine, cfg_name, n, count, b, tol_e17, mode):
     """The mechanism under load: with the Chebyshev core cut at 1e-6 / 1e-7 of its largest coefficient instead of 4e-15
     (option cheb_tol_e17) K1b's variance is off by ~1e-6 -- far more than any mask tolerates.  The plan's band follows (probe
     deviation + the truncation tail, which is a rigorous bound); the sweeps find decisions inside it, re-evaluate those
@@ -120,7 +123,7 @@ def test_guard_band_restores_the_exact_masks_under_a_coarse_chebyshev_cut(engine
         engine.set_grid(lo, hi, count)
         engine.set_option("bilinear", 0)
         out["k1g"] = _bundle(engine, cfg, b, q, d)
-        engine.set_option("bilinear", 1)
+        engine.set_option("bilinear", mode)
         engine.set_option("cheb_tol_e17", tol_e17)
         out["guard"] = _bundle(engine, cfg, b, q, d)
         engine.set_option("guard_band", 0)
@@ -129,7 +132,7 @@ def test_guard_band_restores_the_exact_masks_under_a_coarse_chebyshev_cut(engine
         engine.set_option("guard_band", 1)
         engine.set_option("cheb_tol_e17", 400)
         engine.set_option("bilinear", 1)
-    assert out["guard"]["prof"]["posterior_kernel"] == 4
+    assert out["guard"]["prof"]["posterior_kernel"] == (6 if mode == 1 else 4)
     ys = np.maximum(1.0, cfg["ds"]["Y_std"])
     dv = np.array(out["guard"]["prof"]["guard_dv"][:q]) / ys ** 2
     assert np.max(dv) > 1e-9, dv                      # the band has grown with the cut

@@ -96,7 +96,7 @@ def test_bilinear_posterior_matches_oracle_and_table_kernel(engine, cfg_name, n,
         engine.posterior_run()
         assert engine.profile()["posterior_kernel"] == 3
         m_tab, v_tab = engine.posterior()
-        engine.set_option("bilinear", 1)
+        engine.set_option("bilinear", 2)              # K1b's own plan for the first evaluation (1: node interpolation K1i first)
         engine.posterior_run()
         prof = engine.profile()
         assert prof["posterior_kernel"] == 4 and 0 < prof["posterior_executed_flops"] < prof["posterior_flops"] * 4
@@ -138,8 +138,8 @@ def test_posterior_over_the_hyper_parameter_range(engine, seed):
     engine.set_grid(lo, hi, count)
     mean, var = _check_posterior(engine, ds, pts, TOL64)
     kernel = engine.profile()["posterior_kernel"]
-    assert kernel in (3, 4)
-    if kernel == 4:
+    assert kernel in (3, 4, 6)
+    if kernel in (4, 6):
         engine.set_option("bilinear", 0)
         try:
             engine.posterior_run()
@@ -359,11 +359,11 @@ def test_bilinear_shards_reproduce_the_whole_grid_bitwise(engine):
     engine.set_model(cfg["ds"])
     engine.set_grid(lo, hi, count)
     m, v = engine.posterior()
-    assert engine.profile()["posterior_kernel"] == 4
+    assert engine.profile()["posterior_kernel"] in (4, 6)
     for first_line, lines in [(0, 16), (16, 48), (37, 63), (84, 16)]:
         engine.set_grid(lo, hi, count, first=first_line * 80, n_local=lines * 80)
         ms, vs = engine.posterior()
-        assert engine.profile()["posterior_kernel"] == 4
+        assert engine.profile()["posterior_kernel"] in (4, 6)
         sl = slice(first_line * 80, (first_line + lines) * 80)
         assert np.array_equal(ms, m[sl]) and np.array_equal(vs, v[sl])
 
@@ -1002,7 +1002,7 @@ def test_full_size_goose_properties_config_C(engine):
     finally:
         engine.set_option("goose_pairs", 0)
     res, O = out[0]
-    assert engine.profile()["posterior_kernel"] == 4
+    assert engine.profile()["posterior_kernel"] in (4, 6)
     for c in range(2):
         assert np.array_equal(O[c], out[1][1][c]), f"O{c + 1}"
     for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c"):
@@ -1030,7 +1030,9 @@ def test_full_size_goose_properties_config_C(engine):
     assert s["u_star"] == ucb[0][S].min() and np.array_equal(M, S & (lcb[0] <= s["u_star"]))
     assert s["minimizer_index"] == int(np.argmax(np.where(M, var0, -np.inf)))
     assert list(s["expander_index_c"]) == [int(np.argmax(np.where(G[c], var0, -np.inf))) if G[c].any() else -1 for c in range(2)]
-    assert np.array_equal(s["L"], res["L"])
+    # (the posterior in place is the LAST GoOSE sweep's: the first sweep of the model ran on interpolated node values (K1i), the
+    # sweeps after it on K1b's plan -- the two agree to ~1e-12, not bit for bit)
+    assert np.array_equal(s["L"], out[1][0]["L"]) and np.allclose(s["L"], res["L"], rtol=1e-10, atol=0.0)
     rng = np.random.default_rng(13)
     Lq = res["L"][q - 1]                                   # reference quirk: every constraint uses L_{q-1}
     xu, xs = pts[U], pts[S]
@@ -1063,7 +1065,7 @@ def test_full_size_properties_config_H(engine):
     engine.set_model(cfg["ds"])
     engine.set_grid(lo, hi, count)
     res = engine.sweep_safeopt(cfg["b"], want_masks=True)
-    assert engine.profile()["posterior_kernel"] == 4
+    assert engine.profile()["posterior_kernel"] in (4, 6)
     lcb1, lcb0, ucb0, var0 = (engine.bounds(cfg["b"], 1, "lcb"), engine.bounds(cfg["b"], 0, "lcb"),
                               engine.bounds(cfg["b"], 0, "ucb"), engine.bounds(cfg["b"], 0, "var"))
     S, U, M, G = engine.mask("S"), engine.mask("U"), engine.mask("M"), engine.mask("G", 1)
@@ -1147,7 +1149,7 @@ def test_fused_classification_equals_the_separate_pass(engine, cfg_name, n, coun
             engine.set_model(cfg["ds"])
             engine.set_grid(lo, hi, count)
             s_ = engine.sweep_safeopt(cfg["b"], want_masks=True)
-            assert engine.profile()["posterior_kernel"] == 4
+            assert engine.profile()["posterior_kernel"] in (4, 6)
             masks = {k: engine.mask(k) for k in ("S", "U", "M")}
             masks["G"] = engine.mask("G", 1)
             engine.set_model(cfg["ds"])                       # a fresh posterior for each sweep kind: the fused path again
@@ -1190,7 +1192,7 @@ def test_shared_set_phase_launches_equal_one_launch_per_kernel(engine, cfg_name,
             engine.set_grid(lo, hi, count)
             engine.set_model(cfg["ds"])
             r = engine.sweep_safeopt(b, want_masks=True)
-            assert engine.profile()["posterior_kernel"] == 4
+            assert engine.profile()["posterior_kernel"] in (4, 6)
             masks = {k: engine.mask(k) for k in ("S", "U", "M")}
             masks.update({f"G{c}": engine.mask("G", c) for c in range(1, q)})
             r2 = engine.sweep_safeopt(b, quirk_L_index=False, posterior_ready=True, want_masks=True)
@@ -1522,7 +1524,7 @@ def test_multi_rank_forced_guard_reevaluation_equals_the_exact_kernel(engine, tm
         engine.set_option("tensor_cheb", 1)
     assert _wait_ranks(procs) == [0] * world
     res = json.load(open(out))
-    assert res["posterior_kernel"] in (4, 5), "the shards must run an approximating posterior for this test to mean anything"
+    assert res["posterior_kernel"] in (4, 5, 6), "the shards must run an approximating posterior for this test to mean anything"
     assert res["guard_passes"] >= 1
     parts = [np.load(out + f".rank{r}.npz") for r in range(world)]
     for k, want in rmask.items():
@@ -1718,12 +1720,12 @@ def test_caller_invK_tables_and_deferred_factor(engine, cfg_name, n, count):
     engine.set_grid(lo, hi, count)
     engine.set_model(cfg["ds"])                                  # deferred factor, direct tables
     m1, v1 = _check_posterior(engine, cfg["ds"], pts, TOL64)
-    assert engine.profile()["posterior_kernel"] == 4
+    assert engine.profile()["posterior_kernel"] in (4, 6)
     try:
         engine.set_option("chol_async", 0)
         engine.set_model(cfg["ds"])
         m0, v0 = _check_posterior(engine, cfg["ds"], pts, TOL64)
-        assert engine.profile()["posterior_kernel"] == 4
+        assert engine.profile()["posterior_kernel"] in (4, 6)
     finally:
         engine.set_option("chol_async", 1)
     ys = np.maximum(1.0, cfg["ds"]["Y_std"])
@@ -1760,7 +1762,7 @@ def test_deferred_factor_reports_an_indefinite_invK_where_it_is_needed(engine):
     engine.set_grid(lo, hi, [96, 80])
     engine.set_model(ds)                                          # accepted: nothing on this path factors it
     mean, var = engine.posterior()
-    assert engine.profile()["posterior_kernel"] == 4 and np.all(var >= 0) and np.all(np.isfinite(mean))
+    assert engine.profile()["posterior_kernel"] in (4, 6) and np.all(var >= 0) and np.all(np.isfinite(mean))
     om, ov = oracle.gp_inference(oracle.grid_points(lo, hi, [96, 80]), ds)
     assert _nerr(mean, om, ds["Y_std"], 1) < 1e-9 and _nerr(var, ov, ds["Y_std"], 2) < 1e-9
     try:
