@@ -26,8 +26,9 @@ What the JSON line reports (N = 1 adds the last five):
                         extra sweeps with option comm_events, outside the timed region).
   iteration             what ONE SafeOpt ITERATION costs: the reference refits and sweeps once per model
                         (test/test_SafeOpt.py:144-179), so here two data sets alternate and every timed step is
-                        set_model (upload + alpha on the device; the reverse factor of the caller's invK is deferred) + the
-                        per-(model, grid) table build of K1b + the sweep.
+                        set_model (upload + alpha on the device; the reverse factor of the caller's invK is never made) + the
+                        model's first sweep, which runs on node-interpolated coefficients (K1i) -- K1b's plan belongs to a
+                        model that is swept again, as in the resident-model figure above.
   table_kernel          the same resident-model sweep with the exact O(n^2)-per-candidate kernel K1g (here on H; B and D in
                         `extra`), with `agreement`: every count and index of the two posteriors' results compared.
   config.result         counts, indices and the guard-band bookkeeping (`guard_band` = decisions the approximating posterior
@@ -61,7 +62,8 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, f32-input MFMA
 HBM_PEAK_TBS, HBM_MEASURED_TBS = 8.0, 6.29    # MI355X_MICROARCH.md: datasheet / measured float4 copy
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per K1 launch from rocprofv3 --pmc
 K1_NAMES = {1: "k_posterior", 2: "k_posterior_chunked", 3: "k_posterior_grid", 4: "k_bpost (+ k_bstage1, stage 1)",
-            5: "k_t_final (+ k_posterior_grid on the Chebyshev nodes, k_t_mode)"}
+            5: "k_t_final (+ k_posterior_grid on the Chebyshev nodes, k_t_mode)",
+            6: "k_bpost on node-interpolated coefficients (K1i: + k_bgemm invK K*^T at the Chebyshev nodes, k_i_dct, k_bstage1)"}
 
 
 def parse_args():
@@ -268,8 +270,8 @@ def timed_iterations(eng, models, dtype, step, steps, warmup, barrier):
             "k1_incl_tables_ms": float(np.mean(k1)), "k1_kernels": sorted(kinds), "ms_per_step_min": float(np.min(np.add(t_set, t_sweep))) * 1e3,
             "ms_per_step_median": float(np.median(np.add(t_set, t_sweep))) * 1e3, "ms_per_step_max": float(np.max(np.add(t_set, t_sweep))) * 1e3,
             "slow_steps": [(i, round(float(a + b) * 1e3, 3)) for i, (a, b) in enumerate(zip(t_set, t_sweep)) if a + b > 2.0 * np.median(np.add(t_set, t_sweep))],
-            "definition": "two data sets alternate; every timed step = set_model (upload + factorisation on the device) + the "
-                          "per-(model, grid) K1b table build + one full sweep; wall clock between barriers"}
+            "definition": "two data sets alternate; every timed step = set_model (upload, alpha, the plan of the model's first sweep: "
+                          "exact node values + Chebyshev coefficients, K1i) + one full sweep; wall clock between barriers"}
 
 
 def make_configs(name, n=None):

@@ -477,8 +477,11 @@ __device__ __forceinline__ void classify_final_body(const unsigned long long* __
       for (int c = 0; c < kMaxQ; ++c) {
         if (c < q) {
           sc->vmin_key[c] = vmin[c];
-          const double vm = vmin[c] != ~0ull ? fmax(0.0, ord_val(vmin[c])) : 0.0;
-          sc->gb_du[c] = gb->dm[c] + b * gb_dsqrt(vm, gb->dv[c]);
+          // (no safe candidate on this rank: nothing here to bound -- a variance of "zero" would put sqrt(dv) ~ 1e-6 into the
+          // max over the ranks: 119 members of M inside that band on config H at four ranks, every sweep a second pass)
+          const bool any = vmin[c] != ~0ull;
+          const double vm = any ? fmax(0.0, ord_val(vmin[c])) : 0.0;
+          sc->gb_du[c] = gb->dm[c] + (any ? b * gb_dsqrt(vm, gb->dv[c]) : 0.0);
           sc->gb_rl[c] = gb->rl[c];
         }
       }
@@ -1114,9 +1117,15 @@ static int launch_exact(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, int lidx,
     csU.n_local = c->uwin_n;
     Uall = (const uint8_t*)c->Uwin.p;
   }
+  RcExp rx;
+  memset(&rx, 0, sizeof(rx));
+  if (gb_of(c) && !c->rc_active) {        // (fast path of an approximating posterior: the listed candidates' verdicts are judged against its band)
+    rx.gb_c = cidx;
+    rx.gb_l = c->gb_slow ? -1 : lidx;
+  }
   hipLaunchKernelGGL((k_expander_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, csU, mean_c, var_c, (T)o->b,
                      Uall, (const unsigned long long*)c->Lmax.p, lidx, sc,
-                     (const long long*)c->amb.p, G);
+                     (const long long*)c->amb.p, G, rx);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
@@ -1681,11 +1690,19 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
     for (int t = 0; t < kMaxQ; ++t) h.count_set[t] += (long long)row[kC3Counts + 5 + t];
     h.halo_short += (long long)row[kC3Halo];
   }
+  static const bool dbg_guard = getenv("SBO_DEBUG_GUARD") != nullptr;
+  if (dbg_guard && c->gb_active) {
+    for (int r = 0; r < c->world; ++r) fprintf(stderr, "[guard] rank %d row: counted %g\n", r, rows[(size_t)r * kC3Row + kC3Counts + 4]);
+  }
   for (int t = 0; t < kArgSlots; ++t) {
     h.arg_val[t] = merged[t].i >= 0 ? merged[t].v : 0.0;
     h.arg_idx[t] = merged[t].i;
     h.arg_d[t] = merged[t].d;
-    if (c->gb_active && (slot_is_max[t] ? arg_near<true>(merged[t]) : arg_near<false>(merged[t]))) ++h.n_guard;
+    const bool near = c->gb_active && (slot_is_max[t] ? arg_near<true>(merged[t]) : arg_near<false>(merged[t]));
+    if (dbg_guard && near)
+      fprintf(stderr, "[guard] slot %d near after the merge: v %.17g i %lld d %.3g e1 %.17g e2 %.17g ei %lld\n", t, merged[t].v, merged[t].i, merged[t].d,
+              merged[t].e1, merged[t].e2, merged[t].ei);
+    if (near) ++h.n_guard;
   }
   if (!c->gb_active) h.n_guard = 0;
   return SBO_OK;

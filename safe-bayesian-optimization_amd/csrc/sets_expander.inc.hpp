@@ -736,7 +736,9 @@ __global__ __launch_bounds__(256) void k_edt_decide(const double* __restrict__ D
               rc_defer(rx, sc, g);                 // an fp32 value cannot settle it: re-evaluate, decide in the next pass
               out = ucb - L * dm >= 0.0;
             } else {
-              if (du > 0.0) rc_defer(rx, sc, g);   // (guard band, fast path: counted; the exhaustive recheck still decides it)
+              // (guard band, fast path: the exhaustive recheck decides it AND judges whether the band could move its verdict --
+              // counting here charged every candidate inside the reference's 1e-8 shift to the band: 119 false alarms per
+              // sweep of config H on four ranks, each a second pass)
               const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
               amb[slot] = g;
             }
@@ -957,8 +959,7 @@ __global__ __launch_bounds__(256) void k_edt_scan_list(const DS Din, long long g
             rc_defer(rx, sc, g);
             out = ucb - L * dm >= 0.0;
           } else {
-            if (du > 0.0) rc_defer(rx, sc, g);     // (guard band, fast path: counted)
-            amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
+            amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;     // (guard band: judged by k_expander_exact)
           }
         }
       }
@@ -984,9 +985,13 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const CandSpec csU, const T* __restrict__ mean_c,
                                                         const T* __restrict__ var_c, T b, const uint8_t* __restrict__ U,
                                                         const unsigned long long* Lkeys, int lidx, SweepScalars* sc,
-                                                        const long long* __restrict__ amb, uint8_t* __restrict__ G) {
+                                                        const long long* __restrict__ amb, uint8_t* __restrict__ G, const RcExp rx) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const long long namb = sc->n_amb;
+  // guard band of an approximating posterior (fast path): a listed candidate's verdict is in the band iff the predicate has a
+  // witness with ucb + du but none with ucb - du (du carries the relative band of L as well: rc_du)
+  const bool gband = rx.gb_c > 0 && !rx.list;
+  const RcBandK bk = rc_band(rx, sc);
   constexpr int kParts = 64;   // a listed candidate's box can be as large as the grid: cut into slices, one workgroup each
   for (long long wi = blockIdx.x; wi < namb * kParts; wi += gridDim.x) {
     const long long qi = wi / kParts;
@@ -995,9 +1000,10 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
     T lcb, ucbT;
     lcb_ucb(mean_c[g], var_c[g], b, lcb, ucbT);
     const double ucb = (double)ucbT;
+    const double du = gband ? rc_du(rx, bk, g, 0.0, (double)b, ucb) : 0.0;
     double xg[D];
     cand_coords<D>(cs, g, xg);
-    int found = 0;
+    int found = 0, found_hi = 0, found_lo = 0;
     if (csU.kind == 1) {
       // grid: only witnesses inside the index box of half-width ceil(r / h_a) + 1 around g can satisfy the predicate
       long long lo[D], len[D], stridea[D];
@@ -1039,7 +1045,13 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
           }
         }
         const long long hl = hh - csU.first;
-        if (hl >= 0 && hl < csU.n_local && U[hl] && lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
+        if (hl >= 0 && hl < csU.n_local && U[hl]) {
+          if (lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
+          if (gband) {
+            if (lipschitz_pair<D>(xg, xh, cs.d, ucb + du, L)) found_hi = 1;
+            if (lipschitz_pair<D>(xg, xh, cs.d, ucb - du, L)) found_lo = 1;
+          }
+        }
       }
     } else {
       for (long long hh = (long long)part * blockDim.x + threadIdx.x; hh < csU.n_local && !found; hh += (long long)kParts * blockDim.x) {
@@ -1047,10 +1059,20 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
           double xh[D];
           cand_coords<D>(csU, hh, xh);
           if (lipschitz_pair<D>(xg, xh, cs.d, ucb, L)) found = 1;
+          if (gband) {
+            if (lipschitz_pair<D>(xg, xh, cs.d, ucb + du, L)) found_hi = 1;
+            if (lipschitz_pair<D>(xg, xh, cs.d, ucb - du, L)) found_lo = 1;
+          }
         }
       }
     }
     found = __syncthreads_or(found);
+    if (gband) {
+      // (per slice: a witness under the wide bound only.  A sure witness in another slice makes this a false alarm -- rare, and safe)
+      found_hi = __syncthreads_or(found_hi);
+      found_lo = __syncthreads_or(found_lo);
+      if (threadIdx.x == 0 && found_hi && !found_lo) atomicAdd((unsigned long long*)&sc->n_guard, 1ull);
+    }
     if (threadIdx.x == 0 && found) G[g] = 1;
     __syncthreads();
   }

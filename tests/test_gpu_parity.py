@@ -1407,7 +1407,8 @@ def test_multi_rank_sweep_on_one_gpu_matches_oracle(tmp_path, world, cfg_name, n
 
 
 @pytest.mark.parametrize("world,cfg_name,n,count,b", [(3, "C", 64, [256, 300], 2.0), (2, "D", 128, [34, 33, 32, 70], 0.5),
-                                                      (2, "D", 128, [64, 64, 64, 64], 3.0)])     # (the last: Chebyshev-node posterior K1t on the shards)
+                                                      (2, "D", 128, [64, 64, 64, 64], 3.0),      # (Chebyshev-node posterior K1t on the shards)
+                                                      (4, "H", 300, [384, 512], 3.0)])           # (a rank without a single safe candidate)
 def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_name, n, count, b):
     """Shards big enough for the coarse cell bounds inside each rank's halo window: every mask and index must equal the
     single-rank sweep of the whole grid (itself pinned to the oracle by the tests above)."""
@@ -1437,6 +1438,11 @@ def test_multi_rank_large_grid_matches_single_rank(engine, tmp_path, world, cfg_
     for k in ("minimizer_index", "expander_index", "count_S", "count_M"):
         assert res[k] == ref[k], k
     assert res["count_G"] == ref["count_G"].tolist() and res["u_star"] == ref["u_star"]
+    # the guard band across ranks: what one rank decides outright, the shards decide outright (r04: a rank without safe candidates
+    # used to put a band of sqrt(dv) into the max over the ranks, and every sweep of config H on four ranks took the slow path)
+    assert ref["guard_band"] == 0 and res["guard_band"] == 0 and res["guard_passes"] == 0, (res["guard_band"], res["guard_passes"])
+    if cfg_name == "H":
+        assert not any(np.load(out + f".rank{r}.npz")["S"].any() for r in (world - 1,)), "the last rank was meant to hold no safe candidate"
     g = res["goose"]
     for k in ("safe_min_index", "target_index", "explore_index", "choose_safe_min", "target_best_c"):
         assert g[k] == gref[k], k

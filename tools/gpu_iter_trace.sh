@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel + copy trace of model-change iterations: tools/gpu_r03_iter_trace.sh TAG CONFIG
+# kernel + copy trace of model-change iterations: tools/gpu_iter_trace.sh TAG CONFIG
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$1

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense a gpurun_out/<tag> directory written by tools/gpu_bench_profile.sh into profiles/<tag>_*.
+"""Condense a gpurun_out/<tag> directory written by tools/gpu_profile.sh into profiles/<tag>_*.
 
 Outputs: profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), profiles/<tag>_pmc.json
 (per-kernel mean counter values per launch) and profiles/<tag>_bench.json (the bench line of the same run).
