@@ -1651,6 +1651,11 @@ static int sweep_exchange_back(sbo_ctx* c, SweepScalars& h, const bool* slot_is_
     if (Lk) memcpy(Lk, Lk_pinned, sizeof(unsigned long long) * kMaxQ);
     // decisions the guard band of an approximating posterior leaves open: the classification's and the verdict kernels' count
     // plus what the final reductions found in their slots
+    if (getenv("SBO_DEBUG_GUARD") && c->gb_active) {
+      fprintf(stderr, "[guard] device count %lld (classification %lld), slots:", h.n_guard, h.n_guard_cls);
+      for (int t = 0; t < kArgSlots; ++t) fprintf(stderr, " %lld", h.guard_slot[t]);
+      fprintf(stderr, "\n");
+    }
     if (c->gb_active) for (int t = 0; t < kArgSlots; ++t) h.n_guard += h.guard_slot[t];
     else h.n_guard = 0;
     return SBO_OK;
@@ -2109,7 +2114,8 @@ static int goose_sets(sbo_ctx* c, const sbo_sweep_opts* o, int cidx, const uint8
                            (const long long*)slist);
     }
     hipLaunchKernelGGL((k_goose_exact<T, D>), dim3(1024), dim3(256), 0, c->stream, c->cs, css, W,
-                       (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, (const long long*)c->amb.p, O);
+                       (const unsigned long long*)c->Lmax.p, lidx, sc, cidx, (const long long*)c->amb.p, O,
+                       (gb_of(c) && !c->rc_active && !c->gb_slow) ? 1 : 0);
     SBO_HIP(hipGetLastError());
     return SBO_OK;
   }

@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
       }
       const long long chunk = (total + kParts - 1) / kParts;
       const long long t1 = (part + 1) * chunk < total ? (part + 1) * chunk : total;
-      for (long long t = part * chunk + threadIdx.x; t < t1 && !found; t += blockDim.x) {
+      for (long long t = part * chunk + threadIdx.x; t < t1 && !(gband ? found_lo : found); t += blockDim.x) {   // (band: until a SURE witness)
         long long u = t, hh = 0;
         double xh[D];
 #pragma unroll
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_expander_exact(const CandSpec cs, const
         }
       }
     } else {
-      for (long long hh = (long long)part * blockDim.x + threadIdx.x; hh < csU.n_local && !found; hh += (long long)kParts * blockDim.x) {
+      for (long long hh = (long long)part * blockDim.x + threadIdx.x; hh < csU.n_local && !(gband ? found_lo : found); hh += (long long)kParts * blockDim.x) {
         if (U[hh]) {
           double xh[D];
           cand_coords<D>(csU, hh, xh);

@@ -735,7 +735,8 @@ __global__ __launch_bounds__(256) void k_pdt_decide(const double* __restrict__ P
                                       : pdt_scan_point(Pin, gg, stride, cnt, ia, h, pp, true);
           if (best < -pp.band) out = 1;
           else if (best <= pp.band) {
-            if (pp.gband > 0.0) atomicAdd((unsigned long long*)&sc->n_guard, 1ull);
+            // (guard band: k_goose_exact judges whether the band could move the listed point's verdict -- nearly every point listed
+            // here sits inside the reference's 1e-8 shift, not inside the band, and a counted decision re-evaluates ALL of S)
             const long long slot = (long long)atomicAdd((unsigned long long*)&sc->n_amb, 1ull);
             amb[slot] = g;
           }
@@ -838,8 +839,7 @@ __global__ __launch_bounds__(256) void k_pdt_scan_list(const double* __restrict_
       uint8_t out = 0;
       if (best < -pp.band) out = 1;
       else if (best <= pp.band) {
-        if (pp.gband > 0.0) atomicAdd((unsigned long long*)&sc->n_guard, 1ull);
-        amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;
+        amb[atomicAdd((unsigned long long*)&sc->n_amb, 1ull)] = g;     // (guard band: judged by k_goose_exact)
       }
       O[g] = out;
     }
@@ -851,9 +851,12 @@ __global__ __launch_bounds__(256) void k_pdt_scan_list(const double* __restrict_
 template <typename T, int D>
 __global__ __launch_bounds__(256) void k_goose_exact(const CandSpec cs, const CandSpec css, const T* __restrict__ W,
                                                      const unsigned long long* Lkeys, int lidx, SweepScalars* sc, int c,
-                                                     const long long* __restrict__ amb, uint8_t* __restrict__ O) {
+                                                     const long long* __restrict__ amb, uint8_t* __restrict__ O, int gband) {
   const double L = __longlong_as_double((long long)Lkeys[lidx]);
   const long long namb = sc->n_amb;
+  // guard band (fast path of an approximating posterior): a source's weight is known to dw = du_c + rl |w|; a listed point's verdict
+  // is in the band iff it has a witness with w + dw and none with w - dw
+  const double gdu = gband ? sc->gb_du[c] : 0.0, grl = gband ? sc->gb_rl[lidx] : 0.0;
   const double rm = (L > 0 && sc->rmax_key[c]) ? fmax(0.0, ord_val(sc->rmax_key[c])) / L : 0.0;
   // one listed point can own a box as large as the grid: its box is cut into kParts slices, one workgroup each
   constexpr int kParts = 256;
@@ -883,10 +886,10 @@ __global__ __launch_bounds__(256) void k_goose_exact(const CandSpec cs, const Ca
         sa *= cnt;
       }
     }
-    int found = 0;
+    int found = 0, found_hi = 0, found_lo = 0;
     const long long chunk = (total + kParts - 1) / kParts;
     const long long t1 = (part + 1) * chunk < total ? (part + 1) * chunk : total;
-    for (long long t = part * chunk + threadIdx.x; t < t1 && !found; t += blockDim.x) {
+    for (long long t = part * chunk + threadIdx.x; t < t1 && !(gband ? found_lo : found); t += blockDim.x) {   // (band: until a SURE witness)
       // position in the box (32-bit divisions when the box allows), source weight first: most positions hold no source
       long long gg = 0, ia[D];
       if (total < (1ll << 31)) {
@@ -917,10 +920,20 @@ __global__ __launch_bounds__(256) void k_goose_exact(const CandSpec cs, const Ca
             }
           }
           if (lipschitz_pair<D>(xg, xh, cs.d, w, L)) found = 1;
+          if (gband) {
+            const double dw = gdu + grl * w;
+            if (lipschitz_pair<D>(xg, xh, cs.d, w + dw, L)) found_hi = 1;
+            if (lipschitz_pair<D>(xg, xh, cs.d, w - dw, L)) found_lo = 1;
+          }
         }
       }
     }
     found = __syncthreads_or(found);
+    if (gband) {
+      found_hi = __syncthreads_or(found_hi);
+      found_lo = __syncthreads_or(found_lo);
+      if (threadIdx.x == 0 && found_hi && !found_lo) atomicAdd((unsigned long long*)&sc->n_guard, 1ull);
+    }
     if (threadIdx.x == 0 && found) O[hl] = 1;
     __syncthreads();
   }
