@@ -257,3 +257,36 @@ def test_negative_or_nan_confidence_multiplier_is_rejected(engine):
         with pytest.raises(ValueError):
             engine.sweep_tr(bad, np.zeros(2), 1.0)
     assert engine.sweep_safeopt(cfg["b"])["count_S"] > 0
+
+
+@pytest.mark.parametrize("log_ell,kernel", [(0.0, 6), (-0.5, 6), (-0.85, 6), (-1.2, 4)])
+def test_k1i_node_ladder_and_decline(engine, log_ell, kernel):
+    """K1i (a model's first sweep on fp64 2-D grids, r04) picks its node count from the length scales -- 32, 48 or 64 per axis -- and
+    leaves shorter scales to K1b's plan: posterior against the oracle at the parity bar, every mask and index of the sweeps equal
+    to the exact table kernel's, the guard band reported and no decision inside it."""
+    base = synthetic.make_config("B", n=128)
+    hyp = synthetic.default_hypopt(2, 2, log_ell=log_ell)
+    ds = synthetic.make_dataset(base["X"], base["Y"], hyp)
+    cfg = dict(base, ds=ds)
+    lo, hi, count, b = cfg["bound"][:, 0], cfg["bound"][:, 1], [200, 180], 3.0
+    pts = oracle.grid_points(lo, hi, count)
+    om, ov = oracle.gp_inference(pts, ds)
+    ys = np.maximum(1.0, ds["Y_std"])
+    out = {}
+    try:
+        engine.set_grid(lo, hi, count)
+        for key, bil in (("first", 1), ("k1g", 0)):
+            engine.set_option("bilinear", bil)
+            engine.set_model(ds)
+            out[key] = _bundle(engine, cfg, b, 2, 2, fresh=False)
+            if key == "first":
+                mean, var = engine.posterior()
+                assert np.max(np.abs(mean - om) / ys) < TOL64 and np.max(np.abs(var - ov) / ys ** 2) < TOL64
+    finally:
+        engine.set_option("bilinear", 1)
+    assert out["first"]["prof"]["posterior_kernel"] == kernel and out["k1g"]["prof"]["posterior_kernel"] == 3
+    dm = np.array(out["first"]["prof"]["guard_dm"][:2])
+    assert np.all(dm > 0) and np.all(dm / ys < 1e-10), dm
+    for sweep in ("safeopt", "goose", "tr"):
+        assert out["first"][sweep]["guard_band"] == 0, sweep
+    _same_decisions(out["first"], out["k1g"], ys[0], "k1g")
