@@ -2424,17 +2424,40 @@ __global__ __launch_bounds__(1024) void k_i_dct(const ModelConst mc, const Inter
 // ---- K1i: where the gradient phases have to run (as k_bl_gradcoarse does it for K1b) -------------------------------------------
 // The coarse kernel of K1b takes a rank-r0 bilinear form sum_p Vb[p][line] S0[p][x0]; a Chebyshev series is one with
 // S0[a][x0] = T_a(xi0(x0)) and Vb[comp][a][line] = sum_b ChatT_comp[b][a] T_b(xi1(line)).
-__global__ __launch_bounds__(256) void k_i_ttab(const BlDims dm, const double* __restrict__ xn0, double* __restrict__ S0all) {
-  const int Dn = dm.D0m;
-  for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < dm.cnt0; x += (long long)gridDim.x * blockDim.x) {
-    double xi = (2.0 * xn0[x] - (dm.a[0] + dm.b[0])) / (dm.b[0] - dm.a[0]);
-    xi = xi < 1.0 ? xi : 1.0;
-    xi = xi > -1.0 ? xi : -1.0;
+// K1i's tables of the grid positions in ONE launch (the plan is bound by the host's enqueue rate on the smaller grids: every launch
+// less is ~7 us): normalised positions xn0 / xn1 (k_bl_axes), Chebyshev polynomials as B fragments of axis 0 / A images of axis 1
+// (k_cheb_tab<1> / <0>) and the plain table of axis 0 for the gradient gate.  A thread per position.
+__global__ __launch_bounds__(256) void k_i_tabs(const ModelConst mc, const CandSpec cs, const BlDims dm, long long line0, double* __restrict__ xn0,
+                                                double* __restrict__ xn1, double* __restrict__ P0f, double* __restrict__ P1A,
+                                                double* __restrict__ S0all) {
+  const int KB = dm.KB0, Dn = dm.D0m;
+  const long long n0 = (long long)dm.ncs0 * 16, n1 = (long long)dm.nrb * 16;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n0 + n1; t += (long long)gridDim.x * blockDim.x) {
+    const int axis = t < n0 ? 0 : 1;
+    const long long x = axis == 0 ? t : t - n0, count = axis == 0 ? dm.cnt0 : dm.nlines;
+    double xi = 0.0;
+    if (x < count) {
+      const long long i = axis == 0 ? x : line0 + x, tot = cs.count[axis];
+      const double xr = (i == tot - 1 && tot > 1) ? cs.hi[axis] : __dadd_rn(cs.lo[axis], __dmul_rn((double)i, cs.step[axis]));
+      const double xn = (xr - mc.X_mean[axis]) / mc.X_std[axis];
+      if (axis == 0) xn0[x] = xn; else xn1[x] = xn;
+      xi = (2.0 * xn - (dm.a[axis] + dm.b[axis])) / (dm.b[axis] - dm.a[axis]);
+      xi = xi < 1.0 ? xi : 1.0;
+      xi = xi > -1.0 ? xi : -1.0;
+    }
     double t0 = 1.0, t1 = xi;
-    for (int a = 0; a < Dn; ++a) {
-      double v = a == 0 ? 1.0 : xi;
-      if (a >= 2) { v = 2.0 * xi * t1 - t0; t0 = t1; t1 = v; }
-      for (int o = 0; o < dm.q / 4; ++o) S0all[((size_t)o * Dn + a) * dm.cnt0 + x] = v;
+    for (int k = 0; k < KB * 16; ++k) {
+      double v = k == 0 ? t0 : t1;
+      if (k >= 2) { v = 2.0 * xi * t1 - t0; t0 = t1; t1 = v; }
+      if (x >= count) v = 0.0;
+      const int kb = k >> 4, j = k & 15, kk = j >> 2, slot = j & 3;
+      if (axis == 0) {
+        P0f[(((size_t)(x >> 4) * (KB * 4) + (size_t)(kb * 4 + kk)) << 6) + (size_t)(slot * 16 + (x & 15))] = v;
+        if (x < count && k < Dn)
+          for (int o = 0; o < dm.q / 4; ++o) S0all[((size_t)o * Dn + k) * dm.cnt0 + x] = v;
+      } else {
+        P1A[(((size_t)(x >> 4) * KB + kb) << 8) + (size_t)MM<double>::pack_pos((int)(x & 15), slot, kk)] = v;
+      }
     }
   }
 }
@@ -2661,6 +2684,20 @@ int interp_setup(sbo_ctx* c) {
     SBO_HIP(hipStreamWaitEvent(ys, c->ev[7], 0));
     if (zs != ys) SBO_HIP(hipStreamWaitEvent(zs, c->ev[7], 0));
   }
+  // (enqueue order: the plan is host-bound on the smaller grids -- Z's one long kernel first, then the head of X, then Y's one launch)
+  const bool band = c->guard_band != 0;
+  double *gref_m = nullptr, *gref_v = nullptr, *raw = nullptr, *pgrad = nullptr;
+  if (band) {
+    // Z: the guard band's references at the probe points -- the reference formula (guard.hip) and the exact gradient.
+    // probe buffers: raw [4 q][P] | points [P][2] | exact gradient [q][2][P]
+    if ((rc = ensure(c->gb_pts, sizeof(double) * ((size_t)QP * kGbProbes + 2 * (size_t)kGbProbes + 2 * (size_t)q * kGbProbes)))) return rc;
+    raw = (double*)c->gb_pts.p;
+    double* ppts = raw + (size_t)QP * kGbProbes;
+    pgrad = ppts + 2 * (size_t)kGbProbes;
+    if ((rc = guard_probe_reference(c, zs, &gref_m, &gref_v))) return rc;
+    if ((rc = guard_probe_gradients(c, zs, ppts, pgrad))) return rc;
+    if (zs != ys) SBO_HIP(hipEventRecord(c->ev_join[6], zs));
+  }
   // X: node fields and their coefficients
   hipLaunchKernelGGL(k_i_etab, blocks((size_t)Dn * n, 2 * uq), dim3(256), 0, xs, mc, id, (const double*)c->As.p, E);
   hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, xs, dm, (const double*)E, nZf, Zf);
@@ -2675,7 +2712,6 @@ int interp_setup(sbo_ctx* c) {
   }
   hipLaunchKernelGGL(k_cheb_trunc, dim3((unsigned)QP), dim3(1024), 0, xs, dm, (const double*)Chat, c->cheb_tol, eff);
   hipLaunchKernelGGL(k_cheb_t4f, blocks(ip.sT4f, (unsigned)QP), dim3(256), 0, xs, dm, (const double*)Chat, ip.sT4f, (double*)c->bl_T4f.p);
-  SBO_HIP(hipMemcpyAsync(c->h_back + 5376, eff, sizeof(int) * 4 * std::min(QP, 8), hipMemcpyDeviceToHost, xs));
   // ... and which tiles of k_bpost can hold the largest gradient component (the gate of K1b's gradient phases, fed from the series)
   ip.gtmax = nullptr;
   ip.gkey = nullptr;
@@ -2693,7 +2729,6 @@ int interp_setup(sbo_ctx* c) {
     const double dxi1 = cs.count[1] > 1 ? 0.5 * kGradStep * std::fabs(cs.step[1] / mc.X_std[1]) / id.half[1] : 0.0;
     BlDims dg = dm;                       // (k_bl_gradcoarse: a form of rank Dn)
     dg.q = QP;
-    SBO_HIP(hipMemsetAsync(gkey, 0, sizeof(unsigned long long) * 2 * q, xs));
     hipLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, xs, dm, (const double*)Chat, dxi0, dxi1, slack);
     ip.grad_S0 = S0i;
     ip.grad_Vb = Vbi;
@@ -2706,26 +2741,10 @@ int interp_setup(sbo_ctx* c) {
       ip.gkey = gkey;
     }
   }
-  // Y: the tables of the grid positions
-  hipLaunchKernelGGL(k_bl_axes, dim3((unsigned)std::min<long long>((cnt0 + nlines + 255) / 256, 4096)), dim3(256), 0, ys, mc, cs, cnt0, line0,
-                     nlines, dxn0, dxn1);
-  hipLaunchKernelGGL((k_cheb_tab<1>), dim3((unsigned)((ncs0 * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn0, (double*)c->bl_P0f.p);
-  hipLaunchKernelGGL((k_cheb_tab<0>), dim3((unsigned)((nrb * 16 + 255) / 256)), dim3(256), 0, ys, dm, (const double*)dxn1, (double*)c->bl_P1A.p);
-  hipLaunchKernelGGL(k_i_ttab, dim3((unsigned)std::min<long long>((cnt0 + 255) / 256, 4096)), dim3(256), 0, ys, dm, (const double*)dxn0, ip.grad_S0);
+  // Y: the tables of the grid positions (one launch)
+  hipLaunchKernelGGL(k_i_tabs, dim3((unsigned)std::min<long long>(((long long)(ncs0 + nrb) * 16 + 255) / 256, 4096)), dim3(256), 0, ys, mc, cs, dm,
+                     line0, dxn0, dxn1, (double*)c->bl_P0f.p, (double*)c->bl_P1A.p, ip.grad_S0);
   if (ys != xs) SBO_HIP(hipEventRecord(c->ev_join[3], ys));
-  // Z: the guard band's references at the probe points -- the reference formula (guard.hip) and the exact gradient
-  const bool band = c->guard_band != 0;
-  double *gref_m = nullptr, *gref_v = nullptr, *raw = nullptr, *pgrad = nullptr;
-  if (band) {
-    // probe buffers: raw [4 q][P] | points [P][2] | exact gradient [q][2][P]
-    if ((rc = ensure(c->gb_pts, sizeof(double) * ((size_t)QP * kGbProbes + 2 * (size_t)kGbProbes + 2 * (size_t)q * kGbProbes)))) return rc;
-    raw = (double*)c->gb_pts.p;
-    double* ppts = raw + (size_t)QP * kGbProbes;
-    pgrad = ppts + 2 * (size_t)kGbProbes;
-    if ((rc = guard_probe_reference(c, zs, &gref_m, &gref_v))) return rc;
-    if ((rc = guard_probe_gradients(c, zs, ppts, pgrad))) return rc;
-    if (zs != ys) SBO_HIP(hipEventRecord(c->ev_join[6], zs));
-  }
   if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
   // (X again, with the tables of Y: the lines' sums of the gradient series and the sums at the cell centres of every tile)
   if (ip.gtmax) {
@@ -2800,21 +2819,10 @@ int launch_posterior_interp(sbo_ctx* c) {
   }
   c->k1_stop_attached = true;
   c->gb_active = c->guard_band && ip.band_ready;
-  // flops issued: stage 1 of four coefficient sets per output + four full phases of stage 2 (upper bound: the counts the kernels run
-  // to live on the device)
+  // flops issued: stage 1 of four coefficient sets per output + four full phases of stage 2 (an upper bound: the counts the kernels
+  // run to stay on the device -- a read-back per plan is a launch the host-bound plan does not need)
   const double tiles2 = (double)ip.nrb * ip.ncs0;
   c->last_k1_flops = (double)q * 2.0 * 1024.0 * 4.0 * (4.0 * (double)ip.nrb * KB * KB + tiles2 * KB * 4);
-  const int* he = (const int*)(c->h_back + 5376);
-  if (QP <= 8) {
-    double f = 0.0;
-    bool ok = true;
-    for (int z = 0; z < QP; ++z) {
-      const int ks = he[4 * z], kb0 = he[4 * z + 1], kb1 = he[4 * z + 2];
-      if (ks < 1 || ks > KB * 4 || kb0 < 1 || kb0 > KB || kb1 < 1 || kb1 > KB) { ok = false; break; }
-      f += 2.0 * 1024.0 * (4.0 * (double)ip.nrb * kb0 * kb1 + tiles2 * ks);
-    }
-    if (ok) c->last_k1_flops = f;
-  }
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
