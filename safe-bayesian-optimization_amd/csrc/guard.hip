@@ -35,11 +35,13 @@ constexpr double kInfBand = 1.0e300; // a probe that is not finite: everything i
 // for 256 probes at n = 512) --, the four quarters meet in LDS, and the chunk's share of (k^T invK) k and of k . alpha is written
 // as a partial; k_ref_finish sums the chunks.  pts == nullptr: the candidates are K1b's probe points (gb_probe_index).
 template <int D>
-__global__ __launch_bounds__(256) void k_ref_list(const ModelConst mc, const CandSpec cs, const double* __restrict__ pts, long long N,
+__global__ __launch_bounds__(256) void k_ref_list(const ModelConst mc_val, const ModelConst* __restrict__ mcp /* non-null: the model's constants in
+                                                  device memory (a plan replayed as a HIP graph: bilinear.hip) */, const CandSpec cs, const double* __restrict__ pts, long long N,
                                                   long long nlines, const double* __restrict__ As, const double* __restrict__ sqA,
                                                   const double* __restrict__ alpha, int ald, const double* __restrict__ Mx, size_t mstride,
                                                   int ccols, double* __restrict__ part /* [chunks][2][q][N] */) {
   extern __shared__ double kv[];                 // [kRefPer][npad] | [4][64][kRefPer] quarter sums
+  const ModelConst& mc = mcp ? *mcp : mc_val;
   const int o = blockIdx.y, chunk = blockIdx.z, n = mc.n, npad = mc.npad, q = mc.q;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* wq = kv + (size_t)kRefPer * npad;
@@ -112,8 +114,9 @@ __global__ __launch_bounds__(256) void k_ref_list(const ModelConst mc, const Can
     }
   }
 }
-__global__ __launch_bounds__(256) void k_ref_finish(const ModelConst mc, long long N, int chunks, const double* __restrict__ part,
-                                                    double* __restrict__ mean_out, double* __restrict__ var_out) {
+__global__ __launch_bounds__(256) void k_ref_finish(const ModelConst mc_val, const ModelConst* __restrict__ mcp, long long N, int chunks,
+                                                    const double* __restrict__ part, double* __restrict__ mean_out, double* __restrict__ var_out) {
+  const ModelConst& mc = mcp ? *mcp : mc_val;
   const int q = mc.q;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < N * q; e += (long long)gridDim.x * blockDim.x) {
     const int o = (int)(e / N);
@@ -181,9 +184,10 @@ __global__ __launch_bounds__(256) void k_grad_list(const ModelConst mc, const do
 // the same for a SHORT list (the probe points of a plan): a wave per point, lanes over the observations (a thread per point walks
 // q n exponentials: 0.25 ms for 144 points at n = 512)
 template <int D>
-__global__ __launch_bounds__(256) void k_grad_list_w(const ModelConst mc, const double* __restrict__ pts, long long N,
+__global__ __launch_bounds__(256) void k_grad_list_w(const ModelConst mc_val, const ModelConst* __restrict__ mcp, const double* __restrict__ pts, long long N,
                                                      const double* __restrict__ As, const double* __restrict__ sqA,
                                                      const double* __restrict__ alpha, const double* __restrict__ Xn, double* __restrict__ out) {
+  const ModelConst& mc = mcp ? *mcp : mc_val;
   const int n = mc.n, npad = mc.npad, lane = threadIdx.x & 63;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= N) return;
@@ -269,7 +273,8 @@ static bool ref_direct(const sbo_ctx* c) {
 }
 
 template <int D>
-static int launch_ref(sbo_ctx* c, hipStream_t st, const double* pts, long long N, long long nlines, double* mean_out, double* var_out) {
+static int launch_ref(sbo_ctx* c, hipStream_t st, const double* pts, long long N, long long nlines, double* mean_out, double* var_out,
+                      const ModelConst* mcp = nullptr) {
   const ModelConst& mc = c->mc;
   const int q = mc.q;
   const long long groups = (N + kRefPer - 1) / kRefPer;
@@ -284,11 +289,11 @@ static int launch_ref(sbo_ctx* c, hipStream_t st, const double* pts, long long N
   const size_t lds = sizeof(double) * ((size_t)kRefPer * mc.npad + 256 * kRefPer);
   auto kern = k_ref_list<D>;
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)q, (unsigned)chunks), dim3(256), lds, st, mc, c->cs, pts, N, nlines,
+  hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)q, (unsigned)chunks), dim3(256), lds, st, mc, mcp, c->cs, pts, N, nlines,
                      (const double*)c->As.p, (const double*)c->sqA.p, (const double*)c->alpha64.p, c->a_ld, c->invk_plain,
                      (size_t)mc.n * mc.n, ccols, (double*)c->gb_part.p);
   hipLaunchKernelGGL(k_ref_finish, dim3((unsigned)std::max<long long>(1, std::min<long long>((N * q + 255) / 256, 1024))), dim3(256), 0, st,
-                     mc, N, chunks, (const double*)c->gb_part.p, mean_out, var_out);
+                     mc, mcp, N, chunks, (const double*)c->gb_part.p, mean_out, var_out);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
@@ -337,7 +342,8 @@ int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double
 // axis tables are made on, beside the GEMM chain of the Chebyshev core -- and, once K1b's own values at the probes are there
 // (pm / pv, bilinear.hip), the band from the deviations.  Everything on the device, in stream order: nothing waits for the host,
 // and the band is in place before the plan's first posterior launch (whose fused classification reads it).
-int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double** ref_v) {
+bool guard_reference_is_direct(const sbo_ctx* c) { return ref_direct(c); }
+int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double** ref_v, const ModelConst* mcp) {
   const int q = c->mc.q;
   const long long nlines = c->cs.n_local / c->cs.count[0];
   int rc;
@@ -346,7 +352,7 @@ int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double**
   if ((rc = ensure(c->gb_probe, sizeof(double) * (4 * (size_t)q + 2) * kGbProbes))) return rc;
   *ref_m = (double*)c->gb_probe.p;
   *ref_v = *ref_m + (size_t)q * kGbProbes;
-  if (ref_direct(c)) return launch_ref<2>(c, side, nullptr, kGbProbes, nlines, *ref_m, *ref_v);
+  if (ref_direct(c)) return launch_ref<2>(c, side, nullptr, kGbProbes, nlines, *ref_m, *ref_v, mcp);
   // (library Cholesky, or a caller's invK without chol_async: the factor is there, the generic kernel takes the probe list --
   // on the main stream: it is the context's launcher)
   double* ppts = *ref_m + 4 * (size_t)q * kGbProbes;
@@ -354,10 +360,10 @@ int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double**
   return launch_posterior_on_list(c, ppts, kGbProbes, *ref_m, *ref_v);
 }
 // the probe points as a list [P][d] and the exact gradient components of the mean there ([q][d][P]), on `st` (2-D grids)
-int guard_probe_gradients(sbo_ctx* c, hipStream_t st, double* ppts, double* grad_out) {
+int guard_probe_gradients(sbo_ctx* c, hipStream_t st, double* ppts, double* grad_out, const ModelConst* mcp) {
   if (c->dtype != SBO_F64 || c->mc.dpad != 2) return fail(SBO_E_UNSUPPORTED, "internal: probe gradients are an fp64 2-D path");
   hipLaunchKernelGGL(k_gb_probe_pts, dim3(1), dim3(kGbProbes), 0, st, c->cs, c->cs.n_local / c->cs.count[0], ppts);
-  hipLaunchKernelGGL(k_grad_list_w<2>, dim3((kGbProbes + 3) / 4), dim3(256), 0, st, c->mc, (const double*)ppts, (long long)kGbProbes,
+  hipLaunchKernelGGL(k_grad_list_w<2>, dim3((kGbProbes + 3) / 4), dim3(256), 0, st, c->mc, mcp, (const double*)ppts, (long long)kGbProbes,
                      (const double*)c->As.p, (const double*)c->sqA.p, (const double*)c->alpha.p, (const double*)c->Xn.p, grad_out);
   SBO_HIP(hipGetLastError());
   return SBO_OK;

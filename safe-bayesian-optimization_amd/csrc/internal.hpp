@@ -73,7 +73,17 @@ struct InterpPlan {
   const unsigned long long* gkey = nullptr;
   double *grad_S0 = nullptr, *grad_Vb = nullptr, *grad_gt = nullptr;
   unsigned long long* grad_key = nullptr;
+  // the plan as a HIP graph: captured when a signature repeats, replayed with the next model's parameter block
+  struct Sig {
+    CandSpec cs;
+    int Dn, q, n, npad, dpad, guard, a_ld, gate;
+    double cheb_tol;
+    const void* ptr[32];
+  } sig;
+  bool sig_valid = false, graph_ok = false;
+  void* exec = nullptr;                       // hipGraphExec_t
 };
+using InterpSig = InterpPlan::Sig;
 
 }  // namespace sbo
 
@@ -192,6 +202,8 @@ struct sbo_ctx {
   sbo::DevBuf blockmin; // per-block minima along the last axis (blocked last-axis scans)
   sbo::DevBuf gw;      // GoOSE: source weights (ucb_c on sources, -inf elsewhere), T [max shard]
   sbo::InterpPlan bi;   // K1i plan (first sweep of a model)
+  sbo::DevBuf bi_params; // ... its per-model parameter block (device) and the pinned staging the graph's copy node reads
+  void* h_bi_params = nullptr;
   sbo::DevBuf bl_grad;  // K1b: which tiles run the gradient phases (per plan)
   sbo::DevBuf bl_lpart; // K1b: per-wave Lipschitz partials of k_bpost
   sbo::DevBuf cpart;   // per-workgroup partials of k_classify, field-major [kClassifyRow][cpart_cap]
@@ -298,7 +310,8 @@ int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big);
 bool interp_applicable(const sbo_ctx* c);
 int interp_setup(sbo_ctx* c);
 int launch_posterior_interp(sbo_ctx* c);
-int guard_probe_gradients(sbo_ctx* c, hipStream_t st, double* ppts, double* grad_out);
+int guard_probe_gradients(sbo_ctx* c, hipStream_t st, double* ppts, double* grad_out, const sbo::ModelConst* mcp = nullptr);
+bool guard_reference_is_direct(const sbo_ctx* c);
 int bilinear_setup(sbo_ctx* c);
 int launch_posterior_bilinear(sbo_ctx* c);
 bool tensor_applicable(const sbo_ctx* c);
@@ -311,7 +324,7 @@ int launch_posterior_on_list(sbo_ctx* c, const double* pts, long long N, double*
 // enqueued behind the first posterior launch of a plan); a host-known band (K1t) or "none" (exact kernels)
 int guard_exact_list(sbo_ctx* c, const double* pts, long long N, double* mean_out, double* var_out);
 int guard_exact_grad_list(sbo_ctx* c, const double* pts, long long N, double* grad_out /* [q][d][N] */);
-int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double** ref_v);       // -> gb_probe: [q][P] each; K1b's own values follow at + 2 q P
+int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double** ref_v, const sbo::ModelConst* mcp = nullptr);       // -> gb_probe: [q][P] each; K1b's own values follow at + 2 q P
 int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail);
 int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl);
 }  // namespace sbo
