@@ -258,6 +258,15 @@ __global__ __launch_bounds__(256) void k_posterior_chunked(const ModelConst mc, 
   const T* sqA_o = sqA + (size_t)out * mc.npad;
   const T* al_o = alpha + (size_t)out * mc.npad;
   const T* F_o = Fpk + (size_t)out * fpk_stride;
+  // this lane's B operand of the cross-term products (fp32 generation below): coordinate 4 ks + slot of its candidate
+  T bsel[(D + 3) / 4];
+#pragma unroll
+  for (int ks = 0; ks < (D + 3) / 4; ++ks) {
+    T v = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) v = (a == 4 * ks + slot) ? B[a] : v;
+    bsel[ks] = v;
+  }
   T m0 = 0, ms[D];
 #pragma unroll
   for (int a = 0; a < D; ++a) ms[a] = 0;
@@ -279,20 +288,53 @@ __global__ __launch_bounds__(256) void k_posterior_chunked(const ModelConst mc, 
       __syncthreads();                              // previous chunk's readers are done
       const int Jlo = Jc * CB, Jhi = (Jlo + CB < nb) ? Jlo + CB : nb;
       T* kf_w = Kf + (size_t)wave * CB * 4 * 64 + lane;
-      for (int jl = 0; jl < (Jhi - Jlo) * 4; ++jl) {
-        const int jj = Jlo * 4 + jl;
-        const int j = ((jj >> 2) << 4) + MM<T>::jslot(jj & 3, slot);
-        T dot = 0;
+      if constexpr (std::is_same<T, float>::value) {
+        // (r04) the cross terms A_j . B of a whole 16 x 16 block (observations x this wave's candidates) on the matrix cores: K = D
+        // coordinates = one or two 16x16x4 steps.  Element i of the result at lane (slot, pp) is row 4 slot + i = jslot(i, slot) --
+        // exactly what k-step i of the block's K* fragment wants from this lane, so the values go to LDS where they are.  Leaves
+        // ~6 vector instructions per element (distance, exponential, store) of ~30: on config E the exp() generation was 22 % of
+        // the kernel's issue slots beside 66 % for the contraction.
+        constexpr int KD = (D + 3) / 4;
+        for (int Jb = Jlo; Jb < Jhi; ++Jb) {
+          f4_t dotv = f4_t{0, 0, 0, 0};
 #pragma unroll
-        for (int a = 0; a < D; ++a) dot = fma(As_o[j * D + a], B[a], dot);
-        const T dist = (T(-2) * dot + sqA_o[j]) + sqB;               // GP_Safe.py:119 (expanded form)
-        const T k = sf2 * exp_t<T>(T(-0.5) * dist);                  // GP_Safe.py:166
-        kf_w[(size_t)jl * 64] = k;
-        if (with_dots) {
-          const T w = al_o[j] * k;
-          m0 += w;
+          for (int ks = 0; ks < KD; ++ks) {
+            const int dim = 4 * ks + slot;
+            const float av = dim < D ? (float)As_o[(Jb * 16 + pp) * D + dim] : 0.f;
+            dotv = MM<float>::mfma(av, (float)bsel[ks], dotv);
+          }
+          const int j0 = Jb * 16 + 4 * slot;
+          const f4_t sq = *reinterpret_cast<const f4_t*>(sqA_o + j0);
 #pragma unroll
-          for (int a = 0; a < D; ++a) ms[a] = fma(w, Xn[j * D + a], ms[a]);
+          for (int i = 0; i < 4; ++i) {
+            const float dist = (-2.f * dotv[i] + sq[i]) + (float)sqB;         // GP_Safe.py:119 (expanded form)
+            const float k = (float)sf2 * exp_t<float>(-0.5f * dist);          // GP_Safe.py:166
+            kf_w[(size_t)((Jb - Jlo) * 4 + i) * 64] = (T)k;
+            if (with_dots) {
+              const int j = j0 + i;
+              const T w = al_o[j] * (T)k;
+              m0 += w;
+#pragma unroll
+              for (int a = 0; a < D; ++a) ms[a] = fma(w, Xn[j * D + a], ms[a]);
+            }
+          }
+        }
+      } else {
+        for (int jl = 0; jl < (Jhi - Jlo) * 4; ++jl) {
+          const int jj = Jlo * 4 + jl;
+          const int j = ((jj >> 2) << 4) + MM<T>::jslot(jj & 3, slot);
+          T dot = 0;
+#pragma unroll
+          for (int a = 0; a < D; ++a) dot = fma(As_o[j * D + a], B[a], dot);
+          const T dist = (T(-2) * dot + sqA_o[j]) + sqB;               // GP_Safe.py:119 (expanded form)
+          const T k = sf2 * exp_t<T>(T(-0.5) * dist);                  // GP_Safe.py:166
+          kf_w[(size_t)jl * 64] = k;
+          if (with_dots) {
+            const T w = al_o[j] * k;
+            m0 += w;
+#pragma unroll
+            for (int a = 0; a < D; ++a) ms[a] = fma(w, Xn[j * D + a], ms[a]);
+          }
         }
       }
       __syncthreads();
