@@ -1,5 +1,6 @@
-// micro-benchmark of k_bl_gradcoarse on random operands (config H's shapes):  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
-//   -I include -I safe-bayesian-optimization_amd/csrc tools/dev/gradcoarse_bench.hip -o tools/dev/gradcoarse_bench
+// micro-benchmark of k_bl_gradcoarse on zero operands (config H's shapes).  Build after `make -C safe-bayesian-optimization_amd/csrc`:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I include -I safe-bayesian-optimization_amd/csrc -c tools/dev/gradcoarse_bench.hip -o /tmp/gcb.o
+//   (cd safe-bayesian-optimization_amd/csrc && hipcc --offload-arch=gfx950 -o ../../tools/dev/gradcoarse_bench /tmp/gcb.o api.o model.o posterior.o sets.o comm.o fit.o plant.o tensor.o guard.o -L/opt/rocm/lib -lrccl)
 #include "bilinear.hip"
 #include <cstdio>
 int main() {
