@@ -157,7 +157,8 @@ typedef struct sbo_profile {
   int64_t candidates;      /* candidates swept by this rank                                                */
   int32_t posterior_launches;
   int32_t posterior_kernel;      /* which K1 ran last: 1 generic, 2 generic chunked, 3 separable tables (K1g), 4 bilinear GEMMs (K1b),
-                                    5 Chebyshev-node interpolation on 3-D / 4-D grids (K1t) */
+                                    5 Chebyshev-node interpolation on 3-D / 4-D grids (K1t), 6 the same two GEMMs as 4 on coefficients
+                                    interpolated from exactly evaluated Chebyshev nodes: a model's first sweep on a 2-D grid (K1i) */
   double posterior_executed_flops; /* matrix-core flops the last K1 launch(es) actually issued (K1b: far below the algorithmic count) */
   double posterior_setup_ms;     /* host time of the last per-(model, grid) table build of K1b, 0 when none was needed        */
   int64_t fp64_rechecks;         /* dtype SBO_F32 SafeOpt sweeps: candidates whose fp32 bounds could not decide S / U / u* / M / the
@@ -277,8 +278,10 @@ int sbo_plant_wo(sbo_ctx* ctx, int64_t n, const double* u, double* out);
 int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
 /* Diagnostics / test knobs (every default is the measured-best path; DESIGN.md "Options" has the A/B record of each):
  *   "posterior_path"   0 auto | 1 generic single-phase kernel (K1) | 2 generic chunked kernel (K1c)
- *   "bilinear"         1: fp64 2-D grids run the posterior as two GEMMs on a Chebyshev core (K1b) when the bases qualify; 0: K1g
- *   "cheb_tol_e17"     K1b: coefficients below this x 1e-17 of the largest are not run (default 400 = 4e-15)
+ *   "bilinear"         1: fp64 2-D grids run the posterior as two GEMMs on Chebyshev coefficients -- a model's first sweep with a caller's
+ *                      invK from exactly evaluated nodes (K1i), later sweeps from the reduced-basis plan (K1b) when the bases qualify;
+ *                      2: K1b's plan from the first sweep on; 0: K1g
+ *   "cheb_tol_e17"     K1b / K1i: coefficients below this x 1e-17 of the largest are not run (default 400 = 4e-15)
  *   "tensor_cheb"      1: fp64 3-D / 4-D grids interpolate the exact posterior from a tensor grid of Chebyshev nodes (K1t); 0: K1g
  *   "tensor_guess_pct" K1t test hook: scales the first guess of the node counts (a short guess exercises the probe's retry)
  *   "fuse_classify"    one-constraint K1b sweeps take S / U from the posterior's mean epilogue: 1 | 0 | -1 auto (default)
@@ -295,7 +298,7 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  *   "comm_events"      1: an event pair around every collective (sbo_profile.comm_ms)
  *   "comm_selftest"    1: a one-rank communicator still sends C1 / C2 / C3 through RCCL (results must not change)
  *   "fp64_recheck"     1: fp32 models re-evaluate in fp64 every candidate their 1e-4 contract cannot decide; 0: masks of the fp32 posterior
- *   "guard_band"       1: sweeps on an approximating posterior (K1b / K1t) count the decisions inside its band and re-evaluate exactly
+ *   "guard_band"       1: sweeps on an approximating posterior (K1b / K1i / K1t) count the decisions inside its band and re-evaluate exactly
  *                      when there are any; 0: masks of the approximating posterior as they come; 2: the re-evaluation on every sweep (test) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);
 
