@@ -118,7 +118,13 @@ def test_tcp_rendezvous_refuses_strangers_bad_ranks_and_repeats(monkeypatch):
     from safebo_amd import distributed as D
     assert "pickle" not in open(D.__file__).read().replace("unpickled", "")
     monkeypatch.setenv("SBO_RDZV_SECRET", "job-4711")
-    port = int(_free_port())
+    for _ in range(50):                                  # (a base port whose two neighbours above are free as well)
+        port = int(_free_port())
+        try:
+            with socket.create_server(("127.0.0.1", port + 1)), socket.create_server(("127.0.0.1", port + 2)):
+                break
+        except OSError:
+            continue
     world = 3
     # a stranger already listens on the first port of the window and never says a word: rank 0 moves to the next port, the
     # ranks give the stranger the hello timeout and find rank 0 behind it
