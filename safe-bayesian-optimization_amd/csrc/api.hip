@@ -214,6 +214,7 @@ int sbo_shutdown(sbo_ctx* c) {
   if (c->ev_w) (void)hipEventDestroy(c->ev_w);
   if (c->bi.exec) (void)hipGraphExecDestroy((hipGraphExec_t)c->bi.exec);
   if (c->h_bi_params) (void)hipHostFree(c->h_bi_params);
+  if (c->ev_bi_params) (void)hipEventDestroy((hipEvent_t)c->ev_bi_params);
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);

@@ -2755,9 +2755,18 @@ int interp_setup(sbo_ctx* c) {
     return SBO_OK;
   };
   const bool repeat = ip.sig_valid && !memcmp(&sig, &ip.sig, sizeof(sig));
-  memcpy(c->h_bi_params, &hp, sizeof(hp));        // (the previous plan's copy node has run: a sweep has synchronised since)
+  // (the previous plan's copy of the block has normally run long ago -- a sweep has synchronised since --, but two model changes in
+  // a row must not let the first plan's copy read the second model's block)
+  if (c->ev_bi_params) SBO_HIP(hipEventSynchronize((hipEvent_t)c->ev_bi_params));
+  else {
+    hipEvent_t ev;
+    SBO_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ev_bi_params = ev;
+  }
+  memcpy(c->h_bi_params, &hp, sizeof(hp));
   if (repeat && ip.exec) {
     SBO_HIP(hipGraphLaunch((hipGraphExec_t)ip.exec, xs));
+    SBO_HIP(hipEventRecord((hipEvent_t)c->ev_bi_params, xs));
     return finish();
   }
   if (!repeat) {
@@ -2844,6 +2853,7 @@ int interp_setup(sbo_ctx* c) {
     if (ok) {
       ip.exec = ex;
       SBO_HIP(hipGraphLaunch(ex, xs));
+      SBO_HIP(hipEventRecord((hipEvent_t)c->ev_bi_params, xs));
       return finish();
     }
     (void)hipGetLastError();
@@ -2852,6 +2862,7 @@ int interp_setup(sbo_ctx* c) {
   ip.sig = sig;
   ip.sig_valid = true;
   if ((rc = enqueue())) return rc;
+  SBO_HIP(hipEventRecord((hipEvent_t)c->ev_bi_params, xs));
   return finish();
 }
 

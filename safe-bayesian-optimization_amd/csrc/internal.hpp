@@ -204,6 +204,7 @@ struct sbo_ctx {
   sbo::InterpPlan bi;   // K1i plan (first sweep of a model)
   sbo::DevBuf bi_params; // ... its per-model parameter block (device) and the pinned staging the graph's copy node reads
   void* h_bi_params = nullptr;
+  void* ev_bi_params = nullptr;   // hipEvent_t: the plan's copy of the block (and everything before it on the main stream) has run
   sbo::DevBuf bl_grad;  // K1b: which tiles run the gradient phases (per plan)
   sbo::DevBuf bl_lpart; // K1b: per-wave Lipschitz partials of k_bpost
   sbo::DevBuf cpart;   // per-workgroup partials of k_classify, field-major [kClassifyRow][cpart_cap]

@@ -290,3 +290,31 @@ def test_k1i_node_ladder_and_decline(engine, log_ell, kernel):
     for sweep in ("safeopt", "goose", "tr"):
         assert out["first"][sweep]["guard_band"] == 0, sweep
     _same_decisions(out["first"], out["k1g"], ys[0], "k1g")
+
+
+def test_k1i_back_to_back_models_and_grid_after_model(engine):
+    """K1i's plan is enqueued by the model change and reads the model's constants from a block in device memory: two model changes in
+    a row (different n) must leave the LAST model's plan in force, and a grid that arrives after the model gets its plan with the
+    first sweep -- kernel 6 both times, decisions equal to the exact table kernel's."""
+    a, b_ = synthetic.make_config("B", n=128), synthetic.make_config("B", n=96, seed=synthetic.SEED0 + 77)
+    lo, hi, count, bb = a["bound"][:, 0], a["bound"][:, 1], [160, 176], 3.0
+    out = {}
+    try:
+        engine.set_grid(lo, hi, count)
+        engine.set_model(a["ds"])
+        engine.set_model(b_["ds"])                     # (replaces the model before anything swept it)
+        out["twice"] = _bundle(engine, b_, bb, 2, 2, fresh=False)
+        engine.set_model(b_["ds"])
+        engine.set_grid(lo, hi, [176, 160])            # (drops the plan the model change enqueued)
+        engine.set_grid(lo, hi, count)
+        out["late"] = _bundle(engine, b_, bb, 2, 2, fresh=False)
+        engine.set_option("bilinear", 0)
+        engine.set_model(b_["ds"])
+        out["k1g"] = _bundle(engine, b_, bb, 2, 2, fresh=False)
+    finally:
+        engine.set_option("bilinear", 1)
+    assert out["twice"]["prof"]["posterior_kernel"] == 6 and out["late"]["prof"]["posterior_kernel"] == 6 and out["k1g"]["prof"]["posterior_kernel"] == 3
+    ys = np.maximum(1.0, b_["ds"]["Y_std"])
+    _same_decisions(out["twice"], out["k1g"], ys[0], "twice")
+    _same_decisions(out["late"], out["k1g"], ys[0], "late")
+    _same_decisions(out["twice"], out["late"], ys[0], "twice vs late", floats=True)
