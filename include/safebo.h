@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SBO_ABI_VERSION 2
+#define SBO_ABI_VERSION 3
 #define SBO_MAX_D 8        /* input dimension limit (reference problems use d = 2)          */
 #define SBO_MAX_Q 8        /* modelled outputs: objective + constraints                      */
 #define SBO_MAX_N 2048     /* observations                                                   */
@@ -81,7 +81,12 @@ typedef struct sbo_sweep_opts {
                                       0: constraint c uses L_c                                            */
   int32_t want_masks;              /* 1: keep S/U/M/G (or O) masks in HBM for sbo_masks_get               */
   int32_t posterior_ready;         /* 1: reuse mean/var of the last sbo_posterior_run on these candidates */
-  int32_t reserved;
+  int32_t lean;                    /* the caller wants the sweep's result only -- sets, indices, counts, u*, L.  1: the sweep may leave mean /
+                                      var unwritten where no later stage of it reads them (the objective on posterior tiles without a safe
+                                      candidate: u*, M and the arg-max reductions are over S only, models/SafeOpt.py:47-66); 2: it need not
+                                      even evaluate them there (the result is the same; L_0 still comes from the whole grid).
+                                      sbo_posterior_get / sbo_bounds / a posterior_ready sweep behind a lean sweep run K1 again.  0 (the
+                                      default): the whole posterior is evaluated and stays resident, as models/GP_Safe.py:310-352 returns it */
 } sbo_sweep_opts;
 
 typedef struct sbo_safeopt_result {
@@ -173,7 +178,7 @@ typedef struct sbo_profile {
   double guard_ms;               /* device + host time of the last sweep's re-evaluation (0: none was needed)                      */
   int32_t halo_reruns;           /* multi-rank: set phases run again because SOME rank's speculative halo window was too narrow
                                     (the decision is global; host_syncs / comm_* include the discarded pass)                        */
-  int32_t reserved_p;
+  int32_t set_path;              /* set phase of the last SafeOpt sweep: 0 byte masks, 1 column words written by the GEMM posterior (r05)    */
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */
@@ -289,6 +294,10 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  *   "scan_blocks"      1: blocked last-axis scans of the distance transforms; 0: step by step (A/B checker)
  *   "scan_waves"       1: open candidates of the verdict kernels are listed and scanned by groups of 16 lanes (8 | 32 | 64: lanes); 0: own thread
  *   "goose_pairs"      1: GoOSE coverage by pruned pair evaluation on grids too (A/B checker of the power transform)
+ *   "col_path"         1: one-constraint SafeOpt sweeps of one rank on 2-D grids of whole 64 x 128 tiles run their set phase on column words
+ *                      written by the GEMM posterior's epilogue (sets_colpath.inc.hpp); 0: the byte-mask pipeline (A/B checker)
+ *   "col_overlap"      1: on that path the expander chain (distance transform, verdicts) runs on a second stream beside the objective's
+ *                      posterior launch; 0: every kernel on the main stream
  *   "set_fuse"         1: 2-D grids of one rank share launches between independent set-phase kernels; 0: one launch per kernel
  *   "set_lanes"        1: constraints of a one-rank sweep alternate between two streams; 0: one after the other
  *   "exact_lazy"       1: one-constraint sweeps launch the exhaustive recheck only when in-band verdicts were listed; 2: always that late path (test); 0: eager

@@ -31,7 +31,7 @@ SBO_E_UNSUPPORTED = -8
 
 class SweepOpts(C.Structure):
     _fields_ = [("b", C.c_double), ("reference_quirk_L_index", C.c_int32), ("want_masks", C.c_int32),
-                ("posterior_ready", C.c_int32), ("reserved", C.c_int32)]
+                ("posterior_ready", C.c_int32), ("lean", C.c_int32)]
 
 
 class SafeOptResult(C.Structure):
@@ -73,7 +73,7 @@ class Profile(C.Structure):
         ("fp64_rechecks", C.c_int64), ("recheck_ms", C.c_double),
         ("set_phase_ms", C.c_double), ("host_syncs", C.c_int32), ("comm_calls", C.c_int32), ("comm_bytes", C.c_int64),
         ("guard_dm", C.c_double * SBO_MAX_Q), ("guard_dv", C.c_double * SBO_MAX_Q), ("guard_rl", C.c_double * SBO_MAX_Q),
-        ("guard_ms", C.c_double), ("halo_reruns", C.c_int32), ("reserved_p", C.c_int32),
+        ("guard_ms", C.c_double), ("halo_reruns", C.c_int32), ("set_path", C.c_int32),
     ]
 
 
@@ -150,8 +150,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.sbo_version() != 2:
-        raise ImportError(f"libsafebo ABI version {lib.sbo_version()} != 2")
+    if lib.sbo_version() != 3:
+        raise ImportError(f"libsafebo ABI version {lib.sbo_version()} != 3")
     _lib = lib
     return lib
 

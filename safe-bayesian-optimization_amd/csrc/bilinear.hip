@@ -976,6 +976,15 @@ struct PostCtx {
   bool gb_on;
   double vminS;
   int cB;
+  // column-word classification (r05): role 1 = the constraint's tile packs its S / U bits (bw: S in the low, U in the high 16
+  // bits, bit 4 t + (lane >> 4) of the wave's 16 rows, one word per strip); role 2 = the objective's tile reads the S bits of its
+  // candidates back (bw: its own four bits per strip at 0, 4, 8, 12) and keeps u* / min var_0 over them
+  int role;
+  unsigned int bw[8];
+  unsigned int* lds_bits;   // [4 waves][128 columns] pieces of role 1
+  double umin;              // role 2: min ucb_0 over the thread's safe candidates (+inf: none)
+  double xmin;              // role 1: min of a lower bound of ucb_1 over its safe candidates; role 2: of lcb_0 (the tile's range for the set phase)
+  bool skip_store;          // lean sweep, objective tile without a safe candidate: mean / var are not stored (role 0)
 };
 
 // One GEMM phase of k_bpost on the workgroup's 128 x 128 tile: A images / B fragments of `KB` k-blocks per row block /
@@ -1001,6 +1010,50 @@ __device__ __forceinline__ void post_classify_mv(PostCtx& cx, size_t g, double m
   }
 }
 __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) { post_classify_mv(cx, g, m, cx.var_rd[g]); }
+// the same decisions as bits of the strip's word (role 1): no byte stores
+__device__ __forceinline__ void post_classify_bits(PostCtx& cx, int s2, unsigned int pos, double m, double v) {
+  const LcbSign sg = cx.gb_on ? lcb_sign_gb(m, v, cx.bconf, cx.bb, cx.lband, cx.cB) : lcb_sign(m, v, cx.bconf, cx.bb);
+  cx.bw[s2] |= ((unsigned int)sg.ge | ((unsigned int)sg.le << 16)) << pos;
+  cx.cS += sg.ge;
+  cx.cU += sg.le;
+  if (sg.ge) {
+    cx.vminS = v < cx.vminS ? v : cx.vminS;
+    // bounds of ucb_1 from one single-precision square root (ucb_upper / ucb_lower, device_common.hpp: the hardware's 1-ulp root is
+    // well inside their 2^-20 slack): the exact bound only when it could raise the radius key; the lower bound feeds the tile's range
+    const float sf = __builtin_amdgcn_sqrtf((float)v);
+    const double s_up = (double)sf * (1.0 + 0x1p-20) + 1e-18;
+    double s_lo = (double)sf * (1.0 - 0x1p-20) - 1e-18;
+    s_lo = s_lo > 0.0 ? s_lo : 0.0;
+    const bool fin = sf < 3.0e38f;
+    const double xu = m + cx.bconf * s_up, xl = m + cx.bconf * (fin ? s_lo : 0.0);
+    const double up = fin ? xu + (xu < 0 ? -xu : xu) * 0x1p-50 : 1e300, lo = xl - (xl < 0 ? -xl : xl) * 0x1p-50;
+    cx.xmin = lo < cx.xmin ? lo : cx.xmin;
+    if (!(up <= cx.rmax)) {
+      const double ucb = add_rn(m, mul_rn(cx.bconf, sqrt_rn(v)));
+      if (ucb > cx.rmax) cx.rmax = ucb;
+    }
+  }
+}
+// role 2: a safe candidate of the objective -- u* = min over S of ucb_0 (models/SafeOpt.py:47-51), the exact bound only when the
+// cheap lower bound could beat the thread's running minimum (as k_classify's objective pass), and the smallest var_0 over S
+__device__ __forceinline__ void post_objective(PostCtx& cx, bool set, double m, double v) {
+  if (set) {
+    cx.vminS = v < cx.vminS ? v : cx.vminS;
+    const float sf = __builtin_amdgcn_sqrtf((float)v);
+    const double s_up = (double)sf * (1.0 + 0x1p-20) + 1e-18;
+    double s_lo = (double)sf * (1.0 - 0x1p-20) - 1e-18;
+    s_lo = s_lo > 0.0 ? s_lo : 0.0;
+    const bool fin = sf < 3.0e38f;
+    const double xl = m + cx.bconf * (fin ? s_lo : 0.0), yl = m - cx.bconf * s_up;
+    const double ulo = xl - (xl < 0 ? -xl : xl) * 0x1p-50;                      // ucb_0 >= ulo
+    const double llo = fin ? yl - (yl < 0 ? -yl : yl) * 0x1p-50 : -1e300;       // lcb_0 >= llo: the tile's range for the minimiser
+    cx.xmin = llo < cx.xmin ? llo : cx.xmin;
+    if (ulo < cx.umin) {
+      const double ucb = add_rn(m, mul_rn(cx.bconf, sqrt_rn(v)));
+      cx.umin = ucb < cx.umin ? ucb : cx.umin;
+    }
+  }
+}
 
 // End of a posterior kernel: the waves' Lipschitz maxima (already reduced over the lanes) and, with the fused classification,
 // their counts and radius maxima, merged through LDS into ONE value / row per workgroup.  `sh`: NW x 4 doubles of LDS nobody
@@ -1008,10 +1061,17 @@ __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) {
 template <int NW>
 __device__ __forceinline__ void post_partials(double* sh, int lane, int wave, double gmax, bool fuse, int cS_, int cU_, double rmax_,
                                               int cB_, double vmin_, double* __restrict__ lrow, unsigned long long* __restrict__ crow /* this
-                                              workgroup's row of the field-major partials */, int pcap) {
+                                              workgroup's row of the field-major partials */, int pcap,
+                                              bool objrow = false /* the row of an objective tile (column path): rmax_ carries -min ucb_0 over
+                                              its safe candidates (so that the maximum below is the minimum), vmin_ their smallest var_0 */,
+                                              unsigned long long* __restrict__ slots = nullptr /* column path: the scalars also join slot
+                                              `slot` of every field by atomics (internal.hpp: ColSlotField) */, int slot = 0, int o = 0,
+                                              int tile_row = -1, int tile_col = 0,
+                                              double xmin_ = 1e300 /* column path: the tile's smallest lower bound of ucb_1 (constraint rows,
+                                              field 0) / of lcb_0 (objective rows, field 1) over its safe candidates */) {
   int cS = cS_, cU = cU_, cB = cB_;
-  double rm = rmax_, vm = vmin_;
-  if (fuse) {
+  double rm = rmax_, vm = vmin_, xm = xmin_;
+  if (fuse || objrow) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       cS += __shfl_xor(cS, off);
@@ -1021,6 +1081,8 @@ __device__ __forceinline__ void post_partials(double* sh, int lane, int wave, do
       rm = other > rm ? other : rm;
       const double ov = __shfl_xor(vm, off);
       vm = ov < vm ? ov : vm;
+      const double ox = __shfl_xor(xm, off);
+      xm = ox < xm ? ox : xm;
     }
   }
   __syncthreads();
@@ -1031,26 +1093,51 @@ __device__ __forceinline__ void post_partials(double* sh, int lane, int wave, do
     reinterpret_cast<int*>(sh + wave * 6 + 2)[1] = cU;
     reinterpret_cast<int*>(sh + wave * 6 + 3)[0] = cB;
     sh[wave * 6 + 4] = vm;
+    sh[wave * 6 + 5] = xm;
   }
   __syncthreads();
   if (wave == 0) {
-    double g = sh[0], r = sh[1], vmn = sh[4];
+    double g = sh[0], r = sh[1], vmn = sh[4], xmn = sh[5];
     long long s_ = 0, u_ = 0, b_ = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       g = sh[w * 6] > g ? sh[w * 6] : g;
       r = sh[w * 6 + 1] > r ? sh[w * 6 + 1] : r;
       vmn = sh[w * 6 + 4] < vmn ? sh[w * 6 + 4] : vmn;
+      xmn = sh[w * 6 + 5] < xmn ? sh[w * 6 + 5] : xmn;
       s_ += reinterpret_cast<const int*>(sh + w * 6 + 2)[0];
       u_ += reinterpret_cast<const int*>(sh + w * 6 + 2)[1];
       b_ += reinterpret_cast<const int*>(sh + w * 6 + 3)[0];
     }
     if (lane == 0) *lrow = g;
+    if (slots) {
+      // (no return values: the wave does not wait for them)
+      if (lane == 0) atomicMax(&slots[(size_t)(o == 0 ? kSlotL0 : kSlotL1) * kColSlots + slot], (unsigned long long)__double_as_longlong(g));
+      if (objrow) {
+        if (lane == 1 && r > -1e300) atomicMin(&slots[(size_t)kSlotUmin * kColSlots + slot], ord_key(-r));
+        if (lane == 2 && vmn < 1e300) atomicMin(&slots[(size_t)kSlotVmin0 * kColSlots + slot], ord_key(vmn));
+      } else {
+        if (lane == 1 && s_ != 0) atomicAdd(&slots[(size_t)kSlotS * kColSlots + slot], (unsigned long long)s_);
+        if (lane == 2 && u_ != 0) atomicAdd(&slots[(size_t)kSlotU * kColSlots + slot], (unsigned long long)u_);
+        if (lane == 3 && b_ != 0) atomicAdd(&slots[(size_t)kSlotB * kColSlots + slot], (unsigned long long)b_);
+        if (lane == 4 && vmn < 1e300) atomicMin(&slots[(size_t)kSlotVmin1 * kColSlots + slot], ord_key(vmn));
+        if (lane == 5 && r >= 0.0) atomicMax(&slots[(size_t)kSlotRmax1 * kColSlots + slot], ord_key(r));
+        if (lane == 6 && s_ != 0 && tile_row >= 0) atomicOr(&slots[(size_t)kSlotRowMask * kColSlots + tile_row], 1ull << tile_col);
+      }
+    }
+    if (objrow && lane < kFuseRow) {
+      // [u* key, 0, 0, 0, min-variance key of output 0, none.., no radius keys]
+      unsigned long long v = 0ull;
+      if (lane == 0) v = r > -1e300 ? ord_key(-r) : ~0ull;
+      else if (lane == 1) v = xmn < 1e300 ? ord_key(xmn) : ~0ull;                 // (the tile's range of lcb_0 over S: sets_colpath's minimiser)
+      else if (lane >= kFuseVmin && lane < kFuseRmax) v = (lane == kFuseVmin && vmn < 1e300) ? ord_key(vmn) : ~0ull;
+      crow[(size_t)lane * pcap] = v;
+    } else
     if (fuse && lane < kFuseRow) {
       // partial row of the classification, merged by k_classify_final: [u* key (none here), |S|, |U|, decisions inside the guard
       // band, min-variance keys over S (output 1 only), radius keys (constraint 1 only)]
       unsigned long long v = 0ull;
-      if (lane == 0) v = ~0ull;
+      if (lane == 0) v = (slots && xmn < 1e300) ? ord_key(xmn) : ~0ull;           // (column path: the tile's lower end of ucb_1 over S)
       else if (lane == 1) v = (unsigned long long)s_;
       else if (lane == 2) v = (unsigned long long)u_;
       else if (lane == 3) v = (unsigned long long)b_;
@@ -1062,7 +1149,7 @@ __device__ __forceinline__ void post_partials(double* sh, int lane, int wave, do
 }
 
 // Epilogue of phase PH for the RB x 8 accumulator tiles of a wave (row blocks cx.rb0 + RB cx.wave + i, strips cx.cs0 + s2)
-template <int PH, int RB>
+template <int PH, int RB, int ROLE>
 __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ outp, double c0, double c1, double c2, double& gmax_io,
                                               d4_t (&acc)[RB][8]) {
   // gradient phases: max |c0 v| = fl(|c0| max |v|) -- rounding is monotone --, so the tile keeps max |v| (one v_max_f64 with
@@ -1090,7 +1177,7 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
         const unsigned int line = (unsigned int)(cx.rb0 + RB * cx.wave + i) * 16u + 4u * t + row_in;
         const size_t g0 = (size_t)line * cx.ucnt0 + (unsigned int)cx.cs0 * 16u + col_in;
         double* const rowp = outp + g0;
-        if (PH == 1 && cx.S) {
+        if (PH == 1 && ROLE == 0 && cx.S) {
           // fused classification: the eight variances of this row first (all loads in flight; the byte stores below may
           // alias anything as far as the compiler knows), then bounds, S / U bytes and the partial sums
           double vr[8], mv[8];
@@ -1105,6 +1192,27 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
           for (int s2 = 0; s2 < 8; ++s2) post_classify_mv(cx, g0 + s2 * 16, mv[s2], vr[s2]);
           continue;
         }
+        if (PH == 1 && RB == 1 && ROLE != 0 && cx.role != 0) {
+          // column path (r05).  Role 1, the constraint: the same classification, its S / U decisions packed as bits of the strip's
+          // word.  Role 2, the objective: u* and min var_0 over the tile's safe candidates (bits read back from the constraint's launch).
+          double vr[8], mv[8];
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) vr[s2] = cx.var_rd[g0 + s2 * 16];
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            mv[s2] = (c0 + acc[i][s2][t]) * c1 + c2;
+            rowp[s2 * 16] = mv[s2];
+          }
+          if (ROLE == 1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) post_classify_bits(cx, s2, 4u * t + row_in, mv[s2], vr[s2]);
+          } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) post_objective(cx, ((cx.bw[s2] >> (4 * t)) & 1u) != 0u, mv[s2], vr[s2]);
+          }
+          continue;
+        }
+        if (PH <= 1 && RB == 1 && ROLE == 2 && cx.skip_store) continue;     // (lean sweep: nobody reads this tile's mean / var)
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) {
           const double v = acc[i][s2][t];
@@ -1119,6 +1227,17 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
           }
         }
       }
+    if (PH == 1 && RB == 1 && ROLE == 1) {
+      // the wave's 16 rows of every column: the four lanes that hold a column OR their bits together, lanes 0..15 put the piece
+      // (S low half, U high half) where the end of the kernel assembles the 64-bit words of the tile
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        unsigned int w = cx.bw[s2];
+        w |= (unsigned int)__shfl_xor((int)w, 16);
+        w |= (unsigned int)__shfl_xor((int)w, 32);
+        if (cx.lane < 16) cx.lds_bits[cx.wave * 128 + s2 * 16 + cx.lane] = w;
+      }
+    }
     return;
   }
 #pragma unroll
@@ -1142,7 +1261,7 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
         } else if (PH == 1) {
           const double m = (c0 + v) * c1 + c2;                              // :342, :346
           rowp[x0] = m;
-          if (cx.S) post_classify(cx, (size_t)line * cx.ucnt0 + x0, m);
+          if (ROLE == 0 && cx.S) post_classify(cx, (size_t)line * cx.ucnt0 + x0, m);
         } else {
           // component of the gradient of the un-normalised mean (analytic jax.grad(self.mean), SafeOpt.py:68-71)
           gmax = fmax(gmax, fabs(v));
@@ -1152,7 +1271,7 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
   }
 }
 
-template <int PH, int RB>
+template <int PH, int RB, int ROLE>
 __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict__ A, const double* __restrict__ B, int KB,
                                            int KS, double* __restrict__ outp, double c0, double c1, double c2, double& gmax,
                                            d4_t (&acc)[RB][8], const double* __restrict__ xn0, d4_t (&pre)[4],
@@ -1259,7 +1378,7 @@ __device__ __forceinline__ void post_phase(PostCtx& cx, const double* __restrict
     rb0v = *reinterpret_cast<const d4_t*>(Bpn);
     rb1v = *reinterpret_cast<const d4_t*>(Bpn + 4);
   }
-  post_epilogue<PH, RB>(cx, outp, c0, c1, c2, gmax, acc);
+  post_epilogue<PH, RB, ROLE>(cx, outp, c0, c1, c2, gmax, acc);
 }
 
 #ifdef SBO_PHASE_CLOCKS
@@ -1284,7 +1403,7 @@ __device__ unsigned long long g_phase_clk[kPhaseClkRows][8];
 // RB: row blocks per wave.  2 = the 128 x 128 tile above; 1 = a 64 x 128 tile for grids whose 128 x 128 tiles would leave
 // CUs without a workgroup (1024 x 1024 x 3 outputs: 192 tiles on 256 CUs) -- half the reuse of a B fragment, twice the
 // workgroups.
-template <int RB>
+template <int RB, int ROLE = 0 /* column path: 1 = the constraint's launch (S / U column words), 2 = the objective's (u* over S) */>
 __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
                                                   const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
                                                   size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
@@ -1300,9 +1419,10 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
                                                   const unsigned long long* __restrict__ gkey /* the grid's largest samples [q][2] */,
                                                   int imode /* K1i (interpolation from Chebyshev nodes): BtA / VA hold the stage-1 images of four
                                                   coefficient sets per output (quadratic form, mean sum, two gradient sums), SBf the Chebyshev table
-                                                  P0f; the k-steps of every phase come from eff[4 (4 o + phase)] */) {
-  extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256]
-  const int o = blockIdx.z;
+                                                  P0f; the k-steps of every phase come from eff[4 (4 o + phase)] */,
+                                                  const PostExtra px /* column path: one launch per output (o0), the S / U column words */) {
+  extern __shared__ double lds[];               // [2][A: 8 x 256 | B: 8 x 256] (+ 2 KB of bit pieces behind them, column path)
+  const int o = px.o0 + (int)blockIdx.z;
   PostCtx cx;
   cx.lds = lds;
   cx.tid = threadIdx.x; cx.lane = cx.tid & 63; cx.wave = cx.tid >> 6;
@@ -1335,7 +1455,19 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   cx.bb = bconf * bconf;
   cx.cS = cx.cU = cx.cB = 0;
   cx.rmax = -1.0;
-  cx.gb_on = fuse && gb != nullptr;
+  // column path: a tile is 64 rows (one segment of the column words) x 128 columns
+  const bool cbits = RB == 1 && ROLE == 1 && px.cb.Sw != nullptr && o == 1, obits = RB == 1 && ROLE == 2 && px.cb.Sw != nullptr && o == 0;
+  const size_t ctile = (size_t)blockIdx.y * gridDim.x + blockIdx.x, ntile = (size_t)gridDim.x * gridDim.y;
+  // (objective: how many safe candidates the constraint's launch counted in this tile -- field 1 of its partial row)
+  const unsigned long long tile_nS = obits ? cpart[(size_t)1 * pcap + ctile] : 0ull;
+  cx.role = cbits ? 1 : ((obits && tile_nS != 0ull) ? 2 : 0);
+  cx.skip_store = obits && tile_nS == 0ull && px.lean != 0;
+  cx.lds_bits = reinterpret_cast<unsigned int*>(lds + 2 * (RB == 2 ? 4096 : 3072));
+  cx.umin = 1e300;
+  cx.xmin = 1e300;
+#pragma unroll
+  for (int s2 = 0; s2 < 8; ++s2) cx.bw[s2] = 0u;
+  cx.gb_on = (fuse || cbits) && gb != nullptr;
   cx.lband = cx.gb_on ? lcb_band(cx.bb, gb->dm[1], gb->dv[1]) : LcbBand{0.0, 0.0};
   cx.vminS = 1e300;
   double gmax = 0.0;
@@ -1350,11 +1482,8 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   const int KS1 = imode ? eff[4 * (4 * o + 1)] : KSm, KS2 = imode ? eff[4 * (4 * o + 2)] : KSm, KS3 = imode ? eff[4 * (4 * o + 3)] : KSm;
 #ifdef SBO_PHASE_CLOCKS
   unsigned long long clk_ = wall_clock64();
-  const unsigned int clk_row_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const unsigned int clk_row_ = ((unsigned int)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 #endif
-  post_phase<0, RB>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, eff ? eff[4 * o * es] : KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0, pre,
-                    VAo, SBo, KBm);
-  SBO_CLK(0);
   // The gradient phases (their maxima are the Lipschitz keys, models/SafeOpt.py:68-83) run on the tiles that can hold the grid's
   // maximum: the tile's largest coarse sample + the plan's bound on what lies between the samples reaches the grid's largest
   // sample (k_bl_gradbound / k_bl_gradcoarse above).  Every tile folds its own samples in (true grid values).  NaN: run.
@@ -1363,7 +1492,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   double gfold = 0.0;                       // (uniform: scalar registers -- folded in behind the phases)
   if (gtmax) {
     const size_t nt = (size_t)gridDim.x * gridDim.y, tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const double* slack = gtmax + (size_t)gridDim.z * 2 * nt;
+    const double* slack = gtmax + (size_t)px.q * 2 * nt;
     const double t0 = gtmax[((size_t)o * 2 + 0) * nt + tile], t1 = gtmax[((size_t)o * 2 + 1) * nt + tile];
     const double G0 = __longlong_as_double((long long)gkey[2 * o + 0]), G1 = __longlong_as_double((long long)gkey[2 * o + 1]);
     run2 = !(t0 + slack[2 * o + 0] < G0 * (1.0 - 1e-12));
@@ -1371,13 +1500,30 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
     const double f0 = fabs(cg0 * t0), f1 = fabs(cg1 * t1);
     gfold = fmax(f0, f1);
   }
+  // lean sweeps, level 2: the objective's posterior of a tile without a safe candidate is not even evaluated -- u*, M and the
+  // arg-max reductions read it on S only (models/SafeOpt.py:47-66); the tile still runs the gradient phases the gate asks for
+  // (L_0 is a maximum over the whole grid), and with K1b's operands the mean phase those continue from
+  const bool skip_tile = ROLE == 2 && obits && tile_nS == 0ull && px.lean >= 2;
+  if (!skip_tile)
+    post_phase<0, RB, ROLE>(cx, BtA + (size_t)o * sBtA, P0f + (size_t)o * sP0f, KB0, eff ? eff[4 * o * es] : KS0, vo, sf2, ystd * ystd, 0.0, gmax, acc, xn0, pre,
+                            VAo, SBo, KBm);
+  SBO_CLK(0);
+  if (ROLE == 2 && cx.role == 2) {
+    // the thread's own S bits: rows 16 wave + 4 t + (lane >> 4) of the segment, column (cs0 + s2) 16 + (lane & 15)
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const unsigned long long w = px.cb.Sw[(size_t)blockIdx.y * cx.ucnt0 + (unsigned int)(cx.cs0 + s2) * 16u + (cx.lane & 15)];
+      cx.bw[s2] = (unsigned int)(w >> (16 * cx.wave + (cx.lane >> 4))) & 0x1111u;
+    }
+  }
   // (the mean phase requests the first operands of whichever phase follows it)
-  post_phase<1, RB>(cx, VAo, SBo, KBm, KS1, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0, pre, run2 ? A2 : A3, run2 ? B2 : SBo,
-                    run2 ? KBm2 : KBm);
+  if (!skip_tile || (run2 && !imode))
+    post_phase<1, RB, ROLE>(cx, VAo, SBo, KBm, KS1, mo, mc.mp[o], ystd, mc.Y_mean[o], gmax, acc, xn0, pre, run2 ? A2 : A3, run2 ? B2 : SBo,
+                            run2 ? KBm2 : KBm);
   SBO_CLK(1);
   // phase 2 continues on phase 1's sums: only the V1 half (the first KSm k-steps) of the stacked operands is run
-  if (run2) post_phase<2, RB>(cx, A2, B2, KBm2, KS2, nullptr, cg0, 0.0, 0.0, gmax, acc, xn0, pre, A3, SBo, KBm);
-  if (run3) post_phase<3, RB>(cx, A3, SBo, KBm, KS3, nullptr, cg1, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
+  if (run2) post_phase<2, RB, ROLE>(cx, A2, B2, KBm2, KS2, nullptr, cg0, 0.0, 0.0, gmax, acc, xn0, pre, A3, SBo, KBm);
+  if (run3) post_phase<3, RB, ROLE>(cx, A3, SBo, KBm, KS3, nullptr, cg1, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
   gmax = fmax(gmax, gfold);
   SBO_CLK(2);
 #pragma unroll
@@ -1388,8 +1534,24 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   // one plain store per WORKGROUP, merged by k_lmax_reduce / the classification's final merge: every workgroup of this launch
   // is resident at once and ends at the same time, so atomics on the q keys would queue up in L2 as the kernel's tail -- and
   // a row per wave made that merge (one workgroup, 16384 rows of 88 bytes on config H) the longest job of the launch it shares
-  post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, fuse, cx.cS, cx.cU, cx.rmax, cx.cB, cx.vminS, Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
-                   cpart + ((size_t)blockIdx.y * gridDim.x + blockIdx.x), pcap);
+  // (column path: the constraint's rows first, the objective's rows behind them)
+  post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, fuse || cbits, cx.cS, cx.cU, obits ? -cx.umin : cx.rmax, cx.cB, cx.vminS,
+                   Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, cpart + (obits ? ntile : (size_t)0) + ctile, pcap, obits,
+                   (cbits || obits) ? px.cb.slots : nullptr, (int)(ctile & (kColSlots - 1)), o, cbits ? (int)blockIdx.y : -1, (int)blockIdx.x, cx.xmin);
+  if (cbits && cx.tid < 128) {
+    // the tile's words: column tid, the four waves' 16-row pieces (written before the barriers of post_partials)
+    unsigned long long sw = 0ull, uw = 0ull;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned int pc = cx.lds_bits[w * 128 + cx.tid];
+      sw |= (unsigned long long)(pc & 0xffffu) << (16 * w);
+      uw |= (unsigned long long)(pc >> 16) << (16 * w);
+    }
+    const size_t col = (size_t)cx.cs0 * 16u + cx.tid;
+    px.cb.Sw[(size_t)blockIdx.y * cx.ucnt0 + col] = sw;
+    px.cb.Uw[(size_t)blockIdx.y * cx.ucnt0 + col] = uw;
+    if (uw != 0ull) atomicOr(&px.cb.Usum[col], 1ull << blockIdx.y);
+  }
   SBO_CLK(3);
 #ifdef SBO_PHASE_CLOCKS
   if (threadIdx.x == 0) {
@@ -1399,12 +1561,12 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
 #endif
 }
 #ifdef SBO_PHASE_CLOCKS
-extern "C" int sbo_debug_phase_clocks(unsigned long long* out /* [8]: sums over the rows */, int reset) {
+extern "C" int sbo_debug_phase_clocks(unsigned long long* out /* [16]: sums over the rows below `split` | from `split` on */, int reset, int split) {
   std::vector<unsigned long long> h((size_t)kPhaseClkRows * 8);
   if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_phase_clk), sizeof(unsigned long long) * h.size()) != hipSuccess) return 1;
-  for (int k = 0; k < 8; ++k) out[k] = 0;
+  for (int k = 0; k < 16; ++k) out[k] = 0;
   for (size_t r = 0; r < (size_t)kPhaseClkRows; ++r)
-    for (int k = 0; k < 8; ++k) out[k] += h[r * 8 + k];
+    for (int k = 0; k < 8; ++k) out[(r < (size_t)split ? 0 : 8) + k] += h[r * 8 + k];
   if (reset) {
     std::fill(h.begin(), h.end(), 0ull);
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), h.data(), sizeof(unsigned long long) * h.size()) != hipSuccess) return 1;
@@ -2866,6 +3028,38 @@ int interp_setup(sbo_ctx* c) {
   return finish();
 }
 
+// Column path (r05): can this launch deliver the classification as column words?  One constraint, fp64 grid of whole 64 x 128
+// tiles (every workgroup's tile inside the grid), at most 64 segments (Usum is one word per column); the sweep asked for it.
+static bool col_words_ok(const sbo_ctx* c, long long cnt0, long long nlines) {
+  return c->col_request && c->col_path && c->mc.q == 2 && c->cs.kind == 1 && c->cs.d == 2 && c->cs.first == 0 && cnt0 % 128 == 0 &&
+         nlines % 64 == 0 && nlines / 64 <= 64 && nlines >= 64 && cnt0 >= 128 && cnt0 <= 4096 && c->world == 1 && !c->comm_selftest;
+}
+static int col_words_prepare(sbo_ctx* c, long long cnt0, long long nlines, ColBits* cb) {
+  const size_t words = (size_t)(nlines / 64) * (size_t)cnt0;
+  int rc;
+  if ((rc = ensure(c->cbS, 8 * words)) || (rc = ensure(c->cbU, 8 * words)) || (rc = ensure(c->cbM, 8 * words)) || (rc = ensure(c->cbG, 8 * words))) return rc;
+  const bool fresh = c->cbUsum.bytes < 8 * (size_t)cnt0;
+  if ((rc = ensure(c->cbUsum, 8 * (size_t)cnt0))) return rc;
+  if (fresh || c->usum_dirty) SBO_HIP(hipMemsetAsync(c->cbUsum.p, 0, c->cbUsum.bytes, c->stream));
+  c->usum_dirty = true;       // (until the column path's second kernel has cleared it again)
+  const size_t sbytes = sizeof(unsigned long long) * kColSlotFields * kColSlots;
+  if (c->col_slots.bytes < sbytes) c->slots_clean = false;
+  if ((rc = ensure(c->col_slots, sbytes))) return rc;
+  if (!c->slots_clean) {
+    unsigned long long init[kColSlotFields * kColSlots];
+    for (int f = 0; f < kColSlotFields; ++f)
+      for (int k = 0; k < kColSlots; ++k) init[f * kColSlots + k] = col_slot_is_min(f) ? ~0ull : 0ull;
+    SBO_HIP(hipMemcpyAsync(c->col_slots.p, init, sbytes, hipMemcpyHostToDevice, c->stream));
+    SBO_HIP(hipStreamSynchronize(c->stream));           // (first use, or after a failed sweep: `init` is on this stack)
+  }
+  c->slots_clean = false;     // (until the sweep's finals have reset the block)
+  cb->Sw = (unsigned long long*)c->cbS.p;
+  cb->Uw = (unsigned long long*)c->cbU.p;
+  cb->Usum = (unsigned long long*)c->cbUsum.p;
+  cb->slots = (unsigned long long*)c->col_slots.p;
+  return SBO_OK;
+}
+
 int launch_posterior_interp(sbo_ctx* c) {
   InterpPlan& ip = c->bi;
   const ModelConst& mc = c->mc;
@@ -2879,27 +3073,49 @@ int launch_posterior_interp(sbo_ctx* c) {
                      (const int*)ip.eff);
   const unsigned gx = (unsigned)((ip.ncs0 + 7) / 8), gy = (unsigned)((ip.nrb + 3) / 4);
   const unsigned rows_out = gx * gy;
-  const size_t lds = sizeof(double) * 2 * 3072;
+  const size_t lds = sizeof(double) * 2 * 3072 + 2048;
   int rc;
   if ((rc = ensure(c->bl_lpart, sizeof(double) * (size_t)rows_out * q))) return rc;
   const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
-  const bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local && c->maskU.bytes >= (size_t)cs.n_local;
+  bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local && c->maskU.bytes >= (size_t)cs.n_local;
+  const bool colw = fuse && col_words_ok(c, cnt0, nlines);
+  PostExtra px;
+  memset(&px, 0, sizeof(px));
+  px.q = q;
+  c->col_active = false;
   c->fuse_rows = 0;
   if (fuse) {
-    c->fuse_rows = (int)rows_out;
+    c->fuse_rows = (int)rows_out * (colw ? 2 : 1);
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
     c->cpart_cap = (int)(c->cpart.bytes / (sizeof(unsigned long long) * kFuseRow));
   }
+  if (colw) {
+    if ((rc = col_words_prepare(c, cnt0, nlines, &px.cb))) return rc;
+    px.lean = c->col_lean;
+    c->col_active = true;
+    c->col_forked = true;
+    fuse = false;                      // (no byte masks: the words are the classification)
+  }
   const GuardBand* gb_fused = (c->guard_band && ip.band_ready && c->gb.p) ? (const GuardBand*)c->gb.p : nullptr;
-  auto kpost = k_bpost<1>;
-  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const double* BtA = (const double*)c->bl_BtA.p;
-  hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream, nullptr, c->lmax_defer ? c->ev[1] : nullptr, 0, mc, cs, BtA,
-                        4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, BtA + ip.sBtA, 4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, KB,
-                        KB * 4, KB, KB * 4, KB, ip.nrb, ip.ncs0, nlines, (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p,
-                        (const double*)c->bl_small.p /* xn0 */, fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr,
-                        fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b, (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused,
-                        (const int*)ip.eff, ip.gtmax, ip.gkey, 1);
+  // (column path: the constraint's launch first -- the objective's tiles read its words and its counts of safe candidates per tile)
+  for (int part = 0; part < (colw ? 2 : 1); ++part) {
+    px.o0 = colw ? 1 - part : 0;
+    const bool last = !colw || part == 1;
+    auto kpost = !colw ? k_bpost<1, 0> : (part == 0 ? k_bpost<1, 1> : k_bpost<1, 2>);
+    // (the constraint's launch carries the fork event of the overlapped sweep: the expander chain starts behind it on stream3
+    // while the objective's launch runs here)
+    hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)(colw ? 1 : q)), dim3(256), lds, c->stream, nullptr,
+                          (c->lmax_defer && last) ? c->ev[1] : ((colw && part == 0) ? c->ev_col[0] : nullptr), 0, mc, cs, BtA,
+                          4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, BtA + ip.sBtA, 4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, KB,
+                          KB * 4, KB, KB * 4, KB, ip.nrb, ip.ncs0, nlines, (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p,
+                          (const double*)c->bl_small.p /* xn0 */, fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr,
+                          fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b, (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused,
+                          (const int*)ip.eff, ip.gtmax, ip.gkey, 1, px);
+  }
   if (c->lmax_defer) {
     c->lmax_pending = true;
     c->lmax_per_out = (int)rows_out;
@@ -2934,7 +3150,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   // B-fragment reuse of a 128 x 128 tile (r03: config B 0.204 -> 0.189 ms per sweep, H 0.547 -> 0.543)
   const unsigned gx = (unsigned)((pl.ncs0 + 7) / 8);
   constexpr int rbw = 1;
-  const size_t lds = sizeof(double) * 2 * 3072;
+  const size_t lds = sizeof(double) * 2 * 3072 + 2048;
   const unsigned gy = (unsigned)((pl.nrb + 4 * rbw - 1) / (4 * rbw));
   const unsigned rows_out = gx * gy;                      // partial rows per output: one per workgroup
   int rc;
@@ -2944,27 +3160,47 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   // (r03: with the sqrt-free sign tests the fused epilogue saves the separate pass 76 us on config H and costs the GEMM 36;
   // on config B, two workgroups per CU, the two cancel -- "auto" asks for at least four workgroups per CU)
   const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
-  const bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
-                    c->maskU.bytes >= (size_t)cs.n_local;
+  bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
+              c->maskU.bytes >= (size_t)cs.n_local;
+  const bool colw = fuse && col_words_ok(c, cnt0, nlines);
+  PostExtra px;
+  memset(&px, 0, sizeof(px));
+  px.q = q;
+  c->col_active = false;
   c->fuse_rows = 0;
   if (fuse) {
-    c->fuse_rows = (int)rows_out;
+    c->fuse_rows = (int)rows_out * (colw ? 2 : 1);
     // (room behind the rows for the partials of the objective pass, see sweep_common_front)
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
     c->cpart_cap = (int)(c->cpart.bytes / (sizeof(unsigned long long) * kFuseRow));
   }
+  if (colw) {
+    if ((rc = col_words_prepare(c, cnt0, nlines, &px.cb))) return rc;
+    px.lean = c->col_lean;
+    c->col_active = true;
+    c->col_forked = true;
+    fuse = false;                      // (no byte masks: the words are the classification)
+  }
   // (the fused classification counts its sign tests inside the plan's guard band)
   const GuardBand* gb_fused = (c->guard_band && !c->is_shadow && c->bl.band_ready && c->gb.p) ? (const GuardBand*)c->gb.p : nullptr;
-  auto kpost = k_bpost<rbw>;
-  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kpost), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<rbw, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<rbw, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<rbw, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // the K1 stop event rides on the last launch (hipExtLaunchKernel): a separate hipEventRecord behind it is a barrier packet
   // the next kernel waits ~6 us for.  A sweep merges the Lipschitz partials in its own first small kernel (lmax_defer).
-  hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)q), dim3(256), lds, c->stream, nullptr, c->lmax_defer ? c->ev[1] : nullptr, 0,
-                        mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
-                        pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
-                        (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
-                        fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
-                        (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused, (const int*)pl.eff, pl.gtmax, pl.gkey, 0);
+  // (column path: the constraint's launch first -- the objective's tiles read its words and its counts of safe candidates per tile)
+  for (int part = 0; part < (colw ? 2 : 1); ++part) {
+    px.o0 = colw ? 1 - part : 0;
+    const bool last = !colw || part == 1;
+    auto kpost = !colw ? k_bpost<rbw, 0> : (part == 0 ? k_bpost<rbw, 1> : k_bpost<rbw, 2>);
+    hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)(colw ? 1 : q)), dim3(256), lds, c->stream, nullptr,
+                          (c->lmax_defer && last) ? c->ev[1] : ((colw && part == 0) ? c->ev_col[0] : nullptr), 0,
+                          mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
+                          pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
+                          (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
+                          fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
+                          (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused, (const int*)pl.eff, pl.gtmax, pl.gkey, 0, px);
+  }
   if (c->lmax_defer) {
     c->lmax_pending = true;
     c->lmax_per_out = (int)rows_out;

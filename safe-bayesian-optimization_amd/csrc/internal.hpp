@@ -41,6 +41,34 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// Column-word form of the masks of a 2-D grid (r05): word [s][i] holds the bits of column i (axis 0) for the 64 rows
+// 64 s .. 64 s + 63 of axis 1 -- exactly what one 64 x 128 tile of the GEMM posterior (k_bpost) knows about a column, so the
+// constraint's mean epilogue emits the S / U words itself (128 coalesced 8-byte stores per tile instead of 16384 byte
+// stores), and every set-phase kernel of the column path (sets_colpath.inc.hpp) reads 1/8 of the bytes.  Usum[i]: bit s set
+// iff Uw[s][i] != 0 (the carries of the column distance transform in two dependent loads).
+struct ColBits {
+  unsigned long long* Sw;
+  unsigned long long* Uw;
+  unsigned long long* Usum;
+  unsigned long long* slots;   // [kColSlotFields][kColSlots]: the tiles' partial scalars, merged by atomics as the workgroups end
+};
+// One workgroup merging the 2 x 2048 partial rows of config H took 15 us at the head of the set phase.  Instead a tile's workgroup
+// adds / maxes / mins its scalars into slot (tile mod 64) of each field (64 addresses per field: no queueing in L2), and whoever
+// needs a scalar reduces 64 words with one load per lane.  The finals reset the block for the next sweep.
+constexpr int kColSlots = 64;
+enum ColSlotField { kSlotUmin = 0 /* min key of ucb_0 over S */, kSlotS, kSlotU, kSlotB /* counts */, kSlotVmin0, kSlotVmin1 /* min keys */,
+                    kSlotRmax1 /* max key */, kSlotL0, kSlotL1 /* max of the gradient norms' bit patterns */,
+                    kSlotRowMask /* word s: bit t set iff tile t of tile row s holds a safe candidate */, kColSlotFields };
+__host__ __device__ inline bool col_slot_is_min(int f) { return f == kSlotUmin || f == kSlotVmin0 || f == kSlotVmin1; }
+// what a k_bpost launch is told beyond its operands (r05: one launch per output on the column path)
+struct PostExtra {
+  int o0;        // first output of this launch (blockIdx.z counts from it)
+  int q;         // outputs of the model (layout of the gradient gate's tables)
+  int lean;      // 1: an objective tile without a safe candidate does not store its mean / var (nobody reads them)
+  int pad;
+  ColBits cb;    // Sw == nullptr: no bit words (byte masks or no classification at all)
+};
+
 // K1b (bilinear.hip): device tables of the reduced-basis posterior on a 2-D grid, valid for one (model, candidates) pair
 struct BilinearPlan {
   bool valid = false;    // built (or found unusable) for the current model and candidates
@@ -221,6 +249,24 @@ struct sbo_ctx {
   int fuse_request = 0;    // 0 no, 1 yes, 2 when the GEMM launch is large enough for it to pay (option fuse_classify = -1)
   double fuse_b = 0.0;
   int fuse_rows = 0;
+  // Column path (r05, sets_colpath.inc.hpp): a one-rank SafeOpt sweep of a one-constraint model on a 2-D grid of whole
+  // 64 x 128 tiles asks (col_request) for the classification as column words; the GEMM posterior then runs one launch per
+  // output -- constraint first: S / U words, |S| per tile; objective second: u* and min var_0 over S from its own epilogue --
+  // and says so (col_active).  The words stay resident for sbo_masks_get (masks_bits: expanded to bytes on demand).
+  bool col_request = false, col_active = false;
+  int col_lean = 0;        // the running request: objective tiles without a safe candidate need not store mean / var
+  bool slots_clean = false;// the slot block holds its neutral elements (the finals of the last column sweep reset it)
+  bool usum_dirty = false; // Usum holds bits of an earlier launch (cleared by the column path's second kernel; by a memset after a failure)
+  int col_path = 1;        // option: 0 = never
+  int col_overlap = 1;     // option: 1 = the expander chain runs on stream3 beside the objective's posterior launch; 0: one stream
+  sbo::DevBuf cbS, cbU, cbM, cbG, cbUsum;    // column words [H / 64][W]; Usum [W]
+  sbo::DevBuf col_slots;                     // ColBits::slots
+  sbo::DevBuf col_img, col_bmin;             // column distance image u16 [H][W], block minima u16 [H][W / 32]
+  sbo::DevBuf col_fin;                       // the objective's scalars, the finals' tickets and intermediate rows (4 KB)
+  hipEvent_t ev_col[2]{};      // fork (the constraint's posterior launch has finished) / join (the expander chain on stream3 has)
+  bool col_forked = false;     // the constraint's launch of the running posterior carried ev_col[0]
+  bool masks_bits = false;     // the masks of the last sweep live in the column words (byte buffers stale)
+  bool col_G_bytes = false;    // ... except G, which the exhaustive recheck finished in byte form
   // Lipschitz keys of K1b: a sweep sets lmax_defer before it enqueues the posterior; the posterior then leaves its per-wave
   // partials (lmax_per_out per output) for the sweep's k_classify_final / k_edt_axis0_pair to merge (lmax_pending)
   bool lmax_defer = false;

@@ -1019,6 +1019,8 @@ static int sweep_masks(sbo_ctx* c, double b, bool may_fuse) {
   if ((rc = ensure(c->maskU, (size_t)npad_shard))) return rc;
   if ((rc = ensure(c->maskM, (size_t)n))) return rc;
   if ((rc = ensure(c->maskG, (size_t)n * std::max(1, q - 1)))) return rc;
+  c->masks_bits = false;
+  c->col_G_bytes = false;
   c->fuse_request = (may_fuse && q == 2) ? (c->fuse_classify < 0 ? 2 : c->fuse_classify) : 0;
   c->lmax_defer = may_fuse;        // (every sweep merges K1b's Lipschitz partials in its k_classify_final)
   c->lmax_pending = false;
@@ -1738,6 +1740,8 @@ static void sweep_comm_reset(sbo_ctx* c) {
   c->comm_host_ms = 0.0;
 }
 
+#include "sets_colpath.inc.hpp"
+
 template <typename T>
 static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_result* res) {
   const long long n = c->cs.n_local;
@@ -1747,11 +1751,27 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
-  if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
+  // column path (sets_colpath.inc.hpp): a fresh posterior of a one-constraint fp64 model on one rank may deliver the classification
+  // as column words (the GEMM posterior decides whether its launch qualifies: col_active)
+  c->col_request = !reuse && std::is_same<T, double>::value && q == 2 && !multi_rank(c) && !c->rc_active && c->result_mirror && n > 0;
+  static const int env_lean = getenv("SBO_LEAN") ? atoi(getenv("SBO_LEAN")) : -1;          // (development: tools/dev_col_stats.sh)
+  const int lean = env_lean >= 0 ? env_lean : o->lean;
+  c->col_lean = c->col_request ? (lean >= 2 ? 2 : (lean ? 1 : 0)) : 0;
+  c->col_active = false;
+  if (!reuse && (rc = sbo_posterior_enqueue_(c))) { c->col_request = false; return rc; }
+  c->col_request = false;
   c->fuse_request = 0;
   c->lmax_defer = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
+  SweepScalars h;
+  unsigned long long Lk[kMaxQ];
+  const bool colpath = c->col_active;
+  if (colpath) {
+    // (a lean sweep left the objective's mean / var unwritten where no later stage reads them: whoever wants the posterior re-runs K1)
+    if (c->col_lean) c->posterior_valid = false;
+    if ((rc = col_set_phase(c, o, h, Lk))) return rc;
+  } else {
   MinimizerJob mj;
   const int nb = reduce_blocks(c);
   // one constraint on one rank: the exhaustive recheck of in-band candidates (almost never any) is launched only when the
@@ -1798,10 +1818,8 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
                         lanes ? (const SweepScalars*)c->lane1.scal.p : (const SweepScalars*)nullptr,
                         mirrored ? c->h_back : (unsigned char*)nullptr, (const unsigned long long*)c->Lmax.p, gb_of(c) ? 1 : 0);
   SBO_HIP(hipGetLastError());
-  SweepScalars h;
   bool is_max[kArgSlots];
   for (int t = 0; t < kArgSlots; ++t) is_max[t] = true;
-  unsigned long long Lk[kMaxQ];
   if ((rc = sweep_exchange_back(c, h, is_max, Lk, c->ev[4], mirrored))) return rc;
   if (lazy_exact && (h.n_amb > 0 || c->exact_lazy == 2)) {      // (2: always, the test of this path)
     // in-band candidates after all: their exhaustive recheck, then the expanders' arg-max and the finals once more
@@ -1832,6 +1850,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
     }
     halo_learn(c, h, Lk, o->reference_quirk_L_index);
   }
+  }      // (byte-mask path)
   c->masks_valid = true;
   c->last_sweep = 1;
   if (getenv("SBO_DEBUG_SCAN")) fprintf(stderr, "[safebo] open candidates scanned (last constraint) %lld, exact rechecks %lld\n", h.n_scan, h.n_amb_total);
@@ -1855,6 +1874,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   const double nn = c->mc.n, dd = c->mc.d;
   c->prof.posterior_flops = reuse ? 0.0 : q * (nn * nn + (2 * dd + 10) * nn) * (double)n;
   sweep_times(c);
+  c->prof.set_path = colpath ? 1 : 0;
 
   memset(res, 0, sizeof(*res));
   res->count_S = h.count_S;
@@ -2504,10 +2524,29 @@ int sbo_sweep_tr(sbo_ctx* c, const sbo_sweep_opts* opts, const double* x_0, doub
   return rc;
 }
 
+// development: histograms of wave lifetimes of the column path's kernels (SBO_COL_DBG=9)
+int sbo_debug_col_hist(unsigned long long* out /* [6][64] */, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_col_hist), sizeof(unsigned long long) * 6 * 64) != hipSuccess) return 1;
+  if (reset) {
+    static unsigned long long z[6 * 64];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_col_hist), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+
 int sbo_masks_get(sbo_ctx* c, int which, int cidx, uint8_t* out) {
   if (!c || !out) return fail(SBO_E_INVALID, "NULL argument");
   if (!c->masks_valid) return fail(SBO_E_INVALID, "no sweep has produced masks on these candidates");
   const long long n = c->cs.n_local;
+  if (c->masks_bits && n > 0) {
+    // the last sweep ran on column words (sets_colpath.inc.hpp): the byte form of the mask asked for is made here
+    SBO_HIP(hipSetDevice(c->device));
+    if (which == SBO_MASK_S) col_expand(c, c->cbS, (uint8_t*)c->maskS.p);
+    else if (which == SBO_MASK_U) col_expand(c, c->cbU, (uint8_t*)c->maskU.p);
+    else if (which == SBO_MASK_M) col_expand(c, c->cbM, (uint8_t*)c->maskM.p);
+    else if (which == SBO_MASK_G && cidx == 1 && !c->col_G_bytes) col_expand(c, c->cbG, (uint8_t*)c->maskG.p);
+    SBO_HIP(hipGetLastError());
+  }
   const void* src = nullptr;
   switch (which) {
     case SBO_MASK_S: src = c->maskS.p; break;

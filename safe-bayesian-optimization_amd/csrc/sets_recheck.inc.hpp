@@ -352,7 +352,8 @@ static int sweep_safeopt_recheck(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeop
   int rc;
   if (!kGuard && n == 0 && !multi_rank(c)) return sweep_safeopt_t<float>(c, o, res);
   SBO_HIP(hipEventRecord(c->ev_join[0], c->stream));
-  const bool reuse = kGuard || (o->posterior_ready && c->posterior_valid);
+  // (guard: the posterior is resident -- unless the first pass was a lean sweep, which left part of it unwritten: K1 once more, in full)
+  const bool reuse = (kGuard && c->posterior_valid) || (o->posterior_ready && c->posterior_valid);
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   c->k1_stop_attached = false;
   SBO_HIP(hipEventRecord(c->ev_join[1], c->stream));

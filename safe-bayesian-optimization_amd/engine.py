@@ -173,13 +173,15 @@ class SweepEngine:
         L.check(self._lib.sbo_bounds(self._ctx, float(b), int(index), k, _ptr(out)))
         return out
 
-    def _opts(self, b, quirk, want_masks, posterior_ready):
-        return L.SweepOpts(float(b), int(bool(quirk)), int(bool(want_masks)), int(bool(posterior_ready)), 0)
+    def _opts(self, b, quirk, want_masks, posterior_ready, lean=False):
+        return L.SweepOpts(float(b), int(bool(quirk)), int(bool(want_masks)), int(bool(posterior_ready)), int(lean))
 
     def sweep_safeopt(self, b: float, quirk_L_index: bool = True, want_masks: bool = False,
-                      posterior_ready: bool = False) -> dict:
+                      posterior_ready: bool = False, lean: bool = False) -> dict:
+        """``lean``: the caller wants the sweep's result only.  1 / True: mean / var may stay unwritten where no stage of the sweep
+        reads them; 2: they need not be evaluated there at all (``posterior()`` behind a lean sweep runs K1 again)."""
         res = L.SafeOptResult()
-        opts = self._opts(b, quirk_L_index, want_masks, posterior_ready)
+        opts = self._opts(b, quirk_L_index, want_masks, posterior_ready, lean)
         L.check(self._lib.sbo_sweep_safeopt(self._ctx, C.byref(opts), C.byref(res)))
         d, q = self.d, self.q
         return {

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_struct_layout(tmp_path):
     lib = _lib.load()
-    assert lib.sbo_version() == 2
+    assert lib.sbo_version() == 3
     # the ctypes mirrors must have the sizes a C compiler gives the header's structs
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "safebo.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", '

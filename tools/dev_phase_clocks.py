@@ -16,8 +16,8 @@ from safebo_amd import synthetic                    # noqa: E402
 
 lib = safebo_amd._lib.load()
 clk = lib.sbo_debug_phase_clocks
-clk.restype, clk.argtypes = C.c_int, [C.POINTER(C.c_uint64), C.c_int]
-buf = (C.c_uint64 * 8)()
+clk.restype, clk.argtypes = C.c_int, [C.POINTER(C.c_uint64), C.c_int, C.c_int]
+buf = (C.c_uint64 * 16)()
 nofuse = "--nofuse" in sys.argv
 
 
@@ -38,20 +38,24 @@ for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["H"]:
     for _ in range(5):
         sweep(eng, cfg["b"])
     eng.synchronize()
-    assert clk(buf, 1) == 0
+    split = (cfg["count"][0] // 128) * (cfg["count"][1] // 64)          # rows of output 0 (the objective's tiles)
+    assert clk(buf, 1, split) == 0
     steps, k1 = 50, []
     for _ in range(steps):
         sweep(eng, cfg["b"])
         k1.append(eng.profile()["posterior_ms"])
     eng.synchronize()
-    assert clk(buf, 0) == 0
-    v = np.array(list(buf), dtype=np.float64)
-    wgs = v[5]
+    assert clk(buf, 0, split) == 0
+    both = np.array(list(buf), dtype=np.float64)
     names = ["variance phase (GEMM + epilogue)", "mean phase (+ fused classification on the constraint)", "gradient phases (tiles that run them)",
              "partial rows"]
-    print(f"config {name}: {int(wgs / steps)} workgroups per launch, {v[4] / steps:.0f} gradient phases run per launch, K1 {np.mean(k1) * 1e3:.1f} us")
-    tot = v[:4].sum()
-    for i, nm in enumerate(names):
-        print(f"   {nm:58s} {v[i] / wgs * 1e-2:7.2f} us per workgroup   {100.0 * v[i] / tot:5.1f} % of a workgroup's life")
-    print(f"   {'life of a workgroup':58s} {tot / wgs * 1e-2:7.2f} us")
+    for out_i, v in ((0, both[:8]), (1, both[8:])):
+        wgs = v[5]
+        if wgs == 0:
+            continue
+        print(f"config {name}, output {out_i}: {int(wgs / steps)} workgroups per sweep, {v[4] / steps:.0f} gradient phases run per sweep, K1 {np.mean(k1) * 1e3:.1f} us")
+        tot = v[:4].sum()
+        for i, nm in enumerate(names):
+            print(f"   {nm:58s} {v[i] / wgs * 1e-2:7.2f} us per workgroup   {100.0 * v[i] / tot:5.1f} % of a workgroup's life")
+        print(f"   {'life of a workgroup':58s} {tot / wgs * 1e-2:7.2f} us")
     eng.close()
