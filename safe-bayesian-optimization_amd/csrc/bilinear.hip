@@ -1011,26 +1011,67 @@ __device__ __forceinline__ void post_classify_mv(PostCtx& cx, size_t g, double m
 }
 __device__ __forceinline__ void post_classify(PostCtx& cx, size_t g, double m) { post_classify_mv(cx, g, m, cx.var_rd[g]); }
 // the same decisions as bits of the strip's word (role 1): no byte stores
-__device__ __forceinline__ void post_classify_bits(PostCtx& cx, int s2, unsigned int pos, double m, double v) {
-  const LcbSign sg = cx.gb_on ? lcb_sign_gb(m, v, cx.bconf, cx.bb, cx.lband, cx.cB) : lcb_sign(m, v, cx.bconf, cx.bb);
-  cx.bw[s2] |= ((unsigned int)sg.ge | ((unsigned int)sg.le << 16)) << pos;
-  cx.cS += sg.ge;
-  cx.cU += sg.le;
-  if (sg.ge) {
-    cx.vminS = v < cx.vminS ? v : cx.vminS;
-    // bounds of ucb_1 from one single-precision square root (ucb_upper / ucb_lower, device_common.hpp: the hardware's 1-ulp root is
-    // well inside their 2^-20 slack): the exact bound only when it could raise the radius key; the lower bound feeds the tile's range
-    const float sf = __builtin_amdgcn_sqrtf((float)v);
-    const double s_up = (double)sf * (1.0 + 0x1p-20) + 1e-18;
-    double s_lo = (double)sf * (1.0 - 0x1p-20) - 1e-18;
-    s_lo = s_lo > 0.0 ? s_lo : 0.0;
-    const bool fin = sf < 3.0e38f;
-    const double xu = m + cx.bconf * s_up, xl = m + cx.bconf * (fin ? s_lo : 0.0);
-    const double up = fin ? xu + (xu < 0 ? -xu : xu) * 0x1p-50 : 1e300, lo = xl - (xl < 0 ? -xl : xl) * 0x1p-50;
-    cx.xmin = lo < cx.xmin ? lo : cx.xmin;
-    if (!(up <= cx.rmax)) {
-      const double ucb = add_rn(m, mul_rn(cx.bconf, sqrt_rn(v)));
-      if (ucb > cx.rmax) cx.rmax = ucb;
+// The classification of one tile row (eight strips) of the constraint, branch-lean: the kernel is bound by instruction issue on
+// the datapath the matrix cores share, and three quarters of a grid's tiles hold no safe candidate at all.  The sign of
+// lcb = m - b sqrt(v) as lcb_sign decides it (device_common.hpp) -- from m^2 against b^2 v wherever that is safe, as plain predicates
+// without branches; what they leave open (a bound within a few ulp of zero, NaN, out-of-range products: rare) takes the IEEE
+// square root behind ONE wave-uniform test per row.  |S| and |U| are the populations of the bit words at the end (no counters
+// here); everything that concerns safe candidates only -- the smallest variance, the tile's range of ucb_1 -- runs behind a second
+// uniform test, so a tile without a safe candidate never enters it.  Decisions identical to post_classify_mv.
+__device__ __forceinline__ void post_classify_row(PostCtx& cx, unsigned int pos, const double (&mv)[8], const double (&vr)[8]) {
+  constexpr double c = 1.0 + 0x1p-48, tiny = 1e-250, huge = 1e300;
+  unsigned int gem = 0u, lem = 0u, und = 0u;
+  const bool bok = cx.bconf >= 0.0;
+#pragma unroll
+  for (int s2 = 0; s2 < 8; ++s2) {
+    const double m = mv[s2], v = vr[s2];
+    const double P = m * m, Q = cx.bb * v;
+    if (cx.gb_on) {
+      const double gap = P > Q ? P - Q : Q - P, am = m < 0 ? -m : m;
+      cx.cB += !(gap > fma(am, cx.lband.c1, cx.lband.c0));               // (NaN operands count as near)
+    }
+    const bool ok = bok && v >= 0.0, rng = P < huge && Q < huge;
+    const bool neg = ok && m < 0.0;
+    const bool ge = ok && !neg && rng && P > tiny && P >= Q * c;
+    const bool le = neg || (ok && rng && !ge && Q > tiny && P * c <= Q && m >= 0.0);
+    gem |= ge ? (1u << s2) : 0u;
+    lem |= le ? (1u << s2) : 0u;
+    und |= (!ge && !le) ? (1u << s2) : 0u;
+  }
+  if (__ballot(und != 0u) != 0ull) {
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      if ((und >> s2) & 1u) {
+        const double sd = mul_rn(cx.bconf, sqrt_rn(vr[s2]));
+        gem |= (mv[s2] >= sd) ? (1u << s2) : 0u;
+        lem |= (mv[s2] <= sd) ? (1u << s2) : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 8; ++s2) cx.bw[s2] |= (((gem >> s2) & 1u) | (((lem >> s2) & 1u) << 16)) << pos;
+  if (__ballot(gem != 0u) != 0ull) {
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      if ((gem >> s2) & 1u) {
+        const double m = mv[s2], v = vr[s2];
+        cx.vminS = v < cx.vminS ? v : cx.vminS;
+        // bounds of ucb_1 from one single-precision square root (ucb_upper / ucb_lower, device_common.hpp: the hardware's 1-ulp root
+        // is well inside their 2^-20 slack): the exact bound only when it could raise the radius key; the lower bound feeds the
+        // tile's range
+        const float sf = __builtin_amdgcn_sqrtf((float)v);
+        const double s_up = (double)sf * (1.0 + 0x1p-20) + 1e-18;
+        double s_lo = (double)sf * (1.0 - 0x1p-20) - 1e-18;
+        s_lo = s_lo > 0.0 ? s_lo : 0.0;
+        const bool fin = sf < 3.0e38f;
+        const double xu = m + cx.bconf * s_up, xl = m + cx.bconf * (fin ? s_lo : 0.0);
+        const double up = fin ? xu + (xu < 0 ? -xu : xu) * 0x1p-50 : 1e300, lo = xl - (xl < 0 ? -xl : xl) * 0x1p-50;
+        cx.xmin = lo < cx.xmin ? lo : cx.xmin;
+        if (!(up <= cx.rmax)) {
+          const double ucb = add_rn(m, mul_rn(cx.bconf, sqrt_rn(v)));
+          if (ucb > cx.rmax) cx.rmax = ucb;
+        }
+      }
     }
   }
 }
@@ -1167,6 +1208,66 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
   } fold{gmax_io, gmax, c0, PH >= 2};
   // epilogue: accumulator element t of lane l is row 4 t + (l >> 4), column l & 15 of its 16 x 16 tile
   const unsigned int col_in = cx.lane & 15, row_in = cx.lane >> 4;
+  if (PH == 1 && RB == 1 && ROLE != 0 && cx.role != 0) {
+    // Column path (r05; its tiles are all interior).  Role 1, the constraint: the classification with its S / U decisions packed as
+    // bits of the strip's word.  Role 2, the objective: u* and the range of lcb_0 over the tile's safe candidates (bits read back
+    // from the constraint's launch).  Both need the variances this thread stored in the variance phase: the eight of row t + 1 are
+    // requested BEFORE row t's means are stored (the stores may alias anything as far as the compiler knows, so it would not move
+    // the loads across them itself) -- three of the four round trips to L2 run under the arithmetic of the row before.
+    auto row_g0 = [&](int t) {
+      const unsigned int line = (unsigned int)(cx.rb0 + cx.wave) * 16u + 4u * t + row_in;
+      return (size_t)line * cx.ucnt0 + (unsigned int)cx.cs0 * 16u + col_in;
+    };
+    // (the objective's tiles: 2 us per launch on config H; the constraint's epilogue holds too much in registers for it -- with the
+    // prefetch its allocation spilt 22 vector registers and the launch took 138 us against 132)
+    constexpr bool kPrefetch = ROLE == 2;
+    double vn[8];
+    if (kPrefetch) {
+      const size_t g0 = row_g0(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) vn[s2] = cx.var_rd[g0 + s2 * 16];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const size_t g0 = row_g0(t), g1 = row_g0(t + 1 < 4 ? t + 1 : t);
+      double* const rowp = outp + g0;
+      if (ROLE == 1) {
+        double vr[8], mv[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) vr[s2] = cx.var_rd[g0 + s2 * 16];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          mv[s2] = (c0 + acc[0][s2][t]) * c1 + c2;
+          rowp[s2 * 16] = mv[s2];
+        }
+        post_classify_row(cx, 4u * t + row_in, mv, vr);
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const double v = vn[s2];
+          if (t + 1 < 4) vn[s2] = cx.var_rd[g1 + s2 * 16];       // (the next row's variance: a row of arithmetic ahead of its use)
+          const double m = (c0 + acc[0][s2][t]) * c1 + c2;
+          rowp[s2 * 16] = m;
+          post_objective(cx, ((cx.bw[s2] >> (4 * t)) & 1u) != 0u, m, v);
+        }
+      }
+    }
+    if (ROLE == 1) {
+      // |S| / |U| of this thread: the populations of its words (S low half, U high half)
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) { cx.cS += __popc(cx.bw[s2] & 0xffffu); cx.cU += __popc(cx.bw[s2] >> 16); }
+      // the wave's 16 rows of every column: the four lanes that hold a column OR their bits together, lanes 0..15 put the piece
+      // (S low half, U high half) where the end of the kernel assembles the 64-bit words of the tile
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        unsigned int w = cx.bw[s2];
+        w |= (unsigned int)__shfl_xor((int)w, 16);
+        w |= (unsigned int)__shfl_xor((int)w, 32);
+        if (cx.lane < 16) cx.lds_bits[cx.wave * 128 + s2 * 16 + cx.lane] = w;
+      }
+    }
+    return;
+  }
   if (cx.full) {
     // interior tile: no bounds tests, one pointer per row, the eight strips at immediate offsets.  The matrix cores
     // share the f64 VALU datapath, so every instruction saved here is matrix time.
@@ -1192,26 +1293,6 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
           for (int s2 = 0; s2 < 8; ++s2) post_classify_mv(cx, g0 + s2 * 16, mv[s2], vr[s2]);
           continue;
         }
-        if (PH == 1 && RB == 1 && ROLE != 0 && cx.role != 0) {
-          // column path (r05).  Role 1, the constraint: the same classification, its S / U decisions packed as bits of the strip's
-          // word.  Role 2, the objective: u* and min var_0 over the tile's safe candidates (bits read back from the constraint's launch).
-          double vr[8], mv[8];
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) vr[s2] = cx.var_rd[g0 + s2 * 16];
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) {
-            mv[s2] = (c0 + acc[i][s2][t]) * c1 + c2;
-            rowp[s2 * 16] = mv[s2];
-          }
-          if (ROLE == 1) {
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) post_classify_bits(cx, s2, 4u * t + row_in, mv[s2], vr[s2]);
-          } else {
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) post_objective(cx, ((cx.bw[s2] >> (4 * t)) & 1u) != 0u, mv[s2], vr[s2]);
-          }
-          continue;
-        }
         if (PH <= 1 && RB == 1 && ROLE == 2 && cx.skip_store) continue;     // (lean sweep: nobody reads this tile's mean / var)
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) {
@@ -1227,17 +1308,6 @@ __device__ __forceinline__ void post_epilogue(PostCtx& cx, double* __restrict__ 
           }
         }
       }
-    if (PH == 1 && RB == 1 && ROLE == 1) {
-      // the wave's 16 rows of every column: the four lanes that hold a column OR their bits together, lanes 0..15 put the piece
-      // (S low half, U high half) where the end of the kernel assembles the 64-bit words of the tile
-#pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2) {
-        unsigned int w = cx.bw[s2];
-        w |= (unsigned int)__shfl_xor((int)w, 16);
-        w |= (unsigned int)__shfl_xor((int)w, 32);
-        if (cx.lane < 16) cx.lds_bits[cx.wave * 128 + s2 * 16 + cx.lane] = w;
-      }
-    }
     return;
   }
 #pragma unroll

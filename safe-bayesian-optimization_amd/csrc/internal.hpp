@@ -262,6 +262,8 @@ struct sbo_ctx {
   sbo::DevBuf cbS, cbU, cbM, cbG, cbUsum;    // column words [H / 64][W]; Usum [W]
   sbo::DevBuf col_slots;                     // ColBits::slots
   sbo::DevBuf col_img, col_bmin;             // column distance image u16 [H][W], block minima u16 [H][W / 32]
+  sbo::DevBuf col_cimg, col_cbmin;           // the same on the 8 x 8 cells
+  long long col_ckey = 0;                    // the grid the padding of col_cbmin was laid out for
   sbo::DevBuf col_fin;                       // the objective's scalars, the finals' tickets and intermediate rows (4 KB)
   hipEvent_t ev_col[2]{};      // fork (the constraint's posterior launch has finished) / join (the expander chain on stream3 has)
   bool col_forked = false;     // the constraint's launch of the running posterior carried ev_col[0]

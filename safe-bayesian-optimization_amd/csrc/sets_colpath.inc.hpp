@@ -21,6 +21,7 @@ struct ColGeom {
   int W, H, NS, NB;          // columns (axis 0), rows (axis 1), 64-row segments, 32-column blocks per row
   int NBp;                   // row stride of the block minima (NB rounded up to 8: a lane's eight blocks are one aligned 16-byte load)
   int CW, CH;                // coarse cells per axis (8 x 8 candidates)
+  int CNB, CNBp, CWp;        // 32-cell blocks per coarse row, row strides of the coarse block minima / the coarse image (padded)
   int gxt;                   // k_bpost tiles per tile row (W / 128)
   double h0, h1;
   int dbg;                   // (development: stage cuts for timing, SBO_COL_DBG)
@@ -40,81 +41,6 @@ struct ColClock {
   }
 };
 constexpr int kColBig = 1 << 20;       // "no U point on this side of the column" (far above 65535 through 64 increments)
-
-// any U point in the 8 x 8 cell (ci, cj)?  eight consecutive column words, byte cj & 7 of each
-__device__ __forceinline__ bool coarse_cell_bits(const unsigned long long* __restrict__ Uw, int W, long long cj, int ci) {
-  const unsigned long long* w = Uw + (size_t)(cj >> 3) * W + (size_t)ci * 8;
-  unsigned long long acc = 0ull;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc |= w[k];
-  return ((acc >> (8 * (int)(cj & 7))) & 0xffull) != 0ull;
-}
-
-// coarse axis-0 pass on the cell bits (edt_axis0_wg_body<true> with the bits formed from the column words)
-__device__ __forceinline__ void col_coarse_axis0_body(int bid, int nblk, Axis0Lds& lds, const unsigned long long* __restrict__ Uw, int W,
-                                                      long long clines, int cc0, double h0c, double* __restrict__ D) {
-  unsigned long long* words = lds.words;
-  int* lastw = lds.lastw;
-  int* firstw = lds.firstw;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nwords = (cc0 + 63) >> 6;
-  constexpr int kNone = 0x7fffffff;
-  for (long long line = bid; line < clines; line += nblk) {
-    double* d = D + line * cc0;
-    for (int w = wave; w < nwords; w += 4) {
-      const int i = w * 64 + lane;
-      const unsigned long long m = __ballot(i < cc0 && coarse_cell_bits(Uw, W, line, i));
-      if (lane == 0) words[w] = m;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      int carry = -1;
-      for (int base = 0; base < nwords; base += 64) {
-        const int w = base + lane;
-        const unsigned long long m = w < nwords ? words[w] : 0ull;
-        int v = m ? w * 64 + (63 - __clzll((long long)m)) : -1;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o && t > v) v = t; }
-        v = v > carry ? v : carry;
-        if (w < nwords) lastw[w] = v;
-        carry = __shfl(v, 63);
-      }
-    } else if (wave == 1) {
-      int carry = kNone;
-      for (int base = 0; base < nwords; base += 64) {
-        const int w = nwords - 1 - (base + lane);
-        const unsigned long long m = w >= 0 ? words[w] : 0ull;
-        int v = m ? w * 64 + (__ffsll((long long)m) - 1) : kNone;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o && t < v) v = t; }
-        v = v < carry ? v : carry;
-        if (w >= 0) firstw[w] = v;
-        carry = __shfl(v, 63);
-      }
-    }
-    __syncthreads();
-    for (int w = wave; w < nwords; w += 4) {
-      const int i = w * 64 + lane;
-      const unsigned long long m = words[w];
-      const unsigned long long lower = m & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-      const unsigned long long upper = m >> lane;
-      const int li = lower ? w * 64 + (63 - __clzll((long long)lower)) : (w > 0 ? lastw[w - 1] : -1);
-      const int ri = upper ? i + (__ffsll((long long)upper) - 1) : (w + 1 < nwords ? firstw[w + 1] : kNone);
-      if (i < cc0) {
-        int t = -1;
-        if (li >= 0) t = i - li;
-        if (ri != kNone && (t < 0 || ri - i < t)) t = ri - i;
-        double v = kInfD;
-        if (t >= 0) {
-          const double dt = h0c * (double)t;
-          v = dt * dt;
-        }
-        d[i] = v;
-      }
-    }
-    __syncthreads();
-  }
-}
 
 // Column pass of one (segment, 64 columns) item by one wave: lane = column.  The carries above / below the segment come from Usum
 // (which segments of the column hold a U point) and one more word each; the lane then walks its word as edt_axis0_wave_seq walks
@@ -202,6 +128,88 @@ __device__ __forceinline__ void col_fine_item(long long item, const ColGeom gm, 
   __builtin_amdgcn_wave_barrier();                       // (the wave's next item overwrites the tile)
 }
 
+// The same transform on the 8 x 8 cells (the coarse sandwich of the verdicts): a workgroup takes 32 coarse columns, thread
+// (column, 64-row coarse segment) ORs the bits of its 8 x 64 cells out of the fine column words, finds its carries in the other
+// segments' words (LDS), walks its word, and the 32 columns of the workgroup are exactly one block of the coarse rows' block minima.
+// The per-cell distances themselves are searched where they are needed (k_col_decide: col_row_search<2>): the separate coarse scan of
+// the byte-mask path -- 2 x 190 steps per far cell, 26 us on config H -- is gone.
+__device__ __forceinline__ void col_coarse_job(int blk, const ColGeom gm, const unsigned long long* __restrict__ Uw, unsigned long long* lds_words,
+                                               unsigned short* __restrict__ cimg, unsigned short* __restrict__ cbmin) {
+  const int cl = threadIdx.x & 31, Sg = threadIdx.x >> 5;
+  const int ci = blk * 32 + cl;
+  const int CNS = (gm.CH + 63) >> 6;
+  unsigned long long word = 0ull;
+  if (ci < gm.CW && Sg < CNS) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int s = 8 * Sg + f;
+      if (s < gm.NS) {
+        const unsigned long long* w = Uw + (size_t)s * gm.W + (size_t)ci * 8;
+        unsigned long long x = 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x |= w[k];
+        x |= x >> 4;
+        x |= x >> 2;
+        x |= x >> 1;
+        x &= 0x0101010101010101ull;
+        word |= ((x * 0x0102040810204080ull) >> 56) << (8 * f);
+      }
+    }
+  }
+  lds_words[Sg * 32 + cl] = word;
+  __syncthreads();
+  if (Sg >= CNS) return;
+  int f = kColBig, dn = kColBig;
+  for (int sp = Sg - 1; sp >= 0; --sp) {
+    const unsigned long long w = lds_words[sp * 32 + cl];
+    if (w) { f = 64 * Sg - 1 - (64 * sp + 63 - __clzll((long long)w)); break; }
+  }
+  for (int sn = Sg + 1; sn < CNS; ++sn) {
+    const unsigned long long w = lds_words[sn * 32 + cl];
+    if (w) { dn = (64 * sn + __ffsll((long long)w) - 1) - (64 * Sg + 64); break; }
+  }
+  const unsigned int nlo = ~(unsigned int)word, nhi = ~(unsigned int)(word >> 32);
+  int F[64];
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const unsigned int h = r < 32 ? nlo : nhi;
+    const int keep = (int)(h << (31 - (r & 31))) >> 31;
+    f = (f + 1) & keep;
+    F[r] = f;
+  }
+  unsigned int pk[32];
+#pragma unroll
+  for (int r = 63; r >= 0; --r) {
+    const unsigned int h = r < 32 ? nlo : nhi;
+    const int keep = (int)(h << (31 - (r & 31))) >> 31;
+    dn = (dn + 1) & keep;
+    int t = F[r] < dn ? F[r] : dn;
+    t = t > 0xffff ? 0xffff : t;
+    cimg[(size_t)(64 * Sg + r) * gm.CWp + ci] = (unsigned short)t;
+    if (r & 1) pk[r >> 1] = (unsigned int)t << 16;
+    else pk[r >> 1] |= (unsigned int)t;
+  }
+  // the block minimum of every row over the workgroup's 32 columns (the lanes of one half of a wave), two rows per word
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    us2_t v;
+    v[0] = (unsigned short)(pk[k] & 0xffffu);
+    v[1] = (unsigned short)(pk[k] >> 16);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const unsigned int y = (unsigned int)__shfl_xor((int)((unsigned int)v[0] | ((unsigned int)v[1] << 16)), o);
+      us2_t w2;
+      w2[0] = (unsigned short)(y & 0xffffu);
+      w2[1] = (unsigned short)(y >> 16);
+      v = __builtin_elementwise_min(v, w2);
+    }
+    if (cl == k) {
+      cbmin[(size_t)(64 * Sg + 2 * k) * gm.CNBp + blk] = v[0];
+      cbmin[(size_t)(64 * Sg + 2 * k + 1) * gm.CNBp + blk] = v[1];
+    }
+  }
+}
+
 // The merge of the classification's partial rows, in two halves (the sweep runs as two chains: sets_colpath's host part).
 // Half 1, behind the CONSTRAINT's posterior launch: the scalar block cleared, |S|, |U|, the radius key and the smallest variance of the
 // constraint over S, the sign tests inside the guard band, the constraint's Lipschitz key -- everything the expander chain reads.
@@ -266,11 +274,11 @@ struct ColMergeJob {
   double b;
 };
 // first launch of the expander chain: [1: merge, half 1 | ncoarse: coarse axis-0 pass | the rest: column pass]
-__global__ __launch_bounds__(256) void k_col_a(const ColGeom gm, const ColBits cb, const ColMergeJob mg, int ncoarse, double* __restrict__ Dc0,
-                                               unsigned short* __restrict__ img, unsigned short* __restrict__ bmin,
+__global__ __launch_bounds__(256) void k_col_a(const ColGeom gm, const ColBits cb, const ColMergeJob mg, int ncoarse, unsigned short* __restrict__ cimg,
+                                               unsigned short* __restrict__ cbmin, unsigned short* __restrict__ img, unsigned short* __restrict__ bmin,
                                                unsigned long long* __restrict__ Mw, unsigned long long* __restrict__ Gw) {
   constexpr size_t kTileBytes = 4 * 64 * 64 * sizeof(unsigned short);
-  __shared__ __attribute__((aligned(16))) unsigned char mem[sizeof(Axis0Lds) > kTileBytes ? sizeof(Axis0Lds) : kTileBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char mem[kTileBytes];
   const int bid = (int)blockIdx.x;
   ColClock clk_(0, gm.dbg);
   if (bid == 0) {
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256) void k_col_a(const ColGeom gm, const ColBits c
     col_merge1_body(mg.slots, mg.sc, mg.Lmax, mg.gb, mg.b);
   } else if (bid < 1 + ncoarse) {
     if (gm.dbg == 1 || gm.dbg == 4) return;
-    col_coarse_axis0_body(bid - 1, ncoarse, *reinterpret_cast<Axis0Lds*>(mem), cb.Uw, gm.W, gm.CH, gm.CW, gm.h0 * kCoarse, Dc0);
+    col_coarse_job(bid - 1, gm, cb.Uw, reinterpret_cast<unsigned long long*>(mem), cimg, cbmin);
   } else {
     const int nfine = (int)gridDim.x - 1 - ncoarse;
     unsigned short* tile = reinterpret_cast<unsigned short*>(mem) + (threadIdx.x >> 6) * 64 * 64;
@@ -288,49 +296,6 @@ __global__ __launch_bounds__(256) void k_col_a(const ColGeom gm, const ColBits c
       col_fine_item(item, gm, cb, tile, img, bmin, Mw, Gw);
   }
 }
-// second launch of the chain: the coarse transform's scan along axis 1 (it needs half 1's radius key); Usum cleared for the next
-// sweep's posterior (every reader ran in the launch before)
-// (edt_scan_point with sixteen steps -- 32 loads -- per round of exit tests: a cell far from U walks ~190 steps either way, and
-// at four steps per round its thread waited out ~50 dependent round trips: 26 us of the chain on config H.  A step examined beyond an
-// exit cannot lower the minimum, so the result is the same.)
-__device__ __forceinline__ double col_scan_point16(const double* __restrict__ Din, long long g, long long stride, int cnt, int ia, double h,
-                                                   double cap) {
-  double best = Din[g];
-  // the first round as before (most cells lie near U and leave after it), then wide rounds
-  for (int t = 1, w = 4; t < cnt; t += w, w = 16) {
-    const double dt = h * (double)t;
-    if (dt * dt >= best || dt > cap) break;
-    if (ia - t < 0 && ia + t >= cnt) break;
-    double c1[16], c2[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int tt = t + u;
-      const bool on = u < w;
-      c1[u] = (on && ia - tt >= 0) ? Din[g - (long long)tt * stride] : kInfD;
-      c2[u] = (on && ia + tt < cnt) ? Din[g + (long long)tt * stride] : kInfD;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const double du = h * (double)(t + u);
-      const double c = (c1[u] < c2[u] ? c1[u] : c2[u]) + du * du;
-      if (du <= cap && c < best) best = c;
-    }
-  }
-  return best;
-}
-__global__ __launch_bounds__(256) void k_col_cs(const ColGeom gm, const SweepScalars* sc, const unsigned long long* Lkeys, int lidx,
-                                                const double* __restrict__ dc_in, double* __restrict__ dc_out, long long nc, double cap_extra,
-                                                unsigned long long* __restrict__ Usum) {
-  if (gm.dbg == 1) return;
-  ColClock clk_(1, gm.dbg);
-  const double L = __longlong_as_double((long long)Lkeys[lidx]);
-  const double rmax = sc->rmax_key[1] ? ord_val(sc->rmax_key[1]) : 0.0;
-  const double cap = L > 0 ? rmax / L * 1.000001 + 1e-6 + cap_extra : kInfD;          // (as edt_scan_body)
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < nc; g += (long long)gridDim.x * blockDim.x)
-    dc_out[g] = col_scan_point16(dc_in, g, gm.CW, gm.CH, (int)((g / gm.CW) % gm.CH), gm.h1 * kCoarse, cap);
-  for (int i = (int)blockIdx.x * 256 + threadIdx.x; i < gm.W; i += (int)gridDim.x * 256) Usum[i] = 0ull;
-}
-
 // bounds of lcb = fl(m - fl(b fl(sqrt v))) from a single-precision square root (as ucb_lower / ucb_upper, device_common.hpp)
 __device__ __forceinline__ void lcb_bounds(double m, double v, double b, double& lo, double& hi) {
   const float sf = __fsqrt_rn((float)v);
@@ -578,6 +543,121 @@ __global__ __launch_bounds__(256) void k_col_min(const ColMinJob j) {
   }
 }
 
+// ---- exact nearest-U search along a row of a column image ---------------------------------------------------------------------
+// Position i of row `rowi` (16-bit steps down the columns, 0xffff: no U point in that column) with the row's block minima `rowb`
+// (32 positions per block): min over i' of (h1 t(i'))^2 + (h0 (i' - i))^2, EIGHT lanes per search (eight searches per wave, all
+// lanes of the wave take part in the shuffles).  A lane bounds BPL blocks in SINGLE precision, rounded down (the bounds only
+// prune); the block with the smallest bound is searched first -- 32 entries, four per lane, exact fp64 --, then every block whose
+// bound still beats the running minimum (rounded up to float: "<" never skips a block the fp64 comparison would search).  `cap`:
+// entries further along the row are not examined; `acc2`: a minimum at or below it ends the search (-1: none).  BPL = 16 covers the
+// 128 blocks of a fine row of 4096 columns, BPL = 2 the 16 blocks of a coarse row (the same transform on the 8 x 8 cells).
+template <int BPL>
+__device__ __forceinline__ double col_row_search(const unsigned short* __restrict__ rowi, const unsigned short* __restrict__ rowb, int NB, int i,
+                                                 double h0, double h1, double inv_h0, double cap, double acc2, bool live, int lane, int sub) {
+  constexpr int GL = 8;
+  const float h0f = (float)h0, h1f = (float)h1;
+  unsigned int bm[BPL];
+  {
+    const int bb0 = BPL * lane;
+    if (BPL == 16) {
+      uint4 qa = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu), qb = qa;
+      if (live && bb0 < NB) qa = *reinterpret_cast<const uint4*>(rowb + bb0);
+      if (live && bb0 + 8 < NB) qb = *reinterpret_cast<const uint4*>(rowb + bb0 + 8);
+      const unsigned int ws[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+      for (int e = 0; e < BPL / 2; ++e) { bm[2 * e] = ws[e] & 0xffffu; bm[2 * e + 1] = ws[e] >> 16; }
+    } else {
+      unsigned int w = 0xffffffffu;
+      if (live && bb0 < NB) w = *reinterpret_cast<const unsigned int*>(rowb + bb0);
+      bm[0] = w & 0xffffu;
+      bm[BPL - 1] = w >> 16;
+    }
+  }
+  double best_d = kInfD;
+  if (live) {
+    const unsigned int t = rowi[i];
+    const double dt = h1 * (double)t;
+    best_d = t == 0xffffu ? kInfD : dt * dt;
+  }
+  // steps along the row beyond which h0 gap > cap for sure (a block kept although the cap drops it holds no entry within the cap:
+  // its search changes nothing)
+  const double gq = cap * inv_h0 * (1.0 + 1e-12) + 1.0;
+  const int gapmax = gq < 1.0e9 ? (int)gq : 1000000000;
+  // bounds: (h1 bm)^2 + (h0 gap)^2 carries <= 6 roundings of 2^-24, the factor takes 1e-6 off (a block without a U point holds
+  // 0xffff: its bound is beyond every distance of the grid)
+  float lb[BPL];
+  float lbl = 3.0e38f;
+  int bl = -1;
+#pragma unroll
+  for (int e = 0; e < BPL; ++e) {
+    const int bb = BPL * lane + e;
+    const int ga = i - (bb * 32 + 31), gb_ = bb * 32 - i;
+    int gap = ga > gb_ ? ga : gb_;
+    gap = gap > 0 ? gap : 0;
+    const float x = h1f * (float)bm[e], y = h0f * (float)gap;
+    float v = (x * x + y * y) * (1.0f - 1.0e-6f);
+    if (!live || gap > gapmax || bb >= NB) v = 3.0e38f;
+    lb[e] = v;
+    if (v < lbl) { lbl = v; bl = bb; }
+  }
+  int b_min = bl;
+  {
+    float m = lbl;
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) {
+      const float wm = __shfl_xor(m, o);
+      const int wb = __shfl_xor(b_min, o);
+      if (wm < m || (wm == m && wb >= 0 && (b_min < 0 || wb < b_min))) { m = wm; b_min = wb; }
+    }
+    lbl = m;                                            // (the group's smallest bound and its block: the same in every lane)
+  }
+  auto scan_block = [&](int bb, bool act) {             // the group: the 32 entries of block bb, four per lane
+    double cnd = kInfD;
+    if (act) {
+      const uint2 w2 = *reinterpret_cast<const uint2*>(rowi + bb * 32 + 4 * lane);
+      const unsigned int ts[4] = {w2.x & 0xffffu, w2.x >> 16, w2.y & 0xffffu, w2.y >> 16};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ii = bb * 32 + 4 * lane + e;
+        const double dt = h0 * (double)(ii > i ? ii - i : i - ii);
+        if (dt <= cap && ts[e] != 0xffffu) {
+          const double dv = h1 * (double)ts[e];
+          const double v = dv * dv + dt * dt;
+          cnd = v < cnd ? v : cnd;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) { const double w = __shfl_xor(cnd, o); cnd = w < cnd ? w : cnd; }
+    best_d = cnd < best_d ? cnd : best_d;
+  };
+  float best_f = __double2float_ru(best_d);
+  scan_block(b_min, live && b_min >= 0 && lbl < best_f);
+  best_f = __double2float_ru(best_d);
+  unsigned int todo = 0u;
+#pragma unroll
+  for (int e = 0; e < BPL; ++e) todo |= (lb[e] < best_f && BPL * lane + e != b_min) ? (1u << e) : 0u;
+  if (best_d <= acc2) todo = 0u;
+  while (__ballot(todo != 0u) != 0ull) {
+    const unsigned int gm8 = (unsigned int)((__ballot(todo != 0u) >> (GL * sub)) & 0xffull);
+    const bool act = gm8 != 0u;
+    const int leader = act ? (int)(__ffs((int)gm8) - 1) : 0;
+    const int mine = BPL * lane + (todo ? (int)(__ffs((int)todo) - 1) : 0);
+    const int bb = __shfl(mine, leader + GL * sub);
+    if (act && lane == leader) todo &= todo - 1u;
+    scan_block(bb, act);
+    if (act) {
+      best_f = __double2float_ru(best_d);
+      unsigned int keep = 0u;
+#pragma unroll
+      for (int e = 0; e < BPL; ++e) keep |= (lb[e] < best_f) ? (1u << e) : 0u;
+      todo &= keep;
+      if (best_d <= acc2) todo = 0u;
+    }
+  }
+  return best_d;
+}
+
 // ---- verdicts: G = {g in S : exists h in U, ucb_1(g) - L ||x_g - x_h + 1e-8|| >= 0} (models/SafeOpt.py:85-88, 111) ------------------
 // The coarse sandwich of k_edt_decide8 per candidate, first on the single-precision bounds of ucb (no IEEE square root for the
 // nine candidates in ten it settles), then on the exact bound; what stays open goes to the list.  A workgroup takes one
@@ -598,7 +678,9 @@ constexpr int kColQueue = 512;                  // open candidates a WAVE collec
 __global__ __launch_bounds__(256) void k_col_decide(const ColGeom gm, const unsigned long long* __restrict__ Sw, const unsigned long long* __restrict__ slots,
                                                     const unsigned long long* __restrict__ tumin /* per constraint tile: key of the lower end
                                                     of ucb_1 over its safe candidates */, const unsigned long long* __restrict__ tumax /* of the
-                                                    upper end (the tile's radius key) */, const double* __restrict__ Dc, const ColVerdict cv,
+                                                    upper end (the tile's radius key) */, const unsigned short* __restrict__ cimg, const unsigned short* __restrict__ cbmin,
+                                                    double cap_extra, unsigned long long* __restrict__ Usum,
+                                                    const unsigned short* __restrict__ img /* the fine column image */, const ColVerdict cv,
                                                     SweepScalars* sc, unsigned long long* __restrict__ Gw, long long* __restrict__ scanlist) {
   __shared__ long long qg[4][kColQueue];
   __shared__ double qu[4][kColQueue];
@@ -616,6 +698,13 @@ __global__ __launch_bounds__(256) void k_col_decide(const ColGeom gm, const unsi
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
   uint8_t* Gb = reinterpret_cast<uint8_t*>(Gw);
+  // (Usum cleared for the next sweep's posterior: its readers ran in the launch before)
+  for (int i = (int)blockIdx.x * 256 + threadIdx.x; i < gm.W; i += (int)gridDim.x * 256) Usum[i] = 0ull;
+  // the coarse transform's distances: searched per cell, capped beyond every radius that can matter (as the byte-mask path's coarse
+  // scan: a cell beyond the cap is "beyond every radius" whether its value is the true minimum or a larger one)
+  const double rmax = sc->rmax_key[1] ? ord_val(sc->rmax_key[1]) : 0.0;
+  const double capC = L > 0 ? rmax / L * 1.000001 + 1e-6 + cap_extra : kInfD;
+  const double h0c = gm.h0 * kCoarse, h1c = gm.h1 * kCoarse, inv_h0c = 1.0 / h0c;
   if (gm.dbg == 6) { if (L == 123.25 && nunits == 77 && bk.du == 3.5) Gb[0] = 1; return; }
   int qcnt = 0;                                   // (uniform over the wave)
   auto flush = [&]() {
@@ -640,8 +729,19 @@ __global__ __launch_bounds__(256) void k_col_decide(const ColGeom gm, const unsi
     if (gm.dbg == 2) { gbits[0] = sb[0]; gbits[1] = sb[1]; }
     else if (__ballot(any8 != 0u) != 0ull) {
       const int row0 = 64 * x.s + 8 * x.oct;
-      // (the lane's two columns lie in one coarse cell, the octet is one coarse row)
-      const double dc2 = Dc[(size_t)(row0 >> 3) * gm.CW + (x.c >> 3)];
+      // The coarse distances of the unit's sixteen cells (the octet is one coarse row, the lane's two columns lie in cell lane >> 2):
+      // eight lanes search a cell, two rounds; a lane then picks up its own cell's value.
+      double dc2;
+      {
+        const int cj = row0 >> 3, ci0 = (x.c - 2 * lane) >> 3, l8 = lane & 7, sub = lane >> 3;
+        const unsigned short* rowi = cimg + (size_t)cj * gm.CWp;
+        const unsigned short* rowb = cbmin + (size_t)cj * gm.CNBp;
+        const double d0 = col_row_search<2>(rowi, rowb, gm.CNB, ci0 + sub, h0c, h1c, inv_h0c, capC, -1.0, true, l8, sub);
+        const double d1 = col_row_search<2>(rowi, rowb, gm.CNB, ci0 + 8 + sub, h0c, h1c, inv_h0c, capC, -1.0, true, l8, sub);
+        const int m = lane >> 2;
+        const double v0 = __shfl(d0, 8 * (m & 7)), v1 = __shfl(d1, 8 * (m & 7));
+        dc2 = (m >> 3) ? v1 : v0;
+      }
       // The whole unit at once where that settles it: ucb_1 of every safe candidate of the tile lies in [ulo, uhi] (the posterior's
       // epilogue kept both ends), the coarse distances of the unit's sixteen cells in [dmin, dmax] -- if the candidate with the
       // SMALLEST bound at the LARGEST distance is within its radius for sure, all are (G = S on the unit, no candidate is read), and
@@ -739,7 +839,14 @@ __global__ __launch_bounds__(256) void k_col_decide(const ColGeom gm, const unsi
             const double tolc = 1e-12 * (fabs(ucb) + du + Ldhi);
             if (ucb - du - Lhi > tolc) in = true;                      // within the radius for sure
             else if (ucb + du - Llo < -tolc) in = false;               // beyond it for sure
-            else open = true;
+            else {
+              // the candidate's own column: the U point straight above or below it bounds the distance from above -- within the
+              // radius for sure when that already is (the list search would find a minimum no larger and say the same)
+              const unsigned int t = img[(size_t)g];
+              const double dup = gm.h1 * (double)t;
+              if (t != 0xffffu && ucb - du - L * (dup + eps_abs + 1e-11 * dup) > 1e-12 * (fabs(ucb) + du + L * dup)) in = true;
+              else open = true;
+            }
           }
         }
         gbits[e] |= in ? (1u << k) : 0u;
@@ -781,13 +888,7 @@ __global__ __launch_bounds__(256) void k_col_scan(const ColGeom gm, const unsign
   const int sub = (threadIdx.x & 63) / GL;
   const long long ngroups = (long long)gridDim.x * (blockDim.x / GL);
   const double h0 = gm.h0, h1 = gm.h1;
-  const float h0f = (float)h0, h1f = (float)h1;
   const double invL = 1.0 / L, inv_h0 = 1.0 / h0;
-  auto group_min_d = [&](double v) {
-#pragma unroll
-    for (int o = GL / 2; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; }
-    return v;
-  };
   unsigned int* Gh = reinterpret_cast<unsigned int*>(Gw);
   const long long nrounds = (nscan + ngroups - 1) / ngroups;
   const long long grp = (long long)blockIdx.x * (blockDim.x / GL) + threadIdx.x / GL;
@@ -805,103 +906,7 @@ __global__ __launch_bounds__(256) void k_col_scan(const ColGeom gm, const unsign
     const double cap = rhi * (1.0 + 1e-15) + 4.0 * eps_abs + 1e-9 * fabs(rhi);
     const double thr = rlo * (1.0 - 1e-10) - 2.0 * eps_abs - 1e-12;
     const double acc2 = thr > 0 ? thr * thr : -1.0;
-    const unsigned short* rowi = img + (size_t)j * gm.W;
-    const unsigned short* rowb = bmin + (size_t)j * gm.NBp;
-    // the lane's sixteen block minima, the candidate's own entry
-    unsigned int bm[16];
-    {
-      const int bb0 = 16 * lane;
-      uint4 qa = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu), qb = qa;
-      if (live && bb0 < gm.NB) qa = *reinterpret_cast<const uint4*>(rowb + bb0);
-      if (live && bb0 + 8 < gm.NB) qb = *reinterpret_cast<const uint4*>(rowb + bb0 + 8);
-      const unsigned int ws[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { bm[2 * e] = ws[e] & 0xffffu; bm[2 * e + 1] = ws[e] >> 16; }
-    }
-    double best_d = kInfD;
-    if (live) {
-      const unsigned int t = rowi[i];
-      const double dt = h1 * (double)t;
-      best_d = t == 0xffffu ? kInfD : dt * dt;
-    }
-    // steps along the row beyond which h0 gap > cap for sure (a block the byte-mask path drops at the cap and this one keeps holds
-    // no entry within the cap: its search changes nothing; the same number bounds the reach in blocks)
-    const double gq = cap * inv_h0 * (1.0 + 1e-12) + 1.0;
-    const int gapmax = gq < 1.0e9 ? (int)gq : 1000000000;
-    // bounds in single precision, rounded down: (h1 bm)^2 + (h0 gap)^2 carries <= 6 roundings of 2^-24, the factor takes 1e-6 off
-    // (a block without a U point holds 0xffff: its bound is beyond every distance of the grid)
-    float lb[16];
-    float lbl = 3.0e38f;
-    int bl = -1;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int bb = 16 * lane + e;
-      const int ga = i - (bb * 32 + 31), gb_ = bb * 32 - i;
-      int gap = ga > gb_ ? ga : gb_;
-      gap = gap > 0 ? gap : 0;
-      const float x = h1f * (float)bm[e], y = h0f * (float)gap;
-      float v = (x * x + y * y) * (1.0f - 1.0e-6f);
-      if (!live || gap > gapmax || bb >= gm.NB) v = 3.0e38f;
-      lb[e] = v;
-      if (v < lbl) { lbl = v; bl = bb; }
-    }
-    int b_min = bl;
-    {
-      float m = lbl;
-#pragma unroll
-      for (int o = GL / 2; o > 0; o >>= 1) {
-        const float wm = __shfl_xor(m, o);
-        const int wb = __shfl_xor(b_min, o);
-        if (wm < m || (wm == m && wb >= 0 && (b_min < 0 || wb < b_min))) { m = wm; b_min = wb; }
-      }
-      lbl = m;                                            // (the group's smallest bound and its block: the same in every lane)
-    }
-    auto scan_block = [&](int bb, bool act) {             // the group: the 32 entries of block bb, four per lane
-      double cnd = kInfD;
-      if (act) {
-        const uint2 w2 = *reinterpret_cast<const uint2*>(rowi + bb * 32 + 4 * lane);
-        const unsigned int ts[4] = {w2.x & 0xffffu, w2.x >> 16, w2.y & 0xffffu, w2.y >> 16};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int ii = bb * 32 + 4 * lane + e;
-          const double dt = h0 * (double)(ii > i ? ii - i : i - ii);
-          if (dt <= cap && ts[e] != 0xffffu) {
-            const double dv = h1 * (double)ts[e];
-            const double v = dv * dv + dt * dt;
-            cnd = v < cnd ? v : cnd;
-          }
-        }
-      }
-      cnd = group_min_d(cnd);
-      best_d = cnd < best_d ? cnd : best_d;
-    };
-    // pass A: the block with the smallest bound (a bound is never above the exact value it bounds: "<" in single precision, the
-    // running minimum rounded up, never skips a block the fp64 comparison would search)
-    float best_f = __double2float_ru(best_d);
-    scan_block(b_min, live && b_min >= 0 && lbl < best_f);
-    best_f = __double2float_ru(best_d);
-    // pass B: every other block whose bound still beats the running minimum
-    unsigned int todo = 0u;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) todo |= (lb[e] < best_f && 16 * lane + e != b_min) ? (1u << e) : 0u;
-    if (best_d <= acc2) todo = 0u;
-    while (__ballot(todo != 0u) != 0ull) {
-      const unsigned int gm8 = (unsigned int)((__ballot(todo != 0u) >> (GL * sub)) & 0xffull);
-      const bool act = gm8 != 0u;
-      const int leader = act ? (int)(__ffs((int)gm8) - 1) : 0;
-      const int mine = 16 * lane + (todo ? (int)(__ffs((int)todo) - 1) : 0);
-      const int bb = __shfl(mine, leader + GL * sub);
-      if (act && lane == leader) todo &= todo - 1u;
-      scan_block(bb, act);
-      if (act) {
-        best_f = __double2float_ru(best_d);
-        unsigned int keep = 0u;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) keep |= (lb[e] < best_f) ? (1u << e) : 0u;
-        todo &= keep;
-        if (best_d <= acc2) todo = 0u;
-      }
-    }
+    const double best_d = col_row_search<16>(img + (size_t)j * gm.W, bmin + (size_t)j * gm.NBp, gm.NB, i, h0, h1, inv_h0, cap, acc2, live, lane, sub);
     if (live && lane == 0) {
       bool out = false;
       if (best_d < 0.5 * kInfD) {
@@ -1037,6 +1042,9 @@ static int col_set_phase(sbo_ctx* c, const sbo_sweep_opts* o, SweepScalars& h, u
   gm.CW = gm.W / kCoarse;
   gm.CH = gm.H / kCoarse;
   gm.gxt = gm.W / 128;
+  gm.CNB = (gm.CW + 31) / 32;
+  gm.CNBp = 16;
+  gm.CWp = gm.CNB * 32;
   gm.h0 = c->cs.step[0];
   gm.h1 = c->cs.step[1];
   double h2 = 0.0, hmax = 0.0;
@@ -1071,10 +1079,15 @@ static int col_set_phase(sbo_ctx* c, const sbo_sweep_opts* o, SweepScalars& h, u
   if ((rc = ensure(c->scanlist, 2 * sizeof(long long) * (size_t)n))) return rc;
   if ((rc = ensure(c->col_img, sizeof(unsigned short) * (size_t)n + 64))) return rc;
   if ((rc = ensure(c->col_bmin, sizeof(unsigned short) * (size_t)gm.H * gm.NBp + 64))) return rc;
-  const long long nc = (long long)gm.CW * gm.CH;
-  if ((rc = ensure(c->coarse, ((size_t)nc * 2 * sizeof(double) + 64 + 255) / 256 * 256))) return rc;
-  double* dc0 = (double*)c->coarse.p;
-  double* dc1 = dc0 + nc;
+  // coarse column image / block minima (rows padded to whole 64-row coarse segments; block-minimum entries beyond the row stay 0xffff)
+  const int crows = ((gm.CH + 63) / 64) * 64;
+  const size_t cimg_bytes = sizeof(unsigned short) * (size_t)crows * gm.CWp + 64, cbmin_bytes = sizeof(unsigned short) * (size_t)crows * gm.CNBp + 64;
+  const bool fresh_c = c->col_cbmin.bytes < cbmin_bytes || c->col_ckey != ((long long)gm.W << 32 | gm.H);
+  if ((rc = ensure(c->col_cimg, cimg_bytes)) || (rc = ensure(c->col_cbmin, cbmin_bytes))) return rc;
+  if (fresh_c) {
+    SBO_HIP(hipMemsetAsync(c->col_cbmin.p, 0xff, c->col_cbmin.bytes, es));
+    c->col_ckey = (long long)gm.W << 32 | gm.H;
+  }
   ColBits cb{(unsigned long long*)c->cbS.p, (unsigned long long*)c->cbU.p, (unsigned long long*)c->cbUsum.p, (unsigned long long*)c->col_slots.p};
   c->lmax_pending = false;        // (the Lipschitz keys come out of the slot block)
   c->col_forked = false;
@@ -1087,12 +1100,10 @@ static int col_set_phase(sbo_ctx* c, const sbo_sweep_opts* o, SweepScalars& h, u
   mg.Lmax = (unsigned long long*)c->Lmax.p;
   mg.gb = gb_of(c);
   mg.b = o->b;
-  const int ncoarse = std::min(gm.CH, 4 * c->n_cu);
+  const int ncoarse = gm.CNB;
   const int nfine = (int)std::max<long long>(1, std::min<long long>(((long long)gm.NS * (gm.W / 64) + 3) / 4, (long long)c->n_cu * 5));
-  hipLaunchKernelGGL(k_col_a, dim3((unsigned)(1 + ncoarse + nfine)), dim3(256), 0, es, gm, cb, mg, ncoarse, dc0, (unsigned short*)c->col_img.p,
-                     (unsigned short*)c->col_bmin.p, (unsigned long long*)c->cbM.p, (unsigned long long*)c->cbG.p);
-  hipLaunchKernelGGL(k_col_cs, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1 << 16)), dim3(256), 0, es, gm, (const SweepScalars*)sc,
-                     (const unsigned long long*)c->Lmax.p, lidx, (const double*)dc0, dc1, nc, 2.0 * gm.delta + 2.0 * kCoarse * hmax, cb.Usum);
+  hipLaunchKernelGGL(k_col_a, dim3((unsigned)(1 + ncoarse + nfine)), dim3(256), 0, es, gm, cb, mg, ncoarse, (unsigned short*)c->col_cimg.p,
+                     (unsigned short*)c->col_cbmin.p, (unsigned short*)c->col_img.p, (unsigned short*)c->col_bmin.p, (unsigned long long*)c->cbM.p, (unsigned long long*)c->cbG.p);
   c->usum_dirty = false;
   ColVerdict cv;
   memset(&cv, 0, sizeof(cv));
@@ -1116,7 +1127,8 @@ static int col_set_phase(sbo_ctx* c, const sbo_sweep_opts* o, SweepScalars& h, u
   const unsigned long long* rows = (const unsigned long long*)c->cpart.p;        // the posterior's partial rows: constraint tiles, then objective tiles
   const int ntiles = c->fuse_rows / 2;
   hipLaunchKernelGGL(k_col_decide, dim3((unsigned)ndw), dim3(256), 0, es, gm, (const unsigned long long*)cb.Sw, (const unsigned long long*)cb.slots,
-                     rows, rows + (size_t)(kRowRmax + 1) * c->cpart_cap, (const double*)dc1, cv, sc, (unsigned long long*)c->cbG.p, (long long*)c->scanlist.p);
+                     rows, rows + (size_t)(kRowRmax + 1) * c->cpart_cap, (const unsigned short*)c->col_cimg.p, (const unsigned short*)c->col_cbmin.p,
+                     2.0 * gm.delta + 2.0 * kCoarse * hmax, cb.Usum, (const unsigned short*)c->col_img.p, cv, sc, (unsigned long long*)c->cbG.p, (long long*)c->scanlist.p);
   hipLaunchKernelGGL(k_col_scan, dim3((unsigned)nsc), dim3(256), 0, es, gm, (const unsigned short*)c->col_img.p, (const unsigned short*)c->col_bmin.p,
                      cv, sc, (unsigned long long*)c->cbG.p, (long long*)c->amb.p, (const long long*)c->scanlist.p);
   c->amb_clean = false;
