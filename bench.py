@@ -82,6 +82,10 @@ def parse_args():
                          "table: force the separable-table kernel (K1g), the O(n^2)-per-candidate contraction")
     ap.add_argument("--sweep", choices=["safeopt", "goose"], default="safeopt")
     ap.add_argument("--no-extra", action="store_true", help="skip the iteration / table-kernel / H / C records")
+    ap.add_argument("--lean", type=int, choices=[0, 1, 2], default=1,
+                    help="sbo_sweep_opts.lean of the SafeOpt sweeps: 1 (default) the objective's mean / var are not STORED on posterior tiles "
+                         "without a safe candidate -- no stage of the sweep reads them; every posterior is still evaluated --, 0 the whole "
+                         "posterior stays resident (reported beside the main line as config.full_posterior), 2 not even evaluated there")
     return ap.parse_args()
 
 
@@ -187,8 +191,8 @@ def table_kernel_record(eng, cfg, step, kind, res, kernel_name, n_total, barrier
                                   + " against the exact table kernel's, same model and grid, same run"}}
 
 
-def sweep_fn(eng, kind, b):
-    return (lambda: eng.sweep_safeopt(b)) if kind == "safeopt" else (lambda: eng.sweep_goose(b))
+def sweep_fn(eng, kind, b, lean=0):
+    return (lambda: eng.sweep_safeopt(b, lean=lean)) if kind == "safeopt" else (lambda: eng.sweep_goose(b))
 
 
 def hbm_roofline(q, es, n_local, rows):
@@ -312,7 +316,7 @@ def comm_record(eng, step, transport):
                           "rehearsals the wall clock of the staged calls"}
 
 
-def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None, group=None, table_kernel=False, transport="none"):
+def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None, group=None, table_kernel=False, transport="none", lean=0):
     """Resident-model sweep rate (+ iteration cost for the 2-D grids) of another config, same process.  ``points``: size of the
     explicit candidate list of a scattered config (E).  ``group``: the ranks of an N > 1 run -- the grid is then sharded over
     them (strong scaling) and the time is the slowest rank's."""
@@ -332,7 +336,7 @@ def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None, group=N
         else:
             eng.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
         where = f"implicit grid {'x'.join(map(str, count))} ({n_total} candidates" + (f", sharded over {world} ranks)" if group is not None else ")")
-    step = sweep_fn(eng, kind, cfg["b"])
+    step = sweep_fn(eng, kind, cfg["b"], lean=lean)
     el, rows, res = timed_resident(eng, step, steps, max(1, steps // 5), barrier)
     el = max_over_ranks(group, el)
     mf, _ = mfma_roofline(cfg, rows, n_total // world)
@@ -421,7 +425,7 @@ def main():
             group.barrier()
         eng.synchronize()
 
-    step = sweep_fn(eng, args.sweep, cfg["b"])
+    step = sweep_fn(eng, args.sweep, cfg["b"], lean=args.lean)
     if args.posterior == "table":
         eng.set_option("bilinear", 0)
     elapsed, rows, res = timed_resident(eng, step, args.steps, args.warmup, barrier)
@@ -435,6 +439,17 @@ def main():
         es = 8 if cfg["dtype"] == "f64" else 4
         roof, k1_kind = mfma_roofline(cfg, rows, n_local)
         roof["hbm"] = hbm_roofline(cfg["q"], es, n_local, rows)
+        # what binds the posterior kernel.  K1b / K1i issue ~300 flops per candidate on the matrix cores whatever n is: their roof is the
+        # 2 q s bytes per candidate they write and the instruction issue of their epilogues, not the matrix pipe -- `frac` above is kept
+        # as the issued-flop utilisation (`executed`), the store fraction is the one to read; the SURVEY 8(d)-conformant figure of this
+        # config is the exact table kernel's (table_kernel_frac below, same run)
+        store_bytes = 2.0 * cfg["q"] * es * n_local
+        roof["store_bytes_algorithmic"] = store_bytes
+        roof["store_roofline_frac"] = store_bytes / (roof["kernel_ms"] * 1e-3) / 1e12 / HBM_PEAK_TBS
+        roof["store_roofline_definition"] = ("2 q s bytes per candidate (the posterior API's output, SURVEY.md 8(d)) / K1 device time / 8 TB/s; a lean sweep "
+                                             "writes fewer bytes than that (config.lean), the figure prices the time against the full output")
+        if k1_kind in (4, 6):
+            roof["bound"] = "hbm-store/issue"
         # HBM bytes of the K1 launch(es) are NOT measured by this run: they come from separate rocprofv3 --pmc passes of the
         # same command (tools/gpu_bench_profile.sh), committed with the kernel they belong to; null when no record matches
         roof["traffic"], roof["traffic_source"] = None, None
@@ -456,9 +471,22 @@ def main():
                                       f"implicit grid {'x'.join(str(c) for c in count)} ({n_total} candidates)")
                                    + f", n={cfg['ds']['X_norm'].shape[0]} observations, q={cfg['q']} outputs, b={cfg['b']}"
                                    + (f", sharded over {world} ranks by rows of the slowest axis" if world > 1 else ""),
-                       "per_gpu_candidates": n_local, "sweep": args.sweep, "collectives": transport, "result": result},
+                       "per_gpu_candidates": n_local, "sweep": args.sweep, "collectives": transport, "result": result,
+                       "lean": args.lean if args.sweep == "safeopt" else 0,
+                       "set_path": {0: "byte masks", 1: "column words written by the GEMM posterior (sets_colpath.inc.hpp)"}[int(rows[-1].get("set_path", 0))]},
             "roofline": roof,
         }
+        if args.sweep == "safeopt" and world == 1 and not args.no_extra:
+            # the same sweep at the other lean levels, same process (short timed runs): what storing / evaluating the objective's
+            # posterior where no stage of the sweep reads it costs
+            for lv, key in ((0, "full_posterior"), (2, "lean_2")):
+                if lv == args.lean:
+                    continue
+                el_v, rows_v, res_v = timed_resident(eng, sweep_fn(eng, args.sweep, cfg["b"], lean=lv), max(20, args.steps // 4), 3, barrier)
+                same = result_record(res_v, args.sweep) == result
+                out["config"][key] = {"lean": lv, "ms_per_step": el_v * 1e3 / max(20, args.steps // 4), "value": n_total * max(20, args.steps // 4) / el_v,
+                                      "device_ms_per_step": float(np.mean([p["total_ms"] for p in rows_v])),
+                                      "kernel_ms": float(np.mean([p["posterior_ms"] for p in rows_v])), "result_identical": bool(same)}
         if comm is not None:
             out["comm"] = comm
         if d_rec is not None:
@@ -473,6 +501,9 @@ def main():
                 roof["table_build_ms"] = it["table_build_ms"]
             if k1_kind in (4, 5) and default_run:
                 out["table_kernel"] = table_kernel_record(eng, cfg, step, args.sweep, res, roof["kernel"], n_total, barrier, steps=3)
+                roof["table_kernel_frac"] = out["table_kernel"]["frac"]
+                roof["table_kernel_ms"] = out["table_kernel"]["kernel_ms"]
+            out["config"]["iteration_value"] = it["value"]
         if extras and default_run:
             # every other BASELINE.json config on this one GPU: B (configs[1], with its K1g figure), C (the Williams-Otto plant: GoOSE
             # and SafeOpt), D (the whole 128^4 grid of the 8-GPU config: Chebyshev-node interpolation K1t, with its K1g figure), E (10^7 scattered fp32 points)

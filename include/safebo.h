@@ -294,8 +294,9 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  *   "scan_blocks"      1: blocked last-axis scans of the distance transforms; 0: step by step (A/B checker)
  *   "scan_waves"       1: open candidates of the verdict kernels are listed and scanned by groups of 16 lanes (8 | 32 | 64: lanes); 0: own thread
  *   "goose_pairs"      1: GoOSE coverage by pruned pair evaluation on grids too (A/B checker of the power transform)
- *   "col_path"         1: one-constraint SafeOpt sweeps of one rank on 2-D grids of whole 64 x 128 tiles run their set phase on column words
- *                      written by the GEMM posterior's epilogue (sets_colpath.inc.hpp); 0: the byte-mask pipeline (A/B checker)
+ *   "col_path"         1 (auto): one-constraint SafeOpt sweeps of one rank on 2-D grids of whole 64 x 128 posterior tiles -- at least four tiles
+ *                      per CU and output -- run their set phase on column words written by the GEMM posterior's epilogue
+ *                      (sets_colpath.inc.hpp); 2: on every grid of that shape; 0: the byte-mask pipeline (A/B checker)
  *   "col_overlap"      1: on that path the expander chain (distance transform, verdicts) runs on a second stream beside the objective's
  *                      posterior launch; 0: every kernel on the main stream
  *   "set_fuse"         1: 2-D grids of one rank share launches between independent set-phase kernels; 0: one launch per kernel

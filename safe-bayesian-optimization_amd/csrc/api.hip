@@ -306,7 +306,8 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     return SBO_OK;
   }
   if (!strcmp(key, "col_path")) {
-    c->col_path = value ? 1 : 0;
+    if (value < 0 || value > 2) return fail(SBO_E_INVALID, "col_path must be 0 (never), 1 (auto) or 2 (whenever the grid's shape allows)");
+    c->col_path = (int)value;
     return SBO_OK;
   }
   if (!strcmp(key, "col_overlap")) {

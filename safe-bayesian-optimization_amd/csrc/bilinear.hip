@@ -3101,8 +3101,13 @@ int interp_setup(sbo_ctx* c) {
 // Column path (r05): can this launch deliver the classification as column words?  One constraint, fp64 grid of whole 64 x 128
 // tiles (every workgroup's tile inside the grid), at most 64 segments (Usum is one word per column); the sweep asked for it.
 static bool col_words_ok(const sbo_ctx* c, long long cnt0, long long nlines) {
-  return c->col_request && c->col_path && c->mc.q == 2 && c->cs.kind == 1 && c->cs.d == 2 && c->cs.first == 0 && cnt0 % 128 == 0 &&
-         nlines % 64 == 0 && nlines / 64 <= 64 && nlines >= 64 && cnt0 >= 128 && cnt0 <= 4096 && c->world == 1 && !c->comm_selftest;
+  if (!c->col_request || !c->col_path) return false;
+  const bool shape = c->mc.q == 2 && c->cs.kind == 1 && c->cs.d == 2 && c->cs.first == 0 && cnt0 % 128 == 0 && nlines % 64 == 0 &&
+                     nlines / 64 <= 64 && nlines >= 64 && cnt0 >= 128 && cnt0 <= 4096 && c->world == 1 && !c->comm_selftest;
+  // (auto: from four tiles per CU and output on -- config H.  Below that the two launches per sweep cost more than the column
+  // kernels save: config B, 512 tiles per output, 0.171 ms against 0.162 with the byte masks.  Option col_path = 2: whenever the shape fits.)
+  const long long tiles = (cnt0 / 128) * (nlines / 64);
+  return shape && (c->col_path == 2 || tiles >= 4ll * c->n_cu);
 }
 static int col_words_prepare(sbo_ctx* c, long long cnt0, long long nlines, ColBits* cb) {
   const size_t words = (size_t)(nlines / 64) * (size_t)cnt0;

@@ -1754,8 +1754,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   // column path (sets_colpath.inc.hpp): a fresh posterior of a one-constraint fp64 model on one rank may deliver the classification
   // as column words (the GEMM posterior decides whether its launch qualifies: col_active)
   c->col_request = !reuse && std::is_same<T, double>::value && q == 2 && !multi_rank(c) && !c->rc_active && c->result_mirror && n > 0;
-  static const int env_lean = getenv("SBO_LEAN") ? atoi(getenv("SBO_LEAN")) : -1;          // (development: tools/dev_col_stats.sh)
-  const int lean = env_lean >= 0 ? env_lean : o->lean;
+  const int lean = o->lean;
   c->col_lean = c->col_request ? (lean >= 2 ? 2 : (lean ? 1 : 0)) : 0;
   c->col_active = false;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) { c->col_request = false; return rc; }
@@ -2522,16 +2521,6 @@ int sbo_sweep_tr(sbo_ctx* c, const sbo_sweep_opts* opts, const double* x_0, doub
     if (rc == SBO_OK) result->guard_band = first;
   }
   return rc;
-}
-
-// development: histograms of wave lifetimes of the column path's kernels (SBO_COL_DBG=9)
-int sbo_debug_col_hist(unsigned long long* out /* [6][64] */, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_col_hist), sizeof(unsigned long long) * 6 * 64) != hipSuccess) return 1;
-  if (reset) {
-    static unsigned long long z[6 * 64];
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_col_hist), z, sizeof(z)) != hipSuccess) return 1;
-  }
-  return 0;
 }
 
 int sbo_masks_get(sbo_ctx* c, int which, int cidx, uint8_t* out) {

@@ -24,21 +24,7 @@ struct ColGeom {
   int CNB, CNBp, CWp;        // 32-cell blocks per coarse row, row strides of the coarse block minima / the coarse image (padded)
   int gxt;                   // k_bpost tiles per tile row (W / 128)
   double h0, h1;
-  int dbg;                   // (development: stage cuts for timing, SBO_COL_DBG)
   double delta;              // sandwich of the coarse transform: dC - delta <= dist(g, U) <= dC + delta (sets_expander.inc.hpp)
-};
-// (development: histogram of wave lifetimes in microseconds per kernel, SBO_COL_DBG=9; sbo_debug_col_hist)
-__device__ unsigned long long g_col_hist[6][64];
-struct ColClock {
-  unsigned long long t0;
-  int k, on;
-  __device__ ColClock(int kernel, int dbg) : t0(0), k(kernel), on(dbg == 9) { if (on) t0 = wall_clock64(); }
-  __device__ ~ColClock() {
-    if (on && (threadIdx.x & 63) == 0) {
-      const unsigned long long us = (wall_clock64() - t0) / 100ull;          // (100 MHz counter)
-      atomicAdd(&g_col_hist[k][us < 63 ? us : 63], 1ull);
-    }
-  }
 };
 constexpr int kColBig = 1 << 20;       // "no U point on this side of the column" (far above 65535 through 64 increments)
 
@@ -73,7 +59,6 @@ __device__ __forceinline__ void col_fine_item(long long item, const ColGeom gm, 
     const unsigned long long w = cb.Uw[(size_t)sn * gm.W + i];
     if (w) dn = (64 * sn + __ffsll((long long)w) - 1) - (64 * s + 64);
   }
-  if (gm.dbg == 2) { if (f + dn + (int)m == 12345) img[0] = 1; return; }
   const unsigned int nlo = ~(unsigned int)m, nhi = ~(unsigned int)(m >> 32);     // bit clear -> 1
   int F[64];
 #pragma unroll
@@ -93,7 +78,6 @@ __device__ __forceinline__ void col_fine_item(long long item, const ColGeom gm, 
     tile[r * 64 + lane] = (unsigned short)t;
   }
   __builtin_amdgcn_wave_barrier();
-  if (gm.dbg == 3) return;
   // image rows: store k moves rows 8 k .. 8 k + 7, lane l the 16 bytes (8 columns) l & 7 of row 8 k + (l >> 3)
   {
     const int rsub = lane >> 3, ch = lane & 7;
@@ -280,18 +264,14 @@ __global__ __launch_bounds__(256) void k_col_a(const ColGeom gm, const ColBits c
   constexpr size_t kTileBytes = 4 * 64 * 64 * sizeof(unsigned short);
   __shared__ __attribute__((aligned(16))) unsigned char mem[kTileBytes];
   const int bid = (int)blockIdx.x;
-  ColClock clk_(0, gm.dbg);
   if (bid == 0) {
-    if (gm.dbg == 4) return;
     col_merge1_body(mg.slots, mg.sc, mg.Lmax, mg.gb, mg.b);
   } else if (bid < 1 + ncoarse) {
-    if (gm.dbg == 1 || gm.dbg == 4) return;
     col_coarse_job(bid - 1, gm, cb.Uw, reinterpret_cast<unsigned long long*>(mem), cimg, cbmin);
   } else {
     const int nfine = (int)gridDim.x - 1 - ncoarse;
     unsigned short* tile = reinterpret_cast<unsigned short*>(mem) + (threadIdx.x >> 6) * 64 * 64;
     const long long nitems = (long long)gm.NS * (gm.W >> 6);
-    if (gm.dbg == 1) return;
     for (long long item = (long long)(bid - 1 - ncoarse) * 4 + (threadIdx.x >> 6); item < nitems; item += (long long)nfine * 4)
       col_fine_item(item, gm, cb, tile, img, bmin, Mw, Gw);
   }
@@ -421,8 +401,6 @@ struct ColMinJob {
   const GuardBand* gb;
 };
 __global__ __launch_bounds__(256) void k_col_min(const ColMinJob j) {
-  if (j.gm.dbg == 1) return;
-  ColClock clk_(4, j.gm.dbg);
   unsigned long long ukey, vkey;
   col_merge2_body(j.slots, ukey, vkey);
   const ColUnitMap um = col_unit_map(j.slots, j.gm.NS);
@@ -684,8 +662,6 @@ __global__ __launch_bounds__(256) void k_col_decide(const ColGeom gm, const unsi
                                                     SweepScalars* sc, unsigned long long* __restrict__ Gw, long long* __restrict__ scanlist) {
   __shared__ long long qg[4][kColQueue];
   __shared__ double qu[4][kColQueue];
-  if (gm.dbg == 1) return;
-  ColClock clk_(2, gm.dbg);
   const double L = __longlong_as_double((long long)cv.Lkeys[cv.lidx]);
   const bool on_all = sc->count_U > 0 && sc->count_S > 0;
   const ColUnitMap um = col_unit_map(slots, gm.NS);
@@ -705,7 +681,6 @@ __global__ __launch_bounds__(256) void k_col_decide(const ColGeom gm, const unsi
   const double rmax = sc->rmax_key[1] ? ord_val(sc->rmax_key[1]) : 0.0;
   const double capC = L > 0 ? rmax / L * 1.000001 + 1e-6 + cap_extra : kInfD;
   const double h0c = gm.h0 * kCoarse, h1c = gm.h1 * kCoarse, inv_h0c = 1.0 / h0c;
-  if (gm.dbg == 6) { if (L == 123.25 && nunits == 77 && bk.du == 3.5) Gb[0] = 1; return; }
   int qcnt = 0;                                   // (uniform over the wave)
   auto flush = [&]() {
     if (qcnt == 0) return;
@@ -726,8 +701,7 @@ __global__ __launch_bounds__(256) void k_col_decide(const ColGeom gm, const unsi
     const unsigned int sb[2] = {(unsigned int)(sw[0] >> (8 * x.oct)) & 0xffu, (unsigned int)(sw[1] >> (8 * x.oct)) & 0xffu};
     unsigned int gbits[2] = {0u, 0u};
     const unsigned int any8 = sb[0] | sb[1];
-    if (gm.dbg == 2) { gbits[0] = sb[0]; gbits[1] = sb[1]; }
-    else if (__ballot(any8 != 0u) != 0ull) {
+    if (__ballot(any8 != 0u) != 0ull) {
       const int row0 = 64 * x.s + 8 * x.oct;
       // The coarse distances of the unit's sixteen cells (the octet is one coarse row, the lane's two columns lie in cell lane >> 2):
       // eight lanes search a cell, two rounds; a lane then picks up its own cell's value.
@@ -782,14 +756,6 @@ __global__ __launch_bounds__(256) void k_col_decide(const ColGeom gm, const unsi
         const size_t g = x.g0 + (size_t)k * gm.W;
         mu[k] = on ? *reinterpret_cast<const d2c_t*>(cv.mean_c + g) : d2c_t{0.0, 0.0};
         va[k] = on ? *reinterpret_cast<const d2c_t*>(cv.var_c + g) : d2c_t{0.0, 0.0};
-      }
-      if (gm.dbg == 8) {
-        double acc = dc2;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc += mu[k][0] + mu[k][1] + va[k][0] + va[k][1];
-        gbits[0] = acc == 1.2345 ? 1u : 0u;
-        Gb[8 * x.w0 + x.oct] = (uint8_t)gbits[0];
-        continue;
       }
       const double dC = sqrt(dc2);
       const double dhi = dC * (1.0 + 1e-9) + delta, dlo = fmax(0.0, dC * (1.0 - 1e-9) - delta);
@@ -878,8 +844,6 @@ __global__ __launch_bounds__(256) void k_col_scan(const ColGeom gm, const unsign
                                                   const ColVerdict cv, SweepScalars* sc, unsigned long long* __restrict__ Gw,
                                                   long long* __restrict__ amb, const long long* __restrict__ scanlist) {
   constexpr int GL = 8;
-  if (gm.dbg == 1) return;
-  ColClock clk_(3, gm.dbg);
   const double L = __longlong_as_double((long long)cv.Lkeys[cv.lidx]);
   const long long nscan = sc->n_scan;
   const RcBandK bk = rc_band(cv.rx, sc);
@@ -934,11 +898,12 @@ __global__ __launch_bounds__(256) void k_col_finals(const Best* __restrict__ reg
   const int slot = blockIdx.y, p = blockIdx.x;
   const Best* reg = slot == 0 ? reg0 : reg1;
   const int n = slot == 0 ? n0 : n1;
-  const int i0 = (int)((long long)n * p / kColFinParts), i1 = (int)((long long)n * (p + 1) / kColFinParts);
+  const int i0 = (int)((long long)n * p / (int)gridDim.x), i1 = (int)((long long)n * (p + 1) / (int)gridDim.x);
   Best best = best_none<true>();
   long long cnt = 0, nb = 0;
   {
     const long long* pc = (const long long*)(reg + n);
+#pragma unroll 4
     for (int i = i0 + (int)threadIdx.x; i < i1; i += blockDim.x) {
       best = best_merge<true>(best, reg[i]);
       cnt += pc[i];
@@ -948,24 +913,29 @@ __global__ __launch_bounds__(256) void k_col_finals(const Best* __restrict__ reg
     cnt = block_sum_ll(cnt);
     nb = block_sum_ll(nb);
   }
+  // (one workgroup per slot -- gridDim.x == 1, the launch of today's 2 x 1024 rows -- needs no second level: no ticket, no fences)
+  const int parts = (int)gridDim.x;
   __shared__ int last;
-  if (threadIdx.x == 0) {
-    fin[slot * kColFinParts + p] = ColFinRow{best, cnt, nb};
+  if (parts > 1) {
+    if (threadIdx.x == 0) {
+      fin[slot * kColFinParts + p] = ColFinRow{best, cnt, nb};
+      __threadfence();
+      const unsigned long long t = atomicAdd(&tickets[slot], 1ull);
+      last = t == (unsigned long long)(parts - 1);
+      if (last) tickets[slot] = 0ull;                     // (for the next sweep)
+    }
+    __syncthreads();
+    if (!last) return;
     __threadfence();
-    const unsigned long long t = atomicAdd(&tickets[slot], 1ull);
-    last = t == (unsigned long long)(kColFinParts - 1);
-    if (last) tickets[slot] = 0ull;                     // (for the next sweep)
   }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
   // (the slot block back to its neutral elements: every reader of this sweep ran in an earlier launch)
   if (slot == 1)
     for (int i = threadIdx.x; i < kColSlotFields * kColSlots; i += blockDim.x) slots[i] = col_slot_is_min(i / kColSlots) ? ~0ull : 0ull;
   if (threadIdx.x == 0) {
+    if (parts > 1) {
     best = best_none<true>();
     cnt = nb = 0;
-    for (int k = 0; k < kColFinParts; ++k) {
+    for (int k = 0; k < parts; ++k) {
       const ColFinRow r{Best{__hip_atomic_load(&fin[slot * kColFinParts + k].b.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                              __hip_atomic_load(&fin[slot * kColFinParts + k].b.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                              __hip_atomic_load(&fin[slot * kColFinParts + k].b.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
@@ -977,6 +947,7 @@ __global__ __launch_bounds__(256) void k_col_finals(const Best* __restrict__ reg
       best = best_merge<true>(best, r.b);
       cnt += r.cnt;
       nb += r.nb;
+    }
     }
     store_slot<true>(sc, slot, best, nb, gb_on != 0);
     if (slot == 0) sc->count_M += cnt;
@@ -1050,7 +1021,6 @@ static int col_set_phase(sbo_ctx* c, const sbo_sweep_opts* o, SweepScalars& h, u
   double h2 = 0.0, hmax = 0.0;
   for (int a = 0; a < 2; ++a) { h2 += c->cs.step[a] * c->cs.step[a]; hmax = std::max(hmax, c->cs.step[a]); }
   gm.delta = (kCoarse - 1) * std::sqrt(h2) * (1.0 + 1e-9);
-  { static const char* e = getenv("SBO_COL_DBG"); gm.dbg = e ? atoi(e) : 0; }
   const int lidx = o->reference_quirk_L_index ? q - 1 : 1;     // models/SafeOpt.py:110 (loop-leaked i)
   if ((rc = ensure(c->scal, sizeof(SweepScalars)))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
@@ -1061,8 +1031,7 @@ static int col_set_phase(sbo_ctx* c, const sbo_sweep_opts* o, SweepScalars& h, u
   ColScal2* sc2 = (ColScal2*)c->col_fin.p;
   unsigned long long* tickets = (unsigned long long*)((char*)c->col_fin.p + 64);
   ColFinRow* fin = (ColFinRow*)((char*)c->col_fin.p + 128);
-  static const bool env_no_overlap = getenv("SBO_COL_OVERLAP") && atoi(getenv("SBO_COL_OVERLAP")) == 0;     // (development)
-  const bool overlap = c->col_overlap && !env_no_overlap && c->stream3 && c->col_forked;
+  const bool overlap = c->col_overlap && c->stream3 && c->col_forked;
   hipStream_t xs = c->stream, es = overlap ? c->stream3 : c->stream;      // objective chain / expander chain
   if (fresh_fin) SBO_HIP(hipMemsetAsync(c->col_fin.p, 0, 4096, es));       // (tickets: the last workgroup of a slot resets its own)
   const int nb = reduce_blocks(c);
@@ -1156,7 +1125,7 @@ static int col_set_phase(sbo_ctx* c, const sbo_sweep_opts* o, SweepScalars& h, u
   j.gb = gb_of(c);
   const int nbg = nb;
   hipLaunchKernelGGL(k_col_min, dim3((unsigned)nb), dim3(256), 0, xs, j);
-  hipExtLaunchKernelGGL(k_col_finals, dim3(kColFinParts, 2), dim3(256), 0, xs, nullptr, c->ev[4], 0, (const Best*)reg0, nb, (const Best*)reg1,
+  hipExtLaunchKernelGGL(k_col_finals, dim3(nb > 2048 ? kColFinParts : 1, 2), dim3(256), 0, xs, nullptr, c->ev[4], 0, (const Best*)reg0, nb, (const Best*)reg1,
                         nbg, sc, (const ColScal2*)sc2, fin, tickets, c->h_back, (const unsigned long long*)c->Lmax.p, gb_of(c) ? 1 : 0, cb.slots);
   c->slots_clean = true;
   SBO_HIP(hipGetLastError());

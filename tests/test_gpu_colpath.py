@@ -43,6 +43,7 @@ def test_column_path_matches_oracle(engine, cfg_name, n, count, b):
     pts = oracle.grid_points(lo, hi, count)
     ref = oracle.safeopt_sweep(pts, cfg["ds"], b)
     engine.set_option("fuse_classify", 1)
+    engine.set_option("col_path", 2)
     try:
         engine.set_grid(lo, hi, count)
         engine.set_model(cfg["ds"], dtype="f64")
@@ -62,6 +63,7 @@ def test_column_path_matches_oracle(engine, cfg_name, n, count, b):
         assert set(kernels) <= {4, 6}, kernels
     finally:
         engine.set_option("fuse_classify", -1)
+        engine.set_option("col_path", 1)
 
 
 @pytest.mark.parametrize("overlap", [0, 1])
@@ -71,6 +73,7 @@ def test_column_path_one_stream_and_two(engine, overlap):
     lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [384, 192]
     ref = oracle.safeopt_sweep(oracle.grid_points(lo, hi, count), cfg["ds"], cfg["b"])
     engine.set_option("fuse_classify", 1)
+    engine.set_option("col_path", 2)
     engine.set_option("col_overlap", overlap)
     try:
         engine.set_grid(lo, hi, count)
@@ -82,6 +85,7 @@ def test_column_path_one_stream_and_two(engine, overlap):
     finally:
         engine.set_option("col_overlap", 1)
         engine.set_option("fuse_classify", -1)
+        engine.set_option("col_path", 1)
 
 
 @pytest.mark.parametrize("lean", [0, 1, 2])
@@ -93,6 +97,7 @@ def test_column_path_lean_and_late_recheck(engine, lean):
     pts = oracle.grid_points(lo, hi, count)
     ref = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"])
     engine.set_option("fuse_classify", 1)
+    engine.set_option("col_path", 2)
     try:
         engine.set_grid(lo, hi, count)
         engine.set_model(cfg["ds"], dtype="f64")
@@ -111,6 +116,7 @@ def test_column_path_lean_and_late_recheck(engine, lean):
     finally:
         engine.set_option("exact_lazy", 1)
         engine.set_option("fuse_classify", -1)
+        engine.set_option("col_path", 1)
 
 
 def test_column_path_guard_reevaluation(engine):
@@ -120,6 +126,7 @@ def test_column_path_guard_reevaluation(engine):
     pts = oracle.grid_points(lo, hi, count)
     ref = oracle.safeopt_sweep(pts, cfg["ds"], cfg["b"])
     engine.set_option("fuse_classify", 1)
+    engine.set_option("col_path", 2)
     engine.set_option("guard_band", 2)
     try:
         engine.set_grid(lo, hi, count)
@@ -131,6 +138,7 @@ def test_column_path_guard_reevaluation(engine):
     finally:
         engine.set_option("guard_band", 1)
         engine.set_option("fuse_classify", -1)
+        engine.set_option("col_path", 1)
 
 
 @pytest.mark.parametrize("cfg_name", ["B", "H"])
@@ -144,7 +152,7 @@ def test_column_path_equals_byte_mask_path_full_size(engine, cfg_name):
     out = {}
     try:
         for path in (0, 1):
-            engine.set_option("col_path", path)
+            engine.set_option("col_path", 2 * path)
             engine.set_model(cfg["ds"], dtype="f64")                 # (a new model: the first sweep runs K1i again)
             for sweep in range(4):
                 res = engine.sweep_safeopt(cfg["b"], want_masks=True, lean=max(0, sweep - 1))
