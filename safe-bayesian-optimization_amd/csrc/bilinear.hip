@@ -2151,9 +2151,17 @@ bool bilinear_applicable(const sbo_ctx* c) {
   const CandSpec& cs = c->cs;
   if (!c->bilinear || c->dtype != SBO_F64 || !c->has_cand || cs.kind != 1 || cs.d != 2 || c->mc.d != 2) return false;
   const long long cnt0 = cs.count[0];
-  if (cs.n_local <= 0 || cs.first % cnt0 != 0 || cs.n_local % cnt0 != 0) return false;
+  if ((cs.n_local <= 0 && !(c->sharded && c->world > 1)) || cs.first % cnt0 != 0 || cs.n_local % cnt0 != 0) return false;
   // the bases pay off (and the interpolation interval is meaningful) only on real grids
-  return cnt0 >= 64 && cs.count[1] >= 64 && cs.n_local / cnt0 >= 16 && c->alpha64.p != nullptr && c->f_cap >= c->mc.n;
+  // (ranks > 1: ONE decision for all of them -- the recheck behind an approximating posterior contains collectives, so a rank that
+  // took the exact kernel K1g for its 15-line shard would return while its 16-line neighbours wait for it there.  The shard sizes
+  // are known to every rank: the smallest one decides.)
+  long long min_lines = cs.n_local / cnt0;
+  if (c->sharded && c->first_of.size() == (size_t)c->world + 1)
+    for (int r = 0; r < c->world; ++r) min_lines = std::min(min_lines, (c->first_of[r + 1] - c->first_of[r]) / cnt0);
+  // (a caller's matrix whose factor is deferred: the band's reference runs on the matrix itself and must fit its LDS budget)
+  if (c->mc.factor == SBO_FACTOR_INVK && c->chol_async && c->mc.npad > kGuardRefMaxNpad) return false;
+  return cnt0 >= 64 && cs.count[1] >= 64 && min_lines >= 16 && c->alpha64.p != nullptr && c->f_cap >= c->mc.n;
 }
 
 // layout of bl_basis (doubles): U [2q][kBlMaxR][n] | Vs [2q][kBlMaxR][kBlMaxRc] | sig [2q][kBlMaxR] | info (ints, 2q x 4, in
@@ -2836,6 +2844,9 @@ __global__ __launch_bounds__(256) void k_gb_band_i(const InterpParams* __restric
         e[5] = fmax(e[5], fabs(rg));
       }
     }
+    // (a probe whose deviation is not finite: fmax drops a NaN, so the flag joins the reduction itself -- every thread holds at most
+    // one of the 144 probes, and only lane 1's flag used to be published)
+    if (bad) e[0] = kGbInf;
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -2843,7 +2854,6 @@ __global__ __launch_bounds__(256) void k_gb_band_i(const InterpParams* __restric
     __syncthreads();
     if (lane == 0)
       for (int k = 0; k < 6; ++k) sh[wave][k] = e[k];
-    if (lane == 1 && bad) sh[wave][0] = kGbInf;
     __syncthreads();
     if (tid == 0) {
       for (int w = 1; w < 4; ++w)

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void k_gb_band(const ModelConst mc, const doub
 // ---- host ----------------------------------------------------------------------------------------------------------------
 // can the reference formula run with the caller's matrix (no factor needed)?
 static bool ref_direct(const sbo_ctx* c) {
-  return c->mc.factor == SBO_FACTOR_INVK && c->chol_async && c->invk_w_valid && c->invk_plain != nullptr && c->dtype == SBO_F64 && !c->is_shadow;
+  return c->mc.factor == SBO_FACTOR_INVK && c->chol_async && c->invk_w_valid && c->invk_plain != nullptr && c->dtype == SBO_F64 && !c->is_shadow &&
+         c->mc.npad <= kGuardRefMaxNpad;
 }
 
 template <int D>

@@ -8,6 +8,10 @@
 
 namespace sbo {
 
+// The direct reference of the guard band (guard.hip: k_ref_list) keeps 16 cross-covariance vectors of npad doubles + 32 KB of partial
+// sums in LDS: 160 KB at npad = 1024.  Larger models do not take the GEMM posteriors with a caller's matrix (they run K1g, whose
+// factor is made on demand) -- ADVICE r04.
+constexpr int kGuardRefMaxNpad = 1008;
 constexpr int kMaxD = SBO_MAX_D;
 constexpr int kMaxQ = SBO_MAX_Q;
 

@@ -575,8 +575,10 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     // buffers: node list, node values (mean, var: q each; gradient: q d), interpolation matrices, ping-pong work
     const int nqg = q * d;
     if ((rc = ensure(c->tn_pts, sizeof(double) * 8 * 128))) return rc;       // the node positions of the axes (+ a rank's slab of them)
-    // (the two large buffers: running out of memory for them is a reason to decline -- K1g needs neither --, not to fail the sweep)
-    if ((rc = ensure(c->tn_vals, sizeof(double) * (size_t)Nn * (2 * q + nqg)))) { if (rc == SBO_E_NOMEM) break; return rc; }
+    // (the two large buffers: running out of memory for them is a reason to decline -- K1g needs neither --, not to fail the sweep.
+    // With ranks > 1 it IS an error: the plan is one decision of all ranks, and a rank that left for K1g alone would leave the others
+    // in the all-gather of the node slabs -- ADVICE r04)
+    if ((rc = ensure(c->tn_vals, sizeof(double) * (size_t)Nn * (2 * q + nqg)))) { if (rc == SBO_E_NOMEM && !multi_rank(c)) break; return rc; }
     size_t half_elems = 0;
     {
       long long pre = 1, post = 1;
@@ -588,7 +590,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       }
     }
     c->tn_work_half = half_elems;
-    if ((rc = ensure(c->tn_work, sizeof(double) * 2 * std::max<size_t>(half_elems, 16)))) { if (rc == SBO_E_NOMEM) break; return rc; }
+    if ((rc = ensure(c->tn_work, sizeof(double) * 2 * std::max<size_t>(half_elems, 16)))) { if (rc == SBO_E_NOMEM && !multi_rank(c)) break; return rc; }
     for (int a = 0; a < d; ++a)
       if ((rc = ensure(c->tn_W[a], sizeof(double) * (size_t)td.cnt[a] * td.Dn[a]))) return rc;
     if ((rc = ensure(c->tn_W0t, sizeof(double) * (size_t)td.cnt[0] * td.Dn[0]))) return rc;
@@ -611,7 +613,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       long long pre_all = 1;
       for (int a = 0; a < d - 1; ++a) pre_all *= td.Dn[a];
       const long long Nl = pre_all * per;
-      if ((rc = ensure(c->tn_gather, sizeof(double) * (size_t)nq_all * (size_t)Nl * (size_t)(W + 1)))) { if (rc == SBO_E_NOMEM) break; return rc; }
+      if ((rc = ensure(c->tn_gather, sizeof(double) * (size_t)nq_all * (size_t)Nl * (size_t)(W + 1)))) { if (rc == SBO_E_NOMEM && !multi_rank(c)) break; return rc; }
       double* slab = (double*)c->tn_gather.p;
       double* gathered = slab + (size_t)nq_all * Nl;
       double* axl = (double*)c->tn_pts.p + 4 * 128;

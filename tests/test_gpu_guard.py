@@ -318,3 +318,27 @@ def test_k1i_back_to_back_models_and_grid_after_model(engine):
     _same_decisions(out["twice"], out["k1g"], ys[0], "twice")
     _same_decisions(out["late"], out["k1g"], ys[0], "late")
     _same_decisions(out["twice"], out["late"], ys[0], "twice vs late", floats=True)
+
+
+def test_large_model_with_callers_matrix_takes_the_exact_kernel(engine):
+    """(r05) The direct reference of the guard band (k_ref_list) keeps 16 cross-covariance vectors of npad doubles in
+    LDS: 160 KB at npad = 1024.  A model of n = 1100 observations with the caller's invK on a grid the GEMM posteriors would take must
+    run the exact table kernel K1g (its factor made on demand) -- not fail with SBO_E_HIP while it sets up the band -- and its
+    posterior must match the oracle."""
+    cfg = synthetic.make_config("B", n=1100)
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [128, 128]
+    engine.set_grid(lo, hi, count)
+    engine.set_model(cfg["ds"], dtype="f64", use_invK=True)
+    res = engine.sweep_safeopt(cfg["b"], want_masks=True)
+    assert engine.profile()["posterior_kernel"] == 3
+    assert res["guard_band"] == 0
+    pts = oracle.grid_points(lo, hi, count)
+    sub = np.sort(np.random.default_rng(3).choice(pts.shape[0], size=1024, replace=False))
+    om, ov = oracle.gp_inference(pts[sub], cfg["ds"])
+    mean, var = engine.posterior()
+    ys = np.maximum(1.0, cfg["ds"]["Y_std"])
+    # (n = 1100 on [-0.6, 1.5] x [-1, 1]: an ill-conditioned K; the bar of the fitted-model envelope, docs/history.md section 2)
+    tol = max(TOL64, 8.0 * 2.2e-16 * np.linalg.cond(np.linalg.inv(cfg["ds"]["invKopt"][0])))
+    assert np.max(np.abs(mean[sub] - om) / ys) < tol and np.max(np.abs(var[sub] - ov) / ys ** 2) < tol
+    lcb1 = engine.bounds(cfg["b"], 1, "lcb")
+    assert np.array_equal(engine.mask("S"), lcb1 >= 0)

@@ -1545,6 +1545,41 @@ def test_multi_rank_forced_guard_reevaluation_equals_the_exact_kernel(engine, tm
     assert res["tr"]["index"] == tref["index"] and res["tr"]["count_T"] == tref["count_T"]
 
 
+def test_multi_rank_uneven_shards_pick_one_posterior_kernel(engine, tmp_path):
+    """(r05) 31 lines over two ranks are shards of 15 and 16 lines: 16 qualify for the GEMM posterior (K1b / K1i), 15 do
+    not.  The recheck behind an approximating posterior contains collectives, so the choice must be ONE decision of all ranks (the
+    smallest shard decides) -- a rank that alone took the exact kernel used to return while the other waited in the recheck's
+    all-reduce.  Forced re-evaluation (guard_band = 2): the run must end, every rank on the same kernel, the result the exact one."""
+    world, cfg_name, n, count, b = 2, "B", 128, [256, 31], 3.0
+    port, out = _free_port(), str(tmp_path / "res.json")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r), str(world), port, out, cfg_name + ":guard",
+                               str(n), json.dumps(count), str(b)]) for r in range(world)]
+    try:
+        cfg = synthetic.make_config(cfg_name, n=n)
+        engine.set_option("bilinear", 0)
+        engine.set_model(cfg["ds"])
+        engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], count)
+        ref = engine.sweep_safeopt(b, want_masks=True)
+        rmask = {k: engine.mask(k) for k in ("S", "U", "M")}
+        rmask["G1"] = engine.mask("G", 1)
+    except BaseException:
+        for p in procs:
+            p.kill()
+            p.wait()
+        raise
+    finally:
+        engine.set_option("bilinear", 1)
+    assert _wait_ranks(procs, timeout=150) == [0] * world
+    res = json.load(open(out))
+    parts = [np.load(out + f".rank{r}.npz") for r in range(world)]
+    assert [int(p["n_local"]) // count[0] for p in parts] == [15, 16]
+    assert len({int(p["kernel"]) for p in parts}) == 1, [int(p["kernel"]) for p in parts]
+    for k, want in rmask.items():
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), want), k
+    for k in ("minimizer_index", "expander_index", "count_S", "count_M"):
+        assert res[k] == ref[k], k
+
+
 @pytest.mark.parametrize("world,cfg_name,n,count,bs", [(2, "B", 128, [320, 600], [2.0, 2.0, 3.5, 3.5, 1.0]),
                                                         (3, "C", 64, [256, 300], [2.0, 2.0, 3.0, 1.5])])
 def test_multi_rank_speculative_halo_has_no_wait_inside_the_sweep(engine, tmp_path, world, cfg_name, n, count, bs):
