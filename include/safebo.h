@@ -253,6 +253,10 @@ int sbo_sweep_safeopt(sbo_ctx* ctx, const sbo_sweep_opts* opts, sbo_safeopt_resu
 int sbo_sweep_goose(sbo_ctx* ctx, const sbo_sweep_opts* opts, sbo_goose_result* result);
 /* trust-region acquisition of models/GP_TR.py:43-51 on the resident candidates: x_0[d] centre, r radius */
 int sbo_sweep_tr(sbo_ctx* ctx, const sbo_sweep_opts* opts, const double* x_0, double r, sbo_tr_result* result);
+/* BO.explore_safeset(target) for a target of the caller's choosing (models/GoOSE.py:116-119): the candidate of the LAST sweep's safe set
+ * closest to target[d] (scipy cdist's Euclidean distance, ties -> lowest flat index); x_out[SBO_MAX_D] may be NULL.
+ * SBO_E_EMPTY_SAFE_SET when S_t is empty.  (sbo_sweep_goose answers the same question for its own target in its result.) */
+int sbo_explore_safeset(sbo_ctx* ctx, const double* target, int64_t* index_out, double* x_out);
 /* uint8 mask [n_local] of the last sweep (opts.want_masks); c is the constraint index for G / O */
 int sbo_masks_get(sbo_ctx* ctx, int which, int c, uint8_t* out);
 

@@ -45,17 +45,5 @@ class BO(_SafeOptBO):
         target = np.asarray(target, dtype=np.float64)
         if res["target_index"] >= 0 and np.array_equal(target, res["target_x"]):
             return res["explore_x"]
-        self.goose_sweep(want_masks=True)
-        S = self.engine.mask("S")
-        cnt = self.grid
-        g = np.arange(S.shape[0])
-        d2 = np.zeros(S.shape[0])
-        for a, c in enumerate(cnt):
-            i = g % c
-            g = g // c
-            lo, hi = self.bound[a]
-            x = lo + i * ((hi - lo) / (c - 1) if c > 1 else 0.0)
-            if c > 1:
-                x[i == c - 1] = hi
-            d2 += (x - target[a]) ** 2
-        return self._grid_point(int(np.argmin(np.where(S, np.sqrt(d2), np.inf))))
+        # (a target of the caller's own: the same arg-min on the device, over the safe set the sweep left resident)
+        return self.engine.explore_safeset(target)[1]

@@ -106,6 +106,7 @@ SYMBOLS = [
     ("sbo_sweep_safeopt", C.c_int, [_P, C.POINTER(SweepOpts), C.POINTER(SafeOptResult)]),
     ("sbo_sweep_goose", C.c_int, [_P, C.POINTER(SweepOpts), C.POINTER(GooseResult)]),
     ("sbo_sweep_tr", C.c_int, [_P, C.POINTER(SweepOpts), _P, C.c_double, C.POINTER(TRResult)]),
+    ("sbo_explore_safeset", C.c_int, [_P, _P, C.POINTER(C.c_int64), _P]),
     ("sbo_masks_get", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("sbo_nll_batch", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     ("sbo_fit_de", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_uint64, C.c_int, C.c_double, C.c_double, _P, _P,

@@ -2523,6 +2523,41 @@ int sbo_sweep_tr(sbo_ctx* c, const sbo_sweep_opts* opts, const double* x_0, doub
   return rc;
 }
 
+// explore_safeset(target) with a caller's own target (models/GoOSE.py:116-119): argmin over the safe set S_t of the last sweep of
+// ||x - target||_2 -- the two kernels the GoOSE sweep runs for its own target (r05: the host class used to rebuild all N coordinates
+// and distances in NumPy next to a 0.5 ms device sweep)
+int sbo_explore_safeset(sbo_ctx* c, const double* target, int64_t* index_out, double* x_out) {
+  if (!c || !target || !index_out) return fail(SBO_E_INVALID, "NULL argument");
+  if (!c->masks_valid) return fail(SBO_E_INVALID, "no sweep has produced a safe set on these candidates");
+  SBO_HIP(hipSetDevice(c->device));
+  const long long n = c->cs.n_local;
+  int rc;
+  if ((rc = ensure(c->scal, sizeof(SweepScalars)))) return rc;
+  const int nb = reduce_blocks(c);
+  if ((rc = ensure(c->partial, partial_stride(nb)))) return rc;
+  if (c->masks_bits && n > 0) col_expand(c, c->cbS, (uint8_t*)c->maskS.p);
+  SweepScalars* sc = (SweepScalars*)c->scal.p;
+  double* dev_t = (double*)c->scal.p + 256;
+  double t8[SBO_MAX_D] = {0};
+  for (int a = 0; a < c->cs.d; ++a) t8[a] = target[a];
+  SBO_HIP(hipMemcpyAsync(dev_t, t8, sizeof(t8), hipMemcpyHostToDevice, c->stream));
+  if (n > 0) {
+    if (c->dtype == SBO_F64) launch_argmin_dist<double>(c, dev_t, nb);
+    else launch_argmin_dist<float>(c, dev_t, nb);
+  }
+  hipLaunchKernelGGL((k_arg_final<false>), dim3(1), dim3(256), 0, c->stream, (const Best*)c->partial.p, n > 0 ? nb : 0, sc, kArgSlots - 1,
+                     (long long*)nullptr, 0);
+  SBO_HIP(hipGetLastError());
+  SweepScalars h;
+  bool is_max[kArgSlots];
+  for (int t = 0; t < kArgSlots; ++t) is_max[t] = false;
+  if (multi_rank(c) && (rc = ensure(c->xch, sizeof(double) * (size_t)(c->world * kC3Row + 64)))) return rc;
+  if ((rc = sweep_exchange_back(c, h, is_max))) return rc;
+  *index_out = h.arg_idx[kArgSlots - 1];
+  if (x_out) coords_of(c, h.arg_idx[kArgSlots - 1], x_out);
+  return h.arg_idx[kArgSlots - 1] >= 0 ? SBO_OK : fail(SBO_E_EMPTY_SAFE_SET, "safe set S_t is empty on this candidate set");
+}
+
 int sbo_masks_get(sbo_ctx* c, int which, int cidx, uint8_t* out) {
   if (!c || !out) return fail(SBO_E_INVALID, "NULL argument");
   if (!c->masks_valid) return fail(SBO_E_INVALID, "no sweep has produced masks on these candidates");

@@ -229,6 +229,17 @@ class SweepEngine:
                 "count_S": int(res.count_S), "count_T": int(res.count_T), "guard_band": int(res.guard_band),
                 "guard_rechecks": int(res.guard_rechecks), "guard_passes": int(res.guard_passes)}
 
+    def explore_safeset(self, target):
+        """``BO.explore_safeset(target)`` (models/GoOSE.py:116-119) for a caller's own target: (flat index, x) of the candidate of the
+        last sweep's safe set closest to ``target`` -- arg-min on the device."""
+        t = _f64(target)
+        if t.shape != (self.d,):
+            raise ValueError("target must have shape [d]")
+        idx = C.c_int64()
+        x = np.zeros(L.SBO_MAX_D)
+        L.check(self._lib.sbo_explore_safeset(self._ctx, _ptr(t), C.byref(idx), _ptr(x)))
+        return int(idx.value), x[:self.d].copy()
+
     def mask(self, which: str, c: int = 0) -> np.ndarray:
         w = {"S": L.SBO_MASK_S, "U": L.SBO_MASK_U, "M": L.SBO_MASK_M, "G": L.SBO_MASK_G, "O": L.SBO_MASK_O}[which]
         out = np.empty(self.n_local, dtype=np.uint8)

@@ -82,6 +82,12 @@ def test_column_path_one_stream_and_two(engine, overlap):
             res = engine.sweep_safeopt(cfg["b"], want_masks=True, lean=max(0, sweep - 1))
             assert engine.profile()["set_path"] == 1
             _check_oracle(engine, res, _masks(engine), ref)
+        # explore_safeset with a caller's target (models/GoOSE.py:116-119) reads the safe set out of the column words
+        pts = oracle.grid_points(lo, hi, count)
+        target = np.array([0.9 * hi[0], 0.8 * lo[1]])
+        dist = np.sqrt(((pts - target) ** 2).sum(axis=1))
+        idx, x = engine.explore_safeset(target)
+        assert idx == int(np.argmin(np.where(ref["S"], dist, np.inf))) and np.array_equal(x, pts[idx])
     finally:
         engine.set_option("col_overlap", 1)
         engine.set_option("fuse_classify", -1)
