@@ -523,6 +523,12 @@ def main():
                 bc = extra_cfgs["B"][0]
                 out["cpu_baseline"]["config_B"] = cpu_baseline(bc, list(bc["count"]), 0)
                 out["cpu_baseline"]["config_B"]["config"] = f"config B: n={bc['n']}, grid {'x'.join(map(str, bc['count']))}"
+        # the standing audit of the guard band over everything this process swept (sbo_profile.guard_audit_*, csrc/guard.hip): value
+        # pairs re-evaluated with the reference formula on a side stream, how many lay outside the band, the worst in units of the band
+        eng.synchronize()
+        pa = eng.profile()
+        out["config"]["guard_audit"] = {"samples": int(pa["guard_audit_samples"]), "violations": int(pa["guard_audit_violations"]),
+                                        "worst_over_band": float(pa["guard_audit_worst"])}
         print(json.dumps(out))
     if group is not None:
         group.barrier()

@@ -179,6 +179,13 @@ typedef struct sbo_profile {
   int32_t halo_reruns;           /* multi-rank: set phases run again because SOME rank's speculative halo window was too narrow
                                     (the decision is global; host_syncs / comm_* include the discarded pass)                        */
   int32_t set_path;              /* set phase of the last SafeOpt sweep: 0 byte masks, 1 column words written by the GEMM posterior (r05)    */
+  /* Standing audit of the guard band (r05; option "guard_audit" = samples per sweep, default 4096): behind every SafeOpt sweep on K1b /
+   * K1i with a caller's invK, a rotating sample of the candidates is re-evaluated with the reference formula (models/GP_Safe.py:341-343)
+   * on a side stream and compared with what the posterior kernel stored.  Cumulative over the context's life (a finished audit is
+   * collected by the next call): value pairs compared, pairs whose |difference| exceeded the band (guard_dm / guard_dv) -- the claim
+   * every mask and index rests on: must stay 0 --, and the largest deviation seen in units of the band.                             */
+  int64_t guard_audit_samples, guard_audit_violations;
+  double guard_audit_worst;
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */
@@ -312,6 +319,9 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  *   "comm_events"      1: an event pair around every collective (sbo_profile.comm_ms)
  *   "comm_selftest"    1: a one-rank communicator still sends C1 / C2 / C3 through RCCL (results must not change)
  *   "fp64_recheck"     1: fp32 models re-evaluate in fp64 every candidate their 1e-4 contract cannot decide; 0: masks of the fp32 posterior
+ *   "guard_audit"      samples per audited sweep of the standing audit of the guard band (sbo_profile.guard_audit_*; default 1024); 0: off
+ *   "guard_audit_every" one sweep in this many carries an audit (default 16; the first sweep after setting it does).  An audit shares
+ *                      the card with the sweep it follows (~35 us of config H's set phase at 1024 samples, n = 512): 1 audits every sweep
  *   "guard_band"       1: sweeps on an approximating posterior (K1b / K1i / K1t) count the decisions inside its band and re-evaluate exactly
  *                      when there are any; 0: masks of the approximating posterior as they come; 2: the re-evaluation on every sweep (test) */
 int sbo_set_option(sbo_ctx* ctx, const char* key, int64_t value);

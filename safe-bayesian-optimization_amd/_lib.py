@@ -74,6 +74,7 @@ class Profile(C.Structure):
         ("set_phase_ms", C.c_double), ("host_syncs", C.c_int32), ("comm_calls", C.c_int32), ("comm_bytes", C.c_int64),
         ("guard_dm", C.c_double * SBO_MAX_Q), ("guard_dv", C.c_double * SBO_MAX_Q), ("guard_rl", C.c_double * SBO_MAX_Q),
         ("guard_ms", C.c_double), ("halo_reruns", C.c_int32), ("set_path", C.c_int32),
+        ("guard_audit_samples", C.c_int64), ("guard_audit_violations", C.c_int64), ("guard_audit_worst", C.c_double),
     ]
 
 

@@ -123,10 +123,13 @@ int sbo_init(int device_id, sbo_ctx** out) {
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
     e = hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream_audit, hipStreamNonBlocking, least);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming);
     for (auto& ev : c->ev_col)
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    for (auto& ev : c->ev_audit)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   }
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
@@ -188,6 +191,7 @@ static int shadow_ensure(sbo_ctx* c) {
 int sbo_shutdown(sbo_ctx* c) {
   if (!c) return SBO_OK;
   (void)hipSetDevice(c->device);
+  guard_audit_harvest(c, true);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
@@ -202,7 +206,7 @@ int sbo_shutdown(sbo_ctx* c) {
   }
   sbo_comm_destroy_internal(c);
   for (DevBuf* b : {&c->Fpk, &c->As, &c->sqA, &c->alpha, &c->Xn, &c->pts, &c->mean, &c->var, &c->maskS,
-                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_cheb, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->invk_img, &c->bl_lpart, &c->bl_grad, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg, &c->tn_pts, &c->tn_vals, &c->tn_work, &c->tn_W0t, &c->tn_W1t, &c->tn_probe, &c->tn_scr, &c->tn_gather, &c->bi_params, &c->gb, &c->gb_pts, &c->gb_vals, &c->gb_probe, &c->gb_part, &c->list_scr, &c->cbS, &c->cbU, &c->cbM, &c->cbG, &c->cbUsum, &c->col_img, &c->col_bmin, &c->col_fin, &c->col_slots, &c->col_cimg, &c->col_cbmin})
+                    &c->maskU, &c->maskM, &c->maskG, &c->maskO, &c->dist2, &c->dist2b, &c->coarse, &c->fitbuf, &c->fitwork, &c->scal, &c->partial, &c->amb, &c->runmeta, &c->bl_P0f, &c->bl_P1A, &c->bl_T4f, &c->bl_BtA, &c->bl_SBf, &c->bl_VA, &c->bl_small, &c->bl_work, &c->bl_cheb, &c->bl_basis, &c->mwork, &c->rc_mean, &c->rc_var, &c->rc_list, &c->rc_refined, &c->Fplain, &c->alpha64, &c->blockmin, &c->blockmax, &c->cpart, &c->invk_img, &c->bl_lpart, &c->bl_grad, &c->scanlist, &c->gw, &c->Wfull, &c->Uwin, &c->ubits, &c->lane1.dist2, &c->lane1.dist2b, &c->lane1.coarse, &c->lane1.blockmin, &c->lane1.blockmax, &c->lane1.scanlist, &c->lane1.amb, &c->lane1.gw, &c->lane1.runmeta, &c->lane1.scal, &c->gather, &c->xch, &c->shard_first, &c->E0f, &c->Er, &c->AXg, &c->tn_pts, &c->tn_vals, &c->tn_work, &c->tn_W0t, &c->tn_W1t, &c->tn_probe, &c->tn_scr, &c->tn_gather, &c->bi_params, &c->gb, &c->gb_pts, &c->gb_vals, &c->gb_probe, &c->gb_part, &c->list_scr, &c->cbS, &c->cbU, &c->cbM, &c->cbG, &c->cbUsum, &c->col_img, &c->col_bmin, &c->col_fin, &c->col_slots, &c->col_cimg, &c->col_cbmin, &c->audit_pts, &c->audit_val, &c->audit_part, &c->audit_cnt})
     release(*b);
   for (auto& b : c->tn_W) release(b);
   for (auto& ev : c->ev)
@@ -210,6 +214,8 @@ int sbo_shutdown(sbo_ctx* c) {
   for (auto& ev : c->ev_join)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->ev_col)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->ev_audit)
     if (ev) (void)hipEventDestroy(ev);
   if (c->h_c1) (void)hipHostFree(c->h_c1);
   if (c->h_back) (void)hipHostFree(c->h_back);
@@ -220,6 +226,7 @@ int sbo_shutdown(sbo_ctx* c) {
   if (c->h_bi_params) (void)hipHostFree(c->h_bi_params);
   if (c->ev_bi_params) (void)hipEventDestroy((hipEvent_t)c->ev_bi_params);
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
+  if (c->stream_audit) (void)hipStreamDestroy(c->stream_audit);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -234,6 +241,7 @@ int sbo_synchronize(sbo_ctx* c) {
   if (c->stream2) SBO_HIP(hipStreamSynchronize(c->stream2));
   if (c->stream3) SBO_HIP(hipStreamSynchronize(c->stream3));
   if (c->stream4) SBO_HIP(hipStreamSynchronize(c->stream4));
+  if (c->stream_audit) SBO_HIP(hipStreamSynchronize(c->stream_audit));
   return SBO_OK;
 }
 
@@ -310,6 +318,18 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->col_path = (int)value;
     return SBO_OK;
   }
+  if (!strcmp(key, "guard_audit")) {
+    if (value < 0 || value > (1 << 20)) return fail(SBO_E_INVALID, "guard_audit: samples per sweep, 0 (off) .. 1048576");
+    guard_audit_harvest(c, true);
+    c->guard_audit = (int)value;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "guard_audit_every")) {
+    if (value < 1 || value > (1 << 20)) return fail(SBO_E_INVALID, "guard_audit_every: 1 .. 1048576 sweeps");
+    c->guard_audit_every = (int)value;
+    c->audit_tick = 0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "col_overlap")) {
     c->col_overlap = value ? 1 : 0;
     return SBO_OK;
@@ -358,6 +378,8 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
 static int model_set_impl(sbo_ctx* c, int dtype, const char* kernel, int n, int d, int q, const double* X_mean,
                           const double* X_std, const double* Y_mean, const double* Y_std, const double* X_norm,
                           const double* Y_norm, const double* hypopt, const double* const* invK) {
+  // (a standing audit of the last sweep reads the outgoing model's matrix out of the build workspace this call reuses)
+  if (c) guard_audit_harvest(c, true);
   if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
   if (!kernel || strcmp(kernel, "RBF") != 0)      // models/GP_Safe.py:159-162
     return fail(SBO_E_INVALID, std::string("ERROR no kernel with name ") + (kernel ? kernel : "(null)"));
@@ -444,6 +466,7 @@ int sbo_model_set_list(sbo_ctx* c, int dtype, const char* kernel, int n, int d, 
 // device instead of a refit (the reference always refits and renormalises, models/GP_Safe.py:283-304 -- this is an
 // opt-in fast path, not its behaviour).
 int sbo_model_append(sbo_ctx* c, const double* x_norm_new, const double* y_norm_new) {
+  if (c) guard_audit_harvest(c, true);
   if (!c || !x_norm_new || !y_norm_new) return fail(SBO_E_INVALID, "NULL argument");
   if (!c->has_model || !c->Fplain.p) return fail(SBO_E_NO_MODEL, "sbo_model_set has not been called");
   ModelConst& mc = c->mc;
@@ -498,6 +521,7 @@ static int alloc_workspace(sbo_ctx* c) {
 }
 
 int sbo_candidates_points(sbo_ctx* c, const void* points, int points_dtype, int64_t n_local, int d, int64_t first) {
+  if (c) guard_audit_harvest(c, true);
   if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
   if (n_local < 0 || (n_local > 0 && !points)) return fail(SBO_E_INVALID, "bad points / n_local");
   if (d < 1 || d > SBO_MAX_D) return fail(SBO_E_INVALID, "d out of range");
@@ -525,6 +549,7 @@ int sbo_candidates_points(sbo_ctx* c, const void* points, int points_dtype, int6
 
 int sbo_candidates_grid(sbo_ctx* c, int d, const double* lo, const double* hi, const int64_t* count, int64_t first,
                         int64_t n_local) {
+  if (c) guard_audit_harvest(c, true);
   if (!c) return fail(SBO_E_INVALID, "ctx is NULL");
   if (d < 1 || d > SBO_MAX_D || !lo || !hi || !count) return fail(SBO_E_INVALID, "bad grid description");
   long double total = 1;
@@ -591,7 +616,10 @@ int sbo_posterior_enqueue(sbo_ctx* c) {
   int rc = check_ready(c);
   if (rc) return rc;
   SBO_HIP(hipSetDevice(c->device));
+  guard_audit_harvest(c, false);
   if ((rc = alloc_workspace(c))) return rc;
+  // (a standing audit of the last sweep may not have taken its sample of mean / var yet: it is a few microseconds of work on its stream)
+  if (c->audit_pending) SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_audit[0], 0));
   if (c->cs.n_local > 0 && (rc = launch_posterior(c))) return rc;
   c->posterior_valid = true;
   return SBO_OK;
@@ -672,6 +700,10 @@ int sbo_profile_get(sbo_ctx* c, sbo_profile* out) {
   out->posterior_kernel = c->last_k1;
   out->posterior_executed_flops = c->prof.posterior_launches ? c->last_k1_flops : 0.0;
   out->posterior_setup_ms = c->bl.setup_ms;
+  guard_audit_harvest(c, false);
+  out->guard_audit_samples = c->audit_samples;
+  out->guard_audit_violations = c->audit_violations;
+  out->guard_audit_worst = c->audit_worst;
   // the guard band of the posterior that is resident (K1b measures it on the device: a small read-back, off the hot path)
   for (int o = 0; o < SBO_MAX_Q; ++o) out->guard_dm[o] = out->guard_dv[o] = out->guard_rl[o] = 0.0;
   if (c->gb_active && c->guard_band && c->gb.p && c->posterior_valid) {

@@ -27,6 +27,19 @@ constexpr int kRefPer = 16;         // candidates per workgroup of k_ref_list (a
 constexpr double kGbSafety = 16.0;  // band = safety x the largest probe deviation (+ truncation tail + rounding floor)
 constexpr double kInfBand = 1.0e300; // a probe that is not finite: everything is "inside the band"
 
+__device__ __forceinline__ long long block_sum_i64(long long v) {        // valid in thread 0
+  __shared__ long long sh[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  long long r = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) r += sh[w];
+  return r;
+}
+
 // The reference formula on a list: mean_i = mp_i + k . alpha_i, var_i = max(0, sf2 - (k^T invK) k) with the caller's matrix as
 // given (row-major [n][n]), k from the expanded distance (models/GP_Safe.py:112-119, 166, 326-347).  A workgroup takes kRefPer
 // candidates, one output and a chunk of `ccols` matrix columns (a multiple of 64): the k vectors go to LDS; lane l of wave w
@@ -275,7 +288,7 @@ static bool ref_direct(const sbo_ctx* c) {
 
 template <int D>
 static int launch_ref(sbo_ctx* c, hipStream_t st, const double* pts, long long N, long long nlines, double* mean_out, double* var_out,
-                      const ModelConst* mcp = nullptr) {
+                      const ModelConst* mcp = nullptr, DevBuf* part_buf = nullptr /* the audit's own scratch (it runs beside the main stream) */) {
   const ModelConst& mc = c->mc;
   const int q = mc.q;
   const long long groups = (N + kRefPer - 1) / kRefPer;
@@ -286,15 +299,16 @@ static int launch_ref(sbo_ctx* c, hipStream_t st, const double* pts, long long N
   const int ccols = ((nblk + chunks - 1) / chunks) * 64;
   chunks = (mc.n + ccols - 1) / ccols;
   int rc;
-  if ((rc = ensure(c->gb_part, sizeof(double) * 2 * (size_t)chunks * q * (size_t)N))) return rc;
+  DevBuf& pb = part_buf ? *part_buf : c->gb_part;
+  if ((rc = ensure(pb, sizeof(double) * 2 * (size_t)chunks * q * (size_t)N))) return rc;
   const size_t lds = sizeof(double) * ((size_t)kRefPer * mc.npad + 256 * kRefPer);
   auto kern = k_ref_list<D>;
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)q, (unsigned)chunks), dim3(256), lds, st, mc, mcp, c->cs, pts, N, nlines,
                      (const double*)c->As.p, (const double*)c->sqA.p, (const double*)c->alpha64.p, c->a_ld, c->invk_plain,
-                     (size_t)mc.n * mc.n, ccols, (double*)c->gb_part.p);
+                     (size_t)mc.n * mc.n, ccols, (double*)pb.p);
   hipLaunchKernelGGL(k_ref_finish, dim3((unsigned)std::max<long long>(1, std::min<long long>((N * q + 255) / 256, 1024))), dim3(256), 0, st,
-                     mc, mcp, N, chunks, (const double*)c->gb_part.p, mean_out, var_out);
+                     mc, mcp, N, chunks, (const double*)pb.p, mean_out, var_out);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
@@ -372,6 +386,103 @@ int guard_probe_gradients(sbo_ctx* c, hipStream_t st, double* ppts, double* grad
 int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail) {
   hipLaunchKernelGGL(k_gb_band, dim3(1), dim3(256), 0, c->stream, c->mc, pm, pv, ref_m, ref_v, tail, (GuardBand*)c->gb.p);
   SBO_HIP(hipGetLastError());
+  return SBO_OK;
+}
+
+// ---- standing audit of the guard band (r05) --------------------------------------------------------------------------------
+// sample k of a sweep: candidate (offset + k stride) mod N -- a stride coprime to the grid sizes in use scatters the sample over the
+// grid, the offset moves on with every sweep --; its coordinates for the reference formula and the values the posterior kernel stored
+template <int D>
+__global__ __launch_bounds__(256) void k_audit_pick(const CandSpec cs, int P, unsigned long long offset, unsigned long long stride, int q,
+                                                    const double* __restrict__ mean, const double* __restrict__ var, double* __restrict__ pts,
+                                                    double* __restrict__ apx /* [2][q][P] */) {
+  const long long N = cs.n_local;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < P; k += gridDim.x * blockDim.x) {
+    const long long g = (long long)((offset + (unsigned long long)k * stride) % (unsigned long long)N);
+    double x[D];
+    cand_coords<D>(cs, g, x);
+    for (int a = 0; a < cs.d; ++a) pts[(size_t)k * cs.d + a] = x[a];
+    for (int o = 0; o < q; ++o) {
+      apx[(size_t)o * P + k] = mean[(size_t)o * N + g];
+      apx[(size_t)(q + o) * P + k] = var[(size_t)o * N + g];
+    }
+  }
+}
+// cnt: [0] violations, [1] samples (value pairs compared), [2] bit pattern of the largest deviation in units of the band
+__global__ __launch_bounds__(256) void k_audit_compare(int P, int q, int o_first, const double* __restrict__ apx, const double* __restrict__ ref_m,
+                                                       const double* __restrict__ ref_v, const GuardBand* __restrict__ gb,
+                                                       unsigned long long* __restrict__ cnt) {
+  long long viol = 0, smp = 0;
+  double worst = 0.0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < P * (q - o_first); e += gridDim.x * blockDim.x) {
+    const int o = o_first + e / P, k = e % P;
+    const double dm = fabs(apx[(size_t)o * P + k] - ref_m[(size_t)o * P + k]), dv = fabs(apx[(size_t)(q + o) * P + k] - ref_v[(size_t)o * P + k]);
+    const double rm = dm / gb->dm[o], rv = dv / gb->dv[o];
+    const bool bad = !(dm <= gb->dm[o]) || !(dv <= gb->dv[o]);              // (NaN counts)
+    viol += bad;
+    ++smp;
+    const double r = rm > rv ? rm : rv;
+    worst = r > worst ? r : (r != r ? 1e300 : worst);
+  }
+  viol = block_sum_i64(viol);
+  smp = block_sum_i64(smp);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off));
+  if ((threadIdx.x & 63) == 0 && worst > 0.0) atomicMax(&cnt[2], (unsigned long long)__double_as_longlong(worst));
+  if (threadIdx.x == 0) {
+    if (viol) atomicAdd(&cnt[0], (unsigned long long)viol);
+    atomicAdd(&cnt[1], (unsigned long long)smp);
+  }
+}
+
+void guard_audit_harvest(sbo_ctx* c, bool wait) {
+  if (!c->audit_pending) return;
+  if (wait) (void)hipEventSynchronize(c->ev_audit[1]);
+  else if (hipEventQuery(c->ev_audit[1]) != hipSuccess) return;
+  const unsigned long long* hc = (const unsigned long long*)(c->h_back + 7168);
+  c->audit_violations += (long long)hc[0];
+  c->audit_samples += (long long)hc[1];
+  double w;
+  memcpy(&w, &hc[2], 8);
+  c->audit_worst = std::max(c->audit_worst, w);
+  c->audit_pending = false;
+}
+
+int guard_audit_enqueue(sbo_ctx* c, int first_output) {
+  if (c->guard_audit <= 0 || !c->gb_active || !c->guard_band || c->is_shadow || !(c->last_k1 == 4 || c->last_k1 == 6) || !ref_direct(c) || c->mc.dpad != 2 ||
+      c->cs.n_local <= 0 || !c->stream_audit || first_output >= c->mc.q)
+    return SBO_OK;
+  // (the audit shares the card with the sweep it follows -- ~35 us of a config-H sweep's set phase for 1024 samples at n = 512 --, so
+  // one sweep in guard_audit_every carries one)
+  if (c->audit_tick++ % std::max(1, c->guard_audit_every)) return SBO_OK;
+  guard_audit_harvest(c, false);
+  if (c->audit_pending) return SBO_OK;                 // (the previous audit is still running: this sweep's is skipped, none queues up)
+  const int P = c->guard_audit, q = c->mc.q;
+  int rc;
+  if ((rc = ensure(c->audit_pts, sizeof(double) * (size_t)P * 2)) || (rc = ensure(c->audit_val, sizeof(double) * (size_t)P * q * 4)) ||
+      (rc = ensure(c->audit_cnt, 64)))
+    return rc;
+  double* apx = (double*)c->audit_val.p;
+  double* ref_m = apx + (size_t)2 * q * P;
+  double* ref_v = ref_m + (size_t)q * P;
+  hipStream_t st = c->stream_audit;
+  // the sample is taken behind the posterior (its stop event ev[1] -- no record of its own on the main stream: that would be a bubble
+  // in the sweep) ...
+  SBO_HIP(hipStreamWaitEvent(st, c->ev[1], 0));
+  SBO_HIP(hipMemsetAsync(c->audit_cnt.p, 0, 64, st));
+  const unsigned long long stride = 1000003ull;
+  hipLaunchKernelGGL(k_audit_pick<2>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, c->cs, P, c->audit_offset, stride, q, (const double*)c->mean.p,
+                     (const double*)c->var.p, (double*)c->audit_pts.p, apx);
+  c->audit_offset += (unsigned long long)P * stride + 17ull;
+  // ... and before anything overwrites mean / var again (the next posterior launch waits for this event)
+  SBO_HIP(hipEventRecord(c->ev_audit[0], st));
+  if ((rc = launch_ref<2>(c, st, (const double*)c->audit_pts.p, P, 0, ref_m, ref_v, nullptr, &c->audit_part))) return rc;
+  hipLaunchKernelGGL(k_audit_compare, dim3(8), dim3(256), 0, st, P, q, first_output, (const double*)apx, (const double*)ref_m, (const double*)ref_v,
+                     (const GuardBand*)c->gb.p, (unsigned long long*)c->audit_cnt.p);
+  SBO_HIP(hipMemcpyAsync(c->h_back + 7168, c->audit_cnt.p, 24, hipMemcpyDeviceToHost, st));
+  SBO_HIP(hipEventRecord(c->ev_audit[1], st));
+  SBO_HIP(hipGetLastError());
+  c->audit_pending = true;
   return SBO_OK;
 }
 

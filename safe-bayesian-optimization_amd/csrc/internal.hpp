@@ -123,6 +123,7 @@ struct sbo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // side stream: the K1b axis bases of a new model run next to its factorisation
+  hipStream_t stream_audit = nullptr;   // lowest priority: the standing audit of the guard band (guard.hip) fills what the sweeps leave idle
   hipStream_t stream4 = nullptr;   // the deferred factorisation of a caller's invK (chol_async): off the critical path of a model change
   hipStream_t stream3 = nullptr;   // spare high-priority stream (drained with the others)
   int n_cu = 256;
@@ -186,6 +187,18 @@ struct sbo_ctx {
   bool gb_slow = false;            // the re-evaluation path of the SafeOpt sweep is running (Lipschitz keys exact, lists in use)
   sbo::DevBuf gb;                  // GuardBand of the resident posterior
   long long guard_first = 0;       // decisions the first pass of the running sweep left open
+  // Standing audit of the band (r05): behind every K1b / K1i posterior launch of a sweep a rotating sample of the candidates is
+  // re-evaluated with the reference formula on stream2 -- off the critical path -- and compared with what the posterior kernel
+  // stored: a deviation beyond the band is a VIOLATION of the claim the sweeps' exactness rests on (counted, reported in sbo_profile)
+  int guard_audit = 1024;          // option: samples per audited sweep, 0 = off
+  int guard_audit_every = 16;      // option: one sweep in this many is audited (the context's first one is)
+  long long audit_tick = 0;
+  sbo::DevBuf audit_pts, audit_val, audit_part, audit_cnt;
+  hipEvent_t ev_audit[2]{};        // the sample has been taken (mean / var may be overwritten) / the audit has finished
+  bool audit_pending = false;
+  unsigned long long audit_offset = 0;
+  long long audit_samples = 0, audit_violations = 0;
+  double audit_worst = 0.0;        // largest deviation seen, in units of the band
   bool gb_host_valid = false;      // gb_host mirrors `gb` (read back on demand by sbo_profile_get; dropped when a plan writes the block)
   double gb_host[3 * SBO_MAX_Q] = {0};
   sbo::DevBuf gb_pts, gb_vals;     // re-evaluation: coordinates and exact values of the listed candidates
@@ -380,6 +393,8 @@ int guard_exact_grad_list(sbo_ctx* c, const double* pts, long long N, double* gr
 int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double** ref_v, const sbo::ModelConst* mcp = nullptr);       // -> gb_probe: [q][P] each; K1b's own values follow at + 2 q P
 int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail);
 int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl);
+int guard_audit_enqueue(sbo_ctx* c, int first_output);   // behind the posterior launch of a sweep (first_output 1: a lean sweep left the objective's values incomplete)
+void guard_audit_harvest(sbo_ctx* c, bool wait);         // collect a finished audit's counts (wait: block until it has finished)
 }  // namespace sbo
 
 #define SBO_HIP(x)                                                   \

@@ -1763,6 +1763,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   c->lmax_defer = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
+  if (!reuse && !c->rc_active && (rc = guard_audit_enqueue(c, (c->col_active && c->col_lean) ? 1 : 0))) return rc;
   SweepScalars h;
   unsigned long long Lk[kMaxQ];
   const bool colpath = c->col_active;
@@ -2199,6 +2200,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   c->lmax_defer = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
+  if (!reuse && !c->rc_active && (rc = guard_audit_enqueue(c, 0))) return rc;
   const int nb = reduce_blocks(c);
   const bool lanes = lanes_on(c);
   {
@@ -2393,6 +2395,7 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
   c->lmax_defer = false;
   if (!c->k1_stop_attached) SBO_HIP(hipEventRecord(c->ev[1], c->stream));
   c->k1_stop_attached = false;
+  if (!reuse && !c->rc_active && (rc = guard_audit_enqueue(c, 0))) return rc;
   if ((rc = sweep_common_front<T>(c, o))) return rc;
   SweepScalars* sc = (SweepScalars*)c->scal.p;
   const int nb = reduce_blocks(c);

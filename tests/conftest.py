@@ -23,5 +23,16 @@ def engine():
     must fail the run (there is no CPU fallback to fall back to)."""
     import safebo_amd
     eng = safebo_amd.SweepEngine(0)
+    eng.set_option("guard_audit_every", 1)       # (production default: one sweep in 16; the suite audits every sweep it runs)
     yield eng
     eng.close()
+
+
+@pytest.fixture(autouse=True)
+def _guard_band_audit(request):
+    """Behind every GPU test that swept on the shared engine: the standing audit of the guard band (sbo_profile.guard_audit_*,
+    csrc/guard.hip) must not have seen one sampled value outside the band the masks and indices rest on."""
+    yield
+    if "engine" in request.fixturenames:
+        prof = request.getfixturevalue("engine").profile()
+        assert prof["guard_audit_violations"] == 0, (prof["guard_audit_violations"], prof["guard_audit_samples"], prof["guard_audit_worst"])

@@ -2,7 +2,11 @@
 interpolation on 3-D / 4-D grids) deliver mean / var within a measured band of the exact fp64 kernel; the sweeps count the
 decisions the band leaves open (S / U signs, lcb_0 <= u*, arg-reductions, expander / optimistic-set verdicts: models/SafeOpt.py
 :57-66, 85-124, models/GoOSE.py:63-119) and re-evaluate exactly when there are any, so that the masks and indices returned are
-those of the exact posterior -- not "with high probability", but by construction of the band."""
+those of the exact posterior WHENEVER the band holds.  The band is not a theorem: it is the truncation tails the plan can sum
+(Chebyshev coefficients it drops) plus 16 x the largest deviation at 144 probe points plus a rounding floor (csrc/guard.hip,
+DESIGN.md "Guard band").  What backs it: these tests (every value of full-size grids against the exact kernel), and the standing
+audit -- every sweep re-evaluates a rotating sample of candidates with the reference formula on a side stream and counts values
+outside the band (sbo_profile.guard_audit_violations; tests/conftest.py asserts 0 behind every GPU test)."""
 import numpy as np
 import pytest
 
@@ -342,3 +346,43 @@ def test_large_model_with_callers_matrix_takes_the_exact_kernel(engine):
     assert np.max(np.abs(mean[sub] - om) / ys) < tol and np.max(np.abs(var[sub] - ov) / ys ** 2) < tol
     lcb1 = engine.bounds(cfg["b"], 1, "lcb")
     assert np.array_equal(engine.mask("S"), lcb1 >= 0)
+
+
+@pytest.mark.parametrize("log_ell,count", [(-1.0, [512, 512]), (-1.25, [1024, 512]), (-1.5, [1024, 1024])])
+def test_short_length_scales_band_audit(engine, log_ell, count):
+    """The reference's lower bound on the length scales (models/GP_Safe.py:205: log ell in [-1.5, ...]) -- where the Chebyshev
+    degrees are highest and the truncation tails, not the probes, decide: whatever kernel the plan picks (K1i / K1b, or the exact one
+    after a decline), every stored value agrees with the exact kernel within the band, the audit (here: 64 Ki samples per sweep,
+    grid edges included by the sample's stride) counts no violation, and a forced re-evaluation returns the first pass's result."""
+    cfg = synthetic.make_config("B", n=96)
+    ds = synthetic.make_dataset(cfg["X"], cfg["Y"], synthetic.default_hypopt(2, 2, log_ell=log_ell))
+    lo, hi = cfg["bound"][:, 0], cfg["bound"][:, 1]
+    engine.set_option("guard_audit", 65536)
+    try:
+        engine.set_grid(lo, hi, count)
+        engine.set_model(ds, dtype="f64")
+        base = engine.profile()["guard_audit_samples"]
+        kernels = []
+        for sweep in range(3):
+            res = engine.sweep_safeopt(cfg["b"], want_masks=True)
+            kernels.append(engine.profile()["posterior_kernel"])
+        mean, var = engine.posterior()
+        prof = engine.profile()
+        engine.set_option("bilinear", 0)
+        engine.set_model(ds, dtype="f64")
+        ref = engine.sweep_safeopt(cfg["b"], want_masks=True)
+        m0, v0 = engine.posterior()
+        if kernels[-1] in (4, 6):
+            dm, dv = np.array(prof["guard_dm"])[:2], np.array(prof["guard_dv"])[:2]
+            for o in range(2):
+                assert np.max(np.abs(mean[:, o] - m0[:, o])) <= dm[o], (o, kernels)
+                assert np.max(np.abs(var[:, o] - v0[:, o])) <= dv[o], (o, kernels)
+            engine.synchronize()
+            after = engine.profile()
+            assert after["guard_audit_samples"] > base and after["guard_audit_violations"] == 0
+        for k in ("minimizer_index", "expander_index", "count_S", "count_U", "count_M"):
+            assert res[k] == ref[k], (k, kernels)
+        assert abs(res["u_star"] - ref["u_star"]) < 1e-9                  # (a value of the approximating kernel, not a decision)
+    finally:
+        engine.set_option("bilinear", 1)
+        engine.set_option("guard_audit", 1024)

@@ -11,7 +11,10 @@ cfg = synthetic.make_config(name)
 eng = safebo_amd.SweepEngine(0)
 eng.set_model(cfg["ds"], dtype="f64")
 eng.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], list(cfg["count"]))
-for lean in (0, 1, 2, 0, 1, 2):
+audits = [int(a) for a in os.environ.get("AUDIT", "4096").split(",")]
+for audit, lean in [(a, l) for a in audits for l in (0, 1, 2, 0, 1, 2)]:
+    eng.set_option("guard_audit", audit)
+    eng.set_option("guard_audit_every", int(os.environ.get("EVERY", "16")))
     for _ in range(5):
         eng.sweep_safeopt(cfg["b"], lean=lean)
     tot, k1, sp = [], [], []
@@ -21,4 +24,4 @@ for lean in (0, 1, 2, 0, 1, 2):
         p = eng.profile()
         tot.append(p["total_ms"]); k1.append(p["posterior_ms"]); sp.append(p["set_phase_ms"])
     wall = (time.perf_counter() - t0) / 100 * 1e3
-    print(f"{name} lean={lean}: wall {wall:.4f} ms/sweep, device {np.mean(tot):.4f}, K1 {np.mean(k1):.4f}, set phase {np.mean(sp):.4f}, path {p['set_path']}")
+    print(f"{name} audit={audit} ({p['guard_audit_samples']} pairs, {p['guard_audit_violations']} violations, worst {p['guard_audit_worst']:.3g}) lean={lean}: wall {wall:.4f} ms/sweep, device {np.mean(tot):.4f}, K1 {np.mean(k1):.4f}, set phase {np.mean(sp):.4f}, path {p['set_path']}")
