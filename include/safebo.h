@@ -186,6 +186,11 @@ typedef struct sbo_profile {
    * every mask and index rests on: must stay 0 --, and the largest deviation seen in units of the band.                             */
   int64_t guard_audit_samples, guard_audit_violations;
   double guard_audit_worst;
+  /* What the band is made of (r05, K1b / K1i): the ANALYTIC part -- the truncations the plan makes, carried through the posterior formula
+   * (csrc/guard.hip: k_gb_band; csrc/bilinear.hip: k_gb_band_i) -- and the largest deviation seen at the plan's 144 probe points, which
+   * only CHECKS it: guard_dm = analytic + rounding floor, or 1e300 (plan not trusted, every sweep re-evaluates exactly) when
+   * 4 x probe exceeds that.  Zero for the exact kernels and for K1t (whose band is 16 x 2048 probes, measured).                       */
+  double guard_analytic_dm[SBO_MAX_Q], guard_analytic_dv[SBO_MAX_Q], guard_probe_dm[SBO_MAX_Q], guard_probe_dv[SBO_MAX_Q];
 } sbo_profile;
 
 /* ---- library / context ------------------------------------------------------------------- */

@@ -75,6 +75,8 @@ class Profile(C.Structure):
         ("guard_dm", C.c_double * SBO_MAX_Q), ("guard_dv", C.c_double * SBO_MAX_Q), ("guard_rl", C.c_double * SBO_MAX_Q),
         ("guard_ms", C.c_double), ("halo_reruns", C.c_int32), ("set_path", C.c_int32),
         ("guard_audit_samples", C.c_int64), ("guard_audit_violations", C.c_int64), ("guard_audit_worst", C.c_double),
+        ("guard_analytic_dm", C.c_double * SBO_MAX_Q), ("guard_analytic_dv", C.c_double * SBO_MAX_Q),
+        ("guard_probe_dm", C.c_double * SBO_MAX_Q), ("guard_probe_dv", C.c_double * SBO_MAX_Q),
     ]
 
 

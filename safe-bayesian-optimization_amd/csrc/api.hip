@@ -705,20 +705,29 @@ int sbo_profile_get(sbo_ctx* c, sbo_profile* out) {
   out->guard_audit_violations = c->audit_violations;
   out->guard_audit_worst = c->audit_worst;
   // the guard band of the posterior that is resident (K1b measures it on the device: a small read-back, off the hot path)
-  for (int o = 0; o < SBO_MAX_Q; ++o) out->guard_dm[o] = out->guard_dv[o] = out->guard_rl[o] = 0.0;
+  for (int o = 0; o < SBO_MAX_Q; ++o)
+    out->guard_dm[o] = out->guard_dv[o] = out->guard_rl[o] = out->guard_analytic_dm[o] = out->guard_analytic_dv[o] = out->guard_probe_dm[o] = out->guard_probe_dv[o] = 0.0;
   if (c->gb_active && c->guard_band && c->gb.p && c->posterior_valid) {
     if (!c->gb_host_valid) {               // (once per plan: the profile is read after every sweep of a timing loop)
       GuardBand hb;
       SBO_HIP(hipSetDevice(c->device));
       SBO_HIP(hipMemcpyAsync(&hb, c->gb.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
       SBO_HIP(hipStreamSynchronize(c->stream));
-      for (int o = 0; o < SBO_MAX_Q; ++o) { c->gb_host[o] = hb.dm[o]; c->gb_host[SBO_MAX_Q + o] = hb.dv[o]; c->gb_host[2 * SBO_MAX_Q + o] = hb.rl[o]; }
+      for (int o = 0; o < SBO_MAX_Q; ++o) {
+        c->gb_host[o] = hb.dm[o]; c->gb_host[SBO_MAX_Q + o] = hb.dv[o]; c->gb_host[2 * SBO_MAX_Q + o] = hb.rl[o];
+        c->gb_host[3 * SBO_MAX_Q + o] = hb.an_m[o]; c->gb_host[4 * SBO_MAX_Q + o] = hb.an_v[o];
+        c->gb_host[5 * SBO_MAX_Q + o] = hb.pr_m[o]; c->gb_host[6 * SBO_MAX_Q + o] = hb.pr_v[o];
+      }
       c->gb_host_valid = true;
     }
     for (int o = 0; o < c->mc.q; ++o) {
       out->guard_dm[o] = c->gb_host[o];
       out->guard_dv[o] = c->gb_host[SBO_MAX_Q + o];
       out->guard_rl[o] = c->gb_host[2 * SBO_MAX_Q + o];
+      out->guard_analytic_dm[o] = c->gb_host[3 * SBO_MAX_Q + o];
+      out->guard_analytic_dv[o] = c->gb_host[4 * SBO_MAX_Q + o];
+      out->guard_probe_dm[o] = c->gb_host[5 * SBO_MAX_Q + o];
+      out->guard_probe_dv[o] = c->gb_host[6 * SBO_MAX_Q + o];
     }
   }
   return SBO_OK;

@@ -274,7 +274,7 @@ __device__ __forceinline__ double bl_block_sum(double v, double* red) {
 // the pivot loop; res [rc][n] and Q [..][rc] may live in LDS (pointers derived from the dynamic LDS block at the call site)
 template <int NT, typename Stamp>
 __device__ __forceinline__ int basis_pivot_loop(int n, int rc, double* res, double* Q, double* __restrict__ U, double tol2, double* nrm2,
-                                                double* qv, double* cf, double* red, int* redi, bool& too_large, Stamp stamp) {
+                                                double* qv, double* cf, double* red, int* redi, bool& too_large, Stamp stamp, double& res2_out) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rmax = rc < n ? rc : n;
   int r = 0;
@@ -374,6 +374,7 @@ __device__ __forceinline__ int basis_pivot_loop(int n, int rc, double* res, doub
     __syncthreads();                                       // (red / redi / qv are rewritten by the next step)
     stamp();
   }
+  res2_out = bv > 0.0 ? bv : 0.0;          // (the block's largest residual row norm^2 at every way out of the loop)
   return r;
 }
 
@@ -384,7 +385,7 @@ __device__ __forceinline__ int basis_pivot_loop(int n, int rc, double* res, doub
 // stopping rules; sums are grouped differently (per half row), which moves U by a few ulp.
 template <int NT, int RCH>
 __device__ __forceinline__ int basis_pivot_loop_reg(int n, const double* __restrict__ resG, double* Q, double* __restrict__ U, double* qv, double* cf,
-                                                    double* red, int* redi, bool& too_large, double& fro2_out) {
+                                                    double* red, int* redi, bool& too_large, double& fro2_out, double& res2_out) {
   constexpr int rc = 2 * RCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = tid >> 1, half = tid & 1;
@@ -492,6 +493,7 @@ __device__ __forceinline__ int basis_pivot_loop_reg(int n, const double* __restr
     ++r;
     __syncthreads();                                       // (red / redi / qv are rewritten by the next step)
   }
+  res2_out = bv > 0.0 ? bv : 0.0;          // (the block's largest residual row norm^2 at every way out of the loop)
   return r;
 }
 
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(256) void k_bl_degree(const BlJobs jb, const double
 }
 
 __global__ __launch_bounds__(256) void k_bl_coef(const BlJobs jb, const double* __restrict__ Xn, const int* __restrict__ rc_job,
-                                                 double* __restrict__ work, size_t work_stride) {
+                                                 double* __restrict__ work, size_t work_stride, double* __restrict__ axis_eps) {
   __shared__ double ct[4 * kBlMaxRc];
   __shared__ double fs[kBlMaxRc * kCoefRows];                       // samples [k][row of the tile]
   const int job = blockIdx.y, axis = job & 1, tid = threadIdx.x;
@@ -584,6 +586,7 @@ __global__ __launch_bounds__(256) void k_bl_coef(const BlJobs jb, const double* 
     fs[w] = f;
   }
   __syncthreads();
+  double t4 = 0.0;
   for (int w = tid; w < rc * kCoefRows; w += 256) {
     const int p = w / kCoefRows, jl = w % kCoefRows, j = j0 + jl;
     if (j >= n) continue;
@@ -594,8 +597,15 @@ __global__ __launch_bounds__(256) void k_bl_coef(const BlJobs jb, const double* 
       m += 2 * p;
       if (m >= 4 * rc) m -= 4 * rc;
     }
-    res[(size_t)p * n + j] = s_ * ((p == 0 ? 1.0 : 2.0) / rc);
+    const double cv = s_ * ((p == 0 ? 1.0 : 2.0) / rc);
+    res[(size_t)p * n + j] = cv;
+    if (p >= rc - 4) t4 = fmax(t4, fabs(cv));
   }
+  // the largest of the last four coefficients at the degree chosen: what the guard band extrapolates the dropped tail from
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t4 = fmax(t4, __shfl_xor(t4, o));
+  if ((tid & 63) == 0 && t4 > 0.0 && axis_eps)
+    atomicMax(reinterpret_cast<unsigned long long*>(axis_eps + 2 * job), (unsigned long long)__double_as_longlong(t4));
 }
 
 template <int NT, bool LDSRES>
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
                                                  long long* __restrict__ dbg /* nullptr, or 80 time stamps of job 0 */,
                                                  const int* __restrict__ rc_pre /* nullptr, or the degree per job from k_bl_degree
                                                                                     (its coefficient rows are in the workspace) */,
-                                                 int no_reg /* 1: never the register form of the pivot loop (A/B) */) {
+                                                 int no_reg /* 1: never the register form of the pivot loop (A/B) */, double* __restrict__ axis_eps) {
   extern __shared__ double bl_dyn[];          // [kBasisQLds directions | kBasisResLds samples / residual rows (LDSRES)]
   __shared__ double ct[4 * kBlMaxRc];        // cos(pi m / (2 rc)), m < 4 rc
   __shared__ double qv[kBlMaxRc];            // the direction being built
@@ -727,11 +737,12 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
   double* U = Uout + (size_t)job * kBlMaxR * n;
   bool too_large = false;
   int r;
+  double res2 = 0.0;
   if (regpath) {
     double fro2r = 0.0;
-    if (rc == 32) r = basis_pivot_loop_reg<NT, 16>(n, resG, bl_dyn, U, qv, cf, red, redi, too_large, fro2r);
-    else if (rc == 48) r = basis_pivot_loop_reg<NT, 24>(n, resG, bl_dyn, U, qv, cf, red, redi, too_large, fro2r);
-    else if constexpr (NT <= 256) r = basis_pivot_loop_reg<NT, 32>(n, resG, bl_dyn, U, qv, cf, red, redi, too_large, fro2r);
+    if (rc == 32) r = basis_pivot_loop_reg<NT, 16>(n, resG, bl_dyn, U, qv, cf, red, redi, too_large, fro2r, res2);
+    else if (rc == 48) r = basis_pivot_loop_reg<NT, 24>(n, resG, bl_dyn, U, qv, cf, red, redi, too_large, fro2r, res2);
+    else if constexpr (NT <= 256) r = basis_pivot_loop_reg<NT, 32>(n, resG, bl_dyn, U, qv, cf, red, redi, too_large, fro2r, res2);
     else r = 0;
     stamp();
   } else {
@@ -747,9 +758,9 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
   const double tol2 = (2e-16 * 2e-16) * fro2;
   stamp();
   if (rc <= 64)
-    r = basis_pivot_loop<NT>(n, rc, res, bl_dyn, U, tol2, nrm2, qv, cf, red, redi, too_large, stamp);
+    r = basis_pivot_loop<NT>(n, rc, res, bl_dyn, U, tol2, nrm2, qv, cf, red, redi, too_large, stamp, res2);
   else
-    r = basis_pivot_loop<NT>(n, rc, res, QG, U, tol2, nrm2, qv, cf, red, redi, too_large, stamp);
+    r = basis_pivot_loop<NT>(n, rc, res, QG, U, tol2, nrm2, qv, cf, red, redi, too_large, stamp, res2);
   }
   if (too_large || r < 1) {
     if (tid == 0) { inf[0] = 0; inf[1] = r; inf[2] = rc; inf[3] = 0; }
@@ -761,6 +772,8 @@ __global__ __launch_bounds__(NT) void k_bl_basis(const BlJobs jb, const double* 
   for (int w = tid; w < r * rc; w += NT) Vs[w] = Q[w];
   if (tid < r) sigout[(size_t)job * kBlMaxR + tid] = 1.0;
   if (tid == 0) { inf[0] = 1; inf[1] = r; inf[2] = rc; inf[3] = 0; }
+  // what the rank cut leaves of any factor, as a function on the axis: |sum_p R_jp T_p| <= ||R_j||_1 <= sqrt(rc) ||R_j||_2
+  if (tid == 0 && axis_eps) axis_eps[2 * job + 1] = sqrt((double)rc * res2);
   __syncthreads();
   stamp();
   if (dbg && job == 0 && tid == 0) dbg[80] = ndbg;
@@ -1851,20 +1864,26 @@ __global__ __launch_bounds__(1024) void k_cheb_trunc(const BlDims dm, const doub
     run_ab[1] = (b_hi + 15) / 16 * 16;
   }
   __syncthreads();
-  double ts = 0.0;
+  double ts = 0.0, fs = 0.0;
   for (int i = tid; i < D0 * D1; i += 1024) {
     const int b = i / D0, a = i % D0;
     if (a >= run_ab[0] || b >= run_ab[1]) ts += fabs(Ch[i]);
+    if (a >= D0 - 4 || b >= D1 - 4) fs += fabs(Ch[i]);
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) ts += __shfl_xor(ts, off);
+  for (int off = 32; off > 0; off >>= 1) { ts += __shfl_xor(ts, off); fs += __shfl_xor(fs, off); }
   __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = ts;
+  __shared__ double redf[16];
+  if ((tid & 63) == 0) { red[tid >> 6] = ts; redf[tid >> 6] = fs; }
   __syncthreads();
   if (tid == 0) {
-    double s = 0.0;
-    for (int w = 0; w < 16; ++w) s += red[w];
+    double s = 0.0, f = 0.0;
+    for (int w = 0; w < 16; ++w) { s += red[w]; f += redf[w]; }
     reinterpret_cast<double*>(eff + 4 * dm.q)[o] = s;
+    // frame[o] (behind the tails): the sum of |Chat| over the last four degrees of either axis -- for the series of an INTERPOLANT
+    // (K1i: the coefficients beyond the node count are not zero, they alias into these) the figure its band extrapolates the
+    // aliasing error from; K1b's core is the exact product of degree-(rc - 1) polynomials and holds zeros there
+    reinterpret_cast<double*>(eff + 4 * dm.q)[gridDim.x + o] = f;
   }
 }
 // ChatT [D1m][D0m] -> the B fragments of stage 1 (T4f layout: k = axis-1 degree, column = axis-0 degree)
@@ -2165,9 +2184,9 @@ bool bilinear_applicable(const sbo_ctx* c) {
 }
 
 // layout of bl_basis (doubles): U [2q][kBlMaxR][n] | Vs [2q][kBlMaxR][kBlMaxRc] | sig [2q][kBlMaxR] | info (ints, 2q x 4, in
-// 4 q doubles) | work [2q][3 n kBlMaxRc + kBlMaxR kBlMaxRc]
+// 4 q doubles) | rcjob | eps [2q][2] | work [2q][3 n kBlMaxRc + kBlMaxR kBlMaxRc]
 struct BasisLayout {
-  size_t U, Vs, sig, info, rcjob, work, work_stride, total;
+  size_t U, Vs, sig, info, rcjob, eps, work, work_stride, total;
 };
 static BasisLayout basis_layout(int n, int q) {
   BasisLayout L;
@@ -2176,7 +2195,8 @@ static BasisLayout basis_layout(int n, int q) {
   L.sig = L.Vs + (size_t)2 * q * kBlMaxR * kBlMaxRc;
   L.info = L.sig + (size_t)2 * q * kBlMaxR;
   L.rcjob = L.info + (size_t)4 * q;                 // ints, 2 q (in q doubles): the degree k_bl_degree found per job
-  L.work = L.rcjob + (size_t)q;
+  L.eps = L.rcjob + (size_t)q;                      // [2 q][2]: truncation figures of the axis factors for the guard band (GbAnalytic)
+  L.work = L.eps + (size_t)4 * q;
   L.work_stride = (size_t)3 * n * kBlMaxRc + (size_t)kBlMaxR * kBlMaxRc;
   L.total = L.work + (size_t)2 * q * L.work_stride;
   return L;
@@ -2223,23 +2243,23 @@ int bilinear_basis_enqueue(sbo_ctx* c, hipStream_t st, bool force_big) {
     if (phases && hipMalloc(&dbg, sizeof(long long) * 81) != hipSuccess) dbg = nullptr;
     // front end on the whole chip: degree per job, then its coefficient rows into the jobs' workspaces
     int* rcjob = (int*)(base + L.rcjob);
-    SBO_HIP(hipMemsetAsync(rcjob, 0, sizeof(int) * 2 * q, st));
+    SBO_HIP(hipMemsetAsync(rcjob, 0, sizeof(double) * 5 * q, st));          // (the degrees and, behind them, the truncation figures)
     hipLaunchKernelGGL(k_bl_degree, dim3((unsigned)((n + 63) / 64), (unsigned)(2 * q)), dim3(256), 0, st, jb, (const double*)c->Xn.p, rcjob);
     hipLaunchKernelGGL(k_bl_coef, dim3((unsigned)((n + kCoefRows - 1) / kCoefRows), (unsigned)(2 * q)), dim3(256), 0, st, jb,
-                       (const double*)c->Xn.p, (const int*)rcjob, base + L.work, L.work_stride);
+                       (const double*)c->Xn.p, (const int*)rcjob, base + L.work, L.work_stride, base + L.eps);
     for (int rep = 0; rep < (dbg ? 2 : 1); ++rep) {       // (with SBO_BL_TIMING a second run records the phase stamps of job 0)
       long long* dg = rep ? dbg : nullptr;
       if (rep)      // (the pivot loop consumed the rows in place)
         hipLaunchKernelGGL(k_bl_coef, dim3((unsigned)((n + kCoefRows - 1) / kCoefRows), (unsigned)(2 * q)), dim3(256), 0, st, jb,
-                           (const double*)c->Xn.p, (const int*)rcjob, base + L.work, L.work_stride);
+                           (const double*)c->Xn.p, (const int*)rcjob, base + L.work, L.work_stride, base + L.eps);
       if (small) {
         SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL((k_bl_basis<256, true>), dim3((unsigned)(2 * q)), dim3(256), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
-                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, 0);
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, 0, base + L.eps);
       } else {
         SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bl_basis<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL((k_bl_basis<1024, false>), dim3((unsigned)(2 * q)), dim3(1024), dyn, st, jb, (const double*)c->Xn.p, base + L.work,
-                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, 0);
+                           L.work_stride, base + L.U, base + L.Vs, base + L.sig, (int*)(base + L.info), dg, (const int*)rcjob, 0, base + L.eps);
       }
     }
     SBO_HIP(hipGetLastError());
@@ -2475,6 +2495,9 @@ int bilinear_setup(sbo_ctx* c) {
   const bool band = c->guard_band && !c->is_shadow;
   double *gref_m = nullptr, *gref_v = nullptr;
   if (band && (rc = guard_probe_reference(c, zs, &gref_m, &gref_v))) return rc;
+  // (and the exact gradient components there: the scale the analytic band of the Lipschitz keys is taken relative to)
+  double* gref_g = band ? gref_m + (4 * (size_t)q + 2) * kGbProbes : nullptr;
+  if (band && (rc = guard_probe_gradients(c, zs, gref_m + 4 * (size_t)q * kGbProbes, gref_g, nullptr))) return rc;
   if (band && zs != ys) SBO_HIP(hipEventRecord(c->ev_join[6], zs));
   if (ys != xs) SBO_HIP(hipEventRecord(c->ev_join[3], ys));
   if (!direct && (rc = x_head())) return rc;
@@ -2515,7 +2538,18 @@ int bilinear_setup(sbo_ctx* c) {
     const double* Chat = (const double*)c->bl_cheb.p + (size_t)q * (nPC0 + nPC1 + nT4p + nYt);
     hipLaunchKernelGGL(k_gb_probe_k1b, dim3((unsigned)((kGbProbes + 3) / 4), uq), dim3(256), 0, xs, mc, cs, dm, Chat, (const int*)pl.eff,
                        (const double*)dxn0, (const double*)dxn1, (const double*)dS0, (const double*)dVb, pm, pv);
-    if ((rc = guard_band_from_probes(c, pm, pv, gref_m, gref_v, reinterpret_cast<const double*>(pl.eff + 4 * q)))) return rc;
+    GbAnalytic an;
+    memset(&an, 0, sizeof(an));
+    an.axis_eps = bb + basis_layout(n, q).eps;
+    an.alpha = (const double*)c->alpha64.p;
+    an.a_ld = c->a_ld;
+    an.n = n;
+    for (int o = 0; o < q; ++o) { an.rc[o][0] = dm.rc0[o]; an.rc[o][1] = dm.rc1[o]; }
+    an.Xn = (const double*)c->Xn.p;
+    an.dpad = mc.dpad;
+    for (int t = 0; t < 4; ++t) an.ab[t] = c->bl_basis_ab[t];
+    an.ref_g = gref_g;
+    if ((rc = guard_band_from_probes(c, pm, pv, gref_m, gref_v, reinterpret_cast<const double*>(pl.eff + 4 * q), an))) return rc;
     pl.band_ready = true;
   }
   SBO_HIP(hipGetLastError());
@@ -2562,6 +2596,7 @@ int bilinear_setup(sbo_ctx* c) {
 // (variance: the rounding of the reference formula itself) -- and measured again for every plan at the guard band's probe points
 // (values and gradient), so the sweep's decisions stay those of the exact kernel whatever the interpolation error is.
 constexpr int kIMaxDn = 64;
+constexpr double kGbAliasFactor = 4.0;   // aliasing estimate of an interpolant's band, in units of the last four degrees' coefficient sum
 constexpr double kGbInf = 1.0e300;          // a probe that is not finite: everything is "inside the band" (guard.hip)
 struct InterpDims {
   int Dn, q, n, npad, dpad;
@@ -2820,9 +2855,11 @@ __global__ __launch_bounds__(256) void k_gb_probe_series(const CandSpec cs, cons
 // keys: the gradient sums are derivatives of an interpolant).  raw [4 q][P]; ref_g [q][2][P] the exact gradient components.
 __global__ __launch_bounds__(256) void k_gb_band_i(const InterpParams* __restrict__ P_, const double* __restrict__ raw, const double* __restrict__ ref_m,
                                                    const double* __restrict__ ref_v, const double* __restrict__ ref_g,
-                                                   const double* __restrict__ tail /* [4 q] */, GuardBand* gb) {
+                                                   const double* __restrict__ tail /* [4 q] tails | [4 q] frames */, const double* __restrict__ alpha,
+                                                   int a_ld, GuardBand* gb) {
   const ModelConst& mc = P_->mc;
   __shared__ double sh[4][6];
+  __shared__ double sha[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int o = 0; o < mc.q; ++o) {
     const double ys = mc.Y_std[o];
@@ -2847,13 +2884,19 @@ __global__ __launch_bounds__(256) void k_gb_band_i(const InterpParams* __restric
     // (a probe whose deviation is not finite: fmax drops a NaN, so the flag joins the reduction itself -- every thread holds at most
     // one of the 144 probes, and only lane 1's flag used to be published)
     if (bad) e[0] = kGbInf;
+    double a1p = 0.0;                                         // ||alpha_o||_1 (the worst-case rounding of the mean's sum: the check below)
+    for (int j = tid; j < mc.n; j += blockDim.x) a1p += fabs(alpha[(size_t)o * a_ld + j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a1p += __shfl_xor(a1p, off);
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) e[k] = fmax(e[k], __shfl_xor(e[k], off));
     __syncthreads();
-    if (lane == 0)
+    if (lane == 0) {
       for (int k = 0; k < 6; ++k) sh[wave][k] = e[k];
+      sha[wave] = a1p;
+    }
     __syncthreads();
     if (tid == 0) {
       for (int w = 1; w < 4; ++w)
@@ -2861,8 +2904,21 @@ __global__ __launch_bounds__(256) void k_gb_band_i(const InterpParams* __restric
       e[0] = fmax(e[0], sh[0][0]);
       const double eps = 2.220446049250313e-16;
       const bool inf = !(e[0] < kGbInf);
-      gb->dm[o] = inf ? kGbInf : 16.0 * e[0] + tail[4 * o + 1] * ys + 64.0 * eps * fmax(e[2], fabs(mc.Y_mean[o]) + ys);
-      gb->dv[o] = inf ? kGbInf : 16.0 * e[1] + tail[4 * o] * ys * ys + 64.0 * eps * fmax(e[3], mc.sf2[o] * ys * ys);
+      // analytic part (r05): the dropped coefficients of the series that is run (|T_a T_b| <= 1), and the interpolation error of the node
+      // fields -- at most twice the sum of the TRUE coefficients beyond the node count, which is extrapolated from the last four degrees
+      // held (kGbAliasFactor x their sum: twice a geometric continuation at a ratio <= 0.8 per degree; the posterior of an RBF kernel is
+      // entire, its coefficients decay faster than any such ratio once they decay at all)
+      const double* frame = tail + 4 * mc.q;
+      const double an_m = (tail[4 * o + 1] + kGbAliasFactor * frame[4 * o + 1]) * ys;
+      const double an_v = (tail[4 * o] + kGbAliasFactor * frame[4 * o]) * ys * ys;
+      const double fl_m = 64.0 * eps * fmax(e[2], fabs(mc.Y_mean[o]) + ys), fl_v = 64.0 * eps * fmax(e[3], mc.sf2[o] * ys * ys);
+      gb->an_m[o] = an_m; gb->an_v[o] = an_v; gb->pr_m[o] = e[0]; gb->pr_v[o] = e[1];
+      // ... plus the measured rounding level of the plan's sums; the check: a probe deviation that truncation + the worst-case rounding
+      // of the reference formula do not explain (GuardBand, device_common.hpp)
+      const double a1 = (sha[0] + sha[1]) + (sha[2] + sha[3]);
+      const bool distrust = e[0] > an_m + gb_round_mean(mc.n, mc.sf2[o], a1, ys) || e[1] > an_v + gb_round_var(mc.n, mc.sf2[o], mc.sn2[o], ys);
+      gb->dm[o] = (inf || distrust) ? kGbInf : an_m + kGbSafety * e[0] + fl_m;
+      gb->dv[o] = (inf || distrust) ? kGbInf : an_v + kGbSafety * e[1] + fl_v;
       gb->rl[o] = (e[5] > 0.0 && !inf) ? 16.0 * e[4] / e[5] + 1e-9 : 1e-3;
     }
     __syncthreads();
@@ -3073,7 +3129,7 @@ int interp_setup(sbo_ctx* c) {
       hipLaunchKernelGGL(k_gb_probe_series, dim3((unsigned)((kGbProbes + 3) / 4), (unsigned)QP), dim3(256), 0, xs, cs, dP, (const double*)Chat,
                          (const int*)eff, (const double*)dxn0, (const double*)dxn1, raw);
       hipLaunchKernelGGL(k_gb_band_i, dim3(1), dim3(256), 0, xs, dP, (const double*)raw, (const double*)gref_m, (const double*)gref_v,
-                         (const double*)pgrad, reinterpret_cast<const double*>(eff + 4 * QP), (GuardBand*)c->gb.p);
+                         (const double*)pgrad, reinterpret_cast<const double*>(eff + 4 * QP), (const double*)c->alpha64.p, c->a_ld, (GuardBand*)c->gb.p);
     }
     SBO_HIP(hipGetLastError());
     return SBO_OK;

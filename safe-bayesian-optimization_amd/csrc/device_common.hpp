@@ -119,9 +119,25 @@ __device__ __forceinline__ LcbSign lcb_sign(double m, double v, double b, double
 // (SweepScalars::n_guard); a sweep with a non-zero count re-evaluates the candidates concerned with the exact kernel and runs
 // its set phase again (sets_recheck.inc.hpp), so that the masks and indices it returns are those of the exact posterior.
 // The block lives in device memory: K1b computes its band on the device (no host round trip in a model change).
+// r05: the band has two parts.  an_m / an_v: what the plan can BOUND -- the truncations it makes (Chebyshev degree and rank of the
+// axis bases, dropped coefficients of the 2-D series, the aliasing estimate of an interpolant), carried through the posterior formula.
+// kGbSafety x pr_m / pr_v (the largest deviation at the plan's probe points) + a floor: the ROUNDING of this plan's sums, which is
+// measured, because its a-priori bound is useless as a band -- gamma_n sum |alpha_j k_j| for the mean and gamma_2n |k|^T |A| |k| for the
+// variance, 1e-11 and 1e-7 on config H, five orders above what the sums actually lose; the reference's own jnp.dot is only defined
+// to that bound (models/GP_Safe.py:341-343).  That a-priori bound is the CHECK: a probe deviation that truncation bound + worst-case
+// rounding do not explain means the plan errs in a way nothing here describes, and it is not used at all (band = infinite: every
+// sweep on it re-evaluates with the exact kernel).
 struct GuardBand {
   double dm[kMaxQ], dv[kMaxQ], rl[kMaxQ];
+  double an_m[kMaxQ], an_v[kMaxQ], pr_m[kMaxQ], pr_v[kMaxQ];
 };
+constexpr double kGbSafety = 16.0;
+// worst-case rounding of the reference formula's sums in any order (un-normalised units): n eps sum_j |alpha_j k_j| <= n eps sf2 ||alpha||_1
+// and 2 n eps |k|^T |A| |k| <= 2 n eps ||k||_2^2 || |A| ||_2 <= 2 n eps (n sf2^2) (sqrt(n) / sn2)
+__device__ __forceinline__ double gb_round_mean(int n, double sf2, double a1, double ys) { return (double)n * 2.220446049250313e-16 * sf2 * a1 * ys; }
+__device__ __forceinline__ double gb_round_var(int n, double sf2, double sn2, double ys) {
+  return 2.0 * (double)n * 2.220446049250313e-16 * ((double)n * sf2 * sf2) * (sqrt((double)n) / sn2) * ys * ys;
+}
 // K1b's probe points: a kGbProbe1 x kGbProbe1 tensor of the grid positions nearest to the Chebyshev extrema of each axis (ends
 // included -- a polynomial surrogate errs most there); local index of probe p on the resident grid
 constexpr int kGbProbe1 = 12;

@@ -24,7 +24,6 @@ namespace sbo {
 
 constexpr int kRefPer = 16;         // candidates per workgroup of k_ref_list (a matrix element is read once for all of them: the
                                     // kernel is bound by the L2 traffic of re-reading the matrix per group of candidates)
-constexpr double kGbSafety = 16.0;  // band = safety x the largest probe deviation (+ truncation tail + rounding floor)
 constexpr double kInfBand = 1.0e300; // a probe that is not finite: everything is "inside the band"
 
 __device__ __forceinline__ long long block_sum_i64(long long v) {        // valid in thread 0
@@ -240,13 +239,30 @@ __global__ __launch_bounds__(256) void k_grad_list_w(const ModelConst mc_val, co
 // the Chebyshev coefficients of the variance's quadratic form that the kernels do not run (normalised variance units;
 // k_cheb_trunc).  rl: K1b's Lipschitz keys come from the same reduced-basis mean whose values are probed here -- the gradient sums
 // are exact GEMMs on it --; 1e-9 relative is three decades above what the parity tests measure against K1g (1e-12).
+// K1b's band (r05).  Analytic part: K1b replaces the axis factors f_aj(x) = exp(-(x - x_j)^2 / (2 ell_a)) of the kernel vector
+// k_j(x) = sf2 f_0j(x_0) f_1j(x_1) by members of a reduced basis of degree-(rc - 1) Chebyshev series: uniformly on the axis
+//   |f~ - f| <= eps_a = kGbTailFactor t4_a  (Chebyshev cut: the interpolation error is at most twice the dropped tail, which continues
+//                                            the last four coefficients -- t4: their largest -- at a ratio <= 0.8)
+//                     + res_a                (rank cut: sqrt(rc) x the largest residual row norm the pivot loop left, k_bl_basis)
+//                     + 4 rc eps             (evaluating the series),
+// so every k_j moves by at most eta = sf2 (eps_0 + eps_1 + eps_0 eps_1) and, e = k~ - k,
+//   |mean~ - mean| = ys |e . alpha|                    <= ys eta ||alpha||_1
+//   |var~  - var | = ys^2 |2 e . (A k) + e . A e|      <= ys^2 (2 eta sqrt(n) sqrt(sf2 / sn2) + n eta^2 / sn2)
+//   |grad_a~ - grad_a| = ys / (ell_a X_std_a) |sum_j alpha_j (xn_ja - x_a) e_j|  <= ys / (ell_a X_std_a) eta sum_j |alpha_j| (|xn_ja| + max |x_a|)
+//   (the gradient sums are bilinear forms of the same factors, not derivatives of the approximant); relative to the Lipschitz key
+//   through the largest exact component at the probe points, which the key is not smaller than
+// with A = invK: ||A k||_2^2 = k^T A^2 k <= ||A||_2 k^T A k <= sf2 / sn2, because K = sf2 exp(..) + sn2 I has no eigenvalue below
+// sn2 and the exact variance is not negative (models/GP_Safe.py:226-232, 343).  [A caller's matrix that is NOT that inverse is
+// outside this bound -- the probes below are what notices.]  Plus the dropped coefficients of the 2-D core (tail) and a rounding
+// floor, plus the measured rounding level of the plan (kGbSafety x the probes' largest deviation); the check: see GuardBand.
+constexpr double kGbTailFactor = 8.0;
 __global__ __launch_bounds__(256) void k_gb_band(const ModelConst mc, const double* __restrict__ pm, const double* __restrict__ pv,
                                                  const double* __restrict__ ref_m, const double* __restrict__ ref_v,
-                                                 const double* __restrict__ tail, GuardBand* gb) {
-  __shared__ double sh[4][4];
+                                                 const double* __restrict__ tail, const GbAnalytic an, GuardBand* gb) {
+  __shared__ double sh[4][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int o = 0; o < mc.q; ++o) {
-    double em = 0.0, ev = 0.0, am = 0.0, av = 0.0;
+    double em = 0.0, ev = 0.0, am = 0.0, av = 0.0, a1 = 0.0, ax0 = 0.0, ax1 = 0.0, gmax = 0.0;
     bool bad = false;
     for (int p = tid; p < kGbProbes; p += blockDim.x) {
       const double m = pm[(size_t)o * kGbProbes + p], v = pv[(size_t)o * kGbProbes + p];
@@ -258,6 +274,14 @@ __global__ __launch_bounds__(256) void k_gb_band(const ModelConst mc, const doub
       am = fmax(am, fabs(rm));
       av = fmax(av, fabs(rv));
     }
+    if (an.alpha)
+      for (int j = tid; j < an.n; j += blockDim.x) {
+        const double aj = fabs(an.alpha[(size_t)o * an.a_ld + j]);
+        a1 += aj;
+        if (an.Xn) { ax0 += aj * fabs(an.Xn[(size_t)j * an.dpad]); ax1 += aj * fabs(an.Xn[(size_t)j * an.dpad + 1]); }
+      }
+    if (an.ref_g)
+      for (int p = tid; p < 2 * kGbProbes; p += blockDim.x) gmax = fmax(gmax, fabs(an.ref_g[(size_t)o * 2 * kGbProbes + p]));
     if (bad) { em = kInfBand; ev = kInfBand; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -265,17 +289,41 @@ __global__ __launch_bounds__(256) void k_gb_band(const ModelConst mc, const doub
       ev = fmax(ev, __shfl_xor(ev, off));
       am = fmax(am, __shfl_xor(am, off));
       av = fmax(av, __shfl_xor(av, off));
+      a1 += __shfl_xor(a1, off);
+      ax0 += __shfl_xor(ax0, off);
+      ax1 += __shfl_xor(ax1, off);
+      gmax = fmax(gmax, __shfl_xor(gmax, off));
     }
     __syncthreads();
-    if (lane == 0) { sh[wave][0] = em; sh[wave][1] = ev; sh[wave][2] = am; sh[wave][3] = av; }
+    if (lane == 0) { sh[wave][0] = em; sh[wave][1] = ev; sh[wave][2] = am; sh[wave][3] = av; sh[wave][4] = a1; sh[wave][5] = ax0; sh[wave][6] = ax1; sh[wave][7] = gmax; }
     __syncthreads();
     if (tid == 0) {
-      for (int w = 1; w < 4; ++w) { em = fmax(em, sh[w][0]); ev = fmax(ev, sh[w][1]); am = fmax(am, sh[w][2]); av = fmax(av, sh[w][3]); }
-      const double ys = mc.Y_std[o], eps = 2.220446049250313e-16;
-      gb->dm[o] = kGbSafety * em + 64.0 * eps * fmax(am, fabs(mc.Y_mean[o]) + ys);
-      gb->dv[o] = kGbSafety * ev + (tail ? tail[o] : 0.0) * ys * ys + 64.0 * eps * fmax(av, mc.sf2[o] * ys * ys);
-      gb->rl[o] = 1e-9;
+      for (int w = 1; w < 4; ++w) {
+        em = fmax(em, sh[w][0]); ev = fmax(ev, sh[w][1]); am = fmax(am, sh[w][2]); av = fmax(av, sh[w][3]);
+        a1 += sh[w][4]; ax0 += sh[w][5]; ax1 += sh[w][6]; gmax = fmax(gmax, sh[w][7]);
+      }
+      const double ys = mc.Y_std[o], eps = 2.220446049250313e-16, sf2 = mc.sf2[o], sn2 = mc.sn2[o];
+      double an_m = 0.0, an_v = (tail ? tail[o] : 0.0) * ys * ys, an_g = 0.0;
+      if (an.axis_eps) {
+        double ea[2];
+        for (int a = 0; a < 2; ++a)
+          ea[a] = kGbTailFactor * an.axis_eps[2 * (2 * o + a)] + an.axis_eps[2 * (2 * o + a) + 1] + 4.0 * an.rc[o][a] * eps;
+        const double eta = sf2 * (ea[0] + ea[1] + ea[0] * ea[1]);
+        an_m = ys * eta * a1;
+        an_v += ys * ys * (2.0 * eta * sqrt((double)an.n * sf2 / sn2) + (double)an.n * eta * eta / sn2);
+        const double g0 = ys * mc.inv_ell[o][0] * mc.X_rstd[0] * eta * (ax0 + fmax(fabs(an.ab[0]), fabs(an.ab[1])) * a1);
+        const double g1 = ys * mc.inv_ell[o][1] * mc.X_rstd[1] * eta * (ax1 + fmax(fabs(an.ab[2]), fabs(an.ab[3])) * a1);
+        an_g = fmax(g0, g1);
+      }
+      const double fl_m = 64.0 * eps * fmax(am, fabs(mc.Y_mean[o]) + ys), fl_v = 64.0 * eps * fmax(av, sf2 * ys * ys);
+      gb->an_m[o] = an_m; gb->an_v[o] = an_v; gb->pr_m[o] = em; gb->pr_v[o] = ev;
+      const bool inf = !(em < kInfBand) || !(an_m < kInfBand) || !(an_v < kInfBand);
+      const bool distrust = em > an_m + gb_round_mean(an.n, sf2, a1, ys) || ev > an_v + gb_round_var(an.n, sf2, sn2, ys);
+      gb->dm[o] = (inf || distrust) ? kInfBand : an_m + kGbSafety * em + fl_m;
+      gb->dv[o] = (inf || distrust) ? kInfBand : an_v + kGbSafety * ev + fl_v;
+      gb->rl[o] = 1e-9 + (an_g > 0.0 ? (gmax > 0.0 ? an_g / gmax : 1e-3) : 0.0);
     }
+    __syncthreads();
   }
 }
 
@@ -348,7 +396,10 @@ int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double
   for (int o = 0; o < c->mc.q && dm; ++o) { hb.dm[o] = dm[o]; hb.dv[o] = dv[o]; hb.rl[o] = rl[o]; }
   // (pageable source: the runtime stages it before the call returns)
   SBO_HIP(hipMemcpyAsync(c->gb.p, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
-  for (int o = 0; o < SBO_MAX_Q; ++o) { c->gb_host[o] = hb.dm[o]; c->gb_host[SBO_MAX_Q + o] = hb.dv[o]; c->gb_host[2 * SBO_MAX_Q + o] = hb.rl[o]; }
+  for (int o = 0; o < SBO_MAX_Q; ++o) {
+    c->gb_host[o] = hb.dm[o]; c->gb_host[SBO_MAX_Q + o] = hb.dv[o]; c->gb_host[2 * SBO_MAX_Q + o] = hb.rl[o];
+    c->gb_host[3 * SBO_MAX_Q + o] = hb.an_m[o]; c->gb_host[4 * SBO_MAX_Q + o] = hb.an_v[o]; c->gb_host[5 * SBO_MAX_Q + o] = hb.pr_m[o]; c->gb_host[6 * SBO_MAX_Q + o] = hb.pr_v[o];
+  }
   c->gb_host_valid = true;
   return SBO_OK;
 }
@@ -364,7 +415,8 @@ int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double**
   int rc;
   if ((rc = ensure(c->gb, sizeof(GuardBand)))) return rc;
   c->gb_host_valid = false;
-  if ((rc = ensure(c->gb_probe, sizeof(double) * (4 * (size_t)q + 2) * kGbProbes))) return rc;
+  // (ref_m | ref_v | the plan's own values pm | pv | the probe list [P][2] | exact gradient components [q][2][P])
+  if ((rc = ensure(c->gb_probe, sizeof(double) * (6 * (size_t)q + 2) * kGbProbes))) return rc;
   *ref_m = (double*)c->gb_probe.p;
   *ref_v = *ref_m + (size_t)q * kGbProbes;
   if (ref_direct(c)) return launch_ref<2>(c, side, nullptr, kGbProbes, nlines, *ref_m, *ref_v, mcp);
@@ -383,8 +435,8 @@ int guard_probe_gradients(sbo_ctx* c, hipStream_t st, double* ppts, double* grad
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
-int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail) {
-  hipLaunchKernelGGL(k_gb_band, dim3(1), dim3(256), 0, c->stream, c->mc, pm, pv, ref_m, ref_v, tail, (GuardBand*)c->gb.p);
+int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail, const GbAnalytic& an) {
+  hipLaunchKernelGGL(k_gb_band, dim3(1), dim3(256), 0, c->stream, c->mc, pm, pv, ref_m, ref_v, tail, an, (GuardBand*)c->gb.p);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }

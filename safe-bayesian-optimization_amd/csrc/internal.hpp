@@ -200,7 +200,7 @@ struct sbo_ctx {
   long long audit_samples = 0, audit_violations = 0;
   double audit_worst = 0.0;        // largest deviation seen, in units of the band
   bool gb_host_valid = false;      // gb_host mirrors `gb` (read back on demand by sbo_profile_get; dropped when a plan writes the block)
-  double gb_host[3 * SBO_MAX_Q] = {0};
+  double gb_host[7 * SBO_MAX_Q] = {0};   // dm | dv | rl | analytic dm | dv | largest probe deviation dm | dv
   sbo::DevBuf gb_pts, gb_vals;     // re-evaluation: coordinates and exact values of the listed candidates
   sbo::DevBuf gb_part;             // k_ref_list: per-column-chunk partial sums
   sbo::DevBuf gb_probe;            // K1b: probe indices / coordinates / reference values of the running plan
@@ -391,7 +391,18 @@ int launch_posterior_on_list(sbo_ctx* c, const double* pts, long long N, double*
 int guard_exact_list(sbo_ctx* c, const double* pts, long long N, double* mean_out, double* var_out);
 int guard_exact_grad_list(sbo_ctx* c, const double* pts, long long N, double* grad_out /* [q][d][N] */);
 int guard_probe_reference(sbo_ctx* c, hipStream_t side, double** ref_m, double** ref_v, const sbo::ModelConst* mcp = nullptr);       // -> gb_probe: [q][P] each; K1b's own values follow at + 2 q P
-int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail);
+// what K1b's band kernel needs to carry the axis bases' truncation through the posterior formula (guard.hip: k_gb_band)
+struct GbAnalytic {
+  const double* axis_eps;   // [2 q][2]: largest of the last four Chebyshev coefficients of the axis factors | sqrt(rc) x largest residual row norm of the basis
+  const double* alpha;      // [q][a_ld]
+  int a_ld, n;
+  int rc[sbo::kMaxQ][2];         // Chebyshev degree of the axis factors
+  const double* Xn;         // [n][dpad] normalised observations, and the normalised interval of each grid axis (a0, b0, a1, b1)
+  int dpad, pad;
+  double ab[4];
+  const double* ref_g;      // [q][2][P] exact gradient components of the mean at the probe points (a lower bound on the Lipschitz keys)
+};
+int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail, const GbAnalytic& an);
 int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl);
 int guard_audit_enqueue(sbo_ctx* c, int first_output);   // behind the posterior launch of a sweep (first_output 1: a lean sweep left the objective's values incomplete)
 void guard_audit_harvest(sbo_ctx* c, bool wait);         // collect a finished audit's counts (wait: block until it has finished)

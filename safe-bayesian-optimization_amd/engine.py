@@ -285,5 +285,5 @@ class SweepEngine:
     def profile(self) -> dict:
         p = L.Profile()
         L.check(self._lib.sbo_profile_get(self._ctx, C.byref(p)))
-        return {name: (list(getattr(p, name)) if name in ("guard_dm", "guard_dv", "guard_rl") else getattr(p, name))
+        return {name: (list(getattr(p, name)) if name.startswith("guard_") and not name.startswith("guard_audit") and name != "guard_ms" else getattr(p, name))
                 for name, _ in L.Profile._fields_}

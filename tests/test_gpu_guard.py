@@ -374,6 +374,14 @@ def test_short_length_scales_band_audit(engine, log_ell, count):
         m0, v0 = engine.posterior()
         if kernels[-1] in (4, 6):
             dm, dv = np.array(prof["guard_dm"])[:2], np.array(prof["guard_dv"])[:2]
+            # what the band is made of: the truncation bound and the probes' largest deviation (the measured rounding level, x 16 in the
+            # band).  On K1b the bound is the larger part by far -- the probes only check it
+            an_m, an_v = np.array(prof["guard_analytic_dm"])[:2], np.array(prof["guard_analytic_dv"])[:2]
+            pr_m, pr_v = np.array(prof["guard_probe_dm"])[:2], np.array(prof["guard_probe_dv"])[:2]
+            assert np.all(an_m > 0) and np.all(an_v > 0) and np.all(dm >= an_m + 16 * pr_m) and np.all(dv >= an_v + 16 * pr_v)
+            assert np.all(dm < 1e-9) and np.all(dv < 1e-9), (dm, dv)
+            if kernels[-1] == 4:
+                assert np.all(an_m > 16 * pr_m) and np.all(an_v > 16 * pr_v), (an_m, pr_m, an_v, pr_v)
             for o in range(2):
                 assert np.max(np.abs(mean[:, o] - m0[:, o])) <= dm[o], (o, kernels)
                 assert np.max(np.abs(var[:, o] - v0[:, o])) <= dv[o], (o, kernels)
