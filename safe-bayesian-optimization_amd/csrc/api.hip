@@ -127,6 +127,8 @@ int sbo_init(int device_id, sbo_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming);
+    for (auto& ev : c->ev_grad)
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     for (auto& ev : c->ev_col)
       if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     for (auto& ev : c->ev_audit)
@@ -214,6 +216,8 @@ int sbo_shutdown(sbo_ctx* c) {
   for (auto& ev : c->ev_join)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->ev_col)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->ev_grad)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->ev_audit)
     if (ev) (void)hipEventDestroy(ev);
@@ -328,6 +332,11 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     if (value < 1 || value > (1 << 20)) return fail(SBO_E_INVALID, "guard_audit_every: 1 .. 1048576 sweeps");
     c->guard_audit_every = (int)value;
     c->audit_tick = 0;
+    return SBO_OK;
+  }
+  if (!strcmp(key, "grad_defer")) {
+    c->grad_defer = value ? 1 : 0;
+    c->bi.valid = false;
     return SBO_OK;
   }
   if (!strcmp(key, "col_overlap")) {

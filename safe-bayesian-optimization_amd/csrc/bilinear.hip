@@ -1486,7 +1486,8 @@ __device__ unsigned long long g_phase_clk[kPhaseClkRows][8];
 // RB: row blocks per wave.  2 = the 128 x 128 tile above; 1 = a 64 x 128 tile for grids whose 128 x 128 tiles would leave
 // CUs without a workgroup (1024 x 1024 x 3 outputs: 192 tiles on 256 CUs) -- half the reuse of a B fragment, twice the
 // workgroups.
-template <int RB, int ROLE = 0 /* column path: 1 = the constraint's launch (S / U column words), 2 = the objective's (u* over S) */>
+template <int RB, int ROLE = 0 /* column path: 1 = the constraint's launch (S / U column words), 2 = the objective's (u* over S); 3 = the gradient
+                              phases alone (K1i's deferred gate) */>
 __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
                                                   const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
                                                   size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
@@ -1582,6 +1583,22 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
     run3 = !(t1 + slack[2 * o + 1] < G1 * (1.0 - 1e-12));
     const double f0 = fabs(cg0 * t0), f1 = fabs(cg1 * t1);
     gfold = fmax(f0, f1);
+  }
+  if (px.nograd) { run2 = run3 = false; gfold = 0.0; }          // (the keys come from a launch of the gradient phases alone)
+  if constexpr (ROLE == 3) {
+    // K1i's deferred gradient launch: the two gradient series on the tiles the gate names, nothing else -- behind the gate's kernels
+    // on a side stream, beside the posterior launches that no longer wait for them
+    if (run2) post_phase<2, RB, 3>(cx, A2, B2, KBm2, KS2, nullptr, cg0, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
+    if (run3) post_phase<3, RB, 3>(cx, A3, SBo, KBm, KS3, nullptr, cg1, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
+    gmax = fmax(gmax, gfold);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double other = __shfl_xor(gmax, off);
+      gmax = other > gmax ? other : gmax;
+    }
+    post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, false, 0, 0, -1.0, 0, 1e300, Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+                     cpart, pcap, false, px.cb.slots, (int)(ctile & (kColSlots - 1)), o);
+    return;
   }
   // lean sweeps, level 2: the objective's posterior of a tile without a safe candidate is not even evaluated -- u*, M and the
   // arg-max reductions read it on S only (models/SafeOpt.py:47-66); the tile still runs the gradient phases the gate asks for
@@ -3074,6 +3091,9 @@ int interp_setup(sbo_ctx* c) {
     static const bool want_graph = getenv("SBO_PLAN_GRAPH") != nullptr;
     ip.graph_ok = want_graph && ys != xs;
   }
+  // (a captured plan joins all its branches at its end: the deferred gate is for the plain launches only)
+  const bool defer = gate && c->grad_defer && !ip.graph_ok && !(repeat && ip.exec) && zs != xs && zs != ys;
+  ip.grad_deferred = defer;
   auto enqueue = [&]() -> int {
     SBO_HIP(hipMemcpyAsync(c->bi_params.p, c->h_bi_params, sizeof(InterpParams), hipMemcpyHostToDevice, xs));
     if (ys != xs) {
@@ -3107,22 +3127,32 @@ int interp_setup(sbo_ctx* c) {
     // ... and which tiles of k_bpost can hold the largest gradient component (the gate of K1b's gradient phases, fed from the series.
     // A/B r04: without the gate -- 80 us of plan kernels against 45 us of gradient phases on every tile -- the iteration times are the
     // same within the spread)
-    hipLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, xs, dP, (const double*)Chat, slack);
+    // (deferred gate, r05: these kernels are 80 us of small launches whose result only the Lipschitz keys need.  They run on stream3 --
+    // behind the guard reference there, beside the plan's tail and the posterior launches --, followed by a launch of the gradient
+    // phases alone on the tiles they name (launch_posterior_interp); the posterior launches carry none.  The fork rides on this
+    // kernel as its stop event: a record of its own would be a bubble in the chain)
+    if (defer) hipExtLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, xs, nullptr, c->ev_grad[0], 0, dP, (const double*)Chat, slack);
+    else hipLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, xs, dP, (const double*)Chat, slack);
     // Y: the tables of the grid positions (one launch)
     hipLaunchKernelGGL(k_i_tabs, dim3((unsigned)std::min<long long>(((long long)(ncs0 + nrb) * 16 + 255) / 256, 4096)), dim3(256), 0, ys, dP, cs, line0,
                        dxn0, dxn1, (double*)c->bl_P0f.p, (double*)c->bl_P1A.p, S0i);
     if (ys != xs) SBO_HIP(hipEventRecord(c->ev_join[3], ys));
     if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
     // (X again, with the tables of Y: the lines' sums of the gradient series and the sums at the cell centres of every tile)
+    hipStream_t gs = defer ? zs : xs;
+    if (defer) {
+      SBO_HIP(hipStreamWaitEvent(gs, c->ev_grad[0], 0));
+      if (ys != gs) SBO_HIP(hipStreamWaitEvent(gs, c->ev_join[3], 0));
+    }
     if (gate) {
       switch (Dn) {
-        case 32: hipLaunchKernelGGL((k_i_rtab<32>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, xs, dP, (const double*)Chat, (const int*)eff, (const double*)dxn1, Vbi); break;
-        case 48: hipLaunchKernelGGL((k_i_rtab<48>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, xs, dP, (const double*)Chat, (const int*)eff, (const double*)dxn1, Vbi); break;
-        default: hipLaunchKernelGGL((k_i_rtab<64>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, xs, dP, (const double*)Chat, (const int*)eff, (const double*)dxn1, Vbi); break;
+        case 32: hipLaunchKernelGGL((k_i_rtab<32>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, gs, dP, (const double*)Chat, (const int*)eff, (const double*)dxn1, Vbi); break;
+        case 48: hipLaunchKernelGGL((k_i_rtab<48>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, gs, dP, (const double*)Chat, (const int*)eff, (const double*)dxn1, Vbi); break;
+        default: hipLaunchKernelGGL((k_i_rtab<64>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, gs, dP, (const double*)Chat, (const int*)eff, (const double*)dxn1, Vbi); break;
       }
-      hipLaunchKernelGGL(k_bl_gradcoarse, dim3((unsigned)(ntx * nty), uq), dim3(128), 0, xs, dm, (const double*)S0i, (const double*)Vbi,
+      hipLaunchKernelGGL(k_bl_gradcoarse, dim3((unsigned)(ntx * nty), uq), dim3(128), 0, gs, dm, (const double*)S0i, (const double*)Vbi,
                          (const double*)dxn0, (const double*)dxn1, ntx, gt, gkey);
-      hipLaunchKernelGGL(k_bl_gradmax, dim3(2 * uq), dim3(256), 0, xs, (const double*)gt, ntx * nty, gkey);
+      hipLaunchKernelGGL(k_bl_gradmax, dim3(2 * uq), dim3(256), 0, gs, (const double*)gt, ntx * nty, gkey);
     }
     if (band) {
       if (zs != ys) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[6], 0));
@@ -3209,14 +3239,13 @@ int launch_posterior_interp(sbo_ctx* c) {
   const long long cnt0 = cs.count[0], nlines = cs.n_local / cnt0;
   ip.used = true;
   constexpr int S1 = 3;
-  hipLaunchKernelGGL((k_bstage1<S1>), dim3((unsigned)((KB + S1 - 1) / S1), (unsigned)((ip.nrb + 3) / 4), (unsigned)QP), dim3(256), 0, c->stream,
-                     (const double*)c->bl_P1A.p, (size_t)0, (const double*)c->bl_T4f.p, ip.sT4f, KB, ip.nrb, KB, (double*)c->bl_BtA.p, ip.sBtA,
-                     (const int*)ip.eff);
   const unsigned gx = (unsigned)((ip.ncs0 + 7) / 8), gy = (unsigned)((ip.nrb + 3) / 4);
   const unsigned rows_out = gx * gy;
   const size_t lds = sizeof(double) * 2 * 3072 + 2048;
   int rc;
-  if ((rc = ensure(c->bl_lpart, sizeof(double) * (size_t)rows_out * q))) return rc;
+  // (deferred gate: the posterior launches write their -- empty -- Lipschitz rows behind the real ones, which the gradient launch fills)
+  const bool defer = ip.grad_deferred && c->stream3 != nullptr;
+  if ((rc = ensure(c->bl_lpart, sizeof(double) * (size_t)rows_out * q * 2))) return rc;
   const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
   bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local && c->maskU.bytes >= (size_t)cs.n_local;
   const bool colw = fuse && col_words_ok(c, cnt0, nlines);
@@ -3238,10 +3267,36 @@ int launch_posterior_interp(sbo_ctx* c) {
     fuse = false;                      // (no byte masks: the words are the classification)
   }
   const GuardBand* gb_fused = (c->guard_band && ip.band_ready && c->gb.p) ? (const GuardBand*)c->gb.p : nullptr;
+  // stage 1 (behind col_words_prepare: the gradient launch, which follows this kernel on another stream, merges into the slot block)
+  if (defer)
+    hipExtLaunchKernelGGL((k_bstage1<S1>), dim3((unsigned)((KB + S1 - 1) / S1), (unsigned)((ip.nrb + 3) / 4), (unsigned)QP), dim3(256), 0, c->stream, nullptr,
+                          c->ev_grad[1], 0, (const double*)c->bl_P1A.p, (size_t)0, (const double*)c->bl_T4f.p, ip.sT4f, KB, ip.nrb, KB,
+                          (double*)c->bl_BtA.p, ip.sBtA, (const int*)ip.eff);
+  else
+    hipLaunchKernelGGL((k_bstage1<S1>), dim3((unsigned)((KB + S1 - 1) / S1), (unsigned)((ip.nrb + 3) / 4), (unsigned)QP), dim3(256), 0, c->stream,
+                       (const double*)c->bl_P1A.p, (size_t)0, (const double*)c->bl_T4f.p, ip.sT4f, KB, ip.nrb, KB, (double*)c->bl_BtA.p, ip.sBtA,
+                       (const int*)ip.eff);
+  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const double* BtA = (const double*)c->bl_BtA.p;
+  double* const lrows = (double*)c->bl_lpart.p;
+  if (defer) {
+    // the gradient phases alone, behind the gate on stream3 and behind stage 1 (its images): one launch for all outputs
+    hipStream_t gs = c->stream3;
+    SBO_HIP(hipStreamWaitEvent(gs, c->ev_grad[1], 0));
+    PostExtra pg = px;
+    pg.o0 = 0;
+    pg.lean = 0;
+    hipLaunchKernelGGL((k_bpost<1, 3>), dim3(gx, gy, (unsigned)q), dim3(256), lds, gs, mc, cs, BtA, 4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0,
+                       BtA + ip.sBtA, 4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, KB, KB * 4, KB, KB * 4, KB, ip.nrb, ip.ncs0, nlines,
+                       (double*)c->mean.p, (double*)c->var.p, lrows, (const double*)c->bl_small.p, (uint8_t*)nullptr, (uint8_t*)nullptr, c->fuse_b,
+                       (unsigned long long*)c->cpart.p, c->cpart_cap, (const GuardBand*)nullptr, (const int*)ip.eff, ip.gtmax, ip.gkey, 1, pg);
+    SBO_HIP(hipEventRecord(c->ev_grad[2], gs));
+    c->grad_pending = true;
+    px.nograd = 1;
+  }
   // (column path: the constraint's launch first -- the objective's tiles read its words and its counts of safe candidates per tile)
   for (int part = 0; part < (colw ? 2 : 1); ++part) {
     px.o0 = colw ? 1 - part : 0;
@@ -3252,10 +3307,17 @@ int launch_posterior_interp(sbo_ctx* c) {
     hipExtLaunchKernelGGL(kpost, dim3(gx, gy, (unsigned)(colw ? 1 : q)), dim3(256), lds, c->stream, nullptr,
                           (c->lmax_defer && last) ? c->ev[1] : ((colw && part == 0) ? c->ev_col[0] : nullptr), 0, mc, cs, BtA,
                           4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, BtA + ip.sBtA, 4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, KB,
-                          KB * 4, KB, KB * 4, KB, ip.nrb, ip.ncs0, nlines, (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p,
+                          KB * 4, KB, KB * 4, KB, ip.nrb, ip.ncs0, nlines, (double*)c->mean.p, (double*)c->var.p,
+                          defer ? lrows + (size_t)rows_out * q : lrows,
                           (const double*)c->bl_small.p /* xn0 */, fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr,
                           fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b, (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused,
                           (const int*)ip.eff, ip.gtmax, ip.gkey, 1, px);
+  }
+  // (whoever merges the Lipschitz rows on this stream -- the reduction below, a sweep's first small kernel -- waits for the gradient launch;
+  // the column path reads the keys from the slot block on stream3 itself, in stream order behind that launch: sets_colpath.inc.hpp)
+  if (defer && !colw) {
+    SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_grad[2], 0));
+    c->grad_pending = false;
   }
   if (c->lmax_defer) {
     c->lmax_pending = true;

@@ -69,7 +69,7 @@ struct PostExtra {
   int o0;        // first output of this launch (blockIdx.z counts from it)
   int q;         // outputs of the model (layout of the gradient gate's tables)
   int lean;      // 1: an objective tile without a safe candidate does not store its mean / var (nobody reads them)
-  int pad;
+  int nograd;    // 1: the gradient phases (Lipschitz keys) run in a launch of their own (k_bpost<.., 3>, K1i's deferred gate): none here
   ColBits cb;    // Sw == nullptr: no bit words (byte masks or no classification at all)
 };
 
@@ -114,6 +114,8 @@ struct InterpPlan {
   } sig;
   bool sig_valid = false, graph_ok = false;
   void* exec = nullptr;                       // hipGraphExec_t
+  bool grad_deferred = false;                 // the gate's kernels run on stream3 beside the plan's tail: the posterior launches carry no
+                                              // gradient phases, a launch of those alone follows the gate there (launch_posterior_interp)
 };
 using InterpSig = InterpPlan::Sig;
 
@@ -283,6 +285,9 @@ struct sbo_ctx {
   long long col_ckey = 0;                    // the grid the padding of col_cbmin was laid out for
   sbo::DevBuf col_fin;                       // the objective's scalars, the finals' tickets and intermediate rows (4 KB)
   hipEvent_t ev_col[2]{};      // fork (the constraint's posterior launch has finished) / join (the expander chain on stream3 has)
+  hipEvent_t ev_grad[3]{};     // K1i's deferred gradient launch: fork (plan: the series are in place) / stage 1 has run / the keys are merged
+  bool grad_pending = false;   // a deferred gradient launch is in flight on stream3: whoever reads the Lipschitz partials elsewhere waits for ev_grad[2]
+  int grad_defer = 1;          // option: 0 = the gate stays in front of the posterior launch (r04)
   bool col_forked = false;     // the constraint's launch of the running posterior carried ev_col[0]
   bool masks_bits = false;     // the masks of the last sweep live in the column words (byte buffers stale)
   bool col_G_bytes = false;    // ... except G, which the exhaustive recheck finished in byte form

@@ -1063,6 +1063,10 @@ static int col_set_phase(sbo_ctx* c, const sbo_sweep_opts* o, SweepScalars& h, u
 
   // ---- expander chain
   if (overlap) SBO_HIP(hipStreamWaitEvent(es, c->ev_col[0], 0));
+  // (K1i's deferred gradient launch merges the Lipschitz keys into the slot block on stream3: in stream order ahead of this chain when
+  // the chain runs there, an event otherwise)
+  if (c->grad_pending && es != c->stream3) SBO_HIP(hipStreamWaitEvent(es, c->ev_grad[2], 0));
+  c->grad_pending = false;
   ColMergeJob mg;
   mg.slots = cb.slots;
   mg.sc = sc;

@@ -185,3 +185,45 @@ def test_column_path_equals_byte_mask_path_full_size(engine, cfg_name):
     om, ov = oracle.gp_inference(oracle.grid_points(lo, hi, count)[sub], cfg["ds"])
     ys = np.maximum(1.0, cfg["ds"]["Y_std"])
     assert np.max(np.abs(mean[sub] - om) / ys) < 1e-10 and np.max(np.abs(var[sub] - ov) / ys ** 2) < 1e-10
+
+
+@pytest.mark.parametrize("col", [0, 2])
+def test_deferred_gradient_launch_equals_the_gate_in_front(engine, col):
+    """K1i's first sweep of a model (option grad_defer, default 1): the gradient gate's kernels and a launch of the gradient phases alone
+    run beside the posterior launches on stream3 instead of in front of them -- the Lipschitz keys (models/SafeOpt.py:68-83), every
+    count and index, and both outputs' posterior are those of the r04 order, on the byte-mask path and on the column path; GoOSE and
+    trust-region sweeps on such a first posterior read the same keys."""
+    cfg = synthetic.make_config("B", n=96)
+    lo, hi, count = cfg["bound"][:, 0], cfg["bound"][:, 1], [512, 256]
+    out = {}
+    engine.set_option("col_path", col)
+    engine.set_grid(lo, hi, count)
+    try:
+        for defer in (0, 1):
+            engine.set_option("grad_defer", defer)
+            rows = []
+            for kind in ("safeopt", "goose", "tr"):
+                engine.set_model(cfg["ds"], dtype="f64")         # (a new model: K1i again)
+                if kind == "safeopt":
+                    res = engine.sweep_safeopt(cfg["b"], want_masks=True)
+                elif kind == "goose":
+                    res = engine.sweep_goose(cfg["b"])
+                else:
+                    res = engine.sweep_tr(cfg["b"], 0.5 * (lo + hi), 0.3 * float(np.min(hi - lo)))
+                assert engine.profile()["posterior_kernel"] == 6
+                rows.append((res, engine.posterior()))
+            out[defer] = rows
+    finally:
+        engine.set_option("grad_defer", 1)
+        engine.set_option("col_path", 1)
+    for (r0, (m0, v0)), (r1, (m1, v1)) in zip(out[0], out[1]):
+        assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+        for k in r0:
+            a, b = r0[k], r1[k]
+            if k.endswith("_ms"):
+                continue
+            if isinstance(a, np.ndarray) or isinstance(a, (list, tuple)):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), k
+            else:
+                assert a == b or (isinstance(a, float) and np.isnan(a) and np.isnan(b)), (k, a, b)
+    assert np.all(np.asarray(out[1][0][0]["L"]) > 0)

@@ -20,4 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --cpu-sample 0 --no-extra $EXTRA > $OUT/pmc_fetch.log 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --cpu-sample 0 --no-extra $EXTRA > $OUT/pmc_write.log 2>&1 &&
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --cpu-sample 0 --no-extra $EXTRA > $OUT/pmc_sq.log 2>&1
-echo "exit $?"
+rc=$?
+# the waits of the posterior kernel: LDS instructions and the cycles waves wait for them, VALU issue, the store path
+[ $rc = 0 ] && rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq2 -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --cpu-sample 0 --no-extra $EXTRA > $OUT/pmc_sq2.log 2>&1
+echo "exit $rc $?"

@@ -24,7 +24,7 @@ ks = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), ke
 if ks:
     shutil.copy(ks[-1], os.path.join(dst, f"{tag}_kernel_stats.csv"))      # (the newest run of this tag)
 pmc = collections.defaultdict(dict)
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for f in sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
