@@ -1486,8 +1486,7 @@ __device__ unsigned long long g_phase_clk[kPhaseClkRows][8];
 // RB: row blocks per wave.  2 = the 128 x 128 tile above; 1 = a 64 x 128 tile for grids whose 128 x 128 tiles would leave
 // CUs without a workgroup (1024 x 1024 x 3 outputs: 192 tiles on 256 CUs) -- half the reuse of a B fragment, twice the
 // workgroups.
-template <int RB, int ROLE = 0 /* column path: 1 = the constraint's launch (S / U column words), 2 = the objective's (u* over S); 3 = the gradient
-                              phases alone (K1i's deferred gate) */>
+template <int RB, int ROLE = 0 /* column path: 1 = the constraint's launch (S / U column words), 2 = the objective's (u* over S) */>
 __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelConst mc, const CandSpec cs, const double* __restrict__ BtA, size_t sBtA,
                                                   const double* __restrict__ P0f, size_t sP0f, const double* __restrict__ VA,
                                                   size_t sVA, const double* __restrict__ SBf, size_t sSBf, int KB0, int KS0, int KBm,
@@ -1584,22 +1583,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
     const double f0 = fabs(cg0 * t0), f1 = fabs(cg1 * t1);
     gfold = fmax(f0, f1);
   }
-  if (px.nograd) { run2 = run3 = false; gfold = 0.0; }          // (the keys come from a launch of the gradient phases alone)
-  if constexpr (ROLE == 3) {
-    // K1i's deferred gradient launch: the two gradient series on the tiles the gate names, nothing else -- behind the gate's kernels
-    // on a side stream, beside the posterior launches that no longer wait for them
-    if (run2) post_phase<2, RB, 3>(cx, A2, B2, KBm2, KS2, nullptr, cg0, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
-    if (run3) post_phase<3, RB, 3>(cx, A3, SBo, KBm, KS3, nullptr, cg1, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
-    gmax = fmax(gmax, gfold);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double other = __shfl_xor(gmax, off);
-      gmax = other > gmax ? other : gmax;
-    }
-    post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, false, 0, 0, -1.0, 0, 1e300, Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
-                     cpart, pcap, false, px.cb.slots, (int)(ctile & (kColSlots - 1)), o);
-    return;
-  }
+  if (px.nograd) { run2 = run3 = false; gfold = 0.0; }          // (the keys come from a launch of the gradient phases alone: k_bgrad)
   // lean sweeps, level 2: the objective's posterior of a tile without a safe candidate is not even evaluated -- u*, M and the
   // arg-max reductions read it on S only (models/SafeOpt.py:47-66); the tile still runs the gradient phases the gate asks for
   // (L_0 is a maximum over the whole grid), and with K1b's operands the mean phase those continue from
@@ -1675,6 +1659,82 @@ extern "C" int sbo_debug_phase_clocks(unsigned long long* out /* [16]: sums over
 }
 #endif
 
+
+// K1i's deferred gradient launch (r05): the two gradient series of every output on the tiles the gate names, nothing else -- on
+// stream3 behind the gate's kernels, beside the posterior launches, which then carry no gradient phases (PostExtra::nograd).  A
+// resident-sized grid walks the (output, tile) table: a tile the gate excludes costs two loads, and its row of the Lipschitz partials
+// holds its largest coarse sample as before.  Rows [q][tiles] as k_bpost writes them; column path: the workgroup's maximum per output
+// also joins the slot block.
+__global__ __launch_bounds__(256, 3) void k_bgrad(const ModelConst mc, const CandSpec cs, const double* __restrict__ VA, size_t sVA,
+                                                  const double* __restrict__ P0f, int KB, int nrb, int ncs, long long nlines, int gx, int gy,
+                                                  const int* __restrict__ eff, const double* __restrict__ gtmax,
+                                                  const unsigned long long* __restrict__ gkey, const double* __restrict__ xn0, int q,
+                                                  double* __restrict__ Lpart, unsigned long long* __restrict__ slots) {
+  extern __shared__ double lds[];
+  PostCtx cx;
+  cx.lds = lds;
+  cx.tid = threadIdx.x; cx.lane = cx.tid & 63; cx.wave = cx.tid >> 6;
+  cx.nrb = nrb; cx.ncs = ncs;
+  cx.ucnt0 = (unsigned int)cs.count[0];
+  cx.nlines = nlines;
+  cx.imode = true;
+  const int st_i = cx.tid >> 5, st_j = cx.tid & 31;
+  cx.st_off = st_j * 8;
+  cx.a_lo = st_i < 4 ? st_i * 256 + (st_j >> 3) * 64 + (st_j & 7) * 4 : -1;
+  cx.b_st = 1024 + st_i * 256 + cx.st_off;
+  cx.a_rd = (((cx.lane >> 4) << 2) + (cx.lane & 3)) * 2;
+  cx.var_rd = nullptr; cx.S = nullptr; cx.U = nullptr;
+  cx.bconf = 0.0; cx.bb = 0.0; cx.cS = cx.cU = cx.cB = 0; cx.rmax = -1.0;
+  cx.lband = LcbBand{0.0, 0.0}; cx.gb_on = false; cx.vminS = 1e300;
+  cx.role = 0; cx.lds_bits = nullptr; cx.umin = 1e300; cx.xmin = 1e300; cx.skip_store = false;
+#pragma unroll
+  for (int s2 = 0; s2 < 8; ++s2) cx.bw[s2] = 0u;
+  const size_t nt = (size_t)gx * gy;
+  const double* slack = gtmax + (size_t)q * 2 * nt;
+  d4_t acc[1][8];
+  d4_t pre[4];
+  for (int o = 0; o < q; ++o) {
+    const double ystd = mc.Y_std[o];
+    const double cg0 = ystd * mc.inv_ell[o][0] * mc.X_rstd[0], cg1 = ystd * mc.inv_ell[o][1] * mc.X_rstd[1];
+    const double G0 = __longlong_as_double((long long)gkey[2 * o + 0]), G1 = __longlong_as_double((long long)gkey[2 * o + 1]);
+    const double s0 = slack[2 * o + 0], s1 = slack[2 * o + 1];
+    const int KS2 = eff[4 * (4 * o + 2)], KS3 = eff[4 * (4 * o + 3)];
+    const double* VAo = VA + (size_t)o * sVA;
+    const double* A2 = VAo + (size_t)nrb * KB * 256;
+    const double* A3 = VAo + (size_t)nrb * (2 * KB) * 256;
+    double wg_max = 0.0;
+    for (size_t tile = blockIdx.x; tile < nt; tile += gridDim.x) {
+      const double t0 = gtmax[((size_t)o * 2 + 0) * nt + tile], t1 = gtmax[((size_t)o * 2 + 1) * nt + tile];
+      const bool run2 = !(t0 + s0 < G0 * (1.0 - 1e-12)), run3 = !(t1 + s1 < G1 * (1.0 - 1e-12));          // (NaN: run)
+      double g = fmax(fabs(cg0 * t0), fabs(cg1 * t1));
+      if (run2 || run3) {
+        const int bx = (int)(tile % (size_t)gx), by = (int)(tile / (size_t)gx);
+        cx.rb0 = by * 4; cx.cs0 = bx * 8;
+        cx.full = (long long)(cx.rb0 + 4) * 16 <= nlines && (long long)(cx.cs0 + 8) * 16 <= cs.count[0];
+        cx.st_rb = cx.rb0 + st_i < nrb ? cx.rb0 + st_i : nrb - 1;
+        cx.st_cs = cx.cs0 + st_i < ncs ? cx.cs0 + st_i : ncs - 1;
+        double gmax = 0.0;
+        if (run2) post_phase<2, 1, 0>(cx, A2, P0f, KB, KS2, nullptr, cg0, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
+        if (run3) post_phase<3, 1, 0>(cx, A3, P0f, KB, KS3, nullptr, cg1, 0.0, 0.0, gmax, acc, xn0, pre, nullptr, nullptr, 0);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const double other = __shfl_xor(gmax, off);
+          gmax = other > gmax ? other : gmax;
+        }
+        __syncthreads();
+        if (cx.lane == 0) lds[cx.wave] = gmax;
+        __syncthreads();
+        gmax = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+        __syncthreads();
+        g = fmax(g, gmax);
+      }
+      if (cx.tid == 0) Lpart[(size_t)o * nt + tile] = g;
+      wg_max = fmax(wg_max, g);
+    }
+    if (slots && cx.tid == 0)
+      atomicMax(&slots[(size_t)(o == 0 ? kSlotL0 : kSlotL1) * kColSlots + (blockIdx.x & (kColSlots - 1))], (unsigned long long)__double_as_longlong(wg_max));
+  }
+}
 
 // Lipschitz keys of a K1b launch: Lmax[o] = max of the per-wave partials (values >= 0, so the bit pattern orders them)
 __global__ __launch_bounds__(256) void k_lmax_reduce(const double* __restrict__ Lpart, int per_out, unsigned long long* __restrict__ Lmax) {
@@ -3122,28 +3182,27 @@ int interp_setup(sbo_ctx* c) {
       SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_i_dct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_i_dct, dim3(2 * uq), dim3(1024), lds, xs, dP, (const double*)V, Chat);
     }
-    hipLaunchKernelGGL(k_cheb_trunc, dim3((unsigned)QP), dim3(1024), 0, xs, dm, (const double*)Chat, c->cheb_tol, eff);
+    // (deferred tail, r05: the fork of the gate's and the band's side chains rides on this kernel as its stop event -- a record of its own
+    // would be a bubble in the chain)
+    if (defer) hipExtLaunchKernelGGL(k_cheb_trunc, dim3((unsigned)QP), dim3(1024), 0, xs, nullptr, c->ev_grad[0], 0, dm, (const double*)Chat, c->cheb_tol, eff);
+    else hipLaunchKernelGGL(k_cheb_trunc, dim3((unsigned)QP), dim3(1024), 0, xs, dm, (const double*)Chat, c->cheb_tol, eff);
     hipLaunchKernelGGL(k_cheb_t4f, blocks(ip.sT4f, (unsigned)QP), dim3(256), 0, xs, dm, (const double*)Chat, ip.sT4f, (double*)c->bl_T4f.p);
     // ... and which tiles of k_bpost can hold the largest gradient component (the gate of K1b's gradient phases, fed from the series.
     // A/B r04: without the gate -- 80 us of plan kernels against 45 us of gradient phases on every tile -- the iteration times are the
     // same within the spread)
     // (deferred gate, r05: these kernels are 80 us of small launches whose result only the Lipschitz keys need.  They run on stream3 --
     // behind the guard reference there, beside the plan's tail and the posterior launches --, followed by a launch of the gradient
-    // phases alone on the tiles they name (launch_posterior_interp); the posterior launches carry none.  The fork rides on this
-    // kernel as its stop event: a record of its own would be a bubble in the chain)
-    if (defer) hipExtLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, xs, nullptr, c->ev_grad[0], 0, dP, (const double*)Chat, slack);
-    else hipLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, xs, dP, (const double*)Chat, slack);
+    // phases alone on the tiles they name (launch_posterior_interp); the posterior launches carry none)
+    hipStream_t gs = defer ? zs : xs;
+    if (defer) SBO_HIP(hipStreamWaitEvent(gs, c->ev_grad[0], 0));
+    hipLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, gs, dP, (const double*)Chat, slack);
     // Y: the tables of the grid positions (one launch)
     hipLaunchKernelGGL(k_i_tabs, dim3((unsigned)std::min<long long>(((long long)(ncs0 + nrb) * 16 + 255) / 256, 4096)), dim3(256), 0, ys, dP, cs, line0,
                        dxn0, dxn1, (double*)c->bl_P0f.p, (double*)c->bl_P1A.p, S0i);
     if (ys != xs) SBO_HIP(hipEventRecord(c->ev_join[3], ys));
     if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
     // (X again, with the tables of Y: the lines' sums of the gradient series and the sums at the cell centres of every tile)
-    hipStream_t gs = defer ? zs : xs;
-    if (defer) {
-      SBO_HIP(hipStreamWaitEvent(gs, c->ev_grad[0], 0));
-      if (ys != gs) SBO_HIP(hipStreamWaitEvent(gs, c->ev_join[3], 0));
-    }
+    if (defer && ys != gs) SBO_HIP(hipStreamWaitEvent(gs, c->ev_join[3], 0));
     if (gate) {
       switch (Dn) {
         case 32: hipLaunchKernelGGL((k_i_rtab<32>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, gs, dP, (const double*)Chat, (const int*)eff, (const double*)dxn1, Vbi); break;
@@ -3155,11 +3214,16 @@ int interp_setup(sbo_ctx* c) {
       hipLaunchKernelGGL(k_bl_gradmax, dim3(2 * uq), dim3(256), 0, gs, (const double*)gt, ntx * nty, gkey);
     }
     if (band) {
-      if (zs != ys) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[6], 0));
-      hipLaunchKernelGGL(k_gb_probe_series, dim3((unsigned)((kGbProbes + 3) / 4), (unsigned)QP), dim3(256), 0, xs, cs, dP, (const double*)Chat,
+      // (deferred: the plan's own values at the probes and the band from them on Y -- idle since its tables -- beside the series' fragments
+      // and stage 1; the posterior launch, whose classification reads the band, waits for ev_grad[3]: launch_posterior_interp)
+      hipStream_t bs = defer ? ys : xs;
+      if (defer) SBO_HIP(hipStreamWaitEvent(bs, c->ev_grad[0], 0));
+      if (zs != ys) SBO_HIP(hipStreamWaitEvent(bs, c->ev_join[6], 0));
+      hipLaunchKernelGGL(k_gb_probe_series, dim3((unsigned)((kGbProbes + 3) / 4), (unsigned)QP), dim3(256), 0, bs, cs, dP, (const double*)Chat,
                          (const int*)eff, (const double*)dxn0, (const double*)dxn1, raw);
-      hipLaunchKernelGGL(k_gb_band_i, dim3(1), dim3(256), 0, xs, dP, (const double*)raw, (const double*)gref_m, (const double*)gref_v,
+      hipLaunchKernelGGL(k_gb_band_i, dim3(1), dim3(256), 0, bs, dP, (const double*)raw, (const double*)gref_m, (const double*)gref_v,
                          (const double*)pgrad, reinterpret_cast<const double*>(eff + 4 * QP), (const double*)c->alpha64.p, c->a_ld, (GuardBand*)c->gb.p);
+      if (defer) SBO_HIP(hipEventRecord(c->ev_grad[3], bs));
     }
     SBO_HIP(hipGetLastError());
     return SBO_OK;
@@ -3276,7 +3340,7 @@ int launch_posterior_interp(sbo_ctx* c) {
     hipLaunchKernelGGL((k_bstage1<S1>), dim3((unsigned)((KB + S1 - 1) / S1), (unsigned)((ip.nrb + 3) / 4), (unsigned)QP), dim3(256), 0, c->stream,
                        (const double*)c->bl_P1A.p, (size_t)0, (const double*)c->bl_T4f.p, ip.sT4f, KB, ip.nrb, KB, (double*)c->bl_BtA.p, ip.sBtA,
                        (const int*)ip.eff);
-  SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (defer && ip.band_ready) SBO_HIP(hipStreamWaitEvent(c->stream, c->ev_grad[3], 0));     // (the band: written on Y beside stage 1)
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bpost<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3286,13 +3350,10 @@ int launch_posterior_interp(sbo_ctx* c) {
     // the gradient phases alone, behind the gate on stream3 and behind stage 1 (its images): one launch for all outputs
     hipStream_t gs = c->stream3;
     SBO_HIP(hipStreamWaitEvent(gs, c->ev_grad[1], 0));
-    PostExtra pg = px;
-    pg.o0 = 0;
-    pg.lean = 0;
-    hipLaunchKernelGGL((k_bpost<1, 3>), dim3(gx, gy, (unsigned)q), dim3(256), lds, gs, mc, cs, BtA, 4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0,
-                       BtA + ip.sBtA, 4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, KB, KB * 4, KB, KB * 4, KB, ip.nrb, ip.ncs0, nlines,
-                       (double*)c->mean.p, (double*)c->var.p, lrows, (const double*)c->bl_small.p, (uint8_t*)nullptr, (uint8_t*)nullptr, c->fuse_b,
-                       (unsigned long long*)c->cpart.p, c->cpart_cap, (const GuardBand*)nullptr, (const int*)ip.eff, ip.gtmax, ip.gkey, 1, pg);
+    SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_bgrad, dim3((unsigned)std::min<long long>((long long)rows_out, 2ll * c->n_cu)), dim3(256), lds, gs, mc, cs, BtA + ip.sBtA,
+                       4 * ip.sBtA, (const double*)c->bl_P0f.p, KB, ip.nrb, ip.ncs0, nlines, (int)gx, (int)gy, (const int*)ip.eff, ip.gtmax, ip.gkey,
+                       (const double*)c->bl_small.p, q, lrows, colw ? px.cb.slots : (unsigned long long*)nullptr);
     SBO_HIP(hipEventRecord(c->ev_grad[2], gs));
     c->grad_pending = true;
     px.nograd = 1;

@@ -285,7 +285,7 @@ struct sbo_ctx {
   long long col_ckey = 0;                    // the grid the padding of col_cbmin was laid out for
   sbo::DevBuf col_fin;                       // the objective's scalars, the finals' tickets and intermediate rows (4 KB)
   hipEvent_t ev_col[2]{};      // fork (the constraint's posterior launch has finished) / join (the expander chain on stream3 has)
-  hipEvent_t ev_grad[3]{};     // K1i's deferred gradient launch: fork (plan: the series are in place) / stage 1 has run / the keys are merged
+  hipEvent_t ev_grad[4]{};     // K1i's deferred tail: fork (plan: the series are in place) / stage 1 has run / the keys are merged / the band is written
   bool grad_pending = false;   // a deferred gradient launch is in flight on stream3: whoever reads the Lipschitz partials elsewhere waits for ev_grad[2]
   int grad_defer = 1;          // option: 0 = the gate stays in front of the posterior launch (r04)
   bool col_forked = false;     // the constraint's launch of the running posterior carried ev_col[0]
