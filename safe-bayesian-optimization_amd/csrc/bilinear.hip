@@ -3173,6 +3173,8 @@ int interp_setup(sbo_ctx* c) {
     // X: node fields and their coefficients
     hipLaunchKernelGGL(k_i_etab, blocks((size_t)Dn * n, 2 * uq), dim3(256), 0, xs, dP, (const double*)c->As.p, E);
     hipLaunchKernelGGL(k_bl_zf, blocks(nZf, uq), dim3(256), 0, xs, dm, (const double*)E, nZf, Zf);
+    // (A/B r05: nine column strips per wave -- exactly one wave per SIMD on config H instead of 2.25 -- took 120 us against 93: the
+    // fragment loads of a lone wave are not hidden by anything)
     hipLaunchKernelGGL((k_bgemm<4, 0, 1>), dim3((unsigned)((ncsR + 3) / 4), (unsigned)((KBn + 3) / 4), uq), dim3(256), 0, xs,
                        (const double*)c->invk_img.p, (size_t)mc.npad * mc.npad, (const double*)Zf, nZf, KBn, KBn, ncsR, Cf, nZf, CtA, 0ll);
     hipLaunchKernelGGL(k_i_nodevals, dim3((unsigned)ncsR, uq), dim3(64), 0, xs, KBn, n, (const double*)Zf, (const double*)Cf, nZf,
