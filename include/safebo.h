@@ -313,6 +313,9 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  *   "col_path"         1 (auto): one-constraint SafeOpt sweeps of one rank on 2-D grids of whole 64 x 128 posterior tiles -- at least four tiles
  *                      per CU and output -- run their set phase on column words written by the GEMM posterior's epilogue
  *                      (sets_colpath.inc.hpp); 2: on every grid of that shape; 0: the byte-mask pipeline (A/B checker)
+ *   "grad_defer"       first sweep of a model on fp64 2-D grids (K1i): where the Lipschitz keys' gradient phases run.  0: inside the posterior
+ *                      launches, behind the gate's kernels (r04); 1 (default): in a launch of their own on a side stream beside the posterior
+ *                      launches -- behind the gate on large grids, on every tile without a gate on small ones; 2: always without, 3: always with
  *   "col_overlap"      1: on that path the expander chain (distance transform, verdicts) runs on a second stream beside the objective's
  *                      posterior launch; 0: every kernel on the main stream
  *   "set_fuse"         1: 2-D grids of one rank share launches between independent set-phase kernels; 0: one launch per kernel

@@ -335,7 +335,8 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     return SBO_OK;
   }
   if (!strcmp(key, "grad_defer")) {
-    c->grad_defer = value ? 1 : 0;
+    if (value < 0 || value > 3) return fail(SBO_E_INVALID, "grad_defer must be 0 .. 3");
+    c->grad_defer = (int)value;
     c->bi.valid = false;
     return SBO_OK;
   }

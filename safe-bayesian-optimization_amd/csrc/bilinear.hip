@@ -1690,21 +1690,21 @@ __global__ __launch_bounds__(256, 3) void k_bgrad(const ModelConst mc, const Can
 #pragma unroll
   for (int s2 = 0; s2 < 8; ++s2) cx.bw[s2] = 0u;
   const size_t nt = (size_t)gx * gy;
-  const double* slack = gtmax + (size_t)q * 2 * nt;
+  const double* slack = gtmax ? gtmax + (size_t)q * 2 * nt : nullptr;       // (no gate: every tile runs both phases)
   d4_t acc[1][8];
   d4_t pre[4];
   for (int o = 0; o < q; ++o) {
     const double ystd = mc.Y_std[o];
     const double cg0 = ystd * mc.inv_ell[o][0] * mc.X_rstd[0], cg1 = ystd * mc.inv_ell[o][1] * mc.X_rstd[1];
-    const double G0 = __longlong_as_double((long long)gkey[2 * o + 0]), G1 = __longlong_as_double((long long)gkey[2 * o + 1]);
-    const double s0 = slack[2 * o + 0], s1 = slack[2 * o + 1];
+    const double G0 = gtmax ? __longlong_as_double((long long)gkey[2 * o + 0]) : 0.0, G1 = gtmax ? __longlong_as_double((long long)gkey[2 * o + 1]) : 0.0;
+    const double s0 = gtmax ? slack[2 * o + 0] : 0.0, s1 = gtmax ? slack[2 * o + 1] : 0.0;
     const int KS2 = eff[4 * (4 * o + 2)], KS3 = eff[4 * (4 * o + 3)];
     const double* VAo = VA + (size_t)o * sVA;
     const double* A2 = VAo + (size_t)nrb * KB * 256;
     const double* A3 = VAo + (size_t)nrb * (2 * KB) * 256;
     double wg_max = 0.0;
     for (size_t tile = blockIdx.x; tile < nt; tile += gridDim.x) {
-      const double t0 = gtmax[((size_t)o * 2 + 0) * nt + tile], t1 = gtmax[((size_t)o * 2 + 1) * nt + tile];
+      const double t0 = gtmax ? gtmax[((size_t)o * 2 + 0) * nt + tile] : 0.0, t1 = gtmax ? gtmax[((size_t)o * 2 + 1) * nt + tile] : 0.0;
       const bool run2 = !(t0 + s0 < G0 * (1.0 - 1e-12)), run3 = !(t1 + s1 < G1 * (1.0 - 1e-12));          // (NaN: run)
       double g = fmax(fabs(cg0 * t0), fabs(cg1 * t1));
       if (run2 || run3) {
@@ -3154,6 +3154,11 @@ int interp_setup(sbo_ctx* c) {
   // (a captured plan joins all its branches at its end: the deferred gate is for the plain launches only)
   const bool defer = gate && c->grad_defer && !ip.graph_ok && !(repeat && ip.exec) && zs != xs && zs != ys;
   ip.grad_deferred = defer;
+  // (no gate at all -- the deferred launch runs both gradient phases on every tile -- where the grid is small enough for the gate's
+  // three launches to cost more than the phases they save: A/B r05, config B 0.419 -> 0.398 ms per iteration, config H 0.870 -> 0.920.
+  // grad_defer = 2: always; 3: never)
+  const bool nogate = defer && (c->grad_defer == 2 || (c->grad_defer == 1 && (long long)ntx * nty * q <= 4ll * c->n_cu));
+  if (nogate) { ip.gtmax = nullptr; ip.gkey = nullptr; }
   auto enqueue = [&]() -> int {
     SBO_HIP(hipMemcpyAsync(c->bi_params.p, c->h_bi_params, sizeof(InterpParams), hipMemcpyHostToDevice, xs));
     if (ys != xs) {
@@ -3197,7 +3202,7 @@ int interp_setup(sbo_ctx* c) {
     // phases alone on the tiles they name (launch_posterior_interp); the posterior launches carry none)
     hipStream_t gs = defer ? zs : xs;
     if (defer) SBO_HIP(hipStreamWaitEvent(gs, c->ev_grad[0], 0));
-    hipLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, gs, dP, (const double*)Chat, slack);
+    if (!nogate) hipLaunchKernelGGL(k_i_gradslack, dim3(2 * uq), dim3(256), 0, gs, dP, (const double*)Chat, slack);
     // Y: the tables of the grid positions (one launch)
     hipLaunchKernelGGL(k_i_tabs, dim3((unsigned)std::min<long long>(((long long)(ncs0 + nrb) * 16 + 255) / 256, 4096)), dim3(256), 0, ys, dP, cs, line0,
                        dxn0, dxn1, (double*)c->bl_P0f.p, (double*)c->bl_P1A.p, S0i);
@@ -3205,7 +3210,7 @@ int interp_setup(sbo_ctx* c) {
     if (ys != xs) SBO_HIP(hipStreamWaitEvent(xs, c->ev_join[3], 0));
     // (X again, with the tables of Y: the lines' sums of the gradient series and the sums at the cell centres of every tile)
     if (defer && ys != gs) SBO_HIP(hipStreamWaitEvent(gs, c->ev_join[3], 0));
-    if (gate) {
+    if (gate && !nogate) {
       switch (Dn) {
         case 32: hipLaunchKernelGGL((k_i_rtab<32>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, gs, dP, (const double*)Chat, (const int*)eff, (const double*)dxn1, Vbi); break;
         case 48: hipLaunchKernelGGL((k_i_rtab<48>), dim3((unsigned)((nlines + 255) / 256), uq, (unsigned)(Dn / 8)), dim3(256), 0, gs, dP, (const double*)Chat, (const int*)eff, (const double*)dxn1, Vbi); break;

@@ -199,7 +199,7 @@ def test_deferred_gradient_launch_equals_the_gate_in_front(engine, col):
     engine.set_option("col_path", col)
     engine.set_grid(lo, hi, count)
     try:
-        for defer in (0, 1):
+        for defer in (0, 3, 2):                                  # (3: behind the gate; 2: no gate at all, both gradient phases on every tile)
             engine.set_option("grad_defer", defer)
             rows = []
             for kind in ("safeopt", "goose", "tr"):
@@ -216,7 +216,7 @@ def test_deferred_gradient_launch_equals_the_gate_in_front(engine, col):
     finally:
         engine.set_option("grad_defer", 1)
         engine.set_option("col_path", 1)
-    for (r0, (m0, v0)), (r1, (m1, v1)) in zip(out[0], out[1]):
+    for (r0, (m0, v0)), (r1, (m1, v1)) in list(zip(out[0], out[3])) + list(zip(out[0], out[2])):
         assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
         for k in r0:
             a, b = r0[k], r1[k]
@@ -226,4 +226,4 @@ def test_deferred_gradient_launch_equals_the_gate_in_front(engine, col):
                 assert np.array_equal(np.asarray(a), np.asarray(b)), k
             else:
                 assert a == b or (isinstance(a, float) and np.isnan(a) and np.isnan(b)), (k, a, b)
-    assert np.all(np.asarray(out[1][0][0]["L"]) > 0)
+    assert np.all(np.asarray(out[3][0][0]["L"]) > 0)
