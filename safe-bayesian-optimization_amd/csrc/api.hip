@@ -720,9 +720,14 @@ int sbo_profile_get(sbo_ctx* c, sbo_profile* out) {
   if (c->gb_active && c->guard_band && c->gb.p && c->posterior_valid) {
     if (!c->gb_host_valid) {               // (once per plan: the profile is read after every sweep of a timing loop)
       GuardBand hb;
-      SBO_HIP(hipSetDevice(c->device));
-      SBO_HIP(hipMemcpyAsync(&hb, c->gb.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
-      SBO_HIP(hipStreamSynchronize(c->stream));
+      if (c->gb_mirrored) {
+        // (the plan's band kernel wrote a copy into the pinned block; the sweep whose posterior is valid has synchronised since)
+        memcpy(&hb, c->h_back + kGbMirrorOffset, sizeof(hb));
+      } else {
+        SBO_HIP(hipSetDevice(c->device));
+        SBO_HIP(hipMemcpyAsync(&hb, c->gb.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+        SBO_HIP(hipStreamSynchronize(c->stream));
+      }
       for (int o = 0; o < SBO_MAX_Q; ++o) {
         c->gb_host[o] = hb.dm[o]; c->gb_host[SBO_MAX_Q + o] = hb.dv[o]; c->gb_host[2 * SBO_MAX_Q + o] = hb.rl[o];
         c->gb_host[3 * SBO_MAX_Q + o] = hb.an_m[o]; c->gb_host[4 * SBO_MAX_Q + o] = hb.an_v[o];

@@ -2933,7 +2933,7 @@ __global__ __launch_bounds__(256) void k_gb_probe_series(const CandSpec cs, cons
 __global__ __launch_bounds__(256) void k_gb_band_i(const InterpParams* __restrict__ P_, const double* __restrict__ raw, const double* __restrict__ ref_m,
                                                    const double* __restrict__ ref_v, const double* __restrict__ ref_g,
                                                    const double* __restrict__ tail /* [4 q] tails | [4 q] frames */, const double* __restrict__ alpha,
-                                                   int a_ld, GuardBand* gb) {
+                                                   int a_ld, GuardBand* gb, GuardBand* gb_mirror /* pinned host copy (sbo_profile_get) */) {
   const ModelConst& mc = P_->mc;
   __shared__ double sh[4][6];
   __shared__ double sha[4];
@@ -2997,6 +2997,10 @@ __global__ __launch_bounds__(256) void k_gb_band_i(const InterpParams* __restric
       gb->dm[o] = (inf || distrust) ? kGbInf : an_m + kGbSafety * e[0] + fl_m;
       gb->dv[o] = (inf || distrust) ? kGbInf : an_v + kGbSafety * e[1] + fl_v;
       gb->rl[o] = (e[5] > 0.0 && !inf) ? 16.0 * e[4] / e[5] + 1e-9 : 1e-3;
+      if (gb_mirror) {
+        gb_mirror->dm[o] = gb->dm[o]; gb_mirror->dv[o] = gb->dv[o]; gb_mirror->rl[o] = gb->rl[o];
+        gb_mirror->an_m[o] = an_m; gb_mirror->an_v[o] = an_v; gb_mirror->pr_m[o] = e[0]; gb_mirror->pr_v[o] = e[1];
+      }
     }
     __syncthreads();
   }
@@ -3229,7 +3233,9 @@ int interp_setup(sbo_ctx* c) {
       hipLaunchKernelGGL(k_gb_probe_series, dim3((unsigned)((kGbProbes + 3) / 4), (unsigned)QP), dim3(256), 0, bs, cs, dP, (const double*)Chat,
                          (const int*)eff, (const double*)dxn0, (const double*)dxn1, raw);
       hipLaunchKernelGGL(k_gb_band_i, dim3(1), dim3(256), 0, bs, dP, (const double*)raw, (const double*)gref_m, (const double*)gref_v,
-                         (const double*)pgrad, reinterpret_cast<const double*>(eff + 4 * QP), (const double*)c->alpha64.p, c->a_ld, (GuardBand*)c->gb.p);
+                         (const double*)pgrad, reinterpret_cast<const double*>(eff + 4 * QP), (const double*)c->alpha64.p, c->a_ld, (GuardBand*)c->gb.p,
+                         (GuardBand*)(c->h_back + kGbMirrorOffset));
+      c->gb_mirrored = true;
       if (defer) SBO_HIP(hipEventRecord(c->ev_grad[3], bs));
     }
     SBO_HIP(hipGetLastError());

@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void k_grad_list_w(const ModelConst mc_val, co
 constexpr double kGbTailFactor = 8.0;
 __global__ __launch_bounds__(256) void k_gb_band(const ModelConst mc, const double* __restrict__ pm, const double* __restrict__ pv,
                                                  const double* __restrict__ ref_m, const double* __restrict__ ref_v,
-                                                 const double* __restrict__ tail, const GbAnalytic an, GuardBand* gb) {
+                                                 const double* __restrict__ tail, const GbAnalytic an, GuardBand* gb,
+                                                 GuardBand* gb_mirror /* pinned host copy for sbo_profile_get (no read-back per plan) */) {
   __shared__ double sh[4][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int o = 0; o < mc.q; ++o) {
@@ -322,6 +323,10 @@ __global__ __launch_bounds__(256) void k_gb_band(const ModelConst mc, const doub
       gb->dm[o] = (inf || distrust) ? kInfBand : an_m + kGbSafety * em + fl_m;
       gb->dv[o] = (inf || distrust) ? kInfBand : an_v + kGbSafety * ev + fl_v;
       gb->rl[o] = 1e-9 + (an_g > 0.0 ? (gmax > 0.0 ? an_g / gmax : 1e-3) : 0.0);
+      if (gb_mirror) {
+        gb_mirror->dm[o] = gb->dm[o]; gb_mirror->dv[o] = gb->dv[o]; gb_mirror->rl[o] = gb->rl[o];
+        gb_mirror->an_m[o] = an_m; gb_mirror->an_v[o] = an_v; gb_mirror->pr_m[o] = em; gb_mirror->pr_v[o] = ev;
+      }
     }
     __syncthreads();
   }
@@ -391,6 +396,7 @@ int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double
   int rc;
   if ((rc = ensure(c->gb, sizeof(GuardBand)))) return rc;
   c->gb_host_valid = false;
+  c->gb_mirrored = false;
   GuardBand hb;
   memset(&hb, 0, sizeof(hb));
   for (int o = 0; o < c->mc.q && dm; ++o) { hb.dm[o] = dm[o]; hb.dv[o] = dv[o]; hb.rl[o] = rl[o]; }
@@ -436,7 +442,9 @@ int guard_probe_gradients(sbo_ctx* c, hipStream_t st, double* ppts, double* grad
   return SBO_OK;
 }
 int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail, const GbAnalytic& an) {
-  hipLaunchKernelGGL(k_gb_band, dim3(1), dim3(256), 0, c->stream, c->mc, pm, pv, ref_m, ref_v, tail, an, (GuardBand*)c->gb.p);
+  hipLaunchKernelGGL(k_gb_band, dim3(1), dim3(256), 0, c->stream, c->mc, pm, pv, ref_m, ref_v, tail, an, (GuardBand*)c->gb.p,
+                     (GuardBand*)(c->h_back + kGbMirrorOffset));
+  c->gb_mirrored = true;
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }

@@ -14,6 +14,7 @@ namespace sbo {
 constexpr int kGuardRefMaxNpad = 1008;
 constexpr int kMaxD = SBO_MAX_D;
 constexpr int kMaxQ = SBO_MAX_Q;
+constexpr int kGbMirrorOffset = 7680;   // pinned landing block h_back: [0, 4096) end-of-sweep read-back | 4096 plan records | 7168 audit counts | 7680 guard band
 
 // Model constants handed to kernels by value (kernarg segment).  Everything is kept in double; the
 // fp32 kernels round on use.  Rows a1/a4 of SURVEY.md section 8 (models/GP_Safe.py:236-245, 326-347).
@@ -201,6 +202,7 @@ struct sbo_ctx {
   unsigned long long audit_offset = 0;
   long long audit_samples = 0, audit_violations = 0;
   double audit_worst = 0.0;        // largest deviation seen, in units of the band
+  bool gb_mirrored = false;        // the plan's band kernel also wrote the block to pinned host memory (h_back + kGbMirrorOffset): valid once a sweep has synchronised
   bool gb_host_valid = false;      // gb_host mirrors `gb` (read back on demand by sbo_profile_get; dropped when a plan writes the block)
   double gb_host[7 * SBO_MAX_Q] = {0};   // dm | dv | rl | analytic dm | dv | largest probe deviation dm | dv
   sbo::DevBuf gb_pts, gb_vals;     // re-evaluation: coordinates and exact values of the listed candidates

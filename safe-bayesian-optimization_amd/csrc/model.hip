@@ -750,8 +750,12 @@ static int model_build_t(sbo_ctx* c, const double* const* host_invK /* q matrice
       hipLaunchKernelGGL((k_cast_alpha<T>), dim3(16), dim3(256), 0, c->stream, (const double*)dalpha, npad, n, q, npad, (T*)c->alpha.p);
       SBO_HIP(hipGetLastError());
       c->factor_todo = true;
-      SBO_HIP(stream_wait(c, c->stream));
-      if (eager_basis) SBO_HIP(stream_wait(c, c->stream2));
+      // (the bases' records come back with this synchronisation; a K1i-first model has none to wait for -- r05: the host goes straight on
+      // to enqueue the plan while these kernels run, ~30 us of a model change)
+      if (eager_basis) {
+        SBO_HIP(stream_wait(c, c->stream));
+        SBO_HIP(stream_wait(c, c->stream2));
+      }
       return SBO_OK;                      // (the verdict on invK comes with the factor: factor_sync)
     }
   }
