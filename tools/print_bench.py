@@ -3,7 +3,7 @@ import json, sys
 for f in sys.argv[1:]:
     d = json.load(open(f))
     r = d["roofline"]
-    line = f"{f}: value {d['value']:.4e} ms/step {d['ms_per_step']:.4f} K1 {r['kernel_ms']:.4f} device {r['device_ms_per_step']:.4f} set {r['hbm']['set_phase_ms']:.4f} (chain {r['hbm'].get('chain_ms', 0):.4f} exposed {r['hbm'].get('exposed', {}).get('ms', 0):.4f}) frac {r['frac']:.3f} hbm {r['hbm']['frac']:.3f}"
+    line = f"{f}: value {d['value']:.4e} ms/step {d['ms_per_step']:.4f} K1 {r['kernel_ms']:.4f} device {r['device_ms_per_step']:.4f} set {r['hbm']['set_phase_ms']:.4f} (chain {r['hbm'].get('chain_ms', 0):.4f} exposed {r['hbm'].get('exposed', {}).get('set_phase_ms', 0):.4f}) frac {r['frac']:.3f} hbm {r['hbm']['frac']:.3f}"
     if "iteration" in d:
         it = d["iteration"]
         line += f" | iteration {it['ms_per_step']:.3f} ms (set_model {it['set_model_ms']:.3f}, sweep {it['sweep_call_ms']:.3f}) slow {it.get('slow_steps')}"
