@@ -545,8 +545,16 @@ def main():
                 out["cpu_baseline"]["config_B"]["config"] = f"config B: n={bc['n']}, grid {'x'.join(map(str, bc['count']))}"
         # the standing audit of the guard band over everything this process swept (sbo_profile.guard_audit_*, csrc/guard.hip): value
         # pairs re-evaluated with the reference formula on a side stream, how many lay outside the band, the worst in units of the band
+        # (flat copies of what lives in nested records: a reader of the top-level scalars alone can recompute the headline fractions)
+        hb = roof["hbm"]
+        roof["set_phase_ms"] = hb["set_phase_ms"]
+        roof["set_phase_hbm_frac"] = hb["frac"]
+        roof["set_phase_bytes_algorithmic"] = hb["bytes"]
+        roof["set_phase_exposed_ms"] = hb.get("exposed", {}).get("set_phase_ms", hb["set_phase_ms"])
         eng.synchronize()
         pa = eng.profile()
+        out["config"]["guard_audit_samples"] = int(pa["guard_audit_samples"])
+        out["config"]["guard_audit_violations"] = int(pa["guard_audit_violations"])
         out["config"]["guard_audit"] = {"samples": int(pa["guard_audit_samples"]), "violations": int(pa["guard_audit_violations"]),
                                         "worst_over_band": float(pa["guard_audit_worst"])}
         print(json.dumps(out))
