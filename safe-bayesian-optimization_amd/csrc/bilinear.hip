@@ -1122,7 +1122,9 @@ __device__ __forceinline__ void post_partials(double* sh, int lane, int wave, do
                                               `slot` of every field by atomics (internal.hpp: ColSlotField) */, int slot = 0, int o = 0,
                                               int tile_row = -1, int tile_col = 0,
                                               double xmin_ = 1e300 /* column path: the tile's smallest lower bound of ucb_1 (constraint rows,
-                                              field 0) / of lcb_0 (objective rows, field 1) over its safe candidates */) {
+                                              field 0) / of lcb_0 (objective rows, field 1) over its safe candidates */,
+                                              bool multi = false /* several constraints: this row is constraint o's (its plane's populations are
+                                              not |S| / |U|; its variance / radius keys are taken over ITS safe candidates, a superset of S) */) {
   int cS = cS_, cU = cU_, cB = cB_;
   double rm = rmax_, vm = vmin_, xm = xmin_;
   if (fuse || objrow) {
@@ -1192,11 +1194,11 @@ __device__ __forceinline__ void post_partials(double* sh, int lane, int wave, do
       // band, min-variance keys over S (output 1 only), radius keys (constraint 1 only)]
       unsigned long long v = 0ull;
       if (lane == 0) v = (slots && xmn < 1e300) ? ord_key(xmn) : ~0ull;           // (column path: the tile's lower end of ucb_1 over S)
-      else if (lane == 1) v = (unsigned long long)s_;
-      else if (lane == 2) v = (unsigned long long)u_;
+      else if (lane == 1) v = multi ? 0ull : (unsigned long long)s_;
+      else if (lane == 2) v = multi ? 0ull : (unsigned long long)u_;
       else if (lane == 3) v = (unsigned long long)b_;
-      else if (lane >= kFuseVmin && lane < kFuseRmax) v = (lane == kFuseVmin + 1 && vmn < 1e300) ? ord_key(vmn) : ~0ull;
-      else if (lane == kFuseRmax + 1) v = r >= 0.0 ? ord_key(r) : 0ull;       // radius key of constraint 1
+      else if (lane >= kFuseVmin && lane < kFuseRmax) v = (lane == kFuseVmin + (o >= 1 ? o : 1) && vmn < 1e300) ? ord_key(vmn) : ~0ull;
+      else if (lane == kFuseRmax + (o >= 1 ? o : 1)) v = r >= 0.0 ? ord_key(r) : 0ull;       // radius key of this constraint
       crow[(size_t)lane * pcap] = v;
     }
   }
@@ -1530,10 +1532,12 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   const double sf2 = mc.sf2[o], ystd = mc.Y_std[o];
   double* const vo = var_out + (size_t)o * cs.n_local;
   double* const mo = mean_out + (size_t)o * cs.n_local;
-  const bool fuse = Sfuse != nullptr && o == 1;          // (offered by the host for one-constraint models only)
+  // (one constraint: the masks themselves; several, r05: constraint o writes byte plane o - 1, AND-ed by k_classify_and)
+  const bool fuse = Sfuse != nullptr && o >= 1;
+  const bool fmulti = px.fstride != 0;
   cx.var_rd = vo;
-  cx.S = fuse ? Sfuse : nullptr;
-  cx.U = Ufuse;
+  cx.S = fuse ? Sfuse + (size_t)(o - 1) * (size_t)px.fstride : nullptr;
+  cx.U = fuse ? Ufuse + (size_t)(o - 1) * (size_t)px.fstride : Ufuse;
   cx.bconf = bconf;
   cx.bb = bconf * bconf;
   cx.cS = cx.cU = cx.cB = 0;
@@ -1551,7 +1555,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
 #pragma unroll
   for (int s2 = 0; s2 < 8; ++s2) cx.bw[s2] = 0u;
   cx.gb_on = (fuse || cbits) && gb != nullptr;
-  cx.lband = cx.gb_on ? lcb_band(cx.bb, gb->dm[1], gb->dv[1]) : LcbBand{0.0, 0.0};
+  cx.lband = cx.gb_on ? lcb_band(cx.bb, gb->dm[o >= 1 ? o : 1], gb->dv[o >= 1 ? o : 1]) : LcbBand{0.0, 0.0};
   cx.vminS = 1e300;
   double gmax = 0.0;
   // (Tried: odd outputs running the three short phases first and the variance phase last, so that the two workgroups of a
@@ -1620,8 +1624,9 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
   // a row per wave made that merge (one workgroup, 16384 rows of 88 bytes on config H) the longest job of the launch it shares
   // (column path: the constraint's rows first, the objective's rows behind them)
   post_partials<4>(cx.lds, cx.lane, cx.wave, gmax, fuse || cbits, cx.cS, cx.cU, obits ? -cx.umin : cx.rmax, cx.cB, cx.vminS,
-                   Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, cpart + (obits ? ntile : (size_t)0) + ctile, pcap, obits,
-                   (cbits || obits) ? px.cb.slots : nullptr, (int)(ctile & (kColSlots - 1)), o, cbits ? (int)blockIdx.y : -1, (int)blockIdx.x, cx.xmin);
+                   Lpart + ((size_t)o * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+                   cpart + (obits ? ntile : (fmulti && o >= 1 ? (size_t)(o - 1) * ntile : (size_t)0)) + ctile, pcap, obits,
+                   (cbits || obits) ? px.cb.slots : nullptr, (int)(ctile & (kColSlots - 1)), o, cbits ? (int)blockIdx.y : -1, (int)blockIdx.x, cx.xmin, fmulti);
   if (cbits && cx.tid < 128) {
     // the tile's words: column tid, the four waves' 16-row pieces (written before the barriers of post_partials)
     unsigned long long sw = 0ull, uw = 0ull;
@@ -3323,8 +3328,9 @@ int launch_posterior_interp(sbo_ctx* c) {
   // (deferred gate: the posterior launches write their -- empty -- Lipschitz rows behind the real ones, which the gradient launch fills)
   const bool defer = ip.grad_deferred && c->stream3 != nullptr;
   if ((rc = ensure(c->bl_lpart, sizeof(double) * (size_t)rows_out * q * 2))) return rc;
-  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
-  bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local && c->maskU.bytes >= (size_t)cs.n_local;
+  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && ((long long)gx * gy * q >= 4ll * c->n_cu || q > 2));   // (several constraints: the separate pass costs more than one constraint's)
+  bool fuse = fuse_wanted && q >= 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local && c->maskU.bytes >= (size_t)cs.n_local &&
+              (q == 2 || (c->fuseS.bytes >= (size_t)cs.n_local * (q - 1) && c->fuseU.bytes >= (size_t)cs.n_local * (q - 1)));
   const bool colw = fuse && col_words_ok(c, cnt0, nlines);
   PostExtra px;
   memset(&px, 0, sizeof(px));
@@ -3332,7 +3338,8 @@ int launch_posterior_interp(sbo_ctx* c) {
   c->col_active = false;
   c->fuse_rows = 0;
   if (fuse) {
-    c->fuse_rows = (int)rows_out * (colw ? 2 : 1);
+    c->fuse_rows = (int)rows_out * (colw ? 2 : (q - 1));
+    px.fstride = q > 2 ? (long long)cs.n_local : 0ll;
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
     c->cpart_cap = (int)(c->cpart.bytes / (sizeof(unsigned long long) * kFuseRow));
   }
@@ -3383,8 +3390,8 @@ int launch_posterior_interp(sbo_ctx* c) {
                           4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, BtA + ip.sBtA, 4 * ip.sBtA, (const double*)c->bl_P0f.p, (size_t)0, KB,
                           KB * 4, KB, KB * 4, KB, ip.nrb, ip.ncs0, nlines, (double*)c->mean.p, (double*)c->var.p,
                           defer ? lrows + (size_t)rows_out * q : lrows,
-                          (const double*)c->bl_small.p /* xn0 */, fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr,
-                          fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b, (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused,
+                          (const double*)c->bl_small.p /* xn0 */, fuse ? (uint8_t*)(q > 2 ? c->fuseS.p : c->maskS.p) : (uint8_t*)nullptr,
+                          fuse ? (uint8_t*)(q > 2 ? c->fuseU.p : c->maskU.p) : (uint8_t*)nullptr, c->fuse_b, (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused,
                           (const int*)ip.eff, ip.gtmax, ip.gkey, 1, px);
   }
   // (whoever merges the Lipschitz rows on this stream -- the reduction below, a sweep's first small kernel -- waits for the gradient launch;
@@ -3436,9 +3443,10 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   // (one-constraint models; the masks are allocated by the sweep before it enqueues the posterior)
   // (r03: with the sqrt-free sign tests the fused epilogue saves the separate pass 76 us on config H and costs the GEMM 36;
   // on config B, two workgroups per CU, the two cancel -- "auto" asks for at least four workgroups per CU)
-  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && (long long)gx * gy * q >= 4ll * c->n_cu);
-  bool fuse = fuse_wanted && q == 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
-              c->maskU.bytes >= (size_t)cs.n_local;
+  const bool fuse_wanted = c->fuse_request == 1 || (c->fuse_request == 2 && ((long long)gx * gy * q >= 4ll * c->n_cu || q > 2));   // (several constraints: the separate pass costs more than one constraint's)
+  bool fuse = fuse_wanted && q >= 2 && c->maskS.p && c->maskU.p && c->maskS.bytes >= (size_t)cs.n_local &&
+              c->maskU.bytes >= (size_t)cs.n_local &&
+              (q == 2 || (c->fuseS.bytes >= (size_t)cs.n_local * (q - 1) && c->fuseU.bytes >= (size_t)cs.n_local * (q - 1)));
   const bool colw = fuse && col_words_ok(c, cnt0, nlines);
   PostExtra px;
   memset(&px, 0, sizeof(px));
@@ -3446,7 +3454,8 @@ int launch_posterior_bilinear(sbo_ctx* c) {
   c->col_active = false;
   c->fuse_rows = 0;
   if (fuse) {
-    c->fuse_rows = (int)rows_out * (colw ? 2 : 1);
+    c->fuse_rows = (int)rows_out * (colw ? 2 : (q - 1));
+    px.fstride = q > 2 ? (long long)cs.n_local : 0ll;
     // (room behind the rows for the partials of the objective pass, see sweep_common_front)
     if ((rc = ensure(c->cpart, sizeof(unsigned long long) * kFuseRow * ((size_t)c->fuse_rows + 4 * (size_t)c->n_cu + 64)))) return rc;
     c->cpart_cap = (int)(c->cpart.bytes / (sizeof(unsigned long long) * kFuseRow));
@@ -3475,7 +3484,7 @@ int launch_posterior_bilinear(sbo_ctx* c) {
                           mc, cs, (const double*)c->bl_BtA.p, pl.sBtA, (const double*)c->bl_P0f.p, pl.sP0f, (const double*)c->bl_VA.p,
                           pl.sVA, (const double*)c->bl_SBf.p, pl.sSBf, pl.KB0, pl.KS0, pl.KBm, pl.KSm, pl.KBm2, pl.nrb, pl.ncs0, nlines,
                           (double*)c->mean.p, (double*)c->var.p, (double*)c->bl_lpart.p, (const double*)c->bl_small.p /* xn0 */,
-                          fuse ? (uint8_t*)c->maskS.p : (uint8_t*)nullptr, fuse ? (uint8_t*)c->maskU.p : (uint8_t*)nullptr, c->fuse_b,
+                          fuse ? (uint8_t*)(q > 2 ? c->fuseS.p : c->maskS.p) : (uint8_t*)nullptr, fuse ? (uint8_t*)(q > 2 ? c->fuseU.p : c->maskU.p) : (uint8_t*)nullptr, c->fuse_b,
                           (unsigned long long*)c->cpart.p, c->cpart_cap, gb_fused, (const int*)pl.eff, pl.gtmax, pl.gkey, 0, px);
   }
   if (c->lmax_defer) {

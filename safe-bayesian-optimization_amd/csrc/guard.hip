@@ -392,14 +392,17 @@ int guard_exact_grad_list(sbo_ctx* c, const double* pts, long long N, double* gr
 }
 
 // a band the host knows (K1t's probe), or all-zero (nullptr arguments)
-int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl) {
+int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl, const double* parts) {
   int rc;
   if ((rc = ensure(c->gb, sizeof(GuardBand)))) return rc;
   c->gb_host_valid = false;
   c->gb_mirrored = false;
   GuardBand hb;
   memset(&hb, 0, sizeof(hb));
-  for (int o = 0; o < c->mc.q && dm; ++o) { hb.dm[o] = dm[o]; hb.dv[o] = dv[o]; hb.rl[o] = rl[o]; }
+  for (int o = 0; o < c->mc.q && dm; ++o) {
+    hb.dm[o] = dm[o]; hb.dv[o] = dv[o]; hb.rl[o] = rl[o];
+    if (parts) { hb.an_m[o] = parts[o]; hb.an_v[o] = parts[kMaxQ + o]; hb.pr_m[o] = parts[2 * kMaxQ + o]; hb.pr_v[o] = parts[3 * kMaxQ + o]; }
+  }
   // (pageable source: the runtime stages it before the call returns)
   SBO_HIP(hipMemcpyAsync(c->gb.p, &hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
   for (int o = 0; o < SBO_MAX_Q; ++o) {

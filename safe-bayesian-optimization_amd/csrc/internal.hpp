@@ -70,6 +70,7 @@ struct PostExtra {
   int o0;        // first output of this launch (blockIdx.z counts from it)
   int q;         // outputs of the model (layout of the gradient gate's tables)
   int lean;      // 1: an objective tile without a safe candidate does not store its mean / var (nobody reads them)
+  long long fstride; // fused classification of several constraints: stride of the S / U byte planes (constraint o writes plane o - 1; 0: one constraint, the masks themselves)
   int nograd;    // 1: the gradient phases (Lipschitz keys) run in a launch of their own (k_bpost<.., 3>, K1i's deferred gate): none here
   ColBits cb;    // Sw == nullptr: no bit words (byte masks or no classification at all)
 };
@@ -181,7 +182,8 @@ struct sbo_ctx {
   double tn_lo[4] = {0, 0, 0, 0}, tn_hi[4] = {0, 0, 0, 0};
   int tn_level[4] = {0, 0, 0, 0};
   int tn_dn[4] = {0, 0, 0, 0};     // node counts of the plan in use
-  double tn_band[3 * SBO_MAX_Q] = {0};   // the plan's guard band (dm | dv | rl per output), from its probe
+  sbo::DevBuf tn_tail;             // K1t: [2 q][d] keys of the node tensors' coefficient tails per axis (k_t_fiber_tail)
+  double tn_band[7 * SBO_MAX_Q] = {0};   // the plan's guard band (dm | dv | rl | analytic dm | dv | probe dm | dv per output)
   int tn_bump = 0;                 // ladder steps added to the first guess on this grid (a previous model's plan needed its second attempt)
   // Guard band of the approximating posteriors K1b / K1t (device_common.hpp: GuardBand; guard.hip)
   int guard_band = 1;              // option: 1 count + re-evaluate exactly when the count is non-zero; 0 off; 2 re-evaluate on every sweep (test)
@@ -267,6 +269,7 @@ struct sbo_ctx {
   int host_syncs = 0;  // host waits on the device inside the running sweep call (sbo_profile.host_syncs)
   // classification fused into the posterior (K1b, one constraint): a sweep sets fuse_request / fuse_b before it enqueues the
   // posterior; fuse_rows > 0 afterwards = the kernel wrote S / U and that many partial rows at the head of cpart
+  sbo::DevBuf fuseS, fuseU;   // [(q - 1)][N] byte planes of a fused classification of several constraints (r05)
   int fuse_request = 0;    // 0 no, 1 yes, 2 when the GEMM launch is large enough for it to pay (option fuse_classify = -1)
   double fuse_b = 0.0;
   int fuse_rows = 0;
@@ -410,7 +413,7 @@ struct GbAnalytic {
   const double* ref_g;      // [q][2][P] exact gradient components of the mean at the probe points (a lower bound on the Lipschitz keys)
 };
 int guard_band_from_probes(sbo_ctx* c, const double* pm, const double* pv, const double* ref_m, const double* ref_v, const double* tail, const GbAnalytic& an);
-int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl);
+int guard_band_host(sbo_ctx* c, const double* dm, const double* dv, const double* rl, const double* parts = nullptr /* analytic dm | dv | probe dm | dv, kMaxQ each */);
 int guard_audit_enqueue(sbo_ctx* c, int first_output);   // behind the posterior launch of a sweep (first_output 1: a lean sweep left the objective's values incomplete)
 void guard_audit_harvest(sbo_ctx* c, bool wait);         // collect a finished audit's counts (wait: block until it has finished)
 }  // namespace sbo

@@ -506,14 +506,30 @@ __global__ __launch_bounds__(256) void k_classify_final(const unsigned long long
 // Objective pass of a classification whose S / U bytes came out of the posterior kernel (K1b, one constraint): u* = min over
 // S of ucb_0, one partial row per workgroup behind the posterior's rows (mask-driven loop as k_minimizer)
 __device__ __forceinline__ bool tile_byte(unsigned long long w, int k, int lane);
+// (r05) several constraints: the posterior kernel's workgroups wrote one S / U byte plane per constraint (a workgroup sees one output);
+// here the planes are AND-ed into the S / U masks on the way (models/SafeOpt.py:57-59: safe = every constraint's lcb >= 0), and the
+// populations counted
+struct PlaneAnd {
+  const uint8_t* Sp;      // [np][stride] planes, nullptr: S below is the mask itself
+  const uint8_t* Up;
+  long long stride;
+  int np;
+  uint8_t* Uout;
+};
 template <typename T>
 __device__ __forceinline__ unsigned long long ustar_partial_body(int bid, int nwg, const T* __restrict__ mean0, const T* __restrict__ var0,
-                                                                 long long n, T b, const uint8_t* __restrict__ S, double& vmin0) {
+                                                                 long long n, T b, const uint8_t* __restrict__ S, double& vmin0,
+                                                                 const PlaneAnd pa = PlaneAnd{nullptr, nullptr, 0, 0, nullptr}, long long* cS = nullptr,
+                                                                 long long* cU = nullptr) {
   unsigned long long umin = ~0ull;
   vmin0 = kInfD;                                    // smallest var_0 over S seen by this thread (guard band, see k_classify)
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)bid * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)nwg * blockDim.x) >> 6;
-  const long long ntiles = (((uintptr_t)S) & 7) == 0 ? n / 512 : 0;
+  const bool planes = pa.Sp != nullptr;
+  uint8_t* const Sw_ = const_cast<uint8_t*>(S);        // (planes: S is written here)
+  const bool al8 = (((uintptr_t)S) & 7) == 0 && (!planes || (((((uintptr_t)pa.Sp) | ((uintptr_t)pa.Up) | ((uintptr_t)pa.Uout)) & 7) == 0 && (pa.stride & 7) == 0));
+  const long long ntiles = al8 ? n / 512 : 0;
+  long long nS = 0, nU = 0;
   auto take = [&](T m, T v) {
     // (fp64: the exact bound only when the cheap lower bound could beat the running minimum)
     if (std::is_same<T, double>::value && ord_key(ucb_lower((double)m, (double)v, (double)b)) >= umin) return;
@@ -529,7 +545,24 @@ __device__ __forceinline__ unsigned long long ustar_partial_body(int bid, int nw
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long t = t0 + j * nwaves;
-      w4[j] = t < ntiles ? ((const unsigned long long*)(S + t * 512))[lane] : 0ull;
+      if (!planes) {
+        w4[j] = t < ntiles ? ((const unsigned long long*)(S + t * 512))[lane] : 0ull;
+      } else {
+        unsigned long long ws = 0ull, wu = 0ull;
+        if (t < ntiles) {
+          ws = ((const unsigned long long*)(pa.Sp + t * 512))[lane];
+          wu = ((const unsigned long long*)(pa.Up + t * 512))[lane];
+          for (int c = 1; c < pa.np; ++c) {
+            ws &= ((const unsigned long long*)(pa.Sp + (size_t)c * pa.stride + t * 512))[lane];
+            wu &= ((const unsigned long long*)(pa.Up + (size_t)c * pa.stride + t * 512))[lane];
+          }
+          ((unsigned long long*)(Sw_ + t * 512))[lane] = ws;
+          ((unsigned long long*)(pa.Uout + t * 512))[lane] = wu;
+          nS += __popcll(ws);                     // (bytes are 0 / 1)
+          nU += __popcll(wu);
+        }
+        w4[j] = ws;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -551,8 +584,22 @@ __device__ __forceinline__ unsigned long long ustar_partial_body(int bid, int nw
       if (set[k]) { vmin0 = fmin(vmin0, (double)va[k]); take(mu[k], va[k]); }
     }
   }
-  for (long long g = ntiles * 512 + (long long)bid * blockDim.x + threadIdx.x; g < n; g += (long long)nwg * blockDim.x)
-    if (S[g]) { const T v = var0[g]; vmin0 = fmin(vmin0, (double)v); take(mean0[g], v); }
+  for (long long g = ntiles * 512 + (long long)bid * blockDim.x + threadIdx.x; g < n; g += (long long)nwg * blockDim.x) {
+    bool sg;
+    if (planes) {
+      uint8_t ss = 1, uu = 1;
+      for (int c = 0; c < pa.np; ++c) { ss &= pa.Sp[(size_t)c * pa.stride + g]; uu &= pa.Up[(size_t)c * pa.stride + g]; }
+      Sw_[g] = ss;
+      pa.Uout[g] = uu;
+      nS += ss;
+      nU += uu;
+      sg = ss != 0;
+    } else {
+      sg = S[g] != 0;
+    }
+    if (sg) { const T v = var0[g]; vmin0 = fmin(vmin0, (double)v); take(mean0[g], v); }
+  }
+  if (cS) { *cS = nS; *cU = nU; }
   return block_ext_u64<false>(umin);   // valid in thread 0
 }
 template <typename T>
@@ -569,6 +616,26 @@ __global__ __launch_bounds__(256) void k_classify_obj(const T* __restrict__ mean
   if (threadIdx.x < kClassifyRow) {
     const int t = threadIdx.x;
     row[(size_t)t * pcap] = t == 0 ? keys[0] : (t == kRowVmin ? keys[1] : ((t > kRowVmin && t < kRowRmax) ? ~0ull : 0ull));
+  }
+}
+
+// the same behind a posterior launch that wrote one byte plane per constraint (r05): S / U = the planes AND-ed, |S|, |U|, u*
+template <typename T>
+__global__ __launch_bounds__(256) void k_classify_and(const T* __restrict__ mean0, const T* __restrict__ var0, long long n, T b, const PlaneAnd pa,
+                                                      uint8_t* __restrict__ S, unsigned long long* __restrict__ part, int pcap) {
+  double vmin0;
+  long long cS = 0, cU = 0;
+  const unsigned long long umin = ustar_partial_body<T>((int)blockIdx.x, (int)gridDim.x, mean0, var0, n, b, S, vmin0, pa, &cS, &cU);
+  const unsigned long long vk = block_ext_u64<false>(vmin0 < kInfD ? ord_key(vmin0) : ~0ull);
+  cS = block_sum_ll(cS);
+  cU = block_sum_ll(cU);
+  __shared__ unsigned long long keys[4];
+  if (threadIdx.x == 0) { keys[0] = umin; keys[1] = vk; keys[2] = (unsigned long long)cS; keys[3] = (unsigned long long)cU; }
+  __syncthreads();
+  unsigned long long* row = part + blockIdx.x;
+  if (threadIdx.x < kClassifyRow) {
+    const int t = threadIdx.x;
+    row[(size_t)t * pcap] = t == 0 ? keys[0] : (t == 1 ? keys[2] : (t == 2 ? keys[3] : (t == kRowVmin ? keys[1] : ((t > kRowVmin && t < kRowRmax) ? ~0ull : 0ull))));
   }
 }
 
@@ -1021,7 +1088,10 @@ static int sweep_masks(sbo_ctx* c, double b, bool may_fuse) {
   if ((rc = ensure(c->maskG, (size_t)n * std::max(1, q - 1)))) return rc;
   c->masks_bits = false;
   c->col_G_bytes = false;
-  c->fuse_request = (may_fuse && q == 2) ? (c->fuse_classify < 0 ? 2 : c->fuse_classify) : 0;
+  c->fuse_request = (may_fuse && q >= 2) ? (c->fuse_classify < 0 ? 2 : c->fuse_classify) : 0;
+  if (c->fuse_request && q > 2) {            // (one S / U byte plane per constraint: bilinear.hip, k_classify_and)
+    if ((rc = ensure(c->fuseS, (size_t)n * (q - 1))) || (rc = ensure(c->fuseU, (size_t)n * (q - 1)))) return rc;
+  }
   c->lmax_defer = may_fuse;        // (every sweep merges K1b's Lipschitz partials in its k_classify_final)
   c->lmax_pending = false;
   c->fuse_b = b;
@@ -1080,6 +1150,11 @@ static int sweep_common_front(sbo_ctx* c, const sbo_sweep_opts* o, FinalJob* def
     // is left, over the safe candidates
     const int nob = std::max(1, c->n_cu * 4);
     unsigned long long* rows = (unsigned long long*)c->cpart.p;
+    if (q > 2) {
+      const PlaneAnd pa{(const uint8_t*)c->fuseS.p, (const uint8_t*)c->fuseU.p, n, q - 1, (uint8_t*)c->maskU.p};
+      hipLaunchKernelGGL(k_classify_and<T>, dim3((unsigned)nob), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b, pa,
+                         (uint8_t*)c->maskS.p, rows + c->fuse_rows, c->cpart_cap);
+    } else
     hipLaunchKernelGGL(k_classify_obj<T>, dim3((unsigned)nob), dim3(256), 0, c->stream, (const T*)c->mean.p, (const T*)c->var.p, n, (T)o->b,
                        (const uint8_t*)c->maskS.p, rows + c->fuse_rows, c->cpart_cap);
     fj.part = (const unsigned long long*)rows;

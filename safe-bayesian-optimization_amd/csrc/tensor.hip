@@ -49,6 +49,37 @@ __global__ void k_t_axes(const TensorDims td, double* __restrict__ axc) {
   }
 }
 
+// Analytic part of K1t's guard band (r05): how fast the node tensors' Chebyshev coefficients have decayed at the node count of each
+// axis.  A fiber of the node tensor along axis a (nodes of the first kind) has the coefficients c_p = 2 / Dn sum_k v_k cos(pi p (k + 1/2) / Dn);
+// the sum of the last four |c_p|, largest over kTFibers pseudo-random fibers per (quantity, axis), is what the band extrapolates the
+// interpolation error of that axis from (tensor.hip: the plan's band).  A workgroup per (fiber, axis, quantity).
+constexpr int kTFibers = 64;
+__global__ __launch_bounds__(64) void k_t_fiber_tail(const TensorDims td, const double* __restrict__ vals /* [nq][Nn] */, long long Nn,
+                                                    unsigned long long seed, unsigned long long* __restrict__ out /* [nq][d] */) {
+  const int f = blockIdx.x, a = blockIdx.y, Q = blockIdx.z, lane = threadIdx.x, Dn = td.Dn[a];
+  // the fiber's base: a pseudo-random multi-index of the other axes (the first fibers pinned to the corners of the node box)
+  unsigned long long sd = seed ^ (0x9e3779b97f4a7c15ull * (unsigned long long)(1 + f + 131 * a));
+  long long base = 0, mul = 1, stride = 1;
+  for (int b = 0; b < td.d; ++b) {
+    sd = sd * 6364136223846793005ull + 1442695040888963407ull;
+    long long k = (long long)((sd >> 11) % (unsigned long long)td.Dn[b]);
+    if (f < (1 << td.d)) k = ((f >> b) & 1) ? td.Dn[b] - 1 : 0;
+    if (b == a) { stride = mul; k = 0; }
+    base += k * mul;
+    mul *= td.Dn[b];
+  }
+  const double* v = vals + (size_t)Q * Nn + base;
+  double s4 = 0.0;
+  for (int p = Dn - 4 > 0 ? Dn - 4 : 0; p < Dn; ++p) {
+    double acc = 0.0;
+    for (int k = lane; k < Dn; k += 64) acc += v[(size_t)k * stride] * cospi((double)p * ((double)k + 0.5) / (double)Dn);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    s4 += fabs(acc) * (2.0 / Dn);
+  }
+  if (lane == 0 && s4 > 0.0) atomicMax(&out[(size_t)Q * td.d + a], (unsigned long long)__double_as_longlong(s4));
+}
+
 // ranks > 1: the nodes are shared out along the LAST axis -- rank r evaluates node planes [r per, (r + 1) per) (the last
 // ranks repeat plane Dn - 1 where the count does not divide) --: the axes' positions with the last axis cut to that slab ...
 __global__ void k_t_axes_slab(const TensorDims td, const double* __restrict__ axc, int k_first, int per, double* __restrict__ out) {
@@ -631,6 +662,13 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
       for (int a = 0; a < d; ++a) cnt[a] = td.Dn[a];
       if ((rc = launch_posterior_on_axes(c, d, cnt, (const double*)c->tn_pts.p, nmean, nvar, ngrad, (unsigned long long*)c->tn_scr.p))) return rc;
     }
+    // (the coefficient tails of the node tensors of mean and variance along every axis: the analytic part of the plan's band, below)
+    if (!same_grid) {
+      if ((rc = ensure(c->tn_tail, sizeof(unsigned long long) * 2 * kMaxQ * kTMaxD))) return rc;
+      SBO_HIP(hipMemsetAsync(c->tn_tail.p, 0, sizeof(unsigned long long) * 2 * kMaxQ * kTMaxD, c->stream));
+      hipLaunchKernelGGL(k_t_fiber_tail, dim3(kTFibers, (unsigned)d, (unsigned)(2 * q)), dim3(64), 0, c->stream, td, (const double*)nmean, Nn,
+                         0x9e3779b97f4a7c15ull ^ (unsigned long long)c->model_serial, (unsigned long long*)c->tn_tail.p);
+    }
     // interpolation: mean, variance (clipped at zero), gradient components -> Lipschitz keys max_a max_x |d MEAN_o / d x_a|
     c->tn_flops = 0.0;
     const double* cur = nullptr;
@@ -678,7 +716,9 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
                          2 * q, nqg, ping);
       SBO_HIP(hipMemcpyAsync(pkeys, c->Lmax.p, sizeof(double) * kMaxQ, hipMemcpyDeviceToDevice, c->stream));
       std::vector<double> h((size_t)(4 * q + 2 * nqg) * kTProbes + kMaxQ);
+      double tails[2 * kMaxQ * kTMaxD];
       SBO_HIP(hipMemcpyAsync(h.data(), pexm, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+      SBO_HIP(hipMemcpyAsync(tails, c->tn_tail.p, sizeof(tails), hipMemcpyDeviceToHost, c->stream));
       SBO_HIP(hipStreamSynchronize(c->stream));
       // deviations per output (un-normalised: the band's units) and the probe error in normalised units (the plan's gate);
       // a value that is not finite fails the gate (NaN compares false)
@@ -717,14 +757,35 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
         SBO_HIP(hipMemcpyAsync(&ok_all, dkey, 8, hipMemcpyDeviceToHost, c->stream));
         SBO_HIP(hipStreamSynchronize(c->stream));
       }
-      // the plan's guard band (guard.hip): 16 x the largest probe deviation + a rounding floor; the Lipschitz keys' relative band
-      // from the gradient components' deviation
-      const double eps = 2.220446049250313e-16, safety = 16.0;
+      // the plan's guard band (guard.hip).  Analytic ESTIMATE (r05): interpolating axis by axis, the error is at most
+      // sum_a (prod_{b != a} Lambda_b) E_a with Lambda_b <= 2 / pi ln Dn_b + 1 the Lebesgue constant of Chebyshev nodes of the first kind and
+      // E_a the interpolation error along axis a -- at most twice the coefficients beyond Dn_a, extrapolated as kAlias x the sum of the
+      // last four coefficients held, largest over 64 sampled fibers of the node tensor (an estimate: sampled fibers, extrapolated tail).
+      // Measured part: 16 x the largest probe deviation (the rounding of the interpolation sums) + a floor; the Lipschitz keys'
+      // relative band from the gradient components' deviation.  The probes gate the plan as before (2e-11).
+      const double eps = 2.220446049250313e-16, safety = 16.0, kAlias = 4.0;
       for (int o = 0; o < q; ++o) {
         const double Lo = h[(size_t)(4 * q + 2 * nqg) * kTProbes + o];
+        double an[2] = {0.0, 0.0};
+        for (int w = 0; w < 2; ++w)
+          for (int a = 0; a < d; ++a) {
+            double lam = 1.0;
+            for (int b = 0; b < d; ++b)
+              if (b != a) lam *= 2.0 / 3.141592653589793 * std::log((double)td.Dn[b]) + 1.0;
+            double t4;
+            memcpy(&t4, &tails[((size_t)(w * q + o)) * d + a], 8);
+            an[w] += lam * kAlias * t4;
+          }
+        // (REPORTED, not added: with the Lebesgue products of a tensor interpolant the estimate is ~1e3 x the deviations seen at the 2048
+        // probes and on whole-grid comparisons with K1g -- 7e-9 against 1e-12 in the variance of a 64^3 grid --, and as a band it would send
+        // about a fifth of config D's sweeps into a second pass of their 5.7 ms set phase.  K1t's band stays MEASURED: sbo_profile shows both)
         c->tn_band[o] = safety * em[o] + 64.0 * eps * std::max(am[o], std::fabs(mc.Y_mean[o]) + mc.Y_std[o]);
         c->tn_band[kMaxQ + o] = safety * ev[o] + 64.0 * eps * std::max(av[o], mc.sf2[o] * mc.Y_std[o] * mc.Y_std[o]);
         c->tn_band[2 * kMaxQ + o] = (Lo > 0.0 ? safety * eg[o] / Lo : 0.0) + 1e-13;
+        c->tn_band[3 * kMaxQ + o] = an[0];
+        c->tn_band[4 * kMaxQ + o] = an[1];
+        c->tn_band[5 * kMaxQ + o] = em[o];
+        c->tn_band[6 * kMaxQ + o] = ev[o];
       }
       c->tn_valid = true;
       c->tn_model = c->model_serial;
@@ -744,7 +805,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
     *declined = false;
     c->last_k1 = 5;
     if (c->guard_band) {
-      if ((rc = guard_band_host(c, c->tn_band, c->tn_band + kMaxQ, c->tn_band + 2 * kMaxQ))) return rc;   // (192 bytes: whoever used the block last)
+      if ((rc = guard_band_host(c, c->tn_band, c->tn_band + kMaxQ, c->tn_band + 2 * kMaxQ, c->tn_band + 3 * kMaxQ))) return rc;   // (whoever used the block last)
       c->gb_active = true;
     }
     // flops issued: node posterior (block-triangular contraction) + interpolation sums
