@@ -238,9 +238,10 @@ def timed_resident(eng, step, steps, warmup, barrier):
     t0 = time.perf_counter()
     for _ in range(steps):
         res = step()
-        rows.append(eng.profile())
+        rows.append(eng.profile_struct())         # (the HIP-event times of this sweep: read here, turned into dicts behind the timed region)
     barrier()
-    return time.perf_counter() - t0, rows, res
+    el = time.perf_counter() - t0
+    return el, [eng.profile_dict(p) for p in rows], res
 
 
 def timed_iterations(eng, models, dtype, step, steps, warmup, barrier):
@@ -259,13 +260,13 @@ def timed_iterations(eng, models, dtype, step, steps, warmup, barrier):
         tb = time.perf_counter()
         step()
         tc = time.perf_counter()
-        p = eng.profile()
+        p = eng.profile_struct()
         t_set.append(tb - ta)
         t_sweep.append(tc - tb)
-        builds.append(p["posterior_setup_ms"])
-        dev.append(p["total_ms"])
-        k1.append(p["posterior_ms"])
-        kinds.add(K1_NAMES.get(p["posterior_kernel"], "?"))
+        builds.append(p.posterior_setup_ms)
+        dev.append(p.total_ms)
+        k1.append(p.posterior_ms)
+        kinds.add(K1_NAMES.get(p.posterior_kernel, "?"))
     barrier()
     el = time.perf_counter() - t0
     return {"ms_per_step": el * 1e3 / steps, "steps": steps,
