@@ -345,6 +345,7 @@ def extra_record(eng, cfg, alt, name, kind, steps, barrier, points=None, group=N
            "sweep": kind, "value": n_total * steps / el, "unit": "candidates/s", "steps": steps, "ms_per_step": el * 1e3 / steps,
            "roofline": {k: mf[k] for k in ("achieved", "peak", "frac", "kernel", "kernel_ms", "device_ms_per_step", "frac_definition")},
            "roofline_hbm": hbm_roofline(cfg["q"], 8 if cfg["dtype"] == "f64" else 4, n_total // world, rows)}
+    out["lean"] = int(lean) if kind == "safeopt" else 0          # (the sweep option this record was measured with)
     if group is not None:
         out["n_gpus"], out["scaling"] = world, "strong"
         out["comm"] = comm_record(eng, step, transport)
@@ -528,10 +529,10 @@ def main():
         if extras and default_run:
             # every other BASELINE.json config on this one GPU: B (configs[1], with its K1g figure), C (the Williams-Otto plant: GoOSE
             # and SafeOpt), D (the whole 128^4 grid of the 8-GPU config: Chebyshev-node interpolation K1t, with its K1g figure), E (10^7 scattered fp32 points)
-            out["extra"] = [extra_record(eng, *extra_cfgs["B"], "B", "safeopt", 100, barrier, table_kernel=True),
+            out["extra"] = [extra_record(eng, *extra_cfgs["B"], "B", "safeopt", 100, barrier, table_kernel=True, lean=args.lean),
                             extra_record(eng, *extra_cfgs["C"], "C", "goose", 40, barrier),
-                            extra_record(eng, *extra_cfgs["C"], "C", "safeopt", 40, barrier),
-                            extra_record(eng, *extra_cfgs["D"], "D", "safeopt", 10, barrier, table_kernel=True),
+                            extra_record(eng, *extra_cfgs["C"], "C", "safeopt", 40, barrier, lean=args.lean),
+                            extra_record(eng, *extra_cfgs["D"], "D", "safeopt", 10, barrier, table_kernel=True, lean=args.lean),
                             extra_record(eng, extra_cfgs["E"][0], None, "E", "safeopt", 3, barrier, points=10_000_000)]
         if world == 1 and args.cpu_sample > 0 and not scattered:
             # the workload of `value` itself: a prefix of this config's grid (a bounded sample -- H whole would be minutes of CPU

@@ -81,10 +81,13 @@ typedef struct sbo_sweep_opts {
                                       0: constraint c uses L_c                                            */
   int32_t want_masks;              /* 1: keep S/U/M/G (or O) masks in HBM for sbo_masks_get               */
   int32_t posterior_ready;         /* 1: reuse mean/var of the last sbo_posterior_run on these candidates */
-  int32_t lean;                    /* the caller wants the sweep's result only -- sets, indices, counts, u*, L.  1: the sweep may leave mean /
-                                      var unwritten where no later stage of it reads them (the objective on posterior tiles without a safe
-                                      candidate: u*, M and the arg-max reductions are over S only, models/SafeOpt.py:47-66); 2: it need not
-                                      even evaluate them there (the result is the same; L_0 still comes from the whole grid).
+  int32_t lean;                    /* the caller wants the sweep's result only -- sets, indices, counts, u*, the constraints' L.  1: the
+                                      sweep may leave mean / var unwritten where no later stage of it reads them (the objective on posterior
+                                      tiles without a safe candidate: u*, M and the arg-max reductions are over S only,
+                                      models/SafeOpt.py:47-66); 2: it need not even evaluate them there (the result is the same).  A lean
+                                      SafeOpt sweep of a model with constraints reports L[0] = 0: the objective's Lipschitz key is read by
+                                      no sweep of the reference (its expanders use the constraints' keys, models/SafeOpt.py:110,
+                                      models/GoOSE.py:100), and the interpolating posteriors then leave its gradient fields out.
                                       sbo_posterior_get / sbo_bounds / a posterior_ready sweep behind a lean sweep run K1 again.  0 (the
                                       default): the whole posterior is evaluated and stays resident, as models/GP_Safe.py:310-352 returns it */
 } sbo_sweep_opts;

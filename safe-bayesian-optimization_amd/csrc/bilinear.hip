@@ -1674,7 +1674,8 @@ __global__ __launch_bounds__(256, 3) void k_bgrad(const ModelConst mc, const Can
                                                   const double* __restrict__ P0f, int KB, int nrb, int ncs, long long nlines, int gx, int gy,
                                                   const int* __restrict__ eff, const double* __restrict__ gtmax,
                                                   const unsigned long long* __restrict__ gkey, const double* __restrict__ xn0, int q,
-                                                  double* __restrict__ Lpart, unsigned long long* __restrict__ slots) {
+                                                  double* __restrict__ Lpart, unsigned long long* __restrict__ slots,
+                                                  int o_first /* 1: a lean sweep -- nobody reads the objective's key, its rows stay zero */) {
   extern __shared__ double lds[];
   PostCtx cx;
   cx.lds = lds;
@@ -1698,7 +1699,9 @@ __global__ __launch_bounds__(256, 3) void k_bgrad(const ModelConst mc, const Can
   const double* slack = gtmax ? gtmax + (size_t)q * 2 * nt : nullptr;       // (no gate: every tile runs both phases)
   d4_t acc[1][8];
   d4_t pre[4];
-  for (int o = 0; o < q; ++o) {
+  for (size_t tile = blockIdx.x; o_first > 0 && tile < nt; tile += gridDim.x)
+    if (cx.tid == 0) Lpart[tile] = 0.0;
+  for (int o = o_first; o < q; ++o) {
     const double ystd = mc.Y_std[o];
     const double cg0 = ystd * mc.inv_ell[o][0] * mc.X_rstd[0], cg1 = ystd * mc.inv_ell[o][1] * mc.X_rstd[1];
     const double G0 = gtmax ? __longlong_as_double((long long)gkey[2 * o + 0]) : 0.0, G1 = gtmax ? __longlong_as_double((long long)gkey[2 * o + 1]) : 0.0;
@@ -3373,7 +3376,7 @@ int launch_posterior_interp(sbo_ctx* c) {
     SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_bgrad, dim3((unsigned)std::min<long long>((long long)rows_out, 2ll * c->n_cu)), dim3(256), lds, gs, mc, cs, BtA + ip.sBtA,
                        4 * ip.sBtA, (const double*)c->bl_P0f.p, KB, ip.nrb, ip.ncs0, nlines, (int)gx, (int)gy, (const int*)ip.eff, ip.gtmax, ip.gkey,
-                       (const double*)c->bl_small.p, q, lrows, colw ? px.cb.slots : (unsigned long long*)nullptr);
+                       (const double*)c->bl_small.p, q, lrows, colw ? px.cb.slots : (unsigned long long*)nullptr, (c->sweep_lean && q >= 2) ? 1 : 0);
     SBO_HIP(hipEventRecord(c->ev_grad[2], gs));
     c->grad_pending = true;
     px.nograd = 1;

@@ -278,6 +278,7 @@ struct sbo_ctx {
   // output -- constraint first: S / U words, |S| per tile; objective second: u* and min var_0 over S from its own epilogue --
   // and says so (col_active).  The words stay resident for sbo_masks_get (masks_bits: expanded to bytes on demand).
   bool col_request = false, col_active = false;
+  int sweep_lean = 0;      // the running SafeOpt sweep is lean: the objective's Lipschitz key L_0 (no sweep reads it) is not computed by K1t / K1i
   int col_lean = 0;        // the running request: objective tiles without a safe candidate need not store mean / var
   bool slots_clean = false;// the slot block holds its neutral elements (the finals of the last column sweep reset it)
   bool usum_dirty = false; // Usum holds bits of an earlier launch (cleared by the column path's second kernel; by a memset after a failure)

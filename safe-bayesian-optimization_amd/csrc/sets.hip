@@ -1831,6 +1831,7 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   c->col_request = !reuse && std::is_same<T, double>::value && q == 2 && !multi_rank(c) && !c->rc_active && c->result_mirror && n > 0;
   const int lean = o->lean;
   c->col_lean = c->col_request ? (lean >= 2 ? 2 : (lean ? 1 : 0)) : 0;
+  c->sweep_lean = (lean && q >= 2 && !reuse) ? 1 : 0;
   c->col_active = false;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) { c->col_request = false; return rc; }
   c->col_request = false;
@@ -1959,6 +1960,9 @@ static int sweep_safeopt_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_safeopt_resu
   res->guard_band = h.n_guard;
   c->guard_first = h.n_guard;
   for (int i = 0; i < q; ++i) memcpy(&res->L[i], &Lk[i], 8);
+  // (a lean sweep does not report the objective's key: no sweep of the reference reads it -- models/SafeOpt.py:110, GoOSE.py:100 --
+  // and K1t / K1i leave its gradient quantities out; zero whichever kernel ran)
+  if (o->lean && q >= 2) res->L[0] = 0.0;
   res->minimizer_index = -1;
   res->expander_index = -1;
   for (int cc = 1; cc < q; ++cc) res->expander_index_c[cc - 1] = -1;
@@ -2270,6 +2274,7 @@ static int sweep_goose_t(sbo_ctx* c, const sbo_sweep_opts* o, sbo_goose_result* 
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
+  c->sweep_lean = 0;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   c->fuse_request = 0;
   c->lmax_defer = false;
@@ -2465,6 +2470,7 @@ static int sweep_tr_t(sbo_ctx* c, const sbo_sweep_opts* o, const double* x0, dou
   SBO_HIP(hipEventRecord(c->ev[0], c->stream));
   const bool reuse = o->posterior_ready && c->posterior_valid;
   if ((rc = sweep_masks(c, o->b, !reuse))) return rc;
+  c->sweep_lean = 0;
   if (!reuse && (rc = sbo_posterior_enqueue_(c))) return rc;
   c->fuse_request = 0;
   c->lmax_defer = false;

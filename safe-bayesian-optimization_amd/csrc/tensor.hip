@@ -144,10 +144,12 @@ __device__ __forceinline__ void core_pos(int p, int dmc, int& a, int& b) {
 // in grid order (k0 fastest) --, i.e. the thread of output position p reads input position a + dmc b, (a, b) = core_pos(p).
 template <int DM>
 __global__ __launch_bounds__(256) void k_t_mode(const double* __restrict__ in, size_t sin, double* __restrict__ out, size_t sout,
-                                                const double* __restrict__ W, long long pre, int Dm, long long nx, long long post, int dmc) {
+                                                const double* __restrict__ W, long long pre, int Dm, long long nx, long long post, int dmc,
+                                                int q2 /* 2 q */, int gskip /* lean sweeps: the gradient tensors of output 0 (quantities 2 q .. 2 q + d - 1)
+                                                are left out -- no sweep reads the objective's Lipschitz key (models/SafeOpt.py:110, GoOSE.py:100) */) {
   constexpr int kRows = 32;
   __shared__ double Ws[kRows][DM];
-  const int qi = blockIdx.y;
+  const int qi = (int)blockIdx.y < q2 ? (int)blockIdx.y : (int)blockIdx.y + gskip;
   const double* I = in + (size_t)qi * sin;
   double* O = out + (size_t)qi * sout;
   const long long total = pre * post;
@@ -206,7 +208,8 @@ template <int DM, int CS>
 __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ in, size_t stride_q, const double* __restrict__ W0t,
                                                     const double* __restrict__ W1t, long long n0, long long n1, long long planes, int q, int d,
                                                     int nq, double* __restrict__ mean, double* __restrict__ var, size_t n_local,
-                                                    unsigned long long* __restrict__ Lmax) {
+                                                    unsigned long long* __restrict__ Lmax, int gskip /* lean sweeps: output 0's d gradient
+                                                    quantities are not enumerated (see k_t_mode) */) {
   constexpr int KS = DM / 4, KB = DM / 16, SP = 36;   // k-steps, k-blocks; row stride of the store patch
   extern __shared__ __attribute__((aligned(32))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -221,7 +224,8 @@ __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ i
   double* Mimg = sm + KS * CS * 64 + 4 * (2 * KB * 256) + 4 * (16 * SP);              // [2][DM * DM]
   const int kq = lane >> 4, col = lane & 15;
   const long long tiles0 = (n0 + 127) / 128, chunks1 = (n1 + 16 * CS - 1) / (16 * CS);
-  const long long per_tile = planes * nq, units = per_tile * tiles0;      // t0 slowest: the W0 fragments change once per tile
+  const int nqe = nq - gskip;                                             // quantities enumerated
+  const long long per_tile = planes * nqe, units = per_tile * tiles0;     // t0 slowest: the W0 fragments change once per tile
   // every wave runs the same number of iterations (the chunk loads of W1 are workgroup-wide); a wave without a unit idles
   const long long iters = (units + gridDim.x - 1) / gridDim.x;
   long long cur_t0 = -1, cur_c1 = -1;
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ i
   double pf[PFN];
   auto core_of = [&](long long it_) {
     const long long u_ = blockIdx.x + it_ * gridDim.x, uu_ = u_ < units ? u_ : units - 1, rest_ = uu_ % per_tile;
-    return in + (size_t)(rest_ % nq) * stride_q + (size_t)(rest_ / nq) * DM * DM;
+    const int qe_ = (int)(rest_ % nqe);
+    return in + (size_t)(qe_ < 2 * q ? qe_ : qe_ + gskip) * stride_q + (size_t)(rest_ / nqe) * DM * DM;
   };
   if (PF) {
     const double* I0 = core_of(0);
@@ -242,8 +247,8 @@ __global__ __launch_bounds__(256, 1) void k_t_final(const double* __restrict__ i
     const bool have = u < units;
     const long long uu = have ? u : units - 1;
     const long long t0 = uu / per_tile, rest = uu % per_tile;
-    const int qi = (int)(rest % nq);
-    const long long plane = rest / nq;
+    const int qe = (int)(rest % nqe), qi = qe < 2 * q ? qe : qe + gskip;
+    const long long plane = rest / nqe;
     const long long x0w = t0 * 128 + wave * 32;                          // first position of this wave
     if (t0 != cur_t0) {
 #pragma unroll
@@ -475,30 +480,31 @@ bool tensor_applicable(const sbo_ctx* c) {
 
 template <int DM>
 static void launch_mode(hipStream_t st, const double* in, size_t sin, double* out, size_t sout, const double* W, long long pre, int Dm,
-                        long long nx, long long post, int nq, int dmc) {
+                        long long nx, long long post, int nq, int dmc, int q2, int gskip) {
   const long long total = pre * post;
-  hipLaunchKernelGGL((k_t_mode<DM>), dim3((unsigned)((total + 255) / 256), (unsigned)nq), dim3(256), 0, st, in, sin, out, sout, W, pre, Dm, nx, post, dmc);
+  hipLaunchKernelGGL((k_t_mode<DM>), dim3((unsigned)((total + 255) / 256), (unsigned)(nq - gskip)), dim3(256), 0, st, in, sin, out, sout, W, pre, Dm, nx,
+                     post, dmc, q2, gskip);
 }
 static int mode_dispatch(hipStream_t st, int DM, const double* in, size_t sin, double* out, size_t sout, const double* W, long long pre, int Dm,
-                         long long nx, long long post, int nq, int dmc) {
+                         long long nx, long long post, int nq, int dmc, int q2, int gskip) {
   switch (DM) {
-    case 32: launch_mode<32>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc); break;
-    case 48: launch_mode<48>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc); break;
-    case 64: launch_mode<64>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc); break;
-    case 96: launch_mode<96>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc); break;
+    case 32: launch_mode<32>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc, q2, gskip); break;
+    case 48: launch_mode<48>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc, q2, gskip); break;
+    case 64: launch_mode<64>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc, q2, gskip); break;
+    case 96: launch_mode<96>(st, in, sin, out, sout, W, pre, Dm, nx, post, nq, dmc, q2, gskip); break;
     default: return fail(SBO_E_UNSUPPORTED, "internal: interpolation degree");
   }
   return SBO_OK;
 }
 template <int DM, int CS>
-static int launch_final(sbo_ctx* c, const double* in, size_t stride_q, const TensorDims& td, long long planes, int nq) {
+static int launch_final(sbo_ctx* c, const double* in, size_t stride_q, const TensorDims& td, long long planes, int nq, int gskip) {
   const size_t lds = sizeof(double) * ((size_t)(DM / 4) * CS * 64 + 4 * (size_t)(2 * (DM / 16) * 256) + 4 * 16 * 36 + (DM <= 48 ? 2 * DM * DM : 0));
   auto kern = k_t_final<DM, CS>;
   SBO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const long long units = planes * nq * ((td.cnt[0] + 127) / 128);
+  const long long units = planes * (nq - gskip) * ((td.cnt[0] + 127) / 128);
   const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(units, (long long)c->n_cu));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, in, stride_q, (const double*)c->tn_W0t.p, (const double*)c->tn_W1t.p, td.cnt[0],
-                     td.cnt[1], planes, td.q, td.d, nq, (double*)c->mean.p, (double*)c->var.p, (size_t)c->cs.n_local, (unsigned long long*)c->Lmax.p);
+                     td.cnt[1], planes, td.q, td.d, nq, (double*)c->mean.p, (double*)c->var.p, (size_t)c->cs.n_local, (unsigned long long*)c->Lmax.p, gskip);
   SBO_HIP(hipGetLastError());
   return SBO_OK;
 }
@@ -507,6 +513,7 @@ static int launch_final(sbo_ctx* c, const double* in, size_t stride_q, const Ten
 static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, long long Nn, int nq, const double** cur_out, size_t* stride_out) {
   const int d = td.d;
   int rc;
+  const int gskip = (c->sweep_lean && td.q >= 2) ? d : 0;      // (a lean sweep: nobody reads L_0)
   // axes d-1 .. 2 on the small tensors (ping-pong in tn_work), then the planes
   const double* cur = nodes;
   size_t cur_stride = (size_t)Nn;
@@ -521,9 +528,9 @@ static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, lo
     double* dst = toA ? bufA : bufB;
     const size_t dst_stride = (size_t)pre * nx * post;
     if ((rc = mode_dispatch(c->stream, td.Dn[a] <= 32 ? 32 : (td.Dn[a] <= 48 ? 48 : (td.Dn[a] <= 64 ? 64 : 96)), cur, cur_stride, dst, dst_stride,
-                            (const double*)c->tn_W[a].p, pre, td.Dn[a], nx, post, nq, a == d - 1 ? td.Dn[0] : 0)))
+                            (const double*)c->tn_W[a].p, pre, td.Dn[a], nx, post, nq, a == d - 1 ? td.Dn[0] : 0, 2 * td.q, gskip)))
       return rc;
-    c->tn_flops += 2.0 * (double)pre * td.Dn[a] * (double)nx * (double)post * nq;
+    c->tn_flops += 2.0 * (double)pre * td.Dn[a] * (double)nx * (double)post * (nq - gskip);
     cur = dst;
     cur_stride = dst_stride;
     post *= nx;
@@ -533,12 +540,12 @@ static int interpolate(sbo_ctx* c, const TensorDims& td, const double* nodes, lo
   // now cur = [DM][DM][planes = post] per quantity
   *cur_out = cur;
   *stride_out = cur_stride;
-  c->tn_flops += 2.0 * (double)post * nq * ((double)td.cnt[0] * td.Dn[0] * td.Dn[1] + (double)td.cnt[0] * td.cnt[1] * td.Dn[1]);
+  c->tn_flops += 2.0 * (double)post * (nq - gskip) * ((double)td.cnt[0] * td.Dn[0] * td.Dn[1] + (double)td.cnt[0] * td.cnt[1] * td.Dn[1]);
   SBO_HIP(hipMemsetAsync(c->Lmax.p, 0, sizeof(unsigned long long) * kMaxQ, c->stream));
   switch (td.Dn[0]) {
-    case 32: return launch_final<32, 8>(c, cur, cur_stride, td, post, nq);
-    case 48: return launch_final<48, 8>(c, cur, cur_stride, td, post, nq);
-    case 64: return launch_final<64, 8>(c, cur, cur_stride, td, post, nq);
+    case 32: return launch_final<32, 8>(c, cur, cur_stride, td, post, nq, gskip);
+    case 48: return launch_final<48, 8>(c, cur, cur_stride, td, post, nq, gskip);
+    case 64: return launch_final<64, 8>(c, cur, cur_stride, td, post, nq, gskip);
   }
   return fail(SBO_E_UNSUPPORTED, "internal: interpolation degree");
 }
@@ -737,7 +744,7 @@ int launch_posterior_tensor(sbo_ctx* c, bool* declined) {
           av[o] = std::max(av[o], std::fabs(xv));
         }
         for (int a = 0; a < d; ++a)
-          for (int i = 0; i < kTProbes; ++i) {
+          for (int i = 0; i < kTProbes && !(o == 0 && c->sweep_lean && q >= 2); ++i) {      // (lean: output 0's gradient cores were not made)
             const double dg = std::fabs(h[((size_t)4 * q + nqg + (size_t)o * d + a) * kTProbes + i] - h[((size_t)4 * q + (size_t)o * d + a) * kTProbes + i]);
             finite = finite && std::isfinite(dg);
             eg[o] = std::max(eg[o], dg);

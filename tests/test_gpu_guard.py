@@ -398,3 +398,30 @@ def test_short_length_scales_band_audit(engine, log_ell, count):
     finally:
         engine.set_option("bilinear", 1)
         engine.set_option("guard_audit", 1024)
+
+
+@pytest.mark.parametrize("d,count", [(3, [160, 168, 160]), (4, [64, 64, 64, 64])])
+def test_lean_tensor_sweep_leaves_out_the_objectives_lipschitz_key(engine, d, count):
+    """A lean SafeOpt sweep on K1t (3-D / 4-D grids) does not interpolate the gradient fields of output 0 -- a third of the plane units of
+    a two-output model: no sweep of the reference reads the objective's Lipschitz key (models/SafeOpt.py:110, models/GoOSE.py:100).
+    Everything else -- masks, indices, counts, the constraint's key, the posterior -- equals the full sweep's; L[0] is reported as 0."""
+    rng = np.random.default_rng(3)
+    n = 96
+    X = rng.uniform(-2.0, 2.0, size=(n, d))
+    Y = np.stack([np.sum(X ** 2, axis=1) + np.sin(2.0 * X[:, 0]), 3.0 - 0.5 * np.sum(X ** 2, axis=1) + X[:, 1]], axis=1)
+    ds = synthetic.make_dataset(X, Y, synthetic.default_hypopt(d, 2, log_ell=-0.5))
+    engine.set_grid(np.full(d, -2.0), np.full(d, 2.0), count)
+    out = {}
+    for lean in (0, 1):
+        engine.set_model(ds)
+        res = engine.sweep_safeopt(2.0, want_masks=True, lean=lean)
+        assert engine.profile()["posterior_kernel"] == 5
+        out[lean] = (res, {k: engine.mask(k) for k in ("S", "U", "M")}, engine.mask("G", 1), engine.posterior())
+    (r0, m0, g0, (pm0, pv0)), (r1, m1, g1, (pm1, pv1)) = out[0], out[1]
+    assert r0["L"][0] > 0 and r1["L"][0] == 0.0 and r0["L"][1] == r1["L"][1]
+    for k in ("minimizer_index", "expander_index", "count_S", "count_U", "count_M", "u_star", "choose_minimizer"):
+        assert r0[k] == r1[k], k
+    assert list(r0["count_G"]) == list(r1["count_G"])
+    for k in m0:
+        assert np.array_equal(m0[k], m1[k]), k
+    assert np.array_equal(g0, g1) and np.array_equal(pm0, pm1) and np.array_equal(pv0, pv1)
