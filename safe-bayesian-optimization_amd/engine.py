@@ -179,7 +179,8 @@ class SweepEngine:
     def sweep_safeopt(self, b: float, quirk_L_index: bool = True, want_masks: bool = False,
                       posterior_ready: bool = False, lean: bool = False) -> dict:
         """``lean``: the caller wants the sweep's result only.  1 / True: mean / var may stay unwritten where no stage of the sweep
-        reads them; 2: they need not be evaluated there at all (``posterior()`` behind a lean sweep runs K1 again)."""
+        reads them; 2: they need not be evaluated there at all (``posterior()`` behind a lean sweep runs K1 again).  A lean sweep of
+        a model with constraints reports ``L[0] = 0``: no sweep reads the objective's Lipschitz key (models/SafeOpt.py:110)."""
         res = L.SafeOptResult()
         opts = self._opts(b, quirk_L_index, want_masks, posterior_ready, lean)
         L.check(self._lib.sbo_sweep_safeopt(self._ctx, C.byref(opts), C.byref(res)))
