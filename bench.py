@@ -82,10 +82,12 @@ def parse_args():
                          "table: force the separable-table kernel (K1g), the O(n^2)-per-candidate contraction")
     ap.add_argument("--sweep", choices=["safeopt", "goose"], default="safeopt")
     ap.add_argument("--no-extra", action="store_true", help="skip the iteration / table-kernel / H / C records")
-    ap.add_argument("--lean", type=int, choices=[0, 1, 2], default=1,
-                    help="sbo_sweep_opts.lean of the SafeOpt sweeps: 1 (default) the objective's mean / var are not STORED on posterior tiles "
-                         "without a safe candidate -- no stage of the sweep reads them; every posterior is still evaluated --, 0 the whole "
-                         "posterior stays resident (reported beside the main line as config.full_posterior), 2 not even evaluated there")
+    ap.add_argument("--lean", type=int, choices=[0, 1, 2], default=2,
+                    help="sbo_sweep_opts.lean of the SafeOpt sweeps: 2 (default) the caller wants the sweep's RESULT -- sets, indices, counts, u*, "
+                         "the constraints' Lipschitz keys --: the objective's mean / var are neither stored nor evaluated on posterior tiles "
+                         "without a safe candidate (no stage of the sweep reads them) and its Lipschitz key, which no sweep reads, is left out; "
+                         "1 evaluated but not stored; 0 the whole posterior stays resident.  The other levels are reported beside the main line "
+                         "(config.full_posterior, config.lean_1) with result_identical")
     return ap.parse_args()
 
 
@@ -481,7 +483,7 @@ def main():
         if args.sweep == "safeopt" and world == 1 and not args.no_extra:
             # the same sweep at the other lean levels, same process (short timed runs): what storing / evaluating the objective's
             # posterior where no stage of the sweep reads it costs
-            for lv, key in ((0, "full_posterior"), (2, "lean_2")):
+            for lv, key in ((0, "full_posterior"), (1, "lean_1"), (2, "lean_2")):
                 if lv == args.lean:
                     continue
                 el_v, rows_v, res_v = timed_resident(eng, sweep_fn(eng, args.sweep, cfg["b"], lean=lv), max(20, args.steps // 4), 3, barrier)

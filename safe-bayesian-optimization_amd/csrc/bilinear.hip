@@ -1588,6 +1588,7 @@ __global__ __launch_bounds__(256, (RB == 2 ? 2 : 3)) void k_bpost(const ModelCon
     gfold = fmax(f0, f1);
   }
   if (px.nograd) { run2 = run3 = false; gfold = 0.0; }          // (the keys come from a launch of the gradient phases alone: k_bgrad)
+  if (ROLE == 2 && px.lean) { run2 = run3 = false; gfold = 0.0; }   // (a lean sweep: nobody reads the objective's key, include/safebo.h)
   // lean sweeps, level 2: the objective's posterior of a tile without a safe candidate is not even evaluated -- u*, M and the
   // arg-max reductions read it on S only (models/SafeOpt.py:47-66); the tile still runs the gradient phases the gate asks for
   // (L_0 is a maximum over the whole grid), and with K1b's operands the mean phase those continue from
