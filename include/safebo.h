@@ -331,6 +331,7 @@ int sbo_profile_get(sbo_ctx* ctx, sbo_profile* out);
  *   "comm_selftest"    1: a one-rank communicator still sends C1 / C2 / C3 through RCCL (results must not change)
  *   "fp64_recheck"     1: fp32 models re-evaluate in fp64 every candidate their 1e-4 contract cannot decide; 0: masks of the fp32 posterior
  *   "guard_audit"      samples per audited sweep of the standing audit of the guard band (sbo_profile.guard_audit_*; default 1024); 0: off
+ *   "guard_audit_scale_ppm" test hook: the audit compares against the band x value / 1e6 (default 1000000); setting it clears the counts
  *   "guard_audit_every" one sweep in this many carries an audit (default 16; the first sweep after setting it does).  An audit shares
  *                      the card with the sweep it follows (~35 us of config H's set phase at 1024 samples, n = 512): 1 audits every sweep
  *   "guard_band"       1: sweeps on an approximating posterior (K1b / K1i / K1t) count the decisions inside its band and re-evaluate exactly

@@ -328,6 +328,16 @@ int sbo_set_option(sbo_ctx* c, const char* key, int64_t value) {
     c->guard_audit = (int)value;
     return SBO_OK;
   }
+  if (!strcmp(key, "guard_audit_scale_ppm")) {
+    // (test hook: the audit compares against the band times value / 1e6 -- with a band a thousand times too narrow it MUST count
+    // violations, which is how the suite shows that it compares real values; setting it clears the counts)
+    if (value < 1 || value > 1000000000) return fail(SBO_E_INVALID, "guard_audit_scale_ppm: 1 .. 1e9");
+    guard_audit_harvest(c, true);
+    c->audit_scale = (double)value * 1e-6;
+    c->audit_samples = c->audit_violations = 0;
+    c->audit_worst = 0.0;
+    return SBO_OK;
+  }
   if (!strcmp(key, "guard_audit_every")) {
     if (value < 1 || value > (1 << 20)) return fail(SBO_E_INVALID, "guard_audit_every: 1 .. 1048576 sweeps");
     c->guard_audit_every = (int)value;

@@ -474,14 +474,15 @@ __global__ __launch_bounds__(256) void k_audit_pick(const CandSpec cs, int P, un
 // cnt: [0] violations, [1] samples (value pairs compared), [2] bit pattern of the largest deviation in units of the band
 __global__ __launch_bounds__(256) void k_audit_compare(int P, int q, int o_first, const double* __restrict__ apx, const double* __restrict__ ref_m,
                                                        const double* __restrict__ ref_v, const GuardBand* __restrict__ gb,
-                                                       unsigned long long* __restrict__ cnt) {
+                                                       unsigned long long* __restrict__ cnt, double scale /* 1, or the test hook's factor on the band */) {
   long long viol = 0, smp = 0;
   double worst = 0.0;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < P * (q - o_first); e += gridDim.x * blockDim.x) {
     const int o = o_first + e / P, k = e % P;
     const double dm = fabs(apx[(size_t)o * P + k] - ref_m[(size_t)o * P + k]), dv = fabs(apx[(size_t)(q + o) * P + k] - ref_v[(size_t)o * P + k]);
-    const double rm = dm / gb->dm[o], rv = dv / gb->dv[o];
-    const bool bad = !(dm <= gb->dm[o]) || !(dv <= gb->dv[o]);              // (NaN counts)
+    const double bm = gb->dm[o] * scale, bv = gb->dv[o] * scale;
+    const double rm = dm / bm, rv = dv / bv;
+    const bool bad = !(dm <= bm) || !(dv <= bv);                            // (NaN counts)
     viol += bad;
     ++smp;
     const double r = rm > rv ? rm : rv;
@@ -541,7 +542,7 @@ int guard_audit_enqueue(sbo_ctx* c, int first_output) {
   SBO_HIP(hipEventRecord(c->ev_audit[0], st));
   if ((rc = launch_ref<2>(c, st, (const double*)c->audit_pts.p, P, 0, ref_m, ref_v, nullptr, &c->audit_part))) return rc;
   hipLaunchKernelGGL(k_audit_compare, dim3(8), dim3(256), 0, st, P, q, first_output, (const double*)apx, (const double*)ref_m, (const double*)ref_v,
-                     (const GuardBand*)c->gb.p, (unsigned long long*)c->audit_cnt.p);
+                     (const GuardBand*)c->gb.p, (unsigned long long*)c->audit_cnt.p, c->audit_scale);
   SBO_HIP(hipMemcpyAsync(c->h_back + 7168, c->audit_cnt.p, 24, hipMemcpyDeviceToHost, st));
   SBO_HIP(hipEventRecord(c->ev_audit[1], st));
   SBO_HIP(hipGetLastError());

@@ -198,6 +198,7 @@ struct sbo_ctx {
   int guard_audit = 1024;          // option: samples per audited sweep, 0 = off
   int guard_audit_every = 16;      // option: one sweep in this many is audited (the context's first one is)
   long long audit_tick = 0;
+  double audit_scale = 1.0;        // option guard_audit_scale_ppm (tests): the audit compares against band x this -- a way to see it fire
   sbo::DevBuf audit_pts, audit_val, audit_part, audit_cnt;
   hipEvent_t ev_audit[2]{};        // the sample has been taken (mean / var may be overwritten) / the audit has finished
   bool audit_pending = false;

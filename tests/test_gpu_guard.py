@@ -425,3 +425,29 @@ def test_lean_tensor_sweep_leaves_out_the_objectives_lipschitz_key(engine, d, co
     for k in m0:
         assert np.array_equal(m0[k], m1[k]), k
     assert np.array_equal(g0, g1) and np.array_equal(pm0, pm1) and np.array_equal(pv0, pv1)
+
+
+def test_the_standing_audit_fires_when_the_band_is_too_narrow(engine):
+    """The audit's claim is only worth something if it can fail: compared against a band a thousand times narrower than the plan's
+    (option guard_audit_scale_ppm, a test hook), the same sweeps MUST count violations -- the deviations of K1b / K1i from the
+    reference formula are ~0.05 - 0.3 of the band, not 1e-4 of it --, and the worst deviation scales with the factor."""
+    cfg = synthetic.make_config("B", n=96)
+    engine.set_grid(cfg["bound"][:, 0], cfg["bound"][:, 1], [512, 384])
+    engine.set_option("guard_audit", 16384)
+    try:
+        worst = {}
+        for ppm in (1000000, 1000):
+            engine.set_option("guard_audit_scale_ppm", ppm)
+            engine.set_model(cfg["ds"], dtype="f64")
+            for sweep in range(3):
+                engine.sweep_safeopt(cfg["b"])
+            engine.synchronize()
+            p = engine.profile()
+            assert p["guard_audit_samples"] >= 3 * 16384
+            worst[ppm] = (p["guard_audit_violations"], p["guard_audit_worst"])
+        assert worst[1000000][0] == 0 and 0 < worst[1000000][1] < 1.0, worst
+        assert worst[1000][0] > 0 and worst[1000][1] > 1.0, worst
+        assert 100.0 < worst[1000][1] / worst[1000000][1] < 10000.0, worst
+    finally:
+        engine.set_option("guard_audit_scale_ppm", 1000000)          # (clears the counts: the suite's fixture asserts zero violations)
+        engine.set_option("guard_audit", 1024)
