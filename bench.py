@@ -452,6 +452,16 @@ def main():
         roof["store_roofline_frac"] = store_bytes / (roof["kernel_ms"] * 1e-3) / 1e12 / HBM_PEAK_TBS
         roof["store_roofline_definition"] = ("2 q s bytes per candidate (the posterior API's output, SURVEY.md 8(d)) / K1 device time / 8 TB/s; a lean sweep "
                                              "writes fewer bytes than that (config.lean), the figure prices the time against the full output")
+        if args.sweep == "safeopt" and args.lean and int(rows[-1].get("set_path", 0)) == 1 and not scattered and world == 1:
+            # ... and against what THIS sweep writes: every constraint's mean / var, the objective's on the 64 x 128 posterior tiles that
+            # hold a safe candidate (counted from the S mask of one more sweep, outside the timed region)
+            eng.sweep_safeopt(cfg["b"], want_masks=True, lean=args.lean)
+            Sm = eng.mask("S").reshape(count[1] // 64, 64, count[0] // 128, 128)
+            tiles_S = int(Sm.any(axis=(1, 3)).sum())
+            written = 2.0 * es * (n_local * (cfg["q"] - 1) + 8192.0 * tiles_S)
+            roof["store_bytes_written"] = written
+            roof["objective_tiles_with_a_safe_candidate"] = [tiles_S, (count[1] // 64) * (count[0] // 128)]
+            roof["store_roofline_frac_written"] = written / (roof["kernel_ms"] * 1e-3) / 1e12 / HBM_PEAK_TBS
         if k1_kind in (4, 6):
             roof["bound"] = "hbm-store/issue"
         # HBM bytes of the K1 launch(es) are NOT measured by this run: they come from separate rocprofv3 --pmc passes of the
